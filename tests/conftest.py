@@ -1,0 +1,133 @@
+import ctypes
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+class Oracle:
+    """ctypes view of oracle/liboracle_dc3.so (+ oracle/_ref/libdivsufsort_ref.so when built).
+    Test infrastructure only."""
+
+    def __init__(self):
+        odir = os.path.join(ROOT, "oracle")
+        so = os.path.join(odir, "liboracle_dc3.so")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(odir, "dc3_oracle.c")):
+            subprocess.check_call(["make", "-s", "-C", odir])
+        L = self.lib = ctypes.CDLL(so)
+        vp, i32, i64, u64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64
+        L.dc3_oracle_sufsort_i32.argtypes = [vp, vp, i32]; L.dc3_oracle_sufsort_i32.restype = ctypes.c_int
+        L.dc3_oracle_sufsort_i64.argtypes = [vp, vp, i64]; L.dc3_oracle_sufsort_i64.restype = ctypes.c_int
+        L.dc3_oracle_trace.argtypes = [vp, i64, vp, vp, ctypes.c_int]; L.dc3_oracle_trace.restype = ctypes.c_int
+        L.dc3_oracle_suffix_array_u64.argtypes = [vp, vp, u64, u64]; L.dc3_oracle_suffix_array_u64.restype = ctypes.c_int
+        L.dc3_oracle_radix_pass_u64.argtypes = [vp, vp, vp, u64, u64]; L.dc3_oracle_radix_pass_u64.restype = ctypes.c_int
+        L.oracle_verify_i32.argtypes = [vp, vp, i64]; L.oracle_verify_i32.restype = i64
+        L.oracle_verify_i64.argtypes = [vp, vp, i64]; L.oracle_verify_i64.restype = i64
+        L.oracle_longest_substring_match_i32.argtypes = [vp, i64, vp, i64, vp, i64, vp, vp]
+        L.oracle_longest_substring_match_i32.restype = ctypes.c_int
+        L.oracle_partitioned_match_i32.argtypes = [vp, i64, vp, i64, i64, vp, i64, vp, vp]
+        L.oracle_partitioned_match_i32.restype = ctypes.c_int
+        L.oracle_gen_bytes.argtypes = [vp, i64, u64, ctypes.c_int]; L.oracle_gen_bytes.restype = None
+        self.ref = None
+        rso = os.path.join(odir, "_ref", "libdivsufsort_ref.so")
+        if os.path.exists(rso):
+            R = self.ref = ctypes.CDLL(rso)
+            R.divsufsort.argtypes = [vp, vp, i32]; R.divsufsort.restype = i32
+            R.sufcheck.argtypes = [vp, vp, i32, i32]; R.sufcheck.restype = i32
+
+    @staticmethod
+    def _u8(data):
+        if isinstance(data, np.ndarray):
+            return np.ascontiguousarray(data, dtype=np.uint8)
+        return np.frombuffer(bytes(data), dtype=np.uint8).copy()
+
+    def sufsort(self, data, dtype=np.int32):
+        t = self._u8(data)
+        sa = np.zeros(len(t), dtype=dtype)
+        f = self.lib.dc3_oracle_sufsort_i32 if dtype == np.int32 else self.lib.dc3_oracle_sufsort_i64
+        rc = f(t.ctypes.data, sa.ctypes.data, len(t))
+        assert rc == 0, rc
+        return sa
+
+    def ref_sufsort(self, data):
+        assert self.ref is not None, "oracle/_ref not built"
+        t = self._u8(data)
+        sa = np.zeros(len(t), dtype=np.int32)
+        rc = self.ref.divsufsort(t.ctypes.data, sa.ctypes.data, len(t))
+        assert rc == 0, rc
+        return sa
+
+    def verify(self, data, sa):
+        t = self._u8(data)
+        sa = np.ascontiguousarray(sa)
+        f = self.lib.oracle_verify_i32 if sa.dtype == np.int32 else self.lib.oracle_verify_i64
+        return int(f(t.ctypes.data, sa.ctypes.data, len(t)))
+
+    def trace(self, data):
+        t = self._u8(data)
+        na = np.zeros(64, dtype=np.int64); ka = np.zeros(64, dtype=np.int64)
+        d = self.lib.dc3_oracle_trace(t.ctypes.data, len(t), na.ctypes.data, ka.ctypes.data, 64)
+        assert d > 0, d
+        return [[int(na[i]), int(ka[i])] for i in range(d)]
+
+    def gen(self, n, seed, kind=0):
+        b = np.zeros(n, dtype=np.uint8)
+        self.lib.oracle_gen_bytes(b.ctypes.data, n, seed, kind)
+        return b
+
+    def search(self, text, sa, needle):
+        t = self._u8(text); nd = self._u8(needle); sa = np.ascontiguousarray(sa, dtype=np.int32)
+        st = ctypes.c_int64(); ln = ctypes.c_int64()
+        rc = self.lib.oracle_longest_substring_match_i32(t.ctypes.data, len(t), sa.ctypes.data, len(sa),
+                                                         nd.ctypes.data, len(nd), ctypes.byref(st), ctypes.byref(ln))
+        assert rc == 0
+        return st.value, ln.value
+
+    def partitioned_search(self, text, sas, partition_size, needle):
+        t = self._u8(text); nd = self._u8(needle)
+        sas = [np.ascontiguousarray(s, dtype=np.int32) for s in sas]
+        arr = (ctypes.c_void_p * len(sas))(*[s.ctypes.data for s in sas])
+        st = ctypes.c_int64(); ln = ctypes.c_int64()
+        rc = self.lib.oracle_partitioned_match_i32(t.ctypes.data, len(t), arr, len(sas), partition_size,
+                                                   nd.ctypes.data, len(nd), ctypes.byref(st), ctypes.byref(ln))
+        assert rc == 0
+        return st.value, ln.value
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    return Oracle()
+
+
+@pytest.fixture(scope="session")
+def kat():
+    return json.load(open(os.path.join(GOLDEN, "kat.json")))
+
+
+@pytest.fixture(scope="session")
+def corpus():
+    cdir = os.path.join(GOLDEN, "corpus")
+    out = {}
+    for name in sorted(os.listdir(cdir)):
+        if name.endswith(".sa.i32"):
+            continue
+        data = open(os.path.join(cdir, name), "rb").read()
+        sa = np.fromfile(os.path.join(cdir, name + ".sa.i32"), dtype="<i4")
+        out[name] = (data, sa)
+    return out
+
+
+def naive_sa(data: bytes):
+    return np.array(sorted(range(len(data)), key=lambda i: data[i:]), dtype=np.int32)
