@@ -1,0 +1,140 @@
+/*
+ * dc3hip.h — C ABI of libdc3hip.so: MI355X-native (gfx950, HIP) suffix-array construction by
+ * DC3/Skew, drop-in for the reference's SACA plug-in boundary.
+ *
+ * Reference interface this replaces (paths relative to the stringsearch repository):
+ *   crates/cdivsufsort/src/lib.rs:1-4       extern "C" { fn divsufsort(T:*const u8, SA:*mut i32, n:i32) -> i32; }
+ *   crates/cdivsufsort/c-sources/divsufsort.h:67-76   saint_t divsufsort(const sauchar_t*, saidx_t*, saidx_t)
+ *   crates/cdivsufsort/c-sources/divsufsort.c:346-349 argument checks and n in {0,1,2}
+ *   crates/dc3/src/lib.rs:44                pub fn suffix_array(T, SA, n, K)   (the algorithm; orphan crate)
+ *   crates/sacabase/src/lib.rs:127-149      verify()                            (dc3hip_sufcheck_*)
+ *   crates/cdivsufsort/c-sources/utils.c:160-241      sufcheck()                (same return convention)
+ *
+ * Contract (identical to divsufsort()):
+ *   - T: exactly n bytes, borrowed, read-only, no padding required.  SA: caller-allocated n indices,
+ *     fully overwritten.  Nothing is retained after return.
+ *   - return 0 on success, -1 for invalid arguments (NULL pointers, n < 0), -2 for (device or host)
+ *     allocation failure; additionally -3 for a HIP runtime error and -4 when n exceeds what this
+ *     build supports (n > DC3HIP_MAX_N).  dc3hip_last_error() describes the failure (thread-local).
+ *   - all entry points are re-entrant and thread-safe: every call owns its context and HIP stream
+ *     (sacapart calls the SACA concurrently from rayon workers, crates/sacapart/src/lib.rs:41-49).
+ *   - there is NO CPU fallback: without a usable gfx950 device the calls fail with -3.
+ *
+ * Plain C, no torch / HIP types in any signature.
+ */
+#ifndef DC3HIP_H
+#define DC3HIP_H 1
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DC3HIP_API __attribute__((visibility("default")))
+
+/* Largest supported text length (32-bit device-side positions, int32 ranks). */
+#define DC3HIP_MAX_N ((int64_t)2147483000)
+
+/* ---- one-shot entry points (the FFI surface a Rust/Go/... shim binds) ------------------------ */
+
+/* Replaces divsufsort(T, SA, n) (cdivsufsort/src/lib.rs:1-4, divsufsort.h:74-76). */
+DC3HIP_API int32_t dc3hip_sufsort_i32(const uint8_t *T, int32_t *SA, int32_t n);
+
+/* 64-bit index variant (sacabase only needs Index: ToPrimitive, sacabase/src/lib.rs:165-167). */
+DC3HIP_API int32_t dc3hip_sufsort_i64(const uint8_t *T, int64_t *SA, int64_t n);
+
+typedef struct dc3hip_opts {
+  int32_t struct_size;   /* = sizeof(dc3hip_opts), for forward compatibility */
+  int32_t index_bits;    /* 32 or 64: element type of SA */
+  int32_t device;        /* HIP device ordinal, -1 = current device */
+  int32_t num_partitions;/* 0/1 = one SA for the whole text; P>1 = sacapart semantics
+                            (sacapart/src/lib.rs:39-58): chunk size n/P+1, SA holds the P local
+                            suffix arrays back to back (chunk c at offset c*(n/P+1)), local indices */
+  int32_t flags;         /* DC3HIP_F_* */
+} dc3hip_opts;
+#define DC3HIP_F_DEVICE_PTRS 1 /* T and SA are device pointers on `device` (no H2D/D2H) */
+
+DC3HIP_API int32_t dc3hip_sufsort_ex(const uint8_t *T, void *SA, int64_t n, const dc3hip_opts *opts);
+
+/* sufcheck() twin, computed on the GPU (utils.c:160-241 return codes: 0 ok, -1 invalid arguments,
+ * -2 out of range, -3 first characters out of order, -4 suffix in wrong position). */
+DC3HIP_API int32_t dc3hip_sufcheck_i32(const uint8_t *T, const int32_t *SA, int32_t n);
+
+DC3HIP_API const char *dc3hip_version(void);
+DC3HIP_API const char *dc3hip_last_error(void); /* thread-local, never NULL */
+DC3HIP_API int32_t dc3hip_device_count(void);   /* number of visible HIP devices, <0 on error */
+
+/* ---- context API: device-resident builds (bench / repeated calls / multi-GPU hosts) ---------- */
+
+typedef struct dc3hip_ctx dc3hip_ctx;
+
+/* Creates a context on `device` (-1 = current) able to index texts of up to max_n bytes.
+ * All device memory (text, SA, work arena) is allocated here, never inside a build. */
+DC3HIP_API int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n);
+DC3HIP_API void dc3hip_ctx_destroy(dc3hip_ctx *ctx);
+
+/* Load the text: from host memory (H2D copy) ... */
+DC3HIP_API int32_t dc3hip_ctx_set_text(dc3hip_ctx *ctx, const uint8_t *T, int64_t n);
+/* ... or generate it on the device: byte i = byte (i&7) of splitmix64(seed + (i>>3)) for kind 0,
+ * "ACGT"[2-bit field] for kind 1 (bit-identical to oracle_gen_bytes). */
+DC3HIP_API int32_t dc3hip_ctx_generate(dc3hip_ctx *ctx, int64_t n, uint64_t seed, int32_t kind);
+/* Same stream, bytes [offset, offset+n): lets each GPU of a sacapart run generate its own chunk. */
+DC3HIP_API int32_t dc3hip_ctx_generate_at(dc3hip_ctx *ctx, int64_t n, uint64_t seed, int32_t kind, int64_t offset);
+
+/* Build SA[0..n) of the loaded text on the device (text and SA stay in HBM).  Blocking. */
+DC3HIP_API int32_t dc3hip_ctx_build(dc3hip_ctx *ctx);
+
+/* Copy results back. */
+DC3HIP_API int32_t dc3hip_ctx_get_sa_i32(dc3hip_ctx *ctx, int32_t *SA);
+DC3HIP_API int32_t dc3hip_ctx_get_sa_i64(dc3hip_ctx *ctx, int64_t *SA);
+DC3HIP_API int32_t dc3hip_ctx_get_text(dc3hip_ctx *ctx, uint8_t *T);
+
+/* Verify the device-resident SA against the device-resident text on the GPU.
+ * Returns the sufcheck() codes above. */
+DC3HIP_API int32_t dc3hip_ctx_sufcheck(dc3hip_ctx *ctx);
+
+/* 64-bit order-sensitive checksum of the device-resident SA (sum over k of mix(k, SA[k])). */
+DC3HIP_API int32_t dc3hip_ctx_sa_checksum(dc3hip_ctx *ctx, uint64_t *out);
+
+#define DC3HIP_MAX_LEVELS 48
+enum dc3hip_phase {
+  DC3HIP_PH_ALPHABET = 0,   /* byte histogram + dense code table (level 0) */
+  DC3HIP_PH_NAME_DIRECT,    /* order-preserving packed-triple names (no sort needed) */
+  DC3HIP_PH_PACK,           /* triple records (key, pos) in position order  (ref lib.rs:62-70 + keys) */
+  DC3HIP_PH_SORT12_UP,      /* radix passes on sample triples: digit histograms   (ref lib.rs:20-22) */
+  DC3HIP_PH_SORT12_SCAN,    /*                                 prefix sums        (ref lib.rs:25-32) */
+  DC3HIP_PH_SORT12_DOWN,    /*                                 stable scatter     (ref lib.rs:35-38) */
+  DC3HIP_PH_NAMING,         /* flag/scan/assign lexicographic names               (ref lib.rs:80-100) */
+  DC3HIP_PH_RANKS,          /* rank <- SA12 inversion                             (ref lib.rs:106-113) */
+  DC3HIP_PH_TUPLES,         /* merge tuples in slot order + gather to SA12 order */
+  DC3HIP_PH_COMPACT,        /* mod-0 suffixes ordered by rank of suffix i+1       (ref lib.rs:118-125) */
+  DC3HIP_PH_SORT0,          /* stable radix sort of mod-0 tuples by first symbol  (ref lib.rs:126) */
+  DC3HIP_PH_MERGE,          /* merge-path merge of SA12 and SA0                   (ref lib.rs:131-192) */
+  DC3HIP_PH_OTHER,
+  DC3HIP_PH_COUNT
+};
+
+typedef struct dc3hip_stats {
+  int32_t struct_size;
+  int32_t levels;                         /* recursion depth reached by the last build */
+  int64_t level_n[DC3HIP_MAX_LEVELS];     /* string length per level (level 0 = n) */
+  int64_t level_K[DC3HIP_MAX_LEVELS];     /* alphabet bound per level */
+  int32_t level_sorted[DC3HIP_MAX_LEVELS];/* 1 = names by radix sort, 0 = direct packed names */
+  double  build_ms;                       /* HIP-event time of the whole device-resident build */
+  double  phase_ms[DC3HIP_PH_COUNT];      /* HIP-event time per phase, summed over levels */
+  int64_t phase_launches[DC3HIP_PH_COUNT];
+  /* dominant kernel (stable radix scatter of 16-byte triple records): */
+  double  downsweep16_ms;                 /* summed HIP-event time of its launches */
+  int64_t downsweep16_launches;
+  int64_t downsweep16_elems;              /* records moved, summed over launches */
+  int64_t arena_bytes;                    /* device work arena size */
+  int64_t arena_peak;                     /* high-water mark of the last build */
+} dc3hip_stats;
+
+DC3HIP_API int32_t dc3hip_ctx_stats(dc3hip_ctx *ctx, dc3hip_stats *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DC3HIP_H */

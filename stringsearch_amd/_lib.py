@@ -1,0 +1,90 @@
+"""ctypes binding of libdc3hip.so — exactly the symbols include/dc3hip.h declares."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+lib_path = os.path.join(_HERE, "libdc3hip.so")
+
+MAX_LEVELS = 48
+PHASES = ["alphabet", "name_direct", "pack", "sort12_up", "sort12_scan", "sort12_down", "naming", "ranks",
+          "tuples", "compact", "sort0", "merge", "other"]
+
+
+class Dc3HipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"dc3hip error {code}: {msg}")
+        self.code = code
+
+
+class Opts(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_int32), ("index_bits", ctypes.c_int32), ("device", ctypes.c_int32),
+                ("num_partitions", ctypes.c_int32), ("flags", ctypes.c_int32)]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_int32), ("levels", ctypes.c_int32),
+                ("level_n", ctypes.c_int64 * MAX_LEVELS), ("level_K", ctypes.c_int64 * MAX_LEVELS),
+                ("level_sorted", ctypes.c_int32 * MAX_LEVELS),
+                ("build_ms", ctypes.c_double), ("phase_ms", ctypes.c_double * len(PHASES)),
+                ("phase_launches", ctypes.c_int64 * len(PHASES)),
+                ("downsweep16_ms", ctypes.c_double), ("downsweep16_launches", ctypes.c_int64),
+                ("downsweep16_elems", ctypes.c_int64), ("arena_bytes", ctypes.c_int64),
+                ("arena_peak", ctypes.c_int64)]
+
+    def as_dict(self):
+        return {
+            "levels": self.levels,
+            "level_n": [self.level_n[i] for i in range(self.levels)],
+            "level_K": [self.level_K[i] for i in range(self.levels)],
+            "level_sorted": [self.level_sorted[i] for i in range(self.levels)],
+            "build_ms": self.build_ms,
+            "phase_ms": {PHASES[i]: self.phase_ms[i] for i in range(len(PHASES))},
+            "phase_launches": {PHASES[i]: self.phase_launches[i] for i in range(len(PHASES))},
+            "downsweep16_ms": self.downsweep16_ms, "downsweep16_launches": self.downsweep16_launches,
+            "downsweep16_elems": self.downsweep16_elems,
+            "arena_bytes": self.arena_bytes, "arena_peak": self.arena_peak,
+        }
+
+
+# every exported symbol of include/dc3hip.h: (restype, argtypes)
+_vp, _i32, _i64, _u64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64
+SYMBOLS = {
+    "dc3hip_sufsort_i32": (_i32, [_vp, _vp, _i32]),
+    "dc3hip_sufsort_i64": (_i32, [_vp, _vp, _i64]),
+    "dc3hip_sufsort_ex": (_i32, [_vp, _vp, _i64, ctypes.POINTER(Opts)]),
+    "dc3hip_sufcheck_i32": (_i32, [_vp, _vp, _i32]),
+    "dc3hip_version": (ctypes.c_char_p, []),
+    "dc3hip_last_error": (ctypes.c_char_p, []),
+    "dc3hip_device_count": (_i32, []),
+    "dc3hip_ctx_create": (_i32, [ctypes.POINTER(_vp), _i32, _i64]),
+    "dc3hip_ctx_destroy": (None, [_vp]),
+    "dc3hip_ctx_set_text": (_i32, [_vp, _vp, _i64]),
+    "dc3hip_ctx_generate": (_i32, [_vp, _i64, _u64, _i32]),
+    "dc3hip_ctx_generate_at": (_i32, [_vp, _i64, _u64, _i32, _i64]),
+    "dc3hip_ctx_build": (_i32, [_vp]),
+    "dc3hip_ctx_get_sa_i32": (_i32, [_vp, _vp]),
+    "dc3hip_ctx_get_sa_i64": (_i32, [_vp, _vp]),
+    "dc3hip_ctx_get_text": (_i32, [_vp, _vp]),
+    "dc3hip_ctx_sufcheck": (_i32, [_vp]),
+    "dc3hip_ctx_sa_checksum": (_i32, [_vp, ctypes.POINTER(_u64)]),
+    "dc3hip_ctx_stats": (_i32, [_vp, ctypes.POINTER(Stats)]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libdc3hip.so (built by __graft_entry__.build() / make -C stringsearch_amd/csrc).
+    Fails loudly when it is missing — there is no other compute path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(lib_path):
+            raise Dc3HipError(-3, f"{lib_path} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                  "or `make -C stringsearch_amd/csrc` (no CPU fallback exists)")
+        L = ctypes.CDLL(lib_path)
+        for name, (res, args) in SYMBOLS.items():
+            f = getattr(L, name)       # AttributeError if the ABI lost a symbol
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib

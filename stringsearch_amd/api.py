@@ -1,0 +1,256 @@
+"""Host-side mirror of the reference's SACA plug-in interface (see package docstring)."""
+import ctypes
+
+import numpy as np
+
+from ._lib import Dc3HipError, Opts, Stats, lib
+
+I32_MAX = 2**31 - 1
+
+
+def version():
+    return lib().dc3hip_version().decode()
+
+
+def last_error():
+    return lib().dc3hip_last_error().decode()
+
+
+def device_count():
+    return int(lib().dc3hip_device_count())
+
+
+def _check(rc):
+    if rc != 0:
+        raise Dc3HipError(rc, last_error())
+
+
+def _as_u8(text):
+    if isinstance(text, np.ndarray):
+        if text.dtype != np.uint8:
+            raise TypeError("text must be bytes-like or a uint8 array")
+        return np.ascontiguousarray(text)
+    return np.frombuffer(memoryview(text).cast("B"), dtype=np.uint8)
+
+
+# ------------------------------------------------------------------------------------------------
+# cdivsufsort/src/lib.rs:9-30
+# ------------------------------------------------------------------------------------------------
+def sort_in_place(text, sa):
+    """Sort suffixes of `text` into the caller's int32 array `sa` (cdivsufsort/src/lib.rs:9-23):
+    asserts len(text) == len(sa) and len(text) < i32::MAX, then calls the FFI and asserts ret == 0
+    (errors become exceptions, as they become panics in the reference)."""
+    t = _as_u8(text)
+    if not (isinstance(sa, np.ndarray) and sa.dtype == np.int32 and sa.flags.c_contiguous and sa.flags.writeable):
+        raise TypeError("sa must be a writable C-contiguous int32 numpy array")
+    assert len(t) == len(sa), "text and suffix array should have same len"
+    assert len(t) < I32_MAX, f"text too large, should not exceed {I32_MAX - 1} bytes"
+    tp = t.ctypes.data if len(t) else ctypes.addressof(ctypes.create_string_buffer(1))
+    sp = sa.ctypes.data if len(sa) else ctypes.addressof(ctypes.create_string_buffer(4))
+    _check(lib().dc3hip_sufsort_i32(tp, sp, len(t)))
+
+
+def sort(text):
+    """Sort suffixes (cdivsufsort/src/lib.rs:26-30): returns a SuffixArray owning an int32 array."""
+    t = _as_u8(text)
+    sa = np.zeros(len(t), dtype=np.int32)
+    sort_in_place(t, sa)
+    return SuffixArray(t, sa)
+
+
+def sort_i64(text):
+    """64-bit index variant (sacabase only requires Index: ToPrimitive)."""
+    t = _as_u8(text)
+    sa = np.zeros(len(t), dtype=np.int64)
+    tp = t.ctypes.data if len(t) else ctypes.addressof(ctypes.create_string_buffer(1))
+    sp = sa.ctypes.data if len(sa) else ctypes.addressof(ctypes.create_string_buffer(8))
+    _check(lib().dc3hip_sufsort_i64(tp, sp, len(t)))
+    return SuffixArray(t, sa)
+
+
+def sufcheck(text, sa):
+    """GPU twin of sufcheck() (cdivsufsort/c-sources/utils.c:160-241); returns its code (0 = ok)."""
+    t = _as_u8(text)
+    s = np.ascontiguousarray(sa, dtype=np.int32)
+    return int(lib().dc3hip_sufcheck_i32(t.ctypes.data, s.ctypes.data, len(t)))
+
+
+# ------------------------------------------------------------------------------------------------
+# sacabase/src/lib.rs
+# ------------------------------------------------------------------------------------------------
+class LongestCommonSubstring:
+    """sacabase/src/lib.rs:4-21"""
+
+    def __init__(self, text, start, length):
+        self.text, self.start, self.len = text, int(start), int(length)
+
+    def as_bytes(self):
+        return bytes(self.text[self.start:self.start + self.len])
+
+    def __repr__(self):
+        return f"T[{self.start}..{self.start + self.len}]"
+
+
+def common_prefix_len(a, b):
+    """sacabase/src/lib.rs:26-35"""
+    a = _as_u8(a); b = _as_u8(b)
+    n = min(len(a), len(b))
+    if n == 0:
+        return 0
+    neq = np.nonzero(a[:n] != b[:n])[0]
+    return int(neq[0]) if len(neq) else n
+
+
+class NotSorted(Exception):
+    """sacabase/src/lib.rs:102-123"""
+
+    def __init__(self, i, j):
+        super().__init__(f"invariant doesn't hold: suf(SA({i})) < suf(SA({j}))")
+        self.i, self.j = i, j
+
+
+def verify(text, sa):
+    """sacabase/src/lib.rs:127-149: raises NotSorted(i, i+1) at the first adjacent pair out of order."""
+    t = bytes(_as_u8(text))
+    for i in range(len(t) - 1):
+        if not (t[int(sa[i]):] < t[int(sa[i + 1]):]):
+            raise NotSorted(i, i + 1)
+
+
+def _longest_substring_match(text_u8, sa, needle_u8):
+    """sacabase/src/lib.rs:39-99 (binary search narrowing to <= 2 candidates)."""
+    tb, nb = bytes(text_u8), bytes(needle_u8)
+    lo, n = 0, len(sa)
+    while True:
+        if n == 1:
+            s = int(sa[lo]); return LongestCommonSubstring(text_u8, s, common_prefix_len(text_u8[s:], needle_u8))
+        if n == 2:
+            s0, s1 = int(sa[lo]), int(sa[lo + 1])
+            x = common_prefix_len(text_u8[s0:], needle_u8); y = common_prefix_len(text_u8[s1:], needle_u8)
+            return LongestCommonSubstring(text_u8, s0, x) if x > y else LongestCommonSubstring(text_u8, s1, y)
+        if n == 0:
+            raise IndexError("empty suffix array")   # the Rust indexes out of bounds here
+        mid = n // 2
+        if nb > tb[int(sa[lo + mid]):]:
+            lo += mid; n -= mid
+        else:
+            n = mid + 1
+
+
+class SuffixArray:
+    """sacabase/src/lib.rs:152-197: owns `sa`, borrows `text`."""
+
+    def __init__(self, text, sa):          # SuffixArray::new, :170
+        self._text = _as_u8(text)
+        self._sa = sa
+
+    def into_parts(self):                  # :175
+        return self._text, self._sa
+
+    def verify(self):                      # :180
+        return verify(self._text, self._sa)
+
+    def text(self):                        # :185
+        return self._text
+
+    def longest_substring_match(self, needle):   # StringIndex, :190-196
+        return _longest_substring_match(self._text, self._sa, _as_u8(needle))
+
+
+# ------------------------------------------------------------------------------------------------
+# sacapart/src/lib.rs
+# ------------------------------------------------------------------------------------------------
+class PartitionedSuffixArray:
+    """sacapart/src/lib.rs:26-97.  `f` maps a chunk to a SuffixArray (e.g. stringsearch_amd.sort);
+    chunks are text[c*S : (c+1)*S] with S = len/P + 1 (lib.rs:43-46).  The reference runs f on a
+    rayon pool; here chunks are independent device builds (see bench.py for one-chunk-per-GPU)."""
+
+    def __init__(self, text, num_partitions, f):
+        self.text = _as_u8(text)
+        self.partition_size = len(self.text) // num_partitions + 1
+        S = self.partition_size
+        self.sas = [f(self.text[off:off + S]) for off in range(0, len(self.text), S)]
+
+    def num_partitions(self):              # :60
+        return len(self.sas)
+
+    def longest_substring_match(self, needle):   # :69-97
+        needle = _as_u8(needle)
+        best = None
+        for i, sa in enumerate(self.sas):
+            lcs = sa.longest_substring_match(needle)
+            offset = i * self.partition_size
+            may_extend = lcs.start + lcs.len == len(sa.text())
+            lcs.start += offset
+            lcs.text = self.text
+            if may_extend:
+                lcs.len = common_prefix_len(self.text[lcs.start:], needle)
+            if best is None or lcs.len > best.len:
+                best = lcs
+        if best is None:
+            raise RuntimeError("partitioned suffix arrays should always find at least one longest common substring")
+        return best
+
+
+# ------------------------------------------------------------------------------------------------
+# device-resident context (bench / repeated builds)
+# ------------------------------------------------------------------------------------------------
+class Context:
+    def __init__(self, max_n, device=-1):
+        self._h = ctypes.c_void_p()
+        _check(lib().dc3hip_ctx_create(ctypes.byref(self._h), device, max_n))
+        self.n = 0
+
+    def close(self):
+        if self._h:
+            lib().dc3hip_ctx_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_text(self, text):
+        t = _as_u8(text)
+        tp = t.ctypes.data if len(t) else None
+        _check(lib().dc3hip_ctx_set_text(self._h, tp, len(t)))
+        self.n = len(t)
+
+    def generate(self, n, seed, kind=0, offset=0):
+        _check(lib().dc3hip_ctx_generate_at(self._h, n, seed, kind, offset))
+        self.n = n
+
+    def build(self):
+        _check(lib().dc3hip_ctx_build(self._h))
+
+    def sa(self, dtype=np.int32):
+        out = np.zeros(self.n, dtype=dtype)
+        f = lib().dc3hip_ctx_get_sa_i32 if dtype == np.int32 else lib().dc3hip_ctx_get_sa_i64
+        _check(f(self._h, out.ctypes.data if self.n else None))
+        return out
+
+    def text(self):
+        out = np.zeros(self.n, dtype=np.uint8)
+        _check(lib().dc3hip_ctx_get_text(self._h, out.ctypes.data if self.n else None))
+        return out
+
+    def sufcheck(self):
+        return int(lib().dc3hip_ctx_sufcheck(self._h))
+
+    def checksum(self):
+        v = ctypes.c_uint64()
+        _check(lib().dc3hip_ctx_sa_checksum(self._h, ctypes.byref(v)))
+        return int(v.value)
+
+    def stats(self):
+        st = Stats()
+        _check(lib().dc3hip_ctx_stats(self._h, ctypes.byref(st)))
+        return st.as_dict()

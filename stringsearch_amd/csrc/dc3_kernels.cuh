@@ -1,0 +1,601 @@
+// dc3_kernels.cuh — gfx950 (CDNA4, wave64) device kernels of the DC3/Skew suffix-array path.
+//
+// Every kernel maps to a loop of the reference's crates/dc3/src/lib.rs (cited per kernel).
+// Design rules: the work is HBM-bound integer/index traffic, so
+//   * arrays are moved as coalesced records ((key,pos) / merge tuples), never sorted indirectly;
+//   * the K+1-counter counting sort of the reference (lib.rs:15-39) becomes 8-bit-digit LSD passes
+//     with per-wave LDS digit counters, wave64 ballot ranking (stable) and an LDS reorder so that
+//     each (tile,digit) run leaves the CU as one contiguous burst;
+//   * blocks own contiguous chunks (up-sweep / scan / down-sweep), so the only inter-block
+//     communication is through kernel boundaries — no spin waits, no placement assumptions.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dc3 {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+constexpr int kBlock = 256;         // 4 waves of 64
+constexpr int kWaves = kBlock / 64;
+
+// ---------------------------------------------------------------------------------------------
+// Record types
+// ---------------------------------------------------------------------------------------------
+// Sample-triple record: 96-bit packed key (k[0] least significant) + text position.
+struct __attribute__((aligned(16))) Rec16 { u32 k0, k1, k2, pos; };
+// Merge tuple of a sample (mod-1 / mod-2) suffix, 16 B:
+//   pos%3==1: (c0=S[pos], r=rank[pos+1]), cx = S[pos-1]   (cx feeds the derived mod-0 tuple)
+//   pos%3==2: (c0=S[pos], cx=S[pos+1], r=rank[pos+2])
+struct __attribute__((aligned(16))) Tup12 { u32 pos, r, c0, cx; };
+// Merge tuple of a mod-0 suffix j: (c0=S[j], c1=S[j+1], r1=rank[j+1], r2=rank[j+2]), 20 B.
+struct Tup0 { u32 pos, c0, c1, r1, r2; };
+
+// ---------------------------------------------------------------------------------------------
+// Symbol readers: level 0 reads bytes through the dense code table (codes 1..sigma, 0 past the
+// end = the sentinel of lib.rs:41-42); deeper levels read u32 names whose zero tail is physical.
+// ---------------------------------------------------------------------------------------------
+struct SymU8 {
+  const uint8_t *t; const uint16_t *code; u32 m;
+  __device__ __forceinline__ u32 get(u32 i) const { return i < m ? (u32)code[t[i]] : 0u; }
+};
+struct SymU32 {
+  const u32 *s; u32 m;   // s has >= 8 zero words after s[m-1]
+  __device__ __forceinline__ u32 get(u32 i) const { return s[i]; }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Wave / block primitives (wave64)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ u32 wave_id() { return threadIdx.x >> 6; }
+
+__device__ __forceinline__ u32 wave_incl_scan(u32 v) {
+  const u32 lane = lane_id();
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { u32 t = __shfl_up(v, o); if (lane >= (u32)o) v += t; }
+  return v;
+}
+__device__ __forceinline__ u32 wave_reduce(u32 v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+// Exclusive scan of one value per thread over a block of NW waves; tmp needs NW words of LDS.
+template <int NW>
+__device__ __forceinline__ u32 block_excl_scan(u32 v, u32 *tmp, u32 &total) {
+  const u32 inc = wave_incl_scan(v);
+  if (lane_id() == 63) tmp[wave_id()] = inc;
+  __syncthreads();
+  u32 woff = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < NW; i++) { u32 t = tmp[i]; if ((u32)i < wave_id()) woff += t; tot += t; }
+  __syncthreads();
+  total = tot;
+  return woff + inc - v;
+}
+
+// popcount of mask bits below this lane
+__device__ __forceinline__ u32 mbcnt(u64 mask) {
+  return __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Single-block exclusive scan of a (small) u32 array in place; used for digit tables and
+// per-chunk counts.  total_out (optional) receives the grand total.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_scan_excl_inplace(u32 *data, u32 n, u32 *total_out) {
+  __shared__ u32 tmp[16];
+  u32 carry = 0;
+  const u32 tid = threadIdx.x;
+  for (u32 base = 0; base < n; base += 1024 * 4) {
+    const u32 i0 = base + tid * 4;
+    u32 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = (i0 + j < n) ? data[i0 + j] : 0u;
+    const u32 s = v[0] + v[1] + v[2] + v[3];
+    u32 tot;
+    u32 ex = block_excl_scan<16>(s, tmp, tot) + carry;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { if (i0 + j < n) data[i0 + j] = ex; ex += v[j]; }
+    carry += tot;
+  }
+  if (tid == 0 && total_out) *total_out = carry;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Level-0 alphabet: byte histogram -> dense order-preserving code table (codes 1..sigma).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_byte_presence(const uint8_t *t, u32 n, u32 *present /*[256]*/) {
+  __shared__ u32 loc[256];
+  loc[threadIdx.x] = 0;
+  __syncthreads();
+  const u32 nvec = n / 16;
+  const uint4 *tv = reinterpret_cast<const uint4 *>(t);
+  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < nvec; i += gridDim.x * kBlock) {
+    uint4 v = tv[i];
+    u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      loc[w[j] & 255] = 1; loc[(w[j] >> 8) & 255] = 1; loc[(w[j] >> 16) & 255] = 1; loc[w[j] >> 24] = 1;
+    }
+  }
+  if (blockIdx.x == 0) for (u32 i = nvec * 16 + threadIdx.x; i < n; i += kBlock) loc[t[i]] = 1;
+  __syncthreads();
+  if (loc[threadIdx.x]) present[threadIdx.x] = 1;   // benign race: every writer stores 1
+}
+// one block of 256 threads: code[b] = 1 + #present bytes below b (0 if absent); sigma_out = #present
+__global__ __launch_bounds__(kBlock) void k_make_codes(const u32 *present, uint16_t *code /*[256]*/, u32 *sigma_out) {
+  __shared__ u32 tmp[kWaves];
+  const u32 p = present[threadIdx.x] ? 1u : 0u;
+  u32 tot;
+  const u32 ex = block_excl_scan<kWaves>(p, tmp, tot);
+  code[threadIdx.x] = (uint16_t)(p ? ex + 1 : 0);   // dense, order-preserving, 1..sigma (sigma <= 256)
+  if (threadIdx.x == 0) *sigma_out = tot;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Direct (sort-free) naming: when (K+1)^3 fits 31 bits the packed triple itself is an
+// order-preserving name, name = ((s0*B + s1)*B + s2) + 1 with B = K+1, so the sample string
+//   R[slot(i)] for i%3 != 0   (slot = i/3 for mod 1, i/3 + m0 for mod 2; lib.rs:93-98)
+// is produced by one streaming pass.  Replaces lib.rs:62-100 for small alphabets (names need not
+// be dense, only order- and equality-preserving).
+// Thread g owns positions 3g+1 and 3g+2.
+// ---------------------------------------------------------------------------------------------
+template <class Sym>
+__global__ __launch_bounds__(kBlock) void k_name_direct(Sym S, u32 m, u32 m0, u32 m02, u32 B, u32 *R) {
+  const u32 ngroups = m0;   // group g: samples 3g+1 (slot g) and 3g+2 (slot m0+g)
+  for (u32 g = blockIdx.x * kBlock + threadIdx.x; g < ngroups; g += gridDim.x * kBlock) {
+    const u32 i = 3 * g + 1;
+    const u32 s1 = S.get(i), s2 = S.get(i + 1), s3 = S.get(i + 2), s4 = S.get(i + 3);
+    // mod-1 sample exists for every g < m0 (includes the dummy at i == m when m%3 == 1)
+    R[g] = ((s1 * B + s2) * B + s3) + 1;
+    if (i + 1 < m) R[m0 + g] = ((s2 * B + s3) * B + s4) + 1;
+  }
+  // zero tail of R (sentinels of the next level, lib.rs:51-53)
+  if (blockIdx.x == 0 && threadIdx.x < 8) R[m02 + threadIdx.x] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Triple records in position order (lib.rs:62-70 fused with the key reads of :74-76).
+// key = s0<<2b | s1<<b | s2  (96-bit, b = bit width of K), thread g emits records of 3g+1, 3g+2
+// at indices 2g, 2g+1 — i.e. ascending text position like the reference's R.
+// n12 = number of sample positions = m02.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ Rec16 make_rec(u32 s0, u32 s1, u32 s2, u32 b, u32 pos) {
+  const u64 lo = (u64)s2 | ((u64)s1 << b);                 // bits [0,2b), 2b <= 62
+  const u64 lo64 = lo | ((u64)s0 << (2 * b));              // truncating shift is intended
+  const u32 hi = (2 * b > 32) ? (u32)((u64)s0 >> (64 - 2 * b)) : 0u;
+  Rec16 r; r.k0 = (u32)lo64; r.k1 = (u32)(lo64 >> 32); r.k2 = hi; r.pos = pos;
+  return r;
+}
+template <class Sym>
+__global__ __launch_bounds__(kBlock) void k_pack_triples(Sym S, u32 m, u32 m0, u32 m02, u32 b, Rec16 *out) {
+  // sample positions in ascending order: 1,2,4,5,7,8,...; index of 3g+1 is 2g, of 3g+2 is 2g+1
+  for (u32 g = blockIdx.x * kBlock + threadIdx.x; g < m0; g += gridDim.x * kBlock) {
+    const u32 i = 3 * g + 1;
+    const u32 s1 = S.get(i), s2 = S.get(i + 1), s3 = S.get(i + 2), s4 = S.get(i + 3);
+    out[2 * g] = make_rec(s1, s2, s3, b, i);
+    if (2 * g + 1 < m02) out[2 * g + 1] = make_rec(s2, s3, s4, b, i + 1);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stable LSD radix pass, 8-bit digits (lib.rs:15-39 with the K+1 counters replaced by digits).
+//   up-sweep  : per-chunk digit histogram (lib.rs:20-22)          -> table[digit][chunk]
+//   scan      : exclusive prefix sums over table (lib.rs:25-32)   (k_scan_excl_inplace)
+//   down-sweep: stable scatter (lib.rs:35-38)
+// Digit functors return byte `p` of the key.
+// ---------------------------------------------------------------------------------------------
+struct Rec16Byte {
+  u32 p;
+  __device__ __forceinline__ u32 operator()(const Rec16 &r) const {
+    const u32 w = p < 4 ? r.k0 : (p < 8 ? r.k1 : r.k2);
+    return (w >> ((p & 3) * 8)) & 255u;
+  }
+};
+struct Tup0Byte {
+  u32 p;
+  __device__ __forceinline__ u32 operator()(const Tup0 &r) const { return (r.c0 >> (p * 8)) & 255u; }
+};
+
+template <class Rec, class Dig>
+__global__ __launch_bounds__(kBlock) void k_rs_upsweep(const Rec *__restrict__ in, u32 n, u32 chunk, u32 nchunks,
+                                                      Dig dig, u32 *__restrict__ table) {
+  __shared__ u32 hist[kWaves][256];
+  const u32 tid = threadIdx.x;
+#pragma unroll
+  for (int w = 0; w < kWaves; w++) hist[w][tid] = 0;
+  __syncthreads();
+  const u32 begin = blockIdx.x * chunk;
+  const u32 end = min(n, begin + chunk);
+  u32 *myh = hist[wave_id()];
+  for (u32 i = begin + tid; i < end; i += kBlock) {
+    const Rec r = in[i];
+    atomicAdd(&myh[dig(r)], 1u);
+  }
+  __syncthreads();
+  u32 s = 0;
+#pragma unroll
+  for (int w = 0; w < kWaves; w++) s += hist[w][tid];
+  table[tid * nchunks + blockIdx.x] = s;
+}
+
+template <class Rec, int IPT>
+struct DownsweepSmem {
+  static constexpr int kTile = kBlock * IPT;
+  static constexpr size_t kBytes = sizeof(Rec) * kTile + sizeof(u32) * (kWaves * 256 + 256 + 256 + 16);
+};
+
+template <class Rec, class Dig, int IPT>
+__global__ __launch_bounds__(kBlock) void k_rs_downsweep(const Rec *__restrict__ in, Rec *__restrict__ out, u32 n,
+                                                        u32 chunk, u32 nchunks, Dig dig,
+                                                        const u32 *__restrict__ table) {
+  constexpr int kTile = kBlock * IPT;
+  constexpr int kWItems = 64 * IPT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Rec *srec = reinterpret_cast<Rec *>(smem);
+  u32 *wcnt = reinterpret_cast<u32 *>(smem + sizeof(Rec) * kTile);   // [kWaves][256]
+  u32 *dbase = wcnt + kWaves * 256;                                  // [256] running global base
+  u32 *texcl = dbase + 256;                                          // [256] tile-exclusive prefix
+  u32 *tmp = texcl + 256;                                            // [16]
+  const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
+  const u32 begin = blockIdx.x * chunk;
+  const u32 end = min(n, begin + chunk);
+  dbase[tid] = table[tid * nchunks + blockIdx.x];
+  volatile u32 *mycnt = wcnt + w * 256;
+
+  for (u32 tile = begin; tile < end; tile += kTile) {
+    const u32 nvalid = min((u32)kTile, end - tile);
+#pragma unroll
+    for (int j = 0; j < 4; j++) mycnt[lane + 64 * j] = 0;
+    Rec r[IPT];
+    u32 d[IPT], rk[IPT];
+    // wave w owns tile items [w*kWItems, (w+1)*kWItems); round k covers 64 consecutive items
+#pragma unroll
+    for (int k = 0; k < IPT; k++) {
+      const u32 t = w * kWItems + k * 64 + lane;
+      if (t < nvalid) { r[k] = in[tile + t]; d[k] = dig(r[k]); }
+      else d[k] = 255u;                               // padding sorts last within the tile
+    }
+    // stable ranking: items of one wave-round with equal digit are ordered by lane
+#pragma unroll
+    for (int k = 0; k < IPT; k++) {
+      u64 peers = ~0ull;
+#pragma unroll
+      for (int bit = 0; bit < 8; bit++) {
+        const bool one = (d[k] >> bit) & 1u;
+        const u64 mk = __ballot(one);
+        peers &= one ? mk : ~mk;
+      }
+      const u32 below = mbcnt(peers);
+      const u32 cnt = __popcll(peers);
+      const u32 base = mycnt[d[k]];
+      rk[k] = base + below;
+      if (below == cnt - 1) mycnt[d[k]] = base + cnt;   // highest peer lane publishes
+    }
+    __syncthreads();
+    // per digit (thread tid = digit): prefix over waves, tile total, tile-exclusive prefix
+    u32 tot = 0;
+    {
+      u32 c[kWaves];
+#pragma unroll
+      for (int i = 0; i < kWaves; i++) c[i] = wcnt[i * 256 + tid];
+#pragma unroll
+      for (int i = 0; i < kWaves; i++) { wcnt[i * 256 + tid] = tot; tot += c[i]; }
+    }
+    u32 dummy_total;
+    const u32 ex = block_excl_scan<kWaves>(tot, tmp, dummy_total);
+    texcl[tid] = ex;
+    __syncthreads();
+    // reorder through LDS so every digit run is contiguous
+#pragma unroll
+    for (int k = 0; k < IPT; k++) {
+      const u32 t = w * kWItems + k * 64 + lane;
+      if (t < nvalid) srec[texcl[d[k]] + wcnt[w * 256 + d[k]] + rk[k]] = r[k];
+    }
+    __syncthreads();
+    for (u32 q = tid; q < nvalid; q += kBlock) {
+      const Rec x = srec[q];
+      const u32 dd = dig(x);
+      out[dbase[dd] + (q - texcl[dd])] = x;
+    }
+    __syncthreads();
+    dbase[tid] += tot;
+    // (the barrier after ranking in the next iteration orders this update before its use)
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Naming (lib.rs:80-100): name = 1 + number of key changes before i in the sorted order.
+//   k_name_count : per-chunk count of "key differs from predecessor" flags
+//   (scan of the counts, total = number of distinct names)
+//   k_name_assign: R[slot(pos_i)] = name_i                      (lib.rs:93-98)
+//   k_assign_unique: when every name is unique (lib.rs:109-113), SA12[i] = slot(pos_i) and
+//                    rank[slot(pos_i)] = i+1 directly
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool key_neq(const Rec16 &a, const Rec16 &b) {
+  return (a.k0 != b.k0) | (a.k1 != b.k1) | (a.k2 != b.k2);
+}
+__device__ __forceinline__ u32 slot_of(u32 pos, u32 m0) {
+  const u32 q = pos / 3, rem = pos - 3 * q;
+  return rem == 1 ? q : q + m0;
+}
+
+constexpr int kNameIPT = 4;
+__global__ __launch_bounds__(kBlock) void k_name_count(const Rec16 *__restrict__ s, u32 n, u32 chunk, u32 *counts) {
+  __shared__ u32 tmp[kWaves];
+  const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
+  u32 c = 0;
+  for (u32 i = begin + threadIdx.x; i < end; i += kBlock) {
+    const Rec16 cur = s[i];
+    bool f = true;
+    if (i > 0) { const Rec16 prev = s[i - 1]; f = key_neq(cur, prev); }
+    c += f ? 1u : 0u;
+  }
+  c = wave_reduce(c);
+  if (lane_id() == 0) tmp[wave_id()] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) { u32 t = 0; for (int i = 0; i < kWaves; i++) t += tmp[i]; counts[blockIdx.x] = t; }
+}
+__global__ __launch_bounds__(kBlock) void k_name_assign(const Rec16 *__restrict__ s, u32 n, u32 chunk,
+                                                       const u32 *__restrict__ base_excl, u32 m0,
+                                                       u32 *__restrict__ R) {
+  __shared__ u32 tmp[kWaves];
+  const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
+  u32 running = base_excl[blockIdx.x];
+  constexpr u32 kTile = kBlock * kNameIPT;
+  for (u32 tile = begin; tile < end; tile += kTile) {
+    const u32 i0 = tile + threadIdx.x * kNameIPT;
+    Rec16 prev;
+    bool havePrev = false;
+    if (i0 > 0 && i0 < end) { prev = s[i0 - 1]; havePrev = true; }
+    u32 f[kNameIPT], pos[kNameIPT];
+    u32 local = 0;
+#pragma unroll
+    for (int j = 0; j < kNameIPT; j++) {
+      f[j] = 0; pos[j] = 0;
+      if (i0 + j < end) {
+        const Rec16 cur = s[i0 + j];
+        f[j] = (!havePrev || key_neq(cur, prev)) ? 1u : 0u;
+        pos[j] = cur.pos; prev = cur; havePrev = true;
+      }
+      local += f[j];
+    }
+    u32 tot;
+    u32 name = running + block_excl_scan<kWaves>(local, tmp, tot);
+#pragma unroll
+    for (int j = 0; j < kNameIPT; j++) {
+      if (i0 + j < end) { name += f[j]; R[slot_of(pos[j], m0)] = name; }
+    }
+    running += tot;
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_assign_unique(const Rec16 *__restrict__ s, u32 n, u32 m0,
+                                                         u32 *__restrict__ sa12, u32 *__restrict__ rank) {
+  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const u32 sl = slot_of(s[i].pos, m0);
+    sa12[i] = sl;
+    rank[sl] = i + 1;
+  }
+}
+__global__ void k_base1(u32 *out_sa, u32 *out_rank) {
+  if (threadIdx.x == 0) { if (out_sa) out_sa[0] = 0; if (out_rank) out_rank[0] = 1; }
+}
+__global__ void k_zero_tail(u32 *p, u32 from, u32 count) {
+  if (threadIdx.x < count) p[from + threadIdx.x] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Merge tuples.  Built in slot order with coalesced reads of S and rank (thread g owns text
+// positions 3g..3g+2), then gathered into SA12 order — one 16-byte gather per sample suffix
+// instead of the 4-6 scattered reads per output of lib.rs:136-162.
+// rank = 1-based rank of sample suffixes in slot order, with >= 3 zero words after rank[m02-1].
+// ---------------------------------------------------------------------------------------------
+template <class Sym>
+__global__ __launch_bounds__(kBlock) void k_build_tuples(Sym S, u32 m, u32 m0, u32 m02,
+                                                        const u32 *__restrict__ rank, Tup12 *__restrict__ tslot) {
+  const bool dummy = (m % 3) == 1;
+  for (u32 g = blockIdx.x * kBlock + threadIdx.x; g < m0; g += gridDim.x * kBlock) {
+    const u32 j = 3 * g;
+    const u32 s0 = S.get(j), s1 = S.get(j + 1), s2 = S.get(j + 2), s3 = S.get(j + 3);
+    // mod-1 sample at j+1 (slot g); exists for all g < m0 (dummy when j+1 == m)
+    Tup12 a;
+    a.pos = j + 1; a.c0 = s1; a.cx = s0;
+    a.r = (j + 2 < m) ? rank[m0 + g] : 0u;                       // rank of suffix j+2 (mod 2)
+    tslot[g] = a;
+    if (j + 2 < m) {                                            // mod-2 sample at j+2 (slot m0+g)
+      Tup12 c;
+      c.pos = j + 2; c.c0 = s2; c.cx = s3;
+      const bool has = (j + 4 < m) || (dummy && j + 4 == m);    // suffix j+4 is mod 1, slot g+1
+      c.r = has ? rank[g + 1] : 0u;
+      tslot[m0 + g] = c;
+    }
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_gather_tuples(const Tup12 *__restrict__ tslot,
+                                                         const u32 *__restrict__ sa12, u32 n,
+                                                         Tup12 *__restrict__ out) {
+  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) out[i] = tslot[sa12[i]];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Step 2 (lib.rs:118-125): order-preserving selection of the mod-1 entries of SA12; each yields
+// the mod-0 suffix one position to the left, already ordered by rank of suffix j+1.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool is_mod1(u32 pos) { return pos % 3 == 1; }
+
+__global__ __launch_bounds__(kBlock) void k_mod0_count(const Tup12 *__restrict__ t, u32 n, u32 chunk, u32 *counts) {
+  __shared__ u32 tmp[kWaves];
+  const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
+  u32 c = 0;
+  for (u32 i = begin + threadIdx.x; i < end; i += kBlock) c += is_mod1(t[i].pos) ? 1u : 0u;
+  c = wave_reduce(c);
+  if (lane_id() == 0) tmp[wave_id()] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) { u32 s = 0; for (int i = 0; i < kWaves; i++) s += tmp[i]; counts[blockIdx.x] = s; }
+}
+__global__ __launch_bounds__(kBlock) void k_mod0_write(const Tup12 *__restrict__ t, u32 n, u32 chunk,
+                                                      const u32 *__restrict__ base_excl, Tup0 *__restrict__ out) {
+  __shared__ u32 tmp[kWaves];
+  const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
+  u32 running = base_excl[blockIdx.x];
+  for (u32 tile = begin; tile < end; tile += kBlock) {
+    const u32 i = tile + threadIdx.x;
+    Tup12 a; bool f = false;
+    if (i < end) { a = t[i]; f = is_mod1(a.pos); }
+    u32 tot;
+    const u32 ex = block_excl_scan<kWaves>(f ? 1u : 0u, tmp, tot);
+    if (f) {
+      Tup0 z;
+      z.pos = a.pos - 1; z.c0 = a.cx; z.c1 = a.c0; z.r1 = i + 1; z.r2 = a.r;
+      out[running + ex] = z;
+    }
+    running += tot;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Step 3 (lib.rs:131-192): merge of SA12 and SA0 as a merge-path merge.
+// Comparator = leq2 / leq3 of lib.rs:3-11 in Kärkkäinen–Sanders argument order (the reference's
+// leq3 parameter list is scrambled, lib.rs:9 vs :154-161).  Suffixes are distinct, so < == <=.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool sample_before(const Tup12 &a, const Tup0 &z) {
+  if (is_mod1(a.pos)) return (a.c0 < z.c0) || (a.c0 == z.c0 && a.r <= z.r1);               // leq2
+  return (a.c0 < z.c0) || (a.c0 == z.c0 && ((a.cx < z.c1) || (a.cx == z.c1 && a.r <= z.r2))); // leq3
+}
+
+constexpr int kMergeVT = 4;
+constexpr int kMergeTile = kBlock * kMergeVT;
+
+__global__ __launch_bounds__(kBlock) void k_merge_partition(const Tup12 *__restrict__ A, u32 nA,
+                                                           const Tup0 *__restrict__ B, u32 nB, u32 ntiles,
+                                                           u32 *__restrict__ part /*[ntiles+1]*/) {
+  const u32 t = blockIdx.x * kBlock + threadIdx.x;
+  if (t > ntiles) return;
+  const u32 total = nA + nB;
+  const u32 diag = min(t * (u32)kMergeTile, total);
+  u32 lo = diag > nB ? diag - nB : 0u, hi = min(diag, nA);
+  while (lo < hi) {
+    const u32 mid = (lo + hi) >> 1;
+    if (sample_before(A[mid], B[diag - 1 - mid])) lo = mid + 1; else hi = mid;
+  }
+  part[t] = lo;
+}
+
+// out_sa[k] = text position of the k-th smallest suffix (coalesced); out_rank[pos] = k+1 (the
+// inverse, which the parent level needs in slot order — fused here instead of a separate
+// R[SA12[i]] = i+1 pass, lib.rs:106-108).
+__global__ __launch_bounds__(kBlock) void k_merge(const Tup12 *__restrict__ A, u32 nA, const Tup0 *__restrict__ B,
+                                                 u32 nB, const u32 *__restrict__ part, u32 *__restrict__ out_sa,
+                                                 u32 *__restrict__ out_rank) {
+  __shared__ Tup12 sa[kMergeTile];
+  __shared__ Tup0 sb[kMergeTile];
+  const u32 total = nA + nB;
+  const u32 d0 = blockIdx.x * (u32)kMergeTile;
+  const u32 d1 = min(d0 + (u32)kMergeTile, total);
+  const u32 a0 = part[blockIdx.x], a1 = part[blockIdx.x + 1];
+  const u32 b0 = d0 - a0, b1 = d1 - a1;
+  const u32 na = a1 - a0, nb = b1 - b0;
+  for (u32 i = threadIdx.x; i < na; i += kBlock) sa[i] = A[a0 + i];
+  for (u32 i = threadIdx.x; i < nb; i += kBlock) sb[i] = B[b0 + i];
+  __syncthreads();
+  const u32 dl = min(threadIdx.x * (u32)kMergeVT, na + nb);
+  u32 lo = dl > nb ? dl - nb : 0u, hi = min(dl, na);
+  while (lo < hi) {
+    const u32 mid = (lo + hi) >> 1;
+    if (sample_before(sa[mid], sb[dl - 1 - mid])) lo = mid + 1; else hi = mid;
+  }
+  u32 ai = lo, bi = dl - lo;
+#pragma unroll
+  for (int v = 0; v < kMergeVT; v++) {
+    const u32 k = dl + v;
+    if (k >= na + nb) break;
+    const bool takeA = (bi >= nb) || (ai < na && sample_before(sa[ai], sb[bi]));
+    const u32 pos = takeA ? sa[ai].pos : sb[bi].pos;
+    ai += takeA ? 1u : 0u; bi += takeA ? 0u : 1u;
+    if (out_sa) out_sa[d0 + k] = pos;
+    if (out_rank) out_rank[pos] = d0 + k + 1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Synthetic text generator — bit-identical twin of oracle_gen_bytes.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 splitmix64(u64 x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__device__ __forceinline__ uint8_t gen_byte(u64 gi, u64 seed, int kind) {
+  if (kind == 0) return (uint8_t)(splitmix64(seed + (gi >> 3)) >> (8 * (gi & 7)));
+  const u32 code = (u32)(splitmix64(seed + (gi >> 5)) >> (2 * (gi & 31))) & 3u;
+  return code == 0 ? 'A' : code == 1 ? 'C' : code == 2 ? 'G' : 'T';
+}
+// t[i] = byte (off+i) of the stream; one thread per 8 output bytes, 8-byte stores
+__global__ __launch_bounds__(kBlock) void k_generate(uint8_t *t, u64 n, u64 seed, int kind, u64 off) {
+  const u64 nw = (n + 7) / 8;
+  for (u64 wi = blockIdx.x * (u64)kBlock + threadIdx.x; wi < nw; wi += (u64)gridDim.x * kBlock) {
+    u64 v = 0;
+    if (kind == 0 && (off & 7) == 0) {
+      v = splitmix64(seed + ((off + wi * 8) >> 3));
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; j++) v |= (u64)gen_byte(off + wi * 8 + j, seed, kind) << (8 * j);
+    }
+    if (wi * 8 + 8 <= n) *reinterpret_cast<u64 *>(t + wi * 8) = v;
+    else for (u64 j = wi * 8; j < n; j++) t[j] = (uint8_t)(v >> (8 * (j & 7)));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GPU verifier = sufcheck() of crates/cdivsufsort/c-sources/utils.c:160-241 restated as parallel
+// passes (equivalently sacabase::verify, sacabase/src/lib.rs:127-149).  With ISA = inverse of SA:
+//   (1) range + permutation: every SA[i] in [0,n) and ISA is a bijection        (-2)
+//   (2) first characters non-decreasing                                          (-3)
+//   (3) for T[SA[i]] == T[SA[i+1]]: rank of suffix SA[i]+1 < rank of suffix SA[i+1]+1, the end
+//       of text ranking lowest                                                   (-4)
+// (1)-(3) hold iff SA is the suffix array.  err receives the smallest failing code seen
+// (as in sufcheck, -2 is reported before -3 before -4).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_check_fill(const u32 *__restrict__ sa, u32 n, u32 *__restrict__ isa,
+                                                      int *err) {
+  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const u32 p = sa[i];
+    if (p >= n) { atomicMax(err, 3); continue; }   // code = -(5 - v): 3 -> -2
+    isa[p] = i + 1;
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_check_order(const uint8_t *__restrict__ t, const u32 *__restrict__ sa,
+                                                       const u32 *__restrict__ isa, u32 n, int *err) {
+  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const u32 p = sa[i];
+    if (p >= n) continue;
+    if (isa[p] != i + 1) { atomicMax(err, 3); continue; }   // not a permutation
+    if (i + 1 >= n) continue;
+    const u32 q = sa[i + 1];
+    if (q >= n) continue;
+    const uint8_t cp = t[p], cq = t[q];
+    if (cp > cq) { atomicMax(err, 2); continue; }           // -3
+    if (cp == cq) {
+      const u32 rp = (p + 1 < n) ? isa[p + 1] : 0u;
+      const u32 rq = (q + 1 < n) ? isa[q + 1] : 0u;
+      if (!(rp < rq)) atomicMax(err, 1);                    // -4
+    }
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_checksum(const u32 *__restrict__ sa, u32 n, u64 *out) {
+  u64 acc = 0;
+  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+    acc += splitmix64(((u64)i << 32) | sa[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane_id() == 0) atomicAdd((unsigned long long *)out, (unsigned long long)acc);
+}
+__global__ __launch_bounds__(kBlock) void k_widen(const u32 *__restrict__ in, int64_t *__restrict__ out, u32 n) {
+  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) out[i] = (int64_t)in[i];
+}
+
+}  // namespace dc3

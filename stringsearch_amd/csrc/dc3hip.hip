@@ -1,0 +1,690 @@
+// dc3hip.hip — host driver + C ABI of libdc3hip.so (see include/dc3hip.h).
+//
+// Host side of the DC3/Skew recursion of crates/dc3/src/lib.rs:44-193, re-designed for MI355X:
+//   * one context = one HIP stream + one device arena (no hipMalloc inside the recursion; the
+//     reference allocates 4 Vecs per level, lib.rs:50-57);
+//   * every level is a fixed sequence of streaming kernels (dc3_kernels.cuh); the only host
+//     round trip per level is the 4-byte "number of distinct names" read-back that decides
+//     lib.rs:103 (recurse or not);
+//   * no CPU fallback of any kind: if HIP fails the call fails (-3).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/dc3hip.h"
+#include "dc3_kernels.cuh"
+
+using namespace dc3;
+
+#define DC3HIP_VERSION_STR "dc3hip 0.1.0 (gfx950, HIP)"
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static void set_err(const char *fmt, ...) {
+  va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+}
+enum { E_OK = 0, E_ARGS = -1, E_ALLOC = -2, E_HIP = -3, E_TOOBIG = -4 };
+
+#define HIPC(expr)                                                                              \
+  do {                                                                                          \
+    hipError_t e__ = (expr);                                                                    \
+    if (e__ != hipSuccess) {                                                                    \
+      set_err("HIP error %d (%s) at %s:%d: %s", (int)e__, hipGetErrorString(e__), __FILE__,     \
+              __LINE__, #expr);                                                                 \
+      return (e__ == hipErrorOutOfMemory) ? E_ALLOC : E_HIP;                                    \
+    }                                                                                           \
+  } while (0)
+#define RC(expr) do { int rc__ = (expr); if (rc__ != E_OK) return rc__; } while (0)
+#define KCHECK() HIPC(hipGetLastError())
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+struct PhaseMark { int phase; hipEvent_t a, b; int64_t elems; };
+
+struct dc3hip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int64_t max_n = 0, n = 0;
+  bool built = false;
+  uint8_t *d_text = nullptr;   // max_n + 64 bytes
+  u32 *d_sa = nullptr;         // max_n + 16 words
+  unsigned char *arena = nullptr;
+  size_t arena_bytes = 0, arena_off = 0, arena_peak = 0;
+  // small device scratch
+  u32 *d_present = nullptr;    // [256]
+  uint16_t *d_code = nullptr;  // [256]
+  u32 *d_words = nullptr;      // [64] misc totals / error words
+  u32 *h_words = nullptr;      // pinned mirror
+  // profiling
+  bool profile = true;
+  std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
+  std::vector<PhaseMark> marks;
+  hipEvent_t ev_build_a = nullptr, ev_build_b = nullptr;
+  dc3hip_stats stats;
+  int num_cu = 256;
+};
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct ArenaMark { size_t off; };
+static ArenaMark arena_mark(dc3hip_ctx *c) { return ArenaMark{c->arena_off}; }
+static void arena_release(dc3hip_ctx *c, ArenaMark m) { c->arena_off = m.off; }
+template <class T>
+static int arena_alloc(dc3hip_ctx *c, size_t count, T **out) {
+  const size_t bytes = align_up(count * sizeof(T), 256);
+  if (c->arena_off + bytes > c->arena_bytes) {
+    set_err("device work arena exhausted: need %zu more bytes (arena %zu, used %zu)", bytes, c->arena_bytes,
+            c->arena_off);
+    return E_ALLOC;
+  }
+  *out = reinterpret_cast<T *>(c->arena + c->arena_off);
+  c->arena_off += bytes;
+  c->arena_peak = std::max(c->arena_peak, c->arena_off);
+  return E_OK;
+}
+
+// Upper bound of the arena a build of n bytes can use (see DESIGN.md "Memory plan"):
+// a level of length m holds 3 index arrays of m02 (+pad) while its child runs and at most
+// 2 record arrays (16 B) or 2 tuple arrays (16 B) + 2 mod-0 tuple arrays (20 B) at its own peak.
+static size_t arena_requirement(int64_t n) {
+  size_t total = 0, held = 0;
+  int64_t m = n;
+  for (int lvl = 0; lvl < DC3HIP_MAX_LEVELS && m >= 2; lvl++) {
+    const int64_t m0 = (m + 2) / 3, m02 = m0 + m / 3;
+    const size_t keep = 3 * align_up((size_t)(m02 + 16) * 4, 256);
+    const size_t recs = 2 * align_up((size_t)m02 * 16, 256) + 2 * align_up((size_t)4 * 4096 * 256, 256);
+    const size_t tups = 2 * align_up((size_t)m02 * 16, 256) + 2 * align_up((size_t)m0 * 20, 256) +
+                        align_up((size_t)(m / 1024 + 16) * 4, 256);
+    total = std::max(total, held + keep + std::max(recs, tups) + (1u << 20));
+    held += keep;
+    m = m02;
+  }
+  return total + (8u << 20);
+}
+
+// ---------------------------------------------------------------------------------------------
+// profiling helpers
+// ---------------------------------------------------------------------------------------------
+static hipEvent_t get_event(dc3hip_ctx *c) {
+  if (c->ev_used == c->ev_pool.size()) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    c->ev_pool.push_back(e);
+  }
+  return c->ev_pool[c->ev_used++];
+}
+struct PhaseScope {
+  dc3hip_ctx *c; size_t idx; bool on;
+  PhaseScope(dc3hip_ctx *ctx, int phase, int64_t elems = 0) : c(ctx), idx(0), on(ctx->profile) {
+    if (!on) return;
+    PhaseMark m; m.phase = phase; m.a = get_event(c); m.b = get_event(c); m.elems = elems;
+    if (!m.a || !m.b) { on = false; return; }
+    (void)hipEventRecord(m.a, c->stream);
+    idx = c->marks.size(); c->marks.push_back(m);
+  }
+  ~PhaseScope() { if (on) (void)hipEventRecord(c->marks[idx].b, c->stream); }
+};
+
+static inline u32 bits_of(u64 v) { u32 b = 0; while (v) { b++; v >>= 1; } return b ? b : 1; }
+static inline int grid_for(dc3hip_ctx *c, u64 work_items, int per_block = kBlock) {
+  u64 g = (work_items + per_block - 1) / per_block;
+  const u64 cap = (u64)c->num_cu * 8;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ---------------------------------------------------------------------------------------------
+// chunking shared by the up-/down-sweep style kernels
+// ---------------------------------------------------------------------------------------------
+struct Chunking { u32 chunk, nchunks; };
+static Chunking make_chunks(dc3hip_ctx *c, u32 n, u32 tile) {
+  const u32 target_blocks = (u32)c->num_cu * 8;
+  u32 chunk = (n + target_blocks - 1) / target_blocks;
+  chunk = (chunk + tile - 1) / tile * tile;
+  if (chunk < tile) chunk = tile;
+  Chunking k; k.chunk = chunk; k.nchunks = (n + chunk - 1) / chunk;
+  if (k.nchunks == 0) k.nchunks = 1;
+  return k;
+}
+
+// ---------------------------------------------------------------------------------------------
+// stable LSD radix sort over `nbytes` key bytes (lib.rs:15-39 per digit)
+// ---------------------------------------------------------------------------------------------
+template <class Rec> struct SortCfg;
+template <> struct SortCfg<Rec16> { static constexpr int IPT = 16; typedef Rec16Byte Dig; };
+template <> struct SortCfg<Tup0>  { static constexpr int IPT = 12; typedef Tup0Byte Dig; };
+
+template <class Rec>
+static int radix_sort(dc3hip_ctx *c, Rec *a, Rec *b, u32 n, u32 nbytes, Rec **result, int ph_up, int ph_scan,
+                      int ph_down) {
+  typedef typename SortCfg<Rec>::Dig Dig;
+  constexpr int IPT = SortCfg<Rec>::IPT;
+  constexpr int kTile = kBlock * IPT;
+  const size_t smem = DownsweepSmem<Rec, IPT>::kBytes;
+  static thread_local bool attr_set[16] = {false};
+  auto kern = k_rs_downsweep<Rec, Dig, IPT>;
+  if (!attr_set[c->device & 15]) {
+    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)smem));
+    attr_set[c->device & 15] = true;
+  }
+  const Chunking ck = make_chunks(c, n, kTile);
+  const ArenaMark mk = arena_mark(c);
+  u32 *table = nullptr;
+  RC(arena_alloc(c, (size_t)256 * ck.nchunks, &table));
+  Rec *src = a, *dst = b;
+  for (u32 p = 0; p < nbytes; p++) {
+    Dig dig; dig.p = p;
+    {
+      PhaseScope ps(c, ph_up, n);
+      hipLaunchKernelGGL((k_rs_upsweep<Rec, Dig>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, src, n, ck.chunk,
+                         ck.nchunks, dig, table);
+      KCHECK();
+    }
+    {
+      PhaseScope ps(c, ph_scan, 256 * ck.nchunks);
+      hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, table, 256u * ck.nchunks,
+                         (u32 *)nullptr);
+      KCHECK();
+    }
+    {
+      PhaseScope ps(c, ph_down, n);
+      hipLaunchKernelGGL(kern, dim3(ck.nchunks), dim3(kBlock), smem, c->stream, src, dst, n, ck.chunk, ck.nchunks,
+                         dig, table);
+      KCHECK();
+    }
+    std::swap(src, dst);
+  }
+  arena_release(c, mk);
+  *result = src;
+  return E_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// one DC3 level (lib.rs:44-193) on the device.
+//   S: symbols in 1..K with zero tail, m >= 2
+//   out_sa  : [m]      k-th smallest suffix -> position   (may be null)
+//   out_rank: [m+3..]  position -> 1-based rank, caller zeroes the tail (may be null)
+// ---------------------------------------------------------------------------------------------
+template <class Sym>
+static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_rank, int depth) {
+  if (depth >= DC3HIP_MAX_LEVELS) { set_err("recursion deeper than %d levels", DC3HIP_MAX_LEVELS); return E_HIP; }
+  if (m == 1) {   // single suffix (only reachable as the child of a 2- or 3-symbol level)
+    c->stats.level_n[depth] = 1; c->stats.level_K[depth] = (int64_t)K; c->stats.levels = depth + 1;
+    hipLaunchKernelGGL(k_base1, dim3(1), dim3(64), 0, c->stream, out_sa, out_rank);
+    KCHECK();
+    return E_OK;
+  }
+  const u32 m0 = (m + 2) / 3, m1 = (m + 1) / 3, m2 = m / 3, m02 = m0 + m2;   // lib.rs:45-48
+  c->stats.level_n[depth] = m; c->stats.level_K[depth] = (int64_t)K; c->stats.levels = depth + 1;
+  const ArenaMark mk0 = arena_mark(c);
+
+  u32 *rank12 = nullptr, *sa12 = nullptr, *R = nullptr;
+  RC(arena_alloc(c, (size_t)m02 + 16, &rank12));
+  RC(arena_alloc(c, (size_t)m02 + 16, &sa12));
+  RC(arena_alloc(c, (size_t)m02 + 16, &R));
+
+  const u64 B = K + 1;
+  const bool direct = (B * B * B) <= 0x7fffffffull;
+  c->stats.level_sorted[depth] = direct ? 0 : 1;
+  if (direct) {
+    // names = packed triples (order-preserving); always recurse (distinctness unknown)
+    {
+      PhaseScope ps(c, DC3HIP_PH_NAME_DIRECT, m02);
+      hipLaunchKernelGGL((k_name_direct<Sym>), dim3(grid_for(c, m0)), dim3(kBlock), 0, c->stream, S, m, m0, m02,
+                         (u32)B, R);
+      KCHECK();
+    }
+    SymU32 RS; RS.s = R; RS.m = m02;
+    RC(dc3_level<SymU32>(c, RS, m02, B * B * B, sa12, rank12, depth + 1));
+  } else {
+    const u32 b = bits_of(K);
+    const u32 nbytes = (3 * b + 7) / 8;
+    const ArenaMark mk1 = arena_mark(c);
+    Rec16 *recA = nullptr, *recB = nullptr, *sorted = nullptr;
+    RC(arena_alloc(c, (size_t)m02, &recA));
+    RC(arena_alloc(c, (size_t)m02, &recB));
+    {
+      PhaseScope ps(c, DC3HIP_PH_PACK, m02);
+      hipLaunchKernelGGL((k_pack_triples<Sym>), dim3(grid_for(c, m0)), dim3(kBlock), 0, c->stream, S, m, m0, m02, b,
+                         recA);
+      KCHECK();
+    }
+    RC(radix_sort<Rec16>(c, recA, recB, m02, nbytes, &sorted, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN,
+                         DC3HIP_PH_SORT12_DOWN));
+    // naming
+    const Chunking ck = make_chunks(c, m02, kBlock * kNameIPT);
+    u32 *counts = nullptr;
+    RC(arena_alloc(c, (size_t)ck.nchunks + 16, &counts));
+    u32 names = 0;
+    {
+      PhaseScope ps(c, DC3HIP_PH_NAMING, m02);
+      hipLaunchKernelGGL(k_name_count, dim3(ck.nchunks), dim3(kBlock), 0, c->stream, sorted, m02, ck.chunk, counts);
+      KCHECK();
+      hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, counts, ck.nchunks, c->d_words);
+      KCHECK();
+      HIPC(hipMemcpyAsync(c->h_words, c->d_words, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPC(hipStreamSynchronize(c->stream));     // the lib.rs:103 decision needs the name count
+    names = c->h_words[0];
+    if (names == m02) {
+      // all names unique (lib.rs:109-113): the sorted order IS the suffix array of the sample
+      PhaseScope ps(c, DC3HIP_PH_RANKS, m02);
+      hipLaunchKernelGGL(k_assign_unique, dim3(grid_for(c, m02)), dim3(kBlock), 0, c->stream, sorted, m02, m0, sa12,
+                         rank12);
+      KCHECK();
+      arena_release(c, mk1);
+    } else {
+      {
+        PhaseScope ps(c, DC3HIP_PH_NAMING, m02);
+        hipLaunchKernelGGL(k_name_assign, dim3(ck.nchunks), dim3(kBlock), 0, c->stream, sorted, m02, ck.chunk, counts,
+                           m0, R);
+        KCHECK();
+        hipLaunchKernelGGL(k_zero_tail, dim3(1), dim3(64), 0, c->stream, R, m02, 8u);
+        KCHECK();
+      }
+      arena_release(c, mk1);
+      SymU32 RS; RS.s = R; RS.m = m02;
+      RC(dc3_level<SymU32>(c, RS, m02, names, sa12, rank12, depth + 1));   // lib.rs:104
+    }
+  }
+  {
+    PhaseScope ps(c, DC3HIP_PH_OTHER);
+    hipLaunchKernelGGL(k_zero_tail, dim3(1), dim3(64), 0, c->stream, rank12, m02, 8u);
+    KCHECK();
+  }
+
+  // ---- Step 2 + 3: tuples, mod-0 order, merge -------------------------------------------------
+  Tup12 *tslot = nullptr, *t12 = nullptr;
+  RC(arena_alloc(c, (size_t)m02, &tslot));
+  RC(arena_alloc(c, (size_t)m02, &t12));
+  {
+    PhaseScope ps(c, DC3HIP_PH_TUPLES, m02);
+    hipLaunchKernelGGL((k_build_tuples<Sym>), dim3(grid_for(c, m0)), dim3(kBlock), 0, c->stream, S, m, m0, m02,
+                       rank12, tslot);
+    KCHECK();
+    hipLaunchKernelGGL(k_gather_tuples, dim3(grid_for(c, m02)), dim3(kBlock), 0, c->stream, tslot, sa12, m02, t12);
+    KCHECK();
+  }
+  Tup0 *z0 = nullptr, *z1 = nullptr, *zs = nullptr;
+  RC(arena_alloc(c, (size_t)m0, &z0));
+  RC(arena_alloc(c, (size_t)m0, &z1));
+  {
+    const Chunking ck = make_chunks(c, m02, kBlock);
+    u32 *counts = nullptr;
+    RC(arena_alloc(c, (size_t)ck.nchunks + 16, &counts));
+    PhaseScope ps(c, DC3HIP_PH_COMPACT, m02);
+    hipLaunchKernelGGL(k_mod0_count, dim3(ck.nchunks), dim3(kBlock), 0, c->stream, t12, m02, ck.chunk, counts);
+    KCHECK();
+    hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, counts, ck.nchunks, (u32 *)nullptr);
+    KCHECK();
+    hipLaunchKernelGGL(k_mod0_write, dim3(ck.nchunks), dim3(kBlock), 0, c->stream, t12, m02, ck.chunk, counts, z0);
+    KCHECK();
+  }
+  RC(radix_sort<Tup0>(c, z0, z1, m0, (bits_of(K) + 7) / 8, &zs, DC3HIP_PH_SORT0, DC3HIP_PH_SORT0, DC3HIP_PH_SORT0));
+  {
+    const u32 dskip = m0 - m1;                  // lib.rs:133: skip the dummy, which sorts first
+    const u32 nA = m02 - dskip, nB = m0;
+    const u32 ntiles = (m + kMergeTile - 1) / kMergeTile;
+    u32 *part = nullptr;
+    RC(arena_alloc(c, (size_t)ntiles + 16, &part));
+    PhaseScope ps(c, DC3HIP_PH_MERGE, m);
+    hipLaunchKernelGGL(k_merge_partition, dim3((ntiles + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
+                       t12 + dskip, nA, zs, nB, ntiles, part);
+    KCHECK();
+    hipLaunchKernelGGL(k_merge, dim3(ntiles), dim3(kBlock), 0, c->stream, t12 + dskip, nA, zs, nB, part, out_sa,
+                       out_rank);
+    KCHECK();
+  }
+  arena_release(c, mk0);
+  return E_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// build: level 0 = bytes through the dense code table
+// ---------------------------------------------------------------------------------------------
+static int ctx_build(dc3hip_ctx *c) {
+  const int64_t n = c->n;
+  c->built = false;
+  c->arena_off = 0; c->arena_peak = 0;
+  c->ev_used = 0; c->marks.clear();
+  memset(&c->stats, 0, sizeof(c->stats));
+  c->stats.struct_size = (int32_t)sizeof(dc3hip_stats);
+  c->stats.arena_bytes = (int64_t)c->arena_bytes;
+  if (n < 0) return E_ARGS;
+  HIPC(hipSetDevice(c->device));
+  if (c->profile) HIPC(hipEventRecord(c->ev_build_a, c->stream));
+  if (n == 1) {
+    HIPC(hipMemsetAsync(c->d_sa, 0, 4, c->stream));
+  } else if (n >= 2) {
+    u32 sigma = 0;
+    {
+      PhaseScope ps(c, DC3HIP_PH_ALPHABET, n);
+      HIPC(hipMemsetAsync(c->d_present, 0, 256 * sizeof(u32), c->stream));
+      hipLaunchKernelGGL(k_byte_presence, dim3(grid_for(c, (u64)n / 16 + 1)), dim3(kBlock), 0, c->stream, c->d_text,
+                         (u32)n, c->d_present);
+      KCHECK();
+      hipLaunchKernelGGL(k_make_codes, dim3(1), dim3(kBlock), 0, c->stream, c->d_present, c->d_code, c->d_words + 1);
+      KCHECK();
+      HIPC(hipMemcpyAsync(c->h_words + 1, c->d_words + 1, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPC(hipStreamSynchronize(c->stream));
+    sigma = c->h_words[1];
+    if (sigma < 1 || sigma > 256) { set_err("internal: alphabet size %u", sigma); return E_HIP; }
+    SymU8 S; S.t = c->d_text; S.code = c->d_code; S.m = (u32)n;
+    RC(dc3_level<SymU8>(c, S, (u32)n, sigma, c->d_sa, nullptr, 0));
+  }
+  if (c->profile) HIPC(hipEventRecord(c->ev_build_b, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  c->stats.arena_peak = (int64_t)c->arena_peak;
+  if (c->profile) {
+    float ms = 0;
+    HIPC(hipEventElapsedTime(&ms, c->ev_build_a, c->ev_build_b));
+    c->stats.build_ms = ms;
+    for (const PhaseMark &m : c->marks) {
+      float t = 0;
+      if (hipEventElapsedTime(&t, m.a, m.b) != hipSuccess) continue;
+      c->stats.phase_ms[m.phase] += t;
+      c->stats.phase_launches[m.phase] += 1;
+      if (m.phase == DC3HIP_PH_SORT12_DOWN) {
+        c->stats.downsweep16_ms += t; c->stats.downsweep16_launches += 1; c->stats.downsweep16_elems += m.elems;
+      }
+    }
+  }
+  c->built = true;
+  return E_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+const char *dc3hip_version(void) { return DC3HIP_VERSION_STR; }
+const char *dc3hip_last_error(void) { return g_err; }
+
+int32_t dc3hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { set_err("hipGetDeviceCount failed"); return E_HIP; }
+  return n;
+}
+
+int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) {
+  if (!out || max_n < 0) { set_err("dc3hip_ctx_create: invalid arguments"); return E_ARGS; }
+  *out = nullptr;
+  if (max_n > DC3HIP_MAX_N) { set_err("n=%lld exceeds DC3HIP_MAX_N", (long long)max_n); return E_TOOBIG; }
+  int ndev = 0;
+  HIPC(hipGetDeviceCount(&ndev));
+  if (ndev <= 0) { set_err("no HIP device visible (no CPU fallback exists)"); return E_HIP; }
+  if (device < 0) HIPC(hipGetDevice(&device));
+  if (device >= ndev) { set_err("device %d out of range (%d devices)", device, ndev); return E_ARGS; }
+  dc3hip_ctx *c = new (std::nothrow) dc3hip_ctx();
+  if (!c) { set_err("host allocation failed"); return E_ALLOC; }
+  c->device = device; c->max_n = max_n;
+  memset(&c->stats, 0, sizeof(c->stats));
+  const char *prof = getenv("DC3HIP_PROFILE");
+  c->profile = !(prof && prof[0] == '0');
+  int rc = [&]() -> int {
+    HIPC(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPC(hipGetDeviceProperties(&prop, device));
+    c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIPC(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPC(hipMalloc(&c->d_text, (size_t)max_n + 64));
+    HIPC(hipMalloc(&c->d_sa, ((size_t)max_n + 16) * sizeof(u32)));
+    c->arena_bytes = arena_requirement(max_n);
+    HIPC(hipMalloc(&c->arena, c->arena_bytes));
+    HIPC(hipMalloc(&c->d_present, 256 * sizeof(u32)));
+    HIPC(hipMalloc(&c->d_code, 256 * sizeof(uint16_t)));
+    HIPC(hipMalloc(&c->d_words, 64 * sizeof(u32)));
+    HIPC(hipHostMalloc(&c->h_words, 64 * sizeof(u32), hipHostMallocDefault));
+    HIPC(hipEventCreate(&c->ev_build_a));
+    HIPC(hipEventCreate(&c->ev_build_b));
+    return E_OK;
+  }();
+  if (rc != E_OK) { dc3hip_ctx_destroy(c); return rc; }
+  *out = c;
+  return E_OK;
+}
+
+void dc3hip_ctx_destroy(dc3hip_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+  if (c->ev_build_a) (void)hipEventDestroy(c->ev_build_a);
+  if (c->ev_build_b) (void)hipEventDestroy(c->ev_build_b);
+  if (c->d_text) (void)hipFree(c->d_text);
+  if (c->d_sa) (void)hipFree(c->d_sa);
+  if (c->arena) (void)hipFree(c->arena);
+  if (c->d_present) (void)hipFree(c->d_present);
+  if (c->d_code) (void)hipFree(c->d_code);
+  if (c->d_words) (void)hipFree(c->d_words);
+  if (c->h_words) (void)hipHostFree(c->h_words);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+static int ctx_check_n(dc3hip_ctx *c, int64_t n) {
+  if (!c || n < 0) { set_err("invalid arguments"); return E_ARGS; }
+  if (n > c->max_n) { set_err("n=%lld exceeds the context capacity %lld", (long long)n, (long long)c->max_n); return E_ARGS; }
+  return E_OK;
+}
+
+int32_t dc3hip_ctx_set_text(dc3hip_ctx *c, const uint8_t *T, int64_t n) {
+  RC(ctx_check_n(c, n));
+  if (!T && n > 0) { set_err("T is NULL"); return E_ARGS; }
+  HIPC(hipSetDevice(c->device));
+  if (n > 0) HIPC(hipMemcpyAsync(c->d_text, T, (size_t)n, hipMemcpyDefault, c->stream));
+  HIPC(hipMemsetAsync(c->d_text + n, 0, 64, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  c->n = n; c->built = false;
+  return E_OK;
+}
+
+int32_t dc3hip_ctx_generate(dc3hip_ctx *c, int64_t n, uint64_t seed, int32_t kind) {
+  return dc3hip_ctx_generate_at(c, n, seed, kind, 0);
+}
+
+int32_t dc3hip_ctx_generate_at(dc3hip_ctx *c, int64_t n, uint64_t seed, int32_t kind, int64_t offset) {
+  RC(ctx_check_n(c, n));
+  if (offset < 0) { set_err("negative offset"); return E_ARGS; }
+  if (kind != 0 && kind != 1) { set_err("unknown generator kind %d", kind); return E_ARGS; }
+  HIPC(hipSetDevice(c->device));
+  if (n > 0) {
+    hipLaunchKernelGGL(k_generate, dim3(grid_for(c, (u64)n / 8 + 1)), dim3(kBlock), 0, c->stream, c->d_text, (u64)n,
+                       (u64)seed, (int)kind, (u64)offset);
+    KCHECK();
+  }
+  HIPC(hipMemsetAsync(c->d_text + n, 0, 64, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  c->n = n; c->built = false;
+  return E_OK;
+}
+
+int32_t dc3hip_ctx_build(dc3hip_ctx *c) {
+  if (!c) { set_err("ctx is NULL"); return E_ARGS; }
+  return ctx_build(c);
+}
+
+int32_t dc3hip_ctx_get_sa_i32(dc3hip_ctx *c, int32_t *SA) {
+  if (!c || (!SA && c->n > 0)) { set_err("invalid arguments"); return E_ARGS; }
+  if (!c->built) { set_err("no suffix array built in this context"); return E_ARGS; }
+  HIPC(hipSetDevice(c->device));
+  if (c->n > 0) HIPC(hipMemcpyAsync(SA, c->d_sa, (size_t)c->n * 4, hipMemcpyDefault, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  return E_OK;
+}
+
+int32_t dc3hip_ctx_get_sa_i64(dc3hip_ctx *c, int64_t *SA) {
+  if (!c || (!SA && c->n > 0)) { set_err("invalid arguments"); return E_ARGS; }
+  if (!c->built) { set_err("no suffix array built in this context"); return E_ARGS; }
+  HIPC(hipSetDevice(c->device));
+  if (c->n == 0) return E_OK;
+  // widen on the device in arena-sized pieces, then copy
+  c->arena_off = 0;
+  const size_t piece = std::min<size_t>((size_t)c->n, c->arena_bytes / 8 > 0 ? c->arena_bytes / 8 : 1);
+  int64_t *tmp = reinterpret_cast<int64_t *>(c->arena);
+  for (size_t off = 0; off < (size_t)c->n; off += piece) {
+    const size_t cnt = std::min(piece, (size_t)c->n - off);
+    hipLaunchKernelGGL(k_widen, dim3(grid_for(c, cnt)), dim3(kBlock), 0, c->stream, c->d_sa + off, tmp, (u32)cnt);
+    KCHECK();
+    HIPC(hipMemcpyAsync(SA + off, tmp, cnt * 8, hipMemcpyDefault, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+  }
+  return E_OK;
+}
+
+int32_t dc3hip_ctx_get_text(dc3hip_ctx *c, uint8_t *T) {
+  if (!c || (!T && c->n > 0)) { set_err("invalid arguments"); return E_ARGS; }
+  HIPC(hipSetDevice(c->device));
+  if (c->n > 0) HIPC(hipMemcpyAsync(T, c->d_text, (size_t)c->n, hipMemcpyDefault, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  return E_OK;
+}
+
+static int ctx_sufcheck(dc3hip_ctx *c, const u32 *d_sa) {
+  // utils.c:160-241 as parallel passes; isa lives in the arena
+  const int64_t n = c->n;
+  if (n == 0) return 0;
+  HIPC(hipSetDevice(c->device));
+  c->arena_off = 0;
+  u32 *isa = nullptr;
+  RC(arena_alloc(c, (size_t)n + 16, &isa));
+  int *err = reinterpret_cast<int *>(c->d_words + 8);
+  HIPC(hipMemsetAsync(err, 0, sizeof(int), c->stream));
+  hipLaunchKernelGGL(k_check_fill, dim3(grid_for(c, n)), dim3(kBlock), 0, c->stream, d_sa, (u32)n, isa, err);
+  KCHECK();
+  hipLaunchKernelGGL(k_check_order, dim3(grid_for(c, n)), dim3(kBlock), 0, c->stream, c->d_text, d_sa, isa, (u32)n,
+                     err);
+  KCHECK();
+  HIPC(hipMemcpyAsync(c->h_words + 8, err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  const int v = (int)c->h_words[8];
+  c->arena_off = 0;
+  return v ? -(5 - v) : 0;
+}
+
+int32_t dc3hip_ctx_sufcheck(dc3hip_ctx *c) {
+  if (!c) { set_err("ctx is NULL"); return E_ARGS; }
+  if (!c->built) { set_err("no suffix array built in this context"); return E_ARGS; }
+  return ctx_sufcheck(c, c->d_sa);
+}
+
+int32_t dc3hip_ctx_sa_checksum(dc3hip_ctx *c, uint64_t *out) {
+  if (!c || !out) { set_err("invalid arguments"); return E_ARGS; }
+  if (!c->built) { set_err("no suffix array built in this context"); return E_ARGS; }
+  HIPC(hipSetDevice(c->device));
+  u64 *acc = reinterpret_cast<u64 *>(c->d_words + 16);
+  HIPC(hipMemsetAsync(acc, 0, sizeof(u64), c->stream));
+  if (c->n > 0) {
+    hipLaunchKernelGGL(k_checksum, dim3(grid_for(c, c->n)), dim3(kBlock), 0, c->stream, c->d_sa, (u32)c->n, acc);
+    KCHECK();
+  }
+  HIPC(hipMemcpyAsync(c->h_words + 16, acc, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  memcpy(out, c->h_words + 16, sizeof(u64));
+  return E_OK;
+}
+
+int32_t dc3hip_ctx_stats(dc3hip_ctx *c, dc3hip_stats *out) {
+  if (!c || !out) { set_err("invalid arguments"); return E_ARGS; }
+  *out = c->stats;
+  out->struct_size = (int32_t)sizeof(dc3hip_stats);
+  return E_OK;
+}
+
+// ---- one-shot entry points -------------------------------------------------------------------
+
+// n in {0,1,2} exactly as divsufsort.c:346-349 (host pointers only)
+static bool tiny_host(const uint8_t *T, void *SA, int64_t n, int bits) {
+  if (n > 2) return false;
+  if (n == 0) return true;
+  int64_t v[2] = {0, 0};
+  if (n == 2) { const int m = (T[0] < T[1]); v[m ^ 1] = 0; v[m] = 1; }
+  for (int64_t i = 0; i < n; i++) {
+    if (bits == 32) static_cast<int32_t *>(SA)[i] = (int32_t)v[i]; else static_cast<int64_t *>(SA)[i] = v[i];
+  }
+  return true;
+}
+
+static int sufsort_one(const uint8_t *T, void *SA, int64_t n, int bits, int device, bool devptrs) {
+  if (!devptrs && tiny_host(T, SA, n, bits)) return E_OK;
+  if (n == 0) return E_OK;
+  dc3hip_ctx *c = nullptr;
+  RC(dc3hip_ctx_create(&c, device, n));
+  int rc = [&]() -> int {
+    RC(dc3hip_ctx_set_text(c, T, n));          // hipMemcpyDefault handles host or device sources
+    RC(ctx_build(c));
+    if (bits == 32) RC(dc3hip_ctx_get_sa_i32(c, static_cast<int32_t *>(SA)));
+    else RC(dc3hip_ctx_get_sa_i64(c, static_cast<int64_t *>(SA)));
+    return E_OK;
+  }();
+  dc3hip_ctx_destroy(c);
+  return rc;
+}
+
+int32_t dc3hip_sufsort_ex(const uint8_t *T, void *SA, int64_t n, const dc3hip_opts *o) {
+  dc3hip_opts d; memset(&d, 0, sizeof(d)); d.index_bits = 32; d.device = -1;
+  if (o) {
+    if (o->struct_size != (int32_t)sizeof(dc3hip_opts)) { set_err("dc3hip_opts.struct_size mismatch"); return E_ARGS; }
+    d = *o;
+  }
+  if (T == nullptr || SA == nullptr || n < 0) { set_err("invalid arguments (NULL pointer or n < 0)"); return E_ARGS; }
+  if (d.index_bits != 32 && d.index_bits != 64) { set_err("index_bits must be 32 or 64"); return E_ARGS; }
+  const bool devptrs = (d.flags & DC3HIP_F_DEVICE_PTRS) != 0;
+  const int64_t P = d.num_partitions > 1 ? d.num_partitions : 1;
+  if (P == 1) {
+    if (n > DC3HIP_MAX_N) { set_err("n=%lld exceeds DC3HIP_MAX_N=%lld", (long long)n, (long long)DC3HIP_MAX_N); return E_TOOBIG; }
+    return sufsort_one(T, SA, n, d.index_bits, d.device, devptrs);
+  }
+  // sacapart semantics (sacapart/src/lib.rs:43-49): chunks of n/P + 1 bytes, independent SAs
+  const int64_t S = n / P + 1;
+  if (S > DC3HIP_MAX_N) { set_err("partition of %lld bytes exceeds DC3HIP_MAX_N", (long long)S); return E_TOOBIG; }
+  const size_t isz = d.index_bits / 8;
+  for (int64_t off = 0; off < n; off += S) {
+    const int64_t len = std::min(S, n - off);
+    RC(sufsort_one(T + off, static_cast<unsigned char *>(SA) + (size_t)off * isz, len, d.index_bits, d.device, devptrs));
+  }
+  return E_OK;
+}
+
+int32_t dc3hip_sufsort_i32(const uint8_t *T, int32_t *SA, int32_t n) {
+  return dc3hip_sufsort_ex(T, SA, (int64_t)n, nullptr);
+}
+
+int32_t dc3hip_sufsort_i64(const uint8_t *T, int64_t *SA, int64_t n) {
+  dc3hip_opts o; memset(&o, 0, sizeof(o));
+  o.struct_size = (int32_t)sizeof(o); o.index_bits = 64; o.device = -1;
+  return dc3hip_sufsort_ex(T, SA, n, &o);
+}
+
+int32_t dc3hip_sufcheck_i32(const uint8_t *T, const int32_t *SA, int32_t n) {
+  if (T == nullptr || SA == nullptr || n < 0) { set_err("invalid arguments"); return -1; }  // utils.c:169-172
+  if (n == 0) return 0;
+  dc3hip_ctx *c = nullptr;
+  int rc = dc3hip_ctx_create(&c, -1, n);
+  if (rc != E_OK) return rc == E_ALLOC ? -5 : -6;   // distinct from sufcheck's own -1..-4
+  rc = [&]() -> int {
+    RC(dc3hip_ctx_set_text(c, T, n));
+    HIPC(hipMemcpyAsync(c->d_sa, SA, (size_t)n * 4, hipMemcpyDefault, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    // negative entries become huge u32 values and fail the range check, like utils.c:179-188
+    return ctx_sufcheck(c, c->d_sa);
+  }();
+  dc3hip_ctx_destroy(c);
+  if (rc == E_HIP) return -6;
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,106 @@
+"""numpy model of the DEVICE pipeline of stringsearch_amd/csrc (same data flow, same record and
+tuple definitions, same slot arithmetic), used by the CPU test-suite to check the algorithmic
+restructuring (direct packed names, tuple merge, dummy handling) against the oracle without a GPU.
+It mirrors dc3_level() in dc3hip.hip step by step; kernels become numpy expressions.
+TEST INFRASTRUCTURE ONLY."""
+import numpy as np
+
+
+def _sym_get(S, m, idx):
+    """S.get(i): symbols with a zero tail."""
+    idx = np.asarray(idx, dtype=np.int64)
+    out = np.zeros(idx.shape, dtype=np.int64)
+    ok = idx < m
+    out[ok] = S[idx[ok]]
+    return out
+
+
+def level(S, m, K, trace=None, depth=0):
+    """returns (sa, rank) of S[0..m), symbols in 1..K; rank is 1-based."""
+    S = np.asarray(S, dtype=np.int64)
+    if trace is not None:
+        trace.append((int(m), int(K)))
+    if m == 1:
+        return np.array([0], dtype=np.int64), np.array([1], dtype=np.int64)
+    m0, m1, m2 = (m + 2) // 3, (m + 1) // 3, m // 3
+    m02 = m0 + m2
+    B = K + 1
+    g = np.arange(m0, dtype=np.int64)
+    s = [_sym_get(S, m, 3 * g + k) for k in range(5)]          # S[3g .. 3g+4]
+    has2 = (3 * g + 2) < m
+    if B ** 3 <= 0x7FFFFFFF:                                   # k_name_direct
+        R = np.zeros(m02, dtype=np.int64)
+        R[g] = ((s[1] * B + s[2]) * B + s[3]) + 1
+        R[m0 + g[has2]] = (((s[2] * B + s[3]) * B + s[4]) + 1)[has2]
+        sa12, rank12 = level(R, m02, B ** 3, trace, depth + 1)
+    else:                                                      # k_pack_triples + radix sort + naming
+        pos = np.concatenate([3 * g + 1, (3 * g + 2)[has2]])
+        keys = np.concatenate([np.stack([s[1], s[2], s[3]], 1), np.stack([s[2], s[3], s[4]], 1)[has2]])
+        order = np.argsort(pos, kind="stable")                 # ascending text position
+        pos, keys = pos[order], keys[order]
+        perm = np.lexsort((keys[:, 2], keys[:, 1], keys[:, 0]))  # stable LSD
+        pos, keys = pos[perm], keys[perm]
+        flag = np.ones(m02, dtype=np.int64)
+        flag[1:] = np.any(keys[1:] != keys[:-1], axis=1)
+        names = np.cumsum(flag)
+        slot = np.where(pos % 3 == 1, pos // 3, pos // 3 + m0)
+        if names[-1] == m02:                                   # k_assign_unique
+            sa12 = slot.copy()
+            rank12 = np.zeros(m02, dtype=np.int64)
+            rank12[slot] = np.arange(1, m02 + 1)
+        else:                                                  # k_name_assign + recursion
+            R = np.zeros(m02, dtype=np.int64)
+            R[slot] = names
+            sa12, rank12 = level(R, m02, int(names[-1]), trace, depth + 1)
+    rk = np.concatenate([rank12, np.zeros(8, dtype=np.int64)])
+    dummy = (m % 3) == 1
+    # k_build_tuples (slot order): columns pos, r, c0, cx
+    t = np.zeros((m02, 4), dtype=np.int64)
+    j = 3 * g
+    t[g, 0] = j + 1; t[g, 2] = s[1]; t[g, 3] = s[0]
+    t[g, 1] = np.where(j + 2 < m, rk[m0 + g], 0)
+    hasr = ((j + 4) < m) | (dummy & ((j + 4) == m))
+    gg = g[has2]
+    t[m0 + gg, 0] = j[has2] + 2; t[m0 + gg, 2] = s[2][has2]; t[m0 + gg, 3] = s[3][has2]
+    t[m0 + gg, 1] = np.where(hasr[has2], rk[gg + 1], 0)
+    t12 = t[sa12]                                              # k_gather_tuples
+    # k_mod0_*: mod-1 entries of SA12, in order
+    idx = np.nonzero(t12[:, 0] % 3 == 1)[0]
+    z = np.stack([t12[idx, 0] - 1, t12[idx, 3], t12[idx, 2], idx + 1, t12[idx, 1]], 1)  # pos,c0,c1,r1,r2
+    z = z[np.argsort(z[:, 1], kind="stable")]                  # radix_sort<Tup0> by c0
+    A = t12[m0 - m1:]
+    # merge (sequential model of k_merge with sample_before)
+    sa = np.zeros(m, dtype=np.int64)
+    ai = bi = 0
+    nA, nB = len(A), len(z)
+    for k in range(m):
+        if bi >= nB:
+            take = True
+        elif ai >= nA:
+            take = False
+        else:
+            a, zz = A[ai], z[bi]
+            if a[0] % 3 == 1:
+                take = (a[2], a[1]) <= (zz[1], zz[3])
+            else:
+                take = (a[2], a[3], a[1]) <= (zz[1], zz[2], zz[4])
+        if take:
+            sa[k] = A[ai][0]; ai += 1
+        else:
+            sa[k] = z[bi][0]; bi += 1
+    rank = np.zeros(m, dtype=np.int64)
+    rank[sa] = np.arange(1, m + 1)
+    return sa, rank
+
+
+def sufsort(data: bytes, trace=None):
+    n = len(data)
+    if n == 0:
+        return np.zeros(0, dtype=np.int32)
+    if n == 1:
+        return np.zeros(1, dtype=np.int32)
+    t = np.frombuffer(data, dtype=np.uint8)
+    present = np.zeros(256, dtype=np.int64); present[t] = 1
+    code = np.where(present > 0, np.cumsum(present), 0)       # k_make_codes
+    sa, _ = level(code[t], n, int(present.sum()), trace)
+    return sa.astype(np.int32)

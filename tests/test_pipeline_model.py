@@ -1,0 +1,39 @@
+"""CPU-only: the numpy model of the device data flow (tests/pipeline_model.py) must agree with the
+oracle — this pins the algorithmic re-design (sort-free packed names, tuple merge, dummy handling)
+independently of the HIP kernels."""
+import itertools
+
+import numpy as np
+
+import pipeline_model as pm
+from conftest import naive_sa
+
+
+def test_model_kat(oracle, kat):
+    for name, e in kat.items():
+        data = bytes.fromhex(e["hex"])
+        assert pm.sufsort(data).tolist() == e["sa"], name
+
+
+def test_model_exhaustive_small(oracle):
+    for alpha, maxlen in (([7], 10), ([0, 255], 8), ([0, 1, 255], 6)):
+        for n in range(0, maxlen + 1):
+            for tup in itertools.product(alpha, repeat=n):
+                data = bytes(tup)
+                assert pm.sufsort(data).tolist() == naive_sa(data).tolist(), data
+
+
+def test_model_random(oracle):
+    rng = np.random.default_rng(99)
+    for sigma in (1, 2, 4, 26, 256):
+        for n in [2, 3, 4, 5, 6, 7, 8, 9, 10, 31, 32, 33, 100, 101, 102, 500]:
+            data = rng.integers(0, sigma, size=n, dtype=np.uint8).tobytes()
+            assert pm.sufsort(data).tolist() == oracle.sufsort(data).tolist(), (sigma, n)
+
+
+def test_model_corpus(oracle, corpus):
+    for name in ("fuzz1", "fuzz2", "fuzz3", "crash-4f8c31dec8c3678a07e0fbacc6bd69e7cc9037fb"):
+        data, want = corpus[name]
+        tr = []
+        assert np.array_equal(pm.sufsort(data, tr), want), name
+        assert len(tr) >= 2
