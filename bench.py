@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py — MB/s of input indexed (suffix-array build) on MI355X, the metric of BASELINE.json.
+
+A "step" = one device-resident DC3 suffix-array build of this rank's partition (text already in HBM,
+SA left in HBM).  N GPUs = sacapart partitioning (crates/sacapart/src/lib.rs:39-58): the N x SIZE byte
+text is cut into chunks of len/N + 1 bytes, rank c builds the independent local SA of chunk c — no
+data-path collective, weak scaling.  Rank 0 prints ONE JSON line.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size BYTES] [--kind random|dna]
+                    [--cpu-sample-mib M] [--no-cpu] [--no-verify]
+    N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+             --master-port P bench.py --gpus N ...
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable copy
+
+
+def parse_size(s):
+    s = s.strip().lower()
+    mult = 1
+    for suf, m in (("gib", 1 << 30), ("mib", 1 << 20), ("kib", 1 << 10), ("g", 1 << 30), ("m", 1 << 20), ("k", 1 << 10)):
+        if s.endswith(suf):
+            s, mult = s[: -len(suf)], m
+            break
+    return int(float(s) * mult)
+
+
+def algorithmic_bytes(level_n):
+    """B(n_l) = n_l * (46w + 29c_l) / 3, w = 4; c_0 = 1 (bytes), c_l = 4 deeper."""
+    total = 0.0
+    for lvl, n in enumerate(level_n):
+        c = 1 if lvl == 0 else 4
+        total += n * (46 * 4 + 29 * c) / 3.0
+    return total
+
+
+def cpu_baseline(text_u8, sample_bytes):
+    """The reference's CPU path (libdivsufsort built from /root/reference into oracle/_ref) or, if that
+    is absent, our C restatement of crates/dc3 — timed on one host core like divsuftest's measure()
+    (crates/divsuftest/src/main.rs:145-151: wall clock around the call incl. the SA allocation)."""
+    import numpy as np
+    sample = np.ascontiguousarray(text_u8[:sample_bytes])
+    ref = os.path.join(ROOT, "oracle", "_ref", "libdivsufsort_ref.so")
+    port = os.path.join(ROOT, "oracle", "liboracle_dc3.so")
+    if os.path.exists(ref):
+        L = ctypes.CDLL(ref); f = L.divsufsort; kind = "reference"
+    elif os.path.exists(port):
+        L = ctypes.CDLL(port); f = L.dc3_oracle_sufsort_i32; kind = "port"
+    else:
+        return None
+    f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]; f.restype = ctypes.c_int32
+    try:
+        os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[0]})
+    except Exception:
+        pass
+    t0 = time.perf_counter()
+    sa = np.zeros(len(sample), dtype=np.int32)
+    rc = f(sample.ctypes.data, sa.ctypes.data, len(sample))
+    dt = time.perf_counter() - t0
+    assert rc == 0
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        model = "unknown"
+    return {"value": len(sample) / dt / 1e6, "unit": "MB/s", "cores": 1, "kind": kind,
+            "sample": f"first {len(sample) / 2**20:.0f} MiB of the same buffer, one divsufsort() call, "
+                      f"wall clock incl. SA allocation ({dt:.2f} s)",
+            "host_cpu": model, "host_cores_available": os.cpu_count()}, sa
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=str, default="1GiB", help="bytes per GPU (partition size is size*N/N+1 rounding aside)")
+    ap.add_argument("--kind", type=str, default="random", choices=["random", "dna"])
+    ap.add_argument("--seed", type=int, default=2)
+    ap.add_argument("--cpu-sample-mib", type=int, default=64)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch            # first: libdc3hip.so then shares the HIP runtime torch loaded
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes", file=sys.stderr)
+            sys.exit(2)
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import stringsearch_amd as ss
+
+    from stringsearch_amd.partition import rank_chunk
+    per_gpu = parse_size(args.size)
+    total_len = per_gpu * world
+    off, n = (0, total_len) if world == 1 else rank_chunk(total_len, world, rank)   # sacapart/src/lib.rs:43-46
+    kind = 0 if args.kind == "random" else 1
+
+    ctx = ss.Context(n, device=local_rank)
+    ctx.generate(n, args.seed, kind, offset=off)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ctx.build()
+    verify = {}
+    if not args.no_verify:
+        if args.warmup == 0:
+            ctx.build()
+        rc = ctx.sufcheck()                  # full-size GPU sufcheck (utils.c:160-241 semantics)
+        assert rc == 0, f"rank {rank}: SA failed sufcheck ({rc}) — no throughput reported"
+        verify["sufcheck_full"] = rc
+        chk0 = ctx.checksum()
+
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = 0.0
+    dsw_ms = 0.0; dsw_launches = 0; dsw_elems = 0
+    for _ in range(args.steps):
+        ctx.build()
+        st = ctx.stats()
+        kernel_ms += st["build_ms"]
+        dsw_ms += st["downsweep16_ms"]; dsw_launches += st["downsweep16_launches"]; dsw_elems += st["downsweep16_elems"]
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if not args.no_verify:
+        assert ctx.checksum() == chk0, "SA changed between identical builds"
+        verify["idempotent_checksum"] = True
+
+    st = ctx.stats()
+    out = None
+    if rank == 0:
+        value = total_len * args.steps / dt / 1e6
+        # dominant kernel: stable radix scatter of 16-byte triple records (k_rs_downsweep<Rec16>).
+        # algorithmic bytes per record-pass = reference scatter loop lib.rs:35-38: read a[i] (w) +
+        # r[a[i]] (c) + write b[..] (w) = 2w + c = 12 B at w = c = 4 (scatter half).
+        roof = None
+        if dsw_launches:
+            per_launch_elems = dsw_elems / dsw_launches
+            avg_ms = dsw_ms / dsw_launches
+            achieved = 12.0 * per_launch_elems / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "k_rs_downsweep<Rec16> (stable 8-bit radix scatter of triple records)",
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": None,
+                    "algorithmic_bytes_per_launch": 12.0 * per_launch_elems, "avg_launch_ms": avg_ms,
+                    "launches_per_step": dsw_launches / args.steps,
+                    "moved_bytes_per_launch": 32.0 * per_launch_elems,
+                    "moved_GBps": 32.0 * per_launch_elems / (avg_ms * 1e-3) / 1e9}
+        alg = algorithmic_bytes(st["level_n"])
+        path = {"algorithmic_bytes_per_step": alg, "device_ms_per_step": kernel_ms / args.steps,
+                "achieved_GBps": alg / (kernel_ms / args.steps * 1e-3) / 1e9,
+                "frac_of_hbm_peak": alg / (kernel_ms / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "levels": list(zip(st["level_n"], st["level_K"], st["level_sorted"])),
+                "phase_ms": {k: round(v, 3) for k, v in st["phase_ms"].items() if v}}
+        out = {
+            "metric": "MB/s of input indexed (SA build), 1 GiB bytes, 1/2/4/8 GPUs",
+            "value": value, "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"{per_gpu / 2**30:g} GiB {args.kind} bytes per GPU (splitmix64 seed {args.seed}), "
+                                   f"i32 SA, DC3 HIP, text and SA resident in HBM",
+                       "bytes_per_gpu": n, "total_bytes": total_len,
+                       "partitioning": "single SA" if world == 1 else f"sacapart: {world} chunks of len/{world}+1 bytes, one per GPU, no collective"},
+            "roofline": roof, "roofline_path": path, "verify": verify,
+            "arena_peak_GB": st["arena_peak"] / 1e9,
+        }
+        if world == 1 and not args.no_cpu:
+            text = ctx.text()
+            sample_bytes = min(n, args.cpu_sample_mib << 20)
+            res = cpu_baseline(text, sample_bytes)
+            if res is not None:
+                cb, cpu_sa = res
+                out["cpu_baseline"] = cb
+                if sample_bytes == n and not args.no_verify:
+                    out["verify"]["equal_cpu_reference"] = bool(np.array_equal(cpu_sa, ctx.sa()))
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -58,7 +58,8 @@ typedef struct dc3hip_opts {
 DC3HIP_API int32_t dc3hip_sufsort_ex(const uint8_t *T, void *SA, int64_t n, const dc3hip_opts *opts);
 
 /* sufcheck() twin, computed on the GPU (utils.c:160-241 return codes: 0 ok, -1 invalid arguments,
- * -2 out of range, -3 first characters out of order, -4 suffix in wrong position). */
+ * -2 out of range, -3 first characters out of order, -4 suffix in wrong position; library failures
+ * are reported as -5 (allocation) / -6 (HIP error), outside sufcheck's own range). */
 DC3HIP_API int32_t dc3hip_sufcheck_i32(const uint8_t *T, const int32_t *SA, int32_t n);
 
 DC3HIP_API const char *dc3hip_version(void);
@@ -77,7 +78,7 @@ DC3HIP_API void dc3hip_ctx_destroy(dc3hip_ctx *ctx);
 /* Load the text: from host memory (H2D copy) ... */
 DC3HIP_API int32_t dc3hip_ctx_set_text(dc3hip_ctx *ctx, const uint8_t *T, int64_t n);
 /* ... or generate it on the device: byte i = byte (i&7) of splitmix64(seed + (i>>3)) for kind 0,
- * "ACGT"[2-bit field] for kind 1 (bit-identical to oracle_gen_bytes). */
+ * "ACGT"[2-bit field] for kind 1. */
 DC3HIP_API int32_t dc3hip_ctx_generate(dc3hip_ctx *ctx, int64_t n, uint64_t seed, int32_t kind);
 /* Same stream, bytes [offset, offset+n): lets each GPU of a sacapart run generate its own chunk. */
 DC3HIP_API int32_t dc3hip_ctx_generate_at(dc3hip_ctx *ctx, int64_t n, uint64_t seed, int32_t kind, int64_t offset);

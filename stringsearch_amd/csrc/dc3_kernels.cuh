@@ -521,7 +521,7 @@ __global__ __launch_bounds__(kBlock) void k_merge(const Tup12 *__restrict__ A, u
 }
 
 // ---------------------------------------------------------------------------------------------
-// Synthetic text generator — bit-identical twin of oracle_gen_bytes.
+// Synthetic text generator: byte i = byte (i&7) of splitmix64(seed + (i>>3)).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ u64 splitmix64(u64 x) {
   x += 0x9E3779B97F4A7C15ull;

@@ -553,10 +553,13 @@ int32_t dc3hip_ctx_get_text(dc3hip_ctx *c, uint8_t *T) {
   return E_OK;
 }
 
-static int ctx_sufcheck(dc3hip_ctx *c, const u32 *d_sa) {
+// Runs the check; *code receives sufcheck()'s result (0, -2, -3, -4); the return value is the
+// library status (E_OK / E_ALLOC / E_HIP), kept apart because the two code spaces overlap.
+static int ctx_sufcheck(dc3hip_ctx *c, const u32 *d_sa, int *code) {
   // utils.c:160-241 as parallel passes; isa lives in the arena
   const int64_t n = c->n;
-  if (n == 0) return 0;
+  *code = 0;
+  if (n == 0) return E_OK;
   HIPC(hipSetDevice(c->device));
   c->arena_off = 0;
   u32 *isa = nullptr;
@@ -572,13 +575,17 @@ static int ctx_sufcheck(dc3hip_ctx *c, const u32 *d_sa) {
   HIPC(hipStreamSynchronize(c->stream));
   const int v = (int)c->h_words[8];
   c->arena_off = 0;
-  return v ? -(5 - v) : 0;
+  *code = v ? -(5 - v) : 0;
+  return E_OK;
 }
 
 int32_t dc3hip_ctx_sufcheck(dc3hip_ctx *c) {
   if (!c) { set_err("ctx is NULL"); return E_ARGS; }
   if (!c->built) { set_err("no suffix array built in this context"); return E_ARGS; }
-  return ctx_sufcheck(c, c->d_sa);
+  int code = 0;
+  const int rc = ctx_sufcheck(c, c->d_sa, &code);
+  if (rc != E_OK) return rc == E_ALLOC ? -5 : -6;   // library failure, distinct from sufcheck's -1..-4
+  return code;
 }
 
 int32_t dc3hip_ctx_sa_checksum(dc3hip_ctx *c, uint64_t *out) {
@@ -675,16 +682,17 @@ int32_t dc3hip_sufcheck_i32(const uint8_t *T, const int32_t *SA, int32_t n) {
   dc3hip_ctx *c = nullptr;
   int rc = dc3hip_ctx_create(&c, -1, n);
   if (rc != E_OK) return rc == E_ALLOC ? -5 : -6;   // distinct from sufcheck's own -1..-4
+  int code = 0;
   rc = [&]() -> int {
     RC(dc3hip_ctx_set_text(c, T, n));
     HIPC(hipMemcpyAsync(c->d_sa, SA, (size_t)n * 4, hipMemcpyDefault, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
     // negative entries become huge u32 values and fail the range check, like utils.c:179-188
-    return ctx_sufcheck(c, c->d_sa);
+    return ctx_sufcheck(c, c->d_sa, &code);
   }();
   dc3hip_ctx_destroy(c);
-  if (rc == E_HIP) return -6;
-  return rc;
+  if (rc != E_OK) return rc == E_ALLOC ? -5 : -6;
+  return code;
 }
 
 }  // extern "C"

@@ -1,0 +1,247 @@
+"""GPU parity tests (-m gpu): libdc3hip.so, called through the C ABI, against
+  * the golden vectors of the reference (tests/golden: corpus + known answers, SAs by libdivsufsort),
+  * the oracle restatement on seeded inputs (bit-exact, int32/int64),
+  * size-independent properties at BASELINE.json sizes (GPU sufcheck, idempotence, checksum),
+  * the reference's interface behaviour (sort / sort_in_place / sacapart semantics).
+Bar: bit-exact."""
+import hashlib
+import itertools
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, naive_sa
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ss():
+    import stringsearch_amd as ss
+    assert ss.device_count() >= 1, "gpu tests need a device; the library has no CPU fallback"
+    return ss
+
+
+def gpu_sa(ss, data):
+    return ss.sort(data).into_parts()[1]
+
+
+def test_kat_vectors(ss, kat):
+    for name, e in kat.items():
+        data = bytes.fromhex(e["hex"])
+        assert gpu_sa(ss, data).tolist() == e["sa"], name
+
+
+def test_reference_corpus(ss, corpus, oracle):
+    # crates/divsufsort/src/lib.rs:31-92: sort then verify(); here also bit-exact vs libdivsufsort
+    for name, (data, want) in corpus.items():
+        idx = ss.sort(data)
+        got = idx.into_parts()[1]
+        assert np.array_equal(got, want), name
+        idx.verify()                                        # sacabase::verify semantics
+        assert ss.sufcheck(data, got) == 0                  # GPU sufcheck
+        got64 = ss.sort_i64(data).into_parts()[1]
+        assert got64.dtype == np.int64 and np.array_equal(got64, want.astype(np.int64)), name
+
+
+def test_level_trace_matches_oracle_depth(ss, corpus, oracle):
+    """Deep recursion (6-7 levels on the periodic fuzz inputs): the device recursion must terminate
+    and index the same text; its depth is within one level of the reference's (packed names at the
+    first level(s) do not detect uniqueness early)."""
+    traces = json.load(open(os.path.join(GOLDEN, "trace.json")))
+    for name, (data, want) in corpus.items():
+        if len(data) < 100:
+            continue
+        with ss.Context(len(data)) as c:
+            c.set_text(data); c.build()
+            st = c.stats()
+            assert np.array_equal(c.sa(), want)
+            assert st["level_n"][0] == len(data)
+            assert [n for n in st["level_n"][:len(traces[name])]] == [t[0] for t in traces[name]][:st["levels"]]
+            assert len(traces[name]) <= st["levels"] <= len(traces[name]) + 1
+
+
+def test_exhaustive_small(ss):
+    for alpha, maxlen in (([0], 10), ([0, 255], 8), ([0, 1, 255], 6)):
+        for n in range(0, maxlen + 1):
+            for tup in itertools.product(alpha, repeat=n):
+                data = bytes(tup)
+                assert gpu_sa(ss, data).tolist() == naive_sa(data).tolist(), data
+
+
+@pytest.mark.parametrize("sigma", [1, 2, 3, 4, 26, 255, 256])
+def test_random_sweep_vs_oracle(ss, oracle, sigma):
+    rng = np.random.default_rng(1000 + sigma)
+    sizes = list(range(0, 20)) + [63, 64, 65, 127, 128, 129, 1023, 1024, 1025, 4095, 4096, 4097, 4098,
+                                  12287, 12288, 12289, 50000, 50001, 50002, 262144]
+    for n in sizes:
+        data = rng.integers(0, sigma, size=n, dtype=np.uint8)
+        got = gpu_sa(ss, data)
+        want = oracle.sufsort(data)
+        assert np.array_equal(got, want), (sigma, n)
+
+
+def test_tile_and_chunk_boundaries(ss, oracle):
+    """sizes around radix tile (4096/3072 records), merge tile (1024) and name tile boundaries, all n mod 3"""
+    rng = np.random.default_rng(77)
+    for base in (1536, 3072, 6144, 4608, 9216, 1024 * 3, 2048 * 3):
+        for d in (-2, -1, 0, 1, 2, 3):
+            n = base + d
+            data = rng.integers(0, 3, size=n, dtype=np.uint8)
+            assert np.array_equal(gpu_sa(ss, data), oracle.sufsort(data)), n
+
+
+def test_low_entropy_and_periodic(ss, oracle):
+    cases = [b"a" * 20000, b"ab" * 15000, b"abc" * 10000 + b"ab", (b"\xff\xf3" * 3000) + b"\x00" + (b"\xff\xf3" * 3000),
+             bytes(range(256)) * 64, b"\x00" * 4097, b"\xff" * 4098]
+    rng = np.random.default_rng(5)
+    block = rng.integers(0, 256, size=1500, dtype=np.uint8).tobytes()
+    cases.append(block * 20 + b"x" + block * 7)
+    for data in cases:
+        got = gpu_sa(ss, data)
+        assert np.array_equal(got, oracle.sufsort(data)), (len(data), data[:8])
+        assert ss.sufcheck(data, got) == 0
+
+
+def test_synthetic_hashes(ss, oracle):
+    """deterministic generator inputs whose SA hashes were produced by the reference libdivsufsort
+    (tests/golden/synth.json); the device generator must be bit-identical to the host one."""
+    synth = json.load(open(os.path.join(GOLDEN, "synth.json")))
+    for label, e in synth.items():
+        with ss.Context(e["n"]) as c:
+            c.generate(e["n"], e["seed"], e["kind"])
+            text = c.text()
+            assert hashlib.sha256(text.tobytes()).hexdigest() == e["text_sha256"], label
+            c.build()
+            sa = c.sa()
+            assert sa[:8].tolist() == e["sa_head"], label
+            assert hashlib.sha256(sa.astype("<i4").tobytes()).hexdigest() == e["sa_i32le_sha256"], label
+            assert c.sufcheck() == 0
+            sa64 = c.sa(np.int64)
+            assert np.array_equal(sa64, sa.astype(np.int64))
+
+
+def test_generator_offsets(ss, oracle):
+    for kind in (0, 1):
+        full = oracle.gen(100000, 9, kind)
+        for off, n in ((0, 100000), (8, 5000), (13, 4001), (33331, 7), (99999, 1)):
+            with ss.Context(n) as c:
+                c.generate(n, 9, kind, offset=off)
+                assert np.array_equal(c.text(), full[off:off + n]), (kind, off, n)
+
+
+def test_sufcheck_detects_errors(ss, oracle):
+    data = oracle.gen(50000, 3, 1)
+    sa = oracle.sufsort(data)
+    assert ss.sufcheck(data, sa) == 0
+    bad = sa.copy(); bad[100] = 50000
+    assert ss.sufcheck(data, bad) == -2                     # out of range (utils.c:179-188)
+    bad = sa.copy(); bad[7] = -1
+    assert ss.sufcheck(data, bad) == -2
+    bad = sa.copy(); bad[[0, len(bad) - 1]] = bad[[len(bad) - 1, 0]]
+    assert ss.sufcheck(data, bad) == -3                     # first characters out of order
+    # swap two adjacent suffixes that share their first character: wrong position
+    i = next(k for k in range(len(sa) - 1) if data[sa[k]] == data[sa[k + 1]])
+    bad = sa.copy(); bad[[i, i + 1]] = bad[[i + 1, i]]
+    assert ss.sufcheck(data, bad) == -4
+    bad = sa.copy(); bad[5] = bad[6]                        # duplicate entry = not a permutation
+    assert ss.sufcheck(data, bad) in (-2, -3, -4) and ss.sufcheck(data, bad) != 0
+
+
+def test_stats_struct_and_phases(ss):
+    with ss.Context(1 << 16) as c:
+        c.generate(1 << 16, 1, 0); c.build()
+        st = c.stats()
+        from stringsearch_amd._lib import Stats
+        import ctypes
+        raw = Stats(); ss.lib().dc3hip_ctx_stats(c._h, ctypes.byref(raw))
+        assert raw.struct_size == ctypes.sizeof(Stats)      # C and Python layouts agree
+        assert st["levels"] == 2 and st["level_sorted"] == [0, 1]
+        assert st["build_ms"] > 0 and st["downsweep16_launches"] == 10   # 75-bit keys -> 10 byte passes
+        assert st["arena_peak"] <= st["arena_bytes"]
+
+
+def test_context_reuse_and_idempotence(ss, oracle):
+    with ss.Context(300000) as c:
+        for n, seed, kind in ((300000, 1, 0), (12345, 2, 1), (299999, 3, 0), (2, 4, 0), (1, 5, 0), (3, 6, 1)):
+            c.generate(n, seed, kind)
+            c.build(); a = c.sa(); chk = c.checksum()
+            c.build(); b = c.sa()
+            assert np.array_equal(a, b) and chk == c.checksum()
+            assert np.array_equal(a, oracle.sufsort(c.text())), (n, seed, kind)
+
+
+def test_ex_partitions_sacapart_semantics(ss, oracle):
+    """dc3hip_sufsort_ex with num_partitions = P == PartitionedSuffixArray::new chunking
+    (sacapart/src/lib.rs:43-49): per-chunk local SAs, bit-exact vs the oracle per chunk."""
+    import ctypes
+    from stringsearch_amd._lib import Opts
+    from stringsearch_amd.partition import chunk_bounds
+    data = oracle.gen(100003, 4, 0)
+    for P in (2, 3, 4):
+        sa = np.zeros(len(data), dtype=np.int32)
+        o = Opts(ctypes.sizeof(Opts), 32, -1, P, 0)
+        rc = ss.lib().dc3hip_sufsort_ex(data.ctypes.data, sa.ctypes.data, len(data), ctypes.byref(o))
+        assert rc == 0, ss.last_error()
+        for off, ln in chunk_bounds(len(data), P):
+            assert np.array_equal(sa[off:off + ln], oracle.sufsort(data[off:off + ln])), (P, off)
+
+
+def test_partitioned_search_on_gpu_sas(ss):
+    # sacapart/src/lib.rs:105-165 with dc3hip::sort plugged in as `f`
+    text = b"totor"
+    full = ss.sort(text); part = ss.PartitionedSuffixArray(text, 2, ss.sort)
+    assert full.longest_substring_match(b"tor").as_bytes() == b"tor"
+    assert part.longest_substring_match(b"tor").as_bytes() == b"to"
+    assert part.longest_substring_match(b"otor").as_bytes() == b"otor"
+    text = b"This is a rather long text. We can probably find matches that span two partitions. Oh yes."
+    full = ss.sort(text)
+    for P in (1, 2, 3):
+        part = ss.PartitionedSuffixArray(text, P, ss.sort)
+        for needle in (b"rather long", b"text. We can", b"We can probably find matches that span"):
+            f, p = full.longest_substring_match(needle), part.longest_substring_match(needle)
+            assert (f.as_bytes(), f.start, f.len) == (p.as_bytes(), p.start, p.len)
+
+
+def test_concurrent_calls_are_thread_safe(ss, oracle):
+    """sacapart calls f concurrently from rayon workers (lib.rs:41-49): the one-shot entry point
+    must be re-entrant."""
+    from concurrent.futures import ThreadPoolExecutor
+    datas = [oracle.gen(40000 + 17 * i, 20 + i, i & 1) for i in range(8)]
+    with ThreadPoolExecutor(4) as ex:
+        outs = list(ex.map(lambda d: gpu_sa(ss, d), datas))
+    for d, got in zip(datas, outs):
+        assert np.array_equal(got, oracle.sufsort(d))
+
+
+def test_config2_64mib_random_bit_exact(ss, oracle):
+    """BASELINE.json configs[1]: 64 MiB random bytes, i32 SA, bit-exact vs divsufsort (full compare
+    when the reference build travelled with the snapshot, GPU sufcheck always)."""
+    n = 64 << 20
+    with ss.Context(n) as c:
+        c.generate(n, 2, 0)
+        c.build()
+        assert c.sufcheck() == 0
+        st = c.stats()
+        assert st["levels"] == 2
+        if oracle.ref is not None:
+            text = c.text()
+            want = oracle.ref_sufsort(text)
+            assert np.array_equal(c.sa(), want)
+
+
+def test_full_size_1gib_properties(ss):
+    """BASELINE.json metric size: 1 GiB random bytes on one GPU — size-independent properties:
+    GPU sufcheck (== sacabase::verify), idempotence, n mod 3 == 1 dummy path."""
+    n = 1 << 30
+    with ss.Context(n) as c:
+        c.generate(n, 2, 0)
+        c.build()
+        assert c.sufcheck() == 0
+        chk = c.checksum()
+        c.build()
+        assert c.checksum() == chk
+        st = c.stats()
+        assert st["level_n"][:2] == [n, 715827883]
