@@ -25,6 +25,8 @@ constexpr int kWaves = kBlock / 64;
 // ---------------------------------------------------------------------------------------------
 // Sample-triple record: 96-bit packed key (k[0] least significant) + text position.
 struct __attribute__((aligned(16))) Rec16 { u32 k0, k1, k2, pos; };
+// (destination, value) pair of an inverse-permutation pass (rank <- SA inversion, lib.rs:106-113).
+struct __attribute__((aligned(8))) Rec8 { u32 key, val; };
 // Merge tuple of a sample (mod-1 / mod-2) suffix, 16 B:
 //   pos%3==1: (c0=S[pos], r=rank[pos+1]), cx = S[pos-1]   (cx feeds the derived mod-0 tuple)
 //   pos%3==2: (c0=S[pos], cx=S[pos+1], r=rank[pos+2])
@@ -195,9 +197,14 @@ struct Rec16Byte {
     return (w >> ((p & 3) * 8)) & 255u;
   }
 };
+struct Rec8Shift {   // 8 bits of the destination index starting at bit `shift`
+  u32 shift;
+  __device__ __forceinline__ u32 operator()(const Rec8 &r) const { return (r.key >> shift) & 255u; }
+};
 struct Tup0Byte {
   u32 p;
-  __device__ __forceinline__ u32 operator()(const Tup0 &r) const { return (r.c0 >> (p * 8)) & 255u; }
+  // mod-0 positions are real symbols (c0 >= 1), so the key is c0-1 in [0, K)
+  __device__ __forceinline__ u32 operator()(const Tup0 &r) const { return ((r.c0 - 1u) >> (p * 8)) & 255u; }
 };
 
 template <class Rec, class Dig>
@@ -222,28 +229,35 @@ __global__ __launch_bounds__(kBlock) void k_rs_upsweep(const Rec *__restrict__ i
   table[tid * nchunks + blockIdx.x] = s;
 }
 
-template <class Rec, int IPT>
+template <class Rec, int IPT, int NW>
 struct DownsweepSmem {
-  static constexpr int kTile = kBlock * IPT;
-  static constexpr size_t kBytes = sizeof(Rec) * kTile + sizeof(u32) * (kWaves * 256 + 256 + 256 + 16);
+  static constexpr int kTile = NW * 64 * IPT;
+  static constexpr size_t kBytes = sizeof(Rec) * kTile + sizeof(u32) * (NW * 256 + 256 + 256 + 32);
 };
 
-template <class Rec, class Dig, int IPT>
-__global__ __launch_bounds__(kBlock) void k_rs_downsweep(const Rec *__restrict__ in, Rec *__restrict__ out, u32 n,
-                                                        u32 chunk, u32 nchunks, Dig dig,
-                                                        const u32 *__restrict__ table) {
-  constexpr int kTile = kBlock * IPT;
+// table rows are scanned per digit (k_scan_rows) and the 256 digit totals separately
+// (k_scan_excl_inplace on digit_base), so the global base of (digit d, chunk c) is
+// digit_base[d] + table[d*nchunks + c].
+// NW waves per block (measured on MI355X, profiles/r01_radix_downsweep_variants.txt: 16 waves x 8
+// items = 8192-record tiles move 3.5 TB/s vs 2.9 TB/s for 4 waves x 16 items).
+template <class Rec, class Dig, int IPT, int NW>
+__global__ __launch_bounds__(NW * 64) void k_rs_downsweep(const Rec *__restrict__ in, Rec *__restrict__ out, u32 n,
+                                                         u32 chunk, u32 nchunks, Dig dig,
+                                                         const u32 *__restrict__ table,
+                                                         const u32 *__restrict__ digit_base) {
+  constexpr int kB = NW * 64;
+  constexpr int kTile = kB * IPT;
   constexpr int kWItems = 64 * IPT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Rec *srec = reinterpret_cast<Rec *>(smem);
-  u32 *wcnt = reinterpret_cast<u32 *>(smem + sizeof(Rec) * kTile);   // [kWaves][256]
-  u32 *dbase = wcnt + kWaves * 256;                                  // [256] running global base
+  u32 *wcnt = reinterpret_cast<u32 *>(smem + sizeof(Rec) * kTile);   // [NW][256]
+  u32 *dbase = wcnt + NW * 256;                                      // [256] running global base
   u32 *texcl = dbase + 256;                                          // [256] tile-exclusive prefix
-  u32 *tmp = texcl + 256;                                            // [16]
+  u32 *tmp = texcl + 256;                                            // [NW]
   const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
   const u32 begin = blockIdx.x * chunk;
   const u32 end = min(n, begin + chunk);
-  dbase[tid] = table[tid * nchunks + blockIdx.x];
+  if (tid < 256) dbase[tid] = digit_base[tid] + table[tid * nchunks + blockIdx.x];
   volatile u32 *mycnt = wcnt + w * 256;
 
   for (u32 tile = begin; tile < end; tile += kTile) {
@@ -278,16 +292,13 @@ __global__ __launch_bounds__(kBlock) void k_rs_downsweep(const Rec *__restrict__
     __syncthreads();
     // per digit (thread tid = digit): prefix over waves, tile total, tile-exclusive prefix
     u32 tot = 0;
-    {
-      u32 c[kWaves];
+    if (tid < 256) {
 #pragma unroll
-      for (int i = 0; i < kWaves; i++) c[i] = wcnt[i * 256 + tid];
-#pragma unroll
-      for (int i = 0; i < kWaves; i++) { wcnt[i * 256 + tid] = tot; tot += c[i]; }
+      for (int i = 0; i < NW; i++) { const u32 c = wcnt[i * 256 + tid]; wcnt[i * 256 + tid] = tot; tot += c; }
     }
     u32 dummy_total;
-    const u32 ex = block_excl_scan<kWaves>(tot, tmp, dummy_total);
-    texcl[tid] = ex;
+    const u32 ex = block_excl_scan<NW>(tid < 256 ? tot : 0u, tmp, dummy_total);
+    if (tid < 256) texcl[tid] = ex;
     __syncthreads();
     // reorder through LDS so every digit run is contiguous
 #pragma unroll
@@ -296,15 +307,35 @@ __global__ __launch_bounds__(kBlock) void k_rs_downsweep(const Rec *__restrict__
       if (t < nvalid) srec[texcl[d[k]] + wcnt[w * 256 + d[k]] + rk[k]] = r[k];
     }
     __syncthreads();
-    for (u32 q = tid; q < nvalid; q += kBlock) {
+    for (u32 q = tid; q < nvalid; q += kB) {
       const Rec x = srec[q];
       const u32 dd = dig(x);
       out[dbase[dd] + (q - texcl[dd])] = x;
     }
     __syncthreads();
-    dbase[tid] += tot;
+    if (tid < 256) dbase[tid] += tot;
     // (the barrier after ranking in the next iteration orders this update before its use)
   }
+}
+
+// Row-wise exclusive scan of the [256][nchunks] digit table: block d scans row d in place and
+// writes the row total to totals[d] (then scanned by k_scan_excl_inplace over 256 entries).
+__global__ __launch_bounds__(kBlock) void k_scan_rows(u32 *__restrict__ table, u32 nchunks, u32 *__restrict__ totals) {
+  __shared__ u32 tmp[kWaves];
+  u32 *row = table + (size_t)blockIdx.x * nchunks;
+  u32 carry = 0;
+  for (u32 base = 0; base < nchunks; base += kBlock * 4) {
+    const u32 i0 = base + threadIdx.x * 4;
+    u32 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = (i0 + j < nchunks) ? row[i0 + j] : 0u;
+    u32 tot;
+    u32 ex = block_excl_scan<kWaves>(v[0] + v[1] + v[2] + v[3], tmp, tot) + carry;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { if (i0 + j < nchunks) row[i0 + j] = ex; ex += v[j]; }
+    carry += tot;
+  }
+  if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -372,13 +403,34 @@ __global__ __launch_bounds__(kBlock) void k_name_assign(const Rec16 *__restrict_
     running += tot;
   }
 }
+// Emits (slot, i+1) pairs (coalesced) for the windowed inversion below instead of scattering 4-byte
+// ranks: random 4-byte stores run at ~25 G/s on MI355X (profiles/r01_membench_access_patterns.txt),
+// a partition by destination window + LDS-local placement is > 2x faster.
 __global__ __launch_bounds__(kBlock) void k_assign_unique(const Rec16 *__restrict__ s, u32 n, u32 m0,
-                                                         u32 *__restrict__ sa12, u32 *__restrict__ rank) {
+                                                         u32 *__restrict__ sa12, Rec8 *__restrict__ pairs) {
   for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     const u32 sl = slot_of(s[i].pos, m0);
     sa12[i] = sl;
-    rank[sl] = i + 1;
+    pairs[i] = Rec8{sl, i + 1};
   }
+}
+
+// Final step of the windowed inversion.  The keys are a bijection onto [0,n), and the pairs are
+// already partitioned by key >> kInvWindowBits, so pair range [w*W, (w+1)*W) holds exactly the
+// destinations of window w: place them in LDS, then store the window with full coalesced lines.
+constexpr int kInvWindowBits = 14;
+constexpr int kInvWindow = 1 << kInvWindowBits;   // 16384 ranks = 64 KiB of LDS
+__global__ __launch_bounds__(1024) void k_invperm_local(const Rec8 *__restrict__ pairs, u32 n, u32 *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32 *win = reinterpret_cast<u32 *>(smem);
+  const u32 base = blockIdx.x * (u32)kInvWindow;
+  const u32 cnt = min((u32)kInvWindow, n - base);
+  for (u32 i = threadIdx.x; i < cnt; i += 1024) {
+    const Rec8 r = pairs[base + i];
+    win[r.key - base] = r.val;
+  }
+  __syncthreads();
+  for (u32 i = threadIdx.x; i < cnt; i += 1024) out[base + i] = win[i];
 }
 __global__ void k_base1(u32 *out_sa, u32 *out_rank) {
   if (threadIdx.x == 0) { if (out_sa) out_sa[0] = 0; if (out_rank) out_rank[0] = 1; }
@@ -417,7 +469,15 @@ __global__ __launch_bounds__(kBlock) void k_build_tuples(Sym S, u32 m, u32 m0, u
 __global__ __launch_bounds__(kBlock) void k_gather_tuples(const Tup12 *__restrict__ tslot,
                                                          const u32 *__restrict__ sa12, u32 n,
                                                          Tup12 *__restrict__ out) {
-  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) out[i] = tslot[sa12[i]];
+  // 4 independent 16-byte gathers in flight per thread
+  const u32 stride = gridDim.x * kBlock;
+  u32 i = blockIdx.x * kBlock + threadIdx.x;
+  for (; i + 3 * stride < n; i += 4 * stride) {
+    const u32 s0 = sa12[i], s1 = sa12[i + stride], s2 = sa12[i + 2 * stride], s3 = sa12[i + 3 * stride];
+    const Tup12 a = tslot[s0], b = tslot[s1], c = tslot[s2], d = tslot[s3];
+    out[i] = a; out[i + stride] = b; out[i + 2 * stride] = c; out[i + 3 * stride] = d;
+  }
+  for (; i < n; i += stride) out[i] = tslot[sa12[i]];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -484,12 +544,11 @@ __global__ __launch_bounds__(kBlock) void k_merge_partition(const Tup12 *__restr
   part[t] = lo;
 }
 
-// out_sa[k] = text position of the k-th smallest suffix (coalesced); out_rank[pos] = k+1 (the
-// inverse, which the parent level needs in slot order — fused here instead of a separate
-// R[SA12[i]] = i+1 pass, lib.rs:106-108).
+// out_sa[k] = text position of the k-th smallest suffix (coalesced); out_pairs[k] = (pos, k+1) feeds
+// the windowed inversion that gives the parent level rank[pos] = k+1 (R[SA12[i]] = i+1, lib.rs:106-108).
 __global__ __launch_bounds__(kBlock) void k_merge(const Tup12 *__restrict__ A, u32 nA, const Tup0 *__restrict__ B,
                                                  u32 nB, const u32 *__restrict__ part, u32 *__restrict__ out_sa,
-                                                 u32 *__restrict__ out_rank) {
+                                                 Rec8 *__restrict__ out_pairs) {
   __shared__ Tup12 sa[kMergeTile];
   __shared__ Tup0 sb[kMergeTile];
   const u32 total = nA + nB;
@@ -516,7 +575,7 @@ __global__ __launch_bounds__(kBlock) void k_merge(const Tup12 *__restrict__ A, u
     const u32 pos = takeA ? sa[ai].pos : sb[bi].pos;
     ai += takeA ? 1u : 0u; bi += takeA ? 0u : 1u;
     if (out_sa) out_sa[d0 + k] = pos;
-    if (out_rank) out_rank[pos] = d0 + k + 1;
+    if (out_pairs) out_pairs[d0 + k] = Rec8{pos, d0 + k + 1};
   }
 }
 

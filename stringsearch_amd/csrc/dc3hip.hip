@@ -101,9 +101,11 @@ static size_t arena_requirement(int64_t n) {
   for (int lvl = 0; lvl < DC3HIP_MAX_LEVELS && m >= 2; lvl++) {
     const int64_t m0 = (m + 2) / 3, m02 = m0 + m / 3;
     const size_t keep = 3 * align_up((size_t)(m02 + 16) * 4, 256);
-    const size_t recs = 2 * align_up((size_t)m02 * 16, 256) + 2 * align_up((size_t)4 * 4096 * 256, 256);
-    const size_t tups = 2 * align_up((size_t)m02 * 16, 256) + 2 * align_up((size_t)m0 * 20, 256) +
-                        align_up((size_t)(m / 1024 + 16) * 4, 256);
+    const size_t tbl = 2 * align_up((size_t)4 * 4096 * 256, 256);
+    const size_t recs = 2 * align_up((size_t)m02 * 16, 256) + 2 * align_up((size_t)m02 * 8, 256) + tbl;
+    const size_t after = 2 * align_up((size_t)m0 * 20, 256) + align_up((size_t)(m / 1024 + 16) * 4, 256) +
+                         (lvl > 0 ? 2 * align_up((size_t)m * 8, 256) : 0) + tbl;
+    const size_t tups = align_up((size_t)m02 * 16, 256) + std::max(align_up((size_t)m02 * 16, 256), after);
     total = std::max(total, held + keep + std::max(recs, tups) + (1u << 20));
     held += keep;
     m = m02;
@@ -161,18 +163,23 @@ static Chunking make_chunks(dc3hip_ctx *c, u32 n, u32 tile) {
 // stable LSD radix sort over `nbytes` key bytes (lib.rs:15-39 per digit)
 // ---------------------------------------------------------------------------------------------
 template <class Rec> struct SortCfg;
-template <> struct SortCfg<Rec16> { static constexpr int IPT = 16; typedef Rec16Byte Dig; };
-template <> struct SortCfg<Tup0>  { static constexpr int IPT = 12; typedef Tup0Byte Dig; };
+template <> struct SortCfg<Rec16> { static constexpr int IPT = 8; static constexpr int NW = 16; typedef Rec16Byte Dig; };
+template <> struct SortCfg<Rec8>  { static constexpr int IPT = 16; static constexpr int NW = 16; typedef Rec8Shift Dig; };
+template <> struct SortCfg<Tup0>  { static constexpr int IPT = 6; static constexpr int NW = 16; typedef Tup0Byte Dig; };
+
+template <class Dig> static Dig make_digit(u32 pass, u32) { Dig d; d.p = pass; return d; }
+template <> Rec8Shift make_digit<Rec8Shift>(u32 pass, u32 shift0) { Rec8Shift d; d.shift = shift0 + 8 * pass; return d; }
 
 template <class Rec>
 static int radix_sort(dc3hip_ctx *c, Rec *a, Rec *b, u32 n, u32 nbytes, Rec **result, int ph_up, int ph_scan,
-                      int ph_down) {
+                      int ph_down, u32 digit_shift = 0) {
   typedef typename SortCfg<Rec>::Dig Dig;
   constexpr int IPT = SortCfg<Rec>::IPT;
-  constexpr int kTile = kBlock * IPT;
-  const size_t smem = DownsweepSmem<Rec, IPT>::kBytes;
+  constexpr int NW = SortCfg<Rec>::NW;
+  constexpr int kTile = NW * 64 * IPT;
+  const size_t smem = DownsweepSmem<Rec, IPT, NW>::kBytes;
   static thread_local bool attr_set[16] = {false};
-  auto kern = k_rs_downsweep<Rec, Dig, IPT>;
+  auto kern = k_rs_downsweep<Rec, Dig, IPT, NW>;
   if (!attr_set[c->device & 15]) {
     HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)smem));
@@ -180,11 +187,12 @@ static int radix_sort(dc3hip_ctx *c, Rec *a, Rec *b, u32 n, u32 nbytes, Rec **re
   }
   const Chunking ck = make_chunks(c, n, kTile);
   const ArenaMark mk = arena_mark(c);
-  u32 *table = nullptr;
+  u32 *table = nullptr, *digit_base = nullptr;
   RC(arena_alloc(c, (size_t)256 * ck.nchunks, &table));
+  RC(arena_alloc(c, (size_t)256, &digit_base));
   Rec *src = a, *dst = b;
   for (u32 p = 0; p < nbytes; p++) {
-    Dig dig; dig.p = p;
+    const Dig dig = make_digit<Dig>(p, digit_shift);
     {
       PhaseScope ps(c, ph_up, n);
       hipLaunchKernelGGL((k_rs_upsweep<Rec, Dig>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, src, n, ck.chunk,
@@ -193,20 +201,44 @@ static int radix_sort(dc3hip_ctx *c, Rec *a, Rec *b, u32 n, u32 nbytes, Rec **re
     }
     {
       PhaseScope ps(c, ph_scan, 256 * ck.nchunks);
-      hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, table, 256u * ck.nchunks,
-                         (u32 *)nullptr);
+      hipLaunchKernelGGL(k_scan_rows, dim3(256), dim3(kBlock), 0, c->stream, table, ck.nchunks, digit_base);
+      KCHECK();
+      hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, digit_base, 256u, (u32 *)nullptr);
       KCHECK();
     }
     {
       PhaseScope ps(c, ph_down, n);
-      hipLaunchKernelGGL(kern, dim3(ck.nchunks), dim3(kBlock), smem, c->stream, src, dst, n, ck.chunk, ck.nchunks,
-                         dig, table);
+      hipLaunchKernelGGL(kern, dim3(ck.nchunks), dim3(NW * 64), smem, c->stream, src, dst, n, ck.chunk, ck.nchunks,
+                         dig, table, digit_base);
       KCHECK();
     }
     std::swap(src, dst);
   }
   arena_release(c, mk);
   *result = src;
+  return E_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// out[key] = val for pairs whose keys are a bijection onto [0,n)  (R[SA12[i]] = i+1, lib.rs:106-108;
+// SA12[R[i]-1] = i, lib.rs:111-113).  Two partition passes by the high key bits, then windows of
+// 16384 destinations are assembled in LDS and stored with full lines.
+// ---------------------------------------------------------------------------------------------
+static int inverse_permute(dc3hip_ctx *c, Rec8 *a, Rec8 *b, u32 n, u32 *out, int phase) {
+  const u32 kb = bits_of(n > 0 ? n - 1 : 0);
+  const u32 top = kb > (u32)kInvWindowBits ? kb - kInvWindowBits : 0;
+  Rec8 *sorted = a;
+  if (top > 0) RC(radix_sort<Rec8>(c, a, b, n, (top + 7) / 8, &sorted, phase, phase, phase, (u32)kInvWindowBits));
+  static thread_local bool attr_set[16] = {false};
+  if (!attr_set[c->device & 15]) {
+    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_invperm_local),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, kInvWindow * 4));
+    attr_set[c->device & 15] = true;
+  }
+  PhaseScope ps(c, phase, n);
+  hipLaunchKernelGGL(k_invperm_local, dim3((n + kInvWindow - 1) / kInvWindow), dim3(1024), kInvWindow * 4, c->stream,
+                     sorted, n, out);
+  KCHECK();
   return E_OK;
 }
 
@@ -279,10 +311,16 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
     names = c->h_words[0];
     if (names == m02) {
       // all names unique (lib.rs:109-113): the sorted order IS the suffix array of the sample
-      PhaseScope ps(c, DC3HIP_PH_RANKS, m02);
-      hipLaunchKernelGGL(k_assign_unique, dim3(grid_for(c, m02)), dim3(kBlock), 0, c->stream, sorted, m02, m0, sa12,
-                         rank12);
-      KCHECK();
+      Rec8 *pa = nullptr, *pb = nullptr;
+      RC(arena_alloc(c, (size_t)m02, &pa));
+      RC(arena_alloc(c, (size_t)m02, &pb));
+      {
+        PhaseScope ps(c, DC3HIP_PH_RANKS, m02);
+        hipLaunchKernelGGL(k_assign_unique, dim3(grid_for(c, m02)), dim3(kBlock), 0, c->stream, sorted, m02, m0,
+                           sa12, pa);
+        KCHECK();
+      }
+      RC(inverse_permute(c, pa, pb, m02, rank12, DC3HIP_PH_RANKS));
       arena_release(c, mk1);
     } else {
       {
@@ -306,8 +344,9 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
 
   // ---- Step 2 + 3: tuples, mod-0 order, merge -------------------------------------------------
   Tup12 *tslot = nullptr, *t12 = nullptr;
-  RC(arena_alloc(c, (size_t)m02, &tslot));
   RC(arena_alloc(c, (size_t)m02, &t12));
+  const ArenaMark mk_tslot = arena_mark(c);
+  RC(arena_alloc(c, (size_t)m02, &tslot));
   {
     PhaseScope ps(c, DC3HIP_PH_TUPLES, m02);
     hipLaunchKernelGGL((k_build_tuples<Sym>), dim3(grid_for(c, m0)), dim3(kBlock), 0, c->stream, S, m, m0, m02,
@@ -316,6 +355,7 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
     hipLaunchKernelGGL(k_gather_tuples, dim3(grid_for(c, m02)), dim3(kBlock), 0, c->stream, tslot, sa12, m02, t12);
     KCHECK();
   }
+  arena_release(c, mk_tslot);   // slot-order tuples are dead; their space is reused below
   Tup0 *z0 = nullptr, *z1 = nullptr, *zs = nullptr;
   RC(arena_alloc(c, (size_t)m0, &z0));
   RC(arena_alloc(c, (size_t)m0, &z1));
@@ -331,20 +371,28 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
     hipLaunchKernelGGL(k_mod0_write, dim3(ck.nchunks), dim3(kBlock), 0, c->stream, t12, m02, ck.chunk, counts, z0);
     KCHECK();
   }
-  RC(radix_sort<Tup0>(c, z0, z1, m0, (bits_of(K) + 7) / 8, &zs, DC3HIP_PH_SORT0, DC3HIP_PH_SORT0, DC3HIP_PH_SORT0));
+  RC(radix_sort<Tup0>(c, z0, z1, m0, (bits_of(K - 1) + 7) / 8, &zs, DC3HIP_PH_SORT0, DC3HIP_PH_SORT0, DC3HIP_PH_SORT0));
   {
     const u32 dskip = m0 - m1;                  // lib.rs:133: skip the dummy, which sorts first
     const u32 nA = m02 - dskip, nB = m0;
     const u32 ntiles = (m + kMergeTile - 1) / kMergeTile;
     u32 *part = nullptr;
     RC(arena_alloc(c, (size_t)ntiles + 16, &part));
-    PhaseScope ps(c, DC3HIP_PH_MERGE, m);
-    hipLaunchKernelGGL(k_merge_partition, dim3((ntiles + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
-                       t12 + dskip, nA, zs, nB, ntiles, part);
-    KCHECK();
-    hipLaunchKernelGGL(k_merge, dim3(ntiles), dim3(kBlock), 0, c->stream, t12 + dskip, nA, zs, nB, part, out_sa,
-                       out_rank);
-    KCHECK();
+    Rec8 *pa = nullptr, *pb = nullptr;
+    if (out_rank) {
+      RC(arena_alloc(c, (size_t)m, &pa));
+      RC(arena_alloc(c, (size_t)m, &pb));
+    }
+    {
+      PhaseScope ps(c, DC3HIP_PH_MERGE, m);
+      hipLaunchKernelGGL(k_merge_partition, dim3((ntiles + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
+                         t12 + dskip, nA, zs, nB, ntiles, part);
+      KCHECK();
+      hipLaunchKernelGGL(k_merge, dim3(ntiles), dim3(kBlock), 0, c->stream, t12 + dskip, nA, zs, nB, part, out_sa,
+                         pa);
+      KCHECK();
+    }
+    if (out_rank) RC(inverse_permute(c, pa, pb, m, out_rank, DC3HIP_PH_RANKS));
   }
   arena_release(c, mk0);
   return E_OK;
