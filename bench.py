@@ -137,12 +137,14 @@ def main():
     barrier()
     t0 = time.perf_counter()
     kernel_ms = 0.0
-    dsw_ms = 0.0; dsw_launches = 0; dsw_elems = 0
+    dsw_ms = [0.0] * 3; dsw_launches = [0] * 3; dsw_elems = [0] * 3
     for _ in range(args.steps):
         ctx.build()
         st = ctx.stats()
         kernel_ms += st["build_ms"]
-        dsw_ms += st["downsweep16_ms"]; dsw_launches += st["downsweep16_launches"]; dsw_elems += st["downsweep16_elems"]
+        for k in range(3):
+            dsw_ms[k] += st["downsweep_ms"][k]; dsw_launches[k] += st["downsweep_launches"][k]
+            dsw_elems[k] += st["downsweep_elems"][k]
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -157,21 +159,27 @@ def main():
     out = None
     if rank == 0:
         value = total_len * args.steps / dt / 1e6
-        # dominant kernel: stable radix scatter of 16-byte triple records (k_rs_downsweep<Rec16>).
-        # algorithmic bytes per record-pass = reference scatter loop lib.rs:35-38: read a[i] (w) +
+        # dominant kernel: the stable 8-bit radix scatter k_rs_downsweep<Rec,...> — the record type
+        # (8-byte pairs / 16-byte triple records / 20-byte mod-0 tuples) with the largest summed time.
+        # algorithmic bytes per record-pass = the reference's scatter loop lib.rs:35-38: read a[i] (w) +
         # r[a[i]] (c) + write b[..] (w) = 2w + c = 12 B at w = c = 4 (scatter half).
         roof = None
-        if dsw_launches:
-            per_launch_elems = dsw_elems / dsw_launches
-            avg_ms = dsw_ms / dsw_launches
+        kc = max(range(3), key=lambda k: dsw_ms[k])
+        if dsw_launches[kc]:
+            rec_bytes = (8, 16, 20)[kc]
+            rec_name = ("Rec8 (key,value) pairs", "Rec16 triple records", "Tup0 mod-0 tuples")[kc]
+            per_launch_elems = dsw_elems[kc] / dsw_launches[kc]
+            avg_ms = dsw_ms[kc] / dsw_launches[kc]
             achieved = 12.0 * per_launch_elems / (avg_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "k_rs_downsweep<Rec16> (stable 8-bit radix scatter of triple records)",
+            roof = {"bound": "hbm", "kernel": f"k_rs_downsweep<{rec_name.split()[0]}> (stable 8-bit radix scatter of {rec_name})",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": None,
                     "algorithmic_bytes_per_launch": 12.0 * per_launch_elems, "avg_launch_ms": avg_ms,
-                    "launches_per_step": dsw_launches / args.steps,
-                    "moved_bytes_per_launch": 32.0 * per_launch_elems,
-                    "moved_GBps": 32.0 * per_launch_elems / (avg_ms * 1e-3) / 1e9}
+                    "launches_per_step": dsw_launches[kc] / args.steps,
+                    "share_of_build_time": dsw_ms[kc] / kernel_ms,
+                    "moved_bytes_per_launch": 2.0 * rec_bytes * per_launch_elems,
+                    "moved_GBps": 2.0 * rec_bytes * per_launch_elems / (avg_ms * 1e-3) / 1e9,
+                    "all_record_types_ms_per_step": [x / args.steps for x in dsw_ms]}
         alg = algorithmic_bytes(st["level_n"])
         path = {"algorithmic_bytes_per_step": alg, "device_ms_per_step": kernel_ms / args.steps,
                 "achieved_GBps": alg / (kernel_ms / args.steps * 1e-3) / 1e9,

@@ -106,6 +106,8 @@ enum dc3hip_phase {
   DC3HIP_PH_SORT12_UP,      /* radix passes on sample triples: digit histograms   (ref lib.rs:20-22) */
   DC3HIP_PH_SORT12_SCAN,    /*                                 prefix sums        (ref lib.rs:25-32) */
   DC3HIP_PH_SORT12_DOWN,    /*                                 stable scatter     (ref lib.rs:35-38) */
+  DC3HIP_PH_SORT8_DOWN,     /* same, 8-byte (top-32-bit key, pos) records of the prefix-sort path */
+  DC3HIP_PH_TIES,           /* tie detection / compaction / write-back of the prefix-sort path */
   DC3HIP_PH_NAMING,         /* flag/scan/assign lexicographic names               (ref lib.rs:80-100) */
   DC3HIP_PH_RANKS,          /* rank <- SA12 inversion                             (ref lib.rs:106-113) */
   DC3HIP_PH_TUPLES,         /* merge tuples in slot order + gather to SA12 order */
@@ -121,14 +123,18 @@ typedef struct dc3hip_stats {
   int32_t levels;                         /* recursion depth reached by the last build */
   int64_t level_n[DC3HIP_MAX_LEVELS];     /* string length per level (level 0 = n) */
   int64_t level_K[DC3HIP_MAX_LEVELS];     /* alphabet bound per level */
-  int32_t level_sorted[DC3HIP_MAX_LEVELS];/* 1 = names by radix sort, 0 = direct packed names */
+  int32_t level_sorted[DC3HIP_MAX_LEVELS];/* 0 = direct packed names, 1 = names by full radix sort,
+                                             2 = names by prefix sort + tie refinement */
+  int64_t level_tied[DC3HIP_MAX_LEVELS];  /* samples re-sorted by the full key (prefix-sort path) */
+  double  level_tie_pred[DC3HIP_MAX_LEVELS]; /* predicted tied fraction (policy input) */
   double  build_ms;                       /* HIP-event time of the whole device-resident build */
   double  phase_ms[DC3HIP_PH_COUNT];      /* HIP-event time per phase, summed over levels */
   int64_t phase_launches[DC3HIP_PH_COUNT];
-  /* dominant kernel (stable radix scatter of 16-byte triple records): */
-  double  downsweep16_ms;                 /* summed HIP-event time of its launches */
-  int64_t downsweep16_launches;
-  int64_t downsweep16_elems;              /* records moved, summed over launches */
+  /* the stable radix scatter kernel k_rs_downsweep<Rec,...>, per record type:
+   * [0] 8-byte (key,value) pairs, [1] 16-byte triple records, [2] 20-byte mod-0 tuples */
+  double  downsweep_ms[3];                /* summed HIP-event time of the launches */
+  int64_t downsweep_launches[3];
+  int64_t downsweep_elems[3];             /* records moved, summed over launches */
   int64_t arena_bytes;                    /* device work arena size */
   int64_t arena_peak;                     /* high-water mark of the last build */
 } dc3hip_stats;

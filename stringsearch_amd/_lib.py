@@ -6,7 +6,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 lib_path = os.path.join(_HERE, "libdc3hip.so")
 
 MAX_LEVELS = 48
-PHASES = ["alphabet", "name_direct", "pack", "sort12_up", "sort12_scan", "sort12_down", "naming", "ranks",
+PHASES = ["alphabet", "name_direct", "pack", "sort12_up", "sort12_scan", "sort12_down", "sort8_down", "ties", "naming", "ranks",
           "tuples", "compact", "sort0", "merge", "other"]
 
 
@@ -25,10 +25,11 @@ class Stats(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_int32), ("levels", ctypes.c_int32),
                 ("level_n", ctypes.c_int64 * MAX_LEVELS), ("level_K", ctypes.c_int64 * MAX_LEVELS),
                 ("level_sorted", ctypes.c_int32 * MAX_LEVELS),
+                ("level_tied", ctypes.c_int64 * MAX_LEVELS), ("level_tie_pred", ctypes.c_double * MAX_LEVELS),
                 ("build_ms", ctypes.c_double), ("phase_ms", ctypes.c_double * len(PHASES)),
                 ("phase_launches", ctypes.c_int64 * len(PHASES)),
-                ("downsweep16_ms", ctypes.c_double), ("downsweep16_launches", ctypes.c_int64),
-                ("downsweep16_elems", ctypes.c_int64), ("arena_bytes", ctypes.c_int64),
+                ("downsweep_ms", ctypes.c_double * 3), ("downsweep_launches", ctypes.c_int64 * 3),
+                ("downsweep_elems", ctypes.c_int64 * 3), ("arena_bytes", ctypes.c_int64),
                 ("arena_peak", ctypes.c_int64)]
 
     def as_dict(self):
@@ -37,11 +38,13 @@ class Stats(ctypes.Structure):
             "level_n": [self.level_n[i] for i in range(self.levels)],
             "level_K": [self.level_K[i] for i in range(self.levels)],
             "level_sorted": [self.level_sorted[i] for i in range(self.levels)],
+            "level_tied": [self.level_tied[i] for i in range(self.levels)],
+            "level_tie_pred": [self.level_tie_pred[i] for i in range(self.levels)],
             "build_ms": self.build_ms,
             "phase_ms": {PHASES[i]: self.phase_ms[i] for i in range(len(PHASES))},
             "phase_launches": {PHASES[i]: self.phase_launches[i] for i in range(len(PHASES))},
-            "downsweep16_ms": self.downsweep16_ms, "downsweep16_launches": self.downsweep16_launches,
-            "downsweep16_elems": self.downsweep16_elems,
+            "downsweep_ms": list(self.downsweep_ms), "downsweep_launches": list(self.downsweep_launches),
+            "downsweep_elems": list(self.downsweep_elems),
             "arena_bytes": self.arena_bytes, "arena_peak": self.arena_peak,
         }
 

@@ -161,15 +161,20 @@ __global__ __launch_bounds__(kBlock) void k_name_direct(Sym S, u32 m, u32 m0, u3
 
 // ---------------------------------------------------------------------------------------------
 // Triple records in position order (lib.rs:62-70 fused with the key reads of :74-76).
-// key = s0<<2b | s1<<b | s2  (96-bit, b = bit width of K), thread g emits records of 3g+1, 3g+2
+// key = (s0*B + s1)*B + s2 (up to 93 bits, B = K+1), thread g emits records of 3g+1, 3g+2
 // at indices 2g, 2g+1 — i.e. ascending text position like the reference's R.
 // n12 = number of sample positions = m02.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ Rec16 make_rec(u32 s0, u32 s1, u32 s2, u32 b, u32 pos) {
-  const u64 lo = (u64)s2 | ((u64)s1 << b);                 // bits [0,2b), 2b <= 62
-  const u64 lo64 = lo | ((u64)s0 << (2 * b));              // truncating shift is intended
-  const u32 hi = (2 * b > 32) ? (u32)((u64)s0 >> (64 - 2 * b)) : 0u;
-  Rec16 r; r.k0 = (u32)lo64; r.k1 = (u32)(lo64 >> 32); r.k2 = hi; r.pos = pos;
+// key = (s0*B + s1)*B + s2 with B = K+1 (dense arithmetic packing: no bits are wasted when K is
+// not a power of two, which keeps the top 32 key bits discriminating for the prefix-sort path)
+__device__ __forceinline__ Rec16 make_rec(u32 s0, u32 s1, u32 s2, u32 B, u32 pos) {
+  const u64 lo = (u64)s1 * B + s2;                     // < B^2 <= 2^62
+  const u64 B2 = (u64)B * B;
+  const u64 p_lo = (u64)s0 * B2;
+  u64 p_hi = __umul64hi((u64)s0, B2);
+  const u64 s_lo = p_lo + lo;
+  p_hi += (s_lo < p_lo) ? 1u : 0u;
+  Rec16 r; r.k0 = (u32)s_lo; r.k1 = (u32)(s_lo >> 32); r.k2 = (u32)p_hi; r.pos = pos;
   return r;
 }
 template <class Sym>
@@ -340,11 +345,15 @@ __global__ __launch_bounds__(kBlock) void k_scan_rows(u32 *__restrict__ table, u
 
 // ---------------------------------------------------------------------------------------------
 // Naming (lib.rs:80-100): name = 1 + number of key changes before i in the sorted order.
-//   k_name_count : per-chunk count of "key differs from predecessor" flags
+// The kernels are generic over an accessor of the sorted sample order:
+//   AccRec16 : fully sorted 16-byte records (straight LSD path)
+//   AccHyb   : (pos, "differs from predecessor" byte) arrays of the prefix-sort + tie-refine path
+//   k_name_count  : per-chunk count of "key differs from predecessor" flags
 //   (scan of the counts, total = number of distinct names)
-//   k_name_assign: R[slot(pos_i)] = name_i                      (lib.rs:93-98)
-//   k_assign_unique: when every name is unique (lib.rs:109-113), SA12[i] = slot(pos_i) and
-//                    rank[slot(pos_i)] = i+1 directly
+//   k_name_assign : emits (slot(pos_i), name_i) pairs      (R[..] = name, lib.rs:93-98)
+//   k_assign_unique: when every name is unique (lib.rs:109-113), SA12[i] = slot(pos_i) and the
+//                    pairs (slot(pos_i), i+1)
+// The pairs go through the windowed inversion (k_invperm_local) instead of a random scatter.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool key_neq(const Rec16 &a, const Rec16 &b) {
   return (a.k0 != b.k0) | (a.k1 != b.k1) | (a.k2 != b.k2);
@@ -353,52 +362,51 @@ __device__ __forceinline__ u32 slot_of(u32 pos, u32 m0) {
   const u32 q = pos / 3, rem = pos - 3 * q;
   return rem == 1 ? q : q + m0;
 }
+struct AccRec16 {
+  const Rec16 *s;
+  __device__ __forceinline__ u32 pos(u32 i) const { return s[i].pos; }
+  __device__ __forceinline__ u32 neq(u32 i) const {
+    if (i == 0) return 1u;
+    const Rec16 a = s[i], b = s[i - 1];
+    return key_neq(a, b) ? 1u : 0u;
+  }
+};
+struct AccHyb {
+  const Rec8 *h; const uint8_t *f;     // h[i].val = pos; f[i] = 1 iff key(i) != key(i-1)
+  __device__ __forceinline__ u32 pos(u32 i) const { return h[i].val; }
+  __device__ __forceinline__ u32 neq(u32 i) const { return f[i]; }
+};
 
 constexpr int kNameIPT = 4;
-__global__ __launch_bounds__(kBlock) void k_name_count(const Rec16 *__restrict__ s, u32 n, u32 chunk, u32 *counts) {
+template <class Acc>
+__global__ __launch_bounds__(kBlock) void k_name_count(Acc acc, u32 n, u32 chunk, u32 *counts) {
   __shared__ u32 tmp[kWaves];
   const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
   u32 c = 0;
-  for (u32 i = begin + threadIdx.x; i < end; i += kBlock) {
-    const Rec16 cur = s[i];
-    bool f = true;
-    if (i > 0) { const Rec16 prev = s[i - 1]; f = key_neq(cur, prev); }
-    c += f ? 1u : 0u;
-  }
+  for (u32 i = begin + threadIdx.x; i < end; i += kBlock) c += acc.neq(i);
   c = wave_reduce(c);
   if (lane_id() == 0) tmp[wave_id()] = c;
   __syncthreads();
   if (threadIdx.x == 0) { u32 t = 0; for (int i = 0; i < kWaves; i++) t += tmp[i]; counts[blockIdx.x] = t; }
 }
-__global__ __launch_bounds__(kBlock) void k_name_assign(const Rec16 *__restrict__ s, u32 n, u32 chunk,
-                                                       const u32 *__restrict__ base_excl, u32 m0,
-                                                       u32 *__restrict__ R) {
+template <class Acc>
+__global__ __launch_bounds__(kBlock) void k_name_assign(Acc acc, u32 n, u32 chunk, const u32 *__restrict__ base_excl,
+                                                       u32 m0, Rec8 *__restrict__ pairs) {
   __shared__ u32 tmp[kWaves];
   const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
   u32 running = base_excl[blockIdx.x];
   constexpr u32 kTile = kBlock * kNameIPT;
   for (u32 tile = begin; tile < end; tile += kTile) {
     const u32 i0 = tile + threadIdx.x * kNameIPT;
-    Rec16 prev;
-    bool havePrev = false;
-    if (i0 > 0 && i0 < end) { prev = s[i0 - 1]; havePrev = true; }
-    u32 f[kNameIPT], pos[kNameIPT];
+    u32 f[kNameIPT];
     u32 local = 0;
 #pragma unroll
-    for (int j = 0; j < kNameIPT; j++) {
-      f[j] = 0; pos[j] = 0;
-      if (i0 + j < end) {
-        const Rec16 cur = s[i0 + j];
-        f[j] = (!havePrev || key_neq(cur, prev)) ? 1u : 0u;
-        pos[j] = cur.pos; prev = cur; havePrev = true;
-      }
-      local += f[j];
-    }
+    for (int j = 0; j < kNameIPT; j++) { f[j] = (i0 + j < end) ? acc.neq(i0 + j) : 0u; local += f[j]; }
     u32 tot;
     u32 name = running + block_excl_scan<kWaves>(local, tmp, tot);
 #pragma unroll
     for (int j = 0; j < kNameIPT; j++) {
-      if (i0 + j < end) { name += f[j]; R[slot_of(pos[j], m0)] = name; }
+      if (i0 + j < end) { name += f[j]; pairs[i0 + j] = Rec8{slot_of(acc.pos(i0 + j), m0), name}; }
     }
     running += tot;
   }
@@ -406,10 +414,11 @@ __global__ __launch_bounds__(kBlock) void k_name_assign(const Rec16 *__restrict_
 // Emits (slot, i+1) pairs (coalesced) for the windowed inversion below instead of scattering 4-byte
 // ranks: random 4-byte stores run at ~25 G/s on MI355X (profiles/r01_membench_access_patterns.txt),
 // a partition by destination window + LDS-local placement is > 2x faster.
-__global__ __launch_bounds__(kBlock) void k_assign_unique(const Rec16 *__restrict__ s, u32 n, u32 m0,
-                                                         u32 *__restrict__ sa12, Rec8 *__restrict__ pairs) {
+template <class Acc>
+__global__ __launch_bounds__(kBlock) void k_assign_unique(Acc acc, u32 n, u32 m0, u32 *__restrict__ sa12,
+                                                         Rec8 *__restrict__ pairs) {
   for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-    const u32 sl = slot_of(s[i].pos, m0);
+    const u32 sl = slot_of(acc.pos(i), m0);
     sa12[i] = sl;
     pairs[i] = Rec8{sl, i + 1};
   }
@@ -432,6 +441,85 @@ __global__ __launch_bounds__(1024) void k_invperm_local(const Rec8 *__restrict__
   __syncthreads();
   for (u32 i = threadIdx.x; i < cnt; i += 1024) out[base + i] = win[i];
 }
+
+// ---------------------------------------------------------------------------------------------
+// Prefix-sort + tie-refine ordering of the sample triples (replaces the 3x radix_pass of
+// lib.rs:74-76 when most 3b-bit keys are already distinct in their top 32 bits):
+//   1. (hi32, pos) 8-byte records, 4 stable LSD passes                       [all samples]
+//   2. elements whose hi32 equals a neighbour's are "tied"; only those are re-sorted by the full
+//      3b-bit key as 16-byte records and written back into the tied slots (same relative order)
+// Result: h[i].val = position of the i-th smallest triple, f[i] = key differs from predecessor.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 key_bits32(const Rec16 &r, u32 sh) {   // bits [sh, sh+32) of the 96-bit key
+  const u32 w = sh >> 5, off = sh & 31;
+  const u32 a = w == 0 ? r.k0 : (w == 1 ? r.k1 : r.k2);
+  const u32 bnext = w == 0 ? r.k1 : (w == 1 ? r.k2 : 0u);
+  return off ? ((a >> off) | (bnext << (32 - off))) : a;
+}
+// stride > 1 samples every stride-th group (tie-rate predictor); out index = g / stride
+template <class Sym>
+__global__ __launch_bounds__(kBlock) void k_pack_hi32(Sym S, u32 m, u32 m0, u32 m02, u32 b, u32 sh, u32 stride,
+                                                     u32 ngroups_out, Rec8 *out) {
+  for (u32 go = blockIdx.x * kBlock + threadIdx.x; go < ngroups_out; go += gridDim.x * kBlock) {
+    const u32 g = go * stride;
+    const u32 i = 3 * g + 1;
+    const u32 s1 = S.get(i), s2 = S.get(i + 1), s3 = S.get(i + 2), s4 = S.get(i + 3);
+    out[2 * go] = Rec8{key_bits32(make_rec(s1, s2, s3, b, i), sh), i};
+    if (stride > 1 || 2 * g + 1 < m02) {
+      // (in sampling mode a possibly non-existent last mod-2 sample only perturbs the estimate)
+      if (2 * g + 1 < m02) out[2 * go + 1] = Rec8{key_bits32(make_rec(s2, s3, s4, b, i + 1), sh), i + 1};
+      else out[2 * go + 1] = Rec8{0xffffffffu, i + 1};
+    }
+  }
+}
+__device__ __forceinline__ bool hyb_tied(const Rec8 *h, u32 i, u32 n) {
+  const u32 a = h[i].key;
+  return (i > 0 && h[i - 1].key == a) || (i + 1 < n && h[i + 1].key == a);
+}
+__global__ __launch_bounds__(kBlock) void k_tie_count(const Rec8 *__restrict__ h, u32 n, u32 chunk, u32 *counts) {
+  __shared__ u32 tmp[kWaves];
+  const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
+  u32 c = 0;
+  for (u32 i = begin + threadIdx.x; i < end; i += kBlock) c += hyb_tied(h, i, n) ? 1u : 0u;
+  c = wave_reduce(c);
+  if (lane_id() == 0) tmp[wave_id()] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) { u32 t = 0; for (int i = 0; i < kWaves; i++) t += tmp[i]; counts[blockIdx.x] = t; }
+}
+// compacts the tied elements (order preserving): full-key record rebuilt from S, and the index of
+// the slot it came from
+template <class Sym>
+__global__ __launch_bounds__(kBlock) void k_tie_compact(Sym S, u32 b, const Rec8 *__restrict__ h, u32 n, u32 chunk,
+                                                       const u32 *__restrict__ base_excl, Rec16 *__restrict__ sub,
+                                                       u32 *__restrict__ tiedidx) {
+  __shared__ u32 tmp[kWaves];
+  const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
+  u32 running = base_excl[blockIdx.x];
+  for (u32 tile = begin; tile < end; tile += kBlock) {
+    const u32 i = tile + threadIdx.x;
+    const bool f = (i < end) && hyb_tied(h, i, n);
+    u32 tot;
+    const u32 ex = block_excl_scan<kWaves>(f ? 1u : 0u, tmp, tot);
+    if (f) {
+      const u32 p = h[i].val;
+      sub[running + ex] = make_rec(S.get(p), S.get(p + 1), S.get(p + 2), b, p);
+      tiedidx[running + ex] = i;
+    }
+    running += tot;
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_tie_writeback(const Rec16 *__restrict__ sub, const u32 *__restrict__ tiedidx,
+                                                         u32 t, Rec8 *__restrict__ h, uint8_t *__restrict__ f) {
+  for (u32 j = blockIdx.x * kBlock + threadIdx.x; j < t; j += gridDim.x * kBlock) {
+    const Rec16 cur = sub[j];
+    const u32 i = tiedidx[j];
+    h[i].val = cur.pos;
+    bool ne = true;
+    if (j > 0) { const Rec16 prev = sub[j - 1]; ne = key_neq(cur, prev); }
+    f[i] = ne ? 1 : 0;
+  }
+}
+
 __global__ void k_base1(u32 *out_sa, u32 *out_rank) {
   if (threadIdx.x == 0) { if (out_sa) out_sa[0] = 0; if (out_rank) out_rank[0] = 1; }
 }

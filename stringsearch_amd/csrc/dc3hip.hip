@@ -13,6 +13,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -48,7 +49,7 @@ enum { E_OK = 0, E_ARGS = -1, E_ALLOC = -2, E_HIP = -3, E_TOOBIG = -4 };
 // ---------------------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------------------
-struct PhaseMark { int phase; hipEvent_t a, b; int64_t elems; };
+struct PhaseMark { int phase; hipEvent_t a, b; int64_t elems; int kclass; };
 
 struct dc3hip_ctx {
   int device = 0;
@@ -66,6 +67,7 @@ struct dc3hip_ctx {
   u32 *h_words = nullptr;      // pinned mirror
   // profiling
   bool profile = true;
+  bool no_hybrid = false;
   std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
   std::vector<PhaseMark> marks;
   hipEvent_t ev_build_a = nullptr, ev_build_b = nullptr;
@@ -126,9 +128,9 @@ static hipEvent_t get_event(dc3hip_ctx *c) {
 }
 struct PhaseScope {
   dc3hip_ctx *c; size_t idx; bool on;
-  PhaseScope(dc3hip_ctx *ctx, int phase, int64_t elems = 0) : c(ctx), idx(0), on(ctx->profile) {
+  PhaseScope(dc3hip_ctx *ctx, int phase, int64_t elems = 0, int kclass = -1) : c(ctx), idx(0), on(ctx->profile) {
     if (!on) return;
-    PhaseMark m; m.phase = phase; m.a = get_event(c); m.b = get_event(c); m.elems = elems;
+    PhaseMark m; m.phase = phase; m.a = get_event(c); m.b = get_event(c); m.elems = elems; m.kclass = kclass;
     if (!m.a || !m.b) { on = false; return; }
     (void)hipEventRecord(m.a, c->stream);
     idx = c->marks.size(); c->marks.push_back(m);
@@ -163,9 +165,9 @@ static Chunking make_chunks(dc3hip_ctx *c, u32 n, u32 tile) {
 // stable LSD radix sort over `nbytes` key bytes (lib.rs:15-39 per digit)
 // ---------------------------------------------------------------------------------------------
 template <class Rec> struct SortCfg;
-template <> struct SortCfg<Rec16> { static constexpr int IPT = 8; static constexpr int NW = 16; typedef Rec16Byte Dig; };
-template <> struct SortCfg<Rec8>  { static constexpr int IPT = 16; static constexpr int NW = 16; typedef Rec8Shift Dig; };
-template <> struct SortCfg<Tup0>  { static constexpr int IPT = 6; static constexpr int NW = 16; typedef Tup0Byte Dig; };
+template <> struct SortCfg<Rec8>  { static constexpr int IPT = 16, NW = 16, kClass = 0; typedef Rec8Shift Dig; };
+template <> struct SortCfg<Rec16> { static constexpr int IPT = 8, NW = 16, kClass = 1; typedef Rec16Byte Dig; };
+template <> struct SortCfg<Tup0>  { static constexpr int IPT = 6, NW = 16, kClass = 2; typedef Tup0Byte Dig; };
 
 template <class Dig> static Dig make_digit(u32 pass, u32) { Dig d; d.p = pass; return d; }
 template <> Rec8Shift make_digit<Rec8Shift>(u32 pass, u32 shift0) { Rec8Shift d; d.shift = shift0 + 8 * pass; return d; }
@@ -207,7 +209,7 @@ static int radix_sort(dc3hip_ctx *c, Rec *a, Rec *b, u32 n, u32 nbytes, Rec **re
       KCHECK();
     }
     {
-      PhaseScope ps(c, ph_down, n);
+      PhaseScope ps(c, ph_down, n, SortCfg<Rec>::kClass);
       hipLaunchKernelGGL(kern, dim3(ck.nchunks), dim3(NW * 64), smem, c->stream, src, dst, n, ck.chunk, ck.nchunks,
                          dig, table, digit_base);
       KCHECK();
@@ -243,6 +245,156 @@ static int inverse_permute(dc3hip_ctx *c, Rec8 *a, Rec8 *b, u32 n, u32 *out, int
 }
 
 // ---------------------------------------------------------------------------------------------
+// naming + rank/name placement shared by both ordering paths (lib.rs:80-113).
+//   unique names  -> sa12[i] = slot(pos_i), rank12 = inverse            (lib.rs:109-113)
+//   otherwise     -> R[slot(pos_i)] = name_i (+ zero tail), caller recurses (lib.rs:93-104)
+// ---------------------------------------------------------------------------------------------
+template <class Acc>
+static int name_and_rank(dc3hip_ctx *c, Acc acc, u32 m02, u32 m0, u32 *sa12, u32 *rank12, u32 *R, u32 *names_out) {
+  const ArenaMark mk = arena_mark(c);
+  const Chunking ck = make_chunks(c, m02, kBlock * kNameIPT);
+  u32 *counts = nullptr;
+  RC(arena_alloc(c, (size_t)ck.nchunks + 16, &counts));
+  {
+    PhaseScope ps(c, DC3HIP_PH_NAMING, m02);
+    hipLaunchKernelGGL((k_name_count<Acc>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, acc, m02, ck.chunk, counts);
+    KCHECK();
+    hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, counts, ck.nchunks, c->d_words);
+    KCHECK();
+    HIPC(hipMemcpyAsync(c->h_words, c->d_words, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPC(hipStreamSynchronize(c->stream));     // the lib.rs:103 decision needs the name count
+  const u32 names = c->h_words[0];
+  *names_out = names;
+  Rec8 *pa = nullptr, *pb = nullptr;
+  RC(arena_alloc(c, (size_t)m02, &pa));
+  RC(arena_alloc(c, (size_t)m02, &pb));
+  if (names == m02) {
+    {
+      PhaseScope ps(c, DC3HIP_PH_RANKS, m02);
+      hipLaunchKernelGGL((k_assign_unique<Acc>), dim3(grid_for(c, m02)), dim3(kBlock), 0, c->stream, acc, m02, m0,
+                         sa12, pa);
+      KCHECK();
+    }
+    RC(inverse_permute(c, pa, pb, m02, rank12, DC3HIP_PH_RANKS));
+  } else {
+    {
+      PhaseScope ps(c, DC3HIP_PH_NAMING, m02);
+      hipLaunchKernelGGL((k_name_assign<Acc>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, acc, m02, ck.chunk,
+                         counts, m0, pa);
+      KCHECK();
+    }
+    RC(inverse_permute(c, pa, pb, m02, R, DC3HIP_PH_NAMING));
+    hipLaunchKernelGGL(k_zero_tail, dim3(1), dim3(64), 0, c->stream, R, m02, 8u);
+    KCHECK();
+  }
+  arena_release(c, mk);
+  return E_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// prefix-sort + tie-refine ordering (see dc3_kernels.cuh).  Policy:
+//   * a strided sample of ~2^20 triples predicts the fraction of samples whose top 32 key bits
+//     collide; the path is taken when the prediction is below kHybridMaxPredicted,
+//   * and abandoned (falling back to the straight 16-byte LSD sort) if the measured fraction turns
+//     out above kHybridMaxMeasured.  Correctness never depends on the policy.
+// ---------------------------------------------------------------------------------------------
+static constexpr u32 kHybridMinSamples = 1u << 22;
+static constexpr double kHybridMaxPredicted = 0.50;
+static constexpr double kHybridMaxMeasured = 0.60;
+
+static int count_ties(dc3hip_ctx *c, const Rec8 *h, u32 n, u32 *counts, const Chunking &ck, u32 *total) {
+  hipLaunchKernelGGL(k_tie_count, dim3(ck.nchunks), dim3(kBlock), 0, c->stream, h, n, ck.chunk, counts);
+  KCHECK();
+  hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, counts, ck.nchunks, c->d_words + 2);
+  KCHECK();
+  HIPC(hipMemcpyAsync(c->h_words + 2, c->d_words + 2, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  *total = c->h_words[2];
+  return E_OK;
+}
+
+template <class Sym>
+static int predict_tie_fraction(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u32 sh, double *pred) {
+  const ArenaMark mk = arena_mark(c);
+  const u32 stride = std::max<u32>(1, m0 >> 19);
+  const u32 ng = (m0 - 1) / stride + 1;      // sampled groups, 2 records each
+  const u32 ns = 2 * ng;
+  Rec8 *a = nullptr, *bb = nullptr, *sorted = nullptr;
+  RC(arena_alloc(c, (size_t)ns, &a));
+  RC(arena_alloc(c, (size_t)ns, &bb));
+  PhaseScope ps(c, DC3HIP_PH_PACK, ns);
+  hipLaunchKernelGGL((k_pack_hi32<Sym>), dim3(grid_for(c, ng)), dim3(kBlock), 0, c->stream, S, m, m0, m02, b, sh,
+                     stride, ng, a);
+  KCHECK();
+  RC(radix_sort<Rec8>(c, a, bb, ns, 4, &sorted, DC3HIP_PH_PACK, DC3HIP_PH_PACK, DC3HIP_PH_PACK, 0));
+  const Chunking ck = make_chunks(c, ns, kBlock);
+  u32 *counts = nullptr;
+  RC(arena_alloc(c, (size_t)ck.nchunks + 16, &counts));
+  u32 ts = 0;
+  RC(count_ties(c, sorted, ns, counts, ck, &ts));
+  const double fs = (double)ts / (double)ns;
+  const double ratio = (double)(m02 - 1) / (double)(ns > 1 ? ns - 1 : 1);
+  *pred = fs >= 1.0 ? 1.0 : 1.0 - pow(1.0 - fs, ratio);
+  arena_release(c, mk);
+  return E_OK;
+}
+
+template <class Sym>
+static int order_hybrid(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u32 kbits, u32 nbytes, u32 *sa12,
+                        u32 *rank12, u32 *R, u32 *names, bool *ok, int depth) {
+  *ok = false;
+  Rec8 *ha = nullptr, *hb = nullptr, *h = nullptr;
+  uint8_t *f = nullptr;
+  RC(arena_alloc(c, (size_t)m02, &ha));
+  RC(arena_alloc(c, (size_t)m02, &hb));
+  RC(arena_alloc(c, (size_t)m02 + 16, &f));
+  {
+    PhaseScope ps(c, DC3HIP_PH_PACK, m02);
+    hipLaunchKernelGGL((k_pack_hi32<Sym>), dim3(grid_for(c, m0)), dim3(kBlock), 0, c->stream, S, m, m0, m02, b,
+                       kbits - 32, 1u, m0, ha);
+    KCHECK();
+  }
+  RC(radix_sort<Rec8>(c, ha, hb, m02, 4, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT8_DOWN, 0));
+  const Chunking ck = make_chunks(c, m02, kBlock);
+  u32 *counts = nullptr;
+  RC(arena_alloc(c, (size_t)ck.nchunks + 16, &counts));
+  u32 tied = 0;
+  {
+    PhaseScope ps(c, DC3HIP_PH_TIES, m02);
+    RC(count_ties(c, h, m02, counts, ck, &tied));
+  }
+  c->stats.level_tied[depth] = tied;
+  if ((double)tied > kHybridMaxMeasured * (double)m02) return E_OK;   // *ok stays false -> straight LSD
+  c->stats.level_sorted[depth] = 2;
+  HIPC(hipMemsetAsync(f, 1, (size_t)m02, c->stream));
+  if (tied > 0) {
+    Rec16 *sa = nullptr, *sb = nullptr, *ss = nullptr;
+    u32 *tiedidx = nullptr;
+    RC(arena_alloc(c, (size_t)tied, &sa));
+    RC(arena_alloc(c, (size_t)tied, &sb));
+    RC(arena_alloc(c, (size_t)tied, &tiedidx));
+    {
+      PhaseScope ps(c, DC3HIP_PH_TIES, tied);
+      hipLaunchKernelGGL((k_tie_compact<Sym>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, S, b, h, m02, ck.chunk,
+                         counts, sa, tiedidx);
+      KCHECK();
+    }
+    RC(radix_sort<Rec16>(c, sa, sb, tied, nbytes, &ss, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN,
+                         DC3HIP_PH_SORT12_DOWN));
+    {
+      PhaseScope ps(c, DC3HIP_PH_TIES, tied);
+      hipLaunchKernelGGL(k_tie_writeback, dim3(grid_for(c, tied)), dim3(kBlock), 0, c->stream, ss, tiedidx, tied, h, f);
+      KCHECK();
+    }
+  }
+  AccHyb acc; acc.h = h; acc.f = f;
+  RC(name_and_rank<AccHyb>(c, acc, m02, m0, sa12, rank12, R, names));
+  *ok = true;
+  return E_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // one DC3 level (lib.rs:44-193) on the device.
 //   S: symbols in 1..K with zero tail, m >= 2
 //   out_sa  : [m]      k-th smallest suffix -> position   (may be null)
@@ -268,7 +420,7 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
 
   const u64 B = K + 1;
   const bool direct = (B * B * B) <= 0x7fffffffull;
-  c->stats.level_sorted[depth] = direct ? 0 : 1;
+  c->stats.level_sorted[depth] = direct ? 0 : 1;   // 2 = prefix-sort + tie-refine
   if (direct) {
     // names = packed triples (order-preserving); always recurse (distinctness unknown)
     {
@@ -280,58 +432,43 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
     SymU32 RS; RS.s = R; RS.m = m02;
     RC(dc3_level<SymU32>(c, RS, m02, B * B * B, sa12, rank12, depth + 1));
   } else {
-    const u32 b = bits_of(K);
-    const u32 nbytes = (3 * b + 7) / 8;
+    const u32 b = (u32)B;                          // packing base of make_rec (K < 2^31)
+    u32 kbits = 0;                                 // bit width of B^3 - 1; > 32 here (else direct path)
+    { unsigned __int128 mx = (unsigned __int128)B * B * B - 1; while (mx) { kbits++; mx >>= 1; } }
+    const u32 nbytes = (kbits + 7) / 8;
     const ArenaMark mk1 = arena_mark(c);
-    Rec16 *recA = nullptr, *recB = nullptr, *sorted = nullptr;
-    RC(arena_alloc(c, (size_t)m02, &recA));
-    RC(arena_alloc(c, (size_t)m02, &recB));
-    {
-      PhaseScope ps(c, DC3HIP_PH_PACK, m02);
-      hipLaunchKernelGGL((k_pack_triples<Sym>), dim3(grid_for(c, m0)), dim3(kBlock), 0, c->stream, S, m, m0, m02, b,
-                         recA);
-      KCHECK();
-    }
-    RC(radix_sort<Rec16>(c, recA, recB, m02, nbytes, &sorted, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN,
-                         DC3HIP_PH_SORT12_DOWN));
-    // naming
-    const Chunking ck = make_chunks(c, m02, kBlock * kNameIPT);
-    u32 *counts = nullptr;
-    RC(arena_alloc(c, (size_t)ck.nchunks + 16, &counts));
     u32 names = 0;
-    {
-      PhaseScope ps(c, DC3HIP_PH_NAMING, m02);
-      hipLaunchKernelGGL(k_name_count, dim3(ck.nchunks), dim3(kBlock), 0, c->stream, sorted, m02, ck.chunk, counts);
-      KCHECK();
-      hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, counts, ck.nchunks, c->d_words);
-      KCHECK();
-      HIPC(hipMemcpyAsync(c->h_words, c->d_words, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    bool done = false;
+    // ---- prefix-sort + tie-refine ordering when the top 32 key bits separate most samples ------
+    if (m02 >= kHybridMinSamples && !c->no_hybrid) {
+      double pred = 1.0;
+      RC(predict_tie_fraction<Sym>(c, S, m, m0, m02, b, kbits - 32, &pred));
+      c->stats.level_tie_pred[depth] = pred;
+      if (pred < kHybridMaxPredicted) {
+        bool ok = false;
+        RC(order_hybrid<Sym>(c, S, m, m0, m02, b, kbits, nbytes, sa12, rank12, R, &names, &ok, depth));
+        done = ok;
+        if (!ok) arena_release(c, mk1);
+      }
     }
-    HIPC(hipStreamSynchronize(c->stream));     // the lib.rs:103 decision needs the name count
-    names = c->h_words[0];
-    if (names == m02) {
-      // all names unique (lib.rs:109-113): the sorted order IS the suffix array of the sample
-      Rec8 *pa = nullptr, *pb = nullptr;
-      RC(arena_alloc(c, (size_t)m02, &pa));
-      RC(arena_alloc(c, (size_t)m02, &pb));
+    if (!done) {
+      c->stats.level_sorted[depth] = 1;
+      Rec16 *recA = nullptr, *recB = nullptr, *sorted = nullptr;
+      RC(arena_alloc(c, (size_t)m02, &recA));
+      RC(arena_alloc(c, (size_t)m02, &recB));
       {
-        PhaseScope ps(c, DC3HIP_PH_RANKS, m02);
-        hipLaunchKernelGGL(k_assign_unique, dim3(grid_for(c, m02)), dim3(kBlock), 0, c->stream, sorted, m02, m0,
-                           sa12, pa);
+        PhaseScope ps(c, DC3HIP_PH_PACK, m02);
+        hipLaunchKernelGGL((k_pack_triples<Sym>), dim3(grid_for(c, m0)), dim3(kBlock), 0, c->stream, S, m, m0, m02, b,
+                           recA);
         KCHECK();
       }
-      RC(inverse_permute(c, pa, pb, m02, rank12, DC3HIP_PH_RANKS));
-      arena_release(c, mk1);
-    } else {
-      {
-        PhaseScope ps(c, DC3HIP_PH_NAMING, m02);
-        hipLaunchKernelGGL(k_name_assign, dim3(ck.nchunks), dim3(kBlock), 0, c->stream, sorted, m02, ck.chunk, counts,
-                           m0, R);
-        KCHECK();
-        hipLaunchKernelGGL(k_zero_tail, dim3(1), dim3(64), 0, c->stream, R, m02, 8u);
-        KCHECK();
-      }
-      arena_release(c, mk1);
+      RC(radix_sort<Rec16>(c, recA, recB, m02, nbytes, &sorted, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN,
+                           DC3HIP_PH_SORT12_DOWN));
+      AccRec16 acc; acc.s = sorted;
+      RC(name_and_rank<AccRec16>(c, acc, m02, m0, sa12, rank12, R, &names));
+    }
+    arena_release(c, mk1);
+    if (names != m02) {
       SymU32 RS; RS.s = R; RS.m = m02;
       RC(dc3_level<SymU32>(c, RS, m02, names, sa12, rank12, depth + 1));   // lib.rs:104
     }
@@ -444,8 +581,9 @@ static int ctx_build(dc3hip_ctx *c) {
       if (hipEventElapsedTime(&t, m.a, m.b) != hipSuccess) continue;
       c->stats.phase_ms[m.phase] += t;
       c->stats.phase_launches[m.phase] += 1;
-      if (m.phase == DC3HIP_PH_SORT12_DOWN) {
-        c->stats.downsweep16_ms += t; c->stats.downsweep16_launches += 1; c->stats.downsweep16_elems += m.elems;
+      if (m.kclass >= 0 && m.kclass < 3) {
+        c->stats.downsweep_ms[m.kclass] += t; c->stats.downsweep_launches[m.kclass] += 1;
+        c->stats.downsweep_elems[m.kclass] += m.elems;
       }
     }
   }
@@ -482,6 +620,8 @@ int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) {
   memset(&c->stats, 0, sizeof(c->stats));
   const char *prof = getenv("DC3HIP_PROFILE");
   c->profile = !(prof && prof[0] == '0');
+  const char *nh = getenv("DC3HIP_NO_HYBRID");
+  c->no_hybrid = (nh && nh[0] == '1');
   int rc = [&]() -> int {
     HIPC(hipSetDevice(device));
     hipDeviceProp_t prop;
