@@ -245,7 +245,10 @@ struct DownsweepSmem {
 // digit_base[d] + table[d*nchunks + c].
 // NW waves per block (measured on MI355X, profiles/r01_radix_downsweep_variants.txt: 16 waves x 8
 // items = 8192-record tiles move 3.5 TB/s vs 2.9 TB/s for 4 waves x 16 items).
-template <class Rec, class Dig, int IPT, int NW>
+// PF: prefetch the next tile into registers while the current one is ranked/reordered (pays for
+// 8-byte records: 2.3 -> 3.4 TB/s; costs registers and loses for 16/20-byte records, see
+// profiles/r01_radix_downsweep_variants_v2.txt).
+template <class Rec, class Dig, int IPT, int NW, bool PF>
 __global__ __launch_bounds__(NW * 64) void k_rs_downsweep(const Rec *__restrict__ in, Rec *__restrict__ out, u32 n,
                                                          u32 chunk, u32 nchunks, Dig dig,
                                                          const u32 *__restrict__ table,
@@ -263,36 +266,59 @@ __global__ __launch_bounds__(NW * 64) void k_rs_downsweep(const Rec *__restrict_
   const u32 begin = blockIdx.x * chunk;
   const u32 end = min(n, begin + chunk);
   if (tid < 256) dbase[tid] = digit_base[tid] + table[tid * nchunks + blockIdx.x];
-  volatile u32 *mycnt = wcnt + w * 256;
+  u32 *mycnt = wcnt + w * 256;
+  Rec r[IPT], rn[PF ? IPT : 1];
+  if (PF) {
+#pragma unroll
+    for (int k = 0; k < IPT; k++) {
+      const u32 t = w * kWItems + k * 64 + lane;
+      if (begin + t < end) rn[PF ? k : 0] = in[begin + t];
+    }
+  }
 
   for (u32 tile = begin; tile < end; tile += kTile) {
     const u32 nvalid = min((u32)kTile, end - tile);
 #pragma unroll
     for (int j = 0; j < 4; j++) mycnt[lane + 64 * j] = 0;
-    Rec r[IPT];
     u32 d[IPT], rk[IPT];
     // wave w owns tile items [w*kWItems, (w+1)*kWItems); round k covers 64 consecutive items
 #pragma unroll
     for (int k = 0; k < IPT; k++) {
       const u32 t = w * kWItems + k * 64 + lane;
-      if (t < nvalid) { r[k] = in[tile + t]; d[k] = dig(r[k]); }
-      else d[k] = 255u;                               // padding sorts last within the tile
+      if (PF) r[k] = rn[PF ? k : 0];
+      else if (t < nvalid) r[k] = in[tile + t];
+      d[k] = (t < nvalid) ? dig(r[k]) : 255u;           // padding sorts last within the tile
     }
-    // stable ranking: items of one wave-round with equal digit are ordered by lane
+    if (PF) {
+      const u32 nt = tile + kTile;
 #pragma unroll
-    for (int k = 0; k < IPT; k++) {
-      u64 peers = ~0ull;
-#pragma unroll
-      for (int bit = 0; bit < 8; bit++) {
-        const bool one = (d[k] >> bit) & 1u;
-        const u64 mk = __ballot(one);
-        peers &= one ? mk : ~mk;
+      for (int k = 0; k < IPT; k++) {
+        const u32 t = w * kWItems + k * 64 + lane;
+        if (nt + t < end) rn[PF ? k : 0] = in[nt + t];
       }
-      const u32 below = mbcnt(peers);
-      const u32 cnt = __popcll(peers);
-      const u32 base = mycnt[d[k]];
-      rk[k] = base + below;
-      if (below == cnt - 1) mycnt[d[k]] = base + cnt;   // highest peer lane publishes
+    }
+    // stable ranking: items of one wave-round with equal digit are ordered by lane.  The lowest
+    // peer lane bumps the wave's digit counter with one LDS atomic per round; the atomics of all
+    // rounds are issued back to back (LDS executes them in order, so the returned values are the
+    // running prefix) and the bases are broadcast afterwards.
+    {
+      u32 below[IPT], leader[IPT], old[IPT];
+#pragma unroll
+      for (int k = 0; k < IPT; k++) {
+        u64 peers = ~0ull;
+#pragma unroll
+        for (int bit = 0; bit < 8; bit++) {
+          const bool one = (d[k] >> bit) & 1u;
+          const u64 mk = __ballot(one);
+          peers &= one ? mk : ~mk;
+        }
+        below[k] = mbcnt(peers);
+        leader[k] = (u32)__ffsll((unsigned long long)peers) - 1u;
+        old[k] = 0;
+        if (below[k] == 0) old[k] = atomicAdd(&mycnt[d[k]], (u32)__popcll(peers));
+      }
+#pragma unroll
+      for (int k = 0; k < IPT; k++) rk[k] = __shfl(old[k], leader[k]) + below[k];
     }
     __syncthreads();
     // per digit (thread tid = digit): prefix over waves, tile total, tile-exclusive prefix
@@ -450,24 +476,27 @@ __global__ __launch_bounds__(1024) void k_invperm_local(const Rec8 *__restrict__
 //      3b-bit key as 16-byte records and written back into the tied slots (same relative order)
 // Result: h[i].val = position of the i-th smallest triple, f[i] = key differs from predecessor.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ u32 key_bits32(const Rec16 &r, u32 sh) {   // bits [sh, sh+32) of the 96-bit key
-  const u32 w = sh >> 5, off = sh & 31;
-  const u32 a = w == 0 ? r.k0 : (w == 1 ? r.k1 : r.k2);
-  const u32 bnext = w == 0 ? r.k1 : (w == 1 ? r.k2 : 0u);
-  return off ? ((a >> off) | (bnext << (32 - off))) : a;
+// Monotone 32-bit image of the full key: X = key >> shx (its top 64 bits), hi32 = floor(X * mfix / 2^64)
+// with mfix = floor(2^96 / (Xmax+1)) — uses the whole 32-bit range whatever the packing base is, so
+// as few samples as possible collide.  Any monotone map is valid for the tie-refine scheme.
+struct HiMap { u64 mfix; u32 shx; };
+__device__ __forceinline__ u32 key_hi32(const Rec16 &r, HiMap hm) {
+  const u64 lo = (u64)r.k0 | ((u64)r.k1 << 32);
+  const u64 x = hm.shx ? ((lo >> hm.shx) | ((u64)r.k2 << (64 - hm.shx))) : lo;
+  return (u32)__umul64hi(x, hm.mfix);
 }
 // stride > 1 samples every stride-th group (tie-rate predictor); out index = g / stride
 template <class Sym>
-__global__ __launch_bounds__(kBlock) void k_pack_hi32(Sym S, u32 m, u32 m0, u32 m02, u32 b, u32 sh, u32 stride,
+__global__ __launch_bounds__(kBlock) void k_pack_hi32(Sym S, u32 m, u32 m0, u32 m02, u32 b, HiMap sh, u32 stride,
                                                      u32 ngroups_out, Rec8 *out) {
   for (u32 go = blockIdx.x * kBlock + threadIdx.x; go < ngroups_out; go += gridDim.x * kBlock) {
     const u32 g = go * stride;
     const u32 i = 3 * g + 1;
     const u32 s1 = S.get(i), s2 = S.get(i + 1), s3 = S.get(i + 2), s4 = S.get(i + 3);
-    out[2 * go] = Rec8{key_bits32(make_rec(s1, s2, s3, b, i), sh), i};
+    out[2 * go] = Rec8{key_hi32(make_rec(s1, s2, s3, b, i), sh), i};
     if (stride > 1 || 2 * g + 1 < m02) {
       // (in sampling mode a possibly non-existent last mod-2 sample only perturbs the estimate)
-      if (2 * g + 1 < m02) out[2 * go + 1] = Rec8{key_bits32(make_rec(s2, s3, s4, b, i + 1), sh), i + 1};
+      if (2 * g + 1 < m02) out[2 * go + 1] = Rec8{key_hi32(make_rec(s2, s3, s4, b, i + 1), sh), i + 1};
       else out[2 * go + 1] = Rec8{0xffffffffu, i + 1};
     }
   }
@@ -554,18 +583,34 @@ __global__ __launch_bounds__(kBlock) void k_build_tuples(Sym S, u32 m, u32 m0, u
     }
   }
 }
+// Block b gathers the contiguous chunk [b*chunk, (b+1)*chunk) and also counts its mod-1 entries
+// (the per-chunk counts of the Step-2 selection below, saving one more pass over the tuples).
 __global__ __launch_bounds__(kBlock) void k_gather_tuples(const Tup12 *__restrict__ tslot,
-                                                         const u32 *__restrict__ sa12, u32 n,
-                                                         Tup12 *__restrict__ out) {
+                                                         const u32 *__restrict__ sa12, u32 n, u32 chunk,
+                                                         Tup12 *__restrict__ out, u32 *__restrict__ counts) {
+  __shared__ u32 tmp[kWaves];
+  const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
+  u32 c1 = 0;
+  u32 i = begin + threadIdx.x;
   // 4 independent 16-byte gathers in flight per thread
-  const u32 stride = gridDim.x * kBlock;
-  u32 i = blockIdx.x * kBlock + threadIdx.x;
-  for (; i + 3 * stride < n; i += 4 * stride) {
-    const u32 s0 = sa12[i], s1 = sa12[i + stride], s2 = sa12[i + 2 * stride], s3 = sa12[i + 3 * stride];
-    const Tup12 a = tslot[s0], b = tslot[s1], c = tslot[s2], d = tslot[s3];
-    out[i] = a; out[i + stride] = b; out[i + 2 * stride] = c; out[i + 3 * stride] = d;
+  // the index stream and the output stream are touched once: non-temporal, so they do not evict
+  // the randomly gathered lines' neighbours from L2 / Infinity Cache
+  typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 *tv = reinterpret_cast<const u32x4 *>(tslot);
+  u32x4 *ov = reinterpret_cast<u32x4 *>(out);
+  for (; i + 3 * kBlock < end; i += 4 * kBlock) {
+    const u32 s0 = __builtin_nontemporal_load(&sa12[i]), s1 = __builtin_nontemporal_load(&sa12[i + kBlock]);
+    const u32 s2 = __builtin_nontemporal_load(&sa12[i + 2 * kBlock]), s3 = __builtin_nontemporal_load(&sa12[i + 3 * kBlock]);
+    const u32x4 a = tv[s0], b = tv[s1], c = tv[s2], d = tv[s3];
+    __builtin_nontemporal_store(a, &ov[i]); __builtin_nontemporal_store(b, &ov[i + kBlock]);
+    __builtin_nontemporal_store(c, &ov[i + 2 * kBlock]); __builtin_nontemporal_store(d, &ov[i + 3 * kBlock]);
+    c1 += (a.x % 3 == 1) + (b.x % 3 == 1) + (c.x % 3 == 1) + (d.x % 3 == 1);   // .x = pos
   }
-  for (; i < n; i += stride) out[i] = tslot[sa12[i]];
+  for (; i < end; i += kBlock) { const u32x4 a = tv[sa12[i]]; ov[i] = a; c1 += (a.x % 3 == 1); }
+  c1 = wave_reduce(c1);
+  if (lane_id() == 0) tmp[wave_id()] = c1;
+  __syncthreads();
+  if (threadIdx.x == 0) { u32 t = 0; for (int k = 0; k < kWaves; k++) t += tmp[k]; counts[blockIdx.x] = t; }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -165,9 +165,9 @@ static Chunking make_chunks(dc3hip_ctx *c, u32 n, u32 tile) {
 // stable LSD radix sort over `nbytes` key bytes (lib.rs:15-39 per digit)
 // ---------------------------------------------------------------------------------------------
 template <class Rec> struct SortCfg;
-template <> struct SortCfg<Rec8>  { static constexpr int IPT = 16, NW = 16, kClass = 0; typedef Rec8Shift Dig; };
-template <> struct SortCfg<Rec16> { static constexpr int IPT = 8, NW = 16, kClass = 1; typedef Rec16Byte Dig; };
-template <> struct SortCfg<Tup0>  { static constexpr int IPT = 6, NW = 16, kClass = 2; typedef Tup0Byte Dig; };
+template <> struct SortCfg<Rec8>  { static constexpr int IPT = 12, NW = 16, kClass = 0; static constexpr bool PF = true; typedef Rec8Shift Dig; };
+template <> struct SortCfg<Rec16> { static constexpr int IPT = 8, NW = 16, kClass = 1; static constexpr bool PF = false; typedef Rec16Byte Dig; };
+template <> struct SortCfg<Tup0>  { static constexpr int IPT = 6, NW = 16, kClass = 2; static constexpr bool PF = false; typedef Tup0Byte Dig; };
 
 template <class Dig> static Dig make_digit(u32 pass, u32) { Dig d; d.p = pass; return d; }
 template <> Rec8Shift make_digit<Rec8Shift>(u32 pass, u32 shift0) { Rec8Shift d; d.shift = shift0 + 8 * pass; return d; }
@@ -181,7 +181,7 @@ static int radix_sort(dc3hip_ctx *c, Rec *a, Rec *b, u32 n, u32 nbytes, Rec **re
   constexpr int kTile = NW * 64 * IPT;
   const size_t smem = DownsweepSmem<Rec, IPT, NW>::kBytes;
   static thread_local bool attr_set[16] = {false};
-  auto kern = k_rs_downsweep<Rec, Dig, IPT, NW>;
+  auto kern = k_rs_downsweep<Rec, Dig, IPT, NW, SortCfg<Rec>::PF>;
   if (!attr_set[c->device & 15]) {
     HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)smem));
@@ -300,6 +300,15 @@ static int name_and_rank(dc3hip_ctx *c, Acc acc, u32 m02, u32 m0, u32 *sa12, u32
 //     out above kHybridMaxMeasured.  Correctness never depends on the policy.
 // ---------------------------------------------------------------------------------------------
 static constexpr u32 kHybridMinSamples = 1u << 22;
+// hi32 = floor(X * mfix / 2^64), X = key >> shx, mfix = floor((2^96-1) / (Xmax+1)); B^3 > 2^32 here
+static HiMap make_himap(u64 B, u32 kbits) {
+  const unsigned __int128 mx = (unsigned __int128)B * B * B - 1;      // largest key
+  HiMap hm; hm.shx = kbits > 64 ? kbits - 64 : 0;
+  const unsigned __int128 xmax1 = (mx >> hm.shx) + 1;                  // > 2^32
+  const unsigned __int128 num = (((unsigned __int128)1) << 96) - 1;
+  hm.mfix = (u64)(num / xmax1);
+  return hm;
+}
 static constexpr double kHybridMaxPredicted = 0.50;
 static constexpr double kHybridMaxMeasured = 0.60;
 
@@ -315,7 +324,7 @@ static int count_ties(dc3hip_ctx *c, const Rec8 *h, u32 n, u32 *counts, const Ch
 }
 
 template <class Sym>
-static int predict_tie_fraction(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u32 sh, double *pred) {
+static int predict_tie_fraction(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, HiMap sh, double *pred) {
   const ArenaMark mk = arena_mark(c);
   const u32 stride = std::max<u32>(1, m0 >> 19);
   const u32 ng = (m0 - 1) / stride + 1;      // sampled groups, 2 records each
@@ -352,7 +361,7 @@ static int order_hybrid(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u32
   {
     PhaseScope ps(c, DC3HIP_PH_PACK, m02);
     hipLaunchKernelGGL((k_pack_hi32<Sym>), dim3(grid_for(c, m0)), dim3(kBlock), 0, c->stream, S, m, m0, m02, b,
-                       kbits - 32, 1u, m0, ha);
+                       make_himap((u64)b, kbits), 1u, m0, ha);
     KCHECK();
   }
   RC(radix_sort<Rec8>(c, ha, hb, m02, 4, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT8_DOWN, 0));
@@ -442,7 +451,7 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
     // ---- prefix-sort + tie-refine ordering when the top 32 key bits separate most samples ------
     if (m02 >= kHybridMinSamples && !c->no_hybrid) {
       double pred = 1.0;
-      RC(predict_tie_fraction<Sym>(c, S, m, m0, m02, b, kbits - 32, &pred));
+      RC(predict_tie_fraction<Sym>(c, S, m, m0, m02, b, make_himap(B, kbits), &pred));
       c->stats.level_tie_pred[depth] = pred;
       if (pred < kHybridMaxPredicted) {
         bool ok = false;
@@ -482,6 +491,9 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
   // ---- Step 2 + 3: tuples, mod-0 order, merge -------------------------------------------------
   Tup12 *tslot = nullptr, *t12 = nullptr;
   RC(arena_alloc(c, (size_t)m02, &t12));
+  const Chunking ckc = make_chunks(c, m02, kBlock);
+  u32 *mod0_counts = nullptr;
+  RC(arena_alloc(c, (size_t)ckc.nchunks + 16, &mod0_counts));
   const ArenaMark mk_tslot = arena_mark(c);
   RC(arena_alloc(c, (size_t)m02, &tslot));
   {
@@ -489,7 +501,8 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
     hipLaunchKernelGGL((k_build_tuples<Sym>), dim3(grid_for(c, m0)), dim3(kBlock), 0, c->stream, S, m, m0, m02,
                        rank12, tslot);
     KCHECK();
-    hipLaunchKernelGGL(k_gather_tuples, dim3(grid_for(c, m02)), dim3(kBlock), 0, c->stream, tslot, sa12, m02, t12);
+    hipLaunchKernelGGL(k_gather_tuples, dim3(ckc.nchunks), dim3(kBlock), 0, c->stream, tslot, sa12, m02, ckc.chunk,
+                       t12, mod0_counts);
     KCHECK();
   }
   arena_release(c, mk_tslot);   // slot-order tuples are dead; their space is reused below
@@ -497,15 +510,12 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
   RC(arena_alloc(c, (size_t)m0, &z0));
   RC(arena_alloc(c, (size_t)m0, &z1));
   {
-    const Chunking ck = make_chunks(c, m02, kBlock);
-    u32 *counts = nullptr;
-    RC(arena_alloc(c, (size_t)ck.nchunks + 16, &counts));
     PhaseScope ps(c, DC3HIP_PH_COMPACT, m02);
-    hipLaunchKernelGGL(k_mod0_count, dim3(ck.nchunks), dim3(kBlock), 0, c->stream, t12, m02, ck.chunk, counts);
+    hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, mod0_counts, ckc.nchunks,
+                       (u32 *)nullptr);
     KCHECK();
-    hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, counts, ck.nchunks, (u32 *)nullptr);
-    KCHECK();
-    hipLaunchKernelGGL(k_mod0_write, dim3(ck.nchunks), dim3(kBlock), 0, c->stream, t12, m02, ck.chunk, counts, z0);
+    hipLaunchKernelGGL(k_mod0_write, dim3(ckc.nchunks), dim3(kBlock), 0, c->stream, t12, m02, ckc.chunk, mod0_counts,
+                       z0);
     KCHECK();
   }
   RC(radix_sort<Tup0>(c, z0, z1, m0, (bits_of(K - 1) + 7) / 8, &zs, DC3HIP_PH_SORT0, DC3HIP_PH_SORT0, DC3HIP_PH_SORT0));

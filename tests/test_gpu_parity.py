@@ -221,7 +221,7 @@ def test_hybrid_and_straight_paths_agree(ss, oracle):
     (DC3HIP_NO_HYBRID=1, level_sorted == 1) are two routes to the same SA; both must be bit-exact.
     Inputs: random bytes (few ties), text-like (prediction rejects the path), forced many ties."""
     import os
-    n = 7_000_001
+    n = 10_000_001
     rng = np.random.default_rng(8)
     words = [bytes(rng.integers(97, 123, size=int(rng.integers(2, 9)), dtype=np.uint8)) + b" " for _ in range(300)]
     texty = b"".join(words[int(i)] for i in rng.integers(0, 300, size=n // 5))[:n]
