@@ -1,0 +1,52 @@
+// host_test.cpp — the reference's own unit tests for the composition layer, restated against the
+// C++ mirror with dc3hip::sort plugged in as the SACA (needs a GPU):
+//   sacapart/src/lib.rs:105-128 worse_test, :130-165 equivalent_test, divsufsort/src/lib.rs:83-91 shruggy
+#include <cassert>
+#include <cstdio>
+#include "dc3hip.hpp"
+#include "sacapart.hpp"
+using sacabase::Bytes;
+
+#define CHECK(c) do { if (!(c)) { std::fprintf(stderr, "CHECK failed at %s:%d: %s\n", __FILE__, __LINE__, #c); return 1; } } while (0)
+
+int main() {
+  {  // worse_test
+    std::string input = "totor";
+    auto sa_full = dc3hip::sort(Bytes(input));
+    sacapart::PartitionedSuffixArray<int32_t> sa_part(Bytes(input), 2, dc3hip::sort);
+    std::string needle = "tor";
+    CHECK(sa_full.longest_substring_match(Bytes(needle)).as_bytes() == Bytes(needle));
+    CHECK(sa_part.longest_substring_match(Bytes(needle)).as_bytes() == Bytes(std::string("to")));
+    needle = "otor";
+    CHECK(sa_full.longest_substring_match(Bytes(needle)).as_bytes() == Bytes(needle));
+    CHECK(sa_part.longest_substring_match(Bytes(needle)).as_bytes() == Bytes(needle));
+  }
+  {  // equivalent_test
+    std::string input = "This is a rather long text. We can probably find matches that span two partitions. Oh yes.";
+    auto sa_full = dc3hip::sort(Bytes(input));
+    for (size_t partitions : {1, 2, 3}) {
+      for (std::string needle : {"rather long", "text. We can", "We can probably find matches that span"}) {
+        sacapart::PartitionedSuffixArray<int32_t> sa_part(Bytes(input), partitions, dc3hip::sort);
+        auto f = sa_full.longest_substring_match(Bytes(needle)), p = sa_part.longest_substring_match(Bytes(needle));
+        CHECK(f.as_bytes() == p.as_bytes()); CHECK(f.start == p.start); CHECK(f.len == p.len);
+      }
+    }
+  }
+  {  // shruggy + verify
+    const uint8_t sh[] = {0xc2, 0xaf, 0x5c, 0x5f, 0x28, 0xe3, 0x83, 0x84, 0x29, 0x5f, 0x2f, 0xc2, 0xaf};
+    auto sa = dc3hip::sort(Bytes(sh, sizeof sh));
+    sa.verify();
+    const int32_t want[] = {4, 8, 10, 2, 3, 9, 6, 7, 12, 1, 11, 0, 5};
+    for (size_t i = 0; i < sizeof sh; i++) CHECK(sa.sa()[i] == want[i]);
+    auto sa64 = dc3hip::sort_i64(Bytes(sh, sizeof sh));
+    for (size_t i = 0; i < sizeof sh; i++) CHECK(sa64.sa()[i] == want[i]);
+  }
+  {  // error behaviour: len mismatch throws like the Rust assert
+    std::vector<int32_t> sa(2);
+    bool threw = false;
+    try { dc3hip::sort_in_place(Bytes(std::string("abc")), sa.data(), sa.size()); } catch (const std::invalid_argument &) { threw = true; }
+    CHECK(threw);
+  }
+  std::printf("host_test ok\n");
+  return 0;
+}

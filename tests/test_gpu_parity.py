@@ -205,6 +205,25 @@ def test_partitioned_search_on_gpu_sas(ss):
             assert (f.as_bytes(), f.start, f.len) == (p.as_bytes(), p.start, p.len)
 
 
+def test_cpp_host_mirror(ss):
+    """C++ mirror of sacabase/sacapart + dc3hip::sort (stringsearch_amd/host): the reference's
+    sacapart unit tests with the HIP SACA plugged in, and the divsuftest-style harness."""
+    import subprocess
+    from conftest import ROOT
+    pkg = os.path.join(ROOT, "stringsearch_amd")
+    out = subprocess.run([os.path.join(pkg, "host_test")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "host_test ok" in out.stdout, out.stdout + out.stderr
+    out = subprocess.run([os.path.join(pkg, "sa_bench"), "verify", os.path.join(GOLDEN, "corpus", "fuzz3")],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "GPU sufcheck: 0" in out.stdout, out.stdout + out.stderr
+    out = subprocess.run([os.path.join(pkg, "sa_bench"), "bench", "gen:random:4m:7", "2m"],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "Input is size 2.0MiB" in out.stdout and "dc3-hip" in out.stdout, out.stdout + out.stderr
+    out = subprocess.run([os.path.join(pkg, "sa_bench"), "run", "gen:dna:1m:3", "--partitions", "3"],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "Done in" in out.stdout, out.stdout + out.stderr
+
+
 def test_concurrent_calls_are_thread_safe(ss, oracle):
     """sacapart calls f concurrently from rayon workers (lib.rs:41-49): the one-shot entry point
     must be re-entrant."""
