@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=str, default="1GiB", help="bytes per GPU (partition size is size*N/N+1 rounding aside)")
-    ap.add_argument("--kind", type=str, default="random", choices=["random", "dna"])
+    ap.add_argument("--kind", type=str, default="random", choices=["random", "dna", "text"])
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--cpu-sample-mib", type=int, default=64)
     ap.add_argument("--no-cpu", action="store_true")
@@ -113,7 +113,7 @@ def main():
     per_gpu = parse_size(args.size)
     total_len = per_gpu * world
     off, n = (0, total_len) if world == 1 else rank_chunk(total_len, world, rank)   # sacapart/src/lib.rs:43-46
-    kind = 0 if args.kind == "random" else 1
+    kind = {"random": 0, "dna": 1, "text": 2}[args.kind]
 
     ctx = ss.Context(n, device=local_rank)
     ctx.generate(n, args.seed, kind, offset=off)

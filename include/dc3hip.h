@@ -78,7 +78,8 @@ DC3HIP_API void dc3hip_ctx_destroy(dc3hip_ctx *ctx);
 /* Load the text: from host memory (H2D copy) ... */
 DC3HIP_API int32_t dc3hip_ctx_set_text(dc3hip_ctx *ctx, const uint8_t *T, int64_t n);
 /* ... or generate it on the device: byte i = byte (i&7) of splitmix64(seed + (i>>3)) for kind 0,
- * "ACGT"[2-bit field] for kind 1. */
+ * "ACGT"[2-bit field] for kind 1, low-entropy text with 1-8 KiB repeated spans for kind 2
+ * (BASELINE.md §3 configs 2/5/3). */
 DC3HIP_API int32_t dc3hip_ctx_generate(dc3hip_ctx *ctx, int64_t n, uint64_t seed, int32_t kind);
 /* Same stream, bytes [offset, offset+n): lets each GPU of a sacapart run generate its own chunk. */
 DC3HIP_API int32_t dc3hip_ctx_generate_at(dc3hip_ctx *ctx, int64_t n, uint64_t seed, int32_t kind, int64_t offset);

@@ -303,9 +303,44 @@ static inline uint64_t splitmix64(uint64_t x) {
   x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
   return x ^ (x >> 31);
 }
-/* kind 0: random bytes; kind 1: DNA "ACGT"[x&3] (2 bits per base) */
+/* kind 2: low-entropy text with deep LCPs (made position-addressable):
+ *   16-byte cells "word1 word2..." with words drawn from a 4096-word vocabulary by a skewed
+ *   (product-of-uniforms) distribution, '\n' every 80 bytes; every 64 KiB block starts, with
+ *   probability 1/2, with a verbatim 1-8 KiB copy of an earlier span. */
+static uint8_t text_base(uint64_t i, uint64_t seed) {
+  const uint64_t cell = i >> 4; const unsigned off = (unsigned)(i & 15);
+  if (cell % 5 == 4 && off == 15) return '\n';
+  const uint64_t hc = splitmix64(seed + cell * 0x9E3779B97F4A7C15ull);
+  const uint64_t a = hc & 0xFFFF, b = (hc >> 16) & 0xFFFF, c = (hc >> 32) & 0xFFFF;
+  const uint64_t wid = (((a * b) >> 16) * c) >> 20;                 /* 0..4095, skewed to small ids */
+  const uint64_t hw = splitmix64(0x5EEDull ^ (wid << 1));
+  const unsigned wlen = 2 + (unsigned)(hw % 11);                     /* 2..12 letters */
+  if (off < wlen) return (uint8_t)('a' + ((hw >> (8 + 4 * off)) % 26));
+  if (off == wlen) return ' ';
+  const uint64_t wid2 = (((hc >> 48) & 0xFFF) * ((hc >> 40) & 0xFF)) >> 8;
+  const uint64_t hw2 = splitmix64(0x5EEDull ^ (wid2 << 1));
+  const unsigned wlen2 = 2 + (unsigned)(hw2 % 11), o2 = off - wlen - 1;
+  if (o2 < wlen2) return (uint8_t)('a' + ((hw2 >> (8 + 4 * o2)) % 26));
+  return ' ';
+}
+static uint8_t text_byte(uint64_t i, uint64_t seed) {
+  const uint64_t block = i >> 16, within = i & 0xFFFF;
+  if (block > 0) {
+    const uint64_t hb = splitmix64((seed ^ 0xB10Cull) + block * 0xD1B54A32D192ED03ull);
+    if (hb & 1) {
+      const uint64_t len = 1024 + ((hb >> 8) % 7169);
+      if (within < len) {
+        const uint64_t sb = (hb >> 24) % block, so = (hb >> 44) % (65536 - 8192);
+        return text_base(sb * 65536 + so + within, seed);
+      }
+    }
+  }
+  return text_base(i, seed);
+}
+/* kind 0: random bytes; kind 1: DNA "ACGT"[x&3] (2 bits per base); kind 2: text (above) */
 ORACLE_API void oracle_gen_bytes(uint8_t *out, int64_t n, uint64_t seed, int kind) {
   static const char acgt[4] = {'A', 'C', 'G', 'T'};
+  if (kind == 2) { for (int64_t i = 0; i < n; i++) out[i] = text_byte((uint64_t)i, seed); return; }
   if (kind == 0) {
     for (int64_t i = 0; i < n; i++) out[i] = (uint8_t)(splitmix64(seed + (uint64_t)(i >> 3)) >> (8 * (i & 7)));
   } else {

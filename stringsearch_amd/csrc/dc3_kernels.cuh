@@ -721,7 +721,41 @@ __device__ __forceinline__ u64 splitmix64(u64 x) {
   x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
   return x ^ (x >> 31);
 }
+// kind 2: low-entropy text with deep LCPs (position-addressable): 16-byte
+// cells "word1 word2.." from a 4096-word vocabulary with a skewed id distribution, newline every
+// 80 bytes, and every 64 KiB block starts with probability 1/2 with a 1-8 KiB copy of an earlier span.
+__device__ __forceinline__ uint8_t text_base(u64 i, u64 seed) {
+  const u64 cell = i >> 4; const u32 off = (u32)(i & 15);
+  if (cell % 5 == 4 && off == 15) return '\n';
+  const u64 hc = splitmix64(seed + cell * 0x9E3779B97F4A7C15ull);
+  const u64 a = hc & 0xFFFF, b = (hc >> 16) & 0xFFFF, c = (hc >> 32) & 0xFFFF;
+  const u64 wid = (((a * b) >> 16) * c) >> 20;
+  const u64 hw = splitmix64(0x5EEDull ^ (wid << 1));
+  const u32 wlen = 2 + (u32)(hw % 11);
+  if (off < wlen) return (uint8_t)('a' + ((hw >> (8 + 4 * off)) % 26));
+  if (off == wlen) return ' ';
+  const u64 wid2 = (((hc >> 48) & 0xFFF) * ((hc >> 40) & 0xFF)) >> 8;
+  const u64 hw2 = splitmix64(0x5EEDull ^ (wid2 << 1));
+  const u32 wlen2 = 2 + (u32)(hw2 % 11), o2 = off - wlen - 1;
+  if (o2 < wlen2) return (uint8_t)('a' + ((hw2 >> (8 + 4 * o2)) % 26));
+  return ' ';
+}
+__device__ __forceinline__ uint8_t text_byte(u64 i, u64 seed) {
+  const u64 block = i >> 16, within = i & 0xFFFF;
+  if (block > 0) {
+    const u64 hb = splitmix64((seed ^ 0xB10Cull) + block * 0xD1B54A32D192ED03ull);
+    if (hb & 1) {
+      const u64 len = 1024 + ((hb >> 8) % 7169);
+      if (within < len) {
+        const u64 sb = (hb >> 24) % block, so = (hb >> 44) % (65536 - 8192);
+        return text_base(sb * 65536 + so + within, seed);
+      }
+    }
+  }
+  return text_base(i, seed);
+}
 __device__ __forceinline__ uint8_t gen_byte(u64 gi, u64 seed, int kind) {
+  if (kind == 2) return text_byte(gi, seed);
   if (kind == 0) return (uint8_t)(splitmix64(seed + (gi >> 3)) >> (8 * (gi & 7)));
   const u32 code = (u32)(splitmix64(seed + (gi >> 5)) >> (2 * (gi & 31))) & 3u;
   return code == 0 ? 'A' : code == 1 ? 'C' : code == 2 ? 'G' : 'T';

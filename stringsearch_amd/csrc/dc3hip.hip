@@ -697,7 +697,7 @@ int32_t dc3hip_ctx_generate(dc3hip_ctx *c, int64_t n, uint64_t seed, int32_t kin
 int32_t dc3hip_ctx_generate_at(dc3hip_ctx *c, int64_t n, uint64_t seed, int32_t kind, int64_t offset) {
   RC(ctx_check_n(c, n));
   if (offset < 0) { set_err("negative offset"); return E_ARGS; }
-  if (kind != 0 && kind != 1) { set_err("unknown generator kind %d", kind); return E_ARGS; }
+  if (kind < 0 || kind > 2) { set_err("unknown generator kind %d", kind); return E_ARGS; }
   HIPC(hipSetDevice(c->device));
   if (n > 0) {
     hipLaunchKernelGGL(k_generate, dim3(grid_for(c, (u64)n / 8 + 1)), dim3(kBlock), 0, c->stream, c->d_text, (u64)n,

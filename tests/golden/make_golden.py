@@ -89,7 +89,8 @@ def main():
     synth = {}
     for (label, n, seed, kind) in [("rand_64k_s7", 65536, 7, 0), ("rand_1m_s1", 1 << 20, 1, 0),
                                    ("dna_1m_s5", 1 << 20, 5, 1), ("rand_1m+1_s9", (1 << 20) + 1, 9, 0),
-                                   ("rand_1m+2_s9", (1 << 20) + 2, 9, 0), ("rand_4m_s2", 1 << 22, 2, 0)]:
+                                   ("rand_1m+2_s9", (1 << 20) + 2, 9, 0), ("rand_4m_s2", 1 << 22, 2, 0),
+                                   ("text_300k_s3", 300000, 3, 2), ("text_3m_s4", 3_000_001, 4, 2)]:
         data = gen(n, seed, kind)
         sa = ref_sa(data)
         synth[label] = {"n": n, "seed": seed, "kind": kind,

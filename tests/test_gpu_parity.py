@@ -124,9 +124,9 @@ def test_synthetic_hashes(ss, oracle):
 
 
 def test_generator_offsets(ss, oracle):
-    for kind in (0, 1):
+    for kind in (0, 1, 2):
         full = oracle.gen(100000, 9, kind)
-        for off, n in ((0, 100000), (8, 5000), (13, 4001), (33331, 7), (99999, 1)):
+        for off, n in ((0, 100000), (8, 5000), (13, 4001), (33331, 7), (99999, 1), (65530, 20000)):
             with ss.Context(n) as c:
                 c.generate(n, 9, kind, offset=off)
                 assert np.array_equal(c.text(), full[off:off + n]), (kind, off, n)

@@ -89,7 +89,7 @@ def test_against_reference_build(oracle):
         pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
     synth = json.load(open(os.path.join(GOLDEN, "synth.json")))
     import hashlib
-    for label in ("rand_64k_s7", "rand_1m_s1", "dna_1m_s5", "rand_1m+1_s9", "rand_1m+2_s9"):
+    for label in ("rand_64k_s7", "rand_1m_s1", "dna_1m_s5", "rand_1m+1_s9", "rand_1m+2_s9", "text_300k_s3"):
         e = synth[label]
         data = oracle.gen(e["n"], e["seed"], e["kind"])
         assert hashlib.sha256(data.tobytes()).hexdigest() == e["text_sha256"]
@@ -103,7 +103,7 @@ def test_synth_hashes_without_reference(oracle):
     # same check as above but against the committed hashes only (runs on the GPU box too)
     import hashlib
     synth = json.load(open(os.path.join(GOLDEN, "synth.json")))
-    for label in ("rand_64k_s7", "dna_1m_s5"):
+    for label in ("rand_64k_s7", "dna_1m_s5", "text_300k_s3"):
         e = synth[label]
         data = oracle.gen(e["n"], e["seed"], e["kind"])
         assert hashlib.sha256(data.tobytes()).hexdigest() == e["text_sha256"]
