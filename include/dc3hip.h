@@ -136,6 +136,8 @@ typedef struct dc3hip_stats {
   double  downsweep_ms[3];                /* summed HIP-event time of the launches */
   int64_t downsweep_launches[3];
   int64_t downsweep_elems[3];             /* records moved, summed over launches */
+  /* k_part_msd: non-stable window partition of (destination,value) pairs (inverse permutations) */
+  double  partition_ms; int64_t partition_launches; int64_t partition_elems;
   int64_t arena_bytes;                    /* device work arena size */
   int64_t arena_peak;                     /* high-water mark of the last build */
 } dc3hip_stats;

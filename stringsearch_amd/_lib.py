@@ -29,7 +29,9 @@ class Stats(ctypes.Structure):
                 ("build_ms", ctypes.c_double), ("phase_ms", ctypes.c_double * len(PHASES)),
                 ("phase_launches", ctypes.c_int64 * len(PHASES)),
                 ("downsweep_ms", ctypes.c_double * 3), ("downsweep_launches", ctypes.c_int64 * 3),
-                ("downsweep_elems", ctypes.c_int64 * 3), ("arena_bytes", ctypes.c_int64),
+                ("downsweep_elems", ctypes.c_int64 * 3),
+                ("partition_ms", ctypes.c_double), ("partition_launches", ctypes.c_int64),
+                ("partition_elems", ctypes.c_int64), ("arena_bytes", ctypes.c_int64),
                 ("arena_peak", ctypes.c_int64)]
 
     def as_dict(self):
@@ -45,6 +47,8 @@ class Stats(ctypes.Structure):
             "phase_launches": {PHASES[i]: self.phase_launches[i] for i in range(len(PHASES))},
             "downsweep_ms": list(self.downsweep_ms), "downsweep_launches": list(self.downsweep_launches),
             "downsweep_elems": list(self.downsweep_elems),
+            "partition_ms": self.partition_ms, "partition_launches": self.partition_launches,
+            "partition_elems": self.partition_elems,
             "arena_bytes": self.arena_bytes, "arena_peak": self.arena_peak,
         }
 

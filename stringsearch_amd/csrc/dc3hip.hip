@@ -227,20 +227,47 @@ static int radix_sort(dc3hip_ctx *c, Rec *a, Rec *b, u32 n, u32 nbytes, Rec **re
 // 16384 destinations are assembled in LDS and stored with full lines.
 // ---------------------------------------------------------------------------------------------
 static int inverse_permute(dc3hip_ctx *c, Rec8 *a, Rec8 *b, u32 n, u32 *out, int phase) {
-  const u32 kb = bits_of(n > 0 ? n - 1 : 0);
-  const u32 top = kb > (u32)kInvWindowBits ? kb - kInvWindowBits : 0;
-  Rec8 *sorted = a;
-  if (top > 0) RC(radix_sort<Rec8>(c, a, b, n, (top + 7) / 8, &sorted, phase, phase, phase, (u32)kInvWindowBits));
   static thread_local bool attr_set[16] = {false};
   if (!attr_set[c->device & 15]) {
     HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_invperm_local),
                              hipFuncAttributeMaxDynamicSharedMemorySize, kInvWindow * 4));
+    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_part_msd), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)kPartSmem));
     attr_set[c->device & 15] = true;
   }
-  PhaseScope ps(c, phase, n);
-  hipLaunchKernelGGL(k_invperm_local, dim3((n + kInvWindow - 1) / kInvWindow), dim3(1024), kInvWindow * 4, c->stream,
-                     sorted, n, out);
-  KCHECK();
+  const u32 kb = bits_of(n > 0 ? n - 1 : 0);
+  const ArenaMark mk = arena_mark(c);
+  const u32 ntiles = (n + kPartTile - 1) / kPartTile;
+  Rec8 *src = a, *dst = b;
+  if (kb > 22) {                       // pass 1: top digit = key >> 22 (<= 512 values for n <= 2^31)
+    const u32 ndig = ((n - 1) >> 22) + 1;
+    u32 *cur = nullptr;
+    RC(arena_alloc(c, (size_t)512, &cur));
+    PhaseScope ps(c, phase, n, 3);
+    HIPC(hipMemsetAsync(cur, 0, 512 * sizeof(u32), c->stream));
+    hipLaunchKernelGGL(k_part_msd, dim3(ntiles), dim3(kPartNW * 64), kPartSmem, c->stream, src, dst, n, 22u, 32u,
+                       ndig, cur);
+    KCHECK();
+    std::swap(src, dst);
+  }
+  if (kb > (u32)kInvWindowBits) {      // pass 2: bits [14,22) inside every 2^22-pair segment
+    const u32 nseg = kb > 22 ? ((n - 1) >> 22) + 1 : 1;
+    u32 *cur = nullptr;
+    RC(arena_alloc(c, (size_t)nseg * 256, &cur));
+    PhaseScope ps(c, phase, n, 3);
+    HIPC(hipMemsetAsync(cur, 0, (size_t)nseg * 256 * sizeof(u32), c->stream));
+    hipLaunchKernelGGL(k_part_msd, dim3(ntiles), dim3(kPartNW * 64), kPartSmem, c->stream, src, dst, n,
+                       (u32)kInvWindowBits, kb > 22 ? 22u : 32u, 256u, cur);
+    KCHECK();
+    std::swap(src, dst);
+  }
+  {
+    PhaseScope ps(c, phase, n);
+    hipLaunchKernelGGL(k_invperm_local, dim3((n + kInvWindow - 1) / kInvWindow), dim3(1024), kInvWindow * 4,
+                       c->stream, src, n, out);
+    KCHECK();
+  }
+  arena_release(c, mk);
   return E_OK;
 }
 
@@ -591,6 +618,7 @@ static int ctx_build(dc3hip_ctx *c) {
       if (hipEventElapsedTime(&t, m.a, m.b) != hipSuccess) continue;
       c->stats.phase_ms[m.phase] += t;
       c->stats.phase_launches[m.phase] += 1;
+      if (m.kclass == 3) { c->stats.partition_ms += t; c->stats.partition_launches += 1; c->stats.partition_elems += m.elems; }
       if (m.kclass >= 0 && m.kclass < 3) {
         c->stats.downsweep_ms[m.kclass] += t; c->stats.downsweep_launches[m.kclass] += 1;
         c->stats.downsweep_elems[m.kclass] += m.elems;
