@@ -245,11 +245,21 @@ struct DownsweepSmem {
 // digit_base[d] + table[d*nchunks + c].
 // NW waves per block (measured on MI355X, profiles/r01_radix_downsweep_variants.txt: 16 waves x 8
 // items = 8192-record tiles move 3.5 TB/s vs 2.9 TB/s for 4 waves x 16 items).
+// Loaders: where a down-sweep takes its records from.  ArrayLoader = a plain record array.  A loader
+// may also DROP elements (load() returns false), which fuses an order-preserving selection into the
+// pass (used for Step 2: mod-0 tuples are made from the mod-1 entries of the sorted sample tuples
+// and immediately partitioned by their first key byte — lib.rs:118-126 in one pass).
+template <class Rec>
+struct ArrayLoader {
+  const Rec *p;
+  __device__ __forceinline__ bool load(u32 i, Rec &r) const { r = p[i]; return true; }
+};
+
 // PF: prefetch the next tile into registers while the current one is ranked/reordered (pays for
 // 8-byte records: 2.3 -> 3.4 TB/s; costs registers and loses for 16/20-byte records, see
 // profiles/r01_radix_downsweep_variants_v2.txt).
-template <class Rec, class Dig, int IPT, int NW, bool PF>
-__global__ __launch_bounds__(NW * 64) void k_rs_downsweep(const Rec *__restrict__ in, Rec *__restrict__ out, u32 n,
+template <class Rec, class Dig, int IPT, int NW, bool PF, class Loader>
+__global__ __launch_bounds__(NW * 64) void k_rs_downsweep(Loader in, Rec *__restrict__ out, u32 n,
                                                          u32 chunk, u32 nchunks, Dig dig,
                                                          const u32 *__restrict__ table,
                                                          const u32 *__restrict__ digit_base) {
@@ -268,44 +278,47 @@ __global__ __launch_bounds__(NW * 64) void k_rs_downsweep(const Rec *__restrict_
   if (tid < 256) dbase[tid] = digit_base[tid] + table[tid * nchunks + blockIdx.x];
   u32 *mycnt = wcnt + w * 256;
   Rec r[IPT], rn[PF ? IPT : 1];
+  bool okn[PF ? IPT : 1];
   if (PF) {
 #pragma unroll
     for (int k = 0; k < IPT; k++) {
       const u32 t = w * kWItems + k * 64 + lane;
-      if (begin + t < end) rn[PF ? k : 0] = in[begin + t];
+      okn[PF ? k : 0] = (begin + t < end) && in.load(begin + t, rn[PF ? k : 0]);
     }
   }
 
   for (u32 tile = begin; tile < end; tile += kTile) {
-    const u32 nvalid = min((u32)kTile, end - tile);
+    const u32 nin = min((u32)kTile, end - tile);
 #pragma unroll
     for (int j = 0; j < 4; j++) mycnt[lane + 64 * j] = 0;
     u32 d[IPT], rk[IPT];
+    bool ok[IPT];
     // wave w owns tile items [w*kWItems, (w+1)*kWItems); round k covers 64 consecutive items
 #pragma unroll
     for (int k = 0; k < IPT; k++) {
       const u32 t = w * kWItems + k * 64 + lane;
-      if (PF) r[k] = rn[PF ? k : 0];
-      else if (t < nvalid) r[k] = in[tile + t];
-      d[k] = (t < nvalid) ? dig(r[k]) : 255u;           // padding sorts last within the tile
+      if (PF) { r[k] = rn[PF ? k : 0]; ok[k] = okn[PF ? k : 0]; }
+      else ok[k] = (t < nin) && in.load(tile + t, r[k]);
+      d[k] = ok[k] ? dig(r[k]) : 0u;
     }
     if (PF) {
       const u32 nt = tile + kTile;
 #pragma unroll
       for (int k = 0; k < IPT; k++) {
         const u32 t = w * kWItems + k * 64 + lane;
-        if (nt + t < end) rn[PF ? k : 0] = in[nt + t];
+        okn[PF ? k : 0] = (nt + t < end) && in.load(nt + t, rn[PF ? k : 0]);
       }
     }
     // stable ranking: items of one wave-round with equal digit are ordered by lane.  The lowest
     // peer lane bumps the wave's digit counter with one LDS atomic per round; the atomics of all
     // rounds are issued back to back (LDS executes them in order, so the returned values are the
-    // running prefix) and the bases are broadcast afterwards.
+    // running prefix) and the bases are broadcast afterwards.  Dropped / out-of-range lanes take
+    // no part.
     {
       u32 below[IPT], leader[IPT], old[IPT];
 #pragma unroll
       for (int k = 0; k < IPT; k++) {
-        u64 peers = ~0ull;
+        u64 peers = __ballot(ok[k]);
 #pragma unroll
         for (int bit = 0; bit < 8; bit++) {
           const bool one = (d[k] >> bit) & 1u;
@@ -313,9 +326,9 @@ __global__ __launch_bounds__(NW * 64) void k_rs_downsweep(const Rec *__restrict_
           peers &= one ? mk : ~mk;
         }
         below[k] = mbcnt(peers);
-        leader[k] = (u32)__ffsll((unsigned long long)peers) - 1u;
+        leader[k] = ok[k] ? (u32)__ffsll((unsigned long long)peers) - 1u : lane;
         old[k] = 0;
-        if (below[k] == 0) old[k] = atomicAdd(&mycnt[d[k]], (u32)__popcll(peers));
+        if (ok[k] && below[k] == 0) old[k] = atomicAdd(&mycnt[d[k]], (u32)__popcll(peers));
       }
 #pragma unroll
       for (int k = 0; k < IPT; k++) rk[k] = __shfl(old[k], leader[k]) + below[k];
@@ -327,18 +340,17 @@ __global__ __launch_bounds__(NW * 64) void k_rs_downsweep(const Rec *__restrict_
 #pragma unroll
       for (int i = 0; i < NW; i++) { const u32 c = wcnt[i * 256 + tid]; wcnt[i * 256 + tid] = tot; tot += c; }
     }
-    u32 dummy_total;
-    const u32 ex = block_excl_scan<NW>(tid < 256 ? tot : 0u, tmp, dummy_total);
+    u32 nkeep;
+    const u32 ex = block_excl_scan<NW>(tid < 256 ? tot : 0u, tmp, nkeep);
     if (tid < 256) texcl[tid] = ex;
     __syncthreads();
     // reorder through LDS so every digit run is contiguous
 #pragma unroll
     for (int k = 0; k < IPT; k++) {
-      const u32 t = w * kWItems + k * 64 + lane;
-      if (t < nvalid) srec[texcl[d[k]] + wcnt[w * 256 + d[k]] + rk[k]] = r[k];
+      if (ok[k]) srec[texcl[d[k]] + wcnt[w * 256 + d[k]] + rk[k]] = r[k];
     }
     __syncthreads();
-    for (u32 q = tid; q < nvalid; q += kB) {
+    for (u32 q = tid; q < nkeep; q += kB) {
       const Rec x = srec[q];
       const u32 dd = dig(x);
       out[dbase[dd] + (q - texcl[dd])] = x;
@@ -642,34 +654,45 @@ __global__ __launch_bounds__(kBlock) void k_build_tuples(Sym S, u32 m, u32 m0, u
     }
   }
 }
-// Block b gathers the contiguous chunk [b*chunk, (b+1)*chunk) and also counts its mod-1 entries
-// (the per-chunk counts of the Step-2 selection below, saving one more pass over the tuples).
+// Block b gathers the contiguous chunk [b*chunk, (b+1)*chunk) and also histograms, for its mod-1
+// entries, the low key byte of the mod-0 tuple each of them yields (c_prev - 1): that is the
+// up-sweep of the fused "select mod-0 + first radix pass" below, for free.
 __global__ __launch_bounds__(kBlock) void k_gather_tuples(const Tup12 *__restrict__ tslot,
                                                          const u32 *__restrict__ sa12, u32 n, u32 chunk,
-                                                         Tup12 *__restrict__ out, u32 *__restrict__ counts) {
-  __shared__ u32 tmp[kWaves];
+                                                         u32 nchunks, Tup12 *__restrict__ out,
+                                                         u32 *__restrict__ table /*[256][nchunks]*/) {
+  __shared__ u32 hist[kWaves][256];
+#pragma unroll
+  for (int w = 0; w < kWaves; w++) hist[w][threadIdx.x] = 0;
+  __syncthreads();
+  u32 *myh = hist[wave_id()];
   const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
-  u32 c1 = 0;
   u32 i = begin + threadIdx.x;
-  // 4 independent 16-byte gathers in flight per thread
-  // the index stream and the output stream are touched once: non-temporal, so they do not evict
-  // the randomly gathered lines' neighbours from L2 / Infinity Cache
+  // the index stream and the output stream are touched once: non-temporal
   typedef u32 u32x4 __attribute__((ext_vector_type(4)));
   const u32x4 *tv = reinterpret_cast<const u32x4 *>(tslot);
   u32x4 *ov = reinterpret_cast<u32x4 *>(out);
+  // 4 independent 16-byte gathers in flight per thread;  .x = pos, .w = cx
   for (; i + 3 * kBlock < end; i += 4 * kBlock) {
     const u32 s0 = __builtin_nontemporal_load(&sa12[i]), s1 = __builtin_nontemporal_load(&sa12[i + kBlock]);
     const u32 s2 = __builtin_nontemporal_load(&sa12[i + 2 * kBlock]), s3 = __builtin_nontemporal_load(&sa12[i + 3 * kBlock]);
     const u32x4 a = tv[s0], b = tv[s1], c = tv[s2], d = tv[s3];
     __builtin_nontemporal_store(a, &ov[i]); __builtin_nontemporal_store(b, &ov[i + kBlock]);
     __builtin_nontemporal_store(c, &ov[i + 2 * kBlock]); __builtin_nontemporal_store(d, &ov[i + 3 * kBlock]);
-    c1 += (a.x % 3 == 1) + (b.x % 3 == 1) + (c.x % 3 == 1) + (d.x % 3 == 1);   // .x = pos
+    if (a.x % 3 == 1) atomicAdd(&myh[(a.w - 1u) & 255u], 1u);
+    if (b.x % 3 == 1) atomicAdd(&myh[(b.w - 1u) & 255u], 1u);
+    if (c.x % 3 == 1) atomicAdd(&myh[(c.w - 1u) & 255u], 1u);
+    if (d.x % 3 == 1) atomicAdd(&myh[(d.w - 1u) & 255u], 1u);
   }
-  for (; i < end; i += kBlock) { const u32x4 a = tv[sa12[i]]; ov[i] = a; c1 += (a.x % 3 == 1); }
-  c1 = wave_reduce(c1);
-  if (lane_id() == 0) tmp[wave_id()] = c1;
+  for (; i < end; i += kBlock) {
+    const u32x4 a = tv[sa12[i]]; ov[i] = a;
+    if (a.x % 3 == 1) atomicAdd(&myh[(a.w - 1u) & 255u], 1u);
+  }
   __syncthreads();
-  if (threadIdx.x == 0) { u32 t = 0; for (int k = 0; k < kWaves; k++) t += tmp[k]; counts[blockIdx.x] = t; }
+  u32 sum = 0;
+#pragma unroll
+  for (int w = 0; w < kWaves; w++) sum += hist[w][threadIdx.x];
+  table[threadIdx.x * nchunks + blockIdx.x] = sum;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -678,35 +701,17 @@ __global__ __launch_bounds__(kBlock) void k_gather_tuples(const Tup12 *__restric
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool is_mod1(u32 pos) { return pos % 3 == 1; }
 
-__global__ __launch_bounds__(kBlock) void k_mod0_count(const Tup12 *__restrict__ t, u32 n, u32 chunk, u32 *counts) {
-  __shared__ u32 tmp[kWaves];
-  const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
-  u32 c = 0;
-  for (u32 i = begin + threadIdx.x; i < end; i += kBlock) c += is_mod1(t[i].pos) ? 1u : 0u;
-  c = wave_reduce(c);
-  if (lane_id() == 0) tmp[wave_id()] = c;
-  __syncthreads();
-  if (threadIdx.x == 0) { u32 s = 0; for (int i = 0; i < kWaves; i++) s += tmp[i]; counts[blockIdx.x] = s; }
-}
-__global__ __launch_bounds__(kBlock) void k_mod0_write(const Tup12 *__restrict__ t, u32 n, u32 chunk,
-                                                      const u32 *__restrict__ base_excl, Tup0 *__restrict__ out) {
-  __shared__ u32 tmp[kWaves];
-  const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
-  u32 running = base_excl[blockIdx.x];
-  for (u32 tile = begin; tile < end; tile += kBlock) {
-    const u32 i = tile + threadIdx.x;
-    Tup12 a; bool f = false;
-    if (i < end) { a = t[i]; f = is_mod1(a.pos); }
-    u32 tot;
-    const u32 ex = block_excl_scan<kWaves>(f ? 1u : 0u, tmp, tot);
-    if (f) {
-      Tup0 z;
-      z.pos = a.pos - 1; z.c0 = a.cx; z.c1 = a.c0; z.r1 = i + 1; z.r2 = a.r;
-      out[running + ex] = z;
-    }
-    running += tot;
+// Loader of the fused Step-2 pass: element i of the sorted sample tuples yields a mod-0 tuple iff it
+// is a mod-1 suffix; r1 = i+1 is the rank of suffix j+1, so the stream is already ordered by it.
+struct Mod0Loader {
+  const Tup12 *t;
+  __device__ __forceinline__ bool load(u32 i, Tup0 &z) const {
+    const Tup12 a = t[i];
+    if (!is_mod1(a.pos)) return false;
+    z.pos = a.pos - 1; z.c0 = a.cx; z.c1 = a.c0; z.r1 = i + 1; z.r2 = a.r;
+    return true;
   }
-}
+};
 
 // ---------------------------------------------------------------------------------------------
 // Step 3 (lib.rs:131-192): merge of SA12 and SA0 as a merge-path merge.
@@ -718,16 +723,13 @@ __device__ __forceinline__ bool sample_before(const Tup12 &a, const Tup0 &z) {
   return (a.c0 < z.c0) || (a.c0 == z.c0 && ((a.cx < z.c1) || (a.cx == z.c1 && a.r <= z.r2))); // leq3
 }
 
-constexpr int kMergeVT = 4;
-constexpr int kMergeTile = kBlock * kMergeVT;
-
 __global__ __launch_bounds__(kBlock) void k_merge_partition(const Tup12 *__restrict__ A, u32 nA,
                                                            const Tup0 *__restrict__ B, u32 nB, u32 ntiles,
-                                                           u32 *__restrict__ part /*[ntiles+1]*/) {
+                                                           u32 tile, u32 *__restrict__ part /*[ntiles+1]*/) {
   const u32 t = blockIdx.x * kBlock + threadIdx.x;
   if (t > ntiles) return;
   const u32 total = nA + nB;
-  const u32 diag = min(t * (u32)kMergeTile, total);
+  const u32 diag = (u32)min((u64)t * tile, (u64)total);
   u32 lo = diag > nB ? diag - nB : 0u, hi = min(diag, nA);
   while (lo < hi) {
     const u32 mid = (lo + hi) >> 1;
@@ -738,36 +740,56 @@ __global__ __launch_bounds__(kBlock) void k_merge_partition(const Tup12 *__restr
 
 // out_sa[k] = text position of the k-th smallest suffix (coalesced); out_pairs[k] = (pos, k+1) feeds
 // the windowed inversion that gives the parent level rank[pos] = k+1 (R[SA12[i]] = i+1, lib.rs:106-108).
-__global__ __launch_bounds__(kBlock) void k_merge(const Tup12 *__restrict__ A, u32 nA, const Tup0 *__restrict__ B,
-                                                 u32 nB, const u32 *__restrict__ part, u32 *__restrict__ out_sa,
-                                                 Rec8 *__restrict__ out_pairs) {
-  __shared__ Tup12 sa[kMergeTile];
-  __shared__ Tup0 sb[kMergeTile];
+// NT threads, VT outputs per thread; the tile's inputs are staged in LDS, outputs are staged in LDS
+// too so that global stores are coalesced.
+template <int NT, int VT>
+struct MergeSmem { static constexpr size_t kBytes = (sizeof(Tup12) + sizeof(Tup0)) * (size_t)(NT * VT) + 64; };
+
+template <int NT, int VT>
+__global__ __launch_bounds__(NT) void k_merge(const Tup12 *__restrict__ A, u32 nA, const Tup0 *__restrict__ B, u32 nB,
+                                             const u32 *__restrict__ part, u32 *__restrict__ out_sa,
+                                             Rec8 *__restrict__ out_pairs) {
+  constexpr u32 kTile = NT * VT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Tup12 *sa = reinterpret_cast<Tup12 *>(smem);
+  Tup0 *sb = reinterpret_cast<Tup0 *>(smem + sizeof(Tup12) * kTile);
   const u32 total = nA + nB;
-  const u32 d0 = blockIdx.x * (u32)kMergeTile;
-  const u32 d1 = min(d0 + (u32)kMergeTile, total);
+  const u32 d0 = blockIdx.x * kTile;
+  const u32 d1 = min(d0 + kTile, total);
   const u32 a0 = part[blockIdx.x], a1 = part[blockIdx.x + 1];
   const u32 b0 = d0 - a0, b1 = d1 - a1;
   const u32 na = a1 - a0, nb = b1 - b0;
-  for (u32 i = threadIdx.x; i < na; i += kBlock) sa[i] = A[a0 + i];
-  for (u32 i = threadIdx.x; i < nb; i += kBlock) sb[i] = B[b0 + i];
+  for (u32 i = threadIdx.x; i < na; i += NT) sa[i] = A[a0 + i];
+  for (u32 i = threadIdx.x; i < nb; i += NT) sb[i] = B[b0 + i];
   __syncthreads();
-  const u32 dl = min(threadIdx.x * (u32)kMergeVT, na + nb);
+  const u32 dl = min(threadIdx.x * (u32)VT, na + nb);
   u32 lo = dl > nb ? dl - nb : 0u, hi = min(dl, na);
   while (lo < hi) {
     const u32 mid = (lo + hi) >> 1;
     if (sample_before(sa[mid], sb[dl - 1 - mid])) lo = mid + 1; else hi = mid;
   }
   u32 ai = lo, bi = dl - lo;
+  u32 outp[VT];
 #pragma unroll
-  for (int v = 0; v < kMergeVT; v++) {
+  for (int v = 0; v < VT; v++) {
     const u32 k = dl + v;
-    if (k >= na + nb) break;
-    const bool takeA = (bi >= nb) || (ai < na && sample_before(sa[ai], sb[bi]));
-    const u32 pos = takeA ? sa[ai].pos : sb[bi].pos;
-    ai += takeA ? 1u : 0u; bi += takeA ? 0u : 1u;
-    if (out_sa) out_sa[d0 + k] = pos;
-    if (out_pairs) out_pairs[d0 + k] = Rec8{pos, d0 + k + 1};
+    outp[v] = 0;
+    if (k < na + nb) {
+      const bool takeA = (bi >= nb) || (ai < na && sample_before(sa[ai], sb[bi]));
+      outp[v] = takeA ? sa[ai].pos : sb[bi].pos;
+      ai += takeA ? 1u : 0u; bi += takeA ? 0u : 1u;
+    }
+  }
+  __syncthreads();                       // inputs are dead: reuse the front of LDS as the output stage
+  u32 *so = reinterpret_cast<u32 *>(smem);
+#pragma unroll
+  for (int v = 0; v < VT; v++) so[threadIdx.x * VT + v] = outp[v];
+  __syncthreads();
+  const u32 nout = d1 - d0;
+  for (u32 q = threadIdx.x; q < nout; q += NT) {
+    const u32 pos = so[q];
+    if (out_sa) out_sa[d0 + q] = pos;
+    if (out_pairs) out_pairs[d0 + q] = Rec8{pos, d0 + q + 1};
   }
 }
 

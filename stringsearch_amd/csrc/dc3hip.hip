@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstring>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/dc3hip.h"
@@ -68,6 +69,7 @@ struct dc3hip_ctx {
   // profiling
   bool profile = true;
   bool no_hybrid = false;
+  int merge_cfg = 1;
   std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
   std::vector<PhaseMark> marks;
   hipEvent_t ev_build_a = nullptr, ev_build_b = nullptr;
@@ -172,28 +174,48 @@ template <> struct SortCfg<Tup0>  { static constexpr int IPT = 6, NW = 16, kClas
 template <class Dig> static Dig make_digit(u32 pass, u32) { Dig d; d.p = pass; return d; }
 template <> Rec8Shift make_digit<Rec8Shift>(u32 pass, u32 shift0) { Rec8Shift d; d.shift = shift0 + 8 * pass; return d; }
 
-template <class Rec>
-static int radix_sort(dc3hip_ctx *c, Rec *a, Rec *b, u32 n, u32 nbytes, Rec **result, int ph_up, int ph_scan,
-                      int ph_down, u32 digit_shift = 0) {
+template <class Rec, class Loader>
+static int launch_downsweep(dc3hip_ctx *c, Loader in, Rec *dst, u32 n, const Chunking &ck,
+                            typename SortCfg<Rec>::Dig dig, const u32 *table, const u32 *digit_base, int phase) {
   typedef typename SortCfg<Rec>::Dig Dig;
-  constexpr int IPT = SortCfg<Rec>::IPT;
-  constexpr int NW = SortCfg<Rec>::NW;
-  constexpr int kTile = NW * 64 * IPT;
+  constexpr int IPT = SortCfg<Rec>::IPT, NW = SortCfg<Rec>::NW;
+  constexpr bool PF = SortCfg<Rec>::PF && std::is_same<Loader, ArrayLoader<Rec>>::value;
   const size_t smem = DownsweepSmem<Rec, IPT, NW>::kBytes;
+  auto kern = k_rs_downsweep<Rec, Dig, IPT, NW, PF, Loader>;
   static thread_local bool attr_set[16] = {false};
-  auto kern = k_rs_downsweep<Rec, Dig, IPT, NW, SortCfg<Rec>::PF>;
   if (!attr_set[c->device & 15]) {
     HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)smem));
     attr_set[c->device & 15] = true;
   }
+  PhaseScope ps(c, phase, n, SortCfg<Rec>::kClass);
+  hipLaunchKernelGGL(kern, dim3(ck.nchunks), dim3(NW * 64), smem, c->stream, in, dst, n, ck.chunk, ck.nchunks, dig,
+                     table, digit_base);
+  KCHECK();
+  return E_OK;
+}
+static int scan_digit_table(dc3hip_ctx *c, u32 *table, u32 nchunks, u32 *digit_base, int phase) {
+  PhaseScope ps(c, phase, 256 * nchunks);
+  hipLaunchKernelGGL(k_scan_rows, dim3(256), dim3(kBlock), 0, c->stream, table, nchunks, digit_base);
+  KCHECK();
+  hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, digit_base, 256u, (u32 *)nullptr);
+  KCHECK();
+  return E_OK;
+}
+
+// passes first_pass..nbytes-1 over records in `a` (ping-pong with `b`)
+template <class Rec>
+static int radix_sort(dc3hip_ctx *c, Rec *a, Rec *b, u32 n, u32 nbytes, Rec **result, int ph_up, int ph_scan,
+                      int ph_down, u32 digit_shift = 0, u32 first_pass = 0) {
+  typedef typename SortCfg<Rec>::Dig Dig;
+  constexpr int kTile = SortCfg<Rec>::NW * 64 * SortCfg<Rec>::IPT;
   const Chunking ck = make_chunks(c, n, kTile);
   const ArenaMark mk = arena_mark(c);
   u32 *table = nullptr, *digit_base = nullptr;
   RC(arena_alloc(c, (size_t)256 * ck.nchunks, &table));
   RC(arena_alloc(c, (size_t)256, &digit_base));
   Rec *src = a, *dst = b;
-  for (u32 p = 0; p < nbytes; p++) {
+  for (u32 p = first_pass; p < nbytes; p++) {
     const Dig dig = make_digit<Dig>(p, digit_shift);
     {
       PhaseScope ps(c, ph_up, n);
@@ -201,19 +223,9 @@ static int radix_sort(dc3hip_ctx *c, Rec *a, Rec *b, u32 n, u32 nbytes, Rec **re
                          ck.nchunks, dig, table);
       KCHECK();
     }
-    {
-      PhaseScope ps(c, ph_scan, 256 * ck.nchunks);
-      hipLaunchKernelGGL(k_scan_rows, dim3(256), dim3(kBlock), 0, c->stream, table, ck.nchunks, digit_base);
-      KCHECK();
-      hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, digit_base, 256u, (u32 *)nullptr);
-      KCHECK();
-    }
-    {
-      PhaseScope ps(c, ph_down, n, SortCfg<Rec>::kClass);
-      hipLaunchKernelGGL(kern, dim3(ck.nchunks), dim3(NW * 64), smem, c->stream, src, dst, n, ck.chunk, ck.nchunks,
-                         dig, table, digit_base);
-      KCHECK();
-    }
+    RC(scan_digit_table(c, table, ck.nchunks, digit_base, ph_scan));
+    ArrayLoader<Rec> ld; ld.p = src;
+    RC((launch_downsweep<Rec, ArrayLoader<Rec>>(c, ld, dst, n, ck, dig, table, digit_base, ph_down)));
     std::swap(src, dst);
   }
   arena_release(c, mk);
@@ -430,6 +442,16 @@ static int order_hybrid(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u32
   return E_OK;
 }
 
+template <int NT, int VT>
+static int launch_merge(dc3hip_ctx *c, u32 ntiles, const Tup12 *A, u32 nA, const Tup0 *B, u32 nB, const u32 *part,
+                        u32 *out_sa, Rec8 *out_pairs) {
+  auto kern = k_merge<NT, VT>;
+  const size_t smem = MergeSmem<NT, VT>::kBytes;
+  HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(kern, dim3(ntiles), dim3(NT), smem, c->stream, A, nA, B, nB, part, out_sa, out_pairs);
+  return E_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // one DC3 level (lib.rs:44-193) on the device.
 //   S: symbols in 1..K with zero tail, m >= 2
@@ -516,11 +538,15 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
   }
 
   // ---- Step 2 + 3: tuples, mod-0 order, merge -------------------------------------------------
+  // t12 = sample tuples in SA12 order.  The gather also produces the digit table of the fused
+  // "select mod-0 + first radix pass" (Step 2, lib.rs:118-126).
   Tup12 *tslot = nullptr, *t12 = nullptr;
   RC(arena_alloc(c, (size_t)m02, &t12));
-  const Chunking ckc = make_chunks(c, m02, kBlock);
-  u32 *mod0_counts = nullptr;
-  RC(arena_alloc(c, (size_t)ckc.nchunks + 16, &mod0_counts));
+  constexpr u32 kTup0Tile = SortCfg<Tup0>::NW * 64 * SortCfg<Tup0>::IPT;
+  const Chunking ckc = make_chunks(c, m02, kTup0Tile);
+  u32 *table0 = nullptr, *dbase0 = nullptr;
+  RC(arena_alloc(c, (size_t)256 * ckc.nchunks, &table0));
+  RC(arena_alloc(c, (size_t)256, &dbase0));
   const ArenaMark mk_tslot = arena_mark(c);
   RC(arena_alloc(c, (size_t)m02, &tslot));
   {
@@ -529,7 +555,7 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
                        rank12, tslot);
     KCHECK();
     hipLaunchKernelGGL(k_gather_tuples, dim3(ckc.nchunks), dim3(kBlock), 0, c->stream, tslot, sa12, m02, ckc.chunk,
-                       t12, mod0_counts);
+                       ckc.nchunks, t12, table0);
     KCHECK();
   }
   arena_release(c, mk_tslot);   // slot-order tuples are dead; their space is reused below
@@ -537,19 +563,20 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
   RC(arena_alloc(c, (size_t)m0, &z0));
   RC(arena_alloc(c, (size_t)m0, &z1));
   {
-    PhaseScope ps(c, DC3HIP_PH_COMPACT, m02);
-    hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, mod0_counts, ckc.nchunks,
-                       (u32 *)nullptr);
-    KCHECK();
-    hipLaunchKernelGGL(k_mod0_write, dim3(ckc.nchunks), dim3(kBlock), 0, c->stream, t12, m02, ckc.chunk, mod0_counts,
-                       z0);
-    KCHECK();
+    // pass 0 of the mod-0 sort reads the sample tuples directly (selection fused in the loader)
+    RC(scan_digit_table(c, table0, ckc.nchunks, dbase0, DC3HIP_PH_COMPACT));
+    Mod0Loader ld; ld.t = t12;
+    Tup0Byte dig; dig.p = 0;
+    RC((launch_downsweep<Tup0, Mod0Loader>(c, ld, z0, m02, ckc, dig, table0, dbase0, DC3HIP_PH_COMPACT)));
   }
-  RC(radix_sort<Tup0>(c, z0, z1, m0, (bits_of(K - 1) + 7) / 8, &zs, DC3HIP_PH_SORT0, DC3HIP_PH_SORT0, DC3HIP_PH_SORT0));
+  RC(radix_sort<Tup0>(c, z0, z1, m0, (bits_of(K - 1) + 7) / 8, &zs, DC3HIP_PH_SORT0, DC3HIP_PH_SORT0, DC3HIP_PH_SORT0,
+                      0, 1));
   {
     const u32 dskip = m0 - m1;                  // lib.rs:133: skip the dummy, which sorts first
     const u32 nA = m02 - dskip, nB = m0;
-    const u32 ntiles = (m + kMergeTile - 1) / kMergeTile;
+    const int cfg = c->merge_cfg;
+    const u32 tile = cfg == 0 ? 256u * 4 : cfg == 1 ? 512u * 2 : cfg == 2 ? 512u * 4 : cfg == 3 ? 1024u * 2 : cfg == 4 ? 128u * 4 : cfg == 5 ? 1024u * 4 : 256u * 2;
+    const u32 ntiles = (m + tile - 1) / tile;
     u32 *part = nullptr;
     RC(arena_alloc(c, (size_t)ntiles + 16, &part));
     Rec8 *pa = nullptr, *pb = nullptr;
@@ -560,10 +587,17 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
     {
       PhaseScope ps(c, DC3HIP_PH_MERGE, m);
       hipLaunchKernelGGL(k_merge_partition, dim3((ntiles + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
-                         t12 + dskip, nA, zs, nB, ntiles, part);
+                         t12 + dskip, nA, zs, nB, ntiles, tile, part);
       KCHECK();
-      hipLaunchKernelGGL(k_merge, dim3(ntiles), dim3(kBlock), 0, c->stream, t12 + dskip, nA, zs, nB, part, out_sa,
-                         pa);
+      switch (cfg) {
+        case 0: RC((launch_merge<256, 4>(c, ntiles, t12 + dskip, nA, zs, nB, part, out_sa, pa))); break;
+        case 1: RC((launch_merge<512, 2>(c, ntiles, t12 + dskip, nA, zs, nB, part, out_sa, pa))); break;
+        case 2: RC((launch_merge<512, 4>(c, ntiles, t12 + dskip, nA, zs, nB, part, out_sa, pa))); break;
+        case 3: RC((launch_merge<1024, 2>(c, ntiles, t12 + dskip, nA, zs, nB, part, out_sa, pa))); break;
+        case 4: RC((launch_merge<128, 4>(c, ntiles, t12 + dskip, nA, zs, nB, part, out_sa, pa))); break;
+        case 5: RC((launch_merge<1024, 4>(c, ntiles, t12 + dskip, nA, zs, nB, part, out_sa, pa))); break;
+        default: RC((launch_merge<256, 2>(c, ntiles, t12 + dskip, nA, zs, nB, part, out_sa, pa))); break;
+      }
       KCHECK();
     }
     if (out_rank) RC(inverse_permute(c, pa, pb, m, out_rank, DC3HIP_PH_RANKS));
@@ -660,6 +694,8 @@ int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) {
   c->profile = !(prof && prof[0] == '0');
   const char *nh = getenv("DC3HIP_NO_HYBRID");
   c->no_hybrid = (nh && nh[0] == '1');
+  const char *mc = getenv("DC3HIP_MERGE_CFG");
+  if (mc) c->merge_cfg = atoi(mc);
   int rc = [&]() -> int {
     HIPC(hipSetDevice(device));
     hipDeviceProp_t prop;
