@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--cpu-sample-mib", type=int, default=64)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--dump-stats", type=str, default=None, help="write the last build's dc3hip_stats as JSON here")
     args = ap.parse_args()
 
     import numpy as np
@@ -103,7 +104,8 @@ def main():
             sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ      # launched by torch.distributed.run
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
@@ -119,7 +121,7 @@ def main():
     ctx.generate(n, args.seed, kind, offset=off)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -138,16 +140,18 @@ def main():
     t0 = time.perf_counter()
     kernel_ms = 0.0
     dsw_ms = [0.0] * 3; dsw_launches = [0] * 3; dsw_elems = [0] * 3
+    g_ms = 0.0; g_launches = 0; g_elems = 0
     for _ in range(args.steps):
         ctx.build()
         st = ctx.stats()
         kernel_ms += st["build_ms"]
+        g_ms += st["gather_ms"]; g_launches += st["gather_launches"]; g_elems += st["gather_elems"]
         for k in range(3):
             dsw_ms[k] += st["downsweep_ms"][k]; dsw_launches[k] += st["downsweep_launches"][k]
             dsw_elems[k] += st["downsweep_elems"][k]
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -180,6 +184,27 @@ def main():
                     "moved_bytes_per_launch": 2.0 * rec_bytes * per_launch_elems,
                     "moved_GBps": 2.0 * rec_bytes * per_launch_elems / (avg_ms * 1e-3) / 1e9,
                     "all_record_types_ms_per_step": [x / args.steps for x in dsw_ms]}
+        pmc = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        except Exception:
+            pass
+        if roof is not None and pmc is not None:
+            key = ("downsweep_rec8", "downsweep_rec16", "downsweep_tup0")[kc]
+            if key in pmc.get("bytes_per_record", {}):
+                roof["traffic"] = pmc["bytes_per_record"][key] * per_launch_elems
+                roof["traffic_source"] = pmc.get("source")
+        roof_gather = None
+        if g_launches:
+            ge = g_elems / g_launches; gms = g_ms / g_launches
+            # per sample suffix: read SA12[i] (w) + one 16-byte tuple (gathered) + write 16 bytes
+            roof_gather = {"bound": "hbm", "kernel": "k_gather_tuples (one random 16-byte gather per sample suffix)",
+                           "achieved": 36.0 * ge / (gms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": 36.0 * ge / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "traffic": (pmc["bytes_per_record"]["gather_tuples"] * ge) if pmc and "gather_tuples" in pmc.get("bytes_per_record", {}) else None,
+                           "algorithmic_bytes_per_launch": 36.0 * ge, "avg_launch_ms": gms,
+                           "launches_per_step": g_launches / args.steps, "share_of_build_time": g_ms / kernel_ms,
+                           "gathers_per_second_G": ge / (gms * 1e-3) / 1e9}
         alg = algorithmic_bytes(st["level_n"])
         path = {"algorithmic_bytes_per_step": alg, "device_ms_per_step": kernel_ms / args.steps,
                 "achieved_GBps": alg / (kernel_ms / args.steps * 1e-3) / 1e9,
@@ -195,7 +220,7 @@ def main():
                                    f"i32 SA, DC3 HIP, text and SA resident in HBM",
                        "bytes_per_gpu": n, "total_bytes": total_len,
                        "partitioning": "single SA" if world == 1 else f"sacapart: {world} chunks of len/{world}+1 bytes, one per GPU, no collective"},
-            "roofline": roof, "roofline_path": path, "verify": verify,
+            "roofline": roof, "roofline_gather": roof_gather, "roofline_path": path, "verify": verify,
             "arena_peak_GB": st["arena_peak"] / 1e9,
         }
         if world == 1 and not args.no_cpu:
@@ -207,8 +232,10 @@ def main():
                 out["cpu_baseline"] = cb
                 if sample_bytes == n and not args.no_verify:
                     out["verify"]["equal_cpu_reference"] = bool(np.array_equal(cpu_sa, ctx.sa()))
+    if args.dump_stats and rank == 0:
+        json.dump(st, open(args.dump_stats, "w"))
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -138,6 +138,8 @@ typedef struct dc3hip_stats {
   int64_t downsweep_elems[3];             /* records moved, summed over launches */
   /* k_part_msd: non-stable window partition of (destination,value) pairs (inverse permutations) */
   double  partition_ms; int64_t partition_launches; int64_t partition_elems;
+  /* k_gather_tuples: the one random 16-byte gather per sample suffix */
+  double  gather_ms; int64_t gather_launches; int64_t gather_elems;
   int64_t arena_bytes;                    /* device work arena size */
   int64_t arena_peak;                     /* high-water mark of the last build */
 } dc3hip_stats;

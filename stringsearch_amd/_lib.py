@@ -31,7 +31,9 @@ class Stats(ctypes.Structure):
                 ("downsweep_ms", ctypes.c_double * 3), ("downsweep_launches", ctypes.c_int64 * 3),
                 ("downsweep_elems", ctypes.c_int64 * 3),
                 ("partition_ms", ctypes.c_double), ("partition_launches", ctypes.c_int64),
-                ("partition_elems", ctypes.c_int64), ("arena_bytes", ctypes.c_int64),
+                ("partition_elems", ctypes.c_int64),
+                ("gather_ms", ctypes.c_double), ("gather_launches", ctypes.c_int64), ("gather_elems", ctypes.c_int64),
+                ("arena_bytes", ctypes.c_int64),
                 ("arena_peak", ctypes.c_int64)]
 
     def as_dict(self):
@@ -49,6 +51,7 @@ class Stats(ctypes.Structure):
             "downsweep_elems": list(self.downsweep_elems),
             "partition_ms": self.partition_ms, "partition_launches": self.partition_launches,
             "partition_elems": self.partition_elems,
+            "gather_ms": self.gather_ms, "gather_launches": self.gather_launches, "gather_elems": self.gather_elems,
             "arena_bytes": self.arena_bytes, "arena_peak": self.arena_peak,
         }
 

@@ -554,9 +554,12 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
     hipLaunchKernelGGL((k_build_tuples<Sym>), dim3(grid_for(c, m0)), dim3(kBlock), 0, c->stream, S, m, m0, m02,
                        rank12, tslot);
     KCHECK();
-    hipLaunchKernelGGL(k_gather_tuples, dim3(ckc.nchunks), dim3(kBlock), 0, c->stream, tslot, sa12, m02, ckc.chunk,
-                       ckc.nchunks, t12, table0);
-    KCHECK();
+    {
+      PhaseScope pg(c, DC3HIP_PH_OTHER, m02, 4);   // timed separately as kernel class 4 (gather)
+      hipLaunchKernelGGL(k_gather_tuples, dim3(ckc.nchunks), dim3(kBlock), 0, c->stream, tslot, sa12, m02, ckc.chunk,
+                         ckc.nchunks, t12, table0);
+      KCHECK();
+    }
   }
   arena_release(c, mk_tslot);   // slot-order tuples are dead; their space is reused below
   Tup0 *z0 = nullptr, *z1 = nullptr, *zs = nullptr;
@@ -650,8 +653,11 @@ static int ctx_build(dc3hip_ctx *c) {
     for (const PhaseMark &m : c->marks) {
       float t = 0;
       if (hipEventElapsedTime(&t, m.a, m.b) != hipSuccess) continue;
-      c->stats.phase_ms[m.phase] += t;
-      c->stats.phase_launches[m.phase] += 1;
+      if (m.kclass != 4) {   // class 4 is nested inside the TUPLES phase mark
+        c->stats.phase_ms[m.phase] += t;
+        c->stats.phase_launches[m.phase] += 1;
+      }
+      if (m.kclass == 4) { c->stats.gather_ms += t; c->stats.gather_launches += 1; c->stats.gather_elems += m.elems; continue; }
       if (m.kclass == 3) { c->stats.partition_ms += t; c->stats.partition_launches += 1; c->stats.partition_elems += m.elems; }
       if (m.kclass >= 0 && m.kclass < 3) {
         c->stats.downsweep_ms[m.kclass] += t; c->stats.downsweep_launches[m.kclass] += 1;
