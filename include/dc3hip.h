@@ -62,6 +62,10 @@ DC3HIP_API int32_t dc3hip_sufsort_ex(const uint8_t *T, void *SA, int64_t n, cons
  * are reported as -5 (allocation) / -6 (HIP error), outside sufcheck's own range). */
 DC3HIP_API int32_t dc3hip_sufcheck_i32(const uint8_t *T, const int32_t *SA, int32_t n);
 
+/* divbwt() twin (divsufsort.c:372-405, divsufsort.h:78-88): Burrows-Wheeler transform via the GPU suffix
+ * array; returns the primary index (>= 0) or a negative error code.  A is ignored (may be NULL). */
+DC3HIP_API int32_t dc3hip_divbwt_i32(const uint8_t *T, uint8_t *U, int32_t *A, int32_t n);
+
 DC3HIP_API const char *dc3hip_version(void);
 DC3HIP_API const char *dc3hip_last_error(void); /* thread-local, never NULL */
 DC3HIP_API int32_t dc3hip_device_count(void);   /* number of visible HIP devices, <0 on error */
@@ -95,6 +99,18 @@ DC3HIP_API int32_t dc3hip_ctx_get_text(dc3hip_ctx *ctx, uint8_t *T);
 /* Verify the device-resident SA against the device-resident text on the GPU.
  * Returns the sufcheck() codes above. */
 DC3HIP_API int32_t dc3hip_ctx_sufcheck(dc3hip_ctx *ctx);
+
+/* Load a suffix array built elsewhere (e.g. by libdivsufsort) next to the text already set. */
+DC3HIP_API int32_t dc3hip_ctx_set_sa_i32(dc3hip_ctx *ctx, const int32_t *SA);
+
+/* bw_transform() of utils.c:53-108 on the device-resident text/SA: U receives n bytes. */
+DC3HIP_API int32_t dc3hip_ctx_bwt(dc3hip_ctx *ctx, uint8_t *U, int64_t *primary_index);
+
+/* Batched sacabase::longest_substring_match (sacabase/src/lib.rs:39-99): needle k is
+ * needles[offsets[k] .. offsets[k+1]); out_start/out_len receive the match exactly as the reference's
+ * binary-search narrowing would return it (LongestCommonSubstring.start / .len). */
+DC3HIP_API int32_t dc3hip_ctx_search(dc3hip_ctx *ctx, const uint8_t *needles, const int64_t *offsets, int32_t count,
+                                     int64_t *out_start, int64_t *out_len);
 
 /* 64-bit order-sensitive checksum of the device-resident SA (sum over k of mix(k, SA[k])). */
 DC3HIP_API int32_t dc3hip_ctx_sa_checksum(dc3hip_ctx *ctx, uint64_t *out);

@@ -63,6 +63,7 @@ SYMBOLS = {
     "dc3hip_sufsort_i64": (_i32, [_vp, _vp, _i64]),
     "dc3hip_sufsort_ex": (_i32, [_vp, _vp, _i64, ctypes.POINTER(Opts)]),
     "dc3hip_sufcheck_i32": (_i32, [_vp, _vp, _i32]),
+    "dc3hip_divbwt_i32": (_i32, [_vp, _vp, _vp, _i32]),
     "dc3hip_version": (ctypes.c_char_p, []),
     "dc3hip_last_error": (ctypes.c_char_p, []),
     "dc3hip_device_count": (_i32, []),
@@ -77,6 +78,9 @@ SYMBOLS = {
     "dc3hip_ctx_get_text": (_i32, [_vp, _vp]),
     "dc3hip_ctx_sufcheck": (_i32, [_vp]),
     "dc3hip_ctx_sa_checksum": (_i32, [_vp, ctypes.POINTER(_u64)]),
+    "dc3hip_ctx_set_sa_i32": (_i32, [_vp, _vp]),
+    "dc3hip_ctx_bwt": (_i32, [_vp, _vp, ctypes.POINTER(_i64)]),
+    "dc3hip_ctx_search": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp]),
     "dc3hip_ctx_stats": (_i32, [_vp, ctypes.POINTER(Stats)]),
 }
 

@@ -250,6 +250,30 @@ class Context:
         _check(lib().dc3hip_ctx_sa_checksum(self._h, ctypes.byref(v)))
         return int(v.value)
 
+    def set_sa(self, sa):
+        s = np.ascontiguousarray(sa, dtype=np.int32)
+        assert len(s) == self.n
+        _check(lib().dc3hip_ctx_set_sa_i32(self._h, s.ctypes.data if self.n else None))
+
+    def bwt(self):
+        """bw_transform (utils.c:53-108): returns (U, primary_index)."""
+        u = np.zeros(self.n, dtype=np.uint8)
+        idx = ctypes.c_int64()
+        _check(lib().dc3hip_ctx_bwt(self._h, u.ctypes.data if self.n else None, ctypes.byref(idx)))
+        return u, int(idx.value)
+
+    def search(self, needles):
+        """Batched longest_substring_match on the GPU: list of bytes-like -> list of (start, len)."""
+        nds = [_as_u8(x) for x in needles]
+        if not nds:
+            return []
+        off = np.zeros(len(nds) + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(x) for x in nds])
+        cat = np.concatenate(nds) if off[-1] else np.zeros(1, dtype=np.uint8)
+        st = np.zeros(len(nds), dtype=np.int64); ln = np.zeros(len(nds), dtype=np.int64)
+        _check(lib().dc3hip_ctx_search(self._h, cat.ctypes.data, off.ctypes.data, len(nds), st.ctypes.data, ln.ctypes.data))
+        return list(zip(st.tolist(), ln.tolist()))
+
     def stats(self):
         st = Stats()
         _check(lib().dc3hip_ctx_stats(self._h, ctypes.byref(st)))

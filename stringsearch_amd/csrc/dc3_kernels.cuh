@@ -901,6 +901,65 @@ __global__ __launch_bounds__(kBlock) void k_checksum(const u32 *__restrict__ sa,
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
   if (lane_id() == 0) atomicAdd((unsigned long long *)out, (unsigned long long)acc);
 }
+// ---------------------------------------------------------------------------------------------
+// By-products of the suffix array ("next" rows of the scope table).
+// BWT: bw_transform()/divbwt() of crates/cdivsufsort/c-sources (utils.c:53-108, divsufsort.c:372-405):
+//   U[0] = T[n-1]; then T[SA[i]-1] for every i with SA[i] != 0, in order; primary index = (i: SA[i]==0) + 1
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_find_zero(const u32 *__restrict__ sa, u32 n, u32 *zpos) {
+  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) if (sa[i] == 0) *zpos = i;
+}
+__global__ __launch_bounds__(kBlock) void k_bwt(const uint8_t *__restrict__ t, const u32 *__restrict__ sa, u32 n,
+                                               const u32 *__restrict__ zpos, uint8_t *__restrict__ u) {
+  const u32 z = *zpos;
+  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    if (i == z) continue;
+    const uint8_t ch = t[sa[i] - 1];
+    u[i < z ? i + 1 : i] = ch;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) u[0] = t[n - 1];
+}
+
+// Batched search = sacabase::longest_substring_match (crates/sacabase/src/lib.rs:39-99), one thread
+// per needle, the reference's own narrowing loop (mid = len/2; needle > suffix(mid) ? right : left
+// inclusive; 1-2 survivors compared by common prefix) so that (start, len) are identical.
+__device__ __forceinline__ u32 d_common_prefix(const uint8_t *a, u64 la, const uint8_t *b, u64 lb) {
+  const u64 l = la < lb ? la : lb;
+  u64 i = 0;
+  while (i < l && a[i] == b[i]) i++;
+  return (u32)i;
+}
+__global__ __launch_bounds__(kBlock) void k_search(const uint8_t *__restrict__ t, u32 n, const u32 *__restrict__ sa,
+                                                  const uint8_t *__restrict__ needles,
+                                                  const int64_t *__restrict__ off, u32 q,
+                                                  int64_t *__restrict__ out_start, int64_t *__restrict__ out_len) {
+  const u32 id = blockIdx.x * kBlock + threadIdx.x;
+  if (id >= q) return;
+  const uint8_t *nd = needles + off[id];
+  const u64 nl = (u64)(off[id + 1] - off[id]);
+  u32 lo = 0, len = n;
+  for (;;) {
+    if (len == 1) {
+      const u32 s = sa[lo];
+      out_start[id] = s; out_len[id] = d_common_prefix(t + s, n - s, nd, nl);
+      return;
+    }
+    if (len == 2) {
+      const u32 s0 = sa[lo], s1 = sa[lo + 1];
+      const u32 x = d_common_prefix(t + s0, n - s0, nd, nl), y = d_common_prefix(t + s1, n - s1, nd, nl);
+      if (x > y) { out_start[id] = s0; out_len[id] = x; } else { out_start[id] = s1; out_len[id] = y; }
+      return;
+    }
+    const u32 mid = len / 2;
+    const u32 s = sa[lo + mid];
+    const u64 sl = n - s;
+    const u32 c = d_common_prefix(t + s, sl, nd, nl);
+    // needle > suffix: first differing byte larger, or suffix is a proper prefix of the needle
+    const bool gt = (c < nl && c < sl) ? (nd[c] > t[s + c]) : (nl > sl);
+    if (gt) { lo += mid; len -= mid; } else { len = mid + 1; }
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void k_widen(const u32 *__restrict__ in, int64_t *__restrict__ out, u32 n) {
   for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) out[i] = (int64_t)in[i];
 }

@@ -872,6 +872,70 @@ int32_t dc3hip_ctx_sa_checksum(dc3hip_ctx *c, uint64_t *out) {
   return E_OK;
 }
 
+int32_t dc3hip_ctx_set_sa_i32(dc3hip_ctx *c, const int32_t *SA) {
+  if (!c || (!SA && c->n > 0)) { set_err("invalid arguments"); return E_ARGS; }
+  HIPC(hipSetDevice(c->device));
+  if (c->n > 0) HIPC(hipMemcpyAsync(c->d_sa, SA, (size_t)c->n * 4, hipMemcpyDefault, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  c->built = true;
+  return E_OK;
+}
+
+int32_t dc3hip_ctx_bwt(dc3hip_ctx *c, uint8_t *U, int64_t *primary_index) {
+  if (!c || !primary_index || (!U && c->n > 0)) { set_err("invalid arguments"); return E_ARGS; }   // utils.c:60
+  if (!c->built) { set_err("no suffix array built in this context"); return E_ARGS; }
+  const int64_t n = c->n;
+  HIPC(hipSetDevice(c->device));
+  if (n <= 1) {                                                                                    // utils.c:61-65
+    if (n == 1) HIPC(hipMemcpy(U, c->d_text, 1, hipMemcpyDefault));
+    *primary_index = n;
+    return E_OK;
+  }
+  c->arena_off = 0;
+  uint8_t *du = nullptr;
+  RC(arena_alloc(c, (size_t)n + 16, &du));
+  u32 *z = c->d_words + 24;
+  hipLaunchKernelGGL(k_find_zero, dim3(grid_for(c, n)), dim3(kBlock), 0, c->stream, c->d_sa, (u32)n, z);
+  KCHECK();
+  hipLaunchKernelGGL(k_bwt, dim3(grid_for(c, n)), dim3(kBlock), 0, c->stream, c->d_text, c->d_sa, (u32)n, z, du);
+  KCHECK();
+  HIPC(hipMemcpyAsync(c->h_words + 24, z, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipMemcpyAsync(U, du, (size_t)n, hipMemcpyDefault, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  *primary_index = (int64_t)c->h_words[24] + 1;                                                    // utils.c:97
+  c->arena_off = 0;
+  return E_OK;
+}
+
+int32_t dc3hip_ctx_search(dc3hip_ctx *c, const uint8_t *needles, const int64_t *offsets, int32_t count,
+                          int64_t *out_start, int64_t *out_len) {
+  if (!c || count < 0 || (count > 0 && (!needles || !offsets || !out_start || !out_len))) {
+    set_err("invalid arguments"); return E_ARGS;
+  }
+  if (!c->built) { set_err("no suffix array built in this context"); return E_ARGS; }
+  if (c->n == 0) { set_err("empty suffix array (the reference indexes out of bounds here)"); return E_ARGS; }
+  if (count == 0) return E_OK;
+  HIPC(hipSetDevice(c->device));
+  const int64_t total = offsets[count];
+  if (total < 0) { set_err("invalid needle offsets"); return E_ARGS; }
+  c->arena_off = 0;
+  uint8_t *dn = nullptr; int64_t *doff = nullptr, *ds = nullptr, *dl = nullptr;
+  RC(arena_alloc(c, (size_t)total + 16, &dn));
+  RC(arena_alloc(c, (size_t)count + 1, &doff));
+  RC(arena_alloc(c, (size_t)count, &ds));
+  RC(arena_alloc(c, (size_t)count, &dl));
+  if (total > 0) HIPC(hipMemcpyAsync(dn, needles, (size_t)total, hipMemcpyDefault, c->stream));
+  HIPC(hipMemcpyAsync(doff, offsets, ((size_t)count + 1) * 8, hipMemcpyDefault, c->stream));
+  hipLaunchKernelGGL(k_search, dim3((count + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->d_text, (u32)c->n,
+                     c->d_sa, dn, doff, (u32)count, ds, dl);
+  KCHECK();
+  HIPC(hipMemcpyAsync(out_start, ds, (size_t)count * 8, hipMemcpyDefault, c->stream));
+  HIPC(hipMemcpyAsync(out_len, dl, (size_t)count * 8, hipMemcpyDefault, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  c->arena_off = 0;
+  return E_OK;
+}
+
 int32_t dc3hip_ctx_stats(dc3hip_ctx *c, dc3hip_stats *out) {
   if (!c || !out) { set_err("invalid arguments"); return E_ARGS; }
   *out = c->stats;
@@ -942,6 +1006,27 @@ int32_t dc3hip_sufsort_i64(const uint8_t *T, int64_t *SA, int64_t n) {
   dc3hip_opts o; memset(&o, 0, sizeof(o));
   o.struct_size = (int32_t)sizeof(o); o.index_bits = 64; o.device = -1;
   return dc3hip_sufsort_ex(T, SA, n, &o);
+}
+
+// divbwt(T, U, A, n) (divsufsort.c:372-405): returns the primary index, -1 / -2 on error; A is an
+// optional temporary in the reference and unused here.
+int32_t dc3hip_divbwt_i32(const uint8_t *T, uint8_t *U, int32_t *A, int32_t n) {
+  (void)A;
+  if (T == nullptr || U == nullptr || n < 0) { set_err("invalid arguments"); return -1; }
+  if (n <= 1) { if (n == 1) U[0] = T[0]; return n; }
+  dc3hip_ctx *c = nullptr;
+  int rc = dc3hip_ctx_create(&c, -1, n);
+  if (rc != E_OK) return rc == E_ARGS ? -1 : (rc == E_ALLOC ? -2 : rc);
+  int64_t pidx = 0;
+  rc = [&]() -> int {
+    RC(dc3hip_ctx_set_text(c, T, n));
+    RC(ctx_build(c));
+    RC(dc3hip_ctx_bwt(c, U, &pidx));
+    return E_OK;
+  }();
+  dc3hip_ctx_destroy(c);
+  if (rc != E_OK) return rc;
+  return (int32_t)pidx;
 }
 
 int32_t dc3hip_sufcheck_i32(const uint8_t *T, const int32_t *SA, int32_t n) {

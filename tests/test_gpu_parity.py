@@ -205,6 +205,53 @@ def test_partitioned_search_on_gpu_sas(ss):
             assert (f.as_bytes(), f.start, f.len) == (p.as_bytes(), p.start, p.len)
 
 
+def test_bwt_matches_reference(ss, oracle):
+    """dc3hip_ctx_bwt / dc3hip_divbwt_i32 vs the reference's divbwt (divsufsort.c:372-405) when its build
+    travelled with the snapshot, and vs the definition from the oracle SA always."""
+    import ctypes
+    cases = [oracle.gen(100003, 3, 2).tobytes(), oracle.gen(4099, 4, 1).tobytes(), b"banana", b"mississippi", b"ab", b"a", b"aaaaaaa"]
+    for data in cases:
+        t = np.frombuffer(data, dtype=np.uint8)
+        u = np.zeros(len(t), dtype=np.uint8)
+        pidx = ss.lib().dc3hip_divbwt_i32(t.ctypes.data, u.ctypes.data, None, len(t))
+        sa = oracle.sufsort(data)
+        if len(t) > 1:
+            z = int(np.nonzero(sa == 0)[0][0])
+            want = np.concatenate([[t[-1]], t[sa[sa != 0] - 1]]).astype(np.uint8)
+            assert pidx == z + 1 and np.array_equal(u, want), data[:10]
+        else:
+            assert pidx == len(t) and bytes(u) == data
+        if oracle.ref is not None and len(t) > 0:
+            oracle.ref.divbwt.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]
+            oracle.ref.divbwt.restype = ctypes.c_int32
+            ur = np.zeros(len(t), dtype=np.uint8)
+            pr = oracle.ref.divbwt(t.ctypes.data, ur.ctypes.data, None, len(t))
+            assert pr == pidx and np.array_equal(ur, u), data[:10]
+    assert ss.lib().dc3hip_divbwt_i32(None, None, None, 5) == -1
+
+
+def test_batched_search_matches_reference_semantics(ss, oracle):
+    """GPU batched longest_substring_match == the restated sacabase search (start AND len), including
+    needles longer than the text, absent needles, and SAs loaded from elsewhere (set_sa)."""
+    rng = np.random.default_rng(12)
+    text = oracle.gen(200001, 8, 2)
+    tb = text.tobytes()
+    needles = [tb[a:a + l] for a, l in zip(rng.integers(0, 199000, 300), rng.integers(1, 40, 300))]
+    needles += [bytes(rng.integers(97, 123, size=int(l), dtype=np.uint8)) for l in rng.integers(1, 12, 200)]
+    needles += [b"", b"\x00", b"\xff" * 5, tb[-7:], tb[-7:] + b"zzz", tb[:50], tb + b"x"]
+    with ss.Context(len(text)) as c:
+        c.set_text(text); c.build()
+        sa = c.sa()
+        got = c.search(needles)
+        for nd, g in zip(needles, got):
+            assert g == oracle.search(text, sa, nd), nd[:20]
+    small = b"totor"
+    with ss.Context(len(small)) as c:
+        c.set_text(small); c.set_sa(oracle.sufsort(small))
+        assert c.search([b"tor", b"otor", b"x"]) == [oracle.search(small, oracle.sufsort(small), x) for x in (b"tor", b"otor", b"x")]
+        assert c.search([b"tor"])[0] == (2, 3)
+
+
 def test_cpp_host_mirror(ss):
     """C++ mirror of sacabase/sacapart + dc3hip::sort (stringsearch_amd/host): the reference's
     sacapart unit tests with the HIP SACA plugged in, and the divsuftest-style harness."""
@@ -222,6 +269,38 @@ def test_cpp_host_mirror(ss):
     out = subprocess.run([os.path.join(pkg, "sa_bench"), "run", "gen:dna:1m:3", "--partitions", "3"],
                          capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "Done in" in out.stdout, out.stdout + out.stderr
+
+
+def test_device_pointer_entry_and_smoke(ss):
+    """dc3hip_sufsort_ex with DC3HIP_F_DEVICE_PTRS (text and SA already in HBM, torch tensors as the
+    allocator) and __graft_entry__.smoke(); run in a child process because torch must be imported before
+    the library when both share a process."""
+    import subprocess, sys
+    from conftest import ROOT
+    code = r"""
+import ctypes, sys, numpy as np, torch
+sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
+import stringsearch_amd as ss
+from stringsearch_amd._lib import Opts
+from conftest import Oracle
+o = Oracle()
+data = o.gen(300007, 5, 2)
+t = torch.from_numpy(data).cuda(); sa = torch.zeros(len(data), dtype=torch.int32, device="cuda")
+opts = Opts(ctypes.sizeof(Opts), 32, 0, 0, 1)
+rc = ss.lib().dc3hip_sufsort_ex(t.data_ptr(), sa.data_ptr(), len(data), ctypes.byref(opts))
+assert rc == 0, ss.last_error()
+torch.cuda.synchronize()
+assert np.array_equal(sa.cpu().numpy(), o.sufsort(data))
+sa64 = torch.zeros(len(data), dtype=torch.int64, device="cuda")
+opts = Opts(ctypes.sizeof(Opts), 64, 0, 0, 1)
+assert ss.lib().dc3hip_sufsort_ex(t.data_ptr(), sa64.data_ptr(), len(data), ctypes.byref(opts)) == 0
+assert np.array_equal(sa64.cpu().numpy(), o.sufsort(data).astype(np.int64))
+import __graft_entry__ as g
+g.smoke()
+print("child ok")
+""" % (ROOT, ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0 and "child ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
 def test_concurrent_calls_are_thread_safe(ss, oracle):
