@@ -59,6 +59,11 @@ __device__ __forceinline__ u32 wave_incl_scan(u32 v) {
   for (int o = 1; o < 64; o <<= 1) { u32 t = __shfl_up(v, o); if (lane >= (u32)o) v += t; }
   return v;
 }
+__device__ __forceinline__ u32 wave_reduce_max(u32 v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, (u32)__shfl_xor(v, o));
+  return v;
+}
 __device__ __forceinline__ u32 wave_reduce(u32 v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -591,7 +596,7 @@ __global__ __launch_bounds__(kBlock) void k_tie_count(const Rec8 *__restrict__ h
 template <class Sym>
 __global__ __launch_bounds__(kBlock) void k_tie_compact(Sym S, u32 b, const Rec8 *__restrict__ h, u32 n, u32 chunk,
                                                        const u32 *__restrict__ base_excl, Rec16 *__restrict__ sub,
-                                                       u32 *__restrict__ tiedidx) {
+                                                       u32 *__restrict__ tiedidx, u32 *__restrict__ gkey) {
   __shared__ u32 tmp[kWaves];
   const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
   u32 running = base_excl[blockIdx.x];
@@ -604,8 +609,48 @@ __global__ __launch_bounds__(kBlock) void k_tie_compact(Sym S, u32 b, const Rec8
       const u32 p = h[i].val;
       sub[running + ex] = make_rec(S.get(p), S.get(p + 1), S.get(p + 2), b, p);
       tiedidx[running + ex] = i;
+      gkey[running + ex] = h[i].key;
     }
     running += tot;
+  }
+}
+// Tied samples form groups (equal hi32) that are tiny on high-entropy input (Poisson: almost all of
+// size 2-3).  When the largest group has at most kTieSmallMax members, one thread per group sorts
+// it by the full key with a stable insertion sort — instead of 10 radix passes over the subset.
+constexpr u32 kTieSmallMax = 16;
+__global__ __launch_bounds__(kBlock) void k_tie_groupmax(const u32 *__restrict__ gkey, u32 t, u32 *maxlen) {
+  u32 best = 0;
+  for (u32 j = blockIdx.x * kBlock + threadIdx.x; j < t; j += gridDim.x * kBlock) {
+    const u32 k = gkey[j];
+    if (j > 0 && gkey[j - 1] == k) continue;            // not a group start
+    u32 e = j + 1;
+    while (e < t && e - j <= kTieSmallMax && gkey[e] == k) e++;
+    best = max(best, e - j);
+  }
+  best = wave_reduce_max(best);
+  if (lane_id() == 0 && best) atomicMax(maxlen, best);
+}
+__device__ __forceinline__ bool key_less(const Rec16 &a, const Rec16 &b) {
+  if (a.k2 != b.k2) return a.k2 < b.k2;
+  if (a.k1 != b.k1) return a.k1 < b.k1;
+  return a.k0 < b.k0;
+}
+__global__ __launch_bounds__(kBlock) void k_tie_sort_small(const Rec16 *__restrict__ sub, const u32 *__restrict__ gkey,
+                                                          u32 t, Rec16 *__restrict__ out) {
+  for (u32 j = blockIdx.x * kBlock + threadIdx.x; j < t; j += gridDim.x * kBlock) {
+    const u32 k = gkey[j];
+    if (j > 0 && gkey[j - 1] == k) continue;
+    u32 e = j + 1;
+    while (e < t && gkey[e] == k) e++;
+    const u32 len = e - j;                               // <= kTieSmallMax (checked by the host)
+    Rec16 loc[kTieSmallMax];
+    for (u32 x = 0; x < len; x++) {                      // stable insertion sort (input is in position order)
+      const Rec16 v = sub[j + x];
+      u32 y = x;
+      while (y > 0 && key_less(v, loc[y - 1])) { loc[y] = loc[y - 1]; y--; }
+      loc[y] = v;
+    }
+    for (u32 x = 0; x < len; x++) out[j + x] = loc[x];
   }
 }
 __global__ __launch_bounds__(kBlock) void k_tie_writeback(const Rec16 *__restrict__ sub, const u32 *__restrict__ tiedidx,

@@ -70,6 +70,7 @@ struct dc3hip_ctx {
   bool profile = true;
   bool no_hybrid = false;
   int merge_cfg = 1;
+  bool no_small_ties = false;
   std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
   std::vector<PhaseMark> marks;
   hipEvent_t ev_build_a = nullptr, ev_build_b = nullptr;
@@ -418,18 +419,35 @@ static int order_hybrid(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u32
   HIPC(hipMemsetAsync(f, 1, (size_t)m02, c->stream));
   if (tied > 0) {
     Rec16 *sa = nullptr, *sb = nullptr, *ss = nullptr;
-    u32 *tiedidx = nullptr;
+    u32 *tiedidx = nullptr, *gkey = nullptr;
     RC(arena_alloc(c, (size_t)tied, &sa));
     RC(arena_alloc(c, (size_t)tied, &sb));
     RC(arena_alloc(c, (size_t)tied, &tiedidx));
+    RC(arena_alloc(c, (size_t)tied, &gkey));
+    u32 gmax = 0;
     {
       PhaseScope ps(c, DC3HIP_PH_TIES, tied);
       hipLaunchKernelGGL((k_tie_compact<Sym>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, S, b, h, m02, ck.chunk,
-                         counts, sa, tiedidx);
+                         counts, sa, tiedidx, gkey);
       KCHECK();
+      HIPC(hipMemsetAsync(c->d_words + 3, 0, sizeof(u32), c->stream));
+      hipLaunchKernelGGL(k_tie_groupmax, dim3(grid_for(c, tied)), dim3(kBlock), 0, c->stream, gkey, tied,
+                         c->d_words + 3);
+      KCHECK();
+      HIPC(hipMemcpyAsync(c->h_words + 3, c->d_words + 3, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
     }
-    RC(radix_sort<Rec16>(c, sa, sb, tied, nbytes, &ss, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN,
-                         DC3HIP_PH_SORT12_DOWN));
+    HIPC(hipStreamSynchronize(c->stream));
+    gmax = c->h_words[3];
+    if (gmax <= kTieSmallMax && !c->no_small_ties) {
+      // tiny groups: one thread sorts one group by the full key
+      PhaseScope ps(c, DC3HIP_PH_TIES, tied);
+      hipLaunchKernelGGL(k_tie_sort_small, dim3(grid_for(c, tied)), dim3(kBlock), 0, c->stream, sa, gkey, tied, sb);
+      KCHECK();
+      ss = sb;
+    } else {
+      RC(radix_sort<Rec16>(c, sa, sb, tied, nbytes, &ss, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN,
+                           DC3HIP_PH_SORT12_DOWN));
+    }
     {
       PhaseScope ps(c, DC3HIP_PH_TIES, tied);
       hipLaunchKernelGGL(k_tie_writeback, dim3(grid_for(c, tied)), dim3(kBlock), 0, c->stream, ss, tiedidx, tied, h, f);
@@ -700,6 +718,8 @@ int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) {
   c->profile = !(prof && prof[0] == '0');
   const char *nh = getenv("DC3HIP_NO_HYBRID");
   c->no_hybrid = (nh && nh[0] == '1');
+  const char *nst = getenv("DC3HIP_NO_SMALL_TIES");
+  c->no_small_ties = (nst && nst[0] == '1');
   const char *mc = getenv("DC3HIP_MERGE_CFG");
   if (mc) c->merge_cfg = atoi(mc);
   int rc = [&]() -> int {

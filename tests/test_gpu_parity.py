@@ -324,23 +324,31 @@ def test_hybrid_and_straight_paths_agree(ss, oracle):
     words = [bytes(rng.integers(97, 123, size=int(rng.integers(2, 9)), dtype=np.uint8)) + b" " for _ in range(300)]
     texty = b"".join(words[int(i)] for i in rng.integers(0, 300, size=n // 5))[:n]
     half = rng.integers(0, 256, size=n // 2, dtype=np.uint8).tobytes()
-    cases = {"random": oracle.gen(n, 21, 0).tobytes(), "text": texty, "repeat": half + half + b"!"}
+    rnd = oracle.gen(n, 21, 0).tobytes()
+    # a long zero run inside random data: few ties overall, but one huge tie group (radix sub-path)
+    zrun = rnd[:n // 2] + bytes(300_000) + rnd[n // 2 + 300_000:]
+    cases = {"random": rnd, "text": texty, "repeat": half + half + b"!", "zero_run": zrun}
     for label, data in cases.items():
         want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)
         seen = {}
-        for flag in ("0", "1"):
-            os.environ["DC3HIP_NO_HYBRID"] = flag
+        for env in ({}, {"DC3HIP_NO_HYBRID": "1"}, {"DC3HIP_NO_SMALL_TIES": "1"}):
+            os.environ.update(env)
             try:
                 with ss.Context(len(data)) as c:
                     c.set_text(data); c.build()
                     st = c.stats()
-                    assert np.array_equal(c.sa(), want), (label, flag)
-                    seen[flag] = st["level_sorted"]
+                    assert np.array_equal(c.sa(), want), (label, env)
+                    seen[tuple(env)] = st
             finally:
-                os.environ.pop("DC3HIP_NO_HYBRID", None)
-        assert 2 not in seen["1"]
-        if label == "random":
-            assert 2 in seen["0"], seen
+                for k in env:
+                    os.environ.pop(k, None)
+        assert 2 not in seen[("DC3HIP_NO_HYBRID",)]["level_sorted"]
+        if label in ("random", "zero_run"):
+            assert 2 in seen[()]["level_sorted"], seen[()]["level_sorted"]
+            # small-group path skips the 16-byte radix passes entirely; the zero run forces them
+            d16 = seen[()]["downsweep_launches"][1]
+            assert (d16 == 0) if label == "random" else (d16 > 0), (label, d16)
+            assert seen[("DC3HIP_NO_SMALL_TIES",)]["downsweep_launches"][1] > 0
 
 
 def test_config2_64mib_random_bit_exact(ss, oracle):
