@@ -18,6 +18,9 @@
  *     build supports (n > DC3HIP_MAX_N).  dc3hip_last_error() describes the failure (thread-local).
  *   - all entry points are re-entrant and thread-safe: every call owns its context and HIP stream
  *     (sacapart calls the SACA concurrently from rayon workers, crates/sacapart/src/lib.rs:41-49).
+ *     The one-shot calls keep that context (device buffers only, never caller data) in a per-thread
+ *     cache so that repeated calls do not pay hipMalloc again; dc3hip_release_cache() or thread exit
+ *     frees it, DC3HIP_CACHE=0 disables it.
  *   - there is NO CPU fallback: without a usable gfx950 device the calls fail with -3.
  *
  * Plain C, no torch / HIP types in any signature.
@@ -65,6 +68,9 @@ DC3HIP_API int32_t dc3hip_sufcheck_i32(const uint8_t *T, const int32_t *SA, int3
 /* divbwt() twin (divsufsort.c:372-405, divsufsort.h:78-88): Burrows-Wheeler transform via the GPU suffix
  * array; returns the primary index (>= 0) or a negative error code.  A is ignored (may be NULL). */
 DC3HIP_API int32_t dc3hip_divbwt_i32(const uint8_t *T, uint8_t *U, int32_t *A, int32_t n);
+
+/* Free the calling thread's cached one-shot context (see the contract above). */
+DC3HIP_API void dc3hip_release_cache(void);
 
 DC3HIP_API const char *dc3hip_version(void);
 DC3HIP_API const char *dc3hip_last_error(void); /* thread-local, never NULL */

@@ -18,6 +18,7 @@ from .api import (  # noqa: F401
     common_prefix_len,
     device_count,
     last_error,
+    release_cache,
     sort,
     sort_i64,
     sort_in_place,
@@ -28,6 +29,6 @@ from .api import (  # noqa: F401
 
 __all__ = [
     "Context", "Dc3HipError", "LongestCommonSubstring", "NotSorted", "PartitionedSuffixArray", "PHASES", "Stats",
-    "SuffixArray", "common_prefix_len", "device_count", "last_error", "lib", "lib_path", "sort", "sort_i64",
+    "SuffixArray", "common_prefix_len", "device_count", "last_error", "lib", "release_cache", "lib_path", "sort", "sort_i64",
     "sort_in_place", "sufcheck", "verify", "version",
 ]

@@ -64,6 +64,7 @@ SYMBOLS = {
     "dc3hip_sufsort_ex": (_i32, [_vp, _vp, _i64, ctypes.POINTER(Opts)]),
     "dc3hip_sufcheck_i32": (_i32, [_vp, _vp, _i32]),
     "dc3hip_divbwt_i32": (_i32, [_vp, _vp, _vp, _i32]),
+    "dc3hip_release_cache": (None, []),
     "dc3hip_version": (ctypes.c_char_p, []),
     "dc3hip_last_error": (ctypes.c_char_p, []),
     "dc3hip_device_count": (_i32, []),

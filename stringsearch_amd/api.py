@@ -16,6 +16,11 @@ def last_error():
     return lib().dc3hip_last_error().decode()
 
 
+def release_cache():
+    """Free the calling thread's cached one-shot device context."""
+    lib().dc3hip_release_cache()
+
+
 def device_count():
     return int(lib().dc3hip_device_count())
 

@@ -977,11 +977,41 @@ static bool tiny_host(const uint8_t *T, void *SA, int64_t n, int bits) {
   return true;
 }
 
+// One-shot calls keep their context (stream + device buffers) in a per-thread cache: a fresh
+// hipMalloc of a multi-GB arena costs 0.2-0.6 s on MI355X, far more than the build itself.  The
+// cache is private to the calling thread (so concurrent sacapart workers never share state), is
+// released by dc3hip_release_cache() or at thread exit, and is disabled by DC3HIP_CACHE=0.
+struct CtxCache {
+  dc3hip_ctx *c = nullptr;
+  ~CtxCache() { if (c) { dc3hip_ctx_destroy(c); c = nullptr; } }
+};
+static thread_local CtxCache g_cache;
+static bool cache_enabled() {
+  static const bool on = [] { const char *e = getenv("DC3HIP_CACHE"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
+static int acquire_ctx(dc3hip_ctx **out, int device, int64_t n, bool *cached) {
+  *cached = false;
+  if (cache_enabled()) {
+    int dev = device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = -1;
+    dc3hip_ctx *cc = g_cache.c;
+    if (cc && dev >= 0 && cc->device == dev && cc->max_n >= n) { *out = cc; *cached = true; return E_OK; }
+    if (cc) { dc3hip_ctx_destroy(cc); g_cache.c = nullptr; }
+    RC(dc3hip_ctx_create(out, device, n));
+    g_cache.c = *out; *cached = true;
+    return E_OK;
+  }
+  return dc3hip_ctx_create(out, device, n);
+}
+
 static int sufsort_one(const uint8_t *T, void *SA, int64_t n, int bits, int device, bool devptrs) {
   if (!devptrs && tiny_host(T, SA, n, bits)) return E_OK;
   if (n == 0) return E_OK;
   dc3hip_ctx *c = nullptr;
-  RC(dc3hip_ctx_create(&c, device, n));
+  bool cached = false;
+  RC(acquire_ctx(&c, device, n, &cached));
   int rc = [&]() -> int {
     RC(dc3hip_ctx_set_text(c, T, n));          // hipMemcpyDefault handles host or device sources
     RC(ctx_build(c));
@@ -989,7 +1019,8 @@ static int sufsort_one(const uint8_t *T, void *SA, int64_t n, int bits, int devi
     else RC(dc3hip_ctx_get_sa_i64(c, static_cast<int64_t *>(SA)));
     return E_OK;
   }();
-  dc3hip_ctx_destroy(c);
+  if (!cached) dc3hip_ctx_destroy(c);
+  else if (rc != E_OK) { dc3hip_ctx_destroy(c); g_cache.c = nullptr; }   // do not keep a context in an unknown state
   return rc;
 }
 
@@ -1026,6 +1057,10 @@ int32_t dc3hip_sufsort_i64(const uint8_t *T, int64_t *SA, int64_t n) {
   dc3hip_opts o; memset(&o, 0, sizeof(o));
   o.struct_size = (int32_t)sizeof(o); o.index_bits = 64; o.device = -1;
   return dc3hip_sufsort_ex(T, SA, n, &o);
+}
+
+void dc3hip_release_cache(void) {
+  if (g_cache.c) { dc3hip_ctx_destroy(g_cache.c); g_cache.c = nullptr; }
 }
 
 // divbwt(T, U, A, n) (divsufsort.c:372-405): returns the primary index, -1 / -2 on error; A is an
