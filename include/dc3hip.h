@@ -36,8 +36,9 @@ extern "C" {
 
 #define DC3HIP_API __attribute__((visibility("default")))
 
-/* Largest supported text length (32-bit device-side positions, int32 ranks). */
-#define DC3HIP_MAX_N ((int64_t)2147483000)
+/* Largest supported text length: positions and ranks are unsigned 32-bit on the device.  Texts of
+ * 2^31 bytes or more need the 64-bit index entry points (int32 cannot hold their positions). */
+#define DC3HIP_MAX_N ((int64_t)4278190080)   /* 2^32 - 2^24 */
 
 /* ---- one-shot entry points (the FFI surface a Rust/Go/... shim binds) ------------------------ */
 

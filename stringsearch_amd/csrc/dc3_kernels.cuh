@@ -473,24 +473,24 @@ __global__ __launch_bounds__(kBlock) void k_assign_unique(Acc acc, u32 n, u32 m0
 //   [ (s << seg_bits) + (d << shift), ... )  and holds exactly the keys that belong there;
 // a tile only has to reserve space inside the region: one global atomicAdd per (tile, digit) on
 // cursors[s*ndig + d].  No up-sweep, no scan: 16 B moved per pair instead of 24.
-//   pass 1: shift = 22, seg_bits = 32 (one segment), ndig = ceil(n / 2^22) <= 512
+//   pass 1: shift = 22, seg_bits = 32 (one segment), ndig = ceil(n / 2^22) <= 1024
 //   pass 2: shift = 14, seg_bits = 22, ndig = 256   (tiles never straddle a 2^22-pair segment)
 constexpr int kPartNW = 16, kPartIPT = 8, kPartTile = kPartNW * 64 * kPartIPT;   // 8192 pairs
-constexpr size_t kPartSmem = sizeof(Rec8) * kPartTile + sizeof(u32) * 3 * 512;
+constexpr size_t kPartSmem = sizeof(Rec8) * kPartTile + sizeof(u32) * (2 * 1024 + 64);
 __global__ __launch_bounds__(kPartNW * 64) void k_part_msd(const Rec8 *__restrict__ in, Rec8 *__restrict__ out, u32 n,
                                                           u32 shift, u32 seg_bits, u32 ndig,
                                                           u32 *__restrict__ cursors) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Rec8 *srec = reinterpret_cast<Rec8 *>(smem);
-  u32 *hist = reinterpret_cast<u32 *>(smem + sizeof(Rec8) * kPartTile);   // [512] counts -> tile-exclusive prefix
-  u32 *gbase = hist + 512;                                                 // [512] global base of the tile's run
-  u32 *tmp = gbase + 512;
+  u32 *hist = reinterpret_cast<u32 *>(smem + sizeof(Rec8) * kPartTile);   // [1024] counts -> tile-exclusive prefix
+  u32 *gbase = hist + 1024;                                                // [1024] global base of the tile's run
+  u32 *tmp = gbase + 1024;
   const u32 tid = threadIdx.x;
   const u32 begin = blockIdx.x * (u32)kPartTile;
   const u32 nvalid = min((u32)kPartTile, n - begin);
   const u32 seg = seg_bits >= 32 ? 0u : (begin >> seg_bits);
   const u32 seg_base = seg_bits >= 32 ? 0u : (seg << seg_bits);
-  if (tid < 512) hist[tid] = 0;
+  hist[tid] = 0;
   __syncthreads();
   Rec8 r[kPartIPT];
   u32 d[kPartIPT], rk[kPartIPT];
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(kPartNW * 64) void k_part_msd(const Rec8 *__restric
   }
   u32 tot;
   const u32 ex = block_excl_scan<kPartNW>(tid < ndig ? cnt : 0u, tmp, tot);
-  if (tid < 512) hist[tid] = ex;
+  hist[tid] = ex;
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < kPartIPT; k++) {

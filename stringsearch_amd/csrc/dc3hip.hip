@@ -13,6 +13,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <climits>
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -252,12 +253,12 @@ static int inverse_permute(dc3hip_ctx *c, Rec8 *a, Rec8 *b, u32 n, u32 *out, int
   const ArenaMark mk = arena_mark(c);
   const u32 ntiles = (n + kPartTile - 1) / kPartTile;
   Rec8 *src = a, *dst = b;
-  if (kb > 22) {                       // pass 1: top digit = key >> 22 (<= 512 values for n <= 2^31)
+  if (kb > 22) {                       // pass 1: top digit = key >> 22 (<= 1024 values for n < 2^32)
     const u32 ndig = ((n - 1) >> 22) + 1;
     u32 *cur = nullptr;
-    RC(arena_alloc(c, (size_t)512, &cur));
+    RC(arena_alloc(c, (size_t)1024, &cur));
     PhaseScope ps(c, phase, n, 3);
-    HIPC(hipMemsetAsync(cur, 0, 512 * sizeof(u32), c->stream));
+    HIPC(hipMemsetAsync(cur, 0, 1024 * sizeof(u32), c->stream));
     hipLaunchKernelGGL(k_part_msd, dim3(ntiles), dim3(kPartNW * 64), kPartSmem, c->stream, src, dst, n, 22u, 32u,
                        ndig, cur);
     KCHECK();
@@ -807,6 +808,7 @@ int32_t dc3hip_ctx_build(dc3hip_ctx *c) {
 
 int32_t dc3hip_ctx_get_sa_i32(dc3hip_ctx *c, int32_t *SA) {
   if (!c || (!SA && c->n > 0)) { set_err("invalid arguments"); return E_ARGS; }
+  if (c->n > (int64_t)INT32_MAX) { set_err("text of %lld bytes needs 64-bit indices", (long long)c->n); return E_TOOBIG; }
   if (!c->built) { set_err("no suffix array built in this context"); return E_ARGS; }
   HIPC(hipSetDevice(c->device));
   if (c->n > 0) HIPC(hipMemcpyAsync(SA, c->d_sa, (size_t)c->n * 4, hipMemcpyDefault, c->stream));
@@ -1034,6 +1036,9 @@ int32_t dc3hip_sufsort_ex(const uint8_t *T, void *SA, int64_t n, const dc3hip_op
   if (d.index_bits != 32 && d.index_bits != 64) { set_err("index_bits must be 32 or 64"); return E_ARGS; }
   const bool devptrs = (d.flags & DC3HIP_F_DEVICE_PTRS) != 0;
   const int64_t P = d.num_partitions > 1 ? d.num_partitions : 1;
+  if (d.index_bits == 32 && (P == 1 ? n : n / P + 1) > (int64_t)INT32_MAX) {
+    set_err("index_bits = 32 cannot address %lld bytes", (long long)n); return E_TOOBIG;
+  }
   if (P == 1) {
     if (n > DC3HIP_MAX_N) { set_err("n=%lld exceeds DC3HIP_MAX_N=%lld", (long long)n, (long long)DC3HIP_MAX_N); return E_TOOBIG; }
     return sufsort_one(T, SA, n, d.index_bits, d.device, devptrs);

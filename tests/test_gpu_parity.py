@@ -380,3 +380,24 @@ def test_full_size_1gib_properties(ss):
         assert c.checksum() == chk
         st = c.stats()
         assert st["level_n"][:2] == [n, 715827883]
+
+
+def test_beyond_2pow31_needs_64bit_indices(ss):
+    """BASELINE.json configs[4] partition size (16 GiB DNA over 8 GPUs = 2 GiB + 1 byte per sacapart chunk):
+    texts of 2^31 bytes and more run on unsigned 32-bit device positions and are only reachable through the
+    64-bit index API; verified with the GPU sufcheck (no trusted CPU oracle exists at this size)."""
+    n = (1 << 31) + 1
+    with ss.Context(n) as c:
+        c.generate(n, 5, 1, offset=7 * n)          # chunk 7 of the 16 GiB stream
+        c.build()
+        assert c.sufcheck() == 0
+        st = c.stats()
+        assert st["level_n"][0] == n and st["levels"] >= 3
+        with pytest.raises(ss.Dc3HipError) as ei:
+            c.sa(np.int32)                         # int32 cannot hold these positions
+        assert ei.value.code == -4
+    import ctypes
+    t = np.zeros(8, dtype=np.uint8); sa = np.zeros(8, dtype=np.int32)
+    from stringsearch_amd._lib import Opts
+    o = Opts(ctypes.sizeof(Opts), 32, -1, 0, 0)
+    assert ss.lib().dc3hip_sufsort_ex(t.ctypes.data, sa.ctypes.data, (1 << 31) + 5, ctypes.byref(o)) == -4
