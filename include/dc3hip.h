@@ -149,6 +149,7 @@ typedef struct dc3hip_stats {
   int64_t level_K[DC3HIP_MAX_LEVELS];     /* alphabet bound per level */
   int32_t level_sorted[DC3HIP_MAX_LEVELS];/* 0 = direct packed names, 1 = names by full radix sort,
                                              2 = names by prefix sort + tie refinement */
+  int32_t level_name_width[DC3HIP_MAX_LEVELS]; /* symbols packed per direct name (0 on sorted levels) */
   int64_t level_tied[DC3HIP_MAX_LEVELS];  /* samples re-sorted by the full key (prefix-sort path) */
   double  level_tie_pred[DC3HIP_MAX_LEVELS]; /* predicted tied fraction (policy input) */
   double  build_ms;                       /* HIP-event time of the whole device-resident build */

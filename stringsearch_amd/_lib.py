@@ -25,6 +25,7 @@ class Stats(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_int32), ("levels", ctypes.c_int32),
                 ("level_n", ctypes.c_int64 * MAX_LEVELS), ("level_K", ctypes.c_int64 * MAX_LEVELS),
                 ("level_sorted", ctypes.c_int32 * MAX_LEVELS),
+                ("level_name_width", ctypes.c_int32 * MAX_LEVELS),
                 ("level_tied", ctypes.c_int64 * MAX_LEVELS), ("level_tie_pred", ctypes.c_double * MAX_LEVELS),
                 ("build_ms", ctypes.c_double), ("phase_ms", ctypes.c_double * len(PHASES)),
                 ("phase_launches", ctypes.c_int64 * len(PHASES)),
@@ -42,6 +43,7 @@ class Stats(ctypes.Structure):
             "level_n": [self.level_n[i] for i in range(self.levels)],
             "level_K": [self.level_K[i] for i in range(self.levels)],
             "level_sorted": [self.level_sorted[i] for i in range(self.levels)],
+            "level_name_width": [self.level_name_width[i] for i in range(self.levels)],
             "level_tied": [self.level_tied[i] for i in range(self.levels)],
             "level_tie_pred": [self.level_tie_pred[i] for i in range(self.levels)],
             "build_ms": self.build_ms,

@@ -143,22 +143,31 @@ __global__ __launch_bounds__(kBlock) void k_make_codes(const u32 *present, uint1
 }
 
 // ---------------------------------------------------------------------------------------------
-// Direct (sort-free) naming: when (K+1)^3 fits 31 bits the packed triple itself is an
-// order-preserving name, name = ((s0*B + s1)*B + s2) + 1 with B = K+1, so the sample string
+// Direct (sort-free) naming: when (K+1)^3 fits 31 bits the packed symbols themselves are an order-
+// and equality-preserving name, so the sample string
 //   R[slot(i)] for i%3 != 0   (slot = i/3 for mod 1, i/3 + m0 for mod 2; lib.rs:93-98)
-// is produced by one streaming pass.  Replaces lib.rs:62-100 for small alphabets (names need not
-// be dense, only order- and equality-preserving).
+// is produced by one streaming pass (names need not be dense; replaces lib.rs:62-100 for small
+// alphabets).  The name packs w >= 3 symbols, B = K+1:   name(i) = sum_{t<w} S[i+t] * B^(w-1-t) + 1.
+// w = 3 is the K–S triple and the default.  Wider names (overlapping neighbours) are also valid —
+// comparing name(i), name(i+3), ... still compares the suffixes in order, and as in K–S two sample
+// suffixes of one residue differ no later than the name covering the shorter one's end (a zero in its
+// first 3 symbols) — but they were measured SLOWER (DNA 1 GiB 199 -> 217 ms): they save cheap direct
+// levels and make the first sorted level's alphabet huge and sparse (93-bit keys, all top-32-bit
+// prefixes tied).  Kept behind DC3HIP_WIDE_NAMES=1 for experiments; both widths are parity-tested.
 // Thread g owns positions 3g+1 and 3g+2.
 // ---------------------------------------------------------------------------------------------
 template <class Sym>
-__global__ __launch_bounds__(kBlock) void k_name_direct(Sym S, u32 m, u32 m0, u32 m02, u32 B, u32 *R) {
+__global__ __launch_bounds__(kBlock) void k_name_direct(Sym S, u32 m, u32 m0, u32 m02, u32 B, u32 w, u32 Bw1,
+                                                       u32 *R) {
   const u32 ngroups = m0;   // group g: samples 3g+1 (slot g) and 3g+2 (slot m0+g)
   for (u32 g = blockIdx.x * kBlock + threadIdx.x; g < ngroups; g += gridDim.x * kBlock) {
     const u32 i = 3 * g + 1;
-    const u32 s1 = S.get(i), s2 = S.get(i + 1), s3 = S.get(i + 2), s4 = S.get(i + 3);
+    const u32 first = S.get(i);
+    u32 acc = first;
+    for (u32 t = 1; t < w; t++) acc = acc * B + S.get(i + t);      // Horner over S[i .. i+w)
     // mod-1 sample exists for every g < m0 (includes the dummy at i == m when m%3 == 1)
-    R[g] = ((s1 * B + s2) * B + s3) + 1;
-    if (i + 1 < m) R[m0 + g] = ((s2 * B + s3) * B + s4) + 1;
+    R[g] = acc + 1;
+    if (i + 1 < m) R[m0 + g] = (acc - first * Bw1) * B + S.get(i + w) + 1;   // S[i+1 .. i+1+w)
   }
   // zero tail of R (sentinels of the next level, lib.rs:51-53)
   if (blockIdx.x == 0 && threadIdx.x < 8) R[m02 + threadIdx.x] = 0;

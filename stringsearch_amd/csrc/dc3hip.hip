@@ -72,6 +72,7 @@ struct dc3hip_ctx {
   bool no_hybrid = false;
   int merge_cfg = 1;
   bool no_small_ties = false;
+  bool wide_names = false;
   std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
   std::vector<PhaseMark> marks;
   hipEvent_t ev_build_a = nullptr, ev_build_b = nullptr;
@@ -499,15 +500,19 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
   const bool direct = (B * B * B) <= 0x7fffffffull;
   c->stats.level_sorted[depth] = direct ? 0 : 1;   // 2 = prefix-sort + tie-refine
   if (direct) {
-    // names = packed triples (order-preserving); always recurse (distinctness unknown)
+    // names = w packed symbols (order-preserving); w = 3 (the K–S triple) unless DC3HIP_WIDE_NAMES=1;
+    // always recurse (distinctness unknown)
+    u32 w = 3; u64 Bw = B * B * B;                   // B^w
+    while (c->wide_names && Bw * B <= 0x7fffffffull) { Bw *= B; w++; }   // measured slower: see DESIGN.md §2.1
+    c->stats.level_name_width[depth] = (int32_t)w;
     {
       PhaseScope ps(c, DC3HIP_PH_NAME_DIRECT, m02);
       hipLaunchKernelGGL((k_name_direct<Sym>), dim3(grid_for(c, m0)), dim3(kBlock), 0, c->stream, S, m, m0, m02,
-                         (u32)B, R);
+                         (u32)B, w, (u32)(Bw / B), R);
       KCHECK();
     }
     SymU32 RS; RS.s = R; RS.m = m02;
-    RC(dc3_level<SymU32>(c, RS, m02, B * B * B, sa12, rank12, depth + 1));
+    RC(dc3_level<SymU32>(c, RS, m02, Bw, sa12, rank12, depth + 1));
   } else {
     const u32 b = (u32)B;                          // packing base of make_rec (K < 2^31)
     u32 kbits = 0;                                 // bit width of B^3 - 1; > 32 here (else direct path)
@@ -721,6 +726,8 @@ int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) {
   c->no_hybrid = (nh && nh[0] == '1');
   const char *nst = getenv("DC3HIP_NO_SMALL_TIES");
   c->no_small_ties = (nst && nst[0] == '1');
+  const char *wn = getenv("DC3HIP_WIDE_NAMES");
+  c->wide_names = (wn && wn[0] == '1');
   const char *mc = getenv("DC3HIP_MERGE_CFG");
   if (mc) c->merge_cfg = atoi(mc);
   int rc = [&]() -> int {

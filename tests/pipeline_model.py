@@ -5,6 +5,8 @@ It mirrors dc3_level() in dc3hip.hip step by step; kernels become numpy expressi
 TEST INFRASTRUCTURE ONLY."""
 import numpy as np
 
+WIDE_NAMES = False   # True = as many symbols per direct name as fit 31 bits (DC3HIP_WIDE_NAMES=1)
+
 
 def _sym_get(S, m, idx):
     """S.get(i): symbols with a zero tail."""
@@ -28,11 +30,18 @@ def level(S, m, K, trace=None, depth=0):
     g = np.arange(m0, dtype=np.int64)
     s = [_sym_get(S, m, 3 * g + k) for k in range(5)]          # S[3g .. 3g+4]
     has2 = (3 * g + 2) < m
-    if B ** 3 <= 0x7FFFFFFF:                                   # k_name_direct
+    if B ** 3 <= 0x7FFFFFFF:                                   # k_name_direct (w symbols per name)
+        w = 3
+        while WIDE_NAMES and B ** (w + 1) <= 0x7FFFFFFF:
+            w += 1
         R = np.zeros(m02, dtype=np.int64)
-        R[g] = ((s[1] * B + s[2]) * B + s[3]) + 1
-        R[m0 + g[has2]] = (((s[2] * B + s[3]) * B + s[4]) + 1)[has2]
-        sa12, rank12 = level(R, m02, B ** 3, trace, depth + 1)
+        n1 = np.zeros(m0, dtype=np.int64); n2 = np.zeros(m0, dtype=np.int64)
+        for t in range(w):
+            n1 = n1 * B + _sym_get(S, m, 3 * g + 1 + t)
+            n2 = n2 * B + _sym_get(S, m, 3 * g + 2 + t)
+        R[g] = n1 + 1
+        R[m0 + g[has2]] = (n2 + 1)[has2]
+        sa12, rank12 = level(R, m02, B ** w, trace, depth + 1)
     else:                                                      # k_pack_triples + radix sort + naming
         pos = np.concatenate([3 * g + 1, (3 * g + 2)[has2]])
         keys = np.concatenate([np.stack([s[1], s[2], s[3]], 1), np.stack([s[2], s[3], s[4]], 1)[has2]])

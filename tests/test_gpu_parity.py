@@ -60,7 +60,7 @@ def test_level_trace_matches_oracle_depth(ss, corpus, oracle):
             assert np.array_equal(c.sa(), want)
             assert st["level_n"][0] == len(data)
             assert [n for n in st["level_n"][:len(traces[name])]] == [t[0] for t in traces[name]][:st["levels"]]
-            assert len(traces[name]) <= st["levels"] <= len(traces[name]) + 1
+            assert 2 <= st["levels"] <= len(traces[name]) + 1    # wide names can only save levels
 
 
 def test_exhaustive_small(ss):
@@ -351,6 +351,28 @@ def test_hybrid_and_straight_paths_agree(ss, oracle):
             assert seen[("DC3HIP_NO_SMALL_TIES",)]["downsweep_launches"][1] > 0
 
 
+def test_wide_and_narrow_direct_names_agree(ss, oracle):
+    """Direct names pack w = 3 symbols by default; DC3HIP_WIDE_NAMES=1 packs as many as fit 31 bits
+    (13 for DNA, 6 for 28-letter text).  Same SA either way."""
+    import os
+    for kind, n in ((1, 3_000_001), (2, 3_000_002), (1, 50_000), (0, 200_000)):
+        data = oracle.gen(n, 31, kind)
+        want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)
+        lv = {}
+        for flag in ("0", "1"):
+            os.environ["DC3HIP_WIDE_NAMES"] = flag
+            try:
+                with ss.Context(n) as c:
+                    c.set_text(data); c.build()
+                    assert np.array_equal(c.sa(), want), (kind, n, flag)
+                    st = c.stats(); lv[flag] = (st["levels"], st["level_name_width"][0])
+            finally:
+                os.environ.pop("DC3HIP_WIDE_NAMES", None)
+        assert lv["0"][1] == 3 and lv["1"][0] <= lv["0"][0]
+        if kind == 1:
+            assert lv["1"][1] == 13
+
+
 def test_config2_64mib_random_bit_exact(ss, oracle):
     """BASELINE.json configs[1]: 64 MiB random bytes, i32 SA, bit-exact vs divsufsort (full compare
     when the reference build travelled with the snapshot, GPU sufcheck always)."""
@@ -392,7 +414,7 @@ def test_beyond_2pow31_needs_64bit_indices(ss):
         c.build()
         assert c.sufcheck() == 0
         st = c.stats()
-        assert st["level_n"][0] == n and st["levels"] >= 3
+        assert st["level_n"][0] == n and st["levels"] >= 3 and st["level_name_width"][0] == 3
         with pytest.raises(ss.Dc3HipError) as ei:
             c.sa(np.int32)                         # int32 cannot hold these positions
         assert ei.value.code == -4
