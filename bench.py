@@ -171,7 +171,7 @@ def main():
         kc = max(range(3), key=lambda k: dsw_ms[k])
         if dsw_launches[kc]:
             rec_bytes = (8, 16, 20)[kc]
-            rec_name = ("Rec8 (key,value) pairs", "Rec16 triple records", "Tup0 mod-0 tuples")[kc]
+            rec_name = ("Rec8 (key,value) pairs", "Rec16 triple records (12-byte Rec12 when the key fits 64 bits)", "Tup0 mod-0 tuples")[kc]
             per_launch_elems = dsw_elems[kc] / dsw_launches[kc]
             avg_ms = dsw_ms[kc] / dsw_launches[kc]
             achieved = 12.0 * per_launch_elems / (avg_ms * 1e-3) / 1e9

@@ -27,6 +27,8 @@ constexpr int kWaves = kBlock / 64;
 struct __attribute__((aligned(16))) Rec16 { u32 k0, k1, k2, pos; };
 // (destination, value) pair of an inverse-permutation pass (rank <- SA inversion, lib.rs:106-113).
 struct __attribute__((aligned(8))) Rec8 { u32 key, val; };
+// Sample-triple record when the packed key fits 64 bits (straight ordering of mid-size alphabets).
+struct Rec12 { u32 k0, k1, pos; };
 // Merge tuple of a sample (mod-1 / mod-2) suffix, 16 B:
 //   pos%3==1: (c0=S[pos], r=rank[pos+1]), cx = S[pos-1]   (cx feeds the derived mod-0 tuple)
 //   pos%3==2: (c0=S[pos], cx=S[pos+1], r=rank[pos+2])
@@ -191,67 +193,71 @@ __device__ __forceinline__ Rec16 make_rec(u32 s0, u32 s1, u32 s2, u32 B, u32 pos
   Rec16 r; r.k0 = (u32)s_lo; r.k1 = (u32)(s_lo >> 32); r.k2 = (u32)p_hi; r.pos = pos;
   return r;
 }
-template <class Sym>
-__global__ __launch_bounds__(kBlock) void k_pack_triples(Sym S, u32 m, u32 m0, u32 m02, u32 b, Rec16 *out) {
+__device__ __forceinline__ void store_rec(Rec16 *out, u32 i, const Rec16 &r) { out[i] = r; }
+__device__ __forceinline__ void store_rec(Rec12 *out, u32 i, const Rec16 &r) { out[i] = Rec12{r.k0, r.k1, r.pos}; }
+template <class Sym, class Rec>
+__global__ __launch_bounds__(kBlock) void k_pack_triples(Sym S, u32 m, u32 m0, u32 m02, u32 b, Rec *out) {
   // sample positions in ascending order: 1,2,4,5,7,8,...; index of 3g+1 is 2g, of 3g+2 is 2g+1
   for (u32 g = blockIdx.x * kBlock + threadIdx.x; g < m0; g += gridDim.x * kBlock) {
     const u32 i = 3 * g + 1;
     const u32 s1 = S.get(i), s2 = S.get(i + 1), s3 = S.get(i + 2), s4 = S.get(i + 3);
-    out[2 * g] = make_rec(s1, s2, s3, b, i);
-    if (2 * g + 1 < m02) out[2 * g + 1] = make_rec(s2, s3, s4, b, i + 1);
+    store_rec(out, 2 * g, make_rec(s1, s2, s3, b, i));
+    if (2 * g + 1 < m02) store_rec(out, 2 * g + 1, make_rec(s2, s3, s4, b, i + 1));
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Stable LSD radix pass, 8-bit digits (lib.rs:15-39 with the K+1 counters replaced by digits).
+// Stable LSD radix pass (lib.rs:15-39 with the K+1 counters replaced by digits of NB = 256 or 512
+// bins; 9-bit digits are used where they save a pass, e.g. 25-27-bit symbols).
 //   up-sweep  : per-chunk digit histogram (lib.rs:20-22)          -> table[digit][chunk]
-//   scan      : exclusive prefix sums over table (lib.rs:25-32)   (k_scan_excl_inplace)
+//   scan      : exclusive prefix sums over table (lib.rs:25-32)   (k_scan_rows + k_scan_excl_inplace)
 //   down-sweep: stable scatter (lib.rs:35-38)
-// Digit functors return byte `p` of the key.
+// A digit is (key >> shift) & mask of the record's sort key.
 // ---------------------------------------------------------------------------------------------
-struct Rec16Byte {
-  u32 p;
-  __device__ __forceinline__ u32 operator()(const Rec16 &r) const {
-    const u32 w = p < 4 ? r.k0 : (p < 8 ? r.k1 : r.k2);
-    return (w >> ((p & 3) * 8)) & 255u;
-  }
-};
-struct Rec8Shift {   // 8 bits of the destination index starting at bit `shift`
-  u32 shift;
-  __device__ __forceinline__ u32 operator()(const Rec8 &r) const { return (r.key >> shift) & 255u; }
-};
-struct Tup0Byte {
-  u32 p;
-  // mod-0 positions are real symbols (c0 >= 1), so the key is c0-1 in [0, K)
-  __device__ __forceinline__ u32 operator()(const Tup0 &r) const { return ((r.c0 - 1u) >> (p * 8)) & 255u; }
-};
+struct KeyDig { u32 shift, mask; };
+__device__ __forceinline__ u32 digit_of(const Rec8 &r, KeyDig d) { return (r.key >> d.shift) & d.mask; }
+__device__ __forceinline__ u32 digit_of(const Rec12 &r, KeyDig d) {
+  const u64 k = (u64)r.k0 | ((u64)r.k1 << 32);
+  return (u32)(k >> d.shift) & d.mask;
+}
+__device__ __forceinline__ u32 digit_of(const Rec16 &r, KeyDig d) {     // 96-bit key, shift < 96
+  const u32 w = d.shift >> 5, off = d.shift & 31;
+  const u32 a = w == 0 ? r.k0 : (w == 1 ? r.k1 : r.k2);
+  const u32 b = w == 0 ? r.k1 : (w == 1 ? r.k2 : 0u);
+  return (off ? ((a >> off) | (b << (32 - off))) : a) & d.mask;
+}
+// mod-0 positions are real symbols (c0 >= 1), so the key is c0-1 in [0, K)
+__device__ __forceinline__ u32 digit_of(const Tup0 &r, KeyDig d) { return ((r.c0 - 1u) >> d.shift) & d.mask; }
 
-template <class Rec, class Dig>
+template <class Rec, int NB>
 __global__ __launch_bounds__(kBlock) void k_rs_upsweep(const Rec *__restrict__ in, u32 n, u32 chunk, u32 nchunks,
-                                                      Dig dig, u32 *__restrict__ table) {
-  __shared__ u32 hist[kWaves][256];
+                                                      KeyDig dig, u32 *__restrict__ table) {
+  __shared__ u32 hist[kWaves][NB];
   const u32 tid = threadIdx.x;
 #pragma unroll
-  for (int w = 0; w < kWaves; w++) hist[w][tid] = 0;
+  for (int w = 0; w < kWaves; w++)
+    for (int j = tid; j < NB; j += kBlock) hist[w][j] = 0;
   __syncthreads();
   const u32 begin = blockIdx.x * chunk;
   const u32 end = min(n, begin + chunk);
   u32 *myh = hist[wave_id()];
   for (u32 i = begin + tid; i < end; i += kBlock) {
     const Rec r = in[i];
-    atomicAdd(&myh[dig(r)], 1u);
+    atomicAdd(&myh[digit_of(r, dig)], 1u);
   }
   __syncthreads();
-  u32 s = 0;
+  for (int j = tid; j < NB; j += kBlock) {
+    u32 sum = 0;
 #pragma unroll
-  for (int w = 0; w < kWaves; w++) s += hist[w][tid];
-  table[tid * nchunks + blockIdx.x] = s;
+    for (int w = 0; w < kWaves; w++) sum += hist[w][j];
+    table[(size_t)j * nchunks + blockIdx.x] = sum;
+  }
 }
 
-template <class Rec, int IPT, int NW>
+template <class Rec, int IPT, int NW, int NB>
 struct DownsweepSmem {
   static constexpr int kTile = NW * 64 * IPT;
-  static constexpr size_t kBytes = sizeof(Rec) * kTile + sizeof(u32) * (NW * 256 + 256 + 256 + 32);
+  static constexpr size_t kBytes = sizeof(Rec) * kTile + sizeof(u32) * (NW * NB + NB + NB + 32);
 };
 
 // table rows are scanned per digit (k_scan_rows) and the 256 digit totals separately
@@ -272,25 +278,28 @@ struct ArrayLoader {
 // PF: prefetch the next tile into registers while the current one is ranked/reordered (pays for
 // 8-byte records: 2.3 -> 3.4 TB/s; costs registers and loses for 16/20-byte records, see
 // profiles/r01_radix_downsweep_variants_v2.txt).
-template <class Rec, class Dig, int IPT, int NW, bool PF, class Loader>
+template <class Rec, int NB, int IPT, int NW, bool PF, class Loader>
 __global__ __launch_bounds__(NW * 64) void k_rs_downsweep(Loader in, Rec *__restrict__ out, u32 n,
-                                                         u32 chunk, u32 nchunks, Dig dig,
+                                                         u32 chunk, u32 nchunks, KeyDig dig,
                                                          const u32 *__restrict__ table,
                                                          const u32 *__restrict__ digit_base) {
   constexpr int kB = NW * 64;
   constexpr int kTile = kB * IPT;
   constexpr int kWItems = 64 * IPT;
+  constexpr int kBits = NB == 512 ? 9 : 8;
+  static_assert(NB == 256 || NB == 512, "digit bins");
+  static_assert(NW * 64 >= NB, "one thread per digit");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Rec *srec = reinterpret_cast<Rec *>(smem);
-  u32 *wcnt = reinterpret_cast<u32 *>(smem + sizeof(Rec) * kTile);   // [NW][256]
-  u32 *dbase = wcnt + NW * 256;                                      // [256] running global base
-  u32 *texcl = dbase + 256;                                          // [256] tile-exclusive prefix
-  u32 *tmp = texcl + 256;                                            // [NW]
+  u32 *wcnt = reinterpret_cast<u32 *>(smem + sizeof(Rec) * kTile);   // [NW][NB]
+  u32 *dbase = wcnt + NW * NB;                                       // [NB] running global base
+  u32 *texcl = dbase + NB;                                           // [NB] tile-exclusive prefix
+  u32 *tmp = texcl + NB;                                             // [NW]
   const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
   const u32 begin = blockIdx.x * chunk;
   const u32 end = min(n, begin + chunk);
-  if (tid < 256) dbase[tid] = digit_base[tid] + table[tid * nchunks + blockIdx.x];
-  u32 *mycnt = wcnt + w * 256;
+  if (tid < NB) dbase[tid] = digit_base[tid] + table[(size_t)tid * nchunks + blockIdx.x];
+  u32 *mycnt = wcnt + w * NB;
   Rec r[IPT], rn[PF ? IPT : 1];
   bool okn[PF ? IPT : 1];
   if (PF) {
@@ -304,7 +313,7 @@ __global__ __launch_bounds__(NW * 64) void k_rs_downsweep(Loader in, Rec *__rest
   for (u32 tile = begin; tile < end; tile += kTile) {
     const u32 nin = min((u32)kTile, end - tile);
 #pragma unroll
-    for (int j = 0; j < 4; j++) mycnt[lane + 64 * j] = 0;
+    for (int j = 0; j < NB / 64; j++) mycnt[lane + 64 * j] = 0;
     u32 d[IPT], rk[IPT];
     bool ok[IPT];
     // wave w owns tile items [w*kWItems, (w+1)*kWItems); round k covers 64 consecutive items
@@ -313,7 +322,7 @@ __global__ __launch_bounds__(NW * 64) void k_rs_downsweep(Loader in, Rec *__rest
       const u32 t = w * kWItems + k * 64 + lane;
       if (PF) { r[k] = rn[PF ? k : 0]; ok[k] = okn[PF ? k : 0]; }
       else ok[k] = (t < nin) && in.load(tile + t, r[k]);
-      d[k] = ok[k] ? dig(r[k]) : 0u;
+      d[k] = ok[k] ? digit_of(r[k], dig) : 0u;
     }
     if (PF) {
       const u32 nt = tile + kTile;
@@ -334,7 +343,7 @@ __global__ __launch_bounds__(NW * 64) void k_rs_downsweep(Loader in, Rec *__rest
       for (int k = 0; k < IPT; k++) {
         u64 peers = __ballot(ok[k]);
 #pragma unroll
-        for (int bit = 0; bit < 8; bit++) {
+        for (int bit = 0; bit < kBits; bit++) {
           const bool one = (d[k] >> bit) & 1u;
           const u64 mk = __ballot(one);
           peers &= one ? mk : ~mk;
@@ -350,33 +359,33 @@ __global__ __launch_bounds__(NW * 64) void k_rs_downsweep(Loader in, Rec *__rest
     __syncthreads();
     // per digit (thread tid = digit): prefix over waves, tile total, tile-exclusive prefix
     u32 tot = 0;
-    if (tid < 256) {
+    if (tid < NB) {
 #pragma unroll
-      for (int i = 0; i < NW; i++) { const u32 c = wcnt[i * 256 + tid]; wcnt[i * 256 + tid] = tot; tot += c; }
+      for (int i = 0; i < NW; i++) { const u32 c = wcnt[i * NB + tid]; wcnt[i * NB + tid] = tot; tot += c; }
     }
     u32 nkeep;
-    const u32 ex = block_excl_scan<NW>(tid < 256 ? tot : 0u, tmp, nkeep);
-    if (tid < 256) texcl[tid] = ex;
+    const u32 ex = block_excl_scan<NW>(tid < NB ? tot : 0u, tmp, nkeep);
+    if (tid < NB) texcl[tid] = ex;
     __syncthreads();
     // reorder through LDS so every digit run is contiguous
 #pragma unroll
     for (int k = 0; k < IPT; k++) {
-      if (ok[k]) srec[texcl[d[k]] + wcnt[w * 256 + d[k]] + rk[k]] = r[k];
+      if (ok[k]) srec[texcl[d[k]] + wcnt[w * NB + d[k]] + rk[k]] = r[k];
     }
     __syncthreads();
     for (u32 q = tid; q < nkeep; q += kB) {
       const Rec x = srec[q];
-      const u32 dd = dig(x);
+      const u32 dd = digit_of(x, dig);
       out[dbase[dd] + (q - texcl[dd])] = x;
     }
     __syncthreads();
-    if (tid < 256) dbase[tid] += tot;
+    if (tid < NB) dbase[tid] += tot;
     // (the barrier after ranking in the next iteration orders this update before its use)
   }
 }
 
-// Row-wise exclusive scan of the [256][nchunks] digit table: block d scans row d in place and
-// writes the row total to totals[d] (then scanned by k_scan_excl_inplace over 256 entries).
+// Row-wise exclusive scan of the [NB][nchunks] digit table: block d scans row d in place and
+// writes the row total to totals[d] (then scanned by k_scan_excl_inplace over NB entries).
 __global__ __launch_bounds__(kBlock) void k_scan_rows(u32 *__restrict__ table, u32 nchunks, u32 *__restrict__ totals) {
   __shared__ u32 tmp[kWaves];
   u32 *row = table + (size_t)blockIdx.x * nchunks;
@@ -398,7 +407,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_rows(u32 *__restrict__ table, u
 // ---------------------------------------------------------------------------------------------
 // Naming (lib.rs:80-100): name = 1 + number of key changes before i in the sorted order.
 // The kernels are generic over an accessor of the sorted sample order:
-//   AccRec16 : fully sorted 16-byte records (straight LSD path)
+//   AccRec<Rec16|Rec12> : fully sorted records (straight LSD path)
 //   AccHyb   : (pos, "differs from predecessor" byte) arrays of the prefix-sort + tie-refine path
 //   k_name_count  : per-chunk count of "key differs from predecessor" flags
 //   (scan of the counts, total = number of distinct names)
@@ -410,16 +419,18 @@ __global__ __launch_bounds__(kBlock) void k_scan_rows(u32 *__restrict__ table, u
 __device__ __forceinline__ bool key_neq(const Rec16 &a, const Rec16 &b) {
   return (a.k0 != b.k0) | (a.k1 != b.k1) | (a.k2 != b.k2);
 }
+__device__ __forceinline__ bool key_neq(const Rec12 &a, const Rec12 &b) { return (a.k0 != b.k0) | (a.k1 != b.k1); }
 __device__ __forceinline__ u32 slot_of(u32 pos, u32 m0) {
   const u32 q = pos / 3, rem = pos - 3 * q;
   return rem == 1 ? q : q + m0;
 }
-struct AccRec16 {
-  const Rec16 *s;
+template <class Rec>
+struct AccRec {
+  const Rec *s;
   __device__ __forceinline__ u32 pos(u32 i) const { return s[i].pos; }
   __device__ __forceinline__ u32 neq(u32 i) const {
     if (i == 0) return 1u;
-    const Rec16 a = s[i], b = s[i - 1];
+    const Rec a = s[i], b = s[i - 1];
     return key_neq(a, b) ? 1u : 0u;
   }
 };

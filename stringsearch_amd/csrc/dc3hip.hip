@@ -73,6 +73,7 @@ struct dc3hip_ctx {
   int merge_cfg = 1;
   bool no_small_ties = false;
   bool wide_names = false;
+  bool no_nine_bit = false, no_rec12 = false;
   std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
   std::vector<PhaseMark> marks;
   hipEvent_t ev_build_a = nullptr, ev_build_b = nullptr;
@@ -167,73 +168,90 @@ static Chunking make_chunks(dc3hip_ctx *c, u32 n, u32 tile) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// stable LSD radix sort over `nbytes` key bytes (lib.rs:15-39 per digit)
+// stable LSD radix sort over a bit range of the key (lib.rs:15-39 per digit)
 // ---------------------------------------------------------------------------------------------
-template <class Rec> struct SortCfg;
-template <> struct SortCfg<Rec8>  { static constexpr int IPT = 12, NW = 16, kClass = 0; static constexpr bool PF = true; typedef Rec8Shift Dig; };
-template <> struct SortCfg<Rec16> { static constexpr int IPT = 8, NW = 16, kClass = 1; static constexpr bool PF = false; typedef Rec16Byte Dig; };
-template <> struct SortCfg<Tup0>  { static constexpr int IPT = 6, NW = 16, kClass = 2; static constexpr bool PF = false; typedef Tup0Byte Dig; };
+// tile shapes per record type and digit width (NB bins); LDS = records + NW*NB counters (<= 160 KiB)
+template <class Rec, int NB> struct SortCfg;
+template <> struct SortCfg<Rec8, 256>  { static constexpr int IPT = 12, NW = 16; static constexpr bool PF = true; };
+template <> struct SortCfg<Rec8, 512>  { static constexpr int IPT = 12, NW = 16; static constexpr bool PF = true; };
+template <> struct SortCfg<Rec12, 256> { static constexpr int IPT = 10, NW = 16; static constexpr bool PF = false; };
+template <> struct SortCfg<Rec12, 512> { static constexpr int IPT = 10, NW = 16; static constexpr bool PF = false; };
+template <> struct SortCfg<Rec16, 256> { static constexpr int IPT = 8, NW = 16; static constexpr bool PF = false; };
+template <> struct SortCfg<Rec16, 512> { static constexpr int IPT = 7, NW = 16; static constexpr bool PF = false; };
+template <> struct SortCfg<Tup0, 256>  { static constexpr int IPT = 6, NW = 16; static constexpr bool PF = false; };
+template <> struct SortCfg<Tup0, 512>  { static constexpr int IPT = 6, NW = 16; static constexpr bool PF = false; };
+template <class Rec> struct RecClass;      // index into dc3hip_stats.downsweep_*
+template <> struct RecClass<Rec8>  { static constexpr int k = 0; };
+template <> struct RecClass<Rec12> { static constexpr int k = 1; };
+template <> struct RecClass<Rec16> { static constexpr int k = 1; };
+template <> struct RecClass<Tup0>  { static constexpr int k = 2; };
 
-template <class Dig> static Dig make_digit(u32 pass, u32) { Dig d; d.p = pass; return d; }
-template <> Rec8Shift make_digit<Rec8Shift>(u32 pass, u32 shift0) { Rec8Shift d; d.shift = shift0 + 8 * pass; return d; }
-
-template <class Rec, class Loader>
-static int launch_downsweep(dc3hip_ctx *c, Loader in, Rec *dst, u32 n, const Chunking &ck,
-                            typename SortCfg<Rec>::Dig dig, const u32 *table, const u32 *digit_base, int phase) {
-  typedef typename SortCfg<Rec>::Dig Dig;
-  constexpr int IPT = SortCfg<Rec>::IPT, NW = SortCfg<Rec>::NW;
-  constexpr bool PF = SortCfg<Rec>::PF && std::is_same<Loader, ArrayLoader<Rec>>::value;
-  const size_t smem = DownsweepSmem<Rec, IPT, NW>::kBytes;
-  auto kern = k_rs_downsweep<Rec, Dig, IPT, NW, PF, Loader>;
+template <class Rec, int NB, class Loader>
+static int launch_downsweep(dc3hip_ctx *c, Loader in, Rec *dst, u32 n, const Chunking &ck, KeyDig dig,
+                            const u32 *table, const u32 *digit_base, int phase) {
+  constexpr int IPT = SortCfg<Rec, NB>::IPT, NW = SortCfg<Rec, NB>::NW;
+  constexpr bool PF = SortCfg<Rec, NB>::PF && std::is_same<Loader, ArrayLoader<Rec>>::value;
+  const size_t smem = DownsweepSmem<Rec, IPT, NW, NB>::kBytes;
+  auto kern = k_rs_downsweep<Rec, NB, IPT, NW, PF, Loader>;
   static thread_local bool attr_set[16] = {false};
   if (!attr_set[c->device & 15]) {
     HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)smem));
     attr_set[c->device & 15] = true;
   }
-  PhaseScope ps(c, phase, n, SortCfg<Rec>::kClass);
+  PhaseScope ps(c, phase, n, RecClass<Rec>::k);
   hipLaunchKernelGGL(kern, dim3(ck.nchunks), dim3(NW * 64), smem, c->stream, in, dst, n, ck.chunk, ck.nchunks, dig,
                      table, digit_base);
   KCHECK();
   return E_OK;
 }
-static int scan_digit_table(dc3hip_ctx *c, u32 *table, u32 nchunks, u32 *digit_base, int phase) {
-  PhaseScope ps(c, phase, 256 * nchunks);
-  hipLaunchKernelGGL(k_scan_rows, dim3(256), dim3(kBlock), 0, c->stream, table, nchunks, digit_base);
+static int scan_digit_table(dc3hip_ctx *c, u32 *table, u32 nchunks, u32 *digit_base, u32 nb, int phase) {
+  PhaseScope ps(c, phase, nb * nchunks);
+  hipLaunchKernelGGL(k_scan_rows, dim3(nb), dim3(kBlock), 0, c->stream, table, nchunks, digit_base);
   KCHECK();
-  hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, digit_base, 256u, (u32 *)nullptr);
+  hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, digit_base, nb, (u32 *)nullptr);
   KCHECK();
   return E_OK;
 }
 
-// passes first_pass..nbytes-1 over records in `a` (ping-pong with `b`)
-template <class Rec>
-static int radix_sort(dc3hip_ctx *c, Rec *a, Rec *b, u32 n, u32 nbytes, Rec **result, int ph_up, int ph_scan,
-                      int ph_down, u32 digit_shift = 0, u32 first_pass = 0) {
-  typedef typename SortCfg<Rec>::Dig Dig;
-  constexpr int kTile = SortCfg<Rec>::NW * 64 * SortCfg<Rec>::IPT;
+// Stable LSD sort of key bits [bit_lo, bit_hi) of the records in `a` (ping-pong with `b`).
+// Digit width: 9 bits where that saves a pass over 8-bit digits, else 8.
+template <class Rec, int NB>
+static int radix_passes(dc3hip_ctx *c, Rec *a, Rec *b, u32 n, u32 bit_lo, u32 bit_hi, Rec **result, int ph_up,
+                        int ph_scan, int ph_down) {
+  constexpr u32 kBits = NB == 512 ? 9 : 8;
+  constexpr int kTile = SortCfg<Rec, NB>::NW * 64 * SortCfg<Rec, NB>::IPT;
   const Chunking ck = make_chunks(c, n, kTile);
   const ArenaMark mk = arena_mark(c);
   u32 *table = nullptr, *digit_base = nullptr;
-  RC(arena_alloc(c, (size_t)256 * ck.nchunks, &table));
-  RC(arena_alloc(c, (size_t)256, &digit_base));
+  RC(arena_alloc(c, (size_t)NB * ck.nchunks, &table));
+  RC(arena_alloc(c, (size_t)NB, &digit_base));
   Rec *src = a, *dst = b;
-  for (u32 p = first_pass; p < nbytes; p++) {
-    const Dig dig = make_digit<Dig>(p, digit_shift);
+  for (u32 lo = bit_lo; lo < bit_hi; lo += kBits) {
+    KeyDig dig; dig.shift = lo; dig.mask = NB - 1;
     {
       PhaseScope ps(c, ph_up, n);
-      hipLaunchKernelGGL((k_rs_upsweep<Rec, Dig>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, src, n, ck.chunk,
+      hipLaunchKernelGGL((k_rs_upsweep<Rec, NB>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, src, n, ck.chunk,
                          ck.nchunks, dig, table);
       KCHECK();
     }
-    RC(scan_digit_table(c, table, ck.nchunks, digit_base, ph_scan));
+    RC(scan_digit_table(c, table, ck.nchunks, digit_base, NB, ph_scan));
     ArrayLoader<Rec> ld; ld.p = src;
-    RC((launch_downsweep<Rec, ArrayLoader<Rec>>(c, ld, dst, n, ck, dig, table, digit_base, ph_down)));
+    RC((launch_downsweep<Rec, NB, ArrayLoader<Rec>>(c, ld, dst, n, ck, dig, table, digit_base, ph_down)));
     std::swap(src, dst);
   }
   arena_release(c, mk);
   *result = src;
   return E_OK;
+}
+template <class Rec>
+static int radix_sort(dc3hip_ctx *c, Rec *a, Rec *b, u32 n, u32 bit_lo, u32 bit_hi, Rec **result, int ph_up,
+                      int ph_scan, int ph_down) {
+  const u32 bits = bit_hi > bit_lo ? bit_hi - bit_lo : 0;
+  if (bits == 0) { *result = a; return E_OK; }
+  const bool nine = !c->no_nine_bit && ((bits + 8) / 9 < (bits + 7) / 8);
+  if (nine) return radix_passes<Rec, 512>(c, a, b, n, bit_lo, bit_hi, result, ph_up, ph_scan, ph_down);
+  return radix_passes<Rec, 256>(c, a, b, n, bit_lo, bit_hi, result, ph_up, ph_scan, ph_down);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -378,7 +396,7 @@ static int predict_tie_fraction(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u3
   hipLaunchKernelGGL((k_pack_hi32<Sym>), dim3(grid_for(c, ng)), dim3(kBlock), 0, c->stream, S, m, m0, m02, b, sh,
                      stride, ng, a);
   KCHECK();
-  RC(radix_sort<Rec8>(c, a, bb, ns, 4, &sorted, DC3HIP_PH_PACK, DC3HIP_PH_PACK, DC3HIP_PH_PACK, 0));
+  RC(radix_sort<Rec8>(c, a, bb, ns, 0, 32, &sorted, DC3HIP_PH_PACK, DC3HIP_PH_PACK, DC3HIP_PH_PACK));
   const Chunking ck = make_chunks(c, ns, kBlock);
   u32 *counts = nullptr;
   RC(arena_alloc(c, (size_t)ck.nchunks + 16, &counts));
@@ -391,8 +409,27 @@ static int predict_tie_fraction(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u3
   return E_OK;
 }
 
+// straight ordering: full-key records (12 bytes when the key fits 64 bits, else 16), LSD over all key bits
+template <class Sym, class Rec>
+static int order_straight(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u32 kbits, u32 *sa12, u32 *rank12,
+                          u32 *R, u32 *names) {
+  Rec *recA = nullptr, *recB = nullptr, *sorted = nullptr;
+  RC(arena_alloc(c, (size_t)m02, &recA));
+  RC(arena_alloc(c, (size_t)m02, &recB));
+  {
+    PhaseScope ps(c, DC3HIP_PH_PACK, m02);
+    hipLaunchKernelGGL((k_pack_triples<Sym, Rec>), dim3(grid_for(c, m0)), dim3(kBlock), 0, c->stream, S, m, m0, m02,
+                       b, recA);
+    KCHECK();
+  }
+  RC(radix_sort<Rec>(c, recA, recB, m02, 0, kbits, &sorted, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN,
+                     DC3HIP_PH_SORT12_DOWN));
+  AccRec<Rec> acc; acc.s = sorted;
+  return name_and_rank<AccRec<Rec>>(c, acc, m02, m0, sa12, rank12, R, names);
+}
+
 template <class Sym>
-static int order_hybrid(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u32 kbits, u32 nbytes, u32 *sa12,
+static int order_hybrid(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u32 kbits, u32 *sa12,
                         u32 *rank12, u32 *R, u32 *names, bool *ok, int depth) {
   *ok = false;
   Rec8 *ha = nullptr, *hb = nullptr, *h = nullptr;
@@ -406,7 +443,7 @@ static int order_hybrid(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u32
                        make_himap((u64)b, kbits), 1u, m0, ha);
     KCHECK();
   }
-  RC(radix_sort<Rec8>(c, ha, hb, m02, 4, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT8_DOWN, 0));
+  RC(radix_sort<Rec8>(c, ha, hb, m02, 0, 32, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT8_DOWN));
   const Chunking ck = make_chunks(c, m02, kBlock);
   u32 *counts = nullptr;
   RC(arena_alloc(c, (size_t)ck.nchunks + 16, &counts));
@@ -447,7 +484,7 @@ static int order_hybrid(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u32
       KCHECK();
       ss = sb;
     } else {
-      RC(radix_sort<Rec16>(c, sa, sb, tied, nbytes, &ss, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN,
+      RC(radix_sort<Rec16>(c, sa, sb, tied, 0, kbits, &ss, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN,
                            DC3HIP_PH_SORT12_DOWN));
     }
     {
@@ -517,7 +554,6 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
     const u32 b = (u32)B;                          // packing base of make_rec (K < 2^31)
     u32 kbits = 0;                                 // bit width of B^3 - 1; > 32 here (else direct path)
     { unsigned __int128 mx = (unsigned __int128)B * B * B - 1; while (mx) { kbits++; mx >>= 1; } }
-    const u32 nbytes = (kbits + 7) / 8;
     const ArenaMark mk1 = arena_mark(c);
     u32 names = 0;
     bool done = false;
@@ -528,26 +564,15 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
       c->stats.level_tie_pred[depth] = pred;
       if (pred < kHybridMaxPredicted) {
         bool ok = false;
-        RC(order_hybrid<Sym>(c, S, m, m0, m02, b, kbits, nbytes, sa12, rank12, R, &names, &ok, depth));
+        RC(order_hybrid<Sym>(c, S, m, m0, m02, b, kbits, sa12, rank12, R, &names, &ok, depth));
         done = ok;
         if (!ok) arena_release(c, mk1);
       }
     }
     if (!done) {
       c->stats.level_sorted[depth] = 1;
-      Rec16 *recA = nullptr, *recB = nullptr, *sorted = nullptr;
-      RC(arena_alloc(c, (size_t)m02, &recA));
-      RC(arena_alloc(c, (size_t)m02, &recB));
-      {
-        PhaseScope ps(c, DC3HIP_PH_PACK, m02);
-        hipLaunchKernelGGL((k_pack_triples<Sym>), dim3(grid_for(c, m0)), dim3(kBlock), 0, c->stream, S, m, m0, m02, b,
-                           recA);
-        KCHECK();
-      }
-      RC(radix_sort<Rec16>(c, recA, recB, m02, nbytes, &sorted, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN,
-                           DC3HIP_PH_SORT12_DOWN));
-      AccRec16 acc; acc.s = sorted;
-      RC(name_and_rank<AccRec16>(c, acc, m02, m0, sa12, rank12, R, &names));
+      if (kbits <= 64 && !c->no_rec12) RC((order_straight<Sym, Rec12>(c, S, m, m0, m02, b, kbits, sa12, rank12, R, &names)));
+      else RC((order_straight<Sym, Rec16>(c, S, m, m0, m02, b, kbits, sa12, rank12, R, &names)));
     }
     arena_release(c, mk1);
     if (names != m02) {
@@ -566,7 +591,7 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
   // "select mod-0 + first radix pass" (Step 2, lib.rs:118-126).
   Tup12 *tslot = nullptr, *t12 = nullptr;
   RC(arena_alloc(c, (size_t)m02, &t12));
-  constexpr u32 kTup0Tile = SortCfg<Tup0>::NW * 64 * SortCfg<Tup0>::IPT;
+  constexpr u32 kTup0Tile = SortCfg<Tup0, 256>::NW * 64 * SortCfg<Tup0, 256>::IPT;
   const Chunking ckc = make_chunks(c, m02, kTup0Tile);
   u32 *table0 = nullptr, *dbase0 = nullptr;
   RC(arena_alloc(c, (size_t)256 * ckc.nchunks, &table0));
@@ -591,13 +616,12 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
   RC(arena_alloc(c, (size_t)m0, &z1));
   {
     // pass 0 of the mod-0 sort reads the sample tuples directly (selection fused in the loader)
-    RC(scan_digit_table(c, table0, ckc.nchunks, dbase0, DC3HIP_PH_COMPACT));
+    RC(scan_digit_table(c, table0, ckc.nchunks, dbase0, 256, DC3HIP_PH_COMPACT));
     Mod0Loader ld; ld.t = t12;
-    Tup0Byte dig; dig.p = 0;
-    RC((launch_downsweep<Tup0, Mod0Loader>(c, ld, z0, m02, ckc, dig, table0, dbase0, DC3HIP_PH_COMPACT)));
+    KeyDig dig; dig.shift = 0; dig.mask = 255;
+    RC((launch_downsweep<Tup0, 256, Mod0Loader>(c, ld, z0, m02, ckc, dig, table0, dbase0, DC3HIP_PH_COMPACT)));
   }
-  RC(radix_sort<Tup0>(c, z0, z1, m0, (bits_of(K - 1) + 7) / 8, &zs, DC3HIP_PH_SORT0, DC3HIP_PH_SORT0, DC3HIP_PH_SORT0,
-                      0, 1));
+  RC(radix_sort<Tup0>(c, z0, z1, m0, 8, bits_of(K - 1), &zs, DC3HIP_PH_SORT0, DC3HIP_PH_SORT0, DC3HIP_PH_SORT0));
   {
     const u32 dskip = m0 - m1;                  // lib.rs:133: skip the dummy, which sorts first
     const u32 nA = m02 - dskip, nB = m0;
@@ -726,6 +750,10 @@ int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) {
   c->no_hybrid = (nh && nh[0] == '1');
   const char *nst = getenv("DC3HIP_NO_SMALL_TIES");
   c->no_small_ties = (nst && nst[0] == '1');
+  const char *n9 = getenv("DC3HIP_NO_9BIT");
+  c->no_nine_bit = (n9 && n9[0] == '1');
+  const char *n12 = getenv("DC3HIP_NO_REC12");
+  c->no_rec12 = (n12 && n12[0] == '1');
   const char *wn = getenv("DC3HIP_WIDE_NAMES");
   c->wide_names = (wn && wn[0] == '1');
   const char *mc = getenv("DC3HIP_MERGE_CFG");

@@ -159,7 +159,7 @@ def test_stats_struct_and_phases(ss):
         raw = Stats(); ss.lib().dc3hip_ctx_stats(c._h, ctypes.byref(raw))
         assert raw.struct_size == ctypes.sizeof(Stats)      # C and Python layouts agree
         assert st["levels"] == 2 and st["level_sorted"] == [0, 1]
-        assert st["build_ms"] > 0 and st["downsweep_launches"][1] == 10   # 75-bit keys -> 10 byte passes
+        assert st["build_ms"] > 0 and st["downsweep_launches"][1] == 9    # 73-bit keys -> 9 passes of 9-bit digits
         assert st["arena_peak"] <= st["arena_bytes"]
 
 
@@ -331,14 +331,15 @@ def test_hybrid_and_straight_paths_agree(ss, oracle):
     for label, data in cases.items():
         want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)
         seen = {}
-        for env in ({}, {"DC3HIP_NO_HYBRID": "1"}, {"DC3HIP_NO_SMALL_TIES": "1"}):
+        for env in ({}, {"DC3HIP_NO_HYBRID": "1"}, {"DC3HIP_NO_SMALL_TIES": "1"},
+                    {"DC3HIP_NO_HYBRID": "1", "DC3HIP_NO_9BIT": "1", "DC3HIP_NO_REC12": "1"}):
             os.environ.update(env)
             try:
                 with ss.Context(len(data)) as c:
                     c.set_text(data); c.build()
                     st = c.stats()
                     assert np.array_equal(c.sa(), want), (label, env)
-                    seen[tuple(env)] = st
+                    seen[tuple(sorted(env))] = st
             finally:
                 for k in env:
                     os.environ.pop(k, None)
