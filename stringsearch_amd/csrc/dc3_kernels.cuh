@@ -807,8 +807,16 @@ __global__ __launch_bounds__(kBlock) void k_merge_partition(const Tup12 *__restr
 // the windowed inversion that gives the parent level rank[pos] = k+1 (R[SA12[i]] = i+1, lib.rs:106-108).
 // NT threads, VT outputs per thread; the tile's inputs are staged in LDS, outputs are staged in LDS
 // too so that global stores are coalesced.
+// LDS image of a tile: sample tuples as 16-byte words (pos, r, c0, cx); mod-0 tuples split into a
+// 16-byte comparison key (c0, c1, r1, r2) and a separate pos array, so that every comparison is two
+// ds_read_b128 (the packed 20-byte Tup0 would be five ds_read_b32).
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bool sample_before4(const u32x4 a /*pos,r,c0,cx*/, const u32x4 z /*c0,c1,r1,r2*/) {
+  if (is_mod1(a.x)) return (a.z < z.x) || (a.z == z.x && a.y <= z.z);                                   // leq2
+  return (a.z < z.x) || (a.z == z.x && ((a.w < z.y) || (a.w == z.y && a.y <= z.w)));                    // leq3
+}
 template <int NT, int VT>
-struct MergeSmem { static constexpr size_t kBytes = (sizeof(Tup12) + sizeof(Tup0)) * (size_t)(NT * VT) + 64; };
+struct MergeSmem { static constexpr size_t kBytes = (16 + 16 + 4) * (size_t)(NT * VT) + 64; };
 
 template <int NT, int VT>
 __global__ __launch_bounds__(NT) void k_merge(const Tup12 *__restrict__ A, u32 nA, const Tup0 *__restrict__ B, u32 nB,
@@ -816,22 +824,28 @@ __global__ __launch_bounds__(NT) void k_merge(const Tup12 *__restrict__ A, u32 n
                                              Rec8 *__restrict__ out_pairs) {
   constexpr u32 kTile = NT * VT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  Tup12 *sa = reinterpret_cast<Tup12 *>(smem);
-  Tup0 *sb = reinterpret_cast<Tup0 *>(smem + sizeof(Tup12) * kTile);
+  u32x4 *sa = reinterpret_cast<u32x4 *>(smem);
+  u32x4 *sbk = reinterpret_cast<u32x4 *>(smem + 16 * kTile);
+  u32 *sbpos = reinterpret_cast<u32 *>(smem + 32 * kTile);
   const u32 total = nA + nB;
   const u32 d0 = blockIdx.x * kTile;
   const u32 d1 = min(d0 + kTile, total);
   const u32 a0 = part[blockIdx.x], a1 = part[blockIdx.x + 1];
   const u32 b0 = d0 - a0, b1 = d1 - a1;
   const u32 na = a1 - a0, nb = b1 - b0;
-  for (u32 i = threadIdx.x; i < na; i += NT) sa[i] = A[a0 + i];
-  for (u32 i = threadIdx.x; i < nb; i += NT) sb[i] = B[b0 + i];
+  const u32x4 *Av = reinterpret_cast<const u32x4 *>(A);
+  for (u32 i = threadIdx.x; i < na; i += NT) sa[i] = Av[a0 + i];
+  for (u32 i = threadIdx.x; i < nb; i += NT) {
+    const Tup0 z = B[b0 + i];
+    u32x4 k; k.x = z.c0; k.y = z.c1; k.z = z.r1; k.w = z.r2;
+    sbk[i] = k; sbpos[i] = z.pos;
+  }
   __syncthreads();
   const u32 dl = min(threadIdx.x * (u32)VT, na + nb);
   u32 lo = dl > nb ? dl - nb : 0u, hi = min(dl, na);
   while (lo < hi) {
     const u32 mid = (lo + hi) >> 1;
-    if (sample_before(sa[mid], sb[dl - 1 - mid])) lo = mid + 1; else hi = mid;
+    if (sample_before4(sa[mid], sbk[dl - 1 - mid])) lo = mid + 1; else hi = mid;
   }
   u32 ai = lo, bi = dl - lo;
   u32 outp[VT];
@@ -840,8 +854,8 @@ __global__ __launch_bounds__(NT) void k_merge(const Tup12 *__restrict__ A, u32 n
     const u32 k = dl + v;
     outp[v] = 0;
     if (k < na + nb) {
-      const bool takeA = (bi >= nb) || (ai < na && sample_before(sa[ai], sb[bi]));
-      outp[v] = takeA ? sa[ai].pos : sb[bi].pos;
+      const bool takeA = (bi >= nb) || (ai < na && sample_before4(sa[ai], sbk[bi]));
+      outp[v] = takeA ? sa[ai].x : sbpos[bi];
       ai += takeA ? 1u : 0u; bi += takeA ? 0u : 1u;
     }
   }

@@ -70,7 +70,7 @@ struct dc3hip_ctx {
   // profiling
   bool profile = true;
   bool no_hybrid = false;
-  int merge_cfg = 1;
+  int merge_cfg = 3;
   bool no_small_ties = false;
   bool wide_names = false;
   bool no_nine_bit = false, no_rec12 = false;
