@@ -40,13 +40,31 @@ struct Tup0 { u32 pos, c0, c1, r1, r2; };
 // Symbol readers: level 0 reads bytes through the dense code table (codes 1..sigma, 0 past the
 // end = the sentinel of lib.rs:41-42); deeper levels read u32 names whose zero tail is physical.
 // ---------------------------------------------------------------------------------------------
+// get4(i, lds, out): symbols i..i+3 — for bytes one (unaligned) dword load + 4 look-ups in a per-block
+// LDS copy of the code table (stage() fills it; the text buffer is padded with 64 zero bytes).
 struct SymU8 {
   const uint8_t *t; const uint16_t *code; u32 m;
+  static constexpr bool kTable = true;
   __device__ __forceinline__ u32 get(u32 i) const { return i < m ? (u32)code[t[i]] : 0u; }
+  __device__ __forceinline__ void stage(uint16_t *lds) const {     // blockDim.x >= 256
+    if (threadIdx.x < 256) lds[threadIdx.x] = code[threadIdx.x];
+    __syncthreads();
+  }
+  __device__ __forceinline__ void get4(u32 i, const uint16_t *lds, u32 *out) const {
+    u32 w; __builtin_memcpy(&w, t + i, 4);
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[k] = (i + k < m) ? (u32)lds[(w >> (8 * k)) & 255u] : 0u;
+  }
 };
 struct SymU32 {
   const u32 *s; u32 m;   // s has >= 8 zero words after s[m-1]
+  static constexpr bool kTable = false;
   __device__ __forceinline__ u32 get(u32 i) const { return s[i]; }
+  __device__ __forceinline__ void stage(uint16_t *) const {}
+  __device__ __forceinline__ void get4(u32 i, const uint16_t *, u32 *out) const {
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[k] = s[i + k];
+  }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -162,14 +180,25 @@ template <class Sym>
 __global__ __launch_bounds__(kBlock) void k_name_direct(Sym S, u32 m, u32 m0, u32 m02, u32 B, u32 w, u32 Bw1,
                                                        u32 *R) {
   const u32 ngroups = m0;   // group g: samples 3g+1 (slot g) and 3g+2 (slot m0+g)
-  for (u32 g = blockIdx.x * kBlock + threadIdx.x; g < ngroups; g += gridDim.x * kBlock) {
-    const u32 i = 3 * g + 1;
-    const u32 first = S.get(i);
-    u32 acc = first;
-    for (u32 t = 1; t < w; t++) acc = acc * B + S.get(i + t);      // Horner over S[i .. i+w)
-    // mod-1 sample exists for every g < m0 (includes the dummy at i == m when m%3 == 1)
-    R[g] = acc + 1;
-    if (i + 1 < m) R[m0 + g] = (acc - first * Bw1) * B + S.get(i + w) + 1;   // S[i+1 .. i+1+w)
+  __shared__ uint16_t lcode[256];
+  S.stage(lcode);
+  if (w == 3) {               // the K–S triple: symbols 3g+1 .. 3g+4 in one get4
+    for (u32 g = blockIdx.x * kBlock + threadIdx.x; g < ngroups; g += gridDim.x * kBlock) {
+      const u32 i = 3 * g + 1;
+      u32 q[4]; S.get4(i, lcode, q);
+      R[g] = ((q[0] * B + q[1]) * B + q[2]) + 1;
+      if (i + 1 < m) R[m0 + g] = ((q[1] * B + q[2]) * B + q[3]) + 1;
+    }
+  } else {
+    for (u32 g = blockIdx.x * kBlock + threadIdx.x; g < ngroups; g += gridDim.x * kBlock) {
+      const u32 i = 3 * g + 1;
+      const u32 first = S.get(i);
+      u32 acc = first;
+      for (u32 t = 1; t < w; t++) acc = acc * B + S.get(i + t);      // Horner over S[i .. i+w)
+      // mod-1 sample exists for every g < m0 (includes the dummy at i == m when m%3 == 1)
+      R[g] = acc + 1;
+      if (i + 1 < m) R[m0 + g] = (acc - first * Bw1) * B + S.get(i + w) + 1;   // S[i+1 .. i+1+w)
+    }
   }
   // zero tail of R (sentinels of the next level, lib.rs:51-53)
   if (blockIdx.x == 0 && threadIdx.x < 8) R[m02 + threadIdx.x] = 0;
@@ -702,9 +731,12 @@ template <class Sym>
 __global__ __launch_bounds__(kBlock) void k_build_tuples(Sym S, u32 m, u32 m0, u32 m02,
                                                         const u32 *__restrict__ rank, Tup12 *__restrict__ tslot) {
   const bool dummy = (m % 3) == 1;
+  __shared__ uint16_t lcode[256];
+  S.stage(lcode);
   for (u32 g = blockIdx.x * kBlock + threadIdx.x; g < m0; g += gridDim.x * kBlock) {
     const u32 j = 3 * g;
-    const u32 s0 = S.get(j), s1 = S.get(j + 1), s2 = S.get(j + 2), s3 = S.get(j + 3);
+    u32 q[4]; S.get4(j, lcode, q);
+    const u32 s0 = q[0], s1 = q[1], s2 = q[2], s3 = q[3];
     // mod-1 sample at j+1 (slot g); exists for all g < m0 (dummy when j+1 == m)
     Tup12 a;
     a.pos = j + 1; a.c0 = s1; a.cx = s0;
