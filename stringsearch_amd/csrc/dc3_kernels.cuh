@@ -244,7 +244,10 @@ __global__ __launch_bounds__(kBlock) void k_pack_triples(Sym S, u32 m, u32 m0, u
 // A digit is (key >> shift) & mask of the record's sort key.
 // ---------------------------------------------------------------------------------------------
 struct KeyDig { u32 shift, mask; };
-__device__ __forceinline__ u32 digit_of(const Rec8 &r, KeyDig d) { return (r.key >> d.shift) & d.mask; }
+// Rec8 as a 64-bit sort word: key = high half, val = low half (prefix-sort records keep the position
+// in the low pbits of val, the rest is the monotone key image)
+__device__ __forceinline__ u64 rec8_word(const Rec8 &r) { return ((u64)r.key << 32) | r.val; }
+__device__ __forceinline__ u32 digit_of(const Rec8 &r, KeyDig d) { return (u32)(rec8_word(r) >> d.shift) & d.mask; }
 __device__ __forceinline__ u32 digit_of(const Rec12 &r, KeyDig d) {
   const u64 k = (u64)r.k0 | ((u64)r.k1 << 32);
   return (u32)(k >> d.shift) & d.mask;
@@ -464,8 +467,8 @@ struct AccRec {
   }
 };
 struct AccHyb {
-  const Rec8 *h; const uint8_t *f;     // h[i].val = pos; f[i] = 1 iff key(i) != key(i-1)
-  __device__ __forceinline__ u32 pos(u32 i) const { return h[i].val; }
+  const Rec8 *h; const uint8_t *f; u32 posmask;   // pos = low bits of h[i].val; f[i] = 1 iff key(i) != key(i-1)
+  __device__ __forceinline__ u32 pos(u32 i) const { return h[i].val & posmask; }
   __device__ __forceinline__ u32 neq(u32 i) const { return f[i]; }
 };
 
@@ -601,40 +604,49 @@ __global__ __launch_bounds__(1024) void k_invperm_local(const Rec8 *__restrict__
 //      3b-bit key as 16-byte records and written back into the tied slots (same relative order)
 // Result: h[i].val = position of the i-th smallest triple, f[i] = key differs from predecessor.
 // ---------------------------------------------------------------------------------------------
-// Monotone 32-bit image of the full key: X = key >> shx (its top 64 bits), hi32 = floor(X * mfix / 2^64)
-// with mfix = floor(2^96 / (Xmax+1)) — uses the whole 32-bit range whatever the packing base is, so
-// as few samples as possible collide.  Any monotone map is valid for the tie-refine scheme.
-struct HiMap { u64 mfix; u32 shx; };
-__device__ __forceinline__ u32 key_hi32(const Rec16 &r, HiMap hm) {
+// Monotone N-bit image of the full key (N = 64 - pbits, pbits = bits of a position; 34 bits at 1 GiB):
+// X = key >> shx (its top 64 bits), hi = floor(X * mfix / 2^64) with mfix = floor(2^(64+N) / (Xmax+1)) —
+// uses the whole N-bit range whatever the packing base is, so as few samples as possible collide
+// (exact: the key itself fits N bits).  Any monotone map is valid for the tie-refine scheme.
+// The record is the 64-bit word (hi << pbits) | pos.
+struct HiMap { u64 mfix; u32 shx, pbits, nbits, exact; };
+__device__ __forceinline__ Rec8 hyb_rec(const Rec16 &r, HiMap hm) {
   const u64 lo = (u64)r.k0 | ((u64)r.k1 << 32);
-  const u64 x = hm.shx ? ((lo >> hm.shx) | ((u64)r.k2 << (64 - hm.shx))) : lo;
-  return (u32)__umul64hi(x, hm.mfix);
+  u64 hi;
+  if (hm.exact) hi = lo;
+  else {
+    const u64 x = hm.shx ? ((lo >> hm.shx) | ((u64)r.k2 << (64 - hm.shx))) : lo;
+    hi = __umul64hi(x, hm.mfix);
+  }
+  const u64 w = (hi << hm.pbits) | r.pos;
+  return Rec8{(u32)(w >> 32), (u32)w};
 }
 // stride > 1 samples every stride-th group (tie-rate predictor); out index = g / stride
 template <class Sym>
-__global__ __launch_bounds__(kBlock) void k_pack_hi32(Sym S, u32 m, u32 m0, u32 m02, u32 b, HiMap sh, u32 stride,
+__global__ __launch_bounds__(kBlock) void k_pack_hi32(Sym S, u32 m, u32 m0, u32 m02, u32 b, HiMap hm, u32 stride,
                                                      u32 ngroups_out, Rec8 *out) {
   for (u32 go = blockIdx.x * kBlock + threadIdx.x; go < ngroups_out; go += gridDim.x * kBlock) {
     const u32 g = go * stride;
     const u32 i = 3 * g + 1;
     const u32 s1 = S.get(i), s2 = S.get(i + 1), s3 = S.get(i + 2), s4 = S.get(i + 3);
-    out[2 * go] = Rec8{key_hi32(make_rec(s1, s2, s3, b, i), sh), i};
+    out[2 * go] = hyb_rec(make_rec(s1, s2, s3, b, i), hm);
     if (stride > 1 || 2 * g + 1 < m02) {
       // (in sampling mode a possibly non-existent last mod-2 sample only perturbs the estimate)
-      if (2 * g + 1 < m02) out[2 * go + 1] = Rec8{key_hi32(make_rec(s2, s3, s4, b, i + 1), sh), i + 1};
-      else out[2 * go + 1] = Rec8{0xffffffffu, i + 1};
+      if (2 * g + 1 < m02) out[2 * go + 1] = hyb_rec(make_rec(s2, s3, s4, b, i + 1), hm);
+      else out[2 * go + 1] = Rec8{0xffffffffu, 0xffffffffu};
     }
   }
 }
-__device__ __forceinline__ bool hyb_tied(const Rec8 *h, u32 i, u32 n) {
-  const u32 a = h[i].key;
-  return (i > 0 && h[i - 1].key == a) || (i + 1 < n && h[i + 1].key == a);
+__device__ __forceinline__ bool hyb_tied(const Rec8 *h, u32 i, u32 n, u32 pbits) {
+  const u64 a = rec8_word(h[i]) >> pbits;
+  return (i > 0 && (rec8_word(h[i - 1]) >> pbits) == a) || (i + 1 < n && (rec8_word(h[i + 1]) >> pbits) == a);
 }
-__global__ __launch_bounds__(kBlock) void k_tie_count(const Rec8 *__restrict__ h, u32 n, u32 chunk, u32 *counts) {
+__global__ __launch_bounds__(kBlock) void k_tie_count(const Rec8 *__restrict__ h, u32 n, u32 chunk, u32 pbits,
+                                                     u32 *counts) {
   __shared__ u32 tmp[kWaves];
   const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
   u32 c = 0;
-  for (u32 i = begin + threadIdx.x; i < end; i += kBlock) c += hyb_tied(h, i, n) ? 1u : 0u;
+  for (u32 i = begin + threadIdx.x; i < end; i += kBlock) c += hyb_tied(h, i, n, pbits) ? 1u : 0u;
   c = wave_reduce(c);
   if (lane_id() == 0) tmp[wave_id()] = c;
   __syncthreads();
@@ -644,6 +656,7 @@ __global__ __launch_bounds__(kBlock) void k_tie_count(const Rec8 *__restrict__ h
 // the slot it came from
 template <class Sym>
 __global__ __launch_bounds__(kBlock) void k_tie_compact(Sym S, u32 b, const Rec8 *__restrict__ h, u32 n, u32 chunk,
+                                                       u32 pbits,
                                                        const u32 *__restrict__ base_excl, Rec16 *__restrict__ sub,
                                                        u32 *__restrict__ tiedidx, u32 *__restrict__ gkey) {
   __shared__ u32 tmp[kWaves];
@@ -651,14 +664,16 @@ __global__ __launch_bounds__(kBlock) void k_tie_compact(Sym S, u32 b, const Rec8
   u32 running = base_excl[blockIdx.x];
   for (u32 tile = begin; tile < end; tile += kBlock) {
     const u32 i = tile + threadIdx.x;
-    const bool f = (i < end) && hyb_tied(h, i, n);
+    const bool f = (i < end) && hyb_tied(h, i, n, pbits);
     u32 tot;
     const u32 ex = block_excl_scan<kWaves>(f ? 1u : 0u, tmp, tot);
     if (f) {
-      const u32 p = h[i].val;
+      const u32 p = h[i].val & (pbits >= 32 ? 0xffffffffu : ((1u << pbits) - 1u));
       sub[running + ex] = make_rec(S.get(p), S.get(p + 1), S.get(p + 2), b, p);
       tiedidx[running + ex] = i;
-      gkey[running + ex] = h[i].key;
+      // group id = low 32 bits of the key image; merging two adjacent groups that differ only above
+      // bit 31 is harmless (the union is sorted by the full key)
+      gkey[running + ex] = (u32)(rec8_word(h[i]) >> pbits);
     }
     running += tot;
   }

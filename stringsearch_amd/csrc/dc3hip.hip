@@ -360,20 +360,27 @@ static int name_and_rank(dc3hip_ctx *c, Acc acc, u32 m02, u32 m0, u32 *sa12, u32
 //     out above kHybridMaxMeasured.  Correctness never depends on the policy.
 // ---------------------------------------------------------------------------------------------
 static constexpr u32 kHybridMinSamples = 1u << 22;
-// hi32 = floor(X * mfix / 2^64), X = key >> shx, mfix = floor((2^96-1) / (Xmax+1)); B^3 > 2^32 here
-static HiMap make_himap(u64 B, u32 kbits) {
-  const unsigned __int128 mx = (unsigned __int128)B * B * B - 1;      // largest key
-  HiMap hm; hm.shx = kbits > 64 ? kbits - 64 : 0;
-  const unsigned __int128 xmax1 = (mx >> hm.shx) + 1;                  // > 2^32
-  const unsigned __int128 num = (((unsigned __int128)1) << 96) - 1;
-  hm.mfix = (u64)(num / xmax1);
-  return hm;
-}
 static constexpr double kHybridMaxPredicted = 0.50;
 static constexpr double kHybridMaxMeasured = 0.60;
+// hi = floor(X * mfix / 2^64) in N = min(64 - pbits, kbits) bits; X = key >> shx; see HiMap
+static HiMap make_himap(u64 B, u32 kbits, u32 m) {
+  const unsigned __int128 mx = (unsigned __int128)B * B * B - 1;      // largest key
+  HiMap hm;
+  hm.pbits = bits_of((u64)m + 2);
+  hm.nbits = std::min<u32>(64 - hm.pbits, kbits);
+  hm.exact = kbits <= hm.nbits ? 1u : 0u;
+  hm.shx = kbits > 64 ? kbits - 64 : 0;
+  hm.mfix = 0;
+  if (!hm.exact) {
+    const unsigned __int128 xmax1 = (mx >> hm.shx) + 1;                // > 2^nbits
+    const unsigned __int128 num = (((unsigned __int128)1) << (64 + hm.nbits)) - 1;
+    hm.mfix = (u64)(num / xmax1);
+  }
+  return hm;
+}
 
-static int count_ties(dc3hip_ctx *c, const Rec8 *h, u32 n, u32 *counts, const Chunking &ck, u32 *total) {
-  hipLaunchKernelGGL(k_tie_count, dim3(ck.nchunks), dim3(kBlock), 0, c->stream, h, n, ck.chunk, counts);
+static int count_ties(dc3hip_ctx *c, const Rec8 *h, u32 n, u32 pbits, u32 *counts, const Chunking &ck, u32 *total) {
+  hipLaunchKernelGGL(k_tie_count, dim3(ck.nchunks), dim3(kBlock), 0, c->stream, h, n, ck.chunk, pbits, counts);
   KCHECK();
   hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, counts, ck.nchunks, c->d_words + 2);
   KCHECK();
@@ -396,12 +403,13 @@ static int predict_tie_fraction(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u3
   hipLaunchKernelGGL((k_pack_hi32<Sym>), dim3(grid_for(c, ng)), dim3(kBlock), 0, c->stream, S, m, m0, m02, b, sh,
                      stride, ng, a);
   KCHECK();
-  RC(radix_sort<Rec8>(c, a, bb, ns, 0, 32, &sorted, DC3HIP_PH_PACK, DC3HIP_PH_PACK, DC3HIP_PH_PACK));
+  RC(radix_sort<Rec8>(c, a, bb, ns, sh.pbits, sh.pbits + sh.nbits, &sorted, DC3HIP_PH_PACK, DC3HIP_PH_PACK,
+                      DC3HIP_PH_PACK));
   const Chunking ck = make_chunks(c, ns, kBlock);
   u32 *counts = nullptr;
   RC(arena_alloc(c, (size_t)ck.nchunks + 16, &counts));
   u32 ts = 0;
-  RC(count_ties(c, sorted, ns, counts, ck, &ts));
+  RC(count_ties(c, sorted, ns, sh.pbits, counts, ck, &ts));
   const double fs = (double)ts / (double)ns;
   const double ratio = (double)(m02 - 1) / (double)(ns > 1 ? ns - 1 : 1);
   *pred = fs >= 1.0 ? 1.0 : 1.0 - pow(1.0 - fs, ratio);
@@ -432,6 +440,7 @@ template <class Sym>
 static int order_hybrid(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u32 kbits, u32 *sa12,
                         u32 *rank12, u32 *R, u32 *names, bool *ok, int depth) {
   *ok = false;
+  const HiMap hm = make_himap((u64)b, kbits, m);
   Rec8 *ha = nullptr, *hb = nullptr, *h = nullptr;
   uint8_t *f = nullptr;
   RC(arena_alloc(c, (size_t)m02, &ha));
@@ -439,18 +448,19 @@ static int order_hybrid(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u32
   RC(arena_alloc(c, (size_t)m02 + 16, &f));
   {
     PhaseScope ps(c, DC3HIP_PH_PACK, m02);
-    hipLaunchKernelGGL((k_pack_hi32<Sym>), dim3(grid_for(c, m0)), dim3(kBlock), 0, c->stream, S, m, m0, m02, b,
-                       make_himap((u64)b, kbits), 1u, m0, ha);
+    hipLaunchKernelGGL((k_pack_hi32<Sym>), dim3(grid_for(c, m0)), dim3(kBlock), 0, c->stream, S, m, m0, m02, b, hm,
+                       1u, m0, ha);
     KCHECK();
   }
-  RC(radix_sort<Rec8>(c, ha, hb, m02, 0, 32, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT8_DOWN));
+  RC(radix_sort<Rec8>(c, ha, hb, m02, hm.pbits, hm.pbits + hm.nbits, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN,
+                      DC3HIP_PH_SORT8_DOWN));
   const Chunking ck = make_chunks(c, m02, kBlock);
   u32 *counts = nullptr;
   RC(arena_alloc(c, (size_t)ck.nchunks + 16, &counts));
   u32 tied = 0;
   {
     PhaseScope ps(c, DC3HIP_PH_TIES, m02);
-    RC(count_ties(c, h, m02, counts, ck, &tied));
+    RC(count_ties(c, h, m02, hm.pbits, counts, ck, &tied));
   }
   c->stats.level_tied[depth] = tied;
   if ((double)tied > kHybridMaxMeasured * (double)m02) return E_OK;   // *ok stays false -> straight LSD
@@ -467,7 +477,7 @@ static int order_hybrid(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u32
     {
       PhaseScope ps(c, DC3HIP_PH_TIES, tied);
       hipLaunchKernelGGL((k_tie_compact<Sym>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, S, b, h, m02, ck.chunk,
-                         counts, sa, tiedidx, gkey);
+                         hm.pbits, counts, sa, tiedidx, gkey);
       KCHECK();
       HIPC(hipMemsetAsync(c->d_words + 3, 0, sizeof(u32), c->stream));
       hipLaunchKernelGGL(k_tie_groupmax, dim3(grid_for(c, tied)), dim3(kBlock), 0, c->stream, gkey, tied,
@@ -493,7 +503,7 @@ static int order_hybrid(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u32
       KCHECK();
     }
   }
-  AccHyb acc; acc.h = h; acc.f = f;
+  AccHyb acc; acc.h = h; acc.f = f; acc.posmask = hm.pbits >= 32 ? 0xffffffffu : ((1u << hm.pbits) - 1u);
   RC(name_and_rank<AccHyb>(c, acc, m02, m0, sa12, rank12, R, names));
   *ok = true;
   return E_OK;
@@ -560,7 +570,7 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
     // ---- prefix-sort + tie-refine ordering when the top 32 key bits separate most samples ------
     if (m02 >= kHybridMinSamples && !c->no_hybrid) {
       double pred = 1.0;
-      RC(predict_tie_fraction<Sym>(c, S, m, m0, m02, b, make_himap(B, kbits), &pred));
+      RC(predict_tie_fraction<Sym>(c, S, m, m0, m02, b, make_himap(B, kbits, m), &pred));
       c->stats.level_tie_pred[depth] = pred;
       if (pred < kHybridMaxPredicted) {
         bool ok = false;
