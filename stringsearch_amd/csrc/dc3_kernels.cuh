@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kBlock) void k_name_direct(Sym S, u32 m, u32 m0, u3
 // n12 = number of sample positions = m02.
 // ---------------------------------------------------------------------------------------------
 // key = (s0*B + s1)*B + s2 with B = K+1 (dense arithmetic packing: no bits are wasted when K is
-// not a power of two, which keeps the top 32 key bits discriminating for the prefix-sort path)
+// not a power of two, which keeps the top key bits discriminating for the prefix-sort path)
 __device__ __forceinline__ Rec16 make_rec(u32 s0, u32 s1, u32 s2, u32 B, u32 pos) {
   const u64 lo = (u64)s1 * B + s2;                     // < B^2 <= 2^62
   const u64 B2 = (u64)B * B;
@@ -598,9 +598,9 @@ __global__ __launch_bounds__(1024) void k_invperm_local(const Rec8 *__restrict__
 
 // ---------------------------------------------------------------------------------------------
 // Prefix-sort + tie-refine ordering of the sample triples (replaces the 3x radix_pass of
-// lib.rs:74-76 when most 3b-bit keys are already distinct in their top 32 bits):
-//   1. (hi32, pos) 8-byte records, 4 stable LSD passes                       [all samples]
-//   2. elements whose hi32 equals a neighbour's are "tied"; only those are re-sorted by the full
+// lib.rs:74-76 when most keys are already distinct in an N-bit monotone image, N = 64 - pbits):
+//   1. (image, pos) packed in one 64-bit word, 4 stable LSD passes over the image bits   [all samples]
+//   2. elements whose image equals a neighbour's are "tied"; only those are re-sorted by the full
 //      3b-bit key as 16-byte records and written back into the tied slots (same relative order)
 // Result: h[i].val = position of the i-th smallest triple, f[i] = key differs from predecessor.
 // ---------------------------------------------------------------------------------------------
@@ -623,7 +623,7 @@ __device__ __forceinline__ Rec8 hyb_rec(const Rec16 &r, HiMap hm) {
 }
 // stride > 1 samples every stride-th group (tie-rate predictor); out index = g / stride
 template <class Sym>
-__global__ __launch_bounds__(kBlock) void k_pack_hi32(Sym S, u32 m, u32 m0, u32 m02, u32 b, HiMap hm, u32 stride,
+__global__ __launch_bounds__(kBlock) void k_pack_image(Sym S, u32 m, u32 m0, u32 m02, u32 b, HiMap hm, u32 stride,
                                                      u32 ngroups_out, Rec8 *out) {
   for (u32 go = blockIdx.x * kBlock + threadIdx.x; go < ngroups_out; go += gridDim.x * kBlock) {
     const u32 g = go * stride;
@@ -678,7 +678,7 @@ __global__ __launch_bounds__(kBlock) void k_tie_compact(Sym S, u32 b, const Rec8
     running += tot;
   }
 }
-// Tied samples form groups (equal hi32) that are tiny on high-entropy input (Poisson: almost all of
+// Tied samples form groups (equal key image) that are tiny on high-entropy input (Poisson: almost all of
 // size 2-3).  When the largest group has at most kTieSmallMax members, one thread per group sorts
 // it by the full key with a stable insertion sort — instead of 10 radix passes over the subset.
 constexpr u32 kTieSmallMax = 16;

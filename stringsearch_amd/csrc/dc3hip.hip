@@ -354,7 +354,7 @@ static int name_and_rank(dc3hip_ctx *c, Acc acc, u32 m02, u32 m0, u32 *sa12, u32
 
 // ---------------------------------------------------------------------------------------------
 // prefix-sort + tie-refine ordering (see dc3_kernels.cuh).  Policy:
-//   * a strided sample of ~2^20 triples predicts the fraction of samples whose top 32 key bits
+//   * a strided sample of ~2^20 triples predicts the fraction of samples whose N-bit key image
 //     collide; the path is taken when the prediction is below kHybridMaxPredicted,
 //   * and abandoned (falling back to the straight 16-byte LSD sort) if the measured fraction turns
 //     out above kHybridMaxMeasured.  Correctness never depends on the policy.
@@ -400,7 +400,7 @@ static int predict_tie_fraction(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u3
   RC(arena_alloc(c, (size_t)ns, &a));
   RC(arena_alloc(c, (size_t)ns, &bb));
   PhaseScope ps(c, DC3HIP_PH_PACK, ns);
-  hipLaunchKernelGGL((k_pack_hi32<Sym>), dim3(grid_for(c, ng)), dim3(kBlock), 0, c->stream, S, m, m0, m02, b, sh,
+  hipLaunchKernelGGL((k_pack_image<Sym>), dim3(grid_for(c, ng)), dim3(kBlock), 0, c->stream, S, m, m0, m02, b, sh,
                      stride, ng, a);
   KCHECK();
   RC(radix_sort<Rec8>(c, a, bb, ns, sh.pbits, sh.pbits + sh.nbits, &sorted, DC3HIP_PH_PACK, DC3HIP_PH_PACK,
@@ -448,7 +448,7 @@ static int order_hybrid(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u32
   RC(arena_alloc(c, (size_t)m02 + 16, &f));
   {
     PhaseScope ps(c, DC3HIP_PH_PACK, m02);
-    hipLaunchKernelGGL((k_pack_hi32<Sym>), dim3(grid_for(c, m0)), dim3(kBlock), 0, c->stream, S, m, m0, m02, b, hm,
+    hipLaunchKernelGGL((k_pack_image<Sym>), dim3(grid_for(c, m0)), dim3(kBlock), 0, c->stream, S, m, m0, m02, b, hm,
                        1u, m0, ha);
     KCHECK();
   }
@@ -567,7 +567,7 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
     const ArenaMark mk1 = arena_mark(c);
     u32 names = 0;
     bool done = false;
-    // ---- prefix-sort + tie-refine ordering when the top 32 key bits separate most samples ------
+    // ---- prefix-sort + tie-refine ordering when the N-bit key image separates most samples ------
     if (m02 >= kHybridMinSamples && !c->no_hybrid) {
       double pred = 1.0;
       RC(predict_tie_fraction<Sym>(c, S, m, m0, m02, b, make_himap(B, kbits, m), &pred));
