@@ -85,7 +85,8 @@ def main():
     ap.add_argument("--size", type=str, default="1GiB", help="bytes per GPU (partition size is size*N/N+1 rounding aside)")
     ap.add_argument("--kind", type=str, default="random", choices=["random", "dna", "text"])
     ap.add_argument("--seed", type=int, default=2)
-    ap.add_argument("--cpu-sample-mib", type=int, default=64)
+    ap.add_argument("--cpu-sample-mib", type=int, default=256,
+                    help="CPU baseline sample (MiB of the same buffer); 256 MiB is ~10-20 s of one-core divsufsort")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--dump-stats", type=str, default=None, help="write the last build's dc3hip_stats as JSON here")
@@ -103,11 +104,17 @@ def main():
             print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes", file=sys.stderr)
             sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
+    # one rank per GPU; DC3HIP_BENCH_BACKEND=gloo lets several ranks share one GPU (plumbing test on 1-GPU boxes)
+    backend = os.environ.get("DC3HIP_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ      # launched by torch.distributed.run
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     import stringsearch_amd as ss
 
@@ -152,7 +159,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     if not args.no_verify:
