@@ -19,9 +19,9 @@ res = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), one
                  "KiB*1024, streaming kernels 2*FETCH+WRITE (gfx950 half-count), gather FETCH+WRITE uncorrected",
        "bytes_per_record": {}, "per_kernel_bytes": {}}
 e = st["downsweep_elems"]
-res["bytes_per_record"]["downsweep_rec8"] = tot(lambda k: "k_rs_downsweep<dc3::Rec8" in k, 2) / e[0]
-res["bytes_per_record"]["downsweep_rec16"] = tot(lambda k: "k_rs_downsweep<dc3::Rec16" in k, 2) / e[1]
-res["bytes_per_record"]["downsweep_tup0"] = tot(lambda k: "k_rs_downsweep<dc3::Tup0" in k, 2) / e[2]
+if e[0]: res["bytes_per_record"]["downsweep_rec8"] = tot(lambda k: "k_rs_downsweep<dc3::Rec8" in k, 2) / e[0]
+if e[1]: res["bytes_per_record"]["downsweep_rec16"] = tot(lambda k: "k_rs_downsweep<dc3::Rec16" in k or "k_rs_downsweep<dc3::Rec12" in k, 2) / e[1]
+if e[2]: res["bytes_per_record"]["downsweep_tup0"] = tot(lambda k: "k_rs_downsweep<dc3::Tup0" in k, 2) / e[2]
 res["bytes_per_record"]["gather_tuples"] = tot(lambda k: "k_gather_tuples" in k, 1) / st["gather_elems"]
 res["bytes_per_record"]["partition_pairs"] = tot(lambda k: "k_part_msd" in k, 2) / st["partition_elems"]
 for k in sorted(set(F) | set(W), key=lambda k: -(2 * F.get(k, 0) + W.get(k, 0))):
