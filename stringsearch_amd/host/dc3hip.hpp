@@ -37,4 +37,52 @@ inline sacabase::SuffixArray<int64_t> sort_i64(sacabase::Bytes text) {
   return sacabase::SuffixArray<int64_t>(text, std::move(sa));
 }
 
+// Device-resident index: text and SA stay in HBM; batched searches and the BWT run on the GPU.
+// search() returns exactly what sacabase::longest_substring_match would (start, len) per needle.
+class DeviceIndex : public sacabase::StringIndex {
+  dc3hip_ctx *ctx_ = nullptr;
+  sacabase::Bytes text_;
+  static void check(int rc) { if (rc != 0) throw Error(rc, dc3hip_last_error()); }
+
+ public:
+  explicit DeviceIndex(sacabase::Bytes text, int device = -1) : text_(text) {
+    check(dc3hip_ctx_create(&ctx_, device, (int64_t)text.len));
+    try {
+      check(dc3hip_ctx_set_text(ctx_, text.ptr, (int64_t)text.len));
+      check(dc3hip_ctx_build(ctx_));
+    } catch (...) { dc3hip_ctx_destroy(ctx_); throw; }
+  }
+  DeviceIndex(const DeviceIndex &) = delete;
+  DeviceIndex &operator=(const DeviceIndex &) = delete;
+  ~DeviceIndex() { dc3hip_ctx_destroy(ctx_); }
+
+  sacabase::SuffixArray<int32_t> to_host() const {
+    std::vector<int32_t> sa(text_.len);
+    check(dc3hip_ctx_get_sa_i32(ctx_, sa.data()));
+    return sacabase::SuffixArray<int32_t>(text_, std::move(sa));
+  }
+  int32_t sufcheck() const { return dc3hip_ctx_sufcheck(ctx_); }
+  std::vector<sacabase::LongestCommonSubstring> search(const std::vector<sacabase::Bytes> &needles) const {
+    std::vector<int64_t> off(needles.size() + 1, 0);
+    for (size_t i = 0; i < needles.size(); i++) off[i + 1] = off[i] + (int64_t)needles[i].len;
+    std::vector<uint8_t> cat((size_t)off.back() + 1);
+    for (size_t i = 0; i < needles.size(); i++) if (needles[i].len) std::memcpy(cat.data() + off[i], needles[i].ptr, needles[i].len);
+    std::vector<int64_t> st(needles.size()), ln(needles.size());
+    check(dc3hip_ctx_search(ctx_, cat.data(), off.data(), (int32_t)needles.size(), st.data(), ln.data()));
+    std::vector<sacabase::LongestCommonSubstring> out;
+    for (size_t i = 0; i < needles.size(); i++) out.push_back(sacabase::LongestCommonSubstring{text_, (size_t)st[i], (size_t)ln[i]});
+    return out;
+  }
+  sacabase::LongestCommonSubstring longest_substring_match(sacabase::Bytes needle) const override {
+    return search({needle})[0];
+  }
+  // bw_transform (utils.c:53-108): returns the primary index
+  int64_t bwt(std::vector<uint8_t> &u) const {
+    u.resize(text_.len);
+    int64_t idx = 0;
+    check(dc3hip_ctx_bwt(ctx_, u.data(), &idx));
+    return idx;
+  }
+};
+
 }  // namespace dc3hip

@@ -41,6 +41,23 @@ int main() {
     auto sa64 = dc3hip::sort_i64(Bytes(sh, sizeof sh));
     for (size_t i = 0; i < sizeof sh; i++) CHECK(sa64.sa()[i] == want[i]);
   }
+  {  // device-resident index: GPU batched search == CPU sacabase search, BWT of "banana"
+    std::string input = "This is a rather long text. We can probably find matches that span two partitions. Oh yes.";
+    dc3hip::DeviceIndex dev{Bytes(input)};
+    CHECK(dev.sufcheck() == 0);
+    auto host = dev.to_host();
+    std::vector<std::string> needles = {"rather long", "text. We can", "zzz", "Oh yes.!", "T", ""};
+    std::vector<Bytes> nb; for (auto &n : needles) nb.push_back(Bytes(n));
+    auto got = dev.search(nb);
+    for (size_t i = 0; i < needles.size(); i++) {
+      auto want = host.longest_substring_match(nb[i]);
+      CHECK(got[i].start == want.start); CHECK(got[i].len == want.len);
+    }
+    std::string b = "banana";
+    dc3hip::DeviceIndex bi{Bytes(b)};
+    std::vector<uint8_t> u; const int64_t pidx = bi.bwt(u);
+    CHECK(std::string(u.begin(), u.end()) == "annbaa"); CHECK(pidx == 4);
+  }
   {  // error behaviour: len mismatch throws like the Rust assert
     std::vector<int32_t> sa(2);
     bool threw = false;
