@@ -133,6 +133,7 @@ enum dc3hip_phase {
   DC3HIP_PH_SORT8_DOWN,     /* same, 8-byte (top-32-bit key, pos) records of the prefix-sort path */
   DC3HIP_PH_TIES,           /* tie detection / compaction / write-back of the prefix-sort path */
   DC3HIP_PH_NAMING,         /* flag/scan/assign lexicographic names               (ref lib.rs:80-100) */
+  DC3HIP_PH_DISCARD,        /* discarding recursion bookkeeping (reduced string, merge back) */
   DC3HIP_PH_RANKS,          /* rank <- SA12 inversion                             (ref lib.rs:106-113) */
   DC3HIP_PH_TUPLES,         /* merge tuples in slot order + gather to SA12 order */
   DC3HIP_PH_COMPACT,        /* mod-0 suffixes ordered by rank of suffix i+1       (ref lib.rs:118-125) */
@@ -148,7 +149,9 @@ typedef struct dc3hip_stats {
   int64_t level_n[DC3HIP_MAX_LEVELS];     /* string length per level (level 0 = n) */
   int64_t level_K[DC3HIP_MAX_LEVELS];     /* alphabet bound per level */
   int32_t level_sorted[DC3HIP_MAX_LEVELS];/* 0 = direct packed names, 1 = names by full radix sort,
-                                             2 = names by prefix sort + tie refinement */
+                                             2 = names by prefix sort + tie refinement,
+                                             3 / 4 = 1 / 2 followed by the discarding recursion */
+  int64_t level_kept[DC3HIP_MAX_LEVELS];  /* length of the reduced recursive string (discarding) */
   int32_t level_name_width[DC3HIP_MAX_LEVELS]; /* symbols packed per direct name (0 on sorted levels) */
   int64_t level_tied[DC3HIP_MAX_LEVELS];  /* samples re-sorted by the full key (prefix-sort path) */
   double  level_tie_pred[DC3HIP_MAX_LEVELS]; /* predicted tied fraction (policy input) */

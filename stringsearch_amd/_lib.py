@@ -6,7 +6,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 lib_path = os.path.join(_HERE, "libdc3hip.so")
 
 MAX_LEVELS = 48
-PHASES = ["alphabet", "name_direct", "pack", "sort12_up", "sort12_scan", "sort12_down", "sort8_down", "ties", "naming", "ranks",
+PHASES = ["alphabet", "name_direct", "pack", "sort12_up", "sort12_scan", "sort12_down", "sort8_down", "ties", "naming", "discard", "ranks",
           "tuples", "compact", "sort0", "merge", "other"]
 
 
@@ -25,6 +25,7 @@ class Stats(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_int32), ("levels", ctypes.c_int32),
                 ("level_n", ctypes.c_int64 * MAX_LEVELS), ("level_K", ctypes.c_int64 * MAX_LEVELS),
                 ("level_sorted", ctypes.c_int32 * MAX_LEVELS),
+                ("level_kept", ctypes.c_int64 * MAX_LEVELS),
                 ("level_name_width", ctypes.c_int32 * MAX_LEVELS),
                 ("level_tied", ctypes.c_int64 * MAX_LEVELS), ("level_tie_pred", ctypes.c_double * MAX_LEVELS),
                 ("build_ms", ctypes.c_double), ("phase_ms", ctypes.c_double * len(PHASES)),
@@ -43,6 +44,7 @@ class Stats(ctypes.Structure):
             "level_n": [self.level_n[i] for i in range(self.levels)],
             "level_K": [self.level_K[i] for i in range(self.levels)],
             "level_sorted": [self.level_sorted[i] for i in range(self.levels)],
+            "level_kept": [self.level_kept[i] for i in range(self.levels)],
             "level_name_width": [self.level_name_width[i] for i in range(self.levels)],
             "level_tied": [self.level_tied[i] for i in range(self.levels)],
             "level_tie_pred": [self.level_tie_pred[i] for i in range(self.levels)],

@@ -473,20 +473,33 @@ struct AccHyb {
 };
 
 constexpr int kNameIPT = 4;
+// a name is unique iff its key differs from both neighbours in the sorted order
 template <class Acc>
-__global__ __launch_bounds__(kBlock) void k_name_count(Acc acc, u32 n, u32 chunk, u32 *counts) {
-  __shared__ u32 tmp[kWaves];
-  const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
-  u32 c = 0;
-  for (u32 i = begin + threadIdx.x; i < end; i += kBlock) c += acc.neq(i);
-  c = wave_reduce(c);
-  if (lane_id() == 0) tmp[wave_id()] = c;
-  __syncthreads();
-  if (threadIdx.x == 0) { u32 t = 0; for (int i = 0; i < kWaves; i++) t += tmp[i]; counts[blockIdx.x] = t; }
+__device__ __forceinline__ u32 acc_unique(const Acc &acc, u32 i, u32 n) {
+  return (acc.neq(i) && (i + 1 == n || acc.neq(i + 1))) ? 1u : 0u;
 }
 template <class Acc>
+__global__ __launch_bounds__(kBlock) void k_name_count(Acc acc, u32 n, u32 chunk, u32 *counts, u32 *uniq_total) {
+  __shared__ u32 tmp[kWaves], tmpu[kWaves];
+  const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
+  u32 c = 0, u = 0;
+  for (u32 i = begin + threadIdx.x; i < end; i += kBlock) { c += acc.neq(i); u += acc_unique(acc, i, n); }
+  c = wave_reduce(c); u = wave_reduce(u);
+  if (lane_id() == 0) { tmp[wave_id()] = c; tmpu[wave_id()] = u; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 t = 0, tu = 0;
+    for (int i = 0; i < kWaves; i++) { t += tmp[i]; tu += tmpu[i]; }
+    counts[blockIdx.x] = t;
+    if (tu) atomicAdd(uniq_total, tu);
+  }
+}
+// sslot (optional, discarding recursion): sslot[i] = slot(pos_i) | unique_i << 31, and the pair value
+// carries the same unique bit (names < 2^31 on that path).
+constexpr u32 kUniqBit = 0x80000000u;
+template <class Acc>
 __global__ __launch_bounds__(kBlock) void k_name_assign(Acc acc, u32 n, u32 chunk, const u32 *__restrict__ base_excl,
-                                                       u32 m0, Rec8 *__restrict__ pairs) {
+                                                       u32 m0, Rec8 *__restrict__ pairs, u32 *__restrict__ sslot) {
   __shared__ u32 tmp[kWaves];
   const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
   u32 running = base_excl[blockIdx.x];
@@ -501,7 +514,17 @@ __global__ __launch_bounds__(kBlock) void k_name_assign(Acc acc, u32 n, u32 chun
     u32 name = running + block_excl_scan<kWaves>(local, tmp, tot);
 #pragma unroll
     for (int j = 0; j < kNameIPT; j++) {
-      if (i0 + j < end) { name += f[j]; pairs[i0 + j] = Rec8{slot_of(acc.pos(i0 + j), m0), name}; }
+      if (i0 + j < end) {
+        name += f[j];
+        const u32 sl = slot_of(acc.pos(i0 + j), m0);
+        if (sslot) {
+          const u32 ub = acc_unique(acc, i0 + j, n) ? kUniqBit : 0u;
+          sslot[i0 + j] = sl | ub;
+          pairs[i0 + j] = Rec8{sl, name | ub};
+        } else {
+          pairs[i0 + j] = Rec8{sl, name};
+        }
+      }
     }
     running += tot;
   }
@@ -516,6 +539,98 @@ __global__ __launch_bounds__(kBlock) void k_assign_unique(Acc acc, u32 n, u32 m0
     const u32 sl = slot_of(acc.pos(i), m0);
     sa12[i] = sl;
     pairs[i] = Rec8{sl, i + 1};
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Discarding recursion (Dementiev/Kärkkäinen/Mehnert/Sanders' refinement of lib.rs:103-108).
+// A sample whose name is unique needs no further sorting — its rank is its index in the sorted
+// array — and a comparison of two suffixes of R stops at the first unique name.  So the recursive
+// string only has to contain the non-unique slots and the unique slots that directly follow a
+// non-unique one (they terminate the comparisons that start before them).  RU[p] = name | unique<<31.
+//   k_keep_count/k_keep_write : R'[j] = name of the j-th kept slot, kept[j] = slot | unique<<31
+//   (child: SA' of R')
+//   k_discard_gather          : x[r] = kept[SA'[r]]            (kept slots in suffix order)
+//   k_nonuniq_count/_write    : pt[t] = t-th non-unique slot of x (their final relative order)
+//   k_final_count/_assign     : walk the level's sorted array; unique entries keep their place, the
+//                               t-th non-unique entry receives pt[t]   -> SA12 and (slot, rank) pairs
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool keep_slot(const u32 *__restrict__ RU, u32 p) {
+  return !((RU[p] & kUniqBit) && (p == 0 || (RU[p - 1] & kUniqBit)));
+}
+__device__ __forceinline__ void block_count_store(u32 c, u32 *tmp, u32 *counts) {
+  c = wave_reduce(c);
+  if (lane_id() == 0) tmp[wave_id()] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) { u32 t = 0; for (int i = 0; i < kWaves; i++) t += tmp[i]; counts[blockIdx.x] = t; }
+}
+__global__ __launch_bounds__(kBlock) void k_keep_count(const u32 *__restrict__ RU, u32 n, u32 chunk, u32 *counts) {
+  __shared__ u32 tmp[kWaves];
+  const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
+  u32 c = 0;
+  for (u32 p = begin + threadIdx.x; p < end; p += kBlock) c += keep_slot(RU, p) ? 1u : 0u;
+  block_count_store(c, tmp, counts);
+}
+__global__ __launch_bounds__(kBlock) void k_keep_write(const u32 *__restrict__ RU, u32 n, u32 chunk,
+                                                      const u32 *__restrict__ base_excl, u32 *__restrict__ Rp,
+                                                      u32 *__restrict__ kept) {
+  __shared__ u32 tmp[kWaves];
+  const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
+  u32 running = base_excl[blockIdx.x];
+  for (u32 tile = begin; tile < end; tile += kBlock) {
+    const u32 p = tile + threadIdx.x;
+    const bool f = (p < end) && keep_slot(RU, p);
+    u32 tot;
+    const u32 ex = block_excl_scan<kWaves>(f ? 1u : 0u, tmp, tot);
+    if (f) { const u32 v = RU[p]; Rp[running + ex] = v & ~kUniqBit; kept[running + ex] = p | (v & kUniqBit); }
+    running += tot;
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_discard_gather(const u32 *__restrict__ sap, u32 n,
+                                                          const u32 *__restrict__ kept, u32 *__restrict__ x) {
+  for (u32 r = blockIdx.x * kBlock + threadIdx.x; r < n; r += gridDim.x * kBlock) x[r] = kept[sap[r]];
+}
+__global__ __launch_bounds__(kBlock) void k_nonuniq_count(const u32 *__restrict__ x, u32 n, u32 chunk, u32 *counts) {
+  __shared__ u32 tmp[kWaves];
+  const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
+  u32 c = 0;
+  for (u32 i = begin + threadIdx.x; i < end; i += kBlock) c += (x[i] & kUniqBit) ? 0u : 1u;
+  block_count_store(c, tmp, counts);
+}
+__global__ __launch_bounds__(kBlock) void k_nonuniq_write(const u32 *__restrict__ x, u32 n, u32 chunk,
+                                                         const u32 *__restrict__ base_excl, u32 *__restrict__ pt) {
+  __shared__ u32 tmp[kWaves];
+  const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
+  u32 running = base_excl[blockIdx.x];
+  for (u32 tile = begin; tile < end; tile += kBlock) {
+    const u32 i = tile + threadIdx.x;
+    const bool f = (i < end) && !(x[i] & kUniqBit);
+    u32 tot;
+    const u32 ex = block_excl_scan<kWaves>(f ? 1u : 0u, tmp, tot);
+    if (f) pt[running + ex] = x[i];
+    running += tot;
+  }
+}
+// sslot[i] = slot | unique<<31 of the i-th entry of the level's sorted array
+__global__ __launch_bounds__(kBlock) void k_final_assign(const u32 *__restrict__ sslot, u32 n, u32 chunk,
+                                                        const u32 *__restrict__ base_excl,
+                                                        const u32 *__restrict__ pt, u32 *__restrict__ sa12,
+                                                        Rec8 *__restrict__ pairs) {
+  __shared__ u32 tmp[kWaves];
+  const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
+  u32 running = base_excl[blockIdx.x];
+  for (u32 tile = begin; tile < end; tile += kBlock) {
+    const u32 i = tile + threadIdx.x;
+    const u32 v = (i < end) ? sslot[i] : kUniqBit;
+    const bool nonu = (i < end) && !(v & kUniqBit);
+    u32 tot;
+    const u32 ex = block_excl_scan<kWaves>(nonu ? 1u : 0u, tmp, tot);
+    if (i < end) {
+      const u32 sl = nonu ? pt[running + ex] : (v & ~kUniqBit);
+      sa12[i] = sl;
+      pairs[i] = Rec8{sl, i + 1};
+    }
+    running += tot;
   }
 }
 

@@ -73,7 +73,7 @@ struct dc3hip_ctx {
   int merge_cfg = 3;
   bool no_small_ties = false;
   bool wide_names = false;
-  bool no_nine_bit = false, no_rec12 = false;
+  bool no_nine_bit = false, no_rec12 = false, no_discard = false;
   std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
   std::vector<PhaseMark> marks;
   hipEvent_t ev_build_a = nullptr, ev_build_b = nullptr;
@@ -108,7 +108,7 @@ static size_t arena_requirement(int64_t n) {
   int64_t m = n;
   for (int lvl = 0; lvl < DC3HIP_MAX_LEVELS && m >= 2; lvl++) {
     const int64_t m0 = (m + 2) / 3, m02 = m0 + m / 3;
-    const size_t keep = 3 * align_up((size_t)(m02 + 16) * 4, 256);
+    const size_t keep = 4 * align_up((size_t)(m02 + 16) * 4, 256);
     const size_t tbl = 2 * align_up((size_t)4 * 4096 * 256, 256);
     const size_t recs = 2 * align_up((size_t)m02 * 16, 256) + 2 * align_up((size_t)m02 * 8, 256) + tbl;
     const size_t after = 2 * align_up((size_t)m0 * 20, 256) + align_up((size_t)(m / 1024 + 16) * 4, 256) +
@@ -309,27 +309,38 @@ static int inverse_permute(dc3hip_ctx *c, Rec8 *a, Rec8 *b, u32 n, u32 *out, int
 //   unique names  -> sa12[i] = slot(pos_i), rank12 = inverse            (lib.rs:109-113)
 //   otherwise     -> R[slot(pos_i)] = name_i (+ zero tail), caller recurses (lib.rs:93-104)
 // ---------------------------------------------------------------------------------------------
+static constexpr double kDiscardMinDropInv = 6.0;  // discard when ~1/6 of the slots would leave the recursion
+
+template <class Sym>
+static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_rank, int depth);
+
+// mode: 0 = names unique, sa12/rank12 complete; 1 = R holds the names, caller recurses on R (lib.rs:104);
+//       2 = R holds name | unique<<31 and sslot the sorted slots: caller runs discard_recurse()
 template <class Acc>
-static int name_and_rank(dc3hip_ctx *c, Acc acc, u32 m02, u32 m0, u32 *sa12, u32 *rank12, u32 *R, u32 *names_out) {
+static int name_and_rank(dc3hip_ctx *c, Acc acc, u32 m02, u32 m0, u32 *sa12, u32 *rank12, u32 *R, u32 *sslot,
+                         u32 *names_out, int *mode) {
   const ArenaMark mk = arena_mark(c);
   const Chunking ck = make_chunks(c, m02, kBlock * kNameIPT);
   u32 *counts = nullptr;
   RC(arena_alloc(c, (size_t)ck.nchunks + 16, &counts));
   {
     PhaseScope ps(c, DC3HIP_PH_NAMING, m02);
-    hipLaunchKernelGGL((k_name_count<Acc>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, acc, m02, ck.chunk, counts);
+    HIPC(hipMemsetAsync(c->d_words + 4, 0, sizeof(u32), c->stream));
+    hipLaunchKernelGGL((k_name_count<Acc>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, acc, m02, ck.chunk, counts,
+                       c->d_words + 4);
     KCHECK();
     hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, counts, ck.nchunks, c->d_words);
     KCHECK();
-    HIPC(hipMemcpyAsync(c->h_words, c->d_words, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipMemcpyAsync(c->h_words, c->d_words, 5 * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
   }
   HIPC(hipStreamSynchronize(c->stream));     // the lib.rs:103 decision needs the name count
-  const u32 names = c->h_words[0];
+  const u32 names = c->h_words[0], uniq = c->h_words[4];
   *names_out = names;
   Rec8 *pa = nullptr, *pb = nullptr;
   RC(arena_alloc(c, (size_t)m02, &pa));
   RC(arena_alloc(c, (size_t)m02, &pb));
   if (names == m02) {
+    *mode = 0;
     {
       PhaseScope ps(c, DC3HIP_PH_RANKS, m02);
       hipLaunchKernelGGL((k_assign_unique<Acc>), dim3(grid_for(c, m02)), dim3(kBlock), 0, c->stream, acc, m02, m0,
@@ -338,16 +349,91 @@ static int name_and_rank(dc3hip_ctx *c, Acc acc, u32 m02, u32 m0, u32 *sa12, u32
     }
     RC(inverse_permute(c, pa, pb, m02, rank12, DC3HIP_PH_RANKS));
   } else {
+    // discard unique names from the recursion when enough slots would leave it to pay for the bookkeeping:
+    // a unique slot is dropped iff its predecessor is unique too, so about uniq^2/m02 slots go
+    const double drop_est = (double)uniq * (double)uniq / (double)m02;
+    const bool discard = sslot && !c->no_discard && m02 < 0x7fffffffu && drop_est * kDiscardMinDropInv >= (double)m02 &&
+                         c->arena_bytes - c->arena_off >= (size_t)m02 * 16 + (64u << 20);
+    *mode = discard ? 2 : 1;
     {
       PhaseScope ps(c, DC3HIP_PH_NAMING, m02);
       hipLaunchKernelGGL((k_name_assign<Acc>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, acc, m02, ck.chunk,
-                         counts, m0, pa);
+                         counts, m0, pa, discard ? sslot : (u32 *)nullptr);
       KCHECK();
     }
     RC(inverse_permute(c, pa, pb, m02, R, DC3HIP_PH_NAMING));
     hipLaunchKernelGGL(k_zero_tail, dim3(1), dim3(64), 0, c->stream, R, m02, 8u);
     KCHECK();
   }
+  arena_release(c, mk);
+  return E_OK;
+}
+
+// Discarding recursion: see dc3_kernels.cuh.  RU[p] = name | unique<<31 (slot order), sslot[i] =
+// slot | unique<<31 (sorted order).  Recurses on the reduced string only; fills sa12 and rank12.
+static int discard_recurse(dc3hip_ctx *c, const u32 *RU, const u32 *sslot, u32 m02, u32 names, u32 *sa12,
+                           u32 *rank12, int depth) {
+  const ArenaMark mk = arena_mark(c);
+  const Chunking ck = make_chunks(c, m02, kBlock);
+  u32 *counts = nullptr;
+  RC(arena_alloc(c, (size_t)ck.nchunks + 16, &counts));
+  u32 mp = 0;
+  {
+    PhaseScope ps(c, DC3HIP_PH_DISCARD, m02);
+    hipLaunchKernelGGL(k_keep_count, dim3(ck.nchunks), dim3(kBlock), 0, c->stream, RU, m02, ck.chunk, counts);
+    KCHECK();
+    hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, counts, ck.nchunks, c->d_words + 5);
+    KCHECK();
+    HIPC(hipMemcpyAsync(c->h_words + 5, c->d_words + 5, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPC(hipStreamSynchronize(c->stream));
+  mp = c->h_words[5];
+  c->stats.level_kept[depth] = mp;
+  if (mp == 0) { set_err("internal: discarding kept no slot"); return E_HIP; }
+  u32 *Rp = nullptr, *kept = nullptr, *sap = nullptr;
+  RC(arena_alloc(c, (size_t)mp + 16, &Rp));
+  RC(arena_alloc(c, (size_t)mp + 16, &kept));
+  RC(arena_alloc(c, (size_t)mp + 16, &sap));
+  {
+    PhaseScope ps(c, DC3HIP_PH_DISCARD, m02);
+    hipLaunchKernelGGL(k_keep_write, dim3(ck.nchunks), dim3(kBlock), 0, c->stream, RU, m02, ck.chunk, counts, Rp, kept);
+    KCHECK();
+    hipLaunchKernelGGL(k_zero_tail, dim3(1), dim3(64), 0, c->stream, Rp, mp, 8u);
+    KCHECK();
+  }
+  SymU32 RS; RS.s = Rp; RS.m = mp;
+  RC(dc3_level<SymU32>(c, RS, mp, names, sap, nullptr, depth + 1));   // m == 1 is the child's base case
+  u32 *x = nullptr, *pt = nullptr;
+  RC(arena_alloc(c, (size_t)mp + 16, &x));
+  RC(arena_alloc(c, (size_t)mp + 16, &pt));
+  {
+    PhaseScope ps(c, DC3HIP_PH_DISCARD, mp);
+    const Chunking ckp = make_chunks(c, mp, kBlock);
+    u32 *cnt2 = nullptr;
+    RC(arena_alloc(c, (size_t)ckp.nchunks + 16, &cnt2));
+    hipLaunchKernelGGL(k_discard_gather, dim3(grid_for(c, mp)), dim3(kBlock), 0, c->stream, sap, mp, kept, x);
+    KCHECK();
+    hipLaunchKernelGGL(k_nonuniq_count, dim3(ckp.nchunks), dim3(kBlock), 0, c->stream, x, mp, ckp.chunk, cnt2);
+    KCHECK();
+    hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, cnt2, ckp.nchunks, (u32 *)nullptr);
+    KCHECK();
+    hipLaunchKernelGGL(k_nonuniq_write, dim3(ckp.nchunks), dim3(kBlock), 0, c->stream, x, mp, ckp.chunk, cnt2, pt);
+    KCHECK();
+  }
+  Rec8 *pa = nullptr, *pb = nullptr;
+  RC(arena_alloc(c, (size_t)m02, &pa));
+  RC(arena_alloc(c, (size_t)m02, &pb));
+  {
+    PhaseScope ps(c, DC3HIP_PH_DISCARD, m02);
+    hipLaunchKernelGGL(k_nonuniq_count, dim3(ck.nchunks), dim3(kBlock), 0, c->stream, sslot, m02, ck.chunk, counts);
+    KCHECK();
+    hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, counts, ck.nchunks, (u32 *)nullptr);
+    KCHECK();
+    hipLaunchKernelGGL(k_final_assign, dim3(ck.nchunks), dim3(kBlock), 0, c->stream, sslot, m02, ck.chunk, counts, pt,
+                       sa12, pa);
+    KCHECK();
+  }
+  RC(inverse_permute(c, pa, pb, m02, rank12, DC3HIP_PH_RANKS));
   arena_release(c, mk);
   return E_OK;
 }
@@ -420,7 +506,7 @@ static int predict_tie_fraction(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u3
 // straight ordering: full-key records (12 bytes when the key fits 64 bits, else 16), LSD over all key bits
 template <class Sym, class Rec>
 static int order_straight(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u32 kbits, u32 *sa12, u32 *rank12,
-                          u32 *R, u32 *names) {
+                          u32 *R, u32 *sslot, u32 *names, int *mode) {
   Rec *recA = nullptr, *recB = nullptr, *sorted = nullptr;
   RC(arena_alloc(c, (size_t)m02, &recA));
   RC(arena_alloc(c, (size_t)m02, &recB));
@@ -433,12 +519,12 @@ static int order_straight(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u
   RC(radix_sort<Rec>(c, recA, recB, m02, 0, kbits, &sorted, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN,
                      DC3HIP_PH_SORT12_DOWN));
   AccRec<Rec> acc; acc.s = sorted;
-  return name_and_rank<AccRec<Rec>>(c, acc, m02, m0, sa12, rank12, R, names);
+  return name_and_rank<AccRec<Rec>>(c, acc, m02, m0, sa12, rank12, R, sslot, names, mode);
 }
 
 template <class Sym>
 static int order_hybrid(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u32 kbits, u32 *sa12,
-                        u32 *rank12, u32 *R, u32 *names, bool *ok, int depth) {
+                        u32 *rank12, u32 *R, u32 *sslot, u32 *names, int *mode, bool *ok, int depth) {
   *ok = false;
   const HiMap hm = make_himap((u64)b, kbits, m);
   Rec8 *ha = nullptr, *hb = nullptr, *h = nullptr;
@@ -504,7 +590,7 @@ static int order_hybrid(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u32
     }
   }
   AccHyb acc; acc.h = h; acc.f = f; acc.posmask = hm.pbits >= 32 ? 0xffffffffu : ((1u << hm.pbits) - 1u);
-  RC(name_and_rank<AccHyb>(c, acc, m02, m0, sa12, rank12, R, names));
+  RC(name_and_rank<AccHyb>(c, acc, m02, m0, sa12, rank12, R, sslot, names, mode));
   *ok = true;
   return E_OK;
 }
@@ -564,8 +650,11 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
     const u32 b = (u32)B;                          // packing base of make_rec (K < 2^31)
     u32 kbits = 0;                                 // bit width of B^3 - 1; > 32 here (else direct path)
     { unsigned __int128 mx = (unsigned __int128)B * B * B - 1; while (mx) { kbits++; mx >>= 1; } }
+    u32 *sslot = nullptr;                           // sorted slots, only used by the discarding recursion
+    RC(arena_alloc(c, (size_t)m02 + 16, &sslot));
     const ArenaMark mk1 = arena_mark(c);
     u32 names = 0;
+    int mode = 0;
     bool done = false;
     // ---- prefix-sort + tie-refine ordering when the N-bit key image separates most samples ------
     if (m02 >= kHybridMinSamples && !c->no_hybrid) {
@@ -574,20 +663,25 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
       c->stats.level_tie_pred[depth] = pred;
       if (pred < kHybridMaxPredicted) {
         bool ok = false;
-        RC(order_hybrid<Sym>(c, S, m, m0, m02, b, kbits, sa12, rank12, R, &names, &ok, depth));
+        RC(order_hybrid<Sym>(c, S, m, m0, m02, b, kbits, sa12, rank12, R, sslot, &names, &mode, &ok, depth));
         done = ok;
         if (!ok) arena_release(c, mk1);
       }
     }
     if (!done) {
       c->stats.level_sorted[depth] = 1;
-      if (kbits <= 64 && !c->no_rec12) RC((order_straight<Sym, Rec12>(c, S, m, m0, m02, b, kbits, sa12, rank12, R, &names)));
-      else RC((order_straight<Sym, Rec16>(c, S, m, m0, m02, b, kbits, sa12, rank12, R, &names)));
+      if (kbits <= 64 && !c->no_rec12)
+        RC((order_straight<Sym, Rec12>(c, S, m, m0, m02, b, kbits, sa12, rank12, R, sslot, &names, &mode)));
+      else
+        RC((order_straight<Sym, Rec16>(c, S, m, m0, m02, b, kbits, sa12, rank12, R, sslot, &names, &mode)));
     }
     arena_release(c, mk1);
-    if (names != m02) {
+    if (mode == 1) {
       SymU32 RS; RS.s = R; RS.m = m02;
       RC(dc3_level<SymU32>(c, RS, m02, names, sa12, rank12, depth + 1));   // lib.rs:104
+    } else if (mode == 2) {
+      c->stats.level_sorted[depth] += 2;                                    // 3 / 4 = straight / prefix-sort + discarding
+      RC(discard_recurse(c, R, sslot, m02, names, sa12, rank12, depth));
     }
   }
   {
@@ -760,6 +854,8 @@ int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) {
   c->no_hybrid = (nh && nh[0] == '1');
   const char *nst = getenv("DC3HIP_NO_SMALL_TIES");
   c->no_small_ties = (nst && nst[0] == '1');
+  const char *nd = getenv("DC3HIP_NO_DISCARD");
+  c->no_discard = (nd && nd[0] == '1');
   const char *n9 = getenv("DC3HIP_NO_9BIT");
   c->no_nine_bit = (n9 && n9[0] == '1');
   const char *n12 = getenv("DC3HIP_NO_REC12");

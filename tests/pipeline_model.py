@@ -5,6 +5,7 @@ It mirrors dc3_level() in dc3hip.hip step by step; kernels become numpy expressi
 TEST INFRASTRUCTURE ONLY."""
 import numpy as np
 
+DISCARD = True       # model of the "discarding" recursion (unique names leave the recursion), see dc3hip.hip
 WIDE_NAMES = False   # True = as many symbols per direct name as fit 31 bits (DC3HIP_WIDE_NAMES=1)
 
 
@@ -57,10 +58,33 @@ def level(S, m, K, trace=None, depth=0):
             sa12 = slot.copy()
             rank12 = np.zeros(m02, dtype=np.int64)
             rank12[slot] = np.arange(1, m02 + 1)
-        else:                                                  # k_name_assign + recursion
+        elif not DISCARD:                                      # k_name_assign + recursion
             R = np.zeros(m02, dtype=np.int64)
             R[slot] = names
             sa12, rank12 = level(R, m02, int(names[-1]), trace, depth + 1)
+        else:
+            # discarding: a sample with a unique name needs no further sorting (its rank is its index in
+            # the sorted array); it only stays in the recursive string when the slot before it is
+            # non-unique (it terminates the comparisons that start there).
+            uniq_sorted = flag.astype(bool) & np.concatenate([flag[1:].astype(bool), [True]])
+            R = np.zeros(m02, dtype=np.int64); U = np.zeros(m02, dtype=bool)
+            R[slot] = names; U[slot] = uniq_sorted
+            prevU = np.concatenate([[True], U[:-1]])           # slot 0 has no predecessor
+            keep = ~(U & prevU)
+            kept_pos = np.nonzero(keep)[0]
+            Rp = R[kept_pos]; mp = len(kept_pos)
+            if mp >= 2:
+                sap, _ = level(Rp, mp, int(names[-1]), trace, depth + 1)
+            else:
+                sap = np.zeros(mp, dtype=np.int64)
+            p_seq = kept_pos[sap]                               # kept slots in suffix order
+            p_t = p_seq[~U[p_seq]]                              # the non-unique ones, in order
+            nonuniq_idx = np.nonzero(~uniq_sorted)[0]           # their places in the sorted array
+            assert len(p_t) == len(nonuniq_idx)
+            sa12 = slot.copy()
+            sa12[nonuniq_idx] = p_t
+            rank12 = np.zeros(m02, dtype=np.int64)
+            rank12[sa12] = np.arange(1, m02 + 1)
     rk = np.concatenate([rank12, np.zeros(8, dtype=np.int64)])
     dummy = (m % 3) == 1
     # k_build_tuples (slot order): columns pos, r, c0, cx

@@ -52,3 +52,19 @@ def test_model_wide_names(oracle):
             assert pm.sufsort(bytes(tup)).tolist() == naive_sa(bytes(tup)).tolist()
     finally:
         pm.WIDE_NAMES = False
+
+
+def test_model_discarding_on_and_off(oracle, corpus):
+    """the discarding recursion and the plain K–S recursion give the same SA (deep-recursion inputs)"""
+    rng = np.random.default_rng(4)
+    block = rng.integers(97, 100, size=700, dtype=np.uint8).tobytes()
+    cases = [corpus["fuzz3"][0], corpus["crash-4f8c31dec8c3678a07e0fbacc6bd69e7cc9037fb"][0], b"ab" * 900 + b"c" + b"ab" * 300,
+             block * 3 + b"x" + block * 2, oracle.gen(6000, 3, 2).tobytes(), b"a" * 1500]
+    for data in cases:
+        want = oracle.sufsort(data).tolist()
+        for flag in (True, False):
+            pm.DISCARD = flag
+            try:
+                assert pm.sufsort(data).tolist() == want, (len(data), flag)
+            finally:
+                pm.DISCARD = True
