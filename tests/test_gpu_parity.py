@@ -402,6 +402,30 @@ def test_discarding_recursion_agrees_and_shrinks(ss, oracle, corpus):
             assert sum(res["0"]["level_n"]) < sum(res["1"]["level_n"])
 
 
+def test_property_random_structures(ss, oracle):
+    """hypothesis-driven: byte strings built from small alphabets, repeated blocks and runs — the GPU SA
+    equals the oracle's and passes sacabase::verify semantics (oracle.verify)."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+
+    alphabet = st.sampled_from([b"\x00", b"\xff", b"a", b"b", b"ab", b"\x00\xff", b"abc", bytes(range(7))])
+    piece = st.one_of(
+        st.binary(min_size=0, max_size=40),
+        st.builds(lambda a, k: a * k, alphabet, st.integers(0, 300)),
+        st.builds(lambda b, k: b * k, st.binary(min_size=1, max_size=12), st.integers(1, 60)),
+    )
+
+    @settings(max_examples=120, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(st.lists(piece, min_size=0, max_size=8))
+    def run(pieces):
+        data = b"".join(pieces)
+        got = gpu_sa(ss, data)
+        assert np.array_equal(got, oracle.sufsort(data)), data[:64]
+        if len(data) > 1:
+            assert oracle.verify(data, got) == -1
+
+    run()
+
+
 def test_config2_64mib_random_bit_exact(ss, oracle):
     """BASELINE.json configs[1]: 64 MiB random bytes, i32 SA, bit-exact vs divsufsort (full compare
     when the reference build travelled with the snapshot, GPU sufcheck always)."""

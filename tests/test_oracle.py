@@ -133,3 +133,11 @@ def test_search_restatement(oracle):
         sas = [oracle.sufsort(c) for c in chunks]
         for needle in (b"rather long", b"text. We can", b"We can probably find matches that span"):
             assert oracle.partitioned_search(text, sas, S, needle) == oracle.search(text, full, needle)
+
+
+def test_oracle_under_sanitizers():
+    """the C restatement over exact-size heap buffers under ASan + UBSan (CPU build only)"""
+    import subprocess
+    from conftest import ROOT
+    out = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "asan"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "asan_check: ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
