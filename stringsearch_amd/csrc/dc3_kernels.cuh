@@ -950,14 +950,25 @@ __device__ __forceinline__ bool sample_before(const Tup12 &a, const Tup0 &z) {
   return (a.c0 < z.c0) || (a.c0 == z.c0 && ((a.cx < z.c1) || (a.cx == z.c1 && a.r <= z.r2))); // leq3
 }
 
+// Merge-path split points: part[t] = number of A elements among the first t*tile outputs.
+// Two levels: `coarse` (optional) holds the split of every `ratio`-th tile boundary, which bounds the
+// binary search of the tiles in between to a window of ratio*tile elements (L2-resident, ~half the
+// dependent steps) — the unbounded search over 10^9 elements fetched 15 GB per build.
 __global__ __launch_bounds__(kBlock) void k_merge_partition(const Tup12 *__restrict__ A, u32 nA,
                                                            const Tup0 *__restrict__ B, u32 nB, u32 ntiles,
-                                                           u32 tile, u32 *__restrict__ part /*[ntiles+1]*/) {
+                                                           u32 tile, const u32 *__restrict__ coarse, u32 ratio,
+                                                           u32 *__restrict__ part /*[ntiles+1]*/) {
   const u32 t = blockIdx.x * kBlock + threadIdx.x;
   if (t > ntiles) return;
   const u32 total = nA + nB;
   const u32 diag = (u32)min((u64)t * tile, (u64)total);
   u32 lo = diag > nB ? diag - nB : 0u, hi = min(diag, nA);
+  if (coarse) {
+    const u32 cidx = t / ratio;
+    if (cidx * ratio == t) { part[t] = coarse[cidx]; return; }     // on a coarse boundary
+    lo = max(lo, coarse[cidx]);
+    hi = min(hi, coarse[cidx + 1]);
+  }
   while (lo < hi) {
     const u32 mid = (lo + hi) >> 1;
     if (sample_before(A[mid], B[diag - 1 - mid])) lo = mid + 1; else hi = mid;

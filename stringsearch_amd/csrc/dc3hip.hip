@@ -741,8 +741,16 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
     }
     {
       PhaseScope ps(c, DC3HIP_PH_MERGE, m);
+      // coarse split of every 16th tile boundary first, then the bounded per-tile searches
+      constexpr u32 kRatio = 16;
+      const u32 nco = (ntiles + kRatio - 1) / kRatio;              // coarse tiles of kRatio*tile outputs
+      u32 *coarse = nullptr;
+      RC(arena_alloc(c, (size_t)nco + 16, &coarse));
+      hipLaunchKernelGGL(k_merge_partition, dim3((nco + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
+                         t12 + dskip, nA, zs, nB, nco, tile * kRatio, (const u32 *)nullptr, 1u, coarse);
+      KCHECK();
       hipLaunchKernelGGL(k_merge_partition, dim3((ntiles + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
-                         t12 + dskip, nA, zs, nB, ntiles, tile, part);
+                         t12 + dskip, nA, zs, nB, ntiles, tile, (const u32 *)coarse, kRatio, part);
       KCHECK();
       switch (cfg) {
         case 0: RC((launch_merge<256, 4>(c, ntiles, t12 + dskip, nA, zs, nB, part, out_sa, pa))); break;
