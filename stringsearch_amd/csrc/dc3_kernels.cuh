@@ -970,7 +970,7 @@ __global__ __launch_bounds__(kBlock) void k_merge_partition(const Tup12 *__restr
     hi = min(hi, coarse[cidx + 1]);
   }
   while (lo < hi) {
-    const u32 mid = (lo + hi) >> 1;
+    const u32 mid = lo + ((hi - lo) >> 1);     // (lo + hi) would overflow u32 beyond 2^31 samples
     if (sample_before(A[mid], B[diag - 1 - mid])) lo = mid + 1; else hi = mid;
   }
   part[t] = lo;
@@ -1017,7 +1017,7 @@ __global__ __launch_bounds__(NT) void k_merge(const Tup12 *__restrict__ A, u32 n
   const u32 dl = min(threadIdx.x * (u32)VT, na + nb);
   u32 lo = dl > nb ? dl - nb : 0u, hi = min(dl, na);
   while (lo < hi) {
-    const u32 mid = (lo + hi) >> 1;
+    const u32 mid = lo + ((hi - lo) >> 1);     // (lo + hi) would overflow u32 beyond 2^31 samples
     if (sample_before4(sa[mid], sbk[dl - 1 - mid])) lo = mid + 1; else hi = mid;
   }
   u32 ai = lo, bi = dl - lo;

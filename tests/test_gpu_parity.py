@@ -476,3 +476,15 @@ def test_beyond_2pow31_needs_64bit_indices(ss):
     from stringsearch_amd._lib import Opts
     o = Opts(ctypes.sizeof(Opts), 32, -1, 0, 0)
     assert ss.lib().dc3hip_sufsort_ex(t.ctypes.data, sa.ctypes.data, (1 << 31) + 5, ctypes.byref(o)) == -4
+
+
+def test_sample_count_beyond_2pow31(ss):
+    """3.4e9 random bytes: more than 2^31 sample suffixes at level 0 (merge-path midpoints, window partition with
+    > 512 top buckets, 32-bit position fields completely used).  Regression test for a u32 midpoint overflow
+    that only showed above 3.2e9 bytes."""
+    n = 3_400_000_000
+    with ss.Context(n) as c:
+        c.generate(n, 9, 0)
+        c.build()
+        assert c.sufcheck() == 0
+        assert c.stats()["level_n"][1] > (1 << 31)
