@@ -488,3 +488,21 @@ def test_sample_count_beyond_2pow31(ss):
         c.build()
         assert c.sufcheck() == 0
         assert c.stats()["level_n"][1] > (1 << 31)
+
+
+def test_boundary_sizes_sufcheck(ss):
+    """Sizes that put n, m02 or a child length on the boundaries of the size-dependent machinery (2^14-entry
+    inversion windows, 2^22-pair partition segments, radix / merge tiles), all generator kinds, GPU sufcheck."""
+    sizes = set()
+    for w in (1 << 14, 1 << 22, 8192, 12288, 6144, 2048):
+        for mult in (1, 2, 3, 5):
+            for d in (-1, 0, 1):
+                base = w * mult + d
+                for s in (base, base * 3 // 2, base * 3, base * 9 // 4):
+                    if 3 <= s <= 60_000_000:
+                        sizes.add(int(s))
+    with ss.Context(60_000_000) as c:
+        for k, n in enumerate(sorted(sizes)):
+            c.generate(n, 77 + k, k % 3)
+            c.build()
+            assert c.sufcheck() == 0, n
