@@ -1,0 +1,179 @@
+// dc3_aux.cuh — synthetic text generator, GPU sufcheck, checksum, BWT, batched search.
+// Part of the gfx950 kernel set of libdc3hip (see dc3_kernels.cuh for the overview); all files share
+// namespace dc3 and are included in this order by dc3_kernels.cuh.
+#pragma once
+
+namespace dc3 {
+
+// ---------------------------------------------------------------------------------------------
+// Synthetic text generator: byte i = byte (i&7) of splitmix64(seed + (i>>3)).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 splitmix64(u64 x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+// kind 2: low-entropy text with deep LCPs (position-addressable): 16-byte
+// cells "word1 word2.." from a 4096-word vocabulary with a skewed id distribution, newline every
+// 80 bytes, and every 64 KiB block starts with probability 1/2 with a 1-8 KiB copy of an earlier span.
+__device__ __forceinline__ uint8_t text_base(u64 i, u64 seed) {
+  const u64 cell = i >> 4; const u32 off = (u32)(i & 15);
+  if (cell % 5 == 4 && off == 15) return '\n';
+  const u64 hc = splitmix64(seed + cell * 0x9E3779B97F4A7C15ull);
+  const u64 a = hc & 0xFFFF, b = (hc >> 16) & 0xFFFF, c = (hc >> 32) & 0xFFFF;
+  const u64 wid = (((a * b) >> 16) * c) >> 20;
+  const u64 hw = splitmix64(0x5EEDull ^ (wid << 1));
+  const u32 wlen = 2 + (u32)(hw % 11);
+  if (off < wlen) return (uint8_t)('a' + ((hw >> (8 + 4 * off)) % 26));
+  if (off == wlen) return ' ';
+  const u64 wid2 = (((hc >> 48) & 0xFFF) * ((hc >> 40) & 0xFF)) >> 8;
+  const u64 hw2 = splitmix64(0x5EEDull ^ (wid2 << 1));
+  const u32 wlen2 = 2 + (u32)(hw2 % 11), o2 = off - wlen - 1;
+  if (o2 < wlen2) return (uint8_t)('a' + ((hw2 >> (8 + 4 * o2)) % 26));
+  return ' ';
+}
+__device__ __forceinline__ uint8_t text_byte(u64 i, u64 seed) {
+  const u64 block = i >> 16, within = i & 0xFFFF;
+  if (block > 0) {
+    const u64 hb = splitmix64((seed ^ 0xB10Cull) + block * 0xD1B54A32D192ED03ull);
+    if (hb & 1) {
+      const u64 len = 1024 + ((hb >> 8) % 7169);
+      if (within < len) {
+        const u64 sb = (hb >> 24) % block, so = (hb >> 44) % (65536 - 8192);
+        return text_base(sb * 65536 + so + within, seed);
+      }
+    }
+  }
+  return text_base(i, seed);
+}
+__device__ __forceinline__ uint8_t gen_byte(u64 gi, u64 seed, int kind) {
+  if (kind == 2) return text_byte(gi, seed);
+  if (kind == 0) return (uint8_t)(splitmix64(seed + (gi >> 3)) >> (8 * (gi & 7)));
+  const u32 code = (u32)(splitmix64(seed + (gi >> 5)) >> (2 * (gi & 31))) & 3u;
+  return code == 0 ? 'A' : code == 1 ? 'C' : code == 2 ? 'G' : 'T';
+}
+// t[i] = byte (off+i) of the stream; one thread per 8 output bytes, 8-byte stores
+__global__ __launch_bounds__(kBlock) void k_generate(uint8_t *t, u64 n, u64 seed, int kind, u64 off) {
+  const u64 nw = (n + 7) / 8;
+  for (u64 wi = blockIdx.x * (u64)kBlock + threadIdx.x; wi < nw; wi += (u64)gridDim.x * kBlock) {
+    u64 v = 0;
+    if (kind == 0 && (off & 7) == 0) {
+      v = splitmix64(seed + ((off + wi * 8) >> 3));
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; j++) v |= (u64)gen_byte(off + wi * 8 + j, seed, kind) << (8 * j);
+    }
+    if (wi * 8 + 8 <= n) *reinterpret_cast<u64 *>(t + wi * 8) = v;
+    else for (u64 j = wi * 8; j < n; j++) t[j] = (uint8_t)(v >> (8 * (j & 7)));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GPU verifier = sufcheck() of crates/cdivsufsort/c-sources/utils.c:160-241 restated as parallel
+// passes (equivalently sacabase::verify, sacabase/src/lib.rs:127-149).  With ISA = inverse of SA:
+//   (1) range + permutation: every SA[i] in [0,n) and ISA is a bijection        (-2)
+//   (2) first characters non-decreasing                                          (-3)
+//   (3) for T[SA[i]] == T[SA[i+1]]: rank of suffix SA[i]+1 < rank of suffix SA[i+1]+1, the end
+//       of text ranking lowest                                                   (-4)
+// (1)-(3) hold iff SA is the suffix array.  err receives the smallest failing code seen
+// (as in sufcheck, -2 is reported before -3 before -4).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_check_fill(const u32 *__restrict__ sa, u32 n, u32 *__restrict__ isa,
+                                                      int *err) {
+  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const u32 p = sa[i];
+    if (p >= n) { atomicMax(err, 3); continue; }   // code = -(5 - v): 3 -> -2
+    isa[p] = i + 1;
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_check_order(const uint8_t *__restrict__ t, const u32 *__restrict__ sa,
+                                                       const u32 *__restrict__ isa, u32 n, int *err) {
+  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const u32 p = sa[i];
+    if (p >= n) continue;
+    if (isa[p] != i + 1) { atomicMax(err, 3); continue; }   // not a permutation
+    if (i + 1 >= n) continue;
+    const u32 q = sa[i + 1];
+    if (q >= n) continue;
+    const uint8_t cp = t[p], cq = t[q];
+    if (cp > cq) { atomicMax(err, 2); continue; }           // -3
+    if (cp == cq) {
+      const u32 rp = (p + 1 < n) ? isa[p + 1] : 0u;
+      const u32 rq = (q + 1 < n) ? isa[q + 1] : 0u;
+      if (!(rp < rq)) atomicMax(err, 1);                    // -4
+    }
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_checksum(const u32 *__restrict__ sa, u32 n, u64 *out) {
+  u64 acc = 0;
+  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+    acc += splitmix64(((u64)i << 32) | sa[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane_id() == 0) atomicAdd((unsigned long long *)out, (unsigned long long)acc);
+}
+// ---------------------------------------------------------------------------------------------
+// By-products of the suffix array ("next" rows of the scope table).
+// BWT: bw_transform()/divbwt() of crates/cdivsufsort/c-sources (utils.c:53-108, divsufsort.c:372-405):
+//   U[0] = T[n-1]; then T[SA[i]-1] for every i with SA[i] != 0, in order; primary index = (i: SA[i]==0) + 1
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_find_zero(const u32 *__restrict__ sa, u32 n, u32 *zpos) {
+  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) if (sa[i] == 0) *zpos = i;
+}
+__global__ __launch_bounds__(kBlock) void k_bwt(const uint8_t *__restrict__ t, const u32 *__restrict__ sa, u32 n,
+                                               const u32 *__restrict__ zpos, uint8_t *__restrict__ u) {
+  const u32 z = *zpos;
+  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    if (i == z) continue;
+    const uint8_t ch = t[sa[i] - 1];
+    u[i < z ? i + 1 : i] = ch;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) u[0] = t[n - 1];
+}
+
+// Batched search = sacabase::longest_substring_match (crates/sacabase/src/lib.rs:39-99), one thread
+// per needle, the reference's own narrowing loop (mid = len/2; needle > suffix(mid) ? right : left
+// inclusive; 1-2 survivors compared by common prefix) so that (start, len) are identical.
+__device__ __forceinline__ u32 d_common_prefix(const uint8_t *a, u64 la, const uint8_t *b, u64 lb) {
+  const u64 l = la < lb ? la : lb;
+  u64 i = 0;
+  while (i < l && a[i] == b[i]) i++;
+  return (u32)i;
+}
+__global__ __launch_bounds__(kBlock) void k_search(const uint8_t *__restrict__ t, u32 n, const u32 *__restrict__ sa,
+                                                  const uint8_t *__restrict__ needles,
+                                                  const int64_t *__restrict__ off, u32 q,
+                                                  int64_t *__restrict__ out_start, int64_t *__restrict__ out_len) {
+  const u32 id = blockIdx.x * kBlock + threadIdx.x;
+  if (id >= q) return;
+  const uint8_t *nd = needles + off[id];
+  const u64 nl = (u64)(off[id + 1] - off[id]);
+  u32 lo = 0, len = n;
+  for (;;) {
+    if (len == 1) {
+      const u32 s = sa[lo];
+      out_start[id] = s; out_len[id] = d_common_prefix(t + s, n - s, nd, nl);
+      return;
+    }
+    if (len == 2) {
+      const u32 s0 = sa[lo], s1 = sa[lo + 1];
+      const u32 x = d_common_prefix(t + s0, n - s0, nd, nl), y = d_common_prefix(t + s1, n - s1, nd, nl);
+      if (x > y) { out_start[id] = s0; out_len[id] = x; } else { out_start[id] = s1; out_len[id] = y; }
+      return;
+    }
+    const u32 mid = len / 2;
+    const u32 s = sa[lo + mid];
+    const u64 sl = n - s;
+    const u32 c = d_common_prefix(t + s, sl, nd, nl);
+    // needle > suffix: first differing byte larger, or suffix is a proper prefix of the needle
+    const bool gt = (c < nl && c < sl) ? (nd[c] > t[s + c]) : (nl > sl);
+    if (gt) { lo += mid; len -= mid; } else { len = mid + 1; }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_widen(const u32 *__restrict__ in, int64_t *__restrict__ out, u32 n) {
+  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) out[i] = (int64_t)in[i];
+}
+
+}  // namespace dc3

@@ -1,0 +1,202 @@
+// dc3_merge.cuh — merge tuples, gather, fused mod-0 selection, merge-path merge.
+// Part of the gfx950 kernel set of libdc3hip (see dc3_kernels.cuh for the overview); all files share
+// namespace dc3 and are included in this order by dc3_kernels.cuh.
+#pragma once
+
+namespace dc3 {
+
+// ---------------------------------------------------------------------------------------------
+// Merge tuples.  Built in slot order with coalesced reads of S and rank (thread g owns text
+// positions 3g..3g+2), then gathered into SA12 order — one 16-byte gather per sample suffix
+// instead of the 4-6 scattered reads per output of lib.rs:136-162.
+// rank = 1-based rank of sample suffixes in slot order, with >= 3 zero words after rank[m02-1].
+// ---------------------------------------------------------------------------------------------
+template <class Sym>
+__global__ __launch_bounds__(kBlock) void k_build_tuples(Sym S, u32 m, u32 m0, u32 m02,
+                                                        const u32 *__restrict__ rank, Tup12 *__restrict__ tslot) {
+  const bool dummy = (m % 3) == 1;
+  __shared__ uint16_t lcode[256];
+  S.stage(lcode);
+  for (u32 g = blockIdx.x * kBlock + threadIdx.x; g < m0; g += gridDim.x * kBlock) {
+    const u32 j = 3 * g;
+    u32 q[4]; S.get4(j, lcode, q);
+    const u32 s0 = q[0], s1 = q[1], s2 = q[2], s3 = q[3];
+    // mod-1 sample at j+1 (slot g); exists for all g < m0 (dummy when j+1 == m)
+    Tup12 a;
+    a.pos = j + 1; a.c0 = s1; a.cx = s0;
+    a.r = (j + 2 < m) ? rank[m0 + g] : 0u;                       // rank of suffix j+2 (mod 2)
+    tslot[g] = a;
+    if (j + 2 < m) {                                            // mod-2 sample at j+2 (slot m0+g)
+      Tup12 c;
+      c.pos = j + 2; c.c0 = s2; c.cx = s3;
+      const bool has = (j + 4 < m) || (dummy && j + 4 == m);    // suffix j+4 is mod 1, slot g+1
+      c.r = has ? rank[g + 1] : 0u;
+      tslot[m0 + g] = c;
+    }
+  }
+}
+// Block b gathers the contiguous chunk [b*chunk, (b+1)*chunk) and also histograms, for its mod-1
+// entries, the low key byte of the mod-0 tuple each of them yields (c_prev - 1): that is the
+// up-sweep of the fused "select mod-0 + first radix pass" below, for free.
+__global__ __launch_bounds__(kBlock) void k_gather_tuples(const Tup12 *__restrict__ tslot,
+                                                         const u32 *__restrict__ sa12, u32 n, u32 chunk,
+                                                         u32 nchunks, Tup12 *__restrict__ out,
+                                                         u32 *__restrict__ table /*[256][nchunks]*/) {
+  __shared__ u32 hist[kWaves][256];
+#pragma unroll
+  for (int w = 0; w < kWaves; w++) hist[w][threadIdx.x] = 0;
+  __syncthreads();
+  u32 *myh = hist[wave_id()];
+  const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
+  u32 i = begin + threadIdx.x;
+  // the index stream and the output stream are touched once: non-temporal
+  typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 *tv = reinterpret_cast<const u32x4 *>(tslot);
+  u32x4 *ov = reinterpret_cast<u32x4 *>(out);
+  // 4 independent 16-byte gathers in flight per thread;  .x = pos, .w = cx
+  for (; i + 3 * kBlock < end; i += 4 * kBlock) {
+    const u32 s0 = __builtin_nontemporal_load(&sa12[i]), s1 = __builtin_nontemporal_load(&sa12[i + kBlock]);
+    const u32 s2 = __builtin_nontemporal_load(&sa12[i + 2 * kBlock]), s3 = __builtin_nontemporal_load(&sa12[i + 3 * kBlock]);
+    const u32x4 a = tv[s0], b = tv[s1], c = tv[s2], d = tv[s3];
+    __builtin_nontemporal_store(a, &ov[i]); __builtin_nontemporal_store(b, &ov[i + kBlock]);
+    __builtin_nontemporal_store(c, &ov[i + 2 * kBlock]); __builtin_nontemporal_store(d, &ov[i + 3 * kBlock]);
+    if (a.x % 3 == 1) atomicAdd(&myh[(a.w - 1u) & 255u], 1u);
+    if (b.x % 3 == 1) atomicAdd(&myh[(b.w - 1u) & 255u], 1u);
+    if (c.x % 3 == 1) atomicAdd(&myh[(c.w - 1u) & 255u], 1u);
+    if (d.x % 3 == 1) atomicAdd(&myh[(d.w - 1u) & 255u], 1u);
+  }
+  for (; i < end; i += kBlock) {
+    const u32x4 a = tv[sa12[i]]; ov[i] = a;
+    if (a.x % 3 == 1) atomicAdd(&myh[(a.w - 1u) & 255u], 1u);
+  }
+  __syncthreads();
+  u32 sum = 0;
+#pragma unroll
+  for (int w = 0; w < kWaves; w++) sum += hist[w][threadIdx.x];
+  table[threadIdx.x * nchunks + blockIdx.x] = sum;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Step 2 (lib.rs:118-125): order-preserving selection of the mod-1 entries of SA12; each yields
+// the mod-0 suffix one position to the left, already ordered by rank of suffix j+1.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool is_mod1(u32 pos) { return pos % 3 == 1; }
+
+// Loader of the fused Step-2 pass: element i of the sorted sample tuples yields a mod-0 tuple iff it
+// is a mod-1 suffix; r1 = i+1 is the rank of suffix j+1, so the stream is already ordered by it.
+struct Mod0Loader {
+  const Tup12 *t;
+  __device__ __forceinline__ bool load(u32 i, Tup0 &z) const {
+    const Tup12 a = t[i];
+    if (!is_mod1(a.pos)) return false;
+    z.pos = a.pos - 1; z.c0 = a.cx; z.c1 = a.c0; z.r1 = i + 1; z.r2 = a.r;
+    return true;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Step 3 (lib.rs:131-192): merge of SA12 and SA0 as a merge-path merge.
+// Comparator = leq2 / leq3 of lib.rs:3-11 in Kärkkäinen–Sanders argument order (the reference's
+// leq3 parameter list is scrambled, lib.rs:9 vs :154-161).  Suffixes are distinct, so < == <=.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool sample_before(const Tup12 &a, const Tup0 &z) {
+  if (is_mod1(a.pos)) return (a.c0 < z.c0) || (a.c0 == z.c0 && a.r <= z.r1);               // leq2
+  return (a.c0 < z.c0) || (a.c0 == z.c0 && ((a.cx < z.c1) || (a.cx == z.c1 && a.r <= z.r2))); // leq3
+}
+
+// Merge-path split points: part[t] = number of A elements among the first t*tile outputs.
+// Two levels: `coarse` (optional) holds the split of every `ratio`-th tile boundary, which bounds the
+// binary search of the tiles in between to a window of ratio*tile elements (L2-resident, ~half the
+// dependent steps) — the unbounded search over 10^9 elements fetched 15 GB per build.
+__global__ __launch_bounds__(kBlock) void k_merge_partition(const Tup12 *__restrict__ A, u32 nA,
+                                                           const Tup0 *__restrict__ B, u32 nB, u32 ntiles,
+                                                           u32 tile, const u32 *__restrict__ coarse, u32 ratio,
+                                                           u32 *__restrict__ part /*[ntiles+1]*/) {
+  const u32 t = blockIdx.x * kBlock + threadIdx.x;
+  if (t > ntiles) return;
+  const u32 total = nA + nB;
+  const u32 diag = (u32)min((u64)t * tile, (u64)total);
+  u32 lo = diag > nB ? diag - nB : 0u, hi = min(diag, nA);
+  if (coarse) {
+    const u32 cidx = t / ratio;
+    if (cidx * ratio == t) { part[t] = coarse[cidx]; return; }     // on a coarse boundary
+    lo = max(lo, coarse[cidx]);
+    hi = min(hi, coarse[cidx + 1]);
+  }
+  while (lo < hi) {
+    const u32 mid = lo + ((hi - lo) >> 1);     // (lo + hi) would overflow u32 beyond 2^31 samples
+    if (sample_before(A[mid], B[diag - 1 - mid])) lo = mid + 1; else hi = mid;
+  }
+  part[t] = lo;
+}
+
+// out_sa[k] = text position of the k-th smallest suffix (coalesced); out_pairs[k] = (pos, k+1) feeds
+// the windowed inversion that gives the parent level rank[pos] = k+1 (R[SA12[i]] = i+1, lib.rs:106-108).
+// NT threads, VT outputs per thread; the tile's inputs are staged in LDS, outputs are staged in LDS
+// too so that global stores are coalesced.
+// LDS image of a tile: sample tuples as 16-byte words (pos, r, c0, cx); mod-0 tuples split into a
+// 16-byte comparison key (c0, c1, r1, r2) and a separate pos array, so that every comparison is two
+// ds_read_b128 (the packed 20-byte Tup0 would be five ds_read_b32).
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bool sample_before4(const u32x4 a /*pos,r,c0,cx*/, const u32x4 z /*c0,c1,r1,r2*/) {
+  if (is_mod1(a.x)) return (a.z < z.x) || (a.z == z.x && a.y <= z.z);                                   // leq2
+  return (a.z < z.x) || (a.z == z.x && ((a.w < z.y) || (a.w == z.y && a.y <= z.w)));                    // leq3
+}
+template <int NT, int VT>
+struct MergeSmem { static constexpr size_t kBytes = (16 + 16 + 4) * (size_t)(NT * VT) + 64; };
+
+template <int NT, int VT>
+__global__ __launch_bounds__(NT) void k_merge(const Tup12 *__restrict__ A, u32 nA, const Tup0 *__restrict__ B, u32 nB,
+                                             const u32 *__restrict__ part, u32 *__restrict__ out_sa,
+                                             Rec8 *__restrict__ out_pairs) {
+  constexpr u32 kTile = NT * VT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32x4 *sa = reinterpret_cast<u32x4 *>(smem);
+  u32x4 *sbk = reinterpret_cast<u32x4 *>(smem + 16 * kTile);
+  u32 *sbpos = reinterpret_cast<u32 *>(smem + 32 * kTile);
+  const u32 total = nA + nB;
+  const u32 d0 = blockIdx.x * kTile;
+  const u32 d1 = min(d0 + kTile, total);
+  const u32 a0 = part[blockIdx.x], a1 = part[blockIdx.x + 1];
+  const u32 b0 = d0 - a0, b1 = d1 - a1;
+  const u32 na = a1 - a0, nb = b1 - b0;
+  const u32x4 *Av = reinterpret_cast<const u32x4 *>(A);
+  for (u32 i = threadIdx.x; i < na; i += NT) sa[i] = Av[a0 + i];
+  for (u32 i = threadIdx.x; i < nb; i += NT) {
+    const Tup0 z = B[b0 + i];
+    u32x4 k; k.x = z.c0; k.y = z.c1; k.z = z.r1; k.w = z.r2;
+    sbk[i] = k; sbpos[i] = z.pos;
+  }
+  __syncthreads();
+  const u32 dl = min(threadIdx.x * (u32)VT, na + nb);
+  u32 lo = dl > nb ? dl - nb : 0u, hi = min(dl, na);
+  while (lo < hi) {
+    const u32 mid = lo + ((hi - lo) >> 1);     // (lo + hi) would overflow u32 beyond 2^31 samples
+    if (sample_before4(sa[mid], sbk[dl - 1 - mid])) lo = mid + 1; else hi = mid;
+  }
+  u32 ai = lo, bi = dl - lo;
+  u32 outp[VT];
+#pragma unroll
+  for (int v = 0; v < VT; v++) {
+    const u32 k = dl + v;
+    outp[v] = 0;
+    if (k < na + nb) {
+      const bool takeA = (bi >= nb) || (ai < na && sample_before4(sa[ai], sbk[bi]));
+      outp[v] = takeA ? sa[ai].x : sbpos[bi];
+      ai += takeA ? 1u : 0u; bi += takeA ? 0u : 1u;
+    }
+  }
+  __syncthreads();                       // inputs are dead: reuse the front of LDS as the output stage
+  u32 *so = reinterpret_cast<u32 *>(smem);
+#pragma unroll
+  for (int v = 0; v < VT; v++) so[threadIdx.x * VT + v] = outp[v];
+  __syncthreads();
+  const u32 nout = d1 - d0;
+  for (u32 q = threadIdx.x; q < nout; q += NT) {
+    const u32 pos = so[q];
+    if (out_sa) out_sa[d0 + q] = pos;
+    if (out_pairs) out_pairs[d0 + q] = Rec8{pos, d0 + q + 1};
+  }
+}
+
+}  // namespace dc3

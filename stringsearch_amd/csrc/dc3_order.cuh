@@ -1,0 +1,423 @@
+// dc3_order.cuh — naming, windowed inverse permutation, discarding recursion, prefix-sort + tie-refine.
+// Part of the gfx950 kernel set of libdc3hip (see dc3_kernels.cuh for the overview); all files share
+// namespace dc3 and are included in this order by dc3_kernels.cuh.
+#pragma once
+
+namespace dc3 {
+
+// ---------------------------------------------------------------------------------------------
+// Naming (lib.rs:80-100): name = 1 + number of key changes before i in the sorted order.
+// The kernels are generic over an accessor of the sorted sample order:
+//   AccRec<Rec16|Rec12> : fully sorted records (straight LSD path)
+//   AccHyb   : (pos, "differs from predecessor" byte) arrays of the prefix-sort + tie-refine path
+//   k_name_count  : per-chunk count of "key differs from predecessor" flags
+//   (scan of the counts, total = number of distinct names)
+//   k_name_assign : emits (slot(pos_i), name_i) pairs      (R[..] = name, lib.rs:93-98)
+//   k_assign_unique: when every name is unique (lib.rs:109-113), SA12[i] = slot(pos_i) and the
+//                    pairs (slot(pos_i), i+1)
+// The pairs go through the windowed inversion (k_invperm_local) instead of a random scatter.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool key_neq(const Rec16 &a, const Rec16 &b) {
+  return (a.k0 != b.k0) | (a.k1 != b.k1) | (a.k2 != b.k2);
+}
+__device__ __forceinline__ bool key_neq(const Rec12 &a, const Rec12 &b) { return (a.k0 != b.k0) | (a.k1 != b.k1); }
+__device__ __forceinline__ u32 slot_of(u32 pos, u32 m0) {
+  const u32 q = pos / 3, rem = pos - 3 * q;
+  return rem == 1 ? q : q + m0;
+}
+template <class Rec>
+struct AccRec {
+  const Rec *s;
+  __device__ __forceinline__ u32 pos(u32 i) const { return s[i].pos; }
+  __device__ __forceinline__ u32 neq(u32 i) const {
+    if (i == 0) return 1u;
+    const Rec a = s[i], b = s[i - 1];
+    return key_neq(a, b) ? 1u : 0u;
+  }
+};
+struct AccHyb {
+  const Rec8 *h; const uint8_t *f; u32 posmask;   // pos = low bits of h[i].val; f[i] = 1 iff key(i) != key(i-1)
+  __device__ __forceinline__ u32 pos(u32 i) const { return h[i].val & posmask; }
+  __device__ __forceinline__ u32 neq(u32 i) const { return f[i]; }
+};
+
+constexpr int kNameIPT = 4;
+// a name is unique iff its key differs from both neighbours in the sorted order
+template <class Acc>
+__device__ __forceinline__ u32 acc_unique(const Acc &acc, u32 i, u32 n) {
+  return (acc.neq(i) && (i + 1 == n || acc.neq(i + 1))) ? 1u : 0u;
+}
+template <class Acc>
+__global__ __launch_bounds__(kBlock) void k_name_count(Acc acc, u32 n, u32 chunk, u32 *counts, u32 *uniq_total) {
+  __shared__ u32 tmp[kWaves], tmpu[kWaves];
+  const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
+  u32 c = 0, u = 0;
+  for (u32 i = begin + threadIdx.x; i < end; i += kBlock) { c += acc.neq(i); u += acc_unique(acc, i, n); }
+  c = wave_reduce(c); u = wave_reduce(u);
+  if (lane_id() == 0) { tmp[wave_id()] = c; tmpu[wave_id()] = u; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u32 t = 0, tu = 0;
+    for (int i = 0; i < kWaves; i++) { t += tmp[i]; tu += tmpu[i]; }
+    counts[blockIdx.x] = t;
+    if (tu) atomicAdd(uniq_total, tu);
+  }
+}
+// sslot (optional, discarding recursion): sslot[i] = slot(pos_i) | unique_i << 31, and the pair value
+// carries the same unique bit (names < 2^31 on that path).
+constexpr u32 kUniqBit = 0x80000000u;
+template <class Acc>
+__global__ __launch_bounds__(kBlock) void k_name_assign(Acc acc, u32 n, u32 chunk, const u32 *__restrict__ base_excl,
+                                                       u32 m0, Rec8 *__restrict__ pairs, u32 *__restrict__ sslot) {
+  __shared__ u32 tmp[kWaves];
+  const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
+  u32 running = base_excl[blockIdx.x];
+  constexpr u32 kTile = kBlock * kNameIPT;
+  for (u32 tile = begin; tile < end; tile += kTile) {
+    const u32 i0 = tile + threadIdx.x * kNameIPT;
+    u32 f[kNameIPT];
+    u32 local = 0;
+#pragma unroll
+    for (int j = 0; j < kNameIPT; j++) { f[j] = (i0 + j < end) ? acc.neq(i0 + j) : 0u; local += f[j]; }
+    u32 tot;
+    u32 name = running + block_excl_scan<kWaves>(local, tmp, tot);
+#pragma unroll
+    for (int j = 0; j < kNameIPT; j++) {
+      if (i0 + j < end) {
+        name += f[j];
+        const u32 sl = slot_of(acc.pos(i0 + j), m0);
+        if (sslot) {
+          const u32 ub = acc_unique(acc, i0 + j, n) ? kUniqBit : 0u;
+          sslot[i0 + j] = sl | ub;
+          pairs[i0 + j] = Rec8{sl, name | ub};
+        } else {
+          pairs[i0 + j] = Rec8{sl, name};
+        }
+      }
+    }
+    running += tot;
+  }
+}
+// Emits (slot, i+1) pairs (coalesced) for the windowed inversion below instead of scattering 4-byte
+// ranks: random 4-byte stores run at ~25 G/s on MI355X (profiles/r01_membench_access_patterns.txt),
+// a partition by destination window + LDS-local placement is > 2x faster.
+template <class Acc>
+__global__ __launch_bounds__(kBlock) void k_assign_unique(Acc acc, u32 n, u32 m0, u32 *__restrict__ sa12,
+                                                         Rec8 *__restrict__ pairs) {
+  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const u32 sl = slot_of(acc.pos(i), m0);
+    sa12[i] = sl;
+    pairs[i] = Rec8{sl, i + 1};
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Discarding recursion (Dementiev/Kärkkäinen/Mehnert/Sanders' refinement of lib.rs:103-108).
+// A sample whose name is unique needs no further sorting — its rank is its index in the sorted
+// array — and a comparison of two suffixes of R stops at the first unique name.  So the recursive
+// string only has to contain the non-unique slots and the unique slots that directly follow a
+// non-unique one (they terminate the comparisons that start before them).  RU[p] = name | unique<<31.
+//   k_keep_count/k_keep_write : R'[j] = name of the j-th kept slot, kept[j] = slot | unique<<31
+//   (child: SA' of R')
+//   k_discard_gather          : x[r] = kept[SA'[r]]            (kept slots in suffix order)
+//   k_nonuniq_count/_write    : pt[t] = t-th non-unique slot of x (their final relative order)
+//   k_final_count/_assign     : walk the level's sorted array; unique entries keep their place, the
+//                               t-th non-unique entry receives pt[t]   -> SA12 and (slot, rank) pairs
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool keep_slot(const u32 *__restrict__ RU, u32 p) {
+  return !((RU[p] & kUniqBit) && (p == 0 || (RU[p - 1] & kUniqBit)));
+}
+__device__ __forceinline__ void block_count_store(u32 c, u32 *tmp, u32 *counts) {
+  c = wave_reduce(c);
+  if (lane_id() == 0) tmp[wave_id()] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) { u32 t = 0; for (int i = 0; i < kWaves; i++) t += tmp[i]; counts[blockIdx.x] = t; }
+}
+__global__ __launch_bounds__(kBlock) void k_keep_count(const u32 *__restrict__ RU, u32 n, u32 chunk, u32 *counts) {
+  __shared__ u32 tmp[kWaves];
+  const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
+  u32 c = 0;
+  for (u32 p = begin + threadIdx.x; p < end; p += kBlock) c += keep_slot(RU, p) ? 1u : 0u;
+  block_count_store(c, tmp, counts);
+}
+__global__ __launch_bounds__(kBlock) void k_keep_write(const u32 *__restrict__ RU, u32 n, u32 chunk,
+                                                      const u32 *__restrict__ base_excl, u32 *__restrict__ Rp,
+                                                      u32 *__restrict__ kept) {
+  __shared__ u32 tmp[kWaves];
+  const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
+  u32 running = base_excl[blockIdx.x];
+  for (u32 tile = begin; tile < end; tile += kBlock) {
+    const u32 p = tile + threadIdx.x;
+    const bool f = (p < end) && keep_slot(RU, p);
+    u32 tot;
+    const u32 ex = block_excl_scan<kWaves>(f ? 1u : 0u, tmp, tot);
+    if (f) { const u32 v = RU[p]; Rp[running + ex] = v & ~kUniqBit; kept[running + ex] = p | (v & kUniqBit); }
+    running += tot;
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_discard_gather(const u32 *__restrict__ sap, u32 n,
+                                                          const u32 *__restrict__ kept, u32 *__restrict__ x) {
+  for (u32 r = blockIdx.x * kBlock + threadIdx.x; r < n; r += gridDim.x * kBlock) x[r] = kept[sap[r]];
+}
+__global__ __launch_bounds__(kBlock) void k_nonuniq_count(const u32 *__restrict__ x, u32 n, u32 chunk, u32 *counts) {
+  __shared__ u32 tmp[kWaves];
+  const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
+  u32 c = 0;
+  for (u32 i = begin + threadIdx.x; i < end; i += kBlock) c += (x[i] & kUniqBit) ? 0u : 1u;
+  block_count_store(c, tmp, counts);
+}
+__global__ __launch_bounds__(kBlock) void k_nonuniq_write(const u32 *__restrict__ x, u32 n, u32 chunk,
+                                                         const u32 *__restrict__ base_excl, u32 *__restrict__ pt) {
+  __shared__ u32 tmp[kWaves];
+  const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
+  u32 running = base_excl[blockIdx.x];
+  for (u32 tile = begin; tile < end; tile += kBlock) {
+    const u32 i = tile + threadIdx.x;
+    const bool f = (i < end) && !(x[i] & kUniqBit);
+    u32 tot;
+    const u32 ex = block_excl_scan<kWaves>(f ? 1u : 0u, tmp, tot);
+    if (f) pt[running + ex] = x[i];
+    running += tot;
+  }
+}
+// sslot[i] = slot | unique<<31 of the i-th entry of the level's sorted array
+__global__ __launch_bounds__(kBlock) void k_final_assign(const u32 *__restrict__ sslot, u32 n, u32 chunk,
+                                                        const u32 *__restrict__ base_excl,
+                                                        const u32 *__restrict__ pt, u32 *__restrict__ sa12,
+                                                        Rec8 *__restrict__ pairs) {
+  __shared__ u32 tmp[kWaves];
+  const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
+  u32 running = base_excl[blockIdx.x];
+  for (u32 tile = begin; tile < end; tile += kBlock) {
+    const u32 i = tile + threadIdx.x;
+    const u32 v = (i < end) ? sslot[i] : kUniqBit;
+    const bool nonu = (i < end) && !(v & kUniqBit);
+    u32 tot;
+    const u32 ex = block_excl_scan<kWaves>(nonu ? 1u : 0u, tmp, tot);
+    if (i < end) {
+      const u32 sl = nonu ? pt[running + ex] : (v & ~kUniqBit);
+      sa12[i] = sl;
+      pairs[i] = Rec8{sl, i + 1};
+    }
+    running += tot;
+  }
+}
+
+// Partition pass of the windowed inversion (MSD order, not stable — order inside a window is
+// irrelevant because k_invperm_local places by exact key).  The keys are a bijection onto [0,n), so
+// the destination region of digit d of segment s is known analytically:
+//   [ (s << seg_bits) + (d << shift), ... )  and holds exactly the keys that belong there;
+// a tile only has to reserve space inside the region: one global atomicAdd per (tile, digit) on
+// cursors[s*ndig + d].  No up-sweep, no scan: 16 B moved per pair instead of 24.
+//   pass 1: shift = 22, seg_bits = 32 (one segment), ndig = ceil(n / 2^22) <= 1024
+//   pass 2: shift = 14, seg_bits = 22, ndig = 256   (tiles never straddle a 2^22-pair segment)
+constexpr int kPartNW = 16, kPartIPT = 8, kPartTile = kPartNW * 64 * kPartIPT;   // 8192 pairs
+constexpr size_t kPartSmem = sizeof(Rec8) * kPartTile + sizeof(u32) * (2 * 1024 + 64);
+__global__ __launch_bounds__(kPartNW * 64) void k_part_msd(const Rec8 *__restrict__ in, Rec8 *__restrict__ out, u32 n,
+                                                          u32 shift, u32 seg_bits, u32 ndig,
+                                                          u32 *__restrict__ cursors) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Rec8 *srec = reinterpret_cast<Rec8 *>(smem);
+  u32 *hist = reinterpret_cast<u32 *>(smem + sizeof(Rec8) * kPartTile);   // [1024] counts -> tile-exclusive prefix
+  u32 *gbase = hist + 1024;                                                // [1024] global base of the tile's run
+  u32 *tmp = gbase + 1024;
+  const u32 tid = threadIdx.x;
+  const u32 begin = blockIdx.x * (u32)kPartTile;
+  const u32 nvalid = min((u32)kPartTile, n - begin);
+  const u32 seg = seg_bits >= 32 ? 0u : (begin >> seg_bits);
+  const u32 seg_base = seg_bits >= 32 ? 0u : (seg << seg_bits);
+  hist[tid] = 0;
+  __syncthreads();
+  Rec8 r[kPartIPT];
+  u32 d[kPartIPT], rk[kPartIPT];
+#pragma unroll
+  for (int k = 0; k < kPartIPT; k++) {
+    const u32 t = k * (kPartNW * 64) + tid;
+    if (t < nvalid) {
+      r[k] = in[begin + t];
+      d[k] = ((r[k].key - seg_base) >> shift);
+      rk[k] = atomicAdd(&hist[d[k]], 1u);
+    }
+  }
+  __syncthreads();
+  u32 cnt = 0;
+  if (tid < ndig) {
+    cnt = hist[tid];
+    if (cnt) gbase[tid] = seg_base + (tid << shift) + atomicAdd(&cursors[seg * ndig + tid], cnt);
+  }
+  u32 tot;
+  const u32 ex = block_excl_scan<kPartNW>(tid < ndig ? cnt : 0u, tmp, tot);
+  hist[tid] = ex;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kPartIPT; k++) {
+    const u32 t = k * (kPartNW * 64) + tid;
+    if (t < nvalid) srec[hist[d[k]] + rk[k]] = r[k];
+  }
+  __syncthreads();
+  for (u32 q = tid; q < nvalid; q += kPartNW * 64) {
+    const Rec8 x = srec[q];
+    const u32 dd = (x.key - seg_base) >> shift;
+    out[gbase[dd] + (q - hist[dd])] = x;
+  }
+}
+
+// Final step of the windowed inversion.  The keys are a bijection onto [0,n), and the pairs are
+// already partitioned by key >> kInvWindowBits, so pair range [w*W, (w+1)*W) holds exactly the
+// destinations of window w: place them in LDS, then store the window with full coalesced lines.
+constexpr int kInvWindowBits = 14;
+constexpr int kInvWindow = 1 << kInvWindowBits;   // 16384 ranks = 64 KiB of LDS
+__global__ __launch_bounds__(1024) void k_invperm_local(const Rec8 *__restrict__ pairs, u32 n, u32 *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u32 *win = reinterpret_cast<u32 *>(smem);
+  const u32 base = blockIdx.x * (u32)kInvWindow;
+  const u32 cnt = min((u32)kInvWindow, n - base);
+  for (u32 i = threadIdx.x; i < cnt; i += 1024) {
+    const Rec8 r = pairs[base + i];
+    win[r.key - base] = r.val;
+  }
+  __syncthreads();
+  for (u32 i = threadIdx.x; i < cnt; i += 1024) out[base + i] = win[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Prefix-sort + tie-refine ordering of the sample triples (replaces the 3x radix_pass of
+// lib.rs:74-76 when most keys are already distinct in an N-bit monotone image, N = 64 - pbits):
+//   1. (image, pos) packed in one 64-bit word, 4 stable LSD passes over the image bits   [all samples]
+//   2. elements whose image equals a neighbour's are "tied"; only those are re-sorted by the full
+//      3b-bit key as 16-byte records and written back into the tied slots (same relative order)
+// Result: h[i].val = position of the i-th smallest triple, f[i] = key differs from predecessor.
+// ---------------------------------------------------------------------------------------------
+// Monotone N-bit image of the full key (N = 64 - pbits, pbits = bits of a position; 34 bits at 1 GiB):
+// X = key >> shx (its top 64 bits), hi = floor(X * mfix / 2^64) with mfix = floor(2^(64+N) / (Xmax+1)) —
+// uses the whole N-bit range whatever the packing base is, so as few samples as possible collide
+// (exact: the key itself fits N bits).  Any monotone map is valid for the tie-refine scheme.
+// The record is the 64-bit word (hi << pbits) | pos.
+struct HiMap { u64 mfix; u32 shx, pbits, nbits, exact; };
+__device__ __forceinline__ Rec8 hyb_rec(const Rec16 &r, HiMap hm) {
+  const u64 lo = (u64)r.k0 | ((u64)r.k1 << 32);
+  u64 hi;
+  if (hm.exact) hi = lo;
+  else {
+    const u64 x = hm.shx ? ((lo >> hm.shx) | ((u64)r.k2 << (64 - hm.shx))) : lo;
+    hi = __umul64hi(x, hm.mfix);
+  }
+  const u64 w = (hi << hm.pbits) | r.pos;
+  return Rec8{(u32)(w >> 32), (u32)w};
+}
+// stride > 1 samples every stride-th group (tie-rate predictor); out index = g / stride
+template <class Sym>
+__global__ __launch_bounds__(kBlock) void k_pack_image(Sym S, u32 m, u32 m0, u32 m02, u32 b, HiMap hm, u32 stride,
+                                                     u32 ngroups_out, Rec8 *out) {
+  for (u32 go = blockIdx.x * kBlock + threadIdx.x; go < ngroups_out; go += gridDim.x * kBlock) {
+    const u32 g = go * stride;
+    const u32 i = 3 * g + 1;
+    const u32 s1 = S.get(i), s2 = S.get(i + 1), s3 = S.get(i + 2), s4 = S.get(i + 3);
+    out[2 * go] = hyb_rec(make_rec(s1, s2, s3, b, i), hm);
+    if (stride > 1 || 2 * g + 1 < m02) {
+      // (in sampling mode a possibly non-existent last mod-2 sample only perturbs the estimate)
+      if (2 * g + 1 < m02) out[2 * go + 1] = hyb_rec(make_rec(s2, s3, s4, b, i + 1), hm);
+      else out[2 * go + 1] = Rec8{0xffffffffu, 0xffffffffu};
+    }
+  }
+}
+__device__ __forceinline__ bool hyb_tied(const Rec8 *h, u32 i, u32 n, u32 pbits) {
+  const u64 a = rec8_word(h[i]) >> pbits;
+  return (i > 0 && (rec8_word(h[i - 1]) >> pbits) == a) || (i + 1 < n && (rec8_word(h[i + 1]) >> pbits) == a);
+}
+__global__ __launch_bounds__(kBlock) void k_tie_count(const Rec8 *__restrict__ h, u32 n, u32 chunk, u32 pbits,
+                                                     u32 *counts) {
+  __shared__ u32 tmp[kWaves];
+  const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
+  u32 c = 0;
+  for (u32 i = begin + threadIdx.x; i < end; i += kBlock) c += hyb_tied(h, i, n, pbits) ? 1u : 0u;
+  c = wave_reduce(c);
+  if (lane_id() == 0) tmp[wave_id()] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) { u32 t = 0; for (int i = 0; i < kWaves; i++) t += tmp[i]; counts[blockIdx.x] = t; }
+}
+// compacts the tied elements (order preserving): full-key record rebuilt from S, and the index of
+// the slot it came from
+template <class Sym>
+__global__ __launch_bounds__(kBlock) void k_tie_compact(Sym S, u32 b, const Rec8 *__restrict__ h, u32 n, u32 chunk,
+                                                       u32 pbits,
+                                                       const u32 *__restrict__ base_excl, Rec16 *__restrict__ sub,
+                                                       u32 *__restrict__ tiedidx, u32 *__restrict__ gkey) {
+  __shared__ u32 tmp[kWaves];
+  const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
+  u32 running = base_excl[blockIdx.x];
+  for (u32 tile = begin; tile < end; tile += kBlock) {
+    const u32 i = tile + threadIdx.x;
+    const bool f = (i < end) && hyb_tied(h, i, n, pbits);
+    u32 tot;
+    const u32 ex = block_excl_scan<kWaves>(f ? 1u : 0u, tmp, tot);
+    if (f) {
+      const u32 p = h[i].val & (pbits >= 32 ? 0xffffffffu : ((1u << pbits) - 1u));
+      sub[running + ex] = make_rec(S.get(p), S.get(p + 1), S.get(p + 2), b, p);
+      tiedidx[running + ex] = i;
+      // group id = low 32 bits of the key image; merging two adjacent groups that differ only above
+      // bit 31 is harmless (the union is sorted by the full key)
+      gkey[running + ex] = (u32)(rec8_word(h[i]) >> pbits);
+    }
+    running += tot;
+  }
+}
+// Tied samples form groups (equal key image) that are tiny on high-entropy input (Poisson: almost all of
+// size 2-3).  When the largest group has at most kTieSmallMax members, one thread per group sorts
+// it by the full key with a stable insertion sort — instead of 10 radix passes over the subset.
+constexpr u32 kTieSmallMax = 16;
+__global__ __launch_bounds__(kBlock) void k_tie_groupmax(const u32 *__restrict__ gkey, u32 t, u32 *maxlen) {
+  u32 best = 0;
+  for (u32 j = blockIdx.x * kBlock + threadIdx.x; j < t; j += gridDim.x * kBlock) {
+    const u32 k = gkey[j];
+    if (j > 0 && gkey[j - 1] == k) continue;            // not a group start
+    u32 e = j + 1;
+    while (e < t && e - j <= kTieSmallMax && gkey[e] == k) e++;
+    best = max(best, e - j);
+  }
+  best = wave_reduce_max(best);
+  if (lane_id() == 0 && best) atomicMax(maxlen, best);
+}
+__device__ __forceinline__ bool key_less(const Rec16 &a, const Rec16 &b) {
+  if (a.k2 != b.k2) return a.k2 < b.k2;
+  if (a.k1 != b.k1) return a.k1 < b.k1;
+  return a.k0 < b.k0;
+}
+__global__ __launch_bounds__(kBlock) void k_tie_sort_small(const Rec16 *__restrict__ sub, const u32 *__restrict__ gkey,
+                                                          u32 t, Rec16 *__restrict__ out) {
+  for (u32 j = blockIdx.x * kBlock + threadIdx.x; j < t; j += gridDim.x * kBlock) {
+    const u32 k = gkey[j];
+    if (j > 0 && gkey[j - 1] == k) continue;
+    u32 e = j + 1;
+    while (e < t && gkey[e] == k) e++;
+    const u32 len = e - j;                               // <= kTieSmallMax (checked by the host)
+    Rec16 loc[kTieSmallMax];
+    for (u32 x = 0; x < len; x++) {                      // stable insertion sort (input is in position order)
+      const Rec16 v = sub[j + x];
+      u32 y = x;
+      while (y > 0 && key_less(v, loc[y - 1])) { loc[y] = loc[y - 1]; y--; }
+      loc[y] = v;
+    }
+    for (u32 x = 0; x < len; x++) out[j + x] = loc[x];
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_tie_writeback(const Rec16 *__restrict__ sub, const u32 *__restrict__ tiedidx,
+                                                         u32 t, Rec8 *__restrict__ h, uint8_t *__restrict__ f) {
+  for (u32 j = blockIdx.x * kBlock + threadIdx.x; j < t; j += gridDim.x * kBlock) {
+    const Rec16 cur = sub[j];
+    const u32 i = tiedidx[j];
+    h[i].val = cur.pos;
+    bool ne = true;
+    if (j > 0) { const Rec16 prev = sub[j - 1]; ne = key_neq(cur, prev); }
+    f[i] = ne ? 1 : 0;
+  }
+}
+
+__global__ void k_base1(u32 *out_sa, u32 *out_rank) {
+  if (threadIdx.x == 0) { if (out_sa) out_sa[0] = 0; if (out_rank) out_rank[0] = 1; }
+}
+__global__ void k_zero_tail(u32 *p, u32 from, u32 count) {
+  if (threadIdx.x < count) p[from + threadIdx.x] = 0;
+}
+
+}  // namespace dc3

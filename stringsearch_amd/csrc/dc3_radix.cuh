@@ -1,0 +1,209 @@
+// dc3_radix.cuh — stable LSD radix passes (up-sweep / row scan / down-sweep with loaders).
+// Part of the gfx950 kernel set of libdc3hip (see dc3_kernels.cuh for the overview); all files share
+// namespace dc3 and are included in this order by dc3_kernels.cuh.
+#pragma once
+
+namespace dc3 {
+
+// ---------------------------------------------------------------------------------------------
+// Stable LSD radix pass (lib.rs:15-39 with the K+1 counters replaced by digits of NB = 256 or 512
+// bins; 9-bit digits are used where they save a pass, e.g. 25-27-bit symbols).
+//   up-sweep  : per-chunk digit histogram (lib.rs:20-22)          -> table[digit][chunk]
+//   scan      : exclusive prefix sums over table (lib.rs:25-32)   (k_scan_rows + k_scan_excl_inplace)
+//   down-sweep: stable scatter (lib.rs:35-38)
+// A digit is (key >> shift) & mask of the record's sort key.
+// ---------------------------------------------------------------------------------------------
+struct KeyDig { u32 shift, mask; };
+// Rec8 as a 64-bit sort word: key = high half, val = low half (prefix-sort records keep the position
+// in the low pbits of val, the rest is the monotone key image)
+__device__ __forceinline__ u64 rec8_word(const Rec8 &r) { return ((u64)r.key << 32) | r.val; }
+__device__ __forceinline__ u32 digit_of(const Rec8 &r, KeyDig d) { return (u32)(rec8_word(r) >> d.shift) & d.mask; }
+__device__ __forceinline__ u32 digit_of(const Rec12 &r, KeyDig d) {
+  const u64 k = (u64)r.k0 | ((u64)r.k1 << 32);
+  return (u32)(k >> d.shift) & d.mask;
+}
+__device__ __forceinline__ u32 digit_of(const Rec16 &r, KeyDig d) {     // 96-bit key, shift < 96
+  const u32 w = d.shift >> 5, off = d.shift & 31;
+  const u32 a = w == 0 ? r.k0 : (w == 1 ? r.k1 : r.k2);
+  const u32 b = w == 0 ? r.k1 : (w == 1 ? r.k2 : 0u);
+  return (off ? ((a >> off) | (b << (32 - off))) : a) & d.mask;
+}
+// mod-0 positions are real symbols (c0 >= 1), so the key is c0-1 in [0, K)
+__device__ __forceinline__ u32 digit_of(const Tup0 &r, KeyDig d) { return ((r.c0 - 1u) >> d.shift) & d.mask; }
+
+template <class Rec, int NB>
+__global__ __launch_bounds__(kBlock) void k_rs_upsweep(const Rec *__restrict__ in, u32 n, u32 chunk, u32 nchunks,
+                                                      KeyDig dig, u32 *__restrict__ table) {
+  __shared__ u32 hist[kWaves][NB];
+  const u32 tid = threadIdx.x;
+#pragma unroll
+  for (int w = 0; w < kWaves; w++)
+    for (int j = tid; j < NB; j += kBlock) hist[w][j] = 0;
+  __syncthreads();
+  const u32 begin = blockIdx.x * chunk;
+  const u32 end = min(n, begin + chunk);
+  u32 *myh = hist[wave_id()];
+  for (u32 i = begin + tid; i < end; i += kBlock) {
+    const Rec r = in[i];
+    atomicAdd(&myh[digit_of(r, dig)], 1u);
+  }
+  __syncthreads();
+  for (int j = tid; j < NB; j += kBlock) {
+    u32 sum = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; w++) sum += hist[w][j];
+    table[(size_t)j * nchunks + blockIdx.x] = sum;
+  }
+}
+
+template <class Rec, int IPT, int NW, int NB>
+struct DownsweepSmem {
+  static constexpr int kTile = NW * 64 * IPT;
+  static constexpr size_t kBytes = sizeof(Rec) * kTile + sizeof(u32) * (NW * NB + NB + NB + 32);
+};
+
+// table rows are scanned per digit (k_scan_rows) and the 256 digit totals separately
+// (k_scan_excl_inplace on digit_base), so the global base of (digit d, chunk c) is
+// digit_base[d] + table[d*nchunks + c].
+// NW waves per block (measured on MI355X, profiles/r01_radix_downsweep_variants.txt: 16 waves x 8
+// items = 8192-record tiles move 3.5 TB/s vs 2.9 TB/s for 4 waves x 16 items).
+// Loaders: where a down-sweep takes its records from.  ArrayLoader = a plain record array.  A loader
+// may also DROP elements (load() returns false), which fuses an order-preserving selection into the
+// pass (used for Step 2: mod-0 tuples are made from the mod-1 entries of the sorted sample tuples
+// and immediately partitioned by their first key byte — lib.rs:118-126 in one pass).
+template <class Rec>
+struct ArrayLoader {
+  const Rec *p;
+  __device__ __forceinline__ bool load(u32 i, Rec &r) const { r = p[i]; return true; }
+};
+
+// PF: prefetch the next tile into registers while the current one is ranked/reordered (pays for
+// 8-byte records: 2.3 -> 3.4 TB/s; costs registers and loses for 16/20-byte records, see
+// profiles/r01_radix_downsweep_variants_v2.txt).
+template <class Rec, int NB, int IPT, int NW, bool PF, class Loader>
+__global__ __launch_bounds__(NW * 64) void k_rs_downsweep(Loader in, Rec *__restrict__ out, u32 n,
+                                                         u32 chunk, u32 nchunks, KeyDig dig,
+                                                         const u32 *__restrict__ table,
+                                                         const u32 *__restrict__ digit_base) {
+  constexpr int kB = NW * 64;
+  constexpr int kTile = kB * IPT;
+  constexpr int kWItems = 64 * IPT;
+  constexpr int kBits = NB == 512 ? 9 : 8;
+  static_assert(NB == 256 || NB == 512, "digit bins");
+  static_assert(NW * 64 >= NB, "one thread per digit");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Rec *srec = reinterpret_cast<Rec *>(smem);
+  u32 *wcnt = reinterpret_cast<u32 *>(smem + sizeof(Rec) * kTile);   // [NW][NB]
+  u32 *dbase = wcnt + NW * NB;                                       // [NB] running global base
+  u32 *texcl = dbase + NB;                                           // [NB] tile-exclusive prefix
+  u32 *tmp = texcl + NB;                                             // [NW]
+  const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
+  const u32 begin = blockIdx.x * chunk;
+  const u32 end = min(n, begin + chunk);
+  if (tid < NB) dbase[tid] = digit_base[tid] + table[(size_t)tid * nchunks + blockIdx.x];
+  u32 *mycnt = wcnt + w * NB;
+  Rec r[IPT], rn[PF ? IPT : 1];
+  bool okn[PF ? IPT : 1];
+  if (PF) {
+#pragma unroll
+    for (int k = 0; k < IPT; k++) {
+      const u32 t = w * kWItems + k * 64 + lane;
+      okn[PF ? k : 0] = (begin + t < end) && in.load(begin + t, rn[PF ? k : 0]);
+    }
+  }
+
+  for (u32 tile = begin; tile < end; tile += kTile) {
+    const u32 nin = min((u32)kTile, end - tile);
+#pragma unroll
+    for (int j = 0; j < NB / 64; j++) mycnt[lane + 64 * j] = 0;
+    u32 d[IPT], rk[IPT];
+    bool ok[IPT];
+    // wave w owns tile items [w*kWItems, (w+1)*kWItems); round k covers 64 consecutive items
+#pragma unroll
+    for (int k = 0; k < IPT; k++) {
+      const u32 t = w * kWItems + k * 64 + lane;
+      if (PF) { r[k] = rn[PF ? k : 0]; ok[k] = okn[PF ? k : 0]; }
+      else ok[k] = (t < nin) && in.load(tile + t, r[k]);
+      d[k] = ok[k] ? digit_of(r[k], dig) : 0u;
+    }
+    if (PF) {
+      const u32 nt = tile + kTile;
+#pragma unroll
+      for (int k = 0; k < IPT; k++) {
+        const u32 t = w * kWItems + k * 64 + lane;
+        okn[PF ? k : 0] = (nt + t < end) && in.load(nt + t, rn[PF ? k : 0]);
+      }
+    }
+    // stable ranking: items of one wave-round with equal digit are ordered by lane.  The lowest
+    // peer lane bumps the wave's digit counter with one LDS atomic per round; the atomics of all
+    // rounds are issued back to back (LDS executes them in order, so the returned values are the
+    // running prefix) and the bases are broadcast afterwards.  Dropped / out-of-range lanes take
+    // no part.
+    {
+      u32 below[IPT], leader[IPT], old[IPT];
+#pragma unroll
+      for (int k = 0; k < IPT; k++) {
+        u64 peers = __ballot(ok[k]);
+#pragma unroll
+        for (int bit = 0; bit < kBits; bit++) {
+          const bool one = (d[k] >> bit) & 1u;
+          const u64 mk = __ballot(one);
+          peers &= one ? mk : ~mk;
+        }
+        below[k] = mbcnt(peers);
+        leader[k] = ok[k] ? (u32)__ffsll((unsigned long long)peers) - 1u : lane;
+        old[k] = 0;
+        if (ok[k] && below[k] == 0) old[k] = atomicAdd(&mycnt[d[k]], (u32)__popcll(peers));
+      }
+#pragma unroll
+      for (int k = 0; k < IPT; k++) rk[k] = __shfl(old[k], leader[k]) + below[k];
+    }
+    __syncthreads();
+    // per digit (thread tid = digit): prefix over waves, tile total, tile-exclusive prefix
+    u32 tot = 0;
+    if (tid < NB) {
+#pragma unroll
+      for (int i = 0; i < NW; i++) { const u32 c = wcnt[i * NB + tid]; wcnt[i * NB + tid] = tot; tot += c; }
+    }
+    u32 nkeep;
+    const u32 ex = block_excl_scan<NW>(tid < NB ? tot : 0u, tmp, nkeep);
+    if (tid < NB) texcl[tid] = ex;
+    __syncthreads();
+    // reorder through LDS so every digit run is contiguous
+#pragma unroll
+    for (int k = 0; k < IPT; k++) {
+      if (ok[k]) srec[texcl[d[k]] + wcnt[w * NB + d[k]] + rk[k]] = r[k];
+    }
+    __syncthreads();
+    for (u32 q = tid; q < nkeep; q += kB) {
+      const Rec x = srec[q];
+      const u32 dd = digit_of(x, dig);
+      out[dbase[dd] + (q - texcl[dd])] = x;
+    }
+    __syncthreads();
+    if (tid < NB) dbase[tid] += tot;
+    // (the barrier after ranking in the next iteration orders this update before its use)
+  }
+}
+
+// Row-wise exclusive scan of the [NB][nchunks] digit table: block d scans row d in place and
+// writes the row total to totals[d] (then scanned by k_scan_excl_inplace over NB entries).
+__global__ __launch_bounds__(kBlock) void k_scan_rows(u32 *__restrict__ table, u32 nchunks, u32 *__restrict__ totals) {
+  __shared__ u32 tmp[kWaves];
+  u32 *row = table + (size_t)blockIdx.x * nchunks;
+  u32 carry = 0;
+  for (u32 base = 0; base < nchunks; base += kBlock * 4) {
+    const u32 i0 = base + threadIdx.x * 4;
+    u32 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = (i0 + j < nchunks) ? row[i0 + j] : 0u;
+    u32 tot;
+    u32 ex = block_excl_scan<kWaves>(v[0] + v[1] + v[2] + v[3], tmp, tot) + carry;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { if (i0 + j < nchunks) row[i0 + j] = ex; ex += v[j]; }
+    carry += tot;
+  }
+  if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+}
+
+}  // namespace dc3
