@@ -150,7 +150,8 @@ typedef struct dc3hip_stats {
   int64_t level_K[DC3HIP_MAX_LEVELS];     /* alphabet bound per level */
   int32_t level_sorted[DC3HIP_MAX_LEVELS];/* 0 = direct packed names, 1 = names by full radix sort,
                                              2 = names by prefix sort + tie refinement,
-                                             3 / 4 = 1 / 2 followed by the discarding recursion */
+                                             3 / 4 = 1 / 2 followed by the discarding recursion,
+                                             5 = whole level ordered at once (all its triples distinct) */
   int64_t level_kept[DC3HIP_MAX_LEVELS];  /* length of the reduced recursive string (discarding) */
   int32_t level_name_width[DC3HIP_MAX_LEVELS]; /* symbols packed per direct name (0 on sorted levels) */
   int64_t level_tied[DC3HIP_MAX_LEVELS];  /* samples re-sorted by the full key (prefix-sort path) */

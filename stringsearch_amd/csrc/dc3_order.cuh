@@ -321,6 +321,23 @@ __global__ __launch_bounds__(kBlock) void k_pack_image(Sym S, u32 m, u32 m0, u32
     }
   }
 }
+// the same records for ALL positions 0..m-1 (whole-level shortcut: if every triple of the level is
+// distinct, the sorted triples are the suffix array of the level and no sampling / merge is needed)
+template <class Sym>
+__global__ __launch_bounds__(kBlock) void k_pack_image_all(Sym S, u32 m, u32 b, HiMap hm, Rec8 *out) {
+  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < m; i += gridDim.x * kBlock)
+    out[i] = hyb_rec(make_rec(S.get(i), S.get(i + 1), S.get(i + 2), b, i), hm);
+}
+// all keys distinct: out_sa[k] = pos_k and the (pos_k, k+1) pairs of the rank inversion
+template <class Acc>
+__global__ __launch_bounds__(kBlock) void k_emit_sorted(Acc acc, u32 n, u32 *__restrict__ out_sa,
+                                                       Rec8 *__restrict__ pairs) {
+  for (u32 k = blockIdx.x * kBlock + threadIdx.x; k < n; k += gridDim.x * kBlock) {
+    const u32 p = acc.pos(k);
+    if (out_sa) out_sa[k] = p;
+    if (pairs) pairs[k] = Rec8{p, k + 1};
+  }
+}
 __device__ __forceinline__ bool hyb_tied(const Rec8 *h, u32 i, u32 n, u32 pbits) {
   const u64 a = rec8_word(h[i]) >> pbits;
   return (i > 0 && (rec8_word(h[i - 1]) >> pbits) == a) || (i + 1 < n && (rec8_word(h[i + 1]) >> pbits) == a);

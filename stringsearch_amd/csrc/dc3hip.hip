@@ -73,7 +73,7 @@ struct dc3hip_ctx {
   int merge_cfg = 3;
   bool no_small_ties = false;
   bool wide_names = false;
-  bool no_nine_bit = false, no_rec12 = false, no_discard = false;
+  bool no_nine_bit = false, no_rec12 = false, no_discard = false, no_fullsort = false;
   std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
   std::vector<PhaseMark> marks;
   hipEvent_t ev_build_a = nullptr, ev_build_b = nullptr;
@@ -448,6 +448,7 @@ static int discard_recurse(dc3hip_ctx *c, const u32 *RU, const u32 *sslot, u32 m
 static constexpr u32 kHybridMinSamples = 1u << 22;
 static constexpr double kHybridMaxPredicted = 0.50;
 static constexpr double kHybridMaxMeasured = 0.60;
+static constexpr double kFullSortMaxPredicted = 0.10;   // whole-level shortcut only for very few predicted ties
 // hi = floor(X * mfix / 2^64) in N = min(64 - pbits, kbits) bits; X = key >> shx; see HiMap
 static HiMap make_himap(u64 B, u32 kbits, u32 m) {
   const unsigned __int128 mx = (unsigned __int128)B * B * B - 1;      // largest key
@@ -522,36 +523,26 @@ static int order_straight(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u
   return name_and_rank<AccRec<Rec>>(c, acc, m02, m0, sa12, rank12, R, sslot, names, mode);
 }
 
+// Core of the prefix-sort + tie-refine ordering: `ha` holds nrec packed (image << pbits | pos) records of the
+// positions to order; on return (ok) h = records sorted by the full key, f[i] = key differs from predecessor.
 template <class Sym>
-static int order_hybrid(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u32 kbits, u32 *sa12,
-                        u32 *rank12, u32 *R, u32 *sslot, u32 *names, int *mode, bool *ok, int depth) {
+static int hybrid_sort_core(dc3hip_ctx *c, Sym S, u32 b, u32 kbits, const HiMap &hm, Rec8 *ha, Rec8 *hb, u32 nrec,
+                            Rec8 **h_out, uint8_t *f, bool *ok, int depth) {
   *ok = false;
-  const HiMap hm = make_himap((u64)b, kbits, m);
-  Rec8 *ha = nullptr, *hb = nullptr, *h = nullptr;
-  uint8_t *f = nullptr;
-  RC(arena_alloc(c, (size_t)m02, &ha));
-  RC(arena_alloc(c, (size_t)m02, &hb));
-  RC(arena_alloc(c, (size_t)m02 + 16, &f));
-  {
-    PhaseScope ps(c, DC3HIP_PH_PACK, m02);
-    hipLaunchKernelGGL((k_pack_image<Sym>), dim3(grid_for(c, m0)), dim3(kBlock), 0, c->stream, S, m, m0, m02, b, hm,
-                       1u, m0, ha);
-    KCHECK();
-  }
-  RC(radix_sort<Rec8>(c, ha, hb, m02, hm.pbits, hm.pbits + hm.nbits, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN,
+  Rec8 *h = nullptr;
+  RC(radix_sort<Rec8>(c, ha, hb, nrec, hm.pbits, hm.pbits + hm.nbits, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN,
                       DC3HIP_PH_SORT8_DOWN));
-  const Chunking ck = make_chunks(c, m02, kBlock);
+  const Chunking ck = make_chunks(c, nrec, kBlock);
   u32 *counts = nullptr;
   RC(arena_alloc(c, (size_t)ck.nchunks + 16, &counts));
   u32 tied = 0;
   {
-    PhaseScope ps(c, DC3HIP_PH_TIES, m02);
-    RC(count_ties(c, h, m02, hm.pbits, counts, ck, &tied));
+    PhaseScope ps(c, DC3HIP_PH_TIES, nrec);
+    RC(count_ties(c, h, nrec, hm.pbits, counts, ck, &tied));
   }
   c->stats.level_tied[depth] = tied;
-  if ((double)tied > kHybridMaxMeasured * (double)m02) return E_OK;   // *ok stays false -> straight LSD
-  c->stats.level_sorted[depth] = 2;
-  HIPC(hipMemsetAsync(f, 1, (size_t)m02, c->stream));
+  if ((double)tied > kHybridMaxMeasured * (double)nrec) return E_OK;   // *ok stays false -> straight LSD
+  HIPC(hipMemsetAsync(f, 1, (size_t)nrec, c->stream));
   if (tied > 0) {
     Rec16 *sa = nullptr, *sb = nullptr, *ss = nullptr;
     u32 *tiedidx = nullptr, *gkey = nullptr;
@@ -562,7 +553,7 @@ static int order_hybrid(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u32
     u32 gmax = 0;
     {
       PhaseScope ps(c, DC3HIP_PH_TIES, tied);
-      hipLaunchKernelGGL((k_tie_compact<Sym>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, S, b, h, m02, ck.chunk,
+      hipLaunchKernelGGL((k_tie_compact<Sym>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, S, b, h, nrec, ck.chunk,
                          hm.pbits, counts, sa, tiedidx, gkey);
       KCHECK();
       HIPC(hipMemsetAsync(c->d_words + 3, 0, sizeof(u32), c->stream));
@@ -589,9 +580,91 @@ static int order_hybrid(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u32
       KCHECK();
     }
   }
+  *h_out = h;
+  *ok = true;
+  return E_OK;
+}
+
+template <class Sym>
+static int order_hybrid(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u32 kbits, u32 *sa12,
+                        u32 *rank12, u32 *R, u32 *sslot, u32 *names, int *mode, bool *ok, int depth) {
+  *ok = false;
+  const HiMap hm = make_himap((u64)b, kbits, m);
+  Rec8 *ha = nullptr, *hb = nullptr, *h = nullptr;
+  uint8_t *f = nullptr;
+  RC(arena_alloc(c, (size_t)m02, &ha));
+  RC(arena_alloc(c, (size_t)m02, &hb));
+  RC(arena_alloc(c, (size_t)m02 + 16, &f));
+  {
+    PhaseScope ps(c, DC3HIP_PH_PACK, m02);
+    hipLaunchKernelGGL((k_pack_image<Sym>), dim3(grid_for(c, m0)), dim3(kBlock), 0, c->stream, S, m, m0, m02, b, hm,
+                       1u, m0, ha);
+    KCHECK();
+  }
+  bool sorted_ok = false;
+  RC(hybrid_sort_core<Sym>(c, S, b, kbits, hm, ha, hb, m02, &h, f, &sorted_ok, depth));
+  if (!sorted_ok) return E_OK;
+  c->stats.level_sorted[depth] = 2;
   AccHyb acc; acc.h = h; acc.f = f; acc.posmask = hm.pbits >= 32 ? 0xffffffffu : ((1u << hm.pbits) - 1u);
   RC(name_and_rank<AccHyb>(c, acc, m02, m0, sa12, rank12, R, sslot, names, mode));
   *ok = true;
+  return E_OK;
+}
+
+// Whole-level shortcut for high-entropy levels: order ALL m positions by their triple; if every triple is
+// distinct the result is the suffix array of the level (suffixes differ within 3 symbols), so sampling,
+// tuples and the merge (lib.rs:62-192) are skipped altogether.  *done = false leaves everything untouched.
+template <class Sym>
+static int order_all_positions(dc3hip_ctx *c, Sym S, u32 m, u32 b, u32 kbits, u32 *out_sa, u32 *out_rank, bool *done,
+                               int depth) {
+  *done = false;
+  const ArenaMark mk = arena_mark(c);
+  const HiMap hm = make_himap((u64)b, kbits, m);
+  Rec8 *ha = nullptr, *hb = nullptr, *h = nullptr;
+  uint8_t *f = nullptr;
+  RC(arena_alloc(c, (size_t)m, &ha));
+  RC(arena_alloc(c, (size_t)m, &hb));
+  RC(arena_alloc(c, (size_t)m + 16, &f));
+  {
+    PhaseScope ps(c, DC3HIP_PH_PACK, m);
+    hipLaunchKernelGGL((k_pack_image_all<Sym>), dim3(grid_for(c, m)), dim3(kBlock), 0, c->stream, S, m, b, hm, ha);
+    KCHECK();
+  }
+  bool sorted_ok = false;
+  RC(hybrid_sort_core<Sym>(c, S, b, kbits, hm, ha, hb, m, &h, f, &sorted_ok, depth));
+  if (sorted_ok) {
+    AccHyb acc; acc.h = h; acc.f = f; acc.posmask = hm.pbits >= 32 ? 0xffffffffu : ((1u << hm.pbits) - 1u);
+    const Chunking ck = make_chunks(c, m, kBlock * kNameIPT);
+    u32 *counts = nullptr;
+    RC(arena_alloc(c, (size_t)ck.nchunks + 16, &counts));
+    {
+      PhaseScope ps(c, DC3HIP_PH_NAMING, m);
+      HIPC(hipMemsetAsync(c->d_words + 4, 0, sizeof(u32), c->stream));
+      hipLaunchKernelGGL((k_name_count<AccHyb>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, acc, m, ck.chunk, counts,
+                         c->d_words + 4);
+      KCHECK();
+      hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, counts, ck.nchunks, c->d_words);
+      KCHECK();
+      HIPC(hipMemcpyAsync(c->h_words, c->d_words, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPC(hipStreamSynchronize(c->stream));
+    if (c->h_words[0] == m) {          // every triple distinct: the sorted order is the suffix array
+      Rec8 *pa = nullptr, *pb = nullptr;
+      if (out_rank) {
+        RC(arena_alloc(c, (size_t)m, &pa));
+        RC(arena_alloc(c, (size_t)m, &pb));
+      }
+      {
+        PhaseScope ps(c, DC3HIP_PH_RANKS, m);
+        hipLaunchKernelGGL((k_emit_sorted<AccHyb>), dim3(grid_for(c, m)), dim3(kBlock), 0, c->stream, acc, m, out_sa,
+                           pa);
+        KCHECK();
+      }
+      if (out_rank) RC(inverse_permute(c, pa, pb, m, out_rank, DC3HIP_PH_RANKS));
+      *done = true;
+    }
+  }
+  arena_release(c, mk);
   return E_OK;
 }
 
@@ -661,6 +734,16 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
       double pred = 1.0;
       RC(predict_tie_fraction<Sym>(c, S, m, m0, m02, b, make_himap(B, kbits, m), &pred));
       c->stats.level_tie_pred[depth] = pred;
+      if (pred < kFullSortMaxPredicted && !c->no_fullsort) {
+        // high entropy: try to finish the whole level by sorting all of its positions
+        bool whole = false;
+        RC(order_all_positions<Sym>(c, S, m, b, kbits, out_sa, out_rank, &whole, depth));
+        if (whole) {
+          c->stats.level_sorted[depth] = 5;
+          arena_release(c, mk0);
+          return E_OK;
+        }
+      }
       if (pred < kHybridMaxPredicted) {
         bool ok = false;
         RC(order_hybrid<Sym>(c, S, m, m0, m02, b, kbits, sa12, rank12, R, sslot, &names, &mode, &ok, depth));
@@ -862,6 +945,8 @@ int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) {
   c->no_hybrid = (nh && nh[0] == '1');
   const char *nst = getenv("DC3HIP_NO_SMALL_TIES");
   c->no_small_ties = (nst && nst[0] == '1');
+  const char *nf = getenv("DC3HIP_NO_FULLSORT");
+  c->no_fullsort = (nf && nf[0] == '1');
   const char *nd = getenv("DC3HIP_NO_DISCARD");
   c->no_discard = (nd && nd[0] == '1');
   const char *n9 = getenv("DC3HIP_NO_9BIT");

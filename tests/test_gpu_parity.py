@@ -331,7 +331,7 @@ def test_hybrid_and_straight_paths_agree(ss, oracle):
     for label, data in cases.items():
         want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)
         seen = {}
-        for env in ({}, {"DC3HIP_NO_HYBRID": "1"}, {"DC3HIP_NO_SMALL_TIES": "1"},
+        for env in ({}, {"DC3HIP_NO_HYBRID": "1"}, {"DC3HIP_NO_SMALL_TIES": "1"}, {"DC3HIP_NO_FULLSORT": "1"},
                     {"DC3HIP_NO_HYBRID": "1", "DC3HIP_NO_9BIT": "1", "DC3HIP_NO_REC12": "1"}):
             os.environ.update(env)
             try:
@@ -343,9 +343,12 @@ def test_hybrid_and_straight_paths_agree(ss, oracle):
             finally:
                 for k in env:
                     os.environ.pop(k, None)
-        assert not any(v in (2, 4) for v in seen[("DC3HIP_NO_HYBRID",)]["level_sorted"])
+        assert not any(v in (2, 4, 5) for v in seen[("DC3HIP_NO_HYBRID",)]["level_sorted"])
+        assert 5 not in seen[("DC3HIP_NO_FULLSORT",)]["level_sorted"]
+        if label == "random":
+            assert 5 in seen[()]["level_sorted"], seen[()]["level_sorted"]       # whole level ordered at once
         if label in ("random", "zero_run"):
-            assert any(v in (2, 4) for v in seen[()]["level_sorted"]), seen[()]["level_sorted"]   # 4 = 2 + discarding
+            assert any(v in (2, 4) for v in seen[("DC3HIP_NO_FULLSORT",)]["level_sorted"])   # 4 = 2 + discarding
             # small-group path skips the 16-byte radix passes entirely; the zero run forces them
             d16 = seen[()]["downsweep_launches"][1]
             assert (d16 == 0) if label == "random" else (d16 > 0), (label, d16)
