@@ -324,18 +324,61 @@ __global__ __launch_bounds__(kBlock) void k_pack_image(Sym S, u32 m, u32 m0, u32
 // the same records for ALL positions 0..m-1 (whole-level shortcut: if every triple of the level is
 // distinct, the sorted triples are the suffix array of the level and no sampling / merge is needed)
 template <class Sym>
-__global__ __launch_bounds__(kBlock) void k_pack_image_all(Sym S, u32 m, u32 b, HiMap hm, Rec8 *out) {
-  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < m; i += gridDim.x * kBlock)
+__global__ __launch_bounds__(kBlock) void k_pack_image_all(Sym S, u32 nrec, u32 b, HiMap hm, Rec8 *out) {
+  // nrec = m, or m+1 to include the dummy sample at position m (triple 0,0,0; lib.rs:61-64)
+  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < nrec; i += gridDim.x * kBlock)
     out[i] = hyb_rec(make_rec(S.get(i), S.get(i + 1), S.get(i + 2), b, i), hm);
 }
 // all keys distinct: out_sa[k] = pos_k and the (pos_k, k+1) pairs of the rank inversion
+// `skip` = 1 when record 0 is the dummy (it always sorts first)
 template <class Acc>
-__global__ __launch_bounds__(kBlock) void k_emit_sorted(Acc acc, u32 n, u32 *__restrict__ out_sa,
+__global__ __launch_bounds__(kBlock) void k_emit_sorted(Acc acc, u32 n, u32 skip, u32 *__restrict__ out_sa,
                                                        Rec8 *__restrict__ pairs) {
   for (u32 k = blockIdx.x * kBlock + threadIdx.x; k < n; k += gridDim.x * kBlock) {
-    const u32 p = acc.pos(k);
+    const u32 p = acc.pos(k + skip);
     if (out_sa) out_sa[k] = p;
     if (pairs) pairs[k] = Rec8{p, k + 1};
+  }
+}
+// Not all triples distinct: keep the work.  The samples (pos % 3 != 0, incl. the dummy at pos == m) are
+// filtered out of the fully sorted order — they are then in sorted sample order — together with their
+// "full name" nf = number of key changes up to them, so equal keys <=> equal nf.
+//   k_filter_count : per-chunk number of samples
+//   k_filter_write : spos[j] = pos, snf[j] = nf of the j-th sample in sorted order
+struct AccFilt {
+  const u32 *spos, *snf;
+  __device__ __forceinline__ u32 pos(u32 j) const { return spos[j]; }
+  __device__ __forceinline__ u32 neq(u32 j) const { return (j == 0 || snf[j] != snf[j - 1]) ? 1u : 0u; }
+};
+template <class Acc>
+__global__ __launch_bounds__(kBlock) void k_filter_count(Acc acc, u32 n, u32 chunk, u32 *counts) {
+  __shared__ u32 tmp[kWaves];
+  const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
+  u32 c = 0;
+  for (u32 i = begin + threadIdx.x; i < end; i += kBlock) c += (acc.pos(i) % 3 != 0) ? 1u : 0u;
+  c = wave_reduce(c);
+  if (lane_id() == 0) tmp[wave_id()] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) { u32 t = 0; for (int i = 0; i < kWaves; i++) t += tmp[i]; counts[blockIdx.x] = t; }
+}
+// name_base[blk] = exclusive prefix of the key-change flags (the scanned k_name_count output for the same
+// chunking), samp_base[blk] = exclusive prefix of the sample counts
+template <class Acc>
+__global__ __launch_bounds__(kBlock) void k_filter_write(Acc acc, u32 n, u32 chunk, const u32 *__restrict__ name_base,
+                                                        const u32 *__restrict__ samp_base, u32 *__restrict__ spos,
+                                                        u32 *__restrict__ snf) {
+  __shared__ u32 tmp[kWaves];
+  const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
+  u32 run_f = name_base[blockIdx.x], run_s = samp_base[blockIdx.x];
+  for (u32 tile = begin; tile < end; tile += kBlock) {
+    const u32 i = tile + threadIdx.x;
+    u32 fl = 0, p = 0; bool smp = false;
+    if (i < end) { fl = acc.neq(i); p = acc.pos(i); smp = (p % 3 != 0); }
+    u32 totf, tots;
+    const u32 exf = block_excl_scan<kWaves>(fl, tmp, totf);
+    const u32 exs = block_excl_scan<kWaves>(smp ? 1u : 0u, tmp, tots);
+    if (smp) { spos[run_s + exs] = p; snf[run_s + exs] = run_f + exf + fl; }
+    run_f += totf; run_s += tots;
   }
 }
 __device__ __forceinline__ bool hyb_tied(const Rec8 *h, u32 i, u32 n, u32 pbits) {

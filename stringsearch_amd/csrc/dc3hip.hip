@@ -611,44 +611,51 @@ static int order_hybrid(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u32
   return E_OK;
 }
 
-// Whole-level shortcut for high-entropy levels: order ALL m positions by their triple; if every triple is
-// distinct the result is the suffix array of the level (suffixes differ within 3 symbols), so sampling,
-// tuples and the merge (lib.rs:62-192) are skipped altogether.  *done = false leaves everything untouched.
+// Whole-level shortcut for high-entropy levels: order ALL m positions (plus the dummy sample) by their triple.
+//   state 1: every triple distinct -> the result is the suffix array of the level (suffixes differ within 3
+//            symbols): sampling, tuples and the merge (lib.rs:62-192) are skipped altogether;
+//   state 2: duplicates exist -> the samples are filtered out of the sorted order (spos/snf), so the usual
+//            naming continues from there and the sort is not repeated;
+//   state 0: too many collisions in the key image, nothing was produced.
+// spos/snf (m02 entries each) must be allocated by the caller below this function's arena mark.
 template <class Sym>
-static int order_all_positions(dc3hip_ctx *c, Sym S, u32 m, u32 b, u32 kbits, u32 *out_sa, u32 *out_rank, bool *done,
-                               int depth) {
-  *done = false;
+static int order_all_positions(dc3hip_ctx *c, Sym S, u32 m, u32 m02, u32 b, u32 kbits, u32 *out_sa, u32 *out_rank,
+                               u32 *spos, u32 *snf, int *state, int depth) {
+  *state = 0;
   const ArenaMark mk = arena_mark(c);
   const HiMap hm = make_himap((u64)b, kbits, m);
+  const u32 dummy = (m % 3 == 1) ? 1u : 0u;
+  const u32 nrec = m + dummy;
   Rec8 *ha = nullptr, *hb = nullptr, *h = nullptr;
   uint8_t *f = nullptr;
-  RC(arena_alloc(c, (size_t)m, &ha));
-  RC(arena_alloc(c, (size_t)m, &hb));
-  RC(arena_alloc(c, (size_t)m + 16, &f));
+  RC(arena_alloc(c, (size_t)nrec, &ha));
+  RC(arena_alloc(c, (size_t)nrec, &hb));
+  RC(arena_alloc(c, (size_t)nrec + 16, &f));
   {
-    PhaseScope ps(c, DC3HIP_PH_PACK, m);
-    hipLaunchKernelGGL((k_pack_image_all<Sym>), dim3(grid_for(c, m)), dim3(kBlock), 0, c->stream, S, m, b, hm, ha);
+    PhaseScope ps(c, DC3HIP_PH_PACK, nrec);
+    hipLaunchKernelGGL((k_pack_image_all<Sym>), dim3(grid_for(c, nrec)), dim3(kBlock), 0, c->stream, S, nrec, b, hm, ha);
     KCHECK();
   }
   bool sorted_ok = false;
-  RC(hybrid_sort_core<Sym>(c, S, b, kbits, hm, ha, hb, m, &h, f, &sorted_ok, depth));
+  RC(hybrid_sort_core<Sym>(c, S, b, kbits, hm, ha, hb, nrec, &h, f, &sorted_ok, depth));
   if (sorted_ok) {
     AccHyb acc; acc.h = h; acc.f = f; acc.posmask = hm.pbits >= 32 ? 0xffffffffu : ((1u << hm.pbits) - 1u);
-    const Chunking ck = make_chunks(c, m, kBlock * kNameIPT);
-    u32 *counts = nullptr;
+    const Chunking ck = make_chunks(c, nrec, kBlock);
+    u32 *counts = nullptr, *scounts = nullptr;
     RC(arena_alloc(c, (size_t)ck.nchunks + 16, &counts));
+    RC(arena_alloc(c, (size_t)ck.nchunks + 16, &scounts));
     {
-      PhaseScope ps(c, DC3HIP_PH_NAMING, m);
+      PhaseScope ps(c, DC3HIP_PH_NAMING, nrec);
       HIPC(hipMemsetAsync(c->d_words + 4, 0, sizeof(u32), c->stream));
-      hipLaunchKernelGGL((k_name_count<AccHyb>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, acc, m, ck.chunk, counts,
-                         c->d_words + 4);
+      hipLaunchKernelGGL((k_name_count<AccHyb>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, acc, nrec, ck.chunk,
+                         counts, c->d_words + 4);
       KCHECK();
       hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, counts, ck.nchunks, c->d_words);
       KCHECK();
       HIPC(hipMemcpyAsync(c->h_words, c->d_words, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
     }
     HIPC(hipStreamSynchronize(c->stream));
-    if (c->h_words[0] == m) {          // every triple distinct: the sorted order is the suffix array
+    if (c->h_words[0] == nrec) {          // every triple distinct: the sorted order is the suffix array
       Rec8 *pa = nullptr, *pb = nullptr;
       if (out_rank) {
         RC(arena_alloc(c, (size_t)m, &pa));
@@ -656,12 +663,24 @@ static int order_all_positions(dc3hip_ctx *c, Sym S, u32 m, u32 b, u32 kbits, u3
       }
       {
         PhaseScope ps(c, DC3HIP_PH_RANKS, m);
-        hipLaunchKernelGGL((k_emit_sorted<AccHyb>), dim3(grid_for(c, m)), dim3(kBlock), 0, c->stream, acc, m, out_sa,
-                           pa);
+        hipLaunchKernelGGL((k_emit_sorted<AccHyb>), dim3(grid_for(c, m)), dim3(kBlock), 0, c->stream, acc, m, dummy,
+                           out_sa, pa);
         KCHECK();
       }
       if (out_rank) RC(inverse_permute(c, pa, pb, m, out_rank, DC3HIP_PH_RANKS));
-      *done = true;
+      *state = 1;
+    } else {                              // keep the sort: filter the samples with their full names
+      PhaseScope ps(c, DC3HIP_PH_NAMING, nrec);
+      hipLaunchKernelGGL((k_filter_count<AccHyb>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, acc, nrec, ck.chunk,
+                         scounts);
+      KCHECK();
+      hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, scounts, ck.nchunks, (u32 *)nullptr);
+      KCHECK();
+      hipLaunchKernelGGL((k_filter_write<AccHyb>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, acc, nrec, ck.chunk,
+                         counts, scounts, spos, snf);
+      KCHECK();
+      (void)m02;
+      *state = 2;
     }
   }
   arena_release(c, mk);
@@ -736,15 +755,24 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
       c->stats.level_tie_pred[depth] = pred;
       if (pred < kFullSortMaxPredicted && !c->no_fullsort) {
         // high entropy: try to finish the whole level by sorting all of its positions
-        bool whole = false;
-        RC(order_all_positions<Sym>(c, S, m, b, kbits, out_sa, out_rank, &whole, depth));
-        if (whole) {
+        u32 *spos = nullptr, *snf = nullptr;
+        RC(arena_alloc(c, (size_t)m02 + 16, &spos));
+        RC(arena_alloc(c, (size_t)m02 + 16, &snf));
+        int state = 0;
+        RC(order_all_positions<Sym>(c, S, m, m02, b, kbits, out_sa, out_rank, spos, snf, &state, depth));
+        if (state == 1) {
           c->stats.level_sorted[depth] = 5;
           arena_release(c, mk0);
           return E_OK;
         }
+        if (state == 2) {      // sorted sample order is already there: name it and continue as usual
+          c->stats.level_sorted[depth] = 2;
+          AccFilt acc; acc.spos = spos; acc.snf = snf;
+          RC(name_and_rank<AccFilt>(c, acc, m02, m0, sa12, rank12, R, sslot, &names, &mode));
+          done = true;
+        }
       }
-      if (pred < kHybridMaxPredicted) {
+      if (!done && pred < kHybridMaxPredicted) {
         bool ok = false;
         RC(order_hybrid<Sym>(c, S, m, m0, m02, b, kbits, sa12, rank12, R, sslot, &names, &mode, &ok, depth));
         done = ok;

@@ -327,7 +327,10 @@ def test_hybrid_and_straight_paths_agree(ss, oracle):
     rnd = oracle.gen(n, 21, 0).tobytes()
     # a long zero run inside random data: few ties overall, but one huge tie group (radix sub-path)
     zrun = rnd[:n // 2] + bytes(300_000) + rnd[n // 2 + 300_000:]
-    cases = {"random": rnd, "text": texty, "repeat": half + half + b"!", "zero_run": zrun}
+    # random data with one duplicated 200 KB block: the whole-level sort finds duplicate triples and its
+    # result is filtered down to the samples instead of being thrown away
+    dup = rnd[:3_000_000] + rnd[1_000_000:1_200_000] + rnd[3_200_000:]
+    cases = {"random": rnd, "text": texty, "repeat": half + half + b"!", "zero_run": zrun, "dup_block": dup}
     for label, data in cases.items():
         want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)
         seen = {}
@@ -349,6 +352,8 @@ def test_hybrid_and_straight_paths_agree(ss, oracle):
             assert 5 in seen[()]["level_sorted"], seen[()]["level_sorted"]       # whole level ordered at once
         if label in ("random", "zero_run"):
             assert any(v in (2, 4) for v in seen[("DC3HIP_NO_FULLSORT",)]["level_sorted"])   # 4 = 2 + discarding
+        if label == "dup_block":
+            assert 5 not in seen[()]["level_sorted"] and any(v in (2, 4) for v in seen[()]["level_sorted"])
             # small-group path skips the 16-byte radix passes entirely; the zero run forces them
             d16 = seen[()]["downsweep_launches"][1]
             assert (d16 == 0) if label == "random" else (d16 > 0), (label, d16)
