@@ -400,24 +400,45 @@ __global__ __launch_bounds__(kBlock) void k_tie_count(const Rec8 *__restrict__ h
 // the slot it came from
 template <class Sym>
 __global__ __launch_bounds__(kBlock) void k_tie_compact(Sym S, u32 b, const Rec8 *__restrict__ h, u32 n, u32 chunk,
-                                                       u32 pbits,
-                                                       const u32 *__restrict__ base_excl, Rec16 *__restrict__ sub,
-                                                       u32 *__restrict__ tiedidx, u32 *__restrict__ gkey) {
+                                                       u32 pbits, const u32 *__restrict__ base_excl,
+                                                       Rec16 *__restrict__ sub, u32 *__restrict__ tiedidx,
+                                                       u32 *__restrict__ gkey) {
+  // 4 consecutive records per thread and block scan (few ties: most threads only read)
   __shared__ u32 tmp[kWaves];
+  constexpr u32 kIPT = 4, kTile = kBlock * kIPT;
   const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
+  const u32 posmask = pbits >= 32 ? 0xffffffffu : ((1u << pbits) - 1u);
   u32 running = base_excl[blockIdx.x];
-  for (u32 tile = begin; tile < end; tile += kBlock) {
-    const u32 i = tile + threadIdx.x;
-    const bool f = (i < end) && hyb_tied(h, i, n, pbits);
+  for (u32 tile = begin; tile < end; tile += kTile) {
+    const u32 i0 = tile + threadIdx.x * kIPT;
+    // image of records i0-1 .. i0+kIPT (neighbours decide "tied")
+    u64 img[kIPT + 2];
+#pragma unroll
+    for (int j = 0; j < (int)kIPT + 2; j++) {
+      const u32 i = i0 + j - 1;
+      img[j] = (i0 + j >= 1 && i < n) ? (rec8_word(h[i]) >> pbits) : ~0ull - j;   // distinct fillers
+    }
+    u32 fl[kIPT], local = 0;
+#pragma unroll
+    for (int j = 0; j < (int)kIPT; j++) {
+      const u32 i = i0 + j;
+      fl[j] = (i < end && (img[j + 1] == img[j] || img[j + 1] == img[j + 2])) ? 1u : 0u;
+      local += fl[j];
+    }
     u32 tot;
-    const u32 ex = block_excl_scan<kWaves>(f ? 1u : 0u, tmp, tot);
-    if (f) {
-      const u32 p = h[i].val & (pbits >= 32 ? 0xffffffffu : ((1u << pbits) - 1u));
-      sub[running + ex] = make_rec(S.get(p), S.get(p + 1), S.get(p + 2), b, p);
-      tiedidx[running + ex] = i;
-      // group id = low 32 bits of the key image; merging two adjacent groups that differ only above
-      // bit 31 is harmless (the union is sorted by the full key)
-      gkey[running + ex] = (u32)(rec8_word(h[i]) >> pbits);
+    u32 o = running + block_excl_scan<kWaves>(local, tmp, tot);
+#pragma unroll
+    for (int j = 0; j < (int)kIPT; j++) {
+      if (fl[j]) {
+        const u32 i = i0 + j;
+        const u32 p = h[i].val & posmask;
+        sub[o] = make_rec(S.get(p), S.get(p + 1), S.get(p + 2), b, p);
+        tiedidx[o] = i;
+        // group id = low 32 bits of the key image; merging two adjacent groups that differ only above
+        // bit 31 is harmless (the union is sorted by the full key)
+        gkey[o] = (u32)img[j + 1];
+        o++;
+      }
     }
     running += tot;
   }
