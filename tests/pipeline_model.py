@@ -5,6 +5,7 @@ It mirrors dc3_level() in dc3hip.hip step by step; kernels become numpy expressi
 TEST INFRASTRUCTURE ONLY."""
 import numpy as np
 
+FULLSORT = True      # model of the whole-level shortcut (all triples of a level distinct -> sorted triples = SA)
 DISCARD = True       # model of the "discarding" recursion (unique names leave the recursion), see dc3hip.hip
 WIDE_NAMES = False   # True = as many symbols per direct name as fit 31 bits (DC3HIP_WIDE_NAMES=1)
 
@@ -44,6 +45,15 @@ def level(S, m, K, trace=None, depth=0):
         R[m0 + g[has2]] = (n2 + 1)[has2]
         sa12, rank12 = level(R, m02, B ** w, trace, depth + 1)
     else:                                                      # k_pack_triples + radix sort + naming
+        if FULLSORT:                                           # order_all_positions: every position + the dummy
+            allp = np.arange(m + (1 if m % 3 == 1 else 0), dtype=np.int64)
+            ak = np.stack([_sym_get(S, m, allp), _sym_get(S, m, allp + 1), _sym_get(S, m, allp + 2)], 1)
+            aperm = np.lexsort((ak[:, 2], ak[:, 1], ak[:, 0]))
+            aks = ak[aperm]
+            if len(allp) == 1 or np.all(np.any(aks[1:] != aks[:-1], axis=1)):
+                sa = allp[aperm][(1 if m % 3 == 1 else 0):]    # the dummy sorts first
+                rank = np.zeros(m, dtype=np.int64); rank[sa] = np.arange(1, m + 1)
+                return sa, rank
         pos = np.concatenate([3 * g + 1, (3 * g + 2)[has2]])
         keys = np.concatenate([np.stack([s[1], s[2], s[3]], 1), np.stack([s[2], s[3], s[4]], 1)[has2]])
         order = np.argsort(pos, kind="stable")                 # ascending text position

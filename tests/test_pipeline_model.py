@@ -63,8 +63,9 @@ def test_model_discarding_on_and_off(oracle, corpus):
     for data in cases:
         want = oracle.sufsort(data).tolist()
         for flag in (True, False):
-            pm.DISCARD = flag
-            try:
-                assert pm.sufsort(data).tolist() == want, (len(data), flag)
-            finally:
-                pm.DISCARD = True
+            for full in (True, False):
+                pm.DISCARD = flag; pm.FULLSORT = full
+                try:
+                    assert pm.sufsort(data).tolist() == want, (len(data), flag, full)
+                finally:
+                    pm.DISCARD = True; pm.FULLSORT = True
