@@ -28,6 +28,7 @@ struct Rec12 { u32 k0, k1, pos; };
 struct __attribute__((aligned(16))) Tup12 { u32 pos, r, c0, cx; };
 // Merge tuple of a mod-0 suffix j: (c0=S[j], c1=S[j+1], r1=rank[j+1], r2=rank[j+2]), 20 B.
 struct Tup0 { u32 pos, c0, c1, r1, r2; };
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------------------------
 // Symbol readers: level 0 reads bytes through the dense code table (codes 1..sigma, 0 past the

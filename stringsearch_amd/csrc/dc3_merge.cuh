@@ -50,7 +50,6 @@ __global__ __launch_bounds__(kBlock) void k_gather_tuples(const Tup12 *__restric
   const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
   u32 i = begin + threadIdx.x;
   // the index stream and the output stream are touched once: non-temporal
-  typedef u32 u32x4 __attribute__((ext_vector_type(4)));
   const u32x4 *tv = reinterpret_cast<const u32x4 *>(tslot);
   u32x4 *ov = reinterpret_cast<u32x4 *>(out);
   // 4 independent 16-byte gathers in flight per thread;  .x = pos, .w = cx
@@ -137,7 +136,6 @@ __global__ __launch_bounds__(kBlock) void k_merge_partition(const Tup12 *__restr
 // LDS image of a tile: sample tuples as 16-byte words (pos, r, c0, cx); mod-0 tuples split into a
 // 16-byte comparison key (c0, c1, r1, r2) and a separate pos array, so that every comparison is two
 // ds_read_b128 (the packed 20-byte Tup0 would be five ds_read_b32).
-typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bool sample_before4(const u32x4 a /*pos,r,c0,cx*/, const u32x4 z /*c0,c1,r1,r2*/) {
   if (is_mod1(a.x)) return (a.z < z.x) || (a.z == z.x && a.y <= z.z);                                   // leq2
   return (a.z < z.x) || (a.z == z.x && ((a.w < z.y) || (a.w == z.y && a.y <= z.w)));                    // leq3

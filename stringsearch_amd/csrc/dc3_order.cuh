@@ -305,6 +305,67 @@ __device__ __forceinline__ Rec8 hyb_rec(const Rec16 &r, HiMap hm) {
   const u64 w = (hi << hm.pbits) | r.pos;
   return Rec8{(u32)(w >> 32), (u32)w};
 }
+// Key makers: the full sort key of position p.  Key3 = the K–S triple of a level's string; Key9 = 9 bytes of the
+// text (three packed byte-triples: exactly the triple key the level-1 string has at the slot of p), used by the
+// level-0 whole-text shortcut.
+template <class Sym>
+struct Key3 {
+  Sym S; u32 B;
+  __device__ __forceinline__ void stage(uint16_t *) const {}
+  __device__ __forceinline__ Rec16 make(u32 p, const uint16_t *) const {
+    return make_rec(S.get(p), S.get(p + 1), S.get(p + 2), B, p);
+  }
+};
+struct Key9 {
+  SymU8 S; u32 B /* sigma+1 */, B3 /* B^3 */;
+  __device__ __forceinline__ void stage(uint16_t *lds) const { S.stage(lds); }
+  __device__ __forceinline__ Rec16 make(u32 p, const uint16_t *lds) const {
+    u32 w[3]; __builtin_memcpy(w, S.t + p, 12);        // one unaligned 12-byte load (64 zero bytes pad the text)
+    u32 q[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) q[k] = (p + k < S.m) ? (u32)lds[(w[k >> 2] >> (8 * (k & 3))) & 255u] : 0u;
+    const u32 t0 = (q[0] * B + q[1]) * B + q[2];
+    const u32 t1 = (q[3] * B + q[4]) * B + q[5];
+    const u32 t2 = (q[6] * B + q[7]) * B + q[8];
+    return make_rec(t0, t1, t2, B3, p);
+  }
+};
+// whole text, 4 consecutive positions per thread: 12 aligned text bytes -> 12 codes -> 10 byte-triples shared by
+// the 4 keys; 32 contiguous output bytes per thread
+__global__ __launch_bounds__(kBlock) void k_pack_image_text(Key9 km, u32 n, HiMap hm, Rec8 *__restrict__ out) {
+  __shared__ uint16_t lcode[256];
+  km.stage(lcode);
+  const u32 nq = (n + 3) / 4;
+  for (u32 g = blockIdx.x * kBlock + threadIdx.x; g < nq; g += gridDim.x * kBlock) {
+    const u32 p0 = 4 * g;
+    const u32 *tw = reinterpret_cast<const u32 *>(km.S.t + p0);
+    const u32 w[3] = {tw[0], tw[1], tw[2]};
+    u32 q[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) q[k] = (p0 + k < n) ? (u32)lcode[(w[k >> 2] >> (8 * (k & 3))) & 255u] : 0u;
+    u32 u[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) u[k] = (q[k] * km.B + q[k + 1]) * km.B + q[k + 2];
+    Rec8 r[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) r[j] = hyb_rec(make_rec(u[j], u[j + 3], u[j + 6], km.B3, p0 + j), hm);
+    if (p0 + 3 < n) {
+      u32x4 *o = reinterpret_cast<u32x4 *>(out + p0);
+      o[0] = u32x4{r[0].key, r[0].val, r[1].key, r[1].val};
+      o[1] = u32x4{r[2].key, r[2].val, r[3].key, r[3].val};
+    } else {
+      for (int j = 0; j < 4; j++) if (p0 + j < n) out[p0 + j] = r[j];
+    }
+  }
+}
+// records of positions 0, stride, 2*stride, ... (stride 1 = all positions; > 1 = tie-rate predictor sample)
+template <class KM>
+__global__ __launch_bounds__(kBlock) void k_pack_image_pos(KM km, u32 nout, u32 stride, HiMap hm, Rec8 *out) {
+  __shared__ uint16_t lcode[256];
+  km.stage(lcode);
+  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < nout; i += gridDim.x * kBlock)
+    out[i] = hyb_rec(km.make(i * stride, lcode), hm);
+}
 // stride > 1 samples every stride-th group (tie-rate predictor); out index = g / stride
 template <class Sym>
 __global__ __launch_bounds__(kBlock) void k_pack_image(Sym S, u32 m, u32 m0, u32 m02, u32 b, HiMap hm, u32 stride,
@@ -320,14 +381,6 @@ __global__ __launch_bounds__(kBlock) void k_pack_image(Sym S, u32 m, u32 m0, u32
       else out[2 * go + 1] = Rec8{0xffffffffu, 0xffffffffu};
     }
   }
-}
-// the same records for ALL positions 0..m-1 (whole-level shortcut: if every triple of the level is
-// distinct, the sorted triples are the suffix array of the level and no sampling / merge is needed)
-template <class Sym>
-__global__ __launch_bounds__(kBlock) void k_pack_image_all(Sym S, u32 nrec, u32 b, HiMap hm, Rec8 *out) {
-  // nrec = m, or m+1 to include the dummy sample at position m (triple 0,0,0; lib.rs:61-64)
-  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < nrec; i += gridDim.x * kBlock)
-    out[i] = hyb_rec(make_rec(S.get(i), S.get(i + 1), S.get(i + 2), b, i), hm);
 }
 // all keys distinct: out_sa[k] = pos_k and the (pos_k, k+1) pairs of the rank inversion
 // `skip` = 1 when record 0 is the dummy (it always sorts first)
@@ -398,13 +451,15 @@ __global__ __launch_bounds__(kBlock) void k_tie_count(const Rec8 *__restrict__ h
 }
 // compacts the tied elements (order preserving): full-key record rebuilt from S, and the index of
 // the slot it came from
-template <class Sym>
-__global__ __launch_bounds__(kBlock) void k_tie_compact(Sym S, u32 b, const Rec8 *__restrict__ h, u32 n, u32 chunk,
+template <class KM>
+__global__ __launch_bounds__(kBlock) void k_tie_compact(KM km, const Rec8 *__restrict__ h, u32 n, u32 chunk,
                                                        u32 pbits, const u32 *__restrict__ base_excl,
                                                        Rec16 *__restrict__ sub, u32 *__restrict__ tiedidx,
                                                        u32 *__restrict__ gkey) {
   // 4 consecutive records per thread and block scan (few ties: most threads only read)
   __shared__ u32 tmp[kWaves];
+  __shared__ uint16_t lcode[256];
+  km.stage(lcode);
   constexpr u32 kIPT = 4, kTile = kBlock * kIPT;
   const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
   const u32 posmask = pbits >= 32 ? 0xffffffffu : ((1u << pbits) - 1u);
@@ -432,7 +487,7 @@ __global__ __launch_bounds__(kBlock) void k_tie_compact(Sym S, u32 b, const Rec8
       if (fl[j]) {
         const u32 i = i0 + j;
         const u32 p = h[i].val & posmask;
-        sub[o] = make_rec(S.get(p), S.get(p + 1), S.get(p + 2), b, p);
+        sub[o] = km.make(p, lcode);
         tiedidx[o] = i;
         // group id = low 32 bits of the key image; merging two adjacent groups that differ only above
         // bit 31 is harmless (the union is sorted by the full key)
@@ -443,43 +498,107 @@ __global__ __launch_bounds__(kBlock) void k_tie_compact(Sym S, u32 b, const Rec8
     running += tot;
   }
 }
-// Tied samples form groups (equal key image) that are tiny on high-entropy input (Poisson: almost all of
-// size 2-3).  When the largest group has at most kTieSmallMax members, one thread per group sorts
-// it by the full key with a stable insertion sort — instead of 10 radix passes over the subset.
+// Tied records form groups (equal key image) that are tiny on high-entropy input (Poisson: almost all of
+// size 2-3); groups of at most kTieSmallMax members are settled by one thread each (k_tie_resolve), the
+// general path radix-sorts the compacted subset by the full key.
 constexpr u32 kTieSmallMax = 16;
-__global__ __launch_bounds__(kBlock) void k_tie_groupmax(const u32 *__restrict__ gkey, u32 t, u32 *maxlen) {
-  u32 best = 0;
-  for (u32 j = blockIdx.x * kBlock + threadIdx.x; j < t; j += gridDim.x * kBlock) {
-    const u32 k = gkey[j];
-    if (j > 0 && gkey[j - 1] == k) continue;            // not a group start
-    u32 e = j + 1;
-    while (e < t && e - j <= kTieSmallMax && gkey[e] == k) e++;
-    best = max(best, e - j);
-  }
-  best = wave_reduce_max(best);
-  if (lane_id() == 0 && best) atomicMax(maxlen, best);
-}
 __device__ __forceinline__ bool key_less(const Rec16 &a, const Rec16 &b) {
   if (a.k2 != b.k2) return a.k2 < b.k2;
   if (a.k1 != b.k1) return a.k1 < b.k1;
   return a.k0 < b.k0;
 }
-__global__ __launch_bounds__(kBlock) void k_tie_sort_small(const Rec16 *__restrict__ sub, const u32 *__restrict__ gkey,
-                                                          u32 t, Rec16 *__restrict__ out) {
-  for (u32 j = blockIdx.x * kBlock + threadIdx.x; j < t; j += gridDim.x * kBlock) {
-    const u32 k = gkey[j];
-    if (j > 0 && gkey[j - 1] == k) continue;
-    u32 e = j + 1;
-    while (e < t && gkey[e] == k) e++;
-    const u32 len = e - j;                               // <= kTieSmallMax (checked by the host)
-    Rec16 loc[kTieSmallMax];
-    for (u32 x = 0; x < len; x++) {                      // stable insertion sort (input is in position order)
-      const Rec16 v = sub[j + x];
-      u32 y = x;
-      while (y > 0 && key_less(v, loc[y - 1])) { loc[y] = loc[y - 1]; y--; }
-      loc[y] = v;
+// The common case in one pass over the sorted records: the thread that sees the start of a tied group of at
+// most kTieSmallMax members rebuilds the members' full keys (one gather each), orders them (stable insertion
+// sort; the LSD passes left them in position order) and rewrites their positions in place, keeping the key
+// image so that concurrent neighbour tests see unchanged images.  f[] must be pre-set to 1.  A larger group
+// raises *overflow and is left to the general path (k_tie_compact .. k_tie_writeback).
+// words[0] = overflow flag, words[1] += tied records, words[2] += records whose full key equals the predecessor's
+// (settled groups only).  emit_sa != nullptr: also write the positions in sorted order to emit_sa[i - skip]
+// (complete when words[0] == 0; it is the suffix array when words[2] == 0 as well).
+template <class KM>
+__global__ __launch_bounds__(kBlock) void k_tie_resolve(KM km, Rec8 *__restrict__ h, u32 n, u32 pbits,
+                                                       uint8_t *__restrict__ f, u32 *words,
+                                                       u32 *__restrict__ emit_sa, u32 skip) {
+  // Group starts are sparse (a few per wave): a block first collects the starts of a 4096-record tile in
+  // LDS, then full waves work the list, so the dependent gathers of many groups are in flight together.
+  constexpr u32 kIPT = 4, kTile = kBlock * kIPT;
+  __shared__ uint16_t lcode[256];
+  __shared__ u32 starts[kTile / 2];
+  __shared__ u32 nstart, ntied, ndup;
+  km.stage(lcode);
+  const u32 posmask = pbits >= 32 ? 0xffffffffu : ((1u << pbits) - 1u);
+  const u32 ntiles = (n + kTile - 1) / kTile;
+  if (threadIdx.x == 0) { ntied = 0; ndup = 0; }
+  for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    if (threadIdx.x == 0) nstart = 0;
+    __syncthreads();
+    u32 tied = 0;
+#pragma unroll
+    for (u32 j = 0; j < kIPT; j++) {
+      const u32 i = tile * kTile + j * kBlock + threadIdx.x;
+      if (i < n) {
+        const Rec8 r = h[i];
+        const u64 a = rec8_word(r) >> pbits;
+        const bool eqp = i > 0 && (rec8_word(h[i - 1]) >> pbits) == a;
+        const bool eqn = i + 1 < n && (rec8_word(h[i + 1]) >> pbits) == a;
+        if (eqn && !eqp) starts[atomicAdd(&nstart, 1u)] = i;
+        if (eqn || eqp) tied++;
+        else if (emit_sa && i >= skip) emit_sa[i - skip] = r.val & posmask;
+      }
     }
-    for (u32 x = 0; x < len; x++) out[j + x] = loc[x];
+    tied = wave_reduce(tied);
+    if (lane_id() == 0 && tied) atomicAdd(&ntied, tied);
+    __syncthreads();
+    const u32 ns = nstart;
+    u32 dup = 0;
+    for (u32 s = threadIdx.x; s < ns; s += kBlock) {
+      const u32 i = starts[s];
+      const Rec8 h0 = h[i];
+      const u64 a = rec8_word(h0) >> pbits;
+      u32 e = i + 2;
+      while (e < n && e - i <= kTieSmallMax && (rec8_word(h[e]) >> pbits) == a) e++;
+      const u32 len = e - i;
+      if (len > kTieSmallMax) { words[0] = 1u; continue; }
+      const u32 lo_img = h0.val & ~posmask;
+      Rec8 o; o.key = h0.key;
+      if (len == 2) {
+        Rec16 x = km.make(h0.val & posmask, lcode), y = km.make(h[i + 1].val & posmask, lcode);
+        if (key_less(y, x)) { const Rec16 t = x; x = y; y = t; }
+        o.val = lo_img | x.pos; h[i] = o;
+        o.val = lo_img | y.pos; h[i + 1] = o;
+        const bool ne = key_neq(x, y);
+        f[i + 1] = ne ? 1 : 0;
+        dup += ne ? 0u : 1u;
+        if (emit_sa) {
+          if (i >= skip) emit_sa[i - skip] = x.pos;
+          emit_sa[i + 1 - skip] = y.pos;
+        }
+        continue;
+      }
+      Rec16 loc[kTieSmallMax];
+      for (u32 x = 0; x < len; x++) {
+        const Rec16 v = km.make(h[i + x].val & posmask, lcode);
+        u32 y = x;
+        while (y > 0 && key_less(v, loc[y - 1])) { loc[y] = loc[y - 1]; y--; }
+        loc[y] = v;
+      }
+      for (u32 x = 0; x < len; x++) {
+        o.val = lo_img | loc[x].pos;
+        h[i + x] = o;
+        if (x > 0) {
+          const bool ne = key_neq(loc[x], loc[x - 1]);
+          f[i + x] = ne ? 1 : 0;
+          dup += ne ? 0u : 1u;
+        }
+        if (emit_sa && i + x >= skip) emit_sa[i + x - skip] = loc[x].pos;
+      }
+    }
+    if (dup) atomicAdd(&ndup, dup);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (ntied) atomicAdd(&words[1], ntied);
+    if (ndup) atomicAdd(&words[2], ndup);
   }
 }
 __global__ __launch_bounds__(kBlock) void k_tie_writeback(const Rec16 *__restrict__ sub, const u32 *__restrict__ tiedidx,

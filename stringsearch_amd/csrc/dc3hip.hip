@@ -73,7 +73,7 @@ struct dc3hip_ctx {
   int merge_cfg = 3;
   bool no_small_ties = false;
   bool wide_names = false;
-  bool no_nine_bit = false, no_rec12 = false, no_discard = false, no_fullsort = false;
+  bool no_nine_bit = false, no_rec12 = false, no_discard = false, no_fullsort = false, no_text_shortcut = false;
   std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
   std::vector<PhaseMark> marks;
   hipEvent_t ev_build_a = nullptr, ev_build_b = nullptr;
@@ -449,11 +449,12 @@ static constexpr u32 kHybridMinSamples = 1u << 22;
 static constexpr double kHybridMaxPredicted = 0.50;
 static constexpr double kHybridMaxMeasured = 0.60;
 static constexpr double kFullSortMaxPredicted = 0.10;   // whole-level shortcut only for very few predicted ties
+static constexpr double kTextSortMaxPredicted = 0.30;   // whole-text shortcut (33-bit images at 2^30 bytes tie ~12 %)
 // hi = floor(X * mfix / 2^64) in N = min(64 - pbits, kbits) bits; X = key >> shx; see HiMap
-static HiMap make_himap(u64 B, u32 kbits, u32 m) {
+static HiMap make_himap(u64 B, u32 kbits, u32 m, u32 pbits = 0) {
   const unsigned __int128 mx = (unsigned __int128)B * B * B - 1;      // largest key
   HiMap hm;
-  hm.pbits = bits_of((u64)m + 2);
+  hm.pbits = pbits ? pbits : bits_of((u64)m + 2);
   hm.nbits = std::min<u32>(64 - hm.pbits, kbits);
   hm.exact = kbits <= hm.nbits ? 1u : 0u;
   hm.shx = kbits > 64 ? kbits - 64 : 0;
@@ -525,10 +526,12 @@ static int order_straight(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u
 
 // Core of the prefix-sort + tie-refine ordering: `ha` holds nrec packed (image << pbits | pos) records of the
 // positions to order; on return (ok) h = records sorted by the full key, f[i] = key differs from predecessor.
-template <class Sym>
-static int hybrid_sort_core(dc3hip_ctx *c, Sym S, u32 b, u32 kbits, const HiMap &hm, Rec8 *ha, Rec8 *hb, u32 nrec,
-                            Rec8 **h_out, uint8_t *f, bool *ok, int depth) {
+template <class KM>
+static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Rec8 *ha, Rec8 *hb, u32 nrec,
+                            Rec8 **h_out, uint8_t *f, bool *ok, int depth, u32 *emit_sa = nullptr, u32 skip = 0,
+                            bool *emitted_distinct = nullptr) {
   *ok = false;
+  if (emitted_distinct) *emitted_distinct = false;
   Rec8 *h = nullptr;
   RC(radix_sort<Rec8>(c, ha, hb, nrec, hm.pbits, hm.pbits + hm.nbits, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN,
                       DC3HIP_PH_SORT8_DOWN));
@@ -536,44 +539,47 @@ static int hybrid_sort_core(dc3hip_ctx *c, Sym S, u32 b, u32 kbits, const HiMap 
   u32 *counts = nullptr;
   RC(arena_alloc(c, (size_t)ck.nchunks + 16, &counts));
   u32 tied = 0;
-  {
+  bool general = false;
+  HIPC(hipMemsetAsync(f, 1, (size_t)nrec, c->stream));
+  if (!c->no_small_ties) {
+    // one in-place pass counts the tied records and settles every tied group of at most kTieSmallMax members
+    {
+      PhaseScope ps(c, DC3HIP_PH_TIES, nrec);
+      HIPC(hipMemsetAsync(c->d_words + 10, 0, 3 * sizeof(u32), c->stream));
+      hipLaunchKernelGGL((k_tie_resolve<KM>), dim3(grid_for(c, nrec / 4 + 1)), dim3(kBlock), 0, c->stream, km, h, nrec,
+                         hm.pbits, f, c->d_words + 10, emit_sa, skip);
+      KCHECK();
+      HIPC(hipMemcpyAsync(c->h_words + 10, c->d_words + 10, 3 * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPC(hipStreamSynchronize(c->stream));
+    tied = c->h_words[11];
+    c->stats.level_tied[depth] = tied;
+    if ((double)tied > kHybridMaxMeasured * (double)nrec) return E_OK;   // *ok stays false -> straight LSD
+    general = c->h_words[10] != 0;       // some group is larger: redo the ties with the general path
+    if (!general && emit_sa && emitted_distinct && c->h_words[12] == 0) *emitted_distinct = true;
+  }
+  if (general || c->no_small_ties) {
     PhaseScope ps(c, DC3HIP_PH_TIES, nrec);
     RC(count_ties(c, h, nrec, hm.pbits, counts, ck, &tied));
+    c->stats.level_tied[depth] = tied;
+    if ((double)tied > kHybridMaxMeasured * (double)nrec) return E_OK;
+    general = tied > 0;
   }
-  c->stats.level_tied[depth] = tied;
-  if ((double)tied > kHybridMaxMeasured * (double)nrec) return E_OK;   // *ok stays false -> straight LSD
-  HIPC(hipMemsetAsync(f, 1, (size_t)nrec, c->stream));
-  if (tied > 0) {
+  if (general) {
     Rec16 *sa = nullptr, *sb = nullptr, *ss = nullptr;
     u32 *tiedidx = nullptr, *gkey = nullptr;
     RC(arena_alloc(c, (size_t)tied, &sa));
     RC(arena_alloc(c, (size_t)tied, &sb));
     RC(arena_alloc(c, (size_t)tied, &tiedidx));
     RC(arena_alloc(c, (size_t)tied, &gkey));
-    u32 gmax = 0;
     {
       PhaseScope ps(c, DC3HIP_PH_TIES, tied);
-      hipLaunchKernelGGL((k_tie_compact<Sym>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, S, b, h, nrec, ck.chunk,
+      hipLaunchKernelGGL((k_tie_compact<KM>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, km, h, nrec, ck.chunk,
                          hm.pbits, counts, sa, tiedidx, gkey);
       KCHECK();
-      HIPC(hipMemsetAsync(c->d_words + 3, 0, sizeof(u32), c->stream));
-      hipLaunchKernelGGL(k_tie_groupmax, dim3(grid_for(c, tied)), dim3(kBlock), 0, c->stream, gkey, tied,
-                         c->d_words + 3);
-      KCHECK();
-      HIPC(hipMemcpyAsync(c->h_words + 3, c->d_words + 3, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
     }
-    HIPC(hipStreamSynchronize(c->stream));
-    gmax = c->h_words[3];
-    if (gmax <= kTieSmallMax && !c->no_small_ties) {
-      // tiny groups: one thread sorts one group by the full key
-      PhaseScope ps(c, DC3HIP_PH_TIES, tied);
-      hipLaunchKernelGGL(k_tie_sort_small, dim3(grid_for(c, tied)), dim3(kBlock), 0, c->stream, sa, gkey, tied, sb);
-      KCHECK();
-      ss = sb;
-    } else {
-      RC(radix_sort<Rec16>(c, sa, sb, tied, 0, kbits, &ss, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN,
-                           DC3HIP_PH_SORT12_DOWN));
-    }
+    RC(radix_sort<Rec16>(c, sa, sb, tied, 0, kbits, &ss, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN,
+                         DC3HIP_PH_SORT12_DOWN));
     {
       PhaseScope ps(c, DC3HIP_PH_TIES, tied);
       hipLaunchKernelGGL(k_tie_writeback, dim3(grid_for(c, tied)), dim3(kBlock), 0, c->stream, ss, tiedidx, tied, h, f);
@@ -582,6 +588,32 @@ static int hybrid_sort_core(dc3hip_ctx *c, Sym S, u32 b, u32 kbits, const HiMap 
   }
   *h_out = h;
   *ok = true;
+  return E_OK;
+}
+
+// tie-rate predictor over all positions (stride sample) for the whole-text shortcut of level 0
+template <class KM>
+static int predict_tie_fraction_pos(dc3hip_ctx *c, KM km, u32 n, const HiMap &hm, double *pred) {
+  const ArenaMark mk = arena_mark(c);
+  const u32 stride = std::max<u32>(1, n >> 20);
+  const u32 ns = (n - 1) / stride + 1;
+  Rec8 *a = nullptr, *bb = nullptr, *sorted = nullptr;
+  RC(arena_alloc(c, (size_t)ns, &a));
+  RC(arena_alloc(c, (size_t)ns, &bb));
+  PhaseScope ps(c, DC3HIP_PH_PACK, ns);
+  hipLaunchKernelGGL((k_pack_image_pos<KM>), dim3(grid_for(c, ns)), dim3(kBlock), 0, c->stream, km, ns, stride, hm, a);
+  KCHECK();
+  RC(radix_sort<Rec8>(c, a, bb, ns, hm.pbits, hm.pbits + hm.nbits, &sorted, DC3HIP_PH_PACK, DC3HIP_PH_PACK,
+                      DC3HIP_PH_PACK));
+  const Chunking ck = make_chunks(c, ns, kBlock);
+  u32 *counts = nullptr;
+  RC(arena_alloc(c, (size_t)ck.nchunks + 16, &counts));
+  u32 ts = 0;
+  RC(count_ties(c, sorted, ns, hm.pbits, counts, ck, &ts));
+  const double fs = (double)ts / (double)ns;
+  const double ratio = (double)(n - 1) / (double)(ns > 1 ? ns - 1 : 1);
+  *pred = fs >= 1.0 ? 1.0 : 1.0 - pow(1.0 - fs, ratio);
+  arena_release(c, mk);
   return E_OK;
 }
 
@@ -602,7 +634,8 @@ static int order_hybrid(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u32
     KCHECK();
   }
   bool sorted_ok = false;
-  RC(hybrid_sort_core<Sym>(c, S, b, kbits, hm, ha, hb, m02, &h, f, &sorted_ok, depth));
+  Key3<Sym> km; km.S = S; km.B = b;
+  RC((hybrid_sort_core<Key3<Sym>>(c, km, kbits, hm, ha, hb, m02, &h, f, &sorted_ok, depth)));
   if (!sorted_ok) return E_OK;
   c->stats.level_sorted[depth] = 2;
   AccHyb acc; acc.h = h; acc.f = f; acc.posmask = hm.pbits >= 32 ? 0xffffffffu : ((1u << hm.pbits) - 1u);
@@ -618,14 +651,20 @@ static int order_hybrid(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u32
 //            naming continues from there and the sort is not repeated;
 //   state 0: too many collisions in the key image, nothing was produced.
 // spos/snf (m02 entries each) must be allocated by the caller below this function's arena mark.
-template <class Sym>
-static int order_all_positions(dc3hip_ctx *c, Sym S, u32 m, u32 m02, u32 b, u32 kbits, u32 *out_sa, u32 *out_rank,
-                               u32 *spos, u32 *snf, int *state, int depth) {
+template <class KM>
+static void launch_pack_all(dc3hip_ctx *c, KM km, u32 nrec, const HiMap &hm, Rec8 *out) {
+  hipLaunchKernelGGL((k_pack_image_pos<KM>), dim3(grid_for(c, nrec)), dim3(kBlock), 0, c->stream, km, nrec, 1u, hm, out);
+}
+template <>
+void launch_pack_all<Key9>(dc3hip_ctx *c, Key9 km, u32 nrec, const HiMap &hm, Rec8 *out) {
+  hipLaunchKernelGGL(k_pack_image_text, dim3(grid_for(c, (nrec + 3) / 4)), dim3(kBlock), 0, c->stream, km, nrec, hm, out);
+}
+template <class KM>
+static int order_all_positions(dc3hip_ctx *c, KM km, u32 m, u32 kbits, const HiMap &hm, u32 dummy, u32 *out_sa,
+                               u32 *out_rank, u32 *spos, u32 *snf, int *state, int depth) {
   *state = 0;
   const ArenaMark mk = arena_mark(c);
-  const HiMap hm = make_himap((u64)b, kbits, m);
-  const u32 dummy = (m % 3 == 1) ? 1u : 0u;
-  const u32 nrec = m + dummy;
+  const u32 nrec = m + dummy;              // dummy = 1: include the dummy sample at position m (lib.rs:61-64)
   Rec8 *ha = nullptr, *hb = nullptr, *h = nullptr;
   uint8_t *f = nullptr;
   RC(arena_alloc(c, (size_t)nrec, &ha));
@@ -633,12 +672,15 @@ static int order_all_positions(dc3hip_ctx *c, Sym S, u32 m, u32 m02, u32 b, u32 
   RC(arena_alloc(c, (size_t)nrec + 16, &f));
   {
     PhaseScope ps(c, DC3HIP_PH_PACK, nrec);
-    hipLaunchKernelGGL((k_pack_image_all<Sym>), dim3(grid_for(c, nrec)), dim3(kBlock), 0, c->stream, S, nrec, b, hm, ha);
+    launch_pack_all(c, km, nrec, hm, ha);
     KCHECK();
   }
-  bool sorted_ok = false;
-  RC(hybrid_sort_core<Sym>(c, S, b, kbits, hm, ha, hb, nrec, &h, f, &sorted_ok, depth));
-  if (sorted_ok) {
+  bool sorted_ok = false, distinct = false;
+  RC((hybrid_sort_core<KM>(c, km, kbits, hm, ha, hb, nrec, &h, f, &sorted_ok, depth, out_rank ? nullptr : out_sa, dummy,
+                           &distinct)));
+  if (sorted_ok && distinct) {
+    *state = 1;                            // the tie pass already wrote the suffix array
+  } else if (sorted_ok) {
     AccHyb acc; acc.h = h; acc.f = f; acc.posmask = hm.pbits >= 32 ? 0xffffffffu : ((1u << hm.pbits) - 1u);
     const Chunking ck = make_chunks(c, nrec, kBlock);
     u32 *counts = nullptr, *scounts = nullptr;
@@ -655,7 +697,7 @@ static int order_all_positions(dc3hip_ctx *c, Sym S, u32 m, u32 m02, u32 b, u32 
       HIPC(hipMemcpyAsync(c->h_words, c->d_words, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
     }
     HIPC(hipStreamSynchronize(c->stream));
-    if (c->h_words[0] == nrec) {          // every triple distinct: the sorted order is the suffix array
+    if (c->h_words[0] == nrec) {          // every key distinct: the sorted order is the suffix array
       Rec8 *pa = nullptr, *pb = nullptr;
       if (out_rank) {
         RC(arena_alloc(c, (size_t)m, &pa));
@@ -669,7 +711,7 @@ static int order_all_positions(dc3hip_ctx *c, Sym S, u32 m, u32 m02, u32 b, u32 
       }
       if (out_rank) RC(inverse_permute(c, pa, pb, m, out_rank, DC3HIP_PH_RANKS));
       *state = 1;
-    } else {                              // keep the sort: filter the samples with their full names
+    } else if (spos && snf) {             // keep the sort: filter the samples with their full names
       PhaseScope ps(c, DC3HIP_PH_NAMING, nrec);
       hipLaunchKernelGGL((k_filter_count<AccHyb>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, acc, nrec, ck.chunk,
                          scounts);
@@ -679,7 +721,6 @@ static int order_all_positions(dc3hip_ctx *c, Sym S, u32 m, u32 m02, u32 b, u32 
       hipLaunchKernelGGL((k_filter_write<AccHyb>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, acc, nrec, ck.chunk,
                          counts, scounts, spos, snf);
       KCHECK();
-      (void)m02;
       *state = 2;
     }
   }
@@ -759,7 +800,9 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
         RC(arena_alloc(c, (size_t)m02 + 16, &spos));
         RC(arena_alloc(c, (size_t)m02 + 16, &snf));
         int state = 0;
-        RC(order_all_positions<Sym>(c, S, m, m02, b, kbits, out_sa, out_rank, spos, snf, &state, depth));
+        Key3<Sym> km; km.S = S; km.B = b;
+        RC((order_all_positions<Key3<Sym>>(c, km, m, kbits, make_himap(B, kbits, m), (m % 3 == 1) ? 1u : 0u, out_sa,
+                                           out_rank, spos, snf, &state, depth)));
         if (state == 1) {
           c->stats.level_sorted[depth] = 5;
           arena_release(c, mk0);
@@ -912,7 +955,27 @@ static int ctx_build(dc3hip_ctx *c) {
     sigma = c->h_words[1];
     if (sigma < 1 || sigma > 256) { set_err("internal: alphabet size %u", sigma); return E_HIP; }
     SymU8 S; S.t = c->d_text; S.code = c->d_code; S.m = (u32)n;
-    RC(dc3_level<SymU8>(c, S, (u32)n, sigma, c->d_sa, nullptr, 0));
+    bool whole_text = false;
+    if ((u64)n >= kHybridMinSamples && !c->no_hybrid && !c->no_fullsort && !c->no_text_shortcut &&
+        c->arena_bytes - c->arena_off >= (size_t)n * 28 + (64u << 20)) {
+      // whole-text shortcut: if all 9-byte windows of a high-entropy text are distinct, sorting all positions by
+      // them is the suffix array (the same test level 1 would make on its triples, without building level 1)
+      const u64 Bq = (u64)sigma + 1, B3 = Bq * Bq * Bq;
+      u32 kbits = 0;
+      { unsigned __int128 mx = (unsigned __int128)B3 * B3 * B3 - 1; while (mx) { kbits++; mx >>= 1; } }
+      Key9 km; km.S = S; km.B = (u32)Bq; km.B3 = (u32)B3;
+      const HiMap hm = make_himap(B3, kbits, (u32)n, bits_of((u64)n - 1));   // positions 0..n-1 only
+      double pred = 1.0;
+      RC(predict_tie_fraction_pos<Key9>(c, km, (u32)n, hm, &pred));
+      c->stats.level_tie_pred[0] = pred;
+      if (pred < kTextSortMaxPredicted) {
+        int state = 0;
+        c->stats.level_n[0] = n; c->stats.level_K[0] = sigma; c->stats.levels = 1;
+        RC((order_all_positions<Key9>(c, km, (u32)n, kbits, hm, 0u, c->d_sa, nullptr, nullptr, nullptr, &state, 0)));
+        if (state == 1) { whole_text = true; c->stats.level_sorted[0] = 5; }
+      }
+    }
+    if (!whole_text) RC(dc3_level<SymU8>(c, S, (u32)n, sigma, c->d_sa, nullptr, 0));
   }
   if (c->profile) HIPC(hipEventRecord(c->ev_build_b, c->stream));
   HIPC(hipStreamSynchronize(c->stream));
@@ -973,6 +1036,8 @@ int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) {
   c->no_hybrid = (nh && nh[0] == '1');
   const char *nst = getenv("DC3HIP_NO_SMALL_TIES");
   c->no_small_ties = (nst && nst[0] == '1');
+  const char *nts = getenv("DC3HIP_NO_TEXT_SHORTCUT");
+  c->no_text_shortcut = (nts && nts[0] == '1');
   const char *nf = getenv("DC3HIP_NO_FULLSORT");
   c->no_fullsort = (nf && nf[0] == '1');
   const char *nd = getenv("DC3HIP_NO_DISCARD");

@@ -335,6 +335,7 @@ def test_hybrid_and_straight_paths_agree(ss, oracle):
         want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)
         seen = {}
         for env in ({}, {"DC3HIP_NO_HYBRID": "1"}, {"DC3HIP_NO_SMALL_TIES": "1"}, {"DC3HIP_NO_FULLSORT": "1"},
+                    {"DC3HIP_NO_TEXT_SHORTCUT": "1"},
                     {"DC3HIP_NO_HYBRID": "1", "DC3HIP_NO_9BIT": "1", "DC3HIP_NO_REC12": "1"}):
             os.environ.update(env)
             try:
@@ -349,7 +350,11 @@ def test_hybrid_and_straight_paths_agree(ss, oracle):
         assert not any(v in (2, 4, 5) for v in seen[("DC3HIP_NO_HYBRID",)]["level_sorted"])
         assert 5 not in seen[("DC3HIP_NO_FULLSORT",)]["level_sorted"]
         if label == "random":
-            assert 5 in seen[()]["level_sorted"], seen[()]["level_sorted"]       # whole level ordered at once
+            # all 9-byte windows distinct: the whole text is ordered at once (level 0); without that
+            # shortcut level 1 is ordered at once
+            assert seen[()]["levels"] == 1 and seen[()]["level_sorted"][0] == 5, seen[()]["level_sorted"]
+            nts = seen[("DC3HIP_NO_TEXT_SHORTCUT",)]
+            assert nts["levels"] == 2 and nts["level_sorted"][:2] == [0, 5], nts["level_sorted"]
         if label in ("random", "zero_run"):
             assert any(v in (2, 4) for v in seen[("DC3HIP_NO_FULLSORT",)]["level_sorted"])   # 4 = 2 + discarding
         if label == "dup_block":
@@ -443,7 +448,7 @@ def test_config2_64mib_random_bit_exact(ss, oracle):
         c.build()
         assert c.sufcheck() == 0
         st = c.stats()
-        assert st["levels"] == 2
+        assert st["levels"] == 1 and st["level_sorted"][0] == 5     # whole-text shortcut: 9-byte keys all distinct
         if oracle.ref is not None:
             text = c.text()
             want = oracle.ref_sufsort(text)
@@ -462,7 +467,17 @@ def test_full_size_1gib_properties(ss):
         c.build()
         assert c.checksum() == chk
         st = c.stats()
-        assert st["level_n"][:2] == [n, 715827883]
+        assert st["levels"] == 1 and st["level_sorted"][0] == 5      # whole-text shortcut
+    import os
+    os.environ["DC3HIP_NO_TEXT_SHORTCUT"] = "1"                      # the DC3 recursion proper at full size
+    try:
+        with ss.Context(n) as c:
+            c.generate(n, 2, 0)
+            c.build()
+            assert c.sufcheck() == 0 and c.checksum() == chk
+            assert c.stats()["level_n"][:2] == [n, 715827883]
+    finally:
+        os.environ.pop("DC3HIP_NO_TEXT_SHORTCUT", None)
 
 
 def test_beyond_2pow31_needs_64bit_indices(ss):
