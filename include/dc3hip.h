@@ -151,7 +151,8 @@ typedef struct dc3hip_stats {
   int32_t level_sorted[DC3HIP_MAX_LEVELS];/* 0 = direct packed names, 1 = names by full radix sort,
                                              2 = names by prefix sort + tie refinement,
                                              3 / 4 = 1 / 2 followed by the discarding recursion,
-                                             5 = whole level ordered at once (all its triples distinct) */
+                                             5 = whole level ordered at once (all its triples distinct; at level 0:
+                                                 all 9-byte windows of the text distinct) */
   int64_t level_kept[DC3HIP_MAX_LEVELS];  /* length of the reduced recursive string (discarding) */
   int32_t level_name_width[DC3HIP_MAX_LEVELS]; /* symbols packed per direct name (0 on sorted levels) */
   int64_t level_tied[DC3HIP_MAX_LEVELS];  /* samples re-sorted by the full key (prefix-sort path) */
@@ -170,6 +171,11 @@ typedef struct dc3hip_stats {
   double  gather_ms; int64_t gather_launches; int64_t gather_elems;
   int64_t arena_bytes;                    /* device work arena size */
   int64_t arena_peak;                     /* high-water mark of the last build */
+  /* whole-text shortcut (all n positions ordered by 9-byte keys before any recursion level is built):
+   * 0 = not tried, 1 = all keys distinct, that order is the SA (levels == 1, level_sorted[0] == 5),
+   * 2 = duplicate keys, the order was filtered into level 1's sorted samples, 3 = abandoned (too many ties) */
+  int32_t text_sort_state;
+  int32_t reserved0;
 } dc3hip_stats;
 
 DC3HIP_API int32_t dc3hip_ctx_stats(dc3hip_ctx *ctx, dc3hip_stats *out);

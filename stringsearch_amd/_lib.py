@@ -36,7 +36,7 @@ class Stats(ctypes.Structure):
                 ("partition_elems", ctypes.c_int64),
                 ("gather_ms", ctypes.c_double), ("gather_launches", ctypes.c_int64), ("gather_elems", ctypes.c_int64),
                 ("arena_bytes", ctypes.c_int64),
-                ("arena_peak", ctypes.c_int64)]
+                ("arena_peak", ctypes.c_int64), ("text_sort_state", ctypes.c_int32), ("reserved0", ctypes.c_int32)]
 
     def as_dict(self):
         return {
@@ -57,6 +57,7 @@ class Stats(ctypes.Structure):
             "partition_elems": self.partition_elems,
             "gather_ms": self.gather_ms, "gather_launches": self.gather_launches, "gather_elems": self.gather_elems,
             "arena_bytes": self.arena_bytes, "arena_peak": self.arena_peak,
+            "text_sort_state": self.text_sort_state,
         }
 
 

@@ -403,12 +403,36 @@ struct AccFilt {
   __device__ __forceinline__ u32 pos(u32 j) const { return spos[j]; }
   __device__ __forceinline__ u32 neq(u32 j) const { return (j == 0 || snf[j] != snf[j - 1]) ? 1u : 0u; }
 };
-template <class Acc>
-__global__ __launch_bounds__(kBlock) void k_filter_count(Acc acc, u32 n, u32 chunk, u32 *counts) {
+// Which sorted records are samples of the level being named, and under which position:
+//   MapSelf : the records are the level's own positions (the dummy, if any, is record 0 at pos == m)
+//   MapText : the records are TEXT positions p ordered by 9-byte keys, the level is level 1 (string of the
+//             byte-triple names): p = 3g+1 -> j = g, p = 3g+2 -> j = m0 + g (lib.rs:55-60), p = 3g is not in
+//             the level-1 string at all.  Two level-1 positions have no text record and are synthesised as
+//             the first outputs (npre of them, positions ppos[], nf = 0, 1; real records get nf >= 2):
+//             level 1's own dummy (j == m1, all-zero key, when m1 % 3 == 1) and level 0's dummy (j == m0-1 when
+//             n % 3 == 1: its name 1 is the smallest and unique, so it follows directly), if it is a sample.
+struct MapSelf {
+  static constexpr u32 npre = 0, nf_off = 0;
+  __device__ __forceinline__ u32 pre_pos(u32) const { return 0; }
+  __device__ __forceinline__ bool map(u32 p, u32 &j) const { j = p; return p % 3 != 0; }
+};
+struct MapText {
+  u32 m0, npre, ppos[2];
+  static constexpr u32 nf_off = 2;
+  __device__ __forceinline__ u32 pre_pos(u32 k) const { return ppos[k]; }
+  __device__ __forceinline__ bool map(u32 p, u32 &j) const {
+    const u32 g = p / 3, r = p - 3 * g;
+    if (r == 0) return false;
+    j = (r == 1) ? g : m0 + g;
+    return j % 3 != 0;
+  }
+};
+template <class Acc, class Map>
+__global__ __launch_bounds__(kBlock) void k_filter_count(Acc acc, Map mp, u32 n, u32 chunk, u32 *counts) {
   __shared__ u32 tmp[kWaves];
   const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
   u32 c = 0;
-  for (u32 i = begin + threadIdx.x; i < end; i += kBlock) c += (acc.pos(i) % 3 != 0) ? 1u : 0u;
+  for (u32 i = begin + threadIdx.x; i < end; i += kBlock) { u32 j; c += mp.map(acc.pos(i), j) ? 1u : 0u; }
   c = wave_reduce(c);
   if (lane_id() == 0) tmp[wave_id()] = c;
   __syncthreads();
@@ -416,21 +440,23 @@ __global__ __launch_bounds__(kBlock) void k_filter_count(Acc acc, u32 n, u32 chu
 }
 // name_base[blk] = exclusive prefix of the key-change flags (the scanned k_name_count output for the same
 // chunking), samp_base[blk] = exclusive prefix of the sample counts
-template <class Acc>
-__global__ __launch_bounds__(kBlock) void k_filter_write(Acc acc, u32 n, u32 chunk, const u32 *__restrict__ name_base,
+template <class Acc, class Map>
+__global__ __launch_bounds__(kBlock) void k_filter_write(Acc acc, Map mp, u32 n, u32 chunk,
+                                                        const u32 *__restrict__ name_base,
                                                         const u32 *__restrict__ samp_base, u32 *__restrict__ spos,
                                                         u32 *__restrict__ snf) {
   __shared__ u32 tmp[kWaves];
   const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
-  u32 run_f = name_base[blockIdx.x], run_s = samp_base[blockIdx.x];
+  u32 run_f = name_base[blockIdx.x] + mp.nf_off, run_s = samp_base[blockIdx.x] + mp.npre;
+  if (blockIdx.x == 0 && threadIdx.x < mp.npre) { spos[threadIdx.x] = mp.pre_pos(threadIdx.x); snf[threadIdx.x] = threadIdx.x; }
   for (u32 tile = begin; tile < end; tile += kBlock) {
     const u32 i = tile + threadIdx.x;
-    u32 fl = 0, p = 0; bool smp = false;
-    if (i < end) { fl = acc.neq(i); p = acc.pos(i); smp = (p % 3 != 0); }
+    u32 fl = 0, j = 0; bool smp = false;
+    if (i < end) { fl = acc.neq(i); smp = mp.map(acc.pos(i), j); }
     u32 totf, tots;
     const u32 exf = block_excl_scan<kWaves>(fl, tmp, totf);
     const u32 exs = block_excl_scan<kWaves>(smp ? 1u : 0u, tmp, tots);
-    if (smp) { spos[run_s + exs] = p; snf[run_s + exs] = run_f + exf + fl; }
+    if (smp) { spos[run_s + exs] = j; snf[run_s + exs] = run_f + exf + fl; }
     run_f += totf; run_s += tots;
   }
 }

@@ -311,8 +311,10 @@ static int inverse_permute(dc3hip_ctx *c, Rec8 *a, Rec8 *b, u32 n, u32 *out, int
 // ---------------------------------------------------------------------------------------------
 static constexpr double kDiscardMinDropInv = 6.0;  // discard when ~1/6 of the slots would leave the recursion
 
+struct Presort { const u32 *spos, *snf; };   // level-1 samples in sorted order + full names (whole-text sort)
 template <class Sym>
-static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_rank, int depth);
+static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_rank, int depth,
+                     const Presort *pre = nullptr);
 
 // mode: 0 = names unique, sa12/rank12 complete; 1 = R holds the names, caller recurses on R (lib.rs:104);
 //       2 = R holds name | unique<<31 and sslot the sorted slots: caller runs discard_recurse()
@@ -659,8 +661,8 @@ template <>
 void launch_pack_all<Key9>(dc3hip_ctx *c, Key9 km, u32 nrec, const HiMap &hm, Rec8 *out) {
   hipLaunchKernelGGL(k_pack_image_text, dim3(grid_for(c, (nrec + 3) / 4)), dim3(kBlock), 0, c->stream, km, nrec, hm, out);
 }
-template <class KM>
-static int order_all_positions(dc3hip_ctx *c, KM km, u32 m, u32 kbits, const HiMap &hm, u32 dummy, u32 *out_sa,
+template <class KM, class Map>
+static int order_all_positions(dc3hip_ctx *c, KM km, Map mp, u32 m, u32 kbits, const HiMap &hm, u32 dummy, u32 *out_sa,
                                u32 *out_rank, u32 *spos, u32 *snf, int *state, int depth) {
   *state = 0;
   const ArenaMark mk = arena_mark(c);
@@ -713,13 +715,13 @@ static int order_all_positions(dc3hip_ctx *c, KM km, u32 m, u32 kbits, const HiM
       *state = 1;
     } else if (spos && snf) {             // keep the sort: filter the samples with their full names
       PhaseScope ps(c, DC3HIP_PH_NAMING, nrec);
-      hipLaunchKernelGGL((k_filter_count<AccHyb>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, acc, nrec, ck.chunk,
-                         scounts);
+      hipLaunchKernelGGL((k_filter_count<AccHyb, Map>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, acc, mp, nrec,
+                         ck.chunk, scounts);
       KCHECK();
       hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, scounts, ck.nchunks, (u32 *)nullptr);
       KCHECK();
-      hipLaunchKernelGGL((k_filter_write<AccHyb>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, acc, nrec, ck.chunk,
-                         counts, scounts, spos, snf);
+      hipLaunchKernelGGL((k_filter_write<AccHyb, Map>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, acc, mp, nrec,
+                         ck.chunk, counts, scounts, spos, snf);
       KCHECK();
       *state = 2;
     }
@@ -745,7 +747,7 @@ static int launch_merge(dc3hip_ctx *c, u32 ntiles, const Tup12 *A, u32 nA, const
 //   out_rank: [m+3..]  position -> 1-based rank, caller zeroes the tail (may be null)
 // ---------------------------------------------------------------------------------------------
 template <class Sym>
-static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_rank, int depth) {
+static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_rank, int depth, const Presort *pre) {
   if (depth >= DC3HIP_MAX_LEVELS) { set_err("recursion deeper than %d levels", DC3HIP_MAX_LEVELS); return E_HIP; }
   if (m == 1) {   // single suffix (only reachable as the child of a 2- or 3-symbol level)
     c->stats.level_n[depth] = 1; c->stats.level_K[depth] = (int64_t)K; c->stats.levels = depth + 1;
@@ -778,7 +780,7 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
       KCHECK();
     }
     SymU32 RS; RS.s = R; RS.m = m02;
-    RC(dc3_level<SymU32>(c, RS, m02, Bw, sa12, rank12, depth + 1));
+    RC(dc3_level<SymU32>(c, RS, m02, Bw, sa12, rank12, depth + 1, pre));
   } else {
     const u32 b = (u32)B;                          // packing base of make_rec (K < 2^31)
     u32 kbits = 0;                                 // bit width of B^3 - 1; > 32 here (else direct path)
@@ -789,8 +791,16 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
     u32 names = 0;
     int mode = 0;
     bool done = false;
+    if (pre && depth == 1) {
+      // the whole-text sort of level 0 found duplicate keys; its order, filtered down to this level's samples,
+      // is the sorted sample order: name it and continue as usual
+      c->stats.level_sorted[depth] = 2;
+      AccFilt acc; acc.spos = pre->spos; acc.snf = pre->snf;
+      RC(name_and_rank<AccFilt>(c, acc, m02, m0, sa12, rank12, R, sslot, &names, &mode));
+      done = true;
+    }
     // ---- prefix-sort + tie-refine ordering when the N-bit key image separates most samples ------
-    if (m02 >= kHybridMinSamples && !c->no_hybrid) {
+    if (!done && m02 >= kHybridMinSamples && !c->no_hybrid) {
       double pred = 1.0;
       RC(predict_tie_fraction<Sym>(c, S, m, m0, m02, b, make_himap(B, kbits, m), &pred));
       c->stats.level_tie_pred[depth] = pred;
@@ -801,8 +811,9 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
         RC(arena_alloc(c, (size_t)m02 + 16, &snf));
         int state = 0;
         Key3<Sym> km; km.S = S; km.B = b;
-        RC((order_all_positions<Key3<Sym>>(c, km, m, kbits, make_himap(B, kbits, m), (m % 3 == 1) ? 1u : 0u, out_sa,
-                                           out_rank, spos, snf, &state, depth)));
+        RC((order_all_positions<Key3<Sym>, MapSelf>(c, km, MapSelf{}, m, kbits, make_himap(B, kbits, m),
+                                                    (m % 3 == 1) ? 1u : 0u, out_sa, out_rank, spos, snf, &state,
+                                                    depth)));
         if (state == 1) {
           c->stats.level_sorted[depth] = 5;
           arena_release(c, mk0);
@@ -956,11 +967,13 @@ static int ctx_build(dc3hip_ctx *c) {
     if (sigma < 1 || sigma > 256) { set_err("internal: alphabet size %u", sigma); return E_HIP; }
     SymU8 S; S.t = c->d_text; S.code = c->d_code; S.m = (u32)n;
     bool whole_text = false;
+    Presort pre{nullptr, nullptr};
+    const u64 Bq = (u64)sigma + 1, B3 = Bq * Bq * Bq;
+    // (level 1 must be a sorted level for its samples to be taken from the whole-text order: B3^3 >= 2^31)
     if ((u64)n >= kHybridMinSamples && !c->no_hybrid && !c->no_fullsort && !c->no_text_shortcut &&
-        c->arena_bytes - c->arena_off >= (size_t)n * 28 + (64u << 20)) {
+        B3 * B3 * B3 > 0x7fffffffull && c->arena_bytes - c->arena_off >= (size_t)n * 32 + (64u << 20)) {
       // whole-text shortcut: if all 9-byte windows of a high-entropy text are distinct, sorting all positions by
       // them is the suffix array (the same test level 1 would make on its triples, without building level 1)
-      const u64 Bq = (u64)sigma + 1, B3 = Bq * Bq * Bq;
       u32 kbits = 0;
       { unsigned __int128 mx = (unsigned __int128)B3 * B3 * B3 - 1; while (mx) { kbits++; mx >>= 1; } }
       Key9 km; km.S = S; km.B = (u32)Bq; km.B3 = (u32)B3;
@@ -969,13 +982,27 @@ static int ctx_build(dc3hip_ctx *c) {
       RC(predict_tie_fraction_pos<Key9>(c, km, (u32)n, hm, &pred));
       c->stats.level_tie_pred[0] = pred;
       if (pred < kTextSortMaxPredicted) {
+        const u32 m0 = (u32)((n + 2) / 3), m1 = m0 + (u32)(n / 3);            // level 1 = string of m1 names
+        const u32 m02_1 = (m1 + 2) / 3 + m1 / 3;                              // its samples (incl. the dummy)
+        // The filtered order (2 * m02_1 words < n) lives in the output buffer: the optimistic SA written there
+        // by the tie pass is void when keys repeat, and nothing else writes d_sa before the final merge.
+        u32 *spos = c->d_sa, *snf = c->d_sa + m02_1 + 16;
+        MapText mp; mp.m0 = m0; mp.npre = 0; mp.ppos[0] = mp.ppos[1] = 0;
+        if (m1 % 3 == 1) mp.ppos[mp.npre++] = m1;                              // level 1's dummy sample
+        if (n % 3 == 1 && (m0 - 1) % 3 != 0) mp.ppos[mp.npre++] = m0 - 1;      // level 0's dummy, a level-1 position
         int state = 0;
-        c->stats.level_n[0] = n; c->stats.level_K[0] = sigma; c->stats.levels = 1;
-        RC((order_all_positions<Key9>(c, km, (u32)n, kbits, hm, 0u, c->d_sa, nullptr, nullptr, nullptr, &state, 0)));
-        if (state == 1) { whole_text = true; c->stats.level_sorted[0] = 5; }
+        RC((order_all_positions<Key9, MapText>(c, km, mp, (u32)n, kbits, hm, 0u, c->d_sa, nullptr, spos, snf, &state,
+                                               0)));
+        c->stats.text_sort_state = state == 1 ? 1 : state == 2 ? 2 : 3;
+        if (state == 1) {
+          whole_text = true;
+          c->stats.level_n[0] = n; c->stats.level_K[0] = sigma; c->stats.levels = 1; c->stats.level_sorted[0] = 5;
+        } else if (state == 2) {
+          pre.spos = spos; pre.snf = snf;      // duplicates: the order still serves level 1
+        }
       }
     }
-    if (!whole_text) RC(dc3_level<SymU8>(c, S, (u32)n, sigma, c->d_sa, nullptr, 0));
+    if (!whole_text) RC(dc3_level<SymU8>(c, S, (u32)n, sigma, c->d_sa, nullptr, 0, pre.spos ? &pre : nullptr));
   }
   if (c->profile) HIPC(hipEventRecord(c->ev_build_b, c->stream));
   HIPC(hipStreamSynchronize(c->stream));

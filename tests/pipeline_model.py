@@ -7,6 +7,7 @@ import numpy as np
 
 FULLSORT = True      # model of the whole-level shortcut (all triples of a level distinct -> sorted triples = SA)
 DISCARD = True       # model of the "discarding" recursion (unique names leave the recursion), see dc3hip.hip
+TEXTSORT = True      # model of the level-0 whole-text shortcut (9-byte keys of all text positions; MapText filter)
 WIDE_NAMES = False   # True = as many symbols per direct name as fit 31 bits (DC3HIP_WIDE_NAMES=1)
 
 
@@ -19,8 +20,10 @@ def _sym_get(S, m, idx):
     return out
 
 
-def level(S, m, K, trace=None, depth=0):
-    """returns (sa, rank) of S[0..m), symbols in 1..K; rank is 1-based."""
+def level(S, m, K, trace=None, depth=0, pre=None):
+    """returns (sa, rank) of S[0..m), symbols in 1..K; rank is 1-based.
+    pre = (spos, snf): this level's samples in sorted order with their full names, handed down by the
+    whole-text sort of level 0 (only consumed at depth 1)."""
     S = np.asarray(S, dtype=np.int64)
     if trace is not None:
         trace.append((int(m), int(K)))
@@ -43,9 +46,9 @@ def level(S, m, K, trace=None, depth=0):
             n2 = n2 * B + _sym_get(S, m, 3 * g + 2 + t)
         R[g] = n1 + 1
         R[m0 + g[has2]] = (n2 + 1)[has2]
-        sa12, rank12 = level(R, m02, B ** w, trace, depth + 1)
+        sa12, rank12 = level(R, m02, B ** w, trace, depth + 1, pre)
     else:                                                      # k_pack_triples + radix sort + naming
-        if FULLSORT:                                           # order_all_positions: every position + the dummy
+        if FULLSORT and not (pre is not None and depth == 1):  # order_all_positions: every position + the dummy
             allp = np.arange(m + (1 if m % 3 == 1 else 0), dtype=np.int64)
             ak = np.stack([_sym_get(S, m, allp), _sym_get(S, m, allp + 1), _sym_get(S, m, allp + 2)], 1)
             aperm = np.lexsort((ak[:, 2], ak[:, 1], ak[:, 0]))
@@ -62,6 +65,18 @@ def level(S, m, K, trace=None, depth=0):
         pos, keys = pos[perm], keys[perm]
         flag = np.ones(m02, dtype=np.int64)
         flag[1:] = np.any(keys[1:] != keys[:-1], axis=1)
+        if pre is not None and depth == 1:                     # AccFilt over the filtered whole-text order
+            spos, snf = pre
+            assert len(spos) == m02
+            # same multiset of samples, same equality classes, an order consistent with the keys
+            assert np.array_equal(np.sort(spos), np.sort(pos))
+            pflag = np.ones(m02, dtype=np.int64); pflag[1:] = snf[1:] != snf[:-1]
+            assert np.array_equal(pflag, flag)
+            kk = np.stack([_sym_get(S, m, spos), _sym_get(S, m, spos + 1), _sym_get(S, m, spos + 2)], 1)
+            same = ~np.any(kk != keys, axis=1)
+            # keys may differ only behind the unique last mod-1 name (see dc3_order.cuh, MapText)
+            assert np.all(same | (flag.astype(bool) & np.concatenate([flag[1:].astype(bool), [True]])))
+            pos, flag = spos.copy(), pflag
         names = np.cumsum(flag)
         slot = np.where(pos % 3 == 1, pos // 3, pos // 3 + m0)
         if names[-1] == m02:                                   # k_assign_unique
@@ -145,5 +160,31 @@ def sufsort(data: bytes, trace=None):
     t = np.frombuffer(data, dtype=np.uint8)
     present = np.zeros(256, dtype=np.int64); present[t] = 1
     code = np.where(present > 0, np.cumsum(present), 0)       # k_make_codes
-    sa, _ = level(code[t], n, int(present.sum()), trace)
+    sigma = int(present.sum())
+    pre = None
+    if TEXTSORT and (sigma + 1) ** 9 > 0x7FFFFFFF:            # ctx_build: whole-text shortcut (Key9 + MapText)
+        c = np.concatenate([code[t], np.zeros(16, dtype=np.int64)])
+        p = np.arange(n, dtype=np.int64)
+        k9 = np.stack([c[p + k] for k in range(9)], 1)
+        perm = np.lexsort(tuple(k9[:, k] for k in range(8, -1, -1)))
+        ks = k9[perm]
+        neq = np.ones(n, dtype=np.int64); neq[1:] = np.any(ks[1:] != ks[:-1], axis=1)
+        if neq.all():
+            if trace is not None:
+                trace.append((n, sigma))
+            return perm.astype(np.int32)
+        # k_filter_*<AccHyb, MapText>
+        m0 = (n + 2) // 3; m1 = m0 + n // 3
+        ps = p[perm]; nf = np.cumsum(neq) + 2
+        g, r = ps // 3, ps % 3
+        j = np.where(r == 1, g, m0 + g)
+        keep = (r != 0) & (j % 3 != 0)
+        head_pos, head_nf = [], []
+        if m1 % 3 == 1:
+            head_pos.append(m1); head_nf.append(len(head_nf))
+        if n % 3 == 1 and (m0 - 1) % 3 != 0:
+            head_pos.append(m0 - 1); head_nf.append(len(head_nf))
+        pre = (np.concatenate([np.array(head_pos, dtype=np.int64), j[keep]]),
+               np.concatenate([np.array(head_nf, dtype=np.int64), nf[keep]]))
+    sa, _ = level(code[t], n, sigma, trace, 0, pre)
     return sa.astype(np.int32)

@@ -353,16 +353,43 @@ def test_hybrid_and_straight_paths_agree(ss, oracle):
             # all 9-byte windows distinct: the whole text is ordered at once (level 0); without that
             # shortcut level 1 is ordered at once
             assert seen[()]["levels"] == 1 and seen[()]["level_sorted"][0] == 5, seen[()]["level_sorted"]
+            assert seen[()]["text_sort_state"] == 1
             nts = seen[("DC3HIP_NO_TEXT_SHORTCUT",)]
             assert nts["levels"] == 2 and nts["level_sorted"][:2] == [0, 5], nts["level_sorted"]
         if label in ("random", "zero_run"):
             assert any(v in (2, 4) for v in seen[("DC3HIP_NO_FULLSORT",)]["level_sorted"])   # 4 = 2 + discarding
         if label == "dup_block":
             assert 5 not in seen[()]["level_sorted"] and any(v in (2, 4) for v in seen[()]["level_sorted"])
+            # the whole-text order had duplicate 9-byte windows and was filtered into level 1's samples
+            assert seen[()]["text_sort_state"] == 2 and seen[("DC3HIP_NO_TEXT_SHORTCUT",)]["text_sort_state"] == 0
             # small-group path skips the 16-byte radix passes entirely; the zero run forces them
             d16 = seen[()]["downsweep_launches"][1]
             assert (d16 == 0) if label == "random" else (d16 > 0), (label, d16)
             assert seen[("DC3HIP_NO_SMALL_TIES",)]["downsweep_launches"][1] > 0
+
+
+def test_whole_text_order_reused_by_level1(ss, oracle):
+    """Whole-text shortcut with duplicate 9-byte windows (text_sort_state == 2): the order of all text positions
+    is filtered into level 1's sorted samples (MapText), including the two level-1 positions without a text
+    record (level 1's dummy when m1 % 3 == 1, level 0's dummy when n % 3 == 1).  Every residue combination."""
+    base = oracle.gen((1 << 22) + 16, 77, 0)
+    combos = set()
+    for k in range(9):
+        n = (1 << 22) + k
+        d = base[:n].copy()
+        d[n // 2:n // 2 + 4000] = d[1000:5000]            # a repeated 4000-byte block
+        if k % 2:
+            d[n - 300:] = d[5000:5300]                    # and a repeat that runs into the end of the text
+        data = d.tobytes()
+        want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)
+        with ss.Context(n) as c:
+            c.set_text(data); c.build()
+            st = c.stats()
+            assert np.array_equal(c.sa(), want), n
+            assert st["text_sort_state"] == 2 and st["level_sorted"][0] == 0 and st["level_sorted"][1] in (2, 4), st
+        m0 = (n + 2) // 3; m1 = m0 + n // 3
+        combos.add((n % 3, m1 % 3))
+    assert len(combos) == 9
 
 
 def test_wide_and_narrow_direct_names_agree(ss, oracle):

@@ -69,3 +69,27 @@ def test_model_discarding_on_and_off(oracle, corpus):
                     assert pm.sufsort(data).tolist() == want, (len(data), flag, full)
                 finally:
                     pm.DISCARD = True; pm.FULLSORT = True
+
+
+def test_model_whole_text_shortcut(oracle):
+    """ctx_build's whole-text shortcut: all text positions ordered by 9-byte keys.  All keys distinct -> that
+    is the SA; duplicates -> the order is filtered (MapText) into level 1's sorted samples, including the two
+    level-1 positions that have no text record (level 1's dummy, level 0's dummy).  Every n mod 3 and
+    m1 mod 3 combination, with and without duplicate windows."""
+    rng = np.random.default_rng(12)
+    seen = set()
+    for n in list(range(40, 76)) + [1000, 1001, 1002, 4099]:
+        base = rng.integers(0, 200, size=n, dtype=np.uint8)
+        m0 = (n + 2) // 3; m1 = m0 + n // 3
+        seen.add((n % 3, m1 % 3, (m0 - 1) % 3 != 0))
+        dupd = base.copy(); dupd[n // 2:n // 2 + 12] = dupd[3:15]          # one repeated 12-byte window
+        tail = base.copy(); tail[-11:] = tail[5:16]                          # a repeat that runs into the end
+        for data in (base.tobytes(), dupd.tobytes(), tail.tobytes()):
+            want = oracle.sufsort(data).tolist()
+            for flag in (True, False):
+                pm.TEXTSORT = flag
+                try:
+                    assert pm.sufsort(data).tolist() == want, (n, flag)
+                finally:
+                    pm.TEXTSORT = True
+    assert len(seen) >= 8
