@@ -89,6 +89,8 @@ def main():
                     help="CPU baseline sample (MiB of the same buffer); 256 MiB is ~10-20 s of one-core divsufsort")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-recursion-line", action="store_true",
+                    help="skip the extra (untimed-in-value) builds with the whole-text shortcut disabled")
     ap.add_argument("--dump-stats", type=str, default=None, help="write the last build's dc3hip_stats as JSON here")
     args = ap.parse_args()
 
@@ -256,6 +258,25 @@ def main():
     if args.dump_stats and rank == 0:
         json.dump(st, open(args.dump_stats, "w"))
     ctx.close()
+    if rank == 0 and world == 1 and not args.no_recursion_line and st.get("text_sort_state", 0) == 1:
+        # The timed builds above finished in the whole-text shortcut (every 9-byte window distinct, no
+        # recursion level built).  For reference, the same input through the DC3 recursion proper
+        # (levels, tuples, merge): not part of `value`.
+        os.environ["DC3HIP_NO_TEXT_SHORTCUT"] = "1"
+        try:
+            with ss.Context(n, device=local_rank) as c2:
+                c2.generate(n, args.seed, kind, offset=off)
+                c2.build()
+                ms = []
+                for _ in range(min(args.steps, 3)):
+                    c2.build(); ms.append(c2.stats()["build_ms"])
+                st2 = c2.stats()
+                out["dc3_recursion_only"] = {"switch": "DC3HIP_NO_TEXT_SHORTCUT=1", "device_ms_per_step": sum(ms) / len(ms),
+                                             "MBps": n / (sum(ms) / len(ms)) / 1e3, "sufcheck": c2.sufcheck(),
+                                             "checksum_equal": (c2.checksum() == chk0) if not args.no_verify else None,
+                                             "levels": list(zip(st2["level_n"], st2["level_K"], st2["level_sorted"]))}
+        finally:
+            os.environ.pop("DC3HIP_NO_TEXT_SHORTCUT", None)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -6,13 +6,14 @@ the bytes of a wide coalesced streaming read -> streaming kernels use 2*FETCH; t
 an uncalibrated access width and is left uncorrected (lower bound)."""
 import csv, json, sys
 d = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
+tag = sys.argv[2] if len(sys.argv) > 2 else ""          # "" = default path, "_recursion" = DC3HIP_NO_TEXT_SHORTCUT=1
 def load(ctr):
     out = {}
-    for row in csv.DictReader(open(f"{d}/pmc_{ctr}_by_kernel.csv")):
+    for row in csv.DictReader(open(f"{d}/pmc{tag}_{ctr}_by_kernel.csv")):
         out[row["kernel"]] = float(row["sum_counter_value"]) * 1024.0
     return out
 F, W = load("FETCH_SIZE"), load("WRITE_SIZE")
-st = json.load(open(f"{d}/pmc_stats.json"))
+st = json.load(open(f"{d}/pmc{tag}_stats.json"))
 def tot(pred, fetch_mul):
     return sum(fetch_mul * F.get(k, 0) + W.get(k, 0) for k in set(F) | set(W) if pred(k))
 res = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), one build of the default bench workload; "
@@ -22,11 +23,12 @@ e = st["downsweep_elems"]
 if e[0]: res["bytes_per_record"]["downsweep_rec8"] = tot(lambda k: "k_rs_downsweep<dc3::Rec8" in k, 2) / e[0]
 if e[1]: res["bytes_per_record"]["downsweep_rec16"] = tot(lambda k: "k_rs_downsweep<dc3::Rec16" in k or "k_rs_downsweep<dc3::Rec12" in k, 2) / e[1]
 if e[2]: res["bytes_per_record"]["downsweep_tup0"] = tot(lambda k: "k_rs_downsweep<dc3::Tup0" in k, 2) / e[2]
-res["bytes_per_record"]["gather_tuples"] = tot(lambda k: "k_gather_tuples" in k, 1) / st["gather_elems"]
-res["bytes_per_record"]["partition_pairs"] = tot(lambda k: "k_part_msd" in k, 2) / st["partition_elems"]
+if st["gather_elems"]: res["bytes_per_record"]["gather_tuples"] = tot(lambda k: "k_gather_tuples" in k, 1) / st["gather_elems"]
+if st["partition_elems"]: res["bytes_per_record"]["partition_pairs"] = tot(lambda k: "k_part_msd" in k, 2) / st["partition_elems"]
 for k in sorted(set(F) | set(W), key=lambda k: -(2 * F.get(k, 0) + W.get(k, 0))):
     res["per_kernel_bytes"][k] = {"fetch_raw": F.get(k, 0), "write": W.get(k, 0)}
 res["whole_build_bytes_streaming_corrected"] = sum(2 * F.get(k, 0) + W.get(k, 0) for k in set(F) | set(W) if "gather" not in k) + tot(lambda k: "k_gather_tuples" in k, 1)
 res["build_ms_under_pmc"] = st["build_ms"]
-json.dump(res, open("profiles/pmc_traffic.json", "w"), indent=1)
+res["levels"] = list(zip(st["level_n"], st["level_sorted"]))
+json.dump(res, open(f"profiles/pmc_traffic{tag}.json", "w"), indent=1)
 print(json.dumps(res["bytes_per_record"], indent=1)); print("whole build GB:", res["whole_build_bytes_streaming_corrected"] / 1e9)
