@@ -330,7 +330,11 @@ def test_hybrid_and_straight_paths_agree(ss, oracle):
     # random data with one duplicated 200 KB block: the whole-level sort finds duplicate triples and its
     # result is filtered down to the samples instead of being thrown away
     dup = rnd[:3_000_000] + rnd[1_000_000:1_200_000] + rnd[3_200_000:]
-    cases = {"random": rnd, "text": texty, "repeat": half + half + b"!", "zero_run": zrun, "dup_block": dup}
+    # geometric byte distribution: few distinct 9-byte windows repeat, but the key images crowd at the low end
+    # (tie groups of every size next to each other)
+    skew = np.minimum(rng.geometric(0.08, size=n) - 1, 255).astype(np.uint8).tobytes()
+    cases = {"random": rnd, "text": texty, "repeat": half + half + b"!", "zero_run": zrun, "dup_block": dup,
+             "skewed": skew}
     for label, data in cases.items():
         want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)
         seen = {}
