@@ -21,7 +21,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable copy
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+COPY_MEASURED_GBS = 4735.0   # read+write copy kernel measured on the box (profiles/r01_membench_access_patterns.txt)
 
 
 def parse_size(s):
@@ -226,6 +227,10 @@ def main():
                            "traffic_source": pmc.get("source") if pmc else None}
         # `roofline` = the kernel with the largest share of the build; the other one is kept beside it
         roof_radix = roof
+        for rr in (roof, roof_gather):
+            if rr is not None:
+                rr["measured_copy_GBps"] = COPY_MEASURED_GBS
+                rr["moved_frac_of_measured_copy"] = rr["moved_GBps"] / COPY_MEASURED_GBS
         if roof_gather is not None and (roof is None or roof_gather["share_of_build_time"] >= roof["share_of_build_time"]):
             roof = roof_gather
         alg = algorithmic_bytes(st["level_n"])
@@ -243,6 +248,7 @@ def main():
                                    f"i32 SA, DC3 HIP, text and SA resident in HBM",
                        "bytes_per_gpu": n, "total_bytes": total_len,
                        "partitioning": "single SA" if world == 1 else f"sacapart: {world} chunks of len/{world}+1 bytes, one per GPU, no collective"},
+            "value_MiBps": total_len * args.steps / dt / 2**20,     # the reference prints binary units (divsuftest main.rs:179-183)
             "roofline": roof, "roofline_radix_scatter": roof_radix, "roofline_path": path, "verify": verify,
             "arena_peak_GB": st["arena_peak"] / 1e9,
         }
