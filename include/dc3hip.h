@@ -58,6 +58,10 @@ typedef struct dc3hip_opts {
   int32_t flags;         /* DC3HIP_F_* */
 } dc3hip_opts;
 #define DC3HIP_F_DEVICE_PTRS 1 /* T and SA are device pointers on `device` (no H2D/D2H) */
+#define DC3HIP_F_ALL_DEVICES 2 /* num_partitions > 1, host pointers: the partitions are shared by all visible GPUs, one
+                                  host worker thread per GPU (the rayon par_chunks of sacapart/src/lib.rs:45-49);
+                                  `device` is ignored.  DC3HIP_WORKERS_PER_DEVICE=2 lets a GPU overlap one chunk's
+                                  PCIe transfers with another chunk's build. */
 
 DC3HIP_API int32_t dc3hip_sufsort_ex(const uint8_t *T, void *SA, int64_t n, const dc3hip_opts *opts);
 

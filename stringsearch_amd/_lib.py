@@ -16,6 +16,10 @@ class Dc3HipError(RuntimeError):
         self.code = code
 
 
+F_DEVICE_PTRS = 1      # DC3HIP_F_DEVICE_PTRS
+F_ALL_DEVICES = 2      # DC3HIP_F_ALL_DEVICES
+
+
 class Opts(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_int32), ("index_bits", ctypes.c_int32), ("device", ctypes.c_int32),
                 ("num_partitions", ctypes.c_int32), ("flags", ctypes.c_int32)]

@@ -176,6 +176,22 @@ class PartitionedSuffixArray:
         S = self.partition_size
         self.sas = [f(self.text[off:off + S]) for off in range(0, len(self.text), S)]
 
+    @classmethod
+    def build(cls, text, num_partitions, all_devices=True):
+        """All chunks in ONE library call: dc3hip_sufsort_ex(num_partitions=P[, DC3HIP_F_ALL_DEVICES]) — the node's
+        GPUs share the chunks, one host worker per GPU (the par_chunks of lib.rs:45-49)."""
+        from ._lib import Opts, F_ALL_DEVICES
+        self = cls.__new__(cls)
+        self.text = _as_u8(text)
+        n = len(self.text)
+        self.partition_size = n // num_partitions + 1
+        sa = np.zeros(n, dtype=np.int32)
+        o = Opts(ctypes.sizeof(Opts), 32, -1, num_partitions, F_ALL_DEVICES if all_devices else 0)
+        _check(lib().dc3hip_sufsort_ex(self.text.ctypes.data, sa.ctypes.data, n, ctypes.byref(o)))
+        S = self.partition_size
+        self.sas = [SuffixArray(self.text[off:off + S], sa[off:off + S]) for off in range(0, n, S)]
+        return self
+
     def num_partitions(self):              # :60
         return len(self.sas)
 

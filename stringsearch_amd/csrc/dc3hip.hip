@@ -19,6 +19,8 @@
 #include <new>
 #include <type_traits>
 #include <vector>
+#include <thread>
+#include <string>
 
 #include "../../include/dc3hip.h"
 #include "dc3_kernels.cuh"
@@ -1401,10 +1403,41 @@ int32_t dc3hip_sufsort_ex(const uint8_t *T, void *SA, int64_t n, const dc3hip_op
   const int64_t S = n / P + 1;
   if (S > DC3HIP_MAX_N) { set_err("partition of %lld bytes exceeds DC3HIP_MAX_N", (long long)S); return E_TOOBIG; }
   const size_t isz = d.index_bits / 8;
-  for (int64_t off = 0; off < n; off += S) {
-    const int64_t len = std::min(S, n - off);
-    RC(sufsort_one(T + off, static_cast<unsigned char *>(SA) + (size_t)off * isz, len, d.index_bits, d.device, devptrs));
+  const int64_t nparts = (n + S - 1) / S;
+  int ndev = 1;
+  if ((d.flags & DC3HIP_F_ALL_DEVICES) && !devptrs) {
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { set_err("no HIP device"); return E_HIP; }
   }
+  int per_dev = 1;
+  if (const char *e = getenv("DC3HIP_WORKERS_PER_DEVICE")) per_dev = std::max(1, std::min(4, atoi(e)));
+  const int workers = (int)std::min<int64_t>(nparts, (d.flags & DC3HIP_F_ALL_DEVICES) && !devptrs ? (int64_t)ndev * per_dev : 1);
+  if (workers <= 1) {
+    for (int64_t off = 0; off < n; off += S) {
+      const int64_t len = std::min(S, n - off);
+      RC(sufsort_one(T + off, static_cast<unsigned char *>(SA) + (size_t)off * isz, len, d.index_bits, d.device, devptrs));
+    }
+    return E_OK;
+  }
+  // The node's GPUs share the partitions (the rayon par_chunks of sacapart/src/lib.rs:45-49): worker w builds chunks
+  // w, w+W, ... on device w % ndev with its own context and stream; no data is exchanged between partitions.
+  std::vector<int> rcs((size_t)workers, E_OK);
+  std::vector<std::string> msgs((size_t)workers);
+  std::vector<std::thread> pool;
+  for (int w = 0; w < workers; w++) {
+    pool.emplace_back([&, w]() {
+      const int dev = w % ndev;
+      for (int64_t part = w; part < nparts; part += workers) {
+        const int64_t off = part * S, len = std::min(S, n - off);
+        const int rc = sufsort_one(T + off, static_cast<unsigned char *>(SA) + (size_t)off * isz, len, d.index_bits, dev,
+                                   false);
+        if (rc != E_OK) { rcs[(size_t)w] = rc; msgs[(size_t)w] = dc3hip_last_error(); break; }
+      }
+      dc3hip_release_cache();            // the worker thread ends here: give its arena back now
+    });
+  }
+  for (auto &t : pool) t.join();
+  for (int w = 0; w < workers; w++)
+    if (rcs[(size_t)w] != E_OK) { set_err("partition worker %d: %s", w, msgs[(size_t)w].c_str()); return rcs[(size_t)w]; }
   return E_OK;
 }
 

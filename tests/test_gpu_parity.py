@@ -189,10 +189,38 @@ def test_ex_partitions_sacapart_semantics(ss, oracle):
             assert np.array_equal(sa[off:off + ln], oracle.sufsort(data[off:off + ln])), (P, off)
 
 
+def test_ex_partitions_shared_by_all_devices(ss, oracle):
+    """DC3HIP_F_ALL_DEVICES: the partitions of one call are built by one host worker per visible GPU (two per GPU
+    with DC3HIP_WORKERS_PER_DEVICE=2, so the worker path also runs on a 1-GPU box), same bytes as the serial loop;
+    errors of a worker surface in the caller's thread."""
+    import ctypes, os
+    from stringsearch_amd._lib import Opts
+    from stringsearch_amd.partition import chunk_bounds
+    data = oracle.gen(700_001, 9, 2)
+    F_ALL = 2
+    for per_dev, P, bits in ((1, 3, 32), (2, 5, 32), (2, 7, 64), (4, 2, 32)):
+        os.environ["DC3HIP_WORKERS_PER_DEVICE"] = str(per_dev)
+        try:
+            sa = np.zeros(len(data), dtype=np.int32 if bits == 32 else np.int64)
+            o = Opts(ctypes.sizeof(Opts), bits, -1, P, F_ALL)
+            rc = ss.lib().dc3hip_sufsort_ex(data.ctypes.data, sa.ctypes.data, len(data), ctypes.byref(o))
+            assert rc == 0, ss.last_error()
+            for off, ln in chunk_bounds(len(data), P):
+                assert np.array_equal(sa[off:off + ln], oracle.sufsort(data[off:off + ln])), (P, off)
+        finally:
+            os.environ.pop("DC3HIP_WORKERS_PER_DEVICE", None)
+    # a failing worker: 32-bit indices cannot address a 2^31-byte partition -> refused before any worker starts
+    o = Opts(ctypes.sizeof(Opts), 32, -1, 2, F_ALL)
+    assert ss.lib().dc3hip_sufsort_ex(data.ctypes.data, sa.ctypes.data, (1 << 32) + 5, ctypes.byref(o)) == -4
+
+
 def test_partitioned_search_on_gpu_sas(ss):
     # sacapart/src/lib.rs:105-165 with dc3hip::sort plugged in as `f`
     text = b"totor"
     full = ss.sort(text); part = ss.PartitionedSuffixArray(text, 2, ss.sort)
+    one_call = ss.PartitionedSuffixArray.build(text, 2)          # same partitions from one library call
+    assert [s.into_parts()[1].tolist() for s in one_call.sas] == [s.into_parts()[1].tolist() for s in part.sas]
+    assert one_call.longest_substring_match(b"tor").as_bytes() == b"to"
     assert full.longest_substring_match(b"tor").as_bytes() == b"tor"
     assert part.longest_substring_match(b"tor").as_bytes() == b"to"
     assert part.longest_substring_match(b"otor").as_bytes() == b"otor"
