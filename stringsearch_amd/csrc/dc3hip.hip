@@ -972,7 +972,9 @@ static int ctx_build(dc3hip_ctx *c) {
     Presort pre{nullptr, nullptr};
     const u64 Bq = (u64)sigma + 1, B3 = Bq * Bq * Bq;
     // (level 1 must be a sorted level for its samples to be taken from the whole-text order: B3^3 >= 2^31)
-    if ((u64)n >= kHybridMinSamples && !c->no_hybrid && !c->no_fullsort && !c->no_text_shortcut &&
+    // (even uniformly random symbols repeat a 9-symbol window once sigma^9 is not well above n^2/2: skip then)
+    const bool windows_can_be_distinct = 9.0 * log2((double)sigma) >= 2.0 * log2((double)n) + 2.0;
+    if ((u64)n >= kHybridMinSamples && !c->no_hybrid && !c->no_fullsort && !c->no_text_shortcut && windows_can_be_distinct &&
         B3 * B3 * B3 > 0x7fffffffull && c->arena_bytes - c->arena_off >= (size_t)n * 32 + (64u << 20)) {
       // whole-text shortcut: if all 9-byte windows of a high-entropy text are distinct, sorting all positions by
       // them is the suffix array (the same test level 1 would make on its triples, without building level 1)
