@@ -89,14 +89,23 @@ __global__ __launch_bounds__(kBlock) void k_check_fill(const u32 *__restrict__ s
 }
 __global__ __launch_bounds__(kBlock) void k_check_order(const uint8_t *__restrict__ t, const u32 *__restrict__ sa,
                                                        const u32 *__restrict__ isa, u32 n, int *err) {
-  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-    const u32 p = sa[i];
-    if (p >= n) continue;
+  // a wave takes 64 consecutive ranks; the successor's position and first byte come from the next lane
+  // (one random text gather per rank instead of two), lane 63 fetches its own
+  const u32 lane = lane_id();
+  for (u32 base = blockIdx.x * kBlock + (threadIdx.x & ~63u); base < n; base += gridDim.x * kBlock) {
+    const u32 i = base + lane;
+    const bool valid = i < n;
+    const u32 p = valid ? sa[i] : 0xffffffffu;
+    const bool pin = valid && p < n;
+    const u32 cp = pin ? (u32)t[p] : 0u;
+    u32 q = __shfl_down(p, 1), cq = __shfl_down(cp, 1);
+    if (lane == 63) {
+      q = (i + 1 < n) ? sa[i + 1] : 0xffffffffu;
+      cq = (i + 1 < n && q < n) ? (u32)t[q] : 0u;
+    }
+    if (!pin) continue;                                       // out of range: reported by k_check_fill
     if (isa[p] != i + 1) { atomicMax(err, 3); continue; }   // not a permutation
-    if (i + 1 >= n) continue;
-    const u32 q = sa[i + 1];
-    if (q >= n) continue;
-    const uint8_t cp = t[p], cq = t[q];
+    if (i + 1 >= n || q >= n) continue;
     if (cp > cq) { atomicMax(err, 2); continue; }           // -3
     if (cp == cq) {
       const u32 rp = (p + 1 < n) ? isa[p + 1] : 0u;
