@@ -539,6 +539,26 @@ def test_full_size_1gib_properties(ss):
         os.environ.pop("DC3HIP_NO_TEXT_SHORTCUT", None)
 
 
+@pytest.mark.parametrize("kind,label", [(2, "low-entropy text (configs[2])"), (1, "DNA alphabet (configs[4] per-GPU class)")])
+def test_full_size_1gib_text_and_dna_properties(ss, kind, label):
+    """BASELINE.json configs[2] (1 GiB low-entropy text with deep LCPs) and the DNA alphabet at 1 GiB: the CPU
+    oracle needs minutes here, so the size-independent properties are checked: GPU sufcheck (== sacabase::verify),
+    idempotence, BWT round trip of a sampled prefix property (U is a permutation of T: equal byte histograms)."""
+    n = 1 << 30
+    with ss.Context(n) as c:
+        c.generate(n, 3, kind)
+        c.build()
+        assert c.sufcheck() == 0, label
+        chk = c.checksum()
+        st = c.stats()
+        assert st["levels"] >= 3 and st["text_sort_state"] == 0, (label, st["level_sorted"])
+        c.build()
+        assert c.checksum() == chk
+        u, pidx = c.bwt()
+        assert 1 <= pidx <= n
+        assert np.array_equal(np.bincount(u, minlength=256), np.bincount(c.text(), minlength=256))
+
+
 def test_beyond_2pow31_needs_64bit_indices(ss):
     """BASELINE.json configs[4] partition size (16 GiB DNA over 8 GPUs = 2 GiB + 1 byte per sacapart chunk):
     texts of 2^31 bytes and more run on unsigned 32-bit device positions and are only reachable through the
