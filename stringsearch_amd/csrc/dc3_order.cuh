@@ -480,8 +480,7 @@ __global__ __launch_bounds__(kBlock) void k_tie_count(const Rec8 *__restrict__ h
 template <class KM>
 __global__ __launch_bounds__(kBlock) void k_tie_compact(KM km, const Rec8 *__restrict__ h, u32 n, u32 chunk,
                                                        u32 pbits, const u32 *__restrict__ base_excl,
-                                                       Rec16 *__restrict__ sub, u32 *__restrict__ tiedidx,
-                                                       u32 *__restrict__ gkey) {
+                                                       Rec16 *__restrict__ sub, u32 *__restrict__ tiedidx) {
   // 4 consecutive records per thread and block scan (few ties: most threads only read)
   __shared__ u32 tmp[kWaves];
   __shared__ uint16_t lcode[256];
@@ -515,9 +514,6 @@ __global__ __launch_bounds__(kBlock) void k_tie_compact(KM km, const Rec8 *__res
         const u32 p = h[i].val & posmask;
         sub[o] = km.make(p, lcode);
         tiedidx[o] = i;
-        // group id = low 32 bits of the key image; merging two adjacent groups that differ only above
-        // bit 31 is harmless (the union is sorted by the full key)
-        gkey[o] = (u32)img[j + 1];
         o++;
       }
     }

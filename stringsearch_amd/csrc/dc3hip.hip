@@ -571,15 +571,14 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
   }
   if (general) {
     Rec16 *sa = nullptr, *sb = nullptr, *ss = nullptr;
-    u32 *tiedidx = nullptr, *gkey = nullptr;
+    u32 *tiedidx = nullptr;
     RC(arena_alloc(c, (size_t)tied, &sa));
     RC(arena_alloc(c, (size_t)tied, &sb));
     RC(arena_alloc(c, (size_t)tied, &tiedidx));
-    RC(arena_alloc(c, (size_t)tied, &gkey));
     {
       PhaseScope ps(c, DC3HIP_PH_TIES, tied);
       hipLaunchKernelGGL((k_tie_compact<KM>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, km, h, nrec, ck.chunk,
-                         hm.pbits, counts, sa, tiedidx, gkey);
+                         hm.pbits, counts, sa, tiedidx);
       KCHECK();
     }
     RC(radix_sort<Rec16>(c, sa, sb, tied, 0, kbits, &ss, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN,
