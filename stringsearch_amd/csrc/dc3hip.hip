@@ -3,9 +3,9 @@
 // Host side of the DC3/Skew recursion of crates/dc3/src/lib.rs:44-193, re-designed for MI355X:
 //   * one context = one HIP stream + one device arena (no hipMalloc inside the recursion; the
 //     reference allocates 4 Vecs per level, lib.rs:50-57);
-//   * every level is a fixed sequence of streaming kernels (dc3_kernels.cuh); the only host
-//     round trip per level is the 4-byte "number of distinct names" read-back that decides
-//     lib.rs:103 (recurse or not);
+//   * every level is a fixed sequence of streaming kernels (dc3_kernels.cuh); the host only reads back a
+//     few words per level: the number of distinct names that decides lib.rs:103 (recurse or not), and the
+//     tie statistics that steer the ordering policy (which never affect the result);
 //   * no CPU fallback of any kind: if HIP fails the call fails (-3).
 #include <hip/hip_runtime.h>
 
