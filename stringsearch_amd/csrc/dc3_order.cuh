@@ -393,6 +393,30 @@ __global__ __launch_bounds__(kBlock) void k_emit_sorted(Acc acc, u32 n, u32 skip
     if (pairs) pairs[k] = Rec8{p, k + 1};
   }
 }
+// Tie-rate predictor: number of sample records whose key image equals another sample's, by insertion into an
+// open-addressing hash table (slot = image + 1, top bit = "seen again"); policy input only, so the count need not
+// be order- or schedule-independent beyond what it is: exact.
+__global__ __launch_bounds__(kBlock) void k_hash_ties(const Rec8 *__restrict__ a, u32 ns, u32 pbits,
+                                                     unsigned long long *table, u32 mask, u32 *ties) {
+  constexpr unsigned long long kSeen = 1ull << 63;
+  u32 cnt = 0;
+  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < ns; i += gridDim.x * kBlock) {
+    const unsigned long long img = (rec8_word(a[i]) >> pbits) + 1ull;
+    u32 hsh = (u32)((img * 0x9E3779B97F4A7C15ull) >> 40) & mask;
+    for (;;) {
+      const unsigned long long cur = atomicCAS(&table[hsh], 0ull, img);
+      if (cur == 0ull) break;                                        // first of its image
+      if ((cur & ~kSeen) == img) {
+        const unsigned long long old = atomicOr(&table[hsh], kSeen);
+        cnt += (old & kSeen) ? 1u : 2u;                              // the first occurrence is counted once, here
+        break;
+      }
+      hsh = (hsh + 1) & mask;
+    }
+  }
+  cnt = wave_reduce(cnt);
+  if (lane_id() == 0 && cnt) atomicAdd(ties, cnt);
+}
 // Not all triples distinct: keep the work.  The samples (pos % 3 != 0, incl. the dummy at pos == m) are
 // filtered out of the fully sorted order — they are then in sorted sample order — together with their
 // "full name" nf = number of key changes up to them, so equal keys <=> equal nf.

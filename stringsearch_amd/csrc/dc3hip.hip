@@ -482,26 +482,36 @@ static int count_ties(dc3hip_ctx *c, const Rec8 *h, u32 n, u32 pbits, u32 *count
   return E_OK;
 }
 
+// sample records whose key image equals another sample's (hash table in the arena; see k_hash_ties)
+static int sample_ties(dc3hip_ctx *c, const Rec8 *a, u32 ns, u32 pbits, u32 *ts) {
+  u32 slots = 1; while (slots < 2 * ns) slots <<= 1;
+  unsigned long long *table = nullptr;
+  RC(arena_alloc(c, (size_t)slots, &table));
+  HIPC(hipMemsetAsync(table, 0, (size_t)slots * sizeof(unsigned long long), c->stream));
+  HIPC(hipMemsetAsync(c->d_words + 2, 0, sizeof(u32), c->stream));
+  hipLaunchKernelGGL(k_hash_ties, dim3(grid_for(c, ns)), dim3(kBlock), 0, c->stream, a, ns, pbits, table, slots - 1,
+                     c->d_words + 2);
+  KCHECK();
+  HIPC(hipMemcpyAsync(c->h_words + 2, c->d_words + 2, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  *ts = c->h_words[2];
+  return E_OK;
+}
+
 template <class Sym>
 static int predict_tie_fraction(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, HiMap sh, double *pred) {
   const ArenaMark mk = arena_mark(c);
   const u32 stride = std::max<u32>(1, m0 >> 19);
   const u32 ng = (m0 - 1) / stride + 1;      // sampled groups, 2 records each
   const u32 ns = 2 * ng;
-  Rec8 *a = nullptr, *bb = nullptr, *sorted = nullptr;
+  Rec8 *a = nullptr;
   RC(arena_alloc(c, (size_t)ns, &a));
-  RC(arena_alloc(c, (size_t)ns, &bb));
   PhaseScope ps(c, DC3HIP_PH_PACK, ns);
   hipLaunchKernelGGL((k_pack_image<Sym>), dim3(grid_for(c, ng)), dim3(kBlock), 0, c->stream, S, m, m0, m02, b, sh,
                      stride, ng, a);
   KCHECK();
-  RC(radix_sort<Rec8>(c, a, bb, ns, sh.pbits, sh.pbits + sh.nbits, &sorted, DC3HIP_PH_PACK, DC3HIP_PH_PACK,
-                      DC3HIP_PH_PACK));
-  const Chunking ck = make_chunks(c, ns, kBlock);
-  u32 *counts = nullptr;
-  RC(arena_alloc(c, (size_t)ck.nchunks + 16, &counts));
   u32 ts = 0;
-  RC(count_ties(c, sorted, ns, sh.pbits, counts, ck, &ts));
+  RC(sample_ties(c, a, ns, sh.pbits, &ts));
   const double fs = (double)ts / (double)ns;
   const double ratio = (double)(m02 - 1) / (double)(ns > 1 ? ns - 1 : 1);
   *pred = fs >= 1.0 ? 1.0 : 1.0 - pow(1.0 - fs, ratio);
@@ -600,19 +610,13 @@ static int predict_tie_fraction_pos(dc3hip_ctx *c, KM km, u32 n, const HiMap &hm
   const ArenaMark mk = arena_mark(c);
   const u32 stride = std::max<u32>(1, n >> 20);
   const u32 ns = (n - 1) / stride + 1;
-  Rec8 *a = nullptr, *bb = nullptr, *sorted = nullptr;
+  Rec8 *a = nullptr;
   RC(arena_alloc(c, (size_t)ns, &a));
-  RC(arena_alloc(c, (size_t)ns, &bb));
   PhaseScope ps(c, DC3HIP_PH_PACK, ns);
   hipLaunchKernelGGL((k_pack_image_pos<KM>), dim3(grid_for(c, ns)), dim3(kBlock), 0, c->stream, km, ns, stride, hm, a);
   KCHECK();
-  RC(radix_sort<Rec8>(c, a, bb, ns, hm.pbits, hm.pbits + hm.nbits, &sorted, DC3HIP_PH_PACK, DC3HIP_PH_PACK,
-                      DC3HIP_PH_PACK));
-  const Chunking ck = make_chunks(c, ns, kBlock);
-  u32 *counts = nullptr;
-  RC(arena_alloc(c, (size_t)ck.nchunks + 16, &counts));
   u32 ts = 0;
-  RC(count_ties(c, sorted, ns, hm.pbits, counts, ck, &ts));
+  RC(sample_ties(c, a, ns, hm.pbits, &ts));
   const double fs = (double)ts / (double)ns;
   const double ratio = (double)(n - 1) / (double)(ns > 1 ? ns - 1 : 1);
   *pred = fs >= 1.0 ? 1.0 : 1.0 - pow(1.0 - fs, ratio);
