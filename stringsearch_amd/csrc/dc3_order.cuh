@@ -331,13 +331,21 @@ struct Key9 {
   }
 };
 // whole text, 4 consecutive positions per thread: 12 aligned text bytes -> 12 codes -> 10 byte-triples shared by
-// the 4 keys; 32 contiguous output bytes per thread
-__global__ __launch_bounds__(kBlock) void k_pack_image_text(Key9 km, u32 n, HiMap hm, Rec8 *__restrict__ out) {
+// the 4 keys; 32 contiguous output bytes per thread.  Blocks own the chunks of the radix sort that follows and
+// also produce its first digit table (the up-sweep of pass 1 never reads the records back): table[d*nchunks + b].
+template <int NB>
+__global__ __launch_bounds__(kBlock) void k_pack_image_text(Key9 km, u32 n, HiMap hm, Rec8 *__restrict__ out, u32 chunk,
+                                                           u32 nchunks, u32 *__restrict__ table) {
   __shared__ uint16_t lcode[256];
+  __shared__ u32 hist[kWaves][NB];
   km.stage(lcode);
-  const u32 nq = (n + 3) / 4;
-  for (u32 g = blockIdx.x * kBlock + threadIdx.x; g < nq; g += gridDim.x * kBlock) {
-    const u32 p0 = 4 * g;
+#pragma unroll
+  for (int w = 0; w < kWaves; w++)
+    for (int j = threadIdx.x; j < NB; j += kBlock) hist[w][j] = 0;
+  __syncthreads();
+  u32 *myh = hist[wave_id()];
+  const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);       // chunk is a multiple of 4
+  for (u32 p0 = begin + 4 * threadIdx.x; p0 < end; p0 += 4 * kBlock) {
     const u32 *tw = reinterpret_cast<const u32 *>(km.S.t + p0);
     const u32 w[3] = {tw[0], tw[1], tw[2]};
     u32 q[12];
@@ -348,14 +356,24 @@ __global__ __launch_bounds__(kBlock) void k_pack_image_text(Key9 km, u32 n, HiMa
     for (int k = 0; k < 10; k++) u[k] = (q[k] * km.B + q[k + 1]) * km.B + q[k + 2];
     Rec8 r[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) r[j] = hyb_rec(make_rec(u[j], u[j + 3], u[j + 6], km.B3, p0 + j), hm);
-    if (p0 + 3 < n) {
+    for (int j = 0; j < 4; j++) {
+      r[j] = hyb_rec(make_rec(u[j], u[j + 3], u[j + 6], km.B3, p0 + j), hm);
+      if (p0 + j < end) atomicAdd(&myh[(u32)(rec8_word(r[j]) >> hm.pbits) & (NB - 1)], 1u);
+    }
+    if (p0 + 3 < end) {
       u32x4 *o = reinterpret_cast<u32x4 *>(out + p0);
       o[0] = u32x4{r[0].key, r[0].val, r[1].key, r[1].val};
       o[1] = u32x4{r[2].key, r[2].val, r[3].key, r[3].val};
     } else {
-      for (int j = 0; j < 4; j++) if (p0 + j < n) out[p0 + j] = r[j];
+      for (int j = 0; j < 4; j++) if (p0 + j < end) out[p0 + j] = r[j];
     }
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < NB; j += kBlock) {
+    u32 sum = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; w++) sum += hist[w][j];
+    table[(size_t)j * nchunks + blockIdx.x] = sum;
   }
 }
 // records of positions 0, stride, 2*stride, ... (stride 1 = all positions; > 1 = tie-rate predictor sample)

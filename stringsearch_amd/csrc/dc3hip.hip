@@ -218,20 +218,22 @@ static int scan_digit_table(dc3hip_ctx *c, u32 *table, u32 nchunks, u32 *digit_b
 
 // Stable LSD sort of key bits [bit_lo, bit_hi) of the records in `a` (ping-pong with `b`).
 // Digit width: 9 bits where that saves a pass over 8-bit digits, else 8.
+// first_table: digit table of the first pass already produced by whoever wrote the records (k_pack_image_text);
+// it must have been made for radix_plan()'s chunking and bin count.
 template <class Rec, int NB>
 static int radix_passes(dc3hip_ctx *c, Rec *a, Rec *b, u32 n, u32 bit_lo, u32 bit_hi, Rec **result, int ph_up,
-                        int ph_scan, int ph_down) {
+                        int ph_scan, int ph_down, u32 *first_table = nullptr) {
   constexpr u32 kBits = NB == 512 ? 9 : 8;
   constexpr int kTile = SortCfg<Rec, NB>::NW * 64 * SortCfg<Rec, NB>::IPT;
   const Chunking ck = make_chunks(c, n, kTile);
   const ArenaMark mk = arena_mark(c);
-  u32 *table = nullptr, *digit_base = nullptr;
-  RC(arena_alloc(c, (size_t)NB * ck.nchunks, &table));
+  u32 *table = first_table, *digit_base = nullptr;
+  if (!table) RC(arena_alloc(c, (size_t)NB * ck.nchunks, &table));
   RC(arena_alloc(c, (size_t)NB, &digit_base));
   Rec *src = a, *dst = b;
   for (u32 lo = bit_lo; lo < bit_hi; lo += kBits) {
     KeyDig dig; dig.shift = lo; dig.mask = NB - 1;
-    {
+    if (!(first_table && lo == bit_lo)) {
       PhaseScope ps(c, ph_up, n);
       hipLaunchKernelGGL((k_rs_upsweep<Rec, NB>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, src, n, ck.chunk,
                          ck.nchunks, dig, table);
@@ -246,14 +248,22 @@ static int radix_passes(dc3hip_ctx *c, Rec *a, Rec *b, u32 n, u32 bit_lo, u32 bi
   *result = src;
   return E_OK;
 }
+static bool radix_nine(const dc3hip_ctx *c, u32 bits) { return !c->no_nine_bit && ((bits + 8) / 9 < (bits + 7) / 8); }
 template <class Rec>
 static int radix_sort(dc3hip_ctx *c, Rec *a, Rec *b, u32 n, u32 bit_lo, u32 bit_hi, Rec **result, int ph_up,
-                      int ph_scan, int ph_down) {
+                      int ph_scan, int ph_down, u32 *first_table = nullptr) {
   const u32 bits = bit_hi > bit_lo ? bit_hi - bit_lo : 0;
   if (bits == 0) { *result = a; return E_OK; }
-  const bool nine = !c->no_nine_bit && ((bits + 8) / 9 < (bits + 7) / 8);
-  if (nine) return radix_passes<Rec, 512>(c, a, b, n, bit_lo, bit_hi, result, ph_up, ph_scan, ph_down);
-  return radix_passes<Rec, 256>(c, a, b, n, bit_lo, bit_hi, result, ph_up, ph_scan, ph_down);
+  if (radix_nine(c, bits)) return radix_passes<Rec, 512>(c, a, b, n, bit_lo, bit_hi, result, ph_up, ph_scan, ph_down, first_table);
+  return radix_passes<Rec, 256>(c, a, b, n, bit_lo, bit_hi, result, ph_up, ph_scan, ph_down, first_table);
+}
+// bins and chunking radix_sort<Rec> will use for n records and `bits` key bits
+template <class Rec>
+static void radix_plan(dc3hip_ctx *c, u32 n, u32 bits, int *nb, Chunking *ck) {
+  const bool nine = radix_nine(c, bits);
+  *nb = nine ? 512 : 256;
+  const int tile = nine ? SortCfg<Rec, 512>::NW * 64 * SortCfg<Rec, 512>::IPT : SortCfg<Rec, 256>::NW * 64 * SortCfg<Rec, 256>::IPT;
+  *ck = make_chunks(c, n, (u32)tile);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -543,12 +553,12 @@ static int order_straight(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u
 template <class KM>
 static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Rec8 *ha, Rec8 *hb, u32 nrec,
                             Rec8 **h_out, uint8_t *f, bool *ok, int depth, u32 *emit_sa = nullptr, u32 skip = 0,
-                            bool *emitted_distinct = nullptr) {
+                            bool *emitted_distinct = nullptr, u32 *first_table = nullptr) {
   *ok = false;
   if (emitted_distinct) *emitted_distinct = false;
   Rec8 *h = nullptr;
   RC(radix_sort<Rec8>(c, ha, hb, nrec, hm.pbits, hm.pbits + hm.nbits, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN,
-                      DC3HIP_PH_SORT8_DOWN));
+                      DC3HIP_PH_SORT8_DOWN, first_table));
   const Chunking ck = make_chunks(c, nrec, kBlock);
   u32 *counts = nullptr;
   RC(arena_alloc(c, (size_t)ck.nchunks + 16, &counts));
@@ -658,13 +668,30 @@ static int order_hybrid(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u32
 //            naming continues from there and the sort is not repeated;
 //   state 0: too many collisions in the key image, nothing was produced.
 // spos/snf (m02 entries each) must be allocated by the caller below this function's arena mark.
+// Packs the records of all positions; *first_table != nullptr on return when the kernel also produced the digit
+// table of the first radix pass (whole text: k_pack_image_text).
 template <class KM>
-static void launch_pack_all(dc3hip_ctx *c, KM km, u32 nrec, const HiMap &hm, Rec8 *out) {
+static int launch_pack_all(dc3hip_ctx *c, KM km, u32 nrec, const HiMap &hm, Rec8 *out, u32 **first_table) {
+  *first_table = nullptr;
   hipLaunchKernelGGL((k_pack_image_pos<KM>), dim3(grid_for(c, nrec)), dim3(kBlock), 0, c->stream, km, nrec, 1u, hm, out);
+  KCHECK();
+  return E_OK;
 }
 template <>
-void launch_pack_all<Key9>(dc3hip_ctx *c, Key9 km, u32 nrec, const HiMap &hm, Rec8 *out) {
-  hipLaunchKernelGGL(k_pack_image_text, dim3(grid_for(c, (nrec + 3) / 4)), dim3(kBlock), 0, c->stream, km, nrec, hm, out);
+int launch_pack_all<Key9>(dc3hip_ctx *c, Key9 km, u32 nrec, const HiMap &hm, Rec8 *out, u32 **first_table) {
+  int nb = 0; Chunking ck;
+  radix_plan<Rec8>(c, nrec, hm.nbits, &nb, &ck);
+  u32 *table = nullptr;
+  RC(arena_alloc(c, (size_t)nb * ck.nchunks, &table));
+  if (nb == 512)
+    hipLaunchKernelGGL((k_pack_image_text<512>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, km, nrec, hm, out, ck.chunk,
+                       ck.nchunks, table);
+  else
+    hipLaunchKernelGGL((k_pack_image_text<256>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, km, nrec, hm, out, ck.chunk,
+                       ck.nchunks, table);
+  KCHECK();
+  *first_table = table;
+  return E_OK;
 }
 template <class KM, class Map>
 static int order_all_positions(dc3hip_ctx *c, KM km, Map mp, u32 m, u32 kbits, const HiMap &hm, u32 dummy, u32 *out_sa,
@@ -677,14 +704,14 @@ static int order_all_positions(dc3hip_ctx *c, KM km, Map mp, u32 m, u32 kbits, c
   RC(arena_alloc(c, (size_t)nrec, &ha));
   RC(arena_alloc(c, (size_t)nrec, &hb));
   RC(arena_alloc(c, (size_t)nrec + 16, &f));
+  u32 *first_table = nullptr;
   {
     PhaseScope ps(c, DC3HIP_PH_PACK, nrec);
-    launch_pack_all(c, km, nrec, hm, ha);
-    KCHECK();
+    RC(launch_pack_all<KM>(c, km, nrec, hm, ha, &first_table));
   }
   bool sorted_ok = false, distinct = false;
   RC((hybrid_sort_core<KM>(c, km, kbits, hm, ha, hb, nrec, &h, f, &sorted_ok, depth, out_rank ? nullptr : out_sa, dummy,
-                           &distinct)));
+                           &distinct, first_table)));
   if (sorted_ok && distinct) {
     *state = 1;                            // the tie pass already wrote the suffix array
   } else if (sorted_ok) {
