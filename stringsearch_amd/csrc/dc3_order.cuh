@@ -384,6 +384,64 @@ __global__ __launch_bounds__(kBlock) void k_pack_image_pos(KM km, u32 nout, u32 
   for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < nout; i += gridDim.x * kBlock)
     out[i] = hyb_rec(km.make(i * stride, lcode), hm);
 }
+// Chunked variants that also produce the digit table of the first radix pass (table[d*nchunks + block]), so the
+// sort that follows starts with its down-sweep: all positions of a level, and the samples of a level.
+template <class KM, int NB>
+__global__ __launch_bounds__(kBlock) void k_pack_image_all_hist(KM km, u32 nrec, HiMap hm, Rec8 *__restrict__ out,
+                                                               u32 chunk, u32 nchunks, u32 *__restrict__ table) {
+  __shared__ uint16_t lcode[256];
+  __shared__ u32 hist[kWaves][NB];
+  km.stage(lcode);
+#pragma unroll
+  for (int w = 0; w < kWaves; w++)
+    for (int j = threadIdx.x; j < NB; j += kBlock) hist[w][j] = 0;
+  __syncthreads();
+  u32 *myh = hist[wave_id()];
+  const u32 begin = blockIdx.x * chunk, end = min(nrec, begin + chunk);
+  for (u32 i = begin + threadIdx.x; i < end; i += kBlock) {
+    const Rec8 r = hyb_rec(km.make(i, lcode), hm);
+    out[i] = r;
+    atomicAdd(&myh[(u32)(rec8_word(r) >> hm.pbits) & (NB - 1)], 1u);
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < NB; j += kBlock) {
+    u32 sum = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; w++) sum += hist[w][j];
+    table[(size_t)j * nchunks + blockIdx.x] = sum;
+  }
+}
+template <class Sym, int NB>
+__global__ __launch_bounds__(kBlock) void k_pack_image_hist(Sym S, u32 m, u32 m0, u32 m02, u32 b, HiMap hm,
+                                                           Rec8 *__restrict__ out, u32 chunk, u32 nchunks,
+                                                           u32 *__restrict__ table) {
+  __shared__ u32 hist[kWaves][NB];
+#pragma unroll
+  for (int w = 0; w < kWaves; w++)
+    for (int j = threadIdx.x; j < NB; j += kBlock) hist[w][j] = 0;
+  __syncthreads();
+  u32 *myh = hist[wave_id()];
+  const u32 begin = blockIdx.x * chunk, end = min(m02, begin + chunk);      // output indices; chunk is even
+  for (u32 g = begin / 2 + threadIdx.x; 2 * g < end; g += kBlock) {
+    const u32 i = 3 * g + 1;
+    const u32 s1 = S.get(i), s2 = S.get(i + 1), s3 = S.get(i + 2), s4 = S.get(i + 3);
+    const Rec8 r0 = hyb_rec(make_rec(s1, s2, s3, b, i), hm);
+    out[2 * g] = r0;
+    atomicAdd(&myh[(u32)(rec8_word(r0) >> hm.pbits) & (NB - 1)], 1u);
+    if (2 * g + 1 < m02) {
+      const Rec8 r1 = hyb_rec(make_rec(s2, s3, s4, b, i + 1), hm);
+      out[2 * g + 1] = r1;
+      atomicAdd(&myh[(u32)(rec8_word(r1) >> hm.pbits) & (NB - 1)], 1u);
+    }
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < NB; j += kBlock) {
+    u32 sum = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; w++) sum += hist[w][j];
+    table[(size_t)j * nchunks + blockIdx.x] = sum;
+  }
+}
 // stride > 1 samples every stride-th group (tie-rate predictor); out index = g / stride
 template <class Sym>
 __global__ __launch_bounds__(kBlock) void k_pack_image(Sym S, u32 m, u32 m0, u32 m02, u32 b, HiMap hm, u32 stride,

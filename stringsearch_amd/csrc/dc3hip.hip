@@ -644,15 +644,24 @@ static int order_hybrid(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u32
   RC(arena_alloc(c, (size_t)m02, &ha));
   RC(arena_alloc(c, (size_t)m02, &hb));
   RC(arena_alloc(c, (size_t)m02 + 16, &f));
+  u32 *first_table = nullptr;
   {
     PhaseScope ps(c, DC3HIP_PH_PACK, m02);
-    hipLaunchKernelGGL((k_pack_image<Sym>), dim3(grid_for(c, m0)), dim3(kBlock), 0, c->stream, S, m, m0, m02, b, hm,
-                       1u, m0, ha);
+    int nb = 0; Chunking ck;
+    radix_plan<Rec8>(c, m02, hm.nbits, &nb, &ck);
+    RC(arena_alloc(c, (size_t)nb * ck.nchunks, &first_table));
+    if (nb == 512)
+      hipLaunchKernelGGL((k_pack_image_hist<Sym, 512>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, S, m, m0, m02, b, hm,
+                         ha, ck.chunk, ck.nchunks, first_table);
+    else
+      hipLaunchKernelGGL((k_pack_image_hist<Sym, 256>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, S, m, m0, m02, b, hm,
+                         ha, ck.chunk, ck.nchunks, first_table);
     KCHECK();
   }
   bool sorted_ok = false;
   Key3<Sym> km; km.S = S; km.B = b;
-  RC((hybrid_sort_core<Key3<Sym>>(c, km, kbits, hm, ha, hb, m02, &h, f, &sorted_ok, depth)));
+  RC((hybrid_sort_core<Key3<Sym>>(c, km, kbits, hm, ha, hb, m02, &h, f, &sorted_ok, depth, nullptr, 0, nullptr,
+                                  first_table)));
   if (!sorted_ok) return E_OK;
   c->stats.level_sorted[depth] = 2;
   AccHyb acc; acc.h = h; acc.f = f; acc.posmask = hm.pbits >= 32 ? 0xffffffffu : ((1u << hm.pbits) - 1u);
@@ -672,9 +681,18 @@ static int order_hybrid(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u32
 // table of the first radix pass (whole text: k_pack_image_text).
 template <class KM>
 static int launch_pack_all(dc3hip_ctx *c, KM km, u32 nrec, const HiMap &hm, Rec8 *out, u32 **first_table) {
-  *first_table = nullptr;
-  hipLaunchKernelGGL((k_pack_image_pos<KM>), dim3(grid_for(c, nrec)), dim3(kBlock), 0, c->stream, km, nrec, 1u, hm, out);
+  int nb = 0; Chunking ck;
+  radix_plan<Rec8>(c, nrec, hm.nbits, &nb, &ck);
+  u32 *table = nullptr;
+  RC(arena_alloc(c, (size_t)nb * ck.nchunks, &table));
+  if (nb == 512)
+    hipLaunchKernelGGL((k_pack_image_all_hist<KM, 512>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, km, nrec, hm, out,
+                       ck.chunk, ck.nchunks, table);
+  else
+    hipLaunchKernelGGL((k_pack_image_all_hist<KM, 256>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, km, nrec, hm, out,
+                       ck.chunk, ck.nchunks, table);
   KCHECK();
+  *first_table = table;
   return E_OK;
 }
 template <>
