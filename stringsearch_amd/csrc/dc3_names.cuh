@@ -109,4 +109,37 @@ __global__ __launch_bounds__(kBlock) void k_pack_triples(Sym S, u32 m, u32 m0, u
   }
 }
 
+// chunked variant that also produces the digit table of the first radix pass over the records (digit = key bits
+// [0, log2 NB), table[d*nchunks + block]); output indices [block*chunk, ...), chunk even
+template <class Sym, class Rec, int NB>
+__global__ __launch_bounds__(kBlock) void k_pack_triples_hist(Sym S, u32 m, u32 m0, u32 m02, u32 b, Rec *out, u32 chunk,
+                                                             u32 nchunks, u32 *__restrict__ table) {
+  __shared__ u32 hist[kWaves][NB];
+#pragma unroll
+  for (int w = 0; w < kWaves; w++)
+    for (int j = threadIdx.x; j < NB; j += kBlock) hist[w][j] = 0;
+  __syncthreads();
+  u32 *myh = hist[wave_id()];
+  const u32 begin = blockIdx.x * chunk, end = min(m02, begin + chunk);
+  for (u32 g = begin / 2 + threadIdx.x; 2 * g < end; g += kBlock) {
+    const u32 i = 3 * g + 1;
+    const u32 s1 = S.get(i), s2 = S.get(i + 1), s3 = S.get(i + 2), s4 = S.get(i + 3);
+    const Rec16 r0 = make_rec(s1, s2, s3, b, i);
+    store_rec(out, 2 * g, r0);
+    atomicAdd(&myh[r0.k0 & (NB - 1)], 1u);
+    if (2 * g + 1 < m02) {
+      const Rec16 r1 = make_rec(s2, s3, s4, b, i + 1);
+      store_rec(out, 2 * g + 1, r1);
+      atomicAdd(&myh[r1.k0 & (NB - 1)], 1u);
+    }
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < NB; j += kBlock) {
+    u32 sum = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; w++) sum += hist[w][j];
+    table[(size_t)j * nchunks + blockIdx.x] = sum;
+  }
+}
+
 }  // namespace dc3

@@ -536,14 +536,22 @@ static int order_straight(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u
   Rec *recA = nullptr, *recB = nullptr, *sorted = nullptr;
   RC(arena_alloc(c, (size_t)m02, &recA));
   RC(arena_alloc(c, (size_t)m02, &recB));
+  u32 *first_table = nullptr;
   {
     PhaseScope ps(c, DC3HIP_PH_PACK, m02);
-    hipLaunchKernelGGL((k_pack_triples<Sym, Rec>), dim3(grid_for(c, m0)), dim3(kBlock), 0, c->stream, S, m, m0, m02,
-                       b, recA);
+    int nb = 0; Chunking ck;
+    radix_plan<Rec>(c, m02, kbits, &nb, &ck);
+    RC(arena_alloc(c, (size_t)nb * ck.nchunks, &first_table));
+    if (nb == 512)
+      hipLaunchKernelGGL((k_pack_triples_hist<Sym, Rec, 512>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, S, m, m0, m02,
+                         b, recA, ck.chunk, ck.nchunks, first_table);
+    else
+      hipLaunchKernelGGL((k_pack_triples_hist<Sym, Rec, 256>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, S, m, m0, m02,
+                         b, recA, ck.chunk, ck.nchunks, first_table);
     KCHECK();
   }
   RC(radix_sort<Rec>(c, recA, recB, m02, 0, kbits, &sorted, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN,
-                     DC3HIP_PH_SORT12_DOWN));
+                     DC3HIP_PH_SORT12_DOWN, first_table));
   AccRec<Rec> acc; acc.s = sorted;
   return name_and_rank<AccRec<Rec>>(c, acc, m02, m0, sa12, rank12, R, sslot, names, mode);
 }
