@@ -140,7 +140,7 @@ __global__ __launch_bounds__(NW * 64) void k_rs_downsweep(Loader in, Rec *__rest
     // running prefix) and the bases are broadcast afterwards.  Dropped / out-of-range lanes take
     // no part.
     {
-      u32 below[IPT], leader[IPT], old[IPT];
+      u32 below[IPT], old[IPT];
 #pragma unroll
       for (int k = 0; k < IPT; k++) {
         u64 peers = __ballot(ok[k]);
@@ -151,12 +151,15 @@ __global__ __launch_bounds__(NW * 64) void k_rs_downsweep(Loader in, Rec *__rest
           peers &= one ? mk : ~mk;
         }
         below[k] = mbcnt(peers);
-        leader[k] = ok[k] ? (u32)__ffsll((unsigned long long)peers) - 1u : lane;
-        old[k] = 0;
-        if (ok[k] && below[k] == 0) old[k] = atomicAdd(&mycnt[d[k]], (u32)__popcll(peers));
+        // every lane reads the wave's running count of its digit, then the lowest peer adds the round's count
+        // (no return value needed); DS operations of one wave execute in issue order, so round k+1 reads what
+        // round k added
+        old[k] = ok[k] ? __hip_atomic_load(&mycnt[d[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) : 0u;
+        if (ok[k] && below[k] == 0)
+          (void)__hip_atomic_fetch_add(&mycnt[d[k]], (u32)__popcll(peers), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       }
 #pragma unroll
-      for (int k = 0; k < IPT; k++) rk[k] = __shfl(old[k], leader[k]) + below[k];
+      for (int k = 0; k < IPT; k++) rk[k] = old[k] + below[k];
     }
     __syncthreads();
     // per digit (thread tid = digit): prefix over waves, tile total, tile-exclusive prefix
