@@ -143,13 +143,17 @@ __global__ __launch_bounds__(NW * 64) void k_rs_downsweep(Loader in, Rec *__rest
       u32 below[IPT], old[IPT];
 #pragma unroll
       for (int k = 0; k < IPT; k++) {
-        u64 peers = __ballot(ok[k]);
+        // peers = lanes whose digit equals mine: a lane differs from me in bit b iff ballot(b) ^ mybit(b) has its
+        // bit set, so peers = ~OR_b (ballot_b ^ splat(mybit_b)), restricted to participating lanes
+        const u64 okm = __ballot(ok[k]);
+        u32 dlo = 0, dhi = 0;
 #pragma unroll
         for (int bit = 0; bit < kBits; bit++) {
-          const bool one = (d[k] >> bit) & 1u;
-          const u64 mk = __ballot(one);
-          peers &= one ? mk : ~mk;
+          const u32 om = (u32)((int)(d[k] << (31 - bit)) >> 31);      // all ones iff my bit is set
+          const u64 mk = __ballot(om != 0u);
+          dlo |= (u32)mk ^ om; dhi |= (u32)(mk >> 32) ^ om;
         }
+        const u64 peers = ~(((u64)dhi << 32) | dlo) & okm;
         below[k] = mbcnt(peers);
         // every lane reads the wave's running count of its digit, then the lowest peer adds the round's count
         // (no return value needed); DS operations of one wave execute in issue order, so round k+1 reads what
