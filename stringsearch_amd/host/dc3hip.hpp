@@ -5,6 +5,7 @@
 #pragma once
 #include <stdexcept>
 #include <string>
+#include <vector>
 #include "../../include/dc3hip.h"
 #include "sacabase.hpp"
 
@@ -35,6 +36,19 @@ inline sacabase::SuffixArray<int64_t> sort_i64(sacabase::Bytes text) {
   const int32_t ret = dc3hip_sufsort_i64(text.len ? text.ptr : &zero, sa.size() ? sa.data() : &dummy, (int64_t)text.len);
   if (ret != 0) throw Error(ret, dc3hip_last_error());
   return sacabase::SuffixArray<int64_t>(text, std::move(sa));
+}
+
+// The local SAs of a sacapart partitioning (chunk size len/P + 1, sacapart/src/lib.rs:43-46) from ONE library call,
+// back to back; with all_devices the node's GPUs share the chunks (one host worker per GPU) — the par_chunks of
+// lib.rs:45-49.  Feed the result to sacapart::PartitionedSuffixArray(text, P, flat).
+inline std::vector<int32_t> sort_partitions(sacabase::Bytes text, size_t num_partitions, bool all_devices = true) {
+  std::vector<int32_t> sa(text.len, 0);
+  if (text.len == 0) return sa;
+  dc3hip_opts o; o.struct_size = (int32_t)sizeof(o); o.index_bits = 32; o.device = -1;
+  o.num_partitions = (int32_t)num_partitions; o.flags = all_devices ? DC3HIP_F_ALL_DEVICES : 0;
+  const int32_t ret = dc3hip_sufsort_ex(text.ptr, sa.data(), (int64_t)text.len, &o);
+  if (ret != 0) throw Error(ret, dc3hip_last_error());
+  return sa;
 }
 
 // Device-resident index: text and SA stay in HBM; batched searches and the BWT run on the GPU.

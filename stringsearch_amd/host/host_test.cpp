@@ -58,6 +58,17 @@ int main() {
     std::vector<uint8_t> u; const int64_t pidx = bi.bwt(u);
     CHECK(std::string(u.begin(), u.end()) == "annbaa"); CHECK(pidx == 4);
   }
+  {  // all partitions from one library call (DC3HIP_F_ALL_DEVICES) == one sort per chunk
+    std::string input = "This is a rather long text. We can probably find matches that span two partitions. Oh yes.";
+    for (size_t partitions = 1; partitions < 6; partitions++) {
+      sacapart::PartitionedSuffixArray<int32_t> a(Bytes(input), partitions, dc3hip::sort);
+      sacapart::PartitionedSuffixArray<int32_t> b(Bytes(input), partitions, dc3hip::sort_partitions(Bytes(input), partitions, true));
+      CHECK(a.num_partitions() == b.num_partitions());
+      for (size_t i = 0; i < a.num_partitions(); i++) CHECK(a.partitions()[i].sa() == b.partitions()[i].sa());
+      CHECK(b.longest_substring_match(Bytes(std::string("find matches that span"))).len ==
+            a.longest_substring_match(Bytes(std::string("find matches that span"))).len);
+    }
+  }
   {  // error behaviour: len mismatch throws like the Rust assert
     std::vector<int32_t> sa(2);
     bool threw = false;

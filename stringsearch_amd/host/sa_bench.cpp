@@ -18,7 +18,7 @@
 #include "dc3hip.hpp"
 #include "sacapart.hpp"
 
-static void usage() { std::printf("Usage: sa_bench bench|run|verify INPUT [LENGTH] [--ref LIBDIVSUFSORT.so] [--partitions P]\n"); std::exit(1); }
+static void usage() { std::printf("Usage: sa_bench bench|run|verify INPUT [LENGTH] [--ref LIBDIVSUFSORT.so] [--partitions P [--all-devices]]\n"); std::exit(1); }
 
 // main.rs:192-208
 static size_t parse_size(std::string s) {
@@ -54,11 +54,12 @@ static std::vector<uint8_t> load_input(const std::string &spec) {
 }
 
 int main(int argc, char **argv) {
-  std::vector<std::string> free_args; std::string ref_path; size_t partitions = 0;
+  std::vector<std::string> free_args; std::string ref_path; size_t partitions = 0; bool all_devices = false;
   for (int i = 1; i < argc; i++) {
     std::string a = argv[i];
     if (a == "--ref" && i + 1 < argc) ref_path = argv[++i];
     else if (a == "--partitions" && i + 1 < argc) partitions = (size_t)std::atoll(argv[++i]);
+    else if (a == "--all-devices") all_devices = true;
     else free_args.push_back(a);
   }
   if (free_args.size() < 2) usage();
@@ -74,7 +75,9 @@ int main(int argc, char **argv) {
   try {
     if (cmd == "run") {                                                           // main.rs:115-121
       const auto t0 = clk::now();
-      if (partitions > 1) sacapart::PartitionedSuffixArray<int32_t> p(input, partitions, dc3hip::sort);
+      if (partitions > 1 && all_devices)      // one library call, the node's GPUs share the chunks
+        sacapart::PartitionedSuffixArray<int32_t> p(input, partitions, dc3hip::sort_partitions(input, partitions, true));
+      else if (partitions > 1) sacapart::PartitionedSuffixArray<int32_t> p(input, partitions, dc3hip::sort);
       else dc3hip::sort(input);
       std::printf("Done in %.6fs\n", std::chrono::duration<double>(clk::now() - t0).count());
       return 0;

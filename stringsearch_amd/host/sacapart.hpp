@@ -37,6 +37,17 @@ class PartitionedSuffixArray : public sacabase::StringIndex {
     for (size_t i = 0; i < chunks.size(); i++) sas_.emplace_back(chunks[i], std::move(out[i]));   // chunk order, :50-51
   }
 
+  // Same object from partition SAs that were built elsewhere, back to back in `flat` (chunk c at offset c*S, local
+  // indices) — what dc3hip_sufsort_ex(num_partitions = P) writes.
+  PartitionedSuffixArray(sacabase::Bytes text, size_t num_partitions, const std::vector<Index> &flat)
+      : partition_size_(text.len / num_partitions + 1), text_(text) {
+    if (flat.size() != text.len) throw std::invalid_argument("flat partition SAs should have the text's length");
+    for (size_t off = 0; off < text.len; off += partition_size_) {
+      const size_t end = std::min(text.len, off + partition_size_);
+      sas_.emplace_back(text.slice(off, end), std::vector<Index>(flat.begin() + off, flat.begin() + end));
+    }
+  }
+
   size_t num_partitions() const { return sas_.size(); }   // :60
   size_t partition_size() const { return partition_size_; }
   const std::vector<sacabase::SuffixArray<Index>> &partitions() const { return sas_; }
