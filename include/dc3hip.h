@@ -116,6 +116,10 @@ DC3HIP_API int32_t dc3hip_ctx_set_sa_i32(dc3hip_ctx *ctx, const int32_t *SA);
 
 /* bw_transform() of utils.c:53-108 on the device-resident text/SA: U receives n bytes. */
 DC3HIP_API int32_t dc3hip_ctx_bwt(dc3hip_ctx *ctx, uint8_t *U, int64_t *primary_index);
+/* LCP array of the resident SA (SURVEY §8f "BWT/LCP by-products"; the reference ships no LCP routine, the definition
+ * is the usual one): LCP[0] = 0, LCP[i] = length of the longest common prefix of the suffixes SA[i-1] and SA[i].
+ * LCP: n x int32, host or device pointer.  n < 2^31. */
+DC3HIP_API int32_t dc3hip_ctx_lcp_i32(dc3hip_ctx *ctx, int32_t *LCP);
 
 /* Batched sacabase::longest_substring_match (sacabase/src/lib.rs:39-99): needle k is
  * needles[offsets[k] .. offsets[k+1]); out_start/out_len receive the match exactly as the reference's

@@ -293,6 +293,29 @@ ORACLE_API int oracle_partitioned_match_i32(const uint8_t *T, int64_t n, const i
 }
 
 /* ------------------------------------------------------------------------------------ */
+/* LCP array by Kasai et al. (checker for the "BWT/LCP by-products" row; the   */
+/* reference has no LCP routine): lcp[0] = 0, lcp[i] = lcp(suffix sa[i-1], suffix sa[i]).    */
+/* ------------------------------------------------------------------------------------ */
+ORACLE_API int oracle_lcp_kasai_i32(const uint8_t *T, int64_t n, const int32_t *sa, int32_t *lcp) {
+  if (n <= 0) return 0;
+  int32_t *rank = (int32_t *)malloc((size_t)n * sizeof(int32_t));
+  if (!rank) return -2;
+  for (int64_t i = 0; i < n; i++) rank[sa[i]] = (int32_t)i;
+  int64_t h = 0;
+  lcp[0] = 0;
+  for (int64_t p = 0; p < n; p++) {
+    const int64_t r = rank[p];
+    if (r == 0) { h = 0; continue; }
+    const int64_t q = sa[r - 1];
+    while (p + h < n && q + h < n && T[p + h] == T[q + h]) h++;
+    lcp[r] = (int32_t)h;
+    if (h > 0) h--;
+  }
+  free(rank);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------ */
 /* Deterministic synthetic inputs: byte i = byte (i&7) of               */
 /* splitmix64(seed + (i>>3)).  Host-side twin of the device generator, so the GPU and the */
 /* CPU baseline see the same buffer without shipping files.                              */

@@ -90,6 +90,7 @@ SYMBOLS = {
     "dc3hip_ctx_sa_checksum": (_i32, [_vp, ctypes.POINTER(_u64)]),
     "dc3hip_ctx_set_sa_i32": (_i32, [_vp, _vp]),
     "dc3hip_ctx_bwt": (_i32, [_vp, _vp, ctypes.POINTER(_i64)]),
+    "dc3hip_ctx_lcp_i32": (_i32, [_vp, _vp]),
     "dc3hip_ctx_search": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp]),
     "dc3hip_ctx_stats": (_i32, [_vp, ctypes.POINTER(Stats)]),
 }

@@ -283,6 +283,12 @@ class Context:
         _check(lib().dc3hip_ctx_bwt(self._h, u.ctypes.data if self.n else None, ctypes.byref(idx)))
         return u, int(idx.value)
 
+    def lcp(self):
+        """LCP array of the resident SA: LCP[0] = 0, LCP[i] = lcp(suffix SA[i-1], suffix SA[i])."""
+        out = np.zeros(self.n, dtype=np.int32)
+        _check(lib().dc3hip_ctx_lcp_i32(self._h, out.ctypes.data if self.n else None))
+        return out
+
     def search(self, needles):
         """Batched longest_substring_match on the GPU: list of bytes-like -> list of (start, len)."""
         nds = [_as_u8(x) for x in needles]

@@ -181,6 +181,102 @@ __global__ __launch_bounds__(kBlock) void k_search(const uint8_t *__restrict__ t
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// LCP array of the resident SA ("next" row f.4): LCP[i] = lcp(suffix SA[i-1], suffix SA[i]), LCP[0] = 0.
+// Kasai's argument in position order, PLCP[p] >= PLCP[p-1] - 1 with PLCP[p] = lcp(p, Phi[p]) and
+// Phi[SA[i]] = SA[i-1], made parallel in two grains so that no thread ever restarts a long match from zero more
+// than once per 2^16 positions:
+//   k_plcp_coarse : one thread per 2^16 positions walks the positions s, s+L, s+2L, ... (L = 64) carrying
+//                   h - L (PLCP[p+L] >= PLCP[p] - L);
+//   k_plcp_fine   : one thread per L positions starts from the coarse value and carries h - 1;
+//   k_lcp_gather  : LCP[i] = PLCP[SA[i]].
+// Matches are extended 8 bytes at a time (the text buffer is padded; lengths are clamped to the text end).
+// ---------------------------------------------------------------------------------------------
+constexpr u32 kLcpFine = 64, kLcpCoarse = 1u << 16, kPhiNone = 0xffffffffu;
+__global__ __launch_bounds__(kBlock) void k_phi_pairs(const u32 *__restrict__ sa, u32 n, Rec8 *__restrict__ pairs) {
+  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+    pairs[i] = Rec8{sa[i], i > 0 ? sa[i - 1] : kPhiNone};          // (destination, value): Phi[sa[i]] = sa[i-1]
+}
+__global__ __launch_bounds__(kBlock) void k_phi_scatter(const u32 *__restrict__ sa, u32 n, u32 *__restrict__ phi) {
+  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const u32 p = sa[i];
+    if (p < n) phi[p] = (i > 0 && sa[i - 1] < n) ? sa[i - 1] : kPhiNone;   // tolerant of a foreign (set_sa) array
+  }
+}
+__device__ __forceinline__ u32 lcp_extend(const uint8_t *__restrict__ t, u32 n, u32 p, u32 q, u32 h) {
+  const u32 lim = n - max(p, q);                       // longest possible common prefix
+  while (h + 8 <= lim) {
+    u64 a, b;
+    __builtin_memcpy(&a, t + p + h, 8); __builtin_memcpy(&b, t + q + h, 8);
+    const u64 x = a ^ b;
+    if (x) return h + (u32)(__ffsll((long long)x) - 1) / 8;
+    h += 8;
+  }
+  while (h < lim && t[p + h] == t[q + h]) h++;
+  return h;
+}
+// one WAVE per 2^16 positions: the 64 lanes extend a match 512 bytes per step, so even a from-scratch match of
+// megabytes (runs, long repeats) is a short loop; the walk over the 1024 coarse positions is sequential
+__global__ __launch_bounds__(kBlock) void k_plcp_coarse(const uint8_t *__restrict__ t, const u32 *__restrict__ phi, u32 n,
+                                                       u32 *__restrict__ plcp) {
+  const u32 g = blockIdx.x * kWaves + wave_id();
+  const u32 lane = lane_id();
+  const u64 first = (u64)g * kLcpCoarse;
+  if (first >= n) return;
+  u32 h = 0;
+  for (u64 p64 = first; p64 < min((u64)n, first + kLcpCoarse); p64 += kLcpFine) {
+    const u32 p = (u32)p64, q = phi[p];
+    if (q == kPhiNone) h = 0;
+    else {
+      const u32 lim = n - max(p, q);
+      h = min(h, lim);
+      for (;;) {                                               // wave-uniform loop
+        const u32 o = h + 8 * lane;                             // this lane's 8 bytes (zero padding past the text)
+        u32 m = 8;                                              // matching bytes in my window, clamped to lim
+        if (o >= lim) m = 0;
+        else {
+          u64 a, b;
+          __builtin_memcpy(&a, t + p + o, 8); __builtin_memcpy(&b, t + q + o, 8);
+          const u64 x = a ^ b;
+          if (x) m = (u32)(__ffsll((long long)x) - 1) / 8;
+          m = min(m, lim - o);
+        }
+        const u64 part = __ballot(m < 8);                       // lanes where the match ends
+        if (part) {
+          const u32 l = (u32)__ffsll((long long)part) - 1;
+          h += 8 * l + (u32)__shfl(m, l);
+          break;
+        }
+        h += 512;
+      }
+    }
+    if (lane == 0) plcp[p] = h;
+    h = h > kLcpFine ? h - kLcpFine : 0u;
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_plcp_fine(const uint8_t *__restrict__ t, const u32 *__restrict__ phi, u32 n,
+                                                     u32 *__restrict__ plcp) {
+  const u32 nseg = (n + kLcpFine - 1) / kLcpFine;
+  for (u32 s = blockIdx.x * kBlock + threadIdx.x; s < nseg; s += gridDim.x * kBlock) {
+    const u32 p0 = s * kLcpFine;
+    u32 h = plcp[p0];
+    const u32 pend = (u32)min((u64)n, (u64)p0 + kLcpFine);
+    for (u32 p = p0 + 1; p < pend; p++) {
+      h = h > 0 ? h - 1 : 0u;
+      const u32 q = phi[p];
+      h = q == kPhiNone ? 0u : lcp_extend(t, n, p, q, min(h, n - max(p, q)));
+      plcp[p] = h;
+    }
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_lcp_gather(const u32 *__restrict__ sa, const u32 *__restrict__ plcp, u32 n,
+                                                      int32_t *__restrict__ out) {
+  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const u32 p = sa[i];
+    out[i] = (i == 0 || p >= n) ? 0 : (int32_t)plcp[p];
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void k_widen(const u32 *__restrict__ in, int64_t *__restrict__ out, u32 n) {
   for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) out[i] = (int64_t)in[i];
 }

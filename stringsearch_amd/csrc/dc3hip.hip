@@ -60,6 +60,7 @@ struct dc3hip_ctx {
   hipStream_t stream = nullptr;
   int64_t max_n = 0, n = 0;
   bool built = false;
+  bool sa_trusted = false;     // the resident SA was produced by ctx_build (a permutation), not handed in by set_sa
   uint8_t *d_text = nullptr;   // max_n + 64 bytes
   u32 *d_sa = nullptr;         // max_n + 16 words
   unsigned char *arena = nullptr;
@@ -1087,6 +1088,7 @@ static int ctx_build(dc3hip_ctx *c) {
     }
   }
   c->built = true;
+  c->sa_trusted = true;
   return E_OK;
 }
 
@@ -1314,6 +1316,50 @@ int32_t dc3hip_ctx_set_sa_i32(dc3hip_ctx *c, const int32_t *SA) {
   if (c->n > 0) HIPC(hipMemcpyAsync(c->d_sa, SA, (size_t)c->n * 4, hipMemcpyDefault, c->stream));
   HIPC(hipStreamSynchronize(c->stream));
   c->built = true;
+  c->sa_trusted = false;
+  return E_OK;
+}
+
+// LCP array of the resident SA (kernels and method: dc3_aux.cuh).  LCP may be a host or a device pointer (n x int32).
+int32_t dc3hip_ctx_lcp_i32(dc3hip_ctx *c, int32_t *LCP) {
+  if (!c || (!LCP && c->n > 0)) { set_err("invalid arguments"); return E_ARGS; }
+  if (!c->built) { set_err("no suffix array built in this context"); return E_ARGS; }
+  const int64_t n64 = c->n;
+  if (n64 == 0) return E_OK;
+  if (n64 > (int64_t)INT32_MAX) { set_err("LCP values of %lld bytes do not fit int32", (long long)n64); return E_TOOBIG; }
+  const u32 n = (u32)n64;
+  HIPC(hipSetDevice(c->device));
+  c->arena_off = 0;
+  u32 *phi = nullptr, *plcp = nullptr;
+  int32_t *dout = nullptr;
+  RC(arena_alloc(c, (size_t)n + 16, &phi));
+  RC(arena_alloc(c, (size_t)n + 16, &plcp));
+  if (c->sa_trusted && n > 1) {
+    Rec8 *pa = nullptr, *pb = nullptr;
+    RC(arena_alloc(c, (size_t)n, &pa));
+    RC(arena_alloc(c, (size_t)n, &pb));
+    hipLaunchKernelGGL(k_phi_pairs, dim3(grid_for(c, n)), dim3(kBlock), 0, c->stream, c->d_sa, n, pa);
+    KCHECK();
+    RC(inverse_permute(c, pa, pb, n, phi, DC3HIP_PH_OTHER));
+  } else {
+    HIPC(hipMemsetAsync(phi, 0xff, (size_t)n * sizeof(u32), c->stream));
+    hipLaunchKernelGGL(k_phi_scatter, dim3(grid_for(c, n)), dim3(kBlock), 0, c->stream, c->d_sa, n, phi);
+    KCHECK();
+  }
+  const u32 ncoarse = (u32)(((u64)n + kLcpCoarse - 1) / kLcpCoarse);
+  hipLaunchKernelGGL(k_plcp_coarse, dim3((ncoarse + kWaves - 1) / kWaves), dim3(kBlock), 0, c->stream, c->d_text, phi, n,
+                     plcp);
+  KCHECK();
+  hipLaunchKernelGGL(k_plcp_fine, dim3(grid_for(c, (n + kLcpFine - 1) / kLcpFine)), dim3(kBlock), 0, c->stream, c->d_text,
+                     phi, n, plcp);
+  KCHECK();
+  // phi is dead: the LCP values in rank order go there before they leave
+  dout = reinterpret_cast<int32_t *>(phi);
+  hipLaunchKernelGGL(k_lcp_gather, dim3(grid_for(c, n)), dim3(kBlock), 0, c->stream, c->d_sa, plcp, n, dout);
+  KCHECK();
+  HIPC(hipMemcpyAsync(LCP, dout, (size_t)n * sizeof(int32_t), hipMemcpyDefault, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  c->arena_off = 0;
   return E_OK;
 }
 

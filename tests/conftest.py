@@ -69,6 +69,15 @@ class Oracle:
         assert rc == 0, rc
         return sa
 
+    def lcp(self, data, sa):
+        """Kasai LCP array (oracle_lcp_kasai_i32): lcp[0] = 0, lcp[i] = lcp(suffix sa[i-1], suffix sa[i])."""
+        t = self._u8(data)
+        sa = np.ascontiguousarray(sa, dtype=np.int32)
+        out = np.zeros(len(t), dtype=np.int32)
+        self.lib.oracle_lcp_kasai_i32.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
+        assert self.lib.oracle_lcp_kasai_i32(t.ctypes.data, len(t), sa.ctypes.data, out.ctypes.data) == 0
+        return out
+
     def verify(self, data, sa):
         t = self._u8(data)
         sa = np.ascontiguousarray(sa)

@@ -214,6 +214,27 @@ def test_ex_partitions_shared_by_all_devices(ss, oracle):
     assert ss.lib().dc3hip_sufsort_ex(data.ctypes.data, sa.ctypes.data, (1 << 32) + 5, ctypes.byref(o)) == -4
 
 
+def test_lcp_array_matches_kasai(ss, oracle, corpus):
+    """dc3hip_ctx_lcp_i32 (two-grain parallel PLCP) == Kasai on the CPU: corpus files, random, DNA, text with KiB-long
+    repeats, runs (LCP ~ n), periodic text; SA built here and SA handed in by set_sa (scatter path for Phi)."""
+    rng = np.random.default_rng(17)
+    cases = {name: data for name, (data, _) in list(corpus.items())[:6]}
+    cases["random"] = oracle.gen(1_000_003, 5, 0).tobytes()
+    cases["dna"] = oracle.gen(700_001, 6, 1).tobytes()
+    cases["text"] = oracle.gen(2_000_000, 7, 2).tobytes()
+    cases["run"] = b"a" * 300_000 + b"b" + b"a" * 200_000
+    cases["period"] = (b"abcde" * 70_000)[:333_333]
+    cases["tiny1"] = b"x"; cases["tiny2"] = b"ab"
+    for name, data in cases.items():
+        with ss.Context(len(data)) as c:
+            c.set_text(data); c.build()
+            sa = c.sa()
+            want = oracle.lcp(data, sa)
+            assert np.array_equal(c.lcp(), want), name
+            c.set_sa(sa)                                   # foreign SA: Phi by bounds-checked scatter
+            assert np.array_equal(c.lcp(), want), name
+
+
 def test_partitioned_search_on_gpu_sas(ss):
     # sacapart/src/lib.rs:105-165 with dc3hip::sort plugged in as `f`
     text = b"totor"

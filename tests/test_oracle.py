@@ -141,3 +141,20 @@ def test_oracle_under_sanitizers():
     from conftest import ROOT
     out = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "asan"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "asan_check: ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_oracle_lcp_matches_naive(oracle):
+    """oracle_lcp_kasai_i32 (checker of the GPU LCP by-product) against the definition on small inputs."""
+    rng = np.random.default_rng(3)
+    cases = [b"banana", b"mississippi", b"aaaaaaaa", b"abababab", b"a", bytes(rng.integers(97, 100, size=300, dtype=np.uint8))]
+    for data in cases:
+        sa = oracle.sufsort(data)
+        got = oracle.lcp(data, sa).tolist()
+        want = [0] * len(data)
+        for i in range(1, len(data)):
+            a, b = data[sa[i - 1]:], data[sa[i]:]
+            h = 0
+            while h < len(a) and h < len(b) and a[h] == b[h]:
+                h += 1
+            want[i] = h
+        assert got == want, data[:20]

@@ -40,6 +40,20 @@ for label, n, kind in (("random_1GiB", 1 << 30, 0), ("text_256MiB", 1 << 28, 2))
             t0 = time.perf_counter(); rcb = ref.bw_transform(text.ctypes.data, t2.ctypes.data, sa2.ctypes.data, n, ctypes.byref(idx))
             r["cpu_bw_transform_ms"] = (time.perf_counter() - t0) * 1e3
             r["bwt_equal"] = bool(rcb == 0 and np.array_equal(t2, u) and idx.value == pidx)
+        # --- LCP array
+        lc = np.ones(n, dtype=np.int32)
+        L0.dc3hip_ctx_lcp_i32(c._h, lc.ctypes.data)
+        t0 = time.perf_counter(); assert L0.dc3hip_ctx_lcp_i32(c._h, lc.ctypes.data) == 0
+        r["gpu_lcp_ms_incl_D2H"] = (time.perf_counter() - t0) * 1e3
+        tl = torch.empty(n, dtype=torch.int32, device="cuda"); torch.cuda.synchronize()
+        t0 = time.perf_counter(); assert L0.dc3hip_ctx_lcp_i32(c._h, tl.data_ptr()) == 0
+        r["gpu_lcp_ms_device_output"] = (time.perf_counter() - t0) * 1e3; del tl
+        if ns == n:
+            orc.oracle_lcp_kasai_i32.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
+            want = np.zeros(n, dtype=np.int32)
+            t0 = time.perf_counter(); assert orc.oracle_lcp_kasai_i32(text.ctypes.data, n, sa.ctypes.data, want.ctypes.data) == 0
+            r["cpu_kasai_ms"] = (time.perf_counter() - t0) * 1e3
+            r["lcp_equal"] = bool(np.array_equal(want, lc)); r["lcp_max"] = int(lc.max())
         # --- batched search: needles = 32-byte substrings of the text with one byte changed in the second half
         rng = np.random.default_rng(5); q = 1 << 20
         pos = rng.integers(0, n - 64, size=q)
