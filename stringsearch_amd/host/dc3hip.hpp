@@ -97,6 +97,13 @@ class DeviceIndex : public sacabase::StringIndex {
     check(dc3hip_ctx_bwt(ctx_, u.data(), &idx));
     return idx;
   }
+  // LCP array: lcp[0] = 0, lcp[i] = longest common prefix of the suffixes sa[i-1] and sa[i]
+  std::vector<int32_t> lcp() const {
+    std::vector<int32_t> out(text_.len);
+    static int32_t dummy = 0;
+    check(dc3hip_ctx_lcp_i32(ctx_, out.empty() ? &dummy : out.data()));
+    return out;
+  }
 };
 
 }  // namespace dc3hip

@@ -57,6 +57,7 @@ int main() {
     dc3hip::DeviceIndex bi{Bytes(b)};
     std::vector<uint8_t> u; const int64_t pidx = bi.bwt(u);
     CHECK(std::string(u.begin(), u.end()) == "annbaa"); CHECK(pidx == 4);
+    CHECK((bi.lcp() == std::vector<int32_t>{0, 1, 3, 0, 0, 2}));
   }
   {  // all partitions from one library call (DC3HIP_F_ALL_DEVICES) == one sort per chunk
     std::string input = "This is a rather long text. We can probably find matches that span two partitions. Oh yes.";
