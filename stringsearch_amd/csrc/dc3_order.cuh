@@ -476,22 +476,46 @@ __global__ __launch_bounds__(kBlock) void k_hash_ties(const Rec8 *__restrict__ a
                                                      unsigned long long *table, u32 mask, u32 *ties) {
   constexpr unsigned long long kSeen = 1ull << 63;
   u32 cnt = 0;
-  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < ns; i += gridDim.x * kBlock) {
-    const unsigned long long img = (rec8_word(a[i]) >> pbits) + 1ull;
+  const u32 lane = lane_id();
+  for (u32 base = blockIdx.x * kBlock + (threadIdx.x & ~63u); base < ns; base += gridDim.x * kBlock) {
+    const u32 i = base + lane;
+    const bool valid = i < ns;
+    const unsigned long long img = valid ? (rec8_word(a[i]) >> pbits) + 1ull : 0ull;
+    // lanes that carry the image of the wave's first valid lane travel with it (a text of one repeated byte would
+    // otherwise send the whole sample to a single table slot one atomic at a time)
+    u64 todo = __ballot(valid);
+    if (!todo) continue;
+    u32 k = 1;                                                       // records this lane stands for
+    bool active = valid;
+#pragma unroll 1
+    for (int round = 0; round < 4 && todo; round++) {                // a few frequent images per wave are aggregated
+      const u32 fl = (u32)__ffsll((long long)todo) - 1;
+      const unsigned long long img0 =
+          ((unsigned long long)(u32)__shfl((u32)(img >> 32), fl) << 32) | (u32)__shfl((u32)img, fl);
+      const u64 same = __ballot(valid && img == img0) & todo;
+      if (valid && img == img0 && ((todo >> lane) & 1ull)) { active = lane == fl; k = (u32)__popcll(same); }
+      todo &= ~same;
+    }
+    if (!active) continue;
     u32 hsh = (u32)((img * 0x9E3779B97F4A7C15ull) >> 40) & mask;
     for (;;) {
+      const unsigned long long peek = __hip_atomic_load(&table[hsh], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (peek == (img | kSeen)) { cnt += k; break; }                // already known to repeat: no atomic needed
       const unsigned long long cur = atomicCAS(&table[hsh], 0ull, img);
-      if (cur == 0ull) break;                                        // first of its image
+      if (cur == 0ull) {                                             // first of its image in the table
+        if (k > 1) { atomicOr(&table[hsh], kSeen); cnt += k; }
+        break;
+      }
       if ((cur & ~kSeen) == img) {
         const unsigned long long old = atomicOr(&table[hsh], kSeen);
-        cnt += (old & kSeen) ? 1u : 2u;                              // the first occurrence is counted once, here
+        cnt += k + ((old & kSeen) ? 0u : 1u);                        // the first occurrence is counted once, here
         break;
       }
       hsh = (hsh + 1) & mask;
     }
   }
   cnt = wave_reduce(cnt);
-  if (lane_id() == 0 && cnt) atomicAdd(ties, cnt);
+  if (lane == 0 && cnt) atomicAdd(ties, cnt);
 }
 // Not all triples distinct: keep the work.  The samples (pos % 3 != 0, incl. the dummy at pos == m) are
 // filtered out of the fully sorted order — they are then in sorted sample order — together with their
