@@ -747,6 +747,74 @@ __global__ __launch_bounds__(kBlock) void k_tie_resolve(KM km, Rec8 *__restrict_
     if (ndup) atomicAdd(&words[2], ndup);
   }
 }
+// Tie pass of the whole-text order when the last radix pass wrote through a SplitSink: img[i] = low 32 bits of the
+// key image of the i-th record, sa[i] = its position (already the answer for every untied record).  Same scheme as
+// k_tie_resolve, 4 bytes per record to read and nothing to write but the members of tied groups.  (Two neighbours
+// whose images differ only above bit 31 look tied here; ordering them by the full key leaves them as they are.)
+// words as for k_tie_resolve.
+template <class KM>
+__global__ __launch_bounds__(kBlock) void k_tie_resolve_split(KM km, const u32 *__restrict__ img, u32 *__restrict__ sa,
+                                                             u32 n, u32 *words) {
+  constexpr u32 kIPT = 4, kTile = kBlock * kIPT;
+  __shared__ uint16_t lcode[256];
+  __shared__ u32 starts[kTile / 2];
+  __shared__ u32 nstart, ntied, ndup;
+  km.stage(lcode);
+  const u32 ntiles = (n + kTile - 1) / kTile;
+  if (threadIdx.x == 0) { ntied = 0; ndup = 0; }
+  for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    if (threadIdx.x == 0) nstart = 0;
+    __syncthreads();
+    u32 tied = 0;
+#pragma unroll
+    for (u32 j = 0; j < kIPT; j++) {
+      const u32 i = tile * kTile + j * kBlock + threadIdx.x;
+      if (i < n) {
+        const u32 a = img[i];
+        const bool eqp = i > 0 && img[i - 1] == a;
+        const bool eqn = i + 1 < n && img[i + 1] == a;
+        if (eqn && !eqp) starts[atomicAdd(&nstart, 1u)] = i;
+        if (eqn || eqp) tied++;
+      }
+    }
+    tied = wave_reduce(tied);
+    if (lane_id() == 0 && tied) atomicAdd(&ntied, tied);
+    __syncthreads();
+    const u32 ns = nstart;
+    u32 dup = 0;
+    for (u32 s = threadIdx.x; s < ns; s += kBlock) {
+      const u32 i = starts[s];
+      const u32 a = img[i];
+      u32 e = i + 2;
+      while (e < n && e - i <= kTieSmallMax && img[e] == a) e++;
+      const u32 len = e - i;
+      if (len > kTieSmallMax) { words[0] = 1u; continue; }
+      if (len == 2) {
+        Rec16 x = km.make(sa[i], lcode), y = km.make(sa[i + 1], lcode);
+        if (key_less(y, x)) { sa[i] = y.pos; sa[i + 1] = x.pos; }
+        dup += key_neq(x, y) ? 0u : 1u;
+        continue;
+      }
+      Rec16 loc[kTieSmallMax];
+      for (u32 x = 0; x < len; x++) {
+        const Rec16 v = km.make(sa[i + x], lcode);
+        u32 y = x;
+        while (y > 0 && key_less(v, loc[y - 1])) { loc[y] = loc[y - 1]; y--; }
+        loc[y] = v;
+      }
+      for (u32 x = 0; x < len; x++) {
+        sa[i + x] = loc[x].pos;
+        if (x > 0) dup += key_neq(loc[x], loc[x - 1]) ? 0u : 1u;
+      }
+    }
+    if (dup) atomicAdd(&ndup, dup);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (ntied) atomicAdd(&words[1], ntied);
+    if (ndup) atomicAdd(&words[2], ndup);
+  }
+}
 __global__ __launch_bounds__(kBlock) void k_tie_writeback(const Rec16 *__restrict__ sub, const u32 *__restrict__ tiedidx,
                                                          u32 t, Rec8 *__restrict__ h, uint8_t *__restrict__ f) {
   for (u32 j = blockIdx.x * kBlock + threadIdx.x; j < t; j += gridDim.x * kBlock) {

@@ -77,11 +77,29 @@ struct ArrayLoader {
   __device__ __forceinline__ bool load(u32 i, Rec &r) const { r = p[i]; return true; }
 };
 
+// Sinks: where a down-sweep puts record x of global output index g.  RecSink = the record array of the next pass.
+// SplitSink (last pass of the whole-text order, 8-byte words (image << pbits) | pos): the position goes straight to
+// the suffix-array buffer and the low 32 image bits to a side array — the same 8 bytes, but the tie pass then
+// reads 4 bytes per record and leaves the positions of untied records alone.
+template <class Rec>
+struct RecSink {
+  Rec *p;
+  __device__ __forceinline__ void store(u32 g, const Rec &x) const { p[g] = x; }
+};
+struct SplitSink {
+  u32 *sa, *img; u32 pbits;
+  __device__ __forceinline__ void store(u32 g, const Rec8 &x) const {
+    const u64 w = rec8_word(x);
+    sa[g] = (u32)(w & ((1ull << pbits) - 1ull));
+    img[g] = (u32)(w >> pbits);
+  }
+};
+
 // PF: prefetch the next tile into registers while the current one is ranked/reordered (pays for
 // 8-byte records: 2.3 -> 3.4 TB/s; costs registers and loses for 16/20-byte records, see
 // profiles/r01_radix_downsweep_variants_v2.txt).
-template <class Rec, int NB, int IPT, int NW, bool PF, class Loader>
-__global__ __launch_bounds__(NW * 64) void k_rs_downsweep(Loader in, Rec *__restrict__ out, u32 n,
+template <class Rec, int NB, int IPT, int NW, bool PF, class Loader, class Sink = RecSink<Rec>>
+__global__ __launch_bounds__(NW * 64) void k_rs_downsweep(Loader in, Sink out, u32 n,
                                                          u32 chunk, u32 nchunks, KeyDig dig,
                                                          const u32 *__restrict__ table,
                                                          const u32 *__restrict__ digit_base) {
@@ -185,7 +203,7 @@ __global__ __launch_bounds__(NW * 64) void k_rs_downsweep(Loader in, Rec *__rest
     for (u32 q = tid; q < nkeep; q += kB) {
       const Rec x = srec[q];
       const u32 dd = digit_of(x, dig);
-      out[dbase[dd] + (q - texcl[dd])] = x;
+      out.store(dbase[dd] + (q - texcl[dd]), x);
     }
     __syncthreads();
     if (tid < NB) dbase[tid] += tot;

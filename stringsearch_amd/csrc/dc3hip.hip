@@ -77,6 +77,7 @@ struct dc3hip_ctx {
   bool no_small_ties = false;
   bool wide_names = false;
   bool no_nine_bit = false, no_rec12 = false, no_discard = false, no_fullsort = false, no_text_shortcut = false;
+  bool no_split_emit = false;
   std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
   std::vector<PhaseMark> marks;
   hipEvent_t ev_build_a = nullptr, ev_build_b = nullptr;
@@ -189,13 +190,13 @@ template <> struct RecClass<Rec12> { static constexpr int k = 1; };
 template <> struct RecClass<Rec16> { static constexpr int k = 1; };
 template <> struct RecClass<Tup0>  { static constexpr int k = 2; };
 
-template <class Rec, int NB, class Loader>
-static int launch_downsweep(dc3hip_ctx *c, Loader in, Rec *dst, u32 n, const Chunking &ck, KeyDig dig,
-                            const u32 *table, const u32 *digit_base, int phase) {
+template <class Rec, int NB, class Loader, class Sink>
+static int launch_downsweep_to(dc3hip_ctx *c, Loader in, Sink dst, u32 n, const Chunking &ck, KeyDig dig,
+                               const u32 *table, const u32 *digit_base, int phase) {
   constexpr int IPT = SortCfg<Rec, NB>::IPT, NW = SortCfg<Rec, NB>::NW;
   constexpr bool PF = SortCfg<Rec, NB>::PF && std::is_same<Loader, ArrayLoader<Rec>>::value;
   const size_t smem = DownsweepSmem<Rec, IPT, NW, NB>::kBytes;
-  auto kern = k_rs_downsweep<Rec, NB, IPT, NW, PF, Loader>;
+  auto kern = k_rs_downsweep<Rec, NB, IPT, NW, PF, Loader, Sink>;
   static thread_local bool attr_set[16] = {false};
   if (!attr_set[c->device & 15]) {
     HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -207,6 +208,12 @@ static int launch_downsweep(dc3hip_ctx *c, Loader in, Rec *dst, u32 n, const Chu
                      table, digit_base);
   KCHECK();
   return E_OK;
+}
+template <class Rec, int NB, class Loader>
+static int launch_downsweep(dc3hip_ctx *c, Loader in, Rec *dst, u32 n, const Chunking &ck, KeyDig dig,
+                            const u32 *table, const u32 *digit_base, int phase) {
+  RecSink<Rec> sink; sink.p = dst;
+  return launch_downsweep_to<Rec, NB, Loader, RecSink<Rec>>(c, in, sink, n, ck, dig, table, digit_base, phase);
 }
 static int scan_digit_table(dc3hip_ctx *c, u32 *table, u32 nchunks, u32 *digit_base, u32 nb, int phase) {
   PhaseScope ps(c, phase, nb * nchunks);
@@ -221,9 +228,14 @@ static int scan_digit_table(dc3hip_ctx *c, u32 *table, u32 nchunks, u32 *digit_b
 // Digit width: 9 bits where that saves a pass over 8-bit digits, else 8.
 // first_table: digit table of the first pass already produced by whoever wrote the records (k_pack_image_text);
 // it must have been made for radix_plan()'s chunking and bin count.
+// final_sink (Rec8 only): the LAST pass writes through it instead of into the other record buffer; *last then
+// describes that pass (source buffer, destination buffer, digit) so that it can be repeated into records
+// (radix_redo_last) if the caller turns out to need them after all.
+struct LastPass { void *src = nullptr, *dst = nullptr; u32 lo = 0; int nb = 0; };
 template <class Rec, int NB>
 static int radix_passes(dc3hip_ctx *c, Rec *a, Rec *b, u32 n, u32 bit_lo, u32 bit_hi, Rec **result, int ph_up,
-                        int ph_scan, int ph_down, u32 *first_table = nullptr) {
+                        int ph_scan, int ph_down, u32 *first_table = nullptr, const SplitSink *final_sink = nullptr,
+                        LastPass *last = nullptr) {
   constexpr u32 kBits = NB == 512 ? 9 : 8;
   constexpr int kTile = SortCfg<Rec, NB>::NW * 64 * SortCfg<Rec, NB>::IPT;
   const Chunking ck = make_chunks(c, n, kTile);
@@ -242,6 +254,16 @@ static int radix_passes(dc3hip_ctx *c, Rec *a, Rec *b, u32 n, u32 bit_lo, u32 bi
     }
     RC(scan_digit_table(c, table, ck.nchunks, digit_base, NB, ph_scan));
     ArrayLoader<Rec> ld; ld.p = src;
+    if constexpr (std::is_same<Rec, Rec8>::value) {
+      if (final_sink && lo + kBits >= bit_hi) {
+        RC((launch_downsweep_to<Rec, NB, ArrayLoader<Rec>, SplitSink>(c, ld, *final_sink, n, ck, dig, table, digit_base,
+                                                                      ph_down)));
+        if (last) { last->src = src; last->dst = dst; last->lo = lo; last->nb = NB; }
+        arena_release(c, mk);
+        *result = nullptr;                 // the order lives in the sink
+        return E_OK;
+      }
+    }
     RC((launch_downsweep<Rec, NB, ArrayLoader<Rec>>(c, ld, dst, n, ck, dig, table, digit_base, ph_down)));
     std::swap(src, dst);
   }
@@ -249,14 +271,44 @@ static int radix_passes(dc3hip_ctx *c, Rec *a, Rec *b, u32 n, u32 bit_lo, u32 bi
   *result = src;
   return E_OK;
 }
+// repeat the last pass of a sort that ended in a SplitSink, this time into records
+template <int NB>
+static int radix_redo_last_nb(dc3hip_ctx *c, const LastPass &lp, u32 n, Rec8 **result, int ph_up, int ph_scan, int ph_down) {
+  constexpr int kTile = SortCfg<Rec8, NB>::NW * 64 * SortCfg<Rec8, NB>::IPT;
+  const Chunking ck = make_chunks(c, n, kTile);
+  const ArenaMark mk = arena_mark(c);
+  u32 *table = nullptr, *digit_base = nullptr;
+  RC(arena_alloc(c, (size_t)NB * ck.nchunks, &table));
+  RC(arena_alloc(c, (size_t)NB, &digit_base));
+  KeyDig dig; dig.shift = lp.lo; dig.mask = NB - 1;
+  Rec8 *src = static_cast<Rec8 *>(lp.src), *dst = static_cast<Rec8 *>(lp.dst);
+  {
+    PhaseScope ps(c, ph_up, n);
+    hipLaunchKernelGGL((k_rs_upsweep<Rec8, NB>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, src, n, ck.chunk, ck.nchunks,
+                       dig, table);
+    KCHECK();
+  }
+  RC(scan_digit_table(c, table, ck.nchunks, digit_base, NB, ph_scan));
+  ArrayLoader<Rec8> ld; ld.p = src;
+  RC((launch_downsweep<Rec8, NB, ArrayLoader<Rec8>>(c, ld, dst, n, ck, dig, table, digit_base, ph_down)));
+  arena_release(c, mk);
+  *result = dst;
+  return E_OK;
+}
+static int radix_redo_last(dc3hip_ctx *c, const LastPass &lp, u32 n, Rec8 **result, int ph_up, int ph_scan, int ph_down) {
+  return lp.nb == 512 ? radix_redo_last_nb<512>(c, lp, n, result, ph_up, ph_scan, ph_down)
+                      : radix_redo_last_nb<256>(c, lp, n, result, ph_up, ph_scan, ph_down);
+}
 static bool radix_nine(const dc3hip_ctx *c, u32 bits) { return !c->no_nine_bit && ((bits + 8) / 9 < (bits + 7) / 8); }
 template <class Rec>
 static int radix_sort(dc3hip_ctx *c, Rec *a, Rec *b, u32 n, u32 bit_lo, u32 bit_hi, Rec **result, int ph_up,
-                      int ph_scan, int ph_down, u32 *first_table = nullptr) {
+                      int ph_scan, int ph_down, u32 *first_table = nullptr, const SplitSink *final_sink = nullptr,
+                      LastPass *last = nullptr) {
   const u32 bits = bit_hi > bit_lo ? bit_hi - bit_lo : 0;
   if (bits == 0) { *result = a; return E_OK; }
-  if (radix_nine(c, bits)) return radix_passes<Rec, 512>(c, a, b, n, bit_lo, bit_hi, result, ph_up, ph_scan, ph_down, first_table);
-  return radix_passes<Rec, 256>(c, a, b, n, bit_lo, bit_hi, result, ph_up, ph_scan, ph_down, first_table);
+  if (radix_nine(c, bits))
+    return radix_passes<Rec, 512>(c, a, b, n, bit_lo, bit_hi, result, ph_up, ph_scan, ph_down, first_table, final_sink, last);
+  return radix_passes<Rec, 256>(c, a, b, n, bit_lo, bit_hi, result, ph_up, ph_scan, ph_down, first_table, final_sink, last);
 }
 // bins and chunking radix_sort<Rec> will use for n records and `bits` key bits
 template <class Rec>
@@ -566,8 +618,36 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
   *ok = false;
   if (emitted_distinct) *emitted_distinct = false;
   Rec8 *h = nullptr;
-  RC(radix_sort<Rec8>(c, ha, hb, nrec, hm.pbits, hm.pbits + hm.nbits, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN,
-                      DC3HIP_PH_SORT8_DOWN, first_table));
+  if (emit_sa && emitted_distinct && skip == 0 && !c->no_small_ties && !c->no_split_emit && hm.pbits < 32) {
+    // optimistic end of the whole-text order: the last pass writes positions to the SA buffer and 32 image bits to a
+    // side array; the tie pass settles the tied groups in place.  Complete unless a key repeats or a group is large.
+    u32 *img = nullptr;
+    RC(arena_alloc(c, (size_t)nrec + 16, &img));
+    SplitSink sink; sink.sa = emit_sa; sink.img = img; sink.pbits = hm.pbits;
+    LastPass lp;
+    RC(radix_sort<Rec8>(c, ha, hb, nrec, hm.pbits, hm.pbits + hm.nbits, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN,
+                        DC3HIP_PH_SORT8_DOWN, first_table, &sink, &lp));
+    if (lp.src) {
+      {
+        PhaseScope ps(c, DC3HIP_PH_TIES, nrec);
+        HIPC(hipMemsetAsync(c->d_words + 10, 0, 3 * sizeof(u32), c->stream));
+        hipLaunchKernelGGL((k_tie_resolve_split<KM>), dim3(grid_for(c, nrec / 4 + 1)), dim3(kBlock), 0, c->stream, km,
+                           (const u32 *)img, emit_sa, nrec, c->d_words + 10);
+        KCHECK();
+        HIPC(hipMemcpyAsync(c->h_words + 10, c->d_words + 10, 3 * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+      }
+      HIPC(hipStreamSynchronize(c->stream));
+      c->stats.level_tied[depth] = c->h_words[11];
+      if ((double)c->h_words[11] > kHybridMaxMeasured * (double)nrec) return E_OK;   // *ok stays false -> straight LSD
+      if (c->h_words[10] == 0 && c->h_words[12] == 0) { *emitted_distinct = true; *h_out = nullptr; *ok = true; return E_OK; }
+      // keys repeat (or a large group): the records are needed after all
+      RC(radix_redo_last(c, lp, nrec, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT8_DOWN));
+    }
+    emit_sa = nullptr;                       // from here on: the record path, positions are emitted by the caller
+  } else {
+    RC(radix_sort<Rec8>(c, ha, hb, nrec, hm.pbits, hm.pbits + hm.nbits, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN,
+                        DC3HIP_PH_SORT8_DOWN, first_table));
+  }
   const Chunking ck = make_chunks(c, nrec, kBlock);
   u32 *counts = nullptr;
   RC(arena_alloc(c, (size_t)ck.nchunks + 16, &counts));
@@ -1125,6 +1205,7 @@ int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) {
   c->no_hybrid = (nh && nh[0] == '1');
   const char *nst = getenv("DC3HIP_NO_SMALL_TIES");
   c->no_small_ties = (nst && nst[0] == '1');
+  { const char *e = getenv("DC3HIP_NO_SPLIT_EMIT"); c->no_split_emit = (e && e[0] == '1'); }
   const char *nts = getenv("DC3HIP_NO_TEXT_SHORTCUT");
   c->no_text_shortcut = (nts && nts[0] == '1');
   const char *nf = getenv("DC3HIP_NO_FULLSORT");
