@@ -388,7 +388,7 @@ def test_hybrid_and_straight_paths_agree(ss, oracle):
         want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)
         seen = {}
         for env in ({}, {"DC3HIP_NO_HYBRID": "1"}, {"DC3HIP_NO_SMALL_TIES": "1"}, {"DC3HIP_NO_FULLSORT": "1"},
-                    {"DC3HIP_NO_TEXT_SHORTCUT": "1"},
+                    {"DC3HIP_NO_TEXT_SHORTCUT": "1"}, {"DC3HIP_NO_SPLIT_EMIT": "1"},
                     {"DC3HIP_NO_HYBRID": "1", "DC3HIP_NO_9BIT": "1", "DC3HIP_NO_REC12": "1"}):
             os.environ.update(env)
             try:
