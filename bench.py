@@ -185,7 +185,7 @@ def main():
             per_launch_elems = dsw_elems[kc] / dsw_launches[kc]
             avg_ms = dsw_ms[kc] / dsw_launches[kc]
             achieved = 12.0 * per_launch_elems / (avg_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": f"k_rs_downsweep<{rec_name.split()[0]}> (stable 8-bit radix scatter of {rec_name})",
+            roof = {"bound": "hbm", "kernel": f"k_rs_downsweep<{rec_name.split()[0]}> (stable 8/9-bit-digit radix scatter of {rec_name})",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": None,
                     "algorithmic_bytes_per_launch": 12.0 * per_launch_elems, "avg_launch_ms": avg_ms,
