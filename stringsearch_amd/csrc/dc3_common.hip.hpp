@@ -1,6 +1,6 @@
-// dc3_common.cuh — record types, symbol readers, wave/block primitives, small scans.
-// Part of the gfx950 kernel set of libdc3hip (see dc3_kernels.cuh for the overview); all files share
-// namespace dc3 and are included in this order by dc3_kernels.cuh.
+// dc3_common.hip.hpp — record types, symbol readers, wave/block primitives, small scans.
+// Part of the gfx950 kernel set of libdc3hip (see dc3_kernels.hip.hpp for the overview); all files share
+// namespace dc3 and are included in this order by dc3_kernels.hip.hpp.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

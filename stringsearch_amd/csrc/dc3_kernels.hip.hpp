@@ -1,4 +1,4 @@
-// dc3_kernels.cuh — gfx950 (CDNA4, wave64) device kernels of the DC3/Skew suffix-array path.
+// dc3_kernels.hip.hpp — gfx950 (CDNA4, wave64) device kernels of the DC3/Skew suffix-array path.
 //
 // Every kernel maps to a loop of the reference's crates/dc3/src/lib.rs (cited per kernel).
 // Design rules: the work is HBM-bound integer/index traffic, so
@@ -9,9 +9,9 @@
 //   * blocks own contiguous chunks (up-sweep / scan / down-sweep), so the only inter-block
 //     communication is through kernel boundaries — no spin waits, no placement assumptions.
 #pragma once
-#include "dc3_common.cuh"
-#include "dc3_names.cuh"
-#include "dc3_radix.cuh"
-#include "dc3_order.cuh"
-#include "dc3_merge.cuh"
-#include "dc3_aux.cuh"
+#include "dc3_common.hip.hpp"
+#include "dc3_names.hip.hpp"
+#include "dc3_radix.hip.hpp"
+#include "dc3_order.hip.hpp"
+#include "dc3_merge.hip.hpp"
+#include "dc3_aux.hip.hpp"

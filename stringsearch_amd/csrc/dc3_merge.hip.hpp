@@ -1,6 +1,6 @@
-// dc3_merge.cuh — merge tuples, gather, fused mod-0 selection, merge-path merge.
-// Part of the gfx950 kernel set of libdc3hip (see dc3_kernels.cuh for the overview); all files share
-// namespace dc3 and are included in this order by dc3_kernels.cuh.
+// dc3_merge.hip.hpp — merge tuples, gather, fused mod-0 selection, merge-path merge.
+// Part of the gfx950 kernel set of libdc3hip (see dc3_kernels.hip.hpp for the overview); all files share
+// namespace dc3 and are included in this order by dc3_kernels.hip.hpp.
 #pragma once
 
 namespace dc3 {

@@ -1,6 +1,6 @@
-// dc3_names.cuh — level-0 alphabet, direct (sort-free) names, triple records.
-// Part of the gfx950 kernel set of libdc3hip (see dc3_kernels.cuh for the overview); all files share
-// namespace dc3 and are included in this order by dc3_kernels.cuh.
+// dc3_names.hip.hpp — level-0 alphabet, direct (sort-free) names, triple records.
+// Part of the gfx950 kernel set of libdc3hip (see dc3_kernels.hip.hpp for the overview); all files share
+// namespace dc3 and are included in this order by dc3_kernels.hip.hpp.
 #pragma once
 
 namespace dc3 {

@@ -1,6 +1,6 @@
-// dc3_order.cuh — naming, windowed inverse permutation, discarding recursion, prefix-sort + tie-refine.
-// Part of the gfx950 kernel set of libdc3hip (see dc3_kernels.cuh for the overview); all files share
-// namespace dc3 and are included in this order by dc3_kernels.cuh.
+// dc3_order.hip.hpp — naming, windowed inverse permutation, discarding recursion, prefix-sort + tie-refine.
+// Part of the gfx950 kernel set of libdc3hip (see dc3_kernels.hip.hpp for the overview); all files share
+// namespace dc3 and are included in this order by dc3_kernels.hip.hpp.
 #pragma once
 
 namespace dc3 {

@@ -1,6 +1,6 @@
-// dc3_radix.cuh — stable LSD radix passes (up-sweep / row scan / down-sweep with loaders).
-// Part of the gfx950 kernel set of libdc3hip (see dc3_kernels.cuh for the overview); all files share
-// namespace dc3 and are included in this order by dc3_kernels.cuh.
+// dc3_radix.hip.hpp — stable LSD radix passes (up-sweep / row scan / down-sweep with loaders).
+// Part of the gfx950 kernel set of libdc3hip (see dc3_kernels.hip.hpp for the overview); all files share
+// namespace dc3 and are included in this order by dc3_kernels.hip.hpp.
 #pragma once
 
 namespace dc3 {

@@ -3,7 +3,7 @@
 // Host side of the DC3/Skew recursion of crates/dc3/src/lib.rs:44-193, re-designed for MI355X:
 //   * one context = one HIP stream + one device arena (no hipMalloc inside the recursion; the
 //     reference allocates 4 Vecs per level, lib.rs:50-57);
-//   * every level is a fixed sequence of streaming kernels (dc3_kernels.cuh); the host only reads back a
+//   * every level is a fixed sequence of streaming kernels (dc3_kernels.hip.hpp); the host only reads back a
 //     few words per level: the number of distinct names that decides lib.rs:103 (recurse or not), and the
 //     tie statistics that steer the ordering policy (which never affect the result);
 //   * no CPU fallback of any kind: if HIP fails the call fails (-3).
@@ -23,7 +23,7 @@
 #include <string>
 
 #include "../../include/dc3hip.h"
-#include "dc3_kernels.cuh"
+#include "dc3_kernels.hip.hpp"
 
 using namespace dc3;
 
@@ -436,7 +436,7 @@ static int name_and_rank(dc3hip_ctx *c, Acc acc, u32 m02, u32 m0, u32 *sa12, u32
   return E_OK;
 }
 
-// Discarding recursion: see dc3_kernels.cuh.  RU[p] = name | unique<<31 (slot order), sslot[i] =
+// Discarding recursion: see dc3_kernels.hip.hpp.  RU[p] = name | unique<<31 (slot order), sslot[i] =
 // slot | unique<<31 (sorted order).  Recurses on the reduced string only; fills sa12 and rank12.
 static int discard_recurse(dc3hip_ctx *c, const u32 *RU, const u32 *sslot, u32 m02, u32 names, u32 *sa12,
                            u32 *rank12, int depth) {
@@ -506,7 +506,7 @@ static int discard_recurse(dc3hip_ctx *c, const u32 *RU, const u32 *sslot, u32 m
 }
 
 // ---------------------------------------------------------------------------------------------
-// prefix-sort + tie-refine ordering (see dc3_kernels.cuh).  Policy:
+// prefix-sort + tie-refine ordering (see dc3_kernels.hip.hpp).  Policy:
 //   * a strided sample of ~2^20 triples predicts the fraction of samples whose N-bit key image
 //     collide; the path is taken when the prediction is below kHybridMaxPredicted,
 //   * and abandoned (falling back to the straight 16-byte LSD sort) if the measured fraction turns
@@ -1401,7 +1401,7 @@ int32_t dc3hip_ctx_set_sa_i32(dc3hip_ctx *c, const int32_t *SA) {
   return E_OK;
 }
 
-// LCP array of the resident SA (kernels and method: dc3_aux.cuh).  LCP may be a host or a device pointer (n x int32).
+// LCP array of the resident SA (kernels and method: dc3_aux.hip.hpp).  LCP may be a host or a device pointer (n x int32).
 int32_t dc3hip_ctx_lcp_i32(dc3hip_ctx *c, int32_t *LCP) {
   if (!c || (!LCP && c->n > 0)) { set_err("invalid arguments"); return E_ARGS; }
   if (!c->built) { set_err("no suffix array built in this context"); return E_ARGS; }

