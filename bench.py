@@ -1,13 +1,19 @@
 #!/usr/bin/env python3
 """bench.py — MB/s of input indexed (suffix-array build) on MI355X, the metric of BASELINE.json.
 
-A "step" = one device-resident DC3 suffix-array build of this rank's partition (text already in HBM,
-SA left in HBM).  N GPUs = sacapart partitioning (crates/sacapart/src/lib.rs:39-58): the N x SIZE byte
-text is cut into chunks of len/N + 1 bytes, rank c builds the independent local SA of chunk c — no
-data-path collective, weak scaling.  Rank 0 prints ONE JSON line.
+A "step" = one device-resident suffix-array build of this rank's share of the text (text already in HBM,
+SA left in HBM).  Two multi-GPU semantics:
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--size BYTES] [--kind random|dna]
-                    [--cpu-sample-mib M] [--no-cpu] [--no-verify]
+  --mode sacapart (default)  crates/sacapart/src/lib.rs:39-58: the N x SIZE byte text is cut into chunks of
+                             len/N + 1 bytes, rank c builds the independent local SA of chunk c — no data-path
+                             collective, weak scaling.
+  --mode global              ONE suffix array of the whole N x SIZE text, sharded over the ranks by suffix rank;
+                             text blocks are all-gathered and sample ranks exchanged over RCCL (xGMI); see DESIGN.md §6.
+
+Rank 0 prints ONE JSON line.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size BYTES] [--kind random|dna|text] [--mode sacapart|global]
+                    [--cpu-sample-mib M] [--no-cpu] [--no-verify] [--no-extras]
     N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
              --master-port P bench.py --gpus N ...
 """
@@ -21,8 +27,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-COPY_MEASURED_GBS = 4735.0   # read+write copy kernel measured on the box (profiles/r01_membench_access_patterns.txt)
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md "Chip-level parameters")
+HBM_ACHIEVABLE_GBS = 6290.0  # float4 copy measured by the same guide ("6.29 TB/s measured (float4 copy, 79%)")
+KINDS = {"random": 0, "dna": 1, "text": 2}
 
 
 def parse_size(s):
@@ -44,12 +51,20 @@ def algorithmic_bytes(level_n):
     return total
 
 
+def host_cpu_model():
+    try:
+        return [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        return "unknown"
+
+
 def cpu_baseline(text_u8, sample_bytes):
     """The reference's CPU path (libdivsufsort built from /root/reference into oracle/_ref) or, if that
     is absent, our C restatement of crates/dc3 — timed on one host core like divsuftest's measure()
     (crates/divsuftest/src/main.rs:145-151: wall clock around the call incl. the SA allocation)."""
     import numpy as np
-    sample = np.ascontiguousarray(text_u8[:sample_bytes])
+    n = len(text_u8)
+    sample = text_u8 if sample_bytes >= n else np.ascontiguousarray(text_u8[:sample_bytes])
     ref = os.path.join(ROOT, "oracle", "_ref", "libdivsufsort_ref.so")
     port = os.path.join(ROOT, "oracle", "liboracle_dc3.so")
     if os.path.exists(ref):
@@ -59,23 +74,102 @@ def cpu_baseline(text_u8, sample_bytes):
     else:
         return None
     f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]; f.restype = ctypes.c_int32
+    old_aff = None
     try:
-        os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[0]})
+        old_aff = os.sched_getaffinity(0)
+        os.sched_setaffinity(0, {sorted(old_aff)[0]})
     except Exception:
         pass
     t0 = time.perf_counter()
     sa = np.zeros(len(sample), dtype=np.int32)
     rc = f(sample.ctypes.data, sa.ctypes.data, len(sample))
     dt = time.perf_counter() - t0
+    if old_aff:
+        try:
+            os.sched_setaffinity(0, old_aff)
+        except Exception:
+            pass
     assert rc == 0
-    try:
-        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
-    except Exception:
-        model = "unknown"
+    what = "the whole buffer" if len(sample) == n else f"first {len(sample) / 2**20:.0f} MiB of the same buffer"
     return {"value": len(sample) / dt / 1e6, "unit": "MB/s", "cores": 1, "kind": kind,
-            "sample": f"first {len(sample) / 2**20:.0f} MiB of the same buffer, one divsufsort() call, "
-                      f"wall clock incl. SA allocation ({dt:.2f} s)",
-            "host_cpu": model, "host_cores_available": os.cpu_count()}, sa
+            "sample": f"{what}, one divsufsort() call, wall clock incl. SA allocation ({dt:.2f} s)",
+            "seconds": dt, "host_cpu": host_cpu_model(), "host_cores_available": os.cpu_count()}, sa
+
+
+def kernel_rooflines(st_acc, steps, st_last, kernel_ms):
+    """roofline objects of the two kernel families that dominate builds: the stable radix scatter
+    k_rs_downsweep<Rec,...> (per record type) and the random tuple gather k_gather_tuples."""
+    dsw_ms, dsw_launches, dsw_elems, g_ms, g_launches, g_elems = st_acc
+    # algorithmic bytes per record-pass of the scatter = the reference's loop lib.rs:35-38: read a[i] (w) +
+    # r[a[i]] (c) + write b[..] (w) = 2w + c = 12 B at w = c = 4 (SURVEY §8d table, scatter half).
+    roof = None
+    kc = max(range(3), key=lambda k: dsw_ms[k])
+    if dsw_launches[kc]:
+        rec_bytes = (8, 16, 20)[kc]
+        rec_name = ("Rec8 (key,value) pairs", "Rec16 triple records (12-byte Rec12 when the key fits 64 bits)", "Tup0 mod-0 tuples")[kc]
+        per_launch_elems = dsw_elems[kc] / dsw_launches[kc]
+        avg_ms = dsw_ms[kc] / dsw_launches[kc]
+        achieved = 12.0 * per_launch_elems / (avg_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": f"k_rs_downsweep<{rec_name.split()[0]}> (stable 8/9-bit-digit radix scatter of {rec_name})",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": 12.0 * per_launch_elems, "avg_launch_ms": avg_ms,
+                "launches_per_step": dsw_launches[kc] / steps,
+                "share_of_build_time": dsw_ms[kc] / kernel_ms,
+                "moved_bytes_per_launch": 2.0 * rec_bytes * per_launch_elems,
+                "moved_GBps": 2.0 * rec_bytes * per_launch_elems / (avg_ms * 1e-3) / 1e9,
+                "all_record_types_ms_per_step": [x / steps for x in dsw_ms]}
+    roof_gather = None
+    if g_launches:
+        ge = g_elems / g_launches; gms = g_ms / g_launches
+        # algorithmic bytes of the gather = what the reference's merge reads at random per sample suffix
+        # (lib.rs:136-162, SURVEY §8d merge row): SA12 entry (w) + position (w) + one rank (w) + 2 symbols (2c)
+        alg_g = 0.0
+        for lvl, mm in enumerate(st_last["level_n"]):
+            if mm < 2:
+                continue
+            m02 = (mm + 2) // 3 + mm // 3
+            alg_g += m02 * (3 * 4 + 2 * (1 if lvl == 0 else 4))
+        alg_g /= (g_launches / steps)
+        roof_gather = {"bound": "hbm", "kernel": "k_gather_tuples (one random tuple gather per sample suffix)",
+                       "achieved": alg_g / (gms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": alg_g / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                       "algorithmic_bytes_per_launch": alg_g, "avg_launch_ms": gms,
+                       "launches_per_step": g_launches / steps, "share_of_build_time": g_ms / kernel_ms,
+                       "gathers_per_second_G": ge / (gms * 1e-3) / 1e9}
+    # PMC traffic is NOT measured by this run (counters need rocprofv3): the per-record figures of the last
+    # committed counter collection are replayed, labelled as such, and never enter `achieved`/`frac`.
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    except Exception:
+        pmc = None
+    if pmc is not None:
+        bpr = pmc.get("bytes_per_record", {})
+        if roof is not None:
+            key = ("downsweep_rec8", "downsweep_rec16", "downsweep_tup0")[kc]
+            if key in bpr:
+                roof["traffic"] = bpr[key] * dsw_elems[kc] / dsw_launches[kc]
+                roof["traffic_replayed_from"] = {"file": "profiles/pmc_traffic.json", "source": pmc.get("source"),
+                                                 "commit": pmc.get("commit"), "note": "replayed per-record constant x this run's records; not a counter read of this run"}
+        if roof_gather is not None and "gather_tuples" in bpr:
+            roof_gather["traffic"] = bpr["gather_tuples"] * g_elems / g_launches
+            roof_gather["traffic_replayed_from"] = {"file": "profiles/pmc_traffic.json", "source": pmc.get("source"), "commit": pmc.get("commit")}
+    if roof is not None:
+        roof["achievable_copy_GBps"] = HBM_ACHIEVABLE_GBS
+        roof["moved_frac_of_achievable"] = roof["moved_GBps"] / HBM_ACHIEVABLE_GBS
+    return roof, roof_gather
+
+
+def path_roofline(st, ms):
+    alg = algorithmic_bytes(st["level_n"])
+    return {"algorithmic_bytes_per_step": alg, "device_ms_per_step": ms,
+            "achieved_GBps": alg / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "levels": list(zip(st["level_n"], st["level_K"], st["level_sorted"])),
+            "phase_ms": {k: round(v, 3) for k, v in st["phase_ms"].items() if v}}
+
+
+PATH_NAMES = {0: "dc3 recursion", 1: "whole-text order (all 9-byte windows distinct; no recursion level built)",
+              2: "whole-text order reused as level 1's sorted samples, then dc3 recursion", 3: "whole-text order abandoned, dc3 recursion"}
 
 
 def main():
@@ -83,17 +177,22 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--size", type=str, default="1GiB", help="bytes per GPU (partition size is size*N/N+1 rounding aside)")
-    ap.add_argument("--kind", type=str, default="random", choices=["random", "dna", "text"])
+    ap.add_argument("--size", type=str, default="1GiB", help="bytes per GPU")
+    ap.add_argument("--kind", type=str, default="random", choices=list(KINDS))
+    ap.add_argument("--mode", type=str, default="sacapart", choices=["sacapart", "global"])
     ap.add_argument("--seed", type=int, default=2)
-    ap.add_argument("--cpu-sample-mib", type=int, default=256,
-                    help="CPU baseline sample (MiB of the same buffer); 256 MiB is ~10-20 s of one-core divsufsort")
+    ap.add_argument("--cpu-sample-mib", type=int, default=0,
+                    help="CPU baseline sample in MiB of the same buffer; 0 = the whole buffer (1 GiB is ~60-80 s of one-core "
+                         "divsufsort and doubles as the bit-exact comparison)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
-    ap.add_argument("--no-recursion-line", action="store_true",
-                    help="skip the extra (untimed-in-value) builds with the whole-text shortcut disabled")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the legs that are not part of `value`: recursion-only build, text/DNA configs, end-to-end FFI")
+    ap.add_argument("--no-recursion-line", action="store_true", help="(kept for old command lines) same as --no-extras")
     ap.add_argument("--dump-stats", type=str, default=None, help="write the last build's dc3hip_stats as JSON here")
     args = ap.parse_args()
+    if args.no_recursion_line:
+        args.no_extras = True
 
     import numpy as np
     import torch            # first: libdc3hip.so then shares the HIP runtime torch loaded
@@ -121,23 +220,35 @@ def main():
 
     import stringsearch_amd as ss
 
-    from stringsearch_amd.partition import rank_chunk
     per_gpu = parse_size(args.size)
-    total_len = per_gpu * world
-    off, n = (0, total_len) if world == 1 else rank_chunk(total_len, world, rank)   # sacapart/src/lib.rs:43-46
-    kind = {"random": 0, "dna": 1, "text": 2}[args.kind]
-
-    ctx = ss.Context(n, device=local_rank)
-    ctx.generate(n, args.seed, kind, offset=off)
+    kind = KINDS[args.kind]
 
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.mode == "global" and world > 1:
+        from stringsearch_amd.bench_global import run_global
+        out = run_global(args, ss, dist, backend, world, rank, local_rank, per_gpu, kind, barrier)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps(out))
+        return
+
+    from stringsearch_amd.partition import rank_chunk
+    total_len = per_gpu * world
+    off, n = (0, total_len) if world == 1 else rank_chunk(total_len, world, rank)   # sacapart/src/lib.rs:43-46
+
+    ctx = ss.Context(n, device=local_rank)
+    ctx.generate(n, args.seed, kind, offset=off)
+
     for _ in range(args.warmup):
         ctx.build()
     verify = {}
+    chk0 = None
     if not args.no_verify:
         if args.warmup == 0:
             ctx.build()
@@ -168,77 +279,20 @@ def main():
     if not args.no_verify:
         assert ctx.checksum() == chk0, "SA changed between identical builds"
         verify["idempotent_checksum"] = True
+    dump = os.environ.get("DC3HIP_BENCH_DUMP_SA")     # tests: every rank leaves its chunk + SA for an oracle comparison
+    if dump:
+        np.save(os.path.join(dump, f"chunk_{rank}.npy"), ctx.text())
+        np.save(os.path.join(dump, f"sa_{rank}.npy"), ctx.sa())
 
     st = ctx.stats()
     out = None
     if rank == 0:
         value = total_len * args.steps / dt / 1e6
-        # dominant kernel: the stable 8-bit radix scatter k_rs_downsweep<Rec,...> — the record type
-        # (8-byte pairs / 16-byte triple records / 20-byte mod-0 tuples) with the largest summed time.
-        # algorithmic bytes per record-pass = the reference's scatter loop lib.rs:35-38: read a[i] (w) +
-        # r[a[i]] (c) + write b[..] (w) = 2w + c = 12 B at w = c = 4 (scatter half).
-        roof = None
-        kc = max(range(3), key=lambda k: dsw_ms[k])
-        if dsw_launches[kc]:
-            rec_bytes = (8, 16, 20)[kc]
-            rec_name = ("Rec8 (key,value) pairs", "Rec16 triple records (12-byte Rec12 when the key fits 64 bits)", "Tup0 mod-0 tuples")[kc]
-            per_launch_elems = dsw_elems[kc] / dsw_launches[kc]
-            avg_ms = dsw_ms[kc] / dsw_launches[kc]
-            achieved = 12.0 * per_launch_elems / (avg_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": f"k_rs_downsweep<{rec_name.split()[0]}> (stable 8/9-bit-digit radix scatter of {rec_name})",
-                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": None,
-                    "algorithmic_bytes_per_launch": 12.0 * per_launch_elems, "avg_launch_ms": avg_ms,
-                    "launches_per_step": dsw_launches[kc] / args.steps,
-                    "share_of_build_time": dsw_ms[kc] / kernel_ms,
-                    "moved_bytes_per_launch": 2.0 * rec_bytes * per_launch_elems,
-                    "moved_GBps": 2.0 * rec_bytes * per_launch_elems / (avg_ms * 1e-3) / 1e9,
-                    "all_record_types_ms_per_step": [x / args.steps for x in dsw_ms]}
-        pmc = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        except Exception:
-            pass
-        if roof is not None and pmc is not None:
-            key = ("downsweep_rec8", "downsweep_rec16", "downsweep_tup0")[kc]
-            if key in pmc.get("bytes_per_record", {}):
-                roof["traffic"] = pmc["bytes_per_record"][key] * per_launch_elems
-                roof["traffic_source"] = pmc.get("source")
-        roof_gather = None
-        if g_launches:
-            ge = g_elems / g_launches; gms = g_ms / g_launches
-            # algorithmic bytes of the gather = what the reference's merge reads at random per sample suffix
-            # (lib.rs:136-162, SURVEY §8d merge row): SA12 entry (w) + position (w) + one rank (w) + 2 symbols (2c)
-            alg_g = 0.0
-            for lvl, mm in enumerate(st["level_n"]):
-                if mm < 2:
-                    continue
-                m02 = (mm + 2) // 3 + mm // 3
-                alg_g += m02 * (3 * 4 + 2 * (1 if lvl == 0 else 4))
-            alg_g /= (g_launches / args.steps)
-            roof_gather = {"bound": "hbm", "kernel": "k_gather_tuples (one random 16-byte gather per sample suffix)",
-                           "achieved": alg_g / (gms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": alg_g / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                           "traffic": (pmc["bytes_per_record"]["gather_tuples"] * ge) if pmc and "gather_tuples" in pmc.get("bytes_per_record", {}) else None,
-                           "algorithmic_bytes_per_launch": alg_g, "avg_launch_ms": gms,
-                           "launches_per_step": g_launches / args.steps, "share_of_build_time": g_ms / kernel_ms,
-                           "moved_bytes_per_launch": 36.0 * ge, "moved_GBps": 36.0 * ge / (gms * 1e-3) / 1e9,
-                           "gathers_per_second_G": ge / (gms * 1e-3) / 1e9,
-                           "traffic_source": pmc.get("source") if pmc else None}
+        roof_radix, roof_gather = kernel_rooflines((dsw_ms, dsw_launches, dsw_elems, g_ms, g_launches, g_elems), args.steps, st, kernel_ms)
         # `roofline` = the kernel with the largest share of the build; the other one is kept beside it
-        roof_radix = roof
-        for rr in (roof, roof_gather):
-            if rr is not None:
-                rr["measured_copy_GBps"] = COPY_MEASURED_GBS
-                rr["moved_frac_of_measured_copy"] = rr["moved_GBps"] / COPY_MEASURED_GBS
+        roof = roof_radix
         if roof_gather is not None and (roof is None or roof_gather["share_of_build_time"] >= roof["share_of_build_time"]):
             roof = roof_gather
-        alg = algorithmic_bytes(st["level_n"])
-        path = {"algorithmic_bytes_per_step": alg, "device_ms_per_step": kernel_ms / args.steps,
-                "achieved_GBps": alg / (kernel_ms / args.steps * 1e-3) / 1e9,
-                "frac_of_hbm_peak": alg / (kernel_ms / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "levels": list(zip(st["level_n"], st["level_K"], st["level_sorted"])),
-                "phase_ms": {k: round(v, 3) for k, v in st["phase_ms"].items() if v}}
         out = {
             "metric": "MB/s of input indexed (SA build), 1 GiB bytes, 1/2/4/8 GPUs",
             "value": value, "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -248,41 +302,92 @@ def main():
                                    f"i32 SA, DC3 HIP, text and SA resident in HBM",
                        "bytes_per_gpu": n, "total_bytes": total_len,
                        "partitioning": "single SA" if world == 1 else f"sacapart: {world} chunks of len/{world}+1 bytes, one per GPU, no collective"},
+            "path": {"text_sort_state": st.get("text_sort_state", 0), "taken": PATH_NAMES.get(st.get("text_sort_state", 0), "?"),
+                     "levels": st["levels"],
+                     "note": "`value` is produced by this path; the DC3 recursion on the same input is `dc3_recursion_only`, "
+                             "low-entropy text and DNA are `per_config`"},
             "value_MiBps": total_len * args.steps / dt / 2**20,     # the reference prints binary units (divsuftest main.rs:179-183)
-            "roofline": roof, "roofline_radix_scatter": roof_radix, "roofline_path": path, "verify": verify,
-            "arena_peak_GB": st["arena_peak"] / 1e9,
+            "roofline": roof, "roofline_radix_scatter": roof_radix, "roofline_path": path_roofline(st, kernel_ms / args.steps),
+            "verify": verify, "arena_peak_GB": st["arena_peak"] / 1e9,
         }
+        text = None
         if world == 1 and not args.no_cpu:
             text = ctx.text()
-            sample_bytes = min(n, args.cpu_sample_mib << 20)
+            sample_bytes = n if args.cpu_sample_mib <= 0 else min(n, args.cpu_sample_mib << 20)
             res = cpu_baseline(text, sample_bytes)
             if res is not None:
                 cb, cpu_sa = res
                 out["cpu_baseline"] = cb
                 if sample_bytes == n and not args.no_verify:
+                    # the north_star target: SA[0..n) bit-exact against the reference's divsufsort on the same buffer
                     out["verify"]["equal_cpu_reference"] = bool(np.array_equal(cpu_sa, ctx.sa()))
+                    out["verify"]["cpu_reference"] = cb["kind"]
+                    assert out["verify"]["equal_cpu_reference"], "GPU suffix array differs from the CPU reference"
+                del cpu_sa
+        if world == 1 and not args.no_extras:
+            # ---- end-to-end FFI time (SURVEY §8d "(ii)"): dc3hip_sufsort_i32 on host buffers, H2D + build + D2H,
+            # the figure comparable with the reference's measure() (divsuftest/src/main.rs:145-151). Never `value`.
+            if text is None:
+                text = ctx.text()
+            sa_host = np.ones(n, dtype=np.int32)        # pre-touched, as a Vec reused by a caller would be
+            ctx.close(); ctx = None                     # the one-shot call owns its (cached) context
+            L = ss.lib()
+            ts = []
+            for _ in range(3):
+                t1 = time.perf_counter()
+                rc = L.dc3hip_sufsort_i32(text.ctypes.data, sa_host.ctypes.data, n)
+                ts.append(time.perf_counter() - t1)
+                assert rc == 0, ss.last_error()
+            warm = min(ts[1:])
+            out["e2e_ffi"] = {"entry": "dc3hip_sufsort_i32(T, SA, n) on pageable host buffers", "ms": warm * 1e3,
+                              "MB/s": n / warm / 1e6, "first_call_ms": ts[0] * 1e3,
+                              "includes": "H2D of n bytes, device build, D2H of 4n bytes; first call also allocates the cached context",
+                              "pcie_floor_ms": 5.0 * n / 56e9 * 1e3}
+            del sa_host
+            ss.release_cache()
     if args.dump_stats and rank == 0:
         json.dump(st, open(args.dump_stats, "w"))
-    ctx.close()
-    if rank == 0 and world == 1 and not args.no_recursion_line and st.get("text_sort_state", 0) == 1:
-        # The timed builds above finished in the whole-text shortcut (every 9-byte window distinct, no
-        # recursion level built).  For reference, the same input through the DC3 recursion proper
-        # (levels, tuples, merge): not part of `value`.
-        os.environ["DC3HIP_NO_TEXT_SHORTCUT"] = "1"
-        try:
-            with ss.Context(n, device=local_rank) as c2:
-                c2.generate(n, args.seed, kind, offset=off)
-                c2.build()
+    if ctx is not None:
+        ctx.close()
+    if rank == 0 and world == 1 and not args.no_extras:
+        if st.get("text_sort_state", 0) == 1:
+            # The timed builds above finished in the whole-text shortcut (every 9-byte window distinct, no
+            # recursion level built).  For reference, the same input through the DC3 recursion proper
+            # (levels, tuples, merge): not part of `value`.
+            os.environ["DC3HIP_NO_TEXT_SHORTCUT"] = "1"
+            try:
+                with ss.Context(n, device=local_rank) as c2:
+                    c2.generate(n, args.seed, kind, offset=off)
+                    c2.build()
+                    ms = []
+                    for _ in range(min(args.steps, 3)):
+                        c2.build(); ms.append(c2.stats()["build_ms"])
+                    st2 = c2.stats()
+                    out["dc3_recursion_only"] = {"switch": "DC3HIP_NO_TEXT_SHORTCUT=1", "device_ms_per_step": sum(ms) / len(ms),
+                                                 "MBps": n / (sum(ms) / len(ms)) / 1e3, "sufcheck": c2.sufcheck(),
+                                                 "checksum_equal": (c2.checksum() == chk0) if chk0 is not None else None,
+                                                 "levels": list(zip(st2["level_n"], st2["level_K"], st2["level_sorted"]))}
+            finally:
+                os.environ.pop("DC3HIP_NO_TEXT_SHORTCUT", None)
+        # BASELINE.json configs[2] (low-entropy text) and the per-GPU class of configs[4] (DNA) at the same size:
+        # device-resident builds, GPU sufcheck each; reported beside `value`, never part of it.
+        per_cfg = {}
+        with ss.Context(n, device=local_rank) as c3:
+            for name, kd, seed in (("text", 2, 3), ("dna", 1, 5)):
+                if kd == kind:
+                    continue
+                c3.generate(n, seed, kd)
+                c3.build()
                 ms = []
-                for _ in range(min(args.steps, 3)):
-                    c2.build(); ms.append(c2.stats()["build_ms"])
-                st2 = c2.stats()
-                out["dc3_recursion_only"] = {"switch": "DC3HIP_NO_TEXT_SHORTCUT=1", "device_ms_per_step": sum(ms) / len(ms),
-                                             "MBps": n / (sum(ms) / len(ms)) / 1e3, "sufcheck": c2.sufcheck(),
-                                             "checksum_equal": (c2.checksum() == chk0) if not args.no_verify else None,
-                                             "levels": list(zip(st2["level_n"], st2["level_K"], st2["level_sorted"]))}
-        finally:
-            os.environ.pop("DC3HIP_NO_TEXT_SHORTCUT", None)
+                for _ in range(3):
+                    c3.build(); ms.append(c3.stats()["build_ms"])
+                st3 = c3.stats()
+                m = sum(ms) / len(ms)
+                per_cfg[f"{name}_{per_gpu / 2**30:g}GiB"] = {
+                    "ms": m, "MB/s": n / m / 1e3, "sufcheck": c3.sufcheck(), "levels": st3["levels"],
+                    "path": PATH_NAMES.get(st3.get("text_sort_state", 0), "?"),
+                    "roofline_path": path_roofline(st3, m)}
+        out["per_config"] = per_cfg
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

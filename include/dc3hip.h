@@ -20,7 +20,10 @@
  *     (sacapart calls the SACA concurrently from rayon workers, crates/sacapart/src/lib.rs:41-49).
  *     The one-shot calls keep that context (device buffers only, never caller data) in a per-thread
  *     cache so that repeated calls do not pay hipMalloc again; dc3hip_release_cache() or thread exit
- *     frees it, DC3HIP_CACHE=0 disables it.
+ *     frees it, DC3HIP_CACHE=0 disables it.  Footprint: a cached context holds n + 4n + ~44n bytes of HBM for
+ *     the largest n the thread has sorted (~50 GB per 1 GiB of text); it is dropped when a later call needs
+ *     less than a quarter of it.  Partitioned use should go through dc3hip_sufsort_ex(num_partitions), which
+ *     runs one worker per GPU, rather than through concurrent one-shot calls on one device.
  *   - there is NO CPU fallback: without a usable gfx950 device the calls fail with -3.
  *
  * Plain C, no torch / HIP types in any signature.
@@ -66,8 +69,9 @@ typedef struct dc3hip_opts {
 DC3HIP_API int32_t dc3hip_sufsort_ex(const uint8_t *T, void *SA, int64_t n, const dc3hip_opts *opts);
 
 /* sufcheck() twin, computed on the GPU (utils.c:160-241 return codes: 0 ok, -1 invalid arguments,
- * -2 out of range, -3 first characters out of order, -4 suffix in wrong position; library failures
- * are reported as -5 (allocation) / -6 (HIP error), outside sufcheck's own range). */
+ * -2 out of range, -3 first characters out of order, -4 suffix in wrong position — an in-range array with
+ * duplicate entries reports -3 / -4 like the reference, which has no separate permutation test; library
+ * failures are reported as -5 (allocation) / -6 (HIP error), outside sufcheck's own range). */
 DC3HIP_API int32_t dc3hip_sufcheck_i32(const uint8_t *T, const int32_t *SA, int32_t n);
 
 /* divbwt() twin (divsufsort.c:372-405, divsufsort.h:78-88): Burrows-Wheeler transform via the GPU suffix
@@ -111,7 +115,9 @@ DC3HIP_API int32_t dc3hip_ctx_get_text(dc3hip_ctx *ctx, uint8_t *T);
  * Returns the sufcheck() codes above. */
 DC3HIP_API int32_t dc3hip_ctx_sufcheck(dc3hip_ctx *ctx);
 
-/* Load a suffix array built elsewhere (e.g. by libdivsufsort) next to the text already set. */
+/* Load a suffix array built elsewhere (e.g. by libdivsufsort) next to the text already set.  The by-product calls
+ * below (bwt, search) verify such an array once with the GPU sufcheck and fail with -1 if it is not the suffix
+ * array of the resident text; lcp tolerates any array (entries out of range yield 0). */
 DC3HIP_API int32_t dc3hip_ctx_set_sa_i32(dc3hip_ctx *ctx, const int32_t *SA);
 
 /* bw_transform() of utils.c:53-108 on the device-resident text/SA: U receives n bytes. */
@@ -123,7 +129,8 @@ DC3HIP_API int32_t dc3hip_ctx_lcp_i32(dc3hip_ctx *ctx, int32_t *LCP);
 
 /* Batched sacabase::longest_substring_match (sacabase/src/lib.rs:39-99): needle k is
  * needles[offsets[k] .. offsets[k+1]); out_start/out_len receive the match exactly as the reference's
- * binary-search narrowing would return it (LongestCommonSubstring.start / .len). */
+ * binary-search narrowing would return it (LongestCommonSubstring.start / .len).  needles, offsets (count+1
+ * non-negative, non-decreasing entries), out_start and out_len are HOST pointers. */
 DC3HIP_API int32_t dc3hip_ctx_search(dc3hip_ctx *ctx, const uint8_t *needles, const int64_t *offsets, int32_t count,
                                      int64_t *out_start, int64_t *out_len);
 
@@ -187,6 +194,62 @@ typedef struct dc3hip_stats {
 } dc3hip_stats;
 
 DC3HIP_API int32_t dc3hip_ctx_stats(dc3hip_ctx *ctx, dc3hip_stats *out);
+
+/* ---- GLOBAL mode: one suffix array over P ranks (one rank per GPU) -------------------------------------------
+ * The other multi-GPU semantics of SURVEY.md §8(e).  sacapart (crates/sacapart/src/lib.rs:39-58; here
+ * dc3hip_sufsort_ex(num_partitions)) keeps P independent local arrays.  A global context builds the TRUE SA[0..n) of
+ * the whole text — bit-identical to dc3hip_sufsort_* / divsufsort on the concatenated text — with the text sharded
+ * over the ranks in sacapart-style blocks (rank r owns bytes [r*S, min(n,(r+1)*S)), S = n/P + 1, lib.rs:43-46) and
+ * the result sharded by suffix rank (rank r holds SA[first_r .. first_r + count_r), the shards in rank order
+ * concatenate to the suffix array).  dc3hip_global_build is a COLLECTIVE: every rank of the group must call it.
+ * Transport: RCCL over xGMI (one process per GPU; the host program carries the 128-byte unique id from rank 0 to
+ * the others, e.g. with torch.distributed / MPI), or the in-process loopback (P ranks on ONE device, used to
+ * parity-test P in {2,4,8} on a single-GPU box).  n <= DC3HIP_MAX_N; P <= 16.
+ * Environment: DC3HIP_GLOBAL_LOCAL_MAX (levels up to this length are finished by every rank on its own replicated
+ * copy, default 2^22), DC3HIP_GLOBAL_NO_TEXT_ORDER=1 (skip the distributed whole-text order). */
+typedef struct dc3hip_gctx dc3hip_gctx;
+
+typedef struct dc3hip_gstats {
+  int32_t struct_size;
+  int32_t nranks, rank;
+  int32_t levels;            /* recursion depth of the last build */
+  int32_t text_order;        /* 1 = finished by the distributed whole-text order (all 9-byte windows distinct) */
+  int32_t local_from_level;  /* first level that every rank finished locally on its replicated copy (-1: none) */
+  int64_t total_n, shard_first, shard_count;
+  int64_t exchanges;         /* rank exchanges (all-to-all + all-gather) of the last build */
+  int64_t exchange_pairs;    /* (destination, value) pairs this rank fed into them */
+  int64_t comm_bytes_out, comm_bytes_in;   /* payload over the transport, self copies excluded */
+  double  comm_ms;           /* host wall time inside collectives (incl. waiting for the slowest rank) */
+  double  device_ms;         /* HIP-event time of this rank's build stream, start to end (incl. transport) */
+  double  wall_ms;           /* host wall time of dc3hip_global_build on this rank */
+} dc3hip_gstats;
+
+/* P loopback ranks on `device` (-1 = current), each able to take part in builds of up to max_total_n bytes. */
+DC3HIP_API int32_t dc3hip_global_loopback_create(dc3hip_gctx **ranks /*[P]*/, int32_t P, int32_t device, int64_t max_total_n);
+/* runs dc3hip_global_build of the P ranks on P host threads and waits for all of them */
+DC3HIP_API int32_t dc3hip_global_loopback_build(dc3hip_gctx **ranks, int32_t P);
+/* RCCL: rank 0 obtains the id, the host program distributes it, every process creates its rank */
+DC3HIP_API int32_t dc3hip_rccl_unique_id(uint8_t *id128);
+DC3HIP_API int32_t dc3hip_global_rccl_create(dc3hip_gctx **out, const uint8_t *id128, int32_t rank, int32_t nranks,
+                                             int32_t device, int64_t max_total_n);
+DC3HIP_API void dc3hip_global_destroy(dc3hip_gctx *g);
+/* the block of a text of total_n bytes this rank owns */
+DC3HIP_API int32_t dc3hip_global_block(dc3hip_gctx *g, int64_t total_n, int64_t *offset, int64_t *length);
+/* load this rank's block (host or device pointer, `length` bytes of dc3hip_global_block) ... */
+DC3HIP_API int32_t dc3hip_global_set_text_block(dc3hip_gctx *g, const uint8_t *block, int64_t total_n);
+/* ... or generate it on the device (the stream of dc3hip_ctx_generate, bytes [offset, offset+length)) */
+DC3HIP_API int32_t dc3hip_global_generate(dc3hip_gctx *g, int64_t total_n, uint64_t seed, int32_t kind);
+DC3HIP_API int32_t dc3hip_global_build(dc3hip_gctx *g);
+/* this rank's shard: SA[first .. first+count) */
+DC3HIP_API int32_t dc3hip_global_shard(dc3hip_gctx *g, int64_t *first, int64_t *count);
+DC3HIP_API int32_t dc3hip_global_get_shard_i64(dc3hip_gctx *g, int64_t *out);
+DC3HIP_API int32_t dc3hip_global_get_shard_u32(dc3hip_gctx *g, uint32_t *out);
+/* sum over the shard of mix(global index, SA[index]); the sum over all ranks equals dc3hip_ctx_sa_checksum of a
+ * single-device build of the same text */
+DC3HIP_API int32_t dc3hip_global_shard_checksum(dc3hip_gctx *g, uint64_t *out);
+DC3HIP_API int32_t dc3hip_global_stats(dc3hip_gctx *g, dc3hip_gstats *out, dc3hip_stats *ctx_stats /* may be NULL */);
+DC3HIP_API const char *dc3hip_global_last_error(dc3hip_gctx *g);   /* error of this rank's last build (loopback threads) */
+DC3HIP_API const char *dc3hip_global_transport(dc3hip_gctx *g);
 
 #ifdef __cplusplus
 }

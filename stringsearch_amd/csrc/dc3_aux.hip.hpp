@@ -72,7 +72,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(uint8_t *t, u64 n, u64 seed
 // ---------------------------------------------------------------------------------------------
 // GPU verifier = sufcheck() of crates/cdivsufsort/c-sources/utils.c:160-241 restated as parallel
 // passes (equivalently sacabase::verify, sacabase/src/lib.rs:127-149).  With ISA = inverse of SA:
-//   (1) range + permutation: every SA[i] in [0,n) and ISA is a bijection        (-2)
+//   (1) range: every SA[i] in [0,n) (-2); ISA a bijection (a duplicate entry reports -4 like the reference's scan)
 //   (2) first characters non-decreasing                                          (-3)
 //   (3) for T[SA[i]] == T[SA[i+1]]: rank of suffix SA[i]+1 < rank of suffix SA[i+1]+1, the end
 //       of text ranking lowest                                                   (-4)
@@ -104,7 +104,9 @@ __global__ __launch_bounds__(kBlock) void k_check_order(const uint8_t *__restric
       cq = (i + 1 < n && q < n) ? (u32)t[q] : 0u;
     }
     if (!pin) continue;                                       // out of range: reported by k_check_fill
-    if (isa[p] != i + 1) { atomicMax(err, 3); continue; }   // not a permutation
+    // an in-range array that is not a permutation (duplicate entries): the reference has no permutation test and
+    // fails such arrays in its psi scan (-4, utils.c:213-238) unless the first characters already disagree (-3)
+    if (isa[p] != i + 1) { atomicMax(err, 1); continue; }
     if (i + 1 >= n || q >= n) continue;
     if (cp > cq) { atomicMax(err, 2); continue; }           // -3
     if (cp == cq) {

@@ -1,0 +1,879 @@
+// dc3_global_host.hpp — host driver of the GLOBAL multi-GPU mode: ONE suffix array of a text whose bytes are sharded
+// over P ranks (sacapart-style blocks, crates/sacapart/src/lib.rs:43-46), result sharded by suffix rank.  Included at
+// the end of dc3hip.hip (same translation unit: it reuses the single-device building blocks above).
+//
+// The reference has no counterpart: its PartitionedSuffixArray keeps P independent local arrays and stitches at search
+// time (sacapart/src/lib.rs:5-25, 69-97).  This is the other semantics SURVEY.md §8(e) names: the true SA[0..n) of the
+// whole text, bit-identical to a single-device build (and so to divsufsort), built by the level structure of
+// crates/dc3/src/lib.rs:44-193 with two rules:
+//   1. replicate what is read at random — the level's string S and the sample ranks rank12, 4 B per element — into
+//      every rank's HBM; then every rank can evaluate any key of the level from local memory, so
+//   2. work is split by KEY RANGE, not by position: a rank streams over all positions, keeps the records whose key
+//      falls into its range (splitters from a deterministic sample every rank computes identically), and sorts,
+//      names and merges only those.  No (key, pos) record ever crosses xGMI.
+// What does cross xGMI is the RANK EXCHANGE (rank_exchange below): (slot, name) / (position, rank) pairs go to the owner
+// of their destination block (all-to-all), each owner builds its block with the windowed inversion, and the 4-byte
+// blocks are all-gathered.  Transport behind a small interface (GComm): RCCL (ncclSend/ncclRecv groups over xGMI, one
+// process per GPU) or an in-process loopback (P rank contexts on one device, hipMemcpyAsync as the wire) that exists so
+// that P in {2,4,8} is parity-tested bit-exactly on a single-GPU box.
+#pragma once
+
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <chrono>
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: the entry points are resolved with dlopen/dlsym at first use
+
+// ---------------------------------------------------------------------------------------------
+// transport
+// ---------------------------------------------------------------------------------------------
+struct GComm {
+  int rank = 0, nranks = 1;
+  double comm_ms = 0;                 // host wall time inside collectives (they are synchronous)
+  uint64_t bytes_out = 0, bytes_in = 0;   // payload that left / reached this rank (self copies excluded)
+  virtual ~GComm() {}
+  // every rank sends send[soff[r] .. +sbytes[r]) to rank r and receives rbytes[r] bytes from rank r at recv + roff[r]
+  virtual int all_to_all_v(const void *send, const size_t *soff, const size_t *sbytes, void *recv, const size_t *roff,
+                           const size_t *rbytes, hipStream_t st) = 0;
+  // every rank contributes sbytes bytes; block r lands at recv + roff[r] (rbytes[r] bytes) on every rank.
+  // send may be recv + roff[rank] (in place).
+  virtual int all_gather_v(const void *send, size_t sbytes, void *recv, const size_t *roff, const size_t *rbytes,
+                           hipStream_t st) = 0;
+  // small host values: out[r*bytes ..] = rank r's in[0..bytes)
+  virtual int all_gather_host(const void *in, void *out, size_t bytes) = 0;
+  virtual void abort_all() {}
+  virtual const char *name() const = 0;
+};
+struct CommTimer {
+  GComm *g; std::chrono::steady_clock::time_point t0;
+  explicit CommTimer(GComm *gc) : g(gc), t0(std::chrono::steady_clock::now()) {}
+  ~CommTimer() { g->comm_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
+// ---- loopback: P ranks = P host threads of one process, each with its own context/stream on the same device -------
+struct LoopWorld {
+  int P;
+  std::mutex mu; std::condition_variable cv;
+  int arrived = 0; uint64_t gen = 0; bool failed = false;
+  struct Post { const void *send; const size_t *soff; const size_t *sbytes; size_t one; };
+  std::vector<Post> post;
+  explicit LoopWorld(int p) : P(p), post((size_t)p) {}
+  bool barrier() {                    // false once any rank has failed (nobody is left waiting for it)
+    std::unique_lock<std::mutex> lk(mu);
+    if (failed) return false;
+    const uint64_t g = gen;
+    if (++arrived == P) { arrived = 0; gen++; cv.notify_all(); return true; }
+    cv.wait(lk, [&] { return gen != g || failed; });
+    return !failed;
+  }
+  void fail() { std::lock_guard<std::mutex> lk(mu); failed = true; cv.notify_all(); }
+};
+struct LoopComm : GComm {
+  std::shared_ptr<LoopWorld> w;
+  const char *name() const override { return "loopback (in-process, hipMemcpyAsync)"; }
+  void abort_all() override { w->fail(); }
+  int sync_fail() { set_err("loopback transport: another rank failed"); return E_HIP; }
+  int all_to_all_v(const void *send, const size_t *soff, const size_t *sbytes, void *recv, const size_t *roff,
+                   const size_t *rbytes, hipStream_t st) override {
+    CommTimer tm(this);
+    HIPC(hipStreamSynchronize(st));                      // my outgoing bytes are complete
+    w->post[(size_t)rank] = LoopWorld::Post{send, soff, sbytes, 0};
+    if (!w->barrier()) return sync_fail();
+    for (int r = 0; r < nranks; r++) {
+      const LoopWorld::Post &p = w->post[(size_t)r];
+      if (p.sbytes[rank] != rbytes[r]) { set_err("loopback all_to_all_v: rank %d sends %zu bytes, rank %d expects %zu", r, p.sbytes[rank], rank, rbytes[r]); w->fail(); return E_HIP; }
+      if (rbytes[r] == 0) continue;
+      HIPC(hipMemcpyAsync(static_cast<char *>(recv) + roff[r], static_cast<const char *>(p.send) + p.soff[rank], rbytes[r],
+                          hipMemcpyDeviceToDevice, st));
+      if (r != rank) { bytes_in += rbytes[r]; bytes_out += sbytes[r]; }
+    }
+    HIPC(hipStreamSynchronize(st));
+    if (!w->barrier()) return sync_fail();               // senders may reuse their buffers
+    return E_OK;
+  }
+  int all_gather_v(const void *send, size_t sbytes, void *recv, const size_t *roff, const size_t *rbytes,
+                   hipStream_t st) override {
+    CommTimer tm(this);
+    HIPC(hipStreamSynchronize(st));
+    w->post[(size_t)rank] = LoopWorld::Post{send, nullptr, nullptr, sbytes};
+    if (!w->barrier()) return sync_fail();
+    for (int r = 0; r < nranks; r++) {
+      const LoopWorld::Post &p = w->post[(size_t)r];
+      if (p.one != rbytes[r]) { set_err("loopback all_gather_v: rank %d contributes %zu bytes, expected %zu", r, p.one, rbytes[r]); w->fail(); return E_HIP; }
+      char *dst = static_cast<char *>(recv) + roff[r];
+      if (rbytes[r] == 0 || dst == p.send) continue;     // in place
+      HIPC(hipMemcpyAsync(dst, p.send, rbytes[r], hipMemcpyDeviceToDevice, st));
+      if (r != rank) { bytes_in += rbytes[r]; bytes_out += sbytes; }
+    }
+    HIPC(hipStreamSynchronize(st));
+    if (!w->barrier()) return sync_fail();
+    return E_OK;
+  }
+  int all_gather_host(const void *in, void *out, size_t bytes) override {
+    CommTimer tm(this);
+    w->post[(size_t)rank] = LoopWorld::Post{in, nullptr, nullptr, bytes};
+    if (!w->barrier()) return sync_fail();
+    for (int r = 0; r < nranks; r++) memcpy(static_cast<char *>(out) + (size_t)r * bytes, w->post[(size_t)r].send, bytes);
+    if (!w->barrier()) return sync_fail();
+    return E_OK;
+  }
+};
+
+// ---- RCCL: one process per GPU, grouped ncclSend/ncclRecv over xGMI --------------------------------------------------
+struct RcclApi {
+  void *h = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  bool load() {
+    if (h) return true;
+    // a process that already carries an RCCL (PyTorch does) hands back that one for the same soname
+    for (const char *nm : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    if (!h) { set_err("RCCL not found (dlopen librccl.so): %s", dlerror()); return false; }
+#define DC3_RCCL_SYM(field, sym) field = reinterpret_cast<decltype(field)>(dlsym(h, #sym)); if (!field) { set_err("RCCL symbol %s missing", #sym); h = nullptr; return false; }
+    DC3_RCCL_SYM(GetUniqueId, ncclGetUniqueId) DC3_RCCL_SYM(CommInitRank, ncclCommInitRank) DC3_RCCL_SYM(CommDestroy, ncclCommDestroy)
+    DC3_RCCL_SYM(GroupStart, ncclGroupStart) DC3_RCCL_SYM(GroupEnd, ncclGroupEnd) DC3_RCCL_SYM(Send, ncclSend) DC3_RCCL_SYM(Recv, ncclRecv)
+    DC3_RCCL_SYM(AllGather, ncclAllGather) DC3_RCCL_SYM(GetErrorString, ncclGetErrorString)
+#undef DC3_RCCL_SYM
+    return true;
+  }
+};
+static RcclApi g_rccl;
+static std::mutex g_rccl_mu;
+#define NCCLC(expr)                                                                                              \
+  do {                                                                                                           \
+    ncclResult_t r__ = (expr);                                                                                   \
+    if (r__ != ncclSuccess) { set_err("RCCL error %d (%s) at %s:%d: %s", (int)r__, g_rccl.GetErrorString(r__), __FILE__, __LINE__, #expr); return E_HIP; } \
+  } while (0)
+struct RcclComm : GComm {
+  ncclComm_t comm = nullptr;
+  unsigned char *d_small = nullptr;   // [ (P + 1) * kSmall ]
+  static constexpr size_t kSmall = 1024;
+  const char *name() const override { return "RCCL (grouped ncclSend/ncclRecv over xGMI)"; }
+  ~RcclComm() override {
+    if (comm) (void)g_rccl.CommDestroy(comm);
+    if (d_small) (void)hipFree(d_small);
+  }
+  int all_to_all_v(const void *send, const size_t *soff, const size_t *sbytes, void *recv, const size_t *roff,
+                   const size_t *rbytes, hipStream_t st) override {
+    CommTimer tm(this);
+    NCCLC(g_rccl.GroupStart());
+    for (int r = 0; r < nranks; r++) {
+      if (r == rank) continue;
+      if (sbytes[r]) NCCLC(g_rccl.Send(static_cast<const char *>(send) + soff[r], sbytes[r], ncclUint8, r, comm, st));
+      if (rbytes[r]) NCCLC(g_rccl.Recv(static_cast<char *>(recv) + roff[r], rbytes[r], ncclUint8, r, comm, st));
+      bytes_out += sbytes[r]; bytes_in += rbytes[r];
+    }
+    NCCLC(g_rccl.GroupEnd());
+    if (rbytes[rank])
+      HIPC(hipMemcpyAsync(static_cast<char *>(recv) + roff[rank], static_cast<const char *>(send) + soff[rank], rbytes[rank],
+                          hipMemcpyDeviceToDevice, st));
+    HIPC(hipStreamSynchronize(st));
+    return E_OK;
+  }
+  int all_gather_v(const void *send, size_t sbytes, void *recv, const size_t *roff, const size_t *rbytes,
+                   hipStream_t st) override {
+    CommTimer tm(this);
+    NCCLC(g_rccl.GroupStart());
+    for (int r = 0; r < nranks; r++) {
+      if (r == rank) continue;
+      if (sbytes) NCCLC(g_rccl.Send(send, sbytes, ncclUint8, r, comm, st));
+      if (rbytes[r]) NCCLC(g_rccl.Recv(static_cast<char *>(recv) + roff[r], rbytes[r], ncclUint8, r, comm, st));
+      bytes_out += sbytes; bytes_in += rbytes[r];
+    }
+    NCCLC(g_rccl.GroupEnd());
+    char *self = static_cast<char *>(recv) + roff[rank];
+    if (sbytes && self != send) HIPC(hipMemcpyAsync(self, send, sbytes, hipMemcpyDeviceToDevice, st));
+    HIPC(hipStreamSynchronize(st));
+    return E_OK;
+  }
+  int all_gather_host(const void *in, void *out, size_t bytes) override {
+    CommTimer tm(this);
+    if (bytes > kSmall) { set_err("all_gather_host: %zu bytes per rank exceed the staging buffer", bytes); return E_ARGS; }
+    unsigned char *din = d_small, *dout = d_small + kSmall;
+    HIPC(hipMemcpy(din, in, bytes, hipMemcpyHostToDevice));
+    NCCLC(g_rccl.AllGather(din, dout, bytes, ncclUint8, comm, nullptr));
+    HIPC(hipStreamSynchronize(nullptr));
+    HIPC(hipMemcpy(out, dout, bytes * (size_t)nranks, hipMemcpyDeviceToHost));
+    return E_OK;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// one rank of a global build
+// ---------------------------------------------------------------------------------------------
+struct dc3hip_gctx {
+  dc3hip_ctx *c = nullptr;
+  GComm *comm = nullptr;
+  int64_t max_total = 0, total_n = 0;
+  bool text_set = false, built = false;
+  int64_t shard_first = 0, shard_count = 0;     // this rank holds SA[shard_first .. shard_first + shard_count)
+  const u32 *shard_ptr = nullptr;               // device
+  u32 local_max = 1u << 22;                     // levels up to this length are finished on every rank redundantly
+  bool no_text_order = false;
+  dc3hip_gstats gs;
+  char err[512] = "";
+  std::vector<dc3hip_gctx *> group;             // loopback: all ranks of the group (rank 0 owns the list)
+};
+
+static void block_of(int64_t n, int P, int r, int64_t *off, int64_t *len) {
+  const int64_t S = n / P + 1;                  // sacapart/src/lib.rs:43
+  const int64_t o = std::min<int64_t>(n, (int64_t)r * S);
+  *off = o; *len = std::min<int64_t>(S, n - o);
+}
+
+// counts of `bytes` per rank -> this rank's prefix and the total
+static int gather_counts(GComm *cm, uint64_t mine, uint64_t *prefix, uint64_t *total, uint64_t *all = nullptr) {
+  uint64_t buf[kMaxRanks];
+  RC(cm->all_gather_host(&mine, buf, sizeof(uint64_t)));
+  uint64_t pre = 0, tot = 0;
+  for (int r = 0; r < cm->nranks; r++) { if (r < cm->rank) pre += buf[r]; tot += buf[r]; if (all) all[r] = buf[r]; }
+  *prefix = pre; *total = tot;
+  return E_OK;
+}
+
+// order-preserving selection (k_sel_count / scan / k_sel_write); *out is allocated from the arena
+template <class Sel>
+static int select_records(dc3hip_ctx *c, const Sel &sel, u32 nitems, typename Sel::Out **out, u32 *count, int phase) {
+  const Chunking ck = make_chunks(c, nitems, kBlock);
+  u32 *counts = nullptr;
+  RC(arena_alloc(c, (size_t)ck.nchunks + 16, &counts));
+  {
+    PhaseScope ps(c, phase, nitems);
+    hipLaunchKernelGGL((k_sel_count<Sel>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, sel, nitems, ck.chunk, counts);
+    KCHECK();
+    hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, counts, ck.nchunks, c->d_words + 32);
+    KCHECK();
+    HIPC(hipMemcpyAsync(c->h_words + 32, c->d_words + 32, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPC(hipStreamSynchronize(c->stream));
+  *count = c->h_words[32];
+  RC(arena_alloc(c, (size_t)*count + 16, out));
+  if (*count) {
+    PhaseScope ps(c, phase, nitems);
+    hipLaunchKernelGGL((k_sel_write<Sel>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, sel, nitems, ck.chunk, counts, *out);
+    KCHECK();
+  }
+  return E_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// RANK EXCHANGE: every rank holds `cnt` (destination, value) pairs; all destinations together are a bijection onto
+// [0, M).  On return out[0..M) is complete on EVERY rank.
+//   1. local partition of the pairs by destination digit (<= 256 digits of >= 2^14 destinations; rank h owns a
+//      contiguous digit range) — one stable radix pass, its digit table gives the send offsets;
+//   2. all-to-all: pairs to the owner of their destination            (8 B x cnt x (P-1)/P per rank over xGMI)
+//   3. the owner builds its block by the windowed inversion (inverse_permute)
+//   4. all-gather of the blocks                                        (4 B x M x (P-1)/P per rank over xGMI)
+// ---------------------------------------------------------------------------------------------
+static int rank_exchange(dc3hip_gctx *G, Rec8 *pairs, u32 cnt, u32 M, u32 *out, int phase) {
+  dc3hip_ctx *c = G->c; GComm *cm = G->comm;
+  const int P = cm->nranks, me = cm->rank;
+  const ArenaMark mk = arena_mark(c);
+  u32 sh = (u32)kInvWindowBits;
+  while ((((u64)M - 1) >> sh) + 1 > 256) sh++;
+  const u32 nd = (u32)((((u64)M - 1) >> sh) + 1);
+  auto dlo = [&](int h) { return (u32)(((u64)h * nd + P - 1) / P); };       // first digit of rank h
+  auto dest_lo = [&](int h) { return (u64)std::min<u64>((u64)M, (u64)dlo(h) << sh); };
+  // 1. partition by digit
+  u32 hdb[257];
+  Rec8 *sorted = pairs;
+  for (u32 d = 0; d <= 256; d++) hdb[d] = 0;
+  if (cnt) {
+    constexpr int kTile = SortCfg<Rec8, 256>::NW * 64 * SortCfg<Rec8, 256>::IPT;
+    const Chunking ck = make_chunks(c, cnt, kTile);
+    u32 *table = nullptr, *digit_base = nullptr;
+    Rec8 *pb = nullptr;
+    RC(arena_alloc(c, (size_t)256 * ck.nchunks, &table));
+    RC(arena_alloc(c, (size_t)256, &digit_base));
+    RC(arena_alloc(c, (size_t)cnt, &pb));
+    KeyDig dig; dig.shift = 32 + sh; dig.mask = 255;
+    {
+      PhaseScope ps(c, phase, cnt);
+      hipLaunchKernelGGL((k_rs_upsweep<Rec8, 256>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, pairs, cnt, ck.chunk,
+                         ck.nchunks, dig, table);
+      KCHECK();
+    }
+    RC(scan_digit_table(c, table, ck.nchunks, digit_base, 256, phase));
+    std::vector<u32> tmp(256);
+    HIPC(hipMemcpyAsync(tmp.data(), digit_base, 256 * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    ArrayLoader<Rec8> ld; ld.p = pairs;
+    RC((launch_downsweep<Rec8, 256, ArrayLoader<Rec8>>(c, ld, pb, cnt, ck, dig, table, digit_base, phase)));
+    HIPC(hipStreamSynchronize(c->stream));
+    for (u32 d = 0; d < 256; d++) hdb[d] = tmp[d];
+    hdb[256] = cnt;
+    for (u32 d = nd; d < 256; d++) hdb[d] = cnt;
+    sorted = pb;
+  }
+  // 2. all-to-all
+  size_t soff[kMaxRanks], sbytes[kMaxRanks], roff[kMaxRanks], rbytes[kMaxRanks];
+  uint64_t scount[kMaxRanks], mat[kMaxRanks * kMaxRanks];
+  for (int h = 0; h < P; h++) {
+    const u32 a = hdb[std::min<u32>(dlo(h), 256)], b = hdb[std::min<u32>(dlo(h + 1), 256)];
+    soff[h] = (size_t)a * sizeof(Rec8); sbytes[h] = (size_t)(b - a) * sizeof(Rec8); scount[h] = b - a;
+  }
+  RC(cm->all_gather_host(scount, mat, sizeof(uint64_t) * (size_t)P));
+  const u64 base = dest_lo(me), myblk = dest_lo(me + 1) - base;
+  u64 got = 0;
+  for (int r = 0; r < P; r++) { roff[r] = (size_t)got * sizeof(Rec8); rbytes[r] = (size_t)mat[(size_t)r * P + me] * sizeof(Rec8); got += mat[(size_t)r * P + me]; }
+  if (got != myblk) { set_err("rank exchange: block of rank %d expects %llu pairs, received %llu (destinations are not a bijection)", me, (unsigned long long)myblk, (unsigned long long)got); return E_HIP; }
+  Rec8 *rb = nullptr, *rt = nullptr;
+  RC(arena_alloc(c, (size_t)myblk + 16, &rb));
+  RC(arena_alloc(c, (size_t)myblk + 16, &rt));
+  RC(cm->all_to_all_v(sorted, soff, sbytes, rb, roff, rbytes, c->stream));
+  // 3. my block
+  if (myblk) {
+    if (base) {
+      PhaseScope ps(c, phase, myblk);
+      hipLaunchKernelGGL(k_rebase_keys, dim3(grid_for(c, myblk)), dim3(kBlock), 0, c->stream, rb, (u32)myblk, (u32)base);
+      KCHECK();
+    }
+    RC(inverse_permute(c, rb, rt, (u32)myblk, out + base, phase));
+  }
+  // 4. all-gather of the blocks, in place
+  size_t goff[kMaxRanks], gbytes[kMaxRanks];
+  for (int r = 0; r < P; r++) { goff[r] = (size_t)dest_lo(r) * 4; gbytes[r] = (size_t)(dest_lo(r + 1) - dest_lo(r)) * 4; }
+  RC(cm->all_gather_v(out + base, (size_t)myblk * 4, out, goff, gbytes, c->stream));
+  G->gs.exchanges += 1;
+  G->gs.exchange_pairs += cnt;
+  arena_release(c, mk);
+  return E_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// one level (lib.rs:44-193) on replicated S.  top: the level's SA slice of this rank goes to c->d_sa (G->shard_*);
+// otherwise out_rank[0..m) (+ zero tail) is produced on every rank (the parent's rank12).
+// ---------------------------------------------------------------------------------------------
+template <class Sym>
+static int glevel(dc3hip_gctx *G, Sym S, u32 m, u64 K, int depth, u32 *out_rank, bool top) {
+  dc3hip_ctx *c = G->c; GComm *cm = G->comm;
+  const int P = cm->nranks, me = cm->rank;
+  if (depth >= DC3HIP_MAX_LEVELS) { set_err("recursion deeper than %d levels", DC3HIP_MAX_LEVELS); return E_HIP; }
+  if (m <= G->local_max || m < 64) {
+    // small level: every rank finishes the recursion on its own copy (no communication below this point)
+    if (G->gs.local_from_level < 0) G->gs.local_from_level = depth;
+    if (top) {
+      RC(dc3_level<Sym>(c, S, m, K, c->d_sa, nullptr, depth));
+      int64_t off, len; block_of(m, P, me, &off, &len);
+      G->shard_first = off; G->shard_count = len; G->shard_ptr = c->d_sa + off;
+    } else {
+      RC(dc3_level<Sym>(c, S, m, K, nullptr, out_rank, depth));
+    }
+    return E_OK;
+  }
+  const u32 m0 = (m + 2) / 3, m1 = (m + 1) / 3, m2 = m / 3, m02 = m0 + m2;   // lib.rs:45-48
+  c->stats.level_n[depth] = m; c->stats.level_K[depth] = (int64_t)K; c->stats.levels = depth + 1;
+  const ArenaMark mk0 = arena_mark(c);
+  u32 *R = nullptr, *rank12 = nullptr;
+  RC(arena_alloc(c, (size_t)m02 + 16, &R));
+  const u64 B = K + 1;
+  const bool direct = (B * B * B) <= 0x7fffffffull;
+  if (direct) {
+    // order-preserving packed-triple names, computed by every rank for the whole level (one streaming pass)
+    c->stats.level_sorted[depth] = 0; c->stats.level_name_width[depth] = 3;
+    {
+      PhaseScope ps(c, DC3HIP_PH_NAME_DIRECT, m02);
+      hipLaunchKernelGGL((k_name_direct<Sym>), dim3(grid_for(c, m0)), dim3(kBlock), 0, c->stream, S, m, m0, m02, (u32)B, 3u,
+                         (u32)(B * B), R);
+      KCHECK();
+    }
+    RC(arena_alloc(c, (size_t)m02 + 16, &rank12));
+    SymU32 RS; RS.s = R; RS.m = m02;
+    RC(glevel<SymU32>(G, RS, m02, B * B * B, depth + 1, rank12, false));
+  } else {
+    // ---- sorted naming, split by key range (lib.rs:62-100) ---------------------------------------------------
+    c->stats.level_sorted[depth] = 1;
+    const u32 b = (u32)B;
+    u32 kbits = 0;
+    { unsigned __int128 mx = (unsigned __int128)B * B * B - 1; while (mx) { kbits++; mx >>= 1; } }
+    const ArenaMark mk1 = arena_mark(c);
+    // splitters: every rank sorts the same deterministic sample of keys
+    Rec16 klo{0, 0, 0, 0}, khi{0, 0, 0, 0};
+    {
+      u32 ns = (u32)std::min<u64>(m02, (u64)1024 * P);
+      const u32 stride = std::max<u32>(1, m02 / ns);
+      ns = (m02 - 1) / stride + 1;
+      Rec16 *smp = nullptr;
+      RC(arena_alloc(c, (size_t)ns, &smp));
+      std::vector<Rec16> hs(ns);
+      hipLaunchKernelGGL((k_sample_triple_keys<Sym>), dim3(grid_for(c, ns)), dim3(kBlock), 0, c->stream, S, b, ns, stride, smp);
+      KCHECK();
+      HIPC(hipMemcpyAsync(hs.data(), smp, (size_t)ns * sizeof(Rec16), hipMemcpyDeviceToHost, c->stream));
+      HIPC(hipStreamSynchronize(c->stream));
+      std::sort(hs.begin(), hs.end(), [](const Rec16 &x, const Rec16 &y) {
+        if (x.k2 != y.k2) return x.k2 < y.k2;
+        if (x.k1 != y.k1) return x.k1 < y.k1;
+        return x.k0 < y.k0;
+      });
+      if (me > 0) klo = hs[(size_t)((u64)me * ns / P)];
+      if (me + 1 < P) khi = hs[(size_t)((u64)(me + 1) * ns / P)];
+    }
+    SelTripleKey<Sym> sel; sel.S = S; sel.B = b; sel.klo = klo; sel.khi = khi; sel.has_lo = me > 0 ? 1u : 0u; sel.last = (me + 1 == P) ? 1u : 0u;
+    Rec16 *recA = nullptr, *recB = nullptr, *sorted = nullptr;
+    u32 cnt = 0;
+    RC(select_records(c, sel, m02, &recA, &cnt, DC3HIP_PH_PACK));
+    RC(arena_alloc(c, (size_t)cnt + 16, &recB));
+    sorted = recA;
+    if (cnt) RC(radix_sort<Rec16>(c, recA, recB, cnt, 0, kbits, &sorted, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT12_DOWN));
+    AccRec<Rec16> acc; acc.s = sorted;
+    const Chunking ck = make_chunks(c, std::max<u32>(cnt, 1), kBlock * kNameIPT);
+    u32 *counts = nullptr;
+    RC(arena_alloc(c, (size_t)ck.nchunks + 16, &counts));
+    u32 distinct = 0;
+    if (cnt) {
+      PhaseScope ps(c, DC3HIP_PH_NAMING, cnt);
+      HIPC(hipMemsetAsync(c->d_words + 4, 0, sizeof(u32), c->stream));
+      hipLaunchKernelGGL((k_name_count<AccRec<Rec16>>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, acc, cnt, ck.chunk, counts,
+                         c->d_words + 4);
+      KCHECK();
+      hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, counts, ck.nchunks, c->d_words);
+      KCHECK();
+      HIPC(hipMemcpyAsync(c->h_words, c->d_words, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+      HIPC(hipStreamSynchronize(c->stream));
+      distinct = c->h_words[0];
+    }
+    // names of this rank follow the names of all smaller key ranges (equal keys never straddle ranks)
+    uint64_t name_off = 0, names_total = 0, cnt_pre = 0, cnt_total = 0;
+    RC(gather_counts(cm, distinct, &name_off, &names_total));
+    RC(gather_counts(cm, cnt, &cnt_pre, &cnt_total));
+    if (cnt_total != m02) { set_err("global naming: %llu of %u samples selected", (unsigned long long)cnt_total, m02); return E_HIP; }
+    Rec8 *pa = nullptr;
+    RC(arena_alloc(c, (size_t)cnt + 16, &pa));
+    if (cnt) {
+      PhaseScope ps(c, DC3HIP_PH_NAMING, cnt);
+      if (name_off) {
+        hipLaunchKernelGGL(k_add_scalar, dim3(grid_for(c, ck.nchunks)), dim3(kBlock), 0, c->stream, counts, ck.nchunks, (u32)name_off);
+        KCHECK();
+      }
+      hipLaunchKernelGGL((k_name_assign<AccRec<Rec16>>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, acc, cnt, ck.chunk, counts,
+                         m0, pa, (u32 *)nullptr);
+      KCHECK();
+    }
+    RC(rank_exchange(G, pa, cnt, m02, R, DC3HIP_PH_NAMING));      // R[slot] = name, everywhere
+    hipLaunchKernelGGL(k_zero_tail, dim3(1), dim3(64), 0, c->stream, R, m02, 8u);
+    KCHECK();
+    arena_release(c, mk1);
+    if (names_total == m02) {
+      rank12 = R;                                                 // all names distinct: the names are the ranks (lib.rs:109-113)
+    } else {
+      RC(arena_alloc(c, (size_t)m02 + 16, &rank12));
+      SymU32 RS; RS.s = R; RS.m = m02;
+      RC(glevel<SymU32>(G, RS, m02, names_total, depth + 1, rank12, false));   // lib.rs:104
+    }
+  }
+  hipLaunchKernelGGL(k_zero_tail, dim3(1), dim3(64), 0, c->stream, rank12, m02, 8u);
+  KCHECK();
+
+  // ---- Step 2 + 3, split by rank range (lib.rs:118-192) -------------------------------------------------------
+  // slot-order sample tuples for the whole level (streaming, every rank)
+  Tup12 *tslot = nullptr;
+  RC(arena_alloc(c, (size_t)m02, &tslot));
+  {
+    PhaseScope ps(c, DC3HIP_PH_TUPLES, m02);
+    hipLaunchKernelGGL((k_build_tuples<Sym>), dim3(grid_for(c, m0)), dim3(kBlock), 0, c->stream, S, m, m0, m02, rank12, tslot);
+    KCHECK();
+  }
+  // rank g owns the output between splitter samples g and g+1; the splitters are the samples of rank bound[g]
+  const u32 dskip = m0 - m1;                      // lib.rs:133: the dummy has sample rank 1 and is not a suffix
+  const u32 first_rank = 1 + dskip, nAtot = m02 - dskip;
+  u32 bound[kMaxRanks + 1];
+  for (int h = 0; h <= P; h++) bound[h] = first_rank + (u32)((u64)nAtot * h / P);
+  Splitters sp; memset(&sp, 0, sizeof(sp)); sp.n = (u32)(P - 1);
+  if (P > 1) {
+    RankTargets t; memset(&t, 0, sizeof(t)); t.n = (u32)(P - 1);
+    for (int h = 1; h < P; h++) t.r[h - 1] = bound[h];
+    HIPC(hipMemsetAsync(c->d_words + 40, 0xff, kMaxRanks * sizeof(u32), c->stream));
+    hipLaunchKernelGGL(k_find_ranks, dim3(grid_for(c, m02)), dim3(kBlock), 0, c->stream, rank12, m02, t, c->d_words + 40);
+    KCHECK();
+    HIPC(hipMemcpyAsync(c->h_words + 40, c->d_words + 40, kMaxRanks * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    for (int h = 1; h < P; h++) {
+      const u32 slot = c->h_words[40 + h - 1];
+      if (bound[h] > m02) { sp.a[h - 1] = Tup12{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}; continue; }   // (no sample left)
+      if (slot >= m02) { set_err("global merge: sample rank %u not found (rank12 is not a bijection)", bound[h]); return E_HIP; }
+      HIPC(hipMemcpyAsync(&sp.a[h - 1], tslot + slot, sizeof(Tup12), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPC(hipStreamSynchronize(c->stream));
+  }
+  const u32 lo = bound[me], hi = bound[me + 1], nA = hi - lo;
+  // A: my samples in rank order = windowed inversion of (rank - lo, slot), then the tuple gather
+  Tup12 *A = nullptr;
+  RC(arena_alloc(c, (size_t)nA + 16, &A));
+  {
+    const ArenaMark mkA = arena_mark(c);
+    SelRankRange sr; sr.rank12 = rank12; sr.lo = lo; sr.hi = hi;
+    Rec8 *pr = nullptr, *pt = nullptr; u32 got = 0;
+    RC(select_records(c, sr, m02, &pr, &got, DC3HIP_PH_RANKS));
+    if (got != nA) { set_err("global merge: %u samples in rank range [%u,%u), expected %u", got, lo, hi, nA); return E_HIP; }
+    if (nA) {
+      u32 *sa12l = nullptr;
+      RC(arena_alloc(c, (size_t)nA + 16, &pt));
+      RC(arena_alloc(c, (size_t)nA + 16, &sa12l));
+      RC(inverse_permute(c, pr, pt, nA, sa12l, DC3HIP_PH_RANKS));
+      constexpr u32 kTup0Tile = SortCfg<Tup0, 256>::NW * 64 * SortCfg<Tup0, 256>::IPT;
+      const Chunking ckc = make_chunks(c, nA, kTup0Tile);
+      u32 *table0 = nullptr;
+      RC(arena_alloc(c, (size_t)256 * ckc.nchunks, &table0));
+      PhaseScope pg(c, DC3HIP_PH_OTHER, nA, 4);
+      hipLaunchKernelGGL(k_gather_tuples, dim3(ckc.nchunks), dim3(kBlock), 0, c->stream, tslot, sa12l, nA, ckc.chunk, ckc.nchunks,
+                         A, table0);
+      KCHECK();
+    }
+    arena_release(c, mkA);
+  }
+  // B: my mod-0 tuples, sorted by (first symbol, rank of the suffix behind it)
+  SelMod0<Sym> sm; sm.S = S; sm.rank12 = rank12; sm.m = m; sm.m0 = m0; sm.me = (u32)me; sm.sp = sp;
+  Tup0 *z0 = nullptr; u32 nB = 0;
+  RC(select_records(c, sm, m0, &z0, &nB, DC3HIP_PH_COMPACT));
+  Tup0G *zs = reinterpret_cast<Tup0G *>(z0);
+  if (nB) {
+    Tup0G *z1 = nullptr;
+    RC(arena_alloc(c, (size_t)nB + 16, &z1));
+    Tup0G *t1 = nullptr;
+    RC(radix_sort<Tup0G>(c, reinterpret_cast<Tup0G *>(z0), z1, nB, 0, bits_of((u64)m02), &t1, DC3HIP_PH_SORT0, DC3HIP_PH_SORT0, DC3HIP_PH_SORT0));
+    Tup0G *other = (t1 == z1) ? reinterpret_cast<Tup0G *>(z0) : z1;
+    RC(radix_sort<Tup0G>(c, t1, other, nB, 32, 32 + bits_of(K - 1), &zs, DC3HIP_PH_SORT0, DC3HIP_PH_SORT0, DC3HIP_PH_SORT0));
+  }
+  // my slice of the level's suffix array
+  const u32 total = nA + nB;
+  uint64_t pre = 0, all = 0;
+  RC(gather_counts(cm, total, &pre, &all));
+  if (all != m) { set_err("global merge: slices hold %llu of %u suffixes", (unsigned long long)all, m); return E_HIP; }
+  if (top) {
+    RC(merge_lists(c, A, nA, reinterpret_cast<const Tup0 *>(zs), nB, c->d_sa, nullptr, 0u));
+    G->shard_first = (int64_t)pre; G->shard_count = total; G->shard_ptr = c->d_sa;
+  } else {
+    u32 *slice = nullptr; Rec8 *pp = nullptr;
+    RC(arena_alloc(c, (size_t)total + 16, &slice));
+    RC(arena_alloc(c, (size_t)total + 16, &pp));
+    RC(merge_lists(c, A, nA, reinterpret_cast<const Tup0 *>(zs), nB, slice, pp, (u32)pre));
+    RC(rank_exchange(G, pp, total, m, out_rank, DC3HIP_PH_RANKS));     // rank[pos] = global index + 1, everywhere
+  }
+  arena_release(c, mk0);
+  return E_OK;
+}
+
+// whole-text order, split by key range: every rank orders the positions whose 9-byte key image falls into its range.
+// *done = all ranks found all their keys distinct -> the concatenation of the slices is the suffix array.
+static int gtext_order(dc3hip_gctx *G, SymU8 S, u32 sigma, bool *done) {
+  dc3hip_ctx *c = G->c; GComm *cm = G->comm;
+  const int P = cm->nranks, me = cm->rank;
+  const u32 n = (u32)G->total_n;
+  *done = false;
+  const u64 Bq = (u64)sigma + 1, B3 = Bq * Bq * Bq;
+  const bool windows_can_be_distinct = 9.0 * log2((double)sigma) >= 2.0 * log2((double)n) + 2.0;
+  if (!(n >= kHybridMinSamples / 4 && !c->no_hybrid && !c->no_fullsort && !c->no_text_shortcut && !G->no_text_order &&
+        windows_can_be_distinct && B3 * B3 * B3 > 0x7fffffffull)) return E_OK;
+  u32 kbits = 0;
+  { unsigned __int128 mx = (unsigned __int128)B3 * B3 * B3 - 1; while (mx) { kbits++; mx >>= 1; } }
+  Key9 km; km.S = S; km.B = (u32)Bq; km.B3 = (u32)B3;
+  const HiMap hm = make_himap(B3, kbits, n, bits_of((u64)n - 1));
+  double pred = 1.0;
+  RC(predict_tie_fraction_pos<Key9>(c, km, n, hm, &pred));
+  c->stats.level_tie_pred[0] = pred;
+  if (!(pred < kTextSortMaxPredicted)) return E_OK;
+  const ArenaMark mk = arena_mark(c);
+  // image splitters from a deterministic sample (every rank computes the same ones)
+  u64 lo = 0, hi = ~0ull;
+  {
+    u32 ns = (u32)std::min<u64>(n, (u64)2048 * P);
+    const u32 stride = std::max<u32>(1, n / ns);
+    ns = (n - 1) / stride + 1;
+    Rec8 *smp = nullptr;
+    RC(arena_alloc(c, (size_t)ns, &smp));
+    std::vector<Rec8> hs(ns);
+    hipLaunchKernelGGL((k_pack_image_pos<Key9>), dim3(grid_for(c, ns)), dim3(kBlock), 0, c->stream, km, ns, stride, hm, smp);
+    KCHECK();
+    HIPC(hipMemcpyAsync(hs.data(), smp, (size_t)ns * sizeof(Rec8), hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    std::vector<u64> img(ns);
+    for (u32 i = 0; i < ns; i++) img[i] = ((((u64)hs[i].key) << 32) | hs[i].val) >> hm.pbits;
+    std::sort(img.begin(), img.end());
+    if (me > 0) lo = img[(size_t)((u64)me * ns / P)];
+    if (me + 1 < P) hi = img[(size_t)((u64)(me + 1) * ns / P)];
+  }
+  SelTextImage sel; sel.km = km; sel.hm = hm; sel.lo = lo; sel.hi = hi; sel.last = (me + 1 == P) ? 1u : 0u;
+  Rec8 *ha = nullptr, *hb = nullptr, *h = nullptr; uint8_t *f = nullptr;
+  u32 nrec = 0;
+  RC(select_records(c, sel, n, &ha, &nrec, DC3HIP_PH_PACK));
+  RC(arena_alloc(c, (size_t)nrec + 16, &hb));
+  RC(arena_alloc(c, (size_t)nrec + 16, &f));
+  bool ok = true, distinct = true;
+  if (nrec) RC((hybrid_sort_core<Key9>(c, km, kbits, hm, ha, hb, nrec, &h, f, &ok, 0, c->d_sa, 0, &distinct, nullptr)));
+  uint64_t good = 0, ngood = 0, pre = 0, tot = 0;
+  RC(gather_counts(cm, (ok && distinct) ? 1 : 0, &good, &ngood));
+  RC(gather_counts(cm, nrec, &pre, &tot));
+  arena_release(c, mk);
+  if (tot != n) { set_err("global text order: %llu of %u positions selected", (unsigned long long)tot, n); return E_HIP; }
+  if (ngood == (uint64_t)P) {
+    *done = true;
+    G->shard_first = (int64_t)pre; G->shard_count = nrec; G->shard_ptr = c->d_sa;
+    c->stats.text_sort_state = 1;
+    c->stats.level_n[0] = n; c->stats.level_K[0] = sigma; c->stats.levels = 1; c->stats.level_sorted[0] = 5;
+  } else {
+    c->stats.text_sort_state = 3;       // some 9-byte window repeats somewhere: the recursion decides
+  }
+  return E_OK;
+}
+
+static int gbuild_inner(dc3hip_gctx *G) {
+  dc3hip_ctx *c = G->c; GComm *cm = G->comm;
+  const int P = cm->nranks, me = cm->rank;
+  const int64_t n = G->total_n;
+  c->n = n;
+  RC(build_begin(c));
+  // 1. the text, replicated: all-gather of the ranks' blocks (n x (P-1)/P bytes in per rank)
+  {
+    size_t roff[kMaxRanks], rbytes[kMaxRanks];
+    for (int r = 0; r < P; r++) { int64_t o, l; block_of(n, P, r, &o, &l); roff[r] = (size_t)o; rbytes[r] = (size_t)l; }
+    RC(cm->all_gather_v(c->d_text + roff[me], rbytes[me], c->d_text, roff, rbytes, c->stream));
+    HIPC(hipMemsetAsync(c->d_text + n, 0, 64, c->stream));
+  }
+  G->gs.local_from_level = -1;
+  if (n <= 2 || P == 1 || (u64)n <= (u64)G->local_max) {
+    if (n >= 1) RC(build_core(c));
+    int64_t off, len; block_of(n, P, me, &off, &len);
+    G->shard_first = off; G->shard_count = len; G->shard_ptr = c->d_sa + off;
+    G->gs.local_from_level = 0;
+  } else {
+    u32 sigma = 0;
+    RC(build_alphabet(c, &sigma));
+    SymU8 S; S.t = c->d_text; S.code = c->d_code; S.m = (u32)n;
+    bool done = false;
+    RC(gtext_order(G, S, sigma, &done));
+    if (!done) RC(glevel<SymU8>(G, S, (u32)n, sigma, 0, nullptr, true));
+  }
+  RC(build_end(c));
+  return E_OK;
+}
+
+static int gbuild(dc3hip_gctx *G) {
+  if (!G || !G->c || !G->comm) { set_err("invalid global context"); return E_ARGS; }
+  if (!G->text_set) { set_err("no text block set in this global context"); return E_ARGS; }
+  G->built = false;
+  GComm *cm = G->comm;
+  cm->comm_ms = 0; cm->bytes_in = cm->bytes_out = 0;
+  memset(&G->gs, 0, sizeof(G->gs));
+  const auto t0 = std::chrono::steady_clock::now();
+  const int rc = gbuild_inner(G);
+  if (rc != E_OK) { snprintf(G->err, sizeof(G->err), "%s", g_err); cm->abort_all(); return rc; }
+  G->gs.struct_size = (int32_t)sizeof(dc3hip_gstats);
+  G->gs.nranks = cm->nranks; G->gs.rank = cm->rank;
+  G->gs.total_n = G->total_n; G->gs.shard_first = G->shard_first; G->gs.shard_count = G->shard_count;
+  G->gs.wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  G->gs.comm_ms = cm->comm_ms; G->gs.comm_bytes_out = (int64_t)cm->bytes_out; G->gs.comm_bytes_in = (int64_t)cm->bytes_in;
+  G->gs.device_ms = G->c->stats.build_ms;
+  G->gs.levels = G->c->stats.levels;
+  G->gs.text_order = G->c->stats.text_sort_state == 1 ? 1 : 0;
+  G->built = true;
+  return E_OK;
+}
+
+static void gctx_env(dc3hip_gctx *G) {
+  if (const char *e = getenv("DC3HIP_GLOBAL_LOCAL_MAX")) { const long long v = atoll(e); if (v >= 0) G->local_max = (u32)std::min<long long>(v, 0x7fffffffll); }
+  if (const char *e = getenv("DC3HIP_GLOBAL_NO_TEXT_ORDER")) G->no_text_order = e[0] == '1';
+}
+
+// ---------------------------------------------------------------------------------------------
+// C ABI of the global mode
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int32_t dc3hip_global_loopback_create(dc3hip_gctx **ranks, int32_t P, int32_t device, int64_t max_total_n) {
+  if (!ranks || P < 1 || P > kMaxRanks || max_total_n < 0) { set_err("dc3hip_global_loopback_create: invalid arguments (1 <= P <= %d)", kMaxRanks); return E_ARGS; }
+  for (int r = 0; r < P; r++) ranks[r] = nullptr;
+  auto world = std::make_shared<LoopWorld>(P);
+  std::vector<dc3hip_gctx *> made;
+  for (int r = 0; r < P; r++) {
+    dc3hip_gctx *G = new (std::nothrow) dc3hip_gctx();
+    if (!G) { set_err("host allocation failed"); for (auto *g : made) dc3hip_global_destroy(g); return E_ALLOC; }
+    made.push_back(G);
+    const int rc = dc3hip_ctx_create(&G->c, device, max_total_n);
+    if (rc != E_OK) { for (auto *g : made) dc3hip_global_destroy(g); return rc; }
+    LoopComm *lc = new LoopComm(); lc->rank = r; lc->nranks = P; lc->w = world;
+    G->comm = lc; G->max_total = max_total_n;
+    gctx_env(G);
+  }
+  for (int r = 0; r < P; r++) { ranks[r] = made[(size_t)r]; made[(size_t)r]->group = made; }
+  return E_OK;
+}
+
+int32_t dc3hip_rccl_unique_id(uint8_t *id128) {
+  if (!id128) { set_err("id is NULL"); return E_ARGS; }
+  std::lock_guard<std::mutex> lk(g_rccl_mu);
+  if (!g_rccl.load()) return E_HIP;
+  ncclUniqueId id;
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  NCCLC(g_rccl.GetUniqueId(&id));
+  memcpy(id128, &id, 128);
+  return E_OK;
+}
+
+int32_t dc3hip_global_rccl_create(dc3hip_gctx **out, const uint8_t *id128, int32_t rank, int32_t nranks, int32_t device,
+                                  int64_t max_total_n) {
+  if (!out || !id128 || nranks < 1 || nranks > kMaxRanks || rank < 0 || rank >= nranks || max_total_n < 0) {
+    set_err("dc3hip_global_rccl_create: invalid arguments (1 <= nranks <= %d)", kMaxRanks); return E_ARGS;
+  }
+  *out = nullptr;
+  { std::lock_guard<std::mutex> lk(g_rccl_mu); if (!g_rccl.load()) return E_HIP; }
+  dc3hip_gctx *G = new (std::nothrow) dc3hip_gctx();
+  if (!G) { set_err("host allocation failed"); return E_ALLOC; }
+  int rc = dc3hip_ctx_create(&G->c, device, max_total_n);
+  if (rc != E_OK) { dc3hip_global_destroy(G); return rc; }
+  RcclComm *rcm = new RcclComm(); rcm->rank = rank; rcm->nranks = nranks;
+  G->comm = rcm; G->max_total = max_total_n;
+  rc = [&]() -> int {
+    HIPC(hipSetDevice(G->c->device));
+    HIPC(hipMalloc(&rcm->d_small, RcclComm::kSmall * (size_t)(nranks + 1)));
+    ncclUniqueId id; memcpy(&id, id128, 128);
+    NCCLC(g_rccl.CommInitRank(&rcm->comm, nranks, id, rank));
+    return E_OK;
+  }();
+  if (rc != E_OK) { dc3hip_global_destroy(G); return rc; }
+  gctx_env(G);
+  *out = G;
+  return E_OK;
+}
+
+void dc3hip_global_destroy(dc3hip_gctx *G) {
+  if (!G) return;
+  if (G->c) { (void)hipSetDevice(G->c->device); if (G->c->stream) (void)hipStreamSynchronize(G->c->stream); }
+  delete G->comm;
+  if (G->c) dc3hip_ctx_destroy(G->c);
+  delete G;
+}
+
+static int gctx_set_total(dc3hip_gctx *G, int64_t total_n, int64_t *off, int64_t *len) {
+  if (!G || total_n < 0) { set_err("invalid arguments"); return E_ARGS; }
+  if (total_n > G->max_total) { set_err("n=%lld exceeds the context capacity %lld", (long long)total_n, (long long)G->max_total); return E_ARGS; }
+  block_of(total_n, G->comm->nranks, G->comm->rank, off, len);
+  G->total_n = total_n; G->built = false;
+  return E_OK;
+}
+
+int32_t dc3hip_global_block(dc3hip_gctx *G, int64_t total_n, int64_t *offset, int64_t *length) {
+  if (!G || !offset || !length || total_n < 0) { set_err("invalid arguments"); return E_ARGS; }
+  block_of(total_n, G->comm->nranks, G->comm->rank, offset, length);
+  return E_OK;
+}
+
+int32_t dc3hip_global_set_text_block(dc3hip_gctx *G, const uint8_t *block, int64_t total_n) {
+  int64_t off, len;
+  RC(gctx_set_total(G, total_n, &off, &len));
+  if (!block && len > 0) { set_err("block is NULL"); return E_ARGS; }
+  dc3hip_ctx *c = G->c;
+  HIPC(hipSetDevice(c->device));
+  if (len > 0) HIPC(hipMemcpyAsync(c->d_text + off, block, (size_t)len, hipMemcpyDefault, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  G->text_set = true;
+  return E_OK;
+}
+
+int32_t dc3hip_global_generate(dc3hip_gctx *G, int64_t total_n, uint64_t seed, int32_t kind) {
+  int64_t off, len;
+  RC(gctx_set_total(G, total_n, &off, &len));
+  if (kind < 0 || kind > 2) { set_err("unknown generator kind %d", kind); return E_ARGS; }
+  dc3hip_ctx *c = G->c;
+  HIPC(hipSetDevice(c->device));
+  if (len > 0) {
+    // only this rank's block: the others arrive by the all-gather of the build
+    hipLaunchKernelGGL(k_generate, dim3(grid_for(c, (u64)len / 8 + 1)), dim3(kBlock), 0, c->stream, c->d_text + off, (u64)len,
+                       (u64)seed, (int)kind, (u64)off);
+    KCHECK();
+  }
+  HIPC(hipStreamSynchronize(c->stream));
+  G->text_set = true;
+  return E_OK;
+}
+
+int32_t dc3hip_global_build(dc3hip_gctx *G) { return gbuild(G); }
+
+// loopback convenience: run the P ranks of a group on P host threads and wait for all of them
+int32_t dc3hip_global_loopback_build(dc3hip_gctx **ranks, int32_t P) {
+  if (!ranks || P < 1 || P > kMaxRanks) { set_err("invalid arguments"); return E_ARGS; }
+  for (int r = 0; r < P; r++) if (!ranks[r] || ranks[r]->comm->nranks != P) { set_err("not a loopback group of %d ranks", P); return E_ARGS; }
+  std::vector<int> rcs((size_t)P, E_OK);
+  std::vector<std::thread> pool;
+  for (int r = 0; r < P; r++) pool.emplace_back([&, r]() { rcs[(size_t)r] = gbuild(ranks[r]); });
+  for (auto &t : pool) t.join();
+  for (int r = 0; r < P; r++)
+    if (rcs[(size_t)r] != E_OK && strstr(ranks[r]->err, "another rank failed") == nullptr) { set_err("rank %d: %s", r, ranks[r]->err); return rcs[(size_t)r]; }
+  for (int r = 0; r < P; r++) if (rcs[(size_t)r] != E_OK) { set_err("rank %d: %s", r, ranks[r]->err); return rcs[(size_t)r]; }
+  return E_OK;
+}
+
+int32_t dc3hip_global_shard(dc3hip_gctx *G, int64_t *first, int64_t *count) {
+  if (!G || !first || !count) { set_err("invalid arguments"); return E_ARGS; }
+  if (!G->built) { set_err("no suffix array built in this global context"); return E_ARGS; }
+  *first = G->shard_first; *count = G->shard_count;
+  return E_OK;
+}
+
+int32_t dc3hip_global_get_shard_i64(dc3hip_gctx *G, int64_t *out) {
+  if (!G || (!out && G->shard_count > 0)) { set_err("invalid arguments"); return E_ARGS; }
+  if (!G->built) { set_err("no suffix array built in this global context"); return E_ARGS; }
+  dc3hip_ctx *c = G->c;
+  HIPC(hipSetDevice(c->device));
+  if (G->shard_count == 0) return E_OK;
+  c->arena_off = 0;
+  const size_t piece = std::min<size_t>((size_t)G->shard_count, std::max<size_t>(c->arena_bytes / 8, 1));
+  int64_t *tmp = reinterpret_cast<int64_t *>(c->arena);
+  for (size_t off = 0; off < (size_t)G->shard_count; off += piece) {
+    const size_t cnt = std::min(piece, (size_t)G->shard_count - off);
+    hipLaunchKernelGGL(k_widen_off, dim3(grid_for(c, cnt)), dim3(kBlock), 0, c->stream, G->shard_ptr + off, tmp, (u32)cnt);
+    KCHECK();
+    HIPC(hipMemcpyAsync(out + off, tmp, cnt * 8, hipMemcpyDefault, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+  }
+  return E_OK;
+}
+
+int32_t dc3hip_global_get_shard_u32(dc3hip_gctx *G, uint32_t *out) {
+  if (!G || (!out && G->shard_count > 0)) { set_err("invalid arguments"); return E_ARGS; }
+  if (!G->built) { set_err("no suffix array built in this global context"); return E_ARGS; }
+  dc3hip_ctx *c = G->c;
+  HIPC(hipSetDevice(c->device));
+  if (G->shard_count > 0) HIPC(hipMemcpyAsync(out, G->shard_ptr, (size_t)G->shard_count * 4, hipMemcpyDefault, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  return E_OK;
+}
+
+// order-sensitive checksum of this rank's shard with GLOBAL indices: the sum over all ranks equals
+// dc3hip_ctx_sa_checksum of a single-device build of the same text
+int32_t dc3hip_global_shard_checksum(dc3hip_gctx *G, uint64_t *out) {
+  if (!G || !out) { set_err("invalid arguments"); return E_ARGS; }
+  if (!G->built) { set_err("no suffix array built in this global context"); return E_ARGS; }
+  dc3hip_ctx *c = G->c;
+  HIPC(hipSetDevice(c->device));
+  u64 *acc = reinterpret_cast<u64 *>(c->d_words + 16);
+  HIPC(hipMemsetAsync(acc, 0, sizeof(u64), c->stream));
+  if (G->shard_count > 0) {
+    hipLaunchKernelGGL(k_checksum_off, dim3(grid_for(c, G->shard_count)), dim3(kBlock), 0, c->stream, G->shard_ptr,
+                       (u32)G->shard_count, (u64)G->shard_first, acc);
+    KCHECK();
+  }
+  HIPC(hipMemcpyAsync(c->h_words + 16, acc, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  memcpy(out, c->h_words + 16, sizeof(u64));
+  return E_OK;
+}
+
+int32_t dc3hip_global_stats(dc3hip_gctx *G, dc3hip_gstats *out, dc3hip_stats *ctx_stats) {
+  if (!G || !out) { set_err("invalid arguments"); return E_ARGS; }
+  *out = G->gs;
+  out->struct_size = (int32_t)sizeof(dc3hip_gstats);
+  if (ctx_stats) { *ctx_stats = G->c->stats; ctx_stats->struct_size = (int32_t)sizeof(dc3hip_stats); }
+  return E_OK;
+}
+
+const char *dc3hip_global_last_error(dc3hip_gctx *G) { return G ? G->err : ""; }
+const char *dc3hip_global_transport(dc3hip_gctx *G) { return (G && G->comm) ? G->comm->name() : ""; }
+
+}  // extern "C"

@@ -15,3 +15,4 @@
 #include "dc3_order.hip.hpp"
 #include "dc3_merge.hip.hpp"
 #include "dc3_aux.hip.hpp"
+#include "dc3_global.hip.hpp"

@@ -146,7 +146,7 @@ struct MergeSmem { static constexpr size_t kBytes = (16 + 16 + 4) * (size_t)(NT 
 template <int NT, int VT>
 __global__ __launch_bounds__(NT) void k_merge(const Tup12 *__restrict__ A, u32 nA, const Tup0 *__restrict__ B, u32 nB,
                                              const u32 *__restrict__ part, u32 *__restrict__ out_sa,
-                                             Rec8 *__restrict__ out_pairs) {
+                                             Rec8 *__restrict__ out_pairs, u32 rank_base) {
   constexpr u32 kTile = NT * VT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u32x4 *sa = reinterpret_cast<u32x4 *>(smem);
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(NT) void k_merge(const Tup12 *__restrict__ A, u32 n
   for (u32 q = threadIdx.x; q < nout; q += NT) {
     const u32 pos = so[q];
     if (out_sa) out_sa[d0 + q] = pos;
-    if (out_pairs) out_pairs[d0 + q] = Rec8{pos, d0 + q + 1};
+    if (out_pairs) out_pairs[d0 + q] = Rec8{pos, rank_base + d0 + q + 1};   // rank_base: ranks of a slice of the merge (global mode)
   }
 }
 

@@ -184,7 +184,10 @@ template <> struct SortCfg<Rec16, 256> { static constexpr int IPT = 8, NW = 16; 
 template <> struct SortCfg<Rec16, 512> { static constexpr int IPT = 7, NW = 16; static constexpr bool PF = false; };
 template <> struct SortCfg<Tup0, 256>  { static constexpr int IPT = 6, NW = 16; static constexpr bool PF = false; };
 template <> struct SortCfg<Tup0, 512>  { static constexpr int IPT = 6, NW = 16; static constexpr bool PF = false; };
+template <> struct SortCfg<Tup0G, 256> { static constexpr int IPT = 6, NW = 16; static constexpr bool PF = false; };
+template <> struct SortCfg<Tup0G, 512> { static constexpr int IPT = 6, NW = 16; static constexpr bool PF = false; };
 template <class Rec> struct RecClass;      // index into dc3hip_stats.downsweep_*
+template <> struct RecClass<Tup0G> { static constexpr int k = 2; };
 template <> struct RecClass<Rec8>  { static constexpr int k = 0; };
 template <> struct RecClass<Rec12> { static constexpr int k = 1; };
 template <> struct RecClass<Rec16> { static constexpr int k = 1; };
@@ -679,6 +682,10 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
     general = tied > 0;
   }
   if (general) {
+    // the tied subset is re-sorted as 16-byte records (2 x 16 B + index + radix tables): when the arena cannot hold
+    // that on top of what the caller holds, give the ordering up (*ok stays false -> the caller's next ordering
+    // runs instead); arena_requirement() only bounds the straight ordering
+    if (c->arena_bytes - c->arena_off < (size_t)tied * 36 + (32u << 20)) return E_OK;
     Rec16 *sa = nullptr, *sb = nullptr, *ss = nullptr;
     u32 *tiedidx = nullptr;
     RC(arena_alloc(c, (size_t)tied, &sa));
@@ -871,11 +878,51 @@ static int order_all_positions(dc3hip_ctx *c, KM km, Map mp, u32 m, u32 kbits, c
 
 template <int NT, int VT>
 static int launch_merge(dc3hip_ctx *c, u32 ntiles, const Tup12 *A, u32 nA, const Tup0 *B, u32 nB, const u32 *part,
-                        u32 *out_sa, Rec8 *out_pairs) {
+                        u32 *out_sa, Rec8 *out_pairs, u32 rank_base = 0) {
   auto kern = k_merge<NT, VT>;
   const size_t smem = MergeSmem<NT, VT>::kBytes;
   HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  hipLaunchKernelGGL(kern, dim3(ntiles), dim3(NT), smem, c->stream, A, nA, B, nB, part, out_sa, out_pairs);
+  hipLaunchKernelGGL(kern, dim3(ntiles), dim3(NT), smem, c->stream, A, nA, B, nB, part, out_sa, out_pairs, rank_base);
+  return E_OK;
+}
+
+// Step 3 (lib.rs:131-192): merge-path merge of the sorted sample tuples A and the sorted mod-0 tuples B into
+// out_sa[0 .. nA+nB) (and, when out_pairs != nullptr, the (pos, rank_base + k + 1) pairs of the rank inversion).
+static int merge_lists(dc3hip_ctx *c, const Tup12 *A, u32 nA, const Tup0 *B, u32 nB, u32 *out_sa, Rec8 *out_pairs,
+                       u32 rank_base) {
+  const u32 total = nA + nB;
+  if (total == 0) return E_OK;
+  const int cfg = c->merge_cfg;
+  const u32 tile = cfg == 0 ? 256u * 4 : cfg == 1 ? 512u * 2 : cfg == 2 ? 512u * 4 : cfg == 3 ? 1024u * 2 : cfg == 4 ? 128u * 4 : cfg == 5 ? 1024u * 4 : 256u * 2;
+  const u32 ntiles = (total + tile - 1) / tile;
+  const ArenaMark mk = arena_mark(c);
+  u32 *part = nullptr;
+  RC(arena_alloc(c, (size_t)ntiles + 16, &part));
+  {
+    PhaseScope ps(c, DC3HIP_PH_MERGE, total);
+    // coarse split of every 16th tile boundary first, then the bounded per-tile searches
+    constexpr u32 kRatio = 16;
+    const u32 nco = (ntiles + kRatio - 1) / kRatio;              // coarse tiles of kRatio*tile outputs
+    u32 *coarse = nullptr;
+    RC(arena_alloc(c, (size_t)nco + 16, &coarse));
+    hipLaunchKernelGGL(k_merge_partition, dim3((nco + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, A, nA, B, nB,
+                       nco, tile * kRatio, (const u32 *)nullptr, 1u, coarse);
+    KCHECK();
+    hipLaunchKernelGGL(k_merge_partition, dim3((ntiles + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, A, nA, B, nB,
+                       ntiles, tile, (const u32 *)coarse, kRatio, part);
+    KCHECK();
+    switch (cfg) {
+      case 0: RC((launch_merge<256, 4>(c, ntiles, A, nA, B, nB, part, out_sa, out_pairs, rank_base))); break;
+      case 1: RC((launch_merge<512, 2>(c, ntiles, A, nA, B, nB, part, out_sa, out_pairs, rank_base))); break;
+      case 2: RC((launch_merge<512, 4>(c, ntiles, A, nA, B, nB, part, out_sa, out_pairs, rank_base))); break;
+      case 3: RC((launch_merge<1024, 2>(c, ntiles, A, nA, B, nB, part, out_sa, out_pairs, rank_base))); break;
+      case 4: RC((launch_merge<128, 4>(c, ntiles, A, nA, B, nB, part, out_sa, out_pairs, rank_base))); break;
+      case 5: RC((launch_merge<1024, 4>(c, ntiles, A, nA, B, nB, part, out_sa, out_pairs, rank_base))); break;
+      default: RC((launch_merge<256, 2>(c, ntiles, A, nA, B, nB, part, out_sa, out_pairs, rank_base))); break;
+    }
+    KCHECK();
+  }
+  arena_release(c, mk);
   return E_OK;
 }
 
@@ -943,7 +990,9 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
       double pred = 1.0;
       RC(predict_tie_fraction<Sym>(c, S, m, m0, m02, b, make_himap(B, kbits, m), &pred));
       c->stats.level_tie_pred[depth] = pred;
-      if (pred < kFullSortMaxPredicted && !c->no_fullsort) {
+      // (the whole-level order holds 17 B per position + the filtered samples; skipped when the arena is short)
+      if (pred < kFullSortMaxPredicted && !c->no_fullsort &&
+          c->arena_bytes - c->arena_off >= (size_t)(m + 1) * 17 + (size_t)m02 * 8 + (64u << 20)) {
         // high entropy: try to finish the whole level by sorting all of its positions
         u32 *spos = nullptr, *snf = nullptr;
         RC(arena_alloc(c, (size_t)m02 + 16, &spos));
@@ -1032,41 +1081,12 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
   RC(radix_sort<Tup0>(c, z0, z1, m0, 8, bits_of(K - 1), &zs, DC3HIP_PH_SORT0, DC3HIP_PH_SORT0, DC3HIP_PH_SORT0));
   {
     const u32 dskip = m0 - m1;                  // lib.rs:133: skip the dummy, which sorts first
-    const u32 nA = m02 - dskip, nB = m0;
-    const int cfg = c->merge_cfg;
-    const u32 tile = cfg == 0 ? 256u * 4 : cfg == 1 ? 512u * 2 : cfg == 2 ? 512u * 4 : cfg == 3 ? 1024u * 2 : cfg == 4 ? 128u * 4 : cfg == 5 ? 1024u * 4 : 256u * 2;
-    const u32 ntiles = (m + tile - 1) / tile;
-    u32 *part = nullptr;
-    RC(arena_alloc(c, (size_t)ntiles + 16, &part));
     Rec8 *pa = nullptr, *pb = nullptr;
     if (out_rank) {
       RC(arena_alloc(c, (size_t)m, &pa));
       RC(arena_alloc(c, (size_t)m, &pb));
     }
-    {
-      PhaseScope ps(c, DC3HIP_PH_MERGE, m);
-      // coarse split of every 16th tile boundary first, then the bounded per-tile searches
-      constexpr u32 kRatio = 16;
-      const u32 nco = (ntiles + kRatio - 1) / kRatio;              // coarse tiles of kRatio*tile outputs
-      u32 *coarse = nullptr;
-      RC(arena_alloc(c, (size_t)nco + 16, &coarse));
-      hipLaunchKernelGGL(k_merge_partition, dim3((nco + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
-                         t12 + dskip, nA, zs, nB, nco, tile * kRatio, (const u32 *)nullptr, 1u, coarse);
-      KCHECK();
-      hipLaunchKernelGGL(k_merge_partition, dim3((ntiles + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
-                         t12 + dskip, nA, zs, nB, ntiles, tile, (const u32 *)coarse, kRatio, part);
-      KCHECK();
-      switch (cfg) {
-        case 0: RC((launch_merge<256, 4>(c, ntiles, t12 + dskip, nA, zs, nB, part, out_sa, pa))); break;
-        case 1: RC((launch_merge<512, 2>(c, ntiles, t12 + dskip, nA, zs, nB, part, out_sa, pa))); break;
-        case 2: RC((launch_merge<512, 4>(c, ntiles, t12 + dskip, nA, zs, nB, part, out_sa, pa))); break;
-        case 3: RC((launch_merge<1024, 2>(c, ntiles, t12 + dskip, nA, zs, nB, part, out_sa, pa))); break;
-        case 4: RC((launch_merge<128, 4>(c, ntiles, t12 + dskip, nA, zs, nB, part, out_sa, pa))); break;
-        case 5: RC((launch_merge<1024, 4>(c, ntiles, t12 + dskip, nA, zs, nB, part, out_sa, pa))); break;
-        default: RC((launch_merge<256, 2>(c, ntiles, t12 + dskip, nA, zs, nB, part, out_sa, pa))); break;
-      }
-      KCHECK();
-    }
+    RC(merge_lists(c, t12 + dskip, m02 - dskip, zs, m0, out_sa, pa, 0u));
     if (out_rank) RC(inverse_permute(c, pa, pb, m, out_rank, DC3HIP_PH_RANKS));
   }
   arena_release(c, mk0);
@@ -1076,34 +1096,74 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
 // ---------------------------------------------------------------------------------------------
 // build: level 0 = bytes through the dense code table
 // ---------------------------------------------------------------------------------------------
-static int ctx_build(dc3hip_ctx *c) {
-  const int64_t n = c->n;
+// prologue / epilogue shared by the single-device build and the global (multi-rank) build
+static int build_begin(dc3hip_ctx *c) {
   c->built = false;
   c->arena_off = 0; c->arena_peak = 0;
   c->ev_used = 0; c->marks.clear();
   memset(&c->stats, 0, sizeof(c->stats));
   c->stats.struct_size = (int32_t)sizeof(dc3hip_stats);
   c->stats.arena_bytes = (int64_t)c->arena_bytes;
-  if (n < 0) return E_ARGS;
+  if (c->n < 0) return E_ARGS;
   HIPC(hipSetDevice(c->device));
   if (c->profile) HIPC(hipEventRecord(c->ev_build_a, c->stream));
+  return E_OK;
+}
+static int build_end(dc3hip_ctx *c) {
+  if (c->profile) HIPC(hipEventRecord(c->ev_build_b, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  c->stats.arena_peak = (int64_t)c->arena_peak;
+  if (c->profile) {
+    float ms = 0;
+    HIPC(hipEventElapsedTime(&ms, c->ev_build_a, c->ev_build_b));
+    c->stats.build_ms = ms;
+    for (const PhaseMark &m : c->marks) {
+      float t = 0;
+      if (hipEventElapsedTime(&t, m.a, m.b) != hipSuccess) continue;
+      if (m.kclass != 4) {   // class 4 is nested inside the TUPLES phase mark
+        c->stats.phase_ms[m.phase] += t;
+        c->stats.phase_launches[m.phase] += 1;
+      }
+      if (m.kclass == 4) { c->stats.gather_ms += t; c->stats.gather_launches += 1; c->stats.gather_elems += m.elems; continue; }
+      if (m.kclass == 3) { c->stats.partition_ms += t; c->stats.partition_launches += 1; c->stats.partition_elems += m.elems; }
+      if (m.kclass >= 0 && m.kclass < 3) {
+        c->stats.downsweep_ms[m.kclass] += t; c->stats.downsweep_launches[m.kclass] += 1;
+        c->stats.downsweep_elems[m.kclass] += m.elems;
+      }
+    }
+  }
+  c->built = true;
+  c->sa_trusted = true;
+  return E_OK;
+}
+// level-0 alphabet: dense order-preserving codes 1..sigma of the bytes that occur
+static int build_alphabet(dc3hip_ctx *c, u32 *sigma_out) {
+  const int64_t n = c->n;
+  {
+    PhaseScope ps(c, DC3HIP_PH_ALPHABET, n);
+    HIPC(hipMemsetAsync(c->d_present, 0, 256 * sizeof(u32), c->stream));
+    hipLaunchKernelGGL(k_byte_presence, dim3(grid_for(c, (u64)n / 16 + 1)), dim3(kBlock), 0, c->stream, c->d_text,
+                       (u32)n, c->d_present);
+    KCHECK();
+    hipLaunchKernelGGL(k_make_codes, dim3(1), dim3(kBlock), 0, c->stream, c->d_present, c->d_code, c->d_words + 1);
+    KCHECK();
+    HIPC(hipMemcpyAsync(c->h_words + 1, c->d_words + 1, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPC(hipStreamSynchronize(c->stream));
+  const u32 sigma = c->h_words[1];
+  if (sigma < 1 || sigma > 256) { set_err("internal: alphabet size %u", sigma); return E_HIP; }
+  *sigma_out = sigma;
+  return E_OK;
+}
+
+// the device-resident build proper: SA of c->d_text[0..n) into c->d_sa
+static int build_core(dc3hip_ctx *c) {
+  const int64_t n = c->n;
   if (n == 1) {
     HIPC(hipMemsetAsync(c->d_sa, 0, 4, c->stream));
   } else if (n >= 2) {
     u32 sigma = 0;
-    {
-      PhaseScope ps(c, DC3HIP_PH_ALPHABET, n);
-      HIPC(hipMemsetAsync(c->d_present, 0, 256 * sizeof(u32), c->stream));
-      hipLaunchKernelGGL(k_byte_presence, dim3(grid_for(c, (u64)n / 16 + 1)), dim3(kBlock), 0, c->stream, c->d_text,
-                         (u32)n, c->d_present);
-      KCHECK();
-      hipLaunchKernelGGL(k_make_codes, dim3(1), dim3(kBlock), 0, c->stream, c->d_present, c->d_code, c->d_words + 1);
-      KCHECK();
-      HIPC(hipMemcpyAsync(c->h_words + 1, c->d_words + 1, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
-    }
-    HIPC(hipStreamSynchronize(c->stream));
-    sigma = c->h_words[1];
-    if (sigma < 1 || sigma > 256) { set_err("internal: alphabet size %u", sigma); return E_HIP; }
+    RC(build_alphabet(c, &sigma));
     SymU8 S; S.t = c->d_text; S.code = c->d_code; S.m = (u32)n;
     bool whole_text = false;
     Presort pre{nullptr, nullptr};
@@ -1145,31 +1205,13 @@ static int ctx_build(dc3hip_ctx *c) {
     }
     if (!whole_text) RC(dc3_level<SymU8>(c, S, (u32)n, sigma, c->d_sa, nullptr, 0, pre.spos ? &pre : nullptr));
   }
-  if (c->profile) HIPC(hipEventRecord(c->ev_build_b, c->stream));
-  HIPC(hipStreamSynchronize(c->stream));
-  c->stats.arena_peak = (int64_t)c->arena_peak;
-  if (c->profile) {
-    float ms = 0;
-    HIPC(hipEventElapsedTime(&ms, c->ev_build_a, c->ev_build_b));
-    c->stats.build_ms = ms;
-    for (const PhaseMark &m : c->marks) {
-      float t = 0;
-      if (hipEventElapsedTime(&t, m.a, m.b) != hipSuccess) continue;
-      if (m.kclass != 4) {   // class 4 is nested inside the TUPLES phase mark
-        c->stats.phase_ms[m.phase] += t;
-        c->stats.phase_launches[m.phase] += 1;
-      }
-      if (m.kclass == 4) { c->stats.gather_ms += t; c->stats.gather_launches += 1; c->stats.gather_elems += m.elems; continue; }
-      if (m.kclass == 3) { c->stats.partition_ms += t; c->stats.partition_launches += 1; c->stats.partition_elems += m.elems; }
-      if (m.kclass >= 0 && m.kclass < 3) {
-        c->stats.downsweep_ms[m.kclass] += t; c->stats.downsweep_launches[m.kclass] += 1;
-        c->stats.downsweep_elems[m.kclass] += m.elems;
-      }
-    }
-  }
-  c->built = true;
-  c->sa_trusted = true;
   return E_OK;
+}
+
+static int ctx_build(dc3hip_ctx *c) {
+  RC(build_begin(c));
+  RC(build_core(c));
+  return build_end(c);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1366,6 +1408,17 @@ static int ctx_sufcheck(dc3hip_ctx *c, const u32 *d_sa, int *code) {
   return E_OK;
 }
 
+// By-products read T[SA[i]..] without range checks: an array handed in by dc3hip_ctx_set_sa_i32 is verified once
+// (full sufcheck) before the first by-product call and refused if it is not the suffix array of the resident text.
+static int ensure_trusted_sa(dc3hip_ctx *c) {
+  if (c->sa_trusted || c->n == 0) return E_OK;
+  int code = 0;
+  RC(ctx_sufcheck(c, c->d_sa, &code));
+  if (code != 0) { set_err("the resident array (dc3hip_ctx_set_sa_i32) is not the suffix array of the text: sufcheck %d", code); return E_ARGS; }
+  c->sa_trusted = true;
+  return E_OK;
+}
+
 int32_t dc3hip_ctx_sufcheck(dc3hip_ctx *c) {
   if (!c) { set_err("ctx is NULL"); return E_ARGS; }
   if (!c->built) { set_err("no suffix array built in this context"); return E_ARGS; }
@@ -1449,6 +1502,7 @@ int32_t dc3hip_ctx_bwt(dc3hip_ctx *c, uint8_t *U, int64_t *primary_index) {
   if (!c->built) { set_err("no suffix array built in this context"); return E_ARGS; }
   const int64_t n = c->n;
   HIPC(hipSetDevice(c->device));
+  RC(ensure_trusted_sa(c));
   if (n <= 1) {                                                                                    // utils.c:61-65
     if (n == 1) HIPC(hipMemcpy(U, c->d_text, 1, hipMemcpyDefault));
     *primary_index = n;
@@ -1458,6 +1512,7 @@ int32_t dc3hip_ctx_bwt(dc3hip_ctx *c, uint8_t *U, int64_t *primary_index) {
   uint8_t *du = nullptr;
   RC(arena_alloc(c, (size_t)n + 16, &du));
   u32 *z = c->d_words + 24;
+  HIPC(hipMemsetAsync(z, 0xff, sizeof(u32), c->stream));            // sentinel: "no entry is 0"
   hipLaunchKernelGGL(k_find_zero, dim3(grid_for(c, n)), dim3(kBlock), 0, c->stream, c->d_sa, (u32)n, z);
   KCHECK();
   hipLaunchKernelGGL(k_bwt, dim3(grid_for(c, n)), dim3(kBlock), 0, c->stream, c->d_text, c->d_sa, (u32)n, z, du);
@@ -1465,6 +1520,7 @@ int32_t dc3hip_ctx_bwt(dc3hip_ctx *c, uint8_t *U, int64_t *primary_index) {
   HIPC(hipMemcpyAsync(c->h_words + 24, z, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
   HIPC(hipMemcpyAsync(U, du, (size_t)n, hipMemcpyDefault, c->stream));
   HIPC(hipStreamSynchronize(c->stream));
+  if (c->h_words[24] == 0xffffffffu) { set_err("internal: the suffix array holds no entry 0"); return E_HIP; }
   *primary_index = (int64_t)c->h_words[24] + 1;                                                    // utils.c:97
   c->arena_off = 0;
   return E_OK;
@@ -1479,8 +1535,11 @@ int32_t dc3hip_ctx_search(dc3hip_ctx *c, const uint8_t *needles, const int64_t *
   if (c->n == 0) { set_err("empty suffix array (the reference indexes out of bounds here)"); return E_ARGS; }
   if (count == 0) return E_OK;
   HIPC(hipSetDevice(c->device));
+  // offsets is a HOST array of count+1 non-decreasing byte offsets into needles, offsets[0] >= 0
+  for (int32_t k = 0; k < count; k++)
+    if (offsets[k] < 0 || offsets[k + 1] < offsets[k]) { set_err("invalid needle offsets (must be non-negative and non-decreasing)"); return E_ARGS; }
   const int64_t total = offsets[count];
-  if (total < 0) { set_err("invalid needle offsets"); return E_ARGS; }
+  RC(ensure_trusted_sa(c));
   c->arena_off = 0;
   uint8_t *dn = nullptr; int64_t *doff = nullptr, *ds = nullptr, *dl = nullptr;
   RC(arena_alloc(c, (size_t)total + 16, &dn));
@@ -1540,7 +1599,10 @@ static int acquire_ctx(dc3hip_ctx **out, int device, int64_t n, bool *cached) {
     int dev = device;
     if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = -1;
     dc3hip_ctx *cc = g_cache.c;
-    if (cc && dev >= 0 && cc->device == dev && cc->max_n >= n) { *out = cc; *cached = true; return E_OK; }
+    // reuse when it fits, unless the cached arena is far larger than this call needs (a context for 1 GiB holds
+    // ~50 GB of HBM: do not pin that for a thread that has moved on to small texts)
+    const bool oversized = cc && cc->max_n > 4 * std::max<int64_t>(n, 1) && cc->arena_bytes > ((size_t)4 << 30);
+    if (cc && dev >= 0 && cc->device == dev && cc->max_n >= n && !oversized) { *out = cc; *cached = true; return E_OK; }
     if (cc) { dc3hip_ctx_destroy(cc); g_cache.c = nullptr; }
     RC(dc3hip_ctx_create(out, device, n));
     g_cache.c = *out; *cached = true;
@@ -1681,3 +1743,5 @@ int32_t dc3hip_sufcheck_i32(const uint8_t *T, const int32_t *SA, int32_t n) {
 }
 
 }  // extern "C"
+
+#include "dc3_global_host.hpp"

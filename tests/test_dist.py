@@ -1,7 +1,8 @@
-"""CPU-only, world_size 2 over gloo: the N>1 path of bench.py — sacapart chunk ownership per rank
-(no data-path collective), position-addressable generator, max-over-ranks timing reduce.  The SA of
-each chunk is computed by the ORACLE here (no GPU on this machine); on the GPU box the same
-arithmetic feeds dc3hip contexts."""
+"""world_size 2 over gloo: the N>1 path of bench.py — sacapart chunk ownership per rank (no data-path
+collective), position-addressable generator, max-over-ranks timing reduce.  Without a GPU (this
+container) the ranks compute their chunk's SA with the ORACLE, so only the host logic is under test; the
+`-m gpu` variant runs the same two processes with the PRODUCT (libdc3hip through the C ABI, both ranks on
+GPU 0) and the parent compares every chunk with the oracle."""
 import os
 import socket
 import sys
@@ -19,7 +20,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, total_len, seed, q):
+def _worker(rank, world, port, total_len, seed, q, use_product=False):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -30,7 +31,12 @@ def _worker(rank, world, port, total_len, seed, q):
     # each rank generates ONLY its chunk of the global stream (offset-addressable generator)
     full = o.gen(total_len, seed, 0)
     chunk = full[off:off + n]
-    sa = o.sufsort(chunk)
+    if use_product:
+        import stringsearch_amd as ss
+        assert ss.device_count() >= 1, "product variant needs a device (no CPU fallback)"
+        sa = ss.sort(chunk).into_parts()[1]
+    else:
+        sa = o.sufsort(chunk)
     # whole-job time = max over ranks
     t = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -41,17 +47,27 @@ def _worker(rank, world, port, total_len, seed, q):
     dist.destroy_process_group()
 
 
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_two_rank_sacapart_gloo_product(oracle):
+    _two_rank(oracle, True)
+
+
 @pytest.mark.timeout(120)
 def test_two_rank_sacapart_gloo(oracle):
+    _two_rank(oracle, False)
+
+
+def _two_rank(oracle, use_product):
     import stringsearch_amd as ss
     from stringsearch_amd.partition import chunk_bounds
     world, total_len, seed = 2, 20001, 6
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, total_len, seed, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total_len, seed, q, use_product)) for r in range(world)]
     [p.start() for p in procs]
-    res = sorted(q.get(timeout=100) for _ in range(world))
+    res = sorted(q.get(timeout=250 if use_product else 100) for _ in range(world))
     [p.join(30) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     text = oracle.gen(total_len, seed, 0)
