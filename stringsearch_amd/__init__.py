@@ -8,7 +8,8 @@ Host-side mirror (Python, over the C ABI of include/dc3hip.h) of the reference's
 The compute path is libdc3hip.so ONLY.  There is no CPU fallback: importing works without a GPU
 (so the ABI can be inspected), but every build call fails loudly if the library or a device is missing.
 """
-from ._lib import lib, lib_path, Dc3HipError, Stats, PHASES  # noqa: F401
+from ._lib import lib, lib_path, Dc3HipError, Stats, GStats, PHASES  # noqa: F401
+from .global_sa import GlobalRank, LoopbackGroup  # noqa: F401
 from .api import (  # noqa: F401
     Context,
     LongestCommonSubstring,
@@ -28,7 +29,7 @@ from .api import (  # noqa: F401
 )
 
 __all__ = [
-    "Context", "Dc3HipError", "LongestCommonSubstring", "NotSorted", "PartitionedSuffixArray", "PHASES", "Stats",
+    "Context", "Dc3HipError", "GlobalRank", "GStats", "LoopbackGroup", "LongestCommonSubstring", "NotSorted", "PartitionedSuffixArray", "PHASES", "Stats",
     "SuffixArray", "common_prefix_len", "device_count", "last_error", "lib", "release_cache", "lib_path", "sort", "sort_i64",
     "sort_in_place", "sufcheck", "verify", "version",
 ]

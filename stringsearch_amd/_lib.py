@@ -65,6 +65,19 @@ class Stats(ctypes.Structure):
         }
 
 
+class GStats(ctypes.Structure):
+    """dc3hip_gstats (global mode)."""
+    _fields_ = [("struct_size", ctypes.c_int32), ("nranks", ctypes.c_int32), ("rank", ctypes.c_int32),
+                ("levels", ctypes.c_int32), ("text_order", ctypes.c_int32), ("local_from_level", ctypes.c_int32),
+                ("total_n", ctypes.c_int64), ("shard_first", ctypes.c_int64), ("shard_count", ctypes.c_int64),
+                ("exchanges", ctypes.c_int64), ("exchange_pairs", ctypes.c_int64),
+                ("comm_bytes_out", ctypes.c_int64), ("comm_bytes_in", ctypes.c_int64),
+                ("comm_ms", ctypes.c_double), ("device_ms", ctypes.c_double), ("wall_ms", ctypes.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "struct_size"}
+
+
 # every exported symbol of include/dc3hip.h: (restype, argtypes)
 _vp, _i32, _i64, _u64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64
 SYMBOLS = {
@@ -93,6 +106,23 @@ SYMBOLS = {
     "dc3hip_ctx_lcp_i32": (_i32, [_vp, _vp]),
     "dc3hip_ctx_search": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp]),
     "dc3hip_ctx_stats": (_i32, [_vp, ctypes.POINTER(Stats)]),
+    # global mode
+    "dc3hip_global_loopback_create": (_i32, [ctypes.POINTER(_vp), _i32, _i32, _i64]),
+    "dc3hip_global_loopback_build": (_i32, [ctypes.POINTER(_vp), _i32]),
+    "dc3hip_rccl_unique_id": (_i32, [_vp]),
+    "dc3hip_global_rccl_create": (_i32, [ctypes.POINTER(_vp), _vp, _i32, _i32, _i32, _i64]),
+    "dc3hip_global_destroy": (None, [_vp]),
+    "dc3hip_global_block": (_i32, [_vp, _i64, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
+    "dc3hip_global_set_text_block": (_i32, [_vp, _vp, _i64]),
+    "dc3hip_global_generate": (_i32, [_vp, _i64, _u64, _i32]),
+    "dc3hip_global_build": (_i32, [_vp]),
+    "dc3hip_global_shard": (_i32, [_vp, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
+    "dc3hip_global_get_shard_i64": (_i32, [_vp, _vp]),
+    "dc3hip_global_get_shard_u32": (_i32, [_vp, _vp]),
+    "dc3hip_global_shard_checksum": (_i32, [_vp, ctypes.POINTER(_u64)]),
+    "dc3hip_global_stats": (_i32, [_vp, ctypes.POINTER(GStats), ctypes.POINTER(Stats)]),
+    "dc3hip_global_last_error": (ctypes.c_char_p, [_vp]),
+    "dc3hip_global_transport": (ctypes.c_char_p, [_vp]),
 }
 
 _lib = None

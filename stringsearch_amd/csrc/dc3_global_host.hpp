@@ -218,6 +218,7 @@ struct dc3hip_gctx {
   const u32 *shard_ptr = nullptr;               // device
   u32 local_max = 1u << 22;                     // levels up to this length are finished on every rank redundantly
   bool no_text_order = false;
+  bool force_dist = false;                      // run the distributed path even with one rank (transport tests)
   dc3hip_gstats gs;
   char err[512] = "";
   std::vector<dc3hip_gctx *> group;             // loopback: all ranks of the group (rank 0 owns the list)
@@ -637,7 +638,7 @@ static int gbuild_inner(dc3hip_gctx *G) {
     HIPC(hipMemsetAsync(c->d_text + n, 0, 64, c->stream));
   }
   G->gs.local_from_level = -1;
-  if (n <= 2 || P == 1 || (u64)n <= (u64)G->local_max) {
+  if (n <= 2 || (P == 1 && !G->force_dist) || (u64)n <= (u64)G->local_max) {
     if (n >= 1) RC(build_core(c));
     int64_t off, len; block_of(n, P, me, &off, &len);
     G->shard_first = off; G->shard_count = len; G->shard_ptr = c->d_sa + off;
@@ -679,6 +680,7 @@ static int gbuild(dc3hip_gctx *G) {
 static void gctx_env(dc3hip_gctx *G) {
   if (const char *e = getenv("DC3HIP_GLOBAL_LOCAL_MAX")) { const long long v = atoll(e); if (v >= 0) G->local_max = (u32)std::min<long long>(v, 0x7fffffffll); }
   if (const char *e = getenv("DC3HIP_GLOBAL_NO_TEXT_ORDER")) G->no_text_order = e[0] == '1';
+  if (const char *e = getenv("DC3HIP_GLOBAL_FORCE_DIST")) G->force_dist = e[0] == '1';
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,0 +1,149 @@
+"""Global mode: ONE suffix array of a text sharded over P ranks (include/dc3hip.h, "GLOBAL mode").
+
+    GlobalRank      one rank of a group (RCCL: one process per GPU; the 128-byte id travels through the caller's
+                    own channel, e.g. torch.distributed.broadcast_object_list)
+    LoopbackGroup   P ranks on ONE device inside this process — the parity-test vehicle for P in {2,4,8}
+
+The reference has no global mode (sacapart keeps P independent arrays, crates/sacapart/src/lib.rs:5-25); the result is
+defined by the single-device one: the shards in rank order concatenate to SA[0..n) of the whole text."""
+import ctypes
+
+import numpy as np
+
+from ._lib import Dc3HipError, GStats, Stats, lib
+from .api import _as_u8, _check
+
+
+class GlobalRank:
+    def __init__(self, handle):
+        self._h = ctypes.c_void_p(handle)
+        self.total_n = 0
+
+    @classmethod
+    def rccl(cls, unique_id: bytes, rank: int, nranks: int, device: int, max_total_n: int):
+        assert len(unique_id) == 128
+        h = ctypes.c_void_p()
+        buf = (ctypes.c_uint8 * 128).from_buffer_copy(unique_id)
+        _check(lib().dc3hip_global_rccl_create(ctypes.byref(h), buf, rank, nranks, device, max_total_n))
+        return cls(h.value)
+
+    @staticmethod
+    def rccl_unique_id() -> bytes:
+        buf = (ctypes.c_uint8 * 128)()
+        _check(lib().dc3hip_rccl_unique_id(buf))
+        return bytes(buf)
+
+    def close(self):
+        if self._h:
+            lib().dc3hip_global_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def block(self, total_n):
+        off, ln = ctypes.c_int64(), ctypes.c_int64()
+        _check(lib().dc3hip_global_block(self._h, total_n, ctypes.byref(off), ctypes.byref(ln)))
+        return off.value, ln.value
+
+    def set_text_block(self, block, total_n):
+        b = _as_u8(block)
+        off, ln = self.block(total_n)
+        assert len(b) == ln, f"this rank's block of a {total_n}-byte text is {ln} bytes, got {len(b)}"
+        _check(lib().dc3hip_global_set_text_block(self._h, b.ctypes.data if ln else None, total_n))
+        self.total_n = total_n
+
+    def generate(self, total_n, seed, kind=0):
+        _check(lib().dc3hip_global_generate(self._h, total_n, seed, kind))
+        self.total_n = total_n
+
+    def build(self):
+        rc = lib().dc3hip_global_build(self._h)
+        if rc != 0:
+            raise Dc3HipError(rc, lib().dc3hip_global_last_error(self._h).decode())
+
+    def shard(self):
+        first, cnt = ctypes.c_int64(), ctypes.c_int64()
+        _check(lib().dc3hip_global_shard(self._h, ctypes.byref(first), ctypes.byref(cnt)))
+        return first.value, cnt.value
+
+    def shard_sa(self, dtype=np.int64):
+        first, cnt = self.shard()
+        if dtype == np.int64:
+            out = np.zeros(cnt, dtype=np.int64)
+            _check(lib().dc3hip_global_get_shard_i64(self._h, out.ctypes.data if cnt else None))
+        else:
+            out = np.zeros(cnt, dtype=np.uint32)
+            _check(lib().dc3hip_global_get_shard_u32(self._h, out.ctypes.data if cnt else None))
+        return first, out
+
+    def shard_checksum(self):
+        v = ctypes.c_uint64()
+        _check(lib().dc3hip_global_shard_checksum(self._h, ctypes.byref(v)))
+        return int(v.value)
+
+    def stats(self):
+        g, s = GStats(), Stats()
+        _check(lib().dc3hip_global_stats(self._h, ctypes.byref(g), ctypes.byref(s)))
+        d = g.as_dict()
+        d["ctx"] = s.as_dict()
+        return d
+
+    def transport(self):
+        return lib().dc3hip_global_transport(self._h).decode()
+
+
+class LoopbackGroup:
+    """P ranks on one device, run on P host threads inside the library (dc3hip_global_loopback_build)."""
+
+    def __init__(self, nranks, max_total_n, device=-1):
+        self.P = nranks
+        self._arr = (ctypes.c_void_p * nranks)()
+        _check(lib().dc3hip_global_loopback_create(self._arr, nranks, device, max_total_n))
+        self.ranks = [GlobalRank(self._arr[r]) for r in range(nranks)]
+
+    def close(self):
+        for r in self.ranks:
+            r.close()
+        self.ranks = []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_text(self, text):
+        t = _as_u8(text)
+        for r in self.ranks:
+            off, ln = r.block(len(t))
+            r.set_text_block(t[off:off + ln], len(t))
+
+    def generate(self, total_n, seed, kind=0):
+        for r in self.ranks:
+            r.generate(total_n, seed, kind)
+
+    def build(self):
+        rc = lib().dc3hip_global_loopback_build(self._arr, self.P)
+        if rc != 0:
+            from .api import last_error
+            raise Dc3HipError(rc, last_error())
+
+    def sa(self):
+        """The shards in rank order, concatenated (int64); also checks that they tile [0, n)."""
+        parts, nxt = [], 0
+        for r in self.ranks:
+            first, s = r.shard_sa(np.int64)
+            assert first == nxt, f"shard of rank starts at {first}, expected {nxt}"
+            nxt += len(s)
+            parts.append(s)
+        return np.concatenate(parts) if parts else np.zeros(0, dtype=np.int64)
+
+    def checksum(self):
+        return sum(r.shard_checksum() for r in self.ranks) & (2**64 - 1)
+
+    def stats(self):
+        return [r.stats() for r in self.ranks]

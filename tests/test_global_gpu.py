@@ -1,0 +1,146 @@
+"""GPU parity tests (-m gpu) of the GLOBAL mode: one suffix array over P ranks (include/dc3hip.h "GLOBAL mode").
+The result is defined by the single-device build / divsufsort: the shards, concatenated in rank order, must equal
+SA[0..n) of the whole text bit for bit.  P in {2,4,8} runs as loopback ranks on the one GPU of the box; the RCCL
+transport is exercised with a one-rank communicator (RCCL refuses two ranks on one device)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ss():
+    import stringsearch_amd as ss
+    assert ss.device_count() >= 1, "gpu tests need a device; the library has no CPU fallback"
+    return ss
+
+
+class env:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        for k, v in self.kv.items():
+            os.environ[k] = str(v)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def want_sa(oracle, data):
+    return (oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)).astype(np.int64)
+
+
+def inputs(oracle):
+    rng = np.random.default_rng(11)
+    out = {}
+    out["random256"] = oracle.gen(300_001, 2, 0)
+    out["dna"] = oracle.gen(250_000, 5, 1)
+    out["text"] = oracle.gen(400_003, 3, 2)
+    x = oracle.gen(200_000, 7, 0)
+    out["dup_block"] = np.concatenate([x, x[50_000:120_000], oracle.gen(30_002, 8, 0)])
+    out["all_equal"] = np.full(70_001, 65, dtype=np.uint8)
+    out["period3"] = np.tile(np.frombuffer(b"abc", dtype=np.uint8), 40_000)[:119_999]
+    out["two_symbols"] = rng.integers(0, 2, 150_000).astype(np.uint8)
+    out["zeros_inside"] = (rng.integers(0, 3, 100_000) * 127).astype(np.uint8)
+    return out
+
+
+@pytest.mark.parametrize("P", [2, 4, 8])
+def test_loopback_matches_single_device_all_levels_distributed(ss, oracle, P):
+    """Every level down to 64 symbols runs distributed (key-range selection, rank exchange, sliced merge): the
+    concatenated shards equal the reference SA on inputs with 2..18 recursion levels."""
+    data = inputs(oracle)
+    with env(DC3HIP_GLOBAL_LOCAL_MAX=64, DC3HIP_GLOBAL_NO_TEXT_ORDER=1):
+        with ss.LoopbackGroup(P, max(len(v) for v in data.values())) as g:
+            for name, t in data.items():
+                g.set_text(t)
+                g.build()
+                got = g.sa()
+                assert np.array_equal(got, want_sa(oracle, t)), (name, P)
+                st = g.stats()
+                assert all(s["nranks"] == P and s["exchanges"] >= 2 for s in st), name
+                assert sum(s["shard_count"] for s in st) == len(t)
+
+
+@pytest.mark.parametrize("P", [2, 4, 8])
+def test_loopback_default_policy(ss, oracle, P):
+    """Default thresholds (small levels finished locally, whole-text order allowed) and n % 3 in {0,1,2}."""
+    with ss.LoopbackGroup(P, 6_000_002) as g:
+        for n, kind, seed in [(6_000_000, 0, 2), (5_000_002, 0, 4), (5_000_001, 2, 3), (4_500_000, 1, 5)]:
+            t = oracle.gen(n, seed, kind)
+            g.set_text(t)
+            g.build()
+            assert np.array_equal(g.sa(), want_sa(oracle, t)), (n, kind, P)
+            st = g.stats()
+            if kind == 0:
+                assert all(s["text_order"] == 1 for s in st)        # every 9-byte window distinct
+            with ss.Context(n) as c:
+                c.set_text(t); c.build()
+                assert g.checksum() == c.checksum()                 # checksum of shards == single-device checksum
+
+
+def test_loopback_generated_blocks_and_tiny_inputs(ss, oracle):
+    """Ranks generate only their own block (offset-addressable generator); n in {0,1,2,3,...} and n < P."""
+    with ss.LoopbackGroup(4, 100_000) as g:
+        for n in (0, 1, 2, 3, 4, 5, 7, 64, 65, 1000, 99_999):
+            g.generate(n, 9, 1)
+            g.build()
+            t = oracle.gen(n, 9, 1)
+            assert np.array_equal(g.sa(), want_sa(oracle, t) if n else np.zeros(0, dtype=np.int64)), n
+    with env(DC3HIP_GLOBAL_LOCAL_MAX=0, DC3HIP_GLOBAL_NO_TEXT_ORDER=1):
+        with ss.LoopbackGroup(8, 3000) as g:
+            for n in (70, 100, 257, 2999):
+                g.generate(n, 3, 2)
+                g.build()
+                assert np.array_equal(g.sa(), want_sa(oracle, oracle.gen(n, 3, 2))), n
+
+
+def test_loopback_64mib_random_and_text_properties(ss, oracle):
+    """BASELINE configs[1] size through 4 ranks: random (distributed whole-text order) and low-entropy text
+    (distributed recursion) — checksum of the shards equals the single-device checksum; GPU sufcheck of the
+    concatenated result."""
+    n = 64 << 20
+    for kind, seed in ((0, 2), (2, 3)):
+        with ss.LoopbackGroup(4, n) as g:
+            g.generate(n, seed, kind)
+            g.build()
+            chk = g.checksum()
+            sa = g.sa()
+            st = g.stats()
+        with ss.Context(n) as c:
+            c.generate(n, seed, kind)
+            c.build()
+            assert c.checksum() == chk, kind
+            c.set_sa(sa.astype(np.int32))
+            assert c.sufcheck() == 0
+        assert (st[0]["text_order"] == 1) == (kind == 0)
+        assert all(s["comm_bytes_in"] > 0 for s in st)
+
+
+def test_rccl_transport_single_rank(ss, oracle):
+    """The RCCL backend end to end with a one-rank communicator: dlopen of librccl, unique id, ncclCommInitRank,
+    grouped send/recv paths with no peers, ncclAllGather of the host counts."""
+    uid = ss.GlobalRank.rccl_unique_id()
+    assert len(uid) == 128
+    with env(DC3HIP_GLOBAL_FORCE_DIST=1, DC3HIP_GLOBAL_LOCAL_MAX=1000):
+        r = ss.GlobalRank.rccl(uid, 0, 1, 0, 3_000_000)
+    try:
+        assert "RCCL" in r.transport()
+        for kind, n in ((2, 777_777), (0, 2_500_000)):
+            t = oracle.gen(n, 2, kind)
+            r.set_text_block(t, len(t))
+            r.build()
+            first, sa = r.shard_sa()
+            assert first == 0 and np.array_equal(sa, want_sa(oracle, t))
+            st = r.stats()
+            assert st["local_from_level"] != 0 and (st["exchanges"] >= 2 or st["text_order"] == 1)
+    finally:
+        r.close()
