@@ -232,6 +232,21 @@ DC3HIP_API int32_t dc3hip_global_loopback_build(dc3hip_gctx **ranks, int32_t P);
 DC3HIP_API int32_t dc3hip_rccl_unique_id(uint8_t *id128);
 DC3HIP_API int32_t dc3hip_global_rccl_create(dc3hip_gctx **out, const uint8_t *id128, int32_t rank, int32_t nranks,
                                              int32_t device, int64_t max_total_n);
+/* Host-staged transport: the caller supplies the two collectives on HOST buffers (MPI, gloo, ...); the library
+ * stages device data through pinned memory.  For nodes without GPU peer access, and for multi-process runs on one
+ * GPU (RCCL refuses two ranks on one device).  Offsets and sizes are bytes, arrays have nranks entries.
+ *   all_to_all_v: send[soff[r] .. +sbytes[r]) goes to rank r; rbytes[r] bytes from rank r land at recv + roff[r]
+ *   all_gather_v: every rank contributes sbytes bytes; rank r's land at recv + roff[r] (rbytes[r] bytes) everywhere
+ * Both return 0 on success. */
+typedef struct dc3hip_host_transport {
+  void *user;
+  int32_t (*all_to_all_v)(void *user, const void *send, const uint64_t *soff, const uint64_t *sbytes, void *recv,
+                          const uint64_t *roff, const uint64_t *rbytes);
+  int32_t (*all_gather_v)(void *user, const void *send, uint64_t sbytes, void *recv, const uint64_t *roff,
+                          const uint64_t *rbytes);
+} dc3hip_host_transport;
+DC3HIP_API int32_t dc3hip_global_host_create(dc3hip_gctx **out, const dc3hip_host_transport *t, int32_t rank,
+                                             int32_t nranks, int32_t device, int64_t max_total_n);
 DC3HIP_API void dc3hip_global_destroy(dc3hip_gctx *g);
 /* the block of a text of total_n bytes this rank owns */
 DC3HIP_API int32_t dc3hip_global_block(dc3hip_gctx *g, int64_t total_n, int64_t *offset, int64_t *length);

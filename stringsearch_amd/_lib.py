@@ -78,6 +78,16 @@ class GStats(ctypes.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "struct_size"}
 
 
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+A2A_FN = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, _u64p, _u64p, ctypes.c_void_p, _u64p, _u64p)
+AG_FN = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, _u64p, _u64p)
+
+
+class HostTransport(ctypes.Structure):
+    """dc3hip_host_transport"""
+    _fields_ = [("user", ctypes.c_void_p), ("all_to_all_v", A2A_FN), ("all_gather_v", AG_FN)]
+
+
 # every exported symbol of include/dc3hip.h: (restype, argtypes)
 _vp, _i32, _i64, _u64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64
 SYMBOLS = {
@@ -111,6 +121,7 @@ SYMBOLS = {
     "dc3hip_global_loopback_build": (_i32, [ctypes.POINTER(_vp), _i32]),
     "dc3hip_rccl_unique_id": (_i32, [_vp]),
     "dc3hip_global_rccl_create": (_i32, [ctypes.POINTER(_vp), _vp, _i32, _i32, _i32, _i64]),
+    "dc3hip_global_host_create": (_i32, [ctypes.POINTER(_vp), ctypes.POINTER(HostTransport), _i32, _i32, _i32, _i64]),
     "dc3hip_global_destroy": (None, [_vp]),
     "dc3hip_global_block": (_i32, [_vp, _i64, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "dc3hip_global_set_text_block": (_i32, [_vp, _vp, _i64]),

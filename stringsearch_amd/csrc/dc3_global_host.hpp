@@ -206,6 +206,71 @@ struct RcclComm : GComm {
   }
 };
 
+// ---- host-staged: the caller supplies the two collectives on HOST buffers (MPI, torch.distributed/gloo, ...); the
+// library stages device data through pinned memory.  For nodes without peer access and for multi-process tests on
+// a single GPU (RCCL refuses two ranks on one device).
+struct HostComm : GComm {
+  dc3hip_host_transport t;
+  char *hs = nullptr, *hr = nullptr; size_t cap_s = 0, cap_r = 0;     // pinned staging
+  const char *name() const override { return "host-staged (caller's collectives on pinned host buffers)"; }
+  ~HostComm() override { if (hs) (void)hipHostFree(hs); if (hr) (void)hipHostFree(hr); }
+  int grow(char **p, size_t *cap, size_t need) {
+    if (need <= *cap) return E_OK;
+    if (*p) (void)hipHostFree(*p);
+    *p = nullptr; *cap = 0;
+    const size_t want = std::max<size_t>(need + need / 4, 1u << 20);
+    HIPC(hipHostMalloc(reinterpret_cast<void **>(p), want, hipHostMallocDefault));
+    *cap = want;
+    return E_OK;
+  }
+  int all_to_all_v(const void *send, const size_t *soff, const size_t *sbytes, void *recv, const size_t *roff,
+                   const size_t *rbytes, hipStream_t st) override {
+    CommTimer tm(this);
+    uint64_t so[kMaxRanks], sb[kMaxRanks], ro[kMaxRanks], rb[kMaxRanks];
+    size_t send_hi = 0, recv_hi = 0;
+    for (int r = 0; r < nranks; r++) {
+      so[r] = soff[r]; sb[r] = sbytes[r]; ro[r] = roff[r]; rb[r] = rbytes[r];
+      send_hi = std::max(send_hi, soff[r] + sbytes[r]); recv_hi = std::max(recv_hi, roff[r] + rbytes[r]);
+      if (r != rank) { bytes_out += sbytes[r]; bytes_in += rbytes[r]; }
+    }
+    RC(grow(&hs, &cap_s, send_hi)); RC(grow(&hr, &cap_r, recv_hi));
+    if (send_hi) HIPC(hipMemcpyAsync(hs, send, send_hi, hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
+    if (t.all_to_all_v(t.user, hs, so, sb, hr, ro, rb) != 0) { set_err("host transport: all_to_all_v failed"); return E_HIP; }
+    if (recv_hi) HIPC(hipMemcpyAsync(recv, hr, recv_hi, hipMemcpyHostToDevice, st));
+    HIPC(hipStreamSynchronize(st));
+    return E_OK;
+  }
+  int all_gather_v(const void *send, size_t sbytes, void *recv, const size_t *roff, const size_t *rbytes,
+                   hipStream_t st) override {
+    CommTimer tm(this);
+    uint64_t ro[kMaxRanks], rb[kMaxRanks];
+    size_t recv_hi = 0;
+    for (int r = 0; r < nranks; r++) {
+      ro[r] = roff[r]; rb[r] = rbytes[r]; recv_hi = std::max(recv_hi, roff[r] + rbytes[r]);
+      if (r != rank) { bytes_out += sbytes; bytes_in += rbytes[r]; }
+    }
+    RC(grow(&hs, &cap_s, sbytes)); RC(grow(&hr, &cap_r, recv_hi));
+    if (sbytes) HIPC(hipMemcpyAsync(hs, send, sbytes, hipMemcpyDeviceToHost, st));
+    HIPC(hipStreamSynchronize(st));
+    if (t.all_gather_v(t.user, hs, sbytes, hr, ro, rb) != 0) { set_err("host transport: all_gather_v failed"); return E_HIP; }
+    // every block but my own (already in place, and possibly aliased by `send`)
+    for (int r = 0; r < nranks; r++)
+      if (r != rank && rbytes[r]) HIPC(hipMemcpyAsync(static_cast<char *>(recv) + roff[r], hr + roff[r], rbytes[r], hipMemcpyHostToDevice, st));
+    char *self = static_cast<char *>(recv) + roff[rank];
+    if (sbytes && self != send) HIPC(hipMemcpyAsync(self, send, sbytes, hipMemcpyDeviceToDevice, st));
+    HIPC(hipStreamSynchronize(st));
+    return E_OK;
+  }
+  int all_gather_host(const void *in, void *out, size_t bytes) override {
+    CommTimer tm(this);
+    uint64_t ro[kMaxRanks], rb[kMaxRanks];
+    for (int r = 0; r < nranks; r++) { ro[r] = (uint64_t)r * bytes; rb[r] = bytes; }
+    if (t.all_gather_v(t.user, in, bytes, out, ro, rb) != 0) { set_err("host transport: all_gather_v failed"); return E_HIP; }
+    return E_OK;
+  }
+};
+
 // ---------------------------------------------------------------------------------------------
 // one rank of a global build
 // ---------------------------------------------------------------------------------------------
@@ -739,6 +804,24 @@ int32_t dc3hip_global_rccl_create(dc3hip_gctx **out, const uint8_t *id128, int32
     return E_OK;
   }();
   if (rc != E_OK) { dc3hip_global_destroy(G); return rc; }
+  gctx_env(G);
+  *out = G;
+  return E_OK;
+}
+
+int32_t dc3hip_global_host_create(dc3hip_gctx **out, const dc3hip_host_transport *t, int32_t rank, int32_t nranks,
+                                  int32_t device, int64_t max_total_n) {
+  if (!out || !t || !t->all_to_all_v || !t->all_gather_v || nranks < 1 || nranks > kMaxRanks || rank < 0 || rank >= nranks ||
+      max_total_n < 0) {
+    set_err("dc3hip_global_host_create: invalid arguments (1 <= nranks <= %d)", kMaxRanks); return E_ARGS;
+  }
+  *out = nullptr;
+  dc3hip_gctx *G = new (std::nothrow) dc3hip_gctx();
+  if (!G) { set_err("host allocation failed"); return E_ALLOC; }
+  const int rc = dc3hip_ctx_create(&G->c, device, max_total_n);
+  if (rc != E_OK) { dc3hip_global_destroy(G); return rc; }
+  HostComm *hc = new HostComm(); hc->rank = rank; hc->nranks = nranks; hc->t = *t;
+  G->comm = hc; G->max_total = max_total_n;
   gctx_env(G);
   *out = G;
   return E_OK;

@@ -14,6 +14,64 @@ from ._lib import Dc3HipError, GStats, Stats, lib
 from .api import _as_u8, _check
 
 
+def torch_host_callbacks(dist, rank, nranks):
+    """The two collectives of dc3hip_host_transport on raw host addresses, over torch.distributed (CPU tensors):
+    all_to_all_v by batched isend/irecv, all_gather_v by all_gather of blocks padded to the largest one.
+    Return 0 / 1 (a Python exception must not unwind through the C frames of the caller)."""
+    import torch
+
+    def view(ptr, nbytes):
+        return torch.frombuffer((ctypes.c_uint8 * nbytes).from_address(ptr), dtype=torch.uint8)
+
+    def a2a(user, send, soff, sbytes, recv, roff, rbytes):
+        try:
+            ops, keep = [], []
+            for r in range(nranks):
+                if r == rank:
+                    if rbytes[r]:
+                        ctypes.memmove(recv + roff[r], send + soff[r], rbytes[r])
+                    continue
+                if sbytes[r]:
+                    t = view(send + soff[r], sbytes[r]); keep.append(t)
+                    ops.append(dist.P2POp(dist.isend, t, r))
+                if rbytes[r]:
+                    t = view(recv + roff[r], rbytes[r]); keep.append(t)
+                    ops.append(dist.P2POp(dist.irecv, t, r))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            return 0
+        except Exception as e:
+            print("host transport all_to_all_v:", repr(e), flush=True)
+            return 1
+
+    def ag(user, send, sbytes, recv, roff, rbytes):
+        try:
+            mx = max(max(int(rbytes[r]) for r in range(nranks)), 1)
+            mine = torch.zeros(mx, dtype=torch.uint8)
+            if sbytes:
+                mine[:sbytes] = view(send, sbytes)
+            outs = [torch.zeros(mx, dtype=torch.uint8) for _ in range(nranks)]
+            dist.all_gather(outs, mine)
+            for r in range(nranks):
+                if rbytes[r]:
+                    view(recv + roff[r], rbytes[r]).copy_(outs[r][:rbytes[r]])
+            return 0
+        except Exception as e:
+            print("host transport all_gather_v:", repr(e), flush=True)
+            return 1
+
+    return a2a, ag
+
+
+def block_of(total_n, nranks, rank):
+    """(offset, length) of the text block rank `rank` owns: sacapart-style blocks of len/P + 1 bytes
+    (crates/sacapart/src/lib.rs:43-46), the same arithmetic as dc3hip_global_block."""
+    S = total_n // nranks + 1
+    off = min(total_n, rank * S)
+    return off, min(S, total_n - off)
+
+
 class GlobalRank:
     def __init__(self, handle):
         self._h = ctypes.c_void_p(handle)
@@ -26,6 +84,19 @@ class GlobalRank:
         buf = (ctypes.c_uint8 * 128).from_buffer_copy(unique_id)
         _check(lib().dc3hip_global_rccl_create(ctypes.byref(h), buf, rank, nranks, device, max_total_n))
         return cls(h.value)
+
+    @classmethod
+    def torch_host(cls, dist, rank: int, nranks: int, device: int, max_total_n: int):
+        """Host-staged transport over a torch.distributed CPU process group (gloo): multi-process runs on a single GPU
+        and nodes without peer access.  `dist` = the initialised torch.distributed module."""
+        from ._lib import A2A_FN, AG_FN, HostTransport
+        a2a, ag = torch_host_callbacks(dist, rank, nranks)
+        tr = HostTransport(None, A2A_FN(a2a), AG_FN(ag))
+        h = ctypes.c_void_p()
+        _check(lib().dc3hip_global_host_create(ctypes.byref(h), ctypes.byref(tr), rank, nranks, device, max_total_n))
+        self = cls(h.value)
+        self._transport_keepalive = tr          # the library keeps the function pointers
+        return self
 
     @staticmethod
     def rccl_unique_id() -> bytes:
