@@ -53,13 +53,28 @@ __device__ __forceinline__ bool key_lt(const Rec16 &a, const Rec16 &b) {
 }
 
 // --- selectors --------------------------------------------------------------------------------
-// whole-text order: item p = text position; record = (image << pbits) | p; kept iff lo <= image (< hi unless last)
-struct SelTextImage {
+// whole-level order: item p = position of the level (text position for Key9); record = (image << pbits) | p;
+// kept iff lo <= image (< hi unless last)
+template <class KM>
+struct SelPosImage {
   typedef Rec8 Out;
-  Key9 km; HiMap hm; u64 lo, hi; u32 last;
+  KM km; HiMap hm; u64 lo, hi; u32 last;
   __device__ __forceinline__ void stage(uint16_t *lds) const { km.stage(lds); }
   __device__ __forceinline__ bool pick(u32 p, const uint16_t *lds, Rec8 &o) const {
     o = hyb_rec(km.make(p, lds), hm);
+    const u64 img = rec8_word(o) >> hm.pbits;
+    return img >= lo && (last || img < hi);
+  }
+};
+// prefix-sort naming: item q = q-th sample position; record = (image << pbits) | pos; kept by image range
+template <class Sym>
+struct SelSampleImage {
+  typedef Rec8 Out;
+  Sym S; u32 B; HiMap hm; u64 lo, hi; u32 last;
+  __device__ __forceinline__ void stage(uint16_t *) const {}
+  __device__ __forceinline__ bool pick(u32 q, const uint16_t *, Rec8 &o) const {
+    const u32 g = q >> 1, i = 3 * g + 1 + (q & 1);
+    o = hyb_rec(make_rec(S.get(i), S.get(i + 1), S.get(i + 2), B, i), hm);
     const u64 img = rec8_word(o) >> hm.pbits;
     return img >= lo && (last || img < hi);
   }

@@ -414,23 +414,265 @@ static int rank_exchange(dc3hip_gctx *G, Rec8 *pairs, u32 cnt, u32 M, u32 *out, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// one level (lib.rs:44-193) on replicated S.  top: the level's SA slice of this rank goes to c->d_sa (G->shard_*);
-// otherwise out_rank[0..m) (+ zero tail) is produced on every rank (the parent's rank12).
+// where a level's result goes
+// ---------------------------------------------------------------------------------------------
+enum GOut {
+  G_TOP = 0,    // level 0: this rank's slice of the suffix array stays in c->d_sa (G->shard_*)
+  G_RANK = 1,   // out[pos] = 1-based rank of suffix pos, complete on every rank (the parent's rank12)
+  G_SA = 2      // out[k] = position of the k-th smallest suffix, complete on every rank (discarding parent)
+};
+// slice[0..cnt) = this rank's part of the level's suffix array, starting at global index `pre`
+static int deliver(dc3hip_gctx *G, const u32 *slice, u32 cnt, u64 pre, const uint64_t *all, u32 m, u32 *out, GOut mode) {
+  dc3hip_ctx *c = G->c; GComm *cm = G->comm;
+  if (mode == G_TOP) {
+    G->shard_first = (int64_t)pre; G->shard_count = cnt; G->shard_ptr = slice;
+    return E_OK;
+  }
+  if (mode == G_RANK) {
+    const ArenaMark mk = arena_mark(c);
+    Rec8 *pp = nullptr;
+    RC(arena_alloc(c, (size_t)cnt + 16, &pp));
+    if (cnt) {
+      PhaseScope ps(c, DC3HIP_PH_RANKS, cnt);
+      hipLaunchKernelGGL(k_sa_to_pairs, dim3(grid_for(c, cnt)), dim3(kBlock), 0, c->stream, slice, cnt, (u32)pre, pp);
+      KCHECK();
+    }
+    RC(rank_exchange(G, pp, cnt, m, out, DC3HIP_PH_RANKS));     // rank[pos] = global index + 1, everywhere
+    arena_release(c, mk);
+    return E_OK;
+  }
+  size_t roff[kMaxRanks], rbytes[kMaxRanks];
+  u64 o = 0;
+  for (int r = 0; r < cm->nranks; r++) { roff[r] = (size_t)o * 4; rbytes[r] = (size_t)all[r] * 4; o += all[r]; }
+  return cm->all_gather_v(slice, (size_t)cnt * 4, out, roff, rbytes, c->stream);
+}
+
+// splitters of a 64-bit image order from ns sampled records ((image << pbits) | pos): every rank computes the same
+static int image_splitters(dc3hip_ctx *c, const Rec8 *d_sample, u32 ns, u32 pbits, int P, int me, u64 *lo, u64 *hi) {
+  std::vector<Rec8> hs(ns);
+  HIPC(hipMemcpyAsync(hs.data(), d_sample, (size_t)ns * sizeof(Rec8), hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  std::vector<u64> img(ns);
+  for (u32 i = 0; i < ns; i++) img[i] = ((((u64)hs[i].key) << 32) | hs[i].val) >> pbits;
+  std::sort(img.begin(), img.end());
+  *lo = 0; *hi = ~0ull;
+  if (me > 0) *lo = img[(size_t)((u64)me * ns / P)];
+  if (me + 1 < P) *hi = img[(size_t)((u64)(me + 1) * ns / P)];
+  return E_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Whole-level order, split by key range (the distributed form of order_all_positions): every rank orders the positions
+// p in [0, m) whose key image falls into its range by prefix sort + tie refinement.  If every key on every rank is
+// distinct the concatenated slices ARE the level's suffix array (suffixes differ inside the key: 9 bytes of text for
+// Key9 at level 0, a K-S triple for Key3 below), *done = true and the result has been delivered; otherwise nothing
+// was produced.  emit: where this rank's slice goes (c->d_sa at the top; nullptr = arena, valid until the caller's mark
+// is released).
+// ---------------------------------------------------------------------------------------------
+template <class KM>
+static int gorder_positions(dc3hip_gctx *G, KM km, u32 m, u32 kbits, const HiMap &hm, int depth, u32 *out, GOut mode,
+                            bool *done) {
+  dc3hip_ctx *c = G->c; GComm *cm = G->comm;
+  const int P = cm->nranks, me = cm->rank;
+  *done = false;
+  const ArenaMark mk = arena_mark(c);
+  u64 lo = 0, hi = ~0ull;
+  {
+    u32 ns = (u32)std::min<u64>(m, (u64)2048 * P);
+    const u32 stride = std::max<u32>(1, m / ns);
+    ns = (m - 1) / stride + 1;
+    Rec8 *smp = nullptr;
+    RC(arena_alloc(c, (size_t)ns, &smp));
+    hipLaunchKernelGGL((k_pack_image_pos<KM>), dim3(grid_for(c, ns)), dim3(kBlock), 0, c->stream, km, ns, stride, hm, smp);
+    KCHECK();
+    RC(image_splitters(c, smp, ns, hm.pbits, P, me, &lo, &hi));
+  }
+  SelPosImage<KM> sel; sel.km = km; sel.hm = hm; sel.lo = lo; sel.hi = hi; sel.last = (me + 1 == P) ? 1u : 0u;
+  Rec8 *ha = nullptr, *hb = nullptr, *h = nullptr; uint8_t *f = nullptr;
+  u32 nrec = 0;
+  RC(select_records(c, sel, m, &ha, &nrec, DC3HIP_PH_PACK));
+  u32 *slice = (mode == G_TOP) ? c->d_sa : nullptr;
+  if (!slice) RC(arena_alloc(c, (size_t)nrec + 16, &slice));
+  RC(arena_alloc(c, (size_t)nrec + 16, &hb));
+  RC(arena_alloc(c, (size_t)nrec + 16, &f));
+  bool ok = true, distinct = true;
+  if (nrec) RC((hybrid_sort_core<KM>(c, km, kbits, hm, ha, hb, nrec, &h, f, &ok, depth, slice, 0, &distinct, nullptr)));
+  uint64_t good = 0, ngood = 0, pre = 0, tot = 0, all[kMaxRanks];
+  RC(gather_counts(cm, (ok && distinct) ? 1 : 0, &good, &ngood));
+  RC(gather_counts(cm, nrec, &pre, &tot, all));
+  if (tot != m) { set_err("global order: %llu of %u positions selected", (unsigned long long)tot, m); return E_HIP; }
+  if (ngood == (uint64_t)P) {
+    *done = true;
+    RC(deliver(G, slice, nrec, pre, all, m, out, mode));
+  }
+  arena_release(c, mk);
+  return E_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// one level (lib.rs:44-193) on replicated S; the result goes where `mode` says (GOut).
 // ---------------------------------------------------------------------------------------------
 template <class Sym>
-static int glevel(dc3hip_gctx *G, Sym S, u32 m, u64 K, int depth, u32 *out_rank, bool top) {
+static int glevel(dc3hip_gctx *G, Sym S, u32 m, u64 K, int depth, u32 *out, GOut mode);
+
+// Sorted naming of this rank's key range (lib.rs:80-100), generic over the accessor of the sorted order.
+//   counts of distinct / unique names go around (all-gather of two words), names continue after those of the smaller
+//   key ranges (equal keys never straddle ranks), and (slot, name [| unique << 31]) pairs are exchanged into R.
+template <class Acc>
+static int gname_exchange(dc3hip_gctx *G, Acc acc, u32 cnt, u32 m0, u32 m02, u32 *R, u32 *sslot, uint64_t *names_total,
+                          uint64_t *uniq_total, uint64_t *cnt_pre, bool *discard) {
+  dc3hip_ctx *c = G->c; GComm *cm = G->comm;
+  const ArenaMark mk = arena_mark(c);
+  const Chunking ck = make_chunks(c, std::max<u32>(cnt, 1), kBlock * kNameIPT);
+  u32 *counts = nullptr;
+  RC(arena_alloc(c, (size_t)ck.nchunks + 16, &counts));
+  u32 distinct = 0, uniq = 0;
+  if (cnt) {
+    PhaseScope ps(c, DC3HIP_PH_NAMING, cnt);
+    HIPC(hipMemsetAsync(c->d_words + 4, 0, sizeof(u32), c->stream));
+    hipLaunchKernelGGL((k_name_count<Acc>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, acc, cnt, ck.chunk, counts, c->d_words + 4);
+    KCHECK();
+    hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, counts, ck.nchunks, c->d_words);
+    KCHECK();
+    HIPC(hipMemcpyAsync(c->h_words, c->d_words, 5 * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    distinct = c->h_words[0]; uniq = c->h_words[4];
+  }
+  uint64_t name_off = 0, upre = 0, cnt_total = 0;
+  RC(gather_counts(cm, distinct, &name_off, names_total));
+  RC(gather_counts(cm, uniq, &upre, uniq_total));
+  RC(gather_counts(cm, cnt, cnt_pre, &cnt_total));
+  if (cnt_total != m02) { set_err("global naming: %llu of %u samples selected", (unsigned long long)cnt_total, m02); return E_HIP; }
+  // discarding (see discard_recurse): worth it when ~1/6 of the slots would leave the recursion
+  const double drop_est = (double)*uniq_total * (double)*uniq_total / (double)m02;
+  *discard = sslot && *names_total != m02 && !c->no_discard && m02 < 0x7fffffffu && drop_est * kDiscardMinDropInv >= (double)m02;
+  Rec8 *pa = nullptr;
+  RC(arena_alloc(c, (size_t)cnt + 16, &pa));
+  if (cnt) {
+    PhaseScope ps(c, DC3HIP_PH_NAMING, cnt);
+    if (name_off) {
+      hipLaunchKernelGGL(k_add_scalar, dim3(grid_for(c, ck.nchunks)), dim3(kBlock), 0, c->stream, counts, ck.nchunks, (u32)name_off);
+      KCHECK();
+    }
+    hipLaunchKernelGGL((k_name_assign<Acc>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, acc, cnt, ck.chunk, counts, m0, pa,
+                       *discard ? sslot : (u32 *)nullptr);
+    KCHECK();
+  }
+  RC(rank_exchange(G, pa, cnt, m02, R, DC3HIP_PH_NAMING));      // R[slot] = name (| unique << 31), everywhere
+  hipLaunchKernelGGL(k_zero_tail, dim3(1), dim3(64), 0, c->stream, R, m02, 8u);
+  KCHECK();
+  arena_release(c, mk);
+  return E_OK;
+}
+
+// Discarding recursion, distributed (the scheme of discard_recurse).  RU[p] = name | unique << 31 is replicated, so the
+// reduced string R' and the kept-slot list are built by every rank (streaming); the child returns its suffix array
+// REPLICATED (all-gather of slices: 4 B per kept slot — cheaper than a rank exchange); every rank derives the order of
+// the non-unique slots (pt) from it and rewrites ITS range of the sorted array; one rank exchange gives rank12.
+static int gdiscard(dc3hip_gctx *G, const u32 *RU, const u32 *sslot, u32 cnt, u64 cnt_pre, u32 m02, u64 names, u32 *rank12,
+                    int depth) {
+  dc3hip_ctx *c = G->c; GComm *cm = G->comm;
+  const ArenaMark mk = arena_mark(c);
+  const Chunking ck = make_chunks(c, m02, kBlock);
+  u32 *counts = nullptr;
+  RC(arena_alloc(c, (size_t)ck.nchunks + 16, &counts));
+  {
+    PhaseScope ps(c, DC3HIP_PH_DISCARD, m02);
+    hipLaunchKernelGGL(k_keep_count, dim3(ck.nchunks), dim3(kBlock), 0, c->stream, RU, m02, ck.chunk, counts);
+    KCHECK();
+    hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, counts, ck.nchunks, c->d_words + 5);
+    KCHECK();
+    HIPC(hipMemcpyAsync(c->h_words + 5, c->d_words + 5, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPC(hipStreamSynchronize(c->stream));
+  const u32 mp = c->h_words[5];
+  c->stats.level_kept[depth] = mp;
+  if (mp == 0) { set_err("internal: discarding kept no slot"); return E_HIP; }
+  u32 *Rp = nullptr, *kept = nullptr, *sap = nullptr;
+  RC(arena_alloc(c, (size_t)mp + 16, &Rp));
+  RC(arena_alloc(c, (size_t)mp + 16, &kept));
+  RC(arena_alloc(c, (size_t)mp + 16, &sap));
+  {
+    PhaseScope ps(c, DC3HIP_PH_DISCARD, m02);
+    hipLaunchKernelGGL(k_keep_write, dim3(ck.nchunks), dim3(kBlock), 0, c->stream, RU, m02, ck.chunk, counts, Rp, kept);
+    KCHECK();
+    hipLaunchKernelGGL(k_zero_tail, dim3(1), dim3(64), 0, c->stream, Rp, mp, 8u);
+    KCHECK();
+  }
+  SymU32 RS; RS.s = Rp; RS.m = mp;
+  if (mp == 1) { hipLaunchKernelGGL(k_base1, dim3(1), dim3(64), 0, c->stream, sap, (u32 *)nullptr); KCHECK(); }
+  else RC(glevel<SymU32>(G, RS, mp, names, depth + 1, sap, G_SA));
+  u32 *x = nullptr, *pt = nullptr;
+  RC(arena_alloc(c, (size_t)mp + 16, &x));
+  RC(arena_alloc(c, (size_t)mp + 16, &pt));
+  {
+    PhaseScope ps(c, DC3HIP_PH_DISCARD, mp);
+    const Chunking ckp = make_chunks(c, mp, kBlock);
+    u32 *cnt2 = nullptr;
+    RC(arena_alloc(c, (size_t)ckp.nchunks + 16, &cnt2));
+    hipLaunchKernelGGL(k_discard_gather, dim3(grid_for(c, mp)), dim3(kBlock), 0, c->stream, sap, mp, kept, x);
+    KCHECK();
+    hipLaunchKernelGGL(k_nonuniq_count, dim3(ckp.nchunks), dim3(kBlock), 0, c->stream, x, mp, ckp.chunk, cnt2);
+    KCHECK();
+    hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, cnt2, ckp.nchunks, (u32 *)nullptr);
+    KCHECK();
+    hipLaunchKernelGGL(k_nonuniq_write, dim3(ckp.nchunks), dim3(kBlock), 0, c->stream, x, mp, ckp.chunk, cnt2, pt);
+    KCHECK();
+  }
+  // my range [cnt_pre, cnt_pre + cnt) of the level's sorted array: unique entries keep their place, the t-th
+  // non-unique entry (t counted over all ranks) receives pt[t]
+  Rec8 *pa = nullptr;
+  RC(arena_alloc(c, (size_t)cnt + 16, &pa));
+  const Chunking ckl = make_chunks(c, std::max<u32>(cnt, 1), kBlock);
+  u32 *cl = nullptr;
+  RC(arena_alloc(c, (size_t)ckl.nchunks + 16, &cl));
+  u32 nu_local = 0;
+  if (cnt) {
+    PhaseScope ps(c, DC3HIP_PH_DISCARD, cnt);
+    hipLaunchKernelGGL(k_nonuniq_count, dim3(ckl.nchunks), dim3(kBlock), 0, c->stream, sslot, cnt, ckl.chunk, cl);
+    KCHECK();
+    hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, cl, ckl.nchunks, c->d_words + 6);
+    KCHECK();
+    HIPC(hipMemcpyAsync(c->h_words + 6, c->d_words + 6, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    nu_local = c->h_words[6];
+  }
+  uint64_t nu_pre = 0, nu_tot = 0;
+  RC(gather_counts(cm, nu_local, &nu_pre, &nu_tot));
+  if (cnt) {
+    PhaseScope ps(c, DC3HIP_PH_DISCARD, cnt);
+    if (nu_pre) {
+      hipLaunchKernelGGL(k_add_scalar, dim3(grid_for(c, ckl.nchunks)), dim3(kBlock), 0, c->stream, cl, ckl.nchunks, (u32)nu_pre);
+      KCHECK();
+    }
+    hipLaunchKernelGGL(k_final_assign, dim3(ckl.nchunks), dim3(kBlock), 0, c->stream, sslot, cnt, ckl.chunk, cl, pt, (u32 *)nullptr, pa);
+    KCHECK();
+    if (cnt_pre) {
+      hipLaunchKernelGGL(k_add_val, dim3(grid_for(c, cnt)), dim3(kBlock), 0, c->stream, pa, cnt, (u32)cnt_pre);
+      KCHECK();
+    }
+  }
+  RC(rank_exchange(G, pa, cnt, m02, rank12, DC3HIP_PH_RANKS));
+  arena_release(c, mk);
+  return E_OK;
+}
+
+template <class Sym>
+static int glevel(dc3hip_gctx *G, Sym S, u32 m, u64 K, int depth, u32 *out, GOut mode) {
   dc3hip_ctx *c = G->c; GComm *cm = G->comm;
   const int P = cm->nranks, me = cm->rank;
   if (depth >= DC3HIP_MAX_LEVELS) { set_err("recursion deeper than %d levels", DC3HIP_MAX_LEVELS); return E_HIP; }
   if (m <= G->local_max || m < 64) {
     // small level: every rank finishes the recursion on its own copy (no communication below this point)
     if (G->gs.local_from_level < 0) G->gs.local_from_level = depth;
-    if (top) {
+    if (mode == G_TOP) {
       RC(dc3_level<Sym>(c, S, m, K, c->d_sa, nullptr, depth));
       int64_t off, len; block_of(m, P, me, &off, &len);
       G->shard_first = off; G->shard_count = len; G->shard_ptr = c->d_sa + off;
+    } else if (mode == G_RANK) {
+      RC(dc3_level<Sym>(c, S, m, K, nullptr, out, depth));
     } else {
-      RC(dc3_level<Sym>(c, S, m, K, nullptr, out_rank, depth));
+      RC(dc3_level<Sym>(c, S, m, K, out, nullptr, depth));
     }
     return E_OK;
   }
@@ -452,86 +694,107 @@ static int glevel(dc3hip_gctx *G, Sym S, u32 m, u64 K, int depth, u32 *out_rank,
     }
     RC(arena_alloc(c, (size_t)m02 + 16, &rank12));
     SymU32 RS; RS.s = R; RS.m = m02;
-    RC(glevel<SymU32>(G, RS, m02, B * B * B, depth + 1, rank12, false));
+    RC(glevel<SymU32>(G, RS, m02, B * B * B, depth + 1, rank12, G_RANK));
   } else {
     // ---- sorted naming, split by key range (lib.rs:62-100) ---------------------------------------------------
     c->stats.level_sorted[depth] = 1;
     const u32 b = (u32)B;
     u32 kbits = 0;
     { unsigned __int128 mx = (unsigned __int128)B * B * B - 1; while (mx) { kbits++; mx >>= 1; } }
+    u32 *sslot = nullptr;                          // my range of the sorted slots (| unique << 31), for the discarding
+    RC(arena_alloc(c, (size_t)m02 + 16, &sslot));
     const ArenaMark mk1 = arena_mark(c);
-    // splitters: every rank sorts the same deterministic sample of keys
-    Rec16 klo{0, 0, 0, 0}, khi{0, 0, 0, 0};
-    {
-      u32 ns = (u32)std::min<u64>(m02, (u64)1024 * P);
-      const u32 stride = std::max<u32>(1, m02 / ns);
-      ns = (m02 - 1) / stride + 1;
-      Rec16 *smp = nullptr;
-      RC(arena_alloc(c, (size_t)ns, &smp));
-      std::vector<Rec16> hs(ns);
-      hipLaunchKernelGGL((k_sample_triple_keys<Sym>), dim3(grid_for(c, ns)), dim3(kBlock), 0, c->stream, S, b, ns, stride, smp);
-      KCHECK();
-      HIPC(hipMemcpyAsync(hs.data(), smp, (size_t)ns * sizeof(Rec16), hipMemcpyDeviceToHost, c->stream));
-      HIPC(hipStreamSynchronize(c->stream));
-      std::sort(hs.begin(), hs.end(), [](const Rec16 &x, const Rec16 &y) {
-        if (x.k2 != y.k2) return x.k2 < y.k2;
-        if (x.k1 != y.k1) return x.k1 < y.k1;
-        return x.k0 < y.k0;
-      });
-      if (me > 0) klo = hs[(size_t)((u64)me * ns / P)];
-      if (me + 1 < P) khi = hs[(size_t)((u64)(me + 1) * ns / P)];
+    const HiMap hm = make_himap(B, kbits, m);
+    double pred = 1.0;
+    const bool try_hybrid = m02 >= kHybridMinSamples / 4 && !c->no_hybrid;
+    if (try_hybrid) {
+      RC(predict_tie_fraction<Sym>(c, S, m, m0, m02, b, hm, &pred));
+      c->stats.level_tie_pred[depth] = pred;
     }
-    SelTripleKey<Sym> sel; sel.S = S; sel.B = b; sel.klo = klo; sel.khi = khi; sel.has_lo = me > 0 ? 1u : 0u; sel.last = (me + 1 == P) ? 1u : 0u;
-    Rec16 *recA = nullptr, *recB = nullptr, *sorted = nullptr;
+    Key3<Sym> km; km.S = S; km.B = b;
+    if (try_hybrid && pred < kFullSortMaxPredicted && !c->no_fullsort) {
+      // high-entropy level: if all its triples are distinct, ordering all its positions finishes it
+      bool done = false;
+      RC((gorder_positions<Key3<Sym>>(G, km, m, kbits, hm, depth, out, mode, &done)));
+      if (done) { c->stats.level_sorted[depth] = 5; arena_release(c, mk0); return E_OK; }
+      arena_release(c, mk1);
+    }
+    uint64_t names_total = 0, uniq_total = 0, cnt_pre = 0;
+    bool discard = false, named = false;
     u32 cnt = 0;
-    RC(select_records(c, sel, m02, &recA, &cnt, DC3HIP_PH_PACK));
-    RC(arena_alloc(c, (size_t)cnt + 16, &recB));
-    sorted = recA;
-    if (cnt) RC(radix_sort<Rec16>(c, recA, recB, cnt, 0, kbits, &sorted, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT12_DOWN));
-    AccRec<Rec16> acc; acc.s = sorted;
-    const Chunking ck = make_chunks(c, std::max<u32>(cnt, 1), kBlock * kNameIPT);
-    u32 *counts = nullptr;
-    RC(arena_alloc(c, (size_t)ck.nchunks + 16, &counts));
-    u32 distinct = 0;
-    if (cnt) {
-      PhaseScope ps(c, DC3HIP_PH_NAMING, cnt);
-      HIPC(hipMemsetAsync(c->d_words + 4, 0, sizeof(u32), c->stream));
-      hipLaunchKernelGGL((k_name_count<AccRec<Rec16>>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, acc, cnt, ck.chunk, counts,
-                         c->d_words + 4);
-      KCHECK();
-      hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, counts, ck.nchunks, c->d_words);
-      KCHECK();
-      HIPC(hipMemcpyAsync(c->h_words, c->d_words, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
-      HIPC(hipStreamSynchronize(c->stream));
-      distinct = c->h_words[0];
-    }
-    // names of this rank follow the names of all smaller key ranges (equal keys never straddle ranks)
-    uint64_t name_off = 0, names_total = 0, cnt_pre = 0, cnt_total = 0;
-    RC(gather_counts(cm, distinct, &name_off, &names_total));
-    RC(gather_counts(cm, cnt, &cnt_pre, &cnt_total));
-    if (cnt_total != m02) { set_err("global naming: %llu of %u samples selected", (unsigned long long)cnt_total, m02); return E_HIP; }
-    Rec8 *pa = nullptr;
-    RC(arena_alloc(c, (size_t)cnt + 16, &pa));
-    if (cnt) {
-      PhaseScope ps(c, DC3HIP_PH_NAMING, cnt);
-      if (name_off) {
-        hipLaunchKernelGGL(k_add_scalar, dim3(grid_for(c, ck.nchunks)), dim3(kBlock), 0, c->stream, counts, ck.nchunks, (u32)name_off);
+    if (try_hybrid && pred < kHybridMaxPredicted) {
+      // prefix sort + tie refinement of my IMAGE range (equal keys have equal images, so they stay on one rank)
+      u64 lo = 0, hi = ~0ull;
+      {
+        const u32 stride = std::max<u32>(1, m0 / (u32)std::min<u64>(m0, (u64)1024 * P));
+        const u32 ng = (m0 - 1) / stride + 1;
+        Rec8 *smp = nullptr;
+        RC(arena_alloc(c, (size_t)2 * ng, &smp));
+        HIPC(hipMemsetAsync(smp, 0xff, (size_t)2 * ng * sizeof(Rec8), c->stream));   // (a missing last mod-2 sample stays a filler)
+        hipLaunchKernelGGL((k_pack_image<Sym>), dim3(grid_for(c, ng)), dim3(kBlock), 0, c->stream, S, m, m0, m02, b, hm, stride, ng, smp);
         KCHECK();
+        RC(image_splitters(c, smp, 2 * ng, hm.pbits, P, me, &lo, &hi));
       }
-      hipLaunchKernelGGL((k_name_assign<AccRec<Rec16>>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, acc, cnt, ck.chunk, counts,
-                         m0, pa, (u32 *)nullptr);
-      KCHECK();
+      SelSampleImage<Sym> sel; sel.S = S; sel.B = b; sel.hm = hm; sel.lo = lo; sel.hi = hi; sel.last = (me + 1 == P) ? 1u : 0u;
+      Rec8 *ha = nullptr, *hb = nullptr, *h = nullptr; uint8_t *f = nullptr;
+      RC(select_records(c, sel, m02, &ha, &cnt, DC3HIP_PH_PACK));
+      RC(arena_alloc(c, (size_t)cnt + 16, &hb));
+      RC(arena_alloc(c, (size_t)cnt + 16, &f));
+      bool ok = true;
+      if (cnt) RC((hybrid_sort_core<Key3<Sym>>(c, km, kbits, hm, ha, hb, cnt, &h, f, &ok, depth)));
+      uint64_t g0 = 0, ngood = 0;
+      RC(gather_counts(cm, ok ? 1 : 0, &g0, &ngood));
+      if (ngood == (uint64_t)P) {
+        c->stats.level_sorted[depth] = 2;
+        AccHyb acc; acc.h = h; acc.f = f; acc.posmask = hm.pbits >= 32 ? 0xffffffffu : ((1u << hm.pbits) - 1u);
+        RC(gname_exchange<AccHyb>(G, acc, cnt, m0, m02, R, sslot, &names_total, &uniq_total, &cnt_pre, &discard));
+        named = true;
+      } else {
+        arena_release(c, mk1);                       // too many ties somewhere: every rank takes the straight sort
+      }
     }
-    RC(rank_exchange(G, pa, cnt, m02, R, DC3HIP_PH_NAMING));      // R[slot] = name, everywhere
-    hipLaunchKernelGGL(k_zero_tail, dim3(1), dim3(64), 0, c->stream, R, m02, 8u);
-    KCHECK();
+    if (!named) {
+      // straight sort of my KEY range: splitters = every rank sorts the same deterministic sample of keys
+      Rec16 klo{0, 0, 0, 0}, khi{0, 0, 0, 0};
+      {
+        u32 ns = (u32)std::min<u64>(m02, (u64)1024 * P);
+        const u32 stride = std::max<u32>(1, m02 / ns);
+        ns = (m02 - 1) / stride + 1;
+        Rec16 *smp = nullptr;
+        RC(arena_alloc(c, (size_t)ns, &smp));
+        std::vector<Rec16> hs(ns);
+        hipLaunchKernelGGL((k_sample_triple_keys<Sym>), dim3(grid_for(c, ns)), dim3(kBlock), 0, c->stream, S, b, ns, stride, smp);
+        KCHECK();
+        HIPC(hipMemcpyAsync(hs.data(), smp, (size_t)ns * sizeof(Rec16), hipMemcpyDeviceToHost, c->stream));
+        HIPC(hipStreamSynchronize(c->stream));
+        std::sort(hs.begin(), hs.end(), [](const Rec16 &x, const Rec16 &y) {
+          if (x.k2 != y.k2) return x.k2 < y.k2;
+          if (x.k1 != y.k1) return x.k1 < y.k1;
+          return x.k0 < y.k0;
+        });
+        if (me > 0) klo = hs[(size_t)((u64)me * ns / P)];
+        if (me + 1 < P) khi = hs[(size_t)((u64)(me + 1) * ns / P)];
+      }
+      SelTripleKey<Sym> sel; sel.S = S; sel.B = b; sel.klo = klo; sel.khi = khi; sel.has_lo = me > 0 ? 1u : 0u; sel.last = (me + 1 == P) ? 1u : 0u;
+      Rec16 *recA = nullptr, *recB = nullptr, *sorted = nullptr;
+      RC(select_records(c, sel, m02, &recA, &cnt, DC3HIP_PH_PACK));
+      RC(arena_alloc(c, (size_t)cnt + 16, &recB));
+      sorted = recA;
+      if (cnt) RC(radix_sort<Rec16>(c, recA, recB, cnt, 0, kbits, &sorted, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT12_DOWN));
+      AccRec<Rec16> acc; acc.s = sorted;
+      RC(gname_exchange<AccRec<Rec16>>(G, acc, cnt, m0, m02, R, sslot, &names_total, &uniq_total, &cnt_pre, &discard));
+    }
     arena_release(c, mk1);
     if (names_total == m02) {
       rank12 = R;                                                 // all names distinct: the names are the ranks (lib.rs:109-113)
+    } else if (discard) {
+      c->stats.level_sorted[depth] += 2;
+      RC(arena_alloc(c, (size_t)m02 + 16, &rank12));
+      RC(gdiscard(G, R, sslot, cnt, cnt_pre, m02, names_total, rank12, depth));
     } else {
       RC(arena_alloc(c, (size_t)m02 + 16, &rank12));
       SymU32 RS; RS.s = R; RS.m = m02;
-      RC(glevel<SymU32>(G, RS, m02, names_total, depth + 1, rank12, false));   // lib.rs:104
+      RC(glevel<SymU32>(G, RS, m02, names_total, depth + 1, rank12, G_RANK));   // lib.rs:104
     }
   }
   hipLaunchKernelGGL(k_zero_tail, dim3(1), dim3(64), 0, c->stream, rank12, m02, 8u);
@@ -562,7 +825,6 @@ static int glevel(dc3hip_gctx *G, Sym S, u32 m, u64 K, int depth, u32 *out_rank,
     HIPC(hipStreamSynchronize(c->stream));
     for (int h = 1; h < P; h++) {
       const u32 slot = c->h_words[40 + h - 1];
-      if (bound[h] > m02) { sp.a[h - 1] = Tup12{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}; continue; }   // (no sample left)
       if (slot >= m02) { set_err("global merge: sample rank %u not found (rank12 is not a bijection)", bound[h]); return E_HIP; }
       HIPC(hipMemcpyAsync(&sp.a[h - 1], tslot + slot, sizeof(Tup12), hipMemcpyDeviceToHost, c->stream));
     }
@@ -609,28 +871,20 @@ static int glevel(dc3hip_gctx *G, Sym S, u32 m, u64 K, int depth, u32 *out_rank,
   }
   // my slice of the level's suffix array
   const u32 total = nA + nB;
-  uint64_t pre = 0, all = 0;
-  RC(gather_counts(cm, total, &pre, &all));
-  if (all != m) { set_err("global merge: slices hold %llu of %u suffixes", (unsigned long long)all, m); return E_HIP; }
-  if (top) {
-    RC(merge_lists(c, A, nA, reinterpret_cast<const Tup0 *>(zs), nB, c->d_sa, nullptr, 0u));
-    G->shard_first = (int64_t)pre; G->shard_count = total; G->shard_ptr = c->d_sa;
-  } else {
-    u32 *slice = nullptr; Rec8 *pp = nullptr;
-    RC(arena_alloc(c, (size_t)total + 16, &slice));
-    RC(arena_alloc(c, (size_t)total + 16, &pp));
-    RC(merge_lists(c, A, nA, reinterpret_cast<const Tup0 *>(zs), nB, slice, pp, (u32)pre));
-    RC(rank_exchange(G, pp, total, m, out_rank, DC3HIP_PH_RANKS));     // rank[pos] = global index + 1, everywhere
-  }
+  uint64_t pre = 0, tot = 0, all[kMaxRanks];
+  RC(gather_counts(cm, total, &pre, &tot, all));
+  if (tot != m) { set_err("global merge: slices hold %llu of %u suffixes", (unsigned long long)tot, m); return E_HIP; }
+  u32 *slice = (mode == G_TOP) ? c->d_sa : nullptr;
+  if (!slice) RC(arena_alloc(c, (size_t)total + 16, &slice));
+  RC(merge_lists(c, A, nA, reinterpret_cast<const Tup0 *>(zs), nB, slice, nullptr, 0u));
+  RC(deliver(G, slice, total, pre, all, m, out, mode));
   arena_release(c, mk0);
   return E_OK;
 }
 
-// whole-text order, split by key range: every rank orders the positions whose 9-byte key image falls into its range.
-// *done = all ranks found all their keys distinct -> the concatenation of the slices is the suffix array.
+// level 0 shortcut: the whole-text order by 9-byte keys, split by key range (conditions as in build_core)
 static int gtext_order(dc3hip_gctx *G, SymU8 S, u32 sigma, bool *done) {
-  dc3hip_ctx *c = G->c; GComm *cm = G->comm;
-  const int P = cm->nranks, me = cm->rank;
+  dc3hip_ctx *c = G->c;
   const u32 n = (u32)G->total_n;
   *done = false;
   const u64 Bq = (u64)sigma + 1, B3 = Bq * Bq * Bq;
@@ -645,42 +899,8 @@ static int gtext_order(dc3hip_gctx *G, SymU8 S, u32 sigma, bool *done) {
   RC(predict_tie_fraction_pos<Key9>(c, km, n, hm, &pred));
   c->stats.level_tie_pred[0] = pred;
   if (!(pred < kTextSortMaxPredicted)) return E_OK;
-  const ArenaMark mk = arena_mark(c);
-  // image splitters from a deterministic sample (every rank computes the same ones)
-  u64 lo = 0, hi = ~0ull;
-  {
-    u32 ns = (u32)std::min<u64>(n, (u64)2048 * P);
-    const u32 stride = std::max<u32>(1, n / ns);
-    ns = (n - 1) / stride + 1;
-    Rec8 *smp = nullptr;
-    RC(arena_alloc(c, (size_t)ns, &smp));
-    std::vector<Rec8> hs(ns);
-    hipLaunchKernelGGL((k_pack_image_pos<Key9>), dim3(grid_for(c, ns)), dim3(kBlock), 0, c->stream, km, ns, stride, hm, smp);
-    KCHECK();
-    HIPC(hipMemcpyAsync(hs.data(), smp, (size_t)ns * sizeof(Rec8), hipMemcpyDeviceToHost, c->stream));
-    HIPC(hipStreamSynchronize(c->stream));
-    std::vector<u64> img(ns);
-    for (u32 i = 0; i < ns; i++) img[i] = ((((u64)hs[i].key) << 32) | hs[i].val) >> hm.pbits;
-    std::sort(img.begin(), img.end());
-    if (me > 0) lo = img[(size_t)((u64)me * ns / P)];
-    if (me + 1 < P) hi = img[(size_t)((u64)(me + 1) * ns / P)];
-  }
-  SelTextImage sel; sel.km = km; sel.hm = hm; sel.lo = lo; sel.hi = hi; sel.last = (me + 1 == P) ? 1u : 0u;
-  Rec8 *ha = nullptr, *hb = nullptr, *h = nullptr; uint8_t *f = nullptr;
-  u32 nrec = 0;
-  RC(select_records(c, sel, n, &ha, &nrec, DC3HIP_PH_PACK));
-  RC(arena_alloc(c, (size_t)nrec + 16, &hb));
-  RC(arena_alloc(c, (size_t)nrec + 16, &f));
-  bool ok = true, distinct = true;
-  if (nrec) RC((hybrid_sort_core<Key9>(c, km, kbits, hm, ha, hb, nrec, &h, f, &ok, 0, c->d_sa, 0, &distinct, nullptr)));
-  uint64_t good = 0, ngood = 0, pre = 0, tot = 0;
-  RC(gather_counts(cm, (ok && distinct) ? 1 : 0, &good, &ngood));
-  RC(gather_counts(cm, nrec, &pre, &tot));
-  arena_release(c, mk);
-  if (tot != n) { set_err("global text order: %llu of %u positions selected", (unsigned long long)tot, n); return E_HIP; }
-  if (ngood == (uint64_t)P) {
-    *done = true;
-    G->shard_first = (int64_t)pre; G->shard_count = nrec; G->shard_ptr = c->d_sa;
+  RC((gorder_positions<Key9>(G, km, n, kbits, hm, 0, nullptr, G_TOP, done)));
+  if (*done) {
     c->stats.text_sort_state = 1;
     c->stats.level_n[0] = n; c->stats.level_K[0] = sigma; c->stats.levels = 1; c->stats.level_sorted[0] = 5;
   } else {
@@ -714,7 +934,7 @@ static int gbuild_inner(dc3hip_gctx *G) {
     SymU8 S; S.t = c->d_text; S.code = c->d_code; S.m = (u32)n;
     bool done = false;
     RC(gtext_order(G, S, sigma, &done));
-    if (!done) RC(glevel<SymU8>(G, S, (u32)n, sigma, 0, nullptr, true));
+    if (!done) RC(glevel<SymU8>(G, S, (u32)n, sigma, 0, nullptr, G_TOP));
   }
   RC(build_end(c));
   return E_OK;

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(kBlock) void k_final_assign(const u32 *__restrict__
     const u32 ex = block_excl_scan<kWaves>(nonu ? 1u : 0u, tmp, tot);
     if (i < end) {
       const u32 sl = nonu ? pt[running + ex] : (v & ~kUniqBit);
-      sa12[i] = sl;
+      if (sa12) sa12[i] = sl;
       pairs[i] = Rec8{sl, i + 1};
     }
     running += tot;
