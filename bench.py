@@ -27,8 +27,52 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from stringsearch_amd.benchlib import (HBM_PEAK_GBS, KINDS, PATH_NAMES, cpu_baseline, kernel_rooflines, parse_size,  # noqa: E402
-                                       path_roofline)
+from stringsearch_amd.benchlib import HBM_PEAK_GBS, KINDS, PATH_NAMES, kernel_rooflines, parse_size, path_roofline  # noqa: E402
+
+
+def host_cpu_model():
+    try:
+        return [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        return "unknown"
+
+
+def cpu_baseline(text_u8, sample_bytes):
+    """The reference's CPU path (libdivsufsort built from /root/reference into oracle/_ref) or, if that
+    is absent, our C restatement of crates/dc3 — timed on one host core like divsuftest's measure()
+    (crates/divsuftest/src/main.rs:145-151: wall clock around the call incl. the SA allocation)."""
+    import numpy as np
+    n = len(text_u8)
+    sample = text_u8 if sample_bytes >= n else np.ascontiguousarray(text_u8[:sample_bytes])
+    ref = os.path.join(ROOT, "oracle", "_ref", "libdivsufsort_ref.so")
+    port = os.path.join(ROOT, "oracle", "liboracle_dc3.so")
+    if os.path.exists(ref):
+        L = ctypes.CDLL(ref); f = L.divsufsort; kind = "reference"
+    elif os.path.exists(port):
+        L = ctypes.CDLL(port); f = L.dc3_oracle_sufsort_i32; kind = "port"
+    else:
+        return None
+    f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]; f.restype = ctypes.c_int32
+    old_aff = None
+    try:
+        old_aff = os.sched_getaffinity(0)
+        os.sched_setaffinity(0, {sorted(old_aff)[0]})
+    except Exception:
+        pass
+    t0 = time.perf_counter()
+    sa = np.zeros(len(sample), dtype=np.int32)
+    rc = f(sample.ctypes.data, sa.ctypes.data, len(sample))
+    dt = time.perf_counter() - t0
+    if old_aff:
+        try:
+            os.sched_setaffinity(0, old_aff)
+        except Exception:
+            pass
+    assert rc == 0
+    what = "the whole buffer" if len(sample) == n else f"first {len(sample) / 2**20:.0f} MiB of the same buffer"
+    return {"value": len(sample) / dt / 1e6, "unit": "MB/s", "cores": 1, "kind": kind,
+            "sample": f"{what}, one divsufsort() call, wall clock incl. SA allocation ({dt:.2f} s)",
+            "seconds": dt, "host_cpu": host_cpu_model(), "host_cores_available": os.cpu_count()}, sa
 
 
 def main():

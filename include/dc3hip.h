@@ -190,10 +190,25 @@ typedef struct dc3hip_stats {
    * 0 = not tried, 1 = all keys distinct, that order is the SA (levels == 1, level_sorted[0] == 5),
    * 2 = duplicate keys, the order was filtered into level 1's sorted samples, 3 = abandoned (too many ties) */
   int32_t text_sort_state;
-  int32_t reserved0;
+  int32_t trace_on;                       /* DC3HIP_TRACE=1 was set when the context was created */
+  /* Stage-level parity trace (DC3HIP_TRACE=1; the counterpart of the reference's crosscheck! macro,
+   * crates/divsufsort/src/crosscheck.rs:17-84).  Per level: sum over k of mix(k, x_k) for the sorted samples
+   * (x = position in the level's string, dummy included), the sorted mod-0 suffixes and the level's suffix array;
+   * 0 where a level did not build the array (whole-level / whole-text order).  trace_names = distinct triples of
+   * a sorted level (lib.rs:104 `name`), -1 where names were packed directly.  The CPU restatement produces the same
+   * words (the restatement the tests check against), so a failing build can be narrowed to a level and a stage. */
+  uint64_t trace_sa12[DC3HIP_MAX_LEVELS];
+  uint64_t trace_sa0[DC3HIP_MAX_LEVELS];
+  uint64_t trace_sa[DC3HIP_MAX_LEVELS];
+  int64_t  trace_names[DC3HIP_MAX_LEVELS];
 } dc3hip_stats;
 
 DC3HIP_API int32_t dc3hip_ctx_stats(dc3hip_ctx *ctx, dc3hip_stats *out);
+
+/* Test hook for kernel-level parity against the reference's radix_pass (crates/dc3/src/lib.rs:15-39): ONE stable pass
+ * of the product's radix scatter over n host words, digit = (word >> shift) & (nb - 1), nb = 256 or 512. */
+DC3HIP_API int32_t dc3hip_ctx_debug_radix_pass_u64(dc3hip_ctx *ctx, const uint64_t *words, uint64_t *out, int64_t n,
+                                                   int32_t shift, int32_t nb);
 
 /* ---- GLOBAL mode: one suffix array over P ranks (one rank per GPU) -------------------------------------------
  * The other multi-GPU semantics of SURVEY.md §8(e).  sacapart (crates/sacapart/src/lib.rs:39-58; here

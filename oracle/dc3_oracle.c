@@ -70,12 +70,26 @@ typedef struct {
   int     cap;        /* capacity of the trace arrays (may be 0) */
   int64_t *n_at;      /* n of each invocation */
   int64_t *K_at;      /* K of each invocation */
+  /* optional stage words (dc3_oracle_trace_ex), the same words libdc3hip reports with DC3HIP_TRACE=1: */
+  int64_t  *names_at; /* `name` after the naming loop (lib.rs:80-100) */
+  uint64_t *h_sa12;   /* sum_i mix(i, position of the i-th smallest sample), dummy included (after lib.rs:103-113) */
+  uint64_t *h_sa0;    /* sum_p mix(p, SA0[p])   (after lib.rs:126) */
+  uint64_t *h_sa;     /* sum_k mix(k, SA[k])    (after lib.rs:192) */
 } dc3_trace;
+
+static inline uint64_t trace_mix(uint64_t i, uint64_t v) {   /* splitmix64((i << 32) | v), as k_trace_sum */
+  uint64_t x = (i << 32) | v;
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
 
 /* lib.rs:44-193.  T has n+3 entries, T[n..n+3)=0, symbols in 1..K, n>=2. */
 static int skew(const usz *T, usz *SA, usz n, usz K, dc3_trace *tr) {
+  int lvl = -1;                                   /* this invocation's slot in the trace arrays */
   if (tr) {
-    if (tr->depth < tr->cap) { tr->n_at[tr->depth] = (int64_t)n; tr->K_at[tr->depth] = (int64_t)K; }
+    if (tr->depth < tr->cap) { lvl = tr->depth; tr->n_at[tr->depth] = (int64_t)n; tr->K_at[tr->depth] = (int64_t)K; }
     tr->depth++;
   }
   const usz n0 = (n + 2) / 3, n1 = (n + 1) / 3, n2 = n / 3, n02 = n0 + n2; /* :45-48 */
@@ -119,11 +133,22 @@ static int skew(const usz *T, usz *SA, usz n, usz K, dc3_trace *tr) {
     for (usz i = 0; i < n02; i++) SA12[R[i] - 1] = i;
   }
 
+  if (lvl >= 0 && tr->h_sa12) {
+    uint64_t h = 0;
+    for (usz i = 0; i < n02; i++) h += trace_mix(i, SA12[i] < n0 ? SA12[i] * 3 + 1 : (SA12[i] - n0) * 3 + 2);
+    tr->h_sa12[lvl] = h; tr->names_at[lvl] = (int64_t)name;
+  }
+
   /* Step 2 (:118-126): mod-0 suffixes, ordered by rank of suffix i+1, then by T[i]. */
   {
     usz j = 0;
     for (usz i = 0; i < n02; i++) if (SA12[i] < n0) R0[j++] = 3 * SA12[i];
     if ((err = radix_pass(R0, SA0, T, n0, K))) goto done;
+  }
+  if (lvl >= 0 && tr->h_sa0) {
+    uint64_t h = 0;
+    for (usz p = 0; p < n0; p++) h += trace_mix(p, SA0[p]);
+    tr->h_sa0[lvl] = h;
   }
 
   /* Step 3 (:131-192): merge. t starts at n0-n1 to skip the dummy. */
@@ -147,6 +172,11 @@ static int skew(const usz *T, usz *SA, usz n, usz K, dc3_trace *tr) {
       k++;
     }
 #undef GET_I
+  }
+  if (lvl >= 0 && tr->h_sa) {
+    uint64_t h = 0;
+    for (usz k = 0; k < n; k++) h += trace_mix(k, SA[k]);
+    tr->h_sa[lvl] = h;
   }
 done:
   free(R); free(SA12); free(R0); free(SA0);
@@ -188,7 +218,19 @@ ORACLE_API int dc3_oracle_trace(const uint8_t *T, int64_t n, int64_t *n_at, int6
   if (T == NULL || n < 3) return -1;
   usz *SAw = (usz *)malloc((size_t)n * sizeof(usz));
   if (!SAw) return -2;
-  dc3_trace tr = {0, cap, n_at, K_at};
+  dc3_trace tr = {0, cap, n_at, K_at, NULL, NULL, NULL, NULL};
+  int err = dc3_bytes(T, n, SAw, &tr);
+  free(SAw);
+  return err ? err : tr.depth;
+}
+
+/* The same with the stage words of every level (see dc3_trace): what libdc3hip reports with DC3HIP_TRACE=1. */
+ORACLE_API int dc3_oracle_trace_ex(const uint8_t *T, int64_t n, int cap, int64_t *n_at, int64_t *K_at, int64_t *names_at,
+                                   uint64_t *h_sa12, uint64_t *h_sa0, uint64_t *h_sa) {
+  if (T == NULL || n < 3) return -1;
+  usz *SAw = (usz *)malloc((size_t)n * sizeof(usz));
+  if (!SAw) return -2;
+  dc3_trace tr = {0, cap, n_at, K_at, names_at, h_sa12, h_sa0, h_sa};
   int err = dc3_bytes(T, n, SAw, &tr);
   free(SAw);
   return err ? err : tr.depth;

@@ -40,7 +40,9 @@ class Stats(ctypes.Structure):
                 ("partition_elems", ctypes.c_int64),
                 ("gather_ms", ctypes.c_double), ("gather_launches", ctypes.c_int64), ("gather_elems", ctypes.c_int64),
                 ("arena_bytes", ctypes.c_int64),
-                ("arena_peak", ctypes.c_int64), ("text_sort_state", ctypes.c_int32), ("reserved0", ctypes.c_int32)]
+                ("arena_peak", ctypes.c_int64), ("text_sort_state", ctypes.c_int32), ("trace_on", ctypes.c_int32),
+                ("trace_sa12", ctypes.c_uint64 * MAX_LEVELS), ("trace_sa0", ctypes.c_uint64 * MAX_LEVELS),
+                ("trace_sa", ctypes.c_uint64 * MAX_LEVELS), ("trace_names", ctypes.c_int64 * MAX_LEVELS)]
 
     def as_dict(self):
         return {
@@ -62,6 +64,9 @@ class Stats(ctypes.Structure):
             "gather_ms": self.gather_ms, "gather_launches": self.gather_launches, "gather_elems": self.gather_elems,
             "arena_bytes": self.arena_bytes, "arena_peak": self.arena_peak,
             "text_sort_state": self.text_sort_state,
+            "trace": None if not self.trace_on else [
+                {"n": self.level_n[i], "sa12": self.trace_sa12[i], "sa0": self.trace_sa0[i], "sa": self.trace_sa[i],
+                 "names": self.trace_names[i]} for i in range(self.levels)],
         }
 
 
@@ -116,6 +121,7 @@ SYMBOLS = {
     "dc3hip_ctx_lcp_i32": (_i32, [_vp, _vp]),
     "dc3hip_ctx_search": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp]),
     "dc3hip_ctx_stats": (_i32, [_vp, ctypes.POINTER(Stats)]),
+    "dc3hip_ctx_debug_radix_pass_u64": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32]),
     # global mode
     "dc3hip_global_loopback_create": (_i32, [ctypes.POINTER(_vp), _i32, _i32, _i64]),
     "dc3hip_global_loopback_build": (_i32, [ctypes.POINTER(_vp), _i32]),

@@ -1,8 +1,6 @@
-"""Shared pieces of bench.py and the global-mode bench (roofline bookkeeping, CPU baseline).  Host logic only."""
-import ctypes
+"""Shared pieces of bench.py and the global-mode bench (roofline bookkeeping).  Host logic only."""
 import json
 import os
-import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -28,51 +26,6 @@ def algorithmic_bytes(level_n):
         c = 1 if lvl == 0 else 4
         total += n * (46 * 4 + 29 * c) / 3.0
     return total
-
-
-def host_cpu_model():
-    try:
-        return [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
-    except Exception:
-        return "unknown"
-
-
-def cpu_baseline(text_u8, sample_bytes):
-    """The reference's CPU path (libdivsufsort built from /root/reference into oracle/_ref) or, if that
-    is absent, our C restatement of crates/dc3 — timed on one host core like divsuftest's measure()
-    (crates/divsuftest/src/main.rs:145-151: wall clock around the call incl. the SA allocation)."""
-    import numpy as np
-    n = len(text_u8)
-    sample = text_u8 if sample_bytes >= n else np.ascontiguousarray(text_u8[:sample_bytes])
-    ref = os.path.join(ROOT, "oracle", "_ref", "libdivsufsort_ref.so")
-    port = os.path.join(ROOT, "oracle", "liboracle_dc3.so")
-    if os.path.exists(ref):
-        L = ctypes.CDLL(ref); f = L.divsufsort; kind = "reference"
-    elif os.path.exists(port):
-        L = ctypes.CDLL(port); f = L.dc3_oracle_sufsort_i32; kind = "port"
-    else:
-        return None
-    f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]; f.restype = ctypes.c_int32
-    old_aff = None
-    try:
-        old_aff = os.sched_getaffinity(0)
-        os.sched_setaffinity(0, {sorted(old_aff)[0]})
-    except Exception:
-        pass
-    t0 = time.perf_counter()
-    sa = np.zeros(len(sample), dtype=np.int32)
-    rc = f(sample.ctypes.data, sa.ctypes.data, len(sample))
-    dt = time.perf_counter() - t0
-    if old_aff:
-        try:
-            os.sched_setaffinity(0, old_aff)
-        except Exception:
-            pass
-    assert rc == 0
-    what = "the whole buffer" if len(sample) == n else f"first {len(sample) / 2**20:.0f} MiB of the same buffer"
-    return {"value": len(sample) / dt / 1e6, "unit": "MB/s", "cores": 1, "kind": kind,
-            "sample": f"{what}, one divsufsort() call, wall clock incl. SA allocation ({dt:.2f} s)",
-            "seconds": dt, "host_cpu": host_cpu_model(), "host_cores_available": os.cpu_count()}, sa
 
 
 def kernel_rooflines(st_acc, steps, st_last, kernel_ms):

@@ -78,6 +78,8 @@ struct dc3hip_ctx {
   bool wide_names = false;
   bool no_nine_bit = false, no_rec12 = false, no_discard = false, no_fullsort = false, no_text_shortcut = false;
   bool no_split_emit = false;
+  bool trace = false;          // DC3HIP_TRACE=1: per-level checksums of SA12 / SA0 / SA (dc3hip_stats.trace_*)
+  u64 *d_trace = nullptr;      // [3][DC3HIP_MAX_LEVELS]
   std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
   std::vector<PhaseMark> marks;
   hipEvent_t ev_build_a = nullptr, ev_build_b = nullptr;
@@ -886,6 +888,20 @@ static int launch_merge(dc3hip_ctx *c, u32 ntiles, const Tup12 *A, u32 nA, const
   return E_OK;
 }
 
+// DC3HIP_TRACE=1 (stage-level parity, the counterpart of the reference's crosscheck! macro,
+// crates/divsufsort/src/crosscheck.rs:17-84): order-sensitive checksums of a level's three canonical arrays — the
+// sorted samples SA12 (as text positions of the level, the dummy included), the sorted mod-0 suffixes SA0 and the
+// level's suffix array — which do not depend on HOW names were made (dense by sorting or packed directly), so the
+// CPU restatement the tests check against emits the same words and can be compared level by level.
+enum { TR_SA12 = 0, TR_SA0 = 1, TR_SA = 2 };
+static int trace_sum(dc3hip_ctx *c, int which, int depth, const void *arr, u32 n, int kind /*0 u32 positions, 1 slots, 2 Tup0*/, u32 m0) {
+  if (!c->trace || depth >= DC3HIP_MAX_LEVELS || n == 0) return E_OK;
+  u64 *acc = c->d_trace + (size_t)which * DC3HIP_MAX_LEVELS + depth;
+  hipLaunchKernelGGL(k_trace_sum, dim3(grid_for(c, n)), dim3(kBlock), 0, c->stream, arr, n, kind, m0, acc);
+  KCHECK();
+  return E_OK;
+}
+
 // Step 3 (lib.rs:131-192): merge-path merge of the sorted sample tuples A and the sorted mod-0 tuples B into
 // out_sa[0 .. nA+nB) (and, when out_pairs != nullptr, the (pos, rank_base + k + 1) pairs of the rank inversion).
 static int merge_lists(dc3hip_ctx *c, const Tup12 *A, u32 nA, const Tup0 *B, u32 nB, u32 *out_sa, Rec8 *out_pairs,
@@ -1029,6 +1045,7 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
         RC((order_straight<Sym, Rec16>(c, S, m, m0, m02, b, kbits, sa12, rank12, R, sslot, &names, &mode)));
     }
     arena_release(c, mk1);
+    c->stats.trace_names[depth] = (int64_t)names;
     if (mode == 1) {
       SymU32 RS; RS.s = R; RS.m = m02;
       RC(dc3_level<SymU32>(c, RS, m02, names, sa12, rank12, depth + 1));   // lib.rs:104
@@ -1042,6 +1059,7 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
     hipLaunchKernelGGL(k_zero_tail, dim3(1), dim3(64), 0, c->stream, rank12, m02, 8u);
     KCHECK();
   }
+  RC(trace_sum(c, TR_SA12, depth, sa12, m02, 1, m0));
 
   // ---- Step 2 + 3: tuples, mod-0 order, merge -------------------------------------------------
   // t12 = sample tuples in SA12 order.  The gather also produces the digit table of the fused
@@ -1079,6 +1097,7 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
     RC((launch_downsweep<Tup0, 256, Mod0Loader>(c, ld, z0, m02, ckc, dig, table0, dbase0, DC3HIP_PH_COMPACT)));
   }
   RC(radix_sort<Tup0>(c, z0, z1, m0, 8, bits_of(K - 1), &zs, DC3HIP_PH_SORT0, DC3HIP_PH_SORT0, DC3HIP_PH_SORT0));
+  RC(trace_sum(c, TR_SA0, depth, zs, m0, 2, m0));
   {
     const u32 dskip = m0 - m1;                  // lib.rs:133: skip the dummy, which sorts first
     Rec8 *pa = nullptr, *pb = nullptr;
@@ -1087,6 +1106,7 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
       RC(arena_alloc(c, (size_t)m, &pb));
     }
     RC(merge_lists(c, t12 + dskip, m02 - dskip, zs, m0, out_sa, pa, 0u));
+    if (out_sa) RC(trace_sum(c, TR_SA, depth, out_sa, m, 0, m0));
     if (out_rank) RC(inverse_permute(c, pa, pb, m, out_rank, DC3HIP_PH_RANKS));
   }
   arena_release(c, mk0);
@@ -1106,11 +1126,20 @@ static int build_begin(dc3hip_ctx *c) {
   c->stats.arena_bytes = (int64_t)c->arena_bytes;
   if (c->n < 0) return E_ARGS;
   HIPC(hipSetDevice(c->device));
+  for (int l = 0; l < DC3HIP_MAX_LEVELS; l++) c->stats.trace_names[l] = -1;
+  if (c->trace) HIPC(hipMemsetAsync(c->d_trace, 0, 3 * DC3HIP_MAX_LEVELS * sizeof(u64), c->stream));
   if (c->profile) HIPC(hipEventRecord(c->ev_build_a, c->stream));
   return E_OK;
 }
 static int build_end(dc3hip_ctx *c) {
   if (c->profile) HIPC(hipEventRecord(c->ev_build_b, c->stream));
+  c->stats.trace_on = c->trace ? 1 : 0;
+  if (c->trace) {
+    static_assert(sizeof(c->stats.trace_sa12[0]) == sizeof(u64), "trace words");
+    HIPC(hipMemcpyAsync(c->stats.trace_sa12, c->d_trace, DC3HIP_MAX_LEVELS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipMemcpyAsync(c->stats.trace_sa0, c->d_trace + DC3HIP_MAX_LEVELS, DC3HIP_MAX_LEVELS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipMemcpyAsync(c->stats.trace_sa, c->d_trace + 2 * DC3HIP_MAX_LEVELS, DC3HIP_MAX_LEVELS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+  }
   HIPC(hipStreamSynchronize(c->stream));
   c->stats.arena_peak = (int64_t)c->arena_peak;
   if (c->profile) {
@@ -1248,6 +1277,7 @@ int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) {
   const char *nst = getenv("DC3HIP_NO_SMALL_TIES");
   c->no_small_ties = (nst && nst[0] == '1');
   { const char *e = getenv("DC3HIP_NO_SPLIT_EMIT"); c->no_split_emit = (e && e[0] == '1'); }
+  { const char *e = getenv("DC3HIP_TRACE"); c->trace = (e && e[0] == '1'); }
   const char *nts = getenv("DC3HIP_NO_TEXT_SHORTCUT");
   c->no_text_shortcut = (nts && nts[0] == '1');
   const char *nf = getenv("DC3HIP_NO_FULLSORT");
@@ -1275,6 +1305,7 @@ int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) {
     HIPC(hipMalloc(&c->d_present, 256 * sizeof(u32)));
     HIPC(hipMalloc(&c->d_code, 256 * sizeof(uint16_t)));
     HIPC(hipMalloc(&c->d_words, 64 * sizeof(u32)));
+    HIPC(hipMalloc(&c->d_trace, 3 * DC3HIP_MAX_LEVELS * sizeof(u64)));
     HIPC(hipHostMalloc(&c->h_words, 64 * sizeof(u32), hipHostMallocDefault));
     HIPC(hipEventCreate(&c->ev_build_a));
     HIPC(hipEventCreate(&c->ev_build_b));
@@ -1298,6 +1329,7 @@ void dc3hip_ctx_destroy(dc3hip_ctx *c) {
   if (c->d_present) (void)hipFree(c->d_present);
   if (c->d_code) (void)hipFree(c->d_code);
   if (c->d_words) (void)hipFree(c->d_words);
+  if (c->d_trace) (void)hipFree(c->d_trace);
   if (c->h_words) (void)hipHostFree(c->h_words);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -1554,6 +1586,34 @@ int32_t dc3hip_ctx_search(dc3hip_ctx *c, const uint8_t *needles, const int64_t *
   HIPC(hipMemcpyAsync(out_start, ds, (size_t)count * 8, hipMemcpyDefault, c->stream));
   HIPC(hipMemcpyAsync(out_len, dl, (size_t)count * 8, hipMemcpyDefault, c->stream));
   HIPC(hipStreamSynchronize(c->stream));
+  c->arena_off = 0;
+  return E_OK;
+}
+
+// Test hook for kernel-level parity (the reference's radix_pass, crates/dc3/src/lib.rs:15-39): ONE stable pass of
+// the product's radix scatter (up-sweep, scan, down-sweep) over n host words, digit = (word >> shift) & (nb - 1).
+int32_t dc3hip_ctx_debug_radix_pass_u64(dc3hip_ctx *c, const uint64_t *words, uint64_t *out, int64_t n, int32_t shift,
+                                        int32_t nb) {
+  if (!c || !words || !out || n < 1 || shift < 0 || shift > 55 || (nb != 256 && nb != 512)) { set_err("invalid arguments"); return E_ARGS; }
+  if ((size_t)n * 40 + (64u << 20) > c->arena_bytes) { set_err("n too large for this context"); return E_ARGS; }
+  HIPC(hipSetDevice(c->device));
+  c->arena_off = 0;
+  Rec8 *a = nullptr, *b = nullptr, *res = nullptr;
+  RC(arena_alloc(c, (size_t)n, &a));
+  RC(arena_alloc(c, (size_t)n, &b));
+  // Rec8 = {key (high half), val (low half)}: the in-memory u64 is (val | key << 32) only on the device side of
+  // rec8_word(); host words are split explicitly
+  std::vector<Rec8> h((size_t)n);
+  for (int64_t i = 0; i < n; i++) { h[(size_t)i].key = (u32)(words[i] >> 32); h[(size_t)i].val = (u32)words[i]; }
+  HIPC(hipMemcpyAsync(a, h.data(), (size_t)n * sizeof(Rec8), hipMemcpyHostToDevice, c->stream));
+  const bool saved = c->profile; c->profile = false;
+  int rc = nb == 512 ? radix_passes<Rec8, 512>(c, a, b, (u32)n, (u32)shift, (u32)shift + 9, &res, 0, 0, 0)
+                     : radix_passes<Rec8, 256>(c, a, b, (u32)n, (u32)shift, (u32)shift + 8, &res, 0, 0, 0);
+  c->profile = saved;
+  RC(rc);
+  HIPC(hipMemcpyAsync(h.data(), res, (size_t)n * sizeof(Rec8), hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  for (int64_t i = 0; i < n; i++) out[i] = ((uint64_t)h[(size_t)i].key << 32) | h[(size_t)i].val;
   c->arena_off = 0;
   return E_OK;
 }

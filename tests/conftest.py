@@ -91,6 +91,26 @@ class Oracle:
         assert d > 0, d
         return [[int(na[i]), int(ka[i])] for i in range(d)]
 
+    def trace_ex(self, data, cap=64):
+        """Per level: n, K, names and the three stage checksums (dc3_oracle_trace_ex)."""
+        t = self._u8(data)
+        f = self.lib.dc3_oracle_trace_ex
+        f.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int] + [ctypes.c_void_p] * 6
+        f.restype = ctypes.c_int
+        na = np.zeros(cap, dtype=np.int64); ka = np.zeros(cap, dtype=np.int64); nm = np.zeros(cap, dtype=np.int64)
+        h12 = np.zeros(cap, dtype=np.uint64); h0 = np.zeros(cap, dtype=np.uint64); hs = np.zeros(cap, dtype=np.uint64)
+        d = f(t.ctypes.data, len(t), cap, na.ctypes.data, ka.ctypes.data, nm.ctypes.data, h12.ctypes.data, h0.ctypes.data, hs.ctypes.data)
+        assert d > 0, d
+        return [{"n": int(na[i]), "K": int(ka[i]), "names": int(nm[i]), "sa12": int(h12[i]), "sa0": int(h0[i]), "sa": int(hs[i])}
+                for i in range(min(d, cap))]
+
+    def radix_pass(self, a, r, K):
+        """The reference's radix_pass (lib.rs:15-39): b = a stably sorted by r[a[i]], keys in 0..K."""
+        a = np.ascontiguousarray(a, dtype=np.uint64); r = np.ascontiguousarray(r, dtype=np.uint64)
+        b = np.zeros(len(a), dtype=np.uint64)
+        assert self.lib.dc3_oracle_radix_pass_u64(a.ctypes.data, b.ctypes.data, r.ctypes.data, len(a), K) == 0
+        return b
+
     def gen(self, n, seed, kind=0):
         b = np.zeros(n, dtype=np.uint8)
         self.lib.oracle_gen_bytes(b.ctypes.data, n, seed, kind)

@@ -694,3 +694,60 @@ def test_bench_two_ranks_on_one_gpu_matches_oracle(ss, oracle, tmp_path):
         chunk = np.load(tmp_path / f"chunk_{r}.npy"); sa = np.load(tmp_path / f"sa_{r}.npy")
         assert np.array_equal(chunk, full[off:off + ln])
         assert np.array_equal(sa, oracle.ref_sufsort(chunk) if oracle.ref is not None else oracle.sufsort(chunk))
+
+
+def test_stage_level_trace_matches_oracle(ss, oracle, corpus):
+    """Stage-level parity (SURVEY §5 tracing row; the counterpart of the reference's crosscheck!, crosscheck.rs:17-84):
+    with DC3HIP_TRACE=1 the library reports, per level, checksums of the sorted samples SA12, the sorted mod-0 suffixes
+    SA0 and the level's suffix array; the CPU restatement emits the same words.  In the configuration whose level
+    structure equals the reference's (no discarding, no prefix-sort / whole-level shortcuts) they must agree level by
+    level — a mismatch names the first failing level and stage instead of just "SA differs"."""
+    cases = dict((name, data) for name, (data, _) in corpus.items())
+    cases["kat_dc3"] = b"Once upon a time, in a land most dreary"
+    cases["text_300k"] = oracle.gen(300_001, 3, 2).tobytes()
+    cases["dna_200k"] = oracle.gen(200_000, 5, 1).tobytes()
+    cases["random_100k"] = oracle.gen(100_003, 2, 0).tobytes()
+    keys = ("DC3HIP_TRACE", "DC3HIP_NO_DISCARD", "DC3HIP_NO_HYBRID", "DC3HIP_NO_FULLSORT", "DC3HIP_NO_TEXT_SHORTCUT")
+    for k in keys:
+        os.environ[k] = "1"
+    try:
+        with ss.Context(max(len(v) for v in cases.values())) as c:
+            for name, data in cases.items():
+                c.set_text(data)
+                c.build()
+                got = c.stats()["trace"]
+                want = oracle.trace_ex(data)
+                assert got is not None and len(got) >= len(want), (name, len(got), len(want))
+                for lvl, (g, w) in enumerate(zip(got, want)):
+                    assert g["n"] == w["n"], f"{name}: level {lvl} length {g['n']} != {w['n']}"
+                    if g["names"] >= 0:          # sorted level: distinct triples (lib.rs:104); direct levels pack names
+                        assert g["names"] == w["names"], f"{name}: level {lvl} names {g['names']} != {w['names']}"
+                    for stage in ("sa12", "sa0", "sa"):
+                        assert g[stage] == w[stage], f"{name}: level {lvl} stage {stage} differs"
+    finally:
+        for k in keys:
+            os.environ.pop(k, None)
+
+
+@pytest.mark.parametrize("nb,shift", [(256, 0), (256, 13), (512, 0), (512, 23), (256, 48)])
+def test_one_radix_pass_equals_reference_radix_pass(ss, oracle, nb, shift):
+    """Kernel-level parity: ONE stable pass of the product's radix scatter (k_rs_upsweep / scan / k_rs_downsweep) against
+    the reference's radix_pass (crates/dc3/src/lib.rs:15-39) on the same keys: identical permutation, i.e. the same
+    stable order — tile boundaries, partial tiles, skewed and constant digits included."""
+    rng = np.random.default_rng(nb + shift)
+    with ss.Context(3_000_000) as c:
+        for n, skew in ((1, 0), (63, 0), (12_289, 0), (200_000, 0), (1_000_003, 0), (300_000, 1), (100_000, 2)):
+            if skew == 0:
+                key = rng.integers(0, 1 << 62, n, dtype=np.uint64)
+            elif skew == 1:                                   # a few hot digits
+                key = (rng.integers(0, 3, n).astype(np.uint64) << np.uint64(shift)) | rng.integers(0, 1 << shift if shift else 1, n, dtype=np.uint64)
+            else:                                             # one digit only
+                key = np.full(n, 5 << shift, dtype=np.uint64)
+            words = (key & np.uint64(~((1 << 32) - 1) & (2**64 - 1))) | np.arange(n, dtype=np.uint64)   # low half = original index
+            out = np.zeros(n, dtype=np.uint64)
+            rc = ss.lib().dc3hip_ctx_debug_radix_pass_u64(c._h, words.ctypes.data, out.ctypes.data, n, shift, nb)
+            assert rc == 0, ss.last_error()
+            digit = (words >> np.uint64(shift)) & np.uint64(nb - 1)
+            want = oracle.radix_pass(np.arange(n), digit, nb - 1)          # indices in stable digit order
+            assert np.array_equal(out & np.uint64(0xffffffff), want), (n, skew)
+            assert np.array_equal(out, words[want.astype(np.int64)])

@@ -158,3 +158,22 @@ def test_oracle_lcp_matches_naive(oracle):
                 h += 1
             want[i] = h
         assert got == want, data[:20]
+
+
+def test_trace_ex_words_are_consistent(oracle, corpus):
+    """dc3_oracle_trace_ex: the level-0 suffix-array word is the checksum of the golden SA (libdivsufsort's), the (n, K)
+    trace equals dc3_oracle_trace, and `names` is the next level's K wherever the recursion goes on (lib.rs:104)."""
+    def mix(i, v):
+        x = ((i << 32) | v) & (2**64 - 1)
+        x = (x + 0x9E3779B97F4A7C15) & (2**64 - 1)
+        x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & (2**64 - 1)
+        x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & (2**64 - 1)
+        return x ^ (x >> 31)
+    for name, (data, sa) in corpus.items():
+        tr = oracle.trace_ex(data)
+        assert [[t["n"], t["K"]] for t in tr] == oracle.trace(data), name
+        assert tr[0]["sa"] == sum(mix(k, int(p)) for k, p in enumerate(sa)) & (2**64 - 1), name
+        for a, b in zip(tr, tr[1:]):
+            assert a["names"] == b["K"], name
+        n02 = (tr[-1]["n"] + 2) // 3 + tr[-1]["n"] // 3
+        assert tr[-1]["names"] == n02, name          # the last level's names are all distinct (lib.rs:109)
