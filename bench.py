@@ -291,6 +291,29 @@ def main():
                     "path": PATH_NAMES.get(st3.get("text_sort_state", 0), "?"),
                     "roofline_path": path_roofline(st3, m)}
         out["per_config"] = per_cfg
+        # The GLOBAL mode (one suffix array over P ranks) as P loopback ranks on THIS GPU: the ranks
+        # time-share the device, so wall_ms is about the SUM of all ranks' work (work_inflation = wall / single-device
+        # build) — a correctness and total-work figure, not a scaling measurement.  Checked against the single-device
+        # checksum of the same text.
+        gl = []
+        gn = min(n, 256 << 20)
+        for gkind, gseed, gname in ((0, 2, "random"), (2, 3, "text")):
+            with ss.Context(gn, device=local_rank) as c4:
+                c4.generate(gn, gseed, gkind); c4.build(); c4.build()
+                single_ms = c4.stats()["build_ms"]; single_chk = c4.checksum()
+            for P in (2, 4):
+                with ss.LoopbackGroup(P, gn, device=local_rank) as g:
+                    g.generate(gn, gseed, gkind)
+                    g.build()
+                    t1 = time.perf_counter(); g.build(); wall = (time.perf_counter() - t1) * 1e3
+                    gst = g.stats()
+                    gl.append({"input": f"{gn >> 20} MiB {gname}", "ranks": P, "wall_ms": wall, "single_device_ms": single_ms,
+                               "work_inflation": wall / single_ms, "checksum_equal_single_device": g.checksum() == single_chk,
+                               "text_order": gst[0]["text_order"], "levels": gst[0]["levels"], "rank_exchanges": gst[0]["exchanges"],
+                               "bytes_in_per_rank": [x["comm_bytes_in"] for x in gst],
+                               "shard_counts": [x["shard_count"] for x in gst]})
+                    assert gl[-1]["checksum_equal_single_device"], "global-mode shards differ from the single-device suffix array"
+        out["global_mode_loopback"] = gl
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

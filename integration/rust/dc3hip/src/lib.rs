@@ -18,8 +18,10 @@ struct Dc3hipOpts {
 }
 const DC3HIP_F_ALL_DEVICES: i32 = 2;
 
-/// Sort suffixes of `text` and store their lexographic order in the given suffix array `sa`.
-/// Will panic if `sa.len()` != `text.len()`
+/// Builds the suffix array of `text` on the GPU into the caller's `sa` (one i32 per byte of `text`).
+/// Same contract as the workspace's other SACA crates: the two slices must have equal lengths and the
+/// text must be addressable with i32 indices; a library error (no device, out of HBM) panics, as the
+/// reference's `assert_eq!(0, ret)` does.
 pub fn sort_in_place(text: &[u8], sa: &mut [i32]) {
     assert_eq!(text.len(), sa.len(), "text and suffix array should have same len");
     assert!(
@@ -31,7 +33,7 @@ pub fn sort_in_place(text: &[u8], sa: &mut [i32]) {
     assert_eq!(0, ret);
 }
 
-/// Sort suffixes
+/// Allocating variant: returns a `sacabase::SuffixArray` that borrows `text` and owns the index array.
 pub fn sort<'a>(text: &'a [u8]) -> sacabase::SuffixArray<'a, i32> {
     let mut sa = vec![0; text.len()];
     sort_in_place(text, &mut sa);

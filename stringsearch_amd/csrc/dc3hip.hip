@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -202,7 +203,7 @@ static int launch_downsweep_to(dc3hip_ctx *c, Loader in, Sink dst, u32 n, const 
   constexpr bool PF = SortCfg<Rec, NB>::PF && std::is_same<Loader, ArrayLoader<Rec>>::value;
   const size_t smem = DownsweepSmem<Rec, IPT, NW, NB>::kBytes;
   auto kern = k_rs_downsweep<Rec, NB, IPT, NW, PF, Loader, Sink>;
-  static thread_local bool attr_set[16] = {false};
+  static std::atomic<bool> attr_set[16];   // (per function and device, process-wide; a double set is harmless)
   if (!attr_set[c->device & 15]) {
     HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)smem));
@@ -330,7 +331,7 @@ static void radix_plan(dc3hip_ctx *c, u32 n, u32 bits, int *nb, Chunking *ck) {
 // 16384 destinations are assembled in LDS and stored with full lines.
 // ---------------------------------------------------------------------------------------------
 static int inverse_permute(dc3hip_ctx *c, Rec8 *a, Rec8 *b, u32 n, u32 *out, int phase) {
-  static thread_local bool attr_set[16] = {false};
+  static std::atomic<bool> attr_set[16];   // (per function and device, process-wide; a double set is harmless)
   if (!attr_set[c->device & 15]) {
     HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_invperm_local),
                              hipFuncAttributeMaxDynamicSharedMemorySize, kInvWindow * 4));
@@ -1301,6 +1302,9 @@ int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) {
     HIPC(hipMalloc(&c->d_text, (size_t)max_n + 64));
     HIPC(hipMalloc(&c->d_sa, ((size_t)max_n + 16) * sizeof(u32)));
     c->arena_bytes = arena_requirement(max_n);
+    // testing aid: DC3HIP_ARENA_BYTES=<bytes> replaces the computed size (a build then either fits — possibly through
+    // a fallback ordering — or fails loudly with -2; it never returns a wrong array)
+    if (const char *e = getenv("DC3HIP_ARENA_BYTES")) { const long long v = atoll(e); if (v > 0) c->arena_bytes = (size_t)v; }
     HIPC(hipMalloc(&c->arena, c->arena_bytes));
     HIPC(hipMalloc(&c->d_present, 256 * sizeof(u32)));
     HIPC(hipMalloc(&c->d_code, 256 * sizeof(uint16_t)));

@@ -751,3 +751,37 @@ def test_one_radix_pass_equals_reference_radix_pass(ss, oracle, nb, shift):
             want = oracle.radix_pass(np.arange(n), digit, nb - 1)          # indices in stable digit order
             assert np.array_equal(out & np.uint64(0xffffffff), want), (n, skew)
             assert np.array_equal(out, words[want.astype(np.int64)])
+
+
+def test_short_arena_falls_back_or_fails_loudly(ss, oracle):
+    """ADVICE r1 (arena_requirement is not a bound for the whole-level order + general tie path): with the work arena
+    cut down step by step (DC3HIP_ARENA_BYTES) a build must take a cheaper ordering and still return the exact suffix
+    array, or fail with -2 (allocation) — never a wrong array, never a crash.  Input: mid-size alphabet (no whole-text
+    shortcut), a large duplicated region at an odd offset and a long run, the shape the advisor described."""
+    rng = np.random.default_rng(5)
+    x = rng.integers(0, 23, 2_400_000).astype(np.uint8) + 65
+    data = np.concatenate([x[:1_300_001], rng.integers(0, 23, 700_003).astype(np.uint8) + 65, x[37:1_200_000],
+                           np.full(40_000, 66, dtype=np.uint8), x[5:300_000]])
+    n = len(data)
+    want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)
+    with ss.Context(n) as c:
+        c.set_text(data); c.build()
+        full = c.stats()["arena_bytes"]
+        assert np.array_equal(c.sa(), want)
+    outcomes = set()
+    for pct in (100, 85, 70, 60, 50, 42, 35, 28, 20, 12):
+        os.environ["DC3HIP_ARENA_BYTES"] = str(full * pct // 100)
+        try:
+            with ss.Context(n) as c:
+                c.set_text(data)
+                try:
+                    c.build()
+                except ss.Dc3HipError as e:
+                    assert e.code == -2, (pct, e)
+                    outcomes.add("alloc")
+                    continue
+                assert np.array_equal(c.sa(), want), pct
+                outcomes.add(tuple(c.stats()["level_sorted"]))
+        finally:
+            os.environ.pop("DC3HIP_ARENA_BYTES", None)
+    assert "alloc" in outcomes and len(outcomes) >= 2      # both behaviours were exercised
