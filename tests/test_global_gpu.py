@@ -168,3 +168,41 @@ def test_bench_global_two_processes_on_one_gpu(ss, oracle, tmp_path):
         text = oracle.gen(2 * size, 2, {"random": 0, "text": 2}[kind])
         got = np.concatenate([np.load(tmp_path / f"gshard_{r}.npy") for r in range(2)])
         assert np.array_equal(got, want_sa(oracle, text)), kind
+
+
+@pytest.mark.parametrize("P", [3, 5, 7, 16])
+def test_loopback_odd_rank_counts_and_max_ranks(ss, oracle, P):
+    """Rank counts that do not divide anything evenly (splitter arithmetic, empty key ranges, digit ranges of the rank
+    exchange that do not split evenly) and the maximum of 16 ranks; lengths chosen so that n % 3 and the level lengths
+    hit all dummy / no-dummy combinations."""
+    with env(DC3HIP_GLOBAL_LOCAL_MAX=200, DC3HIP_GLOBAL_NO_TEXT_ORDER=1):
+        with ss.LoopbackGroup(P, 260_000) as g:
+            for n, kind, seed in [(100_000, 2, 1), (100_001, 1, 2), (100_002, 0, 3), (259_999, 2, 4), (17_003, 1, 5), (4_099, 2, 6)]:
+                t = oracle.gen(n, seed, kind)
+                g.set_text(t)
+                g.build()
+                assert np.array_equal(g.sa(), want_sa(oracle, t)), (n, kind, P)
+    # skewed keys: one byte value dominates, so most of a level's samples fall into ONE rank's key range
+    rng = np.random.default_rng(P)
+    t = np.where(rng.random(150_000) < 0.97, 97, rng.integers(98, 101, 150_000)).astype(np.uint8)
+    with env(DC3HIP_GLOBAL_LOCAL_MAX=200):
+        with ss.LoopbackGroup(P, len(t)) as g:
+            g.set_text(t)
+            g.build()
+            assert np.array_equal(g.sa(), want_sa(oracle, t))
+            counts = [s["shard_count"] for s in g.stats()]
+            assert sum(counts) == len(t) and max(counts) <= 3 * len(t) // P + 64      # output slices stay balanced
+
+
+def test_loopback_env_matrix_agrees(ss, oracle):
+    """The orderings the global level driver can take (whole-level order, image-range prefix sort, straight key-range
+    sort, discarding on/off) give the same bytes."""
+    t = np.concatenate([oracle.gen(1_200_000, 3, 2), oracle.gen(600_000, 2, 0), oracle.gen(1_200_000, 3, 2)[100_000:700_000]])
+    want = want_sa(oracle, t)
+    for extra in ({}, {"DC3HIP_NO_HYBRID": 1}, {"DC3HIP_NO_FULLSORT": 1}, {"DC3HIP_NO_DISCARD": 1},
+                  {"DC3HIP_NO_HYBRID": 1, "DC3HIP_NO_DISCARD": 1}, {"DC3HIP_NO_SMALL_TIES": 1}, {"DC3HIP_NO_SPLIT_EMIT": 1}):
+        with env(DC3HIP_GLOBAL_LOCAL_MAX=5000, **extra):
+            with ss.LoopbackGroup(4, len(t)) as g:
+                g.set_text(t)
+                g.build()
+                assert np.array_equal(g.sa(), want), extra
