@@ -476,6 +476,11 @@ static int gorder_positions(dc3hip_gctx *G, KM km, u32 m, u32 kbits, const HiMap
   const int P = cm->nranks, me = cm->rank;
   *done = false;
   const ArenaMark mk = arena_mark(c);
+  // the slice first (worst case: every position in my range), so that the sort's temporaries can be released before
+  // the result is delivered (the rank exchange needs the room)
+  u32 *slice = (mode == G_TOP) ? c->d_sa : nullptr;
+  if (!slice) RC(arena_alloc(c, (size_t)m + 16, &slice));
+  const ArenaMark mk_tmp = arena_mark(c);
   u64 lo = 0, hi = ~0ull;
   {
     u32 ns = (u32)std::min<u64>(m, (u64)2048 * P);
@@ -491,8 +496,6 @@ static int gorder_positions(dc3hip_gctx *G, KM km, u32 m, u32 kbits, const HiMap
   Rec8 *ha = nullptr, *hb = nullptr, *h = nullptr; uint8_t *f = nullptr;
   u32 nrec = 0;
   RC(select_records(c, sel, m, &ha, &nrec, DC3HIP_PH_PACK));
-  u32 *slice = (mode == G_TOP) ? c->d_sa : nullptr;
-  if (!slice) RC(arena_alloc(c, (size_t)nrec + 16, &slice));
   RC(arena_alloc(c, (size_t)nrec + 16, &hb));
   RC(arena_alloc(c, (size_t)nrec + 16, &f));
   bool ok = true, distinct = true;
@@ -501,6 +504,7 @@ static int gorder_positions(dc3hip_gctx *G, KM km, u32 m, u32 kbits, const HiMap
   RC(gather_counts(cm, (ok && distinct) ? 1 : 0, &good, &ngood));
   RC(gather_counts(cm, nrec, &pre, &tot, all));
   if (tot != m) { set_err("global order: %llu of %u positions selected", (unsigned long long)tot, m); return E_HIP; }
+  arena_release(c, mk_tmp);
   if (ngood == (uint64_t)P) {
     *done = true;
     RC(deliver(G, slice, nrec, pre, all, m, out, mode));
@@ -517,10 +521,11 @@ static int glevel(dc3hip_gctx *G, Sym S, u32 m, u64 K, int depth, u32 *out, GOut
 
 // Sorted naming of this rank's key range (lib.rs:80-100), generic over the accessor of the sorted order.
 //   counts of distinct / unique names go around (all-gather of two words), names continue after those of the smaller
-//   key ranges (equal keys never straddle ranks), and (slot, name [| unique << 31]) pairs are exchanged into R.
+//   key ranges (equal keys never straddle ranks); the (slot, name [| unique << 31]) pairs land in the caller's buffer
+//   pa (m02 entries), which the caller exchanges into R AFTER releasing its sort buffers.
 template <class Acc>
-static int gname_exchange(dc3hip_gctx *G, Acc acc, u32 cnt, u32 m0, u32 m02, u32 *R, u32 *sslot, uint64_t *names_total,
-                          uint64_t *uniq_total, uint64_t *cnt_pre, bool *discard) {
+static int gname_pairs(dc3hip_gctx *G, Acc acc, u32 cnt, u32 m0, u32 m02, Rec8 *pa, u32 *sslot, uint64_t *names_total,
+                       uint64_t *uniq_total, uint64_t *cnt_pre, bool *discard) {
   dc3hip_ctx *c = G->c; GComm *cm = G->comm;
   const ArenaMark mk = arena_mark(c);
   const Chunking ck = make_chunks(c, std::max<u32>(cnt, 1), kBlock * kNameIPT);
@@ -546,8 +551,6 @@ static int gname_exchange(dc3hip_gctx *G, Acc acc, u32 cnt, u32 m0, u32 m02, u32
   // discarding (see discard_recurse): worth it when ~1/6 of the slots would leave the recursion
   const double drop_est = (double)*uniq_total * (double)*uniq_total / (double)m02;
   *discard = sslot && *names_total != m02 && !c->no_discard && m02 < 0x7fffffffu && drop_est * kDiscardMinDropInv >= (double)m02;
-  Rec8 *pa = nullptr;
-  RC(arena_alloc(c, (size_t)cnt + 16, &pa));
   if (cnt) {
     PhaseScope ps(c, DC3HIP_PH_NAMING, cnt);
     if (name_off) {
@@ -558,9 +561,6 @@ static int gname_exchange(dc3hip_gctx *G, Acc acc, u32 cnt, u32 m0, u32 m02, u32
                        *discard ? sslot : (u32 *)nullptr);
     KCHECK();
   }
-  RC(rank_exchange(G, pa, cnt, m02, R, DC3HIP_PH_NAMING));      // R[slot] = name (| unique << 31), everywhere
-  hipLaunchKernelGGL(k_zero_tail, dim3(1), dim3(64), 0, c->stream, R, m02, 8u);
-  KCHECK();
   arena_release(c, mk);
   return E_OK;
 }
@@ -703,6 +703,8 @@ static int glevel(dc3hip_gctx *G, Sym S, u32 m, u64 K, int depth, u32 *out, GOut
     { unsigned __int128 mx = (unsigned __int128)B * B * B - 1; while (mx) { kbits++; mx >>= 1; } }
     u32 *sslot = nullptr;                          // my range of the sorted slots (| unique << 31), for the discarding
     RC(arena_alloc(c, (size_t)m02 + 16, &sslot));
+    Rec8 *pa = nullptr;                            // my (slot, name) pairs: below the sort buffers, which go before the exchange
+    RC(arena_alloc(c, (size_t)m02 + 16, &pa));
     const ArenaMark mk1 = arena_mark(c);
     const HiMap hm = make_himap(B, kbits, m);
     double pred = 1.0;
@@ -747,7 +749,7 @@ static int glevel(dc3hip_gctx *G, Sym S, u32 m, u64 K, int depth, u32 *out, GOut
       if (ngood == (uint64_t)P) {
         c->stats.level_sorted[depth] = 2;
         AccHyb acc; acc.h = h; acc.f = f; acc.posmask = hm.pbits >= 32 ? 0xffffffffu : ((1u << hm.pbits) - 1u);
-        RC(gname_exchange<AccHyb>(G, acc, cnt, m0, m02, R, sslot, &names_total, &uniq_total, &cnt_pre, &discard));
+        RC(gname_pairs<AccHyb>(G, acc, cnt, m0, m02, pa, sslot, &names_total, &uniq_total, &cnt_pre, &discard));
         named = true;
       } else {
         arena_release(c, mk1);                       // too many ties somewhere: every rank takes the straight sort
@@ -782,9 +784,12 @@ static int glevel(dc3hip_gctx *G, Sym S, u32 m, u64 K, int depth, u32 *out, GOut
       sorted = recA;
       if (cnt) RC(radix_sort<Rec16>(c, recA, recB, cnt, 0, kbits, &sorted, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT12_DOWN));
       AccRec<Rec16> acc; acc.s = sorted;
-      RC(gname_exchange<AccRec<Rec16>>(G, acc, cnt, m0, m02, R, sslot, &names_total, &uniq_total, &cnt_pre, &discard));
+      RC(gname_pairs<AccRec<Rec16>>(G, acc, cnt, m0, m02, pa, sslot, &names_total, &uniq_total, &cnt_pre, &discard));
     }
     arena_release(c, mk1);
+    RC(rank_exchange(G, pa, cnt, m02, R, DC3HIP_PH_NAMING));      // R[slot] = name (| unique << 31), everywhere
+    hipLaunchKernelGGL(k_zero_tail, dim3(1), dim3(64), 0, c->stream, R, m02, 8u);
+    KCHECK();
     if (names_total == m02) {
       rank12 = R;                                                 // all names distinct: the names are the ranks (lib.rs:109-113)
     } else if (discard) {
@@ -801,6 +806,11 @@ static int glevel(dc3hip_gctx *G, Sym S, u32 m, u64 K, int depth, u32 *out, GOut
   KCHECK();
 
   // ---- Step 2 + 3, split by rank range (lib.rs:118-192) -------------------------------------------------------
+  // my slice of the level's suffix array comes first on the stack (worst case: everything), so that the tuples can be
+  // released before it is delivered
+  u32 *slice = (mode == G_TOP) ? c->d_sa : nullptr;
+  if (!slice) RC(arena_alloc(c, (size_t)m + 16, &slice));
+  const ArenaMark mk_merge = arena_mark(c);
   // slot-order sample tuples for the whole level (streaming, every rank)
   Tup12 *tslot = nullptr;
   RC(arena_alloc(c, (size_t)m02, &tslot));
@@ -874,9 +884,8 @@ static int glevel(dc3hip_gctx *G, Sym S, u32 m, u64 K, int depth, u32 *out, GOut
   uint64_t pre = 0, tot = 0, all[kMaxRanks];
   RC(gather_counts(cm, total, &pre, &tot, all));
   if (tot != m) { set_err("global merge: slices hold %llu of %u suffixes", (unsigned long long)tot, m); return E_HIP; }
-  u32 *slice = (mode == G_TOP) ? c->d_sa : nullptr;
-  if (!slice) RC(arena_alloc(c, (size_t)total + 16, &slice));
   RC(merge_lists(c, A, nA, reinterpret_cast<const Tup0 *>(zs), nB, slice, nullptr, 0u));
+  arena_release(c, mk_merge);
   RC(deliver(G, slice, total, pre, all, m, out, mode));
   arena_release(c, mk0);
   return E_OK;

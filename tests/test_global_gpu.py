@@ -206,3 +206,22 @@ def test_loopback_env_matrix_agrees(ss, oracle):
                 g.set_text(t)
                 g.build()
                 assert np.array_equal(g.sa(), want), extra
+
+
+def test_single_rank_forced_distributed_fits_the_arena(ss, oracle):
+    """One rank doing ALL the distributed work (DC3HIP_GLOBAL_FORCE_DIST=1) is the memory worst case of the level driver
+    (every key range, every rank range and every exchange block is the whole level): it must fit the context's arena —
+    a rank whose splitters degenerate is in the same position — and give the single-device checksum."""
+    n = 48 << 20
+    with env(DC3HIP_GLOBAL_FORCE_DIST=1):
+        for kind, seed in ((0, 2), (2, 3), (1, 5)):
+            with ss.LoopbackGroup(1, n) as g:
+                g.generate(n, seed, kind)
+                g.build()
+                chk = g.checksum()
+                st = g.stats()[0]
+                assert st["local_from_level"] != 0
+            with ss.Context(n) as c:
+                c.generate(n, seed, kind)
+                c.build()
+                assert c.checksum() == chk, kind
