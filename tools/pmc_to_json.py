@@ -27,6 +27,11 @@ if st["gather_elems"]: res["bytes_per_record"]["gather_tuples"] = tot(lambda k: 
 if st["partition_elems"]: res["bytes_per_record"]["partition_pairs"] = tot(lambda k: "k_part_msd" in k, 2) / st["partition_elems"]
 for k in sorted(set(F) | set(W), key=lambda k: -(2 * F.get(k, 0) + W.get(k, 0))):
     res["per_kernel_bytes"][k] = {"fetch_raw": F.get(k, 0), "write": W.get(k, 0)}
+try:
+    import subprocess
+    res["commit"] = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True).strip()
+except Exception:
+    res["commit"] = None
 res["whole_build_bytes_streaming_corrected"] = sum(2 * F.get(k, 0) + W.get(k, 0) for k in set(F) | set(W) if "gather" not in k) + tot(lambda k: "k_gather_tuples" in k, 1)
 res["build_ms_under_pmc"] = st["build_ms"]
 res["levels"] = list(zip(st["level_n"], st["level_sorted"]))
