@@ -28,7 +28,7 @@
 
 using namespace dc3;
 
-#define DC3HIP_VERSION_STR "dc3hip 0.1.0 (gfx950, HIP)"
+#define DC3HIP_VERSION_STR "dc3hip 0.2.0 (gfx950, HIP)"
 
 // ---------------------------------------------------------------------------------------------
 // errors
