@@ -45,6 +45,38 @@ __global__ __launch_bounds__(kBlock) void k_sel_write(Sel sel, u32 nitems, u32 c
   }
 }
 
+// One-evaluation form: block b owns chunk b and writes the records it keeps, compacted, at the START of the chunk's
+// own region of a staging array (stage[b*chunk ..)); counts[b] = how many.  After the scan of the counts k_sel_copy
+// moves the segments next to each other.  pick() runs once per item instead of twice; the extra traffic is one
+// read + write of the kept records only.
+template <class Sel>
+__global__ __launch_bounds__(kBlock) void k_sel_stage(Sel sel, u32 nitems, u32 chunk, typename Sel::Out *__restrict__ stage,
+                                                     u32 *__restrict__ counts) {
+  __shared__ u32 tmp[kWaves];
+  __shared__ uint16_t lcode[256];
+  sel.stage(lcode);
+  const u32 begin = blockIdx.x * chunk, end = min(nitems, begin + chunk);
+  u32 running = 0;
+  for (u32 tile = begin; tile < end; tile += kBlock) {
+    const u32 i = tile + threadIdx.x;
+    typename Sel::Out o;
+    const bool f = (i < end) && sel.pick(i, lcode, o);
+    u32 tot;
+    const u32 ex = block_excl_scan<kWaves>(f ? 1u : 0u, tmp, tot);
+    if (f) stage[(size_t)begin + running + ex] = o;
+    running += tot;
+  }
+  if (threadIdx.x == 0) counts[blockIdx.x] = running;
+}
+template <class Out>
+__global__ __launch_bounds__(kBlock) void k_sel_copy(const Out *__restrict__ stage, u32 chunk, u32 nchunks,
+                                                    const u32 *__restrict__ base_excl, u32 total, Out *__restrict__ out) {
+  const u32 b = blockIdx.x;
+  const u32 lo = base_excl[b], hi = (b + 1 < nchunks) ? base_excl[b + 1] : total;
+  const Out *src = stage + (size_t)b * chunk;
+  for (u32 j = threadIdx.x; j < hi - lo; j += kBlock) out[lo + j] = src[j];
+}
+
 // 96-bit key order of Rec16 (k2 most significant)
 __device__ __forceinline__ bool key_lt(const Rec16 &a, const Rec16 &b) {
   if (a.k2 != b.k2) return a.k2 < b.k2;

@@ -305,12 +305,45 @@ static int gather_counts(GComm *cm, uint64_t mine, uint64_t *prefix, uint64_t *t
   return E_OK;
 }
 
-// order-preserving selection (k_sel_count / scan / k_sel_write); *out is allocated from the arena
+// order-preserving selection; *out is allocated from the arena.  One evaluation of the selector per item when the
+// arena has room for the chunk-local staging array (k_sel_stage / scan / k_sel_copy), else count / scan / write.
 template <class Sel>
 static int select_records(dc3hip_ctx *c, const Sel &sel, u32 nitems, typename Sel::Out **out, u32 *count, int phase) {
+  typedef typename Sel::Out Out;
   const Chunking ck = make_chunks(c, nitems, kBlock);
   u32 *counts = nullptr;
   RC(arena_alloc(c, (size_t)ck.nchunks + 16, &counts));
+  const size_t stage_bytes = align_up((size_t)nitems * sizeof(Out), 256);
+  // staged form needs the staging array ABOVE the result (it is released afterwards), so the result is placed first with
+  // its worst-case size only when that is affordable; otherwise the two-evaluation form
+  const bool staged = c->arena_bytes - c->arena_off >= 2 * stage_bytes + (64u << 20);
+  if (staged) {
+    Out *res = nullptr, *stage = nullptr;
+    RC(arena_alloc(c, (size_t)nitems + 16, &res));         // shrunk to the real count below
+    const ArenaMark mk_stage = arena_mark(c);
+    RC(arena_alloc(c, (size_t)nitems, &stage));
+    {
+      PhaseScope ps(c, phase, nitems);
+      hipLaunchKernelGGL((k_sel_stage<Sel>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, sel, nitems, ck.chunk, stage, counts);
+      KCHECK();
+      hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, counts, ck.nchunks, c->d_words + 32);
+      KCHECK();
+      HIPC(hipMemcpyAsync(c->h_words + 32, c->d_words + 32, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPC(hipStreamSynchronize(c->stream));
+    *count = c->h_words[32];
+    if (*count) {
+      PhaseScope ps(c, phase, *count);
+      hipLaunchKernelGGL((k_sel_copy<Out>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, stage, ck.chunk, ck.nchunks, counts,
+                         *count, res);
+      KCHECK();
+    }
+    // give back the staging array and the unused tail of the result
+    arena_release(c, mk_stage);
+    c->arena_off = (size_t)(reinterpret_cast<unsigned char *>(res) - c->arena) + align_up(((size_t)*count + 16) * sizeof(Out), 256);
+    *out = res;
+    return E_OK;
+  }
   {
     PhaseScope ps(c, phase, nitems);
     hipLaunchKernelGGL((k_sel_count<Sel>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, sel, nitems, ck.chunk, counts);
