@@ -106,4 +106,87 @@ class DeviceIndex : public sacabase::StringIndex {
   }
 };
 
+// GLOBAL mode (include/dc3hip.h): ONE suffix array of a text over P ranks.  GlobalLoopback = P ranks on one device in
+// this process (tests, single-GPU boxes); a multi-process host builds one GlobalRank per GPU from a 128-byte RCCL id it
+// distributes itself (MPI_Bcast, a file, ...).  Shards in rank order concatenate to what dc3hip::sort_i64 returns.
+class GlobalRank {
+  dc3hip_gctx *g_ = nullptr;
+  friend class GlobalLoopback;
+  explicit GlobalRank(dc3hip_gctx *g) : g_(g) {}
+
+ public:
+  static std::vector<uint8_t> rccl_unique_id() {
+    std::vector<uint8_t> id(128);
+    const int rc = dc3hip_rccl_unique_id(id.data());
+    if (rc != 0) throw Error(rc, dc3hip_last_error());
+    return id;
+  }
+  GlobalRank(const std::vector<uint8_t> &id128, int rank, int nranks, int device, int64_t max_total_n) {
+    const int rc = dc3hip_global_rccl_create(&g_, id128.data(), rank, nranks, device, max_total_n);
+    if (rc != 0) throw Error(rc, dc3hip_last_error());
+  }
+  GlobalRank(GlobalRank &&o) noexcept : g_(o.g_) { o.g_ = nullptr; }
+  GlobalRank(const GlobalRank &) = delete;
+  ~GlobalRank() { if (g_) dc3hip_global_destroy(g_); }
+  dc3hip_gctx *handle() const { return g_; }
+  // this rank's bytes of a text of total_n bytes: [offset, offset + length)
+  void block(int64_t total_n, int64_t *offset, int64_t *length) const {
+    const int rc = dc3hip_global_block(g_, total_n, offset, length);
+    if (rc != 0) throw Error(rc, dc3hip_last_error());
+  }
+  void set_text_block(const uint8_t *block_bytes, int64_t total_n) {
+    const int rc = dc3hip_global_set_text_block(g_, block_bytes, total_n);
+    if (rc != 0) throw Error(rc, dc3hip_last_error());
+  }
+  void build() {                                               // collective
+    const int rc = dc3hip_global_build(g_);
+    if (rc != 0) throw Error(rc, dc3hip_global_last_error(g_));
+  }
+  // SA[first .. first + shard.size())
+  std::vector<int64_t> shard(int64_t *first) const {
+    int64_t cnt = 0;
+    int rc = dc3hip_global_shard(g_, first, &cnt);
+    if (rc != 0) throw Error(rc, dc3hip_last_error());
+    std::vector<int64_t> out((size_t)cnt);
+    static int64_t dummy = 0;
+    rc = dc3hip_global_get_shard_i64(g_, cnt ? out.data() : &dummy);
+    if (rc != 0) throw Error(rc, dc3hip_last_error());
+    return out;
+  }
+};
+
+class GlobalLoopback {
+  std::vector<dc3hip_gctx *> h_;
+
+ public:
+  GlobalLoopback(int nranks, int64_t max_total_n, int device = -1) : h_((size_t)nranks, nullptr) {
+    const int rc = dc3hip_global_loopback_create(h_.data(), nranks, device, max_total_n);
+    if (rc != 0) throw Error(rc, dc3hip_last_error());
+  }
+  GlobalLoopback(const GlobalLoopback &) = delete;
+  ~GlobalLoopback() { for (auto *g : h_) if (g) dc3hip_global_destroy(g); }
+  // the whole text lives on this host: every rank takes its block
+  sacabase::SuffixArray<int64_t> sort(sacabase::Bytes text) {
+    for (auto *g : h_) {
+      int64_t off = 0, len = 0;
+      int rc = dc3hip_global_block(g, (int64_t)text.len, &off, &len);
+      if (rc == 0) rc = dc3hip_global_set_text_block(g, text.ptr + off, (int64_t)text.len);
+      if (rc != 0) throw Error(rc, dc3hip_last_error());
+    }
+    const int rc = dc3hip_global_loopback_build(h_.data(), (int32_t)h_.size());
+    if (rc != 0) throw Error(rc, dc3hip_last_error());
+    std::vector<int64_t> sa;
+    sa.reserve(text.len);
+    for (auto *g : h_) {
+      GlobalRank r(g);
+      int64_t first = 0;
+      std::vector<int64_t> part = r.shard(&first);
+      r.g_ = nullptr;                                          // (borrowed handle)
+      if ((size_t)first != sa.size()) throw std::runtime_error("global mode: shards do not tile the suffix array");
+      sa.insert(sa.end(), part.begin(), part.end());
+    }
+    return sacabase::SuffixArray<int64_t>(text, std::move(sa));
+  }
+};
+
 }  // namespace dc3hip

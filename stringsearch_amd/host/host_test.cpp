@@ -3,6 +3,7 @@
 //   sacapart/src/lib.rs:105-128 worse_test, :130-165 equivalent_test, divsufsort/src/lib.rs:83-91 shruggy
 #include <cassert>
 #include <cstdio>
+#include <cstdlib>
 #include "dc3hip.hpp"
 #include "sacapart.hpp"
 using sacabase::Bytes;
@@ -69,6 +70,18 @@ int main() {
       CHECK(b.longest_substring_match(Bytes(std::string("find matches that span"))).len ==
             a.longest_substring_match(Bytes(std::string("find matches that span"))).len);
     }
+  }
+  {  // global mode: one suffix array over 3 loopback ranks == the single-device array (and it verifies)
+    std::string input;
+    for (int i = 0; i < 4000; i++) input += "This is a rather long text. We can probably find matches that span two partitions. Oh yes. ";
+    input += "tail";
+    auto one = dc3hip::sort_i64(Bytes(input));
+    setenv("DC3HIP_GLOBAL_LOCAL_MAX", "100", 1);
+    dc3hip::GlobalLoopback grp(3, (int64_t)input.size());
+    unsetenv("DC3HIP_GLOBAL_LOCAL_MAX");
+    auto all = grp.sort(Bytes(input));
+    CHECK(all.sa() == one.sa());
+    CHECK(all.longest_substring_match(Bytes(std::string("matches that span two"))).len == 21);
   }
   {  // error behaviour: len mismatch throws like the Rust assert
     std::vector<int32_t> sa(2);
