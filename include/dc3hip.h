@@ -220,6 +220,9 @@ DC3HIP_API int32_t dc3hip_ctx_debug_radix_pass_u64(dc3hip_ctx *ctx, const uint64
  * Transport: RCCL over xGMI (one process per GPU; the host program carries the 128-byte unique id from rank 0 to
  * the others, e.g. with torch.distributed / MPI), or the in-process loopback (P ranks on ONE device, used to
  * parity-test P in {2,4,8} on a single-GPU box).  n <= DC3HIP_MAX_N; P <= 16.
+ * Failure semantics: a build that fails on one rank (e.g. -2) returns there at once; loopback peers are released and
+ * return -3 ("another rank failed"), and the group can be used again.  RCCL / host-staged peers are inside a collective
+ * at that point and keep waiting, as in any NCCL program: the host job's watchdog has to tear the group down.
  * Environment: DC3HIP_GLOBAL_LOCAL_MAX (levels up to this length are finished by every rank on its own replicated
  * copy, default 2^22), DC3HIP_GLOBAL_NO_TEXT_ORDER=1 (skip the distributed whole-text order). */
 typedef struct dc3hip_gctx dc3hip_gctx;

@@ -43,6 +43,7 @@ struct GComm {
   // small host values: out[r*bytes ..] = rank r's in[0..bytes)
   virtual int all_gather_host(const void *in, void *out, size_t bytes) = 0;
   virtual void abort_all() {}
+  virtual void reset_all() {}          // before a new collective build of the whole group (no rank inside a collective)
   virtual const char *name() const = 0;
 };
 struct CommTimer {
@@ -68,11 +69,13 @@ struct LoopWorld {
     return !failed;
   }
   void fail() { std::lock_guard<std::mutex> lk(mu); failed = true; cv.notify_all(); }
+  void reset() { std::lock_guard<std::mutex> lk(mu); failed = false; arrived = 0; }
 };
 struct LoopComm : GComm {
   std::shared_ptr<LoopWorld> w;
   const char *name() const override { return "loopback (in-process, hipMemcpyAsync)"; }
   void abort_all() override { w->fail(); }
+  void reset_all() override { w->reset(); }
   int sync_fail() { set_err("loopback transport: another rank failed"); return E_HIP; }
   int all_to_all_v(const void *send, const size_t *soff, const size_t *sbytes, void *recv, const size_t *roff,
                    const size_t *rbytes, hipStream_t st) override {
@@ -1146,6 +1149,7 @@ int32_t dc3hip_global_build(dc3hip_gctx *G) { return gbuild(G); }
 int32_t dc3hip_global_loopback_build(dc3hip_gctx **ranks, int32_t P) {
   if (!ranks || P < 1 || P > kMaxRanks) { set_err("invalid arguments"); return E_ARGS; }
   for (int r = 0; r < P; r++) if (!ranks[r] || ranks[r]->comm->nranks != P) { set_err("not a loopback group of %d ranks", P); return E_ARGS; }
+  ranks[0]->comm->reset_all();         // a failure of an earlier build no longer poisons the group
   std::vector<int> rcs((size_t)P, E_OK);
   std::vector<std::thread> pool;
   for (int r = 0; r < P; r++) pool.emplace_back([&, r]() { rcs[(size_t)r] = gbuild(ranks[r]); });

@@ -225,3 +225,23 @@ def test_single_rank_forced_distributed_fits_the_arena(ss, oracle):
                 c.generate(n, seed, kind)
                 c.build()
                 assert c.checksum() == chk, kind
+
+
+@pytest.mark.timeout(120)
+def test_loopback_rank_failure_releases_the_group(ss, oracle):
+    """A rank that fails (work arena too small: -2) must not leave the others waiting in a collective: the group build
+    returns the failing rank's error promptly, and the group is usable again with a smaller text."""
+    n = 3_000_000
+    with env(DC3HIP_ARENA_BYTES=48 << 20, DC3HIP_GLOBAL_LOCAL_MAX=1000, DC3HIP_GLOBAL_NO_TEXT_ORDER=1):
+        g = ss.LoopbackGroup(4, n)
+    try:
+        g.set_text(oracle.gen(n, 3, 2))
+        with pytest.raises(ss.Dc3HipError) as ei:
+            g.build()
+        assert ei.value.code == -2 and "arena" in str(ei.value)
+        small = oracle.gen(40_000, 3, 2)
+        g.set_text(small)
+        g.build()
+        assert np.array_equal(g.sa(), want_sa(oracle, small))
+    finally:
+        g.close()
