@@ -847,58 +847,51 @@ static int glevel(dc3hip_gctx *G, Sym S, u32 m, u64 K, int depth, u32 *out, GOut
   u32 *slice = (mode == G_TOP) ? c->d_sa : nullptr;
   if (!slice) RC(arena_alloc(c, (size_t)m + 16, &slice));
   const ArenaMark mk_merge = arena_mark(c);
-  // slot-order sample tuples for the whole level (streaming, every rank)
-  Tup12 *tslot = nullptr;
-  RC(arena_alloc(c, (size_t)m02, &tslot));
-  {
-    PhaseScope ps(c, DC3HIP_PH_TUPLES, m02);
-    hipLaunchKernelGGL((k_build_tuples<Sym>), dim3(grid_for(c, m0)), dim3(kBlock), 0, c->stream, S, m, m0, m02, rank12, tslot);
-    KCHECK();
-  }
   // rank g owns the output between splitter samples g and g+1; the splitters are the samples of rank bound[g]
   const u32 dskip = m0 - m1;                      // lib.rs:133: the dummy has sample rank 1 and is not a suffix
   const u32 first_rank = 1 + dskip, nAtot = m02 - dskip;
   u32 bound[kMaxRanks + 1];
   for (int h = 0; h <= P; h++) bound[h] = first_rank + (u32)((u64)nAtot * h / P);
-  Splitters sp; memset(&sp, 0, sizeof(sp)); sp.n = (u32)(P - 1);
+  const u32 nsp = (u32)(P - 1);
   if (P > 1) {
-    RankTargets t; memset(&t, 0, sizeof(t)); t.n = (u32)(P - 1);
+    RankTargets t; memset(&t, 0, sizeof(t)); t.n = nsp;
     for (int h = 1; h < P; h++) t.r[h - 1] = bound[h];
     HIPC(hipMemsetAsync(c->d_words + 40, 0xff, kMaxRanks * sizeof(u32), c->stream));
     hipLaunchKernelGGL(k_find_ranks, dim3(grid_for(c, m02)), dim3(kBlock), 0, c->stream, rank12, m02, t, c->d_words + 40);
     KCHECK();
     HIPC(hipMemcpyAsync(c->h_words + 40, c->d_words + 40, kMaxRanks * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
-    for (int h = 1; h < P; h++) {
-      const u32 slot = c->h_words[40 + h - 1];
-      if (slot >= m02) { set_err("global merge: sample rank %u not found (rank12 is not a bijection)", bound[h]); return E_HIP; }
-      HIPC(hipMemcpyAsync(&sp.a[h - 1], tslot + slot, sizeof(Tup12), hipMemcpyDeviceToHost, c->stream));
-    }
-    HIPC(hipStreamSynchronize(c->stream));
+    for (int h = 1; h < P; h++)
+      if (c->h_words[40 + h - 1] >= m02) { set_err("global merge: sample rank %u not found (rank12 is not a bijection)", bound[h]); return E_HIP; }
   }
   const u32 lo = bound[me], hi = bound[me + 1], nA = hi - lo;
-  // A: my samples in rank order = windowed inversion of (rank - lo, slot), then the tuple gather
+  // A: my samples in rank order = windowed inversion of (rank - lo, slot), then the tuple gather (slot table built by
+  // every rank, streaming).  The P-1 splitter samples ride along behind my nA slots; their tuples come back to the host.
   Tup12 *A = nullptr;
-  RC(arena_alloc(c, (size_t)nA + 16, &A));
+  RC(arena_alloc(c, (size_t)nA + nsp + 16, &A));
+  Splitters sp; memset(&sp, 0, sizeof(sp)); sp.n = nsp;
   {
     const ArenaMark mkA = arena_mark(c);
     SelRankRange sr; sr.rank12 = rank12; sr.lo = lo; sr.hi = hi;
     Rec8 *pr = nullptr, *pt = nullptr; u32 got = 0;
     RC(select_records(c, sr, m02, &pr, &got, DC3HIP_PH_RANKS));
     if (got != nA) { set_err("global merge: %u samples in rank range [%u,%u), expected %u", got, lo, hi, nA); return E_HIP; }
-    if (nA) {
-      u32 *sa12l = nullptr;
-      RC(arena_alloc(c, (size_t)nA + 16, &pt));
-      RC(arena_alloc(c, (size_t)nA + 16, &sa12l));
-      RC(inverse_permute(c, pr, pt, nA, sa12l, DC3HIP_PH_RANKS));
+    u32 *sa12l = nullptr;
+    RC(arena_alloc(c, (size_t)nA + 16, &pt));
+    RC(arena_alloc(c, (size_t)nA + nsp + 16, &sa12l));
+    if (nA) RC(inverse_permute(c, pr, pt, nA, sa12l, DC3HIP_PH_RANKS));
+    if (nsp) HIPC(hipMemcpyAsync(sa12l + nA, c->d_words + 40, nsp * sizeof(u32), hipMemcpyDeviceToDevice, c->stream));
+    const u32 cnt = nA + nsp;
+    if (cnt) {
       constexpr u32 kTup0Tile = SortCfg<Tup0, 256>::NW * 64 * SortCfg<Tup0, 256>::IPT;
-      const Chunking ckc = make_chunks(c, nA, kTup0Tile);
+      const Chunking ckc = make_chunks(c, cnt, kTup0Tile);
       u32 *table0 = nullptr;
       RC(arena_alloc(c, (size_t)256 * ckc.nchunks, &table0));
-      PhaseScope pg(c, DC3HIP_PH_OTHER, nA, 4);
-      hipLaunchKernelGGL(k_gather_tuples, dim3(ckc.nchunks), dim3(kBlock), 0, c->stream, tslot, sa12l, nA, ckc.chunk, ckc.nchunks,
-                         A, table0);
-      KCHECK();
+      RC((build_gather_tuples<Sym>(c, S, m, m0, m02, K, rank12, sa12l, cnt, ckc, A, table0)));
+    }
+    if (nsp) {
+      HIPC(hipMemcpyAsync(sp.a, A + nA, nsp * sizeof(Tup12), hipMemcpyDeviceToHost, c->stream));
+      HIPC(hipStreamSynchronize(c->stream));
     }
     arena_release(c, mkA);
   }

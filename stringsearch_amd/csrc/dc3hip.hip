@@ -79,6 +79,7 @@ struct dc3hip_ctx {
   bool wide_names = false;
   bool no_nine_bit = false, no_rec12 = false, no_discard = false, no_fullsort = false, no_text_shortcut = false;
   bool no_split_emit = false;
+  bool no_tup8 = false;        // DC3HIP_NO_TUP8=1: the slot table of the merge tuples is always 16 bytes per sample
   bool trace = false;          // DC3HIP_TRACE=1: per-level checksums of SA12 / SA0 / SA (dc3hip_stats.trace_*)
   u64 *d_trace = nullptr;      // [3][DC3HIP_MAX_LEVELS]
   std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
@@ -903,6 +904,42 @@ static int trace_sum(dc3hip_ctx *c, int which, int depth, const void *arr, u32 n
   return E_OK;
 }
 
+// Sample tuples of slots sa12l[0..cnt) in that order -> t12 (lib.rs:136-162's reads, gathered once): the slot table is
+// built by streaming (8-byte entries when the level's symbols fit 16 bits, else 16-byte) and gathered.  table0
+// ([256][chunks of cnt]) receives the digit table of the fused mod-0 selection pass.  The slot table lives above the
+// caller's arena mark and is released here.
+template <class Sym>
+static int build_gather_tuples(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u64 K, const u32 *rank12, const u32 *sa12l,
+                               u32 cnt, const Chunking &ckc, Tup12 *t12, u32 *table0) {
+  const ArenaMark mk = arena_mark(c);
+  PhaseScope ps(c, DC3HIP_PH_TUPLES, m02);
+  if (K < 65536 && !c->no_tup8) {
+    TupS8 *ts = nullptr;
+    RC(arena_alloc(c, (size_t)m02, &ts));
+    hipLaunchKernelGGL((k_build_tuples8<Sym>), dim3(grid_for(c, m0)), dim3(kBlock), 0, c->stream, S, m, m0, m02, rank12, ts);
+    KCHECK();
+    if (cnt) {
+      PhaseScope pg(c, DC3HIP_PH_OTHER, cnt, 4);   // timed separately as kernel class 4 (gather)
+      hipLaunchKernelGGL(k_gather_tuples8, dim3(ckc.nchunks), dim3(kBlock), 0, c->stream, ts, sa12l, cnt, m0, ckc.chunk,
+                         ckc.nchunks, t12, table0);
+      KCHECK();
+    }
+  } else {
+    Tup12 *ts = nullptr;
+    RC(arena_alloc(c, (size_t)m02, &ts));
+    hipLaunchKernelGGL((k_build_tuples<Sym>), dim3(grid_for(c, m0)), dim3(kBlock), 0, c->stream, S, m, m0, m02, rank12, ts);
+    KCHECK();
+    if (cnt) {
+      PhaseScope pg(c, DC3HIP_PH_OTHER, cnt, 4);
+      hipLaunchKernelGGL(k_gather_tuples, dim3(ckc.nchunks), dim3(kBlock), 0, c->stream, ts, sa12l, cnt, ckc.chunk, ckc.nchunks,
+                         t12, table0);
+      KCHECK();
+    }
+  }
+  arena_release(c, mk);
+  return E_OK;
+}
+
 // Step 3 (lib.rs:131-192): merge-path merge of the sorted sample tuples A and the sorted mod-0 tuples B into
 // out_sa[0 .. nA+nB) (and, when out_pairs != nullptr, the (pos, rank_base + k + 1) pairs of the rank inversion).
 static int merge_lists(dc3hip_ctx *c, const Tup12 *A, u32 nA, const Tup0 *B, u32 nB, u32 *out_sa, Rec8 *out_pairs,
@@ -1065,28 +1102,14 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
   // ---- Step 2 + 3: tuples, mod-0 order, merge -------------------------------------------------
   // t12 = sample tuples in SA12 order.  The gather also produces the digit table of the fused
   // "select mod-0 + first radix pass" (Step 2, lib.rs:118-126).
-  Tup12 *tslot = nullptr, *t12 = nullptr;
+  Tup12 *t12 = nullptr;
   RC(arena_alloc(c, (size_t)m02, &t12));
   constexpr u32 kTup0Tile = SortCfg<Tup0, 256>::NW * 64 * SortCfg<Tup0, 256>::IPT;
   const Chunking ckc = make_chunks(c, m02, kTup0Tile);
   u32 *table0 = nullptr, *dbase0 = nullptr;
   RC(arena_alloc(c, (size_t)256 * ckc.nchunks, &table0));
   RC(arena_alloc(c, (size_t)256, &dbase0));
-  const ArenaMark mk_tslot = arena_mark(c);
-  RC(arena_alloc(c, (size_t)m02, &tslot));
-  {
-    PhaseScope ps(c, DC3HIP_PH_TUPLES, m02);
-    hipLaunchKernelGGL((k_build_tuples<Sym>), dim3(grid_for(c, m0)), dim3(kBlock), 0, c->stream, S, m, m0, m02,
-                       rank12, tslot);
-    KCHECK();
-    {
-      PhaseScope pg(c, DC3HIP_PH_OTHER, m02, 4);   // timed separately as kernel class 4 (gather)
-      hipLaunchKernelGGL(k_gather_tuples, dim3(ckc.nchunks), dim3(kBlock), 0, c->stream, tslot, sa12, m02, ckc.chunk,
-                         ckc.nchunks, t12, table0);
-      KCHECK();
-    }
-  }
-  arena_release(c, mk_tslot);   // slot-order tuples are dead; their space is reused below
+  RC((build_gather_tuples<Sym>(c, S, m, m0, m02, K, rank12, sa12, m02, ckc, t12, table0)));   // slot table released inside
   Tup0 *z0 = nullptr, *z1 = nullptr, *zs = nullptr;
   RC(arena_alloc(c, (size_t)m0, &z0));
   RC(arena_alloc(c, (size_t)m0, &z1));
@@ -1279,6 +1302,7 @@ int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) {
   c->no_small_ties = (nst && nst[0] == '1');
   { const char *e = getenv("DC3HIP_NO_SPLIT_EMIT"); c->no_split_emit = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_TRACE"); c->trace = (e && e[0] == '1'); }
+  { const char *e = getenv("DC3HIP_NO_TUP8"); c->no_tup8 = (e && e[0] == '1'); }
   const char *nts = getenv("DC3HIP_NO_TEXT_SHORTCUT");
   c->no_text_shortcut = (nts && nts[0] == '1');
   const char *nf = getenv("DC3HIP_NO_FULLSORT");

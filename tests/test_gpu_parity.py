@@ -392,6 +392,7 @@ def test_hybrid_and_straight_paths_agree(ss, oracle):
         seen = {}
         for env in ({}, {"DC3HIP_NO_HYBRID": "1"}, {"DC3HIP_NO_SMALL_TIES": "1"}, {"DC3HIP_NO_FULLSORT": "1"},
                     {"DC3HIP_NO_TEXT_SHORTCUT": "1"}, {"DC3HIP_NO_SPLIT_EMIT": "1"},
+                    {"DC3HIP_NO_TEXT_SHORTCUT": "1", "DC3HIP_NO_TUP8": "1"},
                     {"DC3HIP_NO_HYBRID": "1", "DC3HIP_NO_9BIT": "1", "DC3HIP_NO_REC12": "1"}):
             os.environ.update(env)
             try:
