@@ -827,6 +827,178 @@ __global__ __launch_bounds__(kBlock) void k_tie_writeback(const Rec16 *__restric
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Prefix sort + tie refinement on 12-byte records, for keys wider than 64 bits whose 34-bit image (the Rec8 path
+// above) collides everywhere but whose 63-bit prefix does not — low-entropy text two levels down: 81-bit triples of
+// 27-bit names, ~97 % of them distinct.  Record = (63-bit prefix of the key in k1:k0, pos): 7 passes of 9-bit digits
+// over 12 bytes instead of 9 passes over 16.  Same scheme as above: records whose prefix equals a neighbour's are
+// re-ordered by the full key (rebuilt from the level's string), small groups by one thread each, the rest by a
+// full-key sort of the tied subset; f[i] = key differs from predecessor.
+// ---------------------------------------------------------------------------------------------
+constexpr u32 kImg12Bits = 63;
+__device__ __forceinline__ u64 img12(const Rec12 &r) { return ((u64)r.k1 << 32) | r.k0; }
+// top kImg12Bits bits of the kbits-bit key of r (kbits > 64)
+__device__ __forceinline__ Rec12 hyb_rec12(const Rec16 &r, u32 kbits) {
+  const u32 sh = kbits - kImg12Bits;                         // 2 .. 33
+  const u64 hi = ((u64)r.k2 << 32) | r.k1;
+  const u64 img = sh <= 32 ? ((hi << (32 - sh)) | (sh == 32 ? 0u : (r.k0 >> sh)) ) : (hi >> (sh - 32));
+  return Rec12{(u32)img, (u32)(img >> 32), r.pos};
+}
+struct AccHyb12 {
+  const Rec12 *h; const uint8_t *f;
+  __device__ __forceinline__ u32 pos(u32 i) const { return h[i].pos; }
+  __device__ __forceinline__ u32 neq(u32 i) const { return f[i]; }
+};
+template <class Sym, int NB>
+__global__ __launch_bounds__(kBlock) void k_pack_image12_hist(Sym S, u32 m, u32 m0, u32 m02, u32 b, u32 kbits,
+                                                             Rec12 *__restrict__ out, u32 chunk, u32 nchunks,
+                                                             u32 *__restrict__ table) {
+  __shared__ u32 hist[kWaves][NB];
+#pragma unroll
+  for (int w = 0; w < kWaves; w++)
+    for (int j = threadIdx.x; j < NB; j += kBlock) hist[w][j] = 0;
+  __syncthreads();
+  u32 *myh = hist[wave_id()];
+  const u32 begin = blockIdx.x * chunk, end = min(m02, begin + chunk);      // output indices; chunk is even
+  for (u32 g = begin / 2 + threadIdx.x; 2 * g < end; g += kBlock) {
+    const u32 i = 3 * g + 1;
+    const u32 s1 = S.get(i), s2 = S.get(i + 1), s3 = S.get(i + 2), s4 = S.get(i + 3);
+    const Rec12 r0 = hyb_rec12(make_rec(s1, s2, s3, b, i), kbits);
+    out[2 * g] = r0;
+    atomicAdd(&myh[r0.k0 & (NB - 1)], 1u);
+    if (2 * g + 1 < m02) {
+      const Rec12 r1 = hyb_rec12(make_rec(s2, s3, s4, b, i + 1), kbits);
+      out[2 * g + 1] = r1;
+      atomicAdd(&myh[r1.k0 & (NB - 1)], 1u);
+    }
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < NB; j += kBlock) {
+    u32 sum = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; w++) sum += hist[w][j];
+    table[(size_t)j * nchunks + blockIdx.x] = sum;
+  }
+}
+// tie-rate predictor sample: the 63-bit prefixes of every stride-th sample group as Rec8 words (image << 1 | 0), so
+// that k_hash_ties (pbits = 1) counts colliding prefixes
+template <class Sym>
+__global__ __launch_bounds__(kBlock) void k_pack_image12_sample(Sym S, u32 m, u32 m02, u32 b, u32 kbits, u32 stride,
+                                                               u32 ngroups_out, Rec8 *out) {
+  for (u32 go = blockIdx.x * kBlock + threadIdx.x; go < ngroups_out; go += gridDim.x * kBlock) {
+    const u32 g = go * stride, i = 3 * g + 1;
+    const u32 s1 = S.get(i), s2 = S.get(i + 1), s3 = S.get(i + 2), s4 = S.get(i + 3);
+    const u64 a = img12(hyb_rec12(make_rec(s1, s2, s3, b, i), kbits)) << 1;
+    out[2 * go] = Rec8{(u32)(a >> 32), (u32)a};
+    const u64 c = (2 * g + 1 < m02) ? (img12(hyb_rec12(make_rec(s2, s3, s4, b, i + 1), kbits)) << 1) : (~0ull >> 2);
+    out[2 * go + 1] = Rec8{(u32)(c >> 32), (u32)c};
+  }
+}
+__device__ __forceinline__ bool hyb12_tied(const Rec12 *h, u32 i, u32 n) {
+  const u64 a = img12(h[i]);
+  return (i > 0 && img12(h[i - 1]) == a) || (i + 1 < n && img12(h[i + 1]) == a);
+}
+__global__ __launch_bounds__(kBlock) void k_tie_count12(const Rec12 *__restrict__ h, u32 n, u32 chunk, u32 *counts) {
+  __shared__ u32 tmp[kWaves];
+  const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
+  u32 c = 0;
+  for (u32 i = begin + threadIdx.x; i < end; i += kBlock) c += hyb12_tied(h, i, n) ? 1u : 0u;
+  block_count_store(c, tmp, counts);
+}
+template <class KM>
+__global__ __launch_bounds__(kBlock) void k_tie_compact12(KM km, const Rec12 *__restrict__ h, u32 n, u32 chunk,
+                                                         const u32 *__restrict__ base_excl, Rec16 *__restrict__ sub,
+                                                         u32 *__restrict__ tiedidx) {
+  __shared__ u32 tmp[kWaves];
+  __shared__ uint16_t lcode[256];
+  km.stage(lcode);
+  const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
+  u32 running = base_excl[blockIdx.x];
+  for (u32 tile = begin; tile < end; tile += kBlock) {
+    const u32 i = tile + threadIdx.x;
+    const bool fl = (i < end) && hyb12_tied(h, i, n);
+    u32 tot;
+    const u32 ex = block_excl_scan<kWaves>(fl ? 1u : 0u, tmp, tot);
+    if (fl) { sub[running + ex] = km.make(h[i].pos, lcode); tiedidx[running + ex] = i; }
+    running += tot;
+  }
+}
+// as k_tie_resolve: the thread that sees the start of a tied group of at most kTieSmallMax members orders it by the full
+// key in place (positions only; the prefix stays) and sets f; larger groups raise words[0].
+// words[1] += tied records, words[2] += records whose full key equals the predecessor's (settled groups only)
+template <class KM>
+__global__ __launch_bounds__(kBlock) void k_tie_resolve12(KM km, Rec12 *__restrict__ h, u32 n, uint8_t *__restrict__ f,
+                                                         u32 *words) {
+  constexpr u32 kIPT = 4, kTile = kBlock * kIPT;
+  __shared__ uint16_t lcode[256];
+  __shared__ u32 starts[kTile / 2];
+  __shared__ u32 nstart, ntied, ndup;
+  km.stage(lcode);
+  const u32 ntiles = (n + kTile - 1) / kTile;
+  if (threadIdx.x == 0) { ntied = 0; ndup = 0; }
+  for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    if (threadIdx.x == 0) nstart = 0;
+    __syncthreads();
+    u32 tied = 0;
+#pragma unroll
+    for (u32 j = 0; j < kIPT; j++) {
+      const u32 i = tile * kTile + j * kBlock + threadIdx.x;
+      if (i < n) {
+        const u64 a = img12(h[i]);
+        const bool eqp = i > 0 && img12(h[i - 1]) == a;
+        const bool eqn = i + 1 < n && img12(h[i + 1]) == a;
+        if (eqn && !eqp) starts[atomicAdd(&nstart, 1u)] = i;
+        if (eqn || eqp) tied++;
+      }
+    }
+    tied = wave_reduce(tied);
+    if (lane_id() == 0 && tied) atomicAdd(&ntied, tied);
+    __syncthreads();
+    const u32 ns = nstart;
+    u32 dup = 0;
+    for (u32 s = threadIdx.x; s < ns; s += kBlock) {
+      const u32 i = starts[s];
+      const u64 a = img12(h[i]);
+      u32 e = i + 2;
+      while (e < n && e - i <= kTieSmallMax && img12(h[e]) == a) e++;
+      const u32 len = e - i;
+      if (len > kTieSmallMax) { words[0] = 1u; continue; }
+      Rec16 loc[kTieSmallMax];
+      for (u32 x = 0; x < len; x++) {
+        const Rec16 v = km.make(h[i + x].pos, lcode);
+        u32 y = x;
+        while (y > 0 && key_less(v, loc[y - 1])) { loc[y] = loc[y - 1]; y--; }
+        loc[y] = v;
+      }
+      for (u32 x = 0; x < len; x++) {
+        h[i + x].pos = loc[x].pos;
+        if (x > 0) {
+          const bool ne = key_neq(loc[x], loc[x - 1]);
+          f[i + x] = ne ? 1 : 0;
+          dup += ne ? 0u : 1u;
+        }
+      }
+    }
+    if (dup) atomicAdd(&ndup, dup);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (ntied) atomicAdd(&words[1], ntied);
+    if (ndup) atomicAdd(&words[2], ndup);
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_tie_writeback12(const Rec16 *__restrict__ sub, const u32 *__restrict__ tiedidx,
+                                                           u32 t, Rec12 *__restrict__ h, uint8_t *__restrict__ f) {
+  for (u32 j = blockIdx.x * kBlock + threadIdx.x; j < t; j += gridDim.x * kBlock) {
+    const Rec16 cur = sub[j];
+    const u32 i = tiedidx[j];
+    h[i].pos = cur.pos;
+    bool ne = true;
+    if (j > 0) { const Rec16 prev = sub[j - 1]; ne = key_neq(cur, prev); }
+    f[i] = ne ? 1 : 0;
+  }
+}
+
 __global__ void k_base1(u32 *out_sa, u32 *out_rank) {
   if (threadIdx.x == 0) { if (out_sa) out_sa[0] = 0; if (out_rank) out_rank[0] = 1; }
 }

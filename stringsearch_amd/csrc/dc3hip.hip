@@ -79,6 +79,9 @@ struct dc3hip_ctx {
   bool wide_names = false;
   bool no_nine_bit = false, no_rec12 = false, no_discard = false, no_fullsort = false, no_text_shortcut = false;
   bool no_split_emit = false;
+  u32 hybrid12_min = 1u << 22; // DC3HIP_HYBRID12_MIN: smallest level (samples) that tries it (tests lower it)
+  bool no_hybrid8 = false;     // DC3HIP_NO_HYBRID8=1 (tests): skip the 8-byte prefix sort / whole-level order of a level
+  bool no_hybrid12 = false;    // DC3HIP_NO_HYBRID12=1: no 63-bit-prefix sort on 12-byte records for keys wider than 64 bits
   bool no_tup8 = false;        // DC3HIP_NO_TUP8=1: the slot table of the merge tuples is always 16 bytes per sample
   bool trace = false;          // DC3HIP_TRACE=1: per-level checksums of SA12 / SA0 / SA (dc3hip_stats.trace_*)
   u64 *d_trace = nullptr;      // [3][DC3HIP_MAX_LEVELS]
@@ -714,6 +717,114 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
   return E_OK;
 }
 
+// Prefix sort + tie refinement on 12-byte records (kernels: "Prefix sort ... on 12-byte records" in dc3_order.hip.hpp):
+// for keys wider than 64 bits.  *ok = false: too many ties (predicted or measured), nothing was produced.
+template <class Sym>
+static int order_hybrid12(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u32 kbits, u32 *sa12, u32 *rank12, u32 *R,
+                          u32 *sslot, u32 *names, int *mode, bool *ok, int depth) {
+  *ok = false;
+  const ArenaMark mk = arena_mark(c);
+  Key3<Sym> km; km.S = S; km.B = b;
+  // predicted fraction of samples whose 63-bit prefix collides with another sample's
+  {
+    const u32 stride = std::max<u32>(1, m0 >> 19);
+    const u32 ng = (m0 - 1) / stride + 1, ns = 2 * ng;
+    Rec8 *a = nullptr;
+    RC(arena_alloc(c, (size_t)ns, &a));
+    u32 ts = 0;
+    {
+      PhaseScope ps(c, DC3HIP_PH_PACK, ns);
+      hipLaunchKernelGGL((k_pack_image12_sample<Sym>), dim3(grid_for(c, ng)), dim3(kBlock), 0, c->stream, S, m, m02, b, kbits,
+                         stride, ng, a);
+      KCHECK();
+    }
+    RC(sample_ties(c, a, ns, 1u, &ts));
+    const double fs = (double)ts / (double)ns;
+    const double ratio = (double)(m02 - 1) / (double)(ns > 1 ? ns - 1 : 1);
+    const double pred = fs >= 1.0 ? 1.0 : 1.0 - pow(1.0 - fs, ratio);
+    c->stats.level_tie_pred[depth] = pred;
+    arena_release(c, mk);
+    if (!(pred < kHybridMaxPredicted)) return E_OK;
+  }
+  Rec12 *ha = nullptr, *hb = nullptr, *h = nullptr;
+  uint8_t *f = nullptr;
+  RC(arena_alloc(c, (size_t)m02, &ha));
+  RC(arena_alloc(c, (size_t)m02, &hb));
+  RC(arena_alloc(c, (size_t)m02 + 16, &f));
+  u32 *first_table = nullptr;
+  {
+    PhaseScope ps(c, DC3HIP_PH_PACK, m02);
+    int nb = 0; Chunking ck;
+    radix_plan<Rec12>(c, m02, kImg12Bits, &nb, &ck);
+    RC(arena_alloc(c, (size_t)nb * ck.nchunks, &first_table));
+    if (nb == 512)
+      hipLaunchKernelGGL((k_pack_image12_hist<Sym, 512>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, S, m, m0, m02, b, kbits,
+                         ha, ck.chunk, ck.nchunks, first_table);
+    else
+      hipLaunchKernelGGL((k_pack_image12_hist<Sym, 256>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, S, m, m0, m02, b, kbits,
+                         ha, ck.chunk, ck.nchunks, first_table);
+    KCHECK();
+  }
+  RC(radix_sort<Rec12>(c, ha, hb, m02, 0, kImg12Bits, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT12_DOWN,
+                       first_table));
+  HIPC(hipMemsetAsync(f, 1, (size_t)m02, c->stream));
+  u32 tied = 0;
+  bool general = false;
+  {
+    PhaseScope ps(c, DC3HIP_PH_TIES, m02);
+    HIPC(hipMemsetAsync(c->d_words + 10, 0, 3 * sizeof(u32), c->stream));
+    hipLaunchKernelGGL((k_tie_resolve12<Key3<Sym>>), dim3(grid_for(c, m02 / 4 + 1)), dim3(kBlock), 0, c->stream, km, h, m02, f,
+                       c->d_words + 10);
+    KCHECK();
+    HIPC(hipMemcpyAsync(c->h_words + 10, c->d_words + 10, 3 * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPC(hipStreamSynchronize(c->stream));
+  tied = c->h_words[11];
+  c->stats.level_tied[depth] = tied;
+  general = c->h_words[10] != 0;
+  if ((double)tied > kHybridMaxMeasured * (double)m02) { arena_release(c, mk); return E_OK; }
+  if (general) {
+    // some tied group is larger than kTieSmallMax: re-sort ALL tied records by the full key (the small groups that were
+    // already settled are re-done consistently)
+    if (c->arena_bytes - c->arena_off < (size_t)tied * 36 + (32u << 20)) { arena_release(c, mk); return E_OK; }
+    const Chunking ck = make_chunks(c, m02, kBlock);
+    u32 *counts = nullptr, *tiedidx = nullptr;
+    Rec16 *sa = nullptr, *sb = nullptr, *ss = nullptr;
+    RC(arena_alloc(c, (size_t)ck.nchunks + 16, &counts));
+    {
+      PhaseScope ps(c, DC3HIP_PH_TIES, m02);
+      hipLaunchKernelGGL(k_tie_count12, dim3(ck.nchunks), dim3(kBlock), 0, c->stream, h, m02, ck.chunk, counts);
+      KCHECK();
+      hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, counts, ck.nchunks, c->d_words + 2);
+      KCHECK();
+      HIPC(hipMemcpyAsync(c->h_words + 2, c->d_words + 2, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPC(hipStreamSynchronize(c->stream));
+    tied = c->h_words[2];
+    RC(arena_alloc(c, (size_t)tied, &sa));
+    RC(arena_alloc(c, (size_t)tied, &sb));
+    RC(arena_alloc(c, (size_t)tied, &tiedidx));
+    {
+      PhaseScope ps(c, DC3HIP_PH_TIES, tied);
+      hipLaunchKernelGGL((k_tie_compact12<Key3<Sym>>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, km, h, m02, ck.chunk, counts,
+                         sa, tiedidx);
+      KCHECK();
+    }
+    RC(radix_sort<Rec16>(c, sa, sb, tied, 0, kbits, &ss, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT12_DOWN));
+    {
+      PhaseScope ps(c, DC3HIP_PH_TIES, tied);
+      hipLaunchKernelGGL(k_tie_writeback12, dim3(grid_for(c, tied)), dim3(kBlock), 0, c->stream, ss, tiedidx, tied, h, f);
+      KCHECK();
+    }
+  }
+  c->stats.level_sorted[depth] = 2;
+  AccHyb12 acc; acc.h = h; acc.f = f;
+  RC(name_and_rank<AccHyb12>(c, acc, m02, m0, sa12, rank12, R, sslot, names, mode));
+  *ok = true;
+  arena_release(c, mk);
+  return E_OK;
+}
+
 // tie-rate predictor over all positions (stride sample) for the whole-text shortcut of level 0
 template <class KM>
 static int predict_tie_fraction_pos(dc3hip_ctx *c, KM km, u32 n, const HiMap &hm, double *pred) {
@@ -1040,7 +1151,7 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
       done = true;
     }
     // ---- prefix-sort + tie-refine ordering when the N-bit key image separates most samples ------
-    if (!done && m02 >= kHybridMinSamples && !c->no_hybrid) {
+    if (!done && m02 >= kHybridMinSamples && !c->no_hybrid && !c->no_hybrid8) {
       double pred = 1.0;
       RC(predict_tie_fraction<Sym>(c, S, m, m0, m02, b, make_himap(B, kbits, m), &pred));
       c->stats.level_tie_pred[depth] = pred;
@@ -1074,6 +1185,13 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
         done = ok;
         if (!ok) arena_release(c, mk1);
       }
+    }
+    if (!done && kbits > 64 && m02 >= c->hybrid12_min && !c->no_hybrid && !c->no_hybrid12) {
+      // wide keys whose 34-bit image collides everywhere: try the 63-bit prefix on 12-byte records
+      bool ok = false;
+      RC(order_hybrid12<Sym>(c, S, m, m0, m02, b, kbits, sa12, rank12, R, sslot, &names, &mode, &ok, depth));
+      done = ok;
+      if (!ok) arena_release(c, mk1);
     }
     if (!done) {
       c->stats.level_sorted[depth] = 1;
@@ -1303,6 +1421,9 @@ int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) {
   { const char *e = getenv("DC3HIP_NO_SPLIT_EMIT"); c->no_split_emit = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_TRACE"); c->trace = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_TUP8"); c->no_tup8 = (e && e[0] == '1'); }
+  { const char *e = getenv("DC3HIP_NO_HYBRID12"); c->no_hybrid12 = (e && e[0] == '1'); }
+  { const char *e = getenv("DC3HIP_NO_HYBRID8"); c->no_hybrid8 = (e && e[0] == '1'); }
+  { const char *e = getenv("DC3HIP_HYBRID12_MIN"); if (e) c->hybrid12_min = (u32)std::max(0ll, atoll(e)); }
   const char *nts = getenv("DC3HIP_NO_TEXT_SHORTCUT");
   c->no_text_shortcut = (nts && nts[0] == '1');
   const char *nf = getenv("DC3HIP_NO_FULLSORT");

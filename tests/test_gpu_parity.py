@@ -393,6 +393,8 @@ def test_hybrid_and_straight_paths_agree(ss, oracle):
         for env in ({}, {"DC3HIP_NO_HYBRID": "1"}, {"DC3HIP_NO_SMALL_TIES": "1"}, {"DC3HIP_NO_FULLSORT": "1"},
                     {"DC3HIP_NO_TEXT_SHORTCUT": "1"}, {"DC3HIP_NO_SPLIT_EMIT": "1"},
                     {"DC3HIP_NO_TEXT_SHORTCUT": "1", "DC3HIP_NO_TUP8": "1"},
+                    {"DC3HIP_NO_TEXT_SHORTCUT": "1", "DC3HIP_NO_HYBRID8": "1", "DC3HIP_HYBRID12_MIN": "0"},   # 12-byte prefix sort
+                    {"DC3HIP_NO_HYBRID12": "1"},
                     {"DC3HIP_NO_HYBRID": "1", "DC3HIP_NO_9BIT": "1", "DC3HIP_NO_REC12": "1"}):
             os.environ.update(env)
             try:
@@ -405,6 +407,12 @@ def test_hybrid_and_straight_paths_agree(ss, oracle):
                 for k in env:
                     os.environ.pop(k, None)
         assert not any(v in (2, 4, 5) for v in seen[("DC3HIP_NO_HYBRID",)]["level_sorted"])
+        h12 = seen[("DC3HIP_HYBRID12_MIN", "DC3HIP_NO_HYBRID8", "DC3HIP_NO_TEXT_SHORTCUT")]
+        if label in ("random", "zero_run", "dup_block"):
+            # level 1 (73-bit keys) went through the 63-bit-prefix sort on 12-byte records; the zero run is one huge tie
+            # group (general path), the duplicated block many small ones
+            assert h12["level_sorted"][1] in (2, 4), (label, h12["level_sorted"])
+            assert (h12["level_tied"][1] > 0) == (label != "random"), (label, h12["level_tied"][:3])
         assert 5 not in seen[("DC3HIP_NO_FULLSORT",)]["level_sorted"]
         if label == "random":
             # all 9-byte windows distinct: the whole text is ordered at once (level 0); without that
