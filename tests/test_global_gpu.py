@@ -246,3 +246,34 @@ def test_loopback_rank_failure_releases_the_group(ss, oracle):
         assert np.array_equal(g.sa(), want_sa(oracle, small))
     finally:
         g.close()
+
+
+@pytest.mark.parametrize("P,n,kind,seed,label", [(4, 1 << 30, 0, 4, "configs[3] shape: random bytes over 4 ranks (1/4 scale)"),
+                                                (8, 512 << 20, 1, 5, "configs[4] shape: DNA over 8 ranks, i64 shards (1/32 scale)")])
+def test_baseline_multi_gpu_config_shapes_on_loopback(ss, P, n, kind, seed, label):
+    """BASELINE.json configs[3] / configs[4] as far as one GPU can host them: the same rank counts and input classes
+    through the global mode with loopback ranks (the arenas of all ranks share this GPU's 288 GB, hence the reduced
+    sizes).  The shards tile [0, n), their checksums add up to the single-device checksum, and the concatenated array
+    passes the GPU sufcheck; shards are fetched as int64 as configs[4] asks."""
+    with ss.LoopbackGroup(P, n) as g:
+        g.generate(n, seed, kind)
+        g.build()
+        chk = g.checksum()
+        st = g.stats()
+        parts, nxt = [], 0
+        for r in g.ranks:
+            first, s = r.shard_sa(np.int64)
+            assert first == nxt and s.dtype == np.int64, label
+            nxt += len(s)
+            parts.append(s.astype(np.int32))
+        assert nxt == n
+    sa = np.concatenate(parts)
+    del parts
+    with ss.Context(n) as c:
+        c.generate(n, seed, kind)
+        c.build()
+        assert c.checksum() == chk, label
+        c.set_sa(sa)
+        assert c.sufcheck() == 0, label
+    assert all(s["comm_bytes_in"] >= n * (P - 1) // P - P for s in st)  # at least the other ranks' text blocks crossed the transport
+    assert (st[0]["text_order"] == 1) == (kind == 0)
