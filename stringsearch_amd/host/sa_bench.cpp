@@ -4,21 +4,24 @@
 // gen:dna:SIZE:SEED (the deterministic generator of BASELINE.md §3).  LENGTH takes k/m suffixes
 // (main.rs:192-208).  `bench` prints the table of main.rs:168-188: one un-warmed timed call per
 // algorithm, SA allocation included (main.rs:145-151), speed = len / secs in binary units.
-// Rows: dc3-hip (the FFI entry point), dc3-hip-resident (context API, text/SA in HBM), and, with
-// --ref /path/to/libdivsufsort.so, c-divsufsort (dlopen'ed; never linked).
+// Rows: dc3-hip (the FFI entry point), dc3-hip-resident (context API, text/SA in HBM), with
+// --ref /path/to/libdivsufsort.so c-divsufsort (dlopen'ed; never linked), and with --global-ranks P
+// dc3-hip-global(P): ONE suffix array over P loopback ranks (incl. creating the ranks and the comparison
+// with the one-shot result).
 #include <chrono>
 #include <cinttypes>
 #include <cstdio>
 #include <cstdlib>
 #include <dlfcn.h>
 #include <fstream>
+#include <functional>
 #include <iostream>
 #include <string>
 #include <vector>
 #include "dc3hip.hpp"
 #include "sacapart.hpp"
 
-static void usage() { std::printf("Usage: sa_bench bench|run|verify INPUT [LENGTH] [--ref LIBDIVSUFSORT.so] [--partitions P [--all-devices]]\n"); std::exit(1); }
+static void usage() { std::printf("Usage: sa_bench bench|run|verify INPUT [LENGTH] [--ref LIBDIVSUFSORT.so] [--partitions P [--all-devices]] [--global-ranks P]\n"); std::exit(1); }
 
 // main.rs:192-208
 static size_t parse_size(std::string s) {
@@ -54,12 +57,13 @@ static std::vector<uint8_t> load_input(const std::string &spec) {
 }
 
 int main(int argc, char **argv) {
-  std::vector<std::string> free_args; std::string ref_path; size_t partitions = 0; bool all_devices = false;
+  std::vector<std::string> free_args; std::string ref_path; size_t partitions = 0; bool all_devices = false; int global_ranks = 0;
   for (int i = 1; i < argc; i++) {
     std::string a = argv[i];
     if (a == "--ref" && i + 1 < argc) ref_path = argv[++i];
     else if (a == "--partitions" && i + 1 < argc) partitions = (size_t)std::atoll(argv[++i]);
     else if (a == "--all-devices") all_devices = true;
+    else if (a == "--global-ranks" && i + 1 < argc) global_ranks = std::atoi(argv[++i]);   // bench: extra row, ONE SA over P loopback ranks
     else free_args.push_back(a);
   }
   if (free_args.size() < 2) usage();
@@ -116,6 +120,18 @@ int main(int argc, char **argv) {
       dc3hip_stats st; dc3hip_ctx_stats(c, &st); resident_ms = st.build_ms;
       dc3hip_ctx_destroy(c);
     });
+    if (global_ranks > 1) {
+      // the global mode (one suffix array over P ranks) with the P ranks as loopback ranks on this GPU; checked against
+      // the one-shot result
+      bool same = false;
+      measure(("dc3-hip-global(" + std::to_string(global_ranks) + ")").c_str(), [&] {
+        dc3hip::GlobalLoopback grp(global_ranks, (int64_t)len);
+        auto all = grp.sort(input);
+        auto one = dc3hip::sort_i64(input);
+        same = all.sa() == one.sa();
+      });
+      if (!same) { std::fprintf(stderr, "\nglobal-mode result differs from the single-device result\n"); return 2; }
+    }
     std::printf("done!\n");
     std::printf("%-20s %-14s %s\n", "Algorithm", "Time", "Average speed");
     for (auto &r : rows) std::printf("%-20s %-14s %sB/s\n", r.name.c_str(), (std::to_string(r.secs) + "s").c_str(), fmt_binary((double)len / r.secs).c_str());

@@ -315,9 +315,10 @@ def test_cpp_host_mirror(ss):
     out = subprocess.run([os.path.join(pkg, "sa_bench"), "verify", os.path.join(GOLDEN, "corpus", "fuzz3")],
                          capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "GPU sufcheck: 0" in out.stdout, out.stdout + out.stderr
-    out = subprocess.run([os.path.join(pkg, "sa_bench"), "bench", "gen:random:4m:7", "2m"],
+    out = subprocess.run([os.path.join(pkg, "sa_bench"), "bench", "gen:random:4m:7", "2m", "--global-ranks", "3"],
                          capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "Input is size 2.0MiB" in out.stdout and "dc3-hip" in out.stdout, out.stdout + out.stderr
+    assert "dc3-hip-global(3)" in out.stdout, out.stdout       # one SA over 3 loopback ranks == the one-shot SA
     out = subprocess.run([os.path.join(pkg, "sa_bench"), "run", "gen:dna:1m:3", "--partitions", "3"],
                          capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "Done in" in out.stdout, out.stdout + out.stderr
