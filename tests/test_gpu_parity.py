@@ -795,3 +795,39 @@ def test_short_arena_falls_back_or_fails_loudly(ss, oracle):
         finally:
             os.environ.pop("DC3HIP_ARENA_BYTES", None)
     assert "alloc" in outcomes and len(outcomes) >= 2      # both behaviours were exercised
+
+
+def test_real_text_corpus_bit_exact(ss, oracle):
+    """Real text instead of the synthetic generator: source / header / doc files that ship with the image (code and
+    prose with licence headers and long verbatim repeats — the low-entropy, deep-LCP class of BASELINE configs[2];
+    enwik9 is not available offline).  32 MiB, bit-exact against the reference's divsufsort; the recursion goes
+    deeper than on any synthetic input of the suite."""
+    import importlib.util
+    from conftest import ROOT
+    parts, tot, limit = [], 0, 32 << 20
+    for r in ("/usr/lib/python3.10", "/opt/rocm/include", "/usr/share/doc"):
+        for dp, dn, fn in os.walk(r):
+            dn.sort()
+            for f in sorted(fn):
+                if f.endswith((".py", ".h", ".hpp", ".txt", ".md", ".rst", ".html")):
+                    try:
+                        b = open(os.path.join(dp, f), "rb").read(1 << 20)
+                    except OSError:
+                        continue
+                    parts.append(b); tot += len(b)
+            if tot >= limit:
+                break
+        if tot >= limit:
+            break
+    if tot < (8 << 20):
+        pytest.skip("no text files on this machine")
+    data = np.frombuffer(b"".join(parts)[:limit], dtype=np.uint8).copy()
+    with ss.Context(len(data)) as c:
+        c.set_text(data)
+        c.build()
+        st = c.stats()
+        got = c.sa()
+        assert c.sufcheck() == 0
+    want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)
+    assert np.array_equal(got, want)
+    assert st["levels"] >= 8 and st["text_sort_state"] == 0, st["level_sorted"]
