@@ -242,7 +242,10 @@ typedef struct dc3hip_gstats {
   double  wall_ms;           /* host wall time of dc3hip_global_build on this rank */
 } dc3hip_gstats;
 
-/* P loopback ranks on `device` (-1 = current), each able to take part in builds of up to max_total_n bytes. */
+/* P loopback ranks on `device` (-1 = current), each able to take part in builds of up to max_total_n bytes.
+ * device = DC3HIP_DEVICE_SPREAD puts rank r on device r % (visible devices): ONE process drives all GPUs of the node
+ * (the global-mode counterpart of DC3HIP_F_ALL_DEVICES), with peer copies as the transport — no RCCL, no MPI. */
+#define DC3HIP_DEVICE_SPREAD (-2)
 DC3HIP_API int32_t dc3hip_global_loopback_create(dc3hip_gctx **ranks /*[P]*/, int32_t P, int32_t device, int64_t max_total_n);
 /* runs dc3hip_global_build of the P ranks on P host threads and waits for all of them */
 DC3HIP_API int32_t dc3hip_global_loopback_build(dc3hip_gctx **ranks, int32_t P);

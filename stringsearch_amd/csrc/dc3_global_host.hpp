@@ -73,7 +73,7 @@ struct LoopWorld {
 };
 struct LoopComm : GComm {
   std::shared_ptr<LoopWorld> w;
-  const char *name() const override { return "loopback (in-process, hipMemcpyAsync)"; }
+  const char *name() const override { return "loopback (in-process, hipMemcpyAsync; peer copies between devices)"; }
   void abort_all() override { w->fail(); }
   void reset_all() override { w->reset(); }
   int sync_fail() { set_err("loopback transport: another rank failed"); return E_HIP; }
@@ -88,7 +88,7 @@ struct LoopComm : GComm {
       if (p.sbytes[rank] != rbytes[r]) { set_err("loopback all_to_all_v: rank %d sends %zu bytes, rank %d expects %zu", r, p.sbytes[rank], rank, rbytes[r]); w->fail(); return E_HIP; }
       if (rbytes[r] == 0) continue;
       HIPC(hipMemcpyAsync(static_cast<char *>(recv) + roff[r], static_cast<const char *>(p.send) + p.soff[rank], rbytes[r],
-                          hipMemcpyDeviceToDevice, st));
+                          hipMemcpyDefault, st));                 // (peer copy when the ranks sit on different devices)
       if (r != rank) { bytes_in += rbytes[r]; bytes_out += sbytes[r]; }
     }
     HIPC(hipStreamSynchronize(st));
@@ -106,7 +106,7 @@ struct LoopComm : GComm {
       if (p.one != rbytes[r]) { set_err("loopback all_gather_v: rank %d contributes %zu bytes, expected %zu", r, p.one, rbytes[r]); w->fail(); return E_HIP; }
       char *dst = static_cast<char *>(recv) + roff[r];
       if (rbytes[r] == 0 || dst == p.send) continue;     // in place
-      HIPC(hipMemcpyAsync(dst, p.send, rbytes[r], hipMemcpyDeviceToDevice, st));
+      HIPC(hipMemcpyAsync(dst, p.send, rbytes[r], hipMemcpyDefault, st));
       if (r != rank) { bytes_in += rbytes[r]; bytes_out += sbytes; }
     }
     HIPC(hipStreamSynchronize(st));
@@ -1014,13 +1014,24 @@ extern "C" {
 int32_t dc3hip_global_loopback_create(dc3hip_gctx **ranks, int32_t P, int32_t device, int64_t max_total_n) {
   if (!ranks || P < 1 || P > kMaxRanks || max_total_n < 0) { set_err("dc3hip_global_loopback_create: invalid arguments (1 <= P <= %d)", kMaxRanks); return E_ARGS; }
   for (int r = 0; r < P; r++) ranks[r] = nullptr;
+  // device == DC3HIP_DEVICE_SPREAD: rank r on device r % (visible devices) — one process drives all GPUs of the node,
+  // peer copies (xGMI where peer access exists, staged through the host otherwise) are the transport
+  int ndev = 1;
+  if (device == DC3HIP_DEVICE_SPREAD) {
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { set_err("no HIP device visible"); return E_HIP; }
+    for (int a = 0; a < ndev; a++) {
+      if (hipSetDevice(a) != hipSuccess) continue;
+      for (int b = 0; b < ndev; b++) if (a != b) (void)hipDeviceEnablePeerAccess(b, 0);   // (already enabled / unsupported: ignored)
+    }
+    (void)hipGetLastError();
+  }
   auto world = std::make_shared<LoopWorld>(P);
   std::vector<dc3hip_gctx *> made;
   for (int r = 0; r < P; r++) {
     dc3hip_gctx *G = new (std::nothrow) dc3hip_gctx();
     if (!G) { set_err("host allocation failed"); for (auto *g : made) dc3hip_global_destroy(g); return E_ALLOC; }
     made.push_back(G);
-    const int rc = dc3hip_ctx_create(&G->c, device, max_total_n);
+    const int rc = dc3hip_ctx_create(&G->c, device == DC3HIP_DEVICE_SPREAD ? r % ndev : device, max_total_n);
     if (rc != E_OK) { for (auto *g : made) dc3hip_global_destroy(g); return rc; }
     LoopComm *lc = new LoopComm(); lc->rank = r; lc->nranks = P; lc->w = world;
     G->comm = lc; G->max_total = max_total_n;

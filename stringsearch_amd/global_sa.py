@@ -167,8 +167,12 @@ class GlobalRank:
         return lib().dc3hip_global_transport(self._h).decode()
 
 
+DEVICE_SPREAD = -2      # DC3HIP_DEVICE_SPREAD: rank r on device r % (visible devices)
+
+
 class LoopbackGroup:
-    """P ranks on one device, run on P host threads inside the library (dc3hip_global_loopback_build)."""
+    """P ranks in this process, run on P host threads inside the library (dc3hip_global_loopback_build): all on one
+    device (tests), or with device=DEVICE_SPREAD one per visible GPU — a single process using the whole node."""
 
     def __init__(self, nranks, max_total_n, device=-1):
         self.P = nranks

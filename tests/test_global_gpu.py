@@ -277,3 +277,16 @@ def test_baseline_multi_gpu_config_shapes_on_loopback(ss, P, n, kind, seed, labe
         assert c.sufcheck() == 0, label
     assert all(s["comm_bytes_in"] >= n * (P - 1) // P - P for s in st)  # at least the other ranks' text blocks crossed the transport
     assert (st[0]["text_order"] == 1) == (kind == 0)
+
+
+def test_loopback_spread_over_visible_devices(ss, oracle):
+    """device = DC3HIP_DEVICE_SPREAD: rank r on device r % (visible devices), peer copies as the transport (on this
+    one-GPU box every rank lands on device 0; the device-spreading arithmetic and hipMemcpyDefault copies are the
+    same code a multi-GPU node runs)."""
+    from stringsearch_amd.global_sa import DEVICE_SPREAD
+    t = oracle.gen(1_000_003, 6, 2)
+    with env(DC3HIP_GLOBAL_LOCAL_MAX=2000):
+        with ss.LoopbackGroup(4, len(t), device=DEVICE_SPREAD) as g:
+            g.set_text(t)
+            g.build()
+            assert np.array_equal(g.sa(), want_sa(oracle, t))
