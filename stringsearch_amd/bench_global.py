@@ -13,11 +13,46 @@ XGMI_LINK_GBS = 153.0         # per direction and link (prompt / MI355X guide: 7
 
 
 def make_rank(ss, dist, backend, world, rank, local_rank, max_total):
-    """RCCL (default, one rank per GPU) or the host-staged transport over the gloo group (several ranks per GPU)."""
+    """RCCL (default, one rank per GPU) or the host-staged transport over the gloo group (several ranks per GPU).
+    If the library's own RCCL communicator cannot be created on some rank, ALL ranks fall back to the host-staged
+    transport over a gloo group (the ranks agree on that with one all-reduce)."""
     if backend == "nccl":
-        uid = [ss.GlobalRank.rccl_unique_id() if rank == 0 else None]
+        import torch
+        g = None
+        err = ""
+        try:
+            uid = [ss.GlobalRank.rccl_unique_id() if rank == 0 else None]
+        except Exception as e:          # rank 0 could not even load RCCL: the others must not wait for an id
+            uid, err = [None], repr(e)
         dist.broadcast_object_list(uid, src=0)
-        return ss.GlobalRank.rccl(uid[0], rank, world, local_rank, max_total)
+        if uid[0] is not None:
+            try:
+                g = ss.GlobalRank.rccl(uid[0], rank, world, local_rank, max_total)
+            except Exception as e:
+                err = repr(e)
+        ok = torch.tensor([1 if g is not None else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            return g
+        if g is not None:
+            g.close()
+        if rank == 0:
+            print(f"bench_global: RCCL transport unavailable ({err or 'on another rank'}); using the host-staged transport over gloo",
+                  flush=True)
+        grp = dist.new_group(backend="gloo")
+
+        class _GroupDist:               # the subset of torch.distributed the callbacks use, bound to the gloo group
+            P2POp = dist.P2POp
+            isend = staticmethod(dist.isend); irecv = staticmethod(dist.irecv)
+
+            @staticmethod
+            def batch_isend_irecv(ops):
+                return dist.batch_isend_irecv([dist.P2POp(o.op, o.tensor, o.peer, grp) for o in ops])
+
+            @staticmethod
+            def all_gather(outs, t):
+                return dist.all_gather(outs, t, group=grp)
+        return ss.GlobalRank.torch_host(_GroupDist, rank, world, local_rank, max_total)
     return ss.GlobalRank.torch_host(dist, rank, world, local_rank, max_total)
 
 
