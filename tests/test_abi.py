@@ -105,3 +105,27 @@ def test_product_does_not_touch_oracle():
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in src.lower(), os.path.join(dirpath, f)
     assert "oracle" not in open(os.path.join(ROOT, "include", "dc3hip.h")).read().lower()
+
+
+def test_global_mode_fails_loudly_without_device(built):
+    """The global mode has no CPU path either: creating ranks without a usable device fails with a library error
+    (never a silent fallback), argument errors are reported as -1, and the struct mirrors match the header."""
+    import stringsearch_amd as ss
+    from stringsearch_amd._lib import GStats, HostTransport
+    L = built.lib()
+    arr = (ctypes.c_void_p * 2)()
+    assert L.dc3hip_global_loopback_create(arr, 0, -1, 100) == -1            # P < 1
+    assert L.dc3hip_global_loopback_create(arr, 17, -1, 100) == -1           # P > 16
+    assert L.dc3hip_global_loopback_create(None, 2, -1, 100) == -1
+    if ss.device_count() < 1:
+        rc = L.dc3hip_global_loopback_create(arr, 2, -1, 100)
+        assert rc in (-3, -2), rc
+        assert arr[0] is None and arr[1] is None
+        with pytest.raises(ss.Dc3HipError):
+            ss.LoopbackGroup(2, 100)
+    hdr = open(os.path.join(ROOT, "include", "dc3hip.h")).read()
+    body = re.search(r"typedef struct dc3hip_gstats \{(.*?)\} dc3hip_gstats;", hdr, re.S).group(1)
+    fields = re.findall(r"\b(\w+)\s*(?:,|;)", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
+    assert [f for f, _ in GStats._fields_] == fields
+    assert [f for f, _ in HostTransport._fields_] == ["user", "all_to_all_v", "all_gather_v"]
+    assert int(re.search(r"#define DC3HIP_DEVICE_SPREAD \((-?\d+)\)", hdr).group(1)) == ss.global_sa.DEVICE_SPREAD
