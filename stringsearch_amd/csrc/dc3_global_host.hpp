@@ -952,6 +952,8 @@ static int gbuild_inner(dc3hip_gctx *G) {
   const int P = cm->nranks, me = cm->rank;
   const int64_t n = G->total_n;
   c->n = n;
+  c->arena_off = 0;
+  RC(ensure_arena(c, arena_requirement(n)));      // a rank may end up with a whole level's key range: the full budget
   RC(build_begin(c));
   // 1. the text, replicated: all-gather of the ranks' blocks (n x (P-1)/P bytes in per rank)
   {

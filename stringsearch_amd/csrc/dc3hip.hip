@@ -66,6 +66,7 @@ struct dc3hip_ctx {
   u32 *d_sa = nullptr;         // max_n + 16 words
   unsigned char *arena = nullptr;
   size_t arena_bytes = 0, arena_off = 0, arena_peak = 0;
+  bool arena_fixed = false;    // DC3HIP_ARENA_BYTES given: never grown
   // small device scratch
   u32 *d_present = nullptr;    // [256]
   uint16_t *d_code = nullptr;  // [256]
@@ -130,6 +131,23 @@ static size_t arena_requirement(int64_t n) {
     m = m02;
   }
   return total + (8u << 20);
+}
+
+// What the whole-text order (and every by-product except the LCP array) needs: two 8-byte record arrays, the image
+// side array, a flag byte per record, radix tables and the tie predictor.  A context starts with this much and grows
+// to arena_requirement() the first time a build enters the DC3 recursion (ensure_arena): high-entropy texts never
+// do, so their contexts hold half the memory and the first hipMalloc is half as long.
+static size_t arena_text_requirement(int64_t n) { return (size_t)n * 24 + ((size_t)128 << 20); }
+
+// Grow the (empty) arena to at least `need` bytes.  Never shrinks; a size forced by DC3HIP_ARENA_BYTES stays as it is.
+static int ensure_arena(dc3hip_ctx *c, size_t need) {
+  if (c->arena_bytes >= need || c->arena_fixed) return E_OK;
+  if (c->arena_off != 0) { set_err("internal: arena grown while in use"); return E_HIP; }
+  HIPC(hipStreamSynchronize(c->stream));
+  if (c->arena) { HIPC(hipFree(c->arena)); c->arena = nullptr; c->arena_bytes = 0; }
+  HIPC(hipMalloc(&c->arena, need));
+  c->arena_bytes = need;
+  return E_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1284,6 +1302,7 @@ static int build_end(dc3hip_ctx *c) {
   }
   HIPC(hipStreamSynchronize(c->stream));
   c->stats.arena_peak = (int64_t)c->arena_peak;
+  c->stats.arena_bytes = (int64_t)c->arena_bytes;
   if (c->profile) {
     float ms = 0;
     HIPC(hipEventElapsedTime(&ms, c->ev_build_a, c->ev_build_b));
@@ -1343,7 +1362,7 @@ static int build_core(dc3hip_ctx *c) {
     // (even uniformly random symbols repeat a 9-symbol window once sigma^9 is not well above n^2/2: skip then)
     const bool windows_can_be_distinct = 9.0 * log2((double)sigma) >= 2.0 * log2((double)n) + 2.0;
     if ((u64)n >= kHybridMinSamples && !c->no_hybrid && !c->no_fullsort && !c->no_text_shortcut && windows_can_be_distinct &&
-        B3 * B3 * B3 > 0x7fffffffull && c->arena_bytes - c->arena_off >= (size_t)n * 32 + (64u << 20)) {
+        B3 * B3 * B3 > 0x7fffffffull && c->arena_bytes - c->arena_off >= (size_t)n * 22 + (64u << 20)) {
       // whole-text shortcut: if all 9-byte windows of a high-entropy text are distinct, sorting all positions by
       // them is the suffix array (the same test level 1 would make on its triples, without building level 1)
       u32 kbits = 0;
@@ -1374,7 +1393,10 @@ static int build_core(dc3hip_ctx *c) {
         }
       }
     }
-    if (!whole_text) RC(dc3_level<SymU8>(c, S, (u32)n, sigma, c->d_sa, nullptr, 0, pre.spos ? &pre : nullptr));
+    if (!whole_text) {
+      RC(ensure_arena(c, arena_requirement(n)));          // (the arena is empty here: the filtered order lives in d_sa)
+      RC(dc3_level<SymU8>(c, S, (u32)n, sigma, c->d_sa, nullptr, 0, pre.spos ? &pre : nullptr));
+    }
   }
   return E_OK;
 }
@@ -1446,10 +1468,10 @@ int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) {
     HIPC(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPC(hipMalloc(&c->d_text, (size_t)max_n + 64));
     HIPC(hipMalloc(&c->d_sa, ((size_t)max_n + 16) * sizeof(u32)));
-    c->arena_bytes = arena_requirement(max_n);
+    c->arena_bytes = std::min(arena_requirement(max_n), arena_text_requirement(max_n));   // grown on demand (ensure_arena)
     // testing aid: DC3HIP_ARENA_BYTES=<bytes> replaces the computed size (a build then either fits — possibly through
     // a fallback ordering — or fails loudly with -2; it never returns a wrong array)
-    if (const char *e = getenv("DC3HIP_ARENA_BYTES")) { const long long v = atoll(e); if (v > 0) c->arena_bytes = (size_t)v; }
+    if (const char *e = getenv("DC3HIP_ARENA_BYTES")) { const long long v = atoll(e); if (v > 0) { c->arena_bytes = (size_t)v; c->arena_fixed = true; } }
     HIPC(hipMalloc(&c->arena, c->arena_bytes));
     HIPC(hipMalloc(&c->d_present, 256 * sizeof(u32)));
     HIPC(hipMalloc(&c->d_code, 256 * sizeof(uint16_t)));
@@ -1645,6 +1667,7 @@ int32_t dc3hip_ctx_lcp_i32(dc3hip_ctx *c, int32_t *LCP) {
   const u32 n = (u32)n64;
   HIPC(hipSetDevice(c->device));
   c->arena_off = 0;
+  RC(ensure_arena(c, (size_t)n * 26 + ((size_t)64 << 20)));
   u32 *phi = nullptr, *plcp = nullptr;
   int32_t *dout = nullptr;
   RC(arena_alloc(c, (size_t)n + 16, &phi));
@@ -1722,6 +1745,7 @@ int32_t dc3hip_ctx_search(dc3hip_ctx *c, const uint8_t *needles, const int64_t *
   const int64_t total = offsets[count];
   RC(ensure_trusted_sa(c));
   c->arena_off = 0;
+  RC(ensure_arena(c, (size_t)total + (size_t)count * 24 + ((size_t)1 << 20)));
   uint8_t *dn = nullptr; int64_t *doff = nullptr, *ds = nullptr, *dl = nullptr;
   RC(arena_alloc(c, (size_t)total + 16, &dn));
   RC(arena_alloc(c, (size_t)count + 1, &doff));
@@ -1744,9 +1768,9 @@ int32_t dc3hip_ctx_search(dc3hip_ctx *c, const uint8_t *needles, const int64_t *
 int32_t dc3hip_ctx_debug_radix_pass_u64(dc3hip_ctx *c, const uint64_t *words, uint64_t *out, int64_t n, int32_t shift,
                                         int32_t nb) {
   if (!c || !words || !out || n < 1 || shift < 0 || shift > 55 || (nb != 256 && nb != 512)) { set_err("invalid arguments"); return E_ARGS; }
-  if ((size_t)n * 40 + (64u << 20) > c->arena_bytes) { set_err("n too large for this context"); return E_ARGS; }
   HIPC(hipSetDevice(c->device));
   c->arena_off = 0;
+  RC(ensure_arena(c, (size_t)n * 40 + ((size_t)64 << 20)));
   Rec8 *a = nullptr, *b = nullptr, *res = nullptr;
   RC(arena_alloc(c, (size_t)n, &a));
   RC(arena_alloc(c, (size_t)n, &b));
