@@ -714,6 +714,7 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
     // that on top of what the caller holds, give the ordering up (*ok stays false -> the caller's next ordering
     // runs instead); arena_requirement() only bounds the straight ordering
     if (c->arena_bytes - c->arena_off < (size_t)tied * 36 + (32u << 20)) return E_OK;
+    const ArenaMark mk_general = arena_mark(c);     // the tied subset is dead after the write-back: released there
     Rec16 *sa = nullptr, *sb = nullptr, *ss = nullptr;
     u32 *tiedidx = nullptr;
     RC(arena_alloc(c, (size_t)tied, &sa));
@@ -732,6 +733,7 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
       hipLaunchKernelGGL(k_tie_writeback, dim3(grid_for(c, tied)), dim3(kBlock), 0, c->stream, ss, tiedidx, tied, h, f);
       KCHECK();
     }
+    arena_release(c, mk_general);
   }
   *h_out = h;
   *ok = true;
@@ -808,6 +810,7 @@ static int order_hybrid12(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u
     // some tied group is larger than kTieSmallMax: re-sort ALL tied records by the full key (the small groups that were
     // already settled are re-done consistently)
     if (c->arena_bytes - c->arena_off < (size_t)tied * 36 + (32u << 20)) { arena_release(c, mk); return E_OK; }
+    const ArenaMark mk_general = arena_mark(c);     // the tied subset is dead after the write-back: released there
     const Chunking ck = make_chunks(c, m02, kBlock);
     u32 *counts = nullptr, *tiedidx = nullptr;
     Rec16 *sa = nullptr, *sb = nullptr, *ss = nullptr;
@@ -837,6 +840,7 @@ static int order_hybrid12(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u
       hipLaunchKernelGGL(k_tie_writeback12, dim3(grid_for(c, tied)), dim3(kBlock), 0, c->stream, ss, tiedidx, tied, h, f);
       KCHECK();
     }
+    arena_release(c, mk_general);
   }
   c->stats.level_sorted[depth] = 2;
   AccHyb12 acc; acc.h = h; acc.f = f;
