@@ -69,6 +69,7 @@ struct dc3hip_ctx {
   unsigned char *arena = nullptr;
   size_t arena_bytes = 0, arena_off = 0, arena_peak = 0;
   bool arena_fixed = false;    // DC3HIP_ARENA_BYTES given: never grown
+  bool arena_exhausted = false; // the last E_ALLOC came from the bump allocator (not from hipMalloc)
   // small device scratch
   u32 *d_present = nullptr;    // [256]
   uint16_t *d_code = nullptr;  // [256]
@@ -107,6 +108,7 @@ static int arena_alloc(dc3hip_ctx *c, size_t count, T **out) {
   if (c->arena_off + bytes > c->arena_bytes) {
     set_err("device work arena exhausted: need %zu more bytes (arena %zu, used %zu)", bytes, c->arena_bytes,
             c->arena_off);
+    c->arena_exhausted = true;
     return E_ALLOC;
   }
   *out = reinterpret_cast<T *>(c->arena + c->arena_off);
@@ -1408,10 +1410,25 @@ static int build_core(dc3hip_ctx *c) {
   return E_OK;
 }
 
-static int ctx_build(dc3hip_ctx *c) {
+static int ctx_build_once(dc3hip_ctx *c) {
   RC(build_begin(c));
   RC(build_core(c));
   return build_end(c);
+}
+// arena_requirement() is a model of the paths' peaks, not a proof: if the bump allocator (not hipMalloc) runs out, the
+// arena is grown by half and the build — deterministic, nothing was returned yet — is repeated once.
+static int ctx_build(dc3hip_ctx *c) {
+  c->arena_exhausted = false;
+  int rc = ctx_build_once(c);
+  if (rc == E_ALLOC && c->arena_exhausted && !c->arena_fixed) {
+    (void)hipStreamSynchronize(c->stream);
+    c->arena_off = 0;
+    if (ensure_arena(c, c->arena_bytes + c->arena_bytes / 2 + ((size_t)64 << 20)) == E_OK) {
+      c->arena_exhausted = false;
+      rc = ctx_build_once(c);
+    }
+  }
+  return rc;
 }
 
 // ---------------------------------------------------------------------------------------------
