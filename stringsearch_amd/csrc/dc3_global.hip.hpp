@@ -111,8 +111,16 @@ struct SelSampleImage {
     return img >= lo && (last || img < hi);
   }
 };
+// (key, position) order: equal keys are split between ranks by position, so that a level with few distinct keys
+// (one repeated byte, short periods) is still sorted by all ranks; naming then looks at the neighbours' boundary keys
+__device__ __forceinline__ bool keypos_lt(const Rec16 &a, const Rec16 &b) {
+  if (a.k2 != b.k2) return a.k2 < b.k2;
+  if (a.k1 != b.k1) return a.k1 < b.k1;
+  if (a.k0 != b.k0) return a.k0 < b.k0;
+  return a.pos < b.pos;
+}
 // sorted naming of a level: item q = q-th sample position in ascending order (3g+1, 3g+2, ...); record = full-key Rec16;
-// kept iff klo <= key (< khi unless last).  has_lo = 0 for rank 0.
+// kept iff klo <= (key, pos) (< khi unless last).  has_lo = 0 for rank 0.
 template <class Sym>
 struct SelTripleKey {
   typedef Rec16 Out;
@@ -121,7 +129,7 @@ struct SelTripleKey {
   __device__ __forceinline__ bool pick(u32 q, const uint16_t *, Rec16 &o) const {
     const u32 g = q >> 1, i = 3 * g + 1 + (q & 1);
     o = make_rec(S.get(i), S.get(i + 1), S.get(i + 2), B, i);
-    return (!has_lo || !key_lt(o, klo)) && (last || key_lt(o, khi));
+    return (!has_lo || !keypos_lt(o, klo)) && (last || keypos_lt(o, khi));
   }
 };
 // merge, sample side: item = slot; kept iff lo <= rank12[slot] < hi; record = (rank - lo, slot): a bijection onto

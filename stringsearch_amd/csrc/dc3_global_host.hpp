@@ -559,9 +559,11 @@ static int glevel(dc3hip_gctx *G, Sym S, u32 m, u64 K, int depth, u32 *out, GOut
 //   counts of distinct / unique names go around (all-gather of two words), names continue after those of the smaller
 //   key ranges (equal keys never straddle ranks); the (slot, name [| unique << 31]) pairs land in the caller's buffer
 //   pa (m02 entries), which the caller exchanges into R AFTER releasing its sort buffers.
-template <class Acc>
-static int gname_pairs(dc3hip_gctx *G, Acc acc, u32 cnt, u32 m0, u32 m02, Rec8 *pa, u32 *sslot, uint64_t *names_total,
-                       uint64_t *uniq_total, uint64_t *cnt_pre, bool *discard) {
+template <class Acc0>
+static int gname_pairs(dc3hip_gctx *G, Acc0 acc0, u32 cnt, u32 m0, u32 m02, Rec8 *pa, u32 *sslot, uint64_t *names_total,
+                       uint64_t *uniq_total, uint64_t *cnt_pre, bool *discard, bool first_eq = false, bool last_eq_next = false) {
+  typedef AccBound<Acc0> Acc;
+  Acc acc; acc.a = acc0; acc.first_eq = first_eq ? 1u : 0u; acc.last_eq_next = last_eq_next ? 1u : 0u;
   dc3hip_ctx *c = G->c; GComm *cm = G->comm;
   const ArenaMark mk = arena_mark(c);
   const Chunking ck = make_chunks(c, std::max<u32>(cnt, 1), kBlock * kNameIPT);
@@ -808,7 +810,8 @@ static int glevel(dc3hip_gctx *G, Sym S, u32 m, u64 K, int depth, u32 *out, GOut
         std::sort(hs.begin(), hs.end(), [](const Rec16 &x, const Rec16 &y) {
           if (x.k2 != y.k2) return x.k2 < y.k2;
           if (x.k1 != y.k1) return x.k1 < y.k1;
-          return x.k0 < y.k0;
+          if (x.k0 != y.k0) return x.k0 < y.k0;
+          return x.pos < y.pos;                      // equal keys are split by position (see keypos_lt)
         });
         if (me > 0) klo = hs[(size_t)((u64)me * ns / P)];
         if (me + 1 < P) khi = hs[(size_t)((u64)(me + 1) * ns / P)];
@@ -819,8 +822,27 @@ static int glevel(dc3hip_gctx *G, Sym S, u32 m, u64 K, int depth, u32 *out, GOut
       RC(arena_alloc(c, (size_t)cnt + 16, &recB));
       sorted = recA;
       if (cnt) RC(radix_sort<Rec16>(c, recA, recB, cnt, 0, kbits, &sorted, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT12_DOWN));
+      // equal keys may straddle ranks: every rank learns its neighbours' boundary keys (first / last record of each
+      // rank's sorted range, one small all-gather) and names continue across the boundary where they are equal
+      struct Edge { u32 f[3], l[3], has, pad; } mine, all_e[kMaxRanks];
+      memset(&mine, 0, sizeof(mine));
+      if (cnt) {
+        Rec16 fl[2];
+        HIPC(hipMemcpyAsync(&fl[0], sorted, sizeof(Rec16), hipMemcpyDeviceToHost, c->stream));
+        HIPC(hipMemcpyAsync(&fl[1], sorted + (cnt - 1), sizeof(Rec16), hipMemcpyDeviceToHost, c->stream));
+        HIPC(hipStreamSynchronize(c->stream));
+        mine.f[0] = fl[0].k0; mine.f[1] = fl[0].k1; mine.f[2] = fl[0].k2;
+        mine.l[0] = fl[1].k0; mine.l[1] = fl[1].k1; mine.l[2] = fl[1].k2; mine.has = 1;
+      }
+      RC(cm->all_gather_host(&mine, all_e, sizeof(Edge)));
+      bool first_eq = false, last_eq_next = false;
+      if (cnt) {
+        for (int h = me - 1; h >= 0; h--) if (all_e[h].has) { first_eq = memcmp(all_e[h].l, mine.f, 12) == 0; break; }
+        for (int h = me + 1; h < P; h++) if (all_e[h].has) { last_eq_next = memcmp(all_e[h].f, mine.l, 12) == 0; break; }
+      }
       AccRec<Rec16> acc; acc.s = sorted;
-      RC(gname_pairs<AccRec<Rec16>>(G, acc, cnt, m0, m02, pa, sslot, &names_total, &uniq_total, &cnt_pre, &discard));
+      RC(gname_pairs<AccRec<Rec16>>(G, acc, cnt, m0, m02, pa, sslot, &names_total, &uniq_total, &cnt_pre, &discard, first_eq,
+                                    last_eq_next));
     }
     arena_release(c, mk1);
     RC(rank_exchange(G, pa, cnt, m02, R, DC3HIP_PH_NAMING));      // R[slot] = name (| unique << 31), everywhere

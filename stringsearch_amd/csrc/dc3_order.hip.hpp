@@ -34,19 +34,32 @@ struct AccRec {
     const Rec a = s[i], b = s[i - 1];
     return key_neq(a, b) ? 1u : 0u;
   }
+  __device__ __forceinline__ u32 tail_differs() const { return 1u; }
 };
 struct AccHyb {
   const Rec8 *h; const uint8_t *f; u32 posmask;   // pos = low bits of h[i].val; f[i] = 1 iff key(i) != key(i-1)
   __device__ __forceinline__ u32 pos(u32 i) const { return h[i].val & posmask; }
   __device__ __forceinline__ u32 neq(u32 i) const { return f[i]; }
+  __device__ __forceinline__ u32 tail_differs() const { return 1u; }
 };
 
 constexpr int kNameIPT = 4;
 // a name is unique iff its key differs from both neighbours in the sorted order
+// (tail_differs(): does the key BEHIND the last entry differ from it?  Always for a complete sorted array; the global
+// mode, where a rank holds a range of the sorted order, answers from its right neighbour's first key: AccBound.)
 template <class Acc>
 __device__ __forceinline__ u32 acc_unique(const Acc &acc, u32 i, u32 n) {
-  return (acc.neq(i) && (i + 1 == n || acc.neq(i + 1))) ? 1u : 0u;
+  return (acc.neq(i) && (i + 1 == n ? acc.tail_differs() : acc.neq(i + 1))) ? 1u : 0u;
 }
+// A range [0, n) of a longer sorted order: entry 0 continues the left neighbour's last key iff first_eq, the right
+// neighbour's first key equals the last entry iff last_eq_next.
+template <class Acc>
+struct AccBound {
+  Acc a; u32 first_eq, last_eq_next;
+  __device__ __forceinline__ u32 pos(u32 i) const { return a.pos(i); }
+  __device__ __forceinline__ u32 neq(u32 i) const { return i == 0 ? (first_eq ? 0u : 1u) : a.neq(i); }
+  __device__ __forceinline__ u32 tail_differs() const { return last_eq_next ? 0u : 1u; }
+};
 template <class Acc>
 __global__ __launch_bounds__(kBlock) void k_name_count(Acc acc, u32 n, u32 chunk, u32 *counts, u32 *uniq_total) {
   __shared__ u32 tmp[kWaves], tmpu[kWaves];
@@ -526,6 +539,7 @@ struct AccFilt {
   const u32 *spos, *snf;
   __device__ __forceinline__ u32 pos(u32 j) const { return spos[j]; }
   __device__ __forceinline__ u32 neq(u32 j) const { return (j == 0 || snf[j] != snf[j - 1]) ? 1u : 0u; }
+  __device__ __forceinline__ u32 tail_differs() const { return 1u; }
 };
 // Which sorted records are samples of the level being named, and under which position:
 //   MapSelf : the records are the level's own positions (the dummy, if any, is record 0 at pos == m)
@@ -848,6 +862,7 @@ struct AccHyb12 {
   const Rec12 *h; const uint8_t *f;
   __device__ __forceinline__ u32 pos(u32 i) const { return h[i].pos; }
   __device__ __forceinline__ u32 neq(u32 i) const { return f[i]; }
+  __device__ __forceinline__ u32 tail_differs() const { return 1u; }
 };
 template <class Sym, int NB>
 __global__ __launch_bounds__(kBlock) void k_pack_image12_hist(Sym S, u32 m, u32 m0, u32 m02, u32 b, u32 kbits,
