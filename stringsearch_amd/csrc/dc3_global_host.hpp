@@ -488,12 +488,16 @@ static int image_splitters(dc3hip_ctx *c, const Rec8 *d_sample, u32 ns, u32 pbit
   std::vector<Rec8> hs(ns);
   HIPC(hipMemcpyAsync(hs.data(), d_sample, (size_t)ns * sizeof(Rec8), hipMemcpyDeviceToHost, c->stream));
   HIPC(hipStreamSynchronize(c->stream));
-  std::vector<u64> img(ns);
-  for (u32 i = 0; i < ns; i++) img[i] = ((((u64)hs[i].key) << 32) | hs[i].val) >> pbits;
+  // a few thousand candidates per rank are plenty (a host sort of the whole 2^20-record predictor sample cost 60 ms)
+  const u32 step = std::max<u32>(1, ns / (u32)(4096 * P));
+  std::vector<u64> img;
+  img.reserve(ns / step + 1);
+  for (u32 i = 0; i < ns; i += step) img.push_back(((((u64)hs[i].key) << 32) | hs[i].val) >> pbits);
   std::sort(img.begin(), img.end());
+  const size_t k = img.size();
   *lo = 0; *hi = ~0ull;
-  if (me > 0) *lo = img[(size_t)((u64)me * ns / P)];
-  if (me + 1 < P) *hi = img[(size_t)((u64)(me + 1) * ns / P)];
+  if (me > 0) *lo = img[(size_t)((u64)me * k / P)];
+  if (me + 1 < P) *hi = img[(size_t)((u64)(me + 1) * k / P)];
   return E_OK;
 }
 
@@ -746,7 +750,7 @@ static int glevel(dc3hip_gctx *G, Sym S, u32 m, u64 K, int depth, u32 *out, GOut
     const ArenaMark mk1 = arena_mark(c);
     const HiMap hm = make_himap(B, kbits, m);
     double pred = 1.0;
-    const bool try_hybrid = m02 >= kHybridMinSamples / 4 && !c->no_hybrid;
+    const bool try_hybrid = m02 >= kHybridMinSamples / 4 && !c->no_hybrid && !c->no_hybrid8;
     if (try_hybrid) {
       RC(predict_tie_fraction<Sym>(c, S, m, m0, m02, b, hm, &pred));
       c->stats.level_tie_pred[depth] = pred;

@@ -742,6 +742,67 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
   return E_OK;
 }
 
+// Tie refinement of records sorted by their 63-bit key prefix (see order_hybrid12): f[i] = full key differs from the
+// predecessor's, tied groups ordered by the full key.  *ok = false: too many ties, or no room for the general path.
+template <class KM>
+static int hybrid12_refine(dc3hip_ctx *c, KM km, u32 kbits, Rec12 *h, u32 n, uint8_t *f, bool *ok, int depth) {
+  *ok = false;
+  HIPC(hipMemsetAsync(f, 1, (size_t)n, c->stream));
+  u32 tied = 0;
+  bool general = false;
+  {
+    PhaseScope ps(c, DC3HIP_PH_TIES, n);
+    HIPC(hipMemsetAsync(c->d_words + 10, 0, 3 * sizeof(u32), c->stream));
+    hipLaunchKernelGGL((k_tie_resolve12<KM>), dim3(grid_for(c, n / 4 + 1)), dim3(kBlock), 0, c->stream, km, h, n, f,
+                       c->d_words + 10);
+    KCHECK();
+    HIPC(hipMemcpyAsync(c->h_words + 10, c->d_words + 10, 3 * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPC(hipStreamSynchronize(c->stream));
+  tied = c->h_words[11];
+  c->stats.level_tied[depth] = tied;
+  general = c->h_words[10] != 0;
+  if ((double)tied > std::max(kHybridMaxMeasured, c->hybrid12_max_pred + 0.1) * (double)n) return E_OK;
+  if (general) {
+    // some tied group is larger than kTieSmallMax: re-sort ALL tied records by the full key (the small groups that were
+    // already settled are re-done consistently)
+    if (c->arena_bytes - c->arena_off < (size_t)tied * 36 + (32u << 20)) return E_OK;
+    const ArenaMark mk_general = arena_mark(c);     // the tied subset is dead after the write-back: released there
+    const Chunking ck = make_chunks(c, n, kBlock);
+    u32 *counts = nullptr, *tiedidx = nullptr;
+    Rec16 *sa = nullptr, *sb = nullptr, *ss = nullptr;
+    RC(arena_alloc(c, (size_t)ck.nchunks + 16, &counts));
+    {
+      PhaseScope ps(c, DC3HIP_PH_TIES, n);
+      hipLaunchKernelGGL(k_tie_count12, dim3(ck.nchunks), dim3(kBlock), 0, c->stream, h, n, ck.chunk, counts);
+      KCHECK();
+      hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, counts, ck.nchunks, c->d_words + 2);
+      KCHECK();
+      HIPC(hipMemcpyAsync(c->h_words + 2, c->d_words + 2, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPC(hipStreamSynchronize(c->stream));
+    tied = c->h_words[2];
+    RC(arena_alloc(c, (size_t)tied, &sa));
+    RC(arena_alloc(c, (size_t)tied, &sb));
+    RC(arena_alloc(c, (size_t)tied, &tiedidx));
+    {
+      PhaseScope ps(c, DC3HIP_PH_TIES, tied);
+      hipLaunchKernelGGL((k_tie_compact12<KM>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, km, h, n, ck.chunk, counts,
+                         sa, tiedidx);
+      KCHECK();
+    }
+    RC(radix_sort<Rec16>(c, sa, sb, tied, 0, kbits, &ss, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT12_DOWN));
+    {
+      PhaseScope ps(c, DC3HIP_PH_TIES, tied);
+      hipLaunchKernelGGL(k_tie_writeback12, dim3(grid_for(c, tied)), dim3(kBlock), 0, c->stream, ss, tiedidx, tied, h, f);
+      KCHECK();
+    }
+    arena_release(c, mk_general);
+  }
+  *ok = true;
+  return E_OK;
+}
+
 // Prefix sort + tie refinement on 12-byte records (kernels: "Prefix sort ... on 12-byte records" in dc3_order.hip.hpp):
 // for keys wider than 64 bits.  *ok = false: too many ties (predicted or measured), nothing was produced.
 template <class Sym>
@@ -792,57 +853,10 @@ static int order_hybrid12(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u
   }
   RC(radix_sort<Rec12>(c, ha, hb, m02, 0, kImg12Bits, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT12_DOWN,
                        first_table));
-  HIPC(hipMemsetAsync(f, 1, (size_t)m02, c->stream));
-  u32 tied = 0;
-  bool general = false;
   {
-    PhaseScope ps(c, DC3HIP_PH_TIES, m02);
-    HIPC(hipMemsetAsync(c->d_words + 10, 0, 3 * sizeof(u32), c->stream));
-    hipLaunchKernelGGL((k_tie_resolve12<Key3<Sym>>), dim3(grid_for(c, m02 / 4 + 1)), dim3(kBlock), 0, c->stream, km, h, m02, f,
-                       c->d_words + 10);
-    KCHECK();
-    HIPC(hipMemcpyAsync(c->h_words + 10, c->d_words + 10, 3 * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
-  }
-  HIPC(hipStreamSynchronize(c->stream));
-  tied = c->h_words[11];
-  c->stats.level_tied[depth] = tied;
-  general = c->h_words[10] != 0;
-  if ((double)tied > std::max(kHybridMaxMeasured, c->hybrid12_max_pred + 0.1) * (double)m02) { arena_release(c, mk); return E_OK; }
-  if (general) {
-    // some tied group is larger than kTieSmallMax: re-sort ALL tied records by the full key (the small groups that were
-    // already settled are re-done consistently)
-    if (c->arena_bytes - c->arena_off < (size_t)tied * 36 + (32u << 20)) { arena_release(c, mk); return E_OK; }
-    const ArenaMark mk_general = arena_mark(c);     // the tied subset is dead after the write-back: released there
-    const Chunking ck = make_chunks(c, m02, kBlock);
-    u32 *counts = nullptr, *tiedidx = nullptr;
-    Rec16 *sa = nullptr, *sb = nullptr, *ss = nullptr;
-    RC(arena_alloc(c, (size_t)ck.nchunks + 16, &counts));
-    {
-      PhaseScope ps(c, DC3HIP_PH_TIES, m02);
-      hipLaunchKernelGGL(k_tie_count12, dim3(ck.nchunks), dim3(kBlock), 0, c->stream, h, m02, ck.chunk, counts);
-      KCHECK();
-      hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, counts, ck.nchunks, c->d_words + 2);
-      KCHECK();
-      HIPC(hipMemcpyAsync(c->h_words + 2, c->d_words + 2, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
-    }
-    HIPC(hipStreamSynchronize(c->stream));
-    tied = c->h_words[2];
-    RC(arena_alloc(c, (size_t)tied, &sa));
-    RC(arena_alloc(c, (size_t)tied, &sb));
-    RC(arena_alloc(c, (size_t)tied, &tiedidx));
-    {
-      PhaseScope ps(c, DC3HIP_PH_TIES, tied);
-      hipLaunchKernelGGL((k_tie_compact12<Key3<Sym>>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, km, h, m02, ck.chunk, counts,
-                         sa, tiedidx);
-      KCHECK();
-    }
-    RC(radix_sort<Rec16>(c, sa, sb, tied, 0, kbits, &ss, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT12_DOWN));
-    {
-      PhaseScope ps(c, DC3HIP_PH_TIES, tied);
-      hipLaunchKernelGGL(k_tie_writeback12, dim3(grid_for(c, tied)), dim3(kBlock), 0, c->stream, ss, tiedidx, tied, h, f);
-      KCHECK();
-    }
-    arena_release(c, mk_general);
+    bool refined = false;
+    RC((hybrid12_refine<Key3<Sym>>(c, km, kbits, h, m02, f, &refined, depth)));
+    if (!refined) { arena_release(c, mk); return E_OK; }
   }
   c->stats.level_sorted[depth] = 2;
   AccHyb12 acc; acc.h = h; acc.f = f;

@@ -201,7 +201,7 @@ def test_loopback_env_matrix_agrees(ss, oracle):
     want = want_sa(oracle, t)
     for extra in ({}, {"DC3HIP_NO_HYBRID": 1}, {"DC3HIP_NO_FULLSORT": 1}, {"DC3HIP_NO_DISCARD": 1},
                   {"DC3HIP_NO_HYBRID": 1, "DC3HIP_NO_DISCARD": 1}, {"DC3HIP_NO_SMALL_TIES": 1}, {"DC3HIP_NO_SPLIT_EMIT": 1},
-                  {"DC3HIP_NO_TUP8": 1}):
+                  {"DC3HIP_NO_TUP8": 1}, {"DC3HIP_NO_HYBRID8": 1}, {"DC3HIP_NO_HYBRID8": 1, "DC3HIP_NO_DISCARD": 1}):
         with env(DC3HIP_GLOBAL_LOCAL_MAX=5000, **extra):
             with ss.LoopbackGroup(4, len(t)) as g:
                 g.set_text(t)

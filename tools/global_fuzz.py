@@ -47,8 +47,12 @@ while time.time() - t0 < budget:
     n = int(rng.integers(0, 40)) if rng.random() < 0.1 else int(10 ** rng.uniform(1.5, 5.6))
     lm = [0, 64, 1000, 30000, 1 << 22][int(rng.integers(0, 5))]
     envs = {"DC3HIP_GLOBAL_LOCAL_MAX": str(lm)}
-    for k in ("DC3HIP_GLOBAL_NO_TEXT_ORDER", "DC3HIP_NO_HYBRID", "DC3HIP_NO_DISCARD", "DC3HIP_NO_FULLSORT", "DC3HIP_GLOBAL_FORCE_DIST"):
+    for k in ("DC3HIP_GLOBAL_NO_TEXT_ORDER", "DC3HIP_NO_HYBRID", "DC3HIP_NO_DISCARD", "DC3HIP_NO_FULLSORT", "DC3HIP_GLOBAL_FORCE_DIST",
+              "DC3HIP_NO_HYBRID8"):
         if rng.random() < 0.25: envs[k] = "1"
+    if rng.random() < 0.5:
+        envs["DC3HIP_HYBRID12_MIN"] = "0"
+        if rng.random() < 0.5: envs["DC3HIP_HYBRID12_MAX_PRED"] = "2"
     text = make_text(n)
     for k, v in envs.items(): os.environ[k] = v
     try:
