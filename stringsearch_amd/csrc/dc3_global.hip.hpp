@@ -93,7 +93,7 @@ struct SelPosImage {
   KM km; HiMap hm; u64 lo, hi; u32 last;
   __device__ __forceinline__ void stage(uint16_t *lds) const { km.stage(lds); }
   __device__ __forceinline__ bool pick(u32 p, const uint16_t *lds, Rec8 &o) const {
-    o = hyb_rec(km.make(p, lds), hm);
+    o = km.image(p, lds, hm);
     const u64 img = rec8_word(o) >> hm.pbits;
     return img >= lo && (last || img < hi);
   }

@@ -328,6 +328,7 @@ struct Key3 {
   __device__ __forceinline__ Rec16 make(u32 p, const uint16_t *) const {
     return make_rec(S.get(p), S.get(p + 1), S.get(p + 2), B, p);
   }
+  __device__ __forceinline__ Rec8 image(u32 p, const uint16_t *lds, const HiMap &hm) const { return hyb_rec(make(p, lds), hm); }
 };
 struct Key9 {
   SymU8 S; u32 B /* sigma+1 */, B3 /* B^3 */;
@@ -342,7 +343,136 @@ struct Key9 {
     const u32 t2 = (q[6] * B + q[7]) * B + q[8];
     return make_rec(t0, t1, t2, B3, p);
   }
+  __device__ __forceinline__ Rec8 image(u32 p, const uint16_t *lds, const HiMap &hm) const { return hyb_rec(make(p, lds), hm); }
 };
+// KeyT = 3*L symbols of the text as three limbs of L symbols in base B (limb base BL = B^L < 2^32): the longer window
+// a small alphabet needs before windows can be distinct (DNA, B = 5: L = 13, 39 symbols, 90 bits).  L = 3 is Key9's
+// key.  Positions past the end read as the sentinel 0 (the text is followed by 64 zero bytes; 3*L <= 60).
+// Its sort image is NOT taken from that key: base B = sigma + 1 spends log2(sigma + 1) bits per symbol on an alphabet of
+// sigma (the sentinel never occurs inside the text), which at sigma = 4 leaves a 34-bit image 14 symbols — fewer values
+// than a 1 GiB text has positions.  The image is v = the first J symbols in base sigma (digit = code - 1, past the end
+// = 0: a monotone, not injective, map of the key — exactly what the tie refinement allows) scaled to the image
+// width: floor(v * mfix / 2^64), sigma^J in (2^nbits, 2^63), J <= 3L, J <= kKeyTMaxImageSyms.
+constexpr u32 kKeyTMaxImageSyms = 48;
+struct KeyT {
+  SymU8 S; u32 B, BL /* B^L */, L, sigma, J;
+  __device__ __forceinline__ void stage(uint16_t *lds) const { S.stage(lds); }
+  __device__ __forceinline__ Rec16 make(u32 p, const uint16_t *lds) const {
+    u32 limb[3];
+    u32 k = 0, w = 0;
+#pragma unroll 1
+    for (int j = 0; j < 3; j++) {
+      u32 v = 0;
+#pragma unroll 1
+      for (u32 i = 0; i < L; i++, k++) {
+        if ((k & 3u) == 0) __builtin_memcpy(&w, S.t + p + k, 4);
+        const u32 q = (p + k < S.m) ? (u32)lds[(w >> (8 * (k & 3u))) & 255u] : 0u;
+        v = v * B + q;
+      }
+      limb[j] = v;
+    }
+    return make_rec(limb[0], limb[1], limb[2], BL, p);
+  }
+  // order of the keys of positions p and q (< 0, 0, > 0) without building them: the windows are compared a word at
+  // a time and only a differing (or end-crossing) word is decoded (equal bytes have equal codes)
+  __device__ __forceinline__ int cmp(u32 p, u32 q, const uint16_t *lds) const {
+    const u32 nsym = 3 * L;
+#pragma unroll 1
+    for (u32 k = 0; k < nsym; k += 4) {
+      u32 wp, wq;
+      __builtin_memcpy(&wp, S.t + p + k, 4);
+      __builtin_memcpy(&wq, S.t + q + k, 4);
+      if (wp == wq && k + 4 <= nsym && p + k + 4 <= S.m && q + k + 4 <= S.m) continue;
+#pragma unroll
+      for (u32 b = 0; b < 4; b++) {
+        if (k + b < nsym) {
+          const u32 cp = (p + k + b < S.m) ? (u32)lds[(wp >> (8 * b)) & 255u] : 0u;
+          const u32 cq = (q + k + b < S.m) ? (u32)lds[(wq >> (8 * b)) & 255u] : 0u;
+          if (cp != cq) return cp < cq ? -1 : 1;
+        }
+      }
+    }
+    return 0;
+  }
+  __device__ __forceinline__ Rec8 image(u32 p, const uint16_t *lds, const HiMap &hm) const {
+    const u32 nw = (J + 3) / 4;
+    u32 w[kKeyTMaxImageSyms / 4];
+#pragma unroll
+    for (u32 i = 0; i < kKeyTMaxImageSyms / 4; i++)
+      if (i < nw) __builtin_memcpy(&w[i], S.t + p + 4 * i, 4); else w[i] = 0;
+    u64 v = 0;
+#pragma unroll
+    for (u32 k = 0; k < kKeyTMaxImageSyms; k++) {
+      if (k < J) {
+        u32 q = (p + k < S.m) ? (u32)lds[(w[k >> 2] >> (8 * (k & 3u))) & 255u] : 0u;
+        q = q ? q - 1 : 0u;
+        v = v * sigma + q;
+      }
+    }
+    const u64 word = (__umul64hi(v, hm.mfix) << hm.pbits) | p;
+    return Rec8{(u32)(word >> 32), (u32)word};
+  }
+};
+// whole text with KeyT, 4 consecutive positions per thread: J + 3 digits, the first image from scratch and the next
+// three by rolling (v' = (v - d_first * sigma^(J-1)) * sigma + d_next); same output, chunking and digit table as
+// k_pack_image_text.  P1 = sigma^(J-1).
+template <int NB>
+__global__ __launch_bounds__(kBlock) void k_pack_image_textT(KeyT km, u32 n, HiMap hm, u64 P1, Rec8 *__restrict__ out,
+                                                            u32 chunk, u32 nchunks, u32 *__restrict__ table) {
+  __shared__ uint16_t lcode[256];
+  __shared__ u32 hist[kWaves][NB];
+  km.stage(lcode);
+#pragma unroll
+  for (int w = 0; w < kWaves; w++)
+    for (int j = threadIdx.x; j < NB; j += kBlock) hist[w][j] = 0;
+  __syncthreads();
+  u32 *myh = hist[wave_id()];
+  const u32 J = km.J, sigma = km.sigma, nw = (J + 3 + 3) / 4;
+  constexpr u32 kW = (kKeyTMaxImageSyms + 3 + 3) / 4;
+  const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);       // chunk is a multiple of 4
+  for (u32 p0 = begin + 4 * threadIdx.x; p0 < end; p0 += 4 * kBlock) {
+    const u32 *tw = reinterpret_cast<const u32 *>(km.S.t + p0);
+    u32 w[kW];
+#pragma unroll
+    for (u32 i = 0; i < kW; i++) w[i] = i < nw ? tw[i] : 0u;
+    u64 v = 0;
+    u32 dh[3] = {0, 0, 0}, dt0 = 0, dt1 = 0, dt2 = 0;
+#pragma unroll
+    for (u32 k = 0; k < kKeyTMaxImageSyms + 3; k++) {
+      if (k < J + 3) {
+        u32 q = (p0 + k < n) ? (u32)lcode[(w[k >> 2] >> (8 * (k & 3u))) & 255u] : 0u;
+        q = q ? q - 1 : 0u;
+        if (k < 3) dh[k] = q;
+        if (k < J) v = v * sigma + q;
+        else if (k == J) dt0 = q;
+        else if (k == J + 1) dt1 = q;
+        else dt2 = q;
+      }
+    }
+    Rec8 r[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const u64 word = (__umul64hi(v, hm.mfix) << hm.pbits) | (p0 + j);
+      r[j] = Rec8{(u32)(word >> 32), (u32)word};
+      if (p0 + j < end) atomicAdd(&myh[(u32)(word >> hm.pbits) & (NB - 1)], 1u);
+      if (j < 3) v = (v - (u64)dh[j] * P1) * sigma + (j == 0 ? dt0 : j == 1 ? dt1 : dt2);
+    }
+    if (p0 + 3 < end) {
+      u32x4 *o = reinterpret_cast<u32x4 *>(out + p0);
+      o[0] = u32x4{r[0].key, r[0].val, r[1].key, r[1].val};
+      o[1] = u32x4{r[2].key, r[2].val, r[3].key, r[3].val};
+    } else {
+      for (int j = 0; j < 4; j++) if (p0 + j < end) out[p0 + j] = r[j];
+    }
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < NB; j += kBlock) {
+    u32 sum = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; w++) sum += hist[w][j];
+    table[(size_t)j * nchunks + blockIdx.x] = sum;
+  }
+}
 // whole text, 4 consecutive positions per thread: 12 aligned text bytes -> 12 codes -> 10 byte-triples shared by
 // the 4 keys; 32 contiguous output bytes per thread.  Blocks own the chunks of the radix sort that follows and
 // also produce its first digit table (the up-sweep of pass 1 never reads the records back): table[d*nchunks + b].
@@ -395,7 +525,7 @@ __global__ __launch_bounds__(kBlock) void k_pack_image_pos(KM km, u32 nout, u32 
   __shared__ uint16_t lcode[256];
   km.stage(lcode);
   for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < nout; i += gridDim.x * kBlock)
-    out[i] = hyb_rec(km.make(i * stride, lcode), hm);
+    out[i] = km.image(i * stride, lcode, hm);
 }
 // Chunked variants that also produce the digit table of the first radix pass (table[d*nchunks + block]), so the
 // sort that follows starts with its down-sweep: all positions of a level, and the samples of a level.
@@ -412,7 +542,7 @@ __global__ __launch_bounds__(kBlock) void k_pack_image_all_hist(KM km, u32 nrec,
   u32 *myh = hist[wave_id()];
   const u32 begin = blockIdx.x * chunk, end = min(nrec, begin + chunk);
   for (u32 i = begin + threadIdx.x; i < end; i += kBlock) {
-    const Rec8 r = hyb_rec(km.make(i, lcode), hm);
+    const Rec8 r = km.image(i, lcode, hm);
     out[i] = r;
     atomicAdd(&myh[(u32)(rec8_word(r) >> hm.pbits) & (NB - 1)], 1u);
   }
@@ -667,6 +797,26 @@ __device__ __forceinline__ bool key_less(const Rec16 &a, const Rec16 &b) {
   if (a.k1 != b.k1) return a.k1 < b.k1;
   return a.k0 < b.k0;
 }
+// A member of a small tied group under key maker KM: the full key in registers, or — KeyT, whose key is long and whose
+// ties are settled by its first few symbols past the image — just the position, compared lazily.
+template <class KM>
+struct TieKey {
+  Rec16 r;
+  __device__ __forceinline__ void load(const KM &km, u32 p, const uint16_t *lds) { r = km.make(p, lds); }
+  __device__ __forceinline__ u32 pos() const { return r.pos; }
+  static __device__ __forceinline__ int cmp3(const KM &, const uint16_t *, const TieKey &a, const TieKey &b) {
+    return key_less(a.r, b.r) ? -1 : key_neq(a.r, b.r) ? 1 : 0;
+  }
+};
+template <>
+struct TieKey<KeyT> {
+  u32 p;
+  __device__ __forceinline__ void load(const KeyT &, u32 pp, const uint16_t *) { p = pp; }
+  __device__ __forceinline__ u32 pos() const { return p; }
+  static __device__ __forceinline__ int cmp3(const KeyT &km, const uint16_t *lds, const TieKey &a, const TieKey &b) {
+    return km.cmp(a.p, b.p, lds);
+  }
+};
 // The common case in one pass over the sorted records: the thread that sees the start of a tied group of at
 // most kTieSmallMax members rebuilds the members' full keys (one gather each), orders them (stable insertion
 // sort; the LSD passes left them in position order) and rewrites their positions in place, keeping the key
@@ -722,35 +872,38 @@ __global__ __launch_bounds__(kBlock) void k_tie_resolve(KM km, Rec8 *__restrict_
       const u32 lo_img = h0.val & ~posmask;
       Rec8 o; o.key = h0.key;
       if (len == 2) {
-        Rec16 x = km.make(h0.val & posmask, lcode), y = km.make(h[i + 1].val & posmask, lcode);
-        if (key_less(y, x)) { const Rec16 t = x; x = y; y = t; }
-        o.val = lo_img | x.pos; h[i] = o;
-        o.val = lo_img | y.pos; h[i + 1] = o;
-        const bool ne = key_neq(x, y);
+        TieKey<KM> x, y;
+        x.load(km, h0.val & posmask, lcode); y.load(km, h[i + 1].val & posmask, lcode);
+        const int c3 = TieKey<KM>::cmp3(km, lcode, y, x);
+        if (c3 < 0) { const TieKey<KM> t = x; x = y; y = t; }
+        o.val = lo_img | x.pos(); h[i] = o;
+        o.val = lo_img | y.pos(); h[i + 1] = o;
+        const bool ne = c3 != 0;
         f[i + 1] = ne ? 1 : 0;
         dup += ne ? 0u : 1u;
         if (emit_sa) {
-          if (i >= skip) emit_sa[i - skip] = x.pos;
-          emit_sa[i + 1 - skip] = y.pos;
+          if (i >= skip) emit_sa[i - skip] = x.pos();
+          emit_sa[i + 1 - skip] = y.pos();
         }
         continue;
       }
-      Rec16 loc[kTieSmallMax];
+      TieKey<KM> loc[kTieSmallMax];
       for (u32 x = 0; x < len; x++) {
-        const Rec16 v = km.make(h[i + x].val & posmask, lcode);
+        TieKey<KM> v;
+        v.load(km, h[i + x].val & posmask, lcode);
         u32 y = x;
-        while (y > 0 && key_less(v, loc[y - 1])) { loc[y] = loc[y - 1]; y--; }
+        while (y > 0 && TieKey<KM>::cmp3(km, lcode, v, loc[y - 1]) < 0) { loc[y] = loc[y - 1]; y--; }
         loc[y] = v;
       }
       for (u32 x = 0; x < len; x++) {
-        o.val = lo_img | loc[x].pos;
+        o.val = lo_img | loc[x].pos();
         h[i + x] = o;
         if (x > 0) {
-          const bool ne = key_neq(loc[x], loc[x - 1]);
+          const bool ne = TieKey<KM>::cmp3(km, lcode, loc[x], loc[x - 1]) != 0;
           f[i + x] = ne ? 1 : 0;
           dup += ne ? 0u : 1u;
         }
-        if (emit_sa && i + x >= skip) emit_sa[i + x - skip] = loc[x].pos;
+        if (emit_sa && i + x >= skip) emit_sa[i + x - skip] = loc[x].pos();
       }
     }
     if (dup) atomicAdd(&ndup, dup);
@@ -804,21 +957,24 @@ __global__ __launch_bounds__(kBlock) void k_tie_resolve_split(KM km, const u32 *
       const u32 len = e - i;
       if (len > kTieSmallMax) { words[0] = 1u; continue; }
       if (len == 2) {
-        Rec16 x = km.make(sa[i], lcode), y = km.make(sa[i + 1], lcode);
-        if (key_less(y, x)) { sa[i] = y.pos; sa[i + 1] = x.pos; }
-        dup += key_neq(x, y) ? 0u : 1u;
+        TieKey<KM> x, y;
+        x.load(km, sa[i], lcode); y.load(km, sa[i + 1], lcode);
+        const int c3 = TieKey<KM>::cmp3(km, lcode, y, x);
+        if (c3 < 0) { sa[i] = y.pos(); sa[i + 1] = x.pos(); }
+        dup += c3 != 0 ? 0u : 1u;
         continue;
       }
-      Rec16 loc[kTieSmallMax];
+      TieKey<KM> loc[kTieSmallMax];
       for (u32 x = 0; x < len; x++) {
-        const Rec16 v = km.make(sa[i + x], lcode);
+        TieKey<KM> v;
+        v.load(km, sa[i + x], lcode);
         u32 y = x;
-        while (y > 0 && key_less(v, loc[y - 1])) { loc[y] = loc[y - 1]; y--; }
+        while (y > 0 && TieKey<KM>::cmp3(km, lcode, v, loc[y - 1]) < 0) { loc[y] = loc[y - 1]; y--; }
         loc[y] = v;
       }
       for (u32 x = 0; x < len; x++) {
-        sa[i + x] = loc[x].pos;
-        if (x > 0) dup += key_neq(loc[x], loc[x - 1]) ? 0u : 1u;
+        sa[i + x] = loc[x].pos();
+        if (x > 0) dup += TieKey<KM>::cmp3(km, lcode, loc[x], loc[x - 1]) != 0 ? 0u : 1u;
       }
     }
     if (dup) atomicAdd(&ndup, dup);

@@ -83,6 +83,7 @@ struct dc3hip_ctx {
   bool wide_names = false;
   bool no_nine_bit = false, no_rec12 = false, no_discard = false, no_fullsort = false, no_text_shortcut = false;
   bool no_split_emit = false;
+  bool no_long_keys = false;   // DC3HIP_NO_LONG_KEYS=1: the whole-text shortcut only with 9-symbol windows (no KeyT)
   double hybrid12_max_pred = kHybrid12MaxPredicted;   // DC3HIP_HYBRID12_MAX_PRED (tuning)
   u32 hybrid12_min = 1u << 22; // DC3HIP_HYBRID12_MIN: smallest level (samples) that tries it (tests lower it)
   bool no_hybrid8 = false;     // DC3HIP_NO_HYBRID8=1 (tests): skip the 8-byte prefix sort / whole-level order of a level
@@ -963,6 +964,24 @@ int launch_pack_all<Key9>(dc3hip_ctx *c, Key9 km, u32 nrec, const HiMap &hm, Rec
   *first_table = table;
   return E_OK;
 }
+template <>
+int launch_pack_all<KeyT>(dc3hip_ctx *c, KeyT km, u32 nrec, const HiMap &hm, Rec8 *out, u32 **first_table) {
+  int nb = 0; Chunking ck;
+  radix_plan<Rec8>(c, nrec, hm.nbits, &nb, &ck);
+  u32 *table = nullptr;
+  RC(arena_alloc(c, (size_t)nb * ck.nchunks, &table));
+  u64 P1 = 1;
+  for (u32 i = 0; i + 1 < km.J; i++) P1 *= km.sigma;
+  if (nb == 512)
+    hipLaunchKernelGGL((k_pack_image_textT<512>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, km, nrec, hm, P1, out,
+                       ck.chunk, ck.nchunks, table);
+  else
+    hipLaunchKernelGGL((k_pack_image_textT<256>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, km, nrec, hm, P1, out,
+                       ck.chunk, ck.nchunks, table);
+  KCHECK();
+  *first_table = table;
+  return E_OK;
+}
 template <class KM, class Map>
 static int order_all_positions(dc3hip_ctx *c, KM km, Map mp, u32 m, u32 kbits, const HiMap &hm, u32 dummy, u32 *out_sa,
                                u32 *out_rank, u32 *spos, u32 *snf, int *state, int depth) {
@@ -1157,7 +1176,8 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
   RC(arena_alloc(c, (size_t)m02 + 16, &R));
 
   const u64 B = K + 1;
-  const bool direct = (B * B * B) <= 0x7fffffffull;
+  // (level 1 takes its sample order from the whole-text order when there is one, whatever its alphabet)
+  const bool direct = (B * B * B) <= 0x7fffffffull && !(pre && depth == 1);
   c->stats.level_sorted[depth] = direct ? 0 : 1;   // 2 = prefix-sort + tie-refine
   if (direct) {
     // names = w packed symbols (order-preserving); w = 3 (the K–S triple) unless DC3HIP_WIDE_NAMES=1;
@@ -1369,6 +1389,56 @@ static int build_alphabet(dc3hip_ctx *c, u32 *sigma_out) {
   return E_OK;
 }
 
+// KeyT and the map of its image (see the struct): J = fewest symbols whose base-sigma value exceeds the image width by
+// two bits, within 63 bits, the key's 3L symbols and kKeyTMaxImageSyms.  false = no such J (the caller skips the path).
+static bool make_keyt(SymU8 S, u32 sigma, u32 L, u64 BL, u32 n, KeyT *km, HiMap *hm) {
+  if (sigma < 2) return false;
+  hm->pbits = bits_of((u64)n - 1);                                       // positions 0..n-1 only
+  hm->nbits = 64 - hm->pbits;
+  hm->shx = 0; hm->exact = 0;
+  u32 J = 1; u64 SJ = sigma;                                             // sigma^J
+  const u32 jmax = std::min<u32>(3 * L, kKeyTMaxImageSyms);
+  while (J < jmax && (SJ >> (hm->nbits + 2)) == 0 && SJ * sigma < (1ull << 63)) { SJ *= sigma; J++; }
+  if ((SJ >> hm->nbits) == 0) return false;                              // the image must be a proper scaling
+  hm->mfix = (u64)(((((unsigned __int128)1) << (64 + hm->nbits)) - 1) / SJ);
+  km->S = S; km->B = sigma + 1; km->BL = (u32)BL; km->L = L; km->sigma = sigma; km->J = J;
+  return true;
+}
+
+// Whole-text shortcut with key maker KM (three limbs of base BL: Key9's 9 symbols or KeyT's 3L): predicted ties
+// permitting, order all n positions by their windows.  All windows distinct: that order is the suffix array
+// (*whole_text).  Otherwise the order, filtered down to level 1's samples with the dense ranks of the windows as
+// their names, still serves level 1 (*pre): a name built from a window LONGER than the K-S triple orders the samples
+// consistently and equal names still imply equal triples, which is all lib.rs:78-104 needs of a name.
+template <class KM>
+static int try_text_order(dc3hip_ctx *c, KM km, u64 BL, const HiMap &hm, u32 sigma, bool *whole_text, Presort *pre) {
+  const int64_t n = c->n;
+  u32 kbits = 0;                          // of the full key (limb base BL)
+  { unsigned __int128 mx = (unsigned __int128)BL * BL * BL - 1; while (mx) { kbits++; mx >>= 1; } }
+  double pred = 1.0;
+  RC(predict_tie_fraction_pos<KM>(c, km, (u32)n, hm, &pred));
+  c->stats.level_tie_pred[0] = pred;
+  if (!(pred < kTextSortMaxPredicted)) return E_OK;
+  const u32 m0 = (u32)((n + 2) / 3), m1 = m0 + (u32)(n / 3);            // level 1 = string of m1 names
+  const u32 m02_1 = (m1 + 2) / 3 + m1 / 3;                              // its samples (incl. the dummy)
+  // The filtered order (2 * m02_1 words < n) lives in the output buffer: the optimistic SA written there
+  // by the tie pass is void when keys repeat, and nothing else writes d_sa before the final merge.
+  u32 *spos = c->d_sa, *snf = c->d_sa + m02_1 + 16;
+  MapText mp; mp.m0 = m0; mp.npre = 0; mp.ppos[0] = mp.ppos[1] = 0;
+  if (m1 % 3 == 1) mp.ppos[mp.npre++] = m1;                              // level 1's dummy sample
+  if (n % 3 == 1 && (m0 - 1) % 3 != 0) mp.ppos[mp.npre++] = m0 - 1;      // level 0's dummy, a level-1 position
+  int state = 0;
+  RC((order_all_positions<KM, MapText>(c, km, mp, (u32)n, kbits, hm, 0u, c->d_sa, nullptr, spos, snf, &state, 0)));
+  c->stats.text_sort_state = state == 1 ? 1 : state == 2 ? 2 : 3;
+  if (state == 1) {
+    *whole_text = true;
+    c->stats.level_n[0] = n; c->stats.level_K[0] = sigma; c->stats.levels = 1; c->stats.level_sorted[0] = 5;
+  } else if (state == 2) {
+    pre->spos = spos; pre->snf = snf;      // duplicates: the order still serves level 1
+  }
+  return E_OK;
+}
+
 // the device-resident build proper: SA of c->d_text[0..n) into c->d_sa
 static int build_core(dc3hip_ctx *c) {
   const int64_t n = c->n;
@@ -1381,39 +1451,24 @@ static int build_core(dc3hip_ctx *c) {
     bool whole_text = false;
     Presort pre{nullptr, nullptr};
     const u64 Bq = (u64)sigma + 1, B3 = Bq * Bq * Bq;
-    // (level 1 must be a sorted level for its samples to be taken from the whole-text order: B3^3 >= 2^31)
-    // (even uniformly random symbols repeat a 9-symbol window once sigma^9 is not well above n^2/2: skip then)
-    const bool windows_can_be_distinct = 9.0 * log2((double)sigma) >= 2.0 * log2((double)n) + 2.0;
-    if ((u64)n >= kHybridMinSamples && !c->no_hybrid && !c->no_fullsort && !c->no_text_shortcut && windows_can_be_distinct &&
-        B3 * B3 * B3 > 0x7fffffffull && c->arena_bytes - c->arena_off >= (size_t)n * 22 + (64u << 20)) {
-      // whole-text shortcut: if all 9-byte windows of a high-entropy text are distinct, sorting all positions by
+    // (even uniformly random symbols repeat a w-symbol window once sigma^w is not well above n^2/2: skip then)
+    const double need_bits = 2.0 * log2((double)n) + 2.0, sym_bits = log2((double)sigma);
+    if ((u64)n >= kHybridMinSamples && !c->no_hybrid && !c->no_fullsort && !c->no_text_shortcut &&
+        c->arena_bytes - c->arena_off >= (size_t)n * 22 + (64u << 20)) {
+      // whole-text shortcut: if all w-symbol windows of a high-entropy text are distinct, sorting all positions by
       // them is the suffix array (the same test level 1 would make on its triples, without building level 1)
-      u32 kbits = 0;
-      { unsigned __int128 mx = (unsigned __int128)B3 * B3 * B3 - 1; while (mx) { kbits++; mx >>= 1; } }
-      Key9 km; km.S = S; km.B = (u32)Bq; km.B3 = (u32)B3;
-      const HiMap hm = make_himap(B3, kbits, (u32)n, bits_of((u64)n - 1));   // positions 0..n-1 only
-      double pred = 1.0;
-      RC(predict_tie_fraction_pos<Key9>(c, km, (u32)n, hm, &pred));
-      c->stats.level_tie_pred[0] = pred;
-      if (pred < kTextSortMaxPredicted) {
-        const u32 m0 = (u32)((n + 2) / 3), m1 = m0 + (u32)(n / 3);            // level 1 = string of m1 names
-        const u32 m02_1 = (m1 + 2) / 3 + m1 / 3;                              // its samples (incl. the dummy)
-        // The filtered order (2 * m02_1 words < n) lives in the output buffer: the optimistic SA written there
-        // by the tie pass is void when keys repeat, and nothing else writes d_sa before the final merge.
-        u32 *spos = c->d_sa, *snf = c->d_sa + m02_1 + 16;
-        MapText mp; mp.m0 = m0; mp.npre = 0; mp.ppos[0] = mp.ppos[1] = 0;
-        if (m1 % 3 == 1) mp.ppos[mp.npre++] = m1;                              // level 1's dummy sample
-        if (n % 3 == 1 && (m0 - 1) % 3 != 0) mp.ppos[mp.npre++] = m0 - 1;      // level 0's dummy, a level-1 position
-        int state = 0;
-        RC((order_all_positions<Key9, MapText>(c, km, mp, (u32)n, kbits, hm, 0u, c->d_sa, nullptr, spos, snf, &state,
-                                               0)));
-        c->stats.text_sort_state = state == 1 ? 1 : state == 2 ? 2 : 3;
-        if (state == 1) {
-          whole_text = true;
-          c->stats.level_n[0] = n; c->stats.level_K[0] = sigma; c->stats.levels = 1; c->stats.level_sorted[0] = 5;
-        } else if (state == 2) {
-          pre.spos = spos; pre.snf = snf;      // duplicates: the order still serves level 1
-        }
+      if (9.0 * sym_bits >= need_bits && B3 * B3 * B3 > 0x7fffffffull) {
+        Key9 km; km.S = S; km.B = (u32)Bq; km.B3 = (u32)B3;
+        u32 kbits = 0;
+        { unsigned __int128 mx = (unsigned __int128)B3 * B3 * B3 - 1; while (mx) { kbits++; mx >>= 1; } }
+        RC(try_text_order<Key9>(c, km, B3, make_himap(B3, kbits, (u32)n, bits_of((u64)n - 1)), sigma, &whole_text, &pre));
+      } else if (!c->no_long_keys) {
+        // small alphabets: limbs of L > 3 symbols (as many as fit 32 bits), 3L-symbol windows
+        u32 L = 1; u64 BL = Bq;
+        while (L < 20 && BL * Bq <= 0xffffffffull) { BL *= Bq; L++; }
+        KeyT km; HiMap hm;
+        if (L > 3 && 3.0 * L * sym_bits >= need_bits && make_keyt(S, sigma, L, BL, (u32)n, &km, &hm))
+          RC(try_text_order<KeyT>(c, km, BL, hm, sigma, &whole_text, &pre));
       }
     }
     if (!whole_text) {
@@ -1480,6 +1535,7 @@ int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) {
   c->no_small_ties = (nst && nst[0] == '1');
   { const char *e = getenv("DC3HIP_NO_SPLIT_EMIT"); c->no_split_emit = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_TRACE"); c->trace = (e && e[0] == '1'); }
+  { const char *e = getenv("DC3HIP_NO_LONG_KEYS"); c->no_long_keys = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_TUP8"); c->no_tup8 = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_HYBRID12"); c->no_hybrid12 = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_HYBRID8"); c->no_hybrid8 = (e && e[0] == '1'); }
