@@ -946,29 +946,46 @@ static int glevel(dc3hip_gctx *G, Sym S, u32 m, u64 K, int depth, u32 *out, GOut
   return E_OK;
 }
 
-// level 0 shortcut: the whole-text order by 9-byte keys, split by key range (conditions as in build_core)
+// level 0 shortcut: the whole-text order by 9-symbol (Key9) or, on small alphabets, 3L-symbol windows (KeyT), split by
+// key range (conditions as in build_core; no reuse of the order when windows repeat: the recursion decides then)
+template <class KM>
+static int gtext_order_with(dc3hip_gctx *G, KM km, u64 BL, const HiMap &hm, u32 sigma, bool *done) {
+  dc3hip_ctx *c = G->c;
+  const u32 n = (u32)G->total_n;
+  u32 kbits = 0;
+  { unsigned __int128 mx = (unsigned __int128)BL * BL * BL - 1; while (mx) { kbits++; mx >>= 1; } }
+  double pred = 1.0;
+  RC(predict_tie_fraction_pos<KM>(c, km, n, hm, &pred));
+  c->stats.level_tie_pred[0] = pred;
+  if (!(pred < kTextSortMaxPredicted)) return E_OK;
+  RC((gorder_positions<KM>(G, km, n, kbits, hm, 0, nullptr, G_TOP, done)));
+  if (*done) {
+    c->stats.text_sort_state = 1;
+    c->stats.level_n[0] = n; c->stats.level_K[0] = sigma; c->stats.levels = 1; c->stats.level_sorted[0] = 5;
+  } else {
+    c->stats.text_sort_state = 3;       // some window repeats somewhere: the recursion decides
+  }
+  return E_OK;
+}
 static int gtext_order(dc3hip_gctx *G, SymU8 S, u32 sigma, bool *done) {
   dc3hip_ctx *c = G->c;
   const u32 n = (u32)G->total_n;
   *done = false;
   const u64 Bq = (u64)sigma + 1, B3 = Bq * Bq * Bq;
-  const bool windows_can_be_distinct = 9.0 * log2((double)sigma) >= 2.0 * log2((double)n) + 2.0;
-  if (!(n >= kHybridMinSamples / 4 && !c->no_hybrid && !c->no_fullsort && !c->no_text_shortcut && !G->no_text_order &&
-        windows_can_be_distinct && B3 * B3 * B3 > 0x7fffffffull)) return E_OK;
-  u32 kbits = 0;
-  { unsigned __int128 mx = (unsigned __int128)B3 * B3 * B3 - 1; while (mx) { kbits++; mx >>= 1; } }
-  Key9 km; km.S = S; km.B = (u32)Bq; km.B3 = (u32)B3;
-  const HiMap hm = make_himap(B3, kbits, n, bits_of((u64)n - 1));
-  double pred = 1.0;
-  RC(predict_tie_fraction_pos<Key9>(c, km, n, hm, &pred));
-  c->stats.level_tie_pred[0] = pred;
-  if (!(pred < kTextSortMaxPredicted)) return E_OK;
-  RC((gorder_positions<Key9>(G, km, n, kbits, hm, 0, nullptr, G_TOP, done)));
-  if (*done) {
-    c->stats.text_sort_state = 1;
-    c->stats.level_n[0] = n; c->stats.level_K[0] = sigma; c->stats.levels = 1; c->stats.level_sorted[0] = 5;
-  } else {
-    c->stats.text_sort_state = 3;       // some 9-byte window repeats somewhere: the recursion decides
+  const double need_bits = 2.0 * log2((double)n) + 2.0, sym_bits = log2((double)sigma);
+  if (!(n >= kHybridMinSamples / 4 && !c->no_hybrid && !c->no_fullsort && !c->no_text_shortcut && !G->no_text_order)) return E_OK;
+  if (9.0 * sym_bits >= need_bits && B3 * B3 * B3 > 0x7fffffffull) {
+    u32 kbits = 0;
+    { unsigned __int128 mx = (unsigned __int128)B3 * B3 * B3 - 1; while (mx) { kbits++; mx >>= 1; } }
+    Key9 km; km.S = S; km.B = (u32)Bq; km.B3 = (u32)B3;
+    return gtext_order_with<Key9>(G, km, B3, make_himap(B3, kbits, n, bits_of((u64)n - 1)), sigma, done);
+  }
+  if (!c->no_long_keys) {
+    u32 L = 1; u64 BL = Bq;
+    while (L < 20 && BL * Bq <= 0xffffffffull) { BL *= Bq; L++; }
+    KeyT km; HiMap hm;
+    if (L > 3 && 3.0 * L * sym_bits >= need_bits && make_keyt(S, sigma, L, BL, n, &km, &hm))
+      return gtext_order_with<KeyT>(G, km, BL, hm, sigma, done);
   }
   return E_OK;
 }

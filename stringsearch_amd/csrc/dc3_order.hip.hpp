@@ -318,6 +318,26 @@ __device__ __forceinline__ Rec8 hyb_rec(const Rec16 &r, HiMap hm) {
   const u64 w = (hi << hm.pbits) | r.pos;
   return Rec8{(u32)(w >> 32), (u32)w};
 }
+// Order (< 0, 0, > 0) of the nsym-symbol windows of text positions p and q without building their keys: compared a
+// word at a time, only a differing (or end-crossing) word is decoded (equal bytes have equal codes; past the end = 0).
+__device__ __forceinline__ int window_cmp(const SymU8 &S, u32 p, u32 q, u32 nsym, const uint16_t *lds) {
+#pragma unroll 1
+  for (u32 k = 0; k < nsym; k += 4) {
+    u32 wp, wq;
+    __builtin_memcpy(&wp, S.t + p + k, 4);
+    __builtin_memcpy(&wq, S.t + q + k, 4);
+    if (wp == wq && k + 4 <= nsym && p + k + 4 <= S.m && q + k + 4 <= S.m) continue;
+#pragma unroll
+    for (u32 b = 0; b < 4; b++) {
+      if (k + b < nsym) {
+        const u32 cp = (p + k + b < S.m) ? (u32)lds[(wp >> (8 * b)) & 255u] : 0u;
+        const u32 cq = (q + k + b < S.m) ? (u32)lds[(wq >> (8 * b)) & 255u] : 0u;
+        if (cp != cq) return cp < cq ? -1 : 1;
+      }
+    }
+  }
+  return 0;
+}
 // Key makers: the full sort key of position p.  Key3 = the K–S triple of a level's string; Key9 = 9 bytes of the
 // text (three packed byte-triples: exactly the triple key the level-1 string has at the slot of p), used by the
 // level-0 whole-text shortcut.
@@ -373,27 +393,7 @@ struct KeyT {
     }
     return make_rec(limb[0], limb[1], limb[2], BL, p);
   }
-  // order of the keys of positions p and q (< 0, 0, > 0) without building them: the windows are compared a word at
-  // a time and only a differing (or end-crossing) word is decoded (equal bytes have equal codes)
-  __device__ __forceinline__ int cmp(u32 p, u32 q, const uint16_t *lds) const {
-    const u32 nsym = 3 * L;
-#pragma unroll 1
-    for (u32 k = 0; k < nsym; k += 4) {
-      u32 wp, wq;
-      __builtin_memcpy(&wp, S.t + p + k, 4);
-      __builtin_memcpy(&wq, S.t + q + k, 4);
-      if (wp == wq && k + 4 <= nsym && p + k + 4 <= S.m && q + k + 4 <= S.m) continue;
-#pragma unroll
-      for (u32 b = 0; b < 4; b++) {
-        if (k + b < nsym) {
-          const u32 cp = (p + k + b < S.m) ? (u32)lds[(wp >> (8 * b)) & 255u] : 0u;
-          const u32 cq = (q + k + b < S.m) ? (u32)lds[(wq >> (8 * b)) & 255u] : 0u;
-          if (cp != cq) return cp < cq ? -1 : 1;
-        }
-      }
-    }
-    return 0;
-  }
+  __device__ __forceinline__ int cmp(u32 p, u32 q, const uint16_t *lds) const { return window_cmp(S, p, q, 3 * L, lds); }
   __device__ __forceinline__ Rec8 image(u32 p, const uint16_t *lds, const HiMap &hm) const {
     const u32 nw = (J + 3) / 4;
     u32 w[kKeyTMaxImageSyms / 4];
@@ -817,6 +817,15 @@ struct TieKey<KeyT> {
     return km.cmp(a.p, b.p, lds);
   }
 };
+template <>
+struct TieKey<Key9> {
+  u32 p;
+  __device__ __forceinline__ void load(const Key9 &, u32 pp, const uint16_t *) { p = pp; }
+  __device__ __forceinline__ u32 pos() const { return p; }
+  static __device__ __forceinline__ int cmp3(const Key9 &km, const uint16_t *lds, const TieKey &a, const TieKey &b) {
+    return window_cmp(km.S, a.p, b.p, 9, lds);
+  }
+};
 // The common case in one pass over the sorted records: the thread that sees the start of a tied group of at
 // most kTieSmallMax members rebuilds the members' full keys (one gather each), orders them (stable insertion
 // sort; the LSD passes left them in position order) and rewrites their positions in place, keeping the key
@@ -922,16 +931,18 @@ __global__ __launch_bounds__(kBlock) void k_tie_resolve(KM km, Rec8 *__restrict_
 template <class KM>
 __global__ __launch_bounds__(kBlock) void k_tie_resolve_split(KM km, const u32 *__restrict__ img, u32 *__restrict__ sa,
                                                              u32 n, u32 *words) {
-  constexpr u32 kIPT = 4, kTile = kBlock * kIPT;
+  // Group starts are sparse (3 % of the records on random input): a block keeps collecting them tile after tile and
+  // works the list only in full batches of kBlock groups (one per lane), so that every wave has 64 dependent gathers
+  // in flight instead of a handful.
+  constexpr u32 kIPT = 4, kTile = kBlock * kIPT, kCap = kTile / 2 + kBlock;
   __shared__ uint16_t lcode[256];
-  __shared__ u32 starts[kTile / 2];
+  __shared__ u32 starts[kCap];
   __shared__ u32 nstart, ntied, ndup;
   km.stage(lcode);
   const u32 ntiles = (n + kTile - 1) / kTile;
-  if (threadIdx.x == 0) { ntied = 0; ndup = 0; }
+  if (threadIdx.x == 0) { ntied = 0; ndup = 0; nstart = 0; }
+  __syncthreads();
   for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    if (threadIdx.x == 0) nstart = 0;
-    __syncthreads();
     u32 tied = 0;
 #pragma unroll
     for (u32 j = 0; j < kIPT; j++) {
@@ -947,39 +958,49 @@ __global__ __launch_bounds__(kBlock) void k_tie_resolve_split(KM km, const u32 *
     tied = wave_reduce(tied);
     if (lane_id() == 0 && tied) atomicAdd(&ntied, tied);
     __syncthreads();
-    const u32 ns = nstart;
+    const bool last = tile + gridDim.x >= ntiles;
     u32 dup = 0;
-    for (u32 s = threadIdx.x; s < ns; s += kBlock) {
-      const u32 i = starts[s];
-      const u32 a = img[i];
-      u32 e = i + 2;
-      while (e < n && e - i <= kTieSmallMax && img[e] == a) e++;
-      const u32 len = e - i;
-      if (len > kTieSmallMax) { words[0] = 1u; continue; }
-      if (len == 2) {
-        TieKey<KM> x, y;
-        x.load(km, sa[i], lcode); y.load(km, sa[i + 1], lcode);
-        const int c3 = TieKey<KM>::cmp3(km, lcode, y, x);
-        if (c3 < 0) { sa[i] = y.pos(); sa[i + 1] = x.pos(); }
-        dup += c3 != 0 ? 0u : 1u;
-        continue;
+    for (;;) {
+      const u32 ns = nstart;
+      __syncthreads();                                         // everyone has read it before anyone appends again
+      if (ns == 0 || (ns < kBlock && !last)) break;
+      const u32 base = ns > kBlock ? ns - kBlock : 0;
+      if (base + threadIdx.x < ns) {
+        const u32 i = starts[base + threadIdx.x];
+        const u32 a = img[i];
+        u32 e = i + 2;
+        while (e < n && e - i <= kTieSmallMax && img[e] == a) e++;
+        const u32 len = e - i;
+        if (len > kTieSmallMax) {
+          words[0] = 1u;
+        } else if (len == 2) {
+          TieKey<KM> x, y;
+          x.load(km, sa[i], lcode); y.load(km, sa[i + 1], lcode);
+          const int c3 = TieKey<KM>::cmp3(km, lcode, y, x);
+          if (c3 < 0) { sa[i] = y.pos(); sa[i + 1] = x.pos(); }
+          dup += c3 != 0 ? 0u : 1u;
+        } else {
+          TieKey<KM> loc[kTieSmallMax];
+          for (u32 x = 0; x < len; x++) {
+            TieKey<KM> v;
+            v.load(km, sa[i + x], lcode);
+            u32 y = x;
+            while (y > 0 && TieKey<KM>::cmp3(km, lcode, v, loc[y - 1]) < 0) { loc[y] = loc[y - 1]; y--; }
+            loc[y] = v;
+          }
+          for (u32 x = 0; x < len; x++) {
+            sa[i + x] = loc[x].pos();
+            if (x > 0) dup += TieKey<KM>::cmp3(km, lcode, loc[x], loc[x - 1]) != 0 ? 0u : 1u;
+          }
+        }
       }
-      TieKey<KM> loc[kTieSmallMax];
-      for (u32 x = 0; x < len; x++) {
-        TieKey<KM> v;
-        v.load(km, sa[i + x], lcode);
-        u32 y = x;
-        while (y > 0 && TieKey<KM>::cmp3(km, lcode, v, loc[y - 1]) < 0) { loc[y] = loc[y - 1]; y--; }
-        loc[y] = v;
-      }
-      for (u32 x = 0; x < len; x++) {
-        sa[i + x] = loc[x].pos();
-        if (x > 0) dup += TieKey<KM>::cmp3(km, lcode, loc[x], loc[x - 1]) != 0 ? 0u : 1u;
-      }
+      __syncthreads();
+      if (threadIdx.x == 0) nstart = base;
+      __syncthreads();
     }
     if (dup) atomicAdd(&ndup, dup);
-    __syncthreads();
   }
+  __syncthreads();
   if (threadIdx.x == 0) {
     if (ntied) atomicAdd(&words[1], ntied);
     if (ndup) atomicAdd(&words[2], ndup);

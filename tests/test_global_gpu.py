@@ -80,11 +80,35 @@ def test_loopback_default_policy(ss, oracle, P):
             g.build()
             assert np.array_equal(g.sa(), want_sa(oracle, t)), (n, kind, P)
             st = g.stats()
-            if kind == 0:
-                assert all(s["text_order"] == 1 for s in st)        # every 9-byte window distinct
+            if kind in (0, 1):
+                assert all(s["text_order"] == 1 for s in st)        # every 9-byte (DNA: 39-symbol) window distinct
             with ss.Context(n) as c:
                 c.set_text(t); c.build()
                 assert g.checksum() == c.checksum()                 # checksum of shards == single-device checksum
+
+
+def test_loopback_small_alphabet_whole_text_order(ss, oracle):
+    """The distributed whole-text order with 3L-symbol windows (small alphabets): random texts over 2..5 symbols finish
+    at level 0 on every rank; a repeated block sends all ranks on to the recursion; an alphabet containing 0x00 and a
+    run of the smallest symbol at the end of the text.  Bit-exact against divsufsort."""
+    rng = np.random.default_rng(41)
+    n = (1 << 22) + 5                 # above the size the ranks would finish locally (DC3HIP_GLOBAL_LOCAL_MAX)
+    with ss.LoopbackGroup(3, n) as g:
+        for sigma in (2, 3, 4, 5):
+            for variant in ("random", "repeat", "zero_run_at_end"):
+                t = rng.integers(0, sigma, size=n, dtype=np.uint8)
+                if variant == "repeat":
+                    t[n // 2:n // 2 + 2000] = t[50:2050]
+                if variant == "zero_run_at_end":
+                    t[n - 150:] = 0; t[300:420] = 0
+                g.set_text(t)
+                g.build()
+                assert np.array_equal(g.sa(), want_sa(oracle, t)), (sigma, variant)
+                st = g.stats()
+                if variant == "random":
+                    assert all(s["text_order"] == 1 for s in st), (sigma, [s["text_order"] for s in st])
+                if variant == "repeat":
+                    assert all(s["text_order"] == 0 and s["levels"] >= 2 for s in st), sigma
 
 
 def test_loopback_generated_blocks_and_tiny_inputs(ss, oracle):
@@ -249,13 +273,15 @@ def test_loopback_rank_failure_releases_the_group(ss, oracle):
 
 
 @pytest.mark.parametrize("P,n,kind,seed,label", [(4, 1 << 30, 0, 4, "configs[3] shape: random bytes over 4 ranks (1/4 scale)"),
-                                                (8, 512 << 20, 1, 5, "configs[4] shape: DNA over 8 ranks, i64 shards (1/32 scale)")])
+                                                (8, 512 << 20, 1, 5, "configs[4] shape: DNA over 8 ranks, i64 shards (1/32 scale)"),
+                                                (8, 256 << 20, 1, 6, "configs[4] shape, distributed recursion (no whole-text order)")])
 def test_baseline_multi_gpu_config_shapes_on_loopback(ss, P, n, kind, seed, label):
     """BASELINE.json configs[3] / configs[4] as far as one GPU can host them: the same rank counts and input classes
     through the global mode with loopback ranks (the arenas of all ranks share this GPU's 288 GB, hence the reduced
     sizes).  The shards tile [0, n), their checksums add up to the single-device checksum, and the concatenated array
     passes the GPU sufcheck; shards are fetched as int64 as configs[4] asks."""
-    with ss.LoopbackGroup(P, n) as g:
+    recursion = "recursion" in label
+    with env(**({"DC3HIP_GLOBAL_NO_TEXT_ORDER": 1} if recursion else {})), ss.LoopbackGroup(P, n) as g:
         g.generate(n, seed, kind)
         g.build()
         chk = g.checksum()
@@ -276,7 +302,10 @@ def test_baseline_multi_gpu_config_shapes_on_loopback(ss, P, n, kind, seed, labe
         c.set_sa(sa)
         assert c.sufcheck() == 0, label
     assert all(s["comm_bytes_in"] >= n * (P - 1) // P - P for s in st)  # at least the other ranks' text blocks crossed the transport
-    assert (st[0]["text_order"] == 1) == (kind == 0)
+    # random bytes by 9-byte windows, random DNA by 39-symbol windows: both finish in the distributed whole-text order
+    assert (st[0]["text_order"] == 1) == (not recursion)
+    if recursion:
+        assert st[0]["levels"] >= 2 and st[0]["exchanges"] >= 1, (st[0]["levels"], st[0]["exchanges"])
 
 
 def test_loopback_spread_over_visible_devices(ss, oracle):

@@ -458,6 +458,50 @@ def test_whole_text_order_reused_by_level1(ss, oracle):
     assert len(combos) == 9
 
 
+def test_small_alphabet_long_windows(ss, oracle):
+    """Whole-text shortcut on small alphabets (KeyT: windows of 3L > 9 symbols, base-sigma image, lazy compare in
+    the tie pass): random texts over 2..16 symbols finish at level 0 (text_sort_state 1); a repeated block makes
+    windows repeat and the order is reused by level 1 whatever its alphabet (state 2); ends of text that run into
+    the sentinel (a run of the smallest symbol at the end, with the same run inside) and an alphabet that contains
+    the byte 0x00 (the padding after the text is zero bytes too).  DC3HIP_NO_LONG_KEYS=1 is the same build without
+    the long windows.  All bit-exact against divsufsort."""
+    rng = np.random.default_rng(31)
+    n = (1 << 22) + 7
+    cases = {}
+    for sigma in (2, 3, 4, 5, 16):
+        cases[f"random_sigma{sigma}"] = (rng.integers(0, sigma, size=n, dtype=np.uint8) + 65).astype(np.uint8)
+    dna = cases["random_sigma4"]
+    d = dna.copy(); d[n // 2:n // 2 + 3000] = d[100:3100]
+    cases["dna_repeat_3000"] = d
+    d = dna.copy(); d[n - 200:] = 65; d[1000:1100] = 65                       # ...AAAA$ and AAAA inside
+    cases["dna_min_symbol_run_at_end"] = d
+    d = dna.copy(); d[n - 45:] = d[5000:5045]                                 # a window that repeats up to the end
+    cases["dna_repeat_into_end"] = d
+    cases["alphabet_with_zero_byte"] = rng.integers(0, 4, size=n, dtype=np.uint8)   # bytes 0..3
+    d = cases["alphabet_with_zero_byte"].copy(); d[n - 100:] = 0; d[77:150] = 0
+    cases["zero_byte_run_at_end"] = d
+    for label, arr in cases.items():
+        data = arr.tobytes()
+        want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)
+        seen = {}
+        for env in ({}, {"DC3HIP_NO_LONG_KEYS": "1"}, {"DC3HIP_NO_SPLIT_EMIT": "1"}, {"DC3HIP_NO_SMALL_TIES": "1"}):
+            os.environ.update(env)
+            try:
+                with ss.Context(len(data)) as c:
+                    c.set_text(data); c.build()
+                    assert np.array_equal(c.sa(), want), (label, env)
+                    seen[tuple(sorted(env))] = c.stats()
+            finally:
+                for k in env:
+                    os.environ.pop(k, None)
+        assert seen[("DC3HIP_NO_LONG_KEYS",)]["text_sort_state"] == 0, label
+        if label.startswith("random") or label == "alphabet_with_zero_byte":
+            assert seen[()]["text_sort_state"] == 1 and seen[()]["levels"] == 1, (label, seen[()]["text_sort_state"])
+            assert seen[("DC3HIP_NO_LONG_KEYS",)]["levels"] >= 3, label
+        if label in ("dna_repeat_3000", "dna_repeat_into_end"):
+            assert seen[()]["text_sort_state"] == 2 and seen[()]["level_sorted"][1] in (2, 4), (label, seen[()]["level_sorted"])
+
+
 def test_wide_and_narrow_direct_names_agree(ss, oracle):
     """Direct names pack w = 3 symbols by default; DC3HIP_WIDE_NAMES=1 packs as many as fit 31 bits
     (13 for DNA, 6 for 28-letter text).  Same SA either way."""
