@@ -957,7 +957,7 @@ static int gtext_order_with(dc3hip_gctx *G, KM km, u64 BL, const HiMap &hm, u32 
   double pred = 1.0;
   RC(predict_tie_fraction_pos<KM>(c, km, n, hm, &pred));
   c->stats.level_tie_pred[0] = pred;
-  if (!(pred < kTextSortMaxPredicted)) return E_OK;
+  if (!text_order_worth_trying(pred, (u64)n, hm.nbits)) return E_OK;
   RC((gorder_positions<KM>(G, km, n, kbits, hm, 0, nullptr, G_TOP, done)));
   if (*done) {
     c->stats.text_sort_state = 1;

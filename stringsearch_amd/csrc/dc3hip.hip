@@ -551,6 +551,15 @@ static constexpr double kHybridMaxPredicted = 0.50;
 static constexpr double kHybridMaxMeasured = 0.60;
 static constexpr double kFullSortMaxPredicted = 0.10;   // whole-level shortcut only for very few predicted ties
 static constexpr double kTextSortMaxPredicted = 0.30;   // whole-text shortcut (33-bit images at 2^30 bytes tie ~12 %)
+static constexpr double kTextSortMaxBirthday = 0.55;    // ... or more, if the image width alone explains the ties
+// Whole-text shortcut: go when few image ties are predicted, or when the predicted ties are no more than what a
+// uniformly random text has at this image width (1 - exp(-n / 2^nbits): the 32-bit images of 2^31 positions tie 39 %
+// and the tie pass still costs far less than the recursion), which says the text itself is not repetitive.
+static bool text_order_worth_trying(double pred, u64 n, u32 nbits) {
+  if (pred < kTextSortMaxPredicted) return true;
+  const double birthday = 1.0 - exp(-(double)n / ldexp(1.0, (int)nbits));
+  return pred < kTextSortMaxBirthday && pred <= 1.25 * birthday + 0.02;
+}
 // hi = floor(X * mfix / 2^64) in N = min(64 - pbits, kbits) bits; X = key >> shx; see HiMap
 static HiMap make_himap(u64 B, u32 kbits, u32 m, u32 pbits = 0) {
   const unsigned __int128 mx = (unsigned __int128)B * B * B - 1;      // largest key
@@ -1418,7 +1427,7 @@ static int try_text_order(dc3hip_ctx *c, KM km, u64 BL, const HiMap &hm, u32 sig
   double pred = 1.0;
   RC(predict_tie_fraction_pos<KM>(c, km, (u32)n, hm, &pred));
   c->stats.level_tie_pred[0] = pred;
-  if (!(pred < kTextSortMaxPredicted)) return E_OK;
+  if (!text_order_worth_trying(pred, (u64)n, hm.nbits)) return E_OK;
   const u32 m0 = (u32)((n + 2) / 3), m1 = m0 + (u32)(n / 3);            // level 1 = string of m1 names
   const u32 m02_1 = (m1 + 2) / 3 + m1 / 3;                              // its samples (incl. the dummy)
   // The filtered order (2 * m02_1 words < n) lives in the output buffer: the optimistic SA written there
