@@ -290,6 +290,19 @@ def main():
                     "ms": m, "MB/s": n / m / 1e3, "sufcheck": c3.sufcheck(), "levels": st3["levels"],
                     "path": PATH_NAMES.get(st3.get("text_sort_state", 0), "?"),
                     "roofline_path": path_roofline(st3, m)}
+                if st3.get("text_sort_state", 0) != 0:
+                    # finished (or started) by the whole-text order: the DC3 recursion proper on the same text beside it
+                    chk3 = c3.checksum()
+                    os.environ["DC3HIP_NO_TEXT_SHORTCUT"] = "1"
+                    try:
+                        with ss.Context(n, device=local_rank) as c5:
+                            c5.generate(n, seed, kd)
+                            c5.build(); c5.build()
+                            per_cfg[f"{name}_{per_gpu / 2**30:g}GiB"]["dc3_recursion_only"] = {
+                                "switch": "DC3HIP_NO_TEXT_SHORTCUT=1", "ms": c5.stats()["build_ms"], "levels": c5.stats()["levels"],
+                                "checksum_equal": c5.checksum() == chk3}
+                    finally:
+                        os.environ.pop("DC3HIP_NO_TEXT_SHORTCUT", None)
         out["per_config"] = per_cfg
         # The GLOBAL mode (one suffix array over P ranks) as P loopback ranks on THIS GPU: the ranks
         # time-share the device, so wall_ms is about the SUM of all ranks' work (work_inflation = wall / single-device

@@ -100,7 +100,7 @@ def path_roofline(st, ms):
             "phase_ms": {k: round(v, 3) for k, v in st["phase_ms"].items() if v}}
 
 
-PATH_NAMES = {0: "dc3 recursion", 1: "whole-text order (all 9-byte windows distinct; no recursion level built)",
+PATH_NAMES = {0: "dc3 recursion", 1: "whole-text order (all windows distinct: 9 bytes, or 3L symbols of a small alphabet; no recursion level built)",
               2: "whole-text order reused as level 1's sorted samples, then dc3 recursion", 3: "whole-text order abandoned, dc3 recursion"}
 
 

@@ -838,19 +838,19 @@ template <class KM>
 __global__ __launch_bounds__(kBlock) void k_tie_resolve(KM km, Rec8 *__restrict__ h, u32 n, u32 pbits,
                                                        uint8_t *__restrict__ f, u32 *words,
                                                        u32 *__restrict__ emit_sa, u32 skip) {
-  // Group starts are sparse (a few per wave): a block first collects the starts of a 4096-record tile in
-  // LDS, then full waves work the list, so the dependent gathers of many groups are in flight together.
-  constexpr u32 kIPT = 4, kTile = kBlock * kIPT;
+  // Group starts are sparse (a few per wave): a block collects the starts of 2048-record tiles in LDS, tile after
+  // tile, and works the list in full batches of kBlock groups (one per lane), so the dependent gathers of many groups
+  // are in flight together (see k_tie_resolve_split).
+  constexpr u32 kIPT = 4, kTile = kBlock * kIPT, kCap = kTile / 2 + kBlock;
   __shared__ uint16_t lcode[256];
-  __shared__ u32 starts[kTile / 2];
+  __shared__ u32 starts[kCap];
   __shared__ u32 nstart, ntied, ndup;
   km.stage(lcode);
   const u32 posmask = pbits >= 32 ? 0xffffffffu : ((1u << pbits) - 1u);
   const u32 ntiles = (n + kTile - 1) / kTile;
-  if (threadIdx.x == 0) { ntied = 0; ndup = 0; }
+  if (threadIdx.x == 0) { ntied = 0; ndup = 0; nstart = 0; }
+  __syncthreads();
   for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    if (threadIdx.x == 0) nstart = 0;
-    __syncthreads();
     u32 tied = 0;
 #pragma unroll
     for (u32 j = 0; j < kIPT; j++) {
@@ -868,56 +868,66 @@ __global__ __launch_bounds__(kBlock) void k_tie_resolve(KM km, Rec8 *__restrict_
     tied = wave_reduce(tied);
     if (lane_id() == 0 && tied) atomicAdd(&ntied, tied);
     __syncthreads();
-    const u32 ns = nstart;
+    const bool last = tile + gridDim.x >= ntiles;
     u32 dup = 0;
-    for (u32 s = threadIdx.x; s < ns; s += kBlock) {
-      const u32 i = starts[s];
-      const Rec8 h0 = h[i];
-      const u64 a = rec8_word(h0) >> pbits;
-      u32 e = i + 2;
-      while (e < n && e - i <= kTieSmallMax && (rec8_word(h[e]) >> pbits) == a) e++;
-      const u32 len = e - i;
-      if (len > kTieSmallMax) { words[0] = 1u; continue; }
-      const u32 lo_img = h0.val & ~posmask;
-      Rec8 o; o.key = h0.key;
-      if (len == 2) {
-        TieKey<KM> x, y;
-        x.load(km, h0.val & posmask, lcode); y.load(km, h[i + 1].val & posmask, lcode);
-        const int c3 = TieKey<KM>::cmp3(km, lcode, y, x);
-        if (c3 < 0) { const TieKey<KM> t = x; x = y; y = t; }
-        o.val = lo_img | x.pos(); h[i] = o;
-        o.val = lo_img | y.pos(); h[i + 1] = o;
-        const bool ne = c3 != 0;
-        f[i + 1] = ne ? 1 : 0;
-        dup += ne ? 0u : 1u;
-        if (emit_sa) {
-          if (i >= skip) emit_sa[i - skip] = x.pos();
-          emit_sa[i + 1 - skip] = y.pos();
-        }
-        continue;
-      }
-      TieKey<KM> loc[kTieSmallMax];
-      for (u32 x = 0; x < len; x++) {
-        TieKey<KM> v;
-        v.load(km, h[i + x].val & posmask, lcode);
-        u32 y = x;
-        while (y > 0 && TieKey<KM>::cmp3(km, lcode, v, loc[y - 1]) < 0) { loc[y] = loc[y - 1]; y--; }
-        loc[y] = v;
-      }
-      for (u32 x = 0; x < len; x++) {
-        o.val = lo_img | loc[x].pos();
-        h[i + x] = o;
-        if (x > 0) {
-          const bool ne = TieKey<KM>::cmp3(km, lcode, loc[x], loc[x - 1]) != 0;
-          f[i + x] = ne ? 1 : 0;
+    for (;;) {
+      const u32 ns = nstart;
+      __syncthreads();                                         // everyone has read it before anyone appends again
+      if (ns == 0 || (ns < kBlock && !last)) break;
+      const u32 base = ns > kBlock ? ns - kBlock : 0;
+      if (base + threadIdx.x < ns) {
+        const u32 i = starts[base + threadIdx.x];
+        const Rec8 h0 = h[i];
+        const u64 a = rec8_word(h0) >> pbits;
+        u32 e = i + 2;
+        while (e < n && e - i <= kTieSmallMax && (rec8_word(h[e]) >> pbits) == a) e++;
+        const u32 len = e - i;
+        const u32 lo_img = h0.val & ~posmask;
+        Rec8 o; o.key = h0.key;
+        if (len > kTieSmallMax) {
+          words[0] = 1u;
+        } else if (len == 2) {
+          TieKey<KM> x, y;
+          x.load(km, h0.val & posmask, lcode); y.load(km, h[i + 1].val & posmask, lcode);
+          const int c3 = TieKey<KM>::cmp3(km, lcode, y, x);
+          if (c3 < 0) { const TieKey<KM> t = x; x = y; y = t; }
+          o.val = lo_img | x.pos(); h[i] = o;
+          o.val = lo_img | y.pos(); h[i + 1] = o;
+          const bool ne = c3 != 0;
+          f[i + 1] = ne ? 1 : 0;
           dup += ne ? 0u : 1u;
+          if (emit_sa) {
+            if (i >= skip) emit_sa[i - skip] = x.pos();
+            emit_sa[i + 1 - skip] = y.pos();
+          }
+        } else {
+          TieKey<KM> loc[kTieSmallMax];
+          for (u32 x = 0; x < len; x++) {
+            TieKey<KM> v;
+            v.load(km, h[i + x].val & posmask, lcode);
+            u32 y = x;
+            while (y > 0 && TieKey<KM>::cmp3(km, lcode, v, loc[y - 1]) < 0) { loc[y] = loc[y - 1]; y--; }
+            loc[y] = v;
+          }
+          for (u32 x = 0; x < len; x++) {
+            o.val = lo_img | loc[x].pos();
+            h[i + x] = o;
+            if (x > 0) {
+              const bool ne = TieKey<KM>::cmp3(km, lcode, loc[x], loc[x - 1]) != 0;
+              f[i + x] = ne ? 1 : 0;
+              dup += ne ? 0u : 1u;
+            }
+            if (emit_sa && i + x >= skip) emit_sa[i + x - skip] = loc[x].pos();
+          }
         }
-        if (emit_sa && i + x >= skip) emit_sa[i + x - skip] = loc[x].pos();
       }
+      __syncthreads();
+      if (threadIdx.x == 0) nstart = base;
+      __syncthreads();
     }
     if (dup) atomicAdd(&ndup, dup);
-    __syncthreads();
   }
+  __syncthreads();
   if (threadIdx.x == 0) {
     if (ntied) atomicAdd(&words[1], ntied);
     if (ndup) atomicAdd(&words[2], ndup);
@@ -1121,16 +1131,16 @@ __global__ __launch_bounds__(kBlock) void k_tie_compact12(KM km, const Rec12 *__
 template <class KM>
 __global__ __launch_bounds__(kBlock) void k_tie_resolve12(KM km, Rec12 *__restrict__ h, u32 n, uint8_t *__restrict__ f,
                                                          u32 *words) {
-  constexpr u32 kIPT = 4, kTile = kBlock * kIPT;
+  // (group starts are collected tile after tile and worked in full batches of kBlock: see k_tie_resolve_split)
+  constexpr u32 kIPT = 4, kTile = kBlock * kIPT, kCap = kTile / 2 + kBlock;
   __shared__ uint16_t lcode[256];
-  __shared__ u32 starts[kTile / 2];
+  __shared__ u32 starts[kCap];
   __shared__ u32 nstart, ntied, ndup;
   km.stage(lcode);
   const u32 ntiles = (n + kTile - 1) / kTile;
-  if (threadIdx.x == 0) { ntied = 0; ndup = 0; }
+  if (threadIdx.x == 0) { ntied = 0; ndup = 0; nstart = 0; }
+  __syncthreads();
   for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    if (threadIdx.x == 0) nstart = 0;
-    __syncthreads();
     u32 tied = 0;
 #pragma unroll
     for (u32 j = 0; j < kIPT; j++) {
@@ -1146,34 +1156,46 @@ __global__ __launch_bounds__(kBlock) void k_tie_resolve12(KM km, Rec12 *__restri
     tied = wave_reduce(tied);
     if (lane_id() == 0 && tied) atomicAdd(&ntied, tied);
     __syncthreads();
-    const u32 ns = nstart;
+    const bool last = tile + gridDim.x >= ntiles;
     u32 dup = 0;
-    for (u32 s = threadIdx.x; s < ns; s += kBlock) {
-      const u32 i = starts[s];
-      const u64 a = img12(h[i]);
-      u32 e = i + 2;
-      while (e < n && e - i <= kTieSmallMax && img12(h[e]) == a) e++;
-      const u32 len = e - i;
-      if (len > kTieSmallMax) { words[0] = 1u; continue; }
-      Rec16 loc[kTieSmallMax];
-      for (u32 x = 0; x < len; x++) {
-        const Rec16 v = km.make(h[i + x].pos, lcode);
-        u32 y = x;
-        while (y > 0 && key_less(v, loc[y - 1])) { loc[y] = loc[y - 1]; y--; }
-        loc[y] = v;
-      }
-      for (u32 x = 0; x < len; x++) {
-        h[i + x].pos = loc[x].pos;
-        if (x > 0) {
-          const bool ne = key_neq(loc[x], loc[x - 1]);
-          f[i + x] = ne ? 1 : 0;
-          dup += ne ? 0u : 1u;
+    for (;;) {
+      const u32 ns = nstart;
+      __syncthreads();                                         // everyone has read it before anyone appends again
+      if (ns == 0 || (ns < kBlock && !last)) break;
+      const u32 base = ns > kBlock ? ns - kBlock : 0;
+      if (base + threadIdx.x < ns) {
+        const u32 i = starts[base + threadIdx.x];
+        const u64 a = img12(h[i]);
+        u32 e = i + 2;
+        while (e < n && e - i <= kTieSmallMax && img12(h[e]) == a) e++;
+        const u32 len = e - i;
+        if (len > kTieSmallMax) {
+          words[0] = 1u;
+        } else {
+          Rec16 loc[kTieSmallMax];
+          for (u32 x = 0; x < len; x++) {
+            const Rec16 v = km.make(h[i + x].pos, lcode);
+            u32 y = x;
+            while (y > 0 && key_less(v, loc[y - 1])) { loc[y] = loc[y - 1]; y--; }
+            loc[y] = v;
+          }
+          for (u32 x = 0; x < len; x++) {
+            h[i + x].pos = loc[x].pos;
+            if (x > 0) {
+              const bool ne = key_neq(loc[x], loc[x - 1]);
+              f[i + x] = ne ? 1 : 0;
+              dup += ne ? 0u : 1u;
+            }
+          }
         }
       }
+      __syncthreads();
+      if (threadIdx.x == 0) nstart = base;
+      __syncthreads();
     }
     if (dup) atomicAdd(&ndup, dup);
-    __syncthreads();
   }
+  __syncthreads();
   if (threadIdx.x == 0) {
     if (ntied) atomicAdd(&words[1], ntied);
     if (ndup) atomicAdd(&words[2], ndup);

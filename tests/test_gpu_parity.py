@@ -629,12 +629,26 @@ def test_full_size_1gib_text_and_dna_properties(ss, kind, label):
         assert c.sufcheck() == 0, label
         chk = c.checksum()
         st = c.stats()
-        assert st["levels"] >= 3 and st["text_sort_state"] == 0, (label, st["level_sorted"])
+        if kind == 2:
+            assert st["levels"] >= 3 and st["text_sort_state"] == 0, (label, st["level_sorted"])
+        else:           # random DNA: all 39-symbol windows distinct, the whole-text order is the suffix array
+            assert st["levels"] == 1 and st["text_sort_state"] == 1, (label, st["level_sorted"])
         c.build()
         assert c.checksum() == chk
         u, pidx = c.bwt()
         assert 1 <= pidx <= n
         assert np.array_equal(np.bincount(u, minlength=256), np.bincount(c.text(), minlength=256))
+    if kind == 1:       # and the DC3 recursion proper on the same text gives the same array
+        import os
+        os.environ["DC3HIP_NO_LONG_KEYS"] = "1"
+        try:
+            with ss.Context(n) as c:
+                c.generate(n, 3, kind)
+                c.build()
+                assert c.stats()["levels"] >= 3 and c.stats()["text_sort_state"] == 0
+                assert c.checksum() == chk and c.sufcheck() == 0
+        finally:
+            os.environ.pop("DC3HIP_NO_LONG_KEYS", None)
 
 
 def test_beyond_2pow31_needs_64bit_indices(ss):
@@ -647,10 +661,22 @@ def test_beyond_2pow31_needs_64bit_indices(ss):
         c.build()
         assert c.sufcheck() == 0
         st = c.stats()
-        assert st["level_n"][0] == n and st["levels"] >= 3 and st["level_name_width"][0] == 3
+        # 32-bit images of 2^31 positions tie 39 % even on random symbols; the whole-text order (39-symbol windows) is
+        # taken all the same because the image width alone explains the ties
+        assert st["level_n"][0] == n and st["levels"] == 1 and st["text_sort_state"] == 1, st["level_sorted"]
+        chk = c.checksum()
         with pytest.raises(ss.Dc3HipError) as ei:
             c.sa(np.int32)                         # int32 cannot hold these positions
         assert ei.value.code == -4
+    os.environ["DC3HIP_NO_LONG_KEYS"] = "1"        # and the recursion proper at this size
+    try:
+        with ss.Context(n) as c:
+            c.generate(n, 5, 1, offset=7 * n)
+            c.build()
+            st = c.stats()
+            assert st["levels"] >= 3 and st["level_name_width"][0] == 3 and c.checksum() == chk and c.sufcheck() == 0
+    finally:
+        os.environ.pop("DC3HIP_NO_LONG_KEYS", None)
     import ctypes
     t = np.zeros(8, dtype=np.uint8); sa = np.zeros(8, dtype=np.int32)
     from stringsearch_amd._lib import Opts
@@ -720,7 +746,8 @@ def test_1gib_text_and_dna_pass_reference_sufcheck(ss, oracle, kind, seed):
     with ss.Context(n) as c:
         c.generate(n, seed, kind)
         c.build()
-        assert c.stats()["text_sort_state"] == 0          # the DC3 recursion proper
+        # text: the DC3 recursion proper; random DNA: the whole-text order by 39-symbol windows
+        assert c.stats()["text_sort_state"] == (0 if kind == 2 else 1)
         text = c.text()
         got = c.sa()
     assert _ref_sufcheck(oracle, text, got) == 0
