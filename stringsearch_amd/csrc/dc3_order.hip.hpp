@@ -307,15 +307,14 @@ __global__ __launch_bounds__(1024) void k_invperm_local(const Rec8 *__restrict__
 // (exact: the key itself fits N bits).  Any monotone map is valid for the tie-refine scheme.
 // The record is the 64-bit word (hi << pbits) | pos.
 struct HiMap { u64 mfix; u32 shx, pbits, nbits, exact; };
-__device__ __forceinline__ Rec8 hyb_rec(const Rec16 &r, HiMap hm) {
+__device__ __forceinline__ u64 hyb_hi(const Rec16 &r, const HiMap &hm) {
   const u64 lo = (u64)r.k0 | ((u64)r.k1 << 32);
-  u64 hi;
-  if (hm.exact) hi = lo;
-  else {
-    const u64 x = hm.shx ? ((lo >> hm.shx) | ((u64)r.k2 << (64 - hm.shx))) : lo;
-    hi = __umul64hi(x, hm.mfix);
-  }
-  const u64 w = (hi << hm.pbits) | r.pos;
+  if (hm.exact) return lo;
+  const u64 x = hm.shx ? ((lo >> hm.shx) | ((u64)r.k2 << (64 - hm.shx))) : lo;
+  return __umul64hi(x, hm.mfix);
+}
+__device__ __forceinline__ Rec8 hyb_rec(const Rec16 &r, HiMap hm) {
+  const u64 w = (hyb_hi(r, hm) << hm.pbits) | r.pos;
   return Rec8{(u32)(w >> 32), (u32)w};
 }
 // Order (< 0, 0, > 0) of the nsym-symbol windows of text positions p and q without building their keys: compared a
@@ -349,6 +348,7 @@ struct Key3 {
     return make_rec(S.get(p), S.get(p + 1), S.get(p + 2), B, p);
   }
   __device__ __forceinline__ Rec8 image(u32 p, const uint16_t *lds, const HiMap &hm) const { return hyb_rec(make(p, lds), hm); }
+  __device__ __forceinline__ u64 image_hi(u32 p, const uint16_t *lds, const HiMap &hm) const { return hyb_hi(make(p, lds), hm); }
 };
 struct Key9 {
   SymU8 S; u32 B /* sigma+1 */, B3 /* B^3 */;
@@ -364,6 +364,7 @@ struct Key9 {
     return make_rec(t0, t1, t2, B3, p);
   }
   __device__ __forceinline__ Rec8 image(u32 p, const uint16_t *lds, const HiMap &hm) const { return hyb_rec(make(p, lds), hm); }
+  __device__ __forceinline__ u64 image_hi(u32 p, const uint16_t *lds, const HiMap &hm) const { return hyb_hi(make(p, lds), hm); }
 };
 // KeyT = 3*L symbols of the text as three limbs of L symbols in base B (limb base BL = B^L < 2^32): the longer window
 // a small alphabet needs before windows can be distinct (DNA, B = 5: L = 13, 39 symbols, 90 bits).  L = 3 is Key9's
@@ -394,7 +395,7 @@ struct KeyT {
     return make_rec(limb[0], limb[1], limb[2], BL, p);
   }
   __device__ __forceinline__ int cmp(u32 p, u32 q, const uint16_t *lds) const { return window_cmp(S, p, q, 3 * L, lds); }
-  __device__ __forceinline__ Rec8 image(u32 p, const uint16_t *lds, const HiMap &hm) const {
+  __device__ __forceinline__ u64 image_hi(u32 p, const uint16_t *lds, const HiMap &hm) const {
     const u32 nw = (J + 3) / 4;
     u32 w[kKeyTMaxImageSyms / 4];
 #pragma unroll
@@ -409,15 +410,19 @@ struct KeyT {
         v = v * sigma + q;
       }
     }
-    const u64 word = (__umul64hi(v, hm.mfix) << hm.pbits) | p;
+    return __umul64hi(v, hm.mfix);
+  }
+  __device__ __forceinline__ Rec8 image(u32 p, const uint16_t *lds, const HiMap &hm) const {
+    const u64 word = (image_hi(p, lds, hm) << hm.pbits) | p;
     return Rec8{(u32)(word >> 32), (u32)word};
   }
 };
 // whole text with KeyT, 4 consecutive positions per thread: J + 3 digits, the first image from scratch and the next
 // three by rolling (v' = (v - d_first * sigma^(J-1)) * sigma + d_next); same output, chunking and digit table as
 // k_pack_image_text.  P1 = sigma^(J-1).
-template <int NB>
-__global__ __launch_bounds__(kBlock) void k_pack_image_textT(KeyT km, u32 n, HiMap hm, u64 P1, Rec8 *__restrict__ out,
+// kWide: 12-byte records {image, position} (k_pack_image12_all_hist's output) instead of (image << pbits) | position.
+template <int NB, bool kWide>
+__global__ __launch_bounds__(kBlock) void k_pack_image_textT(KeyT km, u32 n, HiMap hm, u64 P1, void *__restrict__ outv,
                                                             u32 chunk, u32 nchunks, u32 *__restrict__ table) {
   __shared__ uint16_t lcode[256];
   __shared__ u32 hist[kWaves][NB];
@@ -449,20 +454,38 @@ __global__ __launch_bounds__(kBlock) void k_pack_image_textT(KeyT km, u32 n, HiM
         else dt2 = q;
       }
     }
-    Rec8 r[4];
+    u64 img[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      const u64 word = (__umul64hi(v, hm.mfix) << hm.pbits) | (p0 + j);
-      r[j] = Rec8{(u32)(word >> 32), (u32)word};
-      if (p0 + j < end) atomicAdd(&myh[(u32)(word >> hm.pbits) & (NB - 1)], 1u);
+      img[j] = __umul64hi(v, hm.mfix);
+      if (p0 + j < end) atomicAdd(&myh[(u32)img[j] & (NB - 1)], 1u);
       if (j < 3) v = (v - (u64)dh[j] * P1) * sigma + (j == 0 ? dt0 : j == 1 ? dt1 : dt2);
     }
-    if (p0 + 3 < end) {
-      u32x4 *o = reinterpret_cast<u32x4 *>(out + p0);
-      o[0] = u32x4{r[0].key, r[0].val, r[1].key, r[1].val};
-      o[1] = u32x4{r[2].key, r[2].val, r[3].key, r[3].val};
+    if (kWide) {
+      Rec12 *out = static_cast<Rec12 *>(outv);
+      if (p0 + 3 < end) {                                    // 48 contiguous, 16-byte aligned bytes (p0 % 4 == 0)
+        u32x4 *o = reinterpret_cast<u32x4 *>(out + p0);
+        o[0] = u32x4{(u32)img[0], (u32)(img[0] >> 32), p0, (u32)img[1]};
+        o[1] = u32x4{(u32)(img[1] >> 32), p0 + 1, (u32)img[2], (u32)(img[2] >> 32)};
+        o[2] = u32x4{p0 + 2, (u32)img[3], (u32)(img[3] >> 32), p0 + 3};
+      } else {
+        for (int j = 0; j < 4; j++) if (p0 + j < end) out[p0 + j] = Rec12{(u32)img[j], (u32)(img[j] >> 32), p0 + j};
+      }
     } else {
-      for (int j = 0; j < 4; j++) if (p0 + j < end) out[p0 + j] = r[j];
+      Rec8 *out = static_cast<Rec8 *>(outv);
+      Rec8 r[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const u64 word = (img[j] << hm.pbits) | (p0 + j);
+        r[j] = Rec8{(u32)(word >> 32), (u32)word};
+      }
+      if (p0 + 3 < end) {
+        u32x4 *o = reinterpret_cast<u32x4 *>(out + p0);
+        o[0] = u32x4{r[0].key, r[0].val, r[1].key, r[1].val};
+        o[1] = u32x4{r[2].key, r[2].val, r[3].key, r[3].val};
+      } else {
+        for (int j = 0; j < 4; j++) if (p0 + j < end) out[p0 + j] = r[j];
+      }
     }
   }
   __syncthreads();
@@ -1130,7 +1153,7 @@ __global__ __launch_bounds__(kBlock) void k_tie_compact12(KM km, const Rec12 *__
 // words[1] += tied records, words[2] += records whose full key equals the predecessor's (settled groups only)
 template <class KM>
 __global__ __launch_bounds__(kBlock) void k_tie_resolve12(KM km, Rec12 *__restrict__ h, u32 n, uint8_t *__restrict__ f,
-                                                         u32 *words) {
+                                                         u32 *words, u32 *__restrict__ emit_sa) {
   // (group starts are collected tile after tile and worked in full batches of kBlock: see k_tie_resolve_split)
   constexpr u32 kIPT = 4, kTile = kBlock * kIPT, kCap = kTile / 2 + kBlock;
   __shared__ uint16_t lcode[256];
@@ -1146,11 +1169,13 @@ __global__ __launch_bounds__(kBlock) void k_tie_resolve12(KM km, Rec12 *__restri
     for (u32 j = 0; j < kIPT; j++) {
       const u32 i = tile * kTile + j * kBlock + threadIdx.x;
       if (i < n) {
-        const u64 a = img12(h[i]);
+        const Rec12 r = h[i];
+        const u64 a = img12(r);
         const bool eqp = i > 0 && img12(h[i - 1]) == a;
         const bool eqn = i + 1 < n && img12(h[i + 1]) == a;
         if (eqn && !eqp) starts[atomicAdd(&nstart, 1u)] = i;
         if (eqn || eqp) tied++;
+        else if (emit_sa) emit_sa[i] = r.pos;       // optimistic suffix array (complete when no group overflowed)
       }
     }
     tied = wave_reduce(tied);
@@ -1181,6 +1206,7 @@ __global__ __launch_bounds__(kBlock) void k_tie_resolve12(KM km, Rec12 *__restri
           }
           for (u32 x = 0; x < len; x++) {
             h[i + x].pos = loc[x].pos;
+            if (emit_sa) emit_sa[i + x] = loc[x].pos;
             if (x > 0) {
               const bool ne = key_neq(loc[x], loc[x - 1]);
               f[i + x] = ne ? 1 : 0;
@@ -1210,6 +1236,44 @@ __global__ __launch_bounds__(kBlock) void k_tie_writeback12(const Rec16 *__restr
     bool ne = true;
     if (j > 0) { const Rec16 prev = sub[j - 1]; ne = key_neq(cur, prev); }
     f[i] = ne ? 1 : 0;
+  }
+}
+
+// Whole-text (or whole-level) order on 12-byte records: image of hm.nbits <= 63 bits next to a full 32-bit position —
+// for texts beyond 2^31 positions, where the 8-byte record leaves a 32-bit image that ties 39 % of even random
+// positions.  Chunking and digit table as k_pack_image_all_hist; k_pack_image12_pos = tie-predictor sample (image << 1).
+template <class KM, int NB>
+__global__ __launch_bounds__(kBlock) void k_pack_image12_all_hist(KM km, u32 nrec, HiMap hm, Rec12 *__restrict__ out,
+                                                                 u32 chunk, u32 nchunks, u32 *__restrict__ table) {
+  __shared__ uint16_t lcode[256];
+  __shared__ u32 hist[kWaves][NB];
+  km.stage(lcode);
+#pragma unroll
+  for (int w = 0; w < kWaves; w++)
+    for (int j = threadIdx.x; j < NB; j += kBlock) hist[w][j] = 0;
+  __syncthreads();
+  u32 *myh = hist[wave_id()];
+  const u32 begin = blockIdx.x * chunk, end = min(nrec, begin + chunk);
+  for (u32 i = begin + threadIdx.x; i < end; i += kBlock) {
+    const u64 img = km.image_hi(i, lcode, hm);
+    out[i] = Rec12{(u32)img, (u32)(img >> 32), i};
+    atomicAdd(&myh[(u32)img & (NB - 1)], 1u);
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < NB; j += kBlock) {
+    u32 sum = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; w++) sum += hist[w][j];
+    table[(size_t)j * nchunks + blockIdx.x] = sum;
+  }
+}
+template <class KM>
+__global__ __launch_bounds__(kBlock) void k_pack_image12_pos(KM km, u32 nout, u32 stride, HiMap hm, Rec8 *out) {
+  __shared__ uint16_t lcode[256];
+  km.stage(lcode);
+  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < nout; i += gridDim.x * kBlock) {
+    const u64 w = km.image_hi(i * stride, lcode, hm) << 1;
+    out[i] = Rec8{(u32)(w >> 32), (u32)w};
   }
 }
 

@@ -84,6 +84,7 @@ struct dc3hip_ctx {
   bool no_nine_bit = false, no_rec12 = false, no_discard = false, no_fullsort = false, no_text_shortcut = false;
   bool no_split_emit = false;
   bool no_long_keys = false;   // DC3HIP_NO_LONG_KEYS=1: the whole-text shortcut only with 9-symbol windows (no KeyT)
+  int text_order12 = -1;       // DC3HIP_TEXT_ORDER12=1/0: whole-text shortcut on 12-byte records always / never (default: n > 2^31)
   double hybrid12_max_pred = kHybrid12MaxPredicted;   // DC3HIP_HYBRID12_MAX_PRED (tuning)
   u32 hybrid12_min = 1u << 22; // DC3HIP_HYBRID12_MIN: smallest level (samples) that tries it (tests lower it)
   bool no_hybrid8 = false;     // DC3HIP_NO_HYBRID8=1 (tests): skip the 8-byte prefix sort / whole-level order of a level
@@ -755,8 +756,10 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
 // Tie refinement of records sorted by their 63-bit key prefix (see order_hybrid12): f[i] = full key differs from the
 // predecessor's, tied groups ordered by the full key.  *ok = false: too many ties, or no room for the general path.
 template <class KM>
-static int hybrid12_refine(dc3hip_ctx *c, KM km, u32 kbits, Rec12 *h, u32 n, uint8_t *f, bool *ok, int depth) {
+static int hybrid12_refine(dc3hip_ctx *c, KM km, u32 kbits, Rec12 *h, u32 n, uint8_t *f, bool *ok, int depth,
+                           u32 *emit_sa = nullptr, bool *distinct = nullptr) {
   *ok = false;
+  if (distinct) *distinct = false;
   HIPC(hipMemsetAsync(f, 1, (size_t)n, c->stream));
   u32 tied = 0;
   bool general = false;
@@ -764,7 +767,7 @@ static int hybrid12_refine(dc3hip_ctx *c, KM km, u32 kbits, Rec12 *h, u32 n, uin
     PhaseScope ps(c, DC3HIP_PH_TIES, n);
     HIPC(hipMemsetAsync(c->d_words + 10, 0, 3 * sizeof(u32), c->stream));
     hipLaunchKernelGGL((k_tie_resolve12<KM>), dim3(grid_for(c, n / 4 + 1)), dim3(kBlock), 0, c->stream, km, h, n, f,
-                       c->d_words + 10);
+                       c->d_words + 10, emit_sa);
     KCHECK();
     HIPC(hipMemcpyAsync(c->h_words + 10, c->d_words + 10, 3 * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
   }
@@ -772,6 +775,8 @@ static int hybrid12_refine(dc3hip_ctx *c, KM km, u32 kbits, Rec12 *h, u32 n, uin
   tied = c->h_words[11];
   c->stats.level_tied[depth] = tied;
   general = c->h_words[10] != 0;
+  // no group overflowed and no full key repeats: the positions the tie pass wrote to emit_sa are the sorted order
+  if (distinct) *distinct = emit_sa && !general && c->h_words[12] == 0;
   if ((double)tied > std::max(kHybridMaxMeasured, c->hybrid12_max_pred + 0.1) * (double)n) return E_OK;
   if (general) {
     // some tied group is larger than kTieSmallMax: re-sort ALL tied records by the full key (the small groups that were
@@ -982,15 +987,65 @@ int launch_pack_all<KeyT>(dc3hip_ctx *c, KeyT km, u32 nrec, const HiMap &hm, Rec
   u64 P1 = 1;
   for (u32 i = 0; i + 1 < km.J; i++) P1 *= km.sigma;
   if (nb == 512)
-    hipLaunchKernelGGL((k_pack_image_textT<512>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, km, nrec, hm, P1, out,
-                       ck.chunk, ck.nchunks, table);
+    hipLaunchKernelGGL((k_pack_image_textT<512, false>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, km, nrec, hm, P1,
+                       (void *)out, ck.chunk, ck.nchunks, table);
   else
-    hipLaunchKernelGGL((k_pack_image_textT<256>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, km, nrec, hm, P1, out,
-                       ck.chunk, ck.nchunks, table);
+    hipLaunchKernelGGL((k_pack_image_textT<256, false>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, km, nrec, hm, P1,
+                       (void *)out, ck.chunk, ck.nchunks, table);
   KCHECK();
   *first_table = table;
   return E_OK;
 }
+// The records of all m (+dummy) positions are in key order behind accessor `acc` (pos, neq): all keys distinct -> the
+// order is the suffix array (*state = 1; out_sa / out_rank written); else, with spos/snf given, the samples are
+// filtered out with their full names (*state = 2); else *state stays 0.
+template <class Acc, class Map>
+static int finish_position_order(dc3hip_ctx *c, Acc acc, Map mp, u32 nrec, u32 m, u32 dummy, u32 *out_sa, u32 *out_rank,
+                                 u32 *spos, u32 *snf, int *state) {
+  const Chunking ck = make_chunks(c, nrec, kBlock);
+  u32 *counts = nullptr, *scounts = nullptr;
+  RC(arena_alloc(c, (size_t)ck.nchunks + 16, &counts));
+  RC(arena_alloc(c, (size_t)ck.nchunks + 16, &scounts));
+  {
+    PhaseScope ps(c, DC3HIP_PH_NAMING, nrec);
+    HIPC(hipMemsetAsync(c->d_words + 4, 0, sizeof(u32), c->stream));
+    hipLaunchKernelGGL((k_name_count<Acc>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, acc, nrec, ck.chunk,
+                       counts, c->d_words + 4);
+    KCHECK();
+    hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, counts, ck.nchunks, c->d_words);
+    KCHECK();
+    HIPC(hipMemcpyAsync(c->h_words, c->d_words, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPC(hipStreamSynchronize(c->stream));
+  if (c->h_words[0] == nrec) {          // every key distinct: the sorted order is the suffix array
+    Rec8 *pa = nullptr, *pb = nullptr;
+    if (out_rank) {
+      RC(arena_alloc(c, (size_t)m, &pa));
+      RC(arena_alloc(c, (size_t)m, &pb));
+    }
+    {
+      PhaseScope ps(c, DC3HIP_PH_RANKS, m);
+      hipLaunchKernelGGL((k_emit_sorted<Acc>), dim3(grid_for(c, m)), dim3(kBlock), 0, c->stream, acc, m, dummy,
+                         out_sa, pa);
+      KCHECK();
+    }
+    if (out_rank) RC(inverse_permute(c, pa, pb, m, out_rank, DC3HIP_PH_RANKS));
+    *state = 1;
+  } else if (spos && snf) {             // keep the sort: filter the samples with their full names
+    PhaseScope ps(c, DC3HIP_PH_NAMING, nrec);
+    hipLaunchKernelGGL((k_filter_count<Acc, Map>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, acc, mp, nrec,
+                       ck.chunk, scounts);
+    KCHECK();
+    hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, scounts, ck.nchunks, (u32 *)nullptr);
+    KCHECK();
+    hipLaunchKernelGGL((k_filter_write<Acc, Map>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, acc, mp, nrec,
+                       ck.chunk, counts, scounts, spos, snf);
+    KCHECK();
+    *state = 2;
+  }
+  return E_OK;
+}
+
 template <class KM, class Map>
 static int order_all_positions(dc3hip_ctx *c, KM km, Map mp, u32 m, u32 kbits, const HiMap &hm, u32 dummy, u32 *out_sa,
                                u32 *out_rank, u32 *spos, u32 *snf, int *state, int depth) {
@@ -1014,47 +1069,7 @@ static int order_all_positions(dc3hip_ctx *c, KM km, Map mp, u32 m, u32 kbits, c
     *state = 1;                            // the tie pass already wrote the suffix array
   } else if (sorted_ok) {
     AccHyb acc; acc.h = h; acc.f = f; acc.posmask = hm.pbits >= 32 ? 0xffffffffu : ((1u << hm.pbits) - 1u);
-    const Chunking ck = make_chunks(c, nrec, kBlock);
-    u32 *counts = nullptr, *scounts = nullptr;
-    RC(arena_alloc(c, (size_t)ck.nchunks + 16, &counts));
-    RC(arena_alloc(c, (size_t)ck.nchunks + 16, &scounts));
-    {
-      PhaseScope ps(c, DC3HIP_PH_NAMING, nrec);
-      HIPC(hipMemsetAsync(c->d_words + 4, 0, sizeof(u32), c->stream));
-      hipLaunchKernelGGL((k_name_count<AccHyb>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, acc, nrec, ck.chunk,
-                         counts, c->d_words + 4);
-      KCHECK();
-      hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, counts, ck.nchunks, c->d_words);
-      KCHECK();
-      HIPC(hipMemcpyAsync(c->h_words, c->d_words, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
-    }
-    HIPC(hipStreamSynchronize(c->stream));
-    if (c->h_words[0] == nrec) {          // every key distinct: the sorted order is the suffix array
-      Rec8 *pa = nullptr, *pb = nullptr;
-      if (out_rank) {
-        RC(arena_alloc(c, (size_t)m, &pa));
-        RC(arena_alloc(c, (size_t)m, &pb));
-      }
-      {
-        PhaseScope ps(c, DC3HIP_PH_RANKS, m);
-        hipLaunchKernelGGL((k_emit_sorted<AccHyb>), dim3(grid_for(c, m)), dim3(kBlock), 0, c->stream, acc, m, dummy,
-                           out_sa, pa);
-        KCHECK();
-      }
-      if (out_rank) RC(inverse_permute(c, pa, pb, m, out_rank, DC3HIP_PH_RANKS));
-      *state = 1;
-    } else if (spos && snf) {             // keep the sort: filter the samples with their full names
-      PhaseScope ps(c, DC3HIP_PH_NAMING, nrec);
-      hipLaunchKernelGGL((k_filter_count<AccHyb, Map>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, acc, mp, nrec,
-                         ck.chunk, scounts);
-      KCHECK();
-      hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, scounts, ck.nchunks, (u32 *)nullptr);
-      KCHECK();
-      hipLaunchKernelGGL((k_filter_write<AccHyb, Map>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, acc, mp, nrec,
-                         ck.chunk, counts, scounts, spos, snf);
-      KCHECK();
-      *state = 2;
-    }
+    RC((finish_position_order<AccHyb, Map>(c, acc, mp, nrec, m, dummy, out_sa, out_rank, spos, snf, state)));
   }
   arena_release(c, mk);
   return E_OK;
@@ -1400,14 +1415,14 @@ static int build_alphabet(dc3hip_ctx *c, u32 *sigma_out) {
 
 // KeyT and the map of its image (see the struct): J = fewest symbols whose base-sigma value exceeds the image width by
 // two bits, within 63 bits, the key's 3L symbols and kKeyTMaxImageSyms.  false = no such J (the caller skips the path).
-static bool make_keyt(SymU8 S, u32 sigma, u32 L, u64 BL, u32 n, KeyT *km, HiMap *hm) {
+static bool make_keyt(SymU8 S, u32 sigma, u32 L, u64 BL, u32 n, KeyT *km, HiMap *hm, u32 image_bits = 0) {
   if (sigma < 2) return false;
-  hm->pbits = bits_of((u64)n - 1);                                       // positions 0..n-1 only
+  hm->pbits = image_bits ? 64 - image_bits : bits_of((u64)n - 1);        // positions 0..n-1 only
   hm->nbits = 64 - hm->pbits;
   hm->shx = 0; hm->exact = 0;
   u32 J = 1; u64 SJ = sigma;                                             // sigma^J
   const u32 jmax = std::min<u32>(3 * L, kKeyTMaxImageSyms);
-  while (J < jmax && (SJ >> (hm->nbits + 2)) == 0 && SJ * sigma < (1ull << 63)) { SJ *= sigma; J++; }
+  while (J < jmax && (SJ >> std::min<u32>(hm->nbits + 2, 62)) == 0 && SJ * sigma < (1ull << 63)) { SJ *= sigma; J++; }
   if ((SJ >> hm->nbits) == 0) return false;                              // the image must be a proper scaling
   hm->mfix = (u64)(((((unsigned __int128)1) << (64 + hm->nbits)) - 1) / SJ);
   km->S = S; km->B = sigma + 1; km->BL = (u32)BL; km->L = L; km->sigma = sigma; km->J = J;
@@ -1448,6 +1463,105 @@ static int try_text_order(dc3hip_ctx *c, KM km, u64 BL, const HiMap &hm, u32 sig
   return E_OK;
 }
 
+template <class KM>
+static int launch_pack12_all(dc3hip_ctx *c, KM km, u32 nrec, const HiMap &hm, Rec12 *out, int nb, const Chunking &ck, u32 *table) {
+  if (nb == 512)
+    hipLaunchKernelGGL((k_pack_image12_all_hist<KM, 512>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, km, nrec, hm, out,
+                       ck.chunk, ck.nchunks, table);
+  else
+    hipLaunchKernelGGL((k_pack_image12_all_hist<KM, 256>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, km, nrec, hm, out,
+                       ck.chunk, ck.nchunks, table);
+  KCHECK();
+  return E_OK;
+}
+template <>
+int launch_pack12_all<KeyT>(dc3hip_ctx *c, KeyT km, u32 nrec, const HiMap &hm, Rec12 *out, int nb, const Chunking &ck, u32 *table) {
+  u64 P1 = 1;
+  for (u32 i = 0; i + 1 < km.J; i++) P1 *= km.sigma;
+  if (nb == 512)
+    hipLaunchKernelGGL((k_pack_image_textT<512, true>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, km, nrec, hm, P1,
+                       (void *)out, ck.chunk, ck.nchunks, table);
+  else
+    hipLaunchKernelGGL((k_pack_image_textT<256, true>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, km, nrec, hm, P1,
+                       (void *)out, ck.chunk, ck.nchunks, table);
+  KCHECK();
+  return E_OK;
+}
+// The same shortcut on 12-byte records (image of ibits <= 63 bits NEXT TO the position instead of sharing a 64-bit
+// word with it): beyond 2^31 positions the 8-byte record has 32 image bits left and ties 39 % of even random
+// positions; here the image is as wide as the text needs (log2 n + 4.2 bits rounded up to whole 9-bit digits: 36 bits =
+// 4 passes of 24 B per record up to 3.5 GiB, 3-5 % ties; 45 bits above).  hm = map of KM's image to ibits.
+template <class KM>
+static int try_text_order12(dc3hip_ctx *c, KM km, u64 BL, const HiMap &hm, u32 sigma, bool *whole_text, Presort *pre) {
+  const int64_t n = c->n;
+  u32 kbits = 0;
+  { unsigned __int128 mx = (unsigned __int128)BL * BL * BL - 1; while (mx) { kbits++; mx >>= 1; } }
+  const size_t need = (size_t)n * 26 + ((size_t)256 << 20);
+  if (c->arena_bytes - c->arena_off < need) {
+    if (c->arena_fixed || c->arena_off != 0) return E_OK;
+    if (ensure_arena(c, need) != E_OK) return E_OK;
+  }
+  const ArenaMark mk = arena_mark(c);
+  {
+    const u32 stride = std::max<u32>(1, (u32)n >> 20);
+    const u32 ns = ((u32)n - 1) / stride + 1;
+    Rec8 *a = nullptr;
+    RC(arena_alloc(c, (size_t)ns, &a));
+    u32 ts = 0;
+    {
+      PhaseScope ps(c, DC3HIP_PH_PACK, ns);
+      hipLaunchKernelGGL((k_pack_image12_pos<KM>), dim3(grid_for(c, ns)), dim3(kBlock), 0, c->stream, km, ns, stride, hm, a);
+      KCHECK();
+    }
+    RC(sample_ties(c, a, ns, 1u, &ts));
+    const double fs = (double)ts / (double)ns;
+    const double ratio = (double)(n - 1) / (double)(ns > 1 ? ns - 1 : 1);
+    const double pred = fs >= 1.0 ? 1.0 : 1.0 - pow(1.0 - fs, ratio);
+    c->stats.level_tie_pred[0] = pred;
+    arena_release(c, mk);
+    if (!(pred < kTextSortMaxPredicted)) return E_OK;
+  }
+  Rec12 *ha = nullptr, *hb = nullptr, *h = nullptr;
+  uint8_t *f = nullptr;
+  RC(arena_alloc(c, (size_t)n, &ha));
+  RC(arena_alloc(c, (size_t)n, &hb));
+  RC(arena_alloc(c, (size_t)n + 16, &f));
+  u32 *first_table = nullptr;
+  {
+    PhaseScope ps(c, DC3HIP_PH_PACK, n);
+    int nb = 0; Chunking ck;
+    radix_plan<Rec12>(c, (u32)n, hm.nbits, &nb, &ck);
+    RC(arena_alloc(c, (size_t)nb * ck.nchunks, &first_table));
+    RC(launch_pack12_all(c, km, (u32)n, hm, ha, nb, ck, first_table));
+  }
+  RC(radix_sort<Rec12>(c, ha, hb, (u32)n, 0, hm.nbits, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT12_DOWN,
+                       first_table));
+  bool refined = false, distinct = false;
+  RC((hybrid12_refine<KM>(c, km, kbits, h, (u32)n, f, &refined, 0, c->d_sa, &distinct)));
+  int state = 0;
+  const u32 m0 = (u32)((n + 2) / 3), m1 = m0 + (u32)(n / 3);
+  const u32 m02_1 = (m1 + 2) / 3 + m1 / 3;
+  u32 *spos = c->d_sa, *snf = c->d_sa + m02_1 + 16;                        // (as in try_text_order)
+  if (refined && distinct) {
+    state = 1;                             // the tie pass already wrote the suffix array
+  } else if (refined) {
+    MapText mp; mp.m0 = m0; mp.npre = 0; mp.ppos[0] = mp.ppos[1] = 0;
+    if (m1 % 3 == 1) mp.ppos[mp.npre++] = m1;
+    if (n % 3 == 1 && (m0 - 1) % 3 != 0) mp.ppos[mp.npre++] = m0 - 1;
+    AccHyb12 acc; acc.h = h; acc.f = f;
+    RC((finish_position_order<AccHyb12, MapText>(c, acc, mp, (u32)n, (u32)n, 0u, c->d_sa, nullptr, spos, snf, &state)));
+  }
+  arena_release(c, mk);
+  c->stats.text_sort_state = state == 1 ? 1 : state == 2 ? 2 : 3;
+  if (state == 1) {
+    *whole_text = true;
+    c->stats.level_n[0] = n; c->stats.level_K[0] = sigma; c->stats.levels = 1; c->stats.level_sorted[0] = 5;
+  } else if (state == 2) {
+    pre->spos = spos; pre->snf = snf;
+  }
+  return E_OK;
+}
+
 // the device-resident build proper: SA of c->d_text[0..n) into c->d_sa
 static int build_core(dc3hip_ctx *c) {
   const int64_t n = c->n;
@@ -1466,18 +1580,27 @@ static int build_core(dc3hip_ctx *c) {
         c->arena_bytes - c->arena_off >= (size_t)n * 22 + (64u << 20)) {
       // whole-text shortcut: if all w-symbol windows of a high-entropy text are distinct, sorting all positions by
       // them is the suffix array (the same test level 1 would make on its triples, without building level 1)
+      // 12-byte records (image beside the position) once positions take all 32 bits; DC3HIP_TEXT_ORDER12=1/0 forces
+      // / forbids them (tests).  Image width: log2 n + 4.2 bits, rounded up to whole 9-bit digits.
+      const bool wide = c->text_order12 >= 0 ? c->text_order12 == 1 : bits_of((u64)n - 1) >= 32;
+      const u32 ibits = std::min<u32>(63, 9 * (u32)ceil((log2((double)n) + 4.2) / 9.0));
       if (9.0 * sym_bits >= need_bits && B3 * B3 * B3 > 0x7fffffffull) {
         Key9 km; km.S = S; km.B = (u32)Bq; km.B3 = (u32)B3;
         u32 kbits = 0;
         { unsigned __int128 mx = (unsigned __int128)B3 * B3 * B3 - 1; while (mx) { kbits++; mx >>= 1; } }
-        RC(try_text_order<Key9>(c, km, B3, make_himap(B3, kbits, (u32)n, bits_of((u64)n - 1)), sigma, &whole_text, &pre));
+        if (wide)
+          RC(try_text_order12<Key9>(c, km, B3, make_himap(B3, kbits, (u32)n, 64 - ibits), sigma, &whole_text, &pre));
+        else
+          RC(try_text_order<Key9>(c, km, B3, make_himap(B3, kbits, (u32)n, bits_of((u64)n - 1)), sigma, &whole_text, &pre));
       } else if (!c->no_long_keys) {
         // small alphabets: limbs of L > 3 symbols (as many as fit 32 bits), 3L-symbol windows
         u32 L = 1; u64 BL = Bq;
         while (L < 20 && BL * Bq <= 0xffffffffull) { BL *= Bq; L++; }
         KeyT km; HiMap hm;
-        if (L > 3 && 3.0 * L * sym_bits >= need_bits && make_keyt(S, sigma, L, BL, (u32)n, &km, &hm))
-          RC(try_text_order<KeyT>(c, km, BL, hm, sigma, &whole_text, &pre));
+        if (L > 3 && 3.0 * L * sym_bits >= need_bits && make_keyt(S, sigma, L, BL, (u32)n, &km, &hm, wide ? ibits : 0u)) {
+          if (wide) RC(try_text_order12<KeyT>(c, km, BL, hm, sigma, &whole_text, &pre));
+          else RC(try_text_order<KeyT>(c, km, BL, hm, sigma, &whole_text, &pre));
+        }
       }
     }
     if (!whole_text) {
@@ -1545,6 +1668,7 @@ int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) {
   { const char *e = getenv("DC3HIP_NO_SPLIT_EMIT"); c->no_split_emit = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_TRACE"); c->trace = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_LONG_KEYS"); c->no_long_keys = (e && e[0] == '1'); }
+  { const char *e = getenv("DC3HIP_TEXT_ORDER12"); if (e && (e[0] == '0' || e[0] == '1')) c->text_order12 = e[0] - '0'; }
   { const char *e = getenv("DC3HIP_NO_TUP8"); c->no_tup8 = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_HYBRID12"); c->no_hybrid12 = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_HYBRID8"); c->no_hybrid8 = (e && e[0] == '1'); }

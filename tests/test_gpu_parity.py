@@ -392,7 +392,7 @@ def test_hybrid_and_straight_paths_agree(ss, oracle):
         want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)
         seen = {}
         for env in ({}, {"DC3HIP_NO_HYBRID": "1"}, {"DC3HIP_NO_SMALL_TIES": "1"}, {"DC3HIP_NO_FULLSORT": "1"},
-                    {"DC3HIP_NO_TEXT_SHORTCUT": "1"}, {"DC3HIP_NO_SPLIT_EMIT": "1"},
+                    {"DC3HIP_NO_TEXT_SHORTCUT": "1"}, {"DC3HIP_NO_SPLIT_EMIT": "1"}, {"DC3HIP_TEXT_ORDER12": "1"},
                     {"DC3HIP_NO_TEXT_SHORTCUT": "1", "DC3HIP_NO_TUP8": "1"},
                     {"DC3HIP_NO_TEXT_SHORTCUT": "1", "DC3HIP_NO_HYBRID8": "1", "DC3HIP_HYBRID12_MIN": "0"},   # 12-byte prefix sort
                     {"DC3HIP_NO_HYBRID12": "1"},
@@ -448,11 +448,16 @@ def test_whole_text_order_reused_by_level1(ss, oracle):
             d[n - 300:] = d[5000:5300]                    # and a repeat that runs into the end of the text
         data = d.tobytes()
         want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)
-        with ss.Context(n) as c:
-            c.set_text(data); c.build()
-            st = c.stats()
-            assert np.array_equal(c.sa(), want), n
-            assert st["text_sort_state"] == 2 and st["level_sorted"][0] == 0 and st["level_sorted"][1] in (2, 4), st
+        for wide in ("0", "1"):                           # 8-byte records, and the 12-byte ones of texts beyond 2^31
+            os.environ["DC3HIP_TEXT_ORDER12"] = wide
+            try:
+                with ss.Context(n) as c:
+                    c.set_text(data); c.build()
+                    st = c.stats()
+                    assert np.array_equal(c.sa(), want), (n, wide)
+                    assert st["text_sort_state"] == 2 and st["level_sorted"][0] == 0 and st["level_sorted"][1] in (2, 4), st
+            finally:
+                os.environ.pop("DC3HIP_TEXT_ORDER12", None)
         m0 = (n + 2) // 3; m1 = m0 + n // 3
         combos.add((n % 3, m1 % 3))
     assert len(combos) == 9
@@ -484,7 +489,8 @@ def test_small_alphabet_long_windows(ss, oracle):
         data = arr.tobytes()
         want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)
         seen = {}
-        for env in ({}, {"DC3HIP_NO_LONG_KEYS": "1"}, {"DC3HIP_NO_SPLIT_EMIT": "1"}, {"DC3HIP_NO_SMALL_TIES": "1"}):
+        for env in ({}, {"DC3HIP_NO_LONG_KEYS": "1"}, {"DC3HIP_NO_SPLIT_EMIT": "1"}, {"DC3HIP_NO_SMALL_TIES": "1"},
+                    {"DC3HIP_TEXT_ORDER12": "1"}, {"DC3HIP_TEXT_ORDER12": "1", "DC3HIP_NO_SMALL_TIES": "1"}):
             os.environ.update(env)
             try:
                 with ss.Context(len(data)) as c:
@@ -498,6 +504,8 @@ def test_small_alphabet_long_windows(ss, oracle):
         if label.startswith("random") or label == "alphabet_with_zero_byte":
             assert seen[()]["text_sort_state"] == 1 and seen[()]["levels"] == 1, (label, seen[()]["text_sort_state"])
             assert seen[("DC3HIP_NO_LONG_KEYS",)]["levels"] >= 3, label
+        w12 = seen[("DC3HIP_TEXT_ORDER12",)]                 # the same shortcut on 12-byte records (default beyond 2^31)
+        assert w12["text_sort_state"] == seen[()]["text_sort_state"] and w12["downsweep_launches"][1] > 0, (label, w12["text_sort_state"])
         if label in ("dna_repeat_3000", "dna_repeat_into_end"):
             assert seen[()]["text_sort_state"] == 2 and seen[()]["level_sorted"][1] in (2, 4), (label, seen[()]["level_sorted"])
 
