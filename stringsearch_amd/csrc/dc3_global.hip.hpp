@@ -98,6 +98,18 @@ struct SelPosImage {
     return img >= lo && (last || img < hi);
   }
 };
+// the same on 12-byte records (image of hm.nbits <= 63 bits beside a full 32-bit position): texts beyond 2^31 positions
+template <class KM>
+struct SelPosImage12 {
+  typedef Rec12 Out;
+  KM km; HiMap hm; u64 lo, hi; u32 last;
+  __device__ __forceinline__ void stage(uint16_t *lds) const { km.stage(lds); }
+  __device__ __forceinline__ bool pick(u32 p, const uint16_t *lds, Rec12 &o) const {
+    const u64 img = km.image_hi(p, lds, hm);
+    o = Rec12{(u32)img, (u32)(img >> 32), p};
+    return img >= lo && (last || img < hi);
+  }
+};
 // prefix-sort naming: item q = q-th sample position; record = (image << pbits) | pos; kept by image range
 template <class Sym>
 struct SelSampleImage {

@@ -553,6 +553,49 @@ static int gorder_positions(dc3hip_gctx *G, KM km, u32 m, u32 kbits, const HiMap
   return E_OK;
 }
 
+// The whole-text order on 12-byte records (try_text_order12's distributed form; top level only): hm maps KM's image to
+// hm.nbits <= 63 bits, sorted in full; the tie pass writes the slice.
+template <class KM>
+static int gorder_positions12(dc3hip_gctx *G, KM km, u32 m, u32 kbits, const HiMap &hm, bool *done) {
+  dc3hip_ctx *c = G->c; GComm *cm = G->comm;
+  const int P = cm->nranks, me = cm->rank;
+  *done = false;
+  const ArenaMark mk = arena_mark(c);
+  u32 *slice = c->d_sa;
+  u64 lo = 0, hi = ~0ull;
+  {
+    u32 ns = (u32)std::min<u64>(m, (u64)2048 * P);
+    const u32 stride = std::max<u32>(1, m / ns);
+    ns = (m - 1) / stride + 1;
+    Rec8 *smp = nullptr;
+    RC(arena_alloc(c, (size_t)ns, &smp));
+    hipLaunchKernelGGL((k_pack_image12_pos<KM>), dim3(grid_for(c, ns)), dim3(kBlock), 0, c->stream, km, ns, stride, hm, smp);
+    KCHECK();
+    RC(image_splitters(c, smp, ns, 1u, P, me, &lo, &hi));
+  }
+  SelPosImage12<KM> sel; sel.km = km; sel.hm = hm; sel.lo = lo; sel.hi = hi; sel.last = (me + 1 == P) ? 1u : 0u;
+  Rec12 *ha = nullptr, *hb = nullptr, *h = nullptr; uint8_t *f = nullptr;
+  u32 nrec = 0;
+  RC(select_records(c, sel, m, &ha, &nrec, DC3HIP_PH_PACK));
+  RC(arena_alloc(c, (size_t)nrec + 16, &hb));
+  RC(arena_alloc(c, (size_t)nrec + 16, &f));
+  bool ok = true, distinct = true;
+  if (nrec) {
+    RC(radix_sort<Rec12>(c, ha, hb, nrec, 0, hm.nbits, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT12_DOWN));
+    RC((hybrid12_refine<KM>(c, km, kbits, h, nrec, f, &ok, 0, slice, &distinct)));
+  }
+  uint64_t good = 0, ngood = 0, pre = 0, tot = 0, all[kMaxRanks];
+  RC(gather_counts(cm, (ok && distinct) ? 1 : 0, &good, &ngood));
+  RC(gather_counts(cm, nrec, &pre, &tot, all));
+  if (tot != m) { set_err("global order: %llu of %u positions selected", (unsigned long long)tot, m); return E_HIP; }
+  arena_release(c, mk);
+  if (ngood == (uint64_t)P) {
+    *done = true;
+    RC(deliver(G, slice, nrec, pre, all, m, nullptr, G_TOP));
+  }
+  return E_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // one level (lib.rs:44-193) on replicated S; the result goes where `mode` says (GOut).
 // ---------------------------------------------------------------------------------------------
@@ -949,16 +992,34 @@ static int glevel(dc3hip_gctx *G, Sym S, u32 m, u64 K, int depth, u32 *out, GOut
 // level 0 shortcut: the whole-text order by 9-symbol (Key9) or, on small alphabets, 3L-symbol windows (KeyT), split by
 // key range (conditions as in build_core; no reuse of the order when windows repeat: the recursion decides then)
 template <class KM>
-static int gtext_order_with(dc3hip_gctx *G, KM km, u64 BL, const HiMap &hm, u32 sigma, bool *done) {
+static int gtext_order_with(dc3hip_gctx *G, KM km, u64 BL, const HiMap &hm, u32 sigma, bool wide, bool *done) {
   dc3hip_ctx *c = G->c;
   const u32 n = (u32)G->total_n;
   u32 kbits = 0;
   { unsigned __int128 mx = (unsigned __int128)BL * BL * BL - 1; while (mx) { kbits++; mx >>= 1; } }
   double pred = 1.0;
-  RC(predict_tie_fraction_pos<KM>(c, km, n, hm, &pred));
-  c->stats.level_tie_pred[0] = pred;
-  if (!text_order_worth_trying(pred, (u64)n, hm.nbits)) return E_OK;
-  RC((gorder_positions<KM>(G, km, n, kbits, hm, 0, nullptr, G_TOP, done)));
+  if (wide) {                               // hm: image of hm.nbits bits for 12-byte records (see try_text_order12)
+    const ArenaMark mk = arena_mark(c);
+    const u32 stride = std::max<u32>(1, n >> 20);
+    const u32 ns = (n - 1) / stride + 1;
+    Rec8 *a = nullptr;
+    RC(arena_alloc(c, (size_t)ns, &a));
+    hipLaunchKernelGGL((k_pack_image12_pos<KM>), dim3(grid_for(c, ns)), dim3(kBlock), 0, c->stream, km, ns, stride, hm, a);
+    KCHECK();
+    u32 ts = 0;
+    RC(sample_ties(c, a, ns, 1u, &ts));
+    const double fs = (double)ts / (double)ns;
+    pred = fs >= 1.0 ? 1.0 : 1.0 - pow(1.0 - fs, (double)(n - 1) / (double)(ns > 1 ? ns - 1 : 1));
+    arena_release(c, mk);
+    c->stats.level_tie_pred[0] = pred;
+    if (!(pred < kTextSortMaxPredicted)) return E_OK;
+    RC((gorder_positions12<KM>(G, km, n, kbits, hm, done)));
+  } else {
+    RC(predict_tie_fraction_pos<KM>(c, km, n, hm, &pred));
+    c->stats.level_tie_pred[0] = pred;
+    if (!text_order_worth_trying(pred, (u64)n, hm.nbits)) return E_OK;
+    RC((gorder_positions<KM>(G, km, n, kbits, hm, 0, nullptr, G_TOP, done)));
+  }
   if (*done) {
     c->stats.text_sort_state = 1;
     c->stats.level_n[0] = n; c->stats.level_K[0] = sigma; c->stats.levels = 1; c->stats.level_sorted[0] = 5;
@@ -974,18 +1035,20 @@ static int gtext_order(dc3hip_gctx *G, SymU8 S, u32 sigma, bool *done) {
   const u64 Bq = (u64)sigma + 1, B3 = Bq * Bq * Bq;
   const double need_bits = 2.0 * log2((double)n) + 2.0, sym_bits = log2((double)sigma);
   if (!(n >= kHybridMinSamples / 4 && !c->no_hybrid && !c->no_fullsort && !c->no_text_shortcut && !G->no_text_order)) return E_OK;
+  const bool wide = c->text_order12 >= 0 ? c->text_order12 == 1 : bits_of((u64)n - 1) >= 32;
+  const u32 ibits = std::min<u32>(63, 9 * (u32)ceil((log2((double)n) + 4.2) / 9.0));
   if (9.0 * sym_bits >= need_bits && B3 * B3 * B3 > 0x7fffffffull) {
     u32 kbits = 0;
     { unsigned __int128 mx = (unsigned __int128)B3 * B3 * B3 - 1; while (mx) { kbits++; mx >>= 1; } }
     Key9 km; km.S = S; km.B = (u32)Bq; km.B3 = (u32)B3;
-    return gtext_order_with<Key9>(G, km, B3, make_himap(B3, kbits, n, bits_of((u64)n - 1)), sigma, done);
+    return gtext_order_with<Key9>(G, km, B3, make_himap(B3, kbits, n, wide ? 64 - ibits : bits_of((u64)n - 1)), sigma, wide, done);
   }
   if (!c->no_long_keys) {
     u32 L = 1; u64 BL = Bq;
     while (L < 20 && BL * Bq <= 0xffffffffull) { BL *= Bq; L++; }
     KeyT km; HiMap hm;
-    if (L > 3 && 3.0 * L * sym_bits >= need_bits && make_keyt(S, sigma, L, BL, n, &km, &hm))
-      return gtext_order_with<KeyT>(G, km, BL, hm, sigma, done);
+    if (L > 3 && 3.0 * L * sym_bits >= need_bits && make_keyt(S, sigma, L, BL, n, &km, &hm, wide ? ibits : 0u))
+      return gtext_order_with<KeyT>(G, km, BL, hm, sigma, wide, done);
   }
   return E_OK;
 }

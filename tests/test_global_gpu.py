@@ -111,6 +111,27 @@ def test_loopback_small_alphabet_whole_text_order(ss, oracle):
                     assert all(s["text_order"] == 0 and s["levels"] >= 2 for s in st), sigma
 
 
+@pytest.mark.parametrize("P", [2, 5])
+def test_loopback_whole_text_order_on_12_byte_records(ss, oracle, P):
+    """The distributed whole-text order on 12-byte records (the default beyond 2^31 positions, forced here by
+    DC3HIP_TEXT_ORDER12=1): random bytes (9-byte windows), DNA and a binary text (3L-symbol windows), and a text with a
+    repeated block, which no rank may finish (all ranks go on to the recursion)."""
+    rng = np.random.default_rng(43)
+    n = (1 << 22) + 11
+    with env(DC3HIP_TEXT_ORDER12=1), ss.LoopbackGroup(P, n) as g:
+        cases = {"bytes": rng.integers(0, 256, size=n, dtype=np.uint8), "dna": oracle.gen(n, 5, 1),
+                 "binary": rng.integers(0, 2, size=n, dtype=np.uint8)}
+        rep = cases["dna"].copy(); rep[n // 3:n // 3 + 5000] = rep[10:5010]
+        cases["dna_repeat"] = rep
+        for label, t in cases.items():
+            g.set_text(t)
+            g.build()
+            assert np.array_equal(g.sa(), want_sa(oracle, t)), (label, P)
+            st = g.stats()
+            assert all(s["text_order"] == (0 if label == "dna_repeat" else 1) for s in st), (label, [s["text_order"] for s in st])
+            assert all(s["ctx"]["downsweep_launches"][1] > 0 for s in st if s["shard_count"]), label      # 12-byte passes ran
+
+
 def test_loopback_generated_blocks_and_tiny_inputs(ss, oracle):
     """Ranks generate only their own block (offset-addressable generator); n in {0,1,2,3,...} and n < P."""
     with ss.LoopbackGroup(4, 100_000) as g:
