@@ -303,6 +303,24 @@ def main():
                                 "checksum_equal": c5.checksum() == chk3}
                     finally:
                         os.environ.pop("DC3HIP_NO_TEXT_SHORTCUT", None)
+        # the per-GPU chunk of BASELINE.json configs[4] (16 GiB DNA over 8 GPUs, sacapart chunks of 2 GiB + 1 byte, 64-bit
+        # indices at the boundary): beyond 2^31 positions, device-resident, GPU sufcheck
+        if per_gpu == 1 << 30 and not args.no_verify:
+            nc = (1 << 31) + 1
+            try:
+                with ss.Context(nc, device=local_rank) as c6:
+                    c6.generate(nc, 5, 1, offset=7 * nc)
+                    c6.build()
+                    ms = []
+                    for _ in range(2):
+                        c6.build(); ms.append(c6.stats()["build_ms"])
+                    st6 = c6.stats()
+                    m = sum(ms) / len(ms)
+                    per_cfg["dna_2GiB_plus_1_chunk_of_configs4"] = {
+                        "ms": m, "MB/s": nc / m / 1e3, "sufcheck": c6.sufcheck(), "levels": st6["levels"],
+                        "path": PATH_NAMES.get(st6.get("text_sort_state", 0), "?"), "index_type": "u32 on the device, widened to i64 on delivery"}
+            except ss.Dc3HipError as e:
+                per_cfg["dna_2GiB_plus_1_chunk_of_configs4"] = {"skipped": str(e)}
         out["per_config"] = per_cfg
         # The GLOBAL mode (one suffix array over P ranks) as P loopback ranks on THIS GPU: the ranks
         # time-share the device, so wall_ms is about the SUM of all ranks' work (work_inflation = wall / single-device

@@ -167,7 +167,8 @@ typedef struct dc3hip_stats {
                                              2 = names by prefix sort + tie refinement,
                                              3 / 4 = 1 / 2 followed by the discarding recursion,
                                              5 = whole level ordered at once (all its triples distinct; at level 0:
-                                                 all 9-byte windows of the text distinct) */
+                                                 all windows of the text distinct - 9 bytes, or 3L symbols of a small
+                                                 alphabet, L = symbols per 32-bit limb in base sigma+1) */
   int64_t level_kept[DC3HIP_MAX_LEVELS];  /* length of the reduced recursive string (discarding) */
   int32_t level_name_width[DC3HIP_MAX_LEVELS]; /* symbols packed per direct name (0 on sorted levels) */
   int64_t level_tied[DC3HIP_MAX_LEVELS];  /* samples re-sorted by the full key (prefix-sort path) */
@@ -186,7 +187,8 @@ typedef struct dc3hip_stats {
   double  gather_ms; int64_t gather_launches; int64_t gather_elems;
   int64_t arena_bytes;                    /* device work arena size */
   int64_t arena_peak;                     /* high-water mark of the last build */
-  /* whole-text shortcut (all n positions ordered by 9-byte keys before any recursion level is built):
+  /* whole-text shortcut (all n positions ordered by their 9-byte - small alphabets: 3L-symbol - windows before any
+   * recursion level is built; 8-byte records, 12-byte ones beyond 2^31 positions):
    * 0 = not tried, 1 = all keys distinct, that order is the SA (levels == 1, level_sorted[0] == 5),
    * 2 = duplicate keys, the order was filtered into level 1's sorted samples, 3 = abandoned (too many ties) */
   int32_t text_sort_state;
@@ -231,7 +233,7 @@ typedef struct dc3hip_gstats {
   int32_t struct_size;
   int32_t nranks, rank;
   int32_t levels;            /* recursion depth of the last build */
-  int32_t text_order;        /* 1 = finished by the distributed whole-text order (all 9-byte windows distinct) */
+  int32_t text_order;        /* 1 = finished by the distributed whole-text order (all 9-byte / 3L-symbol windows distinct) */
   int32_t local_from_level;  /* first level that every rank finished locally on its replicated copy (-1: none) */
   int64_t total_n, shard_first, shard_count;
   int64_t exchanges;         /* rank exchanges (all-to-all + all-gather) of the last build */

@@ -697,11 +697,21 @@ def test_sample_count_beyond_2pow31(ss):
     > 512 top buckets, 32-bit position fields completely used).  Regression test for a u32 midpoint overflow
     that only showed above 3.2e9 bytes."""
     n = 3_400_000_000
-    with ss.Context(n) as c:
+    with ss.Context(n) as c:                       # default: the whole-text order on 12-byte records, one level
         c.generate(n, 9, 0)
         c.build()
         assert c.sufcheck() == 0
-        assert c.stats()["level_n"][1] > (1 << 31)
+        assert c.stats()["levels"] == 1 and c.stats()["text_sort_state"] == 1
+        chk = c.checksum()
+    os.environ["DC3HIP_TEXT_ORDER12"] = "0"        # the recursion at this size (8-byte images tie too much here)
+    try:
+        with ss.Context(n) as c:
+            c.generate(n, 9, 0)
+            c.build()
+            assert c.sufcheck() == 0 and c.checksum() == chk
+            assert c.stats()["level_n"][1] > (1 << 31)
+    finally:
+        os.environ.pop("DC3HIP_TEXT_ORDER12", None)
 
 
 def test_boundary_sizes_sufcheck(ss):

@@ -1,5 +1,7 @@
 """GPU box: randomized soak — sizes 1 .. 8M, alphabets 1..256, random / periodic / block-copy / run-heavy structure,
-one-shot C ABI (dc3hip_sufsort_i32) against libdivsufsort (oracle/_ref).  Usage: gpu_soak.py SEED SECONDS"""
+one-shot C ABI (dc3hip_sufsort_i32) against libdivsufsort (oracle/_ref).  Usage: gpu_soak.py SEED SECONDS [big]
+("big": 70 % of the cases between 4M and 8M bytes, where the whole-text shortcut is eligible; combine with
+DC3HIP_TEXT_ORDER12=1 / DC3HIP_NO_LONG_KEYS=1 in the environment to soak those variants)."""
 import os, sys, time, ctypes, json
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,7 +17,8 @@ t_end = time.time() + budget
 cases = bad = 0; total = 0
 while time.time() < t_end:
     r = rng.random()
-    n = int(rng.integers(1, 5000)) if r < 0.3 else int(rng.integers(5000, 300_000)) if r < 0.7 else int(rng.integers(300_000, 8_000_000))
+    if len(sys.argv) > 3 and sys.argv[3] == "big": r = 0.3 + 0.7 * r if r < 0.3 else r; r = 1.0 if rng.random() < 0.6 else r
+    n = int(rng.integers(4_194_304, 8_000_000)) if r >= 1.0 else int(rng.integers(1, 5000)) if r < 0.3 else int(rng.integers(5000, 300_000)) if r < 0.7 else int(rng.integers(300_000, 8_000_000))
     sigma = int(rng.choice([1, 2, 3, 4, 5, 9, 10, 16, 26, 64, 255, 256]))
     d = rng.integers(0, sigma, size=n, dtype=np.uint16).astype(np.uint8)
     if sigma < 200 and rng.random() < 0.5:
