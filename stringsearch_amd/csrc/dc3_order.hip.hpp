@@ -1196,19 +1196,28 @@ __global__ __launch_bounds__(kBlock) void k_tie_resolve12(KM km, Rec12 *__restri
         const u32 len = e - i;
         if (len > kTieSmallMax) {
           words[0] = 1u;
+        } else if (len == 2) {
+          TieKey<KM> x, y;
+          x.load(km, h[i].pos, lcode); y.load(km, h[i + 1].pos, lcode);
+          const int c3 = TieKey<KM>::cmp3(km, lcode, y, x);
+          if (c3 < 0) { const TieKey<KM> t = x; x = y; y = t; h[i].pos = x.pos(); h[i + 1].pos = y.pos(); }
+          if (emit_sa) { emit_sa[i] = x.pos(); emit_sa[i + 1] = y.pos(); }
+          f[i + 1] = c3 != 0 ? 1 : 0;
+          dup += c3 != 0 ? 0u : 1u;
         } else {
-          Rec16 loc[kTieSmallMax];
+          TieKey<KM> loc[kTieSmallMax];
           for (u32 x = 0; x < len; x++) {
-            const Rec16 v = km.make(h[i + x].pos, lcode);
+            TieKey<KM> v;
+            v.load(km, h[i + x].pos, lcode);
             u32 y = x;
-            while (y > 0 && key_less(v, loc[y - 1])) { loc[y] = loc[y - 1]; y--; }
+            while (y > 0 && TieKey<KM>::cmp3(km, lcode, v, loc[y - 1]) < 0) { loc[y] = loc[y - 1]; y--; }
             loc[y] = v;
           }
           for (u32 x = 0; x < len; x++) {
-            h[i + x].pos = loc[x].pos;
-            if (emit_sa) emit_sa[i + x] = loc[x].pos;
+            h[i + x].pos = loc[x].pos();
+            if (emit_sa) emit_sa[i + x] = loc[x].pos();
             if (x > 0) {
-              const bool ne = key_neq(loc[x], loc[x - 1]);
+              const bool ne = TieKey<KM>::cmp3(km, lcode, loc[x], loc[x - 1]) != 0;
               f[i + x] = ne ? 1 : 0;
               dup += ne ? 0u : 1u;
             }
