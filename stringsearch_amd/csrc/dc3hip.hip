@@ -144,7 +144,10 @@ static size_t arena_requirement(int64_t n) {
 // side array, a flag byte per record, radix tables and the tie predictor.  A context starts with this much and grows
 // to arena_requirement() the first time a build enters the DC3 recursion (ensure_arena): high-entropy texts never
 // do, so their contexts hold half the memory and the first hipMalloc is half as long.
-static size_t arena_text_requirement(int64_t n) { return (size_t)n * 24 + ((size_t)128 << 20); }
+static size_t arena_text_requirement(int64_t n) {
+  // (beyond 2^31 positions the whole-text order runs on 12-byte records: 2 x 12 + 1 bytes per position + tables)
+  return n > ((int64_t)1 << 31) ? (size_t)n * 26 + ((size_t)256 << 20) : (size_t)n * 24 + ((size_t)128 << 20);
+}
 
 // Grow the (empty) arena to at least `need` bytes.  Never shrinks; a size forced by DC3HIP_ARENA_BYTES stays as it is.
 static int ensure_arena(dc3hip_ctx *c, size_t need) {
