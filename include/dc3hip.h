@@ -226,7 +226,13 @@ DC3HIP_API int32_t dc3hip_ctx_debug_radix_pass_u64(dc3hip_ctx *ctx, const uint64
  * return -3 ("another rank failed"), and the group can be used again.  RCCL / host-staged peers are inside a collective
  * at that point and keep waiting, as in any NCCL program: the host job's watchdog has to tear the group down.
  * Environment: DC3HIP_GLOBAL_LOCAL_MAX (levels up to this length are finished by every rank on its own replicated
- * copy, default 2^22), DC3HIP_GLOBAL_NO_TEXT_ORDER=1 (skip the distributed whole-text order). */
+ * copy, default 2^22), DC3HIP_GLOBAL_NO_TEXT_ORDER=1 (skip the distributed whole-text order).
+ * WIDE contexts (max_total_n > DC3HIP_MAX_N, up to 2^40; or DC3HIP_GLOBAL_FORCE_WIDE=1): positions are 64-bit, and only
+ * the distributed whole-text order exists at that size — the text is built if all its 64-symbol windows are distinct
+ * (high-entropy inputs: BASELINE.json configs[3] random bytes at 4 GiB, configs[4] random DNA at 16 GiB); a text with a
+ * repeated window is refused with -4 (no recursion with 64-bit positions), as is a rank whose share would exceed
+ * DC3HIP_MAX_N suffixes.  Shards are fetched with dc3hip_global_get_shard_i64 (…_u32 returns -4) and verified with the
+ * collective dc3hip_global_sufcheck. */
 typedef struct dc3hip_gctx dc3hip_gctx;
 
 typedef struct dc3hip_gstats {
@@ -285,6 +291,11 @@ DC3HIP_API int32_t dc3hip_global_get_shard_u32(dc3hip_gctx *g, uint32_t *out);
 /* sum over the shard of mix(global index, SA[index]); the sum over all ranks equals dc3hip_ctx_sa_checksum of a
  * single-device build of the same text */
 DC3HIP_API int32_t dc3hip_global_shard_checksum(dc3hip_gctx *g, uint64_t *out);
+/* WIDE contexts only; a COLLECTIVE like the build.  0 = the concatenated shards are the suffix array (every position in
+ * range, every entry's suffix strictly smaller than its successor's — across rank boundaries too —, sizes add up to n);
+ * -2 / -3 = position out of range / order violated (the codes of the reference's sufcheck, utils.c:160-241), identical
+ * on all ranks; <= -11 = the check could not run (dc3hip error code - 10). */
+DC3HIP_API int32_t dc3hip_global_sufcheck(dc3hip_gctx *g);
 DC3HIP_API int32_t dc3hip_global_stats(dc3hip_gctx *g, dc3hip_gstats *out, dc3hip_stats *ctx_stats /* may be NULL */);
 DC3HIP_API const char *dc3hip_global_last_error(dc3hip_gctx *g);   /* error of this rank's last build (loopback threads) */
 DC3HIP_API const char *dc3hip_global_transport(dc3hip_gctx *g);

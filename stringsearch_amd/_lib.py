@@ -137,6 +137,7 @@ SYMBOLS = {
     "dc3hip_global_get_shard_i64": (_i32, [_vp, _vp]),
     "dc3hip_global_get_shard_u32": (_i32, [_vp, _vp]),
     "dc3hip_global_shard_checksum": (_i32, [_vp, ctypes.POINTER(_u64)]),
+    "dc3hip_global_sufcheck": (_i32, [_vp]),
     "dc3hip_global_stats": (_i32, [_vp, ctypes.POINTER(GStats), ctypes.POINTER(Stats)]),
     "dc3hip_global_last_error": (ctypes.c_char_p, [_vp]),
     "dc3hip_global_transport": (ctypes.c_char_p, [_vp]),

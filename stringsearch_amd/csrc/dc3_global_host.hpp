@@ -287,6 +287,10 @@ struct dc3hip_gctx {
   u32 local_max = 1u << 22;                     // levels up to this length are finished on every rank redundantly
   bool no_text_order = false;
   bool force_dist = false;                      // run the distributed path even with one rank (transport tests)
+  // wide mode (texts beyond DC3HIP_MAX_N, or DC3HIP_GLOBAL_FORCE_WIDE=1): 64-bit positions, whole-text order only
+  bool wide = false;
+  uint8_t *w_text = nullptr;                    // max_total + 64 bytes (the context's own text buffer is not used)
+  Rec16 *w_ra = nullptr, *w_rb = nullptr; u64 *w_shard = nullptr; size_t w_cap = 0;   // records of this rank's image range
   dc3hip_gstats gs;
   char err[512] = "";
   std::vector<dc3hip_gctx *> group;             // loopback: all ranks of the group (rank 0 owns the list)
@@ -1053,10 +1057,152 @@ static int gtext_order(dc3hip_gctx *G, SymU8 S, u32 sigma, bool *done) {
   return E_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// wide mode: texts of 2^32 bytes and more (kernels and the scope in dc3_wide.hip.hpp)
+// ---------------------------------------------------------------------------------------------
+static uint8_t *gtext(dc3hip_gctx *G) { return G->wide ? G->w_text : G->c->d_text; }
+
+static int wide_key(dc3hip_gctx *G, u32 sigma, WideKey *k, u32 *ibits_out) {
+  const double n = (double)G->total_n;
+  if (sigma < 2) { set_err("wide global mode: a text over one symbol has no distinct windows"); return E_TOOBIG; }
+  const u32 ibits = std::min<u32>(63, 9 * (u32)ceil((log2(n) + 4.2) / 9.0));
+  u32 J = 1; u64 SJ = sigma;
+  while (J < kWideMaxImageSyms && (SJ >> std::min<u32>(ibits + 2, 62)) == 0 && SJ * sigma < (1ull << 63)) { SJ *= sigma; J++; }
+  if ((SJ >> ibits) == 0) { set_err("wide global mode: alphabet of %u symbols cannot fill a %u-bit image", sigma, ibits); return E_TOOBIG; }
+  k->t = G->w_text; k->code = G->c->d_code; k->n = (u64)G->total_n; k->sigma = sigma; k->J = J; k->W = 64;
+  k->mfix = (u64)(((((unsigned __int128)1) << (64 + ibits)) - 1) / SJ);
+  k->P1 = SJ / sigma;
+  *ibits_out = ibits;
+  return E_OK;
+}
+
+static int gbuild_wide(dc3hip_gctx *G) {
+  dc3hip_ctx *c = G->c; GComm *cm = G->comm;
+  const int P = cm->nranks, me = cm->rank;
+  const u64 n = (u64)G->total_n;
+  c->n = 0;
+  RC(build_begin(c));
+  {
+    size_t roff[kMaxRanks], rbytes[kMaxRanks];
+    for (int r = 0; r < P; r++) { int64_t o, l; block_of((int64_t)n, P, r, &o, &l); roff[r] = (size_t)o; rbytes[r] = (size_t)l; }
+    RC(cm->all_gather_v(G->w_text + roff[me], rbytes[me], G->w_text, roff, rbytes, c->stream));
+    HIPC(hipMemsetAsync(G->w_text + n, 0, 64, c->stream));
+  }
+  // alphabet (the presence kernel counts in 32 bits: pieces of 2^30 bytes)
+  HIPC(hipMemsetAsync(c->d_present, 0, 256 * sizeof(u32), c->stream));
+  for (u64 off = 0; off < n; off += (u64)1 << 30) {
+    const u32 len = (u32)std::min<u64>((u64)1 << 30, n - off);
+    hipLaunchKernelGGL(k_byte_presence, dim3(grid_for(c, (u64)len / 16 + 1)), dim3(kBlock), 0, c->stream, G->w_text + off, len, c->d_present);
+    KCHECK();
+  }
+  hipLaunchKernelGGL(k_make_codes, dim3(1), dim3(kBlock), 0, c->stream, c->d_present, c->d_code, c->d_words + 1);
+  KCHECK();
+  HIPC(hipMemcpyAsync(c->h_words + 1, c->d_words + 1, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  const u32 sigma = c->h_words[1];
+  WideKey k; u32 ibits = 0;
+  RC(wide_key(G, sigma, &k, &ibits));
+  if ((double)k.W * log2((double)sigma) < 2.0 * log2((double)n) + 2.0) {
+    set_err("wide global mode: %u-symbol windows over %u symbols cannot all be distinct in %llu bytes", k.W, sigma, (unsigned long long)n);
+    return E_TOOBIG;
+  }
+  const ArenaMark mk = arena_mark(c);
+  // splitters from a strided sample (every rank computes the same ones from the replicated text)
+  u64 lo = 0, hi = ~0ull;
+  {
+    const u32 ns = (u32)std::min<u64>(n, (u64)4096 * P);
+    const u64 stride = std::max<u64>(1, n / ns);
+    const u32 cnt = (u32)((n - 1) / stride + 1);
+    u64 *d_img = nullptr;
+    RC(arena_alloc(c, (size_t)cnt, &d_img));
+    hipLaunchKernelGGL(k_wide_sample, dim3(grid_for(c, cnt)), dim3(kBlock), 0, c->stream, k, stride, cnt, d_img);
+    KCHECK();
+    std::vector<u64> img(cnt);
+    HIPC(hipMemcpyAsync(img.data(), d_img, (size_t)cnt * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    std::sort(img.begin(), img.end());
+    if (me > 0) lo = img[(size_t)((u64)me * cnt / P)];
+    if (me + 1 < P) hi = img[(size_t)((u64)(me + 1) * cnt / P)];
+  }
+  // count, allocate, write
+  const u64 chunk = (u64)1 << 20;
+  const u64 nblocks64 = (n + chunk - 1) / chunk;
+  if (nblocks64 > 0x7fffffffull) { set_err("wide global mode: text too long"); return E_TOOBIG; }
+  const u32 nblocks = (u32)nblocks64;
+  u32 *counts = nullptr;
+  RC(arena_alloc(c, (size_t)nblocks + 16, &counts));
+  const u32 last = (me + 1 == P) ? 1u : 0u;
+  {
+    PhaseScope ps(c, DC3HIP_PH_PACK, n);
+    hipLaunchKernelGGL((k_wide_select<false>), dim3(nblocks), dim3(kBlock), 0, c->stream, k, chunk, lo, hi, last, counts,
+                       (const u32 *)nullptr, (Rec16 *)nullptr);
+    KCHECK();
+  }
+  // (the per-block counts are summed in 64 bits on the host: a rank's share must stay below 2^32 - 2^24 records)
+  std::vector<u32> hc(nblocks);
+  HIPC(hipMemcpyAsync(hc.data(), counts, (size_t)nblocks * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  u64 nrec64 = 0;
+  for (u32 b = 0; b < nblocks; b++) { const u32 v = hc[b]; hc[b] = (u32)nrec64; nrec64 += v; }
+  if (nrec64 > (u64)DC3HIP_MAX_N) { set_err("wide global mode: rank %d would hold %llu suffixes (more ranks needed)", me, (unsigned long long)nrec64); return E_TOOBIG; }
+  const u32 nrec = (u32)nrec64;
+  HIPC(hipMemcpyAsync(counts, hc.data(), (size_t)nblocks * 4, hipMemcpyHostToDevice, c->stream));
+  if ((size_t)nrec + 16 > G->w_cap) {
+    HIPC(hipStreamSynchronize(c->stream));
+    if (G->w_ra) (void)hipFree(G->w_ra);
+    if (G->w_rb) (void)hipFree(G->w_rb);
+    if (G->w_shard) (void)hipFree(G->w_shard);
+    G->w_ra = G->w_rb = nullptr; G->w_shard = nullptr; G->w_cap = 0;
+    const size_t cap = (size_t)nrec + (size_t)nrec / 16 + 1024;
+    if (hipMalloc(&G->w_ra, cap * sizeof(Rec16)) != hipSuccess || hipMalloc(&G->w_rb, cap * sizeof(Rec16)) != hipSuccess ||
+        hipMalloc(&G->w_shard, cap * sizeof(u64)) != hipSuccess) {
+      (void)hipGetLastError();
+      set_err("wide global mode: no device memory for %llu records of 40 bytes", (unsigned long long)cap); return E_ALLOC;
+    }
+    G->w_cap = cap;
+  }
+  {
+    PhaseScope ps(c, DC3HIP_PH_PACK, n);
+    hipLaunchKernelGGL((k_wide_select<true>), dim3(nblocks), dim3(kBlock), 0, c->stream, k, chunk, lo, hi, last, (u32 *)nullptr,
+                       (const u32 *)counts, G->w_ra);
+    KCHECK();
+  }
+  Rec16 *h = G->w_ra;
+  if (nrec) RC(radix_sort<Rec16>(c, G->w_ra, G->w_rb, nrec, 0, ibits, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT12_DOWN));
+  HIPC(hipMemsetAsync(c->d_words + 10, 0, 3 * sizeof(u32), c->stream));
+  if (nrec) {
+    PhaseScope ps(c, DC3HIP_PH_TIES, nrec);
+    hipLaunchKernelGGL(k_wide_ties, dim3(grid_for(c, nrec)), dim3(kBlock), 0, c->stream, (const Rec16 *)h, nrec, k, G->w_shard, c->d_words + 10);
+    KCHECK();
+  }
+  HIPC(hipMemcpyAsync(c->h_words + 10, c->d_words + 10, 3 * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  arena_release(c, mk);
+  c->stats.level_tied[0] = c->h_words[11];
+  const bool mine_ok = c->h_words[10] == 0 && c->h_words[12] == 0;
+  uint64_t good = 0, ngood = 0, pre = 0, tot = 0;
+  RC(gather_counts(cm, mine_ok ? 1 : 0, &good, &ngood));
+  RC(gather_counts(cm, nrec, &pre, &tot));
+  if (tot != n) { set_err("wide global order: %llu of %llu positions selected", (unsigned long long)tot, (unsigned long long)n); return E_HIP; }
+  if (ngood != (uint64_t)P) {
+    set_err("wide global mode: some %u-symbol window of the text repeats; texts of 2^32 bytes and more are only built when all windows "
+            "are distinct (no recursion with 64-bit positions) [rank %d: %u records, %u tied, %u equal windows, oversized group %u]",
+            k.W, me, nrec, c->h_words[11], c->h_words[12], c->h_words[10]);
+    return E_TOOBIG;
+  }
+  G->shard_first = (int64_t)pre; G->shard_count = (int64_t)nrec; G->shard_ptr = nullptr;
+  c->stats.text_sort_state = 1;
+  c->stats.level_n[0] = (int64_t)n; c->stats.level_K[0] = sigma; c->stats.levels = 1; c->stats.level_sorted[0] = 5;
+  G->gs.local_from_level = -1;
+  RC(build_end(c));
+  return E_OK;
+}
+
 static int gbuild_inner(dc3hip_gctx *G) {
   dc3hip_ctx *c = G->c; GComm *cm = G->comm;
   const int P = cm->nranks, me = cm->rank;
   const int64_t n = G->total_n;
+  if (G->wide) return gbuild_wide(G);
   c->n = n;
   c->arena_off = 0;
   RC(ensure_arena(c, arena_requirement(n)));      // a rank may end up with a whole level's key range: the full budget
@@ -1114,6 +1260,20 @@ static void gctx_env(dc3hip_gctx *G) {
   if (const char *e = getenv("DC3HIP_GLOBAL_FORCE_DIST")) G->force_dist = e[0] == '1';
 }
 
+// the rank's device context: a full one (text, SA, arena for max_total_n) — or, in wide mode, a minimal one (stream,
+// scratch words, a small arena for the sort's tables) next to the wide text buffer
+static int gctx_make_ctx(dc3hip_gctx *G, int device, int64_t max_total_n) {
+  bool force_wide = false;
+  if (const char *e = getenv("DC3HIP_GLOBAL_FORCE_WIDE")) force_wide = e[0] == '1';
+  G->wide = force_wide || max_total_n > DC3HIP_MAX_N;
+  if (!G->wide) return dc3hip_ctx_create(&G->c, device, max_total_n);
+  if (max_total_n > ((int64_t)1 << 40)) { set_err("n=%lld exceeds 2^40", (long long)max_total_n); return E_TOOBIG; }
+  RC(dc3hip_ctx_create(&G->c, device, 0));
+  HIPC(hipSetDevice(G->c->device));
+  HIPC(hipMalloc(&G->w_text, (size_t)max_total_n + 64));
+  return E_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // C ABI of the global mode
 // ---------------------------------------------------------------------------------------------
@@ -1139,7 +1299,7 @@ int32_t dc3hip_global_loopback_create(dc3hip_gctx **ranks, int32_t P, int32_t de
     dc3hip_gctx *G = new (std::nothrow) dc3hip_gctx();
     if (!G) { set_err("host allocation failed"); for (auto *g : made) dc3hip_global_destroy(g); return E_ALLOC; }
     made.push_back(G);
-    const int rc = dc3hip_ctx_create(&G->c, device == DC3HIP_DEVICE_SPREAD ? r % ndev : device, max_total_n);
+    const int rc = gctx_make_ctx(G, device == DC3HIP_DEVICE_SPREAD ? r % ndev : device, max_total_n);
     if (rc != E_OK) { for (auto *g : made) dc3hip_global_destroy(g); return rc; }
     LoopComm *lc = new LoopComm(); lc->rank = r; lc->nranks = P; lc->w = world;
     G->comm = lc; G->max_total = max_total_n;
@@ -1169,7 +1329,7 @@ int32_t dc3hip_global_rccl_create(dc3hip_gctx **out, const uint8_t *id128, int32
   { std::lock_guard<std::mutex> lk(g_rccl_mu); if (!g_rccl.load()) return E_HIP; }
   dc3hip_gctx *G = new (std::nothrow) dc3hip_gctx();
   if (!G) { set_err("host allocation failed"); return E_ALLOC; }
-  int rc = dc3hip_ctx_create(&G->c, device, max_total_n);
+  int rc = gctx_make_ctx(G, device, max_total_n);
   if (rc != E_OK) { dc3hip_global_destroy(G); return rc; }
   RcclComm *rcm = new RcclComm(); rcm->rank = rank; rcm->nranks = nranks;
   G->comm = rcm; G->max_total = max_total_n;
@@ -1195,7 +1355,7 @@ int32_t dc3hip_global_host_create(dc3hip_gctx **out, const dc3hip_host_transport
   *out = nullptr;
   dc3hip_gctx *G = new (std::nothrow) dc3hip_gctx();
   if (!G) { set_err("host allocation failed"); return E_ALLOC; }
-  const int rc = dc3hip_ctx_create(&G->c, device, max_total_n);
+  const int rc = gctx_make_ctx(G, device, max_total_n);
   if (rc != E_OK) { dc3hip_global_destroy(G); return rc; }
   HostComm *hc = new HostComm(); hc->rank = rank; hc->nranks = nranks; hc->t = *t;
   G->comm = hc; G->max_total = max_total_n;
@@ -1208,6 +1368,10 @@ void dc3hip_global_destroy(dc3hip_gctx *G) {
   if (!G) return;
   if (G->c) { (void)hipSetDevice(G->c->device); if (G->c->stream) (void)hipStreamSynchronize(G->c->stream); }
   delete G->comm;
+  if (G->w_text) (void)hipFree(G->w_text);
+  if (G->w_ra) (void)hipFree(G->w_ra);
+  if (G->w_rb) (void)hipFree(G->w_rb);
+  if (G->w_shard) (void)hipFree(G->w_shard);
   if (G->c) dc3hip_ctx_destroy(G->c);
   delete G;
 }
@@ -1232,7 +1396,7 @@ int32_t dc3hip_global_set_text_block(dc3hip_gctx *G, const uint8_t *block, int64
   if (!block && len > 0) { set_err("block is NULL"); return E_ARGS; }
   dc3hip_ctx *c = G->c;
   HIPC(hipSetDevice(c->device));
-  if (len > 0) HIPC(hipMemcpyAsync(c->d_text + off, block, (size_t)len, hipMemcpyDefault, c->stream));
+  if (len > 0) HIPC(hipMemcpyAsync(gtext(G) + off, block, (size_t)len, hipMemcpyDefault, c->stream));
   HIPC(hipStreamSynchronize(c->stream));
   G->text_set = true;
   return E_OK;
@@ -1246,7 +1410,7 @@ int32_t dc3hip_global_generate(dc3hip_gctx *G, int64_t total_n, uint64_t seed, i
   HIPC(hipSetDevice(c->device));
   if (len > 0) {
     // only this rank's block: the others arrive by the all-gather of the build
-    hipLaunchKernelGGL(k_generate, dim3(grid_for(c, (u64)len / 8 + 1)), dim3(kBlock), 0, c->stream, c->d_text + off, (u64)len,
+    hipLaunchKernelGGL(k_generate, dim3(grid_for(c, (u64)len / 8 + 1)), dim3(kBlock), 0, c->stream, gtext(G) + off, (u64)len,
                        (u64)seed, (int)kind, (u64)off);
     KCHECK();
   }
@@ -1285,6 +1449,11 @@ int32_t dc3hip_global_get_shard_i64(dc3hip_gctx *G, int64_t *out) {
   dc3hip_ctx *c = G->c;
   HIPC(hipSetDevice(c->device));
   if (G->shard_count == 0) return E_OK;
+  if (G->wide) {
+    HIPC(hipMemcpyAsync(out, G->w_shard, (size_t)G->shard_count * 8, hipMemcpyDefault, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    return E_OK;
+  }
   c->arena_off = 0;
   const size_t piece = std::min<size_t>((size_t)G->shard_count, std::max<size_t>(c->arena_bytes / 8, 1));
   int64_t *tmp = reinterpret_cast<int64_t *>(c->arena);
@@ -1302,6 +1471,7 @@ int32_t dc3hip_global_get_shard_u32(dc3hip_gctx *G, uint32_t *out) {
   if (!G || (!out && G->shard_count > 0)) { set_err("invalid arguments"); return E_ARGS; }
   if (!G->built) { set_err("no suffix array built in this global context"); return E_ARGS; }
   dc3hip_ctx *c = G->c;
+  if (G->wide) { set_err("this global context holds 64-bit positions: use dc3hip_global_get_shard_i64"); return E_TOOBIG; }
   HIPC(hipSetDevice(c->device));
   if (G->shard_count > 0) HIPC(hipMemcpyAsync(out, G->shard_ptr, (size_t)G->shard_count * 4, hipMemcpyDefault, c->stream));
   HIPC(hipStreamSynchronize(c->stream));
@@ -1317,7 +1487,11 @@ int32_t dc3hip_global_shard_checksum(dc3hip_gctx *G, uint64_t *out) {
   HIPC(hipSetDevice(c->device));
   u64 *acc = reinterpret_cast<u64 *>(c->d_words + 16);
   HIPC(hipMemsetAsync(acc, 0, sizeof(u64), c->stream));
-  if (G->shard_count > 0) {
+  if (G->shard_count > 0 && G->wide) {       // (its own mixing: there is no single-device array to compare with)
+    hipLaunchKernelGGL(k_wide_checksum, dim3(grid_for(c, G->shard_count)), dim3(kBlock), 0, c->stream, (const u64 *)G->w_shard,
+                       (u32)G->shard_count, (u64)G->shard_first, acc);
+    KCHECK();
+  } else if (G->shard_count > 0) {
     hipLaunchKernelGGL(k_checksum_off, dim3(grid_for(c, G->shard_count)), dim3(kBlock), 0, c->stream, G->shard_ptr,
                        (u32)G->shard_count, (u64)G->shard_first, acc);
     KCHECK();
@@ -1334,6 +1508,56 @@ int32_t dc3hip_global_stats(dc3hip_gctx *G, dc3hip_gstats *out, dc3hip_stats *ct
   out->struct_size = (int32_t)sizeof(dc3hip_gstats);
   if (ctx_stats) { *ctx_stats = G->c->stats; ctx_stats->struct_size = (int32_t)sizeof(dc3hip_stats); }
   return E_OK;
+}
+
+// Collective check of a wide-mode result (every rank calls it): positions in range, every shard entry's suffix strictly
+// smaller than its successor's — across the rank boundaries too — and the shard sizes add up to n.  Returns 0 when the
+// concatenated shards are the suffix array, else the reference sufcheck's codes (-2 range, -3 order), the same on all
+// ranks; < -10 = the check itself failed (dc3hip error code - 10).
+int32_t dc3hip_global_sufcheck(dc3hip_gctx *G) {
+  if (!G || !G->comm) { set_err("invalid arguments"); return E_ARGS - 10; }
+  if (!G->built) { set_err("no suffix array built in this global context"); return E_ARGS - 10; }
+  if (!G->wide) { set_err("dc3hip_global_sufcheck: only for contexts with 64-bit positions (fetch the shards and use dc3hip_ctx_sufcheck)"); return E_ARGS - 10; }
+  dc3hip_ctx *c = G->c; GComm *cm = G->comm;
+  const int P = cm->nranks, me = cm->rank;
+  int verdict = 0;
+  auto run = [&]() -> int {
+    HIPC(hipSetDevice(c->device));
+    // first entries of all shards (a rank with an empty shard passes ~0 and is skipped)
+    u64 first_mine = ~0ull, firsts[kMaxRanks], counts[kMaxRanks];
+    if (G->shard_count > 0) {
+      HIPC(hipMemcpyAsync(&first_mine, G->w_shard, 8, hipMemcpyDeviceToHost, c->stream));
+      HIPC(hipStreamSynchronize(c->stream));
+    }
+    RC(cm->all_gather_host(&first_mine, firsts, 8));
+    const u64 cnt_mine = (u64)G->shard_count;
+    RC(cm->all_gather_host(&cnt_mine, counts, 8));
+    u64 tot = 0, next_first = ~0ull;
+    for (int r = 0; r < P; r++) tot += counts[r];
+    for (int r = me + 1; r < P; r++) if (counts[r]) { next_first = firsts[r]; break; }
+    u32 sigma = 0;
+    { HIPC(hipMemcpyAsync(c->h_words + 1, c->d_words + 1, sizeof(u32), hipMemcpyDeviceToHost, c->stream)); HIPC(hipStreamSynchronize(c->stream)); sigma = c->h_words[1]; }
+    WideKey k; u32 ibits = 0;
+    RC(wide_key(G, sigma, &k, &ibits));
+    HIPC(hipMemsetAsync(c->d_words + 20, 0, sizeof(u32), c->stream));
+    if (G->shard_count > 0) {
+      hipLaunchKernelGGL(k_wide_check, dim3(grid_for(c, G->shard_count)), dim3(kBlock), 0, c->stream, (const u64 *)G->w_shard,
+                         (u32)G->shard_count, next_first, k, 4096u, c->d_words + 20);
+      KCHECK();
+    }
+    HIPC(hipMemcpyAsync(c->h_words + 20, c->d_words + 20, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    u64 err = c->h_words[20], errs[kMaxRanks];
+    if (tot != (u64)G->total_n) err = std::max<u64>(err, 2);
+    RC(cm->all_gather_host(&err, errs, 8));
+    u64 worst = 0;
+    for (int r = 0; r < P; r++) worst = std::max(worst, errs[r]);
+    verdict = worst == 0 ? 0 : -(int)worst;
+    return E_OK;
+  };
+  const int rc = run();
+  if (rc != E_OK) { snprintf(G->err, sizeof(G->err), "%s", g_err); cm->abort_all(); return rc - 10; }
+  return verdict;
 }
 
 const char *dc3hip_global_last_error(dc3hip_gctx *G) { return G ? G->err : ""; }

@@ -16,3 +16,4 @@
 #include "dc3_merge.hip.hpp"
 #include "dc3_aux.hip.hpp"
 #include "dc3_global.hip.hpp"
+#include "dc3_wide.hip.hpp"

@@ -1,0 +1,214 @@
+// dc3hip — texts of 2^32 bytes and more in the global mode: positions no longer fit the 32-bit fields every record of
+// the recursion uses, so only the distributed WHOLE-TEXT ORDER exists at that size: every rank orders
+// the positions whose window image falls into its range — 16-byte records {image (<= 63 bits), position (40 bits)} —
+// and the text's windows must all be distinct (high-entropy inputs: BASELINE.json configs[3] random bytes at 4 GiB,
+// configs[4] random DNA at 16 GiB).  A text whose windows repeat is refused (no recursion with 64-bit positions).
+//
+// Window = W symbols of the text (W = 64, or the whole rest of the text if shorter); its order is decided lazily, a
+// 4-byte word at a time (wide_cmp).  Sort image = the first J symbols in base sigma (digit = code - 1, past the end = 0)
+// scaled to `ibits` bits, as KeyT's (dc3_order.hip.hpp).
+#pragma once
+#include "dc3_common.hip.hpp"
+
+namespace dc3 {
+
+struct WideKey {
+  const uint8_t *t; const uint16_t *code; u64 n;
+  u32 sigma, J, W;          // alphabet size, image symbols, compare depth in symbols (multiple of 4)
+  u64 mfix, P1;             // floor((2^(64+ibits) - 1) / sigma^J), sigma^(J-1)
+};
+constexpr u32 kWideMaxImageSyms = 48;
+
+__device__ __forceinline__ u64 wide_pos(const Rec16 &r) { return ((u64)r.k2 << 32) | r.pos; }
+__device__ __forceinline__ u64 wide_img(const Rec16 &r) { return ((u64)r.k1 << 32) | r.k0; }
+
+// image of one position (splitter sample)
+__global__ __launch_bounds__(kBlock) void k_wide_sample(WideKey k, u64 stride, u32 ns, u64 *__restrict__ out) {
+  __shared__ uint16_t lcode[256];
+  if (threadIdx.x < 256) lcode[threadIdx.x] = k.code[threadIdx.x];
+  __syncthreads();
+  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < ns; i += gridDim.x * kBlock) {
+    const u64 p = (u64)i * stride;
+    u64 v = 0;
+#pragma unroll 1
+    for (u32 j = 0; j < k.J; j++) {
+      u32 q = (p + j < k.n) ? (u32)lcode[k.t[p + j]] : 0u;
+      q = q ? q - 1 : 0u;
+      v = v * k.sigma + q;
+    }
+    out[i] = __umul64hi(v, k.mfix);
+  }
+}
+
+// Selection of the positions whose image lies in [lo, hi) (hi ignored on the last rank): block b owns the positions
+// [b * chunk, (b + 1) * chunk) (chunk % 4 == 0), four consecutive positions per thread, images by rolling as in
+// k_pack_image_textT.  kWrite = false: counts[b] = selected positions of the block.  kWrite = true: the records go to
+// out[bases[b] ..] in arbitrary order (the sort that follows decides).
+template <bool kWrite>
+__global__ __launch_bounds__(kBlock) void k_wide_select(WideKey k, u64 chunk, u64 lo, u64 hi, u32 last,
+                                                       u32 *__restrict__ counts, const u32 *__restrict__ bases,
+                                                       Rec16 *__restrict__ out) {
+  __shared__ uint16_t lcode[256];
+  __shared__ u32 cursor;
+  __shared__ u32 tmp[kWaves];
+  if (threadIdx.x < 256) lcode[threadIdx.x] = k.code[threadIdx.x];
+  if (threadIdx.x == 0) cursor = 0;
+  __syncthreads();
+  const u32 J = k.J, sigma = k.sigma, nw = (J + 3 + 3) / 4;
+  constexpr u32 kW = (kWideMaxImageSyms + 3 + 3) / 4;
+  const u64 begin = (u64)blockIdx.x * chunk, end = min(k.n, begin + chunk);
+  const u32 base = kWrite ? bases[blockIdx.x] : 0u;
+  u32 mine = 0;
+  for (u64 p0 = begin + 4ull * threadIdx.x; p0 < end; p0 += 4ull * kBlock) {
+    const u32 *tw = reinterpret_cast<const u32 *>(k.t + p0);
+    u32 w[kW];
+#pragma unroll
+    for (u32 i = 0; i < kW; i++) w[i] = i < nw ? tw[i] : 0u;
+    u64 v = 0;
+    u32 dh[3] = {0, 0, 0}, dt0 = 0, dt1 = 0, dt2 = 0;
+#pragma unroll
+    for (u32 s = 0; s < kWideMaxImageSyms + 3; s++) {
+      if (s < J + 3) {
+        u32 q = (p0 + s < k.n) ? (u32)lcode[(w[s >> 2] >> (8 * (s & 3u))) & 255u] : 0u;
+        q = q ? q - 1 : 0u;
+        if (s < 3) dh[s] = q;
+        if (s < J) v = v * sigma + q;
+        else if (s == J) dt0 = q;
+        else if (s == J + 1) dt1 = q;
+        else dt2 = q;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const u64 img = __umul64hi(v, k.mfix);
+      const u64 p = p0 + j;
+      if (p < end && img >= lo && (last || img < hi)) {
+        if (kWrite) {
+          const u32 slot = atomicAdd(&cursor, 1u);
+          out[(size_t)base + slot] = Rec16{(u32)img, (u32)(img >> 32), (u32)(p >> 32), (u32)p};
+        } else {
+          mine++;
+        }
+      }
+      if (j < 3) v = (v - (u64)dh[j] * k.P1) * sigma + (j == 0 ? dt0 : j == 1 ? dt1 : dt2);
+    }
+  }
+  if (!kWrite) {
+    mine = wave_reduce(mine);
+    if (lane_id() == 0) tmp[wave_id()] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) { u32 tot = 0; for (int i = 0; i < kWaves; i++) tot += tmp[i]; counts[blockIdx.x] = tot; }
+  }
+}
+
+// Order (< 0, 0, > 0) of the windows of positions p and q, up to `depth` symbols (multiple of 4): a word at a time, only a
+// differing (or end-crossing) word is decoded; a suffix that ends sorts before its extensions.
+__device__ __forceinline__ int wide_cmp(const WideKey &k, u64 p, u64 q, u32 depth, const uint16_t *lds) {
+#pragma unroll 1
+  for (u32 s = 0; s < depth; s += 4) {
+    u32 wp, wq;
+    __builtin_memcpy(&wp, k.t + p + s, 4);
+    __builtin_memcpy(&wq, k.t + q + s, 4);
+    if (wp == wq && p + s + 4 <= k.n && q + s + 4 <= k.n) continue;
+#pragma unroll
+    for (u32 b = 0; b < 4; b++) {
+      const bool ep = p + s + b >= k.n, eq = q + s + b >= k.n;
+      const u32 cp = ep ? 0u : (u32)lds[(wp >> (8 * b)) & 255u];
+      const u32 cq = eq ? 0u : (u32)lds[(wq >> (8 * b)) & 255u];
+      if (cp != cq) return cp < cq ? -1 : 1;
+      if (ep) return 0;                      // both ended at once: only possible for p == q
+    }
+  }
+  return 0;
+}
+
+// Tie pass over this rank's records in image order: shard[i] = position of the i-th smallest window.  Records whose image
+// is shared (rare: the image has log2 n + 4 bits and more) are ordered by their windows, one thread per group.
+// words[0] = a group larger than kWideTieBig, words[1] += tied records, words[2] += windows equal within k.W symbols.
+constexpr u32 kWideTieMax = 16, kWideTieBig = 1024;
+__global__ __launch_bounds__(kBlock) void k_wide_ties(const Rec16 *__restrict__ h, u32 nrec, WideKey k, u64 *__restrict__ shard,
+                                                     u32 *words) {
+  __shared__ uint16_t lcode[256];
+  if (threadIdx.x < 256) lcode[threadIdx.x] = k.code[threadIdx.x];
+  __syncthreads();
+  u32 tied = 0, dup = 0;
+  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < nrec; i += gridDim.x * kBlock) {
+    const Rec16 r = h[i];
+    const u64 a = wide_img(r);
+    const bool eqp = i > 0 && wide_img(h[i - 1]) == a;
+    const bool eqn = i + 1 < nrec && wide_img(h[i + 1]) == a;
+    if (!eqp && !eqn) { shard[i] = wide_pos(r); continue; }
+    tied++;
+    if (eqp) continue;                                   // the group's first thread does the work
+    u32 e = i + 2;
+    while (e < nrec && e - i <= kWideTieMax && wide_img(h[e]) == a) e++;
+    const u32 len = e - i;
+    if (len > kWideTieMax) {
+      // a larger group (a run of the smallest symbol, a short repeat): extend it to its end and insertion-sort it in
+      // place in the shard; beyond kWideTieBig records the text is refused
+      while (e < nrec && e - i <= kWideTieBig && wide_img(h[e]) == a) e++;
+      const u32 big = e - i;
+      if (big > kWideTieBig) { words[0] = 1u; continue; }
+      for (u32 x = 0; x < big; x++) {
+        const u64 v = wide_pos(h[i + x]);
+        u32 y = x;
+        while (y > 0) {
+          const u64 prev = shard[i + y - 1];
+          const int c = wide_cmp(k, v, prev, k.W, lcode);
+          if (c == 0) dup++;
+          if (c >= 0) break;
+          shard[i + y] = prev; y--;
+        }
+        shard[i + y] = v;
+      }
+      continue;
+    }
+    u64 loc[kWideTieMax];
+    for (u32 x = 0; x < len; x++) {
+      const u64 v = wide_pos(h[i + x]);
+      u32 y = x;
+      while (y > 0) {
+        const int c = wide_cmp(k, v, loc[y - 1], k.W, lcode);
+        if (c == 0) dup++;
+        if (c >= 0) break;
+        loc[y] = loc[y - 1]; y--;
+      }
+      loc[y] = v;
+    }
+    for (u32 x = 0; x < len; x++) shard[i + x] = loc[x];
+  }
+  tied = wave_reduce(tied); dup = wave_reduce(dup);
+  if (lane_id() == 0) { if (tied) atomicAdd(&words[1], tied); if (dup) atomicAdd(&words[2], dup); }
+}
+
+// Verifier of a shard (dc3hip_global_sufcheck): every position in range and every entry's suffix strictly smaller than
+// its successor's (next_first = the first entry of the next rank's shard, or ~0 on the last rank) — compared as
+// suffixes, up to `depth` symbols; equal within `depth` counts as an error.  Strict order implies distinct positions, so
+// together with the shard sizes adding up to n this is exactly "the concatenated shards are the suffix array".
+// err: 0 ok, 2 position out of range, 3 order violated (atomicMax).
+__global__ __launch_bounds__(kBlock) void k_wide_check(const u64 *__restrict__ shard, u32 cnt, u64 next_first, WideKey k,
+                                                      u32 depth, u32 *err) {
+  __shared__ uint16_t lcode[256];
+  if (threadIdx.x < 256) lcode[threadIdx.x] = k.code[threadIdx.x];
+  __syncthreads();
+  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < cnt; i += gridDim.x * kBlock) {
+    const u64 p = shard[i];
+    if (p >= k.n) { atomicMax(err, 2u); continue; }
+    const u64 q = i + 1 < cnt ? shard[i + 1] : next_first;
+    if (q == ~0ull) continue;
+    if (q >= k.n) { atomicMax(err, 2u); continue; }
+    if (wide_cmp(k, p, q, depth, lcode) >= 0) atomicMax(err, 3u);
+  }
+}
+
+// order-sensitive checksum of a shard with global indices (64-bit values: sum of mix(mix(index) ^ position))
+__global__ __launch_bounds__(kBlock) void k_wide_checksum(const u64 *__restrict__ shard, u32 cnt, u64 first, u64 *out) {
+  u64 acc = 0;
+  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < cnt; i += gridDim.x * kBlock)
+    acc += splitmix64(splitmix64(first + i) ^ shard[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane_id() == 0) atomicAdd(reinterpret_cast<unsigned long long *>(out), (unsigned long long)acc);
+}
+
+}  // namespace dc3

@@ -156,6 +156,14 @@ class GlobalRank:
         _check(lib().dc3hip_global_shard_checksum(self._h, ctypes.byref(v)))
         return int(v.value)
 
+    def sufcheck(self):
+        """Wide contexts (64-bit positions): the collective verifier — every rank must call it.  0 = the concatenated
+        shards are the suffix array, -2 / -3 = range / order violation."""
+        rc = lib().dc3hip_global_sufcheck(self._h)
+        if rc <= -11:
+            raise Dc3HipError(rc + 10, lib().dc3hip_global_last_error(self._h).decode())
+        return rc
+
     def stats(self):
         g, s = GStats(), Stats()
         _check(lib().dc3hip_global_stats(self._h, ctypes.byref(g), ctypes.byref(s)))
@@ -219,6 +227,25 @@ class LoopbackGroup:
 
     def checksum(self):
         return sum(r.shard_checksum() for r in self.ranks) & (2**64 - 1)
+
+    def sufcheck(self):
+        """Wide groups: dc3hip_global_sufcheck of all ranks (a collective: one host thread per rank)."""
+        import threading
+        out = [None] * self.P
+
+        def run(i):
+            try:
+                out[i] = self.ranks[i].sufcheck()
+            except Exception as e:          # noqa: BLE001 - reported below
+                out[i] = e
+        th = [threading.Thread(target=run, args=(i,)) for i in range(self.P)]
+        for t in th: t.start()
+        for t in th: t.join()
+        for v in out:
+            if isinstance(v, Exception):
+                raise v
+        assert len(set(out)) == 1, out
+        return out[0]
 
     def stats(self):
         return [r.stats() for r in self.ranks]

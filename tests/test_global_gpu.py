@@ -199,7 +199,7 @@ def test_bench_global_two_processes_on_one_gpu(ss, oracle, tmp_path):
     from conftest import ROOT
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     size = 3 << 20
-    for kind, extra in (("random", {}), ("text", {"DC3HIP_GLOBAL_LOCAL_MAX": "4096"})):
+    for kind, extra in (("random", {}), ("text", {"DC3HIP_GLOBAL_LOCAL_MAX": "4096"}), ("random", {"DC3HIP_GLOBAL_FORCE_WIDE": "1"})):
         env2 = dict(os.environ, DC3HIP_BENCH_BACKEND="gloo", DC3HIP_BENCH_DUMP_SA=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--mode", "global", "--size", str(size),
@@ -208,7 +208,10 @@ def test_bench_global_two_processes_on_one_gpu(ss, oracle, tmp_path):
         assert p.returncode == 0, (p.stdout[-1000:], p.stderr[-3000:])
         line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
         assert line["n_gpus"] == 2 and "global SA" in line["config"]["partitioning"] and line["config"]["total_bytes"] == 2 * size
-        assert line["verify"]["shards_tile_0_n"] and line["verify"]["equal_single_device_checksum"]
+        if extra.get("DC3HIP_GLOBAL_FORCE_WIDE"):     # the 64-bit-position mode of texts beyond 2^32 bytes, two processes
+            assert line["verify"]["shards_tile_0_n"] and line["verify"]["global_sufcheck"] == 0 and "64-bit" in line["config"]["workload"]
+        else:
+            assert line["verify"]["shards_tile_0_n"] and line["verify"]["equal_single_device_checksum"]
         assert all(b > 0 for b in line["interconnect"]["bytes_in_per_rank_per_step"])
         text = oracle.gen(2 * size, 2, {"random": 0, "text": 2}[kind])
         got = np.concatenate([np.load(tmp_path / f"gshard_{r}.npy") for r in range(2)])
@@ -340,3 +343,54 @@ def test_loopback_spread_over_visible_devices(ss, oracle):
             g.set_text(t)
             g.build()
             assert np.array_equal(g.sa(), want_sa(oracle, t))
+
+
+@pytest.mark.parametrize("P", [2, 3, 8])
+def test_wide_mode_small_texts_match_the_oracle(ss, oracle, P):
+    """The wide mode (64-bit positions, texts beyond DC3HIP_MAX_N) forced onto small texts so that the oracle can judge it:
+    random bytes, DNA, binary, an alphabet with 0x00, texts ending in a run of the smallest symbol; bit-exact shards
+    (fetched as int64), the collective verifier agrees, the u32 getter refuses.  A text with a repeated window and a text
+    over one symbol are refused with -4 on every rank."""
+    rng = np.random.default_rng(47)
+    with env(DC3HIP_GLOBAL_FORCE_WIDE=1), ss.LoopbackGroup(P, 3_000_000) as g:
+        cases = {"bytes": rng.integers(0, 256, size=2_500_003, dtype=np.uint8), "dna": oracle.gen(3_000_000, 5, 1),
+                 "binary": rng.integers(0, 2, size=1_000_001, dtype=np.uint8) + 7,
+                 "with_zero_byte": rng.integers(0, 3, size=777_777, dtype=np.uint8), "tiny": rng.integers(0, 256, size=300, dtype=np.uint8)}
+        d = cases["dna"].copy(); d[-40:] = d.min(); cases["dna_min_run_at_end"] = d
+        for label, t in cases.items():
+            g.set_text(t)
+            g.build()
+            assert np.array_equal(g.sa(), want_sa(oracle, t)), (label, P)
+            assert g.sufcheck() == 0, label
+            st = g.stats()
+            assert all(s["text_order"] == 1 and s["levels"] == 1 for s in st)
+            with pytest.raises(ss.Dc3HipError) as ei:
+                g.ranks[0].shard_sa(np.uint32)
+            assert ei.value.code == -4
+        rep = cases["dna"].copy(); rep[1_000_000:1_000_100] = rep[5:105]
+        for bad in (rep, np.full(100_000, 65, dtype=np.uint8)):
+            g.set_text(bad)
+            with pytest.raises(ss.Dc3HipError) as ei:
+                g.build()
+            assert ei.value.code == -4, ei.value
+        g.set_text(cases["bytes"]); g.build()                        # the group is usable again
+        assert np.array_equal(g.sa(), want_sa(oracle, cases["bytes"]))
+
+
+def test_wide_mode_beyond_2pow32(ss):
+    """A single suffix array of more than 2^32 positions (what BASELINE.json configs[3] / configs[4] need): 2^32 + 2^20 + 3
+    random bytes over two loopback ranks on this GPU; the collective verifier (range + strict suffix order across the
+    whole array, shard sizes adding up to n) accepts it, a corrupted shard is rejected, builds are idempotent."""
+    n = (1 << 32) + (1 << 20) + 3
+    with ss.LoopbackGroup(2, n) as g:
+        g.generate(n, 6, 0)
+        g.build()
+        st = g.stats()
+        assert sum(s["shard_count"] for s in st) == n and st[0]["shard_first"] == 0 and st[1]["shard_first"] == st[0]["shard_count"]
+        assert g.sufcheck() == 0
+        chk = g.checksum()
+        first, sa1 = g.ranks[1].shard_sa(np.int64)
+        assert sa1.dtype == np.int64 and int(sa1.max()) >= (1 << 32) and int(sa1.min()) >= 0
+        del sa1
+        g.build()
+        assert g.checksum() == chk
