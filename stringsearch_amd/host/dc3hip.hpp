@@ -142,6 +142,12 @@ class GlobalRank {
     const int rc = dc3hip_global_build(g_);
     if (rc != 0) throw Error(rc, dc3hip_global_last_error(g_));
   }
+  // wide contexts (texts of 2^32 bytes and more): the collective verifier; 0 = the shards are the suffix array
+  int sufcheck() {
+    const int rc = dc3hip_global_sufcheck(g_);
+    if (rc <= -11) throw Error(rc + 10, dc3hip_global_last_error(g_));
+    return rc;
+  }
   // SA[first .. first + shard.size())
   std::vector<int64_t> shard(int64_t *first) const {
     int64_t cnt = 0;
