@@ -1191,6 +1191,15 @@ static int gbuild_wide(dc3hip_gctx *G) {
     return E_TOOBIG;
   }
   G->shard_first = (int64_t)pre; G->shard_count = (int64_t)nrec; G->shard_ptr = nullptr;
+  if (const char *e = getenv("DC3HIP_WIDE_CORRUPT")) {
+    // test hook for the verifier: 1 = swap two neighbours of the last rank's shard, 2 = put one position out of range
+    if (me == P - 1 && nrec >= 2 && (e[0] == '1' || e[0] == '2')) {
+      u64 two[2];
+      HIPC(hipMemcpy(two, G->w_shard + nrec / 2, 16, hipMemcpyDeviceToHost));
+      if (e[0] == '1') std::swap(two[0], two[1]); else two[0] = n;
+      HIPC(hipMemcpy(G->w_shard + nrec / 2, two, 16, hipMemcpyHostToDevice));
+    }
+  }
   c->stats.text_sort_state = 1;
   c->stats.level_n[0] = (int64_t)n; c->stats.level_K[0] = sigma; c->stats.levels = 1; c->stats.level_sorted[0] = 5;
   G->gs.local_from_level = -1;

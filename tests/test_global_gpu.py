@@ -375,12 +375,20 @@ def test_wide_mode_small_texts_match_the_oracle(ss, oracle, P):
             assert ei.value.code == -4, ei.value
         g.set_text(cases["bytes"]); g.build()                        # the group is usable again
         assert np.array_equal(g.sa(), want_sa(oracle, cases["bytes"]))
+        # the verifier must see a damaged array (test hook: two neighbours swapped / one position out of range)
+        for how, code in (("1", -3), ("2", -2)):
+            with env(DC3HIP_WIDE_CORRUPT=how):
+                g.build()
+            assert g.sufcheck() == code, how
+        g.build()
+        assert g.sufcheck() == 0
 
 
 def test_wide_mode_beyond_2pow32(ss):
     """A single suffix array of more than 2^32 positions (what BASELINE.json configs[3] / configs[4] need): 2^32 + 2^20 + 3
     random bytes over two loopback ranks on this GPU; the collective verifier (range + strict suffix order across the
-    whole array, shard sizes adding up to n) accepts it, a corrupted shard is rejected, builds are idempotent."""
+    whole array, shard sizes adding up to n) accepts it; builds are idempotent.  (The verifier itself is tested against
+    the oracle and against refused inputs at small sizes in test_wide_mode_small_texts_match_the_oracle.)"""
     n = (1 << 32) + (1 << 20) + 3
     with ss.LoopbackGroup(2, n) as g:
         g.generate(n, 6, 0)
@@ -389,8 +397,6 @@ def test_wide_mode_beyond_2pow32(ss):
         assert sum(s["shard_count"] for s in st) == n and st[0]["shard_first"] == 0 and st[1]["shard_first"] == st[0]["shard_count"]
         assert g.sufcheck() == 0
         chk = g.checksum()
-        first, sa1 = g.ranks[1].shard_sa(np.int64)
-        assert sa1.dtype == np.int64 and int(sa1.max()) >= (1 << 32) and int(sa1.min()) >= 0
-        del sa1
+        assert all(s["ctx"]["level_tied"][0] < n // 1000 for s in st)      # 45-bit images: hardly any ties
         g.build()
         assert g.checksum() == chk
