@@ -168,7 +168,10 @@ typedef struct dc3hip_stats {
                                              3 / 4 = 1 / 2 followed by the discarding recursion,
                                              5 = whole level ordered at once (all its triples distinct; at level 0:
                                                  all windows of the text distinct - 9 bytes, or 3L symbols of a small
-                                                 alphabet, L = symbols per 32-bit limb in base sigma+1) */
+                                                 alphabet, L = symbols per 32-bit limb in base sigma+1),
+                                             6 = level 0 only: the whole text ordered at once and the few positions whose
+                                                 windows repeat settled by prefix doubling (level_tied[0] = those positions,
+                                                 level_kept[0] = doubling rounds) */
   int64_t level_kept[DC3HIP_MAX_LEVELS];  /* length of the reduced recursive string (discarding) */
   int32_t level_name_width[DC3HIP_MAX_LEVELS]; /* symbols packed per direct name (0 on sorted levels) */
   int64_t level_tied[DC3HIP_MAX_LEVELS];  /* samples re-sorted by the full key (prefix-sort path) */

@@ -17,3 +17,4 @@
 #include "dc3_aux.hip.hpp"
 #include "dc3_global.hip.hpp"
 #include "dc3_wide.hip.hpp"
+#include "dc3_doubling.hip.hpp"

@@ -365,6 +365,8 @@ struct Key9 {
   }
   __device__ __forceinline__ Rec8 image(u32 p, const uint16_t *lds, const HiMap &hm) const { return hyb_rec(make(p, lds), hm); }
   __device__ __forceinline__ u64 image_hi(u32 p, const uint16_t *lds, const HiMap &hm) const { return hyb_hi(make(p, lds), hm); }
+  __device__ __forceinline__ int cmp(u32 p, u32 q, const uint16_t *lds) const { return window_cmp(S, p, q, 9, lds); }
+  __host__ __device__ u32 window_syms() const { return 9; }
 };
 // KeyT = 3*L symbols of the text as three limbs of L symbols in base B (limb base BL = B^L < 2^32): the longer window
 // a small alphabet needs before windows can be distinct (DNA, B = 5: L = 13, 39 symbols, 90 bits).  L = 3 is Key9's
@@ -395,6 +397,7 @@ struct KeyT {
     return make_rec(limb[0], limb[1], limb[2], BL, p);
   }
   __device__ __forceinline__ int cmp(u32 p, u32 q, const uint16_t *lds) const { return window_cmp(S, p, q, 3 * L, lds); }
+  __host__ __device__ u32 window_syms() const { return 3 * L; }
   __device__ __forceinline__ u64 image_hi(u32 p, const uint16_t *lds, const HiMap &hm) const {
     const u32 nw = (J + 3) / 4;
     u32 w[kKeyTMaxImageSyms / 4];

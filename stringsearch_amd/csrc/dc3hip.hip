@@ -84,6 +84,7 @@ struct dc3hip_ctx {
   bool no_nine_bit = false, no_rec12 = false, no_discard = false, no_fullsort = false, no_text_shortcut = false;
   bool no_split_emit = false;
   bool no_long_keys = false;   // DC3HIP_NO_LONG_KEYS=1: the whole-text shortcut only with 9-symbol windows (no KeyT)
+  bool no_doubling = false;    // DC3HIP_NO_DOUBLING=1: repeated windows always hand the whole-text order to level 1
   int text_order12 = -1;       // DC3HIP_TEXT_ORDER12=1/0: whole-text shortcut on 12-byte records always / never (default: n > 2^31)
   double hybrid12_max_pred = kHybrid12MaxPredicted;   // DC3HIP_HYBRID12_MAX_PRED (tuning)
   u32 hybrid12_min = 1u << 22; // DC3HIP_HYBRID12_MIN: smallest level (samples) that tries it (tests lower it)
@@ -1049,6 +1050,97 @@ static int finish_position_order(dc3hip_ctx *c, Acc acc, Map mp, u32 nrec, u32 m
   return E_OK;
 }
 
+// Few windows repeat (dc3_doubling.hip.hpp): refine the tied positions alone by prefix doubling and finish the suffix
+// array at level 0.  acc = the n positions in window order with their "differs from predecessor" flags; W = symbols per
+// window.  *done = false (nothing lost: out_sa is scratch until a caller declares it the result) when too many
+// positions are tied, the arena is short, or the rounds do not converge.
+static constexpr u32 kDoublingMaxTied = 4u << 20;          // records; and at most 1/64 of the positions
+template <class KM, class Acc>
+static int doubling_finish(dc3hip_ctx *c, KM km, Acc acc, u32 n, u32 W, u32 *out_sa, bool *done) {
+  *done = false;
+  if (c->no_doubling || !out_sa || n < 2) return E_OK;
+  const ArenaMark mk = arena_mark(c);
+  const Chunking ck = make_chunks(c, n, kBlock);
+  u32 *counts = nullptr;
+  RC(arena_alloc(c, (size_t)ck.nchunks + 16, &counts));
+  {
+    PhaseScope ps(c, DC3HIP_PH_TIES, n);
+    hipLaunchKernelGGL((k_dbl_count<Acc>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, acc, n, ck.chunk, counts);
+    KCHECK();
+    hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, counts, ck.nchunks, c->d_words + 2);
+    KCHECK();
+    HIPC(hipMemcpyAsync(c->h_words + 2, c->d_words + 2, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPC(hipStreamSynchronize(c->stream));
+  const u32 t = c->h_words[2];
+  if (t == 0 || t > kDoublingMaxTied || t > n / 64 || c->arena_bytes - c->arena_off < (size_t)t * 128 + (32u << 20)) {
+    arena_release(c, mk);
+    return E_OK;
+  }
+  u32 *slot = nullptr, *pos = nullptr, *start = nullptr, *gid = nullptr, *mapidx = nullptr, *map_pos = nullptr, *map_val = nullptr;
+  Rec8 *pa = nullptr, *pb = nullptr, *ps_sorted = nullptr;
+  Rec16 *act = nullptr, *tmp = nullptr, *next = nullptr;
+  RC(arena_alloc(c, (size_t)t + 16, &slot)); RC(arena_alloc(c, (size_t)t + 16, &pos)); RC(arena_alloc(c, (size_t)t + 16, &start));
+  RC(arena_alloc(c, (size_t)t + 16, &gid)); RC(arena_alloc(c, (size_t)t + 16, &mapidx));
+  RC(arena_alloc(c, (size_t)t + 16, &map_pos)); RC(arena_alloc(c, (size_t)t + 16, &map_val));
+  RC(arena_alloc(c, (size_t)t + 16, &pa)); RC(arena_alloc(c, (size_t)t + 16, &pb));
+  RC(arena_alloc(c, (size_t)t + 16, &act)); RC(arena_alloc(c, (size_t)t + 16, &tmp)); RC(arena_alloc(c, (size_t)t + 16, &next));
+  const u32 kb = bits_of((u64)n);                            // ranks + 1 and slots are below 2^kb
+  {
+    PhaseScope ps(c, DC3HIP_PH_TIES, t);
+    // the order as it stands (final for every untied position)
+    hipLaunchKernelGGL((k_emit_sorted<Acc>), dim3(grid_for(c, n)), dim3(kBlock), 0, c->stream, acc, n, 0u, out_sa, (Rec8 *)nullptr);
+    KCHECK();
+    hipLaunchKernelGGL((k_dbl_collect<Acc>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, acc, n, ck.chunk, (const u32 *)counts, slot,
+                       pos, start);
+    KCHECK();
+    hipLaunchKernelGGL(k_dbl_gid, dim3(1), dim3(kBlock), 0, c->stream, (const u32 *)slot, (const u32 *)start, t, gid);
+    KCHECK();
+    hipLaunchKernelGGL(k_dbl_map_pairs, dim3(grid_for(c, t)), dim3(kBlock), 0, c->stream, (const u32 *)pos, t, pa);
+    KCHECK();
+  }
+  RC(radix_sort<Rec8>(c, pa, pb, t, 32, 32 + bits_of((u64)n - 1), &ps_sorted, DC3HIP_PH_TIES, DC3HIP_PH_TIES, DC3HIP_PH_TIES));
+  {
+    PhaseScope ps(c, DC3HIP_PH_TIES, t);
+    hipLaunchKernelGGL(k_dbl_map_build, dim3(grid_for(c, t)), dim3(kBlock), 0, c->stream, (const Rec8 *)ps_sorted, t, (const u32 *)gid,
+                       map_pos, map_val, mapidx);
+    KCHECK();
+    hipLaunchKernelGGL(k_dbl_init, dim3(grid_for(c, t)), dim3(kBlock), 0, c->stream, (const u32 *)pos, (const u32 *)gid,
+                       (const u32 *)mapidx, t, act);
+    KCHECK();
+  }
+  u32 a = t;
+  u64 d = W;
+  int rounds = 0;
+  Rec16 *X = act, *Y = tmp, *Z = next;                       // X: this round's records, Y: sort scratch, Z: next round's records
+  for (; a > 0 && rounds < 40 && d < (u64)n * 2; rounds++, d *= 2) {
+    {
+      PhaseScope ps(c, DC3HIP_PH_TIES, a);
+      hipLaunchKernelGGL((k_dbl_key<KM, Acc>), dim3(grid_for(c, a)), dim3(kBlock), 0, c->stream, km, acc, n,
+                         (u32)std::min<u64>(d, 0xffffffffull), (const u32 *)map_pos, (const u32 *)map_val, t, X, a);
+      KCHECK();
+    }
+    // by (group, rank of p + d): LSD, the rank first
+    Rec16 *s1 = nullptr, *s2 = nullptr;
+    RC(radix_sort<Rec16>(c, X, Y, a, 0, kb, &s1, DC3HIP_PH_TIES, DC3HIP_PH_TIES, DC3HIP_PH_TIES));
+    RC(radix_sort<Rec16>(c, s1, s1 == X ? Y : X, a, 32, 32 + kb, &s2, DC3HIP_PH_TIES, DC3HIP_PH_TIES, DC3HIP_PH_TIES));
+    {
+      PhaseScope ps(c, DC3HIP_PH_TIES, a);
+      hipLaunchKernelGGL(k_dbl_regroup, dim3(1), dim3(kBlock), 0, c->stream, (const Rec16 *)s2, a, out_sa, map_val, Z, c->d_words + 2);
+      KCHECK();
+      HIPC(hipMemcpyAsync(c->h_words + 2, c->d_words + 2, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPC(hipStreamSynchronize(c->stream));
+    a = c->h_words[2];
+    Rec16 *nx = Z; Z = Y; Y = X; X = nx;
+  }
+  c->stats.level_tied[0] = t;
+  c->stats.level_kept[0] = rounds;                           // (rounds of prefix doubling over the tied positions)
+  arena_release(c, mk);
+  *done = a == 0;
+  return E_OK;
+}
+
 template <class KM, class Map>
 static int order_all_positions(dc3hip_ctx *c, KM km, Map mp, u32 m, u32 kbits, const HiMap &hm, u32 dummy, u32 *out_sa,
                                u32 *out_rank, u32 *spos, u32 *snf, int *state, int depth) {
@@ -1072,7 +1164,12 @@ static int order_all_positions(dc3hip_ctx *c, KM km, Map mp, u32 m, u32 kbits, c
     *state = 1;                            // the tie pass already wrote the suffix array
   } else if (sorted_ok) {
     AccHyb acc; acc.h = h; acc.f = f; acc.posmask = hm.pbits >= 32 ? 0xffffffffu : ((1u << hm.pbits) - 1u);
-    RC((finish_position_order<AccHyb, Map>(c, acc, mp, nrec, m, dummy, out_sa, out_rank, spos, snf, state)));
+    bool finished = false;
+    if constexpr (std::is_same<Map, MapText>::value) {       // whole text: few repeated windows are settled right here
+      if (dummy == 0 && out_sa && !out_rank) RC((doubling_finish<KM, AccHyb>(c, km, acc, nrec, km.window_syms(), out_sa, &finished)));
+    }
+    if (finished) { *state = 1; c->stats.level_sorted[0] = 6; }
+    else RC((finish_position_order<AccHyb, Map>(c, acc, mp, nrec, m, dummy, out_sa, out_rank, spos, snf, state)));
   }
   arena_release(c, mk);
   return E_OK;
@@ -1459,7 +1556,8 @@ static int try_text_order(dc3hip_ctx *c, KM km, u64 BL, const HiMap &hm, u32 sig
   c->stats.text_sort_state = state == 1 ? 1 : state == 2 ? 2 : 3;
   if (state == 1) {
     *whole_text = true;
-    c->stats.level_n[0] = n; c->stats.level_K[0] = sigma; c->stats.levels = 1; c->stats.level_sorted[0] = 5;
+    c->stats.level_n[0] = n; c->stats.level_K[0] = sigma; c->stats.levels = 1;
+    if (c->stats.level_sorted[0] != 6) c->stats.level_sorted[0] = 5;      // 6 = finished by prefix doubling of the tied positions
   } else if (state == 2) {
     pre->spos = spos; pre->snf = snf;      // duplicates: the order still serves level 1
   }
@@ -1545,8 +1643,13 @@ static int try_text_order12(dc3hip_ctx *c, KM km, u64 BL, const HiMap &hm, u32 s
   const u32 m0 = (u32)((n + 2) / 3), m1 = m0 + (u32)(n / 3);
   const u32 m02_1 = (m1 + 2) / 3 + m1 / 3;
   u32 *spos = c->d_sa, *snf = c->d_sa + m02_1 + 16;                        // (as in try_text_order)
-  if (refined && distinct) {
-    state = 1;                             // the tie pass already wrote the suffix array
+  bool doubled = false;
+  if (refined && !distinct) {
+    AccHyb12 acc; acc.h = h; acc.f = f;
+    RC((doubling_finish<KM, AccHyb12>(c, km, acc, (u32)n, km.window_syms(), c->d_sa, &doubled)));
+  }
+  if (refined && (distinct || doubled)) {
+    state = 1;                             // the tie pass (or the doubling rounds) already wrote the suffix array
   } else if (refined) {
     MapText mp; mp.m0 = m0; mp.npre = 0; mp.ppos[0] = mp.ppos[1] = 0;
     if (m1 % 3 == 1) mp.ppos[mp.npre++] = m1;
@@ -1558,7 +1661,7 @@ static int try_text_order12(dc3hip_ctx *c, KM km, u64 BL, const HiMap &hm, u32 s
   c->stats.text_sort_state = state == 1 ? 1 : state == 2 ? 2 : 3;
   if (state == 1) {
     *whole_text = true;
-    c->stats.level_n[0] = n; c->stats.level_K[0] = sigma; c->stats.levels = 1; c->stats.level_sorted[0] = 5;
+    c->stats.level_n[0] = n; c->stats.level_K[0] = sigma; c->stats.levels = 1; c->stats.level_sorted[0] = doubled ? 6 : 5;
   } else if (state == 2) {
     pre->spos = spos; pre->snf = snf;
   }
@@ -1671,6 +1774,7 @@ int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) {
   { const char *e = getenv("DC3HIP_NO_SPLIT_EMIT"); c->no_split_emit = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_TRACE"); c->trace = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_LONG_KEYS"); c->no_long_keys = (e && e[0] == '1'); }
+  { const char *e = getenv("DC3HIP_NO_DOUBLING"); c->no_doubling = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_TEXT_ORDER12"); if (e && (e[0] == '0' || e[0] == '1')) c->text_order12 = e[0] - '0'; }
   { const char *e = getenv("DC3HIP_NO_TUP8"); c->no_tup8 = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_HYBRID12"); c->no_hybrid12 = (e && e[0] == '1'); }

@@ -392,7 +392,7 @@ def test_hybrid_and_straight_paths_agree(ss, oracle):
         want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)
         seen = {}
         for env in ({}, {"DC3HIP_NO_HYBRID": "1"}, {"DC3HIP_NO_SMALL_TIES": "1"}, {"DC3HIP_NO_FULLSORT": "1"},
-                    {"DC3HIP_NO_TEXT_SHORTCUT": "1"}, {"DC3HIP_NO_SPLIT_EMIT": "1"}, {"DC3HIP_TEXT_ORDER12": "1"},
+                    {"DC3HIP_NO_TEXT_SHORTCUT": "1"}, {"DC3HIP_NO_SPLIT_EMIT": "1"}, {"DC3HIP_TEXT_ORDER12": "1"}, {"DC3HIP_NO_DOUBLING": "1"},
                     {"DC3HIP_NO_TEXT_SHORTCUT": "1", "DC3HIP_NO_TUP8": "1"},
                     {"DC3HIP_NO_TEXT_SHORTCUT": "1", "DC3HIP_NO_HYBRID8": "1", "DC3HIP_HYBRID12_MIN": "0"},   # 12-byte prefix sort
                     {"DC3HIP_NO_HYBRID12": "1"},
@@ -425,9 +425,12 @@ def test_hybrid_and_straight_paths_agree(ss, oracle):
         if label in ("random", "zero_run"):
             assert any(v in (2, 4) for v in seen[("DC3HIP_NO_FULLSORT",)]["level_sorted"])   # 4 = 2 + discarding
         if label == "dup_block":
-            assert 5 not in seen[()]["level_sorted"] and any(v in (2, 4) for v in seen[()]["level_sorted"])
-            # the whole-text order had duplicate 9-byte windows and was filtered into level 1's samples
-            assert seen[()]["text_sort_state"] == 2 and seen[("DC3HIP_NO_TEXT_SHORTCUT",)]["text_sort_state"] == 0
+            nd = seen[("DC3HIP_NO_DOUBLING",)]
+            assert 5 not in nd["level_sorted"] and any(v in (2, 4) for v in nd["level_sorted"])
+            # the whole-text order had duplicate 9-byte windows and was filtered into level 1's samples (4 % of the positions
+            # are tied here: too many for the prefix-doubling finish, so the default takes the same route)
+            assert nd["text_sort_state"] == 2 and seen[("DC3HIP_NO_TEXT_SHORTCUT",)]["text_sort_state"] == 0
+            assert seen[()]["text_sort_state"] == 2
             # small-group path skips the 16-byte radix passes entirely; the zero run forces them
             d16 = seen[()]["downsweep_launches"][1]
             assert (d16 == 0) if label == "random" else (d16 > 0), (label, d16)
@@ -449,15 +452,21 @@ def test_whole_text_order_reused_by_level1(ss, oracle):
         data = d.tobytes()
         want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)
         for wide in ("0", "1"):                           # 8-byte records, and the 12-byte ones of texts beyond 2^31
-            os.environ["DC3HIP_TEXT_ORDER12"] = wide
-            try:
-                with ss.Context(n) as c:
-                    c.set_text(data); c.build()
-                    st = c.stats()
-                    assert np.array_equal(c.sa(), want), (n, wide)
-                    assert st["text_sort_state"] == 2 and st["level_sorted"][0] == 0 and st["level_sorted"][1] in (2, 4), st
-            finally:
-                os.environ.pop("DC3HIP_TEXT_ORDER12", None)
+            for nodbl in ("1", "0"):                      # the order handed to level 1 / finished by prefix doubling
+                os.environ["DC3HIP_TEXT_ORDER12"] = wide
+                os.environ["DC3HIP_NO_DOUBLING"] = nodbl
+                try:
+                    with ss.Context(n) as c:
+                        c.set_text(data); c.build()
+                        st = c.stats()
+                        assert np.array_equal(c.sa(), want), (n, wide, nodbl)
+                        if nodbl == "1":
+                            assert st["text_sort_state"] == 2 and st["level_sorted"][0] == 0 and st["level_sorted"][1] in (2, 4), st
+                        else:
+                            assert st["text_sort_state"] == 1 and st["level_sorted"][0] == 6 and st["levels"] == 1, st
+                finally:
+                    os.environ.pop("DC3HIP_TEXT_ORDER12", None)
+                    os.environ.pop("DC3HIP_NO_DOUBLING", None)
         m0 = (n + 2) // 3; m1 = m0 + n // 3
         combos.add((n % 3, m1 % 3))
     assert len(combos) == 9
@@ -490,7 +499,8 @@ def test_small_alphabet_long_windows(ss, oracle):
         want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)
         seen = {}
         for env in ({}, {"DC3HIP_NO_LONG_KEYS": "1"}, {"DC3HIP_NO_SPLIT_EMIT": "1"}, {"DC3HIP_NO_SMALL_TIES": "1"},
-                    {"DC3HIP_TEXT_ORDER12": "1"}, {"DC3HIP_TEXT_ORDER12": "1", "DC3HIP_NO_SMALL_TIES": "1"}):
+                    {"DC3HIP_TEXT_ORDER12": "1"}, {"DC3HIP_TEXT_ORDER12": "1", "DC3HIP_NO_SMALL_TIES": "1"},
+                    {"DC3HIP_NO_DOUBLING": "1"}, {"DC3HIP_NO_DOUBLING": "1", "DC3HIP_TEXT_ORDER12": "1"}):
             os.environ.update(env)
             try:
                 with ss.Context(len(data)) as c:
@@ -507,7 +517,56 @@ def test_small_alphabet_long_windows(ss, oracle):
         w12 = seen[("DC3HIP_TEXT_ORDER12",)]                 # the same shortcut on 12-byte records (default beyond 2^31)
         assert w12["text_sort_state"] == seen[()]["text_sort_state"] and w12["downsweep_launches"][1] > 0, (label, w12["text_sort_state"])
         if label in ("dna_repeat_3000", "dna_repeat_into_end"):
-            assert seen[()]["text_sort_state"] == 2 and seen[()]["level_sorted"][1] in (2, 4), (label, seen[()]["level_sorted"])
+            # few repeated windows: settled at level 0 by prefix doubling of the tied positions (level_sorted 6) ...
+            assert seen[()]["text_sort_state"] == 1 and seen[()]["level_sorted"][0] == 6 and seen[()]["levels"] == 1, (label, seen[()]["level_sorted"])
+            assert w12["level_sorted"][0] == 6, label
+            # ... or, without it, handed to level 1 as its sorted samples
+            for key in (("DC3HIP_NO_DOUBLING",), ("DC3HIP_NO_DOUBLING", "DC3HIP_TEXT_ORDER12")):
+                nd = seen[key]
+                assert nd["text_sort_state"] == 2 and nd["level_sorted"][1] in (2, 4), (label, key, nd["level_sorted"])
+
+
+def test_prefix_doubling_finish_of_few_repeated_windows(ss, oracle):
+    """The whole-text order with FEW repeated windows is finished at level 0 by prefix doubling of the tied positions
+    (dc3_doubling.hip.hpp; level_sorted[0] == 6, levels == 1) instead of going through the recursion: long duplicated
+    blocks (many rounds), a repeat that runs into the end of the text, a short periodic stretch (overlapping repeats:
+    p and p + period tied with each other), several copies of one block (groups of more than two), on bytes (9-byte
+    windows), DNA (39-symbol windows) and with the 12-byte records of texts beyond 2^31.  Bit-exact against divsufsort."""
+    rng = np.random.default_rng(53)
+    n = (1 << 24) + 5
+
+    def bytes_base():
+        return rng.integers(0, 256, size=n, dtype=np.uint8)
+
+    def dna_base():
+        return np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=n)]
+    cases = {}
+    for name, base in (("bytes", bytes_base), ("dna", dna_base)):
+        d = base(); d[n // 2:n // 2 + 100_000] = d[1000:101_000]; cases[f"{name}_dup_100k"] = d
+        d = base(); d[n - 30_000:] = d[5000:35_000]; cases[f"{name}_dup_into_end"] = d
+        d = base(); d[7_000_000:7_020_000] = np.resize(d[123:130], 20_000); cases[f"{name}_periodic_20k_period7"] = d
+        d = base()
+        for k in range(5):
+            d[1_000_000 * (k + 2):1_000_000 * (k + 2) + 15_000] = d[500:15_500]
+        cases[f"{name}_six_copies_15k"] = d
+    for label, arr in cases.items():
+        data = arr.tobytes()
+        want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)
+        for env in ({}, {"DC3HIP_TEXT_ORDER12": "1"}, {"DC3HIP_NO_DOUBLING": "1"}):
+            os.environ.update(env)
+            try:
+                with ss.Context(len(data)) as c:
+                    c.set_text(data); c.build()
+                    st = c.stats()
+                    assert np.array_equal(c.sa(), want), (label, env)
+                    if "DC3HIP_NO_DOUBLING" in env:
+                        assert st["text_sort_state"] == 2, (label, st["text_sort_state"])
+                    else:
+                        assert st["text_sort_state"] == 1 and st["levels"] == 1 and st["level_sorted"][0] == 6, (label, env, st["level_sorted"])
+                        assert st["level_tied"][0] > 0 and st["level_kept"][0] >= 2, (label, st["level_tied"][0], st["level_kept"][0])
+            finally:
+                for k in env:
+                    os.environ.pop(k, None)
 
 
 def test_wide_and_narrow_direct_names_agree(ss, oracle):
