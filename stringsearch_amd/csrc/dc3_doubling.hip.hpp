@@ -146,90 +146,125 @@ __global__ __launch_bounds__(kBlock) void k_dbl_key(KM km, Acc acc, u32 n, u32 d
   }
 }
 
-// After the sort of the active records by (gid, key2): split the groups.  ONE block, tiles of kDblTile records.
+// After the sort of the active records by (gid, key2): split the groups.  One block per tile of kDblTile records, in two
+// passes around a one-block scan of the tiles' summaries (k_dbl_regroup<false> -> k_dbl_regroup_scan -> k_dbl_regroup<true>):
 //   new slot of record j   = gid + (j - first j of its old group)
 //   new group of record j  = gid + (first j of its (gid, key2) run - first j of its old group)
-// writes out_sa[new slot] = pos, map_val[map index] = new group; records alone in their run are final and dropped, the
-// others are compacted into next[] (count in *next_count).
-__global__ __launch_bounds__(kBlock) void k_dbl_regroup(const Rec16 *__restrict__ act, u32 a, u32 *__restrict__ out_sa,
-                                                       u32 *__restrict__ map_val, Rec16 *__restrict__ next, u32 *next_count) {
+// kApply = false: sums[3 * tile + {0, 1, 2}] = (index + 1 of the tile's last group start, of its last run start, number of
+//   records it keeps).  kApply = true, with carry[3 * tile + ..] = the same for everything before the tile (max, max, sum):
+//   writes out_sa[new slot] = pos, map_val[map index] = new group; records alone in their run are final and dropped, the
+//   others are compacted into next[].
+template <bool kApply>
+__global__ __launch_bounds__(kBlock) void k_dbl_regroup(const Rec16 *__restrict__ act, u32 a, u32 *__restrict__ sums,
+                                                       const u32 *__restrict__ carry, u32 *__restrict__ out_sa,
+                                                       u32 *__restrict__ map_val, Rec16 *__restrict__ next) {
   __shared__ u32 tmp[kWaves];
   __shared__ u32 wave_last[kWaves];
-  __shared__ u32 carry_g, carry_r, out_base;
-  if (threadIdx.x == 0) { carry_g = kNone; carry_r = kNone; out_base = 0; }
-  __syncthreads();
-  for (u32 tile = 0; tile < a; tile += kDblTile) {
-    const u32 j0 = tile + threadIdx.x * kDblIPT;
-    u32 lg = kNone, lr = kNone, locg[kDblIPT], locr[kDblIPT];
-    Rec16 rec[kDblIPT];
-    u32 prev_gid = 0, prev_key = 0;
-    if (j0 > 0 && j0 < a + 1 && j0 - 1 < a) { const Rec16 p = act[j0 - 1]; prev_gid = p.k1; prev_key = p.k0; }
+  const u32 tile = blockIdx.x * kDblTile;
+  const u32 j0 = tile + threadIdx.x * kDblIPT;
+  u32 lg = kNone, lr = kNone, locg[kDblIPT], locr[kDblIPT];
+  Rec16 rec[kDblIPT];
+  u32 prev_gid = 0, prev_key = 0;
+  if (j0 >= 1 && j0 <= a) { const Rec16 p = act[j0 - 1]; prev_gid = p.k1; prev_key = p.k0; }
 #pragma unroll
-    for (u32 x = 0; x < kDblIPT; x++) {
-      const u32 j = j0 + x;
-      if (j < a) {
-        rec[x] = act[j];
-        const bool fg = j == 0 || rec[x].k1 != prev_gid;
-        const bool fr = fg || rec[x].k0 != prev_key;
-        if (fg) lg = j + 1;
-        if (fr) lr = j + 1;
-        prev_gid = rec[x].k1; prev_key = rec[x].k0;
-      }
-      locg[x] = lg; locr[x] = lr;
+  for (u32 x = 0; x < kDblIPT; x++) {
+    const u32 j = j0 + x;
+    if (j < a) {
+      rec[x] = act[j];
+      const bool fg = j == 0 || rec[x].k1 != prev_gid;
+      const bool fr = fg || rec[x].k0 != prev_key;
+      if (fg) lg = j + 1;
+      if (fr) lr = j + 1;
+      prev_gid = rec[x].k1; prev_key = rec[x].k0;
     }
-    // exclusive block max-scans of the threads' last flagged indices (+ carry of the earlier tiles)
-    u32 incl = block_incl_max_scan(lg, tmp);
-    u32 up = __shfl_up(incl, 1);                           // (executed by every lane: a shuffle inside the ?: below would
-    if (lane_id() == 63) wave_last[wave_id()] = incl;      //  read from lanes that do not take part in it)
+    locg[x] = lg; locr[x] = lr;
+  }
+  // which records stay (their run has a second member)?
+  u32 keep = 0, nkeep = 0;
+#pragma unroll
+  for (u32 x = 0; x < kDblIPT; x++) {
+    const u32 j = j0 + x;
+    if (j < a) {
+      const bool is_start = locr[x] == j + 1;
+      bool next_start = true;                              // does a new run start right behind j?
+      if (j + 1 < a) {
+        const Rec16 nx = (x + 1 < kDblIPT) ? rec[x + 1 < kDblIPT ? x + 1 : x] : act[j + 1];
+        next_start = nx.k1 != rec[x].k1 || nx.k0 != rec[x].k0;
+      }
+      if (!(is_start && next_start)) { keep |= 1u << x; nkeep++; }
+    }
+  }
+  // block max-scans of the threads' last flagged indices, block sum-scan of the kept counts
+  u32 incl = block_incl_max_scan(lg, tmp);
+  u32 up = __shfl_up(incl, 1);                             // (executed by every lane: a shuffle inside the ?: below would
+  if (lane_id() == 63) wave_last[wave_id()] = incl;        //  read from lanes that do not take part in it)
+  __syncthreads();
+  u32 before_g = lane_id() == 0 ? (wave_id() == 0 ? kNone : wave_last[wave_id() - 1]) : up;
+  const u32 tile_g = incl;                                 // (of thread kBlock - 1: the tile's last group start)
+  __syncthreads();
+  incl = block_incl_max_scan(lr, tmp);
+  up = __shfl_up(incl, 1);
+  if (lane_id() == 63) wave_last[wave_id()] = incl;
+  __syncthreads();
+  u32 before_r = lane_id() == 0 ? (wave_id() == 0 ? kNone : wave_last[wave_id() - 1]) : up;
+  const u32 tile_r = incl;
+  __syncthreads();
+  u32 tot;
+  const u32 ex = block_excl_scan<kWaves>(nkeep, tmp, tot);
+  if (!kApply) {
+    if (threadIdx.x == kBlock - 1) { sums[3 * blockIdx.x] = tile_g; sums[3 * blockIdx.x + 1] = tile_r; sums[3 * blockIdx.x + 2] = tot; }
+    return;
+  }
+  before_g = max(before_g, carry[3 * blockIdx.x]);
+  before_r = max(before_r, carry[3 * blockIdx.x + 1]);
+  u32 o = carry[3 * blockIdx.x + 2] + ex;
+#pragma unroll
+  for (u32 x = 0; x < kDblIPT; x++) {
+    const u32 j = j0 + x;
+    if (j < a) {
+      const u32 g0 = max(locg[x], before_g) - 1, r0 = max(locr[x], before_r) - 1;
+      const u32 gid = rec[x].k1;
+      const u32 new_slot = gid + (j - g0), new_gid = gid + (r0 - g0);
+      out_sa[new_slot] = rec[x].pos;
+      map_val[rec[x].k2] = new_gid;
+      if (keep & (1u << x)) next[o++] = Rec16{0u, new_gid, rec[x].k2, rec[x].pos};
+    }
+  }
+}
+// exclusive scan of the tile summaries (max, max, sum); *next_count = records kept in total.  ONE block.
+__global__ __launch_bounds__(kBlock) void k_dbl_regroup_scan(const u32 *__restrict__ sums, u32 ntiles, u32 *__restrict__ carry,
+                                                            u32 *next_count) {
+  __shared__ u32 tmp[kWaves];
+  __shared__ u32 wave_last[kWaves];
+  __shared__ u32 cg, cr, cs;
+  if (threadIdx.x == 0) { cg = kNone; cr = kNone; cs = 0; }
+  __syncthreads();
+  for (u32 base = 0; base < ntiles; base += kBlock) {
+    const u32 b = base + threadIdx.x;
+    const u32 g = b < ntiles ? sums[3 * b] : kNone, r = b < ntiles ? sums[3 * b + 1] : kNone, k = b < ntiles ? sums[3 * b + 2] : 0u;
+    u32 incl = block_incl_max_scan(g, tmp);
+    u32 up = __shfl_up(incl, 1);
+    if (lane_id() == 63) wave_last[wave_id()] = incl;
     __syncthreads();
-    u32 before_g = lane_id() == 0 ? (wave_id() == 0 ? kNone : wave_last[wave_id() - 1]) : up;
-    before_g = max(before_g, carry_g);
-    const u32 tile_last_g = max(incl, carry_g);
+    const u32 eg = max(lane_id() == 0 ? (wave_id() == 0 ? kNone : wave_last[wave_id() - 1]) : up, cg);
+    const u32 tg = max(incl, cg);
     __syncthreads();
-    incl = block_incl_max_scan(lr, tmp);
+    incl = block_incl_max_scan(r, tmp);
     up = __shfl_up(incl, 1);
     if (lane_id() == 63) wave_last[wave_id()] = incl;
     __syncthreads();
-    u32 before_r = lane_id() == 0 ? (wave_id() == 0 ? kNone : wave_last[wave_id() - 1]) : up;
-    before_r = max(before_r, carry_r);
-    const u32 tile_last_r = max(incl, carry_r);
-    // which records stay (their run has a second member)?
-    u32 keep = 0, nkeep = 0;
-#pragma unroll
-    for (u32 x = 0; x < kDblIPT; x++) {
-      const u32 j = j0 + x;
-      if (j < a) {
-        const bool is_start = locr[x] == j + 1;
-        bool next_start = true;                            // does a new run start right behind j?
-        if (j + 1 < a) {
-          const Rec16 nx = (x + 1 < kDblIPT) ? rec[x + 1 < kDblIPT ? x + 1 : x] : act[j + 1];
-          next_start = nx.k1 != rec[x].k1 || nx.k0 != rec[x].k0;
-        }
-        if (!(is_start && next_start)) { keep |= 1u << x; nkeep++; }
-      }
-    }
+    const u32 er = max(lane_id() == 0 ? (wave_id() == 0 ? kNone : wave_last[wave_id() - 1]) : up, cr);
+    const u32 tr = max(incl, cr);
     __syncthreads();
     u32 tot;
-    const u32 ex = block_excl_scan<kWaves>(nkeep, tmp, tot);
-    u32 o = out_base + ex;
-#pragma unroll
-    for (u32 x = 0; x < kDblIPT; x++) {
-      const u32 j = j0 + x;
-      if (j < a) {
-        const u32 g0 = max(locg[x], before_g) - 1, r0 = max(locr[x], before_r) - 1;
-        const u32 gid = rec[x].k1;
-        const u32 new_slot = gid + (j - g0), new_gid = gid + (r0 - g0);
-        out_sa[new_slot] = rec[x].pos;
-        map_val[rec[x].k2] = new_gid;
-        if (keep & (1u << x)) next[o++] = Rec16{0u, new_gid, rec[x].k2, rec[x].pos};
-      }
-    }
+    const u32 es = block_excl_scan<kWaves>(k, tmp, tot) + cs;
+    if (b < ntiles) { carry[3 * b] = eg; carry[3 * b + 1] = er; carry[3 * b + 2] = es; }
     __syncthreads();
-    if (threadIdx.x == kBlock - 1) { carry_g = tile_last_g; carry_r = tile_last_r; }
-    if (threadIdx.x == 0) out_base += tot;
+    if (threadIdx.x == kBlock - 1) { cg = tg; cr = tr; }
+    if (threadIdx.x == 0) cs += tot;
     __syncthreads();
   }
-  if (threadIdx.x == 0) *next_count = out_base;
+  if (threadIdx.x == 0) *next_count = cs;
 }
 
 }  // namespace dc3

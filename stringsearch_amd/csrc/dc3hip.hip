@@ -1085,6 +1085,8 @@ static int doubling_finish(dc3hip_ctx *c, KM km, Acc acc, u32 n, u32 W, u32 *out
   RC(arena_alloc(c, (size_t)t + 16, &map_pos)); RC(arena_alloc(c, (size_t)t + 16, &map_val));
   RC(arena_alloc(c, (size_t)t + 16, &pa)); RC(arena_alloc(c, (size_t)t + 16, &pb));
   RC(arena_alloc(c, (size_t)t + 16, &act)); RC(arena_alloc(c, (size_t)t + 16, &tmp)); RC(arena_alloc(c, (size_t)t + 16, &next));
+  u32 *sums = nullptr, *carry = nullptr;                      // per-tile summaries of the regrouping
+  RC(arena_alloc(c, (size_t)3 * (t / kDblTile + 2), &sums)); RC(arena_alloc(c, (size_t)3 * (t / kDblTile + 2), &carry));
   const u32 kb = bits_of((u64)n);                            // ranks + 1 and slots are below 2^kb
   {
     PhaseScope ps(c, DC3HIP_PH_TIES, t);
@@ -1126,7 +1128,14 @@ static int doubling_finish(dc3hip_ctx *c, KM km, Acc acc, u32 n, u32 W, u32 *out
     RC(radix_sort<Rec16>(c, s1, s1 == X ? Y : X, a, 32, 32 + kb, &s2, DC3HIP_PH_TIES, DC3HIP_PH_TIES, DC3HIP_PH_TIES));
     {
       PhaseScope ps(c, DC3HIP_PH_TIES, a);
-      hipLaunchKernelGGL(k_dbl_regroup, dim3(1), dim3(kBlock), 0, c->stream, (const Rec16 *)s2, a, out_sa, map_val, Z, c->d_words + 2);
+      const u32 ntiles = (a + kDblTile - 1) / kDblTile;
+      hipLaunchKernelGGL((k_dbl_regroup<false>), dim3(ntiles), dim3(kBlock), 0, c->stream, (const Rec16 *)s2, a, sums, (const u32 *)nullptr,
+                         (u32 *)nullptr, (u32 *)nullptr, (Rec16 *)nullptr);
+      KCHECK();
+      hipLaunchKernelGGL(k_dbl_regroup_scan, dim3(1), dim3(kBlock), 0, c->stream, (const u32 *)sums, ntiles, carry, c->d_words + 2);
+      KCHECK();
+      hipLaunchKernelGGL((k_dbl_regroup<true>), dim3(ntiles), dim3(kBlock), 0, c->stream, (const Rec16 *)s2, a, (u32 *)nullptr,
+                         (const u32 *)carry, out_sa, map_val, Z);
       KCHECK();
       HIPC(hipMemcpyAsync(c->h_words + 2, c->d_words + 2, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
     }
