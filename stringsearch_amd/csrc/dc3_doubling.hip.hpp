@@ -32,6 +32,26 @@ __device__ __forceinline__ u32 block_incl_max_scan(u32 v, u32 *tmp) {
   return max(v, pre);
 }
 
+// The whole-text order as its split last pass and tie pass leave it (positions in sa[], 32 image bits in img[]): flags
+// f[i] = window of sa[i] differs from that of sa[i-1], so that the doubling can start from there without the records.
+struct AccSplit {
+  const u32 *sa; const uint8_t *f;
+  __device__ __forceinline__ u32 pos(u32 i) const { return sa[i]; }
+  __device__ __forceinline__ u32 neq(u32 i) const { return f[i]; }
+  __device__ __forceinline__ u32 tail_differs() const { return 1u; }
+};
+template <class KM>
+__global__ __launch_bounds__(kBlock) void k_split_flags(KM km, const u32 *__restrict__ img, const u32 *__restrict__ sa, u32 n,
+                                                       uint8_t *__restrict__ f) {
+  __shared__ uint16_t lcode[256];
+  km.stage(lcode);
+  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    bool ne = true;
+    if (i > 0 && img[i] == img[i - 1]) ne = km.cmp(sa[i - 1], sa[i], lcode) != 0;
+    f[i] = ne ? 1 : 0;
+  }
+}
+
 // tied(i): record i shares its key with a neighbour.  counts[b] = tied records of chunk b
 template <class Acc>
 __global__ __launch_bounds__(kBlock) void k_dbl_count(Acc acc, u32 n, u32 chunk, u32 *counts) {

@@ -657,6 +657,13 @@ static int order_straight(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u
   return name_and_rank<AccRec<Rec>>(c, acc, m02, m0, sa12, rank12, R, sslot, names, mode);
 }
 
+template <class KM, class Acc>
+static int doubling_finish(dc3hip_ctx *c, KM km, Acc acc, u32 n, u32 W, u32 *out_sa, bool *done, bool order_in_place = false);
+// key makers of the whole-text order (they know their window; Key3 is a level's triple)
+template <class KM> struct IsTextKey { static constexpr bool value = false; };
+template <> struct IsTextKey<Key9> { static constexpr bool value = true; };
+template <> struct IsTextKey<KeyT> { static constexpr bool value = true; };
+
 // Core of the prefix-sort + tie-refine ordering: `ha` holds nrec packed (image << pbits | pos) records of the
 // positions to order; on return (ok) h = records sorted by the full key, f[i] = key differs from predecessor.
 template <class KM>
@@ -688,6 +695,24 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
       c->stats.level_tied[depth] = c->h_words[11];
       if ((double)c->h_words[11] > kHybridMaxMeasured * (double)nrec) return E_OK;   // *ok stays false -> straight LSD
       if (c->h_words[10] == 0 && c->h_words[12] == 0) { *emitted_distinct = true; *h_out = nullptr; *ok = true; return E_OK; }
+      if constexpr (IsTextKey<KM>::value) {
+        // few windows repeat and no group was too large for the tie pass: the positions are in window order in the SA
+        // buffer; flag the window changes and let the prefix doubling finish from there (no records needed)
+        if (c->h_words[10] == 0 && c->h_words[12] <= nrec / 128 && !c->no_doubling && depth == 0) {
+          {
+            PhaseScope ps(c, DC3HIP_PH_TIES, nrec);
+            hipLaunchKernelGGL((k_split_flags<KM>), dim3(grid_for(c, nrec)), dim3(kBlock), 0, c->stream, km, (const u32 *)img,
+                               (const u32 *)emit_sa, nrec, f);
+            KCHECK();
+          }
+          // (the doubling reads the order from the very buffer whose tied slots it rewrites: a slot of a tied group always
+          //  holds SOME member of that group, whose window — all the binary searches look at — is the group's)
+          AccSplit acc; acc.sa = emit_sa; acc.f = f;
+          bool finished = false;
+          RC((doubling_finish<KM, AccSplit>(c, km, acc, nrec, km.window_syms(), emit_sa, &finished, true)));
+          if (finished) { *emitted_distinct = true; *h_out = nullptr; *ok = true; c->stats.level_sorted[0] = 6; return E_OK; }
+        }
+      }
       // keys repeat (or a large group): the records are needed after all
       RC(radix_redo_last(c, lp, nrec, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT8_DOWN));
     }
@@ -1056,7 +1081,7 @@ static int finish_position_order(dc3hip_ctx *c, Acc acc, Map mp, u32 nrec, u32 m
 // positions are tied, the arena is short, or the rounds do not converge.
 static constexpr u32 kDoublingMaxTied = 4u << 20;          // records; and at most 1/64 of the positions
 template <class KM, class Acc>
-static int doubling_finish(dc3hip_ctx *c, KM km, Acc acc, u32 n, u32 W, u32 *out_sa, bool *done) {
+static int doubling_finish(dc3hip_ctx *c, KM km, Acc acc, u32 n, u32 W, u32 *out_sa, bool *done, bool order_in_place) {
   *done = false;
   if (c->no_doubling || !out_sa || n < 2) return E_OK;
   const ArenaMark mk = arena_mark(c);
@@ -1090,9 +1115,11 @@ static int doubling_finish(dc3hip_ctx *c, KM km, Acc acc, u32 n, u32 W, u32 *out
   const u32 kb = bits_of((u64)n);                            // ranks + 1 and slots are below 2^kb
   {
     PhaseScope ps(c, DC3HIP_PH_TIES, t);
-    // the order as it stands (final for every untied position)
-    hipLaunchKernelGGL((k_emit_sorted<Acc>), dim3(grid_for(c, n)), dim3(kBlock), 0, c->stream, acc, n, 0u, out_sa, (Rec8 *)nullptr);
-    KCHECK();
+    // the order as it stands (final for every untied position) — unless acc already reads it from out_sa
+    if (!order_in_place) {
+      hipLaunchKernelGGL((k_emit_sorted<Acc>), dim3(grid_for(c, n)), dim3(kBlock), 0, c->stream, acc, n, 0u, out_sa, (Rec8 *)nullptr);
+      KCHECK();
+    }
     hipLaunchKernelGGL((k_dbl_collect<Acc>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, acc, n, ck.chunk, (const u32 *)counts, slot,
                        pos, start);
     KCHECK();
