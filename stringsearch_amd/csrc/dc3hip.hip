@@ -669,7 +669,9 @@ template <> struct IsTextKey<KeyT> { static constexpr bool value = true; };
 template <class KM>
 static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Rec8 *ha, Rec8 *hb, u32 nrec,
                             Rec8 **h_out, uint8_t *f, bool *ok, int depth, u32 *emit_sa = nullptr, u32 skip = 0,
-                            bool *emitted_distinct = nullptr, u32 *first_table = nullptr) {
+                            bool *emitted_distinct = nullptr, u32 *first_table = nullptr, bool whole_text = false) {
+  // whole_text: the records are ALL positions of the text (single device): few repeated windows may be settled here by
+  // prefix doubling.  (A rank of the global mode orders only its image range and must not: ranks are global.)
   *ok = false;
   if (emitted_distinct) *emitted_distinct = false;
   Rec8 *h = nullptr;
@@ -698,7 +700,7 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
       if constexpr (IsTextKey<KM>::value) {
         // few windows repeat and no group was too large for the tie pass: the positions are in window order in the SA
         // buffer; flag the window changes and let the prefix doubling finish from there (no records needed)
-        if (c->h_words[10] == 0 && c->h_words[12] <= nrec / 128 && !c->no_doubling && depth == 0) {
+        if (whole_text && c->h_words[10] == 0 && c->h_words[12] <= nrec / 128 && !c->no_doubling && depth == 0) {
           {
             PhaseScope ps(c, DC3HIP_PH_TIES, nrec);
             hipLaunchKernelGGL((k_split_flags<KM>), dim3(grid_for(c, nrec)), dim3(kBlock), 0, c->stream, km, (const u32 *)img,
@@ -1195,7 +1197,7 @@ static int order_all_positions(dc3hip_ctx *c, KM km, Map mp, u32 m, u32 kbits, c
   }
   bool sorted_ok = false, distinct = false;
   RC((hybrid_sort_core<KM>(c, km, kbits, hm, ha, hb, nrec, &h, f, &sorted_ok, depth, out_rank ? nullptr : out_sa, dummy,
-                           &distinct, first_table)));
+                           &distinct, first_table, std::is_same<Map, MapText>::value && dummy == 0 && !out_rank)));
   if (sorted_ok && distinct) {
     *state = 1;                            // the tie pass already wrote the suffix array
   } else if (sorted_ok) {
