@@ -1069,7 +1069,7 @@ static int wide_key(dc3hip_gctx *G, u32 sigma, WideKey *k, u32 *ibits_out) {
   u32 J = 1; u64 SJ = sigma;
   while (J < kWideMaxImageSyms && (SJ >> std::min<u32>(ibits + 2, 62)) == 0 && SJ * sigma < (1ull << 63)) { SJ *= sigma; J++; }
   if ((SJ >> ibits) == 0) { set_err("wide global mode: alphabet of %u symbols cannot fill a %u-bit image", sigma, ibits); return E_TOOBIG; }
-  k->t = G->w_text; k->code = G->c->d_code; k->n = (u64)G->total_n; k->sigma = sigma; k->J = J; k->W = 64;
+  k->t = G->w_text; k->code = G->c->d_code; k->n = (u64)G->total_n; k->sigma = sigma; k->J = J; k->W = kWideWindow;
   k->mfix = (u64)(((((unsigned __int128)1) << (64 + ibits)) - 1) / SJ);
   k->P1 = SJ / sigma;
   *ibits_out = ibits;

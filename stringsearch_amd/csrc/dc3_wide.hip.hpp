@@ -4,7 +4,7 @@
 // and the text's windows must all be distinct (high-entropy inputs: BASELINE.json configs[3] random bytes at 4 GiB,
 // configs[4] random DNA at 16 GiB).  A text whose windows repeat is refused (no recursion with 64-bit positions).
 //
-// Window = W symbols of the text (W = 64, or the whole rest of the text if shorter); its order is decided lazily, a
+// Window = W symbols of the text (W = kWideWindow = 256, or the whole rest of the text if shorter); its order is decided lazily, a
 // 4-byte word at a time (wide_cmp).  Sort image = the first J symbols in base sigma (digit = code - 1, past the end = 0)
 // scaled to `ibits` bits, as KeyT's (dc3_order.hip.hpp).
 #pragma once
@@ -18,6 +18,7 @@ struct WideKey {
   u64 mfix, P1;             // floor((2^(64+ibits) - 1) / sigma^J), sigma^(J-1)
 };
 constexpr u32 kWideMaxImageSyms = 48;
+constexpr u32 kWideWindow = 256;          // symbols compared before two positions count as having the same window
 
 __device__ __forceinline__ u64 wide_pos(const Rec16 &r) { return ((u64)r.k2 << 32) | r.pos; }
 __device__ __forceinline__ u64 wide_img(const Rec16 &r) { return ((u64)r.k1 << 32) | r.k0; }

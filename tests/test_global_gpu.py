@@ -367,7 +367,10 @@ def test_wide_mode_small_texts_match_the_oracle(ss, oracle, P):
             with pytest.raises(ss.Dc3HipError) as ei:
                 g.ranks[0].shard_sa(np.uint32)
             assert ei.value.code == -4
-        rep = cases["dna"].copy(); rep[1_000_000:1_000_100] = rep[5:105]
+        short = cases["dna"].copy(); short[2_000_000:2_000_100] = short[5:105]        # a repeat shorter than the 256-symbol window: built
+        g.set_text(short); g.build()
+        assert np.array_equal(g.sa(), want_sa(oracle, short)) and g.sufcheck() == 0
+        rep = cases["dna"].copy(); rep[1_000_000:1_000_400] = rep[5:405]               # a longer one: refused
         for bad in (rep, np.full(100_000, 65, dtype=np.uint8)):
             g.set_text(bad)
             with pytest.raises(ss.Dc3HipError) as ei:

@@ -1,8 +1,8 @@
 """GPU box soak of the WIDE global mode (64-bit positions) forced onto small texts: random (P, n, alphabet, structure) against
 the oracle through the loopback transport.  A text is either built — then the shards must equal the oracle's suffix array and
-the collective verifier must accept them — or refused with -4, which is only legitimate when some 64-symbol window of the
-text repeats (checked on the oracle's array: two neighbouring suffixes sharing 64 symbols, or one of them ending within
-them ... the library's own criterion is 'equal within 64 symbols', sentinel included) or the text has a single symbol.
+the collective verifier must accept them — or refused with -4, which is only legitimate when some 256-symbol window of the
+text repeats (checked on the oracle's array: two neighbouring suffixes sharing 256 symbols, or one of them ending within
+them ... the library's own criterion is 'equal within 256 symbols', sentinel included) or the text has a single symbol.
 Usage: python tools/global_wide_fuzz.py SECONDS [SEED]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,7 +17,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 
 
-def window_repeats(t, sa, w=64):
+def window_repeats(t, sa, w=256):
     """does any pair of neighbouring suffixes agree on w symbols (both at least w long)?"""
     n = len(t)
     a, b = sa[:-1], sa[1:]
@@ -42,10 +42,10 @@ while time.time() - t0 < budget:
     t = rng.integers(0, sigma, n).astype(np.uint8)
     kind = int(rng.integers(0, 4))
     if kind == 1 and n > 200:                      # a planted repeat, shorter or longer than the window
-        ln = min(int(rng.integers(8, 200)), n // 3); a = int(rng.integers(0, n - ln)); b = int(rng.integers(0, n - ln))
+        ln = min(int(rng.integers(8, 600)), n // 3); a = int(rng.integers(0, n - ln)); b = int(rng.integers(0, n - ln))
         t[b:b + ln] = t[a:a + ln]
     elif kind == 2 and n > 100:                    # a run of the smallest symbol, inside or at the end
-        ln = min(int(rng.integers(4, 120)), n // 3); a = int(rng.integers(0, n - ln)) if rng.random() < 0.5 else n - ln
+        ln = min(int(rng.integers(4, 500)), n // 3); a = int(rng.integers(0, n - ln)) if rng.random() < 0.5 else n - ln
         t[a:a + ln] = 0
     want = o.ref_sufsort(t.tobytes()) if o.ref is not None else o.sufsort(t.tobytes())
     with ss.LoopbackGroup(P, n) as g:
