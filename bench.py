@@ -348,6 +348,26 @@ def main():
                                "shard_counts": [x["shard_count"] for x in gst]})
                     assert gl[-1]["checksum_equal_single_device"], "global-mode shards differ from the single-device suffix array"
         out["global_mode_loopback"] = gl
+        # One suffix array of MORE than 2^32 positions (what BASELINE.json configs[3] / configs[4] need; 64-bit positions,
+        # "wide" global contexts): 2^32 + 2^20 + 3 random bytes over two loopback ranks time-sharing this GPU,
+        # verified by the library's collective checker (no single-device array exists at this size).
+        if per_gpu == 1 << 30 and not args.no_verify:
+            wn = (1 << 32) + (1 << 20) + 3
+            try:
+                with ss.LoopbackGroup(2, wn, device=local_rank) as g:
+                    g.generate(wn, 6, 0)
+                    g.build()
+                    t1 = time.perf_counter(); g.build(); wall = (time.perf_counter() - t1) * 1e3
+                    gst = g.stats()
+                    out["global_mode_beyond_2pow32"] = {
+                        "input": f"{wn} random bytes", "ranks": 2, "transport": "loopback (both ranks on this GPU: wall = sum of their work)",
+                        "wall_ms": wall, "MB/s_of_total_work": wn / wall / 1e3, "global_sufcheck": g.sufcheck(),
+                        "shards_tile_0_n": gst[0]["shard_first"] == 0 and gst[1]["shard_first"] == gst[0]["shard_count"]
+                                           and gst[0]["shard_count"] + gst[1]["shard_count"] == wn,
+                        "positions": "64-bit", "bytes_in_per_rank": [x["comm_bytes_in"] for x in gst]}
+                    assert out["global_mode_beyond_2pow32"]["global_sufcheck"] == 0 and out["global_mode_beyond_2pow32"]["shards_tile_0_n"]
+            except ss.Dc3HipError as e:
+                out["global_mode_beyond_2pow32"] = {"skipped": str(e)}
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
