@@ -231,7 +231,7 @@ DC3HIP_API int32_t dc3hip_ctx_debug_radix_pass_u64(dc3hip_ctx *ctx, const uint64
  * Environment: DC3HIP_GLOBAL_LOCAL_MAX (levels up to this length are finished by every rank on its own replicated
  * copy, default 2^22), DC3HIP_GLOBAL_NO_TEXT_ORDER=1 (skip the distributed whole-text order).
  * WIDE contexts (max_total_n > DC3HIP_MAX_N, up to 2^40; or DC3HIP_GLOBAL_FORCE_WIDE=1): positions are 64-bit, and only
- * the distributed whole-text order exists at that size — the text is built if all its 256-symbol windows are distinct
+ * the distributed whole-text order exists at that size — the text is built if all its 256-symbol windows are distinct (a few repeats of up to 8192 symbols are settled too)
  * (high-entropy inputs: BASELINE.json configs[3] random bytes at 4 GiB, configs[4] random DNA at 16 GiB); a text with a
  * repeated window is refused with -4 (no recursion with 64-bit positions), as is a rank whose share would exceed
  * DC3HIP_MAX_N suffixes.  Shards are fetched with dc3hip_global_get_shard_i64 (…_u32 returns -4) and verified with the

@@ -1169,14 +1169,21 @@ static int gbuild_wide(dc3hip_gctx *G) {
   }
   Rec16 *h = G->w_ra;
   if (nrec) RC(radix_sort<Rec16>(c, G->w_ra, G->w_rb, nrec, 0, ibits, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT12_DOWN));
-  HIPC(hipMemsetAsync(c->d_words + 10, 0, 3 * sizeof(u32), c->stream));
-  if (nrec) {
-    PhaseScope ps(c, DC3HIP_PH_TIES, nrec);
-    hipLaunchKernelGGL(k_wide_ties, dim3(grid_for(c, nrec)), dim3(kBlock), 0, c->stream, (const Rec16 *)h, nrec, k, G->w_shard, c->d_words + 10);
-    KCHECK();
+  // tie pass; if a few windows agree on kWideWindow symbols it is repeated comparing kWideWindowDeep symbols (the compare
+  // is lazy, so the depth only costs where windows really agree that far: repeats up to that length are settled, longer
+  // ones refused)
+  for (u32 depth : {kWideWindow, kWideWindowDeep}) {
+    k.W = depth;
+    HIPC(hipMemsetAsync(c->d_words + 10, 0, 3 * sizeof(u32), c->stream));
+    if (nrec) {
+      PhaseScope ps(c, DC3HIP_PH_TIES, nrec);
+      hipLaunchKernelGGL(k_wide_ties, dim3(grid_for(c, nrec)), dim3(kBlock), 0, c->stream, (const Rec16 *)h, nrec, k, G->w_shard, c->d_words + 10);
+      KCHECK();
+    }
+    HIPC(hipMemcpyAsync(c->h_words + 10, c->d_words + 10, 3 * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    if (c->h_words[10] != 0 || c->h_words[12] == 0 || c->h_words[12] > (1u << 20)) break;
   }
-  HIPC(hipMemcpyAsync(c->h_words + 10, c->d_words + 10, 3 * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
-  HIPC(hipStreamSynchronize(c->stream));
   arena_release(c, mk);
   c->stats.level_tied[0] = c->h_words[11];
   const bool mine_ok = c->h_words[10] == 0 && c->h_words[12] == 0;
@@ -1551,7 +1558,7 @@ int32_t dc3hip_global_sufcheck(dc3hip_gctx *G) {
     HIPC(hipMemsetAsync(c->d_words + 20, 0, sizeof(u32), c->stream));
     if (G->shard_count > 0) {
       hipLaunchKernelGGL(k_wide_check, dim3(grid_for(c, G->shard_count)), dim3(kBlock), 0, c->stream, (const u64 *)G->w_shard,
-                         (u32)G->shard_count, next_first, k, 4096u, c->d_words + 20);
+                         (u32)G->shard_count, next_first, k, 4 * kWideWindowDeep, c->d_words + 20);
       KCHECK();
     }
     HIPC(hipMemcpyAsync(c->h_words + 20, c->d_words + 20, sizeof(u32), hipMemcpyDeviceToHost, c->stream));

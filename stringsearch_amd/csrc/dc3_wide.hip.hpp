@@ -18,7 +18,8 @@ struct WideKey {
   u64 mfix, P1;             // floor((2^(64+ibits) - 1) / sigma^J), sigma^(J-1)
 };
 constexpr u32 kWideMaxImageSyms = 48;
-constexpr u32 kWideWindow = 256;          // symbols compared before two positions count as having the same window
+constexpr u32 kWideWindow = 256;          // symbols compared before two positions count as having the same window ...
+constexpr u32 kWideWindowDeep = 8192;     // ... and in the second attempt, made when only few windows agree on 256 symbols
 
 __device__ __forceinline__ u64 wide_pos(const Rec16 &r) { return ((u64)r.k2 << 32) | r.pos; }
 __device__ __forceinline__ u64 wide_img(const Rec16 &r) { return ((u64)r.k1 << 32) | r.k0; }

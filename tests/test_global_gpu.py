@@ -370,7 +370,10 @@ def test_wide_mode_small_texts_match_the_oracle(ss, oracle, P):
         short = cases["dna"].copy(); short[2_000_000:2_000_100] = short[5:105]        # a repeat shorter than the 256-symbol window: built
         g.set_text(short); g.build()
         assert np.array_equal(g.sa(), want_sa(oracle, short)) and g.sufcheck() == 0
-        rep = cases["dna"].copy(); rep[1_000_000:1_000_400] = rep[5:405]               # a longer one: refused
+        mid = cases["dna"].copy(); mid[1_000_000:1_000_400] = mid[5:405]               # a longer one: settled by the deeper second attempt
+        g.set_text(mid); g.build()
+        assert np.array_equal(g.sa(), want_sa(oracle, mid)) and g.sufcheck() == 0
+        rep = cases["dna"].copy(); rep[1_000_000:1_020_000] = rep[5:20_005]            # beyond 8192 symbols: refused
         for bad in (rep, np.full(100_000, 65, dtype=np.uint8)):
             g.set_text(bad)
             with pytest.raises(ss.Dc3HipError) as ei:

@@ -42,7 +42,7 @@ while time.time() - t0 < budget:
     t = rng.integers(0, sigma, n).astype(np.uint8)
     kind = int(rng.integers(0, 4))
     if kind == 1 and n > 200:                      # a planted repeat, shorter or longer than the window
-        ln = min(int(rng.integers(8, 600)), n // 3); a = int(rng.integers(0, n - ln)); b = int(rng.integers(0, n - ln))
+        ln = min(int(rng.integers(8, 600)) if rng.random() < 0.7 else int(rng.integers(600, 30000)), n // 3); a = int(rng.integers(0, n - ln)); b = int(rng.integers(0, n - ln))
         t[b:b + ln] = t[a:a + ln]
     elif kind == 2 and n > 100:                    # a run of the smallest symbol, inside or at the end
         ln = min(int(rng.integers(4, 500)), n // 3); a = int(rng.integers(0, n - ln)) if rng.random() < 0.5 else n - ln
