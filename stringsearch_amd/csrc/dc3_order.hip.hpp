@@ -352,6 +352,7 @@ struct Key3 {
 };
 struct Key9 {
   SymU8 S; u32 B /* sigma+1 */, B3 /* B^3 */;
+  u32 deep = 0;     // tie passes only: compare this many symbols instead of the window's 9 (second attempt, few repeats)
   __device__ __forceinline__ void stage(uint16_t *lds) const { S.stage(lds); }
   __device__ __forceinline__ Rec16 make(u32 p, const uint16_t *lds) const {
     u32 w[3]; __builtin_memcpy(w, S.t + p, 12);        // one unaligned 12-byte load (64 zero bytes pad the text)
@@ -365,7 +366,7 @@ struct Key9 {
   }
   __device__ __forceinline__ Rec8 image(u32 p, const uint16_t *lds, const HiMap &hm) const { return hyb_rec(make(p, lds), hm); }
   __device__ __forceinline__ u64 image_hi(u32 p, const uint16_t *lds, const HiMap &hm) const { return hyb_hi(make(p, lds), hm); }
-  __device__ __forceinline__ int cmp(u32 p, u32 q, const uint16_t *lds) const { return window_cmp(S, p, q, 9, lds); }
+  __device__ __forceinline__ int cmp(u32 p, u32 q, const uint16_t *lds) const { return window_cmp(S, p, q, deep ? deep : 9u, lds); }
   __host__ __device__ u32 window_syms() const { return 9; }
 };
 // KeyT = 3*L symbols of the text as three limbs of L symbols in base B (limb base BL = B^L < 2^32): the longer window
@@ -379,6 +380,7 @@ struct Key9 {
 constexpr u32 kKeyTMaxImageSyms = 48;
 struct KeyT {
   SymU8 S; u32 B, BL /* B^L */, L, sigma, J;
+  u32 deep = 0;     // as Key9::deep
   __device__ __forceinline__ void stage(uint16_t *lds) const { S.stage(lds); }
   __device__ __forceinline__ Rec16 make(u32 p, const uint16_t *lds) const {
     u32 limb[3];
@@ -396,7 +398,7 @@ struct KeyT {
     }
     return make_rec(limb[0], limb[1], limb[2], BL, p);
   }
-  __device__ __forceinline__ int cmp(u32 p, u32 q, const uint16_t *lds) const { return window_cmp(S, p, q, 3 * L, lds); }
+  __device__ __forceinline__ int cmp(u32 p, u32 q, const uint16_t *lds) const { return window_cmp(S, p, q, deep ? deep : 3 * L, lds); }
   __host__ __device__ u32 window_syms() const { return 3 * L; }
   __device__ __forceinline__ u64 image_hi(u32 p, const uint16_t *lds, const HiMap &hm) const {
     const u32 nw = (J + 3) / 4;
@@ -849,7 +851,7 @@ struct TieKey<Key9> {
   __device__ __forceinline__ void load(const Key9 &, u32 pp, const uint16_t *) { p = pp; }
   __device__ __forceinline__ u32 pos() const { return p; }
   static __device__ __forceinline__ int cmp3(const Key9 &km, const uint16_t *lds, const TieKey &a, const TieKey &b) {
-    return window_cmp(km.S, a.p, b.p, 9, lds);
+    return km.cmp(a.p, b.p, lds);
   }
 };
 // The common case in one pass over the sorted records: the thread that sees the start of a tied group of at

@@ -657,6 +657,7 @@ static int order_straight(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u
   return name_and_rank<AccRec<Rec>>(c, acc, m02, m0, sa12, rank12, R, sslot, names, mode);
 }
 
+static constexpr u32 kDeepSyms = 2048;                     // symbols compared by the second tie pass of a whole-text order
 template <class KM, class Acc>
 static int doubling_finish(dc3hip_ctx *c, KM km, Acc acc, u32 n, u32 W, u32 *out_sa, bool *done, bool order_in_place = false);
 // key makers of the whole-text order (they know their window; Key3 is a level's triple)
@@ -698,6 +699,22 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
       if ((double)c->h_words[11] > kHybridMaxMeasured * (double)nrec) return E_OK;   // *ok stays false -> straight LSD
       if (c->h_words[10] == 0 && c->h_words[12] == 0) { *emitted_distinct = true; *h_out = nullptr; *ok = true; return E_OK; }
       if constexpr (IsTextKey<KM>::value) {
+        // few windows repeat: a second tie pass that compares kDeepSyms symbols instead of the window settles the repeats
+        // shorter than that (the compare is lazy: the depth only costs where windows really agree that far) — single
+        // device and global mode alike
+        if (c->h_words[10] == 0 && c->h_words[12] <= nrec / 4096 + 16 && !c->no_doubling) {
+          KM kd = km; kd.deep = kDeepSyms;
+          {
+            PhaseScope ps(c, DC3HIP_PH_TIES, nrec);
+            HIPC(hipMemsetAsync(c->d_words + 10, 0, 3 * sizeof(u32), c->stream));
+            hipLaunchKernelGGL((k_tie_resolve_split<KM>), dim3(grid_for(c, nrec / 4 + 1)), dim3(kBlock), 0, c->stream, kd,
+                               (const u32 *)img, emit_sa, nrec, c->d_words + 10);
+            KCHECK();
+            HIPC(hipMemcpyAsync(c->h_words + 10, c->d_words + 10, 3 * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+          }
+          HIPC(hipStreamSynchronize(c->stream));
+          if (c->h_words[10] == 0 && c->h_words[12] == 0) { *emitted_distinct = true; *h_out = nullptr; *ok = true; return E_OK; }
+        }
         // few windows repeat and no group was too large for the tie pass: the positions are in window order in the SA
         // buffer; flag the window changes and let the prefix doubling finish from there (no records needed)
         if (whole_text && c->h_words[10] == 0 && c->h_words[12] <= nrec / 128 && !c->no_doubling && depth == 0) {

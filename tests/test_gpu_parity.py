@@ -518,7 +518,9 @@ def test_small_alphabet_long_windows(ss, oracle):
         assert w12["text_sort_state"] == seen[()]["text_sort_state"] and w12["downsweep_launches"][1] > 0, (label, w12["text_sort_state"])
         if label in ("dna_repeat_3000", "dna_repeat_into_end"):
             # few repeated windows: settled at level 0 by prefix doubling of the tied positions (level_sorted 6) ...
-            assert seen[()]["text_sort_state"] == 1 and seen[()]["level_sorted"][0] == 6 and seen[()]["levels"] == 1, (label, seen[()]["level_sorted"])
+            # (a 45-symbol repeat is already settled by the second tie pass, which compares 2048 symbols: level_sorted 5)
+            want0 = 6 if label == "dna_repeat_3000" else 5
+            assert seen[()]["text_sort_state"] == 1 and seen[()]["level_sorted"][0] == want0 and seen[()]["levels"] == 1, (label, seen[()]["level_sorted"])
             assert w12["level_sorted"][0] == 6, label
             # ... or, without it, handed to level 1 as its sorted samples
             for key in (("DC3HIP_NO_DOUBLING",), ("DC3HIP_NO_DOUBLING", "DC3HIP_TEXT_ORDER12")):
