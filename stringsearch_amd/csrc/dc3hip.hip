@@ -823,6 +823,25 @@ static int hybrid12_refine(dc3hip_ctx *c, KM km, u32 kbits, Rec12 *h, u32 n, uin
   tied = c->h_words[11];
   c->stats.level_tied[depth] = tied;
   general = c->h_words[10] != 0;
+  if constexpr (IsTextKey<KM>::value) {
+    // whole-text order: a few windows agree completely -> the tie pass once more, comparing kDeepSyms symbols (see
+    // hybrid_sort_core); settles the repeats shorter than that
+    if (emit_sa && !general && c->h_words[12] > 0 && c->h_words[12] <= n / 4096 + 16 && !c->no_doubling) {
+      KM kd = km; kd.deep = kDeepSyms;
+      {
+        PhaseScope ps(c, DC3HIP_PH_TIES, n);
+        HIPC(hipMemsetAsync(f, 1, (size_t)n, c->stream));
+        HIPC(hipMemsetAsync(c->d_words + 10, 0, 3 * sizeof(u32), c->stream));
+        hipLaunchKernelGGL((k_tie_resolve12<KM>), dim3(grid_for(c, n / 4 + 1)), dim3(kBlock), 0, c->stream, kd, h, n, f,
+                           c->d_words + 10, emit_sa);
+        KCHECK();
+        HIPC(hipMemcpyAsync(c->h_words + 10, c->d_words + 10, 3 * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+      }
+      HIPC(hipStreamSynchronize(c->stream));
+      tied = c->h_words[11];
+      general = c->h_words[10] != 0;
+    }
+  }
   // no group overflowed and no full key repeats: the positions the tie pass wrote to emit_sa are the sorted order
   if (distinct) *distinct = emit_sa && !general && c->h_words[12] == 0;
   if ((double)tied > std::max(kHybridMaxMeasured, c->hybrid12_max_pred + 0.1) * (double)n) return E_OK;
