@@ -753,6 +753,30 @@ def test_beyond_2pow31_needs_64bit_indices(ss):
     assert ss.lib().dc3hip_sufsort_ex(t.ctypes.data, sa.ctypes.data, (1 << 31) + 5, ctypes.byref(o)) == -4
 
 
+def test_configs4_chunk_through_the_ffi_passes_the_reference_sufcheck64(ss):
+    """BASELINE.json configs[4] (16 GiB DNA over 8 GPUs, i64 indices) per GPU = one sacapart chunk of 2 GiB + 1 byte: through the
+    REAL FFI entry with host buffers, dc3hip_sufsort_i64(T, SA, n), and checked by the REFERENCE's own sufcheck() built with
+    64-bit indices (oracle/_ref/libdivsufsort64_ref.so, c-sources/utils.c:160-241) — rc 0 is equivalent to equality with
+    divsufsort64's output.  (Host memory: 2 GiB of text + 16 GiB of int64 indices.)"""
+    import ctypes
+    from conftest import ROOT
+    path = os.path.join(ROOT, "oracle", "_ref", "libdivsufsort64_ref.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libdivsufsort64_ref.so did not travel with the snapshot")
+    ref = ctypes.CDLL(path)
+    ref.sufcheck.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32]
+    ref.sufcheck.restype = ctypes.c_int32
+    n = (1 << 31) + 1
+    with ss.Context(n) as c:
+        c.generate(n, 5, 1, offset=7 * n)          # chunk 7 of the 16 GiB stream
+        text = c.text()
+    sa = np.zeros(n, dtype=np.int64)
+    assert ss.lib().dc3hip_sufsort_i64(text.ctypes.data, sa.ctypes.data, n) == 0, ss.last_error()
+    assert int(sa.max()) == n - 1 and int(sa.min()) == 0
+    assert int(ref.sufcheck(text.ctypes.data, sa.ctypes.data, n, 0)) == 0
+    ss.lib().dc3hip_release_cache()
+
+
 def test_sample_count_beyond_2pow31(ss):
     """3.4e9 random bytes: more than 2^31 sample suffixes at level 0 (merge-path midpoints, window partition with
     > 512 top buckets, 32-bit position fields completely used).  Regression test for a u32 midpoint overflow
