@@ -206,6 +206,15 @@ typedef struct dc3hip_stats {
   uint64_t trace_sa0[DC3HIP_MAX_LEVELS];
   uint64_t trace_sa[DC3HIP_MAX_LEVELS];
   int64_t  trace_names[DC3HIP_MAX_LEVELS];
+  /* bucket (MSD) ordering of the prefix-sort words (dc3_msd.hip.hpp), which replaces the stable LSD passes over
+   * 8-byte records where the key images are well spread: k_msd_part = one non-stable partition pass with XCD-grouped
+   * reservation (2^30 words per launch at 1 GiB), k_msd_local = the in-LDS order of the sub-buckets.
+   * msd_sorts = sorts that took this path in the last build, msd_fallbacks = sorts that gave it up (a sub-bucket too
+   * large for LDS) and ran the LSD passes instead. */
+  double  msd_part_ms;  int64_t msd_part_launches;  int64_t msd_part_elems;
+  double  msd_local_ms; int64_t msd_local_launches; int64_t msd_local_elems;
+  int32_t msd_sorts, msd_fallbacks;
+  int64_t msd_max_subbucket;              /* largest sub-bucket of the last MSD sort */
 } dc3hip_stats;
 
 DC3HIP_API int32_t dc3hip_ctx_stats(dc3hip_ctx *ctx, dc3hip_stats *out);

@@ -42,7 +42,10 @@ class Stats(ctypes.Structure):
                 ("arena_bytes", ctypes.c_int64),
                 ("arena_peak", ctypes.c_int64), ("text_sort_state", ctypes.c_int32), ("trace_on", ctypes.c_int32),
                 ("trace_sa12", ctypes.c_uint64 * MAX_LEVELS), ("trace_sa0", ctypes.c_uint64 * MAX_LEVELS),
-                ("trace_sa", ctypes.c_uint64 * MAX_LEVELS), ("trace_names", ctypes.c_int64 * MAX_LEVELS)]
+                ("trace_sa", ctypes.c_uint64 * MAX_LEVELS), ("trace_names", ctypes.c_int64 * MAX_LEVELS),
+                ("msd_part_ms", ctypes.c_double), ("msd_part_launches", ctypes.c_int64), ("msd_part_elems", ctypes.c_int64),
+                ("msd_local_ms", ctypes.c_double), ("msd_local_launches", ctypes.c_int64), ("msd_local_elems", ctypes.c_int64),
+                ("msd_sorts", ctypes.c_int32), ("msd_fallbacks", ctypes.c_int32), ("msd_max_subbucket", ctypes.c_int64)]
 
     def as_dict(self):
         return {
@@ -64,6 +67,10 @@ class Stats(ctypes.Structure):
             "gather_ms": self.gather_ms, "gather_launches": self.gather_launches, "gather_elems": self.gather_elems,
             "arena_bytes": self.arena_bytes, "arena_peak": self.arena_peak,
             "text_sort_state": self.text_sort_state,
+            "msd_part_ms": self.msd_part_ms, "msd_part_launches": self.msd_part_launches, "msd_part_elems": self.msd_part_elems,
+            "msd_local_ms": self.msd_local_ms, "msd_local_launches": self.msd_local_launches,
+            "msd_local_elems": self.msd_local_elems, "msd_sorts": self.msd_sorts, "msd_fallbacks": self.msd_fallbacks,
+            "msd_max_subbucket": self.msd_max_subbucket,
             "trace": None if not self.trace_on else [
                 {"n": self.level_n[i], "sa12": self.trace_sa12[i], "sa0": self.trace_sa0[i], "sa": self.trace_sa[i],
                  "names": self.trace_names[i]} for i in range(self.levels)],

@@ -1,0 +1,331 @@
+// dc3_msd.hip.hpp — bucket (MSD) ordering of packed (image << pbits | pos) words.
+// Part of the gfx950 kernel set of libdc3hip (see dc3_kernels.hip.hpp for the overview); namespace dc3.
+//
+// The prefix sort of the tie-refine orderings (dc3_order.hip.hpp) sorts 64-bit words by their image bits; the
+// words are all distinct (the position is part of the word), so "ascending by the whole word" is the one result every
+// correct sort produces — the stable LSD passes of lib.rs:15-39 are one way to get it, and stability is only what
+// LSD needs of its own passes.  This file gets the same array with three passes instead of four or five, none of
+// which has to be stable:
+//   pass 1   k_msd_part<false>  partition by the top d1 image bits          (sizes: digit table of the pack kernel)
+//   pass 2   k_msd_part<true>   partition every bucket by the next d2 bits  (sizes: k_msd_hist2 + k_msd_scan2a/c)
+//   pass 3   k_msd_local        every sub-bucket (about a thousand words) is ordered inside LDS: counting sort on the
+//                               next bits into ~one word per bin, then each word counts the smaller words of its bin
+// A partition pass needs no per-(digit, chunk) table and no row scan: a tile ranks its words with one returning LDS
+// atomic each and reserves its run in every bucket with one global atomicAdd per (tile, digit).
+//
+// XCD-aware placement (measured on MI355X, profiles/r03a_radix_lab.jsonl: 2^30 words, 1024 buckets, 7.0 -> 3.9 ms per
+// pass).  A tile's run in a bucket is 8-16 words, i.e. mostly PARTIAL 128-byte lines, and the neighbouring run belongs
+// to whichever tile reserved next.  The eight XCDs have private L2s: when the neighbours run on different XCDs both
+// halves of the shared line leave their L2 as partial writes.  So every bucket is split into eight regions, one per
+// group of blocks with equal blockIdx % 8 — the blocks that share an XCD under the round-robin placement the
+// dispatcher is observed to use — and a group reserves only inside its own region: neighbouring runs are then written
+// through ONE L2 within a microsecond of each other and leave it as full lines.  The groups own contiguous eighths of
+// the input (block j works tile (j % 8) * cpx + j / 8), so the per-group bucket sizes come straight from the pack
+// kernel's per-chunk digit table.  Placement is a speed assumption only: any block may run anywhere, the result does
+// not change.
+//
+// Sub-bucket sizes depend on the data: k_msd_scan2a reports the largest, and the host falls back to the LSD passes
+// when it exceeds the local sort's capacity (skewed images; the orderings that call this are only taken on
+// high-entropy input).
+#pragma once
+
+namespace dc3 {
+
+// The records are Rec8 {key = high half, val = low half} in memory (dc3_radix.hip.hpp: rec8_word); as one 8-byte load
+// that is the word with its halves exchanged — msd_word() puts them back (a register rename, no instruction).
+__device__ __forceinline__ u64 msd_word(u64 mem) { return (mem << 32) | (mem >> 32); }
+
+constexpr int kMsdNW = 16, kMsdIPT = 8, kMsdTile = kMsdNW * 64 * kMsdIPT;      // 8192 words per partition tile
+constexpr int kMsdMaxDig = 1024;                                               // d1, d2 <= 10
+constexpr size_t kMsdPartSmem = sizeof(u64) * kMsdTile + sizeof(u32) * (2 * kMsdMaxDig + 64);
+constexpr u32 kMsdHistTile = 8u * kMsdTile;                                    // words per block of k_msd_hist2
+constexpr u32 kMsdGroups = 8;                                                  // XCDs
+constexpr u32 kMsdScanSeg = 8192;                                              // entries per block of the size scans
+// device words of a sort (plan[] in the kernels below)
+enum { kMsdW_T2 = 0, kMsdW_CPX2 = 1, kMsdW_MAXSUB = 2, kMsdW_COUNT = 4 };
+
+// cntg[d * 8 + g] = words of bucket d inside group g's eighth of the input: the pack kernel's digit table
+// table[d * nchunks + c] summed over the chunks of the group (chunk c belongs to group c / cpg).  One block per bucket.
+__global__ __launch_bounds__(kBlock) void k_msd_cnt1(const u32 *__restrict__ table, u32 nchunks, u32 cpg,
+                                                    u32 *__restrict__ cntg) {
+  __shared__ u32 acc[kMsdGroups];
+  if (threadIdx.x < kMsdGroups) acc[threadIdx.x] = 0;
+  __syncthreads();
+  const u32 d = blockIdx.x;
+  for (u32 c = threadIdx.x; c < nchunks; c += kBlock) {
+    const u32 v = table[(size_t)d * nchunks + c];
+    if (v) atomicAdd(&acc[c / cpg], v);
+  }
+  __syncthreads();
+  if (threadIdx.x < kMsdGroups) cntg[d * kMsdGroups + threadIdx.x] = acc[threadIdx.x];
+}
+
+// From the per-group bucket sizes (nb1 <= 1024 buckets; thread d owns the 8 entries of bucket d):
+//   startg[d * 8 + g]  start of group g's region of bucket d (exclusive prefix in that order), startg[nb1 * 8] = n
+//   cur1[g * nb1 + d]  the pass-1 cursors, one plane per group
+//   bstart[d]          start of bucket d, bstart[nb1] = n
+//   tpre / tpreh       tiles of kMsdTile / kMsdHistTile words per bucket, exclusive prefix (tiles never straddle a
+//                      bucket), [nb1] = total
+//   plan[T2, CPX2]     pass-2 tiles and tiles per group
+// One block of 1024 threads.
+__global__ __launch_bounds__(1024) void k_msd_plan1(const u32 *__restrict__ cntg, u32 nb1, u32 n, u32 *__restrict__ startg,
+                                                   u32 *__restrict__ cur1, u32 *__restrict__ bstart, u32 *__restrict__ tpre,
+                                                   u32 *__restrict__ tpreh, u32 *__restrict__ plan) {
+  __shared__ u32 tmp[16];
+  const u32 d = threadIdx.x;
+  u32 v[kMsdGroups], c = 0;
+#pragma unroll
+  for (u32 g = 0; g < kMsdGroups; g++) { v[g] = d < nb1 ? cntg[d * kMsdGroups + g] : 0u; c += v[g]; }
+  u32 tot;
+  u32 ex = block_excl_scan<16>(c, tmp, tot);
+  if (d < nb1) {
+    bstart[d] = ex;
+#pragma unroll
+    for (u32 g = 0; g < kMsdGroups; g++) { startg[d * kMsdGroups + g] = ex; cur1[g * nb1 + d] = ex; ex += v[g]; }
+  }
+  const u32 ext = block_excl_scan<16>((c + kMsdTile - 1) / kMsdTile, tmp, tot);
+  if (d < nb1) tpre[d] = ext;
+  if (d == 0) { tpre[nb1] = tot; plan[kMsdW_T2] = tot; plan[kMsdW_CPX2] = max(1u, (tot + kMsdGroups - 1) / kMsdGroups); }
+  const u32 exh = block_excl_scan<16>((c + kMsdHistTile - 1) / kMsdHistTile, tmp, tot);
+  if (d < nb1) tpreh[d] = exh;
+  if (d == 0) { tpreh[nb1] = tot; bstart[nb1] = n; startg[nb1 * kMsdGroups] = n; }
+}
+
+// bucket of tile t: the largest b with tpre[b] <= t (tpre is non-decreasing; buckets without tiles are skipped)
+__device__ __forceinline__ u32 msd_find_bucket(const u32 *__restrict__ tpre, u32 nb1, u32 t) {
+  u32 lo = 0, hi = nb1;                 // invariant: tpre[lo] <= t < tpre[hi]
+  while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (tpre[mid] <= t) lo = mid; else hi = mid; }
+  return lo;
+}
+
+// One partition pass; block j belongs to group g = j % 8 and works that group's tile number j / 8.
+// kSeg = false (pass 1): group g owns tiles [g * cpx, (g + 1) * cpx) of the input (tile t = words [t * kMsdTile, ...)),
+//   digit = word >> shift (the top d1 bits), cursors[g * ndig + digit].
+// kSeg = true (pass 2): the tiles are those of the bucket list (tpre / bstart: tile t lies inside one bucket b), group g
+//   owns tiles [g * cpx2, (g + 1) * cpx2), digit = (word >> shift) & mask, cursors[g * gstride + (b << dbits) + digit].
+// Not stable.
+template <bool kSeg>
+__global__ __launch_bounds__(kMsdNW * 64) void k_msd_part(const u64 *__restrict__ in, u64 *__restrict__ out, u32 n, u32 shift,
+                                                         u32 dbits, u32 cpx, u32 ntiles, const u32 *__restrict__ tpre,
+                                                         const u32 *__restrict__ bstart, u32 nb1, const u32 *__restrict__ plan,
+                                                         u32 *__restrict__ cursors, u32 gstride) {
+  constexpr int NT = kMsdNW * 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u64 *srec = reinterpret_cast<u64 *>(smem);
+  u32 *hist = reinterpret_cast<u32 *>(smem + sizeof(u64) * kMsdTile);   // [1024] counts -> tile-exclusive prefix
+  u32 *gbase = hist + kMsdMaxDig;                                        // [1024] global start of the tile's run
+  u32 *tmp = gbase + kMsdMaxDig;
+  const u32 tid = threadIdx.x;
+  const u32 ndig = 1u << dbits, mask = ndig - 1u;
+  const u32 g = blockIdx.x % kMsdGroups, idx = blockIdx.x / kMsdGroups;
+  u32 begin, end;
+  u32 *cur = cursors + (size_t)g * gstride;
+  if (kSeg) {
+    const u32 cpx2 = plan[kMsdW_CPX2], t2 = plan[kMsdW_T2];
+    const u32 tile = g * cpx2 + idx;
+    if (idx >= cpx2 || tile >= t2) return;
+    const u32 b = msd_find_bucket(tpre, nb1, tile);
+    begin = bstart[b] + (tile - tpre[b]) * (u32)kMsdTile;
+    end = min(begin + (u32)kMsdTile, bstart[b + 1]);
+    cur += (size_t)b << dbits;
+  } else {
+    const u32 tile = g * cpx + idx;
+    if (idx >= cpx || tile >= ntiles) return;
+    begin = tile * (u32)kMsdTile;
+    end = min(n, begin + (u32)kMsdTile);
+  }
+  const u32 nvalid = end - begin;                  // >= 1
+  hist[tid] = 0;
+  __syncthreads();
+  u64 r[kMsdIPT];
+  u32 rk[kMsdIPT];
+  // (all loads issued back to back: the index is clamped instead of guarded, a guard would put a wait behind every load)
+#pragma unroll
+  for (int k = 0; k < kMsdIPT; k++) r[k] = in[begin + min((u32)(k * NT) + tid, nvalid - 1u)];
+#pragma unroll
+  for (int k = 0; k < kMsdIPT; k++) r[k] = msd_word(r[k]);
+#pragma unroll
+  for (int k = 0; k < kMsdIPT; k++) {
+    const u32 t = k * NT + tid;
+    if (t < nvalid) rk[k] = atomicAdd(&hist[(u32)(r[k] >> shift) & mask], 1u);
+  }
+  __syncthreads();
+  u32 cnt = 0;
+  if (tid < ndig) {
+    cnt = hist[tid];
+    if (cnt) gbase[tid] = atomicAdd(&cur[tid], cnt);
+  }
+  u32 tot;
+  const u32 ex = block_excl_scan<kMsdNW>(cnt, tmp, tot);
+  hist[tid] = ex;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kMsdIPT; k++) {
+    const u32 t = k * NT + tid;
+    if (t < nvalid) srec[hist[(u32)(r[k] >> shift) & mask] + rk[k]] = r[k];
+  }
+  __syncthreads();
+  for (u32 q = tid; q < nvalid; q += NT) {
+    const u64 x = srec[q];
+    const u32 dd = (u32)(x >> shift) & mask;
+    out[gbase[dd] + (q - hist[dd])] = msd_word(x);
+  }
+}
+
+// Sizes of the sub-buckets per group: block h counts the d2-digits of its piece (8 pass-2 tiles) of bucket b in LDS and
+// adds them to cnt2g[((b << d2) + digit) * 8 + g], g = the group that will work the tile in pass 2 (tile / cpx2).
+__global__ __launch_bounds__(1024) void k_msd_hist2(const u64 *__restrict__ in, u32 shift, u32 dbits,
+                                                   const u32 *__restrict__ tpre, const u32 *__restrict__ tpreh,
+                                                   const u32 *__restrict__ bstart, u32 nb1, const u32 *__restrict__ plan,
+                                                   u32 *__restrict__ cnt2g) {
+  __shared__ u32 hist[kMsdMaxDig];
+  if (blockIdx.x >= tpreh[nb1]) return;
+  const u32 tid = threadIdx.x;
+  const u32 ndig = 1u << dbits, mask = ndig - 1u;
+  const u32 cpx2 = plan[kMsdW_CPX2];
+  const u32 b = msd_find_bucket(tpreh, nb1, blockIdx.x);
+  const u32 hh = blockIdx.x - tpreh[b];
+  const u32 begin = bstart[b] + hh * kMsdHistTile;
+  const u32 end = min(begin + kMsdHistTile, bstart[b + 1]);
+  const u32 tile0 = tpre[b] + hh * (kMsdHistTile / kMsdTile);
+  u32 gcur = tile0 / cpx2;
+  hist[tid] = 0;
+  __syncthreads();
+  for (u32 pt = 0; pt < kMsdHistTile / kMsdTile; pt++) {
+    const u32 pb = begin + pt * (u32)kMsdTile;
+    if (pb >= end) break;
+    const u32 pe = min(pb + (u32)kMsdTile, end);
+    const u32 g = (tile0 + pt) / cpx2;
+    if (g != gcur) {                                  // (block-uniform: at most 7 group changes in the whole array)
+      __syncthreads();
+      if (tid < ndig && hist[tid]) atomicAdd(&cnt2g[(((size_t)b << dbits) + tid) * kMsdGroups + gcur], hist[tid]);
+      hist[tid] = 0;
+      __syncthreads();
+      gcur = g;
+    }
+    u64 w[kMsdTile / 1024];
+#pragma unroll
+    for (u32 k = 0; k < kMsdTile / 1024; k++) w[k] = in[min(pb + k * 1024u + tid, pe - 1u)];
+#pragma unroll
+    for (u32 k = 0; k < kMsdTile / 1024; k++)
+      if (pb + k * 1024u + tid < pe) atomicAdd(&hist[(u32)(msd_word(w[k]) >> shift) & mask], 1u);
+  }
+  __syncthreads();
+  if (tid < ndig && hist[tid]) atomicAdd(&cnt2g[(((size_t)b << dbits) + tid) * kMsdGroups + gcur], hist[tid]);
+}
+
+// Exclusive prefix of cnt[0..N) (N = sub-buckets * 8, in that order), in place, in two launches of ceil(N / 8192) blocks
+// of 1024 threads (thread t owns 8 consecutive entries = the 8 groups of one sub-bucket):
+//   k_msd_scan2a: segsum[block] = sum of the block's entries; plan[MAXSUB] = largest sub-bucket
+//   k_msd_scan2c: cnt[i] <- exclusive prefix (the block re-adds the sums of the blocks before it: N / 8192 <= 1024 of
+//                 them), cnt[N] = total, and cur2[g * n2 + s] = the same values as one plane per group (pass-2 cursors)
+__global__ __launch_bounds__(1024) void k_msd_scan2a(const u32 *__restrict__ cnt, u32 N, u32 *__restrict__ segsum,
+                                                    u32 *__restrict__ plan) {
+  __shared__ u32 tmp[16];
+  const u32 i0 = blockIdx.x * kMsdScanSeg + threadIdx.x * kMsdGroups;
+  u32 s = 0;
+#pragma unroll
+  for (u32 g = 0; g < kMsdGroups; g++) s += (i0 + g < N) ? cnt[i0 + g] : 0u;
+  const u32 mx = wave_reduce_max(s);
+  u32 tot;
+  (void)block_excl_scan<16>(s, tmp, tot);
+  if (threadIdx.x == 0) segsum[blockIdx.x] = tot;
+  if (lane_id() == 0 && mx) atomicMax(&plan[kMsdW_MAXSUB], mx);
+}
+__global__ __launch_bounds__(1024) void k_msd_scan2c(u32 *__restrict__ cnt, u32 N, u32 n2, const u32 *__restrict__ segsum,
+                                                    u32 *__restrict__ cur2) {
+  __shared__ u32 tmp[16];
+  // sum of the segments before this one
+  u32 before = (threadIdx.x < blockIdx.x) ? segsum[threadIdx.x] : 0u;     // gridDim.x <= 1024
+  u32 tot;
+  (void)block_excl_scan<16>(before, tmp, tot);
+  const u32 base = tot;
+  const u32 i0 = blockIdx.x * kMsdScanSeg + threadIdx.x * kMsdGroups;
+  u32 v[kMsdGroups], s = 0;
+#pragma unroll
+  for (u32 g = 0; g < kMsdGroups; g++) { v[g] = (i0 + g < N) ? cnt[i0 + g] : 0u; s += v[g]; }
+  u32 ex = block_excl_scan<16>(s, tmp, tot) + base;
+  const u32 sub = i0 / kMsdGroups;
+#pragma unroll
+  for (u32 g = 0; g < kMsdGroups; g++) {
+    if (i0 + g < N) { cnt[i0 + g] = ex; cur2[(size_t)g * n2 + sub] = ex; }
+    ex += v[g];
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 1023) cnt[N] = base + tot;
+}
+
+// Sinks of the local sort: where word x of global output index g goes (cf. RecSink / SplitSink of the LSD passes).
+struct MsdRecSink {
+  u64 *p;
+  __device__ __forceinline__ void store(u32 g, u64 x) const { p[g] = msd_word(x); }
+};
+struct MsdSplitSink {
+  u32 *sa, *img; u32 pbits;
+  __device__ __forceinline__ void store(u32 g, u64 x) const {
+    sa[g] = (u32)(x & ((1ull << pbits) - 1ull));
+    img[g] = (u32)(x >> pbits);
+  }
+};
+
+// Pass 3: block s orders sub-bucket s = words [start[8 s], start[8 (s + 1)]) (at most CAP of them; larger ones were
+// refused on the host) and writes it through the sink at the same indices.
+//   1. bin = BB bits below the sub-bucket bits; one returning LDS atomic per word gives its arrival number in the bin
+//   2. exclusive scan of the bin counts
+//   3. words are placed bin by bin in LDS (arrival order inside a bin)
+//   4. every word counts the smaller words of its own bin (about one word per bin): final index = bin start + count
+// The words are distinct, so the result is the unique ascending order.
+template <int NT, int CAP, int BB, class Sink>
+__global__ __launch_bounds__(NT) void k_msd_local(const u64 *__restrict__ in, const u32 *__restrict__ start, u32 shb, Sink out) {
+  constexpr int IPT = CAP / NT, NBIN = 1 << BB, BPT = NBIN / NT;
+  static_assert(CAP % NT == 0 && NBIN % NT == 0, "shape");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // CAP words (dynamic: CAP * 8 bytes)
+  u64 *srec = reinterpret_cast<u64 *>(smem);
+  __shared__ u32 cnt[NBIN + 1];
+  __shared__ u32 tmp[NT / 64];
+  const u32 tid = threadIdx.x;
+  const u32 begin = start[(size_t)blockIdx.x * kMsdGroups], end = start[(size_t)(blockIdx.x + 1) * kMsdGroups];
+  const u32 m = end - begin;
+  if (m == 0) return;
+#pragma unroll
+  for (int j = 0; j < BPT; j++) cnt[j * NT + tid] = 0;
+  __syncthreads();
+  u64 r[IPT];
+  u32 rk[IPT];
+  // (clamped, not guarded: all loads in flight at once)
+#pragma unroll
+  for (int k = 0; k < IPT; k++) r[k] = in[begin + min((u32)(k * NT) + tid, m - 1u)];
+#pragma unroll
+  for (int k = 0; k < IPT; k++) r[k] = msd_word(r[k]);
+#pragma unroll
+  for (int k = 0; k < IPT; k++) {
+    const u32 t = k * NT + tid;
+    if (t < m) rk[k] = atomicAdd(&cnt[(u32)(r[k] >> shb) & (NBIN - 1)], 1u);
+  }
+  __syncthreads();
+  // exclusive scan of the bins: thread tid owns bins [tid * BPT, (tid + 1) * BPT)
+  u32 c[BPT], s = 0;
+#pragma unroll
+  for (int j = 0; j < BPT; j++) { c[j] = cnt[tid * BPT + j]; s += c[j]; }
+  u32 tot;
+  u32 ex = block_excl_scan<NT / 64>(s, tmp, tot);
+#pragma unroll
+  for (int j = 0; j < BPT; j++) { cnt[tid * BPT + j] = ex; ex += c[j]; }
+  if (tid == NT - 1) cnt[NBIN] = ex;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < IPT; k++) {
+    const u32 t = k * NT + tid;
+    if (t < m) srec[cnt[(u32)(r[k] >> shb) & (NBIN - 1)] + rk[k]] = r[k];
+  }
+  __syncthreads();
+  for (u32 q = tid; q < m; q += NT) {
+    const u64 x = srec[q];
+    const u32 bin = (u32)(x >> shb) & (NBIN - 1);
+    const u32 lo = cnt[bin], hi = cnt[bin + 1];
+    u32 less = 0;
+    for (u32 j = lo; j < hi; j++) less += srec[j] < x ? 1u : 0u;
+    out.store(begin + lo + less, x);
+  }
+}
+
+}  // namespace dc3

@@ -428,7 +428,7 @@ struct KeyT {
 // kWide: 12-byte records {image, position} (k_pack_image12_all_hist's output) instead of (image << pbits) | position.
 template <int NB, bool kWide>
 __global__ __launch_bounds__(kBlock) void k_pack_image_textT(KeyT km, u32 n, HiMap hm, u64 P1, void *__restrict__ outv,
-                                                            u32 chunk, u32 nchunks, u32 *__restrict__ table) {
+                                                            u32 chunk, u32 nchunks, u32 *__restrict__ table, u32 hshift = 0) {
   __shared__ uint16_t lcode[256];
   __shared__ u32 hist[kWaves][NB];
   km.stage(lcode);
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(kBlock) void k_pack_image_textT(KeyT km, u32 n, HiM
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       img[j] = __umul64hi(v, hm.mfix);
-      if (p0 + j < end) atomicAdd(&myh[(u32)img[j] & (NB - 1)], 1u);
+      if (p0 + j < end) atomicAdd(&myh[(u32)(img[j] >> hshift) & (NB - 1)], 1u);
       if (j < 3) v = (v - (u64)dh[j] * P1) * sigma + (j == 0 ? dt0 : j == 1 ? dt1 : dt2);
     }
     if (kWide) {
@@ -501,12 +501,14 @@ __global__ __launch_bounds__(kBlock) void k_pack_image_textT(KeyT km, u32 n, HiM
     table[(size_t)j * nchunks + blockIdx.x] = sum;
   }
 }
+// (all pack kernels: hshift = which image bits the digit table counts — 0: the lowest digit, for the LSD passes;
+//  nbits - d1 with NB = 1024: the top d1 bits, the bucket sizes of the MSD ordering, dc3_msd.hip.hpp)
 // whole text, 4 consecutive positions per thread: 12 aligned text bytes -> 12 codes -> 10 byte-triples shared by
 // the 4 keys; 32 contiguous output bytes per thread.  Blocks own the chunks of the radix sort that follows and
 // also produce its first digit table (the up-sweep of pass 1 never reads the records back): table[d*nchunks + b].
 template <int NB>
 __global__ __launch_bounds__(kBlock) void k_pack_image_text(Key9 km, u32 n, HiMap hm, Rec8 *__restrict__ out, u32 chunk,
-                                                           u32 nchunks, u32 *__restrict__ table) {
+                                                           u32 nchunks, u32 *__restrict__ table, u32 hshift = 0) {
   __shared__ uint16_t lcode[256];
   __shared__ u32 hist[kWaves][NB];
   km.stage(lcode);
@@ -529,7 +531,7 @@ __global__ __launch_bounds__(kBlock) void k_pack_image_text(Key9 km, u32 n, HiMa
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       r[j] = hyb_rec(make_rec(u[j], u[j + 3], u[j + 6], km.B3, p0 + j), hm);
-      if (p0 + j < end) atomicAdd(&myh[(u32)(rec8_word(r[j]) >> hm.pbits) & (NB - 1)], 1u);
+      if (p0 + j < end) atomicAdd(&myh[(u32)(rec8_word(r[j]) >> (hm.pbits + hshift)) & (NB - 1)], 1u);
     }
     if (p0 + 3 < end) {
       u32x4 *o = reinterpret_cast<u32x4 *>(out + p0);
@@ -559,7 +561,7 @@ __global__ __launch_bounds__(kBlock) void k_pack_image_pos(KM km, u32 nout, u32 
 // sort that follows starts with its down-sweep: all positions of a level, and the samples of a level.
 template <class KM, int NB>
 __global__ __launch_bounds__(kBlock) void k_pack_image_all_hist(KM km, u32 nrec, HiMap hm, Rec8 *__restrict__ out,
-                                                               u32 chunk, u32 nchunks, u32 *__restrict__ table) {
+                                                               u32 chunk, u32 nchunks, u32 *__restrict__ table, u32 hshift = 0) {
   __shared__ uint16_t lcode[256];
   __shared__ u32 hist[kWaves][NB];
   km.stage(lcode);
@@ -572,7 +574,7 @@ __global__ __launch_bounds__(kBlock) void k_pack_image_all_hist(KM km, u32 nrec,
   for (u32 i = begin + threadIdx.x; i < end; i += kBlock) {
     const Rec8 r = km.image(i, lcode, hm);
     out[i] = r;
-    atomicAdd(&myh[(u32)(rec8_word(r) >> hm.pbits) & (NB - 1)], 1u);
+    atomicAdd(&myh[(u32)(rec8_word(r) >> (hm.pbits + hshift)) & (NB - 1)], 1u);
   }
   __syncthreads();
   for (int j = threadIdx.x; j < NB; j += kBlock) {
@@ -585,7 +587,7 @@ __global__ __launch_bounds__(kBlock) void k_pack_image_all_hist(KM km, u32 nrec,
 template <class Sym, int NB>
 __global__ __launch_bounds__(kBlock) void k_pack_image_hist(Sym S, u32 m, u32 m0, u32 m02, u32 b, HiMap hm,
                                                            Rec8 *__restrict__ out, u32 chunk, u32 nchunks,
-                                                           u32 *__restrict__ table) {
+                                                           u32 *__restrict__ table, u32 hshift = 0) {
   __shared__ u32 hist[kWaves][NB];
 #pragma unroll
   for (int w = 0; w < kWaves; w++)
@@ -598,11 +600,11 @@ __global__ __launch_bounds__(kBlock) void k_pack_image_hist(Sym S, u32 m, u32 m0
     const u32 s1 = S.get(i), s2 = S.get(i + 1), s3 = S.get(i + 2), s4 = S.get(i + 3);
     const Rec8 r0 = hyb_rec(make_rec(s1, s2, s3, b, i), hm);
     out[2 * g] = r0;
-    atomicAdd(&myh[(u32)(rec8_word(r0) >> hm.pbits) & (NB - 1)], 1u);
+    atomicAdd(&myh[(u32)(rec8_word(r0) >> (hm.pbits + hshift)) & (NB - 1)], 1u);
     if (2 * g + 1 < m02) {
       const Rec8 r1 = hyb_rec(make_rec(s2, s3, s4, b, i + 1), hm);
       out[2 * g + 1] = r1;
-      atomicAdd(&myh[(u32)(rec8_word(r1) >> hm.pbits) & (NB - 1)], 1u);
+      atomicAdd(&myh[(u32)(rec8_word(r1) >> (hm.pbits + hshift)) & (NB - 1)], 1u);
     }
   }
   __syncthreads();

@@ -102,7 +102,12 @@ template <class Rec, int NB, int IPT, int NW, bool PF, class Loader, class Sink 
 __global__ __launch_bounds__(NW * 64) void k_rs_downsweep(Loader in, Sink out, u32 n,
                                                          u32 chunk, u32 nchunks, KeyDig dig,
                                                          const u32 *__restrict__ table,
-                                                         const u32 *__restrict__ digit_base) {
+                                                         const u32 *__restrict__ digit_base, u32 xcd_cpx = 0) {
+  // xcd_cpx != 0: block j works chunk (j % 8) * xcd_cpx + j / 8 — the blocks that share an XCD (round-robin placement,
+  // a speed assumption only) take CONSECUTIVE chunks at about the same time, so the runs that end up next to each other
+  // in the output are written through one L2 within microseconds and their partial lines meet there
+  const u32 cid = xcd_cpx ? (blockIdx.x & 7u) * xcd_cpx + (blockIdx.x >> 3) : blockIdx.x;
+  if (cid >= nchunks) return;
   constexpr int kB = NW * 64;
   constexpr int kTile = kB * IPT;
   constexpr int kWItems = 64 * IPT;
@@ -116,9 +121,9 @@ __global__ __launch_bounds__(NW * 64) void k_rs_downsweep(Loader in, Sink out, u
   u32 *texcl = dbase + NB;                                           // [NB] tile-exclusive prefix
   u32 *tmp = texcl + NB;                                             // [NW]
   const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
-  const u32 begin = blockIdx.x * chunk;
+  const u32 begin = cid * chunk;
   const u32 end = min(n, begin + chunk);
-  if (tid < NB) dbase[tid] = digit_base[tid] + table[(size_t)tid * nchunks + blockIdx.x];
+  if (tid < NB) dbase[tid] = digit_base[tid] + table[(size_t)tid * nchunks + cid];
   u32 *mycnt = wcnt + w * NB;
   Rec r[IPT], rn[PF ? IPT : 1];
   bool okn[PF ? IPT : 1];

@@ -25,6 +25,7 @@
 
 #include "../../include/dc3hip.h"
 #include "dc3_kernels.hip.hpp"
+#include "dc3_msd.hip.hpp"
 
 using namespace dc3;
 
@@ -90,6 +91,8 @@ struct dc3hip_ctx {
   u32 hybrid12_min = 1u << 22; // DC3HIP_HYBRID12_MIN: smallest level (samples) that tries it (tests lower it)
   bool no_hybrid8 = false;     // DC3HIP_NO_HYBRID8=1 (tests): skip the 8-byte prefix sort / whole-level order of a level
   bool no_hybrid12 = false;    // DC3HIP_NO_HYBRID12=1: no 63-bit-prefix sort on 12-byte records for keys wider than 64 bits
+  bool no_msd = false;         // DC3HIP_NO_MSD=1: the prefix sorts always run the stable LSD passes (no bucket ordering)
+  u32 msd_min = 1u << 20;      // DC3HIP_MSD_MIN: fewest records the bucket ordering is used for (tests lower it)
   bool no_tup8 = false;        // DC3HIP_NO_TUP8=1: the slot table of the merge tuples is always 16 bytes per sample
   bool trace = false;          // DC3HIP_TRACE=1: per-level checksums of SA12 / SA0 / SA (dc3hip_stats.trace_*)
   u64 *d_trace = nullptr;      // [3][DC3HIP_MAX_LEVELS]
@@ -147,7 +150,8 @@ static size_t arena_requirement(int64_t n) {
 // do, so their contexts hold half the memory and the first hipMalloc is half as long.
 static size_t arena_text_requirement(int64_t n) {
   // (beyond 2^31 positions the whole-text order runs on 12-byte records: 2 x 12 + 1 bytes per position + tables)
-  return n > ((int64_t)1 << 31) ? (size_t)n * 26 + ((size_t)256 << 20) : (size_t)n * 24 + ((size_t)128 << 20);
+  // (+ the size tables of the bucket ordering: 2 x 8 words per sub-bucket, at most 2^20 sub-buckets)
+  return n > ((int64_t)1 << 31) ? (size_t)n * 26 + ((size_t)256 << 20) : (size_t)n * 24 + ((size_t)208 << 20);
 }
 
 // Grow the (empty) arena to at least `need` bytes.  Never shrinks; a size forced by DC3HIP_ARENA_BYTES stays as it is.
@@ -244,7 +248,7 @@ static int launch_downsweep_to(dc3hip_ctx *c, Loader in, Sink dst, u32 n, const 
   }
   PhaseScope ps(c, phase, n, RecClass<Rec>::k);
   hipLaunchKernelGGL(kern, dim3(ck.nchunks), dim3(NW * 64), smem, c->stream, in, dst, n, ck.chunk, ck.nchunks, dig,
-                     table, digit_base);
+                     table, digit_base, 0u);
   KCHECK();
   return E_OK;
 }
@@ -357,6 +361,170 @@ static void radix_plan(dc3hip_ctx *c, u32 n, u32 bits, int *nb, Chunking *ck) {
   const int tile = nine ? SortCfg<Rec, 512>::NW * 64 * SortCfg<Rec, 512>::IPT : SortCfg<Rec, 256>::NW * 64 * SortCfg<Rec, 256>::IPT;
   *ck = make_chunks(c, n, (u32)tile);
 }
+
+// ---------------------------------------------------------------------------------------------
+// Bucket (MSD) ordering of the prefix-sort words (dc3_msd.hip.hpp): the same array the stable LSD passes over the image
+// bits produce, in two non-stable partition passes + an in-LDS order of the sub-buckets.
+// ---------------------------------------------------------------------------------------------
+struct MsdGeom {
+  bool on = false;
+  u32 d1 = 0, d2 = 0;                            // digit widths of the two partition passes (d2 = 0: one pass)
+  u32 ntiles1 = 0, tpc = 0, cpg = 0, cpx1 = 0;   // pass-1 tiles; tiles per pack chunk, chunks and tiles per group
+  Chunking ck{0, 0};                             // chunking of the pack kernel that produces the bucket sizes
+};
+static constexpr u32 kMsdCapSmall = 2048, kMsdCapLarge = 4096;     // sub-bucket capacities of the two local-sort shapes
+// Geometry for nrec words with hm's layout, or .on = false when the bucket ordering does not apply (switched off, too
+// few records, 32-bit positions, or too few image bits below the bucket bits for the local sort's bins).
+static MsdGeom msd_geometry(const dc3hip_ctx *c, u32 nrec, const HiMap &hm) {
+  MsdGeom g;
+  if (c->no_msd || nrec < c->msd_min || nrec < 4096 || hm.pbits >= 32 || hm.pbits + hm.nbits > 64) return g;
+  const u32 lg = bits_of((u64)nrec - 1);                       // ceil(log2 nrec)
+  u32 tb = lg > 10 ? lg - 10 : 1;                              // sub-buckets of 512..1024 words on uniform images
+  if (tb > 20) tb = 20;
+  if (hm.nbits < tb + 4) return g;
+  if (tb <= 10) { g.d1 = tb; g.d2 = 0; } else { g.d1 = (tb + 1) / 2; g.d2 = tb - g.d1; }
+  g.ntiles1 = (nrec + kMsdTile - 1) / kMsdTile;
+  g.tpc = std::max<u32>(1, (g.ntiles1 + 2047) / 2048);
+  g.cpg = ((g.ntiles1 + kMsdGroups - 1) / kMsdGroups + g.tpc - 1) / g.tpc;
+  g.cpx1 = g.cpg * g.tpc;
+  g.ck.chunk = g.tpc * (u32)kMsdTile;
+  g.ck.nchunks = (nrec + g.ck.chunk - 1) / g.ck.chunk;
+  g.on = true;
+  return g;
+}
+// what a finished sort leaves behind so that its last pass can be repeated into records (cf. LastPass)
+struct MsdRedo { const u64 *src = nullptr; u64 *dst = nullptr; const u32 *start = nullptr; u32 nsub = 0, shb = 0; bool large = false; };
+template <class Sink>
+static int msd_launch_local(dc3hip_ctx *c, const MsdRedo &r, u32 n, Sink sink) {
+  PhaseScope ps(c, DC3HIP_PH_SORT8_DOWN, n, 6);
+  if (r.large)
+    hipLaunchKernelGGL((k_msd_local<512, (int)kMsdCapLarge, 12, Sink>), dim3(r.nsub), dim3(512), kMsdCapLarge * 8, c->stream, r.src,
+                       r.start, r.shb, sink);
+  else
+    hipLaunchKernelGGL((k_msd_local<256, (int)kMsdCapSmall, 10, Sink>), dim3(r.nsub), dim3(256), kMsdCapSmall * 8, c->stream, r.src,
+                       r.start, r.shb, sink);
+  KCHECK();
+  return E_OK;
+}
+// Sort the n words of `ha` (scratch `hb`) by image bits [pbits, pbits + nbits).  table = the pack kernel's digit table of
+// the top g.d1 image bits ([1024][g.ck.nchunks]).  split != nullptr: the last pass writes positions + 32 image bits
+// through it (as the LSD passes do with a SplitSink) and *result = nullptr; else *result = the sorted records.
+// *ok = false: a sub-bucket was too large for the local sort — nothing was delivered, all records are in *where (in
+// partition order) and the caller runs the LSD passes from there.  The small tables stay allocated in the arena until
+// the caller releases its mark (redo reads them).
+static int msd_sort(dc3hip_ctx *c, Rec8 *ha, Rec8 *hb, u32 n, const HiMap &hm, const MsdGeom &g, const u32 *table,
+                    const SplitSink *split, Rec8 **result, MsdRedo *redo, bool *ok, Rec8 **where) {
+  *ok = false; *where = ha; *result = nullptr;
+  static std::atomic<bool> attr_set[16];
+  if (!attr_set[c->device & 15]) {
+    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_msd_part<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
+    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_msd_part<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
+    attr_set[c->device & 15] = true;
+  }
+  const u32 nb1 = 1u << g.d1, tb = g.d1 + g.d2, n2 = 1u << tb;
+  const u32 sh1 = hm.pbits + hm.nbits - g.d1, sh2 = sh1 - g.d2, rb = hm.nbits - tb;
+  u32 *cntg = nullptr, *startg = nullptr, *cur1 = nullptr, *bstart = nullptr, *tpre = nullptr, *tpreh = nullptr, *plan = nullptr, *segsum = nullptr;
+  RC(arena_alloc(c, (size_t)nb1 * kMsdGroups + 16, &cntg));
+  RC(arena_alloc(c, (size_t)nb1 * kMsdGroups + 16, &startg));
+  RC(arena_alloc(c, (size_t)nb1 * kMsdGroups + 16, &cur1));
+  RC(arena_alloc(c, (size_t)nb1 + 16, &bstart)); RC(arena_alloc(c, (size_t)nb1 + 16, &tpre)); RC(arena_alloc(c, (size_t)nb1 + 16, &tpreh));
+  RC(arena_alloc(c, (size_t)kMsdW_COUNT + 12, &plan)); RC(arena_alloc(c, (size_t)1024 + 16, &segsum));
+  u64 *wa = reinterpret_cast<u64 *>(ha), *wb = reinterpret_cast<u64 *>(hb);
+  {
+    PhaseScope ps(c, DC3HIP_PH_SORT12_SCAN, nb1);
+    HIPC(hipMemsetAsync(plan, 0, (kMsdW_COUNT + 12) * sizeof(u32), c->stream));
+    hipLaunchKernelGGL(k_msd_cnt1, dim3(nb1), dim3(kBlock), 0, c->stream, table, g.ck.nchunks, g.cpg, cntg);
+    KCHECK();
+    hipLaunchKernelGGL(k_msd_plan1, dim3(1), dim3(1024), 0, c->stream, (const u32 *)cntg, nb1, n, startg, cur1, bstart, tpre, tpreh, plan);
+    KCHECK();
+  }
+  {
+    PhaseScope ps(c, DC3HIP_PH_SORT8_DOWN, n, 5);
+    hipLaunchKernelGGL((k_msd_part<false>), dim3(kMsdGroups * g.cpx1), dim3(kMsdNW * 64), kMsdPartSmem, c->stream, (const u64 *)wa, wb, n,
+                       sh1, g.d1, g.cpx1, g.ntiles1, (const u32 *)nullptr, (const u32 *)nullptr, nb1, (const u32 *)plan, cur1, nb1);
+    KCHECK();
+  }
+  MsdRedo r;
+  if (g.d2 > 0) {
+    const size_t N = (size_t)n2 * kMsdGroups;
+    u32 *cnt2g = nullptr, *cur2 = nullptr;
+    RC(arena_alloc(c, N + 16, &cnt2g));
+    RC(arena_alloc(c, N + 16, &cur2));
+    const u32 nseg = (u32)((N + kMsdScanSeg - 1) / kMsdScanSeg);       // <= 1024
+    {
+      PhaseScope ps(c, DC3HIP_PH_SORT12_UP, n);
+      HIPC(hipMemsetAsync(cnt2g, 0, (N + 1) * sizeof(u32), c->stream));
+      hipLaunchKernelGGL(k_msd_hist2, dim3(n / kMsdHistTile + nb1 + 1), dim3(1024), 0, c->stream, (const u64 *)wb, sh2, g.d2,
+                         (const u32 *)tpre, (const u32 *)tpreh, (const u32 *)bstart, nb1, (const u32 *)plan, cnt2g);
+      KCHECK();
+    }
+    {
+      PhaseScope ps(c, DC3HIP_PH_SORT12_SCAN, N);
+      hipLaunchKernelGGL(k_msd_scan2a, dim3(nseg), dim3(1024), 0, c->stream, (const u32 *)cnt2g, (u32)N, segsum, plan);
+      KCHECK();
+      hipLaunchKernelGGL(k_msd_scan2c, dim3(nseg), dim3(1024), 0, c->stream, cnt2g, (u32)N, n2, (const u32 *)segsum, cur2);
+      KCHECK();
+      HIPC(hipMemcpyAsync(c->h_words + 20, plan, kMsdW_COUNT * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    }
+    {
+      PhaseScope ps(c, DC3HIP_PH_SORT8_DOWN, n, 5);
+      const u32 grid2 = kMsdGroups * ((n / kMsdTile + nb1 + 1 + kMsdGroups - 1) / kMsdGroups);
+      hipLaunchKernelGGL((k_msd_part<true>), dim3(grid2), dim3(kMsdNW * 64), kMsdPartSmem, c->stream, (const u64 *)wb, wa, n, sh2, g.d2,
+                         0u, 0u, (const u32 *)tpre, (const u32 *)bstart, nb1, (const u32 *)plan, cur2, n2);
+      KCHECK();
+    }
+    r.src = wa; r.dst = wb; r.start = cnt2g; r.nsub = n2;
+  } else {
+    {
+      PhaseScope ps(c, DC3HIP_PH_SORT12_SCAN, nb1);
+      hipLaunchKernelGGL(k_msd_scan2a, dim3((nb1 * kMsdGroups + kMsdScanSeg - 1) / kMsdScanSeg), dim3(1024), 0, c->stream, (const u32 *)cntg,
+                         nb1 * kMsdGroups, segsum, plan);
+      KCHECK();
+      HIPC(hipMemcpyAsync(c->h_words + 20, plan, kMsdW_COUNT * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    }
+    r.src = wb; r.dst = wa; r.start = startg; r.nsub = nb1;
+  }
+  HIPC(hipStreamSynchronize(c->stream));
+  const u32 maxsub = c->h_words[20 + kMsdW_MAXSUB];
+  c->stats.msd_max_subbucket = maxsub;
+  *where = reinterpret_cast<Rec8 *>(const_cast<u64 *>(r.src));
+  if (maxsub > kMsdCapLarge) { c->stats.msd_fallbacks++; return E_OK; }
+  r.large = maxsub > kMsdCapSmall;
+  r.shb = sh2 - std::min<u32>(r.large ? 12u : 10u, rb);
+  if (split) {
+    MsdSplitSink sk; sk.sa = split->sa; sk.img = split->img; sk.pbits = split->pbits;
+    RC(msd_launch_local(c, r, n, sk));
+  } else {
+    MsdRecSink sk; sk.p = r.dst;
+    RC(msd_launch_local(c, r, n, sk));
+    *result = reinterpret_cast<Rec8 *>(r.dst);
+  }
+  c->stats.msd_sorts++;
+  *redo = r;
+  *ok = true;
+  return E_OK;
+}
+// repeat the last pass of an MSD sort that ended in a split sink, this time into records
+static int msd_redo(dc3hip_ctx *c, const MsdRedo &r, u32 n, Rec8 **result) {
+  MsdRecSink sk; sk.p = r.dst;
+  RC(msd_launch_local(c, r, n, sk));
+  *result = reinterpret_cast<Rec8 *>(r.dst);
+  return E_OK;
+}
+
+// Digit table of a pack kernel (k_pack_image_*): bins, chunking and which image bits it counts.
+// mg (bucket ordering, msd_geometry): the table counts the TOP mg->d1 image bits in mg's chunking instead (1024 rows).
+static void pack_plan(dc3hip_ctx *c, u32 nrec, const HiMap &hm, const MsdGeom *mg, int *nb, Chunking *ck, u32 *hshift) {
+  if (mg && mg->on) { *nb = 1024; *ck = mg->ck; *hshift = hm.nbits - mg->d1; }
+  else { radix_plan<Rec8>(c, nrec, hm.nbits, nb, ck); *hshift = 0; }
+}
+#define DC3_PACK_LAUNCH(KERNEL_NB, ...)                                                                              \
+  do {                                                                                                               \
+    if (nb == 1024) hipLaunchKernelGGL(KERNEL_NB(1024), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, __VA_ARGS__);   \
+    else if (nb == 512) hipLaunchKernelGGL(KERNEL_NB(512), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, __VA_ARGS__); \
+    else hipLaunchKernelGGL(KERNEL_NB(256), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, __VA_ARGS__);               \
+    KCHECK();                                                                                                        \
+  } while (0)
 
 // ---------------------------------------------------------------------------------------------
 // out[key] = val for pairs whose keys are a bijection onto [0,n)  (R[SA12[i]] = i+1, lib.rs:106-108;
@@ -670,7 +838,10 @@ template <> struct IsTextKey<KeyT> { static constexpr bool value = true; };
 template <class KM>
 static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Rec8 *ha, Rec8 *hb, u32 nrec,
                             Rec8 **h_out, uint8_t *f, bool *ok, int depth, u32 *emit_sa = nullptr, u32 skip = 0,
-                            bool *emitted_distinct = nullptr, u32 *first_table = nullptr, bool whole_text = false) {
+                            bool *emitted_distinct = nullptr, u32 *first_table = nullptr, bool whole_text = false,
+                            const MsdGeom *mg = nullptr) {
+  // mg (and mg->on): the records were packed for the bucket ordering — first_table is then the digit table of the TOP
+  // image bits in mg's chunking, and the sort runs msd_sort(); should that give up, the LSD passes start from scratch
   // whole_text: the records are ALL positions of the text (single device): few repeated windows may be settled here by
   // prefix doubling.  (A rank of the global mode orders only its image range and must not: ranks are global.)
   *ok = false;
@@ -683,8 +854,16 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
     RC(arena_alloc(c, (size_t)nrec + 16, &img));
     SplitSink sink; sink.sa = emit_sa; sink.img = img; sink.pbits = hm.pbits;
     LastPass lp;
-    RC(radix_sort<Rec8>(c, ha, hb, nrec, hm.pbits, hm.pbits + hm.nbits, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN,
-                        DC3HIP_PH_SORT8_DOWN, first_table, &sink, &lp));
+    MsdRedo mredo; bool msd_ok = false;
+    if (mg && mg->on) {
+      Rec8 *where = ha;
+      RC(msd_sort(c, ha, hb, nrec, hm, *mg, first_table, &sink, &h, &mredo, &msd_ok, &where));
+      if (msd_ok) lp.src = const_cast<u64 *>(mredo.src);               // (non-null = "the order lives in the sink")
+      else { if (where != ha) std::swap(ha, hb); first_table = nullptr; }
+    }
+    if (!msd_ok)
+      RC(radix_sort<Rec8>(c, ha, hb, nrec, hm.pbits, hm.pbits + hm.nbits, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN,
+                          DC3HIP_PH_SORT8_DOWN, first_table, &sink, &lp));
     if (lp.src) {
       {
         PhaseScope ps(c, DC3HIP_PH_TIES, nrec);
@@ -733,12 +912,20 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
         }
       }
       // keys repeat (or a large group): the records are needed after all
-      RC(radix_redo_last(c, lp, nrec, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT8_DOWN));
+      if (msd_ok) RC(msd_redo(c, mredo, nrec, &h));
+      else RC(radix_redo_last(c, lp, nrec, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT8_DOWN));
     }
     emit_sa = nullptr;                       // from here on: the record path, positions are emitted by the caller
   } else {
-    RC(radix_sort<Rec8>(c, ha, hb, nrec, hm.pbits, hm.pbits + hm.nbits, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN,
-                        DC3HIP_PH_SORT8_DOWN, first_table));
+    bool msd_ok = false;
+    if (mg && mg->on) {
+      MsdRedo mredo; Rec8 *where = ha;
+      RC(msd_sort(c, ha, hb, nrec, hm, *mg, first_table, nullptr, &h, &mredo, &msd_ok, &where));
+      if (!msd_ok) { if (where != ha) std::swap(ha, hb); first_table = nullptr; }
+    }
+    if (!msd_ok)
+      RC(radix_sort<Rec8>(c, ha, hb, nrec, hm.pbits, hm.pbits + hm.nbits, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN,
+                          DC3HIP_PH_SORT8_DOWN, first_table));
   }
   const Chunking ck = make_chunks(c, nrec, kBlock);
   u32 *counts = nullptr;
@@ -805,9 +992,13 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
 // predecessor's, tied groups ordered by the full key.  *ok = false: too many ties, or no room for the general path.
 template <class KM>
 static int hybrid12_refine(dc3hip_ctx *c, KM km, u32 kbits, Rec12 *h, u32 n, uint8_t *f, bool *ok, int depth,
-                           u32 *emit_sa = nullptr, bool *distinct = nullptr) {
+                           u32 *emit_sa = nullptr, bool *distinct = nullptr, bool *deep_flags = nullptr) {
+  // *deep_flags: on return f[] (and the order inside tied groups) reflects equality over kDeepSyms symbols, not over
+  // the window — whoever continues from f[] (doubling_finish) must compare at the same depth
   *ok = false;
   if (distinct) *distinct = false;
+  if (deep_flags) *deep_flags = false;
+  bool deep_ran = false;
   HIPC(hipMemsetAsync(f, 1, (size_t)n, c->stream));
   u32 tied = 0;
   bool general = false;
@@ -840,8 +1031,11 @@ static int hybrid12_refine(dc3hip_ctx *c, KM km, u32 kbits, Rec12 *h, u32 n, uin
       HIPC(hipStreamSynchronize(c->stream));
       tied = c->h_words[11];
       general = c->h_words[10] != 0;
+      deep_ran = true;
     }
   }
+  // (the general path below re-sorts every tied record by the window's full key and rewrites f[] from it)
+  if (deep_flags) *deep_flags = deep_ran && !general;
   // no group overflowed and no full key repeats: the positions the tie pass wrote to emit_sa are the sorted order
   if (distinct) *distinct = emit_sa && !general && c->h_words[12] == 0;
   if ((double)tied > std::max(kHybridMaxMeasured, c->hybrid12_max_pred + 0.1) * (double)n) return E_OK;
@@ -979,23 +1173,20 @@ static int order_hybrid(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u32
   RC(arena_alloc(c, (size_t)m02, &hb));
   RC(arena_alloc(c, (size_t)m02 + 16, &f));
   u32 *first_table = nullptr;
+  const MsdGeom mg = msd_geometry(c, m02, hm);
   {
     PhaseScope ps(c, DC3HIP_PH_PACK, m02);
-    int nb = 0; Chunking ck;
-    radix_plan<Rec8>(c, m02, hm.nbits, &nb, &ck);
+    int nb = 0; Chunking ck; u32 hshift = 0;
+    pack_plan(c, m02, hm, &mg, &nb, &ck, &hshift);
     RC(arena_alloc(c, (size_t)nb * ck.nchunks, &first_table));
-    if (nb == 512)
-      hipLaunchKernelGGL((k_pack_image_hist<Sym, 512>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, S, m, m0, m02, b, hm,
-                         ha, ck.chunk, ck.nchunks, first_table);
-    else
-      hipLaunchKernelGGL((k_pack_image_hist<Sym, 256>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, S, m, m0, m02, b, hm,
-                         ha, ck.chunk, ck.nchunks, first_table);
-    KCHECK();
+#define K_(NB) (k_pack_image_hist<Sym, NB>)
+    DC3_PACK_LAUNCH(K_, S, m, m0, m02, b, hm, ha, ck.chunk, ck.nchunks, first_table, hshift);
+#undef K_
   }
   bool sorted_ok = false;
   Key3<Sym> km; km.S = S; km.B = b;
   RC((hybrid_sort_core<Key3<Sym>>(c, km, kbits, hm, ha, hb, m02, &h, f, &sorted_ok, depth, nullptr, 0, nullptr,
-                                  first_table)));
+                                  first_table, false, &mg)));
   if (!sorted_ok) return E_OK;
   c->stats.level_sorted[depth] = 2;
   AccHyb acc; acc.h = h; acc.f = f; acc.posmask = hm.pbits >= 32 ? 0xffffffffu : ((1u << hm.pbits) - 1u);
@@ -1014,52 +1205,41 @@ static int order_hybrid(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u32
 // Packs the records of all positions; *first_table != nullptr on return when the kernel also produced the digit
 // table of the first radix pass (whole text: k_pack_image_text).
 template <class KM>
-static int launch_pack_all(dc3hip_ctx *c, KM km, u32 nrec, const HiMap &hm, Rec8 *out, u32 **first_table) {
-  int nb = 0; Chunking ck;
-  radix_plan<Rec8>(c, nrec, hm.nbits, &nb, &ck);
+static int launch_pack_all(dc3hip_ctx *c, KM km, u32 nrec, const HiMap &hm, Rec8 *out, u32 **first_table,
+                           const MsdGeom *mg = nullptr) {
+  int nb = 0; Chunking ck; u32 hshift = 0;
+  pack_plan(c, nrec, hm, mg, &nb, &ck, &hshift);
   u32 *table = nullptr;
   RC(arena_alloc(c, (size_t)nb * ck.nchunks, &table));
-  if (nb == 512)
-    hipLaunchKernelGGL((k_pack_image_all_hist<KM, 512>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, km, nrec, hm, out,
-                       ck.chunk, ck.nchunks, table);
-  else
-    hipLaunchKernelGGL((k_pack_image_all_hist<KM, 256>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, km, nrec, hm, out,
-                       ck.chunk, ck.nchunks, table);
-  KCHECK();
+#define K_(NB) (k_pack_image_all_hist<KM, NB>)
+  DC3_PACK_LAUNCH(K_, km, nrec, hm, out, ck.chunk, ck.nchunks, table, hshift);
+#undef K_
   *first_table = table;
   return E_OK;
 }
 template <>
-int launch_pack_all<Key9>(dc3hip_ctx *c, Key9 km, u32 nrec, const HiMap &hm, Rec8 *out, u32 **first_table) {
-  int nb = 0; Chunking ck;
-  radix_plan<Rec8>(c, nrec, hm.nbits, &nb, &ck);
+int launch_pack_all<Key9>(dc3hip_ctx *c, Key9 km, u32 nrec, const HiMap &hm, Rec8 *out, u32 **first_table, const MsdGeom *mg) {
+  int nb = 0; Chunking ck; u32 hshift = 0;
+  pack_plan(c, nrec, hm, mg, &nb, &ck, &hshift);
   u32 *table = nullptr;
   RC(arena_alloc(c, (size_t)nb * ck.nchunks, &table));
-  if (nb == 512)
-    hipLaunchKernelGGL((k_pack_image_text<512>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, km, nrec, hm, out, ck.chunk,
-                       ck.nchunks, table);
-  else
-    hipLaunchKernelGGL((k_pack_image_text<256>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, km, nrec, hm, out, ck.chunk,
-                       ck.nchunks, table);
-  KCHECK();
+#define K_(NB) (k_pack_image_text<NB>)
+  DC3_PACK_LAUNCH(K_, km, nrec, hm, out, ck.chunk, ck.nchunks, table, hshift);
+#undef K_
   *first_table = table;
   return E_OK;
 }
 template <>
-int launch_pack_all<KeyT>(dc3hip_ctx *c, KeyT km, u32 nrec, const HiMap &hm, Rec8 *out, u32 **first_table) {
-  int nb = 0; Chunking ck;
-  radix_plan<Rec8>(c, nrec, hm.nbits, &nb, &ck);
+int launch_pack_all<KeyT>(dc3hip_ctx *c, KeyT km, u32 nrec, const HiMap &hm, Rec8 *out, u32 **first_table, const MsdGeom *mg) {
+  int nb = 0; Chunking ck; u32 hshift = 0;
+  pack_plan(c, nrec, hm, mg, &nb, &ck, &hshift);
   u32 *table = nullptr;
   RC(arena_alloc(c, (size_t)nb * ck.nchunks, &table));
   u64 P1 = 1;
   for (u32 i = 0; i + 1 < km.J; i++) P1 *= km.sigma;
-  if (nb == 512)
-    hipLaunchKernelGGL((k_pack_image_textT<512, false>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, km, nrec, hm, P1,
-                       (void *)out, ck.chunk, ck.nchunks, table);
-  else
-    hipLaunchKernelGGL((k_pack_image_textT<256, false>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, km, nrec, hm, P1,
-                       (void *)out, ck.chunk, ck.nchunks, table);
-  KCHECK();
+#define K_(NB) (k_pack_image_textT<NB, false>)
+  DC3_PACK_LAUNCH(K_, km, nrec, hm, P1, (void *)out, ck.chunk, ck.nchunks, table, hshift);
+#undef K_
   *first_table = table;
   return E_OK;
 }
@@ -1227,13 +1407,14 @@ static int order_all_positions(dc3hip_ctx *c, KM km, Map mp, u32 m, u32 kbits, c
   RC(arena_alloc(c, (size_t)nrec, &hb));
   RC(arena_alloc(c, (size_t)nrec + 16, &f));
   u32 *first_table = nullptr;
+  const MsdGeom mg = msd_geometry(c, nrec, hm);
   {
     PhaseScope ps(c, DC3HIP_PH_PACK, nrec);
-    RC(launch_pack_all<KM>(c, km, nrec, hm, ha, &first_table));
+    RC(launch_pack_all<KM>(c, km, nrec, hm, ha, &first_table, &mg));
   }
   bool sorted_ok = false, distinct = false;
   RC((hybrid_sort_core<KM>(c, km, kbits, hm, ha, hb, nrec, &h, f, &sorted_ok, depth, out_rank ? nullptr : out_sa, dummy,
-                           &distinct, first_table, std::is_same<Map, MapText>::value && dummy == 0 && !out_rank)));
+                           &distinct, first_table, std::is_same<Map, MapText>::value && dummy == 0 && !out_rank, &mg)));
   if (sorted_ok && distinct) {
     *state = 1;                            // the tie pass already wrote the suffix array
   } else if (sorted_ok) {
@@ -1557,6 +1738,8 @@ static int build_end(dc3hip_ctx *c) {
       }
       if (m.kclass == 4) { c->stats.gather_ms += t; c->stats.gather_launches += 1; c->stats.gather_elems += m.elems; continue; }
       if (m.kclass == 3) { c->stats.partition_ms += t; c->stats.partition_launches += 1; c->stats.partition_elems += m.elems; }
+      if (m.kclass == 5) { c->stats.msd_part_ms += t; c->stats.msd_part_launches += 1; c->stats.msd_part_elems += m.elems; }
+      if (m.kclass == 6) { c->stats.msd_local_ms += t; c->stats.msd_local_launches += 1; c->stats.msd_local_elems += m.elems; }
       if (m.kclass >= 0 && m.kclass < 3) {
         c->stats.downsweep_ms[m.kclass] += t; c->stats.downsweep_launches[m.kclass] += 1;
         c->stats.downsweep_elems[m.kclass] += m.elems;
@@ -1655,10 +1838,10 @@ int launch_pack12_all<KeyT>(dc3hip_ctx *c, KeyT km, u32 nrec, const HiMap &hm, R
   for (u32 i = 0; i + 1 < km.J; i++) P1 *= km.sigma;
   if (nb == 512)
     hipLaunchKernelGGL((k_pack_image_textT<512, true>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, km, nrec, hm, P1,
-                       (void *)out, ck.chunk, ck.nchunks, table);
+                       (void *)out, ck.chunk, ck.nchunks, table, 0u);
   else
     hipLaunchKernelGGL((k_pack_image_textT<256, true>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, km, nrec, hm, P1,
-                       (void *)out, ck.chunk, ck.nchunks, table);
+                       (void *)out, ck.chunk, ck.nchunks, table, 0u);
   KCHECK();
   return E_OK;
 }
@@ -1711,8 +1894,8 @@ static int try_text_order12(dc3hip_ctx *c, KM km, u64 BL, const HiMap &hm, u32 s
   }
   RC(radix_sort<Rec12>(c, ha, hb, (u32)n, 0, hm.nbits, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT12_DOWN,
                        first_table));
-  bool refined = false, distinct = false;
-  RC((hybrid12_refine<KM>(c, km, kbits, h, (u32)n, f, &refined, 0, c->d_sa, &distinct)));
+  bool refined = false, distinct = false, deep_flags = false;
+  RC((hybrid12_refine<KM>(c, km, kbits, h, (u32)n, f, &refined, 0, c->d_sa, &distinct, &deep_flags)));
   int state = 0;
   const u32 m0 = (u32)((n + 2) / 3), m1 = m0 + (u32)(n / 3);
   const u32 m02_1 = (m1 + 2) / 3 + m1 / 3;
@@ -1720,7 +1903,12 @@ static int try_text_order12(dc3hip_ctx *c, KM km, u64 BL, const HiMap &hm, u32 s
   bool doubled = false;
   if (refined && !distinct) {
     AccHyb12 acc; acc.h = h; acc.f = f;
-    RC((doubling_finish<KM, AccHyb12>(c, km, acc, (u32)n, km.window_syms(), c->d_sa, &doubled)));
+    // the rank look-ups of the doubling (binary searches with km.cmp) must compare as deep as the flags were made:
+    // after the second tie pass the groups of f[] agree on kDeepSyms symbols, and a search with the window alone
+    // would return the lower bound of the whole window-equal run for an untied position behind such a group
+    KM kd = km;
+    if (deep_flags) kd.deep = kDeepSyms;
+    RC((doubling_finish<KM, AccHyb12>(c, kd, acc, (u32)n, deep_flags ? kDeepSyms : km.window_syms(), c->d_sa, &doubled)));
   }
   if (refined && (distinct || doubled)) {
     state = 1;                             // the tie pass (or the doubling rounds) already wrote the suffix array
@@ -1851,6 +2039,8 @@ int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) {
   { const char *e = getenv("DC3HIP_NO_DOUBLING"); c->no_doubling = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_TEXT_ORDER12"); if (e && (e[0] == '0' || e[0] == '1')) c->text_order12 = e[0] - '0'; }
   { const char *e = getenv("DC3HIP_NO_TUP8"); c->no_tup8 = (e && e[0] == '1'); }
+  { const char *e = getenv("DC3HIP_NO_MSD"); c->no_msd = (e && e[0] == '1'); }
+  { const char *e = getenv("DC3HIP_MSD_MIN"); if (e) c->msd_min = (u32)std::max(4096ll, atoll(e)); }
   { const char *e = getenv("DC3HIP_NO_HYBRID12"); c->no_hybrid12 = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_HYBRID8"); c->no_hybrid8 = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_HYBRID12_MIN"); if (e) c->hybrid12_min = (u32)std::max(0ll, atoll(e)); }

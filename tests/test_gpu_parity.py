@@ -571,6 +571,45 @@ def test_prefix_doubling_finish_of_few_repeated_windows(ss, oracle):
                     os.environ.pop(k, None)
 
 
+def test_deep_tie_pass_then_doubling_on_12_byte_records(ss, oracle):
+    """Regression (round-2 advisor finding): on 12-byte records the second, deeper tie pass leaves f[] marking groups that
+    agree on 2048 symbols; the prefix doubling that follows must look ranks up at the same depth.  The case that broke:
+    a handful of copies (few enough, <= n/4096+16 equal windows, for the deep pass to run) of a block LONGER than 2048
+    symbols whose continuations sort as [A | C, C | G] — an untied copy behind a still-tied pair inside one
+    window-equal run.  Bytes and DNA, 8- and 12-byte records, against divsufsort."""
+    rng = np.random.default_rng(77)
+    n = (1 << 24) + 11
+    for name, sigma in (("dna", 4), ("bytes", 256)):
+        if sigma == 4:
+            d = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=n)].copy()
+            letters = b"ACGT"
+        else:
+            d = rng.integers(0, 256, size=n, dtype=np.uint8)
+            letters = bytes([3, 90, 90, 200, 250])
+        block = d[1000:3500].copy()                                   # 2500 symbols
+        tails = [letters[0], letters[1], letters[1], letters[3 % len(letters)], letters[-1]] if sigma == 4 else list(letters)
+        # two of the copies continue identically for another 3000 symbols (stay tied beyond 2048 + 2500), the others
+        # split off right behind the block
+        cont = d[50_000:53_000].copy()
+        for k, t in enumerate(tails):
+            at = 1_000_003 * (k + 2)
+            d[at:at + 2500] = block
+            d[at + 2500] = t
+            if k in (1, 2):
+                d[at + 2501:at + 2501 + 3000] = cont
+        data = d.tobytes()
+        want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)
+        for env in ({"DC3HIP_TEXT_ORDER12": "1"}, {}, {"DC3HIP_TEXT_ORDER12": "1", "DC3HIP_NO_DOUBLING": "1"}):
+            os.environ.update(env)
+            try:
+                with ss.Context(len(data)) as c:
+                    c.set_text(data); c.build()
+                    assert np.array_equal(c.sa(), want), (name, env, c.stats()["level_sorted"][:3])
+            finally:
+                for k in env:
+                    os.environ.pop(k, None)
+
+
 def test_wide_and_narrow_direct_names_agree(ss, oracle):
     """Direct names pack w = 3 symbols by default; DC3HIP_WIDE_NAMES=1 packs as many as fit 31 bits
     (13 for DNA, 6 for 28-letter text).  Same SA either way."""
