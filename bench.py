@@ -4,15 +4,21 @@
 A "step" = one device-resident suffix-array build of this rank's share of the text (text already in HBM,
 SA left in HBM).  Two multi-GPU semantics:
 
-  --mode sacapart (default)  crates/sacapart/src/lib.rs:39-58: the N x SIZE byte text is cut into chunks of
-                             len/N + 1 bytes, rank c builds the independent local SA of chunk c — no data-path
-                             collective, weak scaling.
-  --mode global              ONE suffix array of the whole N x SIZE text, sharded over the ranks by suffix rank;
-                             text blocks are all-gathered and sample ranks exchanged over RCCL (xGMI); see DESIGN.md §6.
+  sacapart   crates/sacapart/src/lib.rs:39-58: the N x SIZE byte text is cut into chunks of len/N + 1 bytes, rank c
+             builds the independent local SA of chunk c — no data-path collective, weak scaling.
+  global     ONE suffix array of the whole N x SIZE text, sharded over the ranks by suffix rank; text blocks are
+             all-gathered and sample ranks exchanged over RCCL (xGMI); see DESIGN.md §6.
+
+--mode auto (default): N = 1 is the single-GPU build.  N > 1 runs BOTH legs, K timed steps each, and prints ONE line:
+`value` = the global mode (what north_star asks for: one true SA, RCCL rank exchange; `interconnect` has its bytes and
+time), `sacapart` = the reference's own partitioned semantics beside it, `cpu_baseline` = sacapart's parallel story on
+the host (P chunks of len/P + 1 bytes on P pinned threads, one divsufsort() each).  An N > 1 run starts with a transport
+self-test (ragged all-to-all / all-gather of known bytes through the library's RCCL communicator, every byte checked,
+ncclCommCount compared with N) and exits non-zero if it fails — a run never reports a host-staged number as xGMI.
 
 Rank 0 prints ONE JSON line.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--size BYTES] [--kind random|dna|text] [--mode sacapart|global]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size BYTES] [--kind random|dna|text] [--mode auto|sacapart|global]
                     [--cpu-sample-mib M] [--no-cpu] [--no-verify] [--no-extras]
     N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
              --master-port P bench.py --gpus N ...
@@ -27,7 +33,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from stringsearch_amd.benchlib import HBM_PEAK_GBS, KINDS, PATH_NAMES, kernel_rooflines, parse_size, path_roofline  # noqa: E402
+from stringsearch_amd.benchlib import HBM_PEAK_GBS, KINDS, PATH_NAMES, KernelAcc, kernel_rooflines, parse_size, path_roofline  # noqa: E402
 
 
 def host_cpu_model():
@@ -75,6 +81,61 @@ def cpu_baseline(text_u8, sample_bytes):
             "seconds": dt, "host_cpu": host_cpu_model(), "host_cores_available": os.cpu_count()}, sa
 
 
+def cpu_baseline_partitions(ss, P, total_len, sample_bytes, seed, kind, device):
+    """sacapart's parallel story on the host (crates/sacapart/src/lib.rs:12-14,43-49): the P chunks of len/P + 1 bytes,
+    one divsufsort() per chunk, P host threads pinned to P different cores — on a bounded sample (the first
+    `sample_bytes` of every chunk) so that the run stays within minutes.  The chunk texts come from the same device
+    generator as the GPU legs."""
+    import threading
+    import numpy as np
+    from stringsearch_amd.partition import rank_chunk
+    ref = os.path.join(ROOT, "oracle", "_ref", "libdivsufsort_ref.so")
+    port = os.path.join(ROOT, "oracle", "liboracle_dc3.so")
+    if os.path.exists(ref):
+        L = ctypes.CDLL(ref); f = L.divsufsort; kindname = "reference"
+    elif os.path.exists(port):
+        L = ctypes.CDLL(port); f = L.dc3_oracle_sufsort_i32; kindname = "port"
+    else:
+        return None
+    f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]; f.restype = ctypes.c_int32
+    texts = []
+    for c in range(P):
+        off, ln = rank_chunk(total_len, P, c)
+        m = min(ln, sample_bytes)
+        with ss.Context(m, device=device) as cx:
+            cx.generate(m, seed, kind, offset=off)
+            texts.append(cx.text())
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+    except Exception:
+        cores = list(range(os.cpu_count() or 1))
+    secs = [0.0] * P
+    rcs = [0] * P
+
+    def work(c):
+        try:
+            os.sched_setaffinity(0, {cores[c % len(cores)]})       # (Linux: pid 0 = the calling thread)
+        except Exception:
+            pass
+        t = time.perf_counter()
+        sa = np.zeros(len(texts[c]), dtype=np.int32)              # incl. the SA allocation, as divsuftest's measure()
+        rcs[c] = f(texts[c].ctypes.data, sa.ctypes.data, len(texts[c]))
+        secs[c] = time.perf_counter() - t
+    th = [threading.Thread(target=work, args=(c,)) for c in range(P)]
+    t0 = time.perf_counter()
+    for t in th: t.start()
+    for t in th: t.join()
+    wall = time.perf_counter() - t0
+    assert all(r == 0 for r in rcs), rcs
+    nbytes = sum(len(t) for t in texts)
+    whole = all(len(texts[c]) == rank_chunk(total_len, P, c)[1] for c in range(P))
+    return {"value": nbytes / wall / 1e6, "unit": "MB/s", "cores": min(P, len(cores)), "kind": kindname,
+            "sample": (f"sacapart on the host: {P} chunks of len/{P}+1 bytes, " + ("whole chunks" if whole else f"first {sample_bytes >> 20} MiB of every chunk")
+                       + f", one divsufsort() per chunk on {min(P, len(cores))} pinned threads, wall clock incl. SA allocation ({wall:.2f} s)"),
+            "seconds": wall, "per_thread_seconds": [round(x, 3) for x in secs], "host_cpu": host_cpu_model(),
+            "host_cores_available": len(cores)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,11 +143,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=str, default="1GiB", help="bytes per GPU")
     ap.add_argument("--kind", type=str, default="random", choices=list(KINDS))
-    ap.add_argument("--mode", type=str, default="sacapart", choices=["sacapart", "global"])
+    ap.add_argument("--mode", type=str, default="auto", choices=["auto", "sacapart", "global"])
+    ap.add_argument("--global-timeout", type=int, default=900, help="N > 1, --mode auto: seconds the global leg may take before the "
+                    "line is printed with the sacapart leg alone (and the failure stated)")
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--cpu-sample-mib", type=int, default=0,
-                    help="CPU baseline sample in MiB of the same buffer; 0 = the whole buffer (1 GiB is ~60-80 s of one-core "
-                         "divsufsort and doubles as the bit-exact comparison)")
+                    help="CPU baseline sample in MiB of the same buffer; 0 = N = 1: the whole buffer (1 GiB is ~60-80 s of one-core "
+                         "divsufsort and doubles as the bit-exact comparison); N > 1: 256 MiB of every chunk")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -131,9 +194,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.mode == "global" and world > 1:
+    # ---- N > 1: the library's own transport first — created strictly (no silent fallback) and self-tested
+    G = None
+    selftest = None
+    do_global = world > 1 and args.mode in ("auto", "global")
+    do_sacapart = world == 1 or args.mode in ("auto", "sacapart")
+    if do_global:
+        from stringsearch_amd.bench_global import make_rank, global_total
+        gtotal, gwide, gclipped = global_total(per_gpu * world, kind)
+        G = make_rank(ss, dist, backend, world, rank, local_rank, gtotal)          # exits non-zero if RCCL cannot be had
+        try:
+            seen = G.selftest()
+        except Exception as e:
+            print(f"bench.py: rank {rank}: transport self-test FAILED: {e!r}", file=sys.stderr, flush=True)
+            os._exit(4)
+        if backend == "nccl" and seen != world:
+            print(f"bench.py: rank {rank}: the RCCL communicator reports {seen} ranks, the job has {world}: refusing to call this run RCCL over xGMI",
+                  file=sys.stderr, flush=True)
+            os._exit(4)
+        selftest = {"passed": True, "transport": G.transport(), "ranks_seen_by_transport": seen, "world_size": world,
+                    "what": "ragged all_to_all_v + ragged all_gather_v + host all-gather of known bytes through the library's communicator, every byte checked on every rank"}
+    if not do_sacapart:
         from stringsearch_amd.bench_global import run_global
-        out = run_global(args, ss, dist, backend, world, rank, local_rank, per_gpu, kind, barrier)
+        out = run_global(args, ss, dist, backend, world, rank, local_rank, per_gpu, kind, barrier, G=G)
+        if rank == 0:
+            out["transport_selftest"] = selftest
         if use_dist:
             dist.barrier()
             dist.destroy_process_group()
@@ -162,17 +247,11 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    kernel_ms = 0.0
-    dsw_ms = [0.0] * 3; dsw_launches = [0] * 3; dsw_elems = [0] * 3
-    g_ms = 0.0; g_launches = 0; g_elems = 0
+    kacc = KernelAcc()
     for _ in range(args.steps):
         ctx.build()
-        st = ctx.stats()
-        kernel_ms += st["build_ms"]
-        g_ms += st["gather_ms"]; g_launches += st["gather_launches"]; g_elems += st["gather_elems"]
-        for k in range(3):
-            dsw_ms[k] += st["downsweep_ms"][k]; dsw_launches[k] += st["downsweep_launches"][k]
-            dsw_elems[k] += st["downsweep_elems"][k]
+        kacc.add(ctx.stats())
+    kernel_ms = kacc.build_ms
     barrier()
     dt = time.perf_counter() - t0
     if use_dist:
@@ -191,11 +270,8 @@ def main():
     out = None
     if rank == 0:
         value = total_len * args.steps / dt / 1e6
-        roof_radix, roof_gather = kernel_rooflines((dsw_ms, dsw_launches, dsw_elems, g_ms, g_launches, g_elems), args.steps, st, kernel_ms)
-        # `roofline` = the kernel with the largest share of the build; the other one is kept beside it
-        roof = roof_radix
-        if roof_gather is not None and (roof is None or roof_gather["share_of_build_time"] >= roof["share_of_build_time"]):
-            roof = roof_gather
+        # `roofline` = the kernel family with the largest share of the build time; all families are kept beside it
+        roof, roof_all = kernel_rooflines(kacc, args.steps, st, kernel_ms)
         out = {
             "metric": "MB/s of input indexed (SA build), 1 GiB bytes, 1/2/4/8 GPUs",
             "value": value, "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -210,7 +286,8 @@ def main():
                      "note": "`value` is produced by this path; the DC3 recursion on the same input is `dc3_recursion_only`, "
                              "low-entropy text and DNA are `per_config`"},
             "value_MiBps": total_len * args.steps / dt / 2**20,     # the reference prints binary units (divsuftest main.rs:179-183)
-            "roofline": roof, "roofline_radix_scatter": roof_radix, "roofline_path": path_roofline(st, kernel_ms / args.steps),
+            "roofline": roof, "roofline_kernels": roof_all, "roofline_path": path_roofline(st, kernel_ms / args.steps),
+            "msd": {k: st.get(k) for k in ("msd_sorts", "msd_fallbacks", "msd_max_subbucket")},
             "verify": verify, "arena_peak_GB": st["arena_peak"] / 1e9,
         }
         text = None
@@ -368,6 +445,48 @@ def main():
                     assert out["global_mode_beyond_2pow32"]["global_sufcheck"] == 0 and out["global_mode_beyond_2pow32"]["shards_tile_0_n"]
             except ss.Dc3HipError as e:
                 out["global_mode_beyond_2pow32"] = {"skipped": str(e)}
+    if world > 1:
+        sac = out                                   # rank 0: the sacapart leg's line; others: None
+        if do_global:
+            # ---- the global leg (defines `value` of an N > 1 line).  A failure or a hang of this leg must not cost the
+            # run its line: after --global-timeout seconds, or on an exception, rank 0 prints the sacapart leg alone and
+            # says so.
+            import threading
+            done = threading.Event()
+
+            def give_up(why):
+                if done.is_set():
+                    return
+                done.set()
+                if rank == 0:
+                    sac["global_mode"] = {"error": why}
+                    sac["value_mode"] = "sacapart (the global leg did not finish: see global_mode.error)"
+                    sac["transport_selftest"] = selftest
+                    print(json.dumps(sac), flush=True)
+                os._exit(0 if rank == 0 else 5)
+            wd = threading.Timer(args.global_timeout, give_up, args=(f"no result after {args.global_timeout} s",))
+            wd.daemon = True
+            wd.start()
+            try:
+                from stringsearch_amd.bench_global import run_global
+                outg = run_global(args, ss, dist, backend, world, rank, local_rank, per_gpu, kind, barrier, G=G)
+            except BaseException as e:          # noqa: BLE001 - reported in the line
+                give_up(repr(e))
+            wd.cancel()
+            done.set()
+            if rank == 0:
+                keep = ("value", "unit", "ms_per_step", "value_MiBps", "roofline", "roofline_path", "verify", "config", "path", "arena_peak_GB")
+                outg["sacapart"] = {k: sac[k] for k in keep if k in sac}
+                outg["sacapart"]["note"] = ("the reference's own multi-chunk semantics (crates/sacapart/src/lib.rs:39-58): N independent local "
+                                            "suffix arrays, one chunk per GPU, no data-path collective; same K timed steps")
+                outg["value_mode"] = "global (ONE suffix array over all ranks, rank exchange over the transport in `interconnect`)"
+                outg["transport_selftest"] = selftest
+                out = outg
+        if rank == 0 and not args.no_cpu:
+            sample = (args.cpu_sample_mib << 20) if args.cpu_sample_mib > 0 else (256 << 20)
+            cb = cpu_baseline_partitions(ss, world, per_gpu * world, sample, args.seed, kind, local_rank)
+            if cb is not None:
+                out["cpu_baseline"] = cb
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -234,9 +234,12 @@ DC3HIP_API int32_t dc3hip_ctx_debug_radix_pass_u64(dc3hip_ctx *ctx, const uint64
  * Transport: RCCL over xGMI (one process per GPU; the host program carries the 128-byte unique id from rank 0 to
  * the others, e.g. with torch.distributed / MPI), or the in-process loopback (P ranks on ONE device, used to
  * parity-test P in {2,4,8} on a single-GPU box).  n <= DC3HIP_MAX_N; P <= 16.
- * Failure semantics: a build that fails on one rank (e.g. -2) returns there at once; loopback peers are released and
- * return -3 ("another rank failed"), and the group can be used again.  RCCL / host-staged peers are inside a collective
- * at that point and keep waiting, as in any NCCL program: the host job's watchdog has to tear the group down.
+ * Failure semantics: a collective call (build, sufcheck) that fails on one rank (e.g. -2) returns there at once; loopback
+ * peers are released and return -3 ("another rank failed"), and once EVERY rank has returned from the failed call the
+ * group can be used again through any entry point.  Refusals of the wide mode that depend on the data and on the rank (a
+ * rank's share above DC3HIP_MAX_N suffixes: -4, no device memory for its records: -2) are agreed on inside the build: every
+ * rank returns the same code, under every transport.  Other faults under RCCL / the host-staged transport leave the peers
+ * inside a collective, as in any NCCL program: the host job's watchdog has to tear the group down.
  * Environment: DC3HIP_GLOBAL_LOCAL_MAX (levels up to this length are finished by every rank on its own replicated
  * copy, default 2^22), DC3HIP_GLOBAL_NO_TEXT_ORDER=1 (skip the distributed whole-text order).
  * WIDE contexts (max_total_n > DC3HIP_MAX_N, up to 2^40; or DC3HIP_GLOBAL_FORCE_WIDE=1): positions are 64-bit, and only
@@ -311,6 +314,12 @@ DC3HIP_API int32_t dc3hip_global_sufcheck(dc3hip_gctx *g);
 DC3HIP_API int32_t dc3hip_global_stats(dc3hip_gctx *g, dc3hip_gstats *out, dc3hip_stats *ctx_stats /* may be NULL */);
 DC3HIP_API const char *dc3hip_global_last_error(dc3hip_gctx *g);   /* error of this rank's last build (loopback threads) */
 DC3HIP_API const char *dc3hip_global_transport(dc3hip_gctx *g);
+/* Transport self-test, a COLLECTIVE like the build: a ragged all-to-all, a ragged all-gather and a host all-gather of
+ * known bytes through this group's transport, every byte checked on every rank.  0 = delivered exactly; -3 = a byte was
+ * wrong or the transport failed (dc3hip_global_last_error says where).  *transport_ranks (may be NULL) = the number of
+ * ranks the transport itself reports (RCCL: ncclCommCount; -1 if it cannot tell; other transports: nranks) — a host
+ * program uses it to refuse to label a run "RCCL over xGMI" that is not (bench.py does, at the start of every N > 1 run). */
+DC3HIP_API int32_t dc3hip_global_selftest(dc3hip_gctx *g, int32_t *transport_ranks);
 
 #ifdef __cplusplus
 }

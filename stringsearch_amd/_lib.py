@@ -148,6 +148,7 @@ SYMBOLS = {
     "dc3hip_global_stats": (_i32, [_vp, ctypes.POINTER(GStats), ctypes.POINTER(Stats)]),
     "dc3hip_global_last_error": (ctypes.c_char_p, [_vp]),
     "dc3hip_global_transport": (ctypes.c_char_p, [_vp]),
+    "dc3hip_global_selftest": (_i32, [_vp, ctypes.POINTER(_i32)]),
 }
 
 _lib = None

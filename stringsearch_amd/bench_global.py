@@ -6,16 +6,27 @@ over ranks of the wall time between two barriers).  The text is generated per ra
 import os
 import time
 
-from .benchlib import HBM_PEAK_GBS, PATH_NAMES, kernel_rooflines, path_roofline
+from .benchlib import HBM_PEAK_GBS, PATH_NAMES, KernelAcc, kernel_rooflines, path_roofline
 
 MAX_N = 4278190080            # DC3HIP_MAX_N: positions are unsigned 32-bit on the device
 XGMI_LINK_GBS = 153.0         # per direction and link (prompt / MI355X guide: 7 links x ~153 GB/s per GPU)
 
 
+def global_total(total, kind):
+    """(bytes of the one text, wide?, clipped?): beyond DC3HIP_MAX_N the library switches to 64-bit positions (wide mode) —
+    high-entropy inputs only, so the low-entropy text generator is clipped to the 32-bit limit instead."""
+    wide = (total > MAX_N or os.environ.get("DC3HIP_GLOBAL_FORCE_WIDE") == "1") and kind != 2
+    clipped = total > MAX_N and not wide
+    return (MAX_N if clipped else total), wide, clipped
+
+
 def make_rank(ss, dist, backend, world, rank, local_rank, max_total):
-    """RCCL (default, one rank per GPU) or the host-staged transport over the gloo group (several ranks per GPU).
-    If the library's own RCCL communicator cannot be created on some rank, ALL ranks fall back to the host-staged
-    transport over a gloo group (the ranks agree on that with one all-reduce)."""
+    """This process's rank of the group: RCCL (backend nccl: one rank per GPU) or the host-staged transport over the gloo
+    group (DC3HIP_BENCH_BACKEND=gloo: several ranks on one GPU — the plumbing test on 1-GPU boxes, which says so in
+    `interconnect.transport`).  With backend nccl there is NO fallback: if the library's RCCL communicator cannot be
+    created on every rank the run exits non-zero (unless DC3HIP_BENCH_ALLOW_HOST_FALLBACK=1 explicitly asks for the
+    host-staged transport, and then the line names it)."""
+    import sys
     if backend == "nccl":
         import torch
         g = None
@@ -36,9 +47,13 @@ def make_rank(ss, dist, backend, world, rank, local_rank, max_total):
             return g
         if g is not None:
             g.close()
+        if os.environ.get("DC3HIP_BENCH_ALLOW_HOST_FALLBACK") != "1":
+            print(f"bench_global: rank {rank}: the library's RCCL communicator could not be created ({err or 'on another rank'}); "
+                  "not falling back to a host-staged transport (DC3HIP_BENCH_ALLOW_HOST_FALLBACK=1 would)", file=sys.stderr, flush=True)
+            os._exit(4)
         if rank == 0:
-            print(f"bench_global: RCCL transport unavailable ({err or 'on another rank'}); using the host-staged transport over gloo",
-                  flush=True)
+            print(f"bench_global: RCCL transport unavailable ({err or 'on another rank'}); DC3HIP_BENCH_ALLOW_HOST_FALLBACK=1: "
+                  "using the host-staged transport over gloo", flush=True)
         grp = dist.new_group(backend="gloo")
 
         class _GroupDist:               # the subset of torch.distributed the callbacks use, bound to the gloo group
@@ -56,18 +71,13 @@ def make_rank(ss, dist, backend, world, rank, local_rank, max_total):
     return ss.GlobalRank.torch_host(dist, rank, world, local_rank, max_total)
 
 
-def run_global(args, ss, dist, backend, world, rank, local_rank, per_gpu, kind, barrier):
+def run_global(args, ss, dist, backend, world, rank, local_rank, per_gpu, kind, barrier, G=None):
     import numpy as np
     import torch
 
-    total = per_gpu * world
-    # beyond DC3HIP_MAX_N the library switches to 64-bit positions (wide mode): high-entropy inputs only, so the
-    # low-entropy text generator is clipped to the 32-bit limit instead
-    wide = (total > MAX_N or os.environ.get("DC3HIP_GLOBAL_FORCE_WIDE") == "1") and kind != 2
-    clipped = total > MAX_N and not wide
-    if clipped:
-        total = MAX_N
-    G = make_rank(ss, dist, backend, world, rank, local_rank, total)
+    total, wide, clipped = global_total(per_gpu * world, kind)
+    if G is None:
+        G = make_rank(ss, dist, backend, world, rank, local_rank, total)
     G.generate(total, args.seed, kind)
     for _ in range(max(args.warmup, 1)):
         G.build()
@@ -76,20 +86,15 @@ def run_global(args, ss, dist, backend, world, rank, local_rank, per_gpu, kind, 
     barrier()
     t0 = time.perf_counter()
     acc = None
-    kernel_ms = 0.0
-    dsw_ms = [0.0] * 3; dsw_launches = [0] * 3; dsw_elems = [0] * 3
-    g_ms = 0.0; g_launches = 0; g_elems = 0
+    kacc = KernelAcc()
     comm_ms = 0.0; comm_in = 0; comm_out = 0
     for _ in range(args.steps):
         G.build()
         st = G.stats()
-        c = st["ctx"]
-        kernel_ms += c["build_ms"]
-        g_ms += c["gather_ms"]; g_launches += c["gather_launches"]; g_elems += c["gather_elems"]
-        for k in range(3):
-            dsw_ms[k] += c["downsweep_ms"][k]; dsw_launches[k] += c["downsweep_launches"][k]; dsw_elems[k] += c["downsweep_elems"][k]
+        kacc.add(st["ctx"])
         comm_ms += st["comm_ms"]; comm_in += st["comm_bytes_in"]; comm_out += st["comm_bytes_out"]
         acc = st
+    kernel_ms = kacc.build_ms
     barrier()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
@@ -139,11 +144,7 @@ def run_global(args, ss, dist, backend, world, rank, local_rank, per_gpu, kind, 
             except ss.Dc3HipError as e:
                 verify["single_device_reference"] = f"skipped: {e}"
         value = total * args.steps / dt / 1e6
-        roof_radix, roof_gather = kernel_rooflines((dsw_ms, dsw_launches, dsw_elems, g_ms, g_launches, g_elems), args.steps, ctx_stats,
-                                                   max(kernel_ms, 1e-9))
-        roof = roof_radix
-        if roof_gather is not None and (roof is None or roof_gather["share_of_build_time"] >= roof["share_of_build_time"]):
-            roof = roof_gather
+        roof, _ = kernel_rooflines(kacc, args.steps, ctx_stats, max(kernel_ms, 1e-9))
         worst = max(info, key=lambda d: d["comm_ms"])
         out = {
             "metric": "MB/s of input indexed (SA build), 1 GiB bytes, 1/2/4/8 GPUs",
@@ -165,6 +166,7 @@ def run_global(args, ss, dist, backend, world, rank, local_rank, per_gpu, kind, 
             "interconnect": {"transport": transport,
                              "bytes_in_per_rank_per_step": [d["in"] for d in info], "bytes_out_per_rank_per_step": [d["out"] for d in info],
                              "comm_ms_per_step": [round(d["comm_ms"], 3) for d in info],
+                             "comm_ms": round(worst["comm_ms"], 3),
                              "device_ms_per_step": [round(d["device_ms"], 3) for d in info],
                              "achieved_GBps_in_slowest_rank": worst["in"] / max(worst["comm_ms"], 1e-9) / 1e6,
                              "peak_GBps_in": XGMI_LINK_GBS * min(world - 1, 7),

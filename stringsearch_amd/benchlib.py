@@ -28,32 +28,91 @@ def algorithmic_bytes(level_n):
     return total
 
 
-def kernel_rooflines(st_acc, steps, st_last, kernel_ms):
-    """roofline objects of the two kernel families that dominate builds: the stable radix scatter
-    k_rs_downsweep<Rec,...> (per record type) and the random tuple gather k_gather_tuples."""
-    dsw_ms, dsw_launches, dsw_elems, g_ms, g_launches, g_elems = st_acc
-    # algorithmic bytes per record-pass of the scatter = the reference's loop lib.rs:35-38: read a[i] (w) +
-    # r[a[i]] (c) + write b[..] (w) = 2w + c = 12 B at w = c = 4 (SURVEY §8d table, scatter half).
-    roof = None
-    kc = max(range(3), key=lambda k: dsw_ms[k])
-    if dsw_launches[kc]:
-        rec_bytes = (8, 16, 20)[kc]
-        rec_name = ("Rec8 (key,value) pairs", "Rec16 triple records (12-byte Rec12 when the key fits 64 bits)", "Tup0 mod-0 tuples")[kc]
-        per_launch_elems = dsw_elems[kc] / dsw_launches[kc]
-        avg_ms = dsw_ms[kc] / dsw_launches[kc]
-        achieved = 12.0 * per_launch_elems / (avg_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": f"k_rs_downsweep<{rec_name.split()[0]}> (stable 8/9-bit-digit radix scatter of {rec_name})",
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
-                "algorithmic_bytes_per_launch": 12.0 * per_launch_elems, "avg_launch_ms": avg_ms,
-                "launches_per_step": dsw_launches[kc] / steps,
-                "share_of_build_time": dsw_ms[kc] / kernel_ms,
-                "moved_bytes_per_launch": 2.0 * rec_bytes * per_launch_elems,
-                "moved_GBps": 2.0 * rec_bytes * per_launch_elems / (avg_ms * 1e-3) / 1e9,
-                "all_record_types_ms_per_step": [x / steps for x in dsw_ms]}
-    roof_gather = None
-    if g_launches:
-        ge = g_elems / g_launches; gms = g_ms / g_launches
+def kernel_sources_sha():
+    """sha256 over the kernel and host-driver sources the timed kernels are compiled from.  A PMC collection is only
+    replayed into `roofline.traffic` when it was made on exactly these sources (profiles/pmc_traffic.json carries the hash
+    of the tree it profiled): the GPU box has no .git, so a commit id cannot be checked there."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "stringsearch_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hpp")) + glob.glob(os.path.join(d, "*.hip"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+class KernelAcc:
+    """Per-kernel-family HIP-event times summed over the timed steps (dc3hip_stats of every build)."""
+    FAMS = ("downsweep0", "downsweep1", "downsweep2", "gather", "partition", "msd_part", "msd_local")
+
+    def __init__(self):
+        self.ms = {k: 0.0 for k in self.FAMS}
+        self.launches = {k: 0 for k in self.FAMS}
+        self.elems = {k: 0 for k in self.FAMS}
+        self.build_ms = 0.0
+
+    def add(self, st):
+        self.build_ms += st["build_ms"]
+        for k in range(3):
+            self._add(f"downsweep{k}", st["downsweep_ms"][k], st["downsweep_launches"][k], st["downsweep_elems"][k])
+        self._add("gather", st["gather_ms"], st["gather_launches"], st["gather_elems"])
+        self._add("partition", st["partition_ms"], st["partition_launches"], st["partition_elems"])
+        self._add("msd_part", st.get("msd_part_ms", 0.0), st.get("msd_part_launches", 0), st.get("msd_part_elems", 0))
+        self._add("msd_local", st.get("msd_local_ms", 0.0), st.get("msd_local_launches", 0), st.get("msd_local_elems", 0))
+
+    def _add(self, k, ms, launches, elems):
+        self.ms[k] += ms; self.launches[k] += launches; self.elems[k] += elems
+
+
+# family -> (kernel name, algorithmic bytes per record, physically moved bytes per record, key in pmc_traffic.json)
+# Algorithmic bytes of a scatter pass = the reference's loop lib.rs:35-38: read a[i] (w) + r[a[i]] (c) + write b[..] (w) =
+# 2w + c = 12 B at w = c = 4 (SURVEY §8d table, scatter half) — the bucket partition pass does that loop's work for one
+# digit exactly like a stable pass does, so it is priced the same; the in-LDS local order replaces the remaining passes of
+# the sort in one launch and is priced as ONE such pass (a lower bound of what it replaces).
+_FAM = {
+    "downsweep0": ("k_rs_downsweep<Rec8> (stable 8/9-bit-digit radix scatter of 8-byte (key,value) records)", 12.0, 16.0, "downsweep_rec8"),
+    "downsweep1": ("k_rs_downsweep<Rec12/Rec16> (stable radix scatter of triple records)", 12.0, 32.0, "downsweep_rec16"),
+    "downsweep2": ("k_rs_downsweep<Tup0> (stable radix scatter of mod-0 tuples)", 12.0, 40.0, "downsweep_tup0"),
+    "partition": ("k_part_msd (window partition of (destination,value) pairs: inverse permutations)", 8.0, 16.0, "part_msd"),
+    "msd_part": ("k_msd_part (bucket partition of the prefix-sort words: non-stable radix scatter, XCD-grouped reservation)", 12.0, 16.0, "msd_part"),
+    "msd_local": ("k_msd_local (in-LDS order of the sub-buckets: the last passes of the sort in one launch)", 12.0, 16.0, "msd_local"),
+}
+
+
+def kernel_rooflines(acc, steps, st_last, kernel_ms=None):
+    """roofline objects of the kernel families of a build, keyed by family; `dominant` = the one with the largest share
+    of the build time.  achieved = algorithmic bytes per launch / average launch duration (HIP events recorded on the
+    build's own stream around every launch)."""
+    kernel_ms = kernel_ms if kernel_ms is not None else acc.build_ms
+    kernel_ms = max(kernel_ms, 1e-9)
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    except Exception:
+        pmc = None
+    pmc_ok = pmc is not None and pmc.get("kernel_sources_sha") == kernel_sources_sha()
+    out = {}
+    for fam, (name, alg_b, moved_b, pkey) in _FAM.items():
+        if not acc.launches[fam]:
+            continue
+        per_launch = acc.elems[fam] / acc.launches[fam]
+        avg_ms = acc.ms[fam] / acc.launches[fam]
+        achieved = alg_b * per_launch / (avg_ms * 1e-3) / 1e9
+        r = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+             "algorithmic_bytes_per_launch": alg_b * per_launch, "avg_launch_ms": avg_ms,
+             "launches_per_step": acc.launches[fam] / steps, "share_of_build_time": acc.ms[fam] / kernel_ms,
+             "moved_bytes_per_launch": moved_b * per_launch,
+             "moved_GBps": moved_b * per_launch / (avg_ms * 1e-3) / 1e9,
+             "achievable_copy_GBps": HBM_ACHIEVABLE_GBS}
+        r["moved_frac_of_achievable"] = r["moved_GBps"] / HBM_ACHIEVABLE_GBS
+        if pmc_ok and pkey in pmc.get("bytes_per_record", {}):
+            r["traffic"] = pmc["bytes_per_record"][pkey] * per_launch
+            r["traffic_from"] = {"file": "profiles/pmc_traffic.json", "source": pmc.get("source"), "commit": pmc.get("commit"),
+                                 "kernel_sources_sha": pmc.get("kernel_sources_sha"),
+                                 "note": "per-record bytes of the rocprofv3 --pmc passes made on exactly these kernel sources x this run's records per launch"}
+        out[fam] = r
+    if acc.launches["gather"]:
+        ge = acc.elems["gather"] / acc.launches["gather"]; gms = acc.ms["gather"] / acc.launches["gather"]
         # algorithmic bytes of the gather = what the reference's merge reads at random per sample suffix
         # (lib.rs:136-162, SURVEY §8d merge row): SA12 entry (w) + position (w) + one rank (w) + 2 symbols (2c)
         alg_g = 0.0
@@ -62,34 +121,21 @@ def kernel_rooflines(st_acc, steps, st_last, kernel_ms):
                 continue
             m02 = (mm + 2) // 3 + mm // 3
             alg_g += m02 * (3 * 4 + 2 * (1 if lvl == 0 else 4))
-        alg_g /= (g_launches / steps)
-        roof_gather = {"bound": "hbm", "kernel": "k_gather_tuples (one random tuple gather per sample suffix)",
-                       "achieved": alg_g / (gms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": alg_g / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                       "algorithmic_bytes_per_launch": alg_g, "avg_launch_ms": gms,
-                       "launches_per_step": g_launches / steps, "share_of_build_time": g_ms / kernel_ms,
-                       "gathers_per_second_G": ge / (gms * 1e-3) / 1e9}
-    # PMC traffic is NOT measured by this run (counters need rocprofv3): the per-record figures of the last
-    # committed counter collection are replayed, labelled as such, and never enter `achieved`/`frac`.
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-    except Exception:
-        pmc = None
-    if pmc is not None:
-        bpr = pmc.get("bytes_per_record", {})
-        if roof is not None:
-            key = ("downsweep_rec8", "downsweep_rec16", "downsweep_tup0")[kc]
-            if key in bpr:
-                roof["traffic"] = bpr[key] * dsw_elems[kc] / dsw_launches[kc]
-                roof["traffic_replayed_from"] = {"file": "profiles/pmc_traffic.json", "source": pmc.get("source"),
-                                                 "commit": pmc.get("commit"), "note": "replayed per-record constant x this run's records; not a counter read of this run"}
-        if roof_gather is not None and "gather_tuples" in bpr:
-            roof_gather["traffic"] = bpr["gather_tuples"] * g_elems / g_launches
-            roof_gather["traffic_replayed_from"] = {"file": "profiles/pmc_traffic.json", "source": pmc.get("source"), "commit": pmc.get("commit")}
-    if roof is not None:
-        roof["achievable_copy_GBps"] = HBM_ACHIEVABLE_GBS
-        roof["moved_frac_of_achievable"] = roof["moved_GBps"] / HBM_ACHIEVABLE_GBS
-    return roof, roof_gather
+        alg_g /= (acc.launches["gather"] / steps)
+        r = {"bound": "hbm", "kernel": "k_gather_tuples (one random tuple gather per sample suffix)",
+             "achieved": alg_g / (gms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": alg_g / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+             "algorithmic_bytes_per_launch": alg_g, "avg_launch_ms": gms,
+             "launches_per_step": acc.launches["gather"] / steps, "share_of_build_time": acc.ms["gather"] / kernel_ms,
+             "gathers_per_second_G": ge / (gms * 1e-3) / 1e9}
+        if pmc_ok and "gather_tuples" in pmc.get("bytes_per_record", {}):
+            r["traffic"] = pmc["bytes_per_record"]["gather_tuples"] * ge
+        out["gather"] = r
+    dominant = max(out.values(), key=lambda r: r["share_of_build_time"]) if out else None
+    if dominant is not None and pmc is not None and not pmc_ok:
+        dominant["traffic_note"] = ("profiles/pmc_traffic.json was collected on other kernel sources (sha %s, these are %s): not replayed"
+                                    % (pmc.get("kernel_sources_sha"), kernel_sources_sha()))
+    return dominant, out
 
 
 def path_roofline(st, ms):

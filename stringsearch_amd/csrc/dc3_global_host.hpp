@@ -42,7 +42,9 @@ struct GComm {
                            hipStream_t st) = 0;
   // small host values: out[r*bytes ..] = rank r's in[0..bytes)
   virtual int all_gather_host(const void *in, void *out, size_t bytes) = 0;
+  virtual int transport_ranks() { return nranks; }   // ranks the transport itself reports (RCCL: ncclCommCount)
   virtual void abort_all() {}
+  virtual void leave_failed() {}      // this rank returns from a failed collective (loopback: see LoopWorld::leave)
   virtual void reset_all() {}          // before a new collective build of the whole group (no rank inside a collective)
   virtual const char *name() const = 0;
 };
@@ -69,13 +71,23 @@ struct LoopWorld {
     return !failed;
   }
   void fail() { std::lock_guard<std::mutex> lk(mu); failed = true; cv.notify_all(); }
-  void reset() { std::lock_guard<std::mutex> lk(mu); failed = false; arrived = 0; }
+  void reset() { std::lock_guard<std::mutex> lk(mu); failed = false; arrived = 0; left_mask = 0; }
+  // A rank returns from a failed collective entry point (build / sufcheck).  Once every rank has left it, the world is
+  // clean again: the next collective of the group works whichever entry point it comes through.
+  uint32_t left_mask = 0;
+  void leave(int rank) {
+    std::lock_guard<std::mutex> lk(mu);
+    if (!failed) return;
+    left_mask |= 1u << rank;
+    if (left_mask == (P >= 32 ? 0xffffffffu : (1u << P) - 1u)) { failed = false; arrived = 0; left_mask = 0; }
+  }
 };
 struct LoopComm : GComm {
   std::shared_ptr<LoopWorld> w;
   const char *name() const override { return "loopback (in-process, hipMemcpyAsync; peer copies between devices)"; }
   void abort_all() override { w->fail(); }
   void reset_all() override { w->reset(); }
+  void leave_failed() override { w->leave(rank); }
   int sync_fail() { set_err("loopback transport: another rank failed"); return E_HIP; }
   int all_to_all_v(const void *send, const size_t *soff, const size_t *sbytes, void *recv, const size_t *roff,
                    const size_t *rbytes, hipStream_t st) override {
@@ -135,6 +147,7 @@ struct RcclApi {
   decltype(&ncclRecv) Recv = nullptr;
   decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;          // optional (self-test: the rank count RCCL itself reports)
   bool load() {
     if (h) return true;
     // a process that already carries an RCCL (PyTorch does) hands back that one for the same soname
@@ -145,6 +158,7 @@ struct RcclApi {
     DC3_RCCL_SYM(GroupStart, ncclGroupStart) DC3_RCCL_SYM(GroupEnd, ncclGroupEnd) DC3_RCCL_SYM(Send, ncclSend) DC3_RCCL_SYM(Recv, ncclRecv)
     DC3_RCCL_SYM(AllGather, ncclAllGather) DC3_RCCL_SYM(GetErrorString, ncclGetErrorString)
 #undef DC3_RCCL_SYM
+    CommCount = reinterpret_cast<decltype(CommCount)>(dlsym(h, "ncclCommCount"));
     return true;
   }
 };
@@ -160,6 +174,11 @@ struct RcclComm : GComm {
   unsigned char *d_small = nullptr;   // [ (P + 1) * kSmall ]
   static constexpr size_t kSmall = 1024;
   const char *name() const override { return "RCCL (grouped ncclSend/ncclRecv over xGMI)"; }
+  int transport_ranks() override {
+    int cnt = -1;
+    if (g_rccl.CommCount && comm && g_rccl.CommCount(comm, &cnt) == ncclSuccess) return cnt;
+    return -1;
+  }
   ~RcclComm() override {
     if (comm) (void)g_rccl.CommDestroy(comm);
     if (d_small) (void)hipFree(d_small);
@@ -1124,70 +1143,88 @@ static int gbuild_wide(dc3hip_gctx *G) {
     if (me > 0) lo = img[(size_t)((u64)me * cnt / P)];
     if (me + 1 < P) hi = img[(size_t)((u64)(me + 1) * cnt / P)];
   }
-  // count, allocate, write
-  const u64 chunk = (u64)1 << 20;
-  const u64 nblocks64 = (n + chunk - 1) / chunk;
-  if (nblocks64 > 0x7fffffffull) { set_err("wide global mode: text too long"); return E_TOOBIG; }
-  const u32 nblocks = (u32)nblocks64;
-  u32 *counts = nullptr;
-  RC(arena_alloc(c, (size_t)nblocks + 16, &counts));
-  const u32 last = (me + 1 == P) ? 1u : 0u;
-  {
-    PhaseScope ps(c, DC3HIP_PH_PACK, n);
-    hipLaunchKernelGGL((k_wide_select<false>), dim3(nblocks), dim3(kBlock), 0, c->stream, k, chunk, lo, hi, last, counts,
-                       (const u32 *)nullptr, (Rec16 *)nullptr);
-    KCHECK();
-  }
-  // (the per-block counts are summed in 64 bits on the host: a rank's share must stay below 2^32 - 2^24 records)
-  std::vector<u32> hc(nblocks);
-  HIPC(hipMemcpyAsync(hc.data(), counts, (size_t)nblocks * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPC(hipStreamSynchronize(c->stream));
-  u64 nrec64 = 0;
-  for (u32 b = 0; b < nblocks; b++) { const u32 v = hc[b]; hc[b] = (u32)nrec64; nrec64 += v; }
-  if (nrec64 > (u64)DC3HIP_MAX_N) { set_err("wide global mode: rank %d would hold %llu suffixes (more ranks needed)", me, (unsigned long long)nrec64); return E_TOOBIG; }
-  const u32 nrec = (u32)nrec64;
-  HIPC(hipMemcpyAsync(counts, hc.data(), (size_t)nblocks * 4, hipMemcpyHostToDevice, c->stream));
-  if ((size_t)nrec + 16 > G->w_cap) {
-    HIPC(hipStreamSynchronize(c->stream));
-    if (G->w_ra) (void)hipFree(G->w_ra);
-    if (G->w_rb) (void)hipFree(G->w_rb);
-    if (G->w_shard) (void)hipFree(G->w_shard);
-    G->w_ra = G->w_rb = nullptr; G->w_shard = nullptr; G->w_cap = 0;
-    const size_t cap = (size_t)nrec + (size_t)nrec / 16 + 1024;
-    if (hipMalloc(&G->w_ra, cap * sizeof(Rec16)) != hipSuccess || hipMalloc(&G->w_rb, cap * sizeof(Rec16)) != hipSuccess ||
-        hipMalloc(&G->w_shard, cap * sizeof(u64)) != hipSuccess) {
-      (void)hipGetLastError();
-      set_err("wide global mode: no device memory for %llu records of 40 bytes", (unsigned long long)cap); return E_ALLOC;
-    }
-    G->w_cap = cap;
-  }
-  {
-    PhaseScope ps(c, DC3HIP_PH_PACK, n);
-    hipLaunchKernelGGL((k_wide_select<true>), dim3(nblocks), dim3(kBlock), 0, c->stream, k, chunk, lo, hi, last, (u32 *)nullptr,
-                       (const u32 *)counts, G->w_ra);
-    KCHECK();
-  }
-  Rec16 *h = G->w_ra;
-  if (nrec) RC(radix_sort<Rec16>(c, G->w_ra, G->w_rb, nrec, 0, ibits, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT12_DOWN));
-  // tie pass; if a few windows agree on kWideWindow symbols it is repeated comparing kWideWindowDeep symbols (the compare
-  // is lazy, so the depth only costs where windows really agree that far: repeats up to that length are settled, longer
-  // ones refused)
-  for (u32 depth : {kWideWindow, kWideWindowDeep}) {
-    k.W = depth;
-    HIPC(hipMemsetAsync(c->d_words + 10, 0, 3 * sizeof(u32), c->stream));
-    if (nrec) {
-      PhaseScope ps(c, DC3HIP_PH_TIES, nrec);
-      hipLaunchKernelGGL(k_wide_ties, dim3(grid_for(c, nrec)), dim3(kBlock), 0, c->stream, (const Rec16 *)h, nrec, k, G->w_shard, c->d_words + 10);
+  // The selection, the sort and the tie pass of this rank.  A refusal that depends on the data and on the rank (its share
+  // exceeds 2^32 - 2^24 suffixes, no device memory for the records) must not leave the other ranks waiting in the
+  // collectives below: the status is agreed on there and every rank returns the same error.
+  u32 nrec = 0;
+  c->h_words[10] = c->h_words[11] = c->h_words[12] = 0;
+  const int local_rc = [&]() -> int {
+    // count, allocate, write
+    const u64 chunk = (u64)1 << 20;
+    const u64 nblocks64 = (n + chunk - 1) / chunk;
+    if (nblocks64 > 0x7fffffffull) { set_err("wide global mode: text too long"); return E_TOOBIG; }
+    const u32 nblocks = (u32)nblocks64;
+    u32 *counts = nullptr;
+    RC(arena_alloc(c, (size_t)nblocks + 16, &counts));
+    const u32 last = (me + 1 == P) ? 1u : 0u;
+    {
+      PhaseScope ps(c, DC3HIP_PH_PACK, n);
+      hipLaunchKernelGGL((k_wide_select<false>), dim3(nblocks), dim3(kBlock), 0, c->stream, k, chunk, lo, hi, last, counts,
+                         (const u32 *)nullptr, (Rec16 *)nullptr);
       KCHECK();
     }
-    HIPC(hipMemcpyAsync(c->h_words + 10, c->d_words + 10, 3 * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    // (the per-block counts are summed in 64 bits on the host: a rank's share must stay below 2^32 - 2^24 records)
+    std::vector<u32> hc(nblocks);
+    HIPC(hipMemcpyAsync(hc.data(), counts, (size_t)nblocks * 4, hipMemcpyDeviceToHost, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
-    if (c->h_words[10] != 0 || c->h_words[12] == 0 || c->h_words[12] > (1u << 20)) break;
-  }
+    u64 nrec64 = 0;
+    for (u32 b = 0; b < nblocks; b++) { const u32 v = hc[b]; hc[b] = (u32)nrec64; nrec64 += v; }
+    if (nrec64 > (u64)DC3HIP_MAX_N) { set_err("wide global mode: rank %d would hold %llu suffixes (more ranks needed)", me, (unsigned long long)nrec64); return E_TOOBIG; }
+    nrec = (u32)nrec64;
+    HIPC(hipMemcpyAsync(counts, hc.data(), (size_t)nblocks * 4, hipMemcpyHostToDevice, c->stream));
+    if ((size_t)nrec + 16 > G->w_cap) {
+      HIPC(hipStreamSynchronize(c->stream));
+      if (G->w_ra) (void)hipFree(G->w_ra);
+      if (G->w_rb) (void)hipFree(G->w_rb);
+      if (G->w_shard) (void)hipFree(G->w_shard);
+      G->w_ra = G->w_rb = nullptr; G->w_shard = nullptr; G->w_cap = 0;
+      const size_t cap = (size_t)nrec + (size_t)nrec / 16 + 1024;
+      if (hipMalloc(&G->w_ra, cap * sizeof(Rec16)) != hipSuccess || hipMalloc(&G->w_rb, cap * sizeof(Rec16)) != hipSuccess ||
+          hipMalloc(&G->w_shard, cap * sizeof(u64)) != hipSuccess) {
+        (void)hipGetLastError();
+        set_err("wide global mode: no device memory for %llu records of 40 bytes", (unsigned long long)cap); return E_ALLOC;
+      }
+      G->w_cap = cap;
+    }
+    {
+      PhaseScope ps(c, DC3HIP_PH_PACK, n);
+      hipLaunchKernelGGL((k_wide_select<true>), dim3(nblocks), dim3(kBlock), 0, c->stream, k, chunk, lo, hi, last, (u32 *)nullptr,
+                         (const u32 *)counts, G->w_ra);
+      KCHECK();
+    }
+    Rec16 *h = G->w_ra;
+    if (nrec) RC(radix_sort<Rec16>(c, G->w_ra, G->w_rb, nrec, 0, ibits, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT12_DOWN));
+    // tie pass; if a few windows agree on kWideWindow symbols it is repeated comparing kWideWindowDeep symbols (the compare
+    // is lazy, so the depth only costs where windows really agree that far: repeats up to that length are settled, longer
+    // ones refused)
+    for (u32 depth : {kWideWindow, kWideWindowDeep}) {
+      k.W = depth;
+      HIPC(hipMemsetAsync(c->d_words + 10, 0, 3 * sizeof(u32), c->stream));
+      if (nrec) {
+        PhaseScope ps(c, DC3HIP_PH_TIES, nrec);
+        hipLaunchKernelGGL(k_wide_ties, dim3(grid_for(c, nrec)), dim3(kBlock), 0, c->stream, (const Rec16 *)h, nrec, k, G->w_shard, c->d_words + 10);
+        KCHECK();
+      }
+      HIPC(hipMemcpyAsync(c->h_words + 10, c->d_words + 10, 3 * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+      HIPC(hipStreamSynchronize(c->stream));
+      if (c->h_words[10] != 0 || c->h_words[12] == 0 || c->h_words[12] > (1u << 20)) break;
+    }
+    return E_OK;
+  }();
+  if (local_rc != E_OK && local_rc != E_TOOBIG && local_rc != E_ALLOC) return local_rc;     // HIP / transport faults: as before
   arena_release(c, mk);
   c->stats.level_tied[0] = c->h_words[11];
-  const bool mine_ok = c->h_words[10] == 0 && c->h_words[12] == 0;
-  uint64_t good = 0, ngood = 0, pre = 0, tot = 0;
+  const bool mine_ok = local_rc == E_OK && c->h_words[10] == 0 && c->h_words[12] == 0;
+  uint64_t good = 0, ngood = 0, pre = 0, tot = 0, refp = 0, refused = 0;
+  char local_err[sizeof(g_err)];
+  snprintf(local_err, sizeof(local_err), "%s", g_err);
+  RC(gather_counts(cm, local_rc == E_TOOBIG ? 1u : local_rc == E_ALLOC ? (1u << 20) : 0u, &refp, &refused));
+  if (refused) {                                       // some rank refused: all ranks return, each with a message
+    const int rc_all = (refused >> 20) ? E_ALLOC : E_TOOBIG;
+    if (local_rc != E_OK) set_err("%s", local_err);
+    else set_err("wide global mode: another rank refused its share (%s)", rc_all == E_ALLOC ? "no device memory for its records" : "more ranks needed");
+    return rc_all;
+  }
   RC(gather_counts(cm, mine_ok ? 1 : 0, &good, &ngood));
   RC(gather_counts(cm, nrec, &pre, &tot));
   if (tot != n) { set_err("wide global order: %llu of %llu positions selected", (unsigned long long)tot, (unsigned long long)n); return E_HIP; }
@@ -1252,12 +1289,15 @@ static int gbuild(dc3hip_gctx *G) {
   if (!G || !G->c || !G->comm) { set_err("invalid global context"); return E_ARGS; }
   if (!G->text_set) { set_err("no text block set in this global context"); return E_ARGS; }
   G->built = false;
+  // the calling thread may be a fresh one (loopback ranks, a host program's worker) whose current device is 0: every
+  // allocation of the build (ensure_arena comes before build_begin) must land on the rank's own device
+  HIPC(hipSetDevice(G->c->device));
   GComm *cm = G->comm;
   cm->comm_ms = 0; cm->bytes_in = cm->bytes_out = 0;
   memset(&G->gs, 0, sizeof(G->gs));
   const auto t0 = std::chrono::steady_clock::now();
   const int rc = gbuild_inner(G);
-  if (rc != E_OK) { snprintf(G->err, sizeof(G->err), "%s", g_err); cm->abort_all(); return rc; }
+  if (rc != E_OK) { snprintf(G->err, sizeof(G->err), "%s", g_err); cm->abort_all(); cm->leave_failed(); return rc; }
   G->gs.struct_size = (int32_t)sizeof(dc3hip_gstats);
   G->gs.nranks = cm->nranks; G->gs.rank = cm->rank;
   G->gs.total_n = G->total_n; G->gs.shard_first = G->shard_first; G->gs.shard_count = G->shard_count;
@@ -1572,11 +1612,85 @@ int32_t dc3hip_global_sufcheck(dc3hip_gctx *G) {
     return E_OK;
   };
   const int rc = run();
-  if (rc != E_OK) { snprintf(G->err, sizeof(G->err), "%s", g_err); cm->abort_all(); return rc - 10; }
+  if (rc != E_OK) { snprintf(G->err, sizeof(G->err), "%s", g_err); cm->abort_all(); cm->leave_failed(); return rc - 10; }
   return verdict;
 }
 
 const char *dc3hip_global_last_error(dc3hip_gctx *G) { return G ? G->err : ""; }
+// Transport self-test (a COLLECTIVE): a ragged all_to_all_v, a ragged all_gather_v and a host all-gather of known bytes
+// through this group's transport, every byte checked on every rank.  0 = all three delivered exactly what was sent.
+static inline uint8_t selftest_byte(int from, int to, size_t k) {
+  uint64_t x = ((uint64_t)(from + 1) << 40) ^ ((uint64_t)(to + 1) << 20) ^ (uint64_t)k;
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 29;
+  return (uint8_t)x;
+}
+static int gselftest(dc3hip_gctx *G) {
+  dc3hip_ctx *c = G->c; GComm *cm = G->comm;
+  const int P = cm->nranks, me = cm->rank;
+  HIPC(hipSetDevice(c->device));
+  auto a2a_len = [](int from, int to) -> size_t { return 1000 + 37 * (size_t)from + 101 * (size_t)to + (size_t)((from * 7 + to * 3) % 11); };
+  auto ag_len = [](int from) -> size_t { return 5000 + 313 * (size_t)from; };
+  // ---- all_to_all_v
+  size_t soff[kMaxRanks], sb[kMaxRanks], roff[kMaxRanks], rb[kMaxRanks], stot = 0, rtot = 0;
+  for (int r = 0; r < P; r++) { soff[r] = stot; sb[r] = a2a_len(me, r); stot += sb[r]; roff[r] = rtot; rb[r] = a2a_len(r, me); rtot += rb[r]; }
+  std::vector<uint8_t> hs(stot), hr(rtot);
+  for (int r = 0; r < P; r++) for (size_t k = 0; k < sb[r]; k++) hs[soff[r] + k] = selftest_byte(me, r, k);
+  unsigned char *ds = nullptr, *dr = nullptr;
+  HIPC(hipMalloc(&ds, stot + 64)); 
+  if (hipMalloc(&dr, rtot + 64) != hipSuccess) { (void)hipFree(ds); set_err("self-test: no device memory"); return E_ALLOC; }
+  int rc = [&]() -> int {
+    HIPC(hipMemcpyAsync(ds, hs.data(), stot, hipMemcpyHostToDevice, c->stream));
+    HIPC(hipMemsetAsync(dr, 0xEE, rtot, c->stream));
+    RC(cm->all_to_all_v(ds, soff, sb, dr, roff, rb, c->stream));
+    HIPC(hipMemcpyAsync(hr.data(), dr, rtot, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    for (int r = 0; r < P; r++)
+      for (size_t k = 0; k < rb[r]; k++)
+        if (hr[roff[r] + k] != selftest_byte(r, me, k)) {
+          set_err("transport self-test: all_to_all_v delivered a wrong byte (from rank %d to rank %d, offset %zu of %zu)", r, me, k, rb[r]);
+          return E_HIP;
+        }
+    return E_OK;
+  }();
+  (void)hipFree(ds); (void)hipFree(dr);
+  RC(rc);
+  // ---- all_gather_v
+  size_t goff[kMaxRanks], gb[kMaxRanks], gtot = 0;
+  for (int r = 0; r < P; r++) { goff[r] = gtot; gb[r] = ag_len(r); gtot += gb[r]; }
+  std::vector<uint8_t> hg(gtot);
+  unsigned char *dg = nullptr;
+  HIPC(hipMalloc(&dg, gtot + 64));
+  rc = [&]() -> int {
+    HIPC(hipMemsetAsync(dg, 0xEE, gtot, c->stream));
+    for (size_t k = 0; k < gb[me]; k++) hg[goff[me] + k] = selftest_byte(me, 255, k);
+    HIPC(hipMemcpyAsync(dg + goff[me], hg.data() + goff[me], gb[me], hipMemcpyHostToDevice, c->stream));
+    RC(cm->all_gather_v(dg + goff[me], gb[me], dg, goff, gb, c->stream));
+    HIPC(hipMemcpyAsync(hg.data(), dg, gtot, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    for (int r = 0; r < P; r++)
+      for (size_t k = 0; k < gb[r]; k++)
+        if (hg[goff[r] + k] != selftest_byte(r, 255, k)) {
+          set_err("transport self-test: all_gather_v delivered a wrong byte (block of rank %d seen by rank %d, offset %zu of %zu)", r, me, k, gb[r]);
+          return E_HIP;
+        }
+    return E_OK;
+  }();
+  (void)hipFree(dg);
+  RC(rc);
+  // ---- host words
+  uint64_t mine = 0x5eed000000000000ull + (uint64_t)me * 1000003ull, all[kMaxRanks];
+  RC(cm->all_gather_host(&mine, all, sizeof(uint64_t)));
+  for (int r = 0; r < P; r++)
+    if (all[r] != 0x5eed000000000000ull + (uint64_t)r * 1000003ull) { set_err("transport self-test: all_gather_host delivered a wrong word for rank %d", r); return E_HIP; }
+  return E_OK;
+}
+int32_t dc3hip_global_selftest(dc3hip_gctx *G, int32_t *transport_ranks) {
+  if (!G || !G->c || !G->comm) { set_err("invalid global context"); return E_ARGS; }
+  if (transport_ranks) *transport_ranks = G->comm->transport_ranks();
+  const int rc = gselftest(G);
+  if (rc != E_OK) { snprintf(G->err, sizeof(G->err), "%s", g_err); G->comm->abort_all(); G->comm->leave_failed(); }
+  return rc;
+}
 const char *dc3hip_global_transport(dc3hip_gctx *G) { return (G && G->comm) ? G->comm->name() : ""; }
 
 }  // extern "C"

@@ -158,6 +158,7 @@ static size_t arena_text_requirement(int64_t n) {
 static int ensure_arena(dc3hip_ctx *c, size_t need) {
   if (c->arena_bytes >= need || c->arena_fixed) return E_OK;
   if (c->arena_off != 0) { set_err("internal: arena grown while in use"); return E_HIP; }
+  HIPC(hipSetDevice(c->device));            // (callers may be on a thread whose current device is another one)
   HIPC(hipStreamSynchronize(c->stream));
   if (c->arena) { HIPC(hipFree(c->arena)); c->arena = nullptr; c->arena_bytes = 0; }
   HIPC(hipMalloc(&c->arena, need));

@@ -174,6 +174,16 @@ class GlobalRank:
     def transport(self):
         return lib().dc3hip_global_transport(self._h).decode()
 
+    def selftest(self):
+        """Transport self-test, a COLLECTIVE (every rank calls it): ragged all-to-all / all-gather of known bytes, every
+        byte checked.  Returns the number of ranks the transport itself reports (RCCL: ncclCommCount); raises on a
+        wrong byte."""
+        cnt = ctypes.c_int32(0)
+        rc = lib().dc3hip_global_selftest(self._h, ctypes.byref(cnt))
+        if rc != 0:
+            raise Dc3HipError(rc, lib().dc3hip_global_last_error(self._h).decode())
+        return int(cnt.value)
+
 
 DEVICE_SPREAD = -2      # DC3HIP_DEVICE_SPREAD: rank r on device r % (visible devices)
 
@@ -249,3 +259,24 @@ class LoopbackGroup:
 
     def stats(self):
         return [r.stats() for r in self.ranks]
+
+    def _collective(self, fn):
+        import threading
+        out = [None] * self.P
+
+        def run(i):
+            try:
+                out[i] = fn(self.ranks[i])
+            except Exception as e:          # noqa: BLE001 - reported below
+                out[i] = e
+        th = [threading.Thread(target=run, args=(i,)) for i in range(self.P)]
+        for t in th: t.start()
+        for t in th: t.join()
+        for v in out:
+            if isinstance(v, Exception):
+                raise v
+        return out
+
+    def selftest(self):
+        """dc3hip_global_selftest of all ranks (a collective: one host thread per rank)."""
+        return self._collective(lambda r: r.selftest())

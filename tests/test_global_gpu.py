@@ -215,10 +215,31 @@ def test_bench_global_two_processes_on_one_gpu(ss, oracle, tmp_path):
             assert line["verify"]["shards_tile_0_n"] and line["verify"]["global_sufcheck"] == 0 and "64-bit" in line["config"]["workload"]
         else:
             assert line["verify"]["shards_tile_0_n"] and line["verify"]["equal_single_device_checksum"]
-        assert all(b > 0 for b in line["interconnect"]["bytes_in_per_rank_per_step"])
+        assert all(b > 0 for b in line["interconnect"]["bytes_in_per_rank_per_step"]) and line["interconnect"]["comm_ms"] > 0
+        assert line["transport_selftest"]["passed"] is True and line["transport_selftest"]["ranks_seen_by_transport"] == 2
         text = oracle.gen(2 * size, 2, {"random": 0, "text": 2}[kind])
         got = np.concatenate([np.load(tmp_path / f"gshard_{r}.npy") for r in range(2)])
         assert np.array_equal(got, want_sa(oracle, text)), kind
+
+
+def test_transport_selftest_and_recovery_after_a_failed_collective(ss, oracle):
+    """dc3hip_global_selftest (ragged all-to-all / all-gather of known bytes, every byte checked) on loopback groups, and
+    the failure semantics of the header: after a collective that failed on every rank (a one-symbol text in a wide
+    context is refused with -4) the group works again through ANY entry point — the self-test and a build — without the
+    loopback_build wrapper having to reset it (round-2 advisor finding)."""
+    for P in (2, 3, 8):
+        with ss.LoopbackGroup(P, 100_000) as g:
+            assert g.selftest() == [P] * P
+    with env(DC3HIP_GLOBAL_FORCE_WIDE=1):
+        with ss.LoopbackGroup(2, 50_000) as g:
+            g.set_text(b"a" * 20_000)
+            with pytest.raises(ss.Dc3HipError):
+                g._collective(lambda r: r.build())             # every rank through dc3hip_global_build on its own thread
+            assert g.selftest() == [2, 2]                      # the world is clean again
+            t = oracle.gen(40_000, 9, 0)
+            g.set_text(t)
+            g._collective(lambda r: r.build())
+            assert np.array_equal(g.sa(), want_sa(oracle, t))
 
 
 @pytest.mark.parametrize("P", [3, 5, 7, 16])

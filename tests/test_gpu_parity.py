@@ -896,9 +896,12 @@ def test_1gib_text_and_dna_pass_reference_sufcheck(ss, oracle, kind, seed):
 
 
 def test_bench_two_ranks_on_one_gpu_matches_oracle(ss, oracle, tmp_path):
-    """bench.py's N>1 path (rank -> sacapart chunk, offset generator, barrier, MAX-reduce of the time, rank-0 line),
-    executed for real: a fresh child `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` with both
-    ranks on GPU 0 (gloo for the host collectives); every rank's chunk SA is compared with the oracle."""
+    """bench.py's N>1 command exactly as the driver launches it (no extra flags but the size): a fresh child
+    `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` with both ranks on GPU 0 (gloo for the host
+    collectives, the host-staged transport for the library's — RCCL refuses two ranks on one device).  ONE line must carry
+    the global-mode build with its interconnect figures, the sacapart leg beside it, the partitioned CPU baseline (P
+    threads) and the transport self-test; every rank's sacapart chunk SA and the concatenated global shards are compared
+    with the oracle."""
     import subprocess, sys, socket
     from conftest import ROOT
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
@@ -906,17 +909,35 @@ def test_bench_two_ranks_on_one_gpu_matches_oracle(ss, oracle, tmp_path):
     size = 4 << 20
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", str(size), "--steps", "2",
-           "--warmup", "1", "--no-cpu"]
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0, p.stderr[-2000:]
+           "--warmup", "1"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["total_bytes"] == 2 * size
+    # the global leg defines `value` ...
+    assert line["value_mode"].startswith("global") and "global SA" in line["config"]["partitioning"]
+    ic = line["interconnect"]
+    assert all(b > 0 for b in ic["bytes_in_per_rank_per_step"]) and all(b > 0 for b in ic["bytes_out_per_rank_per_step"])
+    assert ic["comm_ms"] > 0 and "host-staged" in ic["transport"]          # (says so: this is not an xGMI number)
+    assert line["verify"]["shards_tile_0_n"] and line["verify"]["equal_single_device_checksum"]
+    # ... after the transport self-test ...
+    tst = line["transport_selftest"]
+    assert tst["passed"] is True and tst["ranks_seen_by_transport"] == 2 and tst["world_size"] == 2
+    # ... with the sacapart leg, the partitioned CPU baseline and the roofline beside it
+    sp = line["sacapart"]
+    assert sp["value"] > 0 and sp["ms_per_step"] > 0 and "sacapart" in sp["config"]["partitioning"]
+    cb = line["cpu_baseline"]
+    assert cb["cores"] == 2 and cb["value"] > 0 and "2 chunks of len/2+1" in cb["sample"] and len(cb["per_thread_seconds"]) == 2
+    assert line["roofline"] is None or line["roofline"]["bound"] == "hbm"
     from stringsearch_amd.partition import chunk_bounds
     full = oracle.gen(2 * size, 2, 0)
     for r, (off, ln) in enumerate(chunk_bounds(2 * size, 2)):
         chunk = np.load(tmp_path / f"chunk_{r}.npy"); sa = np.load(tmp_path / f"sa_{r}.npy")
         assert np.array_equal(chunk, full[off:off + ln])
         assert np.array_equal(sa, oracle.ref_sufsort(chunk) if oracle.ref is not None else oracle.sufsort(chunk))
+    got = np.concatenate([np.load(tmp_path / f"gshard_{r}.npy") for r in range(2)])
+    want = oracle.ref_sufsort(full) if oracle.ref is not None else oracle.sufsort(full)
+    assert np.array_equal(got, want.astype(np.int64))
 
 
 def test_stage_level_trace_matches_oracle(ss, oracle, corpus):
