@@ -47,7 +47,7 @@ __global__ __launch_bounds__(kBlock) void k_make_codes(const u32 *present, uint1
 // suffixes of one residue differ no later than the name covering the shorter one's end (a zero in its
 // first 3 symbols) — but they were measured SLOWER (DNA 1 GiB 199 -> 217 ms): they save cheap direct
 // levels and make the first sorted level's alphabet huge and sparse (93-bit keys, all top-32-bit
-// prefixes tied).  Kept behind DC3HIP_WIDE_NAMES=1 for experiments; both widths are parity-tested.
+// prefixes tied).  The host always passes w = 3 (the switch that tried wider names is gone since round 3).
 // Thread g owns positions 3g+1 and 3g+2.
 // ---------------------------------------------------------------------------------------------
 template <class Sym>

@@ -79,9 +79,7 @@ struct dc3hip_ctx {
   // profiling
   bool profile = true;
   bool no_hybrid = false;
-  int merge_cfg = 3;
   bool no_small_ties = false;
-  bool wide_names = false;
   bool no_nine_bit = false, no_rec12 = false, no_discard = false, no_fullsort = false, no_text_shortcut = false;
   bool no_split_emit = false;
   bool no_long_keys = false;   // DC3HIP_NO_LONG_KEYS=1: the whole-text shortcut only with 9-symbol windows (no KeyT)
@@ -1497,8 +1495,8 @@ static int merge_lists(dc3hip_ctx *c, const Tup12 *A, u32 nA, const Tup0 *B, u32
                        u32 rank_base) {
   const u32 total = nA + nB;
   if (total == 0) return E_OK;
-  const int cfg = c->merge_cfg;
-  const u32 tile = cfg == 0 ? 256u * 4 : cfg == 1 ? 512u * 2 : cfg == 2 ? 512u * 4 : cfg == 3 ? 1024u * 2 : cfg == 4 ? 128u * 4 : cfg == 5 ? 1024u * 4 : 256u * 2;
+  constexpr int kMergeNT = 1024, kMergeVT = 2;       // 2048 outputs per tile (measured best of seven shapes in round 1)
+  const u32 tile = (u32)kMergeNT * kMergeVT;
   const u32 ntiles = (total + tile - 1) / tile;
   const ArenaMark mk = arena_mark(c);
   u32 *part = nullptr;
@@ -1516,15 +1514,7 @@ static int merge_lists(dc3hip_ctx *c, const Tup12 *A, u32 nA, const Tup0 *B, u32
     hipLaunchKernelGGL(k_merge_partition, dim3((ntiles + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, A, nA, B, nB,
                        ntiles, tile, (const u32 *)coarse, kRatio, part);
     KCHECK();
-    switch (cfg) {
-      case 0: RC((launch_merge<256, 4>(c, ntiles, A, nA, B, nB, part, out_sa, out_pairs, rank_base))); break;
-      case 1: RC((launch_merge<512, 2>(c, ntiles, A, nA, B, nB, part, out_sa, out_pairs, rank_base))); break;
-      case 2: RC((launch_merge<512, 4>(c, ntiles, A, nA, B, nB, part, out_sa, out_pairs, rank_base))); break;
-      case 3: RC((launch_merge<1024, 2>(c, ntiles, A, nA, B, nB, part, out_sa, out_pairs, rank_base))); break;
-      case 4: RC((launch_merge<128, 4>(c, ntiles, A, nA, B, nB, part, out_sa, out_pairs, rank_base))); break;
-      case 5: RC((launch_merge<1024, 4>(c, ntiles, A, nA, B, nB, part, out_sa, out_pairs, rank_base))); break;
-      default: RC((launch_merge<256, 2>(c, ntiles, A, nA, B, nB, part, out_sa, out_pairs, rank_base))); break;
-    }
+    RC((launch_merge<kMergeNT, kMergeVT>(c, ntiles, A, nA, B, nB, part, out_sa, out_pairs, rank_base)));
     KCHECK();
   }
   arena_release(c, mk);
@@ -1560,10 +1550,9 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
   const bool direct = (B * B * B) <= 0x7fffffffull && !(pre && depth == 1);
   c->stats.level_sorted[depth] = direct ? 0 : 1;   // 2 = prefix-sort + tie-refine
   if (direct) {
-    // names = w packed symbols (order-preserving); w = 3 (the K–S triple) unless DC3HIP_WIDE_NAMES=1;
-    // always recurse (distinctness unknown)
-    u32 w = 3; u64 Bw = B * B * B;                   // B^w
-    while (c->wide_names && Bw * B <= 0x7fffffffull) { Bw *= B; w++; }   // measured slower: see DESIGN.md §2.1
+    // names = the K–S triple packed in base B (order-preserving); always recurse (distinctness unknown)
+    // (packing more symbols per name is order-isomorphic too but was measured slower)
+    const u32 w = 3; const u64 Bw = B * B * B;       // B^w
     c->stats.level_name_width[depth] = (int32_t)w;
     {
       PhaseScope ps(c, DC3HIP_PH_NAME_DIRECT, m02);
@@ -2056,10 +2045,6 @@ int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) {
   c->no_nine_bit = (n9 && n9[0] == '1');
   const char *n12 = getenv("DC3HIP_NO_REC12");
   c->no_rec12 = (n12 && n12[0] == '1');
-  const char *wn = getenv("DC3HIP_WIDE_NAMES");
-  c->wide_names = (wn && wn[0] == '1');
-  const char *mc = getenv("DC3HIP_MERGE_CFG");
-  if (mc) c->merge_cfg = atoi(mc);
   int rc = [&]() -> int {
     HIPC(hipSetDevice(device));
     hipDeviceProp_t prop;

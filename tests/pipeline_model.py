@@ -8,7 +8,6 @@ import numpy as np
 FULLSORT = True      # model of the whole-level shortcut (all triples of a level distinct -> sorted triples = SA)
 DISCARD = True       # model of the "discarding" recursion (unique names leave the recursion), see dc3hip.hip
 TEXTSORT = True      # model of the level-0 whole-text shortcut (9-byte keys of all text positions; MapText filter)
-WIDE_NAMES = False   # True = as many symbols per direct name as fit 31 bits (DC3HIP_WIDE_NAMES=1)
 
 
 def _sym_get(S, m, idx):
@@ -37,8 +36,6 @@ def level(S, m, K, trace=None, depth=0, pre=None):
     has2 = (3 * g + 2) < m
     if B ** 3 <= 0x7FFFFFFF:                                   # k_name_direct (w symbols per name)
         w = 3
-        while WIDE_NAMES and B ** (w + 1) <= 0x7FFFFFFF:
-            w += 1
         R = np.zeros(m02, dtype=np.int64)
         n1 = np.zeros(m0, dtype=np.int64); n2 = np.zeros(m0, dtype=np.int64)
         for t in range(w):

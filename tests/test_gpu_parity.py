@@ -610,28 +610,6 @@ def test_deep_tie_pass_then_doubling_on_12_byte_records(ss, oracle):
                     os.environ.pop(k, None)
 
 
-def test_wide_and_narrow_direct_names_agree(ss, oracle):
-    """Direct names pack w = 3 symbols by default; DC3HIP_WIDE_NAMES=1 packs as many as fit 31 bits
-    (13 for DNA, 6 for 28-letter text).  Same SA either way."""
-    import os
-    for kind, n in ((1, 3_000_001), (2, 3_000_002), (1, 50_000), (0, 200_000)):
-        data = oracle.gen(n, 31, kind)
-        want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)
-        lv = {}
-        for flag in ("0", "1"):
-            os.environ["DC3HIP_WIDE_NAMES"] = flag
-            try:
-                with ss.Context(n) as c:
-                    c.set_text(data); c.build()
-                    assert np.array_equal(c.sa(), want), (kind, n, flag)
-                    st = c.stats(); lv[flag] = (st["levels"], st["level_name_width"][0])
-            finally:
-                os.environ.pop("DC3HIP_WIDE_NAMES", None)
-        assert lv["0"][1] == 3 and lv["1"][0] <= lv["0"][0]
-        if kind == 1:
-            assert lv["1"][1] == 13
-
-
 def test_discarding_recursion_agrees_and_shrinks(ss, oracle, corpus):
     """Discarding recursion (unique names leave the recursion) vs the plain K–S recursion
     (DC3HIP_NO_DISCARD=1): same SA; on low-entropy text the deeper levels collapse."""

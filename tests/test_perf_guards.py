@@ -1,0 +1,119 @@
+"""Speed guards (-m gpu): upper bounds on the device-resident build time of the route-sensitive inputs.
+
+The library chooses among several orderings (whole-text order by bucket or LSD passes, second tie pass, prefix doubling,
+order handed to level 1, DC3 recursion with prefix sorts / straight sorts / discarding) by sampled predictors and
+thresholds; every route gives the same bytes (the parity tests), but a threshold that drifts sends an input down a
+slower route without failing anything.  These bounds are the measured time of each case at the head that shipped
+(profiles/r03*_perf_guards.json) times 1.3, so a route change — typically 1.5x to 4x — trips them while run-to-run
+noise (a few per cent on MI355X) does not.  Times are HIP-event times of dc3hip_ctx_build (text resident), best of 3."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GIB = 1 << 30
+# case -> measured ms at the shipping head (MI355X); the guard is 1.3x
+MEASURED_MS = {
+    "random_1GiB": 20.5,
+    "random_1GiB_recursion_only": 63.5,
+    "random_1GiB_dup_1MB_block": 63.0,
+    "dna_1GiB": 23.3,
+    "text_1GiB": 194.0,
+    "real_text_256MiB": 78.0,
+}
+SLACK = 1.3
+
+
+@pytest.fixture(scope="module")
+def ss():
+    import stringsearch_amd as ss
+    assert ss.device_count() >= 1
+    return ss
+
+
+def best_ms(c, reps=3):
+    c.build()
+    ms = []
+    for _ in range(reps):
+        c.build()
+        ms.append(c.stats()["build_ms"])
+    return min(ms)
+
+
+def report(name, ms, extra=None):
+    rec = {"case": name, "ms": round(ms, 2), "bound_ms": round(MEASURED_MS[name] * SLACK, 2)}
+    rec.update(extra or {})
+    print("PERF_GUARD " + json.dumps(rec), flush=True)
+    out = os.environ.get("DC3HIP_PERF_GUARD_LOG")
+    if out:
+        with open(out, "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    assert ms <= MEASURED_MS[name] * SLACK, rec
+
+
+def real_corpus(limit):
+    roots = ["/opt/rocm/include", "/usr/lib/python3.10", "/usr/local/lib/python3.10/dist-packages", "/usr/share/doc", "/opt/rocm/share"]
+    exts = (".h", ".hpp", ".py", ".txt", ".md", ".rst", ".cuh", ".inc", ".cpp", ".c", ".pyi", ".cmake", ".html", ".hip", ".cu")
+    parts, tot = [], 0
+    for r in roots:
+        for dp, dn, fn in os.walk(r):
+            dn.sort()
+            for f in sorted(fn):
+                if not f.endswith(exts):
+                    continue
+                try:
+                    b = open(os.path.join(dp, f), "rb").read(2 << 20)
+                except OSError:
+                    continue
+                if b:
+                    parts.append(b); tot += len(b)
+                if tot >= limit:
+                    return np.frombuffer(b"".join(parts)[:limit], dtype=np.uint8).copy()
+    return np.frombuffer(b"".join(parts), dtype=np.uint8).copy()
+
+
+def test_generated_inputs_stay_on_their_routes(ss):
+    with ss.Context(GIB) as c:
+        c.generate(GIB, 2, 0)
+        ms = best_ms(c)
+        st = c.stats()
+        assert st["text_sort_state"] == 1 and st["levels"] == 1
+        report("random_1GiB", ms, {"msd_sorts": st["msd_sorts"], "msd_fallbacks": st["msd_fallbacks"]})
+        # the cliff case of DESIGN.md §2: one duplicated 1 MB block — finished by prefix doubling, one level
+        t = c.text()
+        t[600_000_000:600_000_000 + (1 << 20)] = t[1_000_000:1_000_000 + (1 << 20)]
+        c.set_text(t)
+        ms = best_ms(c, reps=2)
+        st = c.stats()
+        assert c.sufcheck() == 0
+        report("random_1GiB_dup_1MB_block", ms, {"levels": st["levels"], "level_sorted0": st["level_sorted"][0]})
+        del t
+        c.generate(GIB, 5, 1)
+        ms = best_ms(c)
+        assert c.stats()["levels"] == 1
+        report("dna_1GiB", ms)
+        c.generate(GIB, 3, 2)
+        ms = best_ms(c, reps=2)
+        report("text_1GiB", ms, {"levels": c.stats()["levels"]})
+    os.environ["DC3HIP_NO_TEXT_SHORTCUT"] = "1"
+    try:
+        with ss.Context(GIB) as c:
+            c.generate(GIB, 2, 0)
+            ms = best_ms(c)
+            report("random_1GiB_recursion_only", ms, {"levels": c.stats()["levels"]})
+    finally:
+        os.environ.pop("DC3HIP_NO_TEXT_SHORTCUT", None)
+
+
+def test_real_text_stays_on_its_route(ss):
+    data = real_corpus(256 << 20)
+    if len(data) < (256 << 20):
+        pytest.skip("this machine does not have 256 MiB of text files")
+    with ss.Context(len(data)) as c:
+        c.set_text(data)
+        ms = best_ms(c, reps=2)
+        assert c.sufcheck() == 0
+        report("real_text_256MiB", ms, {"levels": c.stats()["levels"]})

@@ -39,21 +39,6 @@ def test_model_corpus(oracle, corpus):
         assert len(tr) >= 2
 
 
-def test_model_wide_names(oracle):
-    """w > 3 symbols per direct name (the DC3HIP_WIDE_NAMES=1 experiment) is order-isomorphic too."""
-    pm.WIDE_NAMES = True
-    try:
-        rng = np.random.default_rng(17)
-        for sigma in (1, 2, 4, 26):
-            for n in [2, 3, 4, 5, 7, 13, 14, 15, 16, 27, 28, 29, 40, 41, 100, 301]:
-                data = rng.integers(0, sigma, size=n, dtype=np.uint8).tobytes()
-                assert pm.sufsort(data).tolist() == oracle.sufsort(data).tolist(), (sigma, n)
-        for tup in itertools.product([3, 9], repeat=9):
-            assert pm.sufsort(bytes(tup)).tolist() == naive_sa(bytes(tup)).tolist()
-    finally:
-        pm.WIDE_NAMES = False
-
-
 def test_model_discarding_on_and_off(oracle, corpus):
     """the discarding recursion and the plain K–S recursion give the same SA (deep-recursion inputs)"""
     rng = np.random.default_rng(4)
