@@ -139,6 +139,182 @@ __global__ __launch_bounds__(kBlock) void k_gather_tuples8(const TupS8 *__restri
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same sample tuples WITHOUT the random gather: scattered to their rank by two partition passes and a window
+// placement (the windowed inversion of dc3_order.hip.hpp with a payload).  The gather fetches a 64-byte line per
+// 8-byte tuple at ~35 G gathers/s (82 B of HBM traffic per sample, 1.7 TB/s); the scatter moves about as many bytes
+// as streams.  Record of slot s: (dest = rank12[s] - 1, r, cc) — 12 bytes; dest is a bijection onto [0, m02), so the
+// region of every bucket and window is known analytically and nothing has to be counted except how a bucket's region
+// splits between the XCD groups in pass 1 (k_tup_hist1: 4 bytes read per slot).
+//   k_tup_hist1  digit table of dest >> kTupSh1 per chunk of slots (same format as the pack kernels' tables; the
+//                per-group bucket sizes and cursors then come from k_msd_cnt1 / k_msd_plan1)
+//   k_tup_part1  builds the records of a tile of slots (coalesced reads of S and rank) and partitions them by
+//                dest >> kTupSh1, XCD-grouped like k_msd_part
+//   k_tup_part2  inside every 2^22-record bucket: by (dest >> kTupWinBits) & 511 into the windows; bucket b is worked by
+//                the XCD group b % 8 (all writes into a bucket go through one L2)
+//   k_tup_local  window w: payloads placed in LDS by dest, then written out in order as Tup12 next to sa12 (which gives
+//                the position), with the c_prev histogram of the fused mod-0 pass
+// ---------------------------------------------------------------------------------------------
+constexpr u32 kTupSh1 = 22, kTupWinBits = 13, kTupWin = 1u << kTupWinBits;       // 8192 destinations per window
+constexpr int kTupNT = 512, kTupIPT = 8, kTupTile = kTupNT * kTupIPT;             // 4096 records per partition tile
+constexpr size_t kTupPartSmem = sizeof(u32) * (3 * kTupTile + 2 * 1024 + 64);
+struct TupRec { u32 dest, r, cc; };
+
+__global__ __launch_bounds__(kBlock) void k_tup_hist1(const u32 *__restrict__ rank12, u32 m02, u32 chunk, u32 nchunks,
+                                                     u32 *__restrict__ table /*[1024][nchunks]*/) {
+  __shared__ u32 hist[kWaves][1024];
+#pragma unroll
+  for (int w = 0; w < kWaves; w++)
+    for (int j = threadIdx.x; j < 1024; j += kBlock) hist[w][j] = 0;
+  __syncthreads();
+  u32 *myh = hist[wave_id()];
+  const u32 begin = blockIdx.x * chunk, end = min(m02, begin + chunk);
+  for (u32 s = begin + threadIdx.x; s < end; s += kBlock) atomicAdd(&myh[(rank12[s] - 1u) >> kTupSh1], 1u);
+  __syncthreads();
+  for (int j = threadIdx.x; j < 1024; j += kBlock) {
+    u32 sum = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; w++) sum += hist[w][j];
+    table[(size_t)j * nchunks + blockIdx.x] = sum;
+  }
+}
+
+// the (r, cc) payload of the sample in slot s (the fields of k_build_tuples8)
+template <class Sym>
+__device__ __forceinline__ void tup_payload(const Sym &S, const uint16_t *lcode, u32 m, u32 m0, bool dummy, const u32 *__restrict__ rank,
+                                            u32 s, u32 &r, u32 &cc) {
+  if (s < m0) {                                          // mod-1 sample at 3s+1: c0 = S[3s+1], cx = S[3s], r = rank of suffix 3s+2
+    const u32 j = 3 * s;
+    u32 q[4]; S.get4(j, lcode, q);
+    cc = q[1] | (q[0] << 16);
+    r = (j + 2 < m) ? rank[m0 + s] : 0u;
+  } else {                                               // mod-2 sample at 3g+2: c0 = S[3g+2], cx = S[3g+3], r = rank of suffix 3g+4
+    const u32 g = s - m0, j = 3 * g;
+    u32 q[4]; S.get4(j + 2, lcode, q);
+    cc = q[0] | (q[1] << 16);
+    const bool has = (j + 4 < m) || (dummy && j + 4 == m);
+    r = has ? rank[g + 1] : 0u;
+  }
+}
+
+// shared tail of the two partition passes: the tile's records sit in registers (dest/r/cc[k], valid for t < nvalid,
+// t = k * kTupNT + tid); rank them by digit in LDS, reserve, reorder, write the runs.
+template <class DigitOf, class BaseOf>
+__device__ __forceinline__ void tup_partition_tile(const u32 (&dest)[kTupIPT], const u32 (&rr)[kTupIPT], const u32 (&cc)[kTupIPT],
+                                                   u32 nvalid, u32 ndig, DigitOf digit_of, BaseOf reserve, TupRec *__restrict__ out,
+                                                   unsigned char *smem) {
+  u32 *sd = reinterpret_cast<u32 *>(smem), *sr = sd + kTupTile, *sc = sr + kTupTile;
+  u32 *hist = sc + kTupTile, *gbase = hist + 1024, *tmp = gbase + 1024;
+  const u32 tid = threadIdx.x;
+  for (u32 j = tid; j < 1024; j += kTupNT) hist[j] = 0;
+  __syncthreads();
+  u32 rk[kTupIPT];
+#pragma unroll
+  for (int k = 0; k < kTupIPT; k++) {
+    const u32 t = k * kTupNT + tid;
+    if (t < nvalid) rk[k] = atomicAdd(&hist[digit_of(dest[k])], 1u);
+  }
+  __syncthreads();
+  // digits of thread tid: 2 * tid, 2 * tid + 1 (ndig <= 1024 = 2 * kTupNT)
+  u32 c0 = 0, c1 = 0;
+  const u32 d0 = 2 * tid, d1 = 2 * tid + 1;
+  if (d0 < ndig) { c0 = hist[d0]; if (c0) gbase[d0] = reserve(d0, c0); }
+  if (d1 < ndig) { c1 = hist[d1]; if (c1) gbase[d1] = reserve(d1, c1); }
+  u32 tot;
+  const u32 ex = block_excl_scan<kTupNT / 64>(c0 + c1, tmp, tot);
+  hist[d0] = ex; hist[d1] = ex + c0;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kTupIPT; k++) {
+    const u32 t = k * kTupNT + tid;
+    if (t < nvalid) { const u32 q = hist[digit_of(dest[k])] + rk[k]; sd[q] = dest[k]; sr[q] = rr[k]; sc[q] = cc[k]; }
+  }
+  __syncthreads();
+  for (u32 q = tid; q < nvalid; q += kTupNT) {
+    const u32 d = sd[q], dd = digit_of(d);
+    out[gbase[dd] + (q - hist[dd])] = TupRec{d, sr[q], sc[q]};
+  }
+}
+
+template <class Sym>
+__global__ __launch_bounds__(kTupNT) void k_tup_part1(Sym S, u32 m, u32 m0, u32 m02, const u32 *__restrict__ rank12, u32 cpx,
+                                                     u32 ntiles, u32 ndig, u32 *__restrict__ cursors /*[8][ndig]*/,
+                                                     TupRec *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ uint16_t lcode[256];
+  const u32 g = blockIdx.x % 8u, idx = blockIdx.x / 8u;
+  const u32 tile = g * cpx + idx;
+  if (idx >= cpx || tile >= ntiles) return;
+  const bool dummy = (m % 3) == 1;
+  S.stage(lcode);
+  const u32 begin = tile * (u32)kTupTile, nvalid = min((u32)kTupTile, m02 - begin);
+  u32 dest[kTupIPT], rr[kTupIPT], cc[kTupIPT];
+#pragma unroll
+  for (int k = 0; k < kTupIPT; k++) {
+    const u32 s = begin + min((u32)(k * kTupNT) + threadIdx.x, nvalid - 1u);
+    dest[k] = rank12[s] - 1u;
+    tup_payload(S, lcode, m, m0, dummy, rank12, s, rr[k], cc[k]);
+  }
+  u32 *cur = cursors + (size_t)g * ndig;
+  tup_partition_tile(dest, rr, cc, nvalid, ndig, [](u32 d) { return d >> kTupSh1; },
+                     [&](u32 d, u32 cnt) { return atomicAdd(&cur[d], cnt); }, out, smem);
+}
+
+// pass 2: bucket b = records [b << 22, min(m02, (b + 1) << 22)); tile list: bucket b on the XCD group b % 8
+__global__ __launch_bounds__(kTupNT) void k_tup_part2(const TupRec *__restrict__ in, u32 m02, u32 nbuckets,
+                                                     u32 *__restrict__ cursors /*[nbuckets][512], zeroed*/, TupRec *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr u32 tpb = (1u << kTupSh1) / kTupTile;         // tiles per bucket
+  const u32 g = blockIdx.x % 8u, idx = blockIdx.x / 8u;
+  const u32 b = g + 8u * (idx / tpb);
+  if (b >= nbuckets) return;
+  const u64 begin64 = ((u64)b << kTupSh1) + (u64)(idx % tpb) * kTupTile;
+  if (begin64 >= m02) return;
+  const u32 begin = (u32)begin64, nvalid = min((u32)kTupTile, m02 - begin);
+  u32 dest[kTupIPT], rr[kTupIPT], cc[kTupIPT];
+#pragma unroll
+  for (int k = 0; k < kTupIPT; k++) {
+    const TupRec x = in[begin + min((u32)(k * kTupNT) + threadIdx.x, nvalid - 1u)];
+    dest[k] = x.dest; rr[k] = x.r; cc[k] = x.cc;
+  }
+  u32 *cur = cursors + ((size_t)b << 9);
+  const u32 base = b << kTupSh1;
+  tup_partition_tile(dest, rr, cc, nvalid, 512u, [](u32 d) { return (d >> kTupWinBits) & 511u; },
+                     [&](u32 d, u32 cnt) { return base + (d << kTupWinBits) + atomicAdd(&cur[d], cnt); }, out, smem);
+}
+
+// window w: the records [w * kTupWin, ...) are exactly those with dest in the window
+__global__ __launch_bounds__(1024) void k_tup_local(const TupRec *__restrict__ in, const u32 *__restrict__ sa12, u32 m02, u32 m0,
+                                                   u32 chunk, u32 nchunks, Tup12 *__restrict__ out,
+                                                   u32 *__restrict__ table /*[256][nchunks], zeroed*/) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // 2 * kTupWin words (dynamic: 64 KiB)
+  u32 *wr = reinterpret_cast<u32 *>(smem), *wc = wr + kTupWin;
+  __shared__ u32 hist[2][256];
+  const u32 base = blockIdx.x * kTupWin, cnt = min(kTupWin, m02 - base);
+  if (threadIdx.x < 512) hist[threadIdx.x >> 8][threadIdx.x & 255] = 0;
+  for (u32 i = threadIdx.x; i < cnt; i += 1024) {
+    const TupRec x = in[base + i];
+    wr[x.dest - base] = x.r; wc[x.dest - base] = x.cc;
+  }
+  __syncthreads();
+  const u32 c_lo = base / chunk;                          // a window touches at most two chunks of the mod-0 pass (chunk >= kTupWin)
+  u32x4 *ov = reinterpret_cast<u32x4 *>(out);
+  for (u32 i = threadIdx.x; i < cnt; i += 1024) {
+    const u32 s = sa12[base + i];
+    const bool mod1 = s < m0;
+    u32x4 o;
+    o.x = mod1 ? 3 * s + 1 : 3 * (s - m0) + 2;
+    o.y = wr[i]; o.z = wc[i] & 0xffffu; o.w = wc[i] >> 16;
+    ov[base + i] = o;
+    if (mod1) atomicAdd(&hist[(base + i) / chunk - c_lo][(o.w - 1u) & 255u], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < 512) {
+    const u32 h = threadIdx.x >> 8, d = threadIdx.x & 255, v = hist[h][d];
+    if (v && c_lo + h < nchunks) atomicAdd(&table[(size_t)d * nchunks + c_lo + h], v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Step 2 (lib.rs:118-125): order-preserving selection of the mod-1 entries of SA12; each yields
 // the mod-0 suffix one position to the left, already ordered by rank of suffix j+1.
 // ---------------------------------------------------------------------------------------------

@@ -226,16 +226,26 @@ __global__ __launch_bounds__(kBlock) void k_final_assign(const u32 *__restrict__
 //   pass 2: shift = 14, seg_bits = 22, ndig = 256   (tiles never straddle a 2^22-pair segment)
 constexpr int kPartNW = 16, kPartIPT = 8, kPartTile = kPartNW * 64 * kPartIPT;   // 8192 pairs
 constexpr size_t kPartSmem = sizeof(Rec8) * kPartTile + sizeof(u32) * (2 * 1024 + 64);
+// xcd_tps != 0 (pass 2): the tiles of segment s (xcd_tps tiles each) are worked by the blocks with blockIdx % 8 == s % 8 —
+// the blocks that share an XCD under the dispatcher's round-robin placement (a speed assumption only) — so that every
+// run written into a segment's windows goes through ONE L2 and the partial lines of neighbouring runs meet there
+// (dc3_msd.hip.hpp explains the effect; grid = 8 * ceil(nseg / 8) * xcd_tps).
 __global__ __launch_bounds__(kPartNW * 64) void k_part_msd(const Rec8 *__restrict__ in, Rec8 *__restrict__ out, u32 n,
                                                           u32 shift, u32 seg_bits, u32 ndig,
-                                                          u32 *__restrict__ cursors) {
+                                                          u32 *__restrict__ cursors, u32 xcd_tps) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Rec8 *srec = reinterpret_cast<Rec8 *>(smem);
   u32 *hist = reinterpret_cast<u32 *>(smem + sizeof(Rec8) * kPartTile);   // [1024] counts -> tile-exclusive prefix
   u32 *gbase = hist + 1024;                                                // [1024] global base of the tile's run
   u32 *tmp = gbase + 1024;
   const u32 tid = threadIdx.x;
-  const u32 begin = blockIdx.x * (u32)kPartTile;
+  u32 tile = blockIdx.x;
+  if (xcd_tps) {
+    const u32 g = blockIdx.x & 7u, idx = blockIdx.x >> 3;
+    tile = (g + 8u * (idx / xcd_tps)) * xcd_tps + idx % xcd_tps;
+    if ((u64)tile * kPartTile >= n) return;
+  }
+  const u32 begin = tile * (u32)kPartTile;
   const u32 nvalid = min((u32)kPartTile, n - begin);
   const u32 seg = seg_bits >= 32 ? 0u : (begin >> seg_bits);
   const u32 seg_base = seg_bits >= 32 ? 0u : (seg << seg_bits);

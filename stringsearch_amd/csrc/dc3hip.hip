@@ -89,6 +89,8 @@ struct dc3hip_ctx {
   u32 hybrid12_min = 1u << 22; // DC3HIP_HYBRID12_MIN: smallest level (samples) that tries it (tests lower it)
   bool no_hybrid8 = false;     // DC3HIP_NO_HYBRID8=1 (tests): skip the 8-byte prefix sort / whole-level order of a level
   bool no_hybrid12 = false;    // DC3HIP_NO_HYBRID12=1: no 63-bit-prefix sort on 12-byte records for keys wider than 64 bits
+  bool no_tup_scatter = false; // DC3HIP_NO_TUP_SCATTER=1: sample tuples always by the random gather
+  bool no_xcd_map = false;     // DC3HIP_NO_XCD_MAP=1: window partitions without the segment -> XCD-group tile order (measurement aid)
   bool no_msd = false;         // DC3HIP_NO_MSD=1: the prefix sorts always run the stable LSD passes (no bucket ordering)
   u32 msd_min = 1u << 20;      // DC3HIP_MSD_MIN: fewest records the bucket ordering is used for (tests lower it)
   bool no_tup8 = false;        // DC3HIP_NO_TUP8=1: the slot table of the merge tuples is always 16 bytes per sample
@@ -550,7 +552,7 @@ static int inverse_permute(dc3hip_ctx *c, Rec8 *a, Rec8 *b, u32 n, u32 *out, int
     PhaseScope ps(c, phase, n, 3);
     HIPC(hipMemsetAsync(cur, 0, 1024 * sizeof(u32), c->stream));
     hipLaunchKernelGGL(k_part_msd, dim3(ntiles), dim3(kPartNW * 64), kPartSmem, c->stream, src, dst, n, 22u, 32u,
-                       ndig, cur);
+                       ndig, cur, 0u);
     KCHECK();
     std::swap(src, dst);
   }
@@ -560,8 +562,12 @@ static int inverse_permute(dc3hip_ctx *c, Rec8 *a, Rec8 *b, u32 n, u32 *out, int
     RC(arena_alloc(c, (size_t)nseg * 256, &cur));
     PhaseScope ps(c, phase, n, 3);
     HIPC(hipMemsetAsync(cur, 0, (size_t)nseg * 256 * sizeof(u32), c->stream));
-    hipLaunchKernelGGL(k_part_msd, dim3(ntiles), dim3(kPartNW * 64), kPartSmem, c->stream, src, dst, n,
-                       (u32)kInvWindowBits, kb > 22 ? 22u : 32u, 256u, cur);
+    // (with more than one 2^22-pair segment: segment s on the XCD group s % 8, see k_part_msd)
+    const u32 tps = (1u << 22) / kPartTile;
+    const bool xcd = kb > 22 && !c->no_xcd_map;
+    const u32 grid = xcd ? 8u * ((nseg + 7) / 8) * tps : ntiles;
+    hipLaunchKernelGGL(k_part_msd, dim3(grid), dim3(kPartNW * 64), kPartSmem, c->stream, src, dst, n,
+                       (u32)kInvWindowBits, kb > 22 ? 22u : 32u, 256u, cur, xcd ? tps : 0u);
     KCHECK();
     std::swap(src, dst);
   }
@@ -1457,9 +1463,76 @@ static int trace_sum(dc3hip_ctx *c, int which, int depth, const void *arr, u32 n
 // built by streaming (8-byte entries when the level's symbols fit 16 bits, else 16-byte) and gathered.  table0
 // ([256][chunks of cnt]) receives the digit table of the fused mod-0 selection pass.  The slot table lives above the
 // caller's arena mark and is released here.
+// Sample tuples in SA12 order by scattering instead of gathering (dc3_merge.hip.hpp, "WITHOUT the random gather"):
+// *done = false when the level is too small or the arena too short for the two record arrays (the caller gathers).
+static constexpr u32 kTupScatterMin = 1u << 25;
+template <class Sym>
+static int scatter_tuples8(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, const u32 *rank12, const u32 *sa12, const Chunking &ckc,
+                           Tup12 *t12, u32 *table0, bool *done) {
+  *done = false;
+  if (c->no_tup_scatter || m02 < kTupScatterMin || ckc.chunk < kTupWin) return E_OK;
+  const u32 ntiles = (m02 + kTupTile - 1) / kTupTile;
+  const u32 tpc = std::max<u32>(1, (ntiles + 2047) / 2048);
+  const u32 cpg = ((ntiles + 7) / 8 + tpc - 1) / tpc, cpx = cpg * tpc;
+  const u32 chunk = tpc * (u32)kTupTile, nchunks = (m02 + chunk - 1) / chunk;
+  const u32 nb = ((m02 - 1) >> kTupSh1) + 1;                     // buckets of 2^22 destinations (<= 1024)
+  if (c->arena_bytes - c->arena_off < (size_t)m02 * 24 + (size_t)1024 * nchunks * 4 + ((size_t)nb << 11) + (16u << 20)) return E_OK;
+  static std::atomic<bool> attr_set[16];
+  if (!attr_set[c->device & 15]) {
+    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tup_part1<Sym>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTupPartSmem));
+    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tup_part2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTupPartSmem));
+    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tup_local), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * kTupWin * 4)));
+    attr_set[c->device & 15] = true;
+  }
+  const ArenaMark mk = arena_mark(c);
+  TupRec *ra = nullptr, *rb = nullptr;
+  u32 *table1 = nullptr, *cntg = nullptr, *startg = nullptr, *cur1 = nullptr, *bstart = nullptr, *tpre = nullptr, *tpreh = nullptr, *plan = nullptr, *cur2 = nullptr;
+  RC(arena_alloc(c, (size_t)m02, &ra)); RC(arena_alloc(c, (size_t)m02, &rb));
+  RC(arena_alloc(c, (size_t)1024 * nchunks, &table1));
+  RC(arena_alloc(c, (size_t)nb * 8 + 16, &cntg)); RC(arena_alloc(c, (size_t)nb * 8 + 16, &startg)); RC(arena_alloc(c, (size_t)nb * 8 + 16, &cur1));
+  RC(arena_alloc(c, (size_t)nb + 16, &bstart)); RC(arena_alloc(c, (size_t)nb + 16, &tpre)); RC(arena_alloc(c, (size_t)nb + 16, &tpreh));
+  RC(arena_alloc(c, (size_t)16, &plan)); RC(arena_alloc(c, (size_t)nb * 512, &cur2));
+  {
+    PhaseScope ps(c, DC3HIP_PH_TUPLES, m02);
+    hipLaunchKernelGGL(k_tup_hist1, dim3(nchunks), dim3(kBlock), 0, c->stream, rank12, m02, chunk, nchunks, table1);
+    KCHECK();
+    hipLaunchKernelGGL(k_msd_cnt1, dim3(nb), dim3(kBlock), 0, c->stream, (const u32 *)table1, nchunks, cpg, cntg);
+    KCHECK();
+    hipLaunchKernelGGL(k_msd_plan1, dim3(1), dim3(1024), 0, c->stream, (const u32 *)cntg, nb, m02, startg, cur1, bstart, tpre, tpreh, plan);
+    KCHECK();
+    HIPC(hipMemsetAsync(cur2, 0, (size_t)nb * 512 * sizeof(u32), c->stream));
+    HIPC(hipMemsetAsync(table0, 0, (size_t)256 * ckc.nchunks * sizeof(u32), c->stream));
+  }
+  {
+    PhaseScope ps(c, DC3HIP_PH_TUPLES, m02, 3);
+    hipLaunchKernelGGL((k_tup_part1<Sym>), dim3(8 * cpx), dim3(kTupNT), kTupPartSmem, c->stream, S, m, m0, m02, rank12, cpx, ntiles, nb, cur1, ra);
+    KCHECK();
+  }
+  {
+    PhaseScope ps(c, DC3HIP_PH_TUPLES, m02, 3);
+    const u32 tpb = (1u << kTupSh1) / kTupTile;
+    hipLaunchKernelGGL(k_tup_part2, dim3(8 * ((nb + 7) / 8) * tpb), dim3(kTupNT), kTupPartSmem, c->stream, (const TupRec *)ra, m02, nb, cur2, rb);
+    KCHECK();
+  }
+  {
+    PhaseScope ps(c, DC3HIP_PH_TUPLES, m02);
+    hipLaunchKernelGGL(k_tup_local, dim3((m02 + kTupWin - 1) / kTupWin), dim3(1024), 2 * kTupWin * 4, c->stream, (const TupRec *)rb, sa12, m02, m0,
+                       ckc.chunk, ckc.nchunks, t12, table0);
+    KCHECK();
+  }
+  arena_release(c, mk);
+  *done = true;
+  return E_OK;
+}
+
 template <class Sym>
 static int build_gather_tuples(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u64 K, const u32 *rank12, const u32 *sa12l,
                                u32 cnt, const Chunking &ckc, Tup12 *t12, u32 *table0) {
+  if (K < 65536 && !c->no_tup8 && cnt == m02) {
+    bool done = false;
+    RC((scatter_tuples8<Sym>(c, S, m, m0, m02, rank12, sa12l, ckc, t12, table0, &done)));
+    if (done) return E_OK;
+  }
   const ArenaMark mk = arena_mark(c);
   PhaseScope ps(c, DC3HIP_PH_TUPLES, m02);
   if (K < 65536 && !c->no_tup8) {
@@ -2030,6 +2103,8 @@ int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) {
   { const char *e = getenv("DC3HIP_TEXT_ORDER12"); if (e && (e[0] == '0' || e[0] == '1')) c->text_order12 = e[0] - '0'; }
   { const char *e = getenv("DC3HIP_NO_TUP8"); c->no_tup8 = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_MSD"); c->no_msd = (e && e[0] == '1'); }
+  { const char *e = getenv("DC3HIP_NO_XCD_MAP"); c->no_xcd_map = (e && e[0] == '1'); }
+  { const char *e = getenv("DC3HIP_NO_TUP_SCATTER"); c->no_tup_scatter = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_MSD_MIN"); if (e) c->msd_min = (u32)std::max(4096ll, atoll(e)); }
   { const char *e = getenv("DC3HIP_NO_HYBRID12"); c->no_hybrid12 = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_HYBRID8"); c->no_hybrid8 = (e && e[0] == '1'); }

@@ -430,3 +430,25 @@ def test_wide_mode_beyond_2pow32(ss):
         assert all(s["ctx"]["level_tied"][0] < n // 1000 for s in st)      # 45-bit images: hardly any ties
         g.build()
         assert g.checksum() == chk
+        # ... and an INDEPENDENT verdict at this size: the reference's own sufcheck() built with 64-bit indices
+        # (oracle/_ref/libdivsufsort64_ref.so, c-sources/utils.c:160-241) on the shards fetched to host memory (34 GB of
+        # int64 + 4.3 GB of text; about 80 s of one host core).  rc 0 <=> this array is the suffix array of this text.
+        import ctypes
+        from conftest import ROOT
+        path = os.path.join(ROOT, "oracle", "_ref", "libdivsufsort64_ref.so")
+        if os.path.exists(path) and os.environ.get("DC3HIP_SKIP_SLOW_REFERENCE_CHECK") != "1":
+            ref = ctypes.CDLL(path)
+            ref.sufcheck.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32]
+            ref.sufcheck.restype = ctypes.c_int32
+            sa = np.zeros(n, dtype=np.int64)
+            for r in g.ranks:
+                first, cnt = r.shard()
+                view = sa[first:first + cnt]
+                assert ss.lib().dc3hip_global_get_shard_i64(r._h, view.ctypes.data) == 0
+            text = np.zeros(n, dtype=np.uint8)
+            with ss.Context(1 << 30) as c:
+                for off in range(0, n, 1 << 30):
+                    m = min(1 << 30, n - off)
+                    c.generate(m, 6, 0, offset=off)
+                    text[off:off + m] = c.text()
+            assert int(ref.sufcheck(text.ctypes.data, sa.ctypes.data, n, 0)) == 0

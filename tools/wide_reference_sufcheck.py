@@ -1,0 +1,70 @@
+"""GPU box: an INDEPENDENT verdict on a suffix array of more than 2^32 positions (BASELINE.json configs[3]'s size class).
+
+The wide global mode (64-bit positions) is checked at full size by the library's own collective verifier
+only.  Here the same build — 2^32 + 2^20 + 3 random bytes over two loopback ranks on this GPU, as in
+tests/test_global_gpu.py::test_wide_mode_beyond_2pow32 — is fetched to host memory (text 4.3 GB + 34 GB of int64) and
+handed to the REFERENCE's sufcheck() compiled with 64-bit saidx_t (oracle/_ref/libdivsufsort64_ref.so,
+c-sources/utils.c:160-241: range, first-character order, then the psi-style "SA[C[T[SA[i]-1]]++] == SA[i]-1" scan).
+rc 0 means: this array is the suffix array of this text.  One JSON line (profiles/r03*_wide_reference_sufcheck64.json).
+
+    python tools/wide_reference_sufcheck.py [extra_bytes=1048579] [kind=0]"""
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import stringsearch_amd as ss  # noqa: E402
+
+extra = int(sys.argv[1]) if len(sys.argv) > 1 else (1 << 20) + 3
+kind = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+seed = 6
+n = (1 << 32) + extra
+path = os.path.join(ROOT, "oracle", "_ref", "libdivsufsort64_ref.so")
+ref = ctypes.CDLL(path)
+ref.sufcheck.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32]
+ref.sufcheck.restype = ctypes.c_int32
+
+out = {"n": n, "kind": kind, "seed": seed, "ranks": 2, "transport": "loopback (both ranks on one GPU)"}
+sa = np.zeros(n, dtype=np.int64)
+with ss.LoopbackGroup(2, n) as g:
+    g.generate(n, seed, kind)
+    g.build()
+    t0 = time.time(); g.build(); out["build_wall_ms"] = round((time.time() - t0) * 1e3, 1)
+    out["library_global_sufcheck"] = g.sufcheck()
+    nxt = 0
+    for r in g.ranks:
+        first, cnt = r.shard()
+        assert first == nxt, (first, nxt)
+        view = sa[first:first + cnt]
+        rc = ss.lib().dc3hip_global_get_shard_i64(r._h, view.ctypes.data)
+        assert rc == 0, ss.last_error()
+        nxt += cnt
+    assert nxt == n
+    out["shard_counts"] = [r.shard()[1] for r in g.ranks]
+# the text, from the same device generator stream, in pieces a single context can hold
+text = np.zeros(n, dtype=np.uint8)
+piece = 1 << 30
+with ss.Context(piece) as c:
+    off = 0
+    while off < n:
+        m = min(piece, n - off)
+        c.generate(m, seed, kind, offset=off)
+        text[off:off + m] = c.text()
+        off += m
+t0 = time.time()
+rc = int(ref.sufcheck(text.ctypes.data, sa.ctypes.data, n, 0))
+out["reference_sufcheck64_rc"] = rc
+out["reference_sufcheck64_seconds"] = round(time.time() - t0, 1)
+out["reference"] = "crates/cdivsufsort/c-sources/utils.c:160-241 sufcheck(), saidx_t = int64_t, compiled where it lies (oracle/Makefile)"
+# and that the checker does notice an error at this size: swap two neighbours in the middle
+i = n // 2
+sa[i], sa[i + 1] = sa[i + 1], sa[i]
+t0 = time.time()
+out["reference_sufcheck64_rc_after_swapping_two_neighbours"] = int(ref.sufcheck(text.ctypes.data, sa.ctypes.data, n, 0))
+out["negative_control_seconds"] = round(time.time() - t0, 1)
+print(json.dumps(out), flush=True)
+assert rc == 0
