@@ -190,6 +190,13 @@ __device__ __forceinline__ u32 digit_of(const Tup0G &r, KeyDig d) {
 __global__ __launch_bounds__(kBlock) void k_add_scalar(u32 *p, u32 n, u32 v) {
   for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) p[i] += v;
 }
+// records of the positions [off, off + len) of the level (the block this rank packs before routing them by key range)
+template <class KM>
+__global__ __launch_bounds__(kBlock) void k_pack_image_range(KM km, u32 off, u32 len, HiMap hm, Rec8 *out) {
+  __shared__ uint16_t lcode[256];
+  km.stage(lcode);
+  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < len; i += gridDim.x * kBlock) out[i] = km.image(off + i, lcode, hm);
+}
 // keys of received pairs relative to the start of this rank's destination block
 __global__ __launch_bounds__(kBlock) void k_rebase_keys(Rec8 *p, u32 n, u32 base) {
   for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) p[i].key -= base;

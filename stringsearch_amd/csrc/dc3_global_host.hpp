@@ -297,6 +297,8 @@ struct HostComm : GComm {
 // one rank of a global build
 // ---------------------------------------------------------------------------------------------
 struct dc3hip_gctx {
+  u32 w_depth = 0;             // wide mode: symbols the last tie pass of the last build compared (the verifier compares at least as deep)
+  bool route = true;           // DC3HIP_GLOBAL_NO_ROUTE=1: every rank evaluates all positions and keeps its key range (the round-2 form)
   dc3hip_ctx *c = nullptr;
   GComm *comm = nullptr;
   int64_t max_total = 0, total_n = 0;
@@ -544,25 +546,106 @@ static int gorder_positions(dc3hip_gctx *G, KM km, u32 m, u32 kbits, const HiMap
   u32 *slice = (mode == G_TOP) ? c->d_sa : nullptr;
   if (!slice) RC(arena_alloc(c, (size_t)m + 16, &slice));
   const ArenaMark mk_tmp = arena_mark(c);
-  u64 lo = 0, hi = ~0ull;
-  {
-    u32 ns = (u32)std::min<u64>(m, (u64)2048 * P);
-    const u32 stride = std::max<u32>(1, m / ns);
-    ns = (m - 1) / stride + 1;
-    Rec8 *smp = nullptr;
-    RC(arena_alloc(c, (size_t)ns, &smp));
-    hipLaunchKernelGGL((k_pack_image_pos<KM>), dim3(grid_for(c, ns)), dim3(kBlock), 0, c->stream, km, ns, stride, hm, smp);
-    KCHECK();
-    RC(image_splitters(c, smp, ns, hm.pbits, P, me, &lo, &hi));
-  }
-  SelPosImage<KM> sel; sel.km = km; sel.hm = hm; sel.lo = lo; sel.hi = hi; sel.last = (me + 1 == P) ? 1u : 0u;
   Rec8 *ha = nullptr, *hb = nullptr, *h = nullptr; uint8_t *f = nullptr;
   u32 nrec = 0;
-  RC(select_records(c, sel, m, &ha, &nrec, DC3HIP_PH_PACK));
+  u64 img_lo = 0, img_span = 0;
+  if (G->route && hm.nbits >= 8) {
+    // ROUTED (default): every rank packs the records of ITS block of positions only (m / P of them), partitions them by
+    // the top 8 image bits — rank h owns a contiguous digit range, chosen from a replicated sample so that the ranges hold
+    // about m / P records each — and sends every record to its owner: one all-to-all of 8-byte records
+    // (8 m (P-1) / P^2 bytes out per rank).  Work per rank is O(m / P); SURVEY.md §8(e) step 2.
+    u32 dlo[kMaxRanks + 1];
+    {
+      u32 ns = (u32)std::min<u64>(m, (u64)4096 * P);
+      const u32 stride = std::max<u32>(1, m / ns);
+      ns = (m - 1) / stride + 1;
+      Rec8 *smp = nullptr;
+      RC(arena_alloc(c, (size_t)ns, &smp));
+      hipLaunchKernelGGL((k_pack_image_pos<KM>), dim3(grid_for(c, ns)), dim3(kBlock), 0, c->stream, km, ns, stride, hm, smp);
+      KCHECK();
+      std::vector<Rec8> hs(ns);
+      HIPC(hipMemcpyAsync(hs.data(), smp, (size_t)ns * sizeof(Rec8), hipMemcpyDeviceToHost, c->stream));
+      HIPC(hipStreamSynchronize(c->stream));
+      u32 cnt256[257] = {0};
+      for (u32 i = 0; i < ns; i++) cnt256[(u32)((((((u64)hs[i].key) << 32) | hs[i].val) >> (hm.pbits + hm.nbits - 8)) & 255u)]++;
+      // boundaries: rank h starts at the first digit whose prefix count reaches h * ns / P (identical on all ranks)
+      dlo[0] = 0; dlo[P] = 256;
+      u32 acc = 0, hnext = 1;
+      for (u32 d = 0; d < 256 && hnext < (u32)P; d++) {
+        while (hnext < (u32)P && (u64)acc * P >= (u64)hnext * ns) dlo[hnext++] = d;
+        acc += cnt256[d];
+      }
+      while (hnext < (u32)P) dlo[hnext++] = 256;
+      for (int r = 1; r <= P; r++) dlo[r] = std::max(dlo[r], dlo[r - 1]);
+    }
+    const u32 boff = (u32)((u64)m * me / P), blen = (u32)((u64)m * (me + 1) / P) - boff;
+    Rec8 *mine = nullptr, *sorted = nullptr;
+    RC(arena_alloc(c, (size_t)blen + 16, &mine));
+    u32 hdb[257];
+    for (u32 d = 0; d <= 256; d++) hdb[d] = 0;
+    if (blen) {
+      {
+        PhaseScope ps(c, DC3HIP_PH_PACK, blen);
+        hipLaunchKernelGGL((k_pack_image_range<KM>), dim3(grid_for(c, blen)), dim3(kBlock), 0, c->stream, km, boff, blen, hm, mine);
+        KCHECK();
+      }
+      constexpr int kTile = SortCfg<Rec8, 256>::NW * 64 * SortCfg<Rec8, 256>::IPT;
+      const Chunking ck = make_chunks(c, blen, kTile);
+      u32 *table = nullptr, *digit_base = nullptr;
+      RC(arena_alloc(c, (size_t)256 * ck.nchunks, &table));
+      RC(arena_alloc(c, (size_t)256, &digit_base));
+      RC(arena_alloc(c, (size_t)blen + 16, &sorted));
+      KeyDig dig; dig.shift = hm.pbits + hm.nbits - 8; dig.mask = 255;
+      {
+        PhaseScope ps(c, DC3HIP_PH_PACK, blen);
+        hipLaunchKernelGGL((k_rs_upsweep<Rec8, 256>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, mine, blen, ck.chunk, ck.nchunks, dig, table);
+        KCHECK();
+      }
+      RC(scan_digit_table(c, table, ck.nchunks, digit_base, 256, DC3HIP_PH_PACK));
+      std::vector<u32> tmp(256);
+      HIPC(hipMemcpyAsync(tmp.data(), digit_base, 256 * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+      ArrayLoader<Rec8> ld; ld.p = mine;
+      RC((launch_downsweep<Rec8, 256, ArrayLoader<Rec8>>(c, ld, sorted, blen, ck, dig, table, digit_base, DC3HIP_PH_PACK)));
+      HIPC(hipStreamSynchronize(c->stream));
+      for (u32 d = 0; d < 256; d++) hdb[d] = tmp[d];
+      hdb[256] = blen;
+    }
+    size_t soff[kMaxRanks], sbytes[kMaxRanks], roff[kMaxRanks], rbytes[kMaxRanks];
+    uint64_t scount[kMaxRanks], mat[kMaxRanks * kMaxRanks];
+    for (int r = 0; r < P; r++) {
+      const u32 a0 = hdb[dlo[r]], b0 = hdb[dlo[r + 1]];
+      soff[r] = (size_t)a0 * sizeof(Rec8); sbytes[r] = (size_t)(b0 - a0) * sizeof(Rec8); scount[r] = b0 - a0;
+    }
+    RC(cm->all_gather_host(scount, mat, sizeof(uint64_t) * (size_t)P));
+    u64 got = 0;
+    for (int r = 0; r < P; r++) { roff[r] = (size_t)got * sizeof(Rec8); rbytes[r] = (size_t)mat[(size_t)r * P + me] * sizeof(Rec8); got += mat[(size_t)r * P + me]; }
+    if (got > (u64)m) { set_err("global order: %llu records routed to rank %d of a level of %u", (unsigned long long)got, me, m); return E_HIP; }
+    nrec = (u32)got;
+    RC(arena_alloc(c, (size_t)nrec + 16, &ha));
+    RC(cm->all_to_all_v(sorted ? sorted : mine, soff, sbytes, ha, roff, rbytes, c->stream));
+    G->gs.exchanges += 1;
+    img_lo = (u64)dlo[me] << (hm.nbits - 8);
+    img_span = (u64)(dlo[me + 1] - dlo[me]) << (hm.nbits - 8);
+  } else {
+    u64 lo = 0, hi = ~0ull;
+    {
+      u32 ns = (u32)std::min<u64>(m, (u64)2048 * P);
+      const u32 stride = std::max<u32>(1, m / ns);
+      ns = (m - 1) / stride + 1;
+      Rec8 *smp = nullptr;
+      RC(arena_alloc(c, (size_t)ns, &smp));
+      hipLaunchKernelGGL((k_pack_image_pos<KM>), dim3(grid_for(c, ns)), dim3(kBlock), 0, c->stream, km, ns, stride, hm, smp);
+      KCHECK();
+      RC(image_splitters(c, smp, ns, hm.pbits, P, me, &lo, &hi));
+    }
+    SelPosImage<KM> sel; sel.km = km; sel.hm = hm; sel.lo = lo; sel.hi = hi; sel.last = (me + 1 == P) ? 1u : 0u;
+    RC(select_records(c, sel, m, &ha, &nrec, DC3HIP_PH_PACK));
+  }
   RC(arena_alloc(c, (size_t)nrec + 16, &hb));
   RC(arena_alloc(c, (size_t)nrec + 16, &f));
   bool ok = true, distinct = true;
-  if (nrec) RC((hybrid_sort_core<KM>(c, km, kbits, hm, ha, hb, nrec, &h, f, &ok, depth, slice, 0, &distinct, nullptr)));
+  if (nrec) RC((hybrid_sort_core<KM>(c, km, kbits, hm, ha, hb, nrec, &h, f, &ok, depth, slice, 0, &distinct, nullptr, false, nullptr,
+                                     img_lo, img_span)));
   uint64_t good = 0, ngood = 0, pre = 0, tot = 0, all[kMaxRanks];
   RC(gather_counts(cm, (ok && distinct) ? 1 : 0, &good, &ngood));
   RC(gather_counts(cm, nrec, &pre, &tot, all));
@@ -832,7 +915,7 @@ static int glevel(dc3hip_gctx *G, Sym S, u32 m, u64 K, int depth, u32 *out, GOut
     uint64_t names_total = 0, uniq_total = 0, cnt_pre = 0;
     bool discard = false, named = false;
     u32 cnt = 0;
-    if (try_hybrid && pred < kHybridMaxPredicted) {
+    if (try_hybrid && pred < c->hybrid_max_pred) {
       // prefix sort + tie refinement of my IMAGE range (equal keys have equal images, so they stay on one rank)
       u64 lo = 0, hi = ~0ull;
       {
@@ -1194,11 +1277,15 @@ static int gbuild_wide(dc3hip_gctx *G) {
     }
     Rec16 *h = G->w_ra;
     if (nrec) RC(radix_sort<Rec16>(c, G->w_ra, G->w_rb, nrec, 0, ibits, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT12_DOWN));
-    // tie pass; if a few windows agree on kWideWindow symbols it is repeated comparing kWideWindowDeep symbols (the compare
-    // is lazy, so the depth only costs where windows really agree that far: repeats up to that length are settled, longer
-    // ones refused)
-    for (u32 depth : {kWideWindow, kWideWindowDeep}) {
+    // tie pass; while a few windows still agree completely it is repeated with a deeper compare: kWideWindow symbols, then
+    // kWideWindowDeep, then 16 times deeper per round for as long as (windows that still agree) x (next depth) stays inside
+    // a work budget — the compare is lazy, so the depth only costs where windows really agree that far.  This settles
+    // repeats of any length a few of which exist (two copies of a 100 kB block: 10^5 tied pairs x 10^5 symbols); what
+    // the budget does not cover is refused (there is no recursion with 64-bit positions).
+    u32 depth = kWideWindow;
+    for (int round = 0;; round++) {
       k.W = depth;
+      G->w_depth = depth;
       HIPC(hipMemsetAsync(c->d_words + 10, 0, 3 * sizeof(u32), c->stream));
       if (nrec) {
         PhaseScope ps(c, DC3HIP_PH_TIES, nrec);
@@ -1207,7 +1294,11 @@ static int gbuild_wide(dc3hip_gctx *G) {
       }
       HIPC(hipMemcpyAsync(c->h_words + 10, c->d_words + 10, 3 * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
       HIPC(hipStreamSynchronize(c->stream));
-      if (c->h_words[10] != 0 || c->h_words[12] == 0 || c->h_words[12] > (1u << 20)) break;
+      if (c->h_words[10] != 0 || c->h_words[12] == 0) break;
+      if (round == 0) { if (c->h_words[12] > (1u << 20)) break; depth = kWideWindowDeep; continue; }
+      const u64 next = (u64)depth * 16;
+      if (next > kWideMaxDepth || (u64)c->h_words[12] * next > kWideTieBudget) break;
+      depth = (u32)next;
     }
     return E_OK;
   }();
@@ -1314,6 +1405,7 @@ static void gctx_env(dc3hip_gctx *G) {
   if (const char *e = getenv("DC3HIP_GLOBAL_LOCAL_MAX")) { const long long v = atoll(e); if (v >= 0) G->local_max = (u32)std::min<long long>(v, 0x7fffffffll); }
   if (const char *e = getenv("DC3HIP_GLOBAL_NO_TEXT_ORDER")) G->no_text_order = e[0] == '1';
   if (const char *e = getenv("DC3HIP_GLOBAL_FORCE_DIST")) G->force_dist = e[0] == '1';
+  if (const char *e = getenv("DC3HIP_GLOBAL_NO_ROUTE")) G->route = e[0] != '1';
 }
 
 // the rank's device context: a full one (text, SA, arena for max_total_n) — or, in wide mode, a minimal one (stream,
@@ -1598,7 +1690,7 @@ int32_t dc3hip_global_sufcheck(dc3hip_gctx *G) {
     HIPC(hipMemsetAsync(c->d_words + 20, 0, sizeof(u32), c->stream));
     if (G->shard_count > 0) {
       hipLaunchKernelGGL(k_wide_check, dim3(grid_for(c, G->shard_count)), dim3(kBlock), 0, c->stream, (const u64 *)G->w_shard,
-                         (u32)G->shard_count, next_first, k, 4 * kWideWindowDeep, c->d_words + 20);
+                         (u32)G->shard_count, next_first, k, std::max<u32>(4 * kWideWindowDeep, G->w_depth), c->d_words + 20);
       KCHECK();
     }
     HIPC(hipMemcpyAsync(c->h_words + 20, c->d_words + 20, sizeof(u32), hipMemcpyDeviceToHost, c->stream));

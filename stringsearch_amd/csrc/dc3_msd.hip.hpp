@@ -31,6 +31,9 @@
 
 namespace dc3 {
 
+// `base` (all kernels): the smallest word of the range the records come from, (image_lo << pbits); digits are taken from
+// word - base, so that a caller holding only a slice of the image range (a rank of the global mode) still gets evenly
+// filled buckets.  0 for the whole range.
 // The records are Rec8 {key = high half, val = low half} in memory (dc3_radix.hip.hpp: rec8_word); as one 8-byte load
 // that is the word with its halves exchanged — msd_word() puts them back (a register rename, no instruction).
 __device__ __forceinline__ u64 msd_word(u64 mem) { return (mem << 32) | (mem >> 32); }
@@ -43,6 +46,27 @@ constexpr u32 kMsdGroups = 8;                                                  /
 constexpr u32 kMsdScanSeg = 8192;                                              // entries per block of the size scans
 // device words of a sort (plan[] in the kernels below)
 enum { kMsdW_T2 = 0, kMsdW_CPX2 = 1, kMsdW_MAXSUB = 2, kMsdW_COUNT = 4 };
+
+// Digit table of the top d1 image bits when the records were not packed for this ordering (callers that build their
+// records elsewhere, e.g. the ranks of the global mode): table[d * nchunks + c] as the pack kernels write it.
+__global__ __launch_bounds__(kBlock) void k_msd_hist1(const u64 *__restrict__ in, u32 n, u64 base, u32 shift, u32 chunk, u32 nchunks,
+                                                     u32 *__restrict__ table /*[1024][nchunks]*/) {
+  __shared__ u32 hist[kWaves][kMsdMaxDig];
+#pragma unroll
+  for (int w = 0; w < kWaves; w++)
+    for (int j = threadIdx.x; j < kMsdMaxDig; j += kBlock) hist[w][j] = 0;
+  __syncthreads();
+  u32 *myh = hist[wave_id()];
+  const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
+  for (u32 i = begin + threadIdx.x; i < end; i += kBlock) atomicAdd(&myh[(u32)((msd_word(in[i]) - base) >> shift) & (kMsdMaxDig - 1)], 1u);
+  __syncthreads();
+  for (int j = threadIdx.x; j < kMsdMaxDig; j += kBlock) {
+    u32 sum = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; w++) sum += hist[w][j];
+    table[(size_t)j * nchunks + blockIdx.x] = sum;
+  }
+}
 
 // cntg[d * 8 + g] = words of bucket d inside group g's eighth of the input: the pack kernel's digit table
 // table[d * nchunks + c] summed over the chunks of the group (chunk c belongs to group c / cpg).  One block per bucket.
@@ -105,7 +129,7 @@ __device__ __forceinline__ u32 msd_find_bucket(const u32 *__restrict__ tpre, u32
 //   owns tiles [g * cpx2, (g + 1) * cpx2), digit = (word >> shift) & mask, cursors[g * gstride + (b << dbits) + digit].
 // Not stable.
 template <bool kSeg>
-__global__ __launch_bounds__(kMsdNW * 64) void k_msd_part(const u64 *__restrict__ in, u64 *__restrict__ out, u32 n, u32 shift,
+__global__ __launch_bounds__(kMsdNW * 64) void k_msd_part(const u64 *__restrict__ in, u64 *__restrict__ out, u32 n, u64 base, u32 shift,
                                                          u32 dbits, u32 cpx, u32 ntiles, const u32 *__restrict__ tpre,
                                                          const u32 *__restrict__ bstart, u32 nb1, const u32 *__restrict__ plan,
                                                          u32 *__restrict__ cursors, u32 gstride) {
@@ -147,7 +171,7 @@ __global__ __launch_bounds__(kMsdNW * 64) void k_msd_part(const u64 *__restrict_
 #pragma unroll
   for (int k = 0; k < kMsdIPT; k++) {
     const u32 t = k * NT + tid;
-    if (t < nvalid) rk[k] = atomicAdd(&hist[(u32)(r[k] >> shift) & mask], 1u);
+    if (t < nvalid) rk[k] = atomicAdd(&hist[(u32)((r[k] - base) >> shift) & mask], 1u);
   }
   __syncthreads();
   u32 cnt = 0;
@@ -162,19 +186,19 @@ __global__ __launch_bounds__(kMsdNW * 64) void k_msd_part(const u64 *__restrict_
 #pragma unroll
   for (int k = 0; k < kMsdIPT; k++) {
     const u32 t = k * NT + tid;
-    if (t < nvalid) srec[hist[(u32)(r[k] >> shift) & mask] + rk[k]] = r[k];
+    if (t < nvalid) srec[hist[(u32)((r[k] - base) >> shift) & mask] + rk[k]] = r[k];
   }
   __syncthreads();
   for (u32 q = tid; q < nvalid; q += NT) {
     const u64 x = srec[q];
-    const u32 dd = (u32)(x >> shift) & mask;
+    const u32 dd = (u32)((x - base) >> shift) & mask;
     out[gbase[dd] + (q - hist[dd])] = msd_word(x);
   }
 }
 
 // Sizes of the sub-buckets per group: block h counts the d2-digits of its piece (8 pass-2 tiles) of bucket b in LDS and
 // adds them to cnt2g[((b << d2) + digit) * 8 + g], g = the group that will work the tile in pass 2 (tile / cpx2).
-__global__ __launch_bounds__(1024) void k_msd_hist2(const u64 *__restrict__ in, u32 shift, u32 dbits,
+__global__ __launch_bounds__(1024) void k_msd_hist2(const u64 *__restrict__ in, u64 base, u32 shift, u32 dbits,
                                                    const u32 *__restrict__ tpre, const u32 *__restrict__ tpreh,
                                                    const u32 *__restrict__ bstart, u32 nb1, const u32 *__restrict__ plan,
                                                    u32 *__restrict__ cnt2g) {
@@ -208,7 +232,7 @@ __global__ __launch_bounds__(1024) void k_msd_hist2(const u64 *__restrict__ in, 
     for (u32 k = 0; k < kMsdTile / 1024; k++) w[k] = in[min(pb + k * 1024u + tid, pe - 1u)];
 #pragma unroll
     for (u32 k = 0; k < kMsdTile / 1024; k++)
-      if (pb + k * 1024u + tid < pe) atomicAdd(&hist[(u32)(msd_word(w[k]) >> shift) & mask], 1u);
+      if (pb + k * 1024u + tid < pe) atomicAdd(&hist[(u32)((msd_word(w[k]) - base) >> shift) & mask], 1u);
   }
   __syncthreads();
   if (tid < ndig && hist[tid]) atomicAdd(&cnt2g[(((size_t)b << dbits) + tid) * kMsdGroups + gcur], hist[tid]);
@@ -275,7 +299,7 @@ struct MsdSplitSink {
 //   4. every word counts the smaller words of its own bin (about one word per bin): final index = bin start + count
 // The words are distinct, so the result is the unique ascending order.
 template <int NT, int CAP, int BB, class Sink>
-__global__ __launch_bounds__(NT) void k_msd_local(const u64 *__restrict__ in, const u32 *__restrict__ start, u32 shb, Sink out) {
+__global__ __launch_bounds__(NT) void k_msd_local(const u64 *__restrict__ in, const u32 *__restrict__ start, u64 base, u32 shb, Sink out) {
   constexpr int IPT = CAP / NT, NBIN = 1 << BB, BPT = NBIN / NT;
   static_assert(CAP % NT == 0 && NBIN % NT == 0, "shape");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // CAP words (dynamic: CAP * 8 bytes)
@@ -299,7 +323,7 @@ __global__ __launch_bounds__(NT) void k_msd_local(const u64 *__restrict__ in, co
 #pragma unroll
   for (int k = 0; k < IPT; k++) {
     const u32 t = k * NT + tid;
-    if (t < m) rk[k] = atomicAdd(&cnt[(u32)(r[k] >> shb) & (NBIN - 1)], 1u);
+    if (t < m) rk[k] = atomicAdd(&cnt[(u32)((r[k] - base) >> shb) & (NBIN - 1)], 1u);
   }
   __syncthreads();
   // exclusive scan of the bins: thread tid owns bins [tid * BPT, (tid + 1) * BPT)
@@ -315,12 +339,12 @@ __global__ __launch_bounds__(NT) void k_msd_local(const u64 *__restrict__ in, co
 #pragma unroll
   for (int k = 0; k < IPT; k++) {
     const u32 t = k * NT + tid;
-    if (t < m) srec[cnt[(u32)(r[k] >> shb) & (NBIN - 1)] + rk[k]] = r[k];
+    if (t < m) srec[cnt[(u32)((r[k] - base) >> shb) & (NBIN - 1)] + rk[k]] = r[k];
   }
   __syncthreads();
   for (u32 q = tid; q < m; q += NT) {
     const u64 x = srec[q];
-    const u32 bin = (u32)(x >> shb) & (NBIN - 1);
+    const u32 bin = (u32)((x - base) >> shb) & (NBIN - 1);
     const u32 lo = cnt[bin], hi = cnt[bin + 1];
     u32 less = 0;
     for (u32 j = lo; j < hi; j++) less += srec[j] < x ? 1u : 0u;

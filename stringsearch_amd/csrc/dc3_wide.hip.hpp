@@ -20,6 +20,8 @@ struct WideKey {
 constexpr u32 kWideMaxImageSyms = 48;
 constexpr u32 kWideWindow = 256;          // symbols compared before two positions count as having the same window ...
 constexpr u32 kWideWindowDeep = 8192;     // ... and in the second attempt, made when only few windows agree on 256 symbols
+constexpr u64 kWideMaxDepth = 1ull << 30; // further attempts go 16 times deeper each, up to this many symbols ...
+constexpr u64 kWideTieBudget = 1ull << 37;// ... while (windows that still agree) x depth stays below this many symbol compares
 
 __device__ __forceinline__ u64 wide_pos(const Rec16 &r) { return ((u64)r.k2 << 32) | r.pos; }
 __device__ __forceinline__ u64 wide_img(const Rec16 &r) { return ((u64)r.k1 << 32) | r.k0; }

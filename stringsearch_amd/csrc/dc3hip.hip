@@ -85,6 +85,7 @@ struct dc3hip_ctx {
   bool no_long_keys = false;   // DC3HIP_NO_LONG_KEYS=1: the whole-text shortcut only with 9-symbol windows (no KeyT)
   bool no_doubling = false;    // DC3HIP_NO_DOUBLING=1: repeated windows always hand the whole-text order to level 1
   int text_order12 = -1;       // DC3HIP_TEXT_ORDER12=1/0: whole-text shortcut on 12-byte records always / never (default: n > 2^31)
+  double hybrid_max_pred = 0.50;                      // DC3HIP_HYBRID_MAX_PRED (tuning): 8-byte prefix sort of a level's samples below this predicted tied fraction
   double hybrid12_max_pred = kHybrid12MaxPredicted;   // DC3HIP_HYBRID12_MAX_PRED (tuning)
   u32 hybrid12_min = 1u << 22; // DC3HIP_HYBRID12_MIN: smallest level (samples) that tries it (tests lower it)
   bool no_hybrid8 = false;     // DC3HIP_NO_HYBRID8=1 (tests): skip the 8-byte prefix sort / whole-level order of a level
@@ -372,17 +373,22 @@ struct MsdGeom {
   u32 d1 = 0, d2 = 0;                            // digit widths of the two partition passes (d2 = 0: one pass)
   u32 ntiles1 = 0, tpc = 0, cpg = 0, cpx1 = 0;   // pass-1 tiles; tiles per pack chunk, chunks and tiles per group
   Chunking ck{0, 0};                             // chunking of the pack kernel that produces the bucket sizes
+  u64 img_lo = 0;                                // the records' images lie in [img_lo, img_lo + 2^ebits): digits come from
+  u32 ebits = 0;                                 // image - img_lo, ebits wide (the whole range: 0, hm.nbits)
 };
 static constexpr u32 kMsdCapSmall = 2048, kMsdCapLarge = 4096;     // sub-bucket capacities of the two local-sort shapes
 // Geometry for nrec words with hm's layout, or .on = false when the bucket ordering does not apply (switched off, too
 // few records, 32-bit positions, or too few image bits below the bucket bits for the local sort's bins).
-static MsdGeom msd_geometry(const dc3hip_ctx *c, u32 nrec, const HiMap &hm) {
+// img_lo / img_span: the records hold only the images in [img_lo, img_lo + img_span) (0 = the whole range).
+static MsdGeom msd_geometry(const dc3hip_ctx *c, u32 nrec, const HiMap &hm, u64 img_lo = 0, u64 img_span = 0) {
   MsdGeom g;
   if (c->no_msd || nrec < c->msd_min || nrec < 4096 || hm.pbits >= 32 || hm.pbits + hm.nbits > 64) return g;
+  g.img_lo = img_span ? img_lo : 0;
+  g.ebits = img_span ? std::min<u32>(hm.nbits, bits_of(img_span - 1)) : hm.nbits;
   const u32 lg = bits_of((u64)nrec - 1);                       // ceil(log2 nrec)
   u32 tb = lg > 10 ? lg - 10 : 1;                              // sub-buckets of 512..1024 words on uniform images
   if (tb > 20) tb = 20;
-  if (hm.nbits < tb + 4) return g;
+  if (g.ebits < tb + 4) return g;
   if (tb <= 10) { g.d1 = tb; g.d2 = 0; } else { g.d1 = (tb + 1) / 2; g.d2 = tb - g.d1; }
   g.ntiles1 = (nrec + kMsdTile - 1) / kMsdTile;
   g.tpc = std::max<u32>(1, (g.ntiles1 + 2047) / 2048);
@@ -394,16 +400,16 @@ static MsdGeom msd_geometry(const dc3hip_ctx *c, u32 nrec, const HiMap &hm) {
   return g;
 }
 // what a finished sort leaves behind so that its last pass can be repeated into records (cf. LastPass)
-struct MsdRedo { const u64 *src = nullptr; u64 *dst = nullptr; const u32 *start = nullptr; u32 nsub = 0, shb = 0; bool large = false; };
+struct MsdRedo { const u64 *src = nullptr; u64 *dst = nullptr; const u32 *start = nullptr; u32 nsub = 0, shb = 0; bool large = false; u64 base = 0; };
 template <class Sink>
 static int msd_launch_local(dc3hip_ctx *c, const MsdRedo &r, u32 n, Sink sink) {
   PhaseScope ps(c, DC3HIP_PH_SORT8_DOWN, n, 6);
   if (r.large)
     hipLaunchKernelGGL((k_msd_local<512, (int)kMsdCapLarge, 12, Sink>), dim3(r.nsub), dim3(512), kMsdCapLarge * 8, c->stream, r.src,
-                       r.start, r.shb, sink);
+                       r.start, r.base, r.shb, sink);
   else
     hipLaunchKernelGGL((k_msd_local<256, (int)kMsdCapSmall, 10, Sink>), dim3(r.nsub), dim3(256), kMsdCapSmall * 8, c->stream, r.src,
-                       r.start, r.shb, sink);
+                       r.start, r.base, r.shb, sink);
   KCHECK();
   return E_OK;
 }
@@ -423,7 +429,8 @@ static int msd_sort(dc3hip_ctx *c, Rec8 *ha, Rec8 *hb, u32 n, const HiMap &hm, c
     attr_set[c->device & 15] = true;
   }
   const u32 nb1 = 1u << g.d1, tb = g.d1 + g.d2, n2 = 1u << tb;
-  const u32 sh1 = hm.pbits + hm.nbits - g.d1, sh2 = sh1 - g.d2, rb = hm.nbits - tb;
+  const u32 sh1 = hm.pbits + g.ebits - g.d1, sh2 = sh1 - g.d2, rb = g.ebits - tb;
+  const u64 base = g.img_lo << hm.pbits;
   u32 *cntg = nullptr, *startg = nullptr, *cur1 = nullptr, *bstart = nullptr, *tpre = nullptr, *tpreh = nullptr, *plan = nullptr, *segsum = nullptr;
   RC(arena_alloc(c, (size_t)nb1 * kMsdGroups + 16, &cntg));
   RC(arena_alloc(c, (size_t)nb1 * kMsdGroups + 16, &startg));
@@ -431,6 +438,14 @@ static int msd_sort(dc3hip_ctx *c, Rec8 *ha, Rec8 *hb, u32 n, const HiMap &hm, c
   RC(arena_alloc(c, (size_t)nb1 + 16, &bstart)); RC(arena_alloc(c, (size_t)nb1 + 16, &tpre)); RC(arena_alloc(c, (size_t)nb1 + 16, &tpreh));
   RC(arena_alloc(c, (size_t)kMsdW_COUNT + 12, &plan)); RC(arena_alloc(c, (size_t)1024 + 16, &segsum));
   u64 *wa = reinterpret_cast<u64 *>(ha), *wb = reinterpret_cast<u64 *>(hb);
+  if (!table) {                              // records packed elsewhere: count the top digit here (one read of the records)
+    u32 *t = nullptr;
+    RC(arena_alloc(c, (size_t)kMsdMaxDig * g.ck.nchunks, &t));
+    PhaseScope ps(c, DC3HIP_PH_SORT12_UP, n);
+    hipLaunchKernelGGL(k_msd_hist1, dim3(g.ck.nchunks), dim3(kBlock), 0, c->stream, (const u64 *)wa, n, base, sh1, g.ck.chunk, g.ck.nchunks, t);
+    KCHECK();
+    table = t;
+  }
   {
     PhaseScope ps(c, DC3HIP_PH_SORT12_SCAN, nb1);
     HIPC(hipMemsetAsync(plan, 0, (kMsdW_COUNT + 12) * sizeof(u32), c->stream));
@@ -442,10 +457,11 @@ static int msd_sort(dc3hip_ctx *c, Rec8 *ha, Rec8 *hb, u32 n, const HiMap &hm, c
   {
     PhaseScope ps(c, DC3HIP_PH_SORT8_DOWN, n, 5);
     hipLaunchKernelGGL((k_msd_part<false>), dim3(kMsdGroups * g.cpx1), dim3(kMsdNW * 64), kMsdPartSmem, c->stream, (const u64 *)wa, wb, n,
-                       sh1, g.d1, g.cpx1, g.ntiles1, (const u32 *)nullptr, (const u32 *)nullptr, nb1, (const u32 *)plan, cur1, nb1);
+                       base, sh1, g.d1, g.cpx1, g.ntiles1, (const u32 *)nullptr, (const u32 *)nullptr, nb1, (const u32 *)plan, cur1, nb1);
     KCHECK();
   }
   MsdRedo r;
+  r.base = base;
   if (g.d2 > 0) {
     const size_t N = (size_t)n2 * kMsdGroups;
     u32 *cnt2g = nullptr, *cur2 = nullptr;
@@ -455,7 +471,7 @@ static int msd_sort(dc3hip_ctx *c, Rec8 *ha, Rec8 *hb, u32 n, const HiMap &hm, c
     {
       PhaseScope ps(c, DC3HIP_PH_SORT12_UP, n);
       HIPC(hipMemsetAsync(cnt2g, 0, (N + 1) * sizeof(u32), c->stream));
-      hipLaunchKernelGGL(k_msd_hist2, dim3(n / kMsdHistTile + nb1 + 1), dim3(1024), 0, c->stream, (const u64 *)wb, sh2, g.d2,
+      hipLaunchKernelGGL(k_msd_hist2, dim3(n / kMsdHistTile + nb1 + 1), dim3(1024), 0, c->stream, (const u64 *)wb, base, sh2, g.d2,
                          (const u32 *)tpre, (const u32 *)tpreh, (const u32 *)bstart, nb1, (const u32 *)plan, cnt2g);
       KCHECK();
     }
@@ -470,7 +486,7 @@ static int msd_sort(dc3hip_ctx *c, Rec8 *ha, Rec8 *hb, u32 n, const HiMap &hm, c
     {
       PhaseScope ps(c, DC3HIP_PH_SORT8_DOWN, n, 5);
       const u32 grid2 = kMsdGroups * ((n / kMsdTile + nb1 + 1 + kMsdGroups - 1) / kMsdGroups);
-      hipLaunchKernelGGL((k_msd_part<true>), dim3(grid2), dim3(kMsdNW * 64), kMsdPartSmem, c->stream, (const u64 *)wb, wa, n, sh2, g.d2,
+      hipLaunchKernelGGL((k_msd_part<true>), dim3(grid2), dim3(kMsdNW * 64), kMsdPartSmem, c->stream, (const u64 *)wb, wa, n, base, sh2, g.d2,
                          0u, 0u, (const u32 *)tpre, (const u32 *)bstart, nb1, (const u32 *)plan, cur2, n2);
       KCHECK();
     }
@@ -725,7 +741,7 @@ static int discard_recurse(dc3hip_ctx *c, const u32 *RU, const u32 *sslot, u32 m
 //     out above kHybridMaxMeasured.  Correctness never depends on the policy.
 // ---------------------------------------------------------------------------------------------
 static constexpr u32 kHybridMinSamples = 1u << 22;
-static constexpr double kHybridMaxPredicted = 0.50;
+// (kHybridMaxPredicted = dc3hip_ctx::hybrid_max_pred, 0.50 unless DC3HIP_HYBRID_MAX_PRED says otherwise)
 static constexpr double kHybridMaxMeasured = 0.60;
 static constexpr double kFullSortMaxPredicted = 0.10;   // whole-level shortcut only for very few predicted ties
 static constexpr double kTextSortMaxPredicted = 0.30;   // whole-text shortcut (33-bit images at 2^30 bytes tie ~12 %)
@@ -844,9 +860,16 @@ template <class KM>
 static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Rec8 *ha, Rec8 *hb, u32 nrec,
                             Rec8 **h_out, uint8_t *f, bool *ok, int depth, u32 *emit_sa = nullptr, u32 skip = 0,
                             bool *emitted_distinct = nullptr, u32 *first_table = nullptr, bool whole_text = false,
-                            const MsdGeom *mg = nullptr) {
+                            const MsdGeom *mg = nullptr, u64 img_lo = 0, u64 img_span = 0) {
+  // img_lo / img_span (only with mg == nullptr): the records hold the images of [img_lo, img_lo + img_span) only
   // mg (and mg->on): the records were packed for the bucket ordering — first_table is then the digit table of the TOP
-  // image bits in mg's chunking, and the sort runs msd_sort(); should that give up, the LSD passes start from scratch
+  // image bits in mg's chunking, and the sort runs msd_sort(); should that give up, the LSD passes start from scratch.
+  // mg == nullptr (callers that build their records elsewhere): the bucket ordering counts its top digit itself.
+  MsdGeom mg_self;
+  if (!mg) {
+    mg_self = msd_geometry(c, nrec, hm, img_lo, img_span);
+    if (mg_self.on) { mg = &mg_self; first_table = nullptr; }
+  }
   // whole_text: the records are ALL positions of the text (single device): few repeated windows may be settled here by
   // prefix doubling.  (A rank of the global mode orders only its image range and must not: ranks are global.)
   *ok = false;
@@ -1682,7 +1705,7 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
           done = true;
         }
       }
-      if (!done && pred < kHybridMaxPredicted) {
+      if (!done && pred < c->hybrid_max_pred) {
         bool ok = false;
         RC(order_hybrid<Sym>(c, S, m, m0, m02, b, kbits, sa12, rank12, R, sslot, &names, &mode, &ok, depth));
         done = ok;
@@ -2110,6 +2133,7 @@ int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) {
   { const char *e = getenv("DC3HIP_NO_HYBRID8"); c->no_hybrid8 = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_HYBRID12_MIN"); if (e) c->hybrid12_min = (u32)std::max(0ll, atoll(e)); }
   { const char *e = getenv("DC3HIP_HYBRID12_MAX_PRED"); if (e) c->hybrid12_max_pred = atof(e); }
+  { const char *e = getenv("DC3HIP_HYBRID_MAX_PRED"); if (e) c->hybrid_max_pred = atof(e); }
   const char *nts = getenv("DC3HIP_NO_TEXT_SHORTCUT");
   c->no_text_shortcut = (nts && nts[0] == '1');
   const char *nf = getenv("DC3HIP_NO_FULLSORT");

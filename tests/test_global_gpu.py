@@ -222,6 +222,37 @@ def test_bench_global_two_processes_on_one_gpu(ss, oracle, tmp_path):
         assert np.array_equal(got, want_sa(oracle, text)), kind
 
 
+def test_routed_order_and_bucket_sort_of_a_key_range(ss, oracle):
+    """The distributed whole-text order in its routed form (every rank packs its own block, records go to the owner of their
+    key range by one all-to-all) against the round-2 form (every rank evaluates every position: DC3HIP_GLOBAL_NO_ROUTE=1),
+    with the bucket (MSD) ordering forced onto the small key-range slices (DC3HIP_MSD_MIN: digits are taken from
+    image - range start) and without it: same shards, equal to the reference suffix array.  Random bytes, DNA (39-symbol
+    windows) and a text with a planted repeat (the order is not distinct: falls through to the distributed recursion)."""
+    n = 6_000_011
+    rnd = oracle.gen(n, 21, 0)
+    dna = oracle.gen(n, 22, 1)
+    rep = rnd.copy(); rep[4_000_000:4_050_000] = rep[100_000:150_000]
+    for name, t in (("random", rnd), ("dna", dna), ("planted_repeat", rep)):
+        want = want_sa(oracle, t)
+        for P in (2, 4, 7):
+            for extra in ({"DC3HIP_MSD_MIN": 4096}, {"DC3HIP_NO_MSD": 1}, {"DC3HIP_GLOBAL_NO_ROUTE": 1, "DC3HIP_MSD_MIN": 4096}):
+                with env(**extra):
+                    with ss.LoopbackGroup(P, n) as g:
+                        g.set_text(t)
+                        g.build()
+                        st = g.stats()
+                        assert np.array_equal(g.sa(), want), (name, P, extra)
+                        if name != "planted_repeat":
+                            assert all(s["text_order"] == 1 for s in st), (name, P, extra)
+                            if "DC3HIP_GLOBAL_NO_ROUTE" not in extra:
+                                # routed: a rank receives about n / P records, and sent about (P-1)/P of its block
+                                assert all(abs(s["shard_count"] - n / P) < 0.25 * n / P for s in st), [s["shard_count"] for s in st]
+                                assert all(s["comm_bytes_out"] > 0 for s in st)
+                            if "DC3HIP_MSD_MIN" in extra and "DC3HIP_GLOBAL_NO_ROUTE" not in extra:
+                                # (unrouted slices have arbitrary image ranges: the bucket ordering may give up on them)
+                                assert all(s["ctx"]["msd_sorts"] >= 1 and s["ctx"]["msd_fallbacks"] == 0 for s in st), (name, P, extra)
+
+
 def test_transport_selftest_and_recovery_after_a_failed_collective(ss, oracle):
     """dc3hip_global_selftest (ragged all-to-all / all-gather of known bytes, every byte checked) on loopback groups, and
     the failure semantics of the header: after a collective that failed on every rank (a one-symbol text in a wide
@@ -373,8 +404,9 @@ def test_loopback_spread_over_visible_devices(ss, oracle):
 def test_wide_mode_small_texts_match_the_oracle(ss, oracle, P):
     """The wide mode (64-bit positions, texts beyond DC3HIP_MAX_N) forced onto small texts so that the oracle can judge it:
     random bytes, DNA, binary, an alphabet with 0x00, texts ending in a run of the smallest symbol; bit-exact shards
-    (fetched as int64), the collective verifier agrees, the u32 getter refuses.  A text with a repeated window and a text
-    over one symbol are refused with -4 on every rank."""
+    (fetched as int64), the collective verifier agrees, the u32 getter refuses.  Planted repeats of 100, 400, 20 000 and
+    150 000 symbols are settled by the tie rounds (each 16 times deeper than the last); a text half of which is a copy of
+    the other half and a text over one symbol are refused with -4 on every rank."""
     rng = np.random.default_rng(47)
     with env(DC3HIP_GLOBAL_FORCE_WIDE=1), ss.LoopbackGroup(P, 3_000_000) as g:
         cases = {"bytes": rng.integers(0, 256, size=2_500_003, dtype=np.uint8), "dna": oracle.gen(3_000_000, 5, 1),
@@ -397,8 +429,15 @@ def test_wide_mode_small_texts_match_the_oracle(ss, oracle, P):
         mid = cases["dna"].copy(); mid[1_000_000:1_000_400] = mid[5:405]               # a longer one: settled by the deeper second attempt
         g.set_text(mid); g.build()
         assert np.array_equal(g.sa(), want_sa(oracle, mid)) and g.sufcheck() == 0
-        rep = cases["dna"].copy(); rep[1_000_000:1_020_000] = rep[5:20_005]            # beyond 8192 symbols: refused
-        for bad in (rep, np.full(100_000, 65, dtype=np.uint8)):
+        rep = cases["dna"].copy(); rep[1_000_000:1_020_000] = rep[5:20_005]            # beyond 8192 symbols: settled by the rounds that
+        g.set_text(rep); g.build()                                                     # go 16 times deeper each (round 3)
+        assert np.array_equal(g.sa(), want_sa(oracle, rep)) and g.sufcheck() == 0
+        rep3 = cases["dna"].copy()                                                     # three copies of a 150 000-symbol block, one
+        rep3[1_000_000:1_150_000] = rep3[5:150_005]; rep3[2_500_000:2_650_000] = rep3[5:150_005]   # of them reaching close to the end
+        g.set_text(rep3); g.build()
+        assert np.array_equal(g.sa(), want_sa(oracle, rep3)) and g.sufcheck() == 0
+        huge = cases["dna"].copy(); huge[1_500_000:2_900_000] = huge[5:1_400_005]      # more than 2^20 positions share their window: refused
+        for bad in (huge, np.full(100_000, 65, dtype=np.uint8)):
             g.set_text(bad)
             with pytest.raises(ss.Dc3HipError) as ei:
                 g.build()

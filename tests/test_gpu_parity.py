@@ -571,6 +571,46 @@ def test_prefix_doubling_finish_of_few_repeated_windows(ss, oracle):
                     os.environ.pop(k, None)
 
 
+def test_bucket_ordering_matches_the_stable_passes(ss, oracle):
+    """The bucket (MSD) ordering of the prefix-sort words (dc3_msd.hip.hpp: two XCD-grouped partition passes + in-LDS order
+    of the sub-buckets) against the stable LSD passes it replaces (DC3HIP_NO_MSD=1): same suffix array, equal to
+    divsufsort's, on every route that sorts 8-byte words — whole-text order (bytes: 9-byte windows; DNA: 39-symbol
+    windows), whole-level order and sample prefix sort inside the recursion (DC3HIP_NO_TEXT_SHORTCUT=1), a planted repeat
+    (records needed after all: the last pass is repeated into records), one pass (small n) and two passes, sizes around
+    tile and group boundaries — and the fallback when a sub-bucket is too large for LDS (images crowded into a corner
+    of their range: a text over 200 symbols of which 3 occur 99.9 % of the time passes the tie predictor with a skewed
+    image distribution)."""
+    rng = np.random.default_rng(91)
+    cases = {}
+    for n in ((1 << 22) + 3, 5_000_001, (1 << 23) + 8191):
+        cases[f"bytes_{n}"] = rng.integers(0, 256, size=n, dtype=np.uint8)
+    cases["dna"] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=6_000_000)].copy()
+    d = rng.integers(0, 256, size=6_000_000, dtype=np.uint8); d[3_000_000:3_040_000] = d[10_000:50_000]
+    cases["planted_repeat"] = d
+    sk = rng.integers(0, 200, size=7_000_000).astype(np.uint8)
+    mask = rng.random(7_000_000) < 0.97
+    sk[mask] = rng.integers(0, 3, size=int(mask.sum())).astype(np.uint8)
+    cases["skewed_symbols"] = sk
+    for label, arr in cases.items():
+        data = arr.tobytes()
+        want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)
+        for env in ({"DC3HIP_MSD_MIN": "4096"}, {"DC3HIP_MSD_MIN": "4096", "DC3HIP_NO_TEXT_SHORTCUT": "1"}, {"DC3HIP_NO_MSD": "1"},
+                    {"DC3HIP_MSD_MIN": "4096", "DC3HIP_NO_TUP_SCATTER": "1", "DC3HIP_NO_XCD_MAP": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1"}):
+            os.environ.update(env)
+            try:
+                with ss.Context(len(data)) as c:
+                    c.set_text(data); c.build()
+                    st = c.stats()
+                    assert np.array_equal(c.sa(), want), (label, env)
+                    if "DC3HIP_NO_MSD" in env:
+                        assert st["msd_sorts"] == 0
+                    elif (label.startswith("bytes") or label == "dna") and "DC3HIP_NO_TEXT_SHORTCUT" not in env:
+                        assert st["msd_sorts"] >= 1, (label, env, st["msd_sorts"], st["msd_fallbacks"])
+            finally:
+                for k in env:
+                    os.environ.pop(k, None)
+
+
 def test_deep_tie_pass_then_doubling_on_12_byte_records(ss, oracle):
     """Regression (round-2 advisor finding): on 12-byte records the second, deeper tie pass leaves f[] marking groups that
     agree on 2048 symbols; the prefix doubling that follows must look ranks up at the same depth.  The case that broke:

@@ -24,7 +24,9 @@ if e[0]: res["bytes_per_record"]["downsweep_rec8"] = tot(lambda k: "k_rs_downswe
 if e[1]: res["bytes_per_record"]["downsweep_rec16"] = tot(lambda k: "k_rs_downsweep<dc3::Rec16" in k or "k_rs_downsweep<dc3::Rec12" in k, 2) / e[1]
 if e[2]: res["bytes_per_record"]["downsweep_tup0"] = tot(lambda k: "k_rs_downsweep<dc3::Tup0" in k, 2) / e[2]
 if st["gather_elems"]: res["bytes_per_record"]["gather_tuples"] = tot(lambda k: "k_gather_tuples" in k, 1) / st["gather_elems"]
-if st["partition_elems"]: res["bytes_per_record"]["partition_pairs"] = tot(lambda k: "k_part_msd" in k, 2) / st["partition_elems"]
+if st["partition_elems"]: res["bytes_per_record"]["part_msd"] = tot(lambda k: "k_part_msd" in k or "k_tup_part" in k, 2) / st["partition_elems"]
+if st.get("msd_part_elems"): res["bytes_per_record"]["msd_part"] = tot(lambda k: "k_msd_part" in k, 2) / st["msd_part_elems"]
+if st.get("msd_local_elems"): res["bytes_per_record"]["msd_local"] = tot(lambda k: "k_msd_local" in k, 2) / st["msd_local_elems"]
 for k in sorted(set(F) | set(W), key=lambda k: -(2 * F.get(k, 0) + W.get(k, 0))):
     res["per_kernel_bytes"][k] = {"fetch_raw": F.get(k, 0), "write": W.get(k, 0)}
 try:
@@ -32,6 +34,9 @@ try:
     res["commit"] = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True).strip()
 except Exception:
     res["commit"] = None
+sys.path.insert(0, ".")
+from stringsearch_amd.benchlib import kernel_sources_sha
+res["kernel_sources_sha"] = kernel_sources_sha()       # bench.py replays these figures only on exactly these sources
 res["whole_build_bytes_streaming_corrected"] = sum(2 * F.get(k, 0) + W.get(k, 0) for k in set(F) | set(W) if "gather" not in k) + tot(lambda k: "k_gather_tuples" in k, 1)
 res["build_ms_under_pmc"] = st["build_ms"]
 res["levels"] = list(zip(st["level_n"], st["level_sorted"]))

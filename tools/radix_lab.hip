@@ -104,8 +104,90 @@ __global__ __launch_bounds__(1024) void k_lab_hist_g(const u64 *__restrict__ in,
     if (hist[(g << 10) + d]) atomicAdd(&cntg[d * 8 + g], hist[(g << 10) + d]);
   }
 }
+// pass-2 cursors (one plane per group) back from the scanned starts: cur2[g * n2 + s] = start[s * 8 + g]
+__global__ void k_lab_starts_to_cur(const u32 *start, u32 n2, u32 *cur2) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)n2 * 8; i += (size_t)gridDim.x * blockDim.x) cur2[(i % 8) * n2 + i / 8] = start[i];
+}
 __global__ void k_lab_transpose_cur(const u32 *start_dg, u32 ndig, u32 *cur_gd) {
   for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < 8 * ndig; j += gridDim.x * blockDim.x) cur_gd[(j % 8) * ndig + j / 8] = start_dg[j];
+}
+
+// ---- lab-only: the partition pass with its knobs exposed (tile size, grouped cursors, non-temporal accesses); the
+// product kernel (k_msd_part in dc3_msd.hip.hpp) is the tile8192 / grouped / temporal point of this family with the
+// groups owning contiguous eighths of the input instead of every eighth tile
+constexpr size_t lab_part_smem(int ipt) { return sizeof(u64) * kMsdNW * 64 * ipt + sizeof(u32) * (2 * kMsdMaxDig + 64); }
+template <int IPT, bool kGroup, bool kNT>
+__global__ __launch_bounds__(kMsdNW * 64) void k_lab_part(const u64 *__restrict__ in, u64 *__restrict__ out, u32 n, u32 shift, u32 dbits,
+                                                         u32 *__restrict__ cursors, u32 gstride) {
+  constexpr int NT = kMsdNW * 64, kTile = NT * IPT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u64 *srec = reinterpret_cast<u64 *>(smem);
+  u32 *hist = reinterpret_cast<u32 *>(smem + sizeof(u64) * kTile);
+  u32 *gbase = hist + kMsdMaxDig;
+  u32 *tmp = gbase + kMsdMaxDig;
+  const u32 tid = threadIdx.x;
+  const u32 ndig = 1u << dbits, mask = ndig - 1u;
+  u32 *cur = cursors;
+  if (kGroup) cur += (size_t)(blockIdx.x & 7u) * gstride;
+  const u32 begin = blockIdx.x * (u32)kTile, end = min(n, begin + (u32)kTile);
+  const u32 nvalid = end - begin;
+  hist[tid] = 0;
+  __syncthreads();
+  u64 r[IPT];
+  u32 rk[IPT];
+#pragma unroll
+  for (int k = 0; k < IPT; k++) {
+    const u32 t = min((u32)(k * NT) + tid, nvalid - 1u);
+    r[k] = kNT ? __builtin_nontemporal_load(in + begin + t) : in[begin + t];
+  }
+#pragma unroll
+  for (int k = 0; k < IPT; k++) r[k] = msd_word(r[k]);
+#pragma unroll
+  for (int k = 0; k < IPT; k++) {
+    const u32 t = k * NT + tid;
+    if (t < nvalid) rk[k] = atomicAdd(&hist[(u32)(r[k] >> shift) & mask], 1u);
+  }
+  __syncthreads();
+  u32 cnt = 0;
+  if (tid < ndig) { cnt = hist[tid]; if (cnt) gbase[tid] = atomicAdd(&cur[tid], cnt); }
+  u32 tot;
+  const u32 ex = block_excl_scan<kMsdNW>(cnt, tmp, tot);
+  hist[tid] = ex;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < IPT; k++) {
+    const u32 t = k * NT + tid;
+    if (t < nvalid) srec[hist[(u32)(r[k] >> shift) & mask] + rk[k]] = r[k];
+  }
+  __syncthreads();
+  for (u32 q = tid; q < nvalid; q += NT) {
+    const u64 x = srec[q];
+    const u32 dd = (u32)(x >> shift) & mask;
+    if (kNT) __builtin_nontemporal_store(msd_word(x), out + gbase[dd] + (q - hist[dd]));
+    else out[gbase[dd] + (q - hist[dd])] = msd_word(x);
+  }
+}
+// bucket sizes of the top digit (lab: one global counter per digit)
+__global__ __launch_bounds__(1024) void k_lab_hist(const u64 *__restrict__ in, u32 n, u32 shift, u32 *__restrict__ cnt) {
+  __shared__ u32 hist[1024];
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  const u32 begin = blockIdx.x * 65536u;
+  for (u32 j = 0; j < 64; j++) { const u32 i = begin + j * 1024 + threadIdx.x; if (i < n) atomicAdd(&hist[(u32)(memw(in[i]) >> shift)], 1u); }
+  __syncthreads();
+  if (hist[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], hist[threadIdx.x]);
+}
+__global__ __launch_bounds__(1024) void k_lab_scan(const u32 *cnt, u32 n, u32 *cur) {
+  __shared__ u32 tmp[16];
+  u32 carry = 0;
+  for (u32 base = 0; base < n; base += 1024) {
+    const u32 i = base + threadIdx.x;
+    const u32 v = i < n ? cnt[i] : 0u;
+    u32 tot;
+    const u32 ex = block_excl_scan<16>(v, tmp, tot) + carry;
+    if (i < n) cur[i] = ex;
+    carry += tot;
+  }
 }
 
 struct Timer {
@@ -205,30 +287,27 @@ int main(int argc, char **argv) {
 
   // ---- pass-1 experiments: digit width, tile size, grouped cursors, non-temporal accesses
   if (sections & 4u) {
-    u32 *cnt, *bst, *cur, *tp, *tph, *cntg, *stg, *curg;
-    CK(hipMalloc(&cnt, 4096 * 4)); CK(hipMalloc(&bst, 4100 * 4)); CK(hipMalloc(&cur, 4096 * 4)); CK(hipMalloc(&tp, 4100 * 4)); CK(hipMalloc(&tph, 4100 * 4));
+    u32 *cnt, *cur, *cntg, *stg, *curg;
+    CK(hipMalloc(&cnt, 4096 * 4)); CK(hipMalloc(&cur, 4096 * 4));
     CK(hipMalloc(&cntg, 8200 * 4)); CK(hipMalloc(&stg, 8200 * 4)); CK(hipMalloc(&curg, 8200 * 4));
-    auto set_attr = [&](auto kern, int ipt) { CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)msd_part_smem(ipt))); };
-    set_attr(k_msd_part<false, 8, false, false>, 8); set_attr(k_msd_part<false, 8, false, true>, 8); set_attr(k_msd_part<false, 16, false, false>, 16);
-    set_attr(k_msd_part<false, 8, true, false>, 8); set_attr(k_msd_part<false, 16, true, false>, 16); set_attr(k_msd_part<false, 4, false, false>, 4); set_attr(k_msd_part<false, 4, true, false>, 4);
+    auto set_attr = [&](auto kern, int ipt) { CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lab_part_smem(ipt))); };
+    set_attr(k_lab_part<8, false, false>, 8); set_attr(k_lab_part<8, false, true>, 8); set_attr(k_lab_part<16, false, false>, 16);
+    set_attr(k_lab_part<8, true, false>, 8); set_attr(k_lab_part<16, true, false>, 16); set_attr(k_lab_part<4, false, false>, 4); set_attr(k_lab_part<4, true, false>, 4);
     for (u32 d1 : {8u, 9u, 10u}) {
       const u32 sh1 = pbits + nbits - d1, nb1 = 1u << d1;
       CK(hipMemset(cnt, 0, 4096 * 4));
-      const u32 nt = (n + kMsdHistTile - 1) / kMsdHistTile;
-      u32 h_t[2] = {0, nt}, h_b[2] = {0, n};
-      CK(hipMemcpy(tph, h_t, 8, hipMemcpyHostToDevice)); CK(hipMemcpy(bst, h_b, 8, hipMemcpyHostToDevice));
-      hipLaunchKernelGGL(k_msd_hist2, dim3(nt), dim3(1024), 0, 0, (const u64 *)src, sh1, d1, tph, bst, 1u, cnt);
+      hipLaunchKernelGGL(k_lab_hist, dim3((n + 65535) / 65536), dim3(1024), 0, 0, (const u64 *)src, n, sh1, cnt);
       auto run = [&](const char *name, auto kern, int ipt, bool grouped) {
         const u32 tile = kMsdNW * 64 * ipt, grid = (n + tile - 1) / tile;
         if (grouped) {
           CK(hipMemset(cntg, 0, 8200 * 4));
           hipLaunchKernelGGL(k_lab_hist_g, dim3((n + 65535) / 65536), dim3(1024), 0, 0, (const u64 *)src, n, sh1, d1, tile, cntg);
-          hipLaunchKernelGGL(k_msd_scan2, dim3(1), dim3(1024), 0, 0, cntg, 8 * nb1, stg, curg, words);   // stg[d*8+g]
+          hipLaunchKernelGGL(k_lab_scan, dim3(1), dim3(1024), 0, 0, (const u32 *)cntg, 8 * nb1, stg);   // stg[d*8+g]
         }
         float ms = time_it(reps, [&] {
           if (grouped) hipLaunchKernelGGL(k_lab_transpose_cur, dim3(8), dim3(1024), 0, 0, stg, nb1, curg);
-          else hipLaunchKernelGGL(k_msd_tiles, dim3(1), dim3(1024), 0, 0, cnt, nb1, n, bst, cur, tp, tph);
-          hipLaunchKernelGGL(kern, dim3(grid), dim3(kMsdNW * 64), msd_part_smem(ipt), 0, (const u64 *)src, a, n, sh1, d1, (const u32 *)nullptr, (const u32 *)nullptr, 0u, grouped ? curg : cur, nb1);
+          else hipLaunchKernelGGL(k_lab_scan, dim3(1), dim3(1024), 0, 0, (const u32 *)cnt, nb1, cur);
+          hipLaunchKernelGGL(kern, dim3(grid), dim3(kMsdNW * 64), lab_part_smem(ipt), 0, (const u64 *)src, a, n, sh1, d1, grouped ? curg : cur, nb1);
         });
         CK(hipMemset(acc, 0, 16)); CK(hipMemset(bad, 0, 4));
         hipLaunchKernelGGL(k_check_part, dim3(4096), dim3(256), 0, 0, (const u64 *)a, n, sh1, acc, bad);
@@ -237,88 +316,88 @@ int main(int argc, char **argv) {
         printf("{\"lab\":\"part1\",\"variant\":\"%s\",\"d1\":%u,\"ms\":%.3f,\"TBps_moved\":%.3f,\"ok\":%s}\n", name, d1, ms, 16.0 * n / ms * 1e-9,
                (nbad == 0 && got[0] == ref[0] && got[1] == ref[1]) ? "true" : "false");
       };
-      run("tile8192", k_msd_part<false, 8, false, false>, 8, false);
-      run("tile8192_nt", k_msd_part<false, 8, false, true>, 8, false);
-      run("tile16384", k_msd_part<false, 16, false, false>, 16, false);
-      run("tile4096", k_msd_part<false, 4, false, false>, 4, false);
-      run("tile8192_grouped", k_msd_part<false, 8, true, false>, 8, true);
-      run("tile16384_grouped", k_msd_part<false, 16, true, false>, 16, true);
-      run("tile4096_grouped", k_msd_part<false, 4, true, false>, 4, true);
+      run("tile8192", k_lab_part<8, false, false>, 8, false);
+      run("tile8192_nt", k_lab_part<8, false, true>, 8, false);
+      run("tile16384", k_lab_part<16, false, false>, 16, false);
+      run("tile4096", k_lab_part<4, false, false>, 4, false);
+      run("tile8192_grouped", k_lab_part<8, true, false>, 8, true);
+      run("tile16384_grouped", k_lab_part<16, true, false>, 16, true);
+      run("tile4096_grouped", k_lab_part<4, true, false>, 4, true);
     }
   }
 
-  // ---- MSD pipeline
+  // ---- MSD pipeline as the product runs it (dc3hip.hip: msd_geometry / msd_sort), timed kernel by kernel
   for (int variant = 0; variant < 3 && (sections & 8u); variant++) {
-    MsdPlan pl; pl.pbits = pbits; pl.nbits = nbits;
-    // sub-buckets of ~2048 words (variant 0), ~4096 (1), ~1024 (2)
-    const u32 target = variant == 0 ? 11 : variant == 1 ? 12 : 10;
+    const u32 target = variant == 0 ? 10 : variant == 1 ? 11 : 12;      // log2 of the average sub-bucket
     const u32 lgn = bits_of(n - 1);
-    u32 tb = lgn > target ? lgn - target : 0;
-    if (tb > nbits) tb = nbits;
-    pl.d1 = std::min<u32>(10, (tb + 1) / 2); pl.d2 = std::min<u32>(10, tb - pl.d1);
-    pl.sh1 = pbits + nbits - pl.d1; pl.sh2 = pl.sh1 - pl.d2;
-    const u32 rb = nbits - pl.d1 - pl.d2;
-    const u32 nb1 = 1u << pl.d1, n2 = 1u << (pl.d1 + pl.d2);
-    u32 *cnt1, *bstart, *cur1, *tpre, *tpreh, *cnt2, *start2, *cur2;
-    CK(hipMalloc(&cnt1, 4096 * 4)); CK(hipMalloc(&bstart, 4100 * 4)); CK(hipMalloc(&cur1, 4096 * 4));
-    CK(hipMalloc(&tpre, 4100 * 4)); CK(hipMalloc(&tpreh, 4100 * 4));
-    CK(hipMalloc(&cnt2, ((size_t)n2 + 16) * 4)); CK(hipMalloc(&start2, ((size_t)n2 + 16) * 4)); CK(hipMalloc(&cur2, ((size_t)n2 + 16) * 4));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_msd_part<false, 8, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_msd_part<true, 8, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
-    // bucket sizes (in the product: the pack kernel's digit table); here an up-sweep over the top digit
-    {
-      CK(hipMemset(cnt1, 0, 4096 * 4));
-      // reuse k_msd_hist2 with one pseudo bucket covering everything: tpreh = {0, ntiles}, bstart = {0, n}
-      const u32 nt = (n + kMsdHistTile - 1) / kMsdHistTile;
-      u32 h_t[2] = {0, nt}, h_b[2] = {0, n};
-      CK(hipMemcpy(tpreh, h_t, 8, hipMemcpyHostToDevice)); CK(hipMemcpy(bstart, h_b, 8, hipMemcpyHostToDevice));
-      float ms = time_it(1, [&] { hipLaunchKernelGGL(k_msd_hist2, dim3(nt), dim3(1024), 0, 0, (const u64 *)src, pl.sh1, pl.d1, tpreh, bstart, 1u, cnt1); });
-      printf("{\"lab\":\"msd_hist1\",\"variant\":%d,\"d1\":%u,\"d2\":%u,\"ms\":%.3f}\n", variant, pl.d1, pl.d2, ms);
-    }
-    float t_tiles = time_it(1, [&] { hipLaunchKernelGGL(k_msd_tiles, dim3(1), dim3(1024), 0, 0, cnt1, nb1, n, bstart, cur1, tpre, tpreh); });
-    const u32 grid1 = (n + kMsdTile - 1) / kMsdTile;
+    u32 tb = lgn > target ? lgn - target : 1;
+    if (tb > 20) tb = 20;
+    const u32 d1 = tb <= 10 ? tb : (tb + 1) / 2, d2 = tb - d1;
+    const u32 sh1 = pbits + nbits - d1, sh2 = sh1 - d2, rb = nbits - tb;
+    const u32 nb1 = 1u << d1, n2 = 1u << tb;
+    const u32 ntiles1 = (n + kMsdTile - 1) / kMsdTile, tpc = std::max<u32>(1, (ntiles1 + 2047) / 2048);
+    const u32 cpg = ((ntiles1 + 7) / 8 + tpc - 1) / tpc, cpx1 = cpg * tpc, chunk = tpc * (u32)kMsdTile, nchunks = (n + chunk - 1) / chunk;
+    u32 *table, *cntg, *startg, *cur1, *bstart, *tpre, *tpreh, *plan, *segsum, *cnt2g, *cur2;
+    const size_t N = (size_t)n2 * 8;
+    CK(hipMalloc(&table, (size_t)1024 * nchunks * 4)); CK(hipMalloc(&cntg, 8200 * 4)); CK(hipMalloc(&startg, 8200 * 4)); CK(hipMalloc(&cur1, 8200 * 4));
+    CK(hipMalloc(&bstart, 1040 * 4)); CK(hipMalloc(&tpre, 1040 * 4)); CK(hipMalloc(&tpreh, 1040 * 4)); CK(hipMalloc(&plan, 64)); CK(hipMalloc(&segsum, 1040 * 4));
+    CK(hipMalloc(&cnt2g, (N + 16) * 4)); CK(hipMalloc(&cur2, (N + 16) * 4));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_msd_part<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_msd_part<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
+    float t_h1 = time_it(reps, [&] { hipLaunchKernelGGL(k_msd_hist1, dim3(nchunks), dim3(kBlock), 0, 0, (const u64 *)src, n, (u64)0, sh1, chunk, nchunks, table); });
+    float t_pl = time_it(reps, [&] {
+      CK(hipMemsetAsync(plan, 0, 64, 0));
+      hipLaunchKernelGGL(k_msd_cnt1, dim3(nb1), dim3(kBlock), 0, 0, (const u32 *)table, nchunks, cpg, cntg);
+      hipLaunchKernelGGL(k_msd_plan1, dim3(1), dim3(1024), 0, 0, (const u32 *)cntg, nb1, n, startg, cur1, bstart, tpre, tpreh, plan);
+    });
+    auto plan1 = [&] {
+      CK(hipMemsetAsync(plan, 0, 64, 0));
+      hipLaunchKernelGGL(k_msd_plan1, dim3(1), dim3(1024), 0, 0, (const u32 *)cntg, nb1, n, startg, cur1, bstart, tpre, tpreh, plan);
+    };
     float t_p1 = time_it(reps, [&] {
-      hipLaunchKernelGGL(k_msd_tiles, dim3(1), dim3(1024), 0, 0, cnt1, nb1, n, bstart, cur1, tpre, tpreh);
-      hipLaunchKernelGGL((k_msd_part<false, 8, false, false>), dim3(grid1), dim3(kMsdNW * 64), kMsdPartSmem, 0, (const u64 *)src, a, n, pl.sh1, pl.d1, (const u32 *)nullptr, (const u32 *)nullptr, 0u, cur1, 0u);
+      plan1();
+      hipLaunchKernelGGL((k_msd_part<false>), dim3(8 * cpx1), dim3(kMsdNW * 64), kMsdPartSmem, 0, (const u64 *)src, a, n, (u64)0, sh1, d1, cpx1, ntiles1,
+                         (const u32 *)nullptr, (const u32 *)nullptr, nb1, (const u32 *)plan, cur1, nb1);
     });
     float t_h2 = 0, t_s2 = 0, t_p2 = 0;
-    const u64 *sorted2 = a;
-    if (pl.d2 > 0) {
-      const u32 gridh = n / kMsdHistTile + nb1 + 1;
+    const u64 *sorted2 = a; u64 *other = b; const u32 *starts = startg; u32 nsub = nb1;
+    if (d2 > 0) {
+      const u32 nseg = (u32)((N + kMsdScanSeg - 1) / kMsdScanSeg);
       t_h2 = time_it(reps, [&] {
-        CK(hipMemsetAsync(cnt2, 0, (size_t)n2 * 4, 0));
-        hipLaunchKernelGGL(k_msd_hist2, dim3(gridh), dim3(1024), 0, 0, (const u64 *)a, pl.sh2, pl.d2, tpreh, bstart, nb1, cnt2);
+        CK(hipMemsetAsync(cnt2g, 0, (N + 1) * 4, 0));
+        hipLaunchKernelGGL(k_msd_hist2, dim3(n / kMsdHistTile + nb1 + 1), dim3(1024), 0, 0, (const u64 *)a, (u64)0, sh2, d2, (const u32 *)tpre, (const u32 *)tpreh,
+                           (const u32 *)bstart, nb1, (const u32 *)plan, cnt2g);
       });
-      t_s2 = time_it(reps, [&] { hipLaunchKernelGGL(k_msd_scan2, dim3(1), dim3(1024), 0, 0, cnt2, n2, start2, cur2, words); });
-      const u32 grid2 = n / kMsdTile + nb1 + 1;
+      t_s2 = time_it(1, [&] {
+        hipLaunchKernelGGL(k_msd_scan2a, dim3(nseg), dim3(1024), 0, 0, (const u32 *)cnt2g, (u32)N, segsum, plan);
+        hipLaunchKernelGGL(k_msd_scan2c, dim3(nseg), dim3(1024), 0, 0, cnt2g, (u32)N, n2, (const u32 *)segsum, cur2);
+      });
+      // (the scan is in place: later repetitions of pass 2 restore the cursors from the scanned starts)
+      const u32 grid2 = 8 * ((n / kMsdTile + nb1 + 1 + 7) / 8);
       t_p2 = time_it(reps, [&] {
-        hipLaunchKernelGGL(k_msd_scan2, dim3(1), dim3(1024), 0, 0, cnt2, n2, start2, cur2, words);
-        hipLaunchKernelGGL((k_msd_part<true, 8, false, false>), dim3(grid2), dim3(kMsdNW * 64), kMsdPartSmem, 0, (const u64 *)a, b, n, pl.sh2, pl.d2, tpre, bstart, nb1, cur2, 0u);
+        hipLaunchKernelGGL(k_lab_starts_to_cur, dim3(1024), dim3(256), 0, 0, (const u32 *)cnt2g, n2, cur2);
+        hipLaunchKernelGGL((k_msd_part<true>), dim3(grid2), dim3(kMsdNW * 64), kMsdPartSmem, 0, (const u64 *)a, b, n, (u64)0, sh2, d2, 0u, 0u, (const u32 *)tpre,
+                           (const u32 *)bstart, nb1, (const u32 *)plan, cur2, n2);
       });
-      sorted2 = b;
+      sorted2 = b; other = a; starts = cnt2g; nsub = n2;
     } else {
-      // sub-buckets = buckets
-      CK(hipMemcpy(start2, bstart, ((size_t)nb1 + 1) * 4, hipMemcpyDeviceToDevice));
-      hipLaunchKernelGGL(k_msd_scan2, dim3(1), dim3(1024), 0, 0, cnt1, nb1, start2, cur2, words);
+      hipLaunchKernelGGL(k_msd_scan2a, dim3((nb1 * 8 + kMsdScanSeg - 1) / kMsdScanSeg), dim3(1024), 0, 0, (const u32 *)cntg, nb1 * 8, segsum, plan);
     }
-    u32 maxsub = 0;
-    CK(hipMemcpy(&maxsub, words, 4, hipMemcpyDeviceToHost));
-    printf("{\"lab\":\"msd_parts\",\"variant\":%d,\"d1\":%u,\"d2\":%u,\"rem_bits\":%u,\"tiles_ms\":%.3f,\"part1_ms\":%.3f,\"hist2_ms\":%.3f,\"scan2_ms\":%.3f,\"part2_ms\":%.3f,\"max_subbucket\":%u,"
-           "\"part1_TBps_moved\":%.3f}\n", variant, pl.d1, pl.d2, rb, t_tiles, t_p1, t_h2, t_s2, t_p2, maxsub, 16.0 * n / t_p1 * 1e-9);
-    // local sort shapes
-    auto run_local = [&](const char *name, auto kern_rec, auto kern_split, u32 cap, u32 bb, u32 nt = 256) {
-      CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern_rec), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap * 8));
-      CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern_split), hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap * 8));
-      if (maxsub > cap) { printf("{\"lab\":\"msd_local\",\"shape\":\"%s\",\"skipped\":\"max sub-bucket %u > cap %u\"}\n", name, maxsub, cap); return; }
-      const u32 ubb = std::min(bb, rb);
-      const u32 shb = pl.sh2 - ubb;
-      (void)ubb;
-      MsdRecSink rs; rs.p = a == sorted2 ? b : a;
+    u32 hp[4];
+    CK(hipMemcpy(hp, plan, 16, hipMemcpyDeviceToHost));
+    const u32 maxsub = hp[kMsdW_MAXSUB];
+    printf("{\"lab\":\"msd_parts\",\"variant\":%d,\"d1\":%u,\"d2\":%u,\"rem_bits\":%u,\"hist1_ms\":%.3f,\"plan_ms\":%.3f,\"part1_ms\":%.3f,\"hist2_ms\":%.3f,\"scan2_ms\":%.3f,"
+           "\"part2_ms\":%.3f,\"max_subbucket\":%u,\"part1_TBps_moved\":%.3f,\"part2_TBps_moved\":%.3f}\n", variant, d1, d2, rb, t_h1, t_pl, t_p1, t_h2, t_s2, t_p2, maxsub,
+           16.0 * n / t_p1 * 1e-9, t_p2 > 0 ? 16.0 * n / t_p2 * 1e-9 : 0.0);
+    auto run_local = [&](const char *name, auto kern_rec, auto kern_split, u32 cap, u32 bb, u32 nt) {
+      if (maxsub > cap) { printf("{\"lab\":\"msd_local\",\"variant\":%d,\"shape\":\"%s\",\"skipped\":\"max sub-bucket %u > cap %u\"}\n", variant, name, maxsub, cap); return; }
+      const u32 shb = sh2 - std::min(bb, rb);
+      MsdRecSink rs; rs.p = other;
       MsdSplitSink ss; ss.sa = sa; ss.img = img; ss.pbits = pbits;
-      float t_rec = time_it(reps, [&] { hipLaunchKernelGGL(kern_rec, dim3(n2), dim3(nt), cap * 8, 0, sorted2, start2, shb, rs); });
+      float t_rec = time_it(reps, [&] { hipLaunchKernelGGL(kern_rec, dim3(nsub), dim3(nt), cap * 8, 0, sorted2, starts, (u64)0, shb, rs); });
       unsigned long long got[2]; u32 nbad;
       checksum_words(rs.p, got, &nbad);
-      float t_split = time_it(reps, [&] { hipLaunchKernelGGL(kern_split, dim3(n2), dim3(nt), cap * 8, 0, sorted2, start2, shb, ss); });
+      float t_split = time_it(reps, [&] { hipLaunchKernelGGL(kern_split, dim3(nsub), dim3(nt), cap * 8, 0, sorted2, starts, (u64)0, shb, ss); });
       CK(hipMemset(acc, 0, 16)); CK(hipMemset(bad, 0, 4));
       hipLaunchKernelGGL(k_check_split, dim3(4096), dim3(256), 0, 0, sa, img, n, pbits, nbits, skew, acc, bad);
       unsigned long long got2[2]; u32 nbad2;
@@ -327,17 +406,11 @@ int main(int argc, char **argv) {
              t_rec, t_split, (nbad == 0 && got[0] == ref[0] && got[1] == ref[1]) ? "true" : "false",
              (nbad2 == 0 && got2[0] == ref[0] && got2[1] == ref[1]) ? "true" : "false", nbad, nbad2);
     };
-    if (rb >= 10) {
-      run_local("256x4096,bb12", k_msd_local<256, 4096, 12, MsdRecSink>, k_msd_local<256, 4096, 12, MsdSplitSink>, 4096, 12);
-      run_local("256x4096,bb11", k_msd_local<256, 4096, 11, MsdRecSink>, k_msd_local<256, 4096, 11, MsdSplitSink>, 4096, 11);
-      run_local("512x8192,bb12", k_msd_local<512, 8192, 12, MsdRecSink>, k_msd_local<512, 8192, 12, MsdSplitSink>, 8192, 12, 512);
-      run_local("512x8192,bb13", k_msd_local<512, 8192, 13, MsdRecSink>, k_msd_local<512, 8192, 13, MsdSplitSink>, 8192, 13, 512);
-      run_local("512x4096,bb12", k_msd_local<512, 4096, 12, MsdRecSink>, k_msd_local<512, 4096, 12, MsdSplitSink>, 4096, 12, 512);
-      run_local("256x2048,bb11", k_msd_local<256, 2048, 11, MsdRecSink>, k_msd_local<256, 2048, 11, MsdSplitSink>, 2048, 11);
-      run_local("256x2048,bb10", k_msd_local<256, 2048, 10, MsdRecSink>, k_msd_local<256, 2048, 10, MsdSplitSink>, 2048, 10);
-    }
-    CK(hipFree(cnt1)); CK(hipFree(bstart)); CK(hipFree(cur1)); CK(hipFree(tpre)); CK(hipFree(tpreh));
-    CK(hipFree(cnt2)); CK(hipFree(start2)); CK(hipFree(cur2));
+    run_local("256x2048,bb10 (product, small)", k_msd_local<256, 2048, 10, MsdRecSink>, k_msd_local<256, 2048, 10, MsdSplitSink>, 2048, 10, 256);
+    run_local("512x4096,bb12 (product, large)", k_msd_local<512, 4096, 12, MsdRecSink>, k_msd_local<512, 4096, 12, MsdSplitSink>, 4096, 12, 512);
+    run_local("256x4096,bb12", k_msd_local<256, 4096, 12, MsdRecSink>, k_msd_local<256, 4096, 12, MsdSplitSink>, 4096, 12, 256);
+    CK(hipFree(table)); CK(hipFree(cntg)); CK(hipFree(startg)); CK(hipFree(cur1)); CK(hipFree(bstart)); CK(hipFree(tpre)); CK(hipFree(tpreh));
+    CK(hipFree(plan)); CK(hipFree(segsum)); CK(hipFree(cnt2g)); CK(hipFree(cur2));
   }
   return 0;
 }
