@@ -196,6 +196,72 @@ __global__ __launch_bounds__(kMsdNW * 64) void k_msd_part(const u64 *__restrict_
   }
 }
 
+// Pass 1 that makes its words on the fly: tile t = the positions [t * kMsdTile, ...) of the text / level, their words
+// computed from the key maker (images4: 4 consecutive positions per thread and round, as the pack kernels do) instead of
+// being read — the pack kernel then only has to COUNT (k_pack_image_text<…, kStore = false>), and 8 bytes per position
+// are neither written nor read back.  Everything after the load is k_msd_part<false>.
+template <class KM>
+__global__ __launch_bounds__(kMsdNW * 64) void k_msd_part_keys(KM km, HiMap hm, u64 P1, u64 *__restrict__ out, u32 n, u64 base, u32 shift,
+                                                              u32 dbits, u32 cpx, u32 ntiles, const u32 *__restrict__ plan,
+                                                              u32 *__restrict__ cursors, u32 gstride) {
+  constexpr int NT = kMsdNW * 64;
+  static_assert(kMsdIPT == 8, "two rounds of 4 positions per thread");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u64 *srec = reinterpret_cast<u64 *>(smem);
+  u32 *hist = reinterpret_cast<u32 *>(smem + sizeof(u64) * kMsdTile);
+  u32 *gbase = hist + kMsdMaxDig;
+  u32 *tmp = gbase + kMsdMaxDig;
+  __shared__ uint16_t lcode[256];
+  const u32 tid = threadIdx.x;
+  const u32 ndig = 1u << dbits, mask = ndig - 1u;
+  const u32 g = blockIdx.x % kMsdGroups, idx = blockIdx.x / kMsdGroups;
+  const u32 tile = g * cpx + idx;
+  if (idx >= cpx || tile >= ntiles) return;
+  u32 *cur = cursors + (size_t)g * gstride;
+  const u32 begin = tile * (u32)kMsdTile, end = min(n, begin + (u32)kMsdTile);
+  const u32 nvalid = end - begin;
+  km.stage(lcode);
+  hist[tid] = 0;
+  __syncthreads();
+  u64 r[kMsdIPT];
+  u32 rk[kMsdIPT];
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const u32 p0 = begin + (u32)(k * NT + tid) * 4u;
+    u64 img[4] = {0, 0, 0, 0};
+    if (p0 < end) images4(km, hm, P1, p0, n, lcode, img);
+#pragma unroll
+    for (int j = 0; j < 4; j++) r[k * 4 + j] = (img[j] << hm.pbits) | (u64)(p0 + j);
+  }
+  // word k * 4 + j of thread tid is tile element t = (k * NT + tid) * 4 + j
+#pragma unroll
+  for (int k = 0; k < kMsdIPT; k++) {
+    const u32 t = (u32)((k >> 2) * NT + tid) * 4u + (k & 3);
+    if (t < nvalid) rk[k] = atomicAdd(&hist[(u32)((r[k] - base) >> shift) & mask], 1u);
+  }
+  __syncthreads();
+  u32 cnt = 0;
+  if (tid < ndig) {
+    cnt = hist[tid];
+    if (cnt) gbase[tid] = atomicAdd(&cur[tid], cnt);
+  }
+  u32 tot;
+  const u32 ex = block_excl_scan<kMsdNW>(cnt, tmp, tot);
+  hist[tid] = ex;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kMsdIPT; k++) {
+    const u32 t = (u32)((k >> 2) * NT + tid) * 4u + (k & 3);
+    if (t < nvalid) srec[hist[(u32)((r[k] - base) >> shift) & mask] + rk[k]] = r[k];
+  }
+  __syncthreads();
+  for (u32 q = tid; q < nvalid; q += NT) {
+    const u64 x = srec[q];
+    const u32 dd = (u32)((x - base) >> shift) & mask;
+    out[gbase[dd] + (q - hist[dd])] = msd_word(x);
+  }
+}
+
 // Sizes of the sub-buckets per group: block h counts the d2-digits of its piece (8 pass-2 tiles) of bucket b in LDS and
 // adds them to cnt2g[((b << d2) + digit) * 8 + g], g = the group that will work the tile in pass 2 (tile / cpx2).
 __global__ __launch_bounds__(1024) void k_msd_hist2(const u64 *__restrict__ in, u64 base, u32 shift, u32 dbits,

@@ -432,11 +432,62 @@ struct KeyT {
     return Rec8{(u32)(word >> 32), (u32)word};
   }
 };
+// Key images of the 4 consecutive text positions p0 .. p0+3 (p0 % 4 == 0; positions >= n read the zero padding):
+// the bodies of the whole-text pack kernels, shared with the partition pass that packs on the fly (k_msd_part_keys).
+// Key9: 12 aligned text bytes -> 12 codes -> 10 byte-triples shared by the 4 keys.
+__device__ __forceinline__ void images4(const Key9 &km, const HiMap &hm, u64, u32 p0, u32 n, const uint16_t *lcode, u64 img[4]) {
+  const u32 *tw = reinterpret_cast<const u32 *>(km.S.t + p0);
+  const u32 w[3] = {tw[0], tw[1], tw[2]};
+  u32 q[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) q[k] = (p0 + k < n) ? (u32)lcode[(w[k >> 2] >> (8 * (k & 3))) & 255u] : 0u;
+  u32 u[10];
+#pragma unroll
+  for (int k = 0; k < 10; k++) u[k] = (q[k] * km.B + q[k + 1]) * km.B + q[k + 2];
+#pragma unroll
+  for (int j = 0; j < 4; j++) img[j] = hyb_hi(make_rec(u[j], u[j + 3], u[j + 6], km.B3, 0u), hm);
+}
+// KeyT: J + 3 digits, the first image from scratch and the next three by rolling
+// (v' = (v - d_first * sigma^(J-1)) * sigma + d_next); P1 = sigma^(J-1).
+__device__ __forceinline__ void images4(const KeyT &km, const HiMap &hm, u64 P1, u32 p0, u32 n, const uint16_t *lcode, u64 img[4]) {
+  const u32 J = km.J, sigma = km.sigma, nw = (J + 3 + 3) / 4;
+  constexpr u32 kW = (kKeyTMaxImageSyms + 3 + 3) / 4;
+  const u32 *tw = reinterpret_cast<const u32 *>(km.S.t + p0);
+  u32 w[kW];
+#pragma unroll
+  for (u32 i = 0; i < kW; i++) w[i] = i < nw ? tw[i] : 0u;
+  u64 v = 0;
+  u32 dh[3] = {0, 0, 0}, dt0 = 0, dt1 = 0, dt2 = 0;
+#pragma unroll
+  for (u32 k = 0; k < kKeyTMaxImageSyms + 3; k++) {
+    if (k < J + 3) {
+      u32 q = (p0 + k < n) ? (u32)lcode[(w[k >> 2] >> (8 * (k & 3u))) & 255u] : 0u;
+      q = q ? q - 1 : 0u;
+      if (k < 3) dh[k] = q;
+      if (k < J) v = v * sigma + q;
+      else if (k == J) dt0 = q;
+      else if (k == J + 1) dt1 = q;
+      else dt2 = q;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    img[j] = __umul64hi(v, hm.mfix);
+    if (j < 3) v = (v - (u64)dh[j] * P1) * sigma + (j == 0 ? dt0 : j == 1 ? dt1 : dt2);
+  }
+}
+// any other key maker: position by position
+template <class KM>
+__device__ __forceinline__ void images4(const KM &km, const HiMap &hm, u64, u32 p0, u32 n, const uint16_t *lcode, u64 img[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; j++) img[j] = p0 + j < n ? km.image_hi(p0 + j, lcode, hm) : 0ull;
+}
 // whole text with KeyT, 4 consecutive positions per thread: J + 3 digits, the first image from scratch and the next
 // three by rolling (v' = (v - d_first * sigma^(J-1)) * sigma + d_next); same output, chunking and digit table as
 // k_pack_image_text.  P1 = sigma^(J-1).
 // kWide: 12-byte records {image, position} (k_pack_image12_all_hist's output) instead of (image << pbits) | position.
-template <int NB, bool kWide>
+// kStore = false: count only (the records are made on the fly by the partition pass that follows, k_msd_part_keys).
+template <int NB, bool kWide, bool kStore = true>
 __global__ __launch_bounds__(kBlock) void k_pack_image_textT(KeyT km, u32 n, HiMap hm, u64 P1, void *__restrict__ outv,
                                                             u32 chunk, u32 nchunks, u32 *__restrict__ table, u32 hshift = 0) {
   __shared__ uint16_t lcode[256];
@@ -447,35 +498,14 @@ __global__ __launch_bounds__(kBlock) void k_pack_image_textT(KeyT km, u32 n, HiM
     for (int j = threadIdx.x; j < NB; j += kBlock) hist[w][j] = 0;
   __syncthreads();
   u32 *myh = hist[wave_id()];
-  const u32 J = km.J, sigma = km.sigma, nw = (J + 3 + 3) / 4;
-  constexpr u32 kW = (kKeyTMaxImageSyms + 3 + 3) / 4;
   const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);       // chunk is a multiple of 4
   for (u32 p0 = begin + 4 * threadIdx.x; p0 < end; p0 += 4 * kBlock) {
-    const u32 *tw = reinterpret_cast<const u32 *>(km.S.t + p0);
-    u32 w[kW];
-#pragma unroll
-    for (u32 i = 0; i < kW; i++) w[i] = i < nw ? tw[i] : 0u;
-    u64 v = 0;
-    u32 dh[3] = {0, 0, 0}, dt0 = 0, dt1 = 0, dt2 = 0;
-#pragma unroll
-    for (u32 k = 0; k < kKeyTMaxImageSyms + 3; k++) {
-      if (k < J + 3) {
-        u32 q = (p0 + k < n) ? (u32)lcode[(w[k >> 2] >> (8 * (k & 3u))) & 255u] : 0u;
-        q = q ? q - 1 : 0u;
-        if (k < 3) dh[k] = q;
-        if (k < J) v = v * sigma + q;
-        else if (k == J) dt0 = q;
-        else if (k == J + 1) dt1 = q;
-        else dt2 = q;
-      }
-    }
     u64 img[4];
+    images4(km, hm, P1, p0, n, lcode, img);
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      img[j] = __umul64hi(v, hm.mfix);
+    for (int j = 0; j < 4; j++)
       if (p0 + j < end) atomicAdd(&myh[(u32)(img[j] >> hshift) & (NB - 1)], 1u);
-      if (j < 3) v = (v - (u64)dh[j] * P1) * sigma + (j == 0 ? dt0 : j == 1 ? dt1 : dt2);
-    }
+    if (!kStore) continue;
     if (kWide) {
       Rec12 *out = static_cast<Rec12 *>(outv);
       if (p0 + 3 < end) {                                    // 48 contiguous, 16-byte aligned bytes (p0 % 4 == 0)
@@ -516,7 +546,7 @@ __global__ __launch_bounds__(kBlock) void k_pack_image_textT(KeyT km, u32 n, HiM
 // whole text, 4 consecutive positions per thread: 12 aligned text bytes -> 12 codes -> 10 byte-triples shared by
 // the 4 keys; 32 contiguous output bytes per thread.  Blocks own the chunks of the radix sort that follows and
 // also produce its first digit table (the up-sweep of pass 1 never reads the records back): table[d*nchunks + b].
-template <int NB>
+template <int NB, bool kStore = true>
 __global__ __launch_bounds__(kBlock) void k_pack_image_text(Key9 km, u32 n, HiMap hm, Rec8 *__restrict__ out, u32 chunk,
                                                            u32 nchunks, u32 *__restrict__ table, u32 hshift = 0) {
   __shared__ uint16_t lcode[256];
@@ -529,20 +559,16 @@ __global__ __launch_bounds__(kBlock) void k_pack_image_text(Key9 km, u32 n, HiMa
   u32 *myh = hist[wave_id()];
   const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);       // chunk is a multiple of 4
   for (u32 p0 = begin + 4 * threadIdx.x; p0 < end; p0 += 4 * kBlock) {
-    const u32 *tw = reinterpret_cast<const u32 *>(km.S.t + p0);
-    const u32 w[3] = {tw[0], tw[1], tw[2]};
-    u32 q[12];
-#pragma unroll
-    for (int k = 0; k < 12; k++) q[k] = (p0 + k < n) ? (u32)lcode[(w[k >> 2] >> (8 * (k & 3))) & 255u] : 0u;
-    u32 u[10];
-#pragma unroll
-    for (int k = 0; k < 10; k++) u[k] = (q[k] * km.B + q[k + 1]) * km.B + q[k + 2];
+    u64 img[4];
+    images4(km, hm, 0ull, p0, n, lcode, img);
     Rec8 r[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      r[j] = hyb_rec(make_rec(u[j], u[j + 3], u[j + 6], km.B3, p0 + j), hm);
-      if (p0 + j < end) atomicAdd(&myh[(u32)(rec8_word(r[j]) >> (hm.pbits + hshift)) & (NB - 1)], 1u);
+      const u64 word = (img[j] << hm.pbits) | (p0 + j);
+      r[j] = Rec8{(u32)(word >> 32), (u32)word};
+      if (p0 + j < end) atomicAdd(&myh[(u32)(img[j] >> hshift) & (NB - 1)], 1u);
     }
+    if (!kStore) continue;
     if (p0 + 3 < end) {
       u32x4 *o = reinterpret_cast<u32x4 *>(out + p0);
       o[0] = u32x4{r[0].key, r[0].val, r[1].key, r[1].val};
@@ -569,7 +595,7 @@ __global__ __launch_bounds__(kBlock) void k_pack_image_pos(KM km, u32 nout, u32 
 }
 // Chunked variants that also produce the digit table of the first radix pass (table[d*nchunks + block]), so the
 // sort that follows starts with its down-sweep: all positions of a level, and the samples of a level.
-template <class KM, int NB>
+template <class KM, int NB, bool kStore = true>
 __global__ __launch_bounds__(kBlock) void k_pack_image_all_hist(KM km, u32 nrec, HiMap hm, Rec8 *__restrict__ out,
                                                                u32 chunk, u32 nchunks, u32 *__restrict__ table, u32 hshift = 0) {
   __shared__ uint16_t lcode[256];
@@ -583,7 +609,7 @@ __global__ __launch_bounds__(kBlock) void k_pack_image_all_hist(KM km, u32 nrec,
   const u32 begin = blockIdx.x * chunk, end = min(nrec, begin + chunk);
   for (u32 i = begin + threadIdx.x; i < end; i += kBlock) {
     const Rec8 r = km.image(i, lcode, hm);
-    out[i] = r;
+    if (kStore) out[i] = r;
     atomicAdd(&myh[(u32)(rec8_word(r) >> (hm.pbits + hshift)) & (NB - 1)], 1u);
   }
   __syncthreads();

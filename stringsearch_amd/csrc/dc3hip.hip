@@ -92,6 +92,7 @@ struct dc3hip_ctx {
   bool no_hybrid12 = false;    // DC3HIP_NO_HYBRID12=1: no 63-bit-prefix sort on 12-byte records for keys wider than 64 bits
   bool no_tup_scatter = false; // DC3HIP_NO_TUP_SCATTER=1: sample tuples always by the random gather
   bool no_xcd_map = false;     // DC3HIP_NO_XCD_MAP=1: window partitions without the segment -> XCD-group tile order (measurement aid)
+  bool no_pack_fuse = false;   // DC3HIP_NO_PACK_FUSE=1: the records of a bucket-ordered whole-text / whole-level order are written by the pack kernel
   bool no_msd = false;         // DC3HIP_NO_MSD=1: the prefix sorts always run the stable LSD passes (no bucket ordering)
   u32 msd_min = 1u << 20;      // DC3HIP_MSD_MIN: fewest records the bucket ordering is used for (tests lower it)
   bool no_tup8 = false;        // DC3HIP_NO_TUP8=1: the slot table of the merge tuples is always 16 bytes per sample
@@ -399,6 +400,27 @@ static MsdGeom msd_geometry(const dc3hip_ctx *c, u32 nrec, const HiMap &hm, u64 
   g.on = true;
   return g;
 }
+// Pass 1 of a sort whose words are made on the fly from a key maker (k_msd_part_keys) instead of being read from `ha`:
+// the pack kernel then only counted.  launch() = that kernel with the sort's geometry.
+struct MsdPass1 {
+  virtual ~MsdPass1() {}
+  virtual int launch(dc3hip_ctx *c, u64 *out, u32 n, u64 base, u32 sh1, const MsdGeom &g, u32 nb1, const u32 *plan, u32 *cur1) = 0;
+};
+template <class KM>
+struct MsdPass1Keys : MsdPass1 {
+  KM km; HiMap hm; u64 P1 = 0;
+  int launch(dc3hip_ctx *c, u64 *out, u32 n, u64 base, u32 sh1, const MsdGeom &g, u32 nb1, const u32 *plan, u32 *cur1) override {
+    static std::atomic<bool> attr_set[16];
+    if (!attr_set[c->device & 15]) {
+      HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_msd_part_keys<KM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
+      attr_set[c->device & 15] = true;
+    }
+    hipLaunchKernelGGL((k_msd_part_keys<KM>), dim3(kMsdGroups * g.cpx1), dim3(kMsdNW * 64), kMsdPartSmem, c->stream, km, hm, P1, out, n, base, sh1,
+                       g.d1, g.cpx1, g.ntiles1, plan, cur1, nb1);
+    KCHECK();
+    return E_OK;
+  }
+};
 // what a finished sort leaves behind so that its last pass can be repeated into records (cf. LastPass)
 struct MsdRedo { const u64 *src = nullptr; u64 *dst = nullptr; const u32 *start = nullptr; u32 nsub = 0, shb = 0; bool large = false; u64 base = 0; };
 template <class Sink>
@@ -420,8 +442,11 @@ static int msd_launch_local(dc3hip_ctx *c, const MsdRedo &r, u32 n, Sink sink) {
 // partition order) and the caller runs the LSD passes from there.  The small tables stay allocated in the arena until
 // the caller releases its mark (redo reads them).
 static int msd_sort(dc3hip_ctx *c, Rec8 *ha, Rec8 *hb, u32 n, const HiMap &hm, const MsdGeom &g, const u32 *table,
-                    const SplitSink *split, Rec8 **result, MsdRedo *redo, bool *ok, Rec8 **where) {
+                    const SplitSink *split, Rec8 **result, MsdRedo *redo, bool *ok, Rec8 **where, MsdPass1 *p1 = nullptr) {
+  // p1 != nullptr: the words do not exist yet — pass 1 makes them from the key maker (`ha` is then only the scratch of
+  // pass 2); needs `table` (the counting pack kernel's)
   *ok = false; *where = ha; *result = nullptr;
+  if (p1 && !table) { set_err("internal: on-the-fly pass 1 without a digit table"); return E_HIP; }
   static std::atomic<bool> attr_set[16];
   if (!attr_set[c->device & 15]) {
     HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_msd_part<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
@@ -456,9 +481,13 @@ static int msd_sort(dc3hip_ctx *c, Rec8 *ha, Rec8 *hb, u32 n, const HiMap &hm, c
   }
   {
     PhaseScope ps(c, DC3HIP_PH_SORT8_DOWN, n, 5);
-    hipLaunchKernelGGL((k_msd_part<false>), dim3(kMsdGroups * g.cpx1), dim3(kMsdNW * 64), kMsdPartSmem, c->stream, (const u64 *)wa, wb, n,
-                       base, sh1, g.d1, g.cpx1, g.ntiles1, (const u32 *)nullptr, (const u32 *)nullptr, nb1, (const u32 *)plan, cur1, nb1);
-    KCHECK();
+    if (p1) {
+      RC(p1->launch(c, wb, n, base, sh1, g, nb1, plan, cur1));
+    } else {
+      hipLaunchKernelGGL((k_msd_part<false>), dim3(kMsdGroups * g.cpx1), dim3(kMsdNW * 64), kMsdPartSmem, c->stream, (const u64 *)wa, wb, n,
+                         base, sh1, g.d1, g.cpx1, g.ntiles1, (const u32 *)nullptr, (const u32 *)nullptr, nb1, (const u32 *)plan, cur1, nb1);
+      KCHECK();
+    }
   }
   MsdRedo r;
   r.base = base;
@@ -860,7 +889,9 @@ template <class KM>
 static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Rec8 *ha, Rec8 *hb, u32 nrec,
                             Rec8 **h_out, uint8_t *f, bool *ok, int depth, u32 *emit_sa = nullptr, u32 skip = 0,
                             bool *emitted_distinct = nullptr, u32 *first_table = nullptr, bool whole_text = false,
-                            const MsdGeom *mg = nullptr, u64 img_lo = 0, u64 img_span = 0) {
+                            const MsdGeom *mg = nullptr, u64 img_lo = 0, u64 img_span = 0, MsdPass1 *p1 = nullptr) {
+  // p1 (only with mg->on): the records of `ha` were NOT written — the pack kernel only counted, pass 1 of the bucket
+  // ordering makes them on the fly
   // img_lo / img_span (only with mg == nullptr): the records hold the images of [img_lo, img_lo + img_span) only
   // mg (and mg->on): the records were packed for the bucket ordering — first_table is then the digit table of the TOP
   // image bits in mg's chunking, and the sort runs msd_sort(); should that give up, the LSD passes start from scratch.
@@ -885,7 +916,7 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
     MsdRedo mredo; bool msd_ok = false;
     if (mg && mg->on) {
       Rec8 *where = ha;
-      RC(msd_sort(c, ha, hb, nrec, hm, *mg, first_table, &sink, &h, &mredo, &msd_ok, &where));
+      RC(msd_sort(c, ha, hb, nrec, hm, *mg, first_table, &sink, &h, &mredo, &msd_ok, &where, p1));
       if (msd_ok) lp.src = const_cast<u64 *>(mredo.src);               // (non-null = "the order lives in the sink")
       else { if (where != ha) std::swap(ha, hb); first_table = nullptr; }
     }
@@ -948,7 +979,7 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
     bool msd_ok = false;
     if (mg && mg->on) {
       MsdRedo mredo; Rec8 *where = ha;
-      RC(msd_sort(c, ha, hb, nrec, hm, *mg, first_table, nullptr, &h, &mredo, &msd_ok, &where));
+      RC(msd_sort(c, ha, hb, nrec, hm, *mg, first_table, nullptr, &h, &mredo, &msd_ok, &where, p1));
       if (!msd_ok) { if (where != ha) std::swap(ha, hb); first_table = nullptr; }
     }
     if (!msd_ok)
@@ -1232,45 +1263,70 @@ static int order_hybrid(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u32
 // spos/snf (m02 entries each) must be allocated by the caller below this function's arena mark.
 // Packs the records of all positions; *first_table != nullptr on return when the kernel also produced the digit
 // table of the first radix pass (whole text: k_pack_image_text).
+// store = false (only with mg->on): count only — pass 1 of the bucket ordering makes the records on the fly (MsdPass1Keys).
 template <class KM>
 static int launch_pack_all(dc3hip_ctx *c, KM km, u32 nrec, const HiMap &hm, Rec8 *out, u32 **first_table,
-                           const MsdGeom *mg = nullptr) {
+                           const MsdGeom *mg = nullptr, bool store = true) {
   int nb = 0; Chunking ck; u32 hshift = 0;
   pack_plan(c, nrec, hm, mg, &nb, &ck, &hshift);
   u32 *table = nullptr;
   RC(arena_alloc(c, (size_t)nb * ck.nchunks, &table));
+  if (!store) {
+    hipLaunchKernelGGL((k_pack_image_all_hist<KM, 1024, false>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, km, nrec, hm, out, ck.chunk,
+                       ck.nchunks, table, hshift);
+    KCHECK();
+  } else {
 #define K_(NB) (k_pack_image_all_hist<KM, NB>)
-  DC3_PACK_LAUNCH(K_, km, nrec, hm, out, ck.chunk, ck.nchunks, table, hshift);
+    DC3_PACK_LAUNCH(K_, km, nrec, hm, out, ck.chunk, ck.nchunks, table, hshift);
 #undef K_
+  }
   *first_table = table;
   return E_OK;
 }
 template <>
-int launch_pack_all<Key9>(dc3hip_ctx *c, Key9 km, u32 nrec, const HiMap &hm, Rec8 *out, u32 **first_table, const MsdGeom *mg) {
+int launch_pack_all<Key9>(dc3hip_ctx *c, Key9 km, u32 nrec, const HiMap &hm, Rec8 *out, u32 **first_table, const MsdGeom *mg, bool store) {
   int nb = 0; Chunking ck; u32 hshift = 0;
   pack_plan(c, nrec, hm, mg, &nb, &ck, &hshift);
   u32 *table = nullptr;
   RC(arena_alloc(c, (size_t)nb * ck.nchunks, &table));
+  if (!store) {
+    hipLaunchKernelGGL((k_pack_image_text<1024, false>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, km, nrec, hm, out, ck.chunk, ck.nchunks,
+                       table, hshift);
+    KCHECK();
+  } else {
 #define K_(NB) (k_pack_image_text<NB>)
-  DC3_PACK_LAUNCH(K_, km, nrec, hm, out, ck.chunk, ck.nchunks, table, hshift);
+    DC3_PACK_LAUNCH(K_, km, nrec, hm, out, ck.chunk, ck.nchunks, table, hshift);
 #undef K_
+  }
   *first_table = table;
   return E_OK;
 }
-template <>
-int launch_pack_all<KeyT>(dc3hip_ctx *c, KeyT km, u32 nrec, const HiMap &hm, Rec8 *out, u32 **first_table, const MsdGeom *mg) {
-  int nb = 0; Chunking ck; u32 hshift = 0;
-  pack_plan(c, nrec, hm, mg, &nb, &ck, &hshift);
-  u32 *table = nullptr;
-  RC(arena_alloc(c, (size_t)nb * ck.nchunks, &table));
+static u64 keyt_p1(const KeyT &km) {
   u64 P1 = 1;
   for (u32 i = 0; i + 1 < km.J; i++) P1 *= km.sigma;
+  return P1;
+}
+template <>
+int launch_pack_all<KeyT>(dc3hip_ctx *c, KeyT km, u32 nrec, const HiMap &hm, Rec8 *out, u32 **first_table, const MsdGeom *mg, bool store) {
+  int nb = 0; Chunking ck; u32 hshift = 0;
+  pack_plan(c, nrec, hm, mg, &nb, &ck, &hshift);
+  u32 *table = nullptr;
+  RC(arena_alloc(c, (size_t)nb * ck.nchunks, &table));
+  const u64 P1 = keyt_p1(km);
+  if (!store) {
+    hipLaunchKernelGGL((k_pack_image_textT<1024, false, false>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, km, nrec, hm, P1, (void *)out,
+                       ck.chunk, ck.nchunks, table, hshift);
+    KCHECK();
+  } else {
 #define K_(NB) (k_pack_image_textT<NB, false>)
-  DC3_PACK_LAUNCH(K_, km, nrec, hm, P1, (void *)out, ck.chunk, ck.nchunks, table, hshift);
+    DC3_PACK_LAUNCH(K_, km, nrec, hm, P1, (void *)out, ck.chunk, ck.nchunks, table, hshift);
 #undef K_
+  }
   *first_table = table;
   return E_OK;
 }
+template <class KM> static u64 pass1_p1(const KM &) { return 0; }
+template <> u64 pass1_p1<KeyT>(const KeyT &km) { return keyt_p1(km); }
 // The records of all m (+dummy) positions are in key order behind accessor `acc` (pos, neq): all keys distinct -> the
 // order is the suffix array (*state = 1; out_sa / out_rank written); else, with spos/snf given, the samples are
 // filtered out with their full names (*state = 2); else *state stays 0.
@@ -1436,13 +1492,20 @@ static int order_all_positions(dc3hip_ctx *c, KM km, Map mp, u32 m, u32 kbits, c
   RC(arena_alloc(c, (size_t)nrec + 16, &f));
   u32 *first_table = nullptr;
   const MsdGeom mg = msd_geometry(c, nrec, hm);
+  // bucket ordering: the pack kernel only counts, partition pass 1 makes the records on the fly (8 bytes per position
+  // neither written nor read back)
+  // (measured at 1 GiB: bytes, Key9: pack 3.3 -> 1.8 ms counting only, pass 1 3.7 -> 4.2 ms, build 20.4 -> 19.4 ms; DNA,
+  //  KeyT: the rolling image inside the partition pass makes it VALU-bound, 22.8 -> 27.9 ms — so only for Key9)
+  const bool fuse = mg.on && !c->no_pack_fuse && std::is_same<KM, Key9>::value;
+  MsdPass1Keys<KM> p1; p1.km = km; p1.hm = hm; p1.P1 = pass1_p1<KM>(km);
   {
     PhaseScope ps(c, DC3HIP_PH_PACK, nrec);
-    RC(launch_pack_all<KM>(c, km, nrec, hm, ha, &first_table, &mg));
+    RC(launch_pack_all<KM>(c, km, nrec, hm, ha, &first_table, &mg, !fuse));
   }
   bool sorted_ok = false, distinct = false;
   RC((hybrid_sort_core<KM>(c, km, kbits, hm, ha, hb, nrec, &h, f, &sorted_ok, depth, out_rank ? nullptr : out_sa, dummy,
-                           &distinct, first_table, std::is_same<Map, MapText>::value && dummy == 0 && !out_rank, &mg)));
+                           &distinct, first_table, std::is_same<Map, MapText>::value && dummy == 0 && !out_rank, &mg, 0, 0,
+                           fuse ? &p1 : nullptr)));
   if (sorted_ok && distinct) {
     *state = 1;                            // the tie pass already wrote the suffix array
   } else if (sorted_ok) {
@@ -2126,6 +2189,7 @@ int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) {
   { const char *e = getenv("DC3HIP_TEXT_ORDER12"); if (e && (e[0] == '0' || e[0] == '1')) c->text_order12 = e[0] - '0'; }
   { const char *e = getenv("DC3HIP_NO_TUP8"); c->no_tup8 = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_MSD"); c->no_msd = (e && e[0] == '1'); }
+  { const char *e = getenv("DC3HIP_NO_PACK_FUSE"); c->no_pack_fuse = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_XCD_MAP"); c->no_xcd_map = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_TUP_SCATTER"); c->no_tup_scatter = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_MSD_MIN"); if (e) c->msd_min = (u32)std::max(4096ll, atoll(e)); }
