@@ -197,12 +197,23 @@ def main():
     # ---- N > 1: the library's own transport first — created strictly (no silent fallback) and self-tested
     G = None
     selftest = None
+    global_unavailable = None
     do_global = world > 1 and args.mode in ("auto", "global")
     do_sacapart = world == 1 or args.mode in ("auto", "sacapart")
     if do_global:
         from stringsearch_amd.bench_global import make_rank, global_total
         gtotal, gwide, gclipped = global_total(per_gpu * world, kind)
-        G = make_rank(ss, dist, backend, world, rank, local_rank, gtotal)          # exits non-zero if RCCL cannot be had
+        try:
+            G = make_rank(ss, dist, backend, world, rank, local_rank, gtotal)      # raises on every rank if RCCL cannot be had
+        except RuntimeError as e:
+            # no transport, no global number: the sacapart leg alone, and the line says why (never a host-staged number
+            # under an xGMI label)
+            G = None
+            global_unavailable = str(e)
+            if args.mode == "global":
+                os._exit(4)
+            do_global = False
+    if do_global:
         try:
             seen = G.selftest()
         except Exception as e:
@@ -447,6 +458,9 @@ def main():
                 out["global_mode_beyond_2pow32"] = {"skipped": str(e)}
     if world > 1:
         sac = out                                   # rank 0: the sacapart leg's line; others: None
+        if rank == 0 and args.mode == "auto" and not do_global:
+            out["global_mode"] = {"error": global_unavailable}
+            out["value_mode"] = "sacapart (no global leg: see global_mode.error)"
         if do_global:
             # ---- the global leg (defines `value` of an N > 1 line).  A failure or a hang of this leg must not cost the
             # run its line: after --global-timeout seconds, or on an exception, rank 0 prints the sacapart leg alone and

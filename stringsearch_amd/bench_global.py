@@ -24,8 +24,9 @@ def make_rank(ss, dist, backend, world, rank, local_rank, max_total):
     """This process's rank of the group: RCCL (backend nccl: one rank per GPU) or the host-staged transport over the gloo
     group (DC3HIP_BENCH_BACKEND=gloo: several ranks on one GPU — the plumbing test on 1-GPU boxes, which says so in
     `interconnect.transport`).  With backend nccl there is NO fallback: if the library's RCCL communicator cannot be
-    created on every rank the run exits non-zero (unless DC3HIP_BENCH_ALLOW_HOST_FALLBACK=1 explicitly asks for the
-    host-staged transport, and then the line names it)."""
+    created on every rank, every rank raises (bench.py then reports the sacapart leg alone and says why there is no
+    global number) — unless DC3HIP_BENCH_ALLOW_HOST_FALLBACK=1 explicitly asks for the host-staged transport, and then
+    the line names it."""
     import sys
     if backend == "nccl":
         import torch
@@ -48,9 +49,10 @@ def make_rank(ss, dist, backend, world, rank, local_rank, max_total):
         if g is not None:
             g.close()
         if os.environ.get("DC3HIP_BENCH_ALLOW_HOST_FALLBACK") != "1":
-            print(f"bench_global: rank {rank}: the library's RCCL communicator could not be created ({err or 'on another rank'}); "
-                  "not falling back to a host-staged transport (DC3HIP_BENCH_ALLOW_HOST_FALLBACK=1 would)", file=sys.stderr, flush=True)
-            os._exit(4)
+            msg = (f"the library's RCCL communicator could not be created ({err or 'on another rank'}); not falling back to a "
+                   "host-staged transport (DC3HIP_BENCH_ALLOW_HOST_FALLBACK=1 would)")
+            print(f"bench_global: rank {rank}: {msg}", file=sys.stderr, flush=True)
+            raise RuntimeError(msg)          # (every rank raises: the decision was all-reduced)
         if rank == 0:
             print(f"bench_global: RCCL transport unavailable ({err or 'on another rank'}); DC3HIP_BENCH_ALLOW_HOST_FALLBACK=1: "
                   "using the host-staged transport over gloo", flush=True)

@@ -283,6 +283,15 @@ int main(int argc, char **argv) {
     lsd("512x8x16, tile chunks, swz", LSD(512, 8, 16, false), 0, true);
     lsd("256x12x16, tile chunks, swz", LSD(256, 12, 16, false), 0, true);
     lsd("256x16x8, tile chunks, swz", LSD(256, 16, 8, false), 0, true);
+#define LSDA(NB, IPT, NW, PF) k_rs_downsweep<Rec8, NB, IPT, NW, PF, ArrayLoader<Rec8>, RecSink<Rec8>, true>, DownsweepSmem<Rec8, IPT, NW, NB>::kBytes, NB, NW * 64 * IPT, NW
+    lsd("atomic rank 512x12x16 pf", LSDA(512, 12, 16, true), 2048, false);
+    lsd("atomic rank 512x12x8 (2 blocks/CU)", LSDA(512, 12, 8, false), 4096, false);
+    lsd("atomic rank 512x12x8 pf (2 blocks/CU)", LSDA(512, 12, 8, true), 4096, false);
+    lsd("atomic rank 512x16x8 (2 blocks/CU)", LSDA(512, 16, 8, false), 4096, false);
+    lsd("atomic rank 512x8x8 (3 blocks/CU)", LSDA(512, 8, 8, false), 8192, false);
+    lsd("atomic rank 512x5x16 (2 blocks/CU)", LSDA(512, 5, 16, false), 4096, false);
+    lsd("ballots 512x12x8 (2 blocks/CU)", LSD(512, 12, 8, false), 4096, false);
+    lsd("ballots 512x12x8 pf (2 blocks/CU)", LSD(512, 12, 8, true), 4096, false);
   }
 
   // ---- pass-1 experiments: digit width, tile size, grouped cursors, non-temporal accesses
