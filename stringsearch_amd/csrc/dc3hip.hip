@@ -85,14 +85,14 @@ struct dc3hip_ctx {
   bool no_long_keys = false;   // DC3HIP_NO_LONG_KEYS=1: the whole-text shortcut only with 9-symbol windows (no KeyT)
   bool no_doubling = false;    // DC3HIP_NO_DOUBLING=1: repeated windows always hand the whole-text order to level 1
   int text_order12 = -1;       // DC3HIP_TEXT_ORDER12=1/0: whole-text shortcut on 12-byte records always / never (default: n > 2^31)
-  double hybrid_max_pred = 0.50;                      // DC3HIP_HYBRID_MAX_PRED (tuning): 8-byte prefix sort of a level's samples below this predicted tied fraction
+  double hybrid_max_pred = 0.50;                      // 8-byte prefix sort of a level's samples: taken below this predicted tied fraction
   double hybrid12_max_pred = kHybrid12MaxPredicted;   // DC3HIP_HYBRID12_MAX_PRED (tuning)
   u32 hybrid12_min = 1u << 22; // DC3HIP_HYBRID12_MIN: smallest level (samples) that tries it (tests lower it)
   bool no_hybrid8 = false;     // DC3HIP_NO_HYBRID8=1 (tests): skip the 8-byte prefix sort / whole-level order of a level
   bool no_hybrid12 = false;    // DC3HIP_NO_HYBRID12=1: no 63-bit-prefix sort on 12-byte records for keys wider than 64 bits
   bool no_tup_scatter = false; // DC3HIP_NO_TUP_SCATTER=1: sample tuples always by the random gather
   bool no_xcd_map = false;     // DC3HIP_NO_XCD_MAP=1: window partitions without the segment -> XCD-group tile order (measurement aid)
-  bool no_pack_fuse = false;   // DC3HIP_NO_PACK_FUSE=1: the records of a bucket-ordered whole-text / whole-level order are written by the pack kernel
+  bool pack_fuse = false;      // DC3HIP_PACK_FUSE=1: whole-text order of bytes: the pack kernel only counts, partition pass 1 makes the records on the fly
   bool no_msd = false;         // DC3HIP_NO_MSD=1: the prefix sorts always run the stable LSD passes (no bucket ordering)
   u32 msd_min = 1u << 20;      // DC3HIP_MSD_MIN: fewest records the bucket ordering is used for (tests lower it)
   bool no_tup8 = false;        // DC3HIP_NO_TUP8=1: the slot table of the merge tuples is always 16 bytes per sample
@@ -770,7 +770,7 @@ static int discard_recurse(dc3hip_ctx *c, const u32 *RU, const u32 *sslot, u32 m
 //     out above kHybridMaxMeasured.  Correctness never depends on the policy.
 // ---------------------------------------------------------------------------------------------
 static constexpr u32 kHybridMinSamples = 1u << 22;
-// (kHybridMaxPredicted = dc3hip_ctx::hybrid_max_pred, 0.50 unless DC3HIP_HYBRID_MAX_PRED says otherwise)
+// (kHybridMaxPredicted = dc3hip_ctx::hybrid_max_pred = 0.50)
 static constexpr double kHybridMaxMeasured = 0.60;
 static constexpr double kFullSortMaxPredicted = 0.10;   // whole-level shortcut only for very few predicted ties
 static constexpr double kTextSortMaxPredicted = 0.30;   // whole-text shortcut (33-bit images at 2^30 bytes tie ~12 %)
@@ -1494,9 +1494,11 @@ static int order_all_positions(dc3hip_ctx *c, KM km, Map mp, u32 m, u32 kbits, c
   const MsdGeom mg = msd_geometry(c, nrec, hm);
   // bucket ordering: the pack kernel only counts, partition pass 1 makes the records on the fly (8 bytes per position
   // neither written nor read back)
-  // (measured at 1 GiB: bytes, Key9: pack 3.3 -> 1.8 ms counting only, pass 1 3.7 -> 4.2 ms, build 20.4 -> 19.4 ms; DNA,
-  //  KeyT: the rolling image inside the partition pass makes it VALU-bound, 22.8 -> 27.9 ms — so only for Key9)
-  const bool fuse = mg.on && !c->no_pack_fuse && std::is_same<KM, Key9>::value;
+  // — opt-in (DC3HIP_PACK_FUSE=1), Key9 only.  Measured at 1 GiB: bytes: pack 3.3 -> 1.7 ms counting only, pass 1
+  // 3.7 -> 4.4 ms (it becomes VALU-bound: 9 bytes moved per word instead of 16, but the key arithmetic on top of the
+  // ranking), build 20.4 -> 19.5 ms; DNA (KeyT): the rolling image inside the partition pass costs more than the bytes
+  // save, 22.8 -> 27.9 ms.  A 5 % gain on one input class against a second variant of the dominant kernel: off by default.
+  const bool fuse = mg.on && c->pack_fuse && std::is_same<KM, Key9>::value;
   MsdPass1Keys<KM> p1; p1.km = km; p1.hm = hm; p1.P1 = pass1_p1<KM>(km);
   {
     PhaseScope ps(c, DC3HIP_PH_PACK, nrec);
@@ -2189,7 +2191,7 @@ int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) {
   { const char *e = getenv("DC3HIP_TEXT_ORDER12"); if (e && (e[0] == '0' || e[0] == '1')) c->text_order12 = e[0] - '0'; }
   { const char *e = getenv("DC3HIP_NO_TUP8"); c->no_tup8 = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_MSD"); c->no_msd = (e && e[0] == '1'); }
-  { const char *e = getenv("DC3HIP_NO_PACK_FUSE"); c->no_pack_fuse = (e && e[0] == '1'); }
+  { const char *e = getenv("DC3HIP_PACK_FUSE"); c->pack_fuse = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_XCD_MAP"); c->no_xcd_map = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_TUP_SCATTER"); c->no_tup_scatter = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_MSD_MIN"); if (e) c->msd_min = (u32)std::max(4096ll, atoll(e)); }
@@ -2197,7 +2199,6 @@ int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) {
   { const char *e = getenv("DC3HIP_NO_HYBRID8"); c->no_hybrid8 = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_HYBRID12_MIN"); if (e) c->hybrid12_min = (u32)std::max(0ll, atoll(e)); }
   { const char *e = getenv("DC3HIP_HYBRID12_MAX_PRED"); if (e) c->hybrid12_max_pred = atof(e); }
-  { const char *e = getenv("DC3HIP_HYBRID_MAX_PRED"); if (e) c->hybrid_max_pred = atof(e); }
   const char *nts = getenv("DC3HIP_NO_TEXT_SHORTCUT");
   c->no_text_shortcut = (nts && nts[0] == '1');
   const char *nf = getenv("DC3HIP_NO_FULLSORT");
