@@ -297,6 +297,7 @@ struct HostComm : GComm {
 // one rank of a global build
 // ---------------------------------------------------------------------------------------------
 struct dc3hip_gctx {
+  int wide_route_min_p = 6;    // wide mode: fewest ranks for which the selection is routed (see gbuild_wide)
   u32 w_depth = 0;             // wide mode: symbols the last tie pass of the last build compared (the verifier compares at least as deep)
   bool route = true;           // DC3HIP_GLOBAL_NO_ROUTE=1: every rank evaluates all positions and keeps its key range (the round-2 form)
   dc3hip_ctx *c = nullptr;
@@ -311,7 +312,10 @@ struct dc3hip_gctx {
   // wide mode (texts beyond DC3HIP_MAX_N, or DC3HIP_GLOBAL_FORCE_WIDE=1): 64-bit positions, whole-text order only
   bool wide = false;
   uint8_t *w_text = nullptr;                    // max_total + 64 bytes (the context's own text buffer is not used)
-  Rec16 *w_ra = nullptr, *w_rb = nullptr; u64 *w_shard = nullptr; size_t w_cap = 0;   // records of this rank's image range
+  // wide mode: records of this rank's image range (w_ra / w_rb: pack / partition / sort buffers) and its shard of 64-bit
+  // positions; every array with its own capacity (records / words)
+  Rec16 *w_ra = nullptr, *w_rb = nullptr; u64 *w_shard = nullptr;
+  size_t w_cap_a = 0, w_cap_b = 0, w_cap_s = 0;
   dc3hip_gstats gs;
   char err[512] = "";
   std::vector<dc3hip_gctx *> group;             // loopback: all ranks of the group (rank 0 owns the list)
@@ -1178,6 +1182,52 @@ static int wide_key(dc3hip_gctx *G, u32 sigma, WideKey *k, u32 *ibits_out) {
   return E_OK;
 }
 
+// grow one of the wide mode's arrays to at least `need` elements (never while it holds live data)
+template <class T>
+static int wide_ensure(dc3hip_ctx *c, T **p, size_t *cap, size_t need) {
+  if (need <= *cap) return E_OK;
+  HIPC(hipStreamSynchronize(c->stream));
+  if (*p) (void)hipFree(*p);
+  *p = nullptr; *cap = 0;
+  const size_t want = need + need / 16 + 1024;
+  if (hipMalloc(p, want * sizeof(T)) != hipSuccess) {
+    (void)hipGetLastError();
+    set_err("wide global mode: no device memory for %zu elements of %zu bytes", want, sizeof(T));
+    return E_ALLOC;
+  }
+  *cap = want;
+  return E_OK;
+}
+// The tie rounds of a wide build over the sorted records h[0..nrec): positions to G->w_shard, statistics in
+// c->h_words[10..12] (oversized group, tied records, windows that still agree after the last round).
+static int wide_tie_rounds(dc3hip_gctx *G, const Rec16 *h, u32 nrec, WideKey k) {
+  dc3hip_ctx *c = G->c;
+    // tie pass; while a few windows still agree completely it is repeated with a deeper compare: kWideWindow symbols, then
+    // kWideWindowDeep, then 16 times deeper per round for as long as (windows that still agree) x (next depth) stays inside
+    // a work budget — the compare is lazy, so the depth only costs where windows really agree that far.  This settles
+    // repeats of any length a few of which exist (two copies of a 100 kB block: 10^5 tied pairs x 10^5 symbols); what
+    // the budget does not cover is refused (there is no recursion with 64-bit positions).
+    u32 depth = kWideWindow;
+    for (int round = 0;; round++) {
+      k.W = depth;
+      G->w_depth = depth;
+      HIPC(hipMemsetAsync(c->d_words + 10, 0, 3 * sizeof(u32), c->stream));
+      if (nrec) {
+        PhaseScope ps(c, DC3HIP_PH_TIES, nrec);
+        hipLaunchKernelGGL(k_wide_ties, dim3(grid_for(c, nrec)), dim3(kBlock), 0, c->stream, h, nrec, k, G->w_shard, c->d_words + 10);
+        KCHECK();
+      }
+      HIPC(hipMemcpyAsync(c->h_words + 10, c->d_words + 10, 3 * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+      HIPC(hipStreamSynchronize(c->stream));
+      if (c->h_words[10] != 0 || c->h_words[12] == 0) break;
+      if (round == 0) { if (c->h_words[12] > (1u << 20)) break; depth = kWideWindowDeep; continue; }
+      const u64 next = (u64)depth * 16;
+      if (next > kWideMaxDepth || (u64)c->h_words[12] * next > kWideTieBudget) break;
+      depth = (u32)next;
+    }
+    return E_OK;
+}
+
 static int gbuild_wide(dc3hip_gctx *G) {
   dc3hip_ctx *c = G->c; GComm *cm = G->comm;
   const int P = cm->nranks, me = cm->rank;
@@ -1211,6 +1261,7 @@ static int gbuild_wide(dc3hip_gctx *G) {
   const ArenaMark mk = arena_mark(c);
   // splitters from a strided sample (every rank computes the same ones from the replicated text)
   u64 lo = 0, hi = ~0ull;
+  std::vector<u64> img;
   {
     const u32 ns = (u32)std::min<u64>(n, (u64)4096 * P);
     const u64 stride = std::max<u64>(1, n / ns);
@@ -1219,7 +1270,7 @@ static int gbuild_wide(dc3hip_gctx *G) {
     RC(arena_alloc(c, (size_t)cnt, &d_img));
     hipLaunchKernelGGL(k_wide_sample, dim3(grid_for(c, cnt)), dim3(kBlock), 0, c->stream, k, stride, cnt, d_img);
     KCHECK();
-    std::vector<u64> img(cnt);
+    img.resize(cnt);
     HIPC(hipMemcpyAsync(img.data(), d_img, (size_t)cnt * 8, hipMemcpyDeviceToHost, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
     std::sort(img.begin(), img.end());
@@ -1231,7 +1282,106 @@ static int gbuild_wide(dc3hip_gctx *G) {
   // collectives below: the status is agreed on there and every rank returns the same error.
   u32 nrec = 0;
   c->h_words[10] = c->h_words[11] = c->h_words[12] = 0;
+  // agreement on a refusal (see above): 0, or the code every rank returns
+  auto agree = [&](int rc_local) -> int {
+    uint64_t refp = 0, refused = 0;
+    char local_err[sizeof(g_err)];
+    snprintf(local_err, sizeof(local_err), "%s", g_err);
+    RC(gather_counts(cm, rc_local == E_TOOBIG ? 1u : rc_local == E_ALLOC ? (1u << 20) : 0u, &refp, &refused));
+    if (!refused) return E_OK;
+    const int rc_all = (refused >> 20) ? E_ALLOC : E_TOOBIG;
+    if (rc_local != E_OK) set_err("%s", local_err);
+    else set_err("wide global mode: another rank refused its share (%s)", rc_all == E_ALLOC ? "no device memory for its records" : "more ranks needed");
+    return rc_all;
+  };
+  // ROUTED selection (round 3, the wide counterpart of gorder_positions' routing): every rank packs the records of ITS
+  // block of positions only, partitions them by the top 8 image bits (rank h owns a contiguous digit range, balanced on the
+  // replicated sample) and sends every record to its owner — one all-to-all of 16-byte records, O(n / P) work per rank
+  // instead of two evaluations of all n positions.  Applicable when a block fits 32-bit record counts.
+  bool have_records = false;
+  // From 6 ranks on (DC3HIP_GLOBAL_WIDE_ROUTE_MIN_P): packing + partitioning + exchanging 16-byte records is a constant
+  // ≈ 100 ms of total work per 4.3 GB, two evaluations of all positions on every rank cost ≈ 19 ms per rank — measured as
+  // total work of P loopback ranks on one GPU: P = 2: 386 routed / 329 not, P = 4: 377 / 348, P = 8: 385 / 425 ms.
+  if (G->route && P >= G->wide_route_min_p && ibits >= 8 && n / (u64)P + 16 <= (u64)DC3HIP_MAX_N) {
+    u32 dlo[kMaxRanks + 1];
+    {
+      u32 cnt256[257] = {0};
+      for (u64 v : img) cnt256[(u32)((v >> (ibits - 8)) & 255u)]++;
+      const u64 ns = img.size();
+      dlo[0] = 0; dlo[P] = 256;
+      u64 acc = 0; u32 hnext = 1;
+      for (u32 d = 0; d < 256 && hnext < (u32)P; d++) {
+        while (hnext < (u32)P && acc * P >= (u64)hnext * ns) dlo[hnext++] = d;
+        acc += cnt256[d];
+      }
+      while (hnext < (u32)P) dlo[hnext++] = 256;
+      for (int r = 1; r <= P; r++) dlo[r] = std::max(dlo[r], dlo[r - 1]);
+    }
+    const u64 bbeg = (n * (u64)me / P) & ~3ull, bend = (me + 1 == P) ? n : ((n * (u64)(me + 1) / P) & ~3ull);
+    const u32 blen = (u32)(bend - bbeg);
+    u32 hdb[257];
+    for (u32 d = 0; d <= 256; d++) hdb[d] = 0;
+    const int rcA = [&]() -> int {
+      RC(wide_ensure(c, &G->w_ra, &G->w_cap_a, (size_t)blen + 16));
+      RC(wide_ensure(c, &G->w_rb, &G->w_cap_b, (size_t)blen + 16));
+      if (!blen) return E_OK;
+      {
+        PhaseScope ps(c, DC3HIP_PH_PACK, blen);
+        hipLaunchKernelGGL(k_wide_pack_range, dim3(grid_for(c, (u64)blen / 4 + 1)), dim3(kBlock), 0, c->stream, k, bbeg, blen, G->w_ra);
+        KCHECK();
+      }
+      constexpr int kTile = SortCfg<Rec16, 256>::NW * 64 * SortCfg<Rec16, 256>::IPT;
+      const Chunking ck = make_chunks(c, blen, kTile);
+      u32 *table = nullptr, *digit_base = nullptr;
+      RC(arena_alloc(c, (size_t)256 * ck.nchunks, &table));
+      RC(arena_alloc(c, (size_t)256, &digit_base));
+      KeyDig dig; dig.shift = ibits - 8; dig.mask = 255;
+      {
+        PhaseScope ps(c, DC3HIP_PH_PACK, blen);
+        hipLaunchKernelGGL((k_rs_upsweep<Rec16, 256>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, (const Rec16 *)G->w_ra, blen, ck.chunk, ck.nchunks, dig, table);
+        KCHECK();
+      }
+      RC(scan_digit_table(c, table, ck.nchunks, digit_base, 256, DC3HIP_PH_PACK));
+      std::vector<u32> tmp(256);
+      HIPC(hipMemcpyAsync(tmp.data(), digit_base, 256 * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+      ArrayLoader<Rec16> ld; ld.p = G->w_ra;
+      RC((launch_downsweep<Rec16, 256, ArrayLoader<Rec16>>(c, ld, G->w_rb, blen, ck, dig, table, digit_base, DC3HIP_PH_PACK)));
+      HIPC(hipStreamSynchronize(c->stream));
+      for (u32 d = 0; d < 256; d++) hdb[d] = tmp[d];
+      hdb[256] = blen;
+      return E_OK;
+    }();
+    if (rcA != E_OK && rcA != E_TOOBIG && rcA != E_ALLOC) return rcA;
+    RC(agree(rcA));
+    size_t soff[kMaxRanks], sbytes[kMaxRanks], roff[kMaxRanks], rbytes[kMaxRanks];
+    uint64_t scount[kMaxRanks], mat[kMaxRanks * kMaxRanks];
+    for (int r = 0; r < P; r++) {
+      const u32 a0 = hdb[dlo[r]], b0 = hdb[dlo[r + 1]];
+      soff[r] = (size_t)a0 * sizeof(Rec16); sbytes[r] = (size_t)(b0 - a0) * sizeof(Rec16); scount[r] = b0 - a0;
+    }
+    RC(cm->all_gather_host(scount, mat, sizeof(uint64_t) * (size_t)P));
+    u64 got = 0;
+    for (int r = 0; r < P; r++) { roff[r] = (size_t)got * sizeof(Rec16); rbytes[r] = (size_t)mat[(size_t)r * P + me] * sizeof(Rec16); got += mat[(size_t)r * P + me]; }
+    const int rcB = [&]() -> int {
+      if (got > (u64)DC3HIP_MAX_N) { set_err("wide global mode: rank %d would hold %llu suffixes (more ranks needed)", me, (unsigned long long)got); return E_TOOBIG; }
+      RC(wide_ensure(c, &G->w_ra, &G->w_cap_a, (size_t)got + 16));     // (its packed records are dead: they went to w_rb)
+      RC(wide_ensure(c, &G->w_shard, &G->w_cap_s, (size_t)got + 16));
+      return E_OK;
+    }();
+    if (rcB != E_OK && rcB != E_TOOBIG && rcB != E_ALLOC) return rcB;
+    RC(agree(rcB));
+    RC(cm->all_to_all_v(G->w_rb, soff, sbytes, G->w_ra, roff, rbytes, c->stream));   // (the packed records of w_ra are dead)
+    G->gs.exchanges += 1;
+    nrec = (u32)got;
+    have_records = true;
+  }
   const int local_rc = [&]() -> int {
+    if (have_records) {
+      RC(wide_ensure(c, &G->w_rb, &G->w_cap_b, (size_t)nrec + 16));    // (what it sent is gone: now the sort's second buffer)
+      Rec16 *h = G->w_ra;
+      if (nrec) RC(radix_sort<Rec16>(c, G->w_ra, G->w_rb, nrec, 0, ibits, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT12_DOWN));
+      return wide_tie_rounds(G, h, nrec, k);
+    }
     // count, allocate, write
     const u64 chunk = (u64)1 << 20;
     const u64 nblocks64 = (n + chunk - 1) / chunk;
@@ -1255,20 +1405,9 @@ static int gbuild_wide(dc3hip_gctx *G) {
     if (nrec64 > (u64)DC3HIP_MAX_N) { set_err("wide global mode: rank %d would hold %llu suffixes (more ranks needed)", me, (unsigned long long)nrec64); return E_TOOBIG; }
     nrec = (u32)nrec64;
     HIPC(hipMemcpyAsync(counts, hc.data(), (size_t)nblocks * 4, hipMemcpyHostToDevice, c->stream));
-    if ((size_t)nrec + 16 > G->w_cap) {
-      HIPC(hipStreamSynchronize(c->stream));
-      if (G->w_ra) (void)hipFree(G->w_ra);
-      if (G->w_rb) (void)hipFree(G->w_rb);
-      if (G->w_shard) (void)hipFree(G->w_shard);
-      G->w_ra = G->w_rb = nullptr; G->w_shard = nullptr; G->w_cap = 0;
-      const size_t cap = (size_t)nrec + (size_t)nrec / 16 + 1024;
-      if (hipMalloc(&G->w_ra, cap * sizeof(Rec16)) != hipSuccess || hipMalloc(&G->w_rb, cap * sizeof(Rec16)) != hipSuccess ||
-          hipMalloc(&G->w_shard, cap * sizeof(u64)) != hipSuccess) {
-        (void)hipGetLastError();
-        set_err("wide global mode: no device memory for %llu records of 40 bytes", (unsigned long long)cap); return E_ALLOC;
-      }
-      G->w_cap = cap;
-    }
+    RC(wide_ensure(c, &G->w_ra, &G->w_cap_a, (size_t)nrec + 16));
+    RC(wide_ensure(c, &G->w_rb, &G->w_cap_b, (size_t)nrec + 16));
+    RC(wide_ensure(c, &G->w_shard, &G->w_cap_s, (size_t)nrec + 16));
     {
       PhaseScope ps(c, DC3HIP_PH_PACK, n);
       hipLaunchKernelGGL((k_wide_select<true>), dim3(nblocks), dim3(kBlock), 0, c->stream, k, chunk, lo, hi, last, (u32 *)nullptr,
@@ -1277,45 +1416,14 @@ static int gbuild_wide(dc3hip_gctx *G) {
     }
     Rec16 *h = G->w_ra;
     if (nrec) RC(radix_sort<Rec16>(c, G->w_ra, G->w_rb, nrec, 0, ibits, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT12_DOWN));
-    // tie pass; while a few windows still agree completely it is repeated with a deeper compare: kWideWindow symbols, then
-    // kWideWindowDeep, then 16 times deeper per round for as long as (windows that still agree) x (next depth) stays inside
-    // a work budget — the compare is lazy, so the depth only costs where windows really agree that far.  This settles
-    // repeats of any length a few of which exist (two copies of a 100 kB block: 10^5 tied pairs x 10^5 symbols); what
-    // the budget does not cover is refused (there is no recursion with 64-bit positions).
-    u32 depth = kWideWindow;
-    for (int round = 0;; round++) {
-      k.W = depth;
-      G->w_depth = depth;
-      HIPC(hipMemsetAsync(c->d_words + 10, 0, 3 * sizeof(u32), c->stream));
-      if (nrec) {
-        PhaseScope ps(c, DC3HIP_PH_TIES, nrec);
-        hipLaunchKernelGGL(k_wide_ties, dim3(grid_for(c, nrec)), dim3(kBlock), 0, c->stream, (const Rec16 *)h, nrec, k, G->w_shard, c->d_words + 10);
-        KCHECK();
-      }
-      HIPC(hipMemcpyAsync(c->h_words + 10, c->d_words + 10, 3 * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
-      HIPC(hipStreamSynchronize(c->stream));
-      if (c->h_words[10] != 0 || c->h_words[12] == 0) break;
-      if (round == 0) { if (c->h_words[12] > (1u << 20)) break; depth = kWideWindowDeep; continue; }
-      const u64 next = (u64)depth * 16;
-      if (next > kWideMaxDepth || (u64)c->h_words[12] * next > kWideTieBudget) break;
-      depth = (u32)next;
-    }
-    return E_OK;
+    return wide_tie_rounds(G, h, nrec, k);
   }();
   if (local_rc != E_OK && local_rc != E_TOOBIG && local_rc != E_ALLOC) return local_rc;     // HIP / transport faults: as before
   arena_release(c, mk);
   c->stats.level_tied[0] = c->h_words[11];
   const bool mine_ok = local_rc == E_OK && c->h_words[10] == 0 && c->h_words[12] == 0;
-  uint64_t good = 0, ngood = 0, pre = 0, tot = 0, refp = 0, refused = 0;
-  char local_err[sizeof(g_err)];
-  snprintf(local_err, sizeof(local_err), "%s", g_err);
-  RC(gather_counts(cm, local_rc == E_TOOBIG ? 1u : local_rc == E_ALLOC ? (1u << 20) : 0u, &refp, &refused));
-  if (refused) {                                       // some rank refused: all ranks return, each with a message
-    const int rc_all = (refused >> 20) ? E_ALLOC : E_TOOBIG;
-    if (local_rc != E_OK) set_err("%s", local_err);
-    else set_err("wide global mode: another rank refused its share (%s)", rc_all == E_ALLOC ? "no device memory for its records" : "more ranks needed");
-    return rc_all;
-  }
+  uint64_t good = 0, ngood = 0, pre = 0, tot = 0;
+  RC(agree(local_rc));
   RC(gather_counts(cm, mine_ok ? 1 : 0, &good, &ngood));
   RC(gather_counts(cm, nrec, &pre, &tot));
   if (tot != n) { set_err("wide global order: %llu of %llu positions selected", (unsigned long long)tot, (unsigned long long)n); return E_HIP; }
@@ -1406,6 +1514,7 @@ static void gctx_env(dc3hip_gctx *G) {
   if (const char *e = getenv("DC3HIP_GLOBAL_NO_TEXT_ORDER")) G->no_text_order = e[0] == '1';
   if (const char *e = getenv("DC3HIP_GLOBAL_FORCE_DIST")) G->force_dist = e[0] == '1';
   if (const char *e = getenv("DC3HIP_GLOBAL_NO_ROUTE")) G->route = e[0] != '1';
+  if (const char *e = getenv("DC3HIP_GLOBAL_WIDE_ROUTE_MIN_P")) G->wide_route_min_p = std::max(1, atoi(e));
 }
 
 // the rank's device context: a full one (text, SA, arena for max_total_n) — or, in wide mode, a minimal one (stream,

@@ -408,7 +408,8 @@ def test_wide_mode_small_texts_match_the_oracle(ss, oracle, P):
     150 000 symbols are settled by the tie rounds (each 16 times deeper than the last); a text half of which is a copy of
     the other half and a text over one symbol are refused with -4 on every rank."""
     rng = np.random.default_rng(47)
-    with env(DC3HIP_GLOBAL_FORCE_WIDE=1), ss.LoopbackGroup(P, 3_000_000) as g:
+    # (P = 3 also runs the ROUTED selection, which is otherwise taken from 6 ranks on; P = 8 takes it by default)
+    with env(DC3HIP_GLOBAL_FORCE_WIDE=1, DC3HIP_GLOBAL_WIDE_ROUTE_MIN_P=3), ss.LoopbackGroup(P, 3_000_000) as g:
         cases = {"bytes": rng.integers(0, 256, size=2_500_003, dtype=np.uint8), "dna": oracle.gen(3_000_000, 5, 1),
                  "binary": rng.integers(0, 2, size=1_000_001, dtype=np.uint8) + 7,
                  "with_zero_byte": rng.integers(0, 3, size=777_777, dtype=np.uint8), "tiny": rng.integers(0, 256, size=300, dtype=np.uint8)}
