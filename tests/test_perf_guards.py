@@ -17,12 +17,12 @@ pytestmark = pytest.mark.gpu
 GIB = 1 << 30
 # case -> measured ms at the shipping head (MI355X); the guard is 1.3x
 MEASURED_MS = {
-    "random_1GiB": 20.5,
-    "random_1GiB_recursion_only": 63.5,
-    "random_1GiB_dup_1MB_block": 63.0,
-    "dna_1GiB": 23.3,
-    "text_1GiB": 194.0,
-    "real_text_256MiB": 78.0,
+    "random_1GiB": 20.4,
+    "random_1GiB_recursion_only": 55.0,
+    "random_1GiB_dup_1MB_block": 48.0,
+    "dna_1GiB": 23.2,
+    "text_1GiB": 176.0,
+    "real_text_256MiB": 77.5,
 }
 SLACK = 1.3
 
