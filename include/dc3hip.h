@@ -134,6 +134,18 @@ DC3HIP_API int32_t dc3hip_ctx_lcp_i32(dc3hip_ctx *ctx, int32_t *LCP);
 DC3HIP_API int32_t dc3hip_ctx_search(dc3hip_ctx *ctx, const uint8_t *needles, const int64_t *offsets, int32_t count,
                                      int64_t *out_start, int64_t *out_len);
 
+/* Batched sacapart::PartitionedSuffixArray::longest_substring_match (crates/sacapart/src/lib.rs:69-97) on the device.
+ * The resident array holds the P partition suffix arrays back to back — chunk c = text[c*S .. min(n,(c+1)*S)),
+ * S = n/P + 1 (lib.rs:43-46), LOCAL indices: exactly what dc3hip_sufsort_ex(num_partitions = P) writes.  It gets there
+ * either by dc3hip_ctx_build_partitions (built on the device, chunk by chunk) or by dc3hip_ctx_set_sa_i32 (then every
+ * partition is verified once by the device sufcheck before the first search).  Every needle is searched in every
+ * partition with the reference's narrowing loop; a match that reaches its partition's end is re-extended over the whole
+ * text (lib.rs:77-84); the strictly longer match wins (lib.rs:86-92).  Arguments and results as dc3hip_ctx_search, starts
+ * absolute.  n < 2^31. */
+DC3HIP_API int32_t dc3hip_ctx_build_partitions(dc3hip_ctx *ctx, int32_t num_partitions);
+DC3HIP_API int32_t dc3hip_ctx_search_partitioned(dc3hip_ctx *ctx, int32_t num_partitions, const uint8_t *needles,
+                                                 const int64_t *offsets, int32_t count, int64_t *out_start, int64_t *out_len);
+
 /* 64-bit order-sensitive checksum of the device-resident SA (sum over k of mix(k, SA[k])). */
 DC3HIP_API int32_t dc3hip_ctx_sa_checksum(dc3hip_ctx *ctx, uint64_t *out);
 

@@ -127,6 +127,8 @@ SYMBOLS = {
     "dc3hip_ctx_bwt": (_i32, [_vp, _vp, ctypes.POINTER(_i64)]),
     "dc3hip_ctx_lcp_i32": (_i32, [_vp, _vp]),
     "dc3hip_ctx_search": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp]),
+    "dc3hip_ctx_build_partitions": (_i32, [_vp, _i32]),
+    "dc3hip_ctx_search_partitioned": (_i32, [_vp, _i32, _vp, _vp, _i32, _vp, _vp]),
     "dc3hip_ctx_stats": (_i32, [_vp, ctypes.POINTER(Stats)]),
     "dc3hip_ctx_debug_radix_pass_u64": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32]),
     # global mode

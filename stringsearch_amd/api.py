@@ -301,6 +301,25 @@ class Context:
         _check(lib().dc3hip_ctx_search(self._h, cat.ctypes.data, off.ctypes.data, len(nds), st.ctypes.data, ln.ctypes.data))
         return list(zip(st.tolist(), ln.tolist()))
 
+    def build_partitions(self, num_partitions):
+        """sacapart's partition arrays of the resident text (local indices, back to back), built on this device."""
+        _check(lib().dc3hip_ctx_build_partitions(self._h, num_partitions))
+
+    def search_partitioned(self, num_partitions, needles):
+        """Batched PartitionedSuffixArray::longest_substring_match (sacapart/src/lib.rs:69-97) on the GPU over the
+        resident partition arrays (build_partitions, or set_sa with what dc3hip_sufsort_ex(num_partitions=P) wrote):
+        list of bytes-like -> list of (absolute start, len)."""
+        nds = [_as_u8(x) for x in needles]
+        if not nds:
+            return []
+        off = np.zeros(len(nds) + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(x) for x in nds])
+        cat = np.concatenate(nds) if off[-1] else np.zeros(1, dtype=np.uint8)
+        st = np.zeros(len(nds), dtype=np.int64); ln = np.zeros(len(nds), dtype=np.int64)
+        _check(lib().dc3hip_ctx_search_partitioned(self._h, num_partitions, cat.ctypes.data, off.ctypes.data, len(nds),
+                                                   st.ctypes.data, ln.ctypes.data))
+        return list(zip(st.tolist(), ln.tolist()))
+
     def stats(self):
         st = Stats()
         _check(lib().dc3hip_ctx_stats(self._h, ctypes.byref(st)))

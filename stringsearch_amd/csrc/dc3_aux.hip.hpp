@@ -200,6 +200,51 @@ __global__ __launch_bounds__(kBlock) void k_search(const uint8_t *__restrict__ t
   }
 }
 
+// The narrowing loop of k_search on one (text, SA) pair: the reference's (start, len)
+__device__ __forceinline__ void d_search_one(const uint8_t *__restrict__ t, u32 n, const u32 *__restrict__ sa, const uint8_t *nd, u64 nl,
+                                             u32 &start, u32 &mlen) {
+  u32 lo = 0, len = n;
+  for (;;) {
+    if (len == 1) { const u32 s = sa[lo]; start = s; mlen = d_common_prefix(t + s, n - s, nd, nl); return; }
+    if (len == 2) {
+      const u32 s0 = sa[lo], s1 = sa[lo + 1];
+      const u32 x = d_common_prefix(t + s0, n - s0, nd, nl), y = d_common_prefix(t + s1, n - s1, nd, nl);
+      if (x > y) { start = s0; mlen = x; } else { start = s1; mlen = y; }
+      return;
+    }
+    const u32 mid = len / 2;
+    const u32 s = sa[lo + mid];
+    const u64 sl = n - s;
+    const u32 c = d_common_prefix(t + s, sl, nd, nl);
+    const bool gt = (c < nl && c < sl) ? (nd[c] > t[s + c]) : (nl > sl);
+    if (gt) { lo += mid; len -= mid; } else { len = mid + 1; }
+  }
+}
+// Batched sacapart::PartitionedSuffixArray::longest_substring_match (crates/sacapart/src/lib.rs:69-97), one thread per
+// needle: sa holds the partition arrays back to back (chunk c = t[c*S .. min(n, (c+1)*S)), local indices).  Every
+// partition is searched with the narrowing loop above; a match that reaches its partition's end is re-extended over the
+// whole text (:77-84); the strictly longer match wins, so of equally long ones the first partition's stays (:86-92).
+__global__ __launch_bounds__(kBlock) void k_search_partitioned(const uint8_t *__restrict__ t, u32 n, const u32 *__restrict__ sa, u32 S,
+                                                              const uint8_t *__restrict__ needles, const int64_t *__restrict__ off, u32 q,
+                                                              int64_t *__restrict__ out_start, int64_t *__restrict__ out_len) {
+  const u32 id = blockIdx.x * kBlock + threadIdx.x;
+  if (id >= q) return;
+  const uint8_t *nd = needles + off[id];
+  const u64 nl = (u64)(off[id + 1] - off[id]);
+  bool have = false;
+  u64 best_start = 0; u32 best_len = 0;
+  for (u32 base = 0; base < n; base += S) {
+    const u32 cn = min(S, n - base);
+    u32 st, ln;
+    d_search_one(t + base, cn, sa + base, nd, nl, st, ln);
+    const bool may_extend = st + ln == cn;                                   // :77
+    const u64 abs_start = (u64)base + st;                                    // :80
+    if (may_extend) ln = d_common_prefix(t + abs_start, n - abs_start, nd, nl);   // :82-84
+    if (!have || ln > best_len) { best_start = abs_start; best_len = ln; have = true; }
+  }
+  out_start[id] = (int64_t)best_start; out_len[id] = (int64_t)best_len;
+}
+
 // ---------------------------------------------------------------------------------------------
 // LCP array of the resident SA ("next" row f.4): LCP[i] = lcp(suffix SA[i-1], suffix SA[i]), LCP[0] = 0.
 // Kasai's argument in position order, PLCP[p] >= PLCP[p-1] - 1 with PLCP[p] = lcp(p, Phi[p]) and

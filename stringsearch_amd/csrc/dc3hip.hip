@@ -57,7 +57,7 @@ enum { E_OK = 0, E_ARGS = -1, E_ALLOC = -2, E_HIP = -3, E_TOOBIG = -4 };
 // ---------------------------------------------------------------------------------------------
 static constexpr double kHybrid12MaxPredicted = 0.75;   // 12-byte prefix sort: taken below this predicted tied fraction (the sample
                                                         // extrapolation over-predicts on heavy-tailed repeats: 0.66 predicted, 0.08 measured on 1 GiB text)
-struct PhaseMark { int phase; hipEvent_t a, b; int64_t elems; int kclass; };
+struct PhaseMark { int phase; hipEvent_t a, b; int64_t elems; int kclass; int depth; };
 
 struct dc3hip_ctx {
   int device = 0;
@@ -65,6 +65,9 @@ struct dc3hip_ctx {
   int64_t max_n = 0, n = 0;
   bool built = false;
   bool sa_trusted = false;     // the resident SA was produced by ctx_build (a permutation), not handed in by set_sa
+  int cur_depth = 0;           // recursion level the phase marks are charged to (DC3HIP_LEVEL_PHASES report)
+  bool level_report = false;
+  int parts_trusted = 0;       // the resident array is this many verified partition arrays (0: not known to be)
   uint8_t *d_text = nullptr;   // max_n + 64 bytes
   u32 *d_sa = nullptr;         // max_n + 16 words
   unsigned char *arena = nullptr;
@@ -183,7 +186,7 @@ struct PhaseScope {
   dc3hip_ctx *c; size_t idx; bool on;
   PhaseScope(dc3hip_ctx *ctx, int phase, int64_t elems = 0, int kclass = -1) : c(ctx), idx(0), on(ctx->profile) {
     if (!on) return;
-    PhaseMark m; m.phase = phase; m.a = get_event(c); m.b = get_event(c); m.elems = elems; m.kclass = kclass;
+    PhaseMark m; m.phase = phase; m.a = get_event(c); m.b = get_event(c); m.elems = elems; m.kclass = kclass; m.depth = c->cur_depth;
     if (!m.a || !m.b) { on = false; return; }
     (void)hipEventRecord(m.a, c->stream);
     idx = c->marks.size(); c->marks.push_back(m);
@@ -1698,6 +1701,7 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
     return E_OK;
   }
   const u32 m0 = (m + 2) / 3, m1 = (m + 1) / 3, m2 = m / 3, m02 = m0 + m2;   // lib.rs:45-48
+  struct DepthScope { dc3hip_ctx *c; int was; DepthScope(dc3hip_ctx *x, int d) : c(x), was(x->cur_depth) { c->cur_depth = d; } ~DepthScope() { c->cur_depth = was; } } depth_scope(c, depth);
   c->stats.level_n[depth] = m; c->stats.level_K[depth] = (int64_t)K; c->stats.levels = depth + 1;
   const ArenaMark mk0 = arena_mark(c);
 
@@ -1880,9 +1884,11 @@ static int build_end(dc3hip_ctx *c) {
     float ms = 0;
     HIPC(hipEventElapsedTime(&ms, c->ev_build_a, c->ev_build_b));
     c->stats.build_ms = ms;
+    double by_level[DC3HIP_MAX_LEVELS][DC3HIP_PH_COUNT] = {};
     for (const PhaseMark &m : c->marks) {
       float t = 0;
       if (hipEventElapsedTime(&t, m.a, m.b) != hipSuccess) continue;
+      if (m.kclass != 4 && m.depth >= 0 && m.depth < DC3HIP_MAX_LEVELS) by_level[m.depth][m.phase] += t;
       if (m.kclass != 4) {   // class 4 is nested inside the TUPLES phase mark
         c->stats.phase_ms[m.phase] += t;
         c->stats.phase_launches[m.phase] += 1;
@@ -1896,9 +1902,20 @@ static int build_end(dc3hip_ctx *c) {
         c->stats.downsweep_elems[m.kclass] += m.elems;
       }
     }
+    if (c->level_report) {      // DC3HIP_LEVEL_PHASES=1: the phase times level by level, on stderr (a tuning aid)
+      for (int l = 0; l < c->stats.levels && l < DC3HIP_MAX_LEVELS; l++) {
+        double sum = 0;
+        for (int p = 0; p < DC3HIP_PH_COUNT; p++) sum += by_level[l][p];
+        std::fprintf(stderr, "dc3hip level %d n=%lld K=%lld mode=%d total=%.2f ms:", l, (long long)c->stats.level_n[l], (long long)c->stats.level_K[l],
+                     c->stats.level_sorted[l], sum);
+        for (int p = 0; p < DC3HIP_PH_COUNT; p++) if (by_level[l][p] > 0.005) std::fprintf(stderr, " p%d=%.2f", p, by_level[l][p]);
+        std::fprintf(stderr, "\n");
+      }
+    }
   }
   c->built = true;
   c->sa_trusted = true;
+  c->parts_trusted = 0;
   return E_OK;
 }
 // level-0 alphabet: dense order-preserving codes 1..sigma of the bytes that occur
@@ -2191,6 +2208,7 @@ int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) {
   { const char *e = getenv("DC3HIP_TEXT_ORDER12"); if (e && (e[0] == '0' || e[0] == '1')) c->text_order12 = e[0] - '0'; }
   { const char *e = getenv("DC3HIP_NO_TUP8"); c->no_tup8 = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_MSD"); c->no_msd = (e && e[0] == '1'); }
+  { const char *e = getenv("DC3HIP_LEVEL_PHASES"); c->level_report = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_PACK_FUSE"); c->pack_fuse = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_XCD_MAP"); c->no_xcd_map = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_TUP_SCATTER"); c->no_tup_scatter = (e && e[0] == '1'); }
@@ -2336,9 +2354,10 @@ int32_t dc3hip_ctx_get_text(dc3hip_ctx *c, uint8_t *T) {
 
 // Runs the check; *code receives sufcheck()'s result (0, -2, -3, -4); the return value is the
 // library status (E_OK / E_ALLOC / E_HIP), kept apart because the two code spaces overlap.
-static int ctx_sufcheck(dc3hip_ctx *c, const u32 *d_sa, int *code) {
-  // utils.c:160-241 as parallel passes; isa lives in the arena
-  const int64_t n = c->n;
+static int ctx_sufcheck(dc3hip_ctx *c, const u32 *d_sa, int *code, const uint8_t *text = nullptr, int64_t n_override = -1) {
+  // utils.c:160-241 as parallel passes; isa lives in the arena.  text / n_override: a partition of the resident text
+  const int64_t n = n_override >= 0 ? n_override : c->n;
+  if (!text) text = c->d_text;
   *code = 0;
   if (n == 0) return E_OK;
   HIPC(hipSetDevice(c->device));
@@ -2349,7 +2368,7 @@ static int ctx_sufcheck(dc3hip_ctx *c, const u32 *d_sa, int *code) {
   HIPC(hipMemsetAsync(err, 0, sizeof(int), c->stream));
   hipLaunchKernelGGL(k_check_fill, dim3(grid_for(c, n)), dim3(kBlock), 0, c->stream, d_sa, (u32)n, isa, err);
   KCHECK();
-  hipLaunchKernelGGL(k_check_order, dim3(grid_for(c, n)), dim3(kBlock), 0, c->stream, c->d_text, d_sa, isa, (u32)n,
+  hipLaunchKernelGGL(k_check_order, dim3(grid_for(c, n)), dim3(kBlock), 0, c->stream, text, d_sa, isa, (u32)n,
                      err);
   KCHECK();
   HIPC(hipMemcpyAsync(c->h_words + 8, err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -2403,6 +2422,7 @@ int32_t dc3hip_ctx_set_sa_i32(dc3hip_ctx *c, const int32_t *SA) {
   HIPC(hipStreamSynchronize(c->stream));
   c->built = true;
   c->sa_trusted = false;
+  c->parts_trusted = 0;
   return E_OK;
 }
 
@@ -2504,6 +2524,72 @@ int32_t dc3hip_ctx_search(dc3hip_ctx *c, const uint8_t *needles, const int64_t *
   HIPC(hipMemcpyAsync(doff, offsets, ((size_t)count + 1) * 8, hipMemcpyDefault, c->stream));
   hipLaunchKernelGGL(k_search, dim3((count + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->d_text, (u32)c->n,
                      c->d_sa, dn, doff, (u32)count, ds, dl);
+  KCHECK();
+  HIPC(hipMemcpyAsync(out_start, ds, (size_t)count * 8, hipMemcpyDefault, c->stream));
+  HIPC(hipMemcpyAsync(out_len, dl, (size_t)count * 8, hipMemcpyDefault, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  c->arena_off = 0;
+  return E_OK;
+}
+
+// Partition arrays (sacapart semantics) in the resident SA buffer: chunk c = text[c*S .. min(n,(c+1)*S)), S = n/P + 1
+// (crates/sacapart/src/lib.rs:43-46), local indices, back to back — built here chunk by chunk on the device.
+int32_t dc3hip_ctx_build_partitions(dc3hip_ctx *c, int32_t num_partitions) {
+  if (!c || num_partitions < 1) { set_err("invalid arguments"); return E_ARGS; }
+  const int64_t n = c->n;
+  if (n > (int64_t)INT32_MAX) { set_err("partitioned build of %lld bytes needs 64-bit indices", (long long)n); return E_TOOBIG; }
+  HIPC(hipSetDevice(c->device));
+  const int64_t S = n / num_partitions + 1;
+  dc3hip_ctx *child = nullptr;
+  RC(dc3hip_ctx_create(&child, c->device, std::min<int64_t>(S, n)));
+  int rc = E_OK;
+  for (int64_t off = 0; off < n && rc == E_OK; off += S) {
+    const int64_t len = std::min<int64_t>(S, n - off);
+    rc = dc3hip_ctx_set_text(child, c->d_text + off, len);                       // (device pointer: hipMemcpyDefault)
+    if (rc == E_OK) rc = dc3hip_ctx_build(child);
+    if (rc == E_OK) rc = dc3hip_ctx_get_sa_i32(child, reinterpret_cast<int32_t *>(c->d_sa + off));
+  }
+  dc3hip_ctx_destroy(child);
+  if (rc != E_OK) return rc;
+  c->built = true; c->sa_trusted = false; c->parts_trusted = num_partitions;
+  return E_OK;
+}
+
+int32_t dc3hip_ctx_search_partitioned(dc3hip_ctx *c, int32_t num_partitions, const uint8_t *needles, const int64_t *offsets,
+                                      int32_t count, int64_t *out_start, int64_t *out_len) {
+  if (!c || num_partitions < 1 || count < 0 || (count > 0 && (!needles || !offsets || !out_start || !out_len))) {
+    set_err("invalid arguments"); return E_ARGS;
+  }
+  if (!c->built) { set_err("no partition arrays in this context (dc3hip_ctx_build_partitions / dc3hip_ctx_set_sa_i32)"); return E_ARGS; }
+  if (c->n == 0) { set_err("empty text (the reference indexes out of bounds here)"); return E_ARGS; }
+  if (c->n > (int64_t)INT32_MAX) { set_err("partitioned search of %lld bytes needs 64-bit indices", (long long)c->n); return E_TOOBIG; }
+  if (count == 0) return E_OK;
+  HIPC(hipSetDevice(c->device));
+  for (int32_t k = 0; k < count; k++)
+    if (offsets[k] < 0 || offsets[k + 1] < offsets[k]) { set_err("invalid needle offsets (must be non-negative and non-decreasing)"); return E_ARGS; }
+  const int64_t n = c->n, S = n / num_partitions + 1;
+  // arrays that were handed in (dc3hip_ctx_set_sa_i32) are verified once, partition by partition: the search reads
+  // T[SA[i]..] without range checks
+  if (c->parts_trusted != num_partitions) {
+    for (int64_t off = 0; off < n; off += S) {
+      int code = 0;
+      RC(ctx_sufcheck(c, c->d_sa + off, &code, c->d_text + off, std::min<int64_t>(S, n - off)));
+      if (code != 0) { set_err("the resident array is not %d partition suffix arrays of the text: partition at %lld fails sufcheck (%d)", num_partitions, (long long)off, code); return E_ARGS; }
+    }
+    c->parts_trusted = num_partitions;
+  }
+  const int64_t total = offsets[count];
+  c->arena_off = 0;
+  RC(ensure_arena(c, (size_t)total + (size_t)count * 24 + ((size_t)1 << 20)));
+  uint8_t *dn = nullptr; int64_t *doff = nullptr, *ds = nullptr, *dl = nullptr;
+  RC(arena_alloc(c, (size_t)total + 16, &dn));
+  RC(arena_alloc(c, (size_t)count + 1, &doff));
+  RC(arena_alloc(c, (size_t)count, &ds));
+  RC(arena_alloc(c, (size_t)count, &dl));
+  if (total > 0) HIPC(hipMemcpyAsync(dn, needles, (size_t)total, hipMemcpyDefault, c->stream));
+  HIPC(hipMemcpyAsync(doff, offsets, ((size_t)count + 1) * 8, hipMemcpyDefault, c->stream));
+  hipLaunchKernelGGL(k_search_partitioned, dim3((count + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, c->d_text, (u32)n, c->d_sa, (u32)S,
+                     dn, doff, (u32)count, ds, dl);
   KCHECK();
   HIPC(hipMemcpyAsync(out_start, ds, (size_t)count * 8, hipMemcpyDefault, c->stream));
   HIPC(hipMemcpyAsync(out_len, dl, (size_t)count * 8, hipMemcpyDefault, c->stream));

@@ -106,6 +106,51 @@ class DeviceIndex : public sacabase::StringIndex {
   }
 };
 
+// sacapart::PartitionedSuffixArray (crates/sacapart/src/lib.rs:26-97) resident on one device: the P partition arrays are
+// built there and every needle of a batch is searched in every partition by one kernel (re-extension over partition
+// ends and the strictly-longer rule included) — the same (start, len) the host-side sacapart mirror returns.
+class DevicePartitionedIndex : public sacabase::StringIndex {
+  dc3hip_ctx *ctx_ = nullptr;
+  sacabase::Bytes text_;
+  int32_t parts_;
+  static void check(int rc) { if (rc != 0) throw Error(rc, dc3hip_last_error()); }
+
+ public:
+  DevicePartitionedIndex(sacabase::Bytes text, size_t num_partitions, int device = -1) : text_(text), parts_((int32_t)num_partitions) {
+    check(dc3hip_ctx_create(&ctx_, device, (int64_t)text.len));
+    try {
+      check(dc3hip_ctx_set_text(ctx_, text.ptr, (int64_t)text.len));
+      check(dc3hip_ctx_build_partitions(ctx_, parts_));
+    } catch (...) { dc3hip_ctx_destroy(ctx_); throw; }
+  }
+  DevicePartitionedIndex(const DevicePartitionedIndex &) = delete;
+  DevicePartitionedIndex &operator=(const DevicePartitionedIndex &) = delete;
+  ~DevicePartitionedIndex() { dc3hip_ctx_destroy(ctx_); }
+  size_t partition_size() const { return text_.len / (size_t)parts_ + 1; }                      // lib.rs:43
+  size_t num_partitions() const { return (text_.len + partition_size() - 1) / partition_size(); }   // :60
+  // the partition arrays, back to back (what dc3hip_sufsort_ex(num_partitions = P) writes)
+  std::vector<int32_t> flat() const {
+    std::vector<int32_t> sa(text_.len);
+    static int32_t dummy = 0;
+    check(dc3hip_ctx_get_sa_i32(ctx_, sa.empty() ? &dummy : sa.data()));
+    return sa;
+  }
+  std::vector<sacabase::LongestCommonSubstring> search(const std::vector<sacabase::Bytes> &needles) const {
+    std::vector<int64_t> off(needles.size() + 1, 0);
+    for (size_t i = 0; i < needles.size(); i++) off[i + 1] = off[i] + (int64_t)needles[i].len;
+    std::vector<uint8_t> cat((size_t)off.back() + 1);
+    for (size_t i = 0; i < needles.size(); i++) if (needles[i].len) std::memcpy(cat.data() + off[i], needles[i].ptr, needles[i].len);
+    std::vector<int64_t> st(needles.size()), ln(needles.size());
+    check(dc3hip_ctx_search_partitioned(ctx_, parts_, cat.data(), off.data(), (int32_t)needles.size(), st.data(), ln.data()));
+    std::vector<sacabase::LongestCommonSubstring> out;
+    for (size_t i = 0; i < needles.size(); i++) out.push_back(sacabase::LongestCommonSubstring{text_, (size_t)st[i], (size_t)ln[i]});
+    return out;
+  }
+  sacabase::LongestCommonSubstring longest_substring_match(sacabase::Bytes needle) const override {
+    return search({needle})[0];
+  }
+};
+
 // GLOBAL mode (include/dc3hip.h): ONE suffix array of a text over P ranks.  GlobalLoopback = P ranks on one device in
 // this process (tests, single-GPU boxes); a multi-process host builds one GlobalRank per GPU from a 128-byte RCCL id it
 // distributes itself (MPI_Bcast, a file, ...).  Shards in rank order concatenate to what dc3hip::sort_i64 returns.

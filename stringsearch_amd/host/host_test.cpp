@@ -71,6 +71,27 @@ int main() {
             a.longest_substring_match(Bytes(std::string("find matches that span"))).len);
     }
   }
+  {  // the partitioned index resident on the device: the same partitions and the same matches as the host-side mirror
+    std::string input = "This is a rather long text. We can probably find matches that span two partitions. Oh yes.";
+    std::vector<std::string> needles = {"rather long", "text. We can", "We can probably find matches that span", "zzz", "Oh yes.!", "s.", ""};
+    std::vector<Bytes> nb; for (auto &n : needles) nb.push_back(Bytes(n));
+    for (size_t partitions : {1, 2, 3, 7}) {
+      sacapart::PartitionedSuffixArray<int32_t> host(Bytes(input), partitions, dc3hip::sort);
+      dc3hip::DevicePartitionedIndex dev(Bytes(input), partitions);
+      CHECK(dev.num_partitions() == host.num_partitions());
+      sacapart::PartitionedSuffixArray<int32_t> again(Bytes(input), partitions, dev.flat());
+      for (size_t i = 0; i < host.num_partitions(); i++) CHECK(host.partitions()[i].sa() == again.partitions()[i].sa());
+      auto got = dev.search(nb);
+      for (size_t i = 0; i < nb.size(); i++) {
+        auto want = host.longest_substring_match(nb[i]);
+        CHECK(got[i].start == want.start); CHECK(got[i].len == want.len);
+      }
+    }
+    std::string t = "totor";
+    dc3hip::DevicePartitionedIndex worse(Bytes(t), 2);
+    CHECK(worse.longest_substring_match(Bytes(std::string("tor"))).as_bytes() == Bytes(std::string("to")));    // lib.rs:105-128
+    CHECK(worse.longest_substring_match(Bytes(std::string("otor"))).as_bytes() == Bytes(std::string("otor")));
+  }
   {  // global mode: one suffix array over 3 loopback ranks == the single-device array (and it verifies)
     std::string input;
     for (int i = 0; i < 4000; i++) input += "This is a rather long text. We can probably find matches that span two partitions. Oh yes. ";

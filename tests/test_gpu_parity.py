@@ -257,6 +257,58 @@ def test_partitioned_search_on_gpu_sas(ss):
             assert (f.as_bytes(), f.start, f.len) == (p.as_bytes(), p.start, p.len)
 
 
+def test_partitioned_search_on_the_device(ss, oracle):
+    """dc3hip_ctx_build_partitions + dc3hip_ctx_search_partitioned against the oracle's restatement of
+    sacapart/src/lib.rs:69-97 — the reference's own cases (lib.rs:105-165: worse_test, equivalent_test), then seeded
+    texts with needles cut from the text across partition boundaries, needles that end at the text's end, absent and
+    empty needles; partition counts that do and do not divide the length, and more partitions than bytes."""
+    def oracle_parts(text, P):
+        S = len(text) // P + 1
+        return S, [oracle.sufsort(text[o:o + S]) for o in range(0, len(text), S)]
+
+    def check(text, P, needles, c):
+        S, sas = oracle_parts(text, P)
+        want = [oracle.partitioned_search(text, sas, S, nd) for nd in needles]
+        c.set_text(text); c.build_partitions(P)
+        assert np.array_equal(c.sa(), np.concatenate(sas)), (P, len(text))       # the same arrays sufsort_ex(P) writes
+        assert c.search_partitioned(P, needles) == want, (P, len(text))
+        # handed-in arrays: verified partition by partition, then the same answers
+        c.set_sa(np.concatenate(sas).astype(np.int32))
+        assert c.search_partitioned(P, needles) == want
+        return want
+
+    with ss.Context(1 << 20) as c:
+        got = check(b"totor", 2, [b"tor", b"otor"], c)
+        assert got == [(0, 2), (1, 4)]                                           # "to" (worse than the full "tor"), "otor"
+        text = b"This is a rather long text. We can probably find matches that span two partitions. Oh yes."
+        full = oracle.sufsort(text)
+        needles = [b"rather long", b"text. We can", b"We can probably find matches that span"]
+        for P in (1, 2, 3):
+            assert check(text, P, needles, c) == [oracle.search(text, full, nd) for nd in needles]
+        rng = np.random.default_rng(77)
+        for kind, n, P in ((2, 100_003, 7), (1, 65_536, 8), (0, 40_000, 3), (2, 33, 64), (1, 9_999, 5)):
+            text = oracle.gen(n, 11 + P, kind).tobytes()
+            S = n // P + 1
+            needles = [b"", b"\xff\xfe\xfd", text[-17:], text[-1:], text[:1]]
+            for b in range(S, n, S):                                             # straddling every boundary
+                for back, fwd in ((5, 9), (1, 1), (40, 0), (0, 40)):
+                    needles.append(text[max(0, b - back):b + fwd] + b"\x00")
+                    needles.append(text[max(0, b - back):b + fwd])
+            for _ in range(200):
+                a = int(rng.integers(0, n)); m = int(rng.integers(1, 48))
+                nd = bytearray(text[a:a + m])
+                if rng.integers(0, 2) and nd:
+                    nd[-1] ^= 0x55
+                needles.append(bytes(nd))
+            check(text, P, needles, c)
+        # an array that is not P partition arrays is refused before any search reads through it
+        text = oracle.gen(5000, 3, 2).tobytes()
+        c.set_text(text); c.build()
+        with pytest.raises(ss.Dc3HipError):
+            c.search_partitioned(4, [b"abc"])
+        assert c.search_partitioned(1, [text[100:140]]) == [oracle.search(text, oracle.sufsort(text), text[100:140])]
+
+
 def test_bwt_matches_reference(ss, oracle):
     """dc3hip_ctx_bwt / dc3hip_divbwt_i32 vs the reference's divbwt (divsufsort.c:372-405) when its build
     travelled with the snapshot, and vs the definition from the oracle SA always."""
