@@ -227,6 +227,14 @@ typedef struct dc3hip_stats {
   double  msd_local_ms; int64_t msd_local_launches; int64_t msd_local_elems;
   int32_t msd_sorts, msd_fallbacks;
   int64_t msd_max_subbucket;              /* largest sub-bucket of the last MSD sort */
+  /* splitter (sample) ordering of the 12- / 16-byte sample-triple records (dc3_ssort.hip.hpp), which replaces the stable
+   * LSD passes of the straight orderings on large levels: k_ss_part = one partition pass over sampled splitters,
+   * k_ss_local = the in-LDS comparison order of the sub-buckets.  ssort_fallbacks = sorts that gave it up before
+   * pass 2 (a sub-bucket beyond the local capacity) and ran the LSD passes instead. */
+  double  ssort_part_ms;  int64_t ssort_part_launches;  int64_t ssort_part_elems;
+  double  ssort_local_ms; int64_t ssort_local_launches; int64_t ssort_local_elems;
+  int32_t ssort_sorts, ssort_fallbacks;
+  int64_t ssort_max_subbucket;
 } dc3hip_stats;
 
 DC3HIP_API int32_t dc3hip_ctx_stats(dc3hip_ctx *ctx, dc3hip_stats *out);

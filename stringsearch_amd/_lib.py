@@ -45,7 +45,10 @@ class Stats(ctypes.Structure):
                 ("trace_sa", ctypes.c_uint64 * MAX_LEVELS), ("trace_names", ctypes.c_int64 * MAX_LEVELS),
                 ("msd_part_ms", ctypes.c_double), ("msd_part_launches", ctypes.c_int64), ("msd_part_elems", ctypes.c_int64),
                 ("msd_local_ms", ctypes.c_double), ("msd_local_launches", ctypes.c_int64), ("msd_local_elems", ctypes.c_int64),
-                ("msd_sorts", ctypes.c_int32), ("msd_fallbacks", ctypes.c_int32), ("msd_max_subbucket", ctypes.c_int64)]
+                ("msd_sorts", ctypes.c_int32), ("msd_fallbacks", ctypes.c_int32), ("msd_max_subbucket", ctypes.c_int64),
+                ("ssort_part_ms", ctypes.c_double), ("ssort_part_launches", ctypes.c_int64), ("ssort_part_elems", ctypes.c_int64),
+                ("ssort_local_ms", ctypes.c_double), ("ssort_local_launches", ctypes.c_int64), ("ssort_local_elems", ctypes.c_int64),
+                ("ssort_sorts", ctypes.c_int32), ("ssort_fallbacks", ctypes.c_int32), ("ssort_max_subbucket", ctypes.c_int64)]
 
     def as_dict(self):
         return {
@@ -71,6 +74,10 @@ class Stats(ctypes.Structure):
             "msd_local_ms": self.msd_local_ms, "msd_local_launches": self.msd_local_launches,
             "msd_local_elems": self.msd_local_elems, "msd_sorts": self.msd_sorts, "msd_fallbacks": self.msd_fallbacks,
             "msd_max_subbucket": self.msd_max_subbucket,
+            "ssort_part_ms": self.ssort_part_ms, "ssort_part_launches": self.ssort_part_launches, "ssort_part_elems": self.ssort_part_elems,
+            "ssort_local_ms": self.ssort_local_ms, "ssort_local_launches": self.ssort_local_launches,
+            "ssort_local_elems": self.ssort_local_elems, "ssort_sorts": self.ssort_sorts, "ssort_fallbacks": self.ssort_fallbacks,
+            "ssort_max_subbucket": self.ssort_max_subbucket,
             "trace": None if not self.trace_on else [
                 {"n": self.level_n[i], "sa12": self.trace_sa12[i], "sa0": self.trace_sa0[i], "sa": self.trace_sa[i],
                  "names": self.trace_names[i]} for i in range(self.levels)],

@@ -1,0 +1,390 @@
+// dc3_ssort.hip.hpp — splitter (sample) ordering of the 12- and 16-byte sample-triple records.
+// Part of the gfx950 kernel set of libdc3hip (see dc3_kernels.hip.hpp for the overview); namespace dc3.
+//
+// The straight ordering of a level (lib.rs:62-78: the three radix_pass calls over the sample triples) sorts records
+// (key, pos) whose keys are names of the level above: on text they are badly skewed (a few triples carry most of the
+// mass) and wider than a word, so the bucket ordering of dc3_msd.hip.hpp — digits taken from key BITS — does not
+// apply, and the stable LSD passes cost 5 (45-bit keys) to 9 (81-bit keys) sweeps over the records.  Here the buckets
+// come from the data instead:
+//   sample    every (n / S)-th record, S = 16 per sub-bucket; the sample is sorted by the LSD passes (it is ~1 % of n)
+//   splitters every 16th sample value = one of n2 - 1 fine splitters; every F2-th fine splitter = a coarse one
+//   pass 1    k_ss_part<.., false>   partition by the 1023 coarse splitters   (sizes: k_ss_count1)
+//   pass 2    k_ss_part<.., true>    partition every bucket by its F2 - 1 fine splitters  (sizes: k_ss_hist2 + scans)
+//   pass 3    k_ss_local             every sub-bucket (about 1400 records, at most 4096) is ordered inside LDS
+// A record's sort value is (key, pos): all values are distinct, so "ascending" is one array whatever the partition
+// passes do (they are not stable: XCD-grouped atomic reservation, see dc3_msd.hip.hpp), and it is the array the stable
+// LSD passes produce from records in position order.  Buckets are balanced by construction — a sub-bucket holds the
+// records between two sample values 16 samples apart — so skew and repeated keys (which the position breaks) do not
+// matter; a sub-bucket above the local capacity is reported before pass 2 and the caller runs the LSD passes instead.
+//
+// Local order: a comparison sort, since the keys inside a sub-bucket share no usable bit structure.  127 or 255 of the
+// sub-bucket's own records are ranked against each other (all pairs, broadcast reads) and become bin boundaries; every
+// record finds its bin by binary search, bins are laid out in LDS by arrival, and each record counts the smaller
+// records of its bin (5-11 of them).
+#pragma once
+
+namespace dc3 {
+
+struct __attribute__((aligned(16))) SsVal { u64 hi, lo; };
+__device__ __forceinline__ SsVal ss_val(const Rec12 &r) { SsVal v; v.hi = ((u64)r.k1 << 32) | r.k0; v.lo = (u64)r.pos; return v; }
+__device__ __forceinline__ SsVal ss_val(const Rec16 &r) { SsVal v; v.hi = ((u64)r.k2 << 32) | r.k1; v.lo = ((u64)r.k0 << 32) | r.pos; return v; }
+__device__ __forceinline__ bool ss_le(const SsVal &a, const SsVal &b) { return a.hi < b.hi || (a.hi == b.hi && a.lo <= b.lo); }
+__device__ __forceinline__ bool ss_lt(const SsVal &a, const SsVal &b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }
+
+constexpr int kSsNT = 1024;                    // threads of a partition block
+constexpr u32 kSsGroups = 8;                   // XCDs (as kMsdGroups)
+constexpr u32 kSsMaxDig = 1024;                // coarse buckets, and the most fine splitters + 1 per bucket
+constexpr u32 kSsOver = 16;                    // sample values per sub-bucket
+constexpr u32 kSsHistTiles = 8;                // partition tiles per block of k_ss_hist2
+template <class Rec> struct SsCfg;
+template <> struct SsCfg<Rec12> { static constexpr int IPT = 8; };      // 8192-record tiles (96 KB)
+template <> struct SsCfg<Rec16> { static constexpr int IPT = 6; };      // 6144-record tiles (96 KB)
+template <class Rec> constexpr size_t ss_part_smem() {
+  return sizeof(Rec) * kSsNT * SsCfg<Rec>::IPT + sizeof(u32) * (2 * kSsMaxDig + 64) + sizeof(uint16_t) * kSsNT * SsCfg<Rec>::IPT;
+}
+
+// splitters[0 .. ns) ascending in LDS: how many are <= x
+__device__ __forceinline__ u32 ss_count_le(const SsVal *spl, u32 ns, const SsVal &x) {
+  u32 base = 0, len = ns;
+  while (len > 0) {
+    const u32 half = len >> 1, mid = base + half;
+    const SsVal s = spl[mid];
+    const bool le = ss_le(s, x);
+    base = le ? mid + 1 : base;
+    len = le ? len - half - 1 : half;
+  }
+  return base;
+}
+
+// The same count for K values at once, the K searches advancing in lockstep (K independent LDS reads in flight per
+// step instead of one dependent chain per value).  spl holds (1 << steps) - 1 entries, padded with +inf.
+template <int K>
+__device__ __forceinline__ void ss_count_le_multi(const SsVal *spl, u32 steps, const SsVal (&x)[K], u32 (&pos)[K]) {
+#pragma unroll
+  for (int k = 0; k < K; k++) pos[k] = 0;
+  for (u32 half = 1u << (steps - 1); half; half >>= 1) {
+    SsVal s[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) s[k] = spl[pos[k] + half - 1];
+#pragma unroll
+    for (int k = 0; k < K; k++) pos[k] += ss_le(s[k], x[k]) ? half : 0u;
+  }
+}
+// stage ns splitters from global memory into spl[0 .. (1 << steps) - 1), +inf behind them; blockDim.x >= (1 << steps) - 1
+__device__ __forceinline__ void ss_stage(SsVal *spl, const SsVal *__restrict__ g, u32 ns, u32 steps) {
+  const u32 t = threadIdx.x;
+  if (t < (1u << steps) - 1u) {
+    SsVal v;
+    if (t < ns) v = g[t]; else { v.hi = ~0ull; v.lo = ~0ull; }
+    spl[t] = v;
+  }
+}
+__device__ __forceinline__ u32 ss_steps(u32 ns) { u32 s = 1; while (((1u << s) - 1u) < ns) s++; return s; }   // ns >= 1
+
+// sample[i] = the record at input index (i + 1/2) * n / S: ascending input indices, i.e. ascending pos
+template <class Rec>
+__global__ __launch_bounds__(kBlock) void k_ss_sample(const Rec *__restrict__ in, u32 n, u32 S, Rec *__restrict__ out) {
+  const u32 i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= S) return;
+  u64 idx = ((u64)i * 2 + 1) * n / (2 * (u64)S);
+  if (idx >= n) idx = n - 1;
+  out[i] = in[idx];
+}
+
+// fine[j] = value of sorted sample (j + 1) * kSsOver, j < n2 - 1 (fine[n2 - 1] = +inf); coarse[b] = fine[(b + 1) * F2 - 1]
+template <class Rec>
+__global__ __launch_bounds__(kBlock) void k_ss_splitters(const Rec *__restrict__ ss, u32 n2, u32 F2, SsVal *__restrict__ fine,
+                                                        SsVal *__restrict__ coarse) {
+  const u32 j = blockIdx.x * kBlock + threadIdx.x;
+  if (j >= n2) return;
+  SsVal v;
+  if (j == n2 - 1) { v.hi = ~0ull; v.lo = ~0ull; }
+  else v = ss_val(ss[(size_t)(j + 1) * kSsOver]);
+  fine[j] = v;
+  if ((j + 1) % F2 == 0) coarse[(j + 1) / F2 - 1] = v;      // (coarse[nb1 - 1] = +inf, never searched)
+}
+
+// Sizes of the coarse buckets per group: block j belongs to group g = j % 8 and counts tiles
+// [g * cpx + idx * tpb, ... + tpb) of that group's eighth (idx = j / 8); cntg[d * 8 + g] += its counts.
+template <class Rec>
+__global__ __launch_bounds__(kSsNT) void k_ss_count1(const Rec *__restrict__ in, u32 n, const SsVal *__restrict__ coarse, u32 nb1,
+                                                    u32 tile, u32 cpx, u32 ntiles, u32 tpb, u32 *__restrict__ cntg,
+                                                    uint16_t *__restrict__ dig) {
+  __shared__ SsVal spl[kSsMaxDig];
+  __shared__ u32 hist[kSsMaxDig];
+  const u32 tid = threadIdx.x;
+  const u32 g = blockIdx.x % kSsGroups, idx = blockIdx.x / kSsGroups;
+  const u32 t0 = g * cpx + idx * tpb;
+  const u32 t1 = min(min(t0 + tpb, (g + 1) * cpx), ntiles);
+  if (idx * tpb >= cpx || t0 >= t1) return;
+  const u32 steps = ss_steps(nb1 - 1);
+  ss_stage(spl, coarse, nb1 - 1, steps);
+  hist[tid] = 0;
+  __syncthreads();
+  const u32 begin = t0 * tile, end = min(n, t1 * tile);     // (32-bit: n < 2^32 - tile)
+  for (u32 i = begin + tid; i < end; i += 8 * kSsNT) {
+    SsVal v[8];
+    u32 d[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = ss_val(in[min(i + (u32)k * kSsNT, end - 1u)]);
+    ss_count_le_multi<8>(spl, steps, v, d);
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+      if (i + (u32)k * kSsNT < end) { atomicAdd(&hist[d[k]], 1u); dig[i + (u32)k * kSsNT] = (uint16_t)d[k]; }
+  }
+  __syncthreads();
+  if (tid < nb1 && hist[tid]) atomicAdd(&cntg[tid * kSsGroups + g], hist[tid]);
+}
+
+// k_msd_plan1 with the tile sizes as arguments (the record types have different tiles).
+__global__ __launch_bounds__(1024) void k_ss_plan1(const u32 *__restrict__ cntg, u32 nb1, u32 n, u32 tile, u32 htile,
+                                                  u32 *__restrict__ startg, u32 *__restrict__ cur1, u32 *__restrict__ bstart,
+                                                  u32 *__restrict__ tpre, u32 *__restrict__ tpreh, u32 *__restrict__ plan) {
+  __shared__ u32 tmp[16];
+  const u32 d = threadIdx.x;
+  u32 v[kSsGroups], c = 0;
+#pragma unroll
+  for (u32 g = 0; g < kSsGroups; g++) { v[g] = d < nb1 ? cntg[d * kSsGroups + g] : 0u; c += v[g]; }
+  u32 tot;
+  u32 ex = block_excl_scan<16>(c, tmp, tot);
+  if (d < nb1) {
+    bstart[d] = ex;
+#pragma unroll
+    for (u32 g = 0; g < kSsGroups; g++) { startg[d * kSsGroups + g] = ex; cur1[g * nb1 + d] = ex; ex += v[g]; }
+  }
+  const u32 ext = block_excl_scan<16>((c + tile - 1) / tile, tmp, tot);
+  if (d < nb1) tpre[d] = ext;
+  if (d == 0) { tpre[nb1] = tot; plan[kMsdW_T2] = tot; plan[kMsdW_CPX2] = max(1u, (tot + kSsGroups - 1) / kSsGroups); }
+  const u32 exh = block_excl_scan<16>((c + htile - 1) / htile, tmp, tot);
+  if (d < nb1) tpreh[d] = exh;
+  if (d == 0) { tpreh[nb1] = tot; bstart[nb1] = n; startg[nb1 * kSsGroups] = n; }
+}
+
+// One partition pass (cf. k_msd_part): block j belongs to group g = j % 8 and works that group's tile number j / 8.
+// The digit of record i is dig[i], left there by the counting kernel that sized the buckets (k_ss_count1 / k_ss_hist2):
+// the splitter search is done once per pass pair, 2 bytes per record carry it over.
+// kSeg = false (pass 1): tile t = records [t * tile, ...), digit = coarse bucket, cursors[g * nb1 + digit].
+// kSeg = true (pass 2): the tiles are those of the bucket list (tpre / bstart), digit = sub-bucket inside bucket b,
+//   cursors[g * gstride + b * F2 + digit].
+// Not stable.
+template <class Rec, bool kSeg>
+__global__ __launch_bounds__(kSsNT) void k_ss_part(const Rec *__restrict__ in, Rec *__restrict__ out, u32 n, const uint16_t *__restrict__ dig,
+                                                  u32 F2, u32 cpx, u32 ntiles, const u32 *__restrict__ tpre,
+                                                  const u32 *__restrict__ bstart, u32 nb1, const u32 *__restrict__ plan,
+                                                  u32 *__restrict__ cursors, u32 gstride) {
+  constexpr int NT = kSsNT, IPT = SsCfg<Rec>::IPT, T = NT * IPT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Rec *srec = reinterpret_cast<Rec *>(smem);
+  u32 *hist = reinterpret_cast<u32 *>(smem + sizeof(Rec) * T);                               // counts -> tile-exclusive prefix
+  u32 *gbase = hist + kSsMaxDig;                                                              // global start of the tile's run
+  u32 *tmp = gbase + kSsMaxDig;
+  uint16_t *sdig = reinterpret_cast<uint16_t *>(tmp + 64);                                    // digit of the record in srec[]
+  const u32 tid = threadIdx.x;
+  const u32 g = blockIdx.x % kSsGroups, idx = blockIdx.x / kSsGroups;
+  u32 begin, end, ndig;
+  u32 *cur = cursors + (size_t)g * gstride;
+  if (kSeg) {
+    const u32 cpx2 = plan[kMsdW_CPX2], t2 = plan[kMsdW_T2];
+    const u32 tile = g * cpx2 + idx;
+    if (idx >= cpx2 || tile >= t2) return;
+    const u32 b = msd_find_bucket(tpre, nb1, tile);
+    begin = bstart[b] + (tile - tpre[b]) * (u32)T;
+    end = min(begin + (u32)T, bstart[b + 1]);
+    cur += (size_t)b * F2;
+    ndig = F2;
+  } else {
+    const u32 tile = g * cpx + idx;
+    if (idx >= cpx || tile >= ntiles) return;
+    begin = tile * (u32)T;
+    end = min(n, begin + (u32)T);
+    ndig = nb1;
+  }
+  const u32 nvalid = end - begin;                  // >= 1
+  hist[tid] = 0;
+  __syncthreads();
+  Rec r[IPT];
+  u32 rk[IPT], dg[IPT];
+  // (clamped, not guarded: all loads in flight at once)
+#pragma unroll
+  for (int k = 0; k < IPT; k++) r[k] = in[begin + min((u32)(k * NT) + tid, nvalid - 1u)];
+#pragma unroll
+  for (int k = 0; k < IPT; k++) dg[k] = dig[begin + min((u32)(k * NT) + tid, nvalid - 1u)];
+#pragma unroll
+  for (int k = 0; k < IPT; k++) {
+    const u32 t = k * NT + tid;
+    rk[k] = t < nvalid ? atomicAdd(&hist[dg[k]], 1u) : 0u;
+  }
+  __syncthreads();
+  u32 cnt = 0;
+  if (tid < ndig) {
+    cnt = hist[tid];
+    if (cnt) gbase[tid] = atomicAdd(&cur[tid], cnt);
+  }
+  u32 tot;
+  const u32 ex = block_excl_scan<NT / 64>(cnt, tmp, tot);
+  hist[tid] = ex;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < IPT; k++) {
+    const u32 t = k * NT + tid;
+    if (t < nvalid) { const u32 q = hist[dg[k]] + rk[k]; srec[q] = r[k]; sdig[q] = (uint16_t)dg[k]; }
+  }
+  __syncthreads();
+  for (u32 q = tid; q < nvalid; q += NT) {
+    const u32 dd = sdig[q];
+    out[gbase[dd] + (q - hist[dd])] = srec[q];
+  }
+}
+
+// Sizes of the sub-buckets per group (cf. k_msd_hist2): block h counts the digits of its piece (kSsHistTiles pass-2
+// tiles) of bucket b and adds them to cnt2g[(b * F2 + digit) * 8 + g], g = the group that works the tile in pass 2.
+template <class Rec>
+__global__ __launch_bounds__(kSsNT) void k_ss_hist2(const Rec *__restrict__ in, const SsVal *__restrict__ fine, u32 F2, u32 tile,
+                                                   const u32 *__restrict__ tpre, const u32 *__restrict__ tpreh,
+                                                   const u32 *__restrict__ bstart, u32 nb1, const u32 *__restrict__ plan,
+                                                   u32 *__restrict__ cnt2g, uint16_t *__restrict__ dig) {
+  __shared__ SsVal spl[kSsMaxDig];
+  __shared__ u32 hist[kSsMaxDig];
+  if (blockIdx.x >= tpreh[nb1]) return;
+  const u32 tid = threadIdx.x;
+  const u32 cpx2 = plan[kMsdW_CPX2];
+  const u32 b = msd_find_bucket(tpreh, nb1, blockIdx.x);
+  const u32 hh = blockIdx.x - tpreh[b];
+  const u32 htile = tile * kSsHistTiles;
+  const u32 begin = bstart[b] + hh * htile;
+  const u32 end = min(begin + htile, bstart[b + 1]);
+  const u32 tile0 = tpre[b] + hh * kSsHistTiles;
+  u32 gcur = tile0 / cpx2;
+  const u32 steps = ss_steps(F2 - 1);
+  ss_stage(spl, fine + (size_t)b * F2, F2 - 1, steps);
+  hist[tid] = 0;
+  __syncthreads();
+  for (u32 pt = 0; pt < kSsHistTiles; pt++) {
+    const u32 pb = begin + pt * tile;
+    if (pb >= end) break;
+    const u32 pe = min(pb + tile, end);
+    const u32 g = (tile0 + pt) / cpx2;
+    if (g != gcur) {                                  // (block-uniform: at most 7 group changes in the whole array)
+      __syncthreads();
+      if (tid < F2 && hist[tid]) atomicAdd(&cnt2g[((size_t)b * F2 + tid) * kSsGroups + gcur], hist[tid]);
+      hist[tid] = 0;
+      __syncthreads();
+      gcur = g;
+    }
+    for (u32 i = pb + tid; i < pe; i += 8 * kSsNT) {
+      SsVal v[8];
+      u32 d[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) v[k] = ss_val(in[min(i + (u32)k * kSsNT, pe - 1u)]);
+      ss_count_le_multi<8>(spl, steps, v, d);
+#pragma unroll
+      for (int k = 0; k < 8; k++)
+        if (i + (u32)k * kSsNT < pe) { atomicAdd(&hist[d[k]], 1u); dig[i + (u32)k * kSsNT] = (uint16_t)d[k]; }
+    }
+  }
+  __syncthreads();
+  if (tid < F2 && hist[tid]) atomicAdd(&cnt2g[((size_t)b * F2 + tid) * kSsGroups + gcur], hist[tid]);
+}
+
+// Pass 3: block s orders sub-bucket s = records [start[8 s], start[8 (s + 1)]) (at most NT * IPT of them; larger ones
+// were refused on the host) and writes it to out at the same indices, ascending by (key, pos).
+//   1. the records go to LDS in arrival order; ns = 127 (255 above 2048 records) of them, spread over the arrival order,
+//      are ranked against each other — all pairs, the block's threads sharing the pairs — and become the bin boundaries
+//   2. every record finds its bin (the thread's IPT searches in lockstep) and its arrival number in the bin
+//   3. the bins are laid out in LDS; every record counts the smaller records of its bin: index = bin start + count
+template <class Rec, int NT, int IPT>
+__global__ __launch_bounds__(NT) void k_ss_local(const Rec *__restrict__ in, const u32 *__restrict__ start, Rec *__restrict__ out) {
+  constexpr int CAP = NT * IPT, NSMAX = 256;
+  static_assert(NT >= NSMAX && NT % NSMAX == 0, "threads share the candidate pairs");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Rec *A = reinterpret_cast<Rec *>(smem);                                   // CAP records
+  uint8_t *binid = reinterpret_cast<uint8_t *>(smem + sizeof(Rec) * CAP);   // bin of the record placed at A[q]
+  __shared__ SsVal cand[NSMAX], spl[NSMAX];
+  __shared__ u32 crank[NSMAX], cnt[NSMAX], cex[NSMAX + 1];
+  __shared__ u32 tmp[NT / 64];
+  const u32 tid = threadIdx.x;
+  const u32 begin = start[(size_t)blockIdx.x * kSsGroups], end = start[(size_t)(blockIdx.x + 1) * kSsGroups];
+  const u32 m = end - begin;
+  if (m == 0) return;
+  Rec r[IPT];
+  // (clamped, not guarded: all loads in flight at once)
+#pragma unroll
+  for (int k = 0; k < IPT; k++) r[k] = in[begin + min((u32)(k * NT) + tid, m - 1u)];
+#pragma unroll
+  for (int k = 0; k < IPT; k++) {
+    const u32 t = k * NT + tid;
+    if (t < m) A[t] = r[k];
+  }
+  if (tid < NSMAX) { cnt[tid] = 0; crank[tid] = 0; }
+  __syncthreads();
+  if (m <= (u32)NSMAX) {                    // small: every record counts the smaller ones directly
+    if (tid < m) {
+      const SsVal v = ss_val(r[0]);
+      u32 less = 0;
+      for (u32 j = 0; j < m; j++) less += ss_lt(ss_val(A[j]), v) ? 1u : 0u;
+      out[begin + less] = r[0];
+    }
+    return;
+  }
+  const u32 steps = m > 2048u ? 8u : 7u, ns = (1u << steps) - 1u;          // 255 / 127 boundaries
+  if (tid < ns) cand[tid] = ss_val(A[(u32)(((u64)tid * m) / ns)]);
+  __syncthreads();
+  {
+    // thread t compares candidate t % (ns + 1) with its share of the others
+    const u32 ci = tid & ns, part = tid >> steps, parts = (u32)NT >> steps, span = (ns + parts) / parts;
+    if (ci < ns) {
+      const SsVal v = cand[ci];
+      const u32 j0 = part * span, j1 = min(ns, j0 + span);
+      u32 less = 0;
+      for (u32 j = j0; j < j1; j++) less += ss_lt(cand[j], v) ? 1u : 0u;
+      if (less) atomicAdd(&crank[ci], less);
+    }
+  }
+  __syncthreads();
+  if (tid < ns) spl[crank[tid]] = cand[tid];
+  __syncthreads();
+  u32 bin[IPT], rk[IPT];
+  {
+    SsVal v[IPT];
+#pragma unroll
+    for (int k = 0; k < IPT; k++) v[k] = ss_val(r[k]);
+    ss_count_le_multi<IPT>(spl, steps, v, bin);                            // 0 .. ns
+  }
+#pragma unroll
+  for (int k = 0; k < IPT; k++) {
+    const u32 t = k * NT + tid;
+    rk[k] = t < m ? atomicAdd(&cnt[bin[k]], 1u) : 0u;
+  }
+  __syncthreads();
+  {
+    const u32 c = tid < NSMAX ? cnt[tid] : 0u;                             // bins 0 .. ns <= NSMAX - 1
+    u32 tot;
+    const u32 ex = block_excl_scan<NT / 64>(c, tmp, tot);
+    if (tid < NSMAX) cex[tid] = ex;
+    if (tid == NSMAX - 1) cex[NSMAX] = tot;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < IPT; k++) {
+    const u32 t = k * NT + tid;
+    if (t < m) { const u32 q = cex[bin[k]] + rk[k]; A[q] = r[k]; binid[q] = (uint8_t)bin[k]; }
+  }
+  __syncthreads();
+  for (u32 q = tid; q < m; q += NT) {
+    const Rec x = A[q];
+    const SsVal v = ss_val(x);
+    const u32 bb = binid[q];
+    const u32 lo = cex[bb], hi = cex[bb + 1];
+    u32 less = 0;
+    for (u32 j0 = lo; j0 < hi; j0 += 8) {                                  // (8 independent reads per round)
+      SsVal w[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) w[i] = ss_val(A[min(j0 + (u32)i, hi - 1u)]);
+#pragma unroll
+      for (int i = 0; i < 8; i++) less += (j0 + (u32)i < hi && ss_lt(w[i], v)) ? 1u : 0u;
+    }
+    out[begin + lo + less] = x;
+  }
+}
+
+}  // namespace dc3

@@ -26,6 +26,7 @@
 #include "../../include/dc3hip.h"
 #include "dc3_kernels.hip.hpp"
 #include "dc3_msd.hip.hpp"
+#include "dc3_ssort.hip.hpp"
 
 using namespace dc3;
 
@@ -97,6 +98,10 @@ struct dc3hip_ctx {
   bool no_xcd_map = false;     // DC3HIP_NO_XCD_MAP=1: window partitions without the segment -> XCD-group tile order (measurement aid)
   bool pack_fuse = false;      // DC3HIP_PACK_FUSE=1: whole-text order of bytes: the pack kernel only counts, partition pass 1 makes the records on the fly
   bool no_msd = false;         // DC3HIP_NO_MSD=1: the prefix sorts always run the stable LSD passes (no bucket ordering)
+  u32 ssort_mean = 1400;       // DC3HIP_SSORT_MEAN: records per sub-bucket the splitter ordering aims at (capacity 4096)
+  bool ssort_rec12 = false;    // DC3HIP_SSORT_REC12=1: the splitter ordering also for keys of at most 64 bits (tests)
+  bool no_ssort = false;       // DC3HIP_NO_SSORT=1: the straight orderings always run the stable LSD passes (no splitter ordering)
+  u32 ssort_min = 1u << 23;    // DC3HIP_SSORT_MIN: fewest records the splitter ordering is used for (tests lower it)
   u32 msd_min = 1u << 20;      // DC3HIP_MSD_MIN: fewest records the bucket ordering is used for (tests lower it)
   bool no_tup8 = false;        // DC3HIP_NO_TUP8=1: the slot table of the merge tuples is always 16 bytes per sample
   bool trace = false;          // DC3HIP_TRACE=1: per-level checksums of SA12 / SA0 / SA (dc3hip_stats.trace_*)
@@ -561,6 +566,125 @@ static int msd_redo(dc3hip_ctx *c, const MsdRedo &r, u32 n, Rec8 **result) {
   return E_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Splitter ordering of the sample-triple records (dc3_ssort.hip.hpp): the array radix_sort<Rec>(a, b, n, 0, kbits) makes
+// from records in position order, in two partition passes over sampled splitters + an in-LDS order of the sub-buckets.
+// *ok = false: not applied (too few records, switched off, or a sub-bucket beyond the local capacity — `a` is untouched
+// in every such case and the caller runs the LSD passes).
+// ---------------------------------------------------------------------------------------------
+static constexpr u32 kSsCap = 4096;
+// Measured on MI355X (1 GiB text, profiles/r03h_*): 318 M 16-byte records with 81-bit keys, 21 ms against 32 ms for the 63-bit
+// prefix + tie rounds (and 9 LSD passes for the straight order); 477 M 12-byte records with 45-bit keys, 28 ms against
+// 21 ms for the 5 LSD passes — so the keys of at most 64 bits stay with the LSD passes (DC3HIP_SSORT_REC12=1: tests).
+static bool ssort_applies(const dc3hip_ctx *c, u32 n, u32 kbits) {
+  return !c->no_ssort && n >= c->ssort_min && n >= 8192 && (kbits > 64 || c->ssort_rec12);
+}
+template <class Rec>
+static int ssort(dc3hip_ctx *c, Rec *a, Rec *b, u32 n, u32 kbits, Rec **result, bool *ok) {
+  *ok = false; *result = nullptr;
+  if (!ssort_applies(c, n, kbits)) return E_OK;
+  constexpr int IPT = SsCfg<Rec>::IPT;
+  constexpr u32 tile = (u32)kSsNT * IPT, htile = tile * kSsHistTiles;
+  constexpr int kLocNT = 512, kLocIPT = (int)(kSsCap / kLocNT);
+  constexpr size_t part_smem = ss_part_smem<Rec>(), loc_smem = sizeof(Rec) * kSsCap + kSsCap;
+  static std::atomic<bool> attr_set[16];
+  if (!attr_set[c->device & 15]) {
+    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ss_part<Rec, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_smem));
+    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ss_part<Rec, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_smem));
+    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ss_local<Rec, kLocNT, kLocIPT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)loc_smem));
+    attr_set[c->device & 15] = true;
+  }
+  // geometry: nb1 coarse buckets x F2 sub-buckets of about kSsMeanTarget records
+  const u64 want = ((u64)n + c->ssort_mean - 1) / c->ssort_mean;           // sub-buckets
+  u32 nb1 = kSsMaxDig, F2 = (u32)((want + nb1 - 1) / nb1);
+  if (F2 < 2) { F2 = 2; nb1 = (u32)std::max<u64>(2, (want + 1) / 2); }
+  if (F2 > kSsMaxDig) return E_OK;                                         // (beyond 1.4e9 records: not reachable with u32 n)
+  const u32 n2 = nb1 * F2, S = n2 * kSsOver;
+  if ((u64)S * 4 > n) return E_OK;
+  const u32 ntiles1 = (n + tile - 1) / tile, cpx1 = (ntiles1 + kSsGroups - 1) / kSsGroups;
+  const u32 tpb = std::max<u32>(1, (cpx1 + 255) / 256);
+  const ArenaMark mk = arena_mark(c);
+  Rec *sa = nullptr, *sb = nullptr, *ss = nullptr;
+  SsVal *fine = nullptr, *coarse = nullptr;
+  u32 *cntg = nullptr, *startg = nullptr, *cur1 = nullptr, *bstart = nullptr, *tpre = nullptr, *tpreh = nullptr, *plan = nullptr, *segsum = nullptr;
+  u32 *cnt2g = nullptr, *cur2 = nullptr;
+  uint16_t *dig = nullptr;
+  const size_t N2 = (size_t)n2 * kSsGroups;
+  RC(arena_alloc(c, (size_t)S, &sa)); RC(arena_alloc(c, (size_t)S, &sb));
+  RC(arena_alloc(c, (size_t)n2 + 16, &fine)); RC(arena_alloc(c, (size_t)kSsMaxDig + 16, &coarse));
+  RC(arena_alloc(c, (size_t)nb1 * kSsGroups + 16, &cntg));
+  RC(arena_alloc(c, (size_t)nb1 * kSsGroups + 16, &startg));
+  RC(arena_alloc(c, (size_t)nb1 * kSsGroups + 16, &cur1));
+  RC(arena_alloc(c, (size_t)nb1 + 16, &bstart)); RC(arena_alloc(c, (size_t)nb1 + 16, &tpre)); RC(arena_alloc(c, (size_t)nb1 + 16, &tpreh));
+  RC(arena_alloc(c, (size_t)kMsdW_COUNT + 12, &plan)); RC(arena_alloc(c, (size_t)1024 + 16, &segsum));
+  RC(arena_alloc(c, N2 + 16, &cnt2g)); RC(arena_alloc(c, N2 + 16, &cur2));
+  RC(arena_alloc(c, (size_t)n + 16, &dig));
+  {
+    PhaseScope ps(c, DC3HIP_PH_SORT12_UP, S);
+    hipLaunchKernelGGL((k_ss_sample<Rec>), dim3((S + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, (const Rec *)a, n, S, sa);
+    KCHECK();
+  }
+  RC(radix_sort<Rec>(c, sa, sb, S, 0, kbits, &ss, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT12_DOWN));
+  {
+    PhaseScope ps(c, DC3HIP_PH_SORT12_UP, n);
+    hipLaunchKernelGGL((k_ss_splitters<Rec>), dim3((n2 + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, (const Rec *)ss, n2, F2, fine, coarse);
+    KCHECK();
+    HIPC(hipMemsetAsync(cntg, 0, ((size_t)nb1 * kSsGroups + 16) * sizeof(u32), c->stream));
+    HIPC(hipMemsetAsync(plan, 0, (kMsdW_COUNT + 12) * sizeof(u32), c->stream));
+    HIPC(hipMemsetAsync(cnt2g, 0, (N2 + 1) * sizeof(u32), c->stream));
+    hipLaunchKernelGGL((k_ss_count1<Rec>), dim3(kSsGroups * ((cpx1 + tpb - 1) / tpb)), dim3(kSsNT), 0, c->stream, (const Rec *)a, n,
+                       (const SsVal *)coarse, nb1, tile, cpx1, ntiles1, tpb, cntg, dig);
+    KCHECK();
+  }
+  {
+    PhaseScope ps(c, DC3HIP_PH_SORT12_SCAN, nb1);
+    hipLaunchKernelGGL(k_ss_plan1, dim3(1), dim3(1024), 0, c->stream, (const u32 *)cntg, nb1, n, tile, htile, startg, cur1, bstart, tpre, tpreh, plan);
+    KCHECK();
+  }
+  {
+    PhaseScope ps(c, DC3HIP_PH_SORT12_DOWN, n, 7);
+    hipLaunchKernelGGL((k_ss_part<Rec, false>), dim3(kSsGroups * cpx1), dim3(kSsNT), part_smem, c->stream, (const Rec *)a, b, n,
+                       (const uint16_t *)dig, F2, cpx1, ntiles1, (const u32 *)nullptr, (const u32 *)nullptr, nb1, (const u32 *)plan, cur1, nb1);
+    KCHECK();
+  }
+  const u32 nseg = (u32)((N2 + kMsdScanSeg - 1) / kMsdScanSeg);              // <= 1024
+  {
+    PhaseScope ps(c, DC3HIP_PH_SORT12_UP, n);
+    hipLaunchKernelGGL((k_ss_hist2<Rec>), dim3(n / htile + nb1 + 1), dim3(kSsNT), 0, c->stream, (const Rec *)b, (const SsVal *)fine, F2, tile,
+                       (const u32 *)tpre, (const u32 *)tpreh, (const u32 *)bstart, nb1, (const u32 *)plan, cnt2g, dig);
+    KCHECK();
+  }
+  {
+    PhaseScope ps(c, DC3HIP_PH_SORT12_SCAN, N2);
+    hipLaunchKernelGGL(k_msd_scan2a, dim3(nseg), dim3(1024), 0, c->stream, (const u32 *)cnt2g, (u32)N2, segsum, plan);
+    KCHECK();
+    hipLaunchKernelGGL(k_msd_scan2c, dim3(nseg), dim3(1024), 0, c->stream, cnt2g, (u32)N2, n2, (const u32 *)segsum, cur2);
+    KCHECK();
+    HIPC(hipMemcpyAsync(c->h_words + 20, plan, kMsdW_COUNT * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPC(hipStreamSynchronize(c->stream));
+  const u32 maxsub = c->h_words[20 + kMsdW_MAXSUB];
+  c->stats.ssort_max_subbucket = maxsub;
+  if (maxsub > kSsCap) { c->stats.ssort_fallbacks++; arena_release(c, mk); return E_OK; }     // (a is still the input)
+  {
+    PhaseScope ps(c, DC3HIP_PH_SORT12_DOWN, n, 7);
+    const u32 grid2 = kSsGroups * ((n / tile + nb1 + 1 + kSsGroups - 1) / kSsGroups);
+    hipLaunchKernelGGL((k_ss_part<Rec, true>), dim3(grid2), dim3(kSsNT), part_smem, c->stream, (const Rec *)b, a, n, (const uint16_t *)dig, F2, 0u, 0u,
+                       (const u32 *)tpre, (const u32 *)bstart, nb1, (const u32 *)plan, cur2, n2);
+    KCHECK();
+  }
+  {
+    PhaseScope ps(c, DC3HIP_PH_SORT12_DOWN, n, 8);
+    hipLaunchKernelGGL((k_ss_local<Rec, kLocNT, kLocIPT>), dim3(n2), dim3(kLocNT), loc_smem, c->stream, (const Rec *)a, (const u32 *)cnt2g, b);
+    KCHECK();
+  }
+  c->stats.ssort_sorts++;
+  arena_release(c, mk);        // (the stream orders the kernels above before whatever reuses the scratch)
+  *result = b;
+  *ok = true;
+  return E_OK;
+}
+
 // Digit table of a pack kernel (k_pack_image_*): bins, chunking and which image bits it counts.
 // mg (bucket ordering, msd_geometry): the table counts the TOP mg->d1 image bits in mg's chunking instead (1024 rows).
 static void pack_plan(dc3hip_ctx *c, u32 nrec, const HiMap &hm, const MsdGeom *mg, int *nb, Chunking *ck, u32 *hshift) {
@@ -872,8 +996,11 @@ static int order_straight(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u
                          b, recA, ck.chunk, ck.nchunks, first_table);
     KCHECK();
   }
-  RC(radix_sort<Rec>(c, recA, recB, m02, 0, kbits, &sorted, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN,
-                     DC3HIP_PH_SORT12_DOWN, first_table));
+  bool by_splitters = false;
+  RC(ssort<Rec>(c, recA, recB, m02, kbits, &sorted, &by_splitters));
+  if (!by_splitters)
+    RC(radix_sort<Rec>(c, recA, recB, m02, 0, kbits, &sorted, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN,
+                       DC3HIP_PH_SORT12_DOWN, first_table));
   AccRec<Rec> acc; acc.s = sorted;
   return name_and_rank<AccRec<Rec>>(c, acc, m02, m0, sa12, rank12, R, sslot, names, mode);
 }
@@ -1781,7 +1908,8 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
         if (!ok) arena_release(c, mk1);
       }
     }
-    if (!done && kbits > 64 && m02 >= c->hybrid12_min && !c->no_hybrid && !c->no_hybrid12) {
+    // (with the splitter ordering the full 96-bit key costs three passes: no prefix + tie rounds then)
+    if (!done && kbits > 64 && m02 >= c->hybrid12_min && !c->no_hybrid && !c->no_hybrid12 && !ssort_applies(c, m02, kbits)) {
       // wide keys whose 34-bit image collides everywhere: try the 63-bit prefix on 12-byte records
       bool ok = false;
       RC(order_hybrid12<Sym>(c, S, m, m0, m02, b, kbits, sa12, rank12, R, sslot, &names, &mode, &ok, depth));
@@ -1897,6 +2025,8 @@ static int build_end(dc3hip_ctx *c) {
       if (m.kclass == 3) { c->stats.partition_ms += t; c->stats.partition_launches += 1; c->stats.partition_elems += m.elems; }
       if (m.kclass == 5) { c->stats.msd_part_ms += t; c->stats.msd_part_launches += 1; c->stats.msd_part_elems += m.elems; }
       if (m.kclass == 6) { c->stats.msd_local_ms += t; c->stats.msd_local_launches += 1; c->stats.msd_local_elems += m.elems; }
+      if (m.kclass == 7) { c->stats.ssort_part_ms += t; c->stats.ssort_part_launches += 1; c->stats.ssort_part_elems += m.elems; }
+      if (m.kclass == 8) { c->stats.ssort_local_ms += t; c->stats.ssort_local_launches += 1; c->stats.ssort_local_elems += m.elems; }
       if (m.kclass >= 0 && m.kclass < 3) {
         c->stats.downsweep_ms[m.kclass] += t; c->stats.downsweep_launches[m.kclass] += 1;
         c->stats.downsweep_elems[m.kclass] += m.elems;
@@ -2213,6 +2343,10 @@ int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) {
   { const char *e = getenv("DC3HIP_NO_XCD_MAP"); c->no_xcd_map = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_TUP_SCATTER"); c->no_tup_scatter = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_MSD_MIN"); if (e) c->msd_min = (u32)std::max(4096ll, atoll(e)); }
+  { const char *e = getenv("DC3HIP_NO_SSORT"); c->no_ssort = (e && e[0] == '1'); }
+  { const char *e = getenv("DC3HIP_SSORT_REC12"); c->ssort_rec12 = (e && e[0] == '1'); }
+  { const char *e = getenv("DC3HIP_SSORT_MEAN"); if (e) c->ssort_mean = (u32)std::min(2000ll, std::max(300ll, atoll(e))); }
+  { const char *e = getenv("DC3HIP_SSORT_MIN"); if (e) c->ssort_min = (u32)std::max(8192ll, atoll(e)); }
   { const char *e = getenv("DC3HIP_NO_HYBRID12"); c->no_hybrid12 = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_HYBRID8"); c->no_hybrid8 = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_HYBRID12_MIN"); if (e) c->hybrid12_min = (u32)std::max(0ll, atoll(e)); }

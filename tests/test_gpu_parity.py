@@ -664,6 +664,58 @@ def test_bucket_ordering_matches_the_stable_passes(ss, oracle):
                     os.environ.pop(k, None)
 
 
+def test_splitter_ordering_matches_the_stable_passes(ss, oracle):
+    """The splitter (sample) ordering of the 12- and 16-byte sample-triple records (dc3_ssort.hip.hpp: partition passes
+    over sampled splitters + in-LDS comparison order of the sub-buckets) against the stable LSD passes it replaces
+    (DC3HIP_NO_SSORT=1): same suffix array, equal to divsufsort's.  Inputs that reach the straight orderings with skewed
+    and heavily repeated keys: generated low-entropy text, a period-2 and a period-7 text (every key of a level occurs
+    thousands of times: only the position separates the records), three symbols at random, Fibonacci-like repeats, bytes
+    through the recursion; the threshold lowered so that every level above 8192 samples takes the path, and the default
+    threshold on a text large enough for it."""
+    rng = np.random.default_rng(123)
+    cases = {}
+    cases["text"] = oracle.gen(5_000_003, 5, 2)
+    cases["period2"] = np.frombuffer(b"ab" * 1_500_000 + b"c", dtype=np.uint8).copy()
+    cases["period7"] = np.frombuffer(b"abcabca" * 500_000, dtype=np.uint8).copy()
+    cases["three_symbols"] = rng.integers(0, 3, size=4_000_001).astype(np.uint8)
+    fib_a, fib_b = b"a", b"ab"
+    while len(fib_b) < 3_000_000:
+        fib_a, fib_b = fib_b, fib_b + fib_a
+    cases["fibonacci"] = np.frombuffer(fib_b, dtype=np.uint8).copy()
+    cases["bytes"] = rng.integers(0, 256, size=3_000_017, dtype=np.uint8)
+    blocks = rng.integers(97, 101, size=(40, 3000), dtype=np.uint8)
+    cases["shuffled_blocks"] = blocks[rng.integers(0, 40, size=1200)].reshape(-1).copy()
+    for label, arr in cases.items():
+        data = arr.tobytes()
+        want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)
+        for env in ({"DC3HIP_SSORT_MIN": "8192"}, {"DC3HIP_SSORT_MIN": "8192", "DC3HIP_SSORT_REC12": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1"},
+                    {"DC3HIP_SSORT_MIN": "8192", "DC3HIP_SSORT_REC12": "1", "DC3HIP_NO_HYBRID": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1"},
+                    {"DC3HIP_SSORT_MIN": "8192", "DC3HIP_NO_REC12": "1", "DC3HIP_NO_HYBRID": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1"},
+                    {"DC3HIP_NO_SSORT": "1"}):
+            os.environ.update(env)
+            try:
+                with ss.Context(len(data)) as c:
+                    c.set_text(data); c.build()
+                    st = c.stats()
+                    assert np.array_equal(c.sa(), want), (label, env)
+                    assert st["ssort_fallbacks"] == 0, (label, env, st["ssort_max_subbucket"])
+                    if "DC3HIP_NO_SSORT" in env:
+                        assert st["ssort_sorts"] == 0
+                    elif "DC3HIP_NO_HYBRID" in env:
+                        assert st["ssort_sorts"] >= 1, (label, env)
+            finally:
+                for k in env:
+                    os.environ.pop(k, None)
+    # the default threshold
+    data = oracle.gen(40_000_000, 9, 2).tobytes()
+    want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)
+    with ss.Context(len(data)) as c:
+        c.set_text(data); c.build()
+        st = c.stats()
+        assert np.array_equal(c.sa(), want)
+        assert st["ssort_sorts"] >= 1 and st["ssort_fallbacks"] == 0, st["level_sorted"]
+
+
 def test_deep_tie_pass_then_doubling_on_12_byte_records(ss, oracle):
     """Regression (round-2 advisor finding): on 12-byte records the second, deeper tie pass leaves f[] marking groups that
     agree on 2048 symbols; the prefix doubling that follows must look ranks up at the same depth.  The case that broke:
