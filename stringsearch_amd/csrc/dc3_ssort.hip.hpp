@@ -81,6 +81,30 @@ __device__ __forceinline__ void ss_stage(SsVal *spl, const SsVal *__restrict__ g
 }
 __device__ __forceinline__ u32 ss_steps(u32 ns) { u32 s = 1; while (((1u << s) - 1u) < ns) s++; return s; }   // ns >= 1
 
+// Wide windows: the record of sample position p holds W > 3 symbols, sb bits each, first symbol most significant (the
+// 96-bit key of Rec16).  Names taken from such records refine the triple names of lib.rs:80-100 — equal windows imply
+// equal triples — and order the sample suffixes just as well: comparing (W(p), W(p+3), ...) with (W(q), W(q+3), ...) is
+// comparing the suffixes at p and q, the windows that reach past the end are distinct (they differ in where their first
+// sentinel is), so the recursion of lib.rs:104 is entered with fewer repeated names, or not at all.
+__device__ __forceinline__ Rec16 ss_window_rec(const u32 *s, u32 W, u32 sb, u32 pos) {
+  u64 lo = 0; u32 hi = 0;
+  for (u32 j = 0; j < W; j++) { hi = (hi << sb) | (u32)(lo >> (64 - sb)); lo = (lo << sb) | s[j]; }
+  Rec16 r; r.k0 = (u32)lo; r.k1 = (u32)(lo >> 32); r.k2 = hi; r.pos = pos;
+  return r;
+}
+// records of the sample positions in position order (k_pack_triples with W symbols): thread g makes those of 3g+1, 3g+2
+template <class Sym, int W>
+__global__ __launch_bounds__(kBlock) void k_pack_window16(Sym S, u32 m, u32 m02, u32 sb, Rec16 *__restrict__ out) {
+  const u32 g = blockIdx.x * kBlock + threadIdx.x;
+  if (2 * g >= m02) return;
+  const u32 i = 3 * g + 1;
+  u32 s[W + 1];
+#pragma unroll
+  for (int j = 0; j <= W; j++) s[j] = S.get(i + j);
+  out[2 * g] = ss_window_rec(s, W, sb, i);
+  if (2 * g + 1 < m02) out[2 * g + 1] = ss_window_rec(s + 1, W, sb, i + 1);
+}
+
 // sample[i] = the record at input index (i + 1/2) * n / S: ascending input indices, i.e. ascending pos
 template <class Rec>
 __global__ __launch_bounds__(kBlock) void k_ss_sample(const Rec *__restrict__ in, u32 n, u32 S, Rec *__restrict__ out) {

@@ -99,6 +99,7 @@ struct dc3hip_ctx {
   bool pack_fuse = false;      // DC3HIP_PACK_FUSE=1: whole-text order of bytes: the pack kernel only counts, partition pass 1 makes the records on the fly
   bool no_msd = false;         // DC3HIP_NO_MSD=1: the prefix sorts always run the stable LSD passes (no bucket ordering)
   u32 ssort_mean = 1400;       // DC3HIP_SSORT_MEAN: records per sub-bucket the splitter ordering aims at (capacity 4096)
+  bool no_wide_window = false; // DC3HIP_NO_WIDE_WINDOW=1: straight orderings always sort the triple (no wider window)
   bool ssort_rec12 = false;    // DC3HIP_SSORT_REC12=1: the splitter ordering also for keys of at most 64 bits (tests)
   bool no_ssort = false;       // DC3HIP_NO_SSORT=1: the straight orderings always run the stable LSD passes (no splitter ordering)
   u32 ssort_min = 1u << 23;    // DC3HIP_SSORT_MIN: fewest records the splitter ordering is used for (tests lower it)
@@ -1003,6 +1004,40 @@ static int order_straight(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u
                        DC3HIP_PH_SORT12_DOWN, first_table));
   AccRec<Rec> acc; acc.s = sorted;
   return name_and_rank<AccRec<Rec>>(c, acc, m02, m0, sa12, rank12, R, sslot, names, mode);
+}
+
+// Straight ordering with a wider window than the triple (dc3_ssort.hip.hpp): W = floor(96 / sb) symbols (4..7) in
+// 16-byte records, ordered by the splitter ordering whose cost does not depend on the key width.  For the levels whose
+// triples repeat everywhere (text: the 3-symbol names of level 0 make a level-1 string whose triples are 9 characters):
+// their names would send a string of the same length down the recursion; W symbols settle most samples here.
+static u32 wide_window_syms(const dc3hip_ctx *c, u32 m02, u64 K) {
+  const u32 sb = bits_of(K);
+  if (c->no_wide_window || c->no_hybrid || !ssort_applies(c, m02, 96) || sb > 24) return 0;
+  return std::min<u32>(7, 96 / sb);             // (the zero tail behind a level's string is 8 symbols)
+}
+template <class Sym>
+static int order_wide(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 sb, u32 W, u32 *sa12, u32 *rank12, u32 *R,
+                      u32 *sslot, u32 *names, int *mode) {
+  Rec16 *recA = nullptr, *recB = nullptr, *sorted = nullptr;
+  RC(arena_alloc(c, (size_t)m02, &recA));
+  RC(arena_alloc(c, (size_t)m02, &recB));
+  {
+    PhaseScope ps(c, DC3HIP_PH_PACK, m02);
+    const dim3 grid((m02 / 2 + kBlock) / kBlock);
+    switch (W) {
+      case 4: hipLaunchKernelGGL((k_pack_window16<Sym, 4>), grid, dim3(kBlock), 0, c->stream, S, m, m02, sb, recA); break;
+      case 5: hipLaunchKernelGGL((k_pack_window16<Sym, 5>), grid, dim3(kBlock), 0, c->stream, S, m, m02, sb, recA); break;
+      case 6: hipLaunchKernelGGL((k_pack_window16<Sym, 6>), grid, dim3(kBlock), 0, c->stream, S, m, m02, sb, recA); break;
+      default: hipLaunchKernelGGL((k_pack_window16<Sym, 7>), grid, dim3(kBlock), 0, c->stream, S, m, m02, sb, recA); break;
+    }
+    KCHECK();
+  }
+  bool by_splitters = false;
+  RC(ssort<Rec16>(c, recA, recB, m02, W * sb, &sorted, &by_splitters));
+  if (!by_splitters)
+    RC(radix_sort<Rec16>(c, recA, recB, m02, 0, W * sb, &sorted, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT12_DOWN));
+  AccRec<Rec16> acc; acc.s = sorted;
+  return name_and_rank<AccRec<Rec16>>(c, acc, m02, m0, sa12, rank12, R, sslot, names, mode);
 }
 
 static constexpr u32 kDeepSyms = 2048;                     // symbols compared by the second tie pass of a whole-text order
@@ -1917,6 +1952,15 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
       if (!ok) arena_release(c, mk1);
     }
     if (!done) {
+      const u32 W = wide_window_syms(c, m02, K);
+      if (W > 3) {
+        c->stats.level_sorted[depth] = 1;
+        c->stats.level_name_width[depth] = (int32_t)W;
+        RC((order_wide<Sym>(c, S, m, m0, m02, bits_of(K), W, sa12, rank12, R, sslot, &names, &mode)));
+        done = true;
+      }
+    }
+    if (!done) {
       c->stats.level_sorted[depth] = 1;
       if (kbits <= 64 && !c->no_rec12)
         RC((order_straight<Sym, Rec12>(c, S, m, m0, m02, b, kbits, sa12, rank12, R, sslot, &names, &mode)));
@@ -2345,6 +2389,7 @@ int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) {
   { const char *e = getenv("DC3HIP_MSD_MIN"); if (e) c->msd_min = (u32)std::max(4096ll, atoll(e)); }
   { const char *e = getenv("DC3HIP_NO_SSORT"); c->no_ssort = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_SSORT_REC12"); c->ssort_rec12 = (e && e[0] == '1'); }
+  { const char *e = getenv("DC3HIP_NO_WIDE_WINDOW"); c->no_wide_window = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_SSORT_MEAN"); if (e) c->ssort_mean = (u32)std::min(2000ll, std::max(300ll, atoll(e))); }
   { const char *e = getenv("DC3HIP_SSORT_MIN"); if (e) c->ssort_min = (u32)std::max(8192ll, atoll(e)); }
   { const char *e = getenv("DC3HIP_NO_HYBRID12"); c->no_hybrid12 = (e && e[0] == '1'); }

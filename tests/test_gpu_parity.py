@@ -671,7 +671,8 @@ def test_splitter_ordering_matches_the_stable_passes(ss, oracle):
     and heavily repeated keys: generated low-entropy text, a period-2 and a period-7 text (every key of a level occurs
     thousands of times: only the position separates the records), three symbols at random, Fibonacci-like repeats, bytes
     through the recursion; the threshold lowered so that every level above 8192 samples takes the path, and the default
-    threshold on a text large enough for it."""
+    threshold on a text large enough for it.  The same runs cover the wide-window ordering (4-7 symbols per record
+    instead of the triple, order_wide) and its off switch."""
     rng = np.random.default_rng(123)
     cases = {}
     cases["text"] = oracle.gen(5_000_003, 5, 2)
@@ -691,6 +692,8 @@ def test_splitter_ordering_matches_the_stable_passes(ss, oracle):
         for env in ({"DC3HIP_SSORT_MIN": "8192"}, {"DC3HIP_SSORT_MIN": "8192", "DC3HIP_SSORT_REC12": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1"},
                     {"DC3HIP_SSORT_MIN": "8192", "DC3HIP_SSORT_REC12": "1", "DC3HIP_NO_HYBRID": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1"},
                     {"DC3HIP_SSORT_MIN": "8192", "DC3HIP_NO_REC12": "1", "DC3HIP_NO_HYBRID": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1"},
+                    {"DC3HIP_SSORT_MIN": "8192", "DC3HIP_SSORT_REC12": "1", "DC3HIP_NO_WIDE_WINDOW": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1"},
+                    {"DC3HIP_SSORT_MIN": "8192", "DC3HIP_NO_DISCARD": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1"},
                     {"DC3HIP_NO_SSORT": "1"}):
             os.environ.update(env)
             try:
@@ -701,7 +704,7 @@ def test_splitter_ordering_matches_the_stable_passes(ss, oracle):
                     assert st["ssort_fallbacks"] == 0, (label, env, st["ssort_max_subbucket"])
                     if "DC3HIP_NO_SSORT" in env:
                         assert st["ssort_sorts"] == 0
-                    elif "DC3HIP_NO_HYBRID" in env:
+                    elif "DC3HIP_NO_HYBRID" in env and "DC3HIP_SSORT_REC12" in env:
                         assert st["ssort_sorts"] >= 1, (label, env)
             finally:
                 for k in env:
@@ -714,6 +717,7 @@ def test_splitter_ordering_matches_the_stable_passes(ss, oracle):
         st = c.stats()
         assert np.array_equal(c.sa(), want)
         assert st["ssort_sorts"] >= 1 and st["ssort_fallbacks"] == 0, st["level_sorted"]
+        assert max(st["level_name_width"]) >= 4, st["level_name_width"]          # a wide-window level
 
 
 def test_deep_tie_pass_then_doubling_on_12_byte_records(ss, oracle):
