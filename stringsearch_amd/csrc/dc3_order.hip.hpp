@@ -60,12 +60,29 @@ struct AccBound {
   __device__ __forceinline__ u32 neq(u32 i) const { return i == 0 ? (first_eq ? 0u : 1u) : a.neq(i); }
   __device__ __forceinline__ u32 tail_differs() const { return last_eq_next ? 0u : 1u; }
 };
+// flag of entry i + 1 for every lane of a wave whose lane l holds entry i = row + l and that entry's flag f (f_nextrow:
+// the flags of the 64 entries behind this row when the caller has them, else pass have_next = false): the neighbour
+// lane's flag where there is one, a direct comparison at the end of the row / range
+template <class Acc>
+__device__ __forceinline__ u32 next_flag(const Acc &acc, u32 i, u32 n, u32 end, u32 f, bool have_next, u32 f_nextrow) {
+  u32 fn = __shfl_down(f, 1);
+  const u32 f0 = __shfl(f_nextrow, 0);
+  const bool from_lanes = lane_id() < 63u ? (i + 1 < end) : (have_next && i + 1 < end);
+  if (lane_id() == 63u) fn = f0;
+  if (!from_lanes) fn = (i + 1 >= n) ? (i + 1 == n ? acc.tail_differs() : 0u) : acc.neq(i + 1);
+  return fn;
+}
 template <class Acc>
 __global__ __launch_bounds__(kBlock) void k_name_count(Acc acc, u32 n, u32 chunk, u32 *counts, u32 *uniq_total) {
   __shared__ u32 tmp[kWaves], tmpu[kWaves];
   const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
   u32 c = 0, u = 0;
-  for (u32 i = begin + threadIdx.x; i < end; i += kBlock) { c += acc.neq(i); u += acc_unique(acc, i, n); }
+  for (u32 base = begin; base < end; base += kBlock) {        // (chunk is a multiple of kBlock: whole waves)
+    const u32 i = base + threadIdx.x;
+    const u32 f = i < end ? acc.neq(i) : 0u;
+    const u32 fn = next_flag(acc, i, n, end, f, false, 0u);
+    c += f; u += (i < end) ? (f & fn) : 0u;
+  }
   c = wave_reduce(c); u = wave_reduce(u);
   if (lane_id() == 0) { tmp[wave_id()] = c; tmpu[wave_id()] = u; }
   __syncthreads();
@@ -78,6 +95,8 @@ __global__ __launch_bounds__(kBlock) void k_name_count(Acc acc, u32 n, u32 chunk
 }
 // sslot (optional, discarding recursion): sslot[i] = slot(pos_i) | unique_i << 31, and the pair value
 // carries the same unique bit (names < 2^31 on that path).
+// A wave works 64 * kNameIPT consecutive entries as kNameIPT rows of 64 (coalesced record reads); the running name
+// inside the wave comes from ballots, the waves' sums meet in LDS once per tile.
 constexpr u32 kUniqBit = 0x80000000u;
 template <class Acc>
 __global__ __launch_bounds__(kBlock) void k_name_assign(Acc acc, u32 n, u32 chunk, const u32 *__restrict__ base_excl,
@@ -85,26 +104,40 @@ __global__ __launch_bounds__(kBlock) void k_name_assign(Acc acc, u32 n, u32 chun
   __shared__ u32 tmp[kWaves];
   const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
   u32 running = base_excl[blockIdx.x];
-  constexpr u32 kTile = kBlock * kNameIPT;
+  constexpr u32 kTile = kBlock * kNameIPT, kWaveItems = 64 * kNameIPT;
+  const u32 lane = lane_id(), w = wave_id();
   for (u32 tile = begin; tile < end; tile += kTile) {
-    const u32 i0 = tile + threadIdx.x * kNameIPT;
-    u32 f[kNameIPT];
-    u32 local = 0;
-#pragma unroll
-    for (int j = 0; j < kNameIPT; j++) { f[j] = (i0 + j < end) ? acc.neq(i0 + j) : 0u; local += f[j]; }
-    u32 tot;
-    u32 name = running + block_excl_scan<kWaves>(local, tmp, tot);
+    const u32 wb = tile + w * kWaveItems;
+    u32 f[kNameIPT], pre[kNameIPT];
+    u32 wsum = 0;
 #pragma unroll
     for (int j = 0; j < kNameIPT; j++) {
-      if (i0 + j < end) {
-        name += f[j];
-        const u32 sl = slot_of(acc.pos(i0 + j), m0);
+      const u32 i = wb + j * 64 + lane;
+      f[j] = (i < end) ? acc.neq(i) : 0u;
+      const u64 b = __ballot(f[j] != 0u);
+      pre[j] = wsum + mbcnt(b) + f[j];             // flags among the wave's entries up to and including i
+      wsum += (u32)__popcll(b);
+    }
+    if (lane == 0) tmp[w] = wsum;
+    __syncthreads();
+    u32 woff = 0, tot = 0;
+#pragma unroll
+    for (int x = 0; x < kWaves; x++) { const u32 t = tmp[x]; if ((u32)x < w) woff += t; tot += t; }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kNameIPT; j++) {
+      const u32 i = wb + j * 64 + lane;
+      u32 fn = 0;
+      if (sslot) fn = next_flag(acc, i, n, end, f[j], j + 1 < kNameIPT, j + 1 < kNameIPT ? f[j + 1 < kNameIPT ? j + 1 : j] : 0u);
+      if (i < end) {
+        const u32 name = running + woff + pre[j];
+        const u32 sl = slot_of(acc.pos(i), m0);
         if (sslot) {
-          const u32 ub = acc_unique(acc, i0 + j, n) ? kUniqBit : 0u;
-          sslot[i0 + j] = sl | ub;
-          pairs[i0 + j] = Rec8{sl, name | ub};
+          const u32 ub = (f[j] & fn) ? kUniqBit : 0u;
+          sslot[i] = sl | ub;
+          pairs[i] = Rec8{sl, name | ub};
         } else {
-          pairs[i0 + j] = Rec8{sl, name};
+          pairs[i] = Rec8{sl, name};
         }
       }
     }
