@@ -186,18 +186,48 @@ __global__ __launch_bounds__(kBlock) void k_keep_count(const u32 *__restrict__ R
   for (u32 p = begin + threadIdx.x; p < end; p += kBlock) c += keep_slot(RU, p) ? 1u : 0u;
   block_count_store(c, tmp, counts);
 }
+// Order-preserving selection inside a block: a tile is kBlock * kSelRows consecutive entries, wave w owns
+// [tile + w * 64 * kSelRows, ...) as kSelRows rows of 64 (entry of row j, lane l: + j * 64 + l).  From the flags of the
+// thread's kSelRows entries: ex[j] = selected entries of the tile before that entry, tot = selected entries of the tile
+// (ballots inside the wave, one LDS exchange per tile).  tmp: kWaves words.
+constexpr int kSelRows = 4;
+constexpr u32 kSelTile = kBlock * kSelRows, kSelWave = 64 * kSelRows;
+__device__ __forceinline__ void block_select_rows(const bool (&f)[kSelRows], u32 (&ex)[kSelRows], u32 *tmp, u32 &tot) {
+  u32 wsum = 0;
+#pragma unroll
+  for (int j = 0; j < kSelRows; j++) {
+    const u64 b = __ballot(f[j]);
+    ex[j] = wsum + mbcnt(b);
+    wsum += (u32)__popcll(b);
+  }
+  if (lane_id() == 0) tmp[wave_id()] = wsum;
+  __syncthreads();
+  u32 woff = 0, t = 0;
+#pragma unroll
+  for (int x = 0; x < kWaves; x++) { const u32 v = tmp[x]; if ((u32)x < wave_id()) woff += v; t += v; }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kSelRows; j++) ex[j] += woff;
+  tot = t;
+}
 __global__ __launch_bounds__(kBlock) void k_keep_write(const u32 *__restrict__ RU, u32 n, u32 chunk,
                                                       const u32 *__restrict__ base_excl, u32 *__restrict__ Rp,
                                                       u32 *__restrict__ kept) {
   __shared__ u32 tmp[kWaves];
   const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
   u32 running = base_excl[blockIdx.x];
-  for (u32 tile = begin; tile < end; tile += kBlock) {
-    const u32 p = tile + threadIdx.x;
-    const bool f = (p < end) && keep_slot(RU, p);
-    u32 tot;
-    const u32 ex = block_excl_scan<kWaves>(f ? 1u : 0u, tmp, tot);
-    if (f) { const u32 v = RU[p]; Rp[running + ex] = v & ~kUniqBit; kept[running + ex] = p | (v & kUniqBit); }
+  for (u32 tile = begin; tile < end; tile += kSelTile) {
+    const u32 p0 = tile + wave_id() * kSelWave + lane_id();
+    bool f[kSelRows];
+    u32 ex[kSelRows], tot;
+#pragma unroll
+    for (int j = 0; j < kSelRows; j++) { const u32 p = p0 + j * 64; f[j] = (p < end) && keep_slot(RU, p); }
+    block_select_rows(f, ex, tmp, tot);
+#pragma unroll
+    for (int j = 0; j < kSelRows; j++) {
+      const u32 p = p0 + j * 64;
+      if (f[j]) { const u32 v = RU[p]; Rp[running + ex[j]] = v & ~kUniqBit; kept[running + ex[j]] = p | (v & kUniqBit); }
+    }
     running += tot;
   }
 }
@@ -217,12 +247,16 @@ __global__ __launch_bounds__(kBlock) void k_nonuniq_write(const u32 *__restrict_
   __shared__ u32 tmp[kWaves];
   const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
   u32 running = base_excl[blockIdx.x];
-  for (u32 tile = begin; tile < end; tile += kBlock) {
-    const u32 i = tile + threadIdx.x;
-    const bool f = (i < end) && !(x[i] & kUniqBit);
-    u32 tot;
-    const u32 ex = block_excl_scan<kWaves>(f ? 1u : 0u, tmp, tot);
-    if (f) pt[running + ex] = x[i];
+  for (u32 tile = begin; tile < end; tile += kSelTile) {
+    const u32 i0 = tile + wave_id() * kSelWave + lane_id();
+    bool f[kSelRows];
+    u32 v[kSelRows], ex[kSelRows], tot;
+#pragma unroll
+    for (int j = 0; j < kSelRows; j++) { const u32 i = i0 + j * 64; v[j] = (i < end) ? x[i] : kUniqBit; f[j] = !(v[j] & kUniqBit); }
+    block_select_rows(f, ex, tmp, tot);
+#pragma unroll
+    for (int j = 0; j < kSelRows; j++)
+      if (f[j]) pt[running + ex[j]] = v[j];
     running += tot;
   }
 }
@@ -234,16 +268,21 @@ __global__ __launch_bounds__(kBlock) void k_final_assign(const u32 *__restrict__
   __shared__ u32 tmp[kWaves];
   const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
   u32 running = base_excl[blockIdx.x];
-  for (u32 tile = begin; tile < end; tile += kBlock) {
-    const u32 i = tile + threadIdx.x;
-    const u32 v = (i < end) ? sslot[i] : kUniqBit;
-    const bool nonu = (i < end) && !(v & kUniqBit);
-    u32 tot;
-    const u32 ex = block_excl_scan<kWaves>(nonu ? 1u : 0u, tmp, tot);
-    if (i < end) {
-      const u32 sl = nonu ? pt[running + ex] : (v & ~kUniqBit);
-      if (sa12) sa12[i] = sl;
-      pairs[i] = Rec8{sl, i + 1};
+  for (u32 tile = begin; tile < end; tile += kSelTile) {
+    const u32 i0 = tile + wave_id() * kSelWave + lane_id();
+    bool nonu[kSelRows];
+    u32 v[kSelRows], ex[kSelRows], tot;
+#pragma unroll
+    for (int j = 0; j < kSelRows; j++) { const u32 i = i0 + j * 64; v[j] = (i < end) ? sslot[i] : kUniqBit; nonu[j] = !(v[j] & kUniqBit); }
+    block_select_rows(nonu, ex, tmp, tot);
+#pragma unroll
+    for (int j = 0; j < kSelRows; j++) {
+      const u32 i = i0 + j * 64;
+      if (i < end) {
+        const u32 sl = nonu[j] ? pt[running + ex[j]] : (v[j] & ~kUniqBit);
+        if (sa12) sa12[i] = sl;
+        pairs[i] = Rec8{sl, i + 1};
+      }
     }
     running += tot;
   }
