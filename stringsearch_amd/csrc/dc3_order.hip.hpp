@@ -325,14 +325,14 @@ __global__ __launch_bounds__(kPartNW * 64) void k_part_msd(const Rec8 *__restric
   __syncthreads();
   Rec8 r[kPartIPT];
   u32 d[kPartIPT], rk[kPartIPT];
+  // (all loads issued back to back: the index is clamped instead of guarded, a guard would put a wait behind every load)
+#pragma unroll
+  for (int k = 0; k < kPartIPT; k++) r[k] = in[begin + min((u32)(k * (kPartNW * 64)) + tid, nvalid - 1u)];
 #pragma unroll
   for (int k = 0; k < kPartIPT; k++) {
     const u32 t = k * (kPartNW * 64) + tid;
-    if (t < nvalid) {
-      r[k] = in[begin + t];
-      d[k] = ((r[k].key - seg_base) >> shift);
-      rk[k] = atomicAdd(&hist[d[k]], 1u);
-    }
+    d[k] = ((r[k].key - seg_base) >> shift);
+    if (t < nvalid) rk[k] = atomicAdd(&hist[d[k]], 1u);
   }
   __syncthreads();
   u32 cnt = 0;
