@@ -377,6 +377,11 @@ def main():
                 per_cfg[f"{name}_{per_gpu / 2**30:g}GiB"] = {
                     "ms": m, "MB/s": n / m / 1e3, "sufcheck": c3.sufcheck(), "levels": st3["levels"],
                     "path": PATH_NAMES.get(st3.get("text_sort_state", 0), "?"),
+                    # levels ordered by the splitter (sample) ordering, and symbols per record where a level sorted a
+                    # wider window than the triple (dc3_ssort.hip.hpp)
+                    "splitter_ordering": {k: st3.get(k) for k in ("ssort_sorts", "ssort_fallbacks", "ssort_max_subbucket",
+                                                                  "ssort_part_ms", "ssort_local_ms")},
+                    "level_name_width": st3.get("level_name_width"),
                     "roofline_path": path_roofline(st3, m)}
                 if st3.get("text_sort_state", 0) != 0:
                     # finished (or started) by the whole-text order: the DC3 recursion proper on the same text beside it

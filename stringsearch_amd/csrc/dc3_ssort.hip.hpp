@@ -160,6 +160,58 @@ __global__ __launch_bounds__(kSsNT) void k_ss_count1(const Rec *__restrict__ in,
   if (tid < nb1 && hist[tid]) atomicAdd(&cntg[tid * kSsGroups + g], hist[tid]);
 }
 
+// The two kernels above for records that do not exist yet (the wide-window ordering): the sample is computed from the
+// level's string, and the counting kernel MAKES the records (k_pack_window16's job), stores them, and counts — the
+// records are written once and not read back for the count.  Packed index x is position 3 (x / 2) + 1 + (x & 1).
+template <class Sym, int W>
+__device__ __forceinline__ Rec16 ss_window_at(const Sym &S, u32 x, u32 sb) {
+  const u32 p = 3 * (x >> 1) + 1 + (x & 1u);
+  u32 s[W];
+#pragma unroll
+  for (int j = 0; j < W; j++) s[j] = S.get(p + j);
+  return ss_window_rec(s, W, sb, p);
+}
+template <class Sym, int W>
+__global__ __launch_bounds__(kBlock) void k_ss_sample_window(Sym S, u32 sb, u32 n, u32 Sn, Rec16 *__restrict__ out) {
+  const u32 i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= Sn) return;
+  u64 idx = ((u64)i * 2 + 1) * n / (2 * (u64)Sn);
+  if (idx >= n) idx = n - 1;
+  out[i] = ss_window_at<Sym, W>(S, (u32)idx, sb);
+}
+template <class Sym, int W>
+__global__ __launch_bounds__(kSsNT) void k_ss_pack_count1(Sym S, u32 sb, Rec16 *__restrict__ recs, u32 n, const SsVal *__restrict__ coarse,
+                                                         u32 nb1, u32 tile, u32 cpx, u32 ntiles, u32 tpb, u32 *__restrict__ cntg,
+                                                         uint16_t *__restrict__ dig) {
+  __shared__ SsVal spl[kSsMaxDig];
+  __shared__ u32 hist[kSsMaxDig];
+  const u32 tid = threadIdx.x;
+  const u32 g = blockIdx.x % kSsGroups, idx = blockIdx.x / kSsGroups;
+  const u32 t0 = g * cpx + idx * tpb;
+  const u32 t1 = min(min(t0 + tpb, (g + 1) * cpx), ntiles);
+  if (idx * tpb >= cpx || t0 >= t1) return;
+  const u32 steps = ss_steps(nb1 - 1);
+  ss_stage(spl, coarse, nb1 - 1, steps);
+  hist[tid] = 0;
+  __syncthreads();
+  const u32 begin = t0 * tile, end = min(n, t1 * tile);
+  for (u32 i = begin + tid; i < end; i += 4 * kSsNT) {
+    Rec16 r[4];
+    SsVal v[4];
+    u32 d[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { r[k] = ss_window_at<Sym, W>(S, min(i + (u32)k * kSsNT, end - 1u), sb); v[k] = ss_val(r[k]); }
+    ss_count_le_multi<4>(spl, steps, v, d);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const u32 x = i + (u32)k * kSsNT;
+      if (x < end) { recs[x] = r[k]; atomicAdd(&hist[d[k]], 1u); dig[x] = (uint16_t)d[k]; }
+    }
+  }
+  __syncthreads();
+  if (tid < nb1 && hist[tid]) atomicAdd(&cntg[tid * kSsGroups + g], hist[tid]);
+}
+
 // k_msd_plan1 with the tile sizes as arguments (the record types have different tiles).
 __global__ __launch_bounds__(1024) void k_ss_plan1(const u32 *__restrict__ cntg, u32 nb1, u32 n, u32 tile, u32 htile,
                                                   u32 *__restrict__ startg, u32 *__restrict__ cur1, u32 *__restrict__ bstart,

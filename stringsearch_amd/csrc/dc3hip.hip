@@ -101,6 +101,7 @@ struct dc3hip_ctx {
   u32 ssort_mean = 1400;       // DC3HIP_SSORT_MEAN: records per sub-bucket the splitter ordering aims at (capacity 4096)
   bool no_wide_window = false; // DC3HIP_NO_WIDE_WINDOW=1: straight orderings always sort the triple (no wider window)
   bool ssort_rec12 = false;    // DC3HIP_SSORT_REC12=1: the splitter ordering also for keys of at most 64 bits (tests)
+  bool no_pack_count = false;  // DC3HIP_NO_PACK_COUNT=1: the wide-window records are packed by their own kernel, then counted
   bool no_ssort = false;       // DC3HIP_NO_SSORT=1: the straight orderings always run the stable LSD passes (no splitter ordering)
   u32 ssort_min = 1u << 23;    // DC3HIP_SSORT_MIN: fewest records the splitter ordering is used for (tests lower it)
   u32 msd_min = 1u << 20;      // DC3HIP_MSD_MIN: fewest records the bucket ordering is used for (tests lower it)
@@ -580,10 +581,34 @@ static constexpr u32 kSsCap = 4096;
 static bool ssort_applies(const dc3hip_ctx *c, u32 n, u32 kbits) {
   return !c->no_ssort && n >= c->ssort_min && n >= 8192 && (kbits > 64 || c->ssort_rec12);
 }
+// A caller whose records do not exist yet hands in a producer: sample() computes S of them (ascending index),
+// pack_count() makes all of them into `a` while it counts the coarse buckets (k_ss_count1's arguments).
+struct SsProducer {
+  virtual ~SsProducer() {}
+  virtual int sample(dc3hip_ctx *c, u32 n, u32 S, void *out) = 0;
+  virtual int pack_count(dc3hip_ctx *c, void *a, u32 n, const SsVal *coarse, u32 nb1, u32 tile, u32 cpx, u32 ntiles, u32 tpb,
+                         u32 grid, u32 *cntg, uint16_t *dig) = 0;
+};
+// nb1 coarse buckets x F2 sub-buckets of about ssort_mean records, S sample values; false: the ordering does not apply
+struct SsGeom { u32 nb1, F2, n2, S; };
+static bool ssort_geometry(const dc3hip_ctx *c, u32 n, u32 kbits, SsGeom *g) {
+  if (!ssort_applies(c, n, kbits)) return false;
+  const u64 want = ((u64)n + c->ssort_mean - 1) / c->ssort_mean;           // sub-buckets
+  u32 nb1 = kSsMaxDig, F2 = (u32)((want + nb1 - 1) / nb1);
+  if (F2 < 2) { F2 = 2; nb1 = (u32)std::max<u64>(2, (want + 1) / 2); }
+  if (F2 > kSsMaxDig) return false;                                        // (beyond 1.4e9 records)
+  g->nb1 = nb1; g->F2 = F2; g->n2 = nb1 * F2; g->S = g->n2 * kSsOver;
+  return (u64)g->S * 4 <= n;
+}
 template <class Rec>
-static int ssort(dc3hip_ctx *c, Rec *a, Rec *b, u32 n, u32 kbits, Rec **result, bool *ok) {
+static int ssort(dc3hip_ctx *c, Rec *a, Rec *b, u32 n, u32 kbits, Rec **result, bool *ok, SsProducer *prod = nullptr) {
+  // prod != nullptr: only when ssort_geometry() holds (the caller checked); on return `a` holds the records either way
   *ok = false; *result = nullptr;
-  if (!ssort_applies(c, n, kbits)) return E_OK;
+  SsGeom geo;
+  if (!ssort_geometry(c, n, kbits, &geo)) {
+    if (prod) { set_err("internal: splitter ordering with a producer outside its range"); return E_HIP; }
+    return E_OK;
+  }
   constexpr int IPT = SsCfg<Rec>::IPT;
   constexpr u32 tile = (u32)kSsNT * IPT, htile = tile * kSsHistTiles;
   constexpr int kLocNT = 512, kLocIPT = (int)(kSsCap / kLocNT);
@@ -595,13 +620,7 @@ static int ssort(dc3hip_ctx *c, Rec *a, Rec *b, u32 n, u32 kbits, Rec **result, 
     HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ss_local<Rec, kLocNT, kLocIPT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)loc_smem));
     attr_set[c->device & 15] = true;
   }
-  // geometry: nb1 coarse buckets x F2 sub-buckets of about kSsMeanTarget records
-  const u64 want = ((u64)n + c->ssort_mean - 1) / c->ssort_mean;           // sub-buckets
-  u32 nb1 = kSsMaxDig, F2 = (u32)((want + nb1 - 1) / nb1);
-  if (F2 < 2) { F2 = 2; nb1 = (u32)std::max<u64>(2, (want + 1) / 2); }
-  if (F2 > kSsMaxDig) return E_OK;                                         // (beyond 1.4e9 records: not reachable with u32 n)
-  const u32 n2 = nb1 * F2, S = n2 * kSsOver;
-  if ((u64)S * 4 > n) return E_OK;
+  const u32 nb1 = geo.nb1, F2 = geo.F2, n2 = geo.n2, S = geo.S;
   const u32 ntiles1 = (n + tile - 1) / tile, cpx1 = (ntiles1 + kSsGroups - 1) / kSsGroups;
   const u32 tpb = std::max<u32>(1, (cpx1 + 255) / 256);
   const ArenaMark mk = arena_mark(c);
@@ -622,8 +641,11 @@ static int ssort(dc3hip_ctx *c, Rec *a, Rec *b, u32 n, u32 kbits, Rec **result, 
   RC(arena_alloc(c, (size_t)n + 16, &dig));
   {
     PhaseScope ps(c, DC3HIP_PH_SORT12_UP, S);
-    hipLaunchKernelGGL((k_ss_sample<Rec>), dim3((S + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, (const Rec *)a, n, S, sa);
-    KCHECK();
+    if (prod) RC(prod->sample(c, n, S, sa));
+    else {
+      hipLaunchKernelGGL((k_ss_sample<Rec>), dim3((S + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, (const Rec *)a, n, S, sa);
+      KCHECK();
+    }
   }
   RC(radix_sort<Rec>(c, sa, sb, S, 0, kbits, &ss, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT12_DOWN));
   {
@@ -633,9 +655,13 @@ static int ssort(dc3hip_ctx *c, Rec *a, Rec *b, u32 n, u32 kbits, Rec **result, 
     HIPC(hipMemsetAsync(cntg, 0, ((size_t)nb1 * kSsGroups + 16) * sizeof(u32), c->stream));
     HIPC(hipMemsetAsync(plan, 0, (kMsdW_COUNT + 12) * sizeof(u32), c->stream));
     HIPC(hipMemsetAsync(cnt2g, 0, (N2 + 1) * sizeof(u32), c->stream));
-    hipLaunchKernelGGL((k_ss_count1<Rec>), dim3(kSsGroups * ((cpx1 + tpb - 1) / tpb)), dim3(kSsNT), 0, c->stream, (const Rec *)a, n,
-                       (const SsVal *)coarse, nb1, tile, cpx1, ntiles1, tpb, cntg, dig);
-    KCHECK();
+    const u32 grid1 = kSsGroups * ((cpx1 + tpb - 1) / tpb);
+    if (prod) RC(prod->pack_count(c, a, n, coarse, nb1, tile, cpx1, ntiles1, tpb, grid1, cntg, dig));
+    else {
+      hipLaunchKernelGGL((k_ss_count1<Rec>), dim3(grid1), dim3(kSsNT), 0, c->stream, (const Rec *)a, n,
+                         (const SsVal *)coarse, nb1, tile, cpx1, ntiles1, tpb, cntg, dig);
+      KCHECK();
+    }
   }
   {
     PhaseScope ps(c, DC3HIP_PH_SORT12_SCAN, nb1);
@@ -1016,24 +1042,60 @@ static u32 wide_window_syms(const dc3hip_ctx *c, u32 m02, u64 K) {
   return std::min<u32>(7, 96 / sb);             // (the zero tail behind a level's string is 8 symbols)
 }
 template <class Sym>
+struct WideProducer : SsProducer {
+  Sym S; u32 sb, W;
+  template <int WW> int sample_w(dc3hip_ctx *c, u32 n, u32 Sn, Rec16 *out) {
+    hipLaunchKernelGGL((k_ss_sample_window<Sym, WW>), dim3((Sn + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, S, sb, n, Sn, out);
+    KCHECK();
+    return E_OK;
+  }
+  template <int WW> int pack_w(dc3hip_ctx *c, Rec16 *a, u32 n, const SsVal *coarse, u32 nb1, u32 tile, u32 cpx, u32 ntiles, u32 tpb, u32 grid,
+                               u32 *cntg, uint16_t *dig) {
+    hipLaunchKernelGGL((k_ss_pack_count1<Sym, WW>), dim3(grid), dim3(kSsNT), 0, c->stream, S, sb, a, n, coarse, nb1, tile, cpx, ntiles, tpb, cntg, dig);
+    KCHECK();
+    return E_OK;
+  }
+  int sample(dc3hip_ctx *c, u32 n, u32 Sn, void *out) override {
+    Rec16 *o = static_cast<Rec16 *>(out);
+    switch (W) { case 4: return sample_w<4>(c, n, Sn, o); case 5: return sample_w<5>(c, n, Sn, o); case 6: return sample_w<6>(c, n, Sn, o); default: return sample_w<7>(c, n, Sn, o); }
+  }
+  int pack_count(dc3hip_ctx *c, void *a, u32 n, const SsVal *coarse, u32 nb1, u32 tile, u32 cpx, u32 ntiles, u32 tpb, u32 grid, u32 *cntg,
+                 uint16_t *dig) override {
+    Rec16 *r = static_cast<Rec16 *>(a);
+    switch (W) {
+      case 4: return pack_w<4>(c, r, n, coarse, nb1, tile, cpx, ntiles, tpb, grid, cntg, dig);
+      case 5: return pack_w<5>(c, r, n, coarse, nb1, tile, cpx, ntiles, tpb, grid, cntg, dig);
+      case 6: return pack_w<6>(c, r, n, coarse, nb1, tile, cpx, ntiles, tpb, grid, cntg, dig);
+      default: return pack_w<7>(c, r, n, coarse, nb1, tile, cpx, ntiles, tpb, grid, cntg, dig);
+    }
+  }
+};
+template <class Sym>
 static int order_wide(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 sb, u32 W, u32 *sa12, u32 *rank12, u32 *R,
                       u32 *sslot, u32 *names, int *mode) {
   Rec16 *recA = nullptr, *recB = nullptr, *sorted = nullptr;
   RC(arena_alloc(c, (size_t)m02, &recA));
   RC(arena_alloc(c, (size_t)m02, &recB));
-  {
-    PhaseScope ps(c, DC3HIP_PH_PACK, m02);
-    const dim3 grid((m02 / 2 + kBlock) / kBlock);
-    switch (W) {
-      case 4: hipLaunchKernelGGL((k_pack_window16<Sym, 4>), grid, dim3(kBlock), 0, c->stream, S, m, m02, sb, recA); break;
-      case 5: hipLaunchKernelGGL((k_pack_window16<Sym, 5>), grid, dim3(kBlock), 0, c->stream, S, m, m02, sb, recA); break;
-      case 6: hipLaunchKernelGGL((k_pack_window16<Sym, 6>), grid, dim3(kBlock), 0, c->stream, S, m, m02, sb, recA); break;
-      default: hipLaunchKernelGGL((k_pack_window16<Sym, 7>), grid, dim3(kBlock), 0, c->stream, S, m, m02, sb, recA); break;
-    }
-    KCHECK();
-  }
   bool by_splitters = false;
-  RC(ssort<Rec16>(c, recA, recB, m02, W * sb, &sorted, &by_splitters));
+  SsGeom geo;
+  if (ssort_geometry(c, m02, W * sb, &geo) && !c->no_pack_count) {
+    // the records are made by the kernel that counts the coarse buckets (written once, not read back for the count)
+    WideProducer<Sym> prod; prod.S = S; prod.sb = sb; prod.W = W;
+    RC(ssort<Rec16>(c, recA, recB, m02, W * sb, &sorted, &by_splitters, &prod));
+  } else {
+    {
+      PhaseScope ps(c, DC3HIP_PH_PACK, m02);
+      const dim3 grid((m02 / 2 + kBlock) / kBlock);
+      switch (W) {
+        case 4: hipLaunchKernelGGL((k_pack_window16<Sym, 4>), grid, dim3(kBlock), 0, c->stream, S, m, m02, sb, recA); break;
+        case 5: hipLaunchKernelGGL((k_pack_window16<Sym, 5>), grid, dim3(kBlock), 0, c->stream, S, m, m02, sb, recA); break;
+        case 6: hipLaunchKernelGGL((k_pack_window16<Sym, 6>), grid, dim3(kBlock), 0, c->stream, S, m, m02, sb, recA); break;
+        default: hipLaunchKernelGGL((k_pack_window16<Sym, 7>), grid, dim3(kBlock), 0, c->stream, S, m, m02, sb, recA); break;
+      }
+      KCHECK();
+    }
+    RC(ssort<Rec16>(c, recA, recB, m02, W * sb, &sorted, &by_splitters));
+  }
   if (!by_splitters)
     RC(radix_sort<Rec16>(c, recA, recB, m02, 0, W * sb, &sorted, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT12_DOWN));
   AccRec<Rec16> acc; acc.s = sorted;
@@ -2388,6 +2450,7 @@ int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) {
   { const char *e = getenv("DC3HIP_NO_TUP_SCATTER"); c->no_tup_scatter = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_MSD_MIN"); if (e) c->msd_min = (u32)std::max(4096ll, atoll(e)); }
   { const char *e = getenv("DC3HIP_NO_SSORT"); c->no_ssort = (e && e[0] == '1'); }
+  { const char *e = getenv("DC3HIP_NO_PACK_COUNT"); c->no_pack_count = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_SSORT_REC12"); c->ssort_rec12 = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_WIDE_WINDOW"); c->no_wide_window = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_SSORT_MEAN"); if (e) c->ssort_mean = (u32)std::min(2000ll, std::max(300ll, atoll(e))); }

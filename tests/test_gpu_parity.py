@@ -694,6 +694,7 @@ def test_splitter_ordering_matches_the_stable_passes(ss, oracle):
                     {"DC3HIP_SSORT_MIN": "8192", "DC3HIP_NO_REC12": "1", "DC3HIP_NO_HYBRID": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1"},
                     {"DC3HIP_SSORT_MIN": "8192", "DC3HIP_SSORT_REC12": "1", "DC3HIP_NO_WIDE_WINDOW": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1"},
                     {"DC3HIP_SSORT_MIN": "8192", "DC3HIP_NO_DISCARD": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1"},
+                    {"DC3HIP_SSORT_MIN": "8192", "DC3HIP_NO_PACK_COUNT": "1"},
                     {"DC3HIP_NO_SSORT": "1"}):
             os.environ.update(env)
             try:
