@@ -6,16 +6,18 @@
 // mass) and wider than a word, so the bucket ordering of dc3_msd.hip.hpp — digits taken from key BITS — does not
 // apply, and the stable LSD passes cost 5 (45-bit keys) to 9 (81-bit keys) sweeps over the records.  Here the buckets
 // come from the data instead:
-//   sample    every (n / S)-th record, S = 16 per sub-bucket; the sample is sorted by the LSD passes (it is ~1 % of n)
-//   splitters every 16th sample value = one of n2 - 1 fine splitters; every F2-th fine splitter = a coarse one
+//   sample    every (n / S)-th record, S = 24 per sub-bucket; the sample is sorted by the LSD passes (it is ~2 % of n)
+//   splitters every 24th sample value = one of n2 - 1 fine splitters; every F2-th fine splitter = a coarse one
 //   pass 1    k_ss_part<.., false>   partition by the 1023 coarse splitters   (sizes: k_ss_count1)
 //   pass 2    k_ss_part<.., true>    partition every bucket by its F2 - 1 fine splitters  (sizes: k_ss_hist2 + scans)
 //   pass 3    k_ss_local             every sub-bucket (about 1400 records, at most 4096) is ordered inside LDS
 // A record's sort value is (key, pos): all values are distinct, so "ascending" is one array whatever the partition
 // passes do (they are not stable: XCD-grouped atomic reservation, see dc3_msd.hip.hpp), and it is the array the stable
 // LSD passes produce from records in position order.  Buckets are balanced by construction — a sub-bucket holds the
-// records between two sample values 16 samples apart — so skew and repeated keys (which the position breaks) do not
-// matter; a sub-bucket above the local capacity is reported before pass 2 and the caller runs the LSD passes instead.
+// records between two sample values 24 samples apart (its size is Gamma(24)-distributed around the mean of 1400: beyond
+// the capacity of 4096 with probability 3e-11; 16 samples gave 4e-8, i.e. one sort in fifty with a fallback) — so skew
+// and repeated keys (which the position breaks) do not matter; a sub-bucket above the local capacity is reported before
+// pass 2 and the caller runs the LSD passes instead.
 //
 // Local order: a comparison sort, since the keys inside a sub-bucket share no usable bit structure.  127 or 255 of the
 // sub-bucket's own records are ranked against each other (all pairs, broadcast reads) and become bin boundaries; every
@@ -34,7 +36,6 @@ __device__ __forceinline__ bool ss_lt(const SsVal &a, const SsVal &b) { return a
 constexpr int kSsNT = 1024;                    // threads of a partition block
 constexpr u32 kSsGroups = 8;                   // XCDs (as kMsdGroups)
 constexpr u32 kSsMaxDig = 1024;                // coarse buckets, and the most fine splitters + 1 per bucket
-constexpr u32 kSsOver = 16;                    // sample values per sub-bucket
 constexpr u32 kSsHistTiles = 8;                // partition tiles per block of k_ss_hist2
 template <class Rec> struct SsCfg;
 template <> struct SsCfg<Rec12> { static constexpr int IPT = 8; };      // 8192-record tiles (96 KB)
@@ -115,15 +116,15 @@ __global__ __launch_bounds__(kBlock) void k_ss_sample(const Rec *__restrict__ in
   out[i] = in[idx];
 }
 
-// fine[j] = value of sorted sample (j + 1) * kSsOver, j < n2 - 1 (fine[n2 - 1] = +inf); coarse[b] = fine[(b + 1) * F2 - 1]
+// fine[j] = value of sorted sample (j + 1) * over, j < n2 - 1 (fine[n2 - 1] = +inf); coarse[b] = fine[(b + 1) * F2 - 1]
 template <class Rec>
-__global__ __launch_bounds__(kBlock) void k_ss_splitters(const Rec *__restrict__ ss, u32 n2, u32 F2, SsVal *__restrict__ fine,
+__global__ __launch_bounds__(kBlock) void k_ss_splitters(const Rec *__restrict__ ss, u32 n2, u32 F2, u32 over, SsVal *__restrict__ fine,
                                                         SsVal *__restrict__ coarse) {
   const u32 j = blockIdx.x * kBlock + threadIdx.x;
   if (j >= n2) return;
   SsVal v;
   if (j == n2 - 1) { v.hi = ~0ull; v.lo = ~0ull; }
-  else v = ss_val(ss[(size_t)(j + 1) * kSsOver]);
+  else v = ss_val(ss[(size_t)(j + 1) * over]);
   fine[j] = v;
   if ((j + 1) % F2 == 0) coarse[(j + 1) / F2 - 1] = v;      // (coarse[nb1 - 1] = +inf, never searched)
 }

@@ -98,6 +98,7 @@ struct dc3hip_ctx {
   bool no_xcd_map = false;     // DC3HIP_NO_XCD_MAP=1: window partitions without the segment -> XCD-group tile order (measurement aid)
   bool pack_fuse = false;      // DC3HIP_PACK_FUSE=1: whole-text order of bytes: the pack kernel only counts, partition pass 1 makes the records on the fly
   bool no_msd = false;         // DC3HIP_NO_MSD=1: the prefix sorts always run the stable LSD passes (no bucket ordering)
+  u32 ssort_over = 24;         // DC3HIP_SSORT_OVER: sample values per sub-bucket
   u32 ssort_mean = 1400;       // DC3HIP_SSORT_MEAN: records per sub-bucket the splitter ordering aims at (capacity 4096)
   bool no_wide_window = false; // DC3HIP_NO_WIDE_WINDOW=1: straight orderings always sort the triple (no wider window)
   bool ssort_rec12 = false;    // DC3HIP_SSORT_REC12=1: the splitter ordering also for keys of at most 64 bits (tests)
@@ -597,7 +598,7 @@ static bool ssort_geometry(const dc3hip_ctx *c, u32 n, u32 kbits, SsGeom *g) {
   u32 nb1 = kSsMaxDig, F2 = (u32)((want + nb1 - 1) / nb1);
   if (F2 < 2) { F2 = 2; nb1 = (u32)std::max<u64>(2, (want + 1) / 2); }
   if (F2 > kSsMaxDig) return false;                                        // (beyond 1.4e9 records)
-  g->nb1 = nb1; g->F2 = F2; g->n2 = nb1 * F2; g->S = g->n2 * kSsOver;
+  g->nb1 = nb1; g->F2 = F2; g->n2 = nb1 * F2; g->S = g->n2 * c->ssort_over;
   return (u64)g->S * 4 <= n;
 }
 template <class Rec>
@@ -650,7 +651,7 @@ static int ssort(dc3hip_ctx *c, Rec *a, Rec *b, u32 n, u32 kbits, Rec **result, 
   RC(radix_sort<Rec>(c, sa, sb, S, 0, kbits, &ss, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT12_DOWN));
   {
     PhaseScope ps(c, DC3HIP_PH_SORT12_UP, n);
-    hipLaunchKernelGGL((k_ss_splitters<Rec>), dim3((n2 + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, (const Rec *)ss, n2, F2, fine, coarse);
+    hipLaunchKernelGGL((k_ss_splitters<Rec>), dim3((n2 + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, (const Rec *)ss, n2, F2, c->ssort_over, fine, coarse);
     KCHECK();
     HIPC(hipMemsetAsync(cntg, 0, ((size_t)nb1 * kSsGroups + 16) * sizeof(u32), c->stream));
     HIPC(hipMemsetAsync(plan, 0, (kMsdW_COUNT + 12) * sizeof(u32), c->stream));
@@ -2453,6 +2454,7 @@ int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) {
   { const char *e = getenv("DC3HIP_NO_PACK_COUNT"); c->no_pack_count = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_SSORT_REC12"); c->ssort_rec12 = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_WIDE_WINDOW"); c->no_wide_window = (e && e[0] == '1'); }
+  { const char *e = getenv("DC3HIP_SSORT_OVER"); if (e) c->ssort_over = (u32)std::min(64ll, std::max(4ll, atoll(e))); }
   { const char *e = getenv("DC3HIP_SSORT_MEAN"); if (e) c->ssort_mean = (u32)std::min(2000ll, std::max(300ll, atoll(e))); }
   { const char *e = getenv("DC3HIP_SSORT_MIN"); if (e) c->ssort_min = (u32)std::max(8192ll, atoll(e)); }
   { const char *e = getenv("DC3HIP_NO_HYBRID12"); c->no_hybrid12 = (e && e[0] == '1'); }
