@@ -592,21 +592,25 @@ struct SsProducer {
 };
 // nb1 coarse buckets x F2 sub-buckets of about ssort_mean records, S sample values; false: the ordering does not apply
 struct SsGeom { u32 nb1, F2, n2, S; };
-static bool ssort_geometry(const dc3hip_ctx *c, u32 n, u32 kbits, SsGeom *g) {
+static bool ssort_geometry(const dc3hip_ctx *c, u32 n, u32 kbits, SsGeom *g, size_t rec_bytes = 16) {
   if (!ssort_applies(c, n, kbits)) return false;
   const u64 want = ((u64)n + c->ssort_mean - 1) / c->ssort_mean;           // sub-buckets
   u32 nb1 = kSsMaxDig, F2 = (u32)((want + nb1 - 1) / nb1);
   if (F2 < 2) { F2 = 2; nb1 = (u32)std::max<u64>(2, (want + 1) / 2); }
   if (F2 > kSsMaxDig) return false;                                        // (beyond 1.4e9 records)
   g->nb1 = nb1; g->F2 = F2; g->n2 = nb1 * F2; g->S = g->n2 * c->ssort_over;
-  return (u64)g->S * 4 <= n;
+  if ((u64)g->S * 4 > n) return false;
+  // scratch on top of the caller's two record arrays: the sample twice, a digit per record, splitters and size tables;
+  // when the arena cannot hold it the LSD passes run (arena_requirement() models those)
+  const size_t need = 2 * (size_t)g->S * rec_bytes + (size_t)n * 2 + (size_t)g->n2 * (16 + 2 * 8 * 4) + ((size_t)48 << 20);
+  return c->arena_bytes - c->arena_off >= need;
 }
 template <class Rec>
 static int ssort(dc3hip_ctx *c, Rec *a, Rec *b, u32 n, u32 kbits, Rec **result, bool *ok, SsProducer *prod = nullptr) {
   // prod != nullptr: only when ssort_geometry() holds (the caller checked); on return `a` holds the records either way
   *ok = false; *result = nullptr;
   SsGeom geo;
-  if (!ssort_geometry(c, n, kbits, &geo)) {
+  if (!ssort_geometry(c, n, kbits, &geo, sizeof(Rec))) {
     if (prod) { set_err("internal: splitter ordering with a producer outside its range"); return E_HIP; }
     return E_OK;
   }
