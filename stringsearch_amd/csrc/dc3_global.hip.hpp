@@ -137,10 +137,11 @@ template <class Sym>
 struct SelTripleKey {
   typedef Rec16 Out;
   Sym S; u32 B; Rec16 klo, khi; u32 has_lo, last;
+  u32 W = 0, sb = 0;                              // W > 3: the records are W-symbol windows (sample_rec)
   __device__ __forceinline__ void stage(uint16_t *) const {}
   __device__ __forceinline__ bool pick(u32 q, const uint16_t *, Rec16 &o) const {
     const u32 g = q >> 1, i = 3 * g + 1 + (q & 1);
-    o = make_rec(S.get(i), S.get(i + 1), S.get(i + 2), B, i);
+    o = sample_rec(S, i, B, W, sb);
     return (!has_lo || !keypos_lt(o, klo)) && (last || keypos_lt(o, khi));
   }
 };
@@ -212,10 +213,10 @@ __global__ __launch_bounds__(kBlock) void k_find_ranks(const u32 *__restrict__ r
 }
 // full keys of every stride-th sample position (splitter candidates of the sorted naming)
 template <class Sym>
-__global__ __launch_bounds__(kBlock) void k_sample_triple_keys(Sym S, u32 B, u32 ns, u32 stride, Rec16 *out) {
+__global__ __launch_bounds__(kBlock) void k_sample_triple_keys(Sym S, u32 B, u32 ns, u32 stride, Rec16 *out, u32 W, u32 sb) {
   for (u32 k = blockIdx.x * kBlock + threadIdx.x; k < ns; k += gridDim.x * kBlock) {
     const u32 q = k * stride, g = q >> 1, i = 3 * g + 1 + (q & 1);
-    out[k] = make_rec(S.get(i), S.get(i + 1), S.get(i + 2), B, i);
+    out[k] = sample_rec(S, i, B, W, sb);
   }
 }
 // pairs[k].val += add  (local ranks -> global ranks)

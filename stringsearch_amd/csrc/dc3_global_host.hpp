@@ -951,7 +951,13 @@ static int glevel(dc3hip_gctx *G, Sym S, u32 m, u64 K, int depth, u32 *out, GOut
       }
     }
     if (!named) {
-      // straight sort of my KEY range: splitters = every rank sorts the same deterministic sample of keys
+      // straight sort of my KEY range: splitters = every rank sorts the same deterministic sample of keys.
+      // Where a rank's share is large enough for the splitter ordering (dc3_ssort.hip.hpp), whose cost does not depend on
+      // the key width, the records are W-symbol windows instead of triples (order_wide of the single-device build): more
+      // names are distinct, the discarding recursion keeps less, the distributed levels below shrink.
+      const u32 Ww = wide_window_syms(c, m02 / (u32)P, K), wsb = bits_of(K);
+      const u32 W = Ww > 3 ? Ww : 0u, sort_bits = W ? W * wsb : kbits;
+      if (W) c->stats.level_name_width[depth] = (int32_t)W;
       Rec16 klo{0, 0, 0, 0}, khi{0, 0, 0, 0};
       {
         u32 ns = (u32)std::min<u64>(m02, (u64)1024 * P);
@@ -960,7 +966,7 @@ static int glevel(dc3hip_gctx *G, Sym S, u32 m, u64 K, int depth, u32 *out, GOut
         Rec16 *smp = nullptr;
         RC(arena_alloc(c, (size_t)ns, &smp));
         std::vector<Rec16> hs(ns);
-        hipLaunchKernelGGL((k_sample_triple_keys<Sym>), dim3(grid_for(c, ns)), dim3(kBlock), 0, c->stream, S, b, ns, stride, smp);
+        hipLaunchKernelGGL((k_sample_triple_keys<Sym>), dim3(grid_for(c, ns)), dim3(kBlock), 0, c->stream, S, b, ns, stride, smp, W, wsb);
         KCHECK();
         HIPC(hipMemcpyAsync(hs.data(), smp, (size_t)ns * sizeof(Rec16), hipMemcpyDeviceToHost, c->stream));
         HIPC(hipStreamSynchronize(c->stream));
@@ -974,11 +980,17 @@ static int glevel(dc3hip_gctx *G, Sym S, u32 m, u64 K, int depth, u32 *out, GOut
         if (me + 1 < P) khi = hs[(size_t)((u64)(me + 1) * ns / P)];
       }
       SelTripleKey<Sym> sel; sel.S = S; sel.B = b; sel.klo = klo; sel.khi = khi; sel.has_lo = me > 0 ? 1u : 0u; sel.last = (me + 1 == P) ? 1u : 0u;
+      sel.W = W; sel.sb = wsb;
       Rec16 *recA = nullptr, *recB = nullptr, *sorted = nullptr;
       RC(select_records(c, sel, m02, &recA, &cnt, DC3HIP_PH_PACK));
       RC(arena_alloc(c, (size_t)cnt + 16, &recB));
       sorted = recA;
-      if (cnt) RC(radix_sort<Rec16>(c, recA, recB, cnt, 0, kbits, &sorted, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT12_DOWN));
+      if (cnt) {
+        bool by_splitters = false;
+        RC(ssort<Rec16>(c, recA, recB, cnt, sort_bits, &sorted, &by_splitters));
+        if (!by_splitters)
+          RC(radix_sort<Rec16>(c, recA, recB, cnt, 0, sort_bits, &sorted, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT12_DOWN));
+      }
       // equal keys may straddle ranks: every rank learns its neighbours' boundary keys (first / last record of each
       // rank's sorted range, one small all-gather) and names continue across the boundary where they are equal
       struct Edge { u32 f[3], l[3], has, pad; } mine, all_e[kMaxRanks];

@@ -96,6 +96,23 @@ __device__ __forceinline__ Rec16 make_rec(u32 s0, u32 s1, u32 s2, u32 B, u32 pos
   Rec16 r; r.k0 = (u32)s_lo; r.k1 = (u32)(s_lo >> 32); r.k2 = (u32)p_hi; r.pos = pos;
   return r;
 }
+// the record of a WIDE window: W > 3 symbols of sb bits each, first symbol most significant, in the 96-bit key
+// (dc3_ssort.hip.hpp explains why names taken from such records order the samples as the triple names do)
+__device__ __forceinline__ Rec16 ss_window_rec(const u32 *s, u32 W, u32 sb, u32 pos) {
+  u64 lo = 0; u32 hi = 0;
+  for (u32 j = 0; j < W; j++) { hi = (hi << sb) | (u32)(lo >> (64 - sb)); lo = (lo << sb) | s[j]; }
+  Rec16 r; r.k0 = (u32)lo; r.k1 = (u32)(lo >> 32); r.k2 = hi; r.pos = pos;
+  return r;
+}
+// the sample record of position i: the K-S triple in base B (W == 0), or the W-symbol window
+template <class Sym>
+__device__ __forceinline__ Rec16 sample_rec(const Sym &S, u32 i, u32 B, u32 W, u32 sb) {
+  if (W == 0) return make_rec(S.get(i), S.get(i + 1), S.get(i + 2), B, i);
+  u32 s[7];
+#pragma unroll
+  for (int j = 0; j < 7; j++) s[j] = (u32)j < W ? S.get(i + j) : 0u;
+  return ss_window_rec(s, W, sb, i);
+}
 __device__ __forceinline__ void store_rec(Rec16 *out, u32 i, const Rec16 &r) { out[i] = r; }
 __device__ __forceinline__ void store_rec(Rec12 *out, u32 i, const Rec16 &r) { out[i] = Rec12{r.k0, r.k1, r.pos}; }
 template <class Sym, class Rec>

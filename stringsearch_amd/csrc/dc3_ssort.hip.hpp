@@ -6,7 +6,7 @@
 // mass) and wider than a word, so the bucket ordering of dc3_msd.hip.hpp — digits taken from key BITS — does not
 // apply, and the stable LSD passes cost 5 (45-bit keys) to 9 (81-bit keys) sweeps over the records.  Here the buckets
 // come from the data instead:
-//   sample    every (n / S)-th record, S = 24 per sub-bucket; the sample is sorted by the LSD passes (it is ~2 % of n)
+//   sample    one record per cell of n / S records (jittered), S = 24 per sub-bucket; the sample is sorted by the LSD passes (it is ~2 % of n)
 //   splitters every 24th sample value = one of n2 - 1 fine splitters; every F2-th fine splitter = a coarse one
 //   pass 1    k_ss_part<.., false>   partition by the 1023 coarse splitters   (sizes: k_ss_count1)
 //   pass 2    k_ss_part<.., true>    partition every bucket by its F2 - 1 fine splitters  (sizes: k_ss_hist2 + scans)
@@ -87,12 +87,7 @@ __device__ __forceinline__ u32 ss_steps(u32 ns) { u32 s = 1; while (((1u << s) -
 // equal triples — and order the sample suffixes just as well: comparing (W(p), W(p+3), ...) with (W(q), W(q+3), ...) is
 // comparing the suffixes at p and q, the windows that reach past the end are distinct (they differ in where their first
 // sentinel is), so the recursion of lib.rs:104 is entered with fewer repeated names, or not at all.
-__device__ __forceinline__ Rec16 ss_window_rec(const u32 *s, u32 W, u32 sb, u32 pos) {
-  u64 lo = 0; u32 hi = 0;
-  for (u32 j = 0; j < W; j++) { hi = (hi << sb) | (u32)(lo >> (64 - sb)); lo = (lo << sb) | s[j]; }
-  Rec16 r; r.k0 = (u32)lo; r.k1 = (u32)(lo >> 32); r.k2 = hi; r.pos = pos;
-  return r;
-}
+// (ss_window_rec, the record of a window, is in dc3_names.hip.hpp next to make_rec)
 // records of the sample positions in position order (k_pack_triples with W symbols): thread g makes those of 3g+1, 3g+2
 template <class Sym, int W>
 __global__ __launch_bounds__(kBlock) void k_pack_window16(Sym S, u32 m, u32 m02, u32 sb, Rec16 *__restrict__ out) {
@@ -106,14 +101,21 @@ __global__ __launch_bounds__(kBlock) void k_pack_window16(Sym S, u32 m, u32 m02,
   if (2 * g + 1 < m02) out[2 * g + 1] = ss_window_rec(s + 1, W, sb, i + 1);
 }
 
-// sample[i] = the record at input index (i + 1/2) * n / S: ascending input indices, i.e. ascending pos
+// Index of sample i of S among n records: one per cell [i n / S, (i + 1) n / S), at a pseudo-random offset inside the cell
+// (a fixed function of i: the build stays deterministic).  Ascending in i, i.e. ascending pos.  A regular stride
+// resonates with texts that repeat at fixed distances: a generated text of 3 * 2^23 bytes sampled every 58th record
+// made one sub-bucket of more than 4096 records — the fallback, not an error, but 10 LSD passes instead of 3.
+__device__ __forceinline__ u32 ss_sample_index(u32 i, u32 n, u32 S) {
+  const u64 lo = (u64)i * n / S, hi = (u64)(i + 1) * n / S;      // hi - lo >= 4 (S <= n / 4)
+  u32 h = i * 0x9E3779B1u; h ^= h >> 15; h *= 0x85EBCA77u; h ^= h >> 13;
+  const u64 idx = lo + h % (u32)(hi - lo);
+  return (u32)(idx < n ? idx : n - 1);
+}
 template <class Rec>
 __global__ __launch_bounds__(kBlock) void k_ss_sample(const Rec *__restrict__ in, u32 n, u32 S, Rec *__restrict__ out) {
   const u32 i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= S) return;
-  u64 idx = ((u64)i * 2 + 1) * n / (2 * (u64)S);
-  if (idx >= n) idx = n - 1;
-  out[i] = in[idx];
+  out[i] = in[ss_sample_index(i, n, S)];
 }
 
 // fine[j] = value of sorted sample (j + 1) * over, j < n2 - 1 (fine[n2 - 1] = +inf); coarse[b] = fine[(b + 1) * F2 - 1]
@@ -176,9 +178,7 @@ template <class Sym, int W>
 __global__ __launch_bounds__(kBlock) void k_ss_sample_window(Sym S, u32 sb, u32 n, u32 Sn, Rec16 *__restrict__ out) {
   const u32 i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= Sn) return;
-  u64 idx = ((u64)i * 2 + 1) * n / (2 * (u64)Sn);
-  if (idx >= n) idx = n - 1;
-  out[i] = ss_window_at<Sym, W>(S, (u32)idx, sb);
+  out[i] = ss_window_at<Sym, W>(S, ss_sample_index(i, n, Sn), sb);
 }
 template <class Sym, int W>
 __global__ __launch_bounds__(kSsNT) void k_ss_pack_count1(Sym S, u32 sb, Rec16 *__restrict__ recs, u32 n, const SsVal *__restrict__ coarse,
@@ -267,7 +267,9 @@ __global__ __launch_bounds__(kSsNT) void k_ss_part(const Rec *__restrict__ in, R
     const u32 b = msd_find_bucket(tpre, nb1, tile);
     begin = bstart[b] + (tile - tpre[b]) * (u32)T;
     end = min(begin + (u32)T, bstart[b + 1]);
-    cur += (size_t)b * F2;
+    // a bucket's records are counted for ONE group, that of its first tile (k_ss_hist2): the few tiles of a bucket that
+    // reach into the next group's tile range still reserve in the first group's regions
+    cur = cursors + (size_t)(tpre[b] / cpx2) * gstride + (size_t)b * F2;
     ndig = F2;
   } else {
     const u32 tile = g * cpx + idx;
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(kSsNT) void k_ss_part(const Rec *__restrict__ in, R
 }
 
 // Sizes of the sub-buckets per group (cf. k_msd_hist2): block h counts the digits of its piece (kSsHistTiles pass-2
-// tiles) of bucket b and adds them to cnt2g[(b * F2 + digit) * 8 + g], g = the group that works the tile in pass 2.
+// tiles) of bucket b and adds them to cnt2g[(b * F2 + digit) * 8 + g], g = the group of the bucket's FIRST pass-2 tile.
 template <class Rec>
 __global__ __launch_bounds__(kSsNT) void k_ss_hist2(const Rec *__restrict__ in, const SsVal *__restrict__ fine, u32 F2, u32 tile,
                                                    const u32 *__restrict__ tpre, const u32 *__restrict__ tpreh,
@@ -330,8 +332,7 @@ __global__ __launch_bounds__(kSsNT) void k_ss_hist2(const Rec *__restrict__ in, 
   const u32 htile = tile * kSsHistTiles;
   const u32 begin = bstart[b] + hh * htile;
   const u32 end = min(begin + htile, bstart[b + 1]);
-  const u32 tile0 = tpre[b] + hh * kSsHistTiles;
-  u32 gcur = tile0 / cpx2;
+  const u32 gcur = tpre[b] / cpx2;                  // the whole bucket belongs to the group of its first tile
   const u32 steps = ss_steps(F2 - 1);
   ss_stage(spl, fine + (size_t)b * F2, F2 - 1, steps);
   hist[tid] = 0;
@@ -340,14 +341,6 @@ __global__ __launch_bounds__(kSsNT) void k_ss_hist2(const Rec *__restrict__ in, 
     const u32 pb = begin + pt * tile;
     if (pb >= end) break;
     const u32 pe = min(pb + tile, end);
-    const u32 g = (tile0 + pt) / cpx2;
-    if (g != gcur) {                                  // (block-uniform: at most 7 group changes in the whole array)
-      __syncthreads();
-      if (tid < F2 && hist[tid]) atomicAdd(&cnt2g[((size_t)b * F2 + tid) * kSsGroups + gcur], hist[tid]);
-      hist[tid] = 0;
-      __syncthreads();
-      gcur = g;
-    }
     for (u32 i = pb + tid; i < pe; i += 8 * kSsNT) {
       SsVal v[8];
       u32 d[8];
@@ -361,6 +354,35 @@ __global__ __launch_bounds__(kSsNT) void k_ss_hist2(const Rec *__restrict__ in, 
   }
   __syncthreads();
   if (tid < F2 && hist[tid]) atomicAdd(&cnt2g[((size_t)b * F2 + tid) * kSsGroups + gcur], hist[tid]);
+}
+
+// (debug, DC3HIP_SSORT_VERIFY=1) order-independent checksum of a record array: out[0] += sum of mixes, out[1] += count of
+// records whose successor is smaller (0 for a sorted array)
+template <class Rec>
+__global__ __launch_bounds__(kBlock) void k_ss_verify(const Rec *__restrict__ p, u32 n, unsigned long long *out) {
+  unsigned long long s = 0, bad = 0;
+  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const SsVal v = ss_val(p[i]);
+    unsigned long long x = v.hi * 0x9E3779B97F4A7C15ull ^ (v.lo + 0x7F4A7C15ull) * 0xC2B2AE3D27D4EB4Full;
+    x ^= x >> 29;
+    s += x;
+    if (i + 1 < n && ss_lt(ss_val(p[i + 1]), v)) bad++;
+  }
+  atomicAdd(&out[0], s);
+  if (bad) atomicAdd(&out[1], bad);
+}
+
+// (debug) after pass 2 every cursor must stand at the start of the next region: out[0] = mismatching (sub, group)
+// regions, out[1] = the first such index (sub * 8 + group), out[2] = its cursor, out[3] = the expected value
+__global__ __launch_bounds__(kBlock) void k_ss_verify_cursors(const u32 *__restrict__ start, const u32 *__restrict__ cur2, u32 n2,
+                                                             unsigned long long *out) {
+  const u32 i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n2 * kSsGroups) return;
+  const u32 s = i / kSsGroups, g = i % kSsGroups;
+  const u32 want = start[i + 1], got = cur2[(size_t)g * n2 + s];
+  if (want != got) {
+    if (atomicAdd(&out[0], 1ull) == 0) { out[1] = i; out[2] = got; out[3] = want; }
+  }
 }
 
 // Pass 3: block s orders sub-bucket s = records [start[8 s], start[8 (s + 1)]) (at most NT * IPT of them; larger ones

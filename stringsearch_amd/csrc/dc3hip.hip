@@ -103,6 +103,7 @@ struct dc3hip_ctx {
   bool no_wide_window = false; // DC3HIP_NO_WIDE_WINDOW=1: straight orderings always sort the triple (no wider window)
   bool ssort_rec12 = false;    // DC3HIP_SSORT_REC12=1: the splitter ordering also for keys of at most 64 bits (tests)
   bool no_pack_count = false;  // DC3HIP_NO_PACK_COUNT=1: the wide-window records are packed by their own kernel, then counted
+  bool ssort_verify = false;   // DC3HIP_SSORT_VERIFY=1 (tests): every splitter ordering checks its passes (record checksums, cursors, order); a mismatch fails the build
   bool no_ssort = false;       // DC3HIP_NO_SSORT=1: the straight orderings always run the stable LSD passes (no splitter ordering)
   u32 ssort_min = 1u << 23;    // DC3HIP_SSORT_MIN: fewest records the splitter ordering is used for (tests lower it)
   u32 msd_min = 1u << 20;      // DC3HIP_MSD_MIN: fewest records the bucket ordering is used for (tests lower it)
@@ -668,6 +669,13 @@ static int ssort(dc3hip_ctx *c, Rec *a, Rec *b, u32 n, u32 kbits, Rec **result, 
       KCHECK();
     }
   }
+  unsigned long long *vsum = nullptr;
+  if (c->ssort_verify) {
+    RC(arena_alloc(c, (size_t)8, &vsum));
+    HIPC(hipMemsetAsync(vsum, 0, 8 * sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL((k_ss_verify<Rec>), dim3(2048), dim3(kBlock), 0, c->stream, (const Rec *)a, n, vsum);
+    KCHECK();
+  }
   {
     PhaseScope ps(c, DC3HIP_PH_SORT12_SCAN, nb1);
     hipLaunchKernelGGL(k_ss_plan1, dim3(1), dim3(1024), 0, c->stream, (const u32 *)cntg, nb1, n, tile, htile, startg, cur1, bstart, tpre, tpreh, plan);
@@ -677,6 +685,10 @@ static int ssort(dc3hip_ctx *c, Rec *a, Rec *b, u32 n, u32 kbits, Rec **result, 
     PhaseScope ps(c, DC3HIP_PH_SORT12_DOWN, n, 7);
     hipLaunchKernelGGL((k_ss_part<Rec, false>), dim3(kSsGroups * cpx1), dim3(kSsNT), part_smem, c->stream, (const Rec *)a, b, n,
                        (const uint16_t *)dig, F2, cpx1, ntiles1, (const u32 *)nullptr, (const u32 *)nullptr, nb1, (const u32 *)plan, cur1, nb1);
+    KCHECK();
+  }
+  if (c->ssort_verify) {
+    hipLaunchKernelGGL((k_ss_verify<Rec>), dim3(2048), dim3(kBlock), 0, c->stream, (const Rec *)b, n, vsum + 4);
     KCHECK();
   }
   const u32 nseg = (u32)((N2 + kMsdScanSeg - 1) / kMsdScanSeg);              // <= 1024
@@ -705,10 +717,39 @@ static int ssort(dc3hip_ctx *c, Rec *a, Rec *b, u32 n, u32 kbits, Rec **result, 
                        (const u32 *)tpre, (const u32 *)bstart, nb1, (const u32 *)plan, cur2, n2);
     KCHECK();
   }
+  if (c->ssort_verify) {
+    hipLaunchKernelGGL((k_ss_verify<Rec>), dim3(2048), dim3(kBlock), 0, c->stream, (const Rec *)a, n, vsum + 6);
+    KCHECK();
+    unsigned long long *vc = nullptr;
+    RC(arena_alloc(c, (size_t)8, &vc));
+    HIPC(hipMemsetAsync(vc, 0, 8 * sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(k_ss_verify_cursors, dim3((u32)((N2 + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, (const u32 *)cnt2g, (const u32 *)cur2, n2, vc);
+    KCHECK();
+    unsigned long long hc[4];
+    HIPC(hipMemcpyAsync(hc, vc, sizeof(hc), hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    if (hc[0]) {
+      set_err("DC3HIP_SSORT_VERIFY: after pass 2 %llu regions are off; first (sub-bucket %llu, group %llu): cursor %llu, expected %llu (n=%u F2=%u)",
+              hc[0], hc[1] / 8, hc[1] % 8, hc[2], hc[3], n, F2);
+      return E_HIP;
+    }
+  }
   {
     PhaseScope ps(c, DC3HIP_PH_SORT12_DOWN, n, 8);
     hipLaunchKernelGGL((k_ss_local<Rec, kLocNT, kLocIPT>), dim3(n2), dim3(kLocNT), loc_smem, c->stream, (const Rec *)a, (const u32 *)cnt2g, b);
     KCHECK();
+  }
+  if (c->ssort_verify) {
+    hipLaunchKernelGGL((k_ss_verify<Rec>), dim3(2048), dim3(kBlock), 0, c->stream, (const Rec *)b, n, vsum + 2);
+    KCHECK();
+    unsigned long long h[8];
+    HIPC(hipMemcpyAsync(h, vsum, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    if (h[0] != h[2] || h[3] != 0) {
+      set_err("DC3HIP_SSORT_VERIFY: n=%u rec=%zu nb1=%u F2=%u S=%u checksums in=%llx pass1=%llx pass2=%llx out=%llx, %llu descents, largest sub-bucket %u",
+              n, sizeof(Rec), nb1, F2, S, h[0], h[4], h[6], h[2], h[3], maxsub);
+      return E_HIP;
+    }
   }
   c->stats.ssort_sorts++;
   arena_release(c, mk);        // (the stream orders the kernels above before whatever reuses the scratch)
@@ -2455,6 +2496,7 @@ int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) {
   { const char *e = getenv("DC3HIP_NO_TUP_SCATTER"); c->no_tup_scatter = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_MSD_MIN"); if (e) c->msd_min = (u32)std::max(4096ll, atoll(e)); }
   { const char *e = getenv("DC3HIP_NO_SSORT"); c->no_ssort = (e && e[0] == '1'); }
+  { const char *e = getenv("DC3HIP_SSORT_VERIFY"); c->ssort_verify = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_PACK_COUNT"); c->no_pack_count = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_SSORT_REC12"); c->ssort_rec12 = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_WIDE_WINDOW"); c->no_wide_window = (e && e[0] == '1'); }

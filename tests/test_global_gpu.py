@@ -70,6 +70,21 @@ def test_loopback_matches_single_device_all_levels_distributed(ss, oracle, P):
                 assert sum(s["shard_count"] for s in st) == len(t)
 
 
+@pytest.mark.parametrize("P", [2, 3, 4])
+def test_loopback_wide_windows_all_levels_distributed(ss, oracle, P):
+    """As above with the splitter ordering's threshold lowered: wherever a rank's share of a level has 8192 samples the
+    straight key-range sort orders W-symbol windows (4-7 symbols per 16-byte record instead of the triple) by sampled
+    splitters; names from wider windows change which slots the discarding recursion keeps on every level below."""
+    data = inputs(oracle)
+    data["text_3m"] = oracle.gen(3_000_001, 4, 2)
+    with env(DC3HIP_GLOBAL_LOCAL_MAX=64, DC3HIP_GLOBAL_NO_TEXT_ORDER=1, DC3HIP_SSORT_MIN=8192):
+        with ss.LoopbackGroup(P, max(len(v) for v in data.values())) as g:
+            for name, t in data.items():
+                g.set_text(t)
+                g.build()
+                assert np.array_equal(g.sa(), want_sa(oracle, t)), (name, P)
+
+
 @pytest.mark.parametrize("P", [2, 4, 8])
 def test_loopback_default_policy(ss, oracle, P):
     """Default thresholds (small levels finished locally, whole-text order allowed) and n % 3 in {0,1,2}."""
@@ -304,7 +319,11 @@ def test_loopback_env_matrix_agrees(ss, oracle):
     want = want_sa(oracle, t)
     for extra in ({}, {"DC3HIP_NO_HYBRID": 1}, {"DC3HIP_NO_FULLSORT": 1}, {"DC3HIP_NO_DISCARD": 1},
                   {"DC3HIP_NO_HYBRID": 1, "DC3HIP_NO_DISCARD": 1}, {"DC3HIP_NO_SMALL_TIES": 1}, {"DC3HIP_NO_SPLIT_EMIT": 1},
-                  {"DC3HIP_NO_TUP8": 1}, {"DC3HIP_NO_HYBRID8": 1}, {"DC3HIP_NO_HYBRID8": 1, "DC3HIP_NO_DISCARD": 1}):
+                  {"DC3HIP_NO_TUP8": 1}, {"DC3HIP_NO_HYBRID8": 1}, {"DC3HIP_NO_HYBRID8": 1, "DC3HIP_NO_DISCARD": 1},
+                  # the straight key-range sort on W-symbol windows, by the splitter ordering (threshold lowered)
+                  {"DC3HIP_SSORT_MIN": 8192}, {"DC3HIP_SSORT_MIN": 8192, "DC3HIP_NO_HYBRID8": 1},
+                  {"DC3HIP_SSORT_MIN": 8192, "DC3HIP_NO_HYBRID8": 1, "DC3HIP_NO_DISCARD": 1},
+                  {"DC3HIP_SSORT_MIN": 8192, "DC3HIP_NO_HYBRID8": 1, "DC3HIP_NO_WIDE_WINDOW": 1}):
         with env(DC3HIP_GLOBAL_LOCAL_MAX=5000, **extra):
             with ss.LoopbackGroup(4, len(t)) as g:
                 g.set_text(t)

@@ -119,4 +119,15 @@ def test_real_text_stays_on_its_route(ss):
         c.set_text(data)
         ms = best_ms(c, reps=2)
         assert c.sufcheck() == 0
-        report("real_text_256MiB", ms, {"levels": c.stats()["levels"]})
+        report("real_text_256MiB", ms, {"levels": c.stats()["levels"], "ssort_sorts": c.stats()["ssort_sorts"]})
+    # the corpus whose level 4 (9.8 M samples: 2-3 partition tiles per bucket) found the group-boundary bug of the first
+    # splitter ordering, one build in eight: a few more builds with the ordering's self-check on
+    os.environ["DC3HIP_SSORT_VERIFY"] = "1"
+    try:
+        with ss.Context(len(data)) as c:
+            c.set_text(data)
+            for _ in range(6):
+                c.build()
+            assert c.sufcheck() == 0
+    finally:
+        os.environ.pop("DC3HIP_SSORT_VERIFY", None)
