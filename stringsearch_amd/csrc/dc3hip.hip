@@ -617,7 +617,7 @@ static int ssort(dc3hip_ctx *c, Rec *a, Rec *b, u32 n, u32 kbits, Rec **result, 
   }
   constexpr int IPT = SsCfg<Rec>::IPT;
   constexpr u32 tile = (u32)kSsNT * IPT, htile = tile * kSsHistTiles;
-  constexpr int kLocNT = 512, kLocIPT = (int)(kSsCap / kLocNT);
+  constexpr int kLocNT = 1024, kLocIPT = (int)(kSsCap / kLocNT);
   constexpr size_t part_smem = ss_part_smem<Rec>(), loc_smem = sizeof(Rec) * kSsCap + kSsCap;
   static std::atomic<bool> attr_set[16];
   if (!attr_set[c->device & 15]) {
