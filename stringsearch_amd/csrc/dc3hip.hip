@@ -577,7 +577,7 @@ static int msd_redo(dc3hip_ctx *c, const MsdRedo &r, u32 n, Rec8 **result) {
 // in every such case and the caller runs the LSD passes).
 // ---------------------------------------------------------------------------------------------
 static constexpr u32 kSsCap = 4096;
-// Measured on MI355X (1 GiB text, profiles/r03h_*): 318 M 16-byte records with 81-bit keys, 21 ms against 32 ms for the 63-bit
+// Measured on MI355X (1 GiB text): 318 M 16-byte records with 81-bit keys, 21 ms against 32 ms for the 63-bit
 // prefix + tie rounds (and 9 LSD passes for the straight order); 477 M 12-byte records with 45-bit keys, 28 ms against
 // 21 ms for the 5 LSD passes — so the keys of at most 64 bits stay with the LSD passes (DC3HIP_SSORT_REC12=1: tests).
 static bool ssort_applies(const dc3hip_ctx *c, u32 n, u32 kbits) {
