@@ -49,12 +49,18 @@ struct SymU8 {
 #pragma unroll
     for (int k = 0; k < 4; k++) out[k] = (i + k < m) ? (u32)lds[(w >> (8 * k)) & 255u] : 0u;
   }
+  __device__ __forceinline__ void get2(u32 i, const uint16_t *lds, u32 *out) const {      // symbols i, i + 1
+    uint16_t w; __builtin_memcpy(&w, t + i, 2);
+    out[0] = (i < m) ? (u32)lds[w & 255u] : 0u;
+    out[1] = (i + 1 < m) ? (u32)lds[w >> 8] : 0u;
+  }
 };
 struct SymU32 {
   const u32 *s; u32 m;   // s has >= 8 zero words after s[m-1]
   static constexpr bool kTable = false;
   __device__ __forceinline__ u32 get(u32 i) const { return s[i]; }
   __device__ __forceinline__ void stage(uint16_t *) const {}
+  __device__ __forceinline__ void get2(u32 i, const uint16_t *, u32 *out) const { out[0] = s[i]; out[1] = s[i + 1]; }
   __device__ __forceinline__ void get4(u32 i, const uint16_t *, u32 *out) const {
 #pragma unroll
     for (int k = 0; k < 4; k++) out[k] = s[i + k];

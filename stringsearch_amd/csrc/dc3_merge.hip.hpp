@@ -179,21 +179,21 @@ __global__ __launch_bounds__(kBlock) void k_tup_hist1(const u32 *__restrict__ ra
 }
 
 // the (r, cc) payload of the sample in slot s (the fields of k_build_tuples8)
+// Branch-free (one text load of two symbols, one rank load whatever the residue of the sample: the loads of a thread's
+// eight slots are issued back to back instead of behind each slot's branches).
 template <class Sym>
 __device__ __forceinline__ void tup_payload(const Sym &S, const uint16_t *lcode, u32 m, u32 m0, bool dummy, const u32 *__restrict__ rank,
                                             u32 s, u32 &r, u32 &cc) {
-  if (s < m0) {                                          // mod-1 sample at 3s+1: c0 = S[3s+1], cx = S[3s], r = rank of suffix 3s+2
-    const u32 j = 3 * s;
-    u32 q[4]; S.get4(j, lcode, q);
-    cc = q[1] | (q[0] << 16);
-    r = (j + 2 < m) ? rank[m0 + s] : 0u;
-  } else {                                               // mod-2 sample at 3g+2: c0 = S[3g+2], cx = S[3g+3], r = rank of suffix 3g+4
-    const u32 g = s - m0, j = 3 * g;
-    u32 q[4]; S.get4(j + 2, lcode, q);
-    cc = q[0] | (q[1] << 16);
-    const bool has = (j + 4 < m) || (dummy && j + 4 == m);
-    r = has ? rank[g + 1] : 0u;
-  }
+  // mod-1 sample at 3s+1 (slot s < m0): c0 = S[3s+1], cx = S[3s], r = rank of suffix 3s+2 = slot m0 + s
+  // mod-2 sample at 3g+2 (slot m0 + g): c0 = S[3g+2], cx = S[3g+3], r = rank of suffix 3g+4 = slot g + 1
+  const bool mod1 = s < m0;
+  const u32 g = mod1 ? s : s - m0, j = 3 * g;
+  u32 q[2];
+  S.get2(j + (mod1 ? 0u : 2u), lcode, q);
+  cc = mod1 ? (q[1] | (q[0] << 16)) : (q[0] | (q[1] << 16));
+  const bool has = mod1 ? (j + 2 < m) : ((j + 4 < m) || (dummy && j + 4 == m));
+  const u32 rv = rank[has ? (mod1 ? m0 + s : g + 1) : 0u];
+  r = has ? rv : 0u;
 }
 
 // shared tail of the two partition passes: the tile's records sit in registers (dest/r/cc[k], valid for t < nvalid,
