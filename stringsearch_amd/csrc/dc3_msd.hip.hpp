@@ -286,7 +286,9 @@ __global__ __launch_bounds__(1024) void k_msd_hist2(const u64 *__restrict__ in, 
     if (pb >= end) break;
     const u32 pe = min(pb + (u32)kMsdTile, end);
     const u32 g = (tile0 + pt) / cpx2;
-    if (g != gcur) {                                  // (block-uniform: at most 7 group changes in the whole array)
+    if (g != gcur) {                                  // (block-uniform: at most 7 group changes in the whole array;
+                                                      //  this loop is unrolled and every barrier below has its LDS wait in
+                                                      //  the ISA: tests/test_isa_barriers.py)
       __syncthreads();
       if (tid < ndig && hist[tid]) atomicAdd(&cnt2g[(((size_t)b << dbits) + tid) * kMsdGroups + gcur], hist[tid]);
       hist[tid] = 0;

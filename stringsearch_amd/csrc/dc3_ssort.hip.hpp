@@ -317,6 +317,10 @@ __global__ __launch_bounds__(kSsNT) void k_ss_part(const Rec *__restrict__ in, R
 
 // Sizes of the sub-buckets per group (cf. k_msd_hist2): block h counts the digits of its piece (kSsHistTiles pass-2
 // tiles) of bucket b and adds them to cnt2g[(b * F2 + digit) * 8 + g], g = the group of the bucket's FIRST pass-2 tile.
+// (No barrier inside the tile loop, on purpose: the first version flushed the LDS histogram whenever a bucket's tiles
+// crossed into the next group's tile range, and hipcc emitted that in-loop barrier without the lgkmcnt(0) wait for the
+// ds_add_u32 pending around the loop's back-edge — counts off by a few records; tools/isa_barrier_scan.py
+// checks every barrier of every kernel for this.)
 template <class Rec>
 __global__ __launch_bounds__(kSsNT) void k_ss_hist2(const Rec *__restrict__ in, const SsVal *__restrict__ fine, u32 F2, u32 tile,
                                                    const u32 *__restrict__ tpre, const u32 *__restrict__ tpreh,
