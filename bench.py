@@ -136,6 +136,23 @@ def cpu_baseline_partitions(ss, P, total_len, sample_bytes, seed, kind, device):
             "host_cores_available": len(cores)}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` as a child process.  The child's stdout (the one
+    JSON line of rank 0) and stderr pass through; the child's exit code is returned."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: no launcher around --gpus %d: starting %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -167,10 +184,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Plain `python bench.py --gpus N`: start the one-process-per-GPU job ourselves, as a fresh CHILD process (this
+        # process has not touched the GPU yet and never will; no exec), relay its one JSON line and its exit code.
+        # crates/sacapart/src/lib.rs:39-58 parallelises inside one call; this is the same convenience for the bench.
+        sys.exit(self_launch(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes", file=sys.stderr)
-            sys.exit(2)
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}", file=sys.stderr)
+        sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
     # one rank per GPU; DC3HIP_BENCH_BACKEND=gloo lets several ranks share one GPU (plumbing test on 1-GPU boxes)
     backend = os.environ.get("DC3HIP_BENCH_BACKEND", "nccl")
@@ -223,7 +244,19 @@ def main():
             print(f"bench.py: rank {rank}: the RCCL communicator reports {seen} ranks, the job has {world}: refusing to call this run RCCL over xGMI",
                   file=sys.stderr, flush=True)
             os._exit(4)
-        selftest = {"passed": True, "transport": G.transport(), "ranks_seen_by_transport": seen, "world_size": world,
+        rccl_binding = None
+        if backend == "nccl":
+            # one RCCL per process: the library must have bound to the librccl torch already mapped (same file in
+            # /proc/self/maps, and the only librccl mapped)
+            path, pre = ss.GlobalRank.rccl_library()
+            mapped = sorted({l.split()[-1] for l in open("/proc/self/maps") if "librccl" in l})
+            rccl_binding = {"library": path, "was_already_mapped_by_host_program": pre, "librccl_files_mapped": mapped}
+            same = len(mapped) == 1 and os.path.realpath(mapped[0]) == os.path.realpath(path)
+            if not same:
+                print(f"bench.py: rank {rank}: libdc3hip bound to {path} but the process maps {mapped}: two RCCL instances in one "
+                      "process — refusing", file=sys.stderr, flush=True)
+                os._exit(4)
+        selftest = {"passed": True, "transport": G.transport(), "ranks_seen_by_transport": seen, "world_size": world, "rccl": rccl_binding,
                     "what": "ragged all_to_all_v + ragged all_gather_v + host all-gather of known bytes through the library's communicator, every byte checked on every rank"}
     if not do_sacapart:
         from stringsearch_amd.bench_global import run_global
@@ -473,26 +506,38 @@ def main():
             import threading
             done = threading.Event()
 
+            give_lock = threading.Lock()
+
             def give_up(why):
-                if done.is_set():
-                    return
-                done.set()
-                if rank == 0:
-                    sac["global_mode"] = {"error": why}
-                    sac["value_mode"] = "sacapart (the global leg did not finish: see global_mode.error)"
-                    sac["transport_selftest"] = selftest
-                    print(json.dumps(sac), flush=True)
-                os._exit(0 if rank == 0 else 5)
+                # The global leg did not finish: rank 0 still prints a line (the sacapart leg, `value` = null so that no
+                # harness reads the partitioned number as the global one) and EVERY rank exits non-zero (6).
+                with give_lock:
+                    if done.is_set():
+                        return
+                    done.set()
+                    if rank == 0:
+                        sac["global_mode"] = {"error": why}
+                        sac["value_sacapart"] = sac.get("value")
+                        sac["value"] = None
+                        sac["value_mode"] = "none (the global leg did not finish: see global_mode.error; the sacapart leg is value_sacapart)"
+                        sac["transport_selftest"] = selftest
+                        print(json.dumps(sac), flush=True)
+                    os._exit(6)
             wd = threading.Timer(args.global_timeout, give_up, args=(f"no result after {args.global_timeout} s",))
             wd.daemon = True
             wd.start()
+            outg = None
             try:
                 from stringsearch_amd.bench_global import run_global
                 outg = run_global(args, ss, dist, backend, world, rank, local_rank, per_gpu, kind, barrier, G=G)
             except BaseException as e:          # noqa: BLE001 - reported in the line
                 give_up(repr(e))
-            wd.cancel()
-            done.set()
+                time.sleep(3600)                # (the watchdog thread is printing / exiting: never fall through)
+            with give_lock:
+                if done.is_set():               # the watchdog fired while the leg was returning: it owns the exit
+                    time.sleep(3600)
+                wd.cancel()
+                done.set()
             if rank == 0:
                 keep = ("value", "unit", "ms_per_step", "value_MiBps", "roofline", "roofline_path", "verify", "config", "path", "arena_peak_GB")
                 outg["sacapart"] = {k: sac[k] for k in keep if k in sac}

@@ -294,6 +294,10 @@ DC3HIP_API int32_t dc3hip_global_loopback_create(dc3hip_gctx **ranks /*[P]*/, in
 DC3HIP_API int32_t dc3hip_global_loopback_build(dc3hip_gctx **ranks, int32_t P);
 /* RCCL: rank 0 obtains the id, the host program distributes it, every process creates its rank */
 DC3HIP_API int32_t dc3hip_rccl_unique_id(uint8_t *id128);
+/* Which RCCL the library bound to: the file its entry points were resolved from (dladdr), and whether the host program
+ * had that library mapped already (PyTorch maps its own torch/lib/librccl.so; two RCCL instances in one process must not
+ * happen — the library looks for a mapped one first).  bench.py prints it and compares it with /proc/self/maps. */
+DC3HIP_API int32_t dc3hip_rccl_library_path(char *buf, int32_t len, int32_t *was_already_mapped);
 DC3HIP_API int32_t dc3hip_global_rccl_create(dc3hip_gctx **out, const uint8_t *id128, int32_t rank, int32_t nranks,
                                              int32_t device, int64_t max_total_n);
 /* Host-staged transport: the caller supplies the two collectives on HOST buffers (MPI, gloo, ...); the library

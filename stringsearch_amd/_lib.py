@@ -142,6 +142,7 @@ SYMBOLS = {
     "dc3hip_global_loopback_create": (_i32, [ctypes.POINTER(_vp), _i32, _i32, _i64]),
     "dc3hip_global_loopback_build": (_i32, [ctypes.POINTER(_vp), _i32]),
     "dc3hip_rccl_unique_id": (_i32, [_vp]),
+    "dc3hip_rccl_library_path": (_i32, [ctypes.c_char_p, _i32, ctypes.POINTER(_i32)]),
     "dc3hip_global_rccl_create": (_i32, [ctypes.POINTER(_vp), _vp, _i32, _i32, _i32, _i64]),
     "dc3hip_global_host_create": (_i32, [ctypes.POINTER(_vp), ctypes.POINTER(HostTransport), _i32, _i32, _i32, _i64]),
     "dc3hip_global_destroy": (None, [_vp]),

@@ -148,10 +148,15 @@ struct RcclApi {
   decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   decltype(&ncclCommCount) CommCount = nullptr;          // optional (self-test: the rank count RCCL itself reports)
+  bool preloaded = false;                                // the host program had an RCCL mapped already and this is it
   bool load() {
     if (h) return true;
-    // a process that already carries an RCCL (PyTorch does) hands back that one for the same soname
-    for (const char *nm : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    // A process that already carries an RCCL (PyTorch maps its own torch/lib/librccl.so, soname librccl.so.1) must not get a
+    // second instance: look for a mapped one first (RTLD_NOLOAD matches by soname), load one only when there is none.
+    // dc3hip_rccl_library_path() reports which file the entry points came from; bench.py checks it against /proc/self/maps.
+    for (const char *nm : {"librccl.so.1", "librccl.so"}) { h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD); if (h) { preloaded = true; break; } }
+    if (!h)
+      for (const char *nm : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
     if (!h) { set_err("RCCL not found (dlopen librccl.so): %s", dlerror()); return false; }
 #define DC3_RCCL_SYM(field, sym) field = reinterpret_cast<decltype(field)>(dlsym(h, #sym)); if (!field) { set_err("RCCL symbol %s missing", #sym); h = nullptr; return false; }
     DC3_RCCL_SYM(GetUniqueId, ncclGetUniqueId) DC3_RCCL_SYM(CommInitRank, ncclCommInitRank) DC3_RCCL_SYM(CommDestroy, ncclCommDestroy)
@@ -1586,6 +1591,17 @@ int32_t dc3hip_rccl_unique_id(uint8_t *id128) {
   static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
   NCCLC(g_rccl.GetUniqueId(&id));
   memcpy(id128, &id, 128);
+  return E_OK;
+}
+
+int32_t dc3hip_rccl_library_path(char *buf, int32_t len, int32_t *was_already_mapped) {
+  if (!buf || len < 2) { set_err("buffer is NULL or too short"); return E_ARGS; }
+  std::lock_guard<std::mutex> lk(g_rccl_mu);
+  if (!g_rccl.load()) return E_HIP;
+  Dl_info di;
+  if (!dladdr(reinterpret_cast<const void *>(g_rccl.CommInitRank), &di) || !di.dli_fname) { set_err("dladdr(ncclCommInitRank) failed"); return E_HIP; }
+  snprintf(buf, (size_t)len, "%s", di.dli_fname);
+  if (was_already_mapped) *was_already_mapped = g_rccl.preloaded ? 1 : 0;
   return E_OK;
 }
 

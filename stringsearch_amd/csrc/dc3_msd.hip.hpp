@@ -264,11 +264,13 @@ __global__ __launch_bounds__(kMsdNW * 64) void k_msd_part_keys(KM km, HiMap hm, 
 
 // Sizes of the sub-buckets per group: block h counts the d2-digits of its piece (8 pass-2 tiles) of bucket b in LDS and
 // adds them to cnt2g[((b << d2) + digit) * 8 + g], g = the group that will work the tile in pass 2 (tile / cpx2).
+// No barrier inside the tile loop (hipcc once left out the LDS wait in front of such a barrier, DESIGN.md appendix "ISA
+// barrier scan"): the piece's tiles belong to at most 8 consecutive groups, and each group has its own LDS plane.
 __global__ __launch_bounds__(1024) void k_msd_hist2(const u64 *__restrict__ in, u64 base, u32 shift, u32 dbits,
                                                    const u32 *__restrict__ tpre, const u32 *__restrict__ tpreh,
                                                    const u32 *__restrict__ bstart, u32 nb1, const u32 *__restrict__ plan,
                                                    u32 *__restrict__ cnt2g) {
-  __shared__ u32 hist[kMsdMaxDig];
+  __shared__ u32 hist[kMsdGroups][kMsdMaxDig];
   if (blockIdx.x >= tpreh[nb1]) return;
   const u32 tid = threadIdx.x;
   const u32 ndig = 1u << dbits, mask = ndig - 1u;
@@ -278,32 +280,30 @@ __global__ __launch_bounds__(1024) void k_msd_hist2(const u64 *__restrict__ in, 
   const u32 begin = bstart[b] + hh * kMsdHistTile;
   const u32 end = min(begin + kMsdHistTile, bstart[b + 1]);
   const u32 tile0 = tpre[b] + hh * (kMsdHistTile / kMsdTile);
-  u32 gcur = tile0 / cpx2;
-  hist[tid] = 0;
+  const u32 g0 = tile0 / cpx2;
+#pragma unroll
+  for (u32 p = 0; p < kMsdGroups; p++) hist[p][tid] = 0;
   __syncthreads();
+  u32 gl = g0;
   for (u32 pt = 0; pt < kMsdHistTile / kMsdTile; pt++) {
     const u32 pb = begin + pt * (u32)kMsdTile;
     if (pb >= end) break;
     const u32 pe = min(pb + (u32)kMsdTile, end);
-    const u32 g = (tile0 + pt) / cpx2;
-    if (g != gcur) {                                  // (block-uniform: at most 7 group changes in the whole array;
-                                                      //  this loop is unrolled and every barrier below has its LDS wait in
-                                                      //  the ISA: tests/test_isa_barriers.py)
-      __syncthreads();
-      if (tid < ndig && hist[tid]) atomicAdd(&cnt2g[(((size_t)b << dbits) + tid) * kMsdGroups + gcur], hist[tid]);
-      hist[tid] = 0;
-      __syncthreads();
-      gcur = g;
-    }
+    gl = (tile0 + pt) / cpx2;                         // (block-uniform; gl - g0 <= 7: the groups are 0..7)
+    u32 *h = hist[gl - g0];
     u64 w[kMsdTile / 1024];
 #pragma unroll
     for (u32 k = 0; k < kMsdTile / 1024; k++) w[k] = in[min(pb + k * 1024u + tid, pe - 1u)];
 #pragma unroll
     for (u32 k = 0; k < kMsdTile / 1024; k++)
-      if (pb + k * 1024u + tid < pe) atomicAdd(&hist[(u32)((msd_word(w[k]) - base) >> shift) & mask], 1u);
+      if (pb + k * 1024u + tid < pe) atomicAdd(&h[(u32)((msd_word(w[k]) - base) >> shift) & mask], 1u);
   }
   __syncthreads();
-  if (tid < ndig && hist[tid]) atomicAdd(&cnt2g[(((size_t)b << dbits) + tid) * kMsdGroups + gcur], hist[tid]);
+  if (tid < ndig)
+    for (u32 p = 0; p <= gl - g0; p++) {
+      const u32 v = hist[p][tid];
+      if (v) atomicAdd(&cnt2g[(((size_t)b << dbits) + tid) * kMsdGroups + g0 + p], v);
+    }
 }
 
 // Exclusive prefix of cnt[0..N) (N = sub-buckets * 8, in that order), in place, in two launches of ceil(N / 8192) blocks

@@ -104,6 +104,14 @@ class GlobalRank:
         _check(lib().dc3hip_rccl_unique_id(buf))
         return bytes(buf)
 
+    @staticmethod
+    def rccl_library():
+        """(path of the RCCL the library bound to, True if the host program had it mapped before the library asked)."""
+        buf = ctypes.create_string_buffer(4096)
+        pre = ctypes.c_int32(0)
+        _check(lib().dc3hip_rccl_library_path(buf, 4096, ctypes.byref(pre)))
+        return buf.value.decode(), bool(pre.value)
+
     def close(self):
         if self._h:
             lib().dc3hip_global_destroy(self._h)

@@ -193,6 +193,13 @@ def test_rccl_transport_single_rank(ss, oracle):
     grouped send/recv paths with no peers, ncclAllGather of the host counts."""
     uid = ss.GlobalRank.rccl_unique_id()
     assert len(uid) == 128
+    # one RCCL per process: the library binds to the librccl the host program (torch) already mapped, and no second one
+    path, pre = ss.GlobalRank.rccl_library()
+    mapped = sorted({l.split()[-1] for l in open("/proc/self/maps") if "librccl" in l})
+    assert len(mapped) == 1 and os.path.realpath(mapped[0]) == os.path.realpath(path), (path, mapped)
+    import torch
+    if os.path.dirname(torch.__file__) in mapped[0]:
+        assert pre, "torch's librccl was mapped first, yet the library loaded its own"
     with env(DC3HIP_GLOBAL_FORCE_DIST=1, DC3HIP_GLOBAL_LOCAL_MAX=1000):
         r = ss.GlobalRank.rccl(uid, 0, 1, 0, 3_000_000)
     try:

@@ -1095,6 +1095,41 @@ def test_bench_two_ranks_on_one_gpu_matches_oracle(ss, oracle, tmp_path):
     assert np.array_equal(got, want.astype(np.int64))
 
 
+def test_bench_gpus_2_without_a_launcher(ss, oracle, tmp_path):
+    """`python bench.py --gpus 2 --size 4MiB` with NO launcher around it: bench.py starts the one-process-per-GPU job itself
+    as a fresh child (python -m torch.distributed.run ...), relays rank 0's one JSON line and the exit code.  Same keys as
+    the launched form above; both ranks on GPU 0 (DC3HIP_BENCH_BACKEND=gloo, host-staged transport)."""
+    import subprocess, sys
+    from conftest import ROOT
+    env = dict(os.environ, DC3HIP_BENCH_BACKEND="gloo", DC3HIP_BENCH_DUMP_SA=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    size = 4 << 20
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "4MiB", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert "no launcher around --gpus 2" in p.stderr
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["total_bytes"] == 2 * size
+    assert line["value"] > 0 and line["value_mode"].startswith("global") and "global SA" in line["config"]["partitioning"]
+    ic = line["interconnect"]
+    assert all(b > 0 for b in ic["bytes_in_per_rank_per_step"]) and ic["comm_ms"] > 0 and "host-staged" in ic["transport"]
+    assert line["verify"]["shards_tile_0_n"] and line["verify"]["equal_single_device_checksum"]
+    tst = line["transport_selftest"]
+    assert tst["passed"] is True and tst["ranks_seen_by_transport"] == 2 and tst["world_size"] == 2
+    assert line["sacapart"]["value"] > 0 and line["cpu_baseline"]["cores"] == 2
+    full = oracle.gen(2 * size, 2, 0)
+    got = np.concatenate([np.load(tmp_path / f"gshard_{r}.npy") for r in range(2)])
+    want = oracle.ref_sufsort(full) if oracle.ref is not None else oracle.sufsort(full)
+    assert np.array_equal(got, want.astype(np.int64))
+    # a failing child's exit code is relayed (a backend torch.distributed does not know fails in every rank of the child job)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "4MiB"],
+                       env=dict(env, DC3HIP_BENCH_BACKEND="no-such-backend"), capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
 def test_stage_level_trace_matches_oracle(ss, oracle, corpus):
     """Stage-level parity (SURVEY §5 tracing row; the counterpart of the reference's crosscheck!, crosscheck.rs:17-84):
     with DC3HIP_TRACE=1 the library reports, per level, checksums of the sorted samples SA12, the sorted mod-0 suffixes

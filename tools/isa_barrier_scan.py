@@ -87,3 +87,4 @@ if __name__ == '__main__':
             total += 1
             print(f"{len(bad)} barrier(s) reachable with a pending LDS write: {name[:110]}")
     print(f"kernels flagged: {total}")
+    sys.exit(1 if total else 0)                 # (the library's Makefile runs this on every build: a flagged kernel fails it)
