@@ -91,7 +91,8 @@ class GStats(ctypes.Structure):
                 ("total_n", ctypes.c_int64), ("shard_first", ctypes.c_int64), ("shard_count", ctypes.c_int64),
                 ("exchanges", ctypes.c_int64), ("exchange_pairs", ctypes.c_int64),
                 ("comm_bytes_out", ctypes.c_int64), ("comm_bytes_in", ctypes.c_int64),
-                ("comm_ms", ctypes.c_double), ("device_ms", ctypes.c_double), ("wall_ms", ctypes.c_double)]
+                ("comm_ms", ctypes.c_double), ("device_ms", ctypes.c_double), ("wall_ms", ctypes.c_double),
+                ("wide_msd", ctypes.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "struct_size"}

@@ -125,12 +125,13 @@ __global__ __launch_bounds__(kBlock) void k_checksum(const u32 *__restrict__ sa,
   if (lane_id() == 0) atomicAdd((unsigned long long *)out, (unsigned long long)acc);
 }
 // DC3HIP_TRACE: sum over k of mix(k, value_k); value = arr[k] (kind 0: positions), the level position of slot arr[k]
-// (kind 1: 3s+1 for s < m0, else 3(s-m0)+2 — lib.rs:136-144), or the pos field of a mod-0 tuple (kind 2)
+// (kind 1: 3s+1 for s < m0, else 3(s-m0)+2 — lib.rs:136-144), or the pos field of a mod-0 tuple (kind 2: Tup0, kind 3: Tup0C)
 __global__ __launch_bounds__(kBlock) void k_trace_sum(const void *arr, u32 n, int kind, u32 m0, u64 *out) {
   u64 acc = 0;
   for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     u32 v;
     if (kind == 2) v = static_cast<const Tup0 *>(arr)[i].pos;
+    else if (kind == 3) v = static_cast<const u32 *>(arr)[(size_t)i * 4];          // compact mod-0 tuple (Tup0C): pos is word 0 of 4
     else {
       v = static_cast<const u32 *>(arr)[i];
       if (kind == 1) v = v < m0 ? 3 * v + 1 : 3 * (v - m0) + 2;

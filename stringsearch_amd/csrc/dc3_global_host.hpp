@@ -303,6 +303,8 @@ struct HostComm : GComm {
 // ---------------------------------------------------------------------------------------------
 struct dc3hip_gctx {
   int wide_route_min_p = 6;    // wide mode: fewest ranks for which the selection is routed (see gbuild_wide)
+  bool no_wide_msd = false;    // DC3HIP_NO_WIDE_MSD=1: wide mode always sorts 16-byte records with the LSD passes
+  u64 wide_msd_min = 1ull << 22; // DC3HIP_WIDE_MSD_MIN (tests): fewest positions per rank for the wide bucket ordering
   u32 w_depth = 0;             // wide mode: symbols the last tie pass of the last build compared (the verifier compares at least as deep)
   bool route = true;           // DC3HIP_GLOBAL_NO_ROUTE=1: every rank evaluates all positions and keeps its key range (the round-2 form)
   dc3hip_ctx *c = nullptr;
@@ -1217,7 +1219,8 @@ static int wide_ensure(dc3hip_ctx *c, T **p, size_t *cap, size_t need) {
 }
 // The tie rounds of a wide build over the sorted records h[0..nrec): positions to G->w_shard, statistics in
 // c->h_words[10..12] (oversized group, tied records, windows that still agree after the last round).
-static int wide_tie_rounds(dc3hip_gctx *G, const Rec16 *h, u32 nrec, WideKey k) {
+template <class Launch>
+static int wide_tie_rounds_with(dc3hip_gctx *G, u32 nrec, WideKey k, Launch launch) {
   dc3hip_ctx *c = G->c;
     // tie pass; while a few windows still agree completely it is repeated with a deeper compare: kWideWindow symbols, then
     // kWideWindowDeep, then 16 times deeper per round for as long as (windows that still agree) x (next depth) stays inside
@@ -1231,7 +1234,7 @@ static int wide_tie_rounds(dc3hip_gctx *G, const Rec16 *h, u32 nrec, WideKey k) 
       HIPC(hipMemsetAsync(c->d_words + 10, 0, 3 * sizeof(u32), c->stream));
       if (nrec) {
         PhaseScope ps(c, DC3HIP_PH_TIES, nrec);
-        hipLaunchKernelGGL(k_wide_ties, dim3(grid_for(c, nrec)), dim3(kBlock), 0, c->stream, h, nrec, k, G->w_shard, c->d_words + 10);
+        launch(k);
         KCHECK();
       }
       HIPC(hipMemcpyAsync(c->h_words + 10, c->d_words + 10, 3 * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
@@ -1245,11 +1248,115 @@ static int wide_tie_rounds(dc3hip_gctx *G, const Rec16 *h, u32 nrec, WideKey k) 
     return E_OK;
 }
 
+static int wide_tie_rounds(dc3hip_gctx *G, const Rec16 *h, u32 nrec, WideKey k) {
+  dc3hip_ctx *c = G->c;
+  return wide_tie_rounds_with(G, nrec, k, [&](const WideKey &kk) {
+    hipLaunchKernelGGL(k_wide_ties, dim3(grid_for(c, nrec)), dim3(kBlock), 0, c->stream, h, nrec, kk, G->w_shard, c->d_words + 10);
+  });
+}
+
+// Pass 1 of the bucket ordering of a wide rank: selection + x' + partition by its top d1 bits, straight from the text
+struct WidePass1 : MsdPass1 {
+  WideKey k; WideRange rg; u64 chunk = 0; u32 nchunks = 0, cpg = 0;
+  int launch(dc3hip_ctx *c, u64 *out, u32, u64, u32, const MsdGeom &, u32, const u32 *, u32 *cur1) override {
+    static std::atomic<bool> attr_set[16];
+    if (!attr_set[c->device & 15]) {
+      HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_wide_part1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWidePartSmem));
+      attr_set[c->device & 15] = true;
+    }
+    hipLaunchKernelGGL(k_wide_part1, dim3(kMsdGroups * cpg), dim3(kWideNT), kWidePartSmem, c->stream, k, rg, chunk, nchunks, cpg, cur1, out);
+    KCHECK();
+    return E_OK;
+  }
+};
+
+// whether a wide build of n bytes over P ranks uses the bucket ordering on 8-byte words: the same answer on every rank
+static bool wide_msd_applies(const dc3hip_gctx *G, u64 n, int P, u32 ibits) {
+  const u64 est = n / (u64)P;
+  if (G->c->no_msd || G->no_wide_msd || est < G->wide_msd_min || est < 8192) return false;
+  const u32 pb = bits_of(n - 1), lg = bits_of(est - 1);
+  const u32 tb = std::min<u32>(20, lg > 10 ? lg - 10 : 1);
+  // a rank's span is about 2^ibits / P: x' keeps min(bits of the span, 64 - pb + d1) bits and needs tb + 4 of them
+  const u32 eb_typ = ibits > bits_of((u64)P) ? ibits - bits_of((u64)P) : 0;
+  return pb < 54 && std::min<u32>(eb_typ, 64 - pb + (tb <= 10 ? tb : (tb + 1) / 2)) >= tb + 6;
+}
+
+// The order of this rank's image range [lo, hi) by the bucket ordering on 8-byte words (dc3_wide_msd.hip.hpp): counting
+// pass over the text, partition pass 1 with selection, the 8-byte passes 2 and 3 of dc3_msd.hip.hpp, tie rounds.
+// *done = false: does not apply (switched off, too few positions, too few image bits) or a sub-bucket outgrew the local
+// sort — nothing was delivered and the caller runs the 16-byte LSD form.  *nrec_out = the rank's record count.
+static int wide_msd_order(dc3hip_gctx *G, const WideKey &k, u32 ibits, u64 lo, u64 hi, bool last, u32 *nrec_out, bool *done) {
+  dc3hip_ctx *c = G->c; GComm *cm = G->comm;
+  const int P = cm->nranks;
+  const u64 n = (u64)G->total_n;
+  *done = false;
+  const u64 est = n / (u64)P;
+  const u64 top = ibits >= 64 ? ~0ull : (1ull << ibits);
+  const u64 span = (last ? top : hi) - lo;
+  if (span < 2) return E_OK;
+  const u32 eb = bits_of(span - 1), pb = bits_of(n - 1);
+  const u32 lg = bits_of(est - 1);
+  u32 tb = lg > 10 ? lg - 10 : 1;
+  if (tb > 20) tb = 20;
+  u32 d1, d2;
+  if (tb <= 10) { d1 = tb; d2 = 0; } else { d1 = (tb + 1) / 2; d2 = tb - d1; }
+  const u32 E = std::min<u32>(std::min<u32>(eb, 63u), 64u - pb + d1);
+  if (pb >= 64 || E < tb + 4) return E_OK;
+  WidePass1 p1;
+  p1.k = k;
+  p1.rg.lo = lo; p1.rg.hi = hi; p1.rg.last = last ? 1u : 0u; p1.rg.eb = eb; p1.rg.E = E; p1.rg.d1 = d1; p1.rg.pb = pb;
+  p1.rg.M = (u64)((((unsigned __int128)1) << (63 + eb)) / span);
+  p1.chunk = ((n + 2047) / 2048 + kWideRound - 1) / kWideRound * kWideRound;
+  p1.nchunks = (u32)((n + p1.chunk - 1) / p1.chunk);
+  p1.cpg = (p1.nchunks + kMsdGroups - 1) / kMsdGroups;
+  const u32 nb1 = 1u << d1;
+  const ArenaMark mk = arena_mark(c);
+  u32 *table = nullptr, *cntg = nullptr;
+  RC(arena_alloc(c, (size_t)1024 * p1.nchunks, &table));
+  RC(arena_alloc(c, (size_t)nb1 * kMsdGroups + 16, &cntg));
+  {
+    PhaseScope ps(c, DC3HIP_PH_PACK, (int64_t)n);
+    hipLaunchKernelGGL(k_wide_count1, dim3(p1.nchunks), dim3(kWideNT), 0, c->stream, k, p1.rg, p1.chunk, p1.nchunks, table);
+    KCHECK();
+    hipLaunchKernelGGL(k_msd_cnt1, dim3(nb1), dim3(kBlock), 0, c->stream, (const u32 *)table, p1.nchunks, p1.cpg, cntg);
+    KCHECK();
+  }
+  std::vector<u32> hc((size_t)nb1 * kMsdGroups);
+  HIPC(hipMemcpyAsync(hc.data(), cntg, hc.size() * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  u64 nrec64 = 0;
+  for (u32 v : hc) nrec64 += v;
+  if (nrec64 > (u64)DC3HIP_MAX_N) { set_err("wide global mode: rank %d would hold %llu suffixes (more ranks needed)", cm->rank, (unsigned long long)nrec64); return E_TOOBIG; }
+  const u32 nrec = (u32)nrec64;
+  *nrec_out = nrec;
+  if (nrec < 4096) { arena_release(c, mk); return E_OK; }
+  // two arrays of 8-byte words inside the record buffers, and the shard
+  RC(wide_ensure(c, &G->w_ra, &G->w_cap_a, (size_t)nrec / 2 + 16));
+  RC(wide_ensure(c, &G->w_rb, &G->w_cap_b, (size_t)nrec / 2 + 16));
+  RC(wide_ensure(c, &G->w_shard, &G->w_cap_s, (size_t)nrec + 16));
+  MsdGeom g;
+  g.on = true; g.d1 = d1; g.d2 = d2; g.cpg = p1.cpg; g.ck.nchunks = p1.nchunks; g.ck.chunk = 0; g.img_lo = 0; g.ebits = E;
+  HiMap hm; hm.mfix = 0; hm.shx = 0; hm.pbits = pb; hm.nbits = E; hm.exact = 0;
+  Rec8 *res = nullptr, *where = nullptr; MsdRedo redo; bool ok = false;
+  RC(msd_sort(c, reinterpret_cast<Rec8 *>(G->w_ra), reinterpret_cast<Rec8 *>(G->w_rb), nrec, hm, g, table, nullptr, &res, &redo, &ok, &where, &p1));
+  if (!ok) { arena_release(c, mk); return E_OK; }
+  const u64 *h = reinterpret_cast<const u64 *>(res);
+  RC(wide_tie_rounds_with(G, nrec, k, [&](const WideKey &kk) {
+    hipLaunchKernelGGL(k_wide_ties8, dim3(grid_for(c, nrec)), dim3(kBlock), 0, c->stream, h, nrec, pb, kk, G->w_shard, c->d_words + 10);
+  }));
+  arena_release(c, mk);
+  G->gs.wide_msd = 1;
+  *done = true;
+  return E_OK;
+}
+
 static int gbuild_wide(dc3hip_gctx *G) {
   dc3hip_ctx *c = G->c; GComm *cm = G->comm;
   const int P = cm->nranks, me = cm->rank;
   const u64 n = (u64)G->total_n;
   c->n = 0;
+  c->arena_off = 0;
+  RC(ensure_arena(c, (size_t)256 << 20));   // the sorts' tables: digit table 8 MB, 2 x 2^20 sub-buckets x 8 groups x 4 bytes, counts
   RC(build_begin(c));
   {
     size_t roff[kMaxRanks], rbytes[kMaxRanks];
@@ -1319,7 +1426,11 @@ static int gbuild_wide(dc3hip_gctx *G) {
   // From 6 ranks on (DC3HIP_GLOBAL_WIDE_ROUTE_MIN_P): packing + partitioning + exchanging 16-byte records is a constant
   // ≈ 100 ms of total work per 4.3 GB, two evaluations of all positions on every rank cost ≈ 19 ms per rank — measured as
   // total work of P loopback ranks on one GPU: P = 2: 386 routed / 329 not, P = 4: 377 / 348, P = 8: 385 / 425 ms.
-  if (G->route && P >= G->wide_route_min_p && ibits >= 8 && n / (u64)P + 16 <= (u64)DC3HIP_MAX_N) {
+  // (where the bucket ordering on 8-byte words applies — decided from n and P alone, alike on every rank — nothing is
+  //  routed: its pass 1 selects straight from the replicated text, and what it cannot order falls back to the unrouted
+  //  16-byte form on that rank alone, which needs no collective)
+  const bool msd_static = wide_msd_applies(G, n, P, ibits);
+  if (!msd_static && G->route && P >= G->wide_route_min_p && ibits >= 8 && n / (u64)P + 16 <= (u64)DC3HIP_MAX_N) {
     u32 dlo[kMaxRanks + 1];
     {
       u32 cnt256[257] = {0};
@@ -1398,6 +1509,12 @@ static int gbuild_wide(dc3hip_gctx *G) {
       Rec16 *h = G->w_ra;
       if (nrec) RC(radix_sort<Rec16>(c, G->w_ra, G->w_rb, nrec, 0, ibits, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT12_DOWN));
       return wide_tie_rounds(G, h, nrec, k);
+    }
+    // bucket ordering on 8-byte words where it applies (the 16-byte LSD form below otherwise)
+    if (msd_static) {
+      bool msd_done = false;
+      RC(wide_msd_order(G, k, ibits, lo, hi, me + 1 == P, &nrec, &msd_done));
+      if (msd_done) return E_OK;
     }
     // count, allocate, write
     const u64 chunk = (u64)1 << 20;
@@ -1532,6 +1649,8 @@ static void gctx_env(dc3hip_gctx *G) {
   if (const char *e = getenv("DC3HIP_GLOBAL_FORCE_DIST")) G->force_dist = e[0] == '1';
   if (const char *e = getenv("DC3HIP_GLOBAL_NO_ROUTE")) G->route = e[0] != '1';
   if (const char *e = getenv("DC3HIP_GLOBAL_WIDE_ROUTE_MIN_P")) G->wide_route_min_p = std::max(1, atoi(e));
+  if (const char *e = getenv("DC3HIP_NO_WIDE_MSD")) G->no_wide_msd = e[0] == '1';
+  if (const char *e = getenv("DC3HIP_WIDE_MSD_MIN")) { const long long v = atoll(e); if (v >= 0) G->wide_msd_min = (u64)v; }
 }
 
 // the rank's device context: a full one (text, SA, arena for max_total_n) — or, in wide mode, a minimal one (stream,

@@ -198,9 +198,9 @@ __device__ __forceinline__ void tup_payload(const Sym &S, const uint16_t *lcode,
 
 // shared tail of the two partition passes: the tile's records sit in registers (dest/r/cc[k], valid for t < nvalid,
 // t = k * kTupNT + tid); rank them by digit in LDS, reserve, reorder, write the runs.
-template <class DigitOf, class BaseOf>
+template <class DigitOf, class BaseOf, class Emit>
 __device__ __forceinline__ void tup_partition_tile(const u32 (&dest)[kTupIPT], const u32 (&rr)[kTupIPT], const u32 (&cc)[kTupIPT],
-                                                   u32 nvalid, u32 ndig, DigitOf digit_of, BaseOf reserve, TupRec *__restrict__ out,
+                                                   u32 nvalid, u32 ndig, DigitOf digit_of, BaseOf reserve, Emit emit,
                                                    unsigned char *smem) {
   u32 *sd = reinterpret_cast<u32 *>(smem), *sr = sd + kTupTile, *sc = sr + kTupTile;
   u32 *hist = sc + kTupTile, *gbase = hist + 1024, *tmp = gbase + 1024;
@@ -231,14 +231,39 @@ __device__ __forceinline__ void tup_partition_tile(const u32 (&dest)[kTupIPT], c
   __syncthreads();
   for (u32 q = tid; q < nvalid; q += kTupNT) {
     const u32 d = sd[q], dd = digit_of(d);
-    out[gbase[dd] + (q - hist[dd])] = TupRec{d, sr[q], sc[q]};
+    emit(gbase[dd] + (q - hist[dd]), d, sr[q], sc[q]);
   }
 }
+// what a partition pass leaves per sample:
+//   TupOut12  (dest, r, cc) as three words — any level whose symbols fit 16 bits (cc = c0 | cx << 16)
+//   TupOut8   one 64-bit word  cx << (22 + rb) | r << 22 | (dest & (2^22 - 1))  — level 0 (bytes: cx has 9 bits, r has
+//             rb = bits of m02 <= 32): the top bits of dest are the bucket the record lies in, and c0 is not carried at all
+//             — in SA12 order the first symbols are non-decreasing, so k_tup_local reads c0 off a 258-entry table of
+//             cumulative first-symbol counts (k_sample_sym_hist)
+struct TupOut12 {
+  TupRec *p;
+  typedef TupRec Rec;
+  __device__ __forceinline__ void operator()(u32 i, u32 d, u32 r, u32 cc) const { p[i] = TupRec{d, r, cc}; }
+  __device__ __forceinline__ static void unpack(const TupRec &x, u32, u32 &d, u32 &r, u32 &cc) { d = x.dest; r = x.r; cc = x.cc; }
+};
+struct TupOut8 {
+  u64 *p; u32 rb;
+  typedef u64 Rec;
+  __device__ __forceinline__ void operator()(u32 i, u32 d, u32 r, u32 cc) const {
+    p[i] = (u64)(d & ((1u << kTupSh1) - 1u)) | ((u64)r << kTupSh1) | ((u64)(cc >> 16) << (kTupSh1 + rb));
+  }
+  // d = dest & (2^22 - 1): what the second pass and the window placement need of it;  cc = cx << 16 (c0 absent)
+  __device__ __forceinline__ static void unpack(u64 x, u32 rb, u32 &d, u32 &r, u32 &cc) {
+    d = (u32)x & ((1u << kTupSh1) - 1u);
+    r = (u32)(x >> kTupSh1) & (rb >= 32 ? 0xffffffffu : ((1u << rb) - 1u));
+    cc = (u32)(x >> (kTupSh1 + rb)) << 16;
+  }
+};
 
-template <class Sym>
+template <class Sym, class Out>
 __global__ __launch_bounds__(kTupNT) void k_tup_part1(Sym S, u32 m, u32 m0, u32 m02, const u32 *__restrict__ rank12, u32 cpx,
                                                      u32 ntiles, u32 ndig, u32 *__restrict__ cursors /*[8][ndig]*/,
-                                                     TupRec *__restrict__ out) {
+                                                     Out out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ uint16_t lcode[256];
   const u32 g = blockIdx.x % 8u, idx = blockIdx.x / 8u;
@@ -260,8 +285,9 @@ __global__ __launch_bounds__(kTupNT) void k_tup_part1(Sym S, u32 m, u32 m0, u32 
 }
 
 // pass 2: bucket b = records [b << 22, min(m02, (b + 1) << 22)); tile list: bucket b on the XCD group b % 8
-__global__ __launch_bounds__(kTupNT) void k_tup_part2(const TupRec *__restrict__ in, u32 m02, u32 nbuckets,
-                                                     u32 *__restrict__ cursors /*[nbuckets][512], zeroed*/, TupRec *__restrict__ out) {
+template <class Out>
+__global__ __launch_bounds__(kTupNT) void k_tup_part2(const typename Out::Rec *__restrict__ in, u32 m02, u32 nbuckets,
+                                                     u32 *__restrict__ cursors /*[nbuckets][512], zeroed*/, Out out, u32 rb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr u32 tpb = (1u << kTupSh1) / kTupTile;         // tiles per bucket
   const u32 g = blockIdx.x % 8u, idx = blockIdx.x / 8u;
@@ -273,39 +299,83 @@ __global__ __launch_bounds__(kTupNT) void k_tup_part2(const TupRec *__restrict__
   u32 dest[kTupIPT], rr[kTupIPT], cc[kTupIPT];
 #pragma unroll
   for (int k = 0; k < kTupIPT; k++) {
-    const TupRec x = in[begin + min((u32)(k * kTupNT) + threadIdx.x, nvalid - 1u)];
-    dest[k] = x.dest; rr[k] = x.r; cc[k] = x.cc;
+    const typename Out::Rec x = in[begin + min((u32)(k * kTupNT) + threadIdx.x, nvalid - 1u)];
+    Out::unpack(x, rb, dest[k], rr[k], cc[k]);
   }
   u32 *cur = cursors + ((size_t)b << 9);
   const u32 base = b << kTupSh1;
+  // ((d >> 13) & 511 is the same digit whether d is the whole destination or its low 22 bits)
   tup_partition_tile(dest, rr, cc, nvalid, 512u, [](u32 d) { return (d >> kTupWinBits) & 511u; },
                      [&](u32 d, u32 cnt) { return base + (d << kTupWinBits) + atomicAdd(&cur[d], cnt); }, out, smem);
 }
 
+// Cumulative first-symbol counts of the level's sample suffixes (level 0: codes 0..sigma, 0 = the dummy sample behind
+// the text): hist[c] += samples whose first symbol is c.  One pass over S; `hist` (nsym words, zeroed) is turned into the
+// exclusive prefix cum[0..nsym] by k_scan_excl_inplace.  A sample of SA12 rank k starts with the symbol c for which
+// cum[c] <= k < cum[c + 1] — SA12 is sorted, its first symbols are non-decreasing.
+template <class Sym>
+__global__ __launch_bounds__(kBlock) void k_sample_sym_hist(Sym S, u32 m, u32 m0, u32 nsym, u32 *__restrict__ hist) {
+  __shared__ u32 h[kWaves][264];
+  __shared__ uint16_t lcode[256];
+  for (u32 j = threadIdx.x; j < kWaves * 264; j += kBlock) (&h[0][0])[j] = 0;
+  S.stage(lcode);
+  __syncthreads();
+  u32 *myh = h[wave_id()];
+  for (u32 g = blockIdx.x * kBlock + threadIdx.x; g < m0; g += gridDim.x * kBlock) {
+    const u32 j = 3 * g;
+    u32 q[4]; S.get4(j, lcode, q);
+    atomicAdd(&myh[q[1]], 1u);                       // mod-1 sample at j + 1 (the dummy when j + 1 == m: symbol 0)
+    if (j + 2 < m) atomicAdd(&myh[q[2]], 1u);        // mod-2 sample at j + 2
+  }
+  __syncthreads();
+  for (u32 c = threadIdx.x; c < nsym; c += kBlock) {
+    const u32 v = h[0][c] + h[1][c] + h[2][c] + h[3][c];
+    if (v) atomicAdd(&hist[c], v);
+  }
+}
+
+// Compact merge tuples (levels whose symbols fit 16 bits): 12 bytes per sample and 16 per mod-0 suffix instead of 16 and
+// 20 — the unwinding of a level (tuples, mod-0 order, merge: lib.rs:118-192) is pure record traffic.
+struct TupC { u32 pos, r, cc; };                                      // cc = c0 | cx << 16   (fields as Tup12)
+struct __attribute__((aligned(16))) Tup0C { u32 pos, cc, r1, r2; };   // cc = c0 | c1 << 16   (fields as Tup0)
+
 // window w: the records [w * kTupWin, ...) are exactly those with dest in the window
-__global__ __launch_bounds__(1024) void k_tup_local(const TupRec *__restrict__ in, const u32 *__restrict__ sa12, u32 m02, u32 m0,
-                                                   u32 chunk, u32 nchunks, Tup12 *__restrict__ out,
-                                                   u32 *__restrict__ table /*[256][nchunks], zeroed*/) {
+// kDerive (8-byte records): c0 is not in the record; cum[0..nsym] gives it (see k_sample_sym_hist).
+template <class Out, bool kDerive>
+__global__ __launch_bounds__(1024) void k_tup_local(const typename Out::Rec *__restrict__ in, u32 rb, const u32 *__restrict__ sa12, u32 m02, u32 m0,
+                                                   u32 chunk, u32 nchunks, const u32 *__restrict__ cum, u32 nsym,
+                                                   TupC *__restrict__ out, u32 *__restrict__ table /*[256][nchunks], zeroed*/) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // 2 * kTupWin words (dynamic: 64 KiB)
   u32 *wr = reinterpret_cast<u32 *>(smem), *wc = wr + kTupWin;
   __shared__ u32 hist[2][256];
+  __shared__ u32 scum[kDerive ? 264 : 1];
   const u32 base = blockIdx.x * kTupWin, cnt = min(kTupWin, m02 - base);
   if (threadIdx.x < 512) hist[threadIdx.x >> 8][threadIdx.x & 255] = 0;
+  if (kDerive && threadIdx.x <= nsym) scum[threadIdx.x] = cum[threadIdx.x];            // nsym <= 258
   for (u32 i = threadIdx.x; i < cnt; i += 1024) {
-    const TupRec x = in[base + i];
-    wr[x.dest - base] = x.r; wc[x.dest - base] = x.cc;
+    u32 d, r, cc;
+    Out::unpack(in[base + i], rb, d, r, cc);
+    wr[d & (kTupWin - 1u)] = r; wc[d & (kTupWin - 1u)] = cc;
   }
   __syncthreads();
+  u32 c0 = 0;
+  if (kDerive) {
+    // symbol of the window's first rank: the largest c with cum[c] <= base (block-uniform, broadcast reads)
+    u32 lo = 0, hi = nsym;                    // invariant: cum[lo] <= base < cum[hi]   (cum[0] = 0, cum[nsym] = m02 > base)
+    while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (scum[mid] <= base) lo = mid; else hi = mid; }
+    c0 = lo;
+  }
   const u32 c_lo = base / chunk;                          // a window touches at most two chunks of the mod-0 pass (chunk >= kTupWin)
-  u32x4 *ov = reinterpret_cast<u32x4 *>(out);
   for (u32 i = threadIdx.x; i < cnt; i += 1024) {
     const u32 s = sa12[base + i];
     const bool mod1 = s < m0;
-    u32x4 o;
-    o.x = mod1 ? 3 * s + 1 : 3 * (s - m0) + 2;
-    o.y = wr[i]; o.z = wc[i] & 0xffffu; o.w = wc[i] >> 16;
-    ov[base + i] = o;
-    if (mod1) atomicAdd(&hist[(base + i) / chunk - c_lo][(o.w - 1u) & 255u], 1u);
+    u32 cc = wc[i];
+    if (kDerive) {
+      while (scum[c0 + 1] <= base + i) c0++;              // (ranks grow with i: the walk never goes back)
+      cc |= c0;
+    }
+    out[base + i] = TupC{mod1 ? 3 * s + 1 : 3 * (s - m0) + 2, wr[i], cc};
+    if (mod1) atomicAdd(&hist[(base + i) / chunk - c_lo][((cc >> 16) - 1u) & 255u], 1u);
   }
   __syncthreads();
   if (threadIdx.x < 512) {
@@ -320,6 +390,16 @@ __global__ __launch_bounds__(1024) void k_tup_local(const TupRec *__restrict__ i
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool is_mod1(u32 pos) { return pos % 3 == 1; }
 
+// The two tuple formats behind one face: a sample tuple as (pos, r, c0, cx), a mod-0 tuple as its comparison key
+// (c0, c1, r1, r2) + pos.
+__device__ __forceinline__ u32x4 tupa_words(const Tup12 &a) { u32x4 v; v.x = a.pos; v.y = a.r; v.z = a.c0; v.w = a.cx; return v; }
+__device__ __forceinline__ u32x4 tupa_words(const TupC &a) { u32x4 v; v.x = a.pos; v.y = a.r; v.z = a.cc & 0xffffu; v.w = a.cc >> 16; return v; }
+__device__ __forceinline__ u32x4 tupb_key(const Tup0 &z) { u32x4 k; k.x = z.c0; k.y = z.c1; k.z = z.r1; k.w = z.r2; return k; }
+__device__ __forceinline__ u32x4 tupb_key(const Tup0C &z) { u32x4 k; k.x = z.cc & 0xffffu; k.y = z.cc >> 16; k.z = z.r1; k.w = z.r2; return k; }
+template <class TA> struct Mod0Of;
+template <> struct Mod0Of<Tup12> { typedef Tup0 type; };
+template <> struct Mod0Of<TupC> { typedef Tup0C type; };
+
 // Loader of the fused Step-2 pass: element i of the sorted sample tuples yields a mod-0 tuple iff it
 // is a mod-1 suffix; r1 = i+1 is the rank of suffix j+1, so the stream is already ordered by it.
 struct Mod0Loader {
@@ -331,23 +411,37 @@ struct Mod0Loader {
     return true;
   }
 };
+struct Mod0LoaderC {
+  const TupC *t;
+  __device__ __forceinline__ bool load(u32 i, Tup0C &z) const {
+    const TupC a = t[i];
+    if (!is_mod1(a.pos)) return false;
+    z.pos = a.pos - 1; z.cc = (a.cc >> 16) | (a.cc << 16); z.r1 = i + 1; z.r2 = a.r;     // (c0, c1) = (cx, c0) of the sample
+    return true;
+  }
+};
+// mod-0 positions are real symbols (c0 >= 1), so the key is c0-1 in [0, K)
+__device__ __forceinline__ u32 digit_of(const Tup0C &r, KeyDig d) { return (((r.cc & 0xffffu) - 1u) >> d.shift) & d.mask; }
 
 // ---------------------------------------------------------------------------------------------
 // Step 3 (lib.rs:131-192): merge of SA12 and SA0 as a merge-path merge.
 // Comparator = leq2 / leq3 of lib.rs:3-11 in Kärkkäinen–Sanders argument order (the reference's
 // leq3 parameter list is scrambled, lib.rs:9 vs :154-161).  Suffixes are distinct, so < == <=.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool sample_before(const Tup12 &a, const Tup0 &z) {
-  if (is_mod1(a.pos)) return (a.c0 < z.c0) || (a.c0 == z.c0 && a.r <= z.r1);               // leq2
-  return (a.c0 < z.c0) || (a.c0 == z.c0 && ((a.cx < z.c1) || (a.cx == z.c1 && a.r <= z.r2))); // leq3
+__device__ __forceinline__ bool sample_before4(const u32x4 a /*pos,r,c0,cx*/, const u32x4 z /*c0,c1,r1,r2*/) {
+  if (is_mod1(a.x)) return (a.z < z.x) || (a.z == z.x && a.y <= z.z);                                   // leq2
+  return (a.z < z.x) || (a.z == z.x && ((a.w < z.y) || (a.w == z.y && a.y <= z.w)));                    // leq3
 }
+
+__device__ __forceinline__ bool sample_before(const Tup12 &a, const Tup0 &z) { return sample_before4(tupa_words(a), tupb_key(z)); }
 
 // Merge-path split points: part[t] = number of A elements among the first t*tile outputs.
 // Two levels: `coarse` (optional) holds the split of every `ratio`-th tile boundary, which bounds the
 // binary search of the tiles in between to a window of ratio*tile elements (L2-resident, ~half the
 // dependent steps) — the unbounded search over 10^9 elements fetched 15 GB per build.
-__global__ __launch_bounds__(kBlock) void k_merge_partition(const Tup12 *__restrict__ A, u32 nA,
-                                                           const Tup0 *__restrict__ B, u32 nB, u32 ntiles,
+template <class TA, class TB>
+__global__ __launch_bounds__(kBlock) void k_merge_partition(const TA *__restrict__ A, u32 nA,
+                                                           const TB *__restrict__ B, u32 nB, u32 ntiles,
                                                            u32 tile, const u32 *__restrict__ coarse, u32 ratio,
                                                            u32 *__restrict__ part /*[ntiles+1]*/) {
   const u32 t = blockIdx.x * kBlock + threadIdx.x;
@@ -363,7 +457,7 @@ __global__ __launch_bounds__(kBlock) void k_merge_partition(const Tup12 *__restr
   }
   while (lo < hi) {
     const u32 mid = lo + ((hi - lo) >> 1);     // (lo + hi) would overflow u32 beyond 2^31 samples
-    if (sample_before(A[mid], B[diag - 1 - mid])) lo = mid + 1; else hi = mid;
+    if (sample_before4(tupa_words(A[mid]), tupb_key(B[diag - 1 - mid]))) lo = mid + 1; else hi = mid;
   }
   part[t] = lo;
 }
@@ -375,15 +469,11 @@ __global__ __launch_bounds__(kBlock) void k_merge_partition(const Tup12 *__restr
 // LDS image of a tile: sample tuples as 16-byte words (pos, r, c0, cx); mod-0 tuples split into a
 // 16-byte comparison key (c0, c1, r1, r2) and a separate pos array, so that every comparison is two
 // ds_read_b128 (the packed 20-byte Tup0 would be five ds_read_b32).
-__device__ __forceinline__ bool sample_before4(const u32x4 a /*pos,r,c0,cx*/, const u32x4 z /*c0,c1,r1,r2*/) {
-  if (is_mod1(a.x)) return (a.z < z.x) || (a.z == z.x && a.y <= z.z);                                   // leq2
-  return (a.z < z.x) || (a.z == z.x && ((a.w < z.y) || (a.w == z.y && a.y <= z.w)));                    // leq3
-}
 template <int NT, int VT>
 struct MergeSmem { static constexpr size_t kBytes = (16 + 16 + 4) * (size_t)(NT * VT) + 64; };
 
-template <int NT, int VT>
-__global__ __launch_bounds__(NT) void k_merge(const Tup12 *__restrict__ A, u32 nA, const Tup0 *__restrict__ B, u32 nB,
+template <int NT, int VT, class TA, class TB>
+__global__ __launch_bounds__(NT) void k_merge(const TA *__restrict__ A, u32 nA, const TB *__restrict__ B, u32 nB,
                                              const u32 *__restrict__ part, u32 *__restrict__ out_sa,
                                              Rec8 *__restrict__ out_pairs, u32 rank_base) {
   constexpr u32 kTile = NT * VT;
@@ -397,12 +487,10 @@ __global__ __launch_bounds__(NT) void k_merge(const Tup12 *__restrict__ A, u32 n
   const u32 a0 = part[blockIdx.x], a1 = part[blockIdx.x + 1];
   const u32 b0 = d0 - a0, b1 = d1 - a1;
   const u32 na = a1 - a0, nb = b1 - b0;
-  const u32x4 *Av = reinterpret_cast<const u32x4 *>(A);
-  for (u32 i = threadIdx.x; i < na; i += NT) sa[i] = Av[a0 + i];
+  for (u32 i = threadIdx.x; i < na; i += NT) sa[i] = tupa_words(A[a0 + i]);
   for (u32 i = threadIdx.x; i < nb; i += NT) {
-    const Tup0 z = B[b0 + i];
-    u32x4 k; k.x = z.c0; k.y = z.c1; k.z = z.r1; k.w = z.r2;
-    sbk[i] = k; sbpos[i] = z.pos;
+    const TB z = B[b0 + i];
+    sbk[i] = tupb_key(z); sbpos[i] = z.pos;
   }
   __syncthreads();
   const u32 dl = min(threadIdx.x * (u32)VT, na + nb);

@@ -302,7 +302,23 @@ constexpr size_t kPartSmem = sizeof(Rec8) * kPartTile + sizeof(u32) * (2 * 1024 
 // the blocks that share an XCD under the dispatcher's round-robin placement (a speed assumption only) — so that every
 // run written into a segment's windows goes through ONE L2 and the partial lines of neighbouring runs meet there
 // (dc3_msd.hip.hpp explains the effect; grid = 8 * ceil(nseg / 8) * xcd_tps).
-__global__ __launch_bounds__(kPartNW * 64) void k_part_msd(const Rec8 *__restrict__ in, Rec8 *__restrict__ out, u32 n,
+// Src: where the pairs come from — an array (PairArray), or made on the fly from a sorted order (PairsOfOrder: pair k =
+// (pos_k, k + 1), which also leaves out_sa[k] = pos_k; saves writing the pairs and reading them back).
+struct PairArray {
+  const Rec8 *p;
+  __device__ __forceinline__ Rec8 load(u32 i) const { return p[i]; }
+};
+template <class Acc>
+struct PairsOfOrder {
+  Acc acc; u32 skip; u32 *out_sa;
+  __device__ __forceinline__ Rec8 load(u32 k) const {
+    const u32 p = acc.pos(k + skip);
+    if (out_sa) out_sa[k] = p;
+    return Rec8{p, k + 1};
+  }
+};
+template <class Src>
+__global__ __launch_bounds__(kPartNW * 64) void k_part_msd(Src in, Rec8 *__restrict__ out, u32 n,
                                                           u32 shift, u32 seg_bits, u32 ndig,
                                                           u32 *__restrict__ cursors, u32 xcd_tps) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -327,7 +343,7 @@ __global__ __launch_bounds__(kPartNW * 64) void k_part_msd(const Rec8 *__restric
   u32 d[kPartIPT], rk[kPartIPT];
   // (all loads issued back to back: the index is clamped instead of guarded, a guard would put a wait behind every load)
 #pragma unroll
-  for (int k = 0; k < kPartIPT; k++) r[k] = in[begin + min((u32)(k * (kPartNW * 64)) + tid, nvalid - 1u)];
+  for (int k = 0; k < kPartIPT; k++) r[k] = in.load(begin + min((u32)(k * (kPartNW * 64)) + tid, nvalid - 1u));
 #pragma unroll
   for (int k = 0; k < kPartIPT; k++) {
     const u32 t = k * (kPartNW * 64) + tid;

@@ -27,6 +27,7 @@
 #include "dc3_kernels.hip.hpp"
 #include "dc3_msd.hip.hpp"
 #include "dc3_ssort.hip.hpp"
+#include "dc3_wide_msd.hip.hpp"
 
 using namespace dc3;
 
@@ -95,6 +96,8 @@ struct dc3hip_ctx {
   bool no_hybrid8 = false;     // DC3HIP_NO_HYBRID8=1 (tests): skip the 8-byte prefix sort / whole-level order of a level
   bool no_hybrid12 = false;    // DC3HIP_NO_HYBRID12=1: no 63-bit-prefix sort on 12-byte records for keys wider than 64 bits
   bool no_tup_scatter = false; // DC3HIP_NO_TUP_SCATTER=1: sample tuples always by the random gather
+  u32 tup_scatter_min = 1u << 25; // DC3HIP_TUP_SCATTER_MIN (tests): smallest level (samples) whose tuples are scattered
+  bool no_tup_rec8 = false;    // DC3HIP_NO_TUP_REC8=1 (tests): level 0 moves 12-byte records through the tuple scatter, as deeper levels do
   bool no_xcd_map = false;     // DC3HIP_NO_XCD_MAP=1: window partitions without the segment -> XCD-group tile order (measurement aid)
   bool pack_fuse = false;      // DC3HIP_PACK_FUSE=1: whole-text order of bytes: the pack kernel only counts, partition pass 1 makes the records on the fly
   bool no_msd = false;         // DC3HIP_NO_MSD=1: the prefix sorts always run the stable LSD passes (no bucket ordering)
@@ -239,6 +242,8 @@ template <> struct SortCfg<Rec16, 256> { static constexpr int IPT = 8, NW = 16; 
 template <> struct SortCfg<Rec16, 512> { static constexpr int IPT = 7, NW = 16; static constexpr bool PF = false; };
 template <> struct SortCfg<Tup0, 256>  { static constexpr int IPT = 6, NW = 16; static constexpr bool PF = false; };
 template <> struct SortCfg<Tup0, 512>  { static constexpr int IPT = 6, NW = 16; static constexpr bool PF = false; };
+template <> struct SortCfg<Tup0C, 256> { static constexpr int IPT = 8, NW = 16; static constexpr bool PF = false; };
+template <> struct SortCfg<Tup0C, 512> { static constexpr int IPT = 7, NW = 16; static constexpr bool PF = false; };
 template <> struct SortCfg<Tup0G, 256> { static constexpr int IPT = 6, NW = 16; static constexpr bool PF = false; };
 template <> struct SortCfg<Tup0G, 512> { static constexpr int IPT = 6, NW = 16; static constexpr bool PF = false; };
 template <class Rec> struct RecClass;      // index into dc3hip_stats.downsweep_*
@@ -247,6 +252,7 @@ template <> struct RecClass<Rec8>  { static constexpr int k = 0; };
 template <> struct RecClass<Rec12> { static constexpr int k = 1; };
 template <> struct RecClass<Rec16> { static constexpr int k = 1; };
 template <> struct RecClass<Tup0>  { static constexpr int k = 2; };
+template <> struct RecClass<Tup0C> { static constexpr int k = 2; };
 
 template <class Rec, int NB, class Loader, class Sink>
 static int launch_downsweep_to(dc3hip_ctx *c, Loader in, Sink dst, u32 n, const Chunking &ck, KeyDig dig,
@@ -777,29 +783,37 @@ static void pack_plan(dc3hip_ctx *c, u32 nrec, const HiMap &hm, const MsdGeom *m
 // SA12[R[i]-1] = i, lib.rs:111-113).  Two partition passes by the high key bits, then windows of
 // 16384 destinations are assembled in LDS and stored with full lines.
 // ---------------------------------------------------------------------------------------------
-static int inverse_permute(dc3hip_ctx *c, Rec8 *a, Rec8 *b, u32 n, u32 *out, int phase) {
+// `first`: the source of the first partition pass (PairArray of `a`, or pairs made on the fly — then the pass writes
+// into `a` and `a`'s contents on entry do not matter).  Needs n > 2^14 when `first` is not `a` itself.
+template <class Src>
+static int inverse_permute_from(dc3hip_ctx *c, Src first, bool first_is_a, Rec8 *a, Rec8 *b, u32 n, u32 *out, int phase) {
   static std::atomic<bool> attr_set[16];   // (per function and device, process-wide; a double set is harmless)
   if (!attr_set[c->device & 15]) {
     HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_invperm_local),
                              hipFuncAttributeMaxDynamicSharedMemorySize, kInvWindow * 4));
-    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_part_msd), hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_part_msd<Src>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)kPartSmem));
+    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_part_msd<PairArray>), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)kPartSmem));
     attr_set[c->device & 15] = true;
   }
   const u32 kb = bits_of(n > 0 ? n - 1 : 0);
   const ArenaMark mk = arena_mark(c);
   const u32 ntiles = (n + kPartTile - 1) / kPartTile;
-  Rec8 *src = a, *dst = b;
+  // (a pass fed by `first` writes into a when first is not a itself, else into b)
+  Rec8 *src = a, *dst = first_is_a ? b : a;
+  bool at_first = true;
   if (kb > 22) {                       // pass 1: top digit = key >> 22 (<= 1024 values for n < 2^32)
     const u32 ndig = ((n - 1) >> 22) + 1;
     u32 *cur = nullptr;
     RC(arena_alloc(c, (size_t)1024, &cur));
     PhaseScope ps(c, phase, n, 3);
     HIPC(hipMemsetAsync(cur, 0, 1024 * sizeof(u32), c->stream));
-    hipLaunchKernelGGL(k_part_msd, dim3(ntiles), dim3(kPartNW * 64), kPartSmem, c->stream, src, dst, n, 22u, 32u,
+    hipLaunchKernelGGL((k_part_msd<Src>), dim3(ntiles), dim3(kPartNW * 64), kPartSmem, c->stream, first, dst, n, 22u, 32u,
                        ndig, cur, 0u);
     KCHECK();
-    std::swap(src, dst);
+    src = dst; dst = (src == a) ? b : a;
+    at_first = false;
   }
   if (kb > (u32)kInvWindowBits) {      // pass 2: bits [14,22) inside every 2^22-pair segment
     const u32 nseg = kb > 22 ? ((n - 1) >> 22) + 1 : 1;
@@ -811,11 +825,19 @@ static int inverse_permute(dc3hip_ctx *c, Rec8 *a, Rec8 *b, u32 n, u32 *out, int
     const u32 tps = (1u << 22) / kPartTile;
     const bool xcd = kb > 22 && !c->no_xcd_map;
     const u32 grid = xcd ? 8u * ((nseg + 7) / 8) * tps : ntiles;
-    hipLaunchKernelGGL(k_part_msd, dim3(grid), dim3(kPartNW * 64), kPartSmem, c->stream, src, dst, n,
-                       (u32)kInvWindowBits, kb > 22 ? 22u : 32u, 256u, cur, xcd ? tps : 0u);
+    if (at_first)
+      hipLaunchKernelGGL((k_part_msd<Src>), dim3(grid), dim3(kPartNW * 64), kPartSmem, c->stream, first, dst, n,
+                         (u32)kInvWindowBits, kb > 22 ? 22u : 32u, 256u, cur, xcd ? tps : 0u);
+    else {
+      PairArray pa; pa.p = src;
+      hipLaunchKernelGGL((k_part_msd<PairArray>), dim3(grid), dim3(kPartNW * 64), kPartSmem, c->stream, pa, dst, n,
+                         (u32)kInvWindowBits, kb > 22 ? 22u : 32u, 256u, cur, xcd ? tps : 0u);
+    }
     KCHECK();
-    std::swap(src, dst);
+    src = dst; dst = (src == a) ? b : a;
+    at_first = false;
   }
+  if (at_first && !first_is_a) { set_err("inverse_permute_from: %u pairs are too few for an on-the-fly source", n); return E_ARGS; }
   {
     PhaseScope ps(c, phase, n);
     hipLaunchKernelGGL(k_invperm_local, dim3((n + kInvWindow - 1) / kInvWindow), dim3(1024), kInvWindow * 4,
@@ -824,6 +846,10 @@ static int inverse_permute(dc3hip_ctx *c, Rec8 *a, Rec8 *b, u32 n, u32 *out, int
   }
   arena_release(c, mk);
   return E_OK;
+}
+static int inverse_permute(dc3hip_ctx *c, Rec8 *a, Rec8 *b, u32 n, u32 *out, int phase) {
+  PairArray pa; pa.p = a;
+  return inverse_permute_from<PairArray>(c, pa, true, a, b, n, out, phase);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1627,13 +1653,19 @@ static int finish_position_order(dc3hip_ctx *c, Acc acc, Map mp, u32 nrec, u32 m
       RC(arena_alloc(c, (size_t)m, &pa));
       RC(arena_alloc(c, (size_t)m, &pb));
     }
-    {
-      PhaseScope ps(c, DC3HIP_PH_RANKS, m);
-      hipLaunchKernelGGL((k_emit_sorted<Acc>), dim3(grid_for(c, m)), dim3(kBlock), 0, c->stream, acc, m, dummy,
-                         out_sa, pa);
-      KCHECK();
+    if (out_rank && m > (1u << kInvWindowBits)) {
+      // the pairs (pos_k, k + 1) are made by the first partition pass itself, which also leaves out_sa[k] = pos_k
+      PairsOfOrder<Acc> po; po.acc = acc; po.skip = dummy; po.out_sa = out_sa;
+      RC((inverse_permute_from<PairsOfOrder<Acc>>(c, po, false, pa, pb, m, out_rank, DC3HIP_PH_RANKS)));
+    } else {
+      {
+        PhaseScope ps(c, DC3HIP_PH_RANKS, m);
+        hipLaunchKernelGGL((k_emit_sorted<Acc>), dim3(grid_for(c, m)), dim3(kBlock), 0, c->stream, acc, m, dummy,
+                           out_sa, pa);
+        KCHECK();
+      }
+      if (out_rank) RC(inverse_permute(c, pa, pb, m, out_rank, DC3HIP_PH_RANKS));
     }
-    if (out_rank) RC(inverse_permute(c, pa, pb, m, out_rank, DC3HIP_PH_RANKS));
     *state = 1;
   } else if (spos && snf) {             // keep the sort: filter the samples with their full names
     PhaseScope ps(c, DC3HIP_PH_NAMING, nrec);
@@ -1796,10 +1828,10 @@ static int order_all_positions(dc3hip_ctx *c, KM km, Map mp, u32 m, u32 kbits, c
   return E_OK;
 }
 
-template <int NT, int VT>
-static int launch_merge(dc3hip_ctx *c, u32 ntiles, const Tup12 *A, u32 nA, const Tup0 *B, u32 nB, const u32 *part,
+template <int NT, int VT, class TA, class TB>
+static int launch_merge(dc3hip_ctx *c, u32 ntiles, const TA *A, u32 nA, const TB *B, u32 nB, const u32 *part,
                         u32 *out_sa, Rec8 *out_pairs, u32 rank_base = 0) {
-  auto kern = k_merge<NT, VT>;
+  auto kern = k_merge<NT, VT, TA, TB>;
   const size_t smem = MergeSmem<NT, VT>::kBytes;
   HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipLaunchKernelGGL(kern, dim3(ntiles), dim3(NT), smem, c->stream, A, nA, B, nB, part, out_sa, out_pairs, rank_base);
@@ -1812,7 +1844,7 @@ static int launch_merge(dc3hip_ctx *c, u32 ntiles, const Tup12 *A, u32 nA, const
 // level's suffix array — which do not depend on HOW names were made (dense by sorting or packed directly), so the
 // CPU restatement the tests check against emits the same words and can be compared level by level.
 enum { TR_SA12 = 0, TR_SA0 = 1, TR_SA = 2 };
-static int trace_sum(dc3hip_ctx *c, int which, int depth, const void *arr, u32 n, int kind /*0 u32 positions, 1 slots, 2 Tup0*/, u32 m0) {
+static int trace_sum(dc3hip_ctx *c, int which, int depth, const void *arr, u32 n, int kind /*0 u32 positions, 1 slots, 2 Tup0, 3 Tup0C*/, u32 m0) {
   if (!c->trace || depth >= DC3HIP_MAX_LEVELS || n == 0) return E_OK;
   u64 *acc = c->d_trace + (size_t)which * DC3HIP_MAX_LEVELS + depth;
   hipLaunchKernelGGL(k_trace_sum, dim3(grid_for(c, n)), dim3(kBlock), 0, c->stream, arr, n, kind, m0, acc);
@@ -1824,35 +1856,43 @@ static int trace_sum(dc3hip_ctx *c, int which, int depth, const void *arr, u32 n
 // built by streaming (8-byte entries when the level's symbols fit 16 bits, else 16-byte) and gathered.  table0
 // ([256][chunks of cnt]) receives the digit table of the fused mod-0 selection pass.  The slot table lives above the
 // caller's arena mark and is released here.
-// Sample tuples in SA12 order by scattering instead of gathering (dc3_merge.hip.hpp, "WITHOUT the random gather"):
+// Sample tuples in SA12 order by scattering instead of gathering (dc3_merge.hip.hpp, "WITHOUT the random gather"), as
+// COMPACT tuples (TupC, 12 bytes).  Level 0 (bytes) moves 8-byte records through the two partition passes and reads the
+// first symbol off a table of cumulative counts; deeper levels whose symbols fit 16 bits move 12-byte records.
 // *done = false when the level is too small or the arena too short for the two record arrays (the caller gathers).
-static constexpr u32 kTupScatterMin = 1u << 25;
-template <class Sym>
-static int scatter_tuples8(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, const u32 *rank12, const u32 *sa12, const Chunking &ckc,
-                           Tup12 *t12, u32 *table0, bool *done) {
+template <class Sym, class Out, bool kDerive>
+static int scatter_tuples_run(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, const u32 *rank12, const u32 *sa12, const Chunking &ckc,
+                              TupC *t12, u32 *table0, bool *done) {
+  typedef typename Out::Rec Rec;
   *done = false;
-  if (c->no_tup_scatter || m02 < kTupScatterMin || ckc.chunk < kTupWin) return E_OK;
   const u32 ntiles = (m02 + kTupTile - 1) / kTupTile;
   const u32 tpc = std::max<u32>(1, (ntiles + 2047) / 2048);
   const u32 cpg = ((ntiles + 7) / 8 + tpc - 1) / tpc, cpx = cpg * tpc;
   const u32 chunk = tpc * (u32)kTupTile, nchunks = (m02 + chunk - 1) / chunk;
   const u32 nb = ((m02 - 1) >> kTupSh1) + 1;                     // buckets of 2^22 destinations (<= 1024)
-  if (c->arena_bytes - c->arena_off < (size_t)m02 * 24 + (size_t)1024 * nchunks * 4 + ((size_t)nb << 11) + (16u << 20)) return E_OK;
+  if (c->arena_bytes - c->arena_off < (size_t)m02 * 2 * sizeof(Rec) + (size_t)1024 * nchunks * 4 + ((size_t)nb << 11) + (16u << 20)) return E_OK;
   static std::atomic<bool> attr_set[16];
   if (!attr_set[c->device & 15]) {
-    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tup_part1<Sym>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTupPartSmem));
-    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tup_part2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTupPartSmem));
-    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tup_local), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * kTupWin * 4)));
+    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tup_part1<Sym, Out>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTupPartSmem));
+    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tup_part2<Out>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTupPartSmem));
+    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tup_local<Out, kDerive>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * kTupWin * 4)));
     attr_set[c->device & 15] = true;
   }
   const ArenaMark mk = arena_mark(c);
-  TupRec *ra = nullptr, *rb = nullptr;
+  Rec *ra = nullptr, *rb = nullptr;
   u32 *table1 = nullptr, *cntg = nullptr, *startg = nullptr, *cur1 = nullptr, *bstart = nullptr, *tpre = nullptr, *tpreh = nullptr, *plan = nullptr, *cur2 = nullptr;
+  u32 *cum = nullptr;
+  const u32 nsym = 258;                                          // level 0: codes 0..sigma <= 256 (+ slack)
   RC(arena_alloc(c, (size_t)m02, &ra)); RC(arena_alloc(c, (size_t)m02, &rb));
   RC(arena_alloc(c, (size_t)1024 * nchunks, &table1));
   RC(arena_alloc(c, (size_t)nb * 8 + 16, &cntg)); RC(arena_alloc(c, (size_t)nb * 8 + 16, &startg)); RC(arena_alloc(c, (size_t)nb * 8 + 16, &cur1));
   RC(arena_alloc(c, (size_t)nb + 16, &bstart)); RC(arena_alloc(c, (size_t)nb + 16, &tpre)); RC(arena_alloc(c, (size_t)nb + 16, &tpreh));
   RC(arena_alloc(c, (size_t)16, &plan)); RC(arena_alloc(c, (size_t)nb * 512, &cur2));
+  RC(arena_alloc(c, (size_t)nsym + 16, &cum));
+  const u32 rbits = bits_of(m02);                                // r <= m02
+  Out oa, ob;
+  oa.p = ra; ob.p = rb;
+  if constexpr (kDerive) { oa.rb = rbits; ob.rb = rbits; }
   {
     PhaseScope ps(c, DC3HIP_PH_TUPLES, m02);
     hipLaunchKernelGGL(k_tup_hist1, dim3(nchunks), dim3(kBlock), 0, c->stream, rank12, m02, chunk, nchunks, table1);
@@ -1863,37 +1903,49 @@ static int scatter_tuples8(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, const u
     KCHECK();
     HIPC(hipMemsetAsync(cur2, 0, (size_t)nb * 512 * sizeof(u32), c->stream));
     HIPC(hipMemsetAsync(table0, 0, (size_t)256 * ckc.nchunks * sizeof(u32), c->stream));
+    if (kDerive) {
+      HIPC(hipMemsetAsync(cum, 0, (size_t)(nsym + 1) * sizeof(u32), c->stream));
+      hipLaunchKernelGGL((k_sample_sym_hist<Sym>), dim3(grid_for(c, m0)), dim3(kBlock), 0, c->stream, S, m, m0, nsym, cum);
+      KCHECK();
+      hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, cum, nsym + 1, (u32 *)nullptr);
+      KCHECK();
+    }
   }
   {
     PhaseScope ps(c, DC3HIP_PH_TUPLES, m02, 3);
-    hipLaunchKernelGGL((k_tup_part1<Sym>), dim3(8 * cpx), dim3(kTupNT), kTupPartSmem, c->stream, S, m, m0, m02, rank12, cpx, ntiles, nb, cur1, ra);
+    hipLaunchKernelGGL((k_tup_part1<Sym, Out>), dim3(8 * cpx), dim3(kTupNT), kTupPartSmem, c->stream, S, m, m0, m02, rank12, cpx, ntiles, nb, cur1, oa);
     KCHECK();
   }
   {
     PhaseScope ps(c, DC3HIP_PH_TUPLES, m02, 3);
     const u32 tpb = (1u << kTupSh1) / kTupTile;
-    hipLaunchKernelGGL(k_tup_part2, dim3(8 * ((nb + 7) / 8) * tpb), dim3(kTupNT), kTupPartSmem, c->stream, (const TupRec *)ra, m02, nb, cur2, rb);
+    hipLaunchKernelGGL((k_tup_part2<Out>), dim3(8 * ((nb + 7) / 8) * tpb), dim3(kTupNT), kTupPartSmem, c->stream, (const Rec *)ra, m02, nb, cur2, ob, rbits);
     KCHECK();
   }
   {
     PhaseScope ps(c, DC3HIP_PH_TUPLES, m02);
-    hipLaunchKernelGGL(k_tup_local, dim3((m02 + kTupWin - 1) / kTupWin), dim3(1024), 2 * kTupWin * 4, c->stream, (const TupRec *)rb, sa12, m02, m0,
-                       ckc.chunk, ckc.nchunks, t12, table0);
+    hipLaunchKernelGGL((k_tup_local<Out, kDerive>), dim3((m02 + kTupWin - 1) / kTupWin), dim3(1024), 2 * kTupWin * 4, c->stream, (const Rec *)rb, rbits, sa12, m02, m0,
+                       ckc.chunk, ckc.nchunks, (const u32 *)cum, nsym, t12, table0);
     KCHECK();
   }
   arena_release(c, mk);
   *done = true;
   return E_OK;
 }
+template <class Sym>
+static int scatter_tuples(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, const u32 *rank12, const u32 *sa12, const Chunking &ckc,
+                          TupC *t12, u32 *table0, bool *done) {
+  *done = false;
+  if (c->no_tup_scatter || m02 < c->tup_scatter_min || m02 < 2 || ckc.chunk < kTupWin) return E_OK;
+  if constexpr (std::is_same<Sym, SymU8>::value) {
+    if (!c->no_tup_rec8) return scatter_tuples_run<Sym, TupOut8, true>(c, S, m, m0, m02, rank12, sa12, ckc, t12, table0, done);
+  }
+  return scatter_tuples_run<Sym, TupOut12, false>(c, S, m, m0, m02, rank12, sa12, ckc, t12, table0, done);
+}
 
 template <class Sym>
 static int build_gather_tuples(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u64 K, const u32 *rank12, const u32 *sa12l,
                                u32 cnt, const Chunking &ckc, Tup12 *t12, u32 *table0) {
-  if (K < 65536 && !c->no_tup8 && cnt == m02) {
-    bool done = false;
-    RC((scatter_tuples8<Sym>(c, S, m, m0, m02, rank12, sa12l, ckc, t12, table0, &done)));
-    if (done) return E_OK;
-  }
   const ArenaMark mk = arena_mark(c);
   PhaseScope ps(c, DC3HIP_PH_TUPLES, m02);
   if (K < 65536 && !c->no_tup8) {
@@ -1925,7 +1977,8 @@ static int build_gather_tuples(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u64
 
 // Step 3 (lib.rs:131-192): merge-path merge of the sorted sample tuples A and the sorted mod-0 tuples B into
 // out_sa[0 .. nA+nB) (and, when out_pairs != nullptr, the (pos, rank_base + k + 1) pairs of the rank inversion).
-static int merge_lists(dc3hip_ctx *c, const Tup12 *A, u32 nA, const Tup0 *B, u32 nB, u32 *out_sa, Rec8 *out_pairs,
+template <class TA, class TB>
+static int merge_lists(dc3hip_ctx *c, const TA *A, u32 nA, const TB *B, u32 nB, u32 *out_sa, Rec8 *out_pairs,
                        u32 rank_base) {
   const u32 total = nA + nB;
   if (total == 0) return E_OK;
@@ -1942,14 +1995,58 @@ static int merge_lists(dc3hip_ctx *c, const Tup12 *A, u32 nA, const Tup0 *B, u32
     const u32 nco = (ntiles + kRatio - 1) / kRatio;              // coarse tiles of kRatio*tile outputs
     u32 *coarse = nullptr;
     RC(arena_alloc(c, (size_t)nco + 16, &coarse));
-    hipLaunchKernelGGL(k_merge_partition, dim3((nco + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, A, nA, B, nB,
+    hipLaunchKernelGGL((k_merge_partition<TA, TB>), dim3((nco + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, A, nA, B, nB,
                        nco, tile * kRatio, (const u32 *)nullptr, 1u, coarse);
     KCHECK();
-    hipLaunchKernelGGL(k_merge_partition, dim3((ntiles + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, A, nA, B, nB,
+    hipLaunchKernelGGL((k_merge_partition<TA, TB>), dim3((ntiles + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, A, nA, B, nB,
                        ntiles, tile, (const u32 *)coarse, kRatio, part);
     KCHECK();
-    RC((launch_merge<kMergeNT, kMergeVT>(c, ntiles, A, nA, B, nB, part, out_sa, out_pairs, rank_base)));
+    RC((launch_merge<kMergeNT, kMergeVT, TA, TB>(c, ntiles, A, nA, B, nB, part, out_sa, out_pairs, rank_base)));
     KCHECK();
+  }
+  arena_release(c, mk);
+  return E_OK;
+}
+
+// Steps 2 + 3 of a level (lib.rs:118-192) on compact tuples: sample tuples scattered into SA12 order (TupC), mod-0
+// tuples (Tup0C) selected and ordered by the fused radix pass(es), merge.  *done = false: nothing happened, the caller
+// runs the general form.
+template <class Sym>
+static int unwind_compact(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m1, u32 m02, u64 K, const u32 *rank12, const u32 *sa12,
+                          u32 *out_sa, u32 *out_rank, int depth, bool *done) {
+  *done = false;
+  const ArenaMark mk = arena_mark(c);
+  TupC *t12 = nullptr;
+  RC(arena_alloc(c, (size_t)m02, &t12));
+  constexpr u32 kTup0Tile = SortCfg<Tup0C, 256>::NW * 64 * SortCfg<Tup0C, 256>::IPT;
+  const Chunking ckc = make_chunks(c, m02, kTup0Tile);
+  u32 *table0 = nullptr, *dbase0 = nullptr;
+  RC(arena_alloc(c, (size_t)256 * ckc.nchunks, &table0));
+  RC(arena_alloc(c, (size_t)256, &dbase0));
+  RC((scatter_tuples<Sym>(c, S, m, m0, m02, rank12, sa12, ckc, t12, table0, done)));
+  if (!*done) { arena_release(c, mk); return E_OK; }
+  Tup0C *z0 = nullptr, *z1 = nullptr, *zs = nullptr;
+  RC(arena_alloc(c, (size_t)m0, &z0));
+  RC(arena_alloc(c, (size_t)m0, &z1));
+  {
+    // pass 0 of the mod-0 sort reads the sample tuples directly (selection fused in the loader)
+    RC(scan_digit_table(c, table0, ckc.nchunks, dbase0, 256, DC3HIP_PH_COMPACT));
+    Mod0LoaderC ld; ld.t = t12;
+    KeyDig dig; dig.shift = 0; dig.mask = 255;
+    RC((launch_downsweep<Tup0C, 256, Mod0LoaderC>(c, ld, z0, m02, ckc, dig, table0, dbase0, DC3HIP_PH_COMPACT)));
+  }
+  RC(radix_sort<Tup0C>(c, z0, z1, m0, 8, bits_of(K - 1), &zs, DC3HIP_PH_SORT0, DC3HIP_PH_SORT0, DC3HIP_PH_SORT0));
+  RC(trace_sum(c, TR_SA0, depth, zs, m0, 3, m0));
+  {
+    const u32 dskip = m0 - m1;                  // lib.rs:133: skip the dummy, which sorts first
+    Rec8 *pa = nullptr, *pb = nullptr;
+    if (out_rank) {
+      RC(arena_alloc(c, (size_t)m, &pa));
+      RC(arena_alloc(c, (size_t)m, &pb));
+    }
+    RC(merge_lists(c, t12 + dskip, m02 - dskip, zs, m0, out_sa, pa, 0u));
+    if (out_sa) RC(trace_sum(c, TR_SA, depth, out_sa, m, 0, m0));
+    if (out_rank) RC(inverse_permute(c, pa, pb, m, out_rank, DC3HIP_PH_RANKS));
   }
   arena_release(c, mk);
   return E_OK;
@@ -2095,6 +2192,12 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
   // ---- Step 2 + 3: tuples, mod-0 order, merge -------------------------------------------------
   // t12 = sample tuples in SA12 order.  The gather also produces the digit table of the fused
   // "select mod-0 + first radix pass" (Step 2, lib.rs:118-126).
+  // Levels whose symbols fit 16 bits and that are large enough for the scatter: compact tuples (12 / 16 bytes).
+  if (K < 65536 && !c->no_tup8) {
+    bool done = false;
+    RC((unwind_compact<Sym>(c, S, m, m0, m1, m02, K, rank12, sa12, out_sa, out_rank, depth, &done)));
+    if (done) { arena_release(c, mk0); return E_OK; }
+  }
   Tup12 *t12 = nullptr;
   RC(arena_alloc(c, (size_t)m02, &t12));
   constexpr u32 kTup0Tile = SortCfg<Tup0, 256>::NW * 64 * SortCfg<Tup0, 256>::IPT;
@@ -2494,6 +2597,8 @@ int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) {
   { const char *e = getenv("DC3HIP_PACK_FUSE"); c->pack_fuse = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_XCD_MAP"); c->no_xcd_map = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_TUP_SCATTER"); c->no_tup_scatter = (e && e[0] == '1'); }
+  { const char *e = getenv("DC3HIP_NO_TUP_REC8"); c->no_tup_rec8 = (e && e[0] == '1'); }
+  { const char *e = getenv("DC3HIP_TUP_SCATTER_MIN"); if (e && *e) c->tup_scatter_min = (u32)strtoul(e, nullptr, 10); }
   { const char *e = getenv("DC3HIP_MSD_MIN"); if (e) c->msd_min = (u32)std::max(4096ll, atoll(e)); }
   { const char *e = getenv("DC3HIP_NO_SSORT"); c->no_ssort = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_SSORT_VERIFY"); c->ssort_verify = (e && e[0] == '1'); }

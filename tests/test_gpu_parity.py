@@ -787,6 +787,43 @@ def test_deep_tie_pass_then_doubling_on_12_byte_records(ss, oracle):
                     os.environ.pop(k, None)
 
 
+def test_compact_unwinding_matches_the_general_form(ss, oracle, corpus):
+    """Steps 2 + 3 of a level (lib.rs:118-192) on compact tuples — sample tuples scattered into SA12 order as 12-byte
+    records, level 0 moving 8-byte records through the partition passes with the first symbol read off the cumulative
+    counts, 16-byte mod-0 tuples, the templated merge — against divsufsort, on every level that fits 16-bit symbols
+    (DC3HIP_TUP_SCATTER_MIN=1 takes the size threshold away).  Also with the 12-byte level-0 records
+    (DC3HIP_NO_TUP_REC8=1) and against the gather (DC3HIP_NO_TUP_SCATTER=1).  Inputs: the reference's corpus, n % 3 in
+    {0, 1, 2} around window and tile boundaries, bytes 0x00 / 0xff, a cluster of once-only symbols (many first-symbol
+    boundaries inside one window), DNA, low-entropy text, tiny texts."""
+    rng = np.random.default_rng(404)
+    cases = {name: data for name, (data, _) in corpus.items()}
+    for n in (2, 3, 4, 5, 7, 8191, 8192, 8193, 3 * 8192, 3 * 8192 + 1, 3 * 8192 + 2, 12289, 100_000, 100_001, 100_002, 1_000_003):
+        cases[f"bytes_{n}"] = rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
+    cases["zeros_and_ff"] = rng.choice(np.array([0, 255, 1, 254], dtype=np.uint8), size=300_001).tobytes()
+    rare = rng.integers(97, 100, size=400_000, dtype=np.uint8)
+    rare[rng.choice(400_000, size=200, replace=False)] = np.arange(0, 200, dtype=np.uint8) + 1       # 200 symbols that occur once
+    cases["rare_symbols"] = rare.tobytes()
+    cases["dna"] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=2_000_001)].tobytes()
+    cases["text"] = oracle.gen(3_000_002, 3, 2).tobytes()
+    cases["all_equal"] = b"a" * 50_001
+    cases["period3"] = b"abc" * 33_334
+    envs = ({"DC3HIP_TUP_SCATTER_MIN": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1"},
+            {"DC3HIP_TUP_SCATTER_MIN": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1", "DC3HIP_NO_TUP_REC8": "1"},
+            {"DC3HIP_TUP_SCATTER_MIN": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1", "DC3HIP_NO_XCD_MAP": "1", "DC3HIP_NO_DISCARD": "1"},
+            {"DC3HIP_NO_TUP_SCATTER": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1"})
+    for env in envs:
+        os.environ.update(env)
+        try:
+            with ss.Context(max(len(d) for d in cases.values())) as c:
+                for label, data in cases.items():
+                    want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)
+                    c.set_text(data); c.build()
+                    assert np.array_equal(c.sa(), want), (label, env)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+
+
 def test_discarding_recursion_agrees_and_shrinks(ss, oracle, corpus):
     """Discarding recursion (unique names leave the recursion) vs the plain K–S recursion
     (DC3HIP_NO_DISCARD=1): same SA; on low-entropy text the deeper levels collapse."""
@@ -1142,25 +1179,28 @@ def test_stage_level_trace_matches_oracle(ss, oracle, corpus):
     cases["dna_200k"] = oracle.gen(200_000, 5, 1).tobytes()
     cases["random_100k"] = oracle.gen(100_003, 2, 0).tobytes()
     keys = ("DC3HIP_TRACE", "DC3HIP_NO_DISCARD", "DC3HIP_NO_HYBRID", "DC3HIP_NO_FULLSORT", "DC3HIP_NO_TEXT_SHORTCUT")
-    for k in keys:
-        os.environ[k] = "1"
-    try:
-        with ss.Context(max(len(v) for v in cases.values())) as c:
-            for name, data in cases.items():
-                c.set_text(data)
-                c.build()
-                got = c.stats()["trace"]
-                want = oracle.trace_ex(data)
-                assert got is not None and len(got) >= len(want), (name, len(got), len(want))
-                for lvl, (g, w) in enumerate(zip(got, want)):
-                    assert g["n"] == w["n"], f"{name}: level {lvl} length {g['n']} != {w['n']}"
-                    if g["names"] >= 0:          # sorted level: distinct triples (lib.rs:104); direct levels pack names
-                        assert g["names"] == w["names"], f"{name}: level {lvl} names {g['names']} != {w['names']}"
-                    for stage in ("sa12", "sa0", "sa"):
-                        assert g[stage] == w[stage], f"{name}: level {lvl} stage {stage} differs"
-    finally:
+    # (second round: the same stages through the compact unwinding — scattered 12-byte sample tuples, 16-byte mod-0 tuples)
+    for extra in ({}, {"DC3HIP_TUP_SCATTER_MIN": "1"}):
         for k in keys:
-            os.environ.pop(k, None)
+            os.environ[k] = "1"
+        os.environ.update(extra)
+        try:
+            with ss.Context(max(len(v) for v in cases.values())) as c:
+                for name, data in cases.items():
+                    c.set_text(data)
+                    c.build()
+                    got = c.stats()["trace"]
+                    want = oracle.trace_ex(data)
+                    assert got is not None and len(got) >= len(want), (name, len(got), len(want))
+                    for lvl, (g, w) in enumerate(zip(got, want)):
+                        assert g["n"] == w["n"], f"{name}: level {lvl} length {g['n']} != {w['n']}"
+                        if g["names"] >= 0:          # sorted level: distinct triples (lib.rs:104); direct levels pack names
+                            assert g["names"] == w["names"], f"{name}: level {lvl} names {g['names']} != {w['names']}"
+                        for stage in ("sa12", "sa0", "sa"):
+                            assert g[stage] == w[stage], f"{name}: level {lvl} stage {stage} differs ({extra})"
+        finally:
+            for k in keys + tuple(extra):
+                os.environ.pop(k, None)
 
 
 @pytest.mark.parametrize("nb,shift", [(256, 0), (256, 13), (512, 0), (512, 23), (256, 48)])
