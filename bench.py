@@ -332,6 +332,10 @@ def main():
             "value_MiBps": total_len * args.steps / dt / 2**20,     # the reference prints binary units (divsuftest main.rs:179-183)
             "roofline": roof, "roofline_kernels": roof_all, "roofline_path": path_roofline(st, kernel_ms / args.steps),
             "msd": {k: st.get(k) for k in ("msd_sorts", "msd_fallbacks", "msd_max_subbucket")},
+            # the speed of the bucket ordering's partition passes rests on "blocks with equal blockIdx % 8 share an XCD":
+            # probed when the context is created and counted block by block in the timed builds (HW_REG_XCC_ID)
+            "xcd_grouping_effective": bool(st.get("xcd_round_robin") == 1 and (st.get("xcd_blocks", 0) == 0 or st.get("xcd_group_hit", 0) >= 0.9)),
+            "xcd_grouping": {k: st.get(k) for k in ("xcd_round_robin", "xcd_blocks", "xcd_group_hit")},
             "verify": verify, "arena_peak_GB": st["arena_peak"] / 1e9,
         }
         text = None
@@ -471,7 +475,10 @@ def main():
                                "work_inflation": wall / single_ms, "checksum_equal_single_device": g.checksum() == single_chk,
                                "text_order": gst[0]["text_order"], "levels": gst[0]["levels"], "rank_exchanges": gst[0]["exchanges"],
                                "bytes_in_per_rank": [x["comm_bytes_in"] for x in gst],
-                               "shard_counts": [x["shard_count"] for x in gst]})
+                               "shard_counts": [x["shard_count"] for x in gst],
+                               # (P streams share the device here: does the XCD-grouped reservation still find its XCD?)
+                               "xcd_group_hit_per_rank": [round(x["ctx"]["xcd_group_hit"], 4) for x in gst],
+                               "xcd_grouping_effective": all(x["ctx"]["xcd_round_robin"] == 1 and (x["ctx"]["xcd_blocks"] == 0 or x["ctx"]["xcd_group_hit"] >= 0.9) for x in gst)})
                     assert gl[-1]["checksum_equal_single_device"], "global-mode shards differ from the single-device suffix array"
         out["global_mode_loopback"] = gl
         # One suffix array of MORE than 2^32 positions (what BASELINE.json configs[3] / configs[4] need; 64-bit positions,

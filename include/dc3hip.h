@@ -235,6 +235,15 @@ typedef struct dc3hip_stats {
   double  ssort_local_ms; int64_t ssort_local_launches; int64_t ssort_local_elems;
   int32_t ssort_sorts, ssort_fallbacks;
   int64_t ssort_max_subbucket;
+  /* The XCD-grouped partition kernels (k_msd_part, k_wide_part1) owe their speed to "blocks with equal blockIdx % 8 run
+   * on one XCD" (a placement the dispatcher is observed to use, not a promise).  xcd_round_robin: the probe of context
+   * creation (4096 small blocks report HW_REG_XCC_ID): 1 = they did; 0 = they did not, and the context then orders with the
+   * stable 256-bucket LSD passes instead (DC3HIP_XCD_ASSUME=1 keeps the bucket ordering).  xcd_blocks / xcd_group_hit:
+   * the grouped partition blocks of the LAST build and the share of them that ran on their group's majority XCD (1.0 = the
+   * assumption held throughout, 0.125 = placement unrelated to blockIdx) — also under other streams on the device. */
+  int32_t xcd_round_robin, xcd_reserved;
+  int64_t xcd_blocks;
+  double  xcd_group_hit;
 } dc3hip_stats;
 
 DC3HIP_API int32_t dc3hip_ctx_stats(dc3hip_ctx *ctx, dc3hip_stats *out);

@@ -103,6 +103,16 @@ __device__ __forceinline__ u32 block_excl_scan(u32 v, u32 *tmp, u32 &total) {
   return woff + inc - v;
 }
 
+// The XCD this wave runs on (0..7), HW_REG_XCC_ID.  A speed/diagnostic aid only: nothing may depend on it for correctness.
+__device__ __forceinline__ u32 xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u; }
+// One word per (block group, XCD): mon[g * 8 + xcd] += 1 for a block of group g — the partition kernels whose speed rests
+// on "blocks with equal blockIdx % 8 share an XCD" record where they really ran (dc3hip_stats.xcd_group_hit).
+__device__ __forceinline__ void xcd_note(u32 *mon, u32 g) {
+  if (mon && threadIdx.x == 0) atomicAdd(&mon[(g & 7u) * 8u + xcc_id()], 1u);
+}
+// the placement probe of context creation: out[b] = XCD of block b
+__global__ void k_xcd_probe(u32 *__restrict__ out) { if (threadIdx.x == 0) out[blockIdx.x] = xcc_id(); }
+
 // popcount of mask bits below this lane
 __device__ __forceinline__ u32 mbcnt(u64 mask) {
   return __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));

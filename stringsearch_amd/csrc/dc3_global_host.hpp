@@ -1264,7 +1264,7 @@ struct WidePass1 : MsdPass1 {
       HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_wide_part1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWidePartSmem));
       attr_set[c->device & 15] = true;
     }
-    hipLaunchKernelGGL(k_wide_part1, dim3(kMsdGroups * cpg), dim3(kWideNT), kWidePartSmem, c->stream, k, rg, chunk, nchunks, cpg, cur1, out);
+    hipLaunchKernelGGL(k_wide_part1, dim3(kMsdGroups * cpg), dim3(kWideNT), kWidePartSmem, c->stream, k, rg, chunk, nchunks, cpg, cur1, out, c->d_xcdmon);
     KCHECK();
     return E_OK;
   }

@@ -132,7 +132,7 @@ template <bool kSeg>
 __global__ __launch_bounds__(kMsdNW * 64) void k_msd_part(const u64 *__restrict__ in, u64 *__restrict__ out, u32 n, u64 base, u32 shift,
                                                          u32 dbits, u32 cpx, u32 ntiles, const u32 *__restrict__ tpre,
                                                          const u32 *__restrict__ bstart, u32 nb1, const u32 *__restrict__ plan,
-                                                         u32 *__restrict__ cursors, u32 gstride) {
+                                                         u32 *__restrict__ cursors, u32 gstride, u32 *__restrict__ xcdmon) {
   constexpr int NT = kMsdNW * 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u64 *srec = reinterpret_cast<u64 *>(smem);
@@ -159,6 +159,7 @@ __global__ __launch_bounds__(kMsdNW * 64) void k_msd_part(const u64 *__restrict_
     end = min(n, begin + (u32)kMsdTile);
   }
   const u32 nvalid = end - begin;                  // >= 1
+  xcd_note(xcdmon, g);
   hist[tid] = 0;
   __syncthreads();
   u64 r[kMsdIPT];
@@ -200,12 +201,21 @@ __global__ __launch_bounds__(kMsdNW * 64) void k_msd_part(const u64 *__restrict_
 // computed from the key maker (images4: 4 consecutive positions per thread and round, as the pack kernels do) instead of
 // being read — the pack kernel then only has to COUNT (k_pack_image_text<…, kStore = false>), and 8 bytes per position
 // are neither written nor read back.  Everything after the load is k_msd_part<false>.
-template <class KM>
+// kStrip: `hm` describes an image that is dbits WIDER than the word has room for (hm.pbits = real position bits - dbits).
+// The bucket a word lands in already says what its top dbits are, so the stored word keeps only the bits below them:
+//     word = (image mod 2^(hm.nbits - dbits)) << (hm.pbits + dbits) | position
+// — the order inside every bucket is unchanged, and the image is 2^dbits times finer: at 1 GiB, 44 instead of 34 bits,
+// 0.006 % of the words tied instead of 6 % (the tie pass then has next to nothing to gather).  Words that agree across a
+// bucket boundary are compared by the tie pass like any tie, consistently with their images.  Inside the tile the
+// position field of the LDS copy carries (digit, tile-local index) instead — the position is begin + index — so the
+// digit survives the reorder without a second LDS array.  Needs hm.pbits + dbits >= 23.
+template <class KM, bool kStrip>
 __global__ __launch_bounds__(kMsdNW * 64) void k_msd_part_keys(KM km, HiMap hm, u64 P1, u64 *__restrict__ out, u32 n, u64 base, u32 shift,
                                                               u32 dbits, u32 cpx, u32 ntiles, const u32 *__restrict__ plan,
-                                                              u32 *__restrict__ cursors, u32 gstride) {
+                                                              u32 *__restrict__ cursors, u32 gstride, u32 *__restrict__ xcdmon) {
   constexpr int NT = kMsdNW * 64;
   static_assert(kMsdIPT == 8, "two rounds of 4 positions per thread");
+  static_assert(kMsdTile == 8192 && kMsdMaxDig == 1024, "kStrip keeps (digit, index) in 10 + 13 bits");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u64 *srec = reinterpret_cast<u64 *>(smem);
   u32 *hist = reinterpret_cast<u32 *>(smem + sizeof(u64) * kMsdTile);
@@ -220,24 +230,36 @@ __global__ __launch_bounds__(kMsdNW * 64) void k_msd_part_keys(KM km, HiMap hm, 
   u32 *cur = cursors + (size_t)g * gstride;
   const u32 begin = tile * (u32)kMsdTile, end = min(n, begin + (u32)kMsdTile);
   const u32 nvalid = end - begin;
+  xcd_note(xcdmon, g);
   km.stage(lcode);
   hist[tid] = 0;
   __syncthreads();
+  const u32 pb = hm.pbits + (kStrip ? dbits : 0u);                 // position bits of the stored word
+  const u32 rbits = hm.nbits - dbits;                              // (kStrip) image bits the word keeps
   u64 r[kMsdIPT];
-  u32 rk[kMsdIPT];
+  u32 rk[kMsdIPT], dg[kMsdIPT];
 #pragma unroll
   for (int k = 0; k < 2; k++) {
     const u32 p0 = begin + (u32)(k * NT + tid) * 4u;
     u64 img[4] = {0, 0, 0, 0};
     if (p0 < end) images4(km, hm, P1, p0, n, lcode, img);
 #pragma unroll
-    for (int j = 0; j < 4; j++) r[k * 4 + j] = (img[j] << hm.pbits) | (u64)(p0 + j);
+    for (int j = 0; j < 4; j++) {
+      if (kStrip) {
+        const u32 t = (u32)(k * NT + tid) * 4u + (u32)j;
+        dg[k * 4 + j] = (u32)(img[j] >> rbits) & mask;
+        r[k * 4 + j] = ((img[j] & ((1ull << rbits) - 1ull)) << pb) | ((u64)dg[k * 4 + j] << 13) | t;
+      } else {
+        r[k * 4 + j] = (img[j] << hm.pbits) | (u64)(p0 + j);
+        dg[k * 4 + j] = (u32)((r[k * 4 + j] - base) >> shift) & mask;
+      }
+    }
   }
   // word k * 4 + j of thread tid is tile element t = (k * NT + tid) * 4 + j
 #pragma unroll
   for (int k = 0; k < kMsdIPT; k++) {
     const u32 t = (u32)((k >> 2) * NT + tid) * 4u + (k & 3);
-    if (t < nvalid) rk[k] = atomicAdd(&hist[(u32)((r[k] - base) >> shift) & mask], 1u);
+    if (t < nvalid) rk[k] = atomicAdd(&hist[dg[k]], 1u);
   }
   __syncthreads();
   u32 cnt = 0;
@@ -252,13 +274,19 @@ __global__ __launch_bounds__(kMsdNW * 64) void k_msd_part_keys(KM km, HiMap hm, 
 #pragma unroll
   for (int k = 0; k < kMsdIPT; k++) {
     const u32 t = (u32)((k >> 2) * NT + tid) * 4u + (k & 3);
-    if (t < nvalid) srec[hist[(u32)((r[k] - base) >> shift) & mask] + rk[k]] = r[k];
+    if (t < nvalid) srec[hist[dg[k]] + rk[k]] = r[k];
   }
   __syncthreads();
   for (u32 q = tid; q < nvalid; q += NT) {
     const u64 x = srec[q];
-    const u32 dd = (u32)((x - base) >> shift) & mask;
-    out[gbase[dd] + (q - hist[dd])] = msd_word(x);
+    if (kStrip) {
+      const u32 dd = (u32)(x >> 13) & mask;
+      const u64 w = (x & ~((1ull << pb) - 1ull)) | (u64)(begin + ((u32)x & (kMsdTile - 1u)));
+      out[gbase[dd] + (q - hist[dd])] = msd_word(w);
+    } else {
+      const u32 dd = (u32)((x - base) >> shift) & mask;
+      out[gbase[dd] + (q - hist[dd])] = msd_word(x);
+    }
   }
 }
 

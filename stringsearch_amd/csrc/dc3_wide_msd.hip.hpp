@@ -96,7 +96,7 @@ __global__ __launch_bounds__(kWideNT) void k_wide_count1(WideKey k, WideRange rg
 // j / 8 (chunk c = g * cpg + idx); cursors[g * ndig + d] = the group's cursor of bucket d (k_msd_plan1).  Output words in
 // the memory form of the bucket ordering (msd_word).  Not stable.
 __global__ __launch_bounds__(kWideNT) void k_wide_part1(WideKey k, WideRange rg, u64 chunk, u32 nchunks, u32 cpg,
-                                                       u32 *__restrict__ cursors, u64 *__restrict__ out) {
+                                                       u32 *__restrict__ cursors, u64 *__restrict__ out, u32 *__restrict__ xcdmon) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u64 *stage = reinterpret_cast<u64 *>(smem);
   uint16_t *sdig = reinterpret_cast<uint16_t *>(smem + sizeof(u64) * kWideStage);
@@ -108,6 +108,7 @@ __global__ __launch_bounds__(kWideNT) void k_wide_part1(WideKey k, WideRange rg,
   const u32 g = blockIdx.x % kMsdGroups, idx = blockIdx.x / kMsdGroups;
   const u32 c = g * cpg + idx;
   if (idx >= cpg || c >= nchunks) return;
+  xcd_note(xcdmon, g);
   const u32 ndig = 1u << rg.d1, sh = rg.E - rg.d1;
   const u64 wmask = sh >= 64 ? ~0ull : ((1ull << sh) - 1ull);
   u32 *cur = cursors + (size_t)g * ndig;

@@ -80,6 +80,8 @@ struct dc3hip_ctx {
   u32 *d_present = nullptr;    // [256]
   uint16_t *d_code = nullptr;  // [256]
   u32 *d_words = nullptr;      // [64] misc totals / error words
+  u32 *d_xcdmon = nullptr;     // [64] (block group, XCD) counts of the XCD-grouped partition kernels (xcd_note)
+  int xcd_rr = -1;             // creation-time placement probe: 1 = blocks b and b + 8 shared an XCD and the 8 groups had 8 XCDs
   u32 *h_words = nullptr;      // pinned mirror
   // profiling
   bool profile = true;
@@ -99,7 +101,8 @@ struct dc3hip_ctx {
   u32 tup_scatter_min = 1u << 25; // DC3HIP_TUP_SCATTER_MIN (tests): smallest level (samples) whose tuples are scattered
   bool no_tup_rec8 = false;    // DC3HIP_NO_TUP_REC8=1 (tests): level 0 moves 12-byte records through the tuple scatter, as deeper levels do
   bool no_xcd_map = false;     // DC3HIP_NO_XCD_MAP=1: window partitions without the segment -> XCD-group tile order (measurement aid)
-  bool pack_fuse = false;      // DC3HIP_PACK_FUSE=1: whole-text order of bytes: the pack kernel only counts, partition pass 1 makes the records on the fly
+  bool pack_fuse = true;       // DC3HIP_PACK_FUSE=0: whole-text order of bytes with a pack kernel that WRITES the words (default: it only counts, partition pass 1 makes them on the fly)
+  bool no_pack_strip = false;  // DC3HIP_NO_PACK_STRIP=1: ... from an image no wider than the word (default: d1 bits wider, the bucket's own bits dropped)
   bool no_msd = false;         // DC3HIP_NO_MSD=1: the prefix sorts always run the stable LSD passes (no bucket ordering)
   u32 ssort_over = 24;         // DC3HIP_SSORT_OVER: sample values per sub-bucket
   u32 ssort_mean = 1400;       // DC3HIP_SSORT_MEAN: records per sub-bucket the splitter ordering aims at (capacity 4096)
@@ -423,18 +426,36 @@ static MsdGeom msd_geometry(const dc3hip_ctx *c, u32 nrec, const HiMap &hm, u64 
 struct MsdPass1 {
   virtual ~MsdPass1() {}
   virtual int launch(dc3hip_ctx *c, u64 *out, u32 n, u64 base, u32 sh1, const MsdGeom &g, u32 nb1, const u32 *plan, u32 *cur1) = 0;
+  // strips(): the words it writes lack the bucket's own image bits (k_msd_part_keys<.., true>) — they are only ordered
+  // inside their buckets, so a caller that has to give the bucket ordering up cannot continue from them with the LSD
+  // passes: repack() writes the plain words of all positions, in position order, for a sort from scratch
+  virtual bool strips() const { return false; }
+  virtual int repack(dc3hip_ctx *, Rec8 *, u32, u32 **) { return E_HIP; }
 };
+template <class KM> static int launch_pack_all(dc3hip_ctx *c, KM km, u32 nrec, const HiMap &hm, Rec8 *out, u32 **first_table,
+                                               const MsdGeom *mg = nullptr, bool store = true);
 template <class KM>
 struct MsdPass1Keys : MsdPass1 {
   KM km; HiMap hm; u64 P1 = 0;
+  bool strip = false; HiMap hm_plain{};      // strip: hm is the WIDER image (hm.pbits = position bits - d1); hm_plain the words' own layout
+  bool strips() const override { return strip; }
+  int repack(dc3hip_ctx *c, Rec8 *out, u32 nrec, u32 **first_table) override {
+    PhaseScope ps(c, DC3HIP_PH_PACK, nrec);
+    return launch_pack_all<KM>(c, km, nrec, hm_plain, out, first_table, nullptr, true);
+  }
   int launch(dc3hip_ctx *c, u64 *out, u32 n, u64 base, u32 sh1, const MsdGeom &g, u32 nb1, const u32 *plan, u32 *cur1) override {
     static std::atomic<bool> attr_set[16];
     if (!attr_set[c->device & 15]) {
-      HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_msd_part_keys<KM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
+      HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_msd_part_keys<KM, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
+      HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_msd_part_keys<KM, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
       attr_set[c->device & 15] = true;
     }
-    hipLaunchKernelGGL((k_msd_part_keys<KM>), dim3(kMsdGroups * g.cpx1), dim3(kMsdNW * 64), kMsdPartSmem, c->stream, km, hm, P1, out, n, base, sh1,
-                       g.d1, g.cpx1, g.ntiles1, plan, cur1, nb1);
+    if (strip)
+      hipLaunchKernelGGL((k_msd_part_keys<KM, true>), dim3(kMsdGroups * g.cpx1), dim3(kMsdNW * 64), kMsdPartSmem, c->stream, km, hm, P1, out, n, base, sh1,
+                         g.d1, g.cpx1, g.ntiles1, plan, cur1, nb1, c->d_xcdmon);
+    else
+      hipLaunchKernelGGL((k_msd_part_keys<KM, false>), dim3(kMsdGroups * g.cpx1), dim3(kMsdNW * 64), kMsdPartSmem, c->stream, km, hm, P1, out, n, base, sh1,
+                         g.d1, g.cpx1, g.ntiles1, plan, cur1, nb1, c->d_xcdmon);
     KCHECK();
     return E_OK;
   }
@@ -503,7 +524,7 @@ static int msd_sort(dc3hip_ctx *c, Rec8 *ha, Rec8 *hb, u32 n, const HiMap &hm, c
       RC(p1->launch(c, wb, n, base, sh1, g, nb1, plan, cur1));
     } else {
       hipLaunchKernelGGL((k_msd_part<false>), dim3(kMsdGroups * g.cpx1), dim3(kMsdNW * 64), kMsdPartSmem, c->stream, (const u64 *)wa, wb, n,
-                         base, sh1, g.d1, g.cpx1, g.ntiles1, (const u32 *)nullptr, (const u32 *)nullptr, nb1, (const u32 *)plan, cur1, nb1);
+                         base, sh1, g.d1, g.cpx1, g.ntiles1, (const u32 *)nullptr, (const u32 *)nullptr, nb1, (const u32 *)plan, cur1, nb1, c->d_xcdmon);
       KCHECK();
     }
   }
@@ -534,7 +555,7 @@ static int msd_sort(dc3hip_ctx *c, Rec8 *ha, Rec8 *hb, u32 n, const HiMap &hm, c
       PhaseScope ps(c, DC3HIP_PH_SORT8_DOWN, n, 5);
       const u32 grid2 = kMsdGroups * ((n / kMsdTile + nb1 + 1 + kMsdGroups - 1) / kMsdGroups);
       hipLaunchKernelGGL((k_msd_part<true>), dim3(grid2), dim3(kMsdNW * 64), kMsdPartSmem, c->stream, (const u64 *)wb, wa, n, base, sh2, g.d2,
-                         0u, 0u, (const u32 *)tpre, (const u32 *)bstart, nb1, (const u32 *)plan, cur2, n2);
+                         0u, 0u, (const u32 *)tpre, (const u32 *)bstart, nb1, (const u32 *)plan, cur2, n2, c->d_xcdmon);
       KCHECK();
     }
     r.src = wa; r.dst = wb; r.start = cnt2g; r.nsub = n2;
@@ -1217,6 +1238,7 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
       Rec8 *where = ha;
       RC(msd_sort(c, ha, hb, nrec, hm, *mg, first_table, &sink, &h, &mredo, &msd_ok, &where, p1));
       if (msd_ok) lp.src = const_cast<u64 *>(mredo.src);               // (non-null = "the order lives in the sink")
+      else if (p1 && p1->strips()) { first_table = nullptr; RC(p1->repack(c, ha, nrec, &first_table)); }
       else { if (where != ha) std::swap(ha, hb); first_table = nullptr; }
     }
     if (!msd_ok)
@@ -1279,7 +1301,8 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
     if (mg && mg->on) {
       MsdRedo mredo; Rec8 *where = ha;
       RC(msd_sort(c, ha, hb, nrec, hm, *mg, first_table, nullptr, &h, &mredo, &msd_ok, &where, p1));
-      if (!msd_ok) { if (where != ha) std::swap(ha, hb); first_table = nullptr; }
+      if (!msd_ok && p1 && p1->strips()) { first_table = nullptr; RC(p1->repack(c, ha, nrec, &first_table)); }
+      else if (!msd_ok) { if (where != ha) std::swap(ha, hb); first_table = nullptr; }
     }
     if (!msd_ok)
       RC(radix_sort<Rec8>(c, ha, hb, nrec, hm.pbits, hm.pbits + hm.nbits, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN,
@@ -1565,7 +1588,7 @@ static int order_hybrid(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 b, u32
 // store = false (only with mg->on): count only — pass 1 of the bucket ordering makes the records on the fly (MsdPass1Keys).
 template <class KM>
 static int launch_pack_all(dc3hip_ctx *c, KM km, u32 nrec, const HiMap &hm, Rec8 *out, u32 **first_table,
-                           const MsdGeom *mg = nullptr, bool store = true) {
+                           const MsdGeom *mg, bool store) {
   int nb = 0; Chunking ck; u32 hshift = 0;
   pack_plan(c, nrec, hm, mg, &nb, &ck, &hshift);
   u32 *table = nullptr;
@@ -1805,13 +1828,23 @@ static int order_all_positions(dc3hip_ctx *c, KM km, Map mp, u32 m, u32 kbits, c
   // save, 22.8 -> 27.9 ms.  A 5 % gain on one input class against a second variant of the dominant kernel: off by default.
   const bool fuse = mg.on && c->pack_fuse && std::is_same<KM, Key9>::value;
   MsdPass1Keys<KM> p1; p1.km = km; p1.hm = hm; p1.P1 = pass1_p1<KM>(km);
+  MsdGeom mgx = mg;
+  if constexpr (std::is_same<KM, Key9>::value) {
+    // ... and since the words are made inside pass 1, they can come from an image d1 bits wider than a word has room
+    // for (k_msd_part_keys<.., true>): the tie pass then finds next to nothing tied
+    if (fuse && !c->no_pack_strip && hm.pbits >= 23 && !hm.exact && kbits >= hm.nbits + mg.d1) {
+      p1.strip = true; p1.hm_plain = hm;
+      p1.hm = make_himap(km.B3, kbits, m, hm.pbits - mg.d1);
+      mgx.ebits = p1.hm.nbits;                       // (= hm.nbits + d1: the shifts of passes 2 and 3 follow from it)
+    }
+  }
   {
     PhaseScope ps(c, DC3HIP_PH_PACK, nrec);
-    RC(launch_pack_all<KM>(c, km, nrec, hm, ha, &first_table, &mg, !fuse));
+    RC(launch_pack_all<KM>(c, km, nrec, p1.strip ? p1.hm : hm, ha, &first_table, &mgx, !fuse));
   }
   bool sorted_ok = false, distinct = false;
   RC((hybrid_sort_core<KM>(c, km, kbits, hm, ha, hb, nrec, &h, f, &sorted_ok, depth, out_rank ? nullptr : out_sa, dummy,
-                           &distinct, first_table, std::is_same<Map, MapText>::value && dummy == 0 && !out_rank, &mg, 0, 0,
+                           &distinct, first_table, std::is_same<Map, MapText>::value && dummy == 0 && !out_rank, &mgx, 0, 0,
                            fuse ? &p1 : nullptr)));
   if (sorted_ok && distinct) {
     *state = 1;                            // the tie pass already wrote the suffix array
@@ -2248,6 +2281,7 @@ static int build_begin(dc3hip_ctx *c) {
   HIPC(hipSetDevice(c->device));
   for (int l = 0; l < DC3HIP_MAX_LEVELS; l++) c->stats.trace_names[l] = -1;
   if (c->trace) HIPC(hipMemsetAsync(c->d_trace, 0, 3 * DC3HIP_MAX_LEVELS * sizeof(u64), c->stream));
+  HIPC(hipMemsetAsync(c->d_xcdmon, 0, 64 * sizeof(u32), c->stream));
   if (c->profile) HIPC(hipEventRecord(c->ev_build_a, c->stream));
   return E_OK;
 }
@@ -2260,7 +2294,17 @@ static int build_end(dc3hip_ctx *c) {
     HIPC(hipMemcpyAsync(c->stats.trace_sa0, c->d_trace + DC3HIP_MAX_LEVELS, DC3HIP_MAX_LEVELS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIPC(hipMemcpyAsync(c->stats.trace_sa, c->d_trace + 2 * DC3HIP_MAX_LEVELS, DC3HIP_MAX_LEVELS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
   }
+  u32 mon[64];
+  HIPC(hipMemcpyAsync(mon, c->d_xcdmon, sizeof(mon), hipMemcpyDeviceToHost, c->stream));
   HIPC(hipStreamSynchronize(c->stream));
+  {
+    // where the XCD-grouped partition blocks of this build really ran: share of them on their group's majority XCD
+    u64 all = 0, hit = 0;
+    for (int g = 0; g < 8; g++) { u32 mx = 0; for (int x = 0; x < 8; x++) { all += mon[g * 8 + x]; mx = std::max(mx, mon[g * 8 + x]); } hit += mx; }
+    c->stats.xcd_blocks = (int64_t)all;
+    c->stats.xcd_group_hit = all ? (double)hit / (double)all : 0.0;
+    c->stats.xcd_round_robin = c->xcd_rr;
+  }
   c->stats.arena_peak = (int64_t)c->arena_peak;
   c->stats.arena_bytes = (int64_t)c->arena_bytes;
   if (c->profile) {
@@ -2594,7 +2638,8 @@ int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) {
   { const char *e = getenv("DC3HIP_NO_TUP8"); c->no_tup8 = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_MSD"); c->no_msd = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_LEVEL_PHASES"); c->level_report = (e && e[0] == '1'); }
-  { const char *e = getenv("DC3HIP_PACK_FUSE"); c->pack_fuse = (e && e[0] == '1'); }
+  { const char *e = getenv("DC3HIP_PACK_FUSE"); c->pack_fuse = !(e && e[0] == '0'); }
+  { const char *e = getenv("DC3HIP_NO_PACK_STRIP"); c->no_pack_strip = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_XCD_MAP"); c->no_xcd_map = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_TUP_SCATTER"); c->no_tup_scatter = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_TUP_REC8"); c->no_tup_rec8 = (e && e[0] == '1'); }
@@ -2638,10 +2683,32 @@ int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) {
     HIPC(hipMalloc(&c->d_present, 256 * sizeof(u32)));
     HIPC(hipMalloc(&c->d_code, 256 * sizeof(uint16_t)));
     HIPC(hipMalloc(&c->d_words, 64 * sizeof(u32)));
+    HIPC(hipMalloc(&c->d_xcdmon, 4096 * sizeof(u32)));         // (64 monitor words; 4096 for the placement probe below)
     HIPC(hipMalloc(&c->d_trace, 3 * DC3HIP_MAX_LEVELS * sizeof(u64)));
     HIPC(hipHostMalloc(&c->h_words, 64 * sizeof(u32), hipHostMallocDefault));
     HIPC(hipEventCreate(&c->ev_build_a));
     HIPC(hipEventCreate(&c->ev_build_b));
+    {
+      // Placement probe (dc3hip_stats.xcd_round_robin): 4096 one-wave blocks report the XCD they ran on.  The bucket
+      // ordering's partition passes are only fast when blocks b and b + 8 share an XCD (XCD-grouped reservation,
+      // dc3_msd.hip.hpp); on a device that places blocks otherwise the context keeps to the stable 256-bucket LSD passes,
+      // whose speed does not depend on placement (DC3HIP_XCD_ASSUME=1: keep the bucket ordering anyway).
+      std::vector<u32> xs(4096);
+      hipLaunchKernelGGL(k_xcd_probe, dim3(4096), dim3(64), 0, c->stream, c->d_xcdmon);
+      HIPC(hipMemcpyAsync(xs.data(), c->d_xcdmon, 4096 * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+      HIPC(hipStreamSynchronize(c->stream));
+      u32 cnt[8][8] = {};
+      for (u32 b = 0; b < 4096; b++) cnt[b & 7][xs[b] & 7]++;
+      u32 hit = 0, seen = 0;
+      for (int g = 0; g < 8; g++) {
+        u32 mx = 0, arg = 0;
+        for (int x = 0; x < 8; x++) if (cnt[g][x] > mx) { mx = cnt[g][x]; arg = (u32)x; }
+        hit += mx; seen |= 1u << arg;
+      }
+      c->xcd_rr = (hit >= 4096 * 9 / 10 && seen == 0xffu) ? 1 : 0;
+      const char *e = getenv("DC3HIP_XCD_ASSUME");
+      if (!c->xcd_rr && !(e && e[0] == '1')) c->no_msd = true;
+    }
     return E_OK;
   }();
   if (rc != E_OK) { dc3hip_ctx_destroy(c); return rc; }
