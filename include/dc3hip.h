@@ -244,6 +244,10 @@ typedef struct dc3hip_stats {
   int32_t xcd_round_robin, xcd_reserved;
   int64_t xcd_blocks;
   double  xcd_group_hit;
+  /* k_msd_part_keys / k_wide_part1: partition pass 1 of a bucket ordering that also MAKES the words it partitions (from
+   * the text: the pack kernel only counted) — Step 0 (lib.rs:62-70) and one radix pass (lib.rs:35-38) in one launch;
+   * timed apart from msd_part_*, which then holds pass 2 only. */
+  double  msd_part_keys_ms; int64_t msd_part_keys_launches; int64_t msd_part_keys_elems;
 } dc3hip_stats;
 
 DC3HIP_API int32_t dc3hip_ctx_stats(dc3hip_ctx *ctx, dc3hip_stats *out);

@@ -50,7 +50,8 @@ class Stats(ctypes.Structure):
                 ("ssort_local_ms", ctypes.c_double), ("ssort_local_launches", ctypes.c_int64), ("ssort_local_elems", ctypes.c_int64),
                 ("ssort_sorts", ctypes.c_int32), ("ssort_fallbacks", ctypes.c_int32), ("ssort_max_subbucket", ctypes.c_int64),
                 ("xcd_round_robin", ctypes.c_int32), ("xcd_reserved", ctypes.c_int32), ("xcd_blocks", ctypes.c_int64),
-                ("xcd_group_hit", ctypes.c_double)]
+                ("xcd_group_hit", ctypes.c_double),
+                ("msd_part_keys_ms", ctypes.c_double), ("msd_part_keys_launches", ctypes.c_int64), ("msd_part_keys_elems", ctypes.c_int64)]
 
     def as_dict(self):
         return {
@@ -81,6 +82,8 @@ class Stats(ctypes.Structure):
             "ssort_local_elems": self.ssort_local_elems, "ssort_sorts": self.ssort_sorts, "ssort_fallbacks": self.ssort_fallbacks,
             "ssort_max_subbucket": self.ssort_max_subbucket,
             "xcd_round_robin": self.xcd_round_robin, "xcd_blocks": self.xcd_blocks, "xcd_group_hit": self.xcd_group_hit,
+            "msd_part_keys_ms": self.msd_part_keys_ms, "msd_part_keys_launches": self.msd_part_keys_launches,
+            "msd_part_keys_elems": self.msd_part_keys_elems,
             "trace": None if not self.trace_on else [
                 {"n": self.level_n[i], "sa12": self.trace_sa12[i], "sa0": self.trace_sa0[i], "sa": self.trace_sa[i],
                  "names": self.trace_names[i]} for i in range(self.levels)],

@@ -43,7 +43,7 @@ def kernel_sources_sha():
 
 class KernelAcc:
     """Per-kernel-family HIP-event times summed over the timed steps (dc3hip_stats of every build)."""
-    FAMS = ("downsweep0", "downsweep1", "downsweep2", "gather", "partition", "msd_part", "msd_local")
+    FAMS = ("downsweep0", "downsweep1", "downsweep2", "gather", "partition", "msd_part", "msd_part_keys", "msd_local", "ssort_part", "ssort_local")
 
     def __init__(self):
         self.ms = {k: 0.0 for k in self.FAMS}
@@ -59,6 +59,9 @@ class KernelAcc:
         self._add("partition", st["partition_ms"], st["partition_launches"], st["partition_elems"])
         self._add("msd_part", st.get("msd_part_ms", 0.0), st.get("msd_part_launches", 0), st.get("msd_part_elems", 0))
         self._add("msd_local", st.get("msd_local_ms", 0.0), st.get("msd_local_launches", 0), st.get("msd_local_elems", 0))
+        self._add("msd_part_keys", st.get("msd_part_keys_ms", 0.0), st.get("msd_part_keys_launches", 0), st.get("msd_part_keys_elems", 0))
+        self._add("ssort_part", st.get("ssort_part_ms", 0.0), st.get("ssort_part_launches", 0), st.get("ssort_part_elems", 0))
+        self._add("ssort_local", st.get("ssort_local_ms", 0.0), st.get("ssort_local_launches", 0), st.get("ssort_local_elems", 0))
 
     def _add(self, k, ms, launches, elems):
         self.ms[k] += ms; self.launches[k] += launches; self.elems[k] += elems
@@ -75,7 +78,16 @@ _FAM = {
     "downsweep2": ("k_rs_downsweep<Tup0> (stable radix scatter of mod-0 tuples)", 12.0, 40.0, "downsweep_tup0"),
     "partition": ("k_part_msd (window partition of (destination,value) pairs: inverse permutations)", 8.0, 16.0, "part_msd"),
     "msd_part": ("k_msd_part (bucket partition of the prefix-sort words: non-stable radix scatter, XCD-grouped reservation)", 12.0, 16.0, "msd_part"),
+    # pass 1 that makes its words from the text (the pack kernel only counted): Step 0 of the level (lib.rs:62-70: one
+    # index written per position, w = 4) + the scatter loop of one radix pass (12) in one launch = 16 algorithmic bytes;
+    # it physically reads 1 text byte and writes one 8-byte word per position
+    "msd_part_keys": ("k_msd_part_keys (bucket partition pass 1 that also makes the words from the text: Step 0 + one radix pass, "
+                      "XCD-grouped reservation; image d1 bits wider than the word, the bucket's own bits dropped)", 16.0, 9.0, "msd_part_keys"),
     "msd_local": ("k_msd_local (in-LDS order of the sub-buckets: the last passes of the sort in one launch)", 12.0, 16.0, "msd_local"),
+    # splitter ordering of the 12- / 16-byte sample-triple records (text levels): the same scatter loop, moved bytes 2 x 16
+    # (+ 2 for the digit side array in the partition pass); priced like one radix pass each
+    "ssort_part": ("k_ss_part (partition of the sample-triple records over sampled splitters, XCD-grouped reservation)", 12.0, 34.0, "ssort_part"),
+    "ssort_local": ("k_ss_local (in-LDS comparison order of the sub-buckets: the last passes of the sort in one launch)", 12.0, 32.0, "ssort_local"),
 }
 
 

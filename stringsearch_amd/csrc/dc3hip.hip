@@ -426,11 +426,9 @@ static MsdGeom msd_geometry(const dc3hip_ctx *c, u32 nrec, const HiMap &hm, u64 
 struct MsdPass1 {
   virtual ~MsdPass1() {}
   virtual int launch(dc3hip_ctx *c, u64 *out, u32 n, u64 base, u32 sh1, const MsdGeom &g, u32 nb1, const u32 *plan, u32 *cur1) = 0;
-  // strips(): the words it writes lack the bucket's own image bits (k_msd_part_keys<.., true>) — they are only ordered
-  // inside their buckets, so a caller that has to give the bucket ordering up cannot continue from them with the LSD
-  // passes: repack() writes the plain words of all positions, in position order, for a sort from scratch
-  virtual bool strips() const { return false; }
-  virtual int repack(dc3hip_ctx *, Rec8 *, u32, u32 **) { return E_HIP; }
+  // a caller that has to give the bucket ordering up has no words to continue from (the pack kernel only counted):
+  // repack() writes the plain words of all positions, in position order, with the LSD passes' first digit table
+  virtual int repack(dc3hip_ctx *, Rec8 *, u32, u32 **) { set_err("internal: this pass 1 cannot repack"); return E_HIP; }
 };
 template <class KM> static int launch_pack_all(dc3hip_ctx *c, KM km, u32 nrec, const HiMap &hm, Rec8 *out, u32 **first_table,
                                                const MsdGeom *mg = nullptr, bool store = true);
@@ -438,7 +436,6 @@ template <class KM>
 struct MsdPass1Keys : MsdPass1 {
   KM km; HiMap hm; u64 P1 = 0;
   bool strip = false; HiMap hm_plain{};      // strip: hm is the WIDER image (hm.pbits = position bits - d1); hm_plain the words' own layout
-  bool strips() const override { return strip; }
   int repack(dc3hip_ctx *c, Rec8 *out, u32 nrec, u32 **first_table) override {
     PhaseScope ps(c, DC3HIP_PH_PACK, nrec);
     return launch_pack_all<KM>(c, km, nrec, hm_plain, out, first_table, nullptr, true);
@@ -477,9 +474,11 @@ static int msd_launch_local(dc3hip_ctx *c, const MsdRedo &r, u32 n, Sink sink) {
 // Sort the n words of `ha` (scratch `hb`) by image bits [pbits, pbits + nbits).  table = the pack kernel's digit table of
 // the top g.d1 image bits ([1024][g.ck.nchunks]).  split != nullptr: the last pass writes positions + 32 image bits
 // through it (as the LSD passes do with a SplitSink) and *result = nullptr; else *result = the sorted records.
-// *ok = false: a sub-bucket was too large for the local sort — nothing was delivered, all records are in *where (in
-// partition order) and the caller runs the LSD passes from there.  The small tables stay allocated in the arena until
-// the caller releases its mark (redo reads them).
+// *ok = false: a sub-bucket was too large for the local sort — seen BEFORE pass 2 is launched, so `ha` still holds the
+// caller's words in their original (position) order (*where = ha; with p1 they were never written: the caller repacks)
+// and the stable LSD passes start from there, exactly as if the bucket ordering had not been tried: the order of equal
+// images the tie pass meets does not depend on which way the sort went.  The small tables stay allocated in the arena
+// until the caller releases its mark (redo reads them).
 static int msd_sort(dc3hip_ctx *c, Rec8 *ha, Rec8 *hb, u32 n, const HiMap &hm, const MsdGeom &g, const u32 *table,
                     const SplitSink *split, Rec8 **result, MsdRedo *redo, bool *ok, Rec8 **where, MsdPass1 *p1 = nullptr) {
   // p1 != nullptr: the words do not exist yet — pass 1 makes them from the key maker (`ha` is then only the scratch of
@@ -519,7 +518,7 @@ static int msd_sort(dc3hip_ctx *c, Rec8 *ha, Rec8 *hb, u32 n, const HiMap &hm, c
     KCHECK();
   }
   {
-    PhaseScope ps(c, DC3HIP_PH_SORT8_DOWN, n, 5);
+    PhaseScope ps(c, DC3HIP_PH_SORT8_DOWN, n, p1 ? 9 : 5);     // (class 9: pass 1 that also makes the words, timed on its own)
     if (p1) {
       RC(p1->launch(c, wb, n, base, sh1, g, nb1, plan, cur1));
     } else {
@@ -551,6 +550,8 @@ static int msd_sort(dc3hip_ctx *c, Rec8 *ha, Rec8 *hb, u32 n, const HiMap &hm, c
       KCHECK();
       HIPC(hipMemcpyAsync(c->h_words + 20, plan, kMsdW_COUNT * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
     }
+    HIPC(hipStreamSynchronize(c->stream));                  // (pass 2 overwrites `ha`: decide first)
+    if (c->h_words[20 + kMsdW_MAXSUB] > kMsdCapLarge) { c->stats.msd_max_subbucket = c->h_words[20 + kMsdW_MAXSUB]; c->stats.msd_fallbacks++; return E_OK; }
     {
       PhaseScope ps(c, DC3HIP_PH_SORT8_DOWN, n, 5);
       const u32 grid2 = kMsdGroups * ((n / kMsdTile + nb1 + 1 + kMsdGroups - 1) / kMsdGroups);
@@ -572,8 +573,7 @@ static int msd_sort(dc3hip_ctx *c, Rec8 *ha, Rec8 *hb, u32 n, const HiMap &hm, c
   HIPC(hipStreamSynchronize(c->stream));
   const u32 maxsub = c->h_words[20 + kMsdW_MAXSUB];
   c->stats.msd_max_subbucket = maxsub;
-  *where = reinterpret_cast<Rec8 *>(const_cast<u64 *>(r.src));
-  if (maxsub > kMsdCapLarge) { c->stats.msd_fallbacks++; return E_OK; }
+  if (maxsub > kMsdCapLarge) { c->stats.msd_fallbacks++; return E_OK; }      // (d2 == 0: only `hb` was written)
   r.large = maxsub > kMsdCapSmall;
   r.shb = sh2 - std::min<u32>(r.large ? 12u : 10u, rb);
   if (split) {
@@ -1238,8 +1238,7 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
       Rec8 *where = ha;
       RC(msd_sort(c, ha, hb, nrec, hm, *mg, first_table, &sink, &h, &mredo, &msd_ok, &where, p1));
       if (msd_ok) lp.src = const_cast<u64 *>(mredo.src);               // (non-null = "the order lives in the sink")
-      else if (p1 && p1->strips()) { first_table = nullptr; RC(p1->repack(c, ha, nrec, &first_table)); }
-      else { if (where != ha) std::swap(ha, hb); first_table = nullptr; }
+      else { first_table = nullptr; if (p1) RC(p1->repack(c, ha, nrec, &first_table)); }      // from scratch: `ha` in position order
     }
     if (!msd_ok)
       RC(radix_sort<Rec8>(c, ha, hb, nrec, hm.pbits, hm.pbits + hm.nbits, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN,
@@ -1301,8 +1300,7 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
     if (mg && mg->on) {
       MsdRedo mredo; Rec8 *where = ha;
       RC(msd_sort(c, ha, hb, nrec, hm, *mg, first_table, nullptr, &h, &mredo, &msd_ok, &where, p1));
-      if (!msd_ok && p1 && p1->strips()) { first_table = nullptr; RC(p1->repack(c, ha, nrec, &first_table)); }
-      else if (!msd_ok) { if (where != ha) std::swap(ha, hb); first_table = nullptr; }
+      if (!msd_ok) { first_table = nullptr; if (p1) RC(p1->repack(c, ha, nrec, &first_table)); }
     }
     if (!msd_ok)
       RC(radix_sort<Rec8>(c, ha, hb, nrec, hm.pbits, hm.pbits + hm.nbits, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN,
@@ -2324,6 +2322,7 @@ static int build_end(dc3hip_ctx *c) {
       if (m.kclass == 3) { c->stats.partition_ms += t; c->stats.partition_launches += 1; c->stats.partition_elems += m.elems; }
       if (m.kclass == 5) { c->stats.msd_part_ms += t; c->stats.msd_part_launches += 1; c->stats.msd_part_elems += m.elems; }
       if (m.kclass == 6) { c->stats.msd_local_ms += t; c->stats.msd_local_launches += 1; c->stats.msd_local_elems += m.elems; }
+      if (m.kclass == 9) { c->stats.msd_part_keys_ms += t; c->stats.msd_part_keys_launches += 1; c->stats.msd_part_keys_elems += m.elems; }
       if (m.kclass == 7) { c->stats.ssort_part_ms += t; c->stats.ssort_part_launches += 1; c->stats.ssort_part_elems += m.elems; }
       if (m.kclass == 8) { c->stats.ssort_local_ms += t; c->stats.ssort_local_launches += 1; c->stats.ssort_local_elems += m.elems; }
       if (m.kclass >= 0 && m.kclass < 3) {

@@ -5,6 +5,7 @@
 #   guards; the kernel lab; the plain default bench line.
 # Usage: tools/final_profiles.sh TAG        (then, in the repo: python tools/pmc_to_json.py gpurun_out "" && ... "_recursion")
 tag=${1:-r03f}
+: "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}"
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out

@@ -1,6 +1,7 @@
 #!/bin/bash
 # GPU box: HBM traffic counters of the bench command, separate --pmc passes (FETCH_SIZE / WRITE_SIZE cannot share a pass)
 tag=${1:-}      # "" = default path; "_recursion" = with DC3HIP_NO_TEXT_SHORTCUT=1 exported by the caller
+: "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}"
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 for ctr in FETCH_SIZE WRITE_SIZE; do

@@ -1,5 +1,6 @@
 #!/bin/bash
 # GPU box: SQ (shader) PMC counters of the default bench build, per kernel, one small counter group per pass.
+: "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}"
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 i=0

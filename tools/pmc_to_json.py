@@ -25,8 +25,11 @@ if e[1]: res["bytes_per_record"]["downsweep_rec16"] = tot(lambda k: "k_rs_downsw
 if e[2]: res["bytes_per_record"]["downsweep_tup0"] = tot(lambda k: "k_rs_downsweep<dc3::Tup0" in k, 2) / e[2]
 if st["gather_elems"]: res["bytes_per_record"]["gather_tuples"] = tot(lambda k: "k_gather_tuples" in k, 1) / st["gather_elems"]
 if st["partition_elems"]: res["bytes_per_record"]["part_msd"] = tot(lambda k: "k_part_msd" in k or "k_tup_part" in k, 2) / st["partition_elems"]
-if st.get("msd_part_elems"): res["bytes_per_record"]["msd_part"] = tot(lambda k: "k_msd_part" in k, 2) / st["msd_part_elems"]
+if st.get("msd_part_elems"): res["bytes_per_record"]["msd_part"] = tot(lambda k: "k_msd_part<" in k, 2) / st["msd_part_elems"]
+if st.get("msd_part_keys_elems"): res["bytes_per_record"]["msd_part_keys"] = tot(lambda k: "k_msd_part_keys" in k or "k_wide_part1" in k, 2) / st["msd_part_keys_elems"]
 if st.get("msd_local_elems"): res["bytes_per_record"]["msd_local"] = tot(lambda k: "k_msd_local" in k, 2) / st["msd_local_elems"]
+if st.get("ssort_part_elems"): res["bytes_per_record"]["ssort_part"] = tot(lambda k: "k_ss_part" in k, 2) / st["ssort_part_elems"]
+if st.get("ssort_local_elems"): res["bytes_per_record"]["ssort_local"] = tot(lambda k: "k_ss_local" in k, 2) / st["ssort_local_elems"]
 for k in sorted(set(F) | set(W), key=lambda k: -(2 * F.get(k, 0) + W.get(k, 0))):
     res["per_kernel_bytes"][k] = {"fetch_raw": F.get(k, 0), "write": W.get(k, 0)}
 try:

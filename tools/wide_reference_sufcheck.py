@@ -1,13 +1,13 @@
 """GPU box: an INDEPENDENT verdict on a suffix array of more than 2^32 positions (BASELINE.json configs[3]'s size class).
 
 The wide global mode (64-bit positions) is checked at full size by the library's own collective verifier
-only.  Here the same build — 2^32 + 2^20 + 3 random bytes over two loopback ranks on this GPU, as in
+only.  Here the same build — 2^32 + 2^20 + 3 random bytes over two loopback ranks on this GPU (or the size / input kind / rank count given), as in
 tests/test_global_gpu.py::test_wide_mode_beyond_2pow32 — is fetched to host memory (text 4.3 GB + 34 GB of int64) and
 handed to the REFERENCE's sufcheck() compiled with 64-bit saidx_t (oracle/_ref/libdivsufsort64_ref.so,
 c-sources/utils.c:160-241: range, first-character order, then the psi-style "SA[C[T[SA[i]-1]]++] == SA[i]-1" scan).
 rc 0 means: this array is the suffix array of this text.  One JSON line (profiles/r03*_wide_reference_sufcheck64.json).
 
-    python tools/wide_reference_sufcheck.py [extra_bytes=1048579] [kind=0]"""
+    python tools/wide_reference_sufcheck.py [extra_bytes=1048579 | n >= 2^32] [kind=0] [ranks=2]"""
 import ctypes
 import json
 import os
@@ -19,18 +19,22 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import stringsearch_amd as ss  # noqa: E402
 
+# argument 1: the text length in bytes when it is at least 2^32, else the bytes beyond 2^32; argument 3: loopback ranks
+# (BASELINE.json configs[4]'s class — DNA, 8 ranks, 64-bit indices — as far as one GPU's 288 GB allow:
+#      python tools/wide_reference_sufcheck.py 6442450944 1 8)
 extra = int(sys.argv[1]) if len(sys.argv) > 1 else (1 << 20) + 3
 kind = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-seed = 6
-n = (1 << 32) + extra
+P = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+seed = 6 if kind == 0 else 5
+n = extra if extra >= (1 << 32) else (1 << 32) + extra
 path = os.path.join(ROOT, "oracle", "_ref", "libdivsufsort64_ref.so")
 ref = ctypes.CDLL(path)
 ref.sufcheck.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32]
 ref.sufcheck.restype = ctypes.c_int32
 
-out = {"n": n, "kind": kind, "seed": seed, "ranks": 2, "transport": "loopback (both ranks on one GPU)"}
+out = {"n": n, "kind": kind, "seed": seed, "ranks": P, "transport": "loopback (all ranks on one GPU)"}
 sa = np.zeros(n, dtype=np.int64)
-with ss.LoopbackGroup(2, n) as g:
+with ss.LoopbackGroup(P, n) as g:
     g.generate(n, seed, kind)
     g.build()
     t0 = time.time(); g.build(); out["build_wall_ms"] = round((time.time() - t0) * 1e3, 1)
@@ -45,6 +49,9 @@ with ss.LoopbackGroup(2, n) as g:
         nxt += cnt
     assert nxt == n
     out["shard_counts"] = [r.shard()[1] for r in g.ranks]
+    st = g.stats()
+    out["ordered_by"] = ["bucket ordering on 8-byte words" if x.get("wide_msd") else "LSD passes on 16-byte records" for x in st]
+    out["tied_records_per_rank"] = [x["ctx"]["level_tied"][0] for x in st]
 # the text, from the same device generator stream, in pieces a single context can hold
 text = np.zeros(n, dtype=np.uint8)
 piece = 1 << 30
