@@ -40,14 +40,14 @@ struct AccSplit {
   __device__ __forceinline__ u32 neq(u32 i) const { return f[i]; }
   __device__ __forceinline__ u32 tail_differs() const { return 1u; }
 };
-template <class KM>
-__global__ __launch_bounds__(kBlock) void k_split_flags(KM km, const u32 *__restrict__ img, const u32 *__restrict__ sa, u32 n,
+template <class KM, class Same>
+__global__ __launch_bounds__(kBlock) void k_split_flags(KM km, Same same, const u32 *__restrict__ sa, u32 n,
                                                        uint8_t *__restrict__ f) {
   __shared__ uint16_t lcode[256];
   km.stage(lcode);
   for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     bool ne = true;
-    if (i > 0 && img[i] == img[i - 1]) ne = km.cmp(sa[i - 1], sa[i], lcode) != 0;
+    if (same(i)) ne = km.cmp(sa[i - 1], sa[i], lcode) != 0;
     f[i] = ne ? 1 : 0;
   }
 }

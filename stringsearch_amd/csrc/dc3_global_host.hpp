@@ -302,7 +302,6 @@ struct HostComm : GComm {
 // one rank of a global build
 // ---------------------------------------------------------------------------------------------
 struct dc3hip_gctx {
-  int wide_route_min_p = 6;    // wide mode: fewest ranks for which the selection is routed (see gbuild_wide)
   bool no_wide_msd = false;    // DC3HIP_NO_WIDE_MSD=1: wide mode always sorts 16-byte records with the LSD passes
   u64 wide_msd_min = 1ull << 22; // DC3HIP_WIDE_MSD_MIN (tests): fewest positions per rank for the wide bucket ordering
   u32 w_depth = 0;             // wide mode: symbols the last tie pass of the last build compared (the verifier compares at least as deep)
@@ -1120,6 +1119,7 @@ static int glevel(dc3hip_gctx *G, Sym S, u32 m, u64 K, int depth, u32 *out, GOut
 
 // level 0 shortcut: the whole-text order by 9-symbol (Key9) or, on small alphabets, 3L-symbol windows (KeyT), split by
 // key range (conditions as in build_core; no reuse of the order when windows repeat: the recursion decides then)
+static int gorder_text_msd(dc3hip_gctx *G, u32 sigma, bool *done, bool *tried);     // (defined behind the wide mode's pieces)
 template <class KM>
 static int gtext_order_with(dc3hip_gctx *G, KM km, u64 BL, const HiMap &hm, u32 sigma, bool wide, bool *done) {
   dc3hip_ctx *c = G->c;
@@ -1142,12 +1142,16 @@ static int gtext_order_with(dc3hip_gctx *G, KM km, u64 BL, const HiMap &hm, u32 
     arena_release(c, mk);
     c->stats.level_tie_pred[0] = pred;
     if (!(pred < kTextSortMaxPredicted)) return E_OK;
-    RC((gorder_positions12<KM>(G, km, n, kbits, hm, done)));
+    bool tried = false;
+    RC(gorder_text_msd(G, sigma, done, &tried));
+    if (!tried) RC((gorder_positions12<KM>(G, km, n, kbits, hm, done)));
   } else {
     RC(predict_tie_fraction_pos<KM>(c, km, n, hm, &pred));
     c->stats.level_tie_pred[0] = pred;
     if (!text_order_worth_trying(pred, (u64)n, hm.nbits)) return E_OK;
-    RC((gorder_positions<KM>(G, km, n, kbits, hm, 0, nullptr, G_TOP, done)));
+    bool tried = false;
+    RC(gorder_text_msd(G, sigma, done, &tried));
+    if (!tried) RC((gorder_positions<KM>(G, km, n, kbits, hm, 0, nullptr, G_TOP, done)));
   }
   if (*done) {
     c->stats.text_sort_state = 1;
@@ -1194,7 +1198,7 @@ static int wide_key(dc3hip_gctx *G, u32 sigma, WideKey *k, u32 *ibits_out) {
   u32 J = 1; u64 SJ = sigma;
   while (J < kWideMaxImageSyms && (SJ >> std::min<u32>(ibits + 2, 62)) == 0 && SJ * sigma < (1ull << 63)) { SJ *= sigma; J++; }
   if ((SJ >> ibits) == 0) { set_err("wide global mode: alphabet of %u symbols cannot fill a %u-bit image", sigma, ibits); return E_TOOBIG; }
-  k->t = G->w_text; k->code = G->c->d_code; k->n = (u64)G->total_n; k->sigma = sigma; k->J = J; k->W = kWideWindow;
+  k->t = gtext(G); k->code = G->c->d_code; k->n = (u64)G->total_n; k->sigma = sigma; k->J = J; k->W = kWideWindow;
   k->mfix = (u64)(((((unsigned __int128)1) << (64 + ibits)) - 1) / SJ);
   k->P1 = SJ / sigma;
   *ibits_out = ibits;
@@ -1270,6 +1274,31 @@ struct WidePass1 : MsdPass1 {
   }
 };
 
+// this rank's image range [lo, hi) from a strided sample of the replicated text (every rank computes the same sorted
+// sample `img`; rank r takes the r-th P-quantile as its lower bound)
+static int wide_splitters(dc3hip_gctx *G, const WideKey &k, std::vector<u64> *img, u64 *lo, u64 *hi) {
+  dc3hip_ctx *c = G->c; GComm *cm = G->comm;
+  const int P = cm->nranks, me = cm->rank;
+  const u64 n = k.n;
+  const ArenaMark mk = arena_mark(c);
+  const u32 ns = (u32)std::min<u64>(n, (u64)4096 * P);
+  const u64 stride = std::max<u64>(1, n / ns);
+  const u32 cnt = (u32)((n - 1) / stride + 1);
+  u64 *d_img = nullptr;
+  RC(arena_alloc(c, (size_t)cnt, &d_img));
+  hipLaunchKernelGGL(k_wide_sample, dim3(grid_for(c, cnt)), dim3(kBlock), 0, c->stream, k, stride, cnt, d_img);
+  KCHECK();
+  img->resize(cnt);
+  HIPC(hipMemcpyAsync(img->data(), d_img, (size_t)cnt * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  arena_release(c, mk);
+  std::sort(img->begin(), img->end());
+  *lo = 0; *hi = ~0ull;
+  if (me > 0) *lo = (*img)[(size_t)((u64)me * cnt / P)];
+  if (me + 1 < P) *hi = (*img)[(size_t)((u64)(me + 1) * cnt / P)];
+  return E_OK;
+}
+
 // whether a wide build of n bytes over P ranks uses the bucket ordering on 8-byte words: the same answer on every rank
 static bool wide_msd_applies(const dc3hip_gctx *G, u64 n, int P, u32 ibits) {
   const u64 est = n / (u64)P;
@@ -1285,7 +1314,11 @@ static bool wide_msd_applies(const dc3hip_gctx *G, u64 n, int P, u32 ibits) {
 // pass over the text, partition pass 1 with selection, the 8-byte passes 2 and 3 of dc3_msd.hip.hpp, tie rounds.
 // *done = false: does not apply (switched off, too few positions, too few image bits) or a sub-bucket outgrew the local
 // sort — nothing was delivered and the caller runs the 16-byte LSD form.  *nrec_out = the rank's record count.
-static int wide_msd_order(dc3hip_gctx *G, const WideKey &k, u32 ibits, u64 lo, u64 hi, bool last, u32 *nrec_out, bool *done) {
+// OutT / bufs: where the words and the positions live — bufs(nrec, &wa, &wb, &out) hands out two arrays of nrec 8-byte words
+// and the array of nrec positions (wide contexts: their own device buffers, 64-bit positions; texts below 2^32: the arena
+// and the suffix-array buffer, 32-bit positions).
+template <class OutT, class Bufs>
+static int wide_msd_order(dc3hip_gctx *G, const WideKey &k, u32 ibits, u64 lo, u64 hi, bool last, u32 *nrec_out, bool *done, Bufs bufs) {
   dc3hip_ctx *c = G->c; GComm *cm = G->comm;
   const int P = cm->nranks;
   const u64 n = (u64)G->total_n;
@@ -1330,23 +1363,64 @@ static int wide_msd_order(dc3hip_gctx *G, const WideKey &k, u32 ibits, u64 lo, u
   const u32 nrec = (u32)nrec64;
   *nrec_out = nrec;
   if (nrec < 4096) { arena_release(c, mk); return E_OK; }
-  // two arrays of 8-byte words inside the record buffers, and the shard
-  RC(wide_ensure(c, &G->w_ra, &G->w_cap_a, (size_t)nrec / 2 + 16));
-  RC(wide_ensure(c, &G->w_rb, &G->w_cap_b, (size_t)nrec / 2 + 16));
-  RC(wide_ensure(c, &G->w_shard, &G->w_cap_s, (size_t)nrec + 16));
+  u64 *wa = nullptr, *wb = nullptr; OutT *shard = nullptr;
+  RC(bufs(nrec, &wa, &wb, &shard));
   MsdGeom g;
   g.on = true; g.d1 = d1; g.d2 = d2; g.cpg = p1.cpg; g.ck.nchunks = p1.nchunks; g.ck.chunk = 0; g.img_lo = 0; g.ebits = E;
   HiMap hm; hm.mfix = 0; hm.shx = 0; hm.pbits = pb; hm.nbits = E; hm.exact = 0;
   Rec8 *res = nullptr, *where = nullptr; MsdRedo redo; bool ok = false;
-  RC(msd_sort(c, reinterpret_cast<Rec8 *>(G->w_ra), reinterpret_cast<Rec8 *>(G->w_rb), nrec, hm, g, table, nullptr, &res, &redo, &ok, &where, &p1));
+  RC(msd_sort(c, reinterpret_cast<Rec8 *>(wa), reinterpret_cast<Rec8 *>(wb), nrec, hm, g, table, nullptr, &res, &redo, &ok, &where, &p1));
   if (!ok) { arena_release(c, mk); return E_OK; }
   const u64 *h = reinterpret_cast<const u64 *>(res);
   RC(wide_tie_rounds_with(G, nrec, k, [&](const WideKey &kk) {
-    hipLaunchKernelGGL(k_wide_ties8, dim3(grid_for(c, nrec)), dim3(kBlock), 0, c->stream, h, nrec, pb, kk, G->w_shard, c->d_words + 10);
+    hipLaunchKernelGGL((k_wide_ties8<OutT>), dim3(grid_for(c, nrec)), dim3(kBlock), 0, c->stream, h, nrec, pb, kk, shard, c->d_words + 10);
   }));
   arena_release(c, mk);
   G->gs.wide_msd = 1;
   *done = true;
+  return E_OK;
+}
+
+// The whole-text order of a text below 2^32 bytes in the form the wide contexts use (gbuild_wide / wide_msd_order): every
+// rank takes the images of its range straight from its replica of the text — counting pass, partition pass 1 with
+// selection, 8-byte passes 2 and 3, tie rounds with lazily compared windows — and nothing but the text blocks has crossed
+// the transport.  Replaces the routed order (pack own block, partition by owner, all-to-all of 8-byte records, count the
+// top digit again) where the bucket ordering applies: numbers in DESIGN.md §6.  *done = false: some rank's windows repeat (or the ordering does not apply): the caller goes on as before.
+static int gorder_text_msd(dc3hip_gctx *G, u32 sigma, bool *done, bool *tried) {
+  dc3hip_ctx *c = G->c; GComm *cm = G->comm;
+  const int P = cm->nranks, me = cm->rank;
+  const u64 n = (u64)G->total_n;
+  *done = false; *tried = false;
+  if (sigma < 2) return E_OK;
+  WideKey k; u32 ibits = 0;
+  { char keep[sizeof(g_err)]; snprintf(keep, sizeof(keep), "%s", g_err); if (wide_key(G, sigma, &k, &ibits) != E_OK) { set_err("%s", keep); return E_OK; } }
+  if (!wide_msd_applies(G, n, P, ibits)) return E_OK;
+  if ((double)k.W * log2((double)sigma) < 2.0 * log2((double)n) + 2.0) return E_OK;
+  *tried = true;
+  const ArenaMark mk = arena_mark(c);
+  u64 lo = 0, hi = ~0ull;
+  std::vector<u64> img;
+  RC(wide_splitters(G, k, &img, &lo, &hi));
+  u32 nrec = 0; bool ordered = false;
+  c->h_words[10] = c->h_words[11] = c->h_words[12] = 0;
+  const int rc = wide_msd_order<u32>(G, k, ibits, lo, hi, me + 1 == P, &nrec, &ordered, [&](u32 cnt, u64 **wa, u64 **wb, u32 **out) -> int {
+    RC(arena_alloc(c, (size_t)cnt + 16, wa));
+    RC(arena_alloc(c, (size_t)cnt + 16, wb));
+    *out = c->d_sa;
+    return E_OK;
+  });
+  if (rc != E_OK && rc != E_TOOBIG && rc != E_ALLOC) return rc;
+  const bool mine_ok = rc == E_OK && ordered && c->h_words[10] == 0 && c->h_words[12] == 0;
+  uint64_t good = 0, ngood = 0, pre = 0, tot = 0, all[kMaxRanks];
+  RC(gather_counts(cm, mine_ok ? 1 : 0, &good, &ngood));
+  RC(gather_counts(cm, mine_ok ? nrec : 0, &pre, &tot, all));
+  arena_release(c, mk);
+  if (ngood == (uint64_t)P) {
+    if (tot != n) { set_err("global order: %llu of %llu positions selected", (unsigned long long)tot, (unsigned long long)n); return E_HIP; }
+    c->stats.level_tied[0] = c->h_words[11];
+    *done = true;
+    RC(deliver(G, c->d_sa, nrec, pre, all, (u32)n, nullptr, G_TOP));
+  }
   return E_OK;
 }
 
@@ -1386,21 +1460,7 @@ static int gbuild_wide(dc3hip_gctx *G) {
   // splitters from a strided sample (every rank computes the same ones from the replicated text)
   u64 lo = 0, hi = ~0ull;
   std::vector<u64> img;
-  {
-    const u32 ns = (u32)std::min<u64>(n, (u64)4096 * P);
-    const u64 stride = std::max<u64>(1, n / ns);
-    const u32 cnt = (u32)((n - 1) / stride + 1);
-    u64 *d_img = nullptr;
-    RC(arena_alloc(c, (size_t)cnt, &d_img));
-    hipLaunchKernelGGL(k_wide_sample, dim3(grid_for(c, cnt)), dim3(kBlock), 0, c->stream, k, stride, cnt, d_img);
-    KCHECK();
-    img.resize(cnt);
-    HIPC(hipMemcpyAsync(img.data(), d_img, (size_t)cnt * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPC(hipStreamSynchronize(c->stream));
-    std::sort(img.begin(), img.end());
-    if (me > 0) lo = img[(size_t)((u64)me * cnt / P)];
-    if (me + 1 < P) hi = img[(size_t)((u64)(me + 1) * cnt / P)];
-  }
+  RC(wide_splitters(G, k, &img, &lo, &hi));
   // The selection, the sort and the tie pass of this rank.  A refusal that depends on the data and on the rank (its share
   // exceeds 2^32 - 2^24 suffixes, no device memory for the records) must not leave the other ranks waiting in the
   // collectives below: the status is agreed on there and every rank returns the same error.
@@ -1418,102 +1478,21 @@ static int gbuild_wide(dc3hip_gctx *G) {
     else set_err("wide global mode: another rank refused its share (%s)", rc_all == E_ALLOC ? "no device memory for its records" : "more ranks needed");
     return rc_all;
   };
-  // ROUTED selection (round 3, the wide counterpart of gorder_positions' routing): every rank packs the records of ITS
-  // block of positions only, partitions them by the top 8 image bits (rank h owns a contiguous digit range, balanced on the
-  // replicated sample) and sends every record to its owner — one all-to-all of 16-byte records, O(n / P) work per rank
-  // instead of two evaluations of all n positions.  Applicable when a block fits 32-bit record counts.
-  bool have_records = false;
-  // From 6 ranks on (DC3HIP_GLOBAL_WIDE_ROUTE_MIN_P): packing + partitioning + exchanging 16-byte records is a constant
-  // ≈ 100 ms of total work per 4.3 GB, two evaluations of all positions on every rank cost ≈ 19 ms per rank — measured as
-  // total work of P loopback ranks on one GPU: P = 2: 386 routed / 329 not, P = 4: 377 / 348, P = 8: 385 / 425 ms.
-  // (where the bucket ordering on 8-byte words applies — decided from n and P alone, alike on every rank — nothing is
-  //  routed: its pass 1 selects straight from the replicated text, and what it cannot order falls back to the unrouted
-  //  16-byte form on that rank alone, which needs no collective)
+  // (no record is routed between ranks: every rank selects straight from its replica of the text, so what one rank cannot
+  //  order by the bucket ordering it orders by the 16-byte LSD form on its own, and no collective sits in between)
   const bool msd_static = wide_msd_applies(G, n, P, ibits);
-  if (!msd_static && G->route && P >= G->wide_route_min_p && ibits >= 8 && n / (u64)P + 16 <= (u64)DC3HIP_MAX_N) {
-    u32 dlo[kMaxRanks + 1];
-    {
-      u32 cnt256[257] = {0};
-      for (u64 v : img) cnt256[(u32)((v >> (ibits - 8)) & 255u)]++;
-      const u64 ns = img.size();
-      dlo[0] = 0; dlo[P] = 256;
-      u64 acc = 0; u32 hnext = 1;
-      for (u32 d = 0; d < 256 && hnext < (u32)P; d++) {
-        while (hnext < (u32)P && acc * P >= (u64)hnext * ns) dlo[hnext++] = d;
-        acc += cnt256[d];
-      }
-      while (hnext < (u32)P) dlo[hnext++] = 256;
-      for (int r = 1; r <= P; r++) dlo[r] = std::max(dlo[r], dlo[r - 1]);
-    }
-    const u64 bbeg = (n * (u64)me / P) & ~3ull, bend = (me + 1 == P) ? n : ((n * (u64)(me + 1) / P) & ~3ull);
-    const u32 blen = (u32)(bend - bbeg);
-    u32 hdb[257];
-    for (u32 d = 0; d <= 256; d++) hdb[d] = 0;
-    const int rcA = [&]() -> int {
-      RC(wide_ensure(c, &G->w_ra, &G->w_cap_a, (size_t)blen + 16));
-      RC(wide_ensure(c, &G->w_rb, &G->w_cap_b, (size_t)blen + 16));
-      if (!blen) return E_OK;
-      {
-        PhaseScope ps(c, DC3HIP_PH_PACK, blen);
-        hipLaunchKernelGGL(k_wide_pack_range, dim3(grid_for(c, (u64)blen / 4 + 1)), dim3(kBlock), 0, c->stream, k, bbeg, blen, G->w_ra);
-        KCHECK();
-      }
-      constexpr int kTile = SortCfg<Rec16, 256>::NW * 64 * SortCfg<Rec16, 256>::IPT;
-      const Chunking ck = make_chunks(c, blen, kTile);
-      u32 *table = nullptr, *digit_base = nullptr;
-      RC(arena_alloc(c, (size_t)256 * ck.nchunks, &table));
-      RC(arena_alloc(c, (size_t)256, &digit_base));
-      KeyDig dig; dig.shift = ibits - 8; dig.mask = 255;
-      {
-        PhaseScope ps(c, DC3HIP_PH_PACK, blen);
-        hipLaunchKernelGGL((k_rs_upsweep<Rec16, 256>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, (const Rec16 *)G->w_ra, blen, ck.chunk, ck.nchunks, dig, table);
-        KCHECK();
-      }
-      RC(scan_digit_table(c, table, ck.nchunks, digit_base, 256, DC3HIP_PH_PACK));
-      std::vector<u32> tmp(256);
-      HIPC(hipMemcpyAsync(tmp.data(), digit_base, 256 * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
-      ArrayLoader<Rec16> ld; ld.p = G->w_ra;
-      RC((launch_downsweep<Rec16, 256, ArrayLoader<Rec16>>(c, ld, G->w_rb, blen, ck, dig, table, digit_base, DC3HIP_PH_PACK)));
-      HIPC(hipStreamSynchronize(c->stream));
-      for (u32 d = 0; d < 256; d++) hdb[d] = tmp[d];
-      hdb[256] = blen;
-      return E_OK;
-    }();
-    if (rcA != E_OK && rcA != E_TOOBIG && rcA != E_ALLOC) return rcA;
-    RC(agree(rcA));
-    size_t soff[kMaxRanks], sbytes[kMaxRanks], roff[kMaxRanks], rbytes[kMaxRanks];
-    uint64_t scount[kMaxRanks], mat[kMaxRanks * kMaxRanks];
-    for (int r = 0; r < P; r++) {
-      const u32 a0 = hdb[dlo[r]], b0 = hdb[dlo[r + 1]];
-      soff[r] = (size_t)a0 * sizeof(Rec16); sbytes[r] = (size_t)(b0 - a0) * sizeof(Rec16); scount[r] = b0 - a0;
-    }
-    RC(cm->all_gather_host(scount, mat, sizeof(uint64_t) * (size_t)P));
-    u64 got = 0;
-    for (int r = 0; r < P; r++) { roff[r] = (size_t)got * sizeof(Rec16); rbytes[r] = (size_t)mat[(size_t)r * P + me] * sizeof(Rec16); got += mat[(size_t)r * P + me]; }
-    const int rcB = [&]() -> int {
-      if (got > (u64)DC3HIP_MAX_N) { set_err("wide global mode: rank %d would hold %llu suffixes (more ranks needed)", me, (unsigned long long)got); return E_TOOBIG; }
-      RC(wide_ensure(c, &G->w_ra, &G->w_cap_a, (size_t)got + 16));     // (its packed records are dead: they went to w_rb)
-      RC(wide_ensure(c, &G->w_shard, &G->w_cap_s, (size_t)got + 16));
-      return E_OK;
-    }();
-    if (rcB != E_OK && rcB != E_TOOBIG && rcB != E_ALLOC) return rcB;
-    RC(agree(rcB));
-    RC(cm->all_to_all_v(G->w_rb, soff, sbytes, G->w_ra, roff, rbytes, c->stream));   // (the packed records of w_ra are dead)
-    G->gs.exchanges += 1;
-    nrec = (u32)got;
-    have_records = true;
-  }
   const int local_rc = [&]() -> int {
-    if (have_records) {
-      RC(wide_ensure(c, &G->w_rb, &G->w_cap_b, (size_t)nrec + 16));    // (what it sent is gone: now the sort's second buffer)
-      Rec16 *h = G->w_ra;
-      if (nrec) RC(radix_sort<Rec16>(c, G->w_ra, G->w_rb, nrec, 0, ibits, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT12_DOWN));
-      return wide_tie_rounds(G, h, nrec, k);
-    }
     // bucket ordering on 8-byte words where it applies (the 16-byte LSD form below otherwise)
     if (msd_static) {
       bool msd_done = false;
-      RC(wide_msd_order(G, k, ibits, lo, hi, me + 1 == P, &nrec, &msd_done));
+      // (two arrays of 8-byte words inside the record buffers, and the shard)
+      RC((wide_msd_order<u64>(G, k, ibits, lo, hi, me + 1 == P, &nrec, &msd_done, [&](u32 cnt, u64 **wa, u64 **wb, u64 **out) -> int {
+        RC(wide_ensure(c, &G->w_ra, &G->w_cap_a, (size_t)cnt / 2 + 16));
+        RC(wide_ensure(c, &G->w_rb, &G->w_cap_b, (size_t)cnt / 2 + 16));
+        RC(wide_ensure(c, &G->w_shard, &G->w_cap_s, (size_t)cnt + 16));
+        *wa = reinterpret_cast<u64 *>(G->w_ra); *wb = reinterpret_cast<u64 *>(G->w_rb); *out = G->w_shard;
+        return E_OK;
+      })));
       if (msd_done) return E_OK;
     }
     // count, allocate, write
@@ -1648,7 +1627,6 @@ static void gctx_env(dc3hip_gctx *G) {
   if (const char *e = getenv("DC3HIP_GLOBAL_NO_TEXT_ORDER")) G->no_text_order = e[0] == '1';
   if (const char *e = getenv("DC3HIP_GLOBAL_FORCE_DIST")) G->force_dist = e[0] == '1';
   if (const char *e = getenv("DC3HIP_GLOBAL_NO_ROUTE")) G->route = e[0] != '1';
-  if (const char *e = getenv("DC3HIP_GLOBAL_WIDE_ROUTE_MIN_P")) G->wide_route_min_p = std::max(1, atoi(e));
   if (const char *e = getenv("DC3HIP_NO_WIDE_MSD")) G->no_wide_msd = e[0] == '1';
   if (const char *e = getenv("DC3HIP_WIDE_MSD_MIN")) { const long long v = atoll(e); if (v >= 0) G->wide_msd_min = (u64)v; }
 }

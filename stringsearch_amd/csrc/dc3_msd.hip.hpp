@@ -375,15 +375,24 @@ __global__ __launch_bounds__(1024) void k_msd_scan2c(u32 *__restrict__ cnt, u32 
 }
 
 // Sinks of the local sort: where word x of global output index g goes (cf. RecSink / SplitSink of the LSD passes).
+// kSame: the sink also wants to know whether the word's image equals its predecessor's in the sorted order (= some
+// smaller word of its bin has the same image: equal images share every image bit, hence the sub-bucket and the bin).
 struct MsdRecSink {
   u64 *p;
-  __device__ __forceinline__ void store(u32 g, u64 x) const { p[g] = msd_word(x); }
+  static constexpr bool kSame = false;
+  __device__ __forceinline__ bool same_image(u64, u64) const { return false; }
+  __device__ __forceinline__ void store(u32 g, u64 x, bool) const { p[g] = msd_word(x); }
 };
+// positions to the suffix-array buffer + ONE BYTE per word for the tie pass: 1 = same image as the word before it.  (The
+// LSD passes' SplitSink leaves 32 image bits instead, which the tie pass compares itself: 8 bytes per word written and 4
+// read back, against 5 and 1 here.)
 struct MsdSplitSink {
-  u32 *sa, *img; u32 pbits;
-  __device__ __forceinline__ void store(u32 g, u64 x) const {
+  u32 *sa; uint8_t *same; u32 pbits;
+  static constexpr bool kSame = true;
+  __device__ __forceinline__ bool same_image(u64 a, u64 b) const { return ((a ^ b) >> pbits) == 0; }
+  __device__ __forceinline__ void store(u32 g, u64 x, bool sm) const {
     sa[g] = (u32)(x & ((1ull << pbits) - 1ull));
-    img[g] = (u32)(x >> pbits);
+    same[g] = sm ? 1 : 0;
   }
 };
 
@@ -442,9 +451,13 @@ __global__ __launch_bounds__(NT) void k_msd_local(const u64 *__restrict__ in, co
     const u64 x = srec[q];
     const u32 bin = (u32)((x - base) >> shb) & (NBIN - 1);
     const u32 lo = cnt[bin], hi = cnt[bin + 1];
-    u32 less = 0;
-    for (u32 j = lo; j < hi; j++) less += srec[j] < x ? 1u : 0u;
-    out.store(begin + lo + less, x);
+    u32 less = 0, eql = 0;
+    for (u32 j = lo; j < hi; j++) {
+      const u64 w = srec[j];
+      less += w < x ? 1u : 0u;
+      if (Sink::kSame) eql += (w < x && out.same_image(w, x)) ? 1u : 0u;
+    }
+    out.store(begin + lo + less, x, eql != 0);
   }
 }
 

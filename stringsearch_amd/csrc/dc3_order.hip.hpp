@@ -564,6 +564,13 @@ __device__ __forceinline__ void images4(const KeyT &km, const HiMap &hm, u64 P1,
     if (j < 3) v = (v - (u64)dh[j] * P1) * sigma + (j == 0 ? dt0 : j == 1 ? dt1 : dt2);
   }
 }
+// Key3 over a level's names: the six symbols p0 .. p0+5 loaded once (the string has >= 8 zero words behind its end)
+__device__ __forceinline__ void images4(const Key3<SymU32> &km, const HiMap &hm, u64, u32 p0, u32 n, const uint16_t *, u64 img[4]) {
+  u32 q[6];
+  __builtin_memcpy(q, km.S.s + p0, 24);
+#pragma unroll
+  for (int j = 0; j < 4; j++) img[j] = p0 + j < n ? hyb_hi(make_rec(q[j], q[j + 1], q[j + 2], km.B, 0u), hm) : 0ull;
+}
 // any other key maker: position by position
 template <class KM>
 __device__ __forceinline__ void images4(const KM &km, const HiMap &hm, u64, u32 p0, u32 n, const uint16_t *lcode, u64 img[4]) {
@@ -1092,8 +1099,18 @@ __global__ __launch_bounds__(kBlock) void k_tie_resolve(KM km, Rec8 *__restrict_
 // k_tie_resolve, 4 bytes per record to read and nothing to write but the members of tied groups.  (Two neighbours
 // whose images differ only above bit 31 look tied here; ordering them by the full key leaves them as they are.)
 // words as for k_tie_resolve.
-template <class KM>
-__global__ __launch_bounds__(kBlock) void k_tie_resolve_split(KM km, const u32 *__restrict__ img, u32 *__restrict__ sa,
+// Same = how the pass learns that record i has the image of record i - 1: SameImg compares the 32 image bits the LSD
+// passes' SplitSink left, SameFlag reads the byte the bucket ordering's local sort left (1 byte per record instead of 4).
+struct SameImg {
+  const u32 *img;
+  __device__ __forceinline__ bool operator()(u32 i) const { return i > 0 && img[i] == img[i - 1]; }
+};
+struct SameFlag {
+  const uint8_t *f;
+  __device__ __forceinline__ bool operator()(u32 i) const { return f[i] != 0; }
+};
+template <class KM, class Same>
+__global__ __launch_bounds__(kBlock) void k_tie_resolve_split(KM km, Same same, u32 *__restrict__ sa,
                                                              u32 n, u32 *words) {
   // Group starts are sparse (3 % of the records on random input): a block keeps collecting them tile after tile and
   // works the list only in full batches of kBlock groups (one per lane), so that every wave has 64 dependent gathers
@@ -1112,9 +1129,8 @@ __global__ __launch_bounds__(kBlock) void k_tie_resolve_split(KM km, const u32 *
     for (u32 j = 0; j < kIPT; j++) {
       const u32 i = tile * kTile + j * kBlock + threadIdx.x;
       if (i < n) {
-        const u32 a = img[i];
-        const bool eqp = i > 0 && img[i - 1] == a;
-        const bool eqn = i + 1 < n && img[i + 1] == a;
+        const bool eqp = same(i);
+        const bool eqn = i + 1 < n && same(i + 1);
         if (eqn && !eqp) starts[atomicAdd(&nstart, 1u)] = i;
         if (eqn || eqp) tied++;
       }
@@ -1131,9 +1147,8 @@ __global__ __launch_bounds__(kBlock) void k_tie_resolve_split(KM km, const u32 *
       const u32 base = ns > kBlock ? ns - kBlock : 0;
       if (base + threadIdx.x < ns) {
         const u32 i = starts[base + threadIdx.x];
-        const u32 a = img[i];
         u32 e = i + 2;
-        while (e < n && e - i <= kTieSmallMax && img[e] == a) e++;
+        while (e < n && e - i <= kTieSmallMax && same(e)) e++;
         const u32 len = e - i;
         if (len > kTieSmallMax) {
           words[0] = 1u;

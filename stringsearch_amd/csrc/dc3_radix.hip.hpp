@@ -88,6 +88,8 @@ struct RecSink {
 };
 struct SplitSink {
   u32 *sa, *img; u32 pbits;
+  uint8_t *same = nullptr;     // (not written by the LSD passes: the bucket ordering's local sort leaves "same image as the
+                               //  record before" bytes here instead of the image array, see MsdSplitSink)
   __device__ __forceinline__ void store(u32 g, const Rec8 &x) const {
     const u64 w = rec8_word(x);
     sa[g] = (u32)(w & ((1ull << pbits) - 1ull));

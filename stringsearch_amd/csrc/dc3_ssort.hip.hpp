@@ -479,12 +479,13 @@ __global__ __launch_bounds__(NT) void k_ss_local(const Rec *__restrict__ in, con
     const u32 bb = binid[q];
     const u32 lo = cex[bb], hi = cex[bb + 1];
     u32 less = 0;
-    for (u32 j0 = lo; j0 < hi; j0 += 8) {                                  // (8 independent reads per round)
-      SsVal w[8];
+    // (4 independent reads per round: bins hold about 11 records — rounds of 8 read 16 for them, rounds of 4 read 12)
+    for (u32 j0 = lo; j0 < hi; j0 += 4) {
+      SsVal w[4];
 #pragma unroll
-      for (int i = 0; i < 8; i++) w[i] = ss_val(A[min(j0 + (u32)i, hi - 1u)]);
+      for (int i = 0; i < 4; i++) w[i] = ss_val(A[min(j0 + (u32)i, hi - 1u)]);
 #pragma unroll
-      for (int i = 0; i < 8; i++) less += (j0 + (u32)i < hi && ss_lt(w[i], v)) ? 1u : 0u;
+      for (int i = 0; i < 4; i++) less += (j0 + (u32)i < hi && ss_lt(w[i], v)) ? 1u : 0u;
     }
     out[begin + lo + less] = x;
   }

@@ -105,44 +105,6 @@ __global__ __launch_bounds__(kBlock) void k_wide_select(WideKey k, u64 chunk, u6
   }
 }
 
-// Records of the positions [begin, begin + len) (begin % 4 == 0), in position order: what a rank packs of ITS block before
-// the records are routed to the owners of their image ranges (the routed form of the selection above).
-__global__ __launch_bounds__(kBlock) void k_wide_pack_range(WideKey k, u64 begin, u32 len, Rec16 *__restrict__ out) {
-  __shared__ uint16_t lcode[256];
-  if (threadIdx.x < 256) lcode[threadIdx.x] = k.code[threadIdx.x];
-  __syncthreads();
-  const u32 J = k.J, sigma = k.sigma, nw = (J + 3 + 3) / 4;
-  constexpr u32 kW = (kWideMaxImageSyms + 3 + 3) / 4;
-  for (u64 i0 = 4ull * (blockIdx.x * (u64)kBlock + threadIdx.x); i0 < len; i0 += 4ull * gridDim.x * kBlock) {
-    const u64 p0 = begin + i0;
-    const u32 *tw = reinterpret_cast<const u32 *>(k.t + p0);
-    u32 w[kW];
-#pragma unroll
-    for (u32 i = 0; i < kW; i++) w[i] = i < nw ? tw[i] : 0u;
-    u64 v = 0;
-    u32 dh[3] = {0, 0, 0}, dt0 = 0, dt1 = 0, dt2 = 0;
-#pragma unroll
-    for (u32 s = 0; s < kWideMaxImageSyms + 3; s++) {
-      if (s < J + 3) {
-        u32 q = (p0 + s < k.n) ? (u32)lcode[(w[s >> 2] >> (8 * (s & 3u))) & 255u] : 0u;
-        q = q ? q - 1 : 0u;
-        if (s < 3) dh[s] = q;
-        if (s < J) v = v * sigma + q;
-        else if (s == J) dt0 = q;
-        else if (s == J + 1) dt1 = q;
-        else dt2 = q;
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const u64 img = __umul64hi(v, k.mfix);
-      const u64 p = p0 + j;
-      if (i0 + j < len) out[i0 + j] = Rec16{(u32)img, (u32)(img >> 32), (u32)(p >> 32), (u32)p};
-      if (j < 3) v = (v - (u64)dh[j] * k.P1) * sigma + (j == 0 ? dt0 : j == 1 ? dt1 : dt2);
-    }
-  }
-}
-
 // Order (< 0, 0, > 0) of the windows of positions p and q, up to `depth` symbols (multiple of 4): a word at a time, only a
 // differing (or end-crossing) word is decoded; a suffix that ends sorts before its extensions.
 __device__ __forceinline__ int wide_cmp(const WideKey &k, u64 p, u64 q, u32 depth, const uint16_t *lds) {

@@ -194,7 +194,9 @@ __global__ __launch_bounds__(kWideNT) void k_wide_part1(WideKey k, WideRange rg,
 // Tie pass over a rank's words in ascending order (x' rest, position): shard[i] = position of the i-th smallest window.
 // Words whose image part agrees with a neighbour's are ordered by their windows, one thread per group — k_wide_ties on
 // 8-byte words.  words[0] = a group larger than kWideTieBig, words[1] += tied words, words[2] += windows equal within k.W.
-__global__ __launch_bounds__(kBlock) void k_wide_ties8(const u64 *__restrict__ h, u32 nrec, u32 pb, WideKey k, u64 *__restrict__ shard,
+// OutT: 64-bit positions (wide contexts) or 32-bit ones (the same order for texts below 2^32, whose slices are u32).
+template <class OutT>
+__global__ __launch_bounds__(kBlock) void k_wide_ties8(const u64 *__restrict__ h, u32 nrec, u32 pb, WideKey k, OutT *__restrict__ shard,
                                                       u32 *words) {
   __shared__ uint16_t lcode[256];
   if (threadIdx.x < 256) lcode[threadIdx.x] = k.code[threadIdx.x];
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(kBlock) void k_wide_ties8(const u64 *__restrict__ h
     const u64 a = w >> pb;
     const bool eqp = i > 0 && (msd_word(h[i - 1]) >> pb) == a;
     const bool eqn = i + 1 < nrec && (msd_word(h[i + 1]) >> pb) == a;
-    if (!eqp && !eqn) { shard[i] = w & pmask; continue; }
+    if (!eqp && !eqn) { shard[i] = (OutT)(w & pmask); continue; }
     tied++;
     if (eqp) continue;                                   // the group's first thread does the work
     u32 e = i + 2;
@@ -224,9 +226,9 @@ __global__ __launch_bounds__(kBlock) void k_wide_ties8(const u64 *__restrict__ h
           const int c = wide_cmp(k, v, prev, k.W, lcode);
           if (c == 0) dup++;
           if (c >= 0) break;
-          shard[i + y] = prev; y--;
+          shard[i + y] = (OutT)prev; y--;
         }
-        shard[i + y] = v;
+        shard[i + y] = (OutT)v;
       }
       continue;
     }
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(kBlock) void k_wide_ties8(const u64 *__restrict__ h
       }
       loc[y] = v;
     }
-    for (u32 x = 0; x < len; x++) shard[i + x] = loc[x];
+    for (u32 x = 0; x < len; x++) shard[i + x] = (OutT)loc[x];
   }
   tied = wave_reduce(tied); dup = wave_reduce(dup);
   if (lane_id() == 0) { if (tied) atomicAdd(&words[1], tied); if (dup) atomicAdd(&words[2], dup); }

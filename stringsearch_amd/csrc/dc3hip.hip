@@ -75,6 +75,7 @@ struct dc3hip_ctx {
   unsigned char *arena = nullptr;
   size_t arena_bytes = 0, arena_off = 0, arena_peak = 0;
   bool arena_fixed = false;    // DC3HIP_ARENA_BYTES given: never grown
+  bool arena_borrowed = false; // the arena belongs to another context (ctx_create_impl): never grown, never freed here
   bool arena_exhausted = false; // the last E_ALLOC came from the bump allocator (not from hipMalloc)
   // small device scratch
   u32 *d_present = nullptr;    // [256]
@@ -93,7 +94,7 @@ struct dc3hip_ctx {
   bool no_doubling = false;    // DC3HIP_NO_DOUBLING=1: repeated windows always hand the whole-text order to level 1
   int text_order12 = -1;       // DC3HIP_TEXT_ORDER12=1/0: whole-text shortcut on 12-byte records always / never (default: n > 2^31)
   double hybrid_max_pred = 0.50;                      // 8-byte prefix sort of a level's samples: taken below this predicted tied fraction
-  double hybrid12_max_pred = kHybrid12MaxPredicted;   // DC3HIP_HYBRID12_MAX_PRED (tuning)
+  double hybrid12_max_pred = kHybrid12MaxPredicted;   // 12-byte prefix sort: taken below this predicted tied fraction
   u32 hybrid12_min = 1u << 22; // DC3HIP_HYBRID12_MIN: smallest level (samples) that tries it (tests lower it)
   bool no_hybrid8 = false;     // DC3HIP_NO_HYBRID8=1 (tests): skip the 8-byte prefix sort / whole-level order of a level
   bool no_hybrid12 = false;    // DC3HIP_NO_HYBRID12=1: no 63-bit-prefix sort on 12-byte records for keys wider than 64 bits
@@ -104,8 +105,8 @@ struct dc3hip_ctx {
   bool pack_fuse = true;       // DC3HIP_PACK_FUSE=0: whole-text order of bytes with a pack kernel that WRITES the words (default: it only counts, partition pass 1 makes them on the fly)
   bool no_pack_strip = false;  // DC3HIP_NO_PACK_STRIP=1: ... from an image no wider than the word (default: d1 bits wider, the bucket's own bits dropped)
   bool no_msd = false;         // DC3HIP_NO_MSD=1: the prefix sorts always run the stable LSD passes (no bucket ordering)
-  u32 ssort_over = 24;         // DC3HIP_SSORT_OVER: sample values per sub-bucket
-  u32 ssort_mean = 1400;       // DC3HIP_SSORT_MEAN: records per sub-bucket the splitter ordering aims at (capacity 4096)
+  u32 ssort_over = 24;         // splitter ordering: sample values per sub-bucket
+  u32 ssort_mean = 1400;       // splitter ordering: records per sub-bucket it aims at (capacity 4096)
   bool no_wide_window = false; // DC3HIP_NO_WIDE_WINDOW=1: straight orderings always sort the triple (no wider window)
   bool ssort_rec12 = false;    // DC3HIP_SSORT_REC12=1: the splitter ordering also for keys of at most 64 bits (tests)
   bool no_pack_count = false;  // DC3HIP_NO_PACK_COUNT=1: the wide-window records are packed by their own kernel, then counted
@@ -577,7 +578,7 @@ static int msd_sort(dc3hip_ctx *c, Rec8 *ha, Rec8 *hb, u32 n, const HiMap &hm, c
   r.large = maxsub > kMsdCapSmall;
   r.shb = sh2 - std::min<u32>(r.large ? 12u : 10u, rb);
   if (split) {
-    MsdSplitSink sk; sk.sa = split->sa; sk.img = split->img; sk.pbits = split->pbits;
+    MsdSplitSink sk; sk.sa = split->sa; sk.same = split->same; sk.pbits = split->pbits;
     RC(msd_launch_local(c, r, n, sk));
   } else {
     MsdRecSink sk; sk.p = r.dst;
@@ -1229,9 +1230,13 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
   if (emit_sa && emitted_distinct && skip == 0 && !c->no_small_ties && !c->no_split_emit && hm.pbits < 32) {
     // optimistic end of the whole-text order: the last pass writes positions to the SA buffer and 32 image bits to a
     // side array; the tie pass settles the tied groups in place.  Complete unless a key repeats or a group is large.
+    // (what the tie pass reads: a "same image as the record before" byte from the bucket ordering, or the 32 image bits
+    //  the LSD passes leave when that ordering does not apply or gave up; the image array is only touched in that case)
     u32 *img = nullptr;
+    uint8_t *same = nullptr;
     RC(arena_alloc(c, (size_t)nrec + 16, &img));
-    SplitSink sink; sink.sa = emit_sa; sink.img = img; sink.pbits = hm.pbits;
+    RC(arena_alloc(c, (size_t)nrec + 16, &same));
+    SplitSink sink; sink.sa = emit_sa; sink.img = img; sink.same = same; sink.pbits = hm.pbits;
     LastPass lp;
     MsdRedo mredo; bool msd_ok = false;
     if (mg && mg->on) {
@@ -1247,8 +1252,12 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
       {
         PhaseScope ps(c, DC3HIP_PH_TIES, nrec);
         HIPC(hipMemsetAsync(c->d_words + 10, 0, 3 * sizeof(u32), c->stream));
-        hipLaunchKernelGGL((k_tie_resolve_split<KM>), dim3(grid_for(c, nrec / 4 + 1)), dim3(kBlock), 0, c->stream, km,
-                           (const u32 *)img, emit_sa, nrec, c->d_words + 10);
+        if (msd_ok)
+          hipLaunchKernelGGL((k_tie_resolve_split<KM, SameFlag>), dim3(grid_for(c, nrec / 4 + 1)), dim3(kBlock), 0, c->stream, km,
+                             SameFlag{same}, emit_sa, nrec, c->d_words + 10);
+        else
+          hipLaunchKernelGGL((k_tie_resolve_split<KM, SameImg>), dim3(grid_for(c, nrec / 4 + 1)), dim3(kBlock), 0, c->stream, km,
+                             SameImg{img}, emit_sa, nrec, c->d_words + 10);
         KCHECK();
         HIPC(hipMemcpyAsync(c->h_words + 10, c->d_words + 10, 3 * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
       }
@@ -1265,8 +1274,12 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
           {
             PhaseScope ps(c, DC3HIP_PH_TIES, nrec);
             HIPC(hipMemsetAsync(c->d_words + 10, 0, 3 * sizeof(u32), c->stream));
-            hipLaunchKernelGGL((k_tie_resolve_split<KM>), dim3(grid_for(c, nrec / 4 + 1)), dim3(kBlock), 0, c->stream, kd,
-                               (const u32 *)img, emit_sa, nrec, c->d_words + 10);
+            if (msd_ok)
+              hipLaunchKernelGGL((k_tie_resolve_split<KM, SameFlag>), dim3(grid_for(c, nrec / 4 + 1)), dim3(kBlock), 0, c->stream, kd,
+                                 SameFlag{same}, emit_sa, nrec, c->d_words + 10);
+            else
+              hipLaunchKernelGGL((k_tie_resolve_split<KM, SameImg>), dim3(grid_for(c, nrec / 4 + 1)), dim3(kBlock), 0, c->stream, kd,
+                                 SameImg{img}, emit_sa, nrec, c->d_words + 10);
             KCHECK();
             HIPC(hipMemcpyAsync(c->h_words + 10, c->d_words + 10, 3 * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
           }
@@ -1278,8 +1291,12 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
         if (whole_text && c->h_words[10] == 0 && c->h_words[12] <= nrec / 128 && !c->no_doubling && depth == 0) {
           {
             PhaseScope ps(c, DC3HIP_PH_TIES, nrec);
-            hipLaunchKernelGGL((k_split_flags<KM>), dim3(grid_for(c, nrec)), dim3(kBlock), 0, c->stream, km, (const u32 *)img,
-                               (const u32 *)emit_sa, nrec, f);
+            if (msd_ok)
+              hipLaunchKernelGGL((k_split_flags<KM, SameFlag>), dim3(grid_for(c, nrec)), dim3(kBlock), 0, c->stream, km, SameFlag{same},
+                                 (const u32 *)emit_sa, nrec, f);
+            else
+              hipLaunchKernelGGL((k_split_flags<KM, SameImg>), dim3(grid_for(c, nrec)), dim3(kBlock), 0, c->stream, km, SameImg{img},
+                                 (const u32 *)emit_sa, nrec, f);
             KCHECK();
           }
           // (the doubling reads the order from the very buffer whose tied slots it rewrites: a slot of a tied group always
@@ -1824,15 +1841,20 @@ static int order_all_positions(dc3hip_ctx *c, KM km, Map mp, u32 m, u32 kbits, c
   // 3.7 -> 4.4 ms (it becomes VALU-bound: 9 bytes moved per word instead of 16, but the key arithmetic on top of the
   // ranking), build 20.4 -> 19.5 ms; DNA (KeyT): the rolling image inside the partition pass costs more than the bytes
   // save, 22.8 -> 27.9 ms.  A 5 % gain on one input class against a second variant of the dominant kernel: off by default.
-  const bool fuse = mg.on && c->pack_fuse && std::is_same<KM, Key9>::value;
+  // (byte windows at level 0, name triples at the levels below; the small-alphabet windows KeyT keep a pack kernel
+  //  that writes: their rolling image inside the partition pass was measured slower, 22.8 -> 27.9 ms at 1 GiB DNA)
+  constexpr bool kFusable = std::is_same<KM, Key9>::value || std::is_same<KM, Key3<SymU32>>::value;
+  const bool fuse = mg.on && c->pack_fuse && kFusable;
   MsdPass1Keys<KM> p1; p1.km = km; p1.hm = hm; p1.P1 = pass1_p1<KM>(km);
   MsdGeom mgx = mg;
-  if constexpr (std::is_same<KM, Key9>::value) {
+  if constexpr (kFusable) {
     // ... and since the words are made inside pass 1, they can come from an image d1 bits wider than a word has room
     // for (k_msd_part_keys<.., true>): the tie pass then finds next to nothing tied
     if (fuse && !c->no_pack_strip && hm.pbits >= 23 && !hm.exact && kbits >= hm.nbits + mg.d1) {
+      u64 limb = 0;                                  // base of the key's three limbs (make_himap's B)
+      if constexpr (std::is_same<KM, Key9>::value) limb = km.B3; else limb = km.B;
       p1.strip = true; p1.hm_plain = hm;
-      p1.hm = make_himap(km.B3, kbits, m, hm.pbits - mg.d1);
+      p1.hm = make_himap(limb, kbits, m, hm.pbits - mg.d1);
       mgx.ebits = p1.hm.nbits;                       // (= hm.nbits + d1: the shifts of passes 2 and 3 follow from it)
     }
   }
@@ -2610,7 +2632,11 @@ int32_t dc3hip_device_count(void) {
   return n;
 }
 
-int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) {
+static int ctx_create_impl(dc3hip_ctx **out, int32_t device, int64_t max_n, dc3hip_ctx *arena_from);
+int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) { return ctx_create_impl(out, device, max_n, nullptr); }
+// arena_from != nullptr: the new context works in that context's arena instead of allocating its own (the lender must not
+// build meanwhile; dc3hip_ctx_build_partitions: the partitions are built one after the other in the parent's arena)
+static int ctx_create_impl(dc3hip_ctx **out, int32_t device, int64_t max_n, dc3hip_ctx *arena_from) {
   if (!out || max_n < 0) { set_err("dc3hip_ctx_create: invalid arguments"); return E_ARGS; }
   *out = nullptr;
   if (max_n > DC3HIP_MAX_N) { set_err("n=%lld exceeds DC3HIP_MAX_N", (long long)max_n); return E_TOOBIG; }
@@ -2649,13 +2675,10 @@ int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) {
   { const char *e = getenv("DC3HIP_NO_PACK_COUNT"); c->no_pack_count = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_SSORT_REC12"); c->ssort_rec12 = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_WIDE_WINDOW"); c->no_wide_window = (e && e[0] == '1'); }
-  { const char *e = getenv("DC3HIP_SSORT_OVER"); if (e) c->ssort_over = (u32)std::min(64ll, std::max(4ll, atoll(e))); }
-  { const char *e = getenv("DC3HIP_SSORT_MEAN"); if (e) c->ssort_mean = (u32)std::min(2000ll, std::max(300ll, atoll(e))); }
   { const char *e = getenv("DC3HIP_SSORT_MIN"); if (e) c->ssort_min = (u32)std::max(8192ll, atoll(e)); }
   { const char *e = getenv("DC3HIP_NO_HYBRID12"); c->no_hybrid12 = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_HYBRID8"); c->no_hybrid8 = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_HYBRID12_MIN"); if (e) c->hybrid12_min = (u32)std::max(0ll, atoll(e)); }
-  { const char *e = getenv("DC3HIP_HYBRID12_MAX_PRED"); if (e) c->hybrid12_max_pred = atof(e); }
   const char *nts = getenv("DC3HIP_NO_TEXT_SHORTCUT");
   c->no_text_shortcut = (nts && nts[0] == '1');
   const char *nf = getenv("DC3HIP_NO_FULLSORT");
@@ -2678,7 +2701,11 @@ int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) {
     // testing aid: DC3HIP_ARENA_BYTES=<bytes> replaces the computed size (a build then either fits — possibly through
     // a fallback ordering — or fails loudly with -2; it never returns a wrong array)
     if (const char *e = getenv("DC3HIP_ARENA_BYTES")) { const long long v = atoll(e); if (v > 0) { c->arena_bytes = (size_t)v; c->arena_fixed = true; } }
-    HIPC(hipMalloc(&c->arena, c->arena_bytes));
+    if (arena_from && arena_from->arena && arena_from->device == device) {
+      c->arena = arena_from->arena; c->arena_bytes = arena_from->arena_bytes; c->arena_borrowed = true; c->arena_fixed = true;
+    } else {
+      HIPC(hipMalloc(&c->arena, c->arena_bytes));
+    }
     HIPC(hipMalloc(&c->d_present, 256 * sizeof(u32)));
     HIPC(hipMalloc(&c->d_code, 256 * sizeof(uint16_t)));
     HIPC(hipMalloc(&c->d_words, 64 * sizeof(u32)));
@@ -2724,7 +2751,8 @@ void dc3hip_ctx_destroy(dc3hip_ctx *c) {
   if (c->ev_build_b) (void)hipEventDestroy(c->ev_build_b);
   if (c->d_text) (void)hipFree(c->d_text);
   if (c->d_sa) (void)hipFree(c->d_sa);
-  if (c->arena) (void)hipFree(c->arena);
+  if (c->arena && !c->arena_borrowed) (void)hipFree(c->arena);
+  if (c->d_xcdmon) (void)hipFree(c->d_xcdmon);
   if (c->d_present) (void)hipFree(c->d_present);
   if (c->d_code) (void)hipFree(c->d_code);
   if (c->d_words) (void)hipFree(c->d_words);
@@ -3001,8 +3029,17 @@ int32_t dc3hip_ctx_build_partitions(dc3hip_ctx *c, int32_t num_partitions) {
   if (n > (int64_t)INT32_MAX) { set_err("partitioned build of %lld bytes needs 64-bit indices", (long long)n); return E_TOOBIG; }
   HIPC(hipSetDevice(c->device));
   const int64_t S = n / num_partitions + 1;
+  if (S >= n) {                      // one partition: its array is the suffix array of the whole text
+    RC(dc3hip_ctx_build(c));
+    c->sa_trusted = false; c->parts_trusted = num_partitions;
+    return E_OK;
+  }
+  // the partitions are built one after the other by a child context that holds a chunk's text and array (5 S bytes) and
+  // works in THIS context's arena (sized for n >= 2 S bytes: enough for every ordering of a chunk)
+  c->arena_off = 0;                  // (no build of this context is running)
+  if (!c->arena_fixed) RC(ensure_arena(c, arena_requirement(S)));
   dc3hip_ctx *child = nullptr;
-  RC(dc3hip_ctx_create(&child, c->device, std::min<int64_t>(S, n)));
+  RC(ctx_create_impl(&child, c->device, S, c));
   int rc = E_OK;
   for (int64_t off = 0; off < n && rc == E_OK; off += S) {
     const int64_t len = std::min<int64_t>(S, n - off);

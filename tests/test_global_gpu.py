@@ -275,6 +275,40 @@ def test_routed_order_and_bucket_sort_of_a_key_range(ss, oracle):
                                 assert all(s["ctx"]["msd_sorts"] >= 1 and s["ctx"]["msd_fallbacks"] == 0 for s in st), (name, P, extra)
 
 
+def test_unrouted_bucket_order_of_texts_below_2pow32(ss, oracle):
+    """The top-level whole-text order of a text below 2^32 bytes in the wide contexts' form (gorder_text_msd: every rank
+    selects the images of its range straight from its replica of the text inside partition pass 1 of the bucket ordering, 8-byte
+    words, tie rounds with lazily compared windows; nothing but the text blocks crosses the transport), forced onto small
+    texts (DC3HIP_WIDE_MSD_MIN=1): same shards as the reference suffix array for random bytes, DNA, a binary alphabet and a
+    text with a short planted repeat (settled by the deeper tie rounds); a long planted repeat is not distinct within the
+    budget of the tie rounds -> the distributed recursion builds it, still equal to the reference."""
+    n = 6_000_011
+    rng = np.random.default_rng(77)
+    rnd = oracle.gen(n, 21, 0)
+    dna = oracle.gen(n, 22, 1)
+    binary = (rng.integers(0, 2, size=3_000_001, dtype=np.uint8) + 65)
+    short = rnd.copy(); short[4_000_000:4_000_300] = short[100_000:100_300]
+    long_ = dna.copy(); long_[1_000_000:3_500_000] = long_[5:2_500_005]
+    for name, t in (("random", rnd), ("dna", dna), ("binary", binary), ("short_repeat", short), ("long_repeat", long_)):
+        want = want_sa(oracle, t)
+        for P in (2, 4, 7):
+            with env(DC3HIP_WIDE_MSD_MIN=1):
+                with ss.LoopbackGroup(P, len(t)) as g:
+                    g.set_text(t)
+                    g.build()
+                    st = g.stats()
+                    assert np.array_equal(g.sa(), want), (name, P)
+                    if name != "long_repeat":
+                        assert all(s["text_order"] == 1 and s["wide_msd"] == 1 for s in st), (name, P, [(s["text_order"], s["wide_msd"]) for s in st])
+                        # unrouted: a rank received the other ranks' text blocks and nothing else
+                        assert all(s["comm_bytes_in"] <= len(t) + 4096 for s in st), [s["comm_bytes_in"] for s in st]
+                        assert all(abs(s["shard_count"] - len(t) / P) < 0.25 * len(t) / P for s in st), [s["shard_count"] for s in st]
+                    else:
+                        assert all(s["text_order"] == 0 for s in st), (name, P)
+                    g.build()                                  # idempotent (the context's buffers are reused)
+                    assert np.array_equal(g.sa(), want), (name, P, "second build")
+
+
 def test_transport_selftest_and_recovery_after_a_failed_collective(ss, oracle):
     """dc3hip_global_selftest (ragged all-to-all / all-gather of known bytes, every byte checked) on loopback groups, and
     the failure semantics of the header: after a collective that failed on every rank (a one-symbol text in a wide
@@ -434,8 +468,8 @@ def test_wide_mode_small_texts_match_the_oracle(ss, oracle, P):
     150 000 symbols are settled by the tie rounds (each 16 times deeper than the last); a text half of which is a copy of
     the other half and a text over one symbol are refused with -4 on every rank."""
     rng = np.random.default_rng(47)
-    # (P = 3 also runs the ROUTED selection, which is otherwise taken from 6 ranks on; P = 8 takes it by default)
-    with env(DC3HIP_GLOBAL_FORCE_WIDE=1, DC3HIP_GLOBAL_WIDE_ROUTE_MIN_P=3), ss.LoopbackGroup(P, 3_000_000) as g:
+    # (texts this small stay below the bucket ordering's threshold: the 16-byte LSD form, unrouted selection)
+    with env(DC3HIP_GLOBAL_FORCE_WIDE=1), ss.LoopbackGroup(P, 3_000_000) as g:
         cases = {"bytes": rng.integers(0, 256, size=2_500_003, dtype=np.uint8), "dna": oracle.gen(3_000_000, 5, 1),
                  "binary": rng.integers(0, 2, size=1_000_001, dtype=np.uint8) + 7,
                  "with_zero_byte": rng.integers(0, 3, size=777_777, dtype=np.uint8), "tiny": rng.integers(0, 256, size=300, dtype=np.uint8)}
@@ -484,8 +518,7 @@ def test_wide_mode_small_texts_match_the_oracle(ss, oracle, P):
 def test_wide_mode_bucket_ordering_on_small_texts(ss, oracle, P):
     """The wide mode's bucket ordering on 8-byte words (dc3_wide_msd.hip.hpp: a rank maps the images of its range onto
     [0, 2^E), partition pass 1 selects and computes them straight from the text and drops the bucket's own bits from the
-    word, passes 2 and 3 and the tie pass work on 8-byte words) forced onto small texts (DC3HIP_WIDE_MSD_MIN=1, unrouted
-    selection) so that the oracle can judge it: bit-exact int64 shards, the collective verifier agrees, and the 16-byte LSD
+    word, passes 2 and 3 and the tie pass work on 8-byte words) forced onto small texts (DC3HIP_WIDE_MSD_MIN=1) so that the oracle can judge it: bit-exact int64 shards, the collective verifier agrees, and the 16-byte LSD
     form (DC3HIP_NO_WIDE_MSD=1) gives the same checksum.  Repeats are settled by the same tie rounds."""
     rng = np.random.default_rng(48)
     cases = {"bytes": rng.integers(0, 256, size=2_500_003, dtype=np.uint8), "dna": oracle.gen(3_000_000, 5, 1),
@@ -496,7 +529,7 @@ def test_wide_mode_bucket_ordering_on_small_texts(ss, oracle, P):
     rep = cases["dna"].copy(); rep[1_000_000:1_020_000] = rep[5:20_005]; cases["dna_planted_repeat"] = rep
     sums = {}
     for extra in ({"DC3HIP_WIDE_MSD_MIN": 1}, {"DC3HIP_NO_WIDE_MSD": 1}):
-        with env(DC3HIP_GLOBAL_FORCE_WIDE=1, DC3HIP_GLOBAL_WIDE_ROUTE_MIN_P=99, **extra), ss.LoopbackGroup(P, 3_000_000) as g:
+        with env(DC3HIP_GLOBAL_FORCE_WIDE=1, **extra), ss.LoopbackGroup(P, 3_000_000) as g:
             for label, t in cases.items():
                 g.set_text(t)
                 g.build()

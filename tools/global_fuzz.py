@@ -52,7 +52,6 @@ while time.time() - t0 < budget:
         if rng.random() < 0.25: envs[k] = "1"
     if rng.random() < 0.5:
         envs["DC3HIP_HYBRID12_MIN"] = "0"
-        if rng.random() < 0.5: envs["DC3HIP_HYBRID12_MAX_PRED"] = "2"
     text = make_text(n)
     for k, v in envs.items(): os.environ[k] = v
     try:
