@@ -155,6 +155,21 @@ struct RcclApi {
     // second instance: look for a mapped one first (RTLD_NOLOAD matches by soname), load one only when there is none.
     // dc3hip_rccl_library_path() reports which file the entry points came from; bench.py checks it against /proc/self/maps.
     for (const char *nm : {"librccl.so.1", "librccl.so"}) { h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD); if (h) { preloaded = true; break; } }
+    if (!h) {
+      // None mapped yet.  Prefer the librccl that sits NEXT TO the HIP runtime this process runs on: a PyTorch wheel ships
+      // its own libamdhip64 and a librccl built against it (and maps the latter only when torch.distributed is first
+      // used) — the system's librccl on top of the wheel's runtime aborts at exit (double free, seen with ROCm 7.2's
+      // librccl under a ROCm 7.0 wheel).
+      Dl_info di;
+      if (dladdr(reinterpret_cast<const void *>(&hipGetDeviceCount), &di) && di.dli_fname) {
+        std::string dir(di.dli_fname);
+        const size_t slash = dir.rfind('/');
+        if (slash != std::string::npos) {
+          dir.resize(slash);
+          for (const char *nm : {"/librccl.so", "/librccl.so.1"}) { h = dlopen((dir + nm).c_str(), RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+        }
+      }
+    }
     if (!h)
       for (const char *nm : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
     if (!h) { set_err("RCCL not found (dlopen librccl.so): %s", dlerror()); return false; }
@@ -304,6 +319,7 @@ struct HostComm : GComm {
 struct dc3hip_gctx {
   bool no_wide_msd = false;    // DC3HIP_NO_WIDE_MSD=1: wide mode always sorts 16-byte records with the LSD passes
   u64 wide_msd_min = 1ull << 22; // DC3HIP_WIDE_MSD_MIN (tests): fewest positions per rank for the wide bucket ordering
+  bool wide_msd_forced = false;  // ... given explicitly: texts below 2^32 take the unrouted order at every rank count
   u32 w_depth = 0;             // wide mode: symbols the last tie pass of the last build compared (the verifier compares at least as deep)
   bool route = true;           // DC3HIP_GLOBAL_NO_ROUTE=1: every rank evaluates all positions and keeps its key range (the round-2 form)
   dc3hip_ctx *c = nullptr;
@@ -1201,6 +1217,11 @@ static int wide_key(dc3hip_gctx *G, u32 sigma, WideKey *k, u32 *ibits_out) {
   k->t = gtext(G); k->code = G->c->d_code; k->n = (u64)G->total_n; k->sigma = sigma; k->J = J; k->W = kWideWindow;
   k->mfix = (u64)(((((unsigned __int128)1) << (64 + ibits)) - 1) / SJ);
   k->P1 = SJ / sigma;
+  k->lg = 0; k->sh = 0;
+  if ((sigma & (sigma - 1)) == 0) {          // power of two: sigma^J = 2^(lg J), image = v >> (lg J - ibits) exactly
+    const u32 lg = bits_of((u64)sigma) - 1, sh = lg * J - ibits;
+    if (lg >= 1 && lg * J > ibits && sh < 64) { k->lg = lg; k->sh = sh; k->mfix = 1ull << (64 - sh); }
+  }
   *ibits_out = ibits;
   return E_OK;
 }
@@ -1265,10 +1286,16 @@ struct WidePass1 : MsdPass1 {
   int launch(dc3hip_ctx *c, u64 *out, u32, u64, u32, const MsdGeom &, u32, const u32 *, u32 *cur1) override {
     static std::atomic<bool> attr_set[16];
     if (!attr_set[c->device & 15]) {
-      HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_wide_part1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWidePartSmem));
+#define DC3_WIDE_ATTR(JM, PW) HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_wide_part1<JM, PW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWidePartSmem))
+      DC3_WIDE_ATTR(8, false); DC3_WIDE_ATTR(16, false); DC3_WIDE_ATTR(24, false); DC3_WIDE_ATTR(kWideMaxImageSyms, false);
+      DC3_WIDE_ATTR(8, true); DC3_WIDE_ATTR(16, true); DC3_WIDE_ATTR(24, true); DC3_WIDE_ATTR(kWideMaxImageSyms, true);
+#undef DC3_WIDE_ATTR
       attr_set[c->device & 15] = true;
     }
-    hipLaunchKernelGGL(k_wide_part1, dim3(kMsdGroups * cpg), dim3(kWideNT), kWidePartSmem, c->stream, k, rg, chunk, nchunks, cpg, cur1, out, c->d_xcdmon);
+#define DC3_WIDE_P1(JM, PW) hipLaunchKernelGGL((k_wide_part1<JM, PW>), dim3(kMsdGroups * cpg), dim3(kWideNT), kWidePartSmem, c->stream, k, rg, chunk, nchunks, cpg, cur1, out, c->d_xcdmon)
+    if (k.lg) switch (wide_jmax(k.J)) { case 8: DC3_WIDE_P1(8, true); break; case 16: DC3_WIDE_P1(16, true); break; case 24: DC3_WIDE_P1(24, true); break; default: DC3_WIDE_P1(kWideMaxImageSyms, true); }
+    else switch (wide_jmax(k.J)) { case 8: DC3_WIDE_P1(8, false); break; case 16: DC3_WIDE_P1(16, false); break; case 24: DC3_WIDE_P1(24, false); break; default: DC3_WIDE_P1(kWideMaxImageSyms, false); }
+#undef DC3_WIDE_P1
     KCHECK();
     return E_OK;
   }
@@ -1349,7 +1376,10 @@ static int wide_msd_order(dc3hip_gctx *G, const WideKey &k, u32 ibits, u64 lo, u
   RC(arena_alloc(c, (size_t)nb1 * kMsdGroups + 16, &cntg));
   {
     PhaseScope ps(c, DC3HIP_PH_PACK, (int64_t)n);
-    hipLaunchKernelGGL(k_wide_count1, dim3(p1.nchunks), dim3(kWideNT), 0, c->stream, k, p1.rg, p1.chunk, p1.nchunks, table);
+#define DC3_WIDE_C1(JM, PW) hipLaunchKernelGGL((k_wide_count1<JM, PW>), dim3(p1.nchunks), dim3(kWideNT), 0, c->stream, k, p1.rg, p1.chunk, p1.nchunks, table)
+    if (k.lg) switch (wide_jmax(k.J)) { case 8: DC3_WIDE_C1(8, true); break; case 16: DC3_WIDE_C1(16, true); break; case 24: DC3_WIDE_C1(24, true); break; default: DC3_WIDE_C1(kWideMaxImageSyms, true); }
+    else switch (wide_jmax(k.J)) { case 8: DC3_WIDE_C1(8, false); break; case 16: DC3_WIDE_C1(16, false); break; case 24: DC3_WIDE_C1(24, false); break; default: DC3_WIDE_C1(kWideMaxImageSyms, false); }
+#undef DC3_WIDE_C1
     KCHECK();
     hipLaunchKernelGGL(k_msd_cnt1, dim3(nb1), dim3(kBlock), 0, c->stream, (const u32 *)table, p1.nchunks, p1.cpg, cntg);
     KCHECK();
@@ -1396,6 +1426,10 @@ static int gorder_text_msd(dc3hip_gctx *G, u32 sigma, bool *done, bool *tried) {
   { char keep[sizeof(g_err)]; snprintf(keep, sizeof(keep), "%s", g_err); if (wide_key(G, sigma, &k, &ibits) != E_OK) { set_err("%s", keep); return E_OK; } }
   if (!wide_msd_applies(G, n, P, ibits)) return E_OK;
   if ((double)k.W * log2((double)sigma) < 2.0 * log2((double)n) + 2.0) return E_OK;
+  // Where it pays (total work of P loopback ranks on one GPU, 256 MiB random bytes: routed 8.1 / 9.0 ms for P = 2 / 4,
+  // unrouted 8.3 / 11.5 — every rank evaluates all n positions twice): from 2^31 positions on, where the routed order
+  // would sort 12-byte records with LSD passes, and for two ranks.  DC3HIP_WIDE_MSD_MIN set explicitly (tests) forces it.
+  if (!(G->wide_msd_forced || P <= 2 || bits_of(n - 1) >= 32)) return E_OK;
   *tried = true;
   const ArenaMark mk = arena_mark(c);
   u64 lo = 0, hi = ~0ull;
@@ -1628,7 +1662,7 @@ static void gctx_env(dc3hip_gctx *G) {
   if (const char *e = getenv("DC3HIP_GLOBAL_FORCE_DIST")) G->force_dist = e[0] == '1';
   if (const char *e = getenv("DC3HIP_GLOBAL_NO_ROUTE")) G->route = e[0] != '1';
   if (const char *e = getenv("DC3HIP_NO_WIDE_MSD")) G->no_wide_msd = e[0] == '1';
-  if (const char *e = getenv("DC3HIP_WIDE_MSD_MIN")) { const long long v = atoll(e); if (v >= 0) G->wide_msd_min = (u64)v; }
+  if (const char *e = getenv("DC3HIP_WIDE_MSD_MIN")) { const long long v = atoll(e); if (v >= 0) { G->wide_msd_min = (u64)v; G->wide_msd_forced = true; } }
 }
 
 // the rank's device context: a full one (text, SA, arena for max_total_n) — or, in wide mode, a minimal one (stream,

@@ -309,6 +309,64 @@ __global__ __launch_bounds__(kTupNT) void k_tup_part2(const typename Out::Rec *_
                      [&](u32 d, u32 cnt) { return base + (d << kTupWinBits) + atomicAdd(&cur[d], cnt); }, out, smem);
 }
 
+// Pass 1 of the 8-byte form in the shape of the bucket ordering's partition pass (k_msd_part): 1024 threads, tiles of
+// 6144 slots, the packed words and a 2-byte digit per word in LDS (70 KB: two blocks per CU, 32 waves) instead of three
+// 4-byte planes per record in tiles of 4096 (one tile per 13 us chain of load -> rank -> reserve -> reorder -> write, two
+// blocks of 8 waves per CU): the chain is walked once per 6144 records by twice the waves, and a tile's run in a bucket
+// is 1.5 times as long.
+constexpr int kTup8NT = 1024, kTup8IPT = 6, kTup8Tile = kTup8NT * kTup8IPT;
+constexpr size_t kTup8PartSmem = sizeof(u64) * kTup8Tile + sizeof(uint16_t) * kTup8Tile + sizeof(u32) * (2 * 1024 + 64);
+template <class Sym>
+__global__ __launch_bounds__(kTup8NT) void k_tup8_part1(Sym S, u32 m, u32 m0, u32 m02, const u32 *__restrict__ rank12, u32 cpx,
+                                                       u32 ntiles, u32 ndig, u32 *__restrict__ cursors /*[8][ndig]*/,
+                                                       TupOut8 out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u64 *srec = reinterpret_cast<u64 *>(smem);
+  uint16_t *sdig = reinterpret_cast<uint16_t *>(smem + sizeof(u64) * kTup8Tile);
+  u32 *hist = reinterpret_cast<u32 *>(smem + sizeof(u64) * kTup8Tile + sizeof(uint16_t) * kTup8Tile);
+  u32 *gbase = hist + 1024, *tmp = gbase + 1024;
+  __shared__ uint16_t lcode[256];
+  const u32 tid = threadIdx.x;
+  const u32 g = blockIdx.x % 8u, idx = blockIdx.x / 8u;
+  const u32 tile = g * cpx + idx;
+  if (idx >= cpx || tile >= ntiles) return;
+  const bool dummy = (m % 3) == 1;
+  S.stage(lcode);
+  hist[tid] = 0;
+  __syncthreads();
+  const u32 begin = tile * (u32)kTup8Tile, nvalid = min((u32)kTup8Tile, m02 - begin);
+  u64 w[kTup8IPT];
+  u32 dg[kTup8IPT], rk[kTup8IPT];
+#pragma unroll
+  for (int k = 0; k < kTup8IPT; k++) {
+    const u32 s = begin + min((u32)(k * kTup8NT) + tid, nvalid - 1u);
+    const u32 dest = rank12[s] - 1u;
+    u32 r, cc;
+    tup_payload(S, lcode, m, m0, dummy, rank12, s, r, cc);
+    dg[k] = dest >> kTupSh1;
+    w[k] = (u64)(dest & ((1u << kTupSh1) - 1u)) | ((u64)r << kTupSh1) | ((u64)(cc >> 16) << (kTupSh1 + out.rb));
+  }
+#pragma unroll
+  for (int k = 0; k < kTup8IPT; k++)
+    if ((u32)(k * kTup8NT) + tid < nvalid) rk[k] = atomicAdd(&hist[dg[k]], 1u);
+  __syncthreads();
+  u32 *cur = cursors + (size_t)g * ndig;
+  u32 cnt = 0;
+  if (tid < ndig) { cnt = hist[tid]; if (cnt) gbase[tid] = atomicAdd(&cur[tid], cnt); }
+  u32 tot;
+  const u32 ex = block_excl_scan<kTup8NT / 64>(cnt, tmp, tot);
+  hist[tid] = ex;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kTup8IPT; k++)
+    if ((u32)(k * kTup8NT) + tid < nvalid) { const u32 at = hist[dg[k]] + rk[k]; srec[at] = w[k]; sdig[at] = (uint16_t)dg[k]; }
+  __syncthreads();
+  for (u32 q = tid; q < nvalid; q += kTup8NT) {
+    const u32 dd = sdig[q];
+    out.p[gbase[dd] + (q - hist[dd])] = srec[q];
+  }
+}
+
 // Cumulative first-symbol counts of the level's sample suffixes (level 0: codes 0..sigma, 0 = the dummy sample behind
 // the text): hist[c] += samples whose first symbol is c.  One pass over S; `hist` (nsym words, zeroed) is turned into the
 // exclusive prefix cum[0..nsym] by k_scan_excl_inplace.  A sample of SA12 rank k starts with the symbol c for which

@@ -383,6 +383,13 @@ struct MsdRecSink {
   __device__ __forceinline__ bool same_image(u64, u64) const { return false; }
   __device__ __forceinline__ void store(u32 g, u64 x, bool) const { p[g] = msd_word(x); }
 };
+// the sorted words + the tie pass's byte (the orderings that keep records: whole-level orders inside the recursion)
+struct MsdRecSameSink {
+  u64 *p; uint8_t *same; u32 pbits;
+  static constexpr bool kSame = true;
+  __device__ __forceinline__ bool same_image(u64 a, u64 b) const { return ((a ^ b) >> pbits) == 0; }
+  __device__ __forceinline__ void store(u32 g, u64 x, bool sm) const { p[g] = msd_word(x); same[g] = sm ? 1 : 0; }
+};
 // positions to the suffix-array buffer + ONE BYTE per word for the tie pass: 1 = same image as the word before it.  (The
 // LSD passes' SplitSink leaves 32 image bits instead, which the tie pass compares itself: 8 bytes per word written and 4
 // read back, against 5 and 1 here.)

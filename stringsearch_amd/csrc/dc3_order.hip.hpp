@@ -995,8 +995,14 @@ struct TieKey<Key9> {
 // words[0] = overflow flag, words[1] += tied records, words[2] += records whose full key equals the predecessor's
 // (settled groups only).  emit_sa != nullptr: also write the positions in sorted order to emit_sa[i - skip]
 // (complete when words[0] == 0; it is the suffix array when words[2] == 0 as well).
-template <class KM>
-__global__ __launch_bounds__(kBlock) void k_tie_resolve(KM km, Rec8 *__restrict__ h, u32 n, u32 pbits,
+// Same: SameRec compares the images of neighbouring records; SameFlag reads the byte the bucket ordering's local sort left
+// (the scan then reads 1 byte per record instead of 8).
+struct SameRec {
+  const Rec8 *h; u32 pbits;
+  __device__ __forceinline__ bool operator()(u32 i) const { return i > 0 && (rec8_word(h[i]) >> pbits) == (rec8_word(h[i - 1]) >> pbits); }
+};
+template <class KM, class Same>
+__global__ __launch_bounds__(kBlock) void k_tie_resolve(KM km, Same same, Rec8 *__restrict__ h, u32 n, u32 pbits,
                                                        uint8_t *__restrict__ f, u32 *words,
                                                        u32 *__restrict__ emit_sa, u32 skip) {
   // Group starts are sparse (a few per wave): a block collects the starts of 2048-record tiles in LDS, tile after
@@ -1017,13 +1023,11 @@ __global__ __launch_bounds__(kBlock) void k_tie_resolve(KM km, Rec8 *__restrict_
     for (u32 j = 0; j < kIPT; j++) {
       const u32 i = tile * kTile + j * kBlock + threadIdx.x;
       if (i < n) {
-        const Rec8 r = h[i];
-        const u64 a = rec8_word(r) >> pbits;
-        const bool eqp = i > 0 && (rec8_word(h[i - 1]) >> pbits) == a;
-        const bool eqn = i + 1 < n && (rec8_word(h[i + 1]) >> pbits) == a;
+        const bool eqp = same(i);
+        const bool eqn = i + 1 < n && same(i + 1);
         if (eqn && !eqp) starts[atomicAdd(&nstart, 1u)] = i;
         if (eqn || eqp) tied++;
-        else if (emit_sa && i >= skip) emit_sa[i - skip] = r.val & posmask;
+        else if (emit_sa && i >= skip) emit_sa[i - skip] = h[i].val & posmask;
       }
     }
     tied = wave_reduce(tied);
@@ -1039,9 +1043,8 @@ __global__ __launch_bounds__(kBlock) void k_tie_resolve(KM km, Rec8 *__restrict_
       if (base + threadIdx.x < ns) {
         const u32 i = starts[base + threadIdx.x];
         const Rec8 h0 = h[i];
-        const u64 a = rec8_word(h0) >> pbits;
         u32 e = i + 2;
-        while (e < n && e - i <= kTieSmallMax && (rec8_word(h[e]) >> pbits) == a) e++;
+        while (e < n && e - i <= kTieSmallMax && same(e)) e++;
         const u32 len = e - i;
         const u32 lo_img = h0.val & ~posmask;
         Rec8 o; o.key = h0.key;

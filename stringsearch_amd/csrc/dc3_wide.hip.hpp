@@ -16,6 +16,10 @@ struct WideKey {
   const uint8_t *t; const uint16_t *code; u64 n;
   u32 sigma, J, W;          // alphabet size, image symbols, compare depth in symbols (multiple of 4)
   u64 mfix, P1;             // floor((2^(64+ibits) - 1) / sigma^J), sigma^(J-1)
+  // sigma a power of two (bytes: 256, DNA: 4 — both of BASELINE's input classes): lg = log2 sigma and the image is
+  // v >> sh exactly (mfix = 2^(64 - sh)), so the kernels that evaluate every position of the text can shift and mask
+  // instead of multiplying 64-bit numbers (v_mul_*_u32 run at quarter rate: 12 ms per 4.3 G positions and pass).  lg = 0: general.
+  u32 lg = 0, sh = 0;
 };
 constexpr u32 kWideMaxImageSyms = 48;
 constexpr u32 kWideWindow = 256;          // symbols compared before two positions count as having the same window ...

@@ -32,23 +32,33 @@ __device__ __forceinline__ u64 wide_xprime(const WideRange &r, u64 img) {
   return __umul64hi((img - r.lo) << (64 - r.eb), r.M) >> (63 - r.E);
 }
 
-// images of the four positions p0 .. p0 + 3 (p0 % 4 == 0) by rolling, as k_wide_select does
-__device__ __forceinline__ void wide_images4(const WideKey &k, u64 p0, const uint16_t *lcode, u64 (&img)[4]) {
-  const u32 J = k.J, sigma = k.sigma, nw = (J + 3 + 3) / 4;
-  constexpr u32 kW = (kWideMaxImageSyms + 3 + 3) / 4;
+// images of the four positions p0 .. p0 + 3 (p0 % 4 == 0) by rolling, as k_wide_select does.  JMAX >= k.J bounds the
+// unrolled loops at compile time (bytes need 5-8 image symbols, DNA about 20, a binary alphabet up to 48): with the one
+// bound of 48 every position paid 51 predicated iterations — 4.6 ms per GiB and pass against 1.7 for Key9's pack kernel.
+// the text words behind position p0 that the images of p0 .. p0 + 3 are made of (loaded apart from the arithmetic so that a
+// kernel can fetch the next round's words before it works on this round's)
+template <u32 JMAX>
+struct WideWords { u32 w[(JMAX + 3 + 3) / 4]; };
+template <u32 JMAX>
+__device__ __forceinline__ void wide_load4(const WideKey &k, u64 p0, WideWords<JMAX> &ww) {
+  const u32 nw = (k.J + 3 + 3) / 4;
   const u32 *tw = reinterpret_cast<const u32 *>(k.t + p0);
-  u32 w[kW];
 #pragma unroll
-  for (u32 i = 0; i < kW; i++) w[i] = i < nw ? tw[i] : 0u;
+  for (u32 i = 0; i < (JMAX + 3 + 3) / 4; i++) ww.w[i] = i < nw ? tw[i] : 0u;
+}
+template <u32 JMAX, bool kPow2>
+__device__ __forceinline__ void wide_images4(const WideKey &k, u64 p0, const WideWords<JMAX> &ww, const uint16_t *lcode, u64 (&img)[4]) {
+  const u32 J = k.J, sigma = k.sigma;
+  const u32 (&w)[(JMAX + 3 + 3) / 4] = ww.w;
   u64 v = 0;
   u32 dh[3] = {0, 0, 0}, dt0 = 0, dt1 = 0, dt2 = 0;
 #pragma unroll
-  for (u32 s = 0; s < kWideMaxImageSyms + 3; s++) {
+  for (u32 s = 0; s < JMAX + 3; s++) {
     if (s < J + 3) {
       u32 q = (p0 + s < k.n) ? (u32)lcode[(w[s >> 2] >> (8 * (s & 3u))) & 255u] : 0u;
       q = q ? q - 1 : 0u;
       if (s < 3) dh[s] = q;
-      if (s < J) v = v * sigma + q;
+      if (s < J) v = kPow2 ? ((v << k.lg) | q) : v * sigma + q;
       else if (s == J) dt0 = q;
       else if (s == J + 1) dt1 = q;
       else dt2 = q;
@@ -56,10 +66,13 @@ __device__ __forceinline__ void wide_images4(const WideKey &k, u64 p0, const uin
   }
 #pragma unroll
   for (int j = 0; j < 4; j++) {
-    img[j] = __umul64hi(v, k.mfix);
-    if (j < 3) v = (v - (u64)dh[j] * k.P1) * sigma + (j == 0 ? dt0 : j == 1 ? dt1 : dt2);
+    img[j] = kPow2 ? (v >> k.sh) : __umul64hi(v, k.mfix);
+    const u64 nd = j == 0 ? dt0 : j == 1 ? dt1 : dt2;
+    if (j < 3) v = kPow2 ? (((v & (k.P1 - 1ull)) << k.lg) | nd) : (v - (u64)dh[j] * k.P1) * sigma + nd;
   }
 }
+// the smallest of the compiled bounds that holds J image symbols
+inline u32 wide_jmax(u32 J) { return J <= 8 ? 8u : J <= 16 ? 16u : J <= 24 ? 24u : kWideMaxImageSyms; }
 
 constexpr int kWideNT = 1024;                                  // threads of a block of the two kernels below
 constexpr u32 kWideRound = 4u * kWideNT;                       // positions per round (4 consecutive ones per thread)
@@ -70,6 +83,7 @@ constexpr size_t kWidePartSmem = sizeof(u64) * kWideStage + sizeof(uint16_t) * k
 // Counting pass: table[d * nchunks + c] = selected positions of chunk c (positions [c * chunk, (c + 1) * chunk), chunk a
 // multiple of kWideRound) whose x' has top-d1 digit d — the digit table format of the pack kernels (k_msd_cnt1 sums it
 // per XCD group: chunk c belongs to group c / cpg).
+template <u32 JMAX, bool kPow2>
 __global__ __launch_bounds__(kWideNT) void k_wide_count1(WideKey k, WideRange rg, u64 chunk, u32 nchunks, u32 *__restrict__ table) {
   __shared__ uint16_t lcode[256];
   __shared__ u32 hist[4][1024];
@@ -82,7 +96,9 @@ __global__ __launch_bounds__(kWideNT) void k_wide_count1(WideKey k, WideRange rg
   const u32 sh = rg.E - rg.d1;
   for (u64 p0 = begin + 4ull * tid; p0 < end; p0 += kWideRound) {
     u64 img[4];
-    wide_images4(k, p0, lcode, img);
+    WideWords<JMAX> ww;
+    wide_load4<JMAX>(k, p0, ww);
+    wide_images4<JMAX, kPow2>(k, p0, ww, lcode, img);
 #pragma unroll
     for (int j = 0; j < 4; j++)
       if (p0 + j < end && wide_in_range(rg, img[j])) atomicAdd(&myh[(u32)(wide_xprime(rg, img[j]) >> sh)], 1u);
@@ -95,6 +111,7 @@ __global__ __launch_bounds__(kWideNT) void k_wide_count1(WideKey k, WideRange rg
 // Partition pass 1 with selection (see the header).  Block j belongs to group j % 8 and works that group's chunk number
 // j / 8 (chunk c = g * cpg + idx); cursors[g * ndig + d] = the group's cursor of bucket d (k_msd_plan1).  Output words in
 // the memory form of the bucket ordering (msd_word).  Not stable.
+template <u32 JMAX, bool kPow2>
 __global__ __launch_bounds__(kWideNT) void k_wide_part1(WideKey k, WideRange rg, u64 chunk, u32 nchunks, u32 cpg,
                                                        u32 *__restrict__ cursors, u64 *__restrict__ out, u32 *__restrict__ xcdmon) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -162,10 +179,16 @@ __global__ __launch_bounds__(kWideNT) void k_wide_part1(WideKey k, WideRange rg,
     __syncthreads();
   };
 
+  // (one block of 1024 threads fills a CU: the next round's text words are fetched before this round is worked, or every
+  //  round would wait out a full memory latency with nothing else to run)
+  WideWords<JMAX> wnext;
+  if (begin + 4ull * tid < end) wide_load4<JMAX>(k, begin + 4ull * tid, wnext);
   for (u64 r0 = begin; r0 < end; r0 += kWideRound) {
     const u64 p0 = r0 + 4ull * tid;
+    const WideWords<JMAX> wcur = wnext;
+    if (p0 + kWideRound < end) wide_load4<JMAX>(k, p0 + kWideRound, wnext);
     u64 img[4] = {0, 0, 0, 0};
-    if (p0 < end) wide_images4(k, p0, lcode, img);
+    if (p0 < end) wide_images4<JMAX, kPow2>(k, p0, wcur, lcode, img);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const bool sel = p0 + j < end && wide_in_range(rg, img[j]);

@@ -103,6 +103,7 @@ struct dc3hip_ctx {
   bool no_tup_rec8 = false;    // DC3HIP_NO_TUP_REC8=1 (tests): level 0 moves 12-byte records through the tuple scatter, as deeper levels do
   bool no_xcd_map = false;     // DC3HIP_NO_XCD_MAP=1: window partitions without the segment -> XCD-group tile order (measurement aid)
   bool pack_fuse = true;       // DC3HIP_PACK_FUSE=0: whole-text order of bytes with a pack kernel that WRITES the words (default: it only counts, partition pass 1 makes them on the fly)
+  bool tup_bigtile = true;     // DC3HIP_TUP_BIGTILE=0 (lab / tests): level 0's tuple scatter pass 1 in the 4096-slot, 512-thread shape of the deeper levels
   bool no_pack_strip = false;  // DC3HIP_NO_PACK_STRIP=1: ... from an image no wider than the word (default: d1 bits wider, the bucket's own bits dropped)
   bool no_msd = false;         // DC3HIP_NO_MSD=1: the prefix sorts always run the stable LSD passes (no bucket ordering)
   u32 ssort_over = 24;         // splitter ordering: sample values per sub-bucket
@@ -481,7 +482,9 @@ static int msd_launch_local(dc3hip_ctx *c, const MsdRedo &r, u32 n, Sink sink) {
 // images the tie pass meets does not depend on which way the sort went.  The small tables stay allocated in the arena
 // until the caller releases its mark (redo reads them).
 static int msd_sort(dc3hip_ctx *c, Rec8 *ha, Rec8 *hb, u32 n, const HiMap &hm, const MsdGeom &g, const u32 *table,
-                    const SplitSink *split, Rec8 **result, MsdRedo *redo, bool *ok, Rec8 **where, MsdPass1 *p1 = nullptr) {
+                    const SplitSink *split, Rec8 **result, MsdRedo *redo, bool *ok, Rec8 **where, MsdPass1 *p1 = nullptr,
+                    uint8_t *same_out = nullptr) {
+  // same_out (record form only): same_out[i] = 1 iff sorted record i has the image of record i - 1
   // p1 != nullptr: the words do not exist yet — pass 1 makes them from the key maker (`ha` is then only the scratch of
   // pass 2); needs `table` (the counting pack kernel's)
   *ok = false; *where = ha; *result = nullptr;
@@ -580,6 +583,10 @@ static int msd_sort(dc3hip_ctx *c, Rec8 *ha, Rec8 *hb, u32 n, const HiMap &hm, c
   if (split) {
     MsdSplitSink sk; sk.sa = split->sa; sk.same = split->same; sk.pbits = split->pbits;
     RC(msd_launch_local(c, r, n, sk));
+  } else if (same_out) {
+    MsdRecSameSink sk; sk.p = r.dst; sk.same = same_out; sk.pbits = hm.pbits;
+    RC(msd_launch_local(c, r, n, sk));
+    *result = reinterpret_cast<Rec8 *>(r.dst);
   } else {
     MsdRecSink sk; sk.p = r.dst;
     RC(msd_launch_local(c, r, n, sk));
@@ -1210,7 +1217,10 @@ template <class KM>
 static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Rec8 *ha, Rec8 *hb, u32 nrec,
                             Rec8 **h_out, uint8_t *f, bool *ok, int depth, u32 *emit_sa = nullptr, u32 skip = 0,
                             bool *emitted_distinct = nullptr, u32 *first_table = nullptr, bool whole_text = false,
-                            const MsdGeom *mg = nullptr, u64 img_lo = 0, u64 img_span = 0, MsdPass1 *p1 = nullptr) {
+                            const MsdGeom *mg = nullptr, u64 img_lo = 0, u64 img_span = 0, MsdPass1 *p1 = nullptr,
+                            bool *keys_distinct = nullptr) {
+  // keys_distinct (record form): set when the tie pass settled every tied group and found no two equal keys — the caller
+  // then knows that all nrec keys are distinct without counting the flags
   // p1 (only with mg->on): the records of `ha` were NOT written — the pack kernel only counted, pass 1 of the bucket
   // ordering makes them on the fly
   // img_lo / img_span (only with mg == nullptr): the records hold the images of [img_lo, img_lo + img_span) only
@@ -1226,7 +1236,10 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
   // prefix doubling.  (A rank of the global mode orders only its image range and must not: ranks are global.)
   *ok = false;
   if (emitted_distinct) *emitted_distinct = false;
+  if (keys_distinct) *keys_distinct = false;
   Rec8 *h = nullptr;
+  bool msd_ok = false;                 // (record form) the bucket ordering delivered, with its same-image bytes in same_rec
+  uint8_t *same_rec = nullptr;
   if (emit_sa && emitted_distinct && skip == 0 && !c->no_small_ties && !c->no_split_emit && hm.pbits < 32) {
     // optimistic end of the whole-text order: the last pass writes positions to the SA buffer and 32 image bits to a
     // side array; the tie pass settles the tied groups in place.  Complete unless a key repeats or a group is large.
@@ -1313,10 +1326,10 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
     }
     emit_sa = nullptr;                       // from here on: the record path, positions are emitted by the caller
   } else {
-    bool msd_ok = false;
     if (mg && mg->on) {
       MsdRedo mredo; Rec8 *where = ha;
-      RC(msd_sort(c, ha, hb, nrec, hm, *mg, first_table, nullptr, &h, &mredo, &msd_ok, &where, p1));
+      if (!c->no_small_ties) RC(arena_alloc(c, (size_t)nrec + 16, &same_rec));
+      RC(msd_sort(c, ha, hb, nrec, hm, *mg, first_table, nullptr, &h, &mredo, &msd_ok, &where, p1, same_rec));
       if (!msd_ok) { first_table = nullptr; if (p1) RC(p1->repack(c, ha, nrec, &first_table)); }
     }
     if (!msd_ok)
@@ -1334,8 +1347,12 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
     {
       PhaseScope ps(c, DC3HIP_PH_TIES, nrec);
       HIPC(hipMemsetAsync(c->d_words + 10, 0, 3 * sizeof(u32), c->stream));
-      hipLaunchKernelGGL((k_tie_resolve<KM>), dim3(grid_for(c, nrec / 4 + 1)), dim3(kBlock), 0, c->stream, km, h, nrec,
-                         hm.pbits, f, c->d_words + 10, emit_sa, skip);
+      if (msd_ok && same_rec)
+        hipLaunchKernelGGL((k_tie_resolve<KM, SameFlag>), dim3(grid_for(c, nrec / 4 + 1)), dim3(kBlock), 0, c->stream, km, SameFlag{same_rec}, h, nrec,
+                           hm.pbits, f, c->d_words + 10, emit_sa, skip);
+      else
+        hipLaunchKernelGGL((k_tie_resolve<KM, SameRec>), dim3(grid_for(c, nrec / 4 + 1)), dim3(kBlock), 0, c->stream, km, SameRec{h, hm.pbits}, h, nrec,
+                           hm.pbits, f, c->d_words + 10, emit_sa, skip);
       KCHECK();
       HIPC(hipMemcpyAsync(c->h_words + 10, c->d_words + 10, 3 * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
     }
@@ -1345,6 +1362,7 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
     if ((double)tied > kHybridMaxMeasured * (double)nrec) return E_OK;   // *ok stays false -> straight LSD
     general = c->h_words[10] != 0;       // some group is larger: redo the ties with the general path
     if (!general && emit_sa && emitted_distinct && c->h_words[12] == 0) *emitted_distinct = true;
+    if (!general && keys_distinct && c->h_words[12] == 0) *keys_distinct = true;
   }
   if (general || c->no_small_ties) {
     PhaseScope ps(c, DC3HIP_PH_TIES, nrec);
@@ -1669,12 +1687,15 @@ template <> u64 pass1_p1<KeyT>(const KeyT &km) { return keyt_p1(km); }
 // filtered out with their full names (*state = 2); else *state stays 0.
 template <class Acc, class Map>
 static int finish_position_order(dc3hip_ctx *c, Acc acc, Map mp, u32 nrec, u32 m, u32 dummy, u32 *out_sa, u32 *out_rank,
-                                 u32 *spos, u32 *snf, int *state) {
+                                 u32 *spos, u32 *snf, int *state, bool known_distinct = false) {
+  // known_distinct: the tie pass already established that no two keys are equal (no counting pass, no host round trip)
   const Chunking ck = make_chunks(c, nrec, kBlock);
   u32 *counts = nullptr, *scounts = nullptr;
   RC(arena_alloc(c, (size_t)ck.nchunks + 16, &counts));
   RC(arena_alloc(c, (size_t)ck.nchunks + 16, &scounts));
-  {
+  if (known_distinct) {
+    c->h_words[0] = nrec;
+  } else {
     PhaseScope ps(c, DC3HIP_PH_NAMING, nrec);
     HIPC(hipMemsetAsync(c->d_words + 4, 0, sizeof(u32), c->stream));
     hipLaunchKernelGGL((k_name_count<Acc>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, acc, nrec, ck.chunk,
@@ -1683,8 +1704,8 @@ static int finish_position_order(dc3hip_ctx *c, Acc acc, Map mp, u32 nrec, u32 m
     hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, counts, ck.nchunks, c->d_words);
     KCHECK();
     HIPC(hipMemcpyAsync(c->h_words, c->d_words, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
   }
-  HIPC(hipStreamSynchronize(c->stream));
   if (c->h_words[0] == nrec) {          // every key distinct: the sorted order is the suffix array
     Rec8 *pa = nullptr, *pb = nullptr;
     if (out_rank) {
@@ -1862,10 +1883,10 @@ static int order_all_positions(dc3hip_ctx *c, KM km, Map mp, u32 m, u32 kbits, c
     PhaseScope ps(c, DC3HIP_PH_PACK, nrec);
     RC(launch_pack_all<KM>(c, km, nrec, p1.strip ? p1.hm : hm, ha, &first_table, &mgx, !fuse));
   }
-  bool sorted_ok = false, distinct = false;
+  bool sorted_ok = false, distinct = false, all_distinct = false;
   RC((hybrid_sort_core<KM>(c, km, kbits, hm, ha, hb, nrec, &h, f, &sorted_ok, depth, out_rank ? nullptr : out_sa, dummy,
                            &distinct, first_table, std::is_same<Map, MapText>::value && dummy == 0 && !out_rank, &mgx, 0, 0,
-                           fuse ? &p1 : nullptr)));
+                           fuse ? &p1 : nullptr, &all_distinct)));
   if (sorted_ok && distinct) {
     *state = 1;                            // the tie pass already wrote the suffix array
   } else if (sorted_ok) {
@@ -1875,7 +1896,7 @@ static int order_all_positions(dc3hip_ctx *c, KM km, Map mp, u32 m, u32 kbits, c
       if (dummy == 0 && out_sa && !out_rank) RC((doubling_finish<KM, AccHyb>(c, km, acc, nrec, km.window_syms(), out_sa, &finished)));
     }
     if (finished) { *state = 1; c->stats.level_sorted[0] = 6; }
-    else RC((finish_position_order<AccHyb, Map>(c, acc, mp, nrec, m, dummy, out_sa, out_rank, spos, snf, state)));
+    else RC((finish_position_order<AccHyb, Map>(c, acc, mp, nrec, m, dummy, out_sa, out_rank, spos, snf, state, all_distinct)));
   }
   arena_release(c, mk);
   return E_OK;
@@ -1918,10 +1939,13 @@ static int scatter_tuples_run(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, cons
                               TupC *t12, u32 *table0, bool *done) {
   typedef typename Out::Rec Rec;
   *done = false;
-  const u32 ntiles = (m02 + kTupTile - 1) / kTupTile;
+  // (level 0, 8-byte words: pass 1 in tiles of 6144 slots on 1024 threads, k_tup8_part1, unless DC3HIP_TUP_BIGTILE=0)
+  const bool big = kDerive && c->tup_bigtile;
+  const u32 tile1 = big ? (u32)kTup8Tile : (u32)kTupTile;
+  const u32 ntiles = (m02 + tile1 - 1) / tile1;
   const u32 tpc = std::max<u32>(1, (ntiles + 2047) / 2048);
   const u32 cpg = ((ntiles + 7) / 8 + tpc - 1) / tpc, cpx = cpg * tpc;
-  const u32 chunk = tpc * (u32)kTupTile, nchunks = (m02 + chunk - 1) / chunk;
+  const u32 chunk = tpc * tile1, nchunks = (m02 + chunk - 1) / chunk;
   const u32 nb = ((m02 - 1) >> kTupSh1) + 1;                     // buckets of 2^22 destinations (<= 1024)
   if (c->arena_bytes - c->arena_off < (size_t)m02 * 2 * sizeof(Rec) + (size_t)1024 * nchunks * 4 + ((size_t)nb << 11) + (16u << 20)) return E_OK;
   static std::atomic<bool> attr_set[16];
@@ -1966,7 +1990,20 @@ static int scatter_tuples_run(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, cons
   }
   {
     PhaseScope ps(c, DC3HIP_PH_TUPLES, m02, 3);
-    hipLaunchKernelGGL((k_tup_part1<Sym, Out>), dim3(8 * cpx), dim3(kTupNT), kTupPartSmem, c->stream, S, m, m0, m02, rank12, cpx, ntiles, nb, cur1, oa);
+    if constexpr (kDerive) {
+      if (big) {
+        static std::atomic<bool> attr8[16];
+        if (!attr8[c->device & 15]) {
+          HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tup8_part1<Sym>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTup8PartSmem));
+          attr8[c->device & 15] = true;
+        }
+        hipLaunchKernelGGL((k_tup8_part1<Sym>), dim3(8 * cpx), dim3(kTup8NT), kTup8PartSmem, c->stream, S, m, m0, m02, rank12, cpx, ntiles, nb, cur1, oa);
+      } else {
+        hipLaunchKernelGGL((k_tup_part1<Sym, Out>), dim3(8 * cpx), dim3(kTupNT), kTupPartSmem, c->stream, S, m, m0, m02, rank12, cpx, ntiles, nb, cur1, oa);
+      }
+    } else {
+      hipLaunchKernelGGL((k_tup_part1<Sym, Out>), dim3(8 * cpx), dim3(kTupNT), kTupPartSmem, c->stream, S, m, m0, m02, rank12, cpx, ntiles, nb, cur1, oa);
+    }
     KCHECK();
   }
   {
@@ -2028,14 +2065,11 @@ static int build_gather_tuples(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u64
   return E_OK;
 }
 
-// Step 3 (lib.rs:131-192): merge-path merge of the sorted sample tuples A and the sorted mod-0 tuples B into
-// out_sa[0 .. nA+nB) (and, when out_pairs != nullptr, the (pos, rank_base + k + 1) pairs of the rank inversion).
-template <class TA, class TB>
-static int merge_lists(dc3hip_ctx *c, const TA *A, u32 nA, const TB *B, u32 nB, u32 *out_sa, Rec8 *out_pairs,
-                       u32 rank_base) {
+template <int kMergeNT, int kMergeVT, class TA, class TB>
+static int merge_lists_shape(dc3hip_ctx *c, const TA *A, u32 nA, const TB *B, u32 nB, u32 *out_sa, Rec8 *out_pairs,
+                             u32 rank_base) {
   const u32 total = nA + nB;
   if (total == 0) return E_OK;
-  constexpr int kMergeNT = 1024, kMergeVT = 2;       // 2048 outputs per tile (measured best of seven shapes in round 1)
   const u32 tile = (u32)kMergeNT * kMergeVT;
   const u32 ntiles = (total + tile - 1) / tile;
   const ArenaMark mk = arena_mark(c);
@@ -2059,6 +2093,15 @@ static int merge_lists(dc3hip_ctx *c, const TA *A, u32 nA, const TB *B, u32 nB, 
   }
   arena_release(c, mk);
   return E_OK;
+}
+// Step 3 (lib.rs:131-192): merge-path merge of the sorted sample tuples A and the sorted mod-0 tuples B into
+// out_sa[0 .. nA+nB) (and, when out_pairs != nullptr, the (pos, rank_base + k + 1) pairs of the rank inversion).
+template <class TA, class TB>
+static int merge_lists(dc3hip_ctx *c, const TA *A, u32 nA, const TB *B, u32 nB, u32 *out_sa, Rec8 *out_pairs,
+                       u32 rank_base) {
+  // 1024 threads x 2 outputs: re-measured in round 4 on the compact tuples against 512 x 4, 1024 x 4, 256 x 8, 512 x 8
+  // (merge of 1.07 G suffixes: 6.2 / 7.0 / 8.0 / 10.2 / 10.7 ms, profiles/r04g_lab_shapes.jsonl)
+  return merge_lists_shape<1024, 2, TA, TB>(c, A, nA, B, nB, out_sa, out_pairs, rank_base);
 }
 
 // Steps 2 + 3 of a level (lib.rs:118-192) on compact tuples: sample tuples scattered into SA12 order (TupC), mod-0
@@ -2086,6 +2129,7 @@ static int unwind_compact(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m1, u32 m02, 
     RC(scan_digit_table(c, table0, ckc.nchunks, dbase0, 256, DC3HIP_PH_COMPACT));
     Mod0LoaderC ld; ld.t = t12;
     KeyDig dig; dig.shift = 0; dig.mask = 255;
+    // (tiles of 8192 slots; 6144 and 4096 — two blocks per CU — were measured at 5.6 and 6.1 ms against 5.2 for 716 M slots)
     RC((launch_downsweep<Tup0C, 256, Mod0LoaderC>(c, ld, z0, m02, ckc, dig, table0, dbase0, DC3HIP_PH_COMPACT)));
   }
   RC(radix_sort<Tup0C>(c, z0, z1, m0, 8, bits_of(K - 1), &zs, DC3HIP_PH_SORT0, DC3HIP_PH_SORT0, DC3HIP_PH_SORT0));
@@ -2665,6 +2709,7 @@ static int ctx_create_impl(dc3hip_ctx **out, int32_t device, int64_t max_n, dc3h
   { const char *e = getenv("DC3HIP_LEVEL_PHASES"); c->level_report = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_PACK_FUSE"); c->pack_fuse = !(e && e[0] == '0'); }
   { const char *e = getenv("DC3HIP_NO_PACK_STRIP"); c->no_pack_strip = (e && e[0] == '1'); }
+  { const char *e = getenv("DC3HIP_TUP_BIGTILE"); c->tup_bigtile = !(e && e[0] == '0'); }
   { const char *e = getenv("DC3HIP_NO_XCD_MAP"); c->no_xcd_map = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_TUP_SCATTER"); c->no_tup_scatter = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_TUP_REC8"); c->no_tup_rec8 = (e && e[0] == '1'); }

