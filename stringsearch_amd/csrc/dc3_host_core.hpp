@@ -1,0 +1,205 @@
+// dc3_host_core.hpp — error strings, the context, the bump arena, per-phase HIP-event timing, chunking
+// Host side of libdc3hip (single translation unit: included by dc3hip.hip in this order; everything here is static).
+#pragma once
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static void set_err(const char *fmt, ...) {
+  va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+}
+enum { E_OK = 0, E_ARGS = -1, E_ALLOC = -2, E_HIP = -3, E_TOOBIG = -4 };
+
+#define HIPC(expr)                                                                              \
+  do {                                                                                          \
+    hipError_t e__ = (expr);                                                                    \
+    if (e__ != hipSuccess) {                                                                    \
+      set_err("HIP error %d (%s) at %s:%d: %s", (int)e__, hipGetErrorString(e__), __FILE__,     \
+              __LINE__, #expr);                                                                 \
+      return (e__ == hipErrorOutOfMemory) ? E_ALLOC : E_HIP;                                    \
+    }                                                                                           \
+  } while (0)
+#define RC(expr) do { int rc__ = (expr); if (rc__ != E_OK) return rc__; } while (0)
+#define KCHECK() HIPC(hipGetLastError())
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+static constexpr double kHybrid12MaxPredicted = 0.75;   // 12-byte prefix sort: taken below this predicted tied fraction (the sample
+                                                        // extrapolation over-predicts on heavy-tailed repeats: 0.66 predicted, 0.08 measured on 1 GiB text)
+struct PhaseMark { int phase; hipEvent_t a, b; int64_t elems; int kclass; int depth; };
+
+struct dc3hip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int64_t max_n = 0, n = 0;
+  bool built = false;
+  bool sa_trusted = false;     // the resident SA was produced by ctx_build (a permutation), not handed in by set_sa
+  int cur_depth = 0;           // recursion level the phase marks are charged to (DC3HIP_LEVEL_PHASES report)
+  bool level_report = false;
+  int parts_trusted = 0;       // the resident array is this many verified partition arrays (0: not known to be)
+  uint8_t *d_text = nullptr;   // max_n + 64 bytes
+  u32 *d_sa = nullptr;         // max_n + 16 words
+  unsigned char *arena = nullptr;
+  size_t arena_bytes = 0, arena_off = 0, arena_peak = 0;
+  bool arena_fixed = false;    // DC3HIP_ARENA_BYTES given: never grown
+  bool arena_borrowed = false; // the arena belongs to another context (ctx_create_impl): never grown, never freed here
+  bool arena_exhausted = false; // the last E_ALLOC came from the bump allocator (not from hipMalloc)
+  // small device scratch
+  u32 *d_present = nullptr;    // [256]
+  uint16_t *d_code = nullptr;  // [256]
+  u32 *d_words = nullptr;      // [64] misc totals / error words
+  u32 *d_xcdmon = nullptr;     // [64] (block group, XCD) counts of the XCD-grouped partition kernels (xcd_note)
+  int xcd_rr = -1;             // creation-time placement probe: 1 = blocks b and b + 8 shared an XCD and the 8 groups had 8 XCDs
+  u32 *h_words = nullptr;      // pinned mirror
+  // profiling
+  bool profile = true;
+  bool no_hybrid = false;
+  bool no_small_ties = false;
+  bool no_nine_bit = false, no_rec12 = false, no_discard = false, no_fullsort = false, no_text_shortcut = false;
+  bool no_split_emit = false;
+  bool no_long_keys = false;   // DC3HIP_NO_LONG_KEYS=1: the whole-text shortcut only with 9-symbol windows (no KeyT)
+  bool no_doubling = false;    // DC3HIP_NO_DOUBLING=1: repeated windows always hand the whole-text order to level 1
+  int text_order12 = -1;       // DC3HIP_TEXT_ORDER12=1/0: whole-text shortcut on 12-byte records always / never (default: n > 2^31)
+  double hybrid_max_pred = 0.50;                      // 8-byte prefix sort of a level's samples: taken below this predicted tied fraction
+  double hybrid12_max_pred = kHybrid12MaxPredicted;   // 12-byte prefix sort: taken below this predicted tied fraction
+  u32 hybrid12_min = 1u << 22; // DC3HIP_HYBRID12_MIN: smallest level (samples) that tries it (tests lower it)
+  bool no_hybrid8 = false;     // DC3HIP_NO_HYBRID8=1 (tests): skip the 8-byte prefix sort / whole-level order of a level
+  bool no_hybrid12 = false;    // DC3HIP_NO_HYBRID12=1: no 63-bit-prefix sort on 12-byte records for keys wider than 64 bits
+  bool no_tup_scatter = false; // DC3HIP_NO_TUP_SCATTER=1: sample tuples always by the random gather
+  u32 tup_scatter_min = 1u << 25; // DC3HIP_TUP_SCATTER_MIN (tests): smallest level (samples) whose tuples are scattered
+  bool no_tup_rec8 = false;    // DC3HIP_NO_TUP_REC8=1 (tests): level 0 moves 12-byte records through the tuple scatter, as deeper levels do
+  bool no_xcd_map = false;     // DC3HIP_NO_XCD_MAP=1: window partitions without the segment -> XCD-group tile order (measurement aid)
+  bool pack_fuse = true;       // DC3HIP_PACK_FUSE=0: whole-text order of bytes with a pack kernel that WRITES the words (default: it only counts, partition pass 1 makes them on the fly)
+  bool tup_bigtile = true;     // DC3HIP_TUP_BIGTILE=0 (lab / tests): level 0's tuple scatter pass 1 in the 4096-slot, 512-thread shape of the deeper levels
+  bool no_pack_strip = false;  // DC3HIP_NO_PACK_STRIP=1: ... from an image no wider than the word (default: d1 bits wider, the bucket's own bits dropped)
+  bool no_msd = false;         // DC3HIP_NO_MSD=1: the prefix sorts always run the stable LSD passes (no bucket ordering)
+  u32 ssort_over = 24;         // splitter ordering: sample values per sub-bucket
+  u32 ssort_mean = 1400;       // splitter ordering: records per sub-bucket it aims at (capacity 4096)
+  bool no_wide_window = false; // DC3HIP_NO_WIDE_WINDOW=1: straight orderings always sort the triple (no wider window)
+  bool ssort_rec12 = false;    // DC3HIP_SSORT_REC12=1: the splitter ordering also for keys of at most 64 bits (tests)
+  bool no_pack_count = false;  // DC3HIP_NO_PACK_COUNT=1: the wide-window records are packed by their own kernel, then counted
+  bool ssort_verify = false;   // DC3HIP_SSORT_VERIFY=1 (tests): every splitter ordering checks its passes (record checksums, cursors, order); a mismatch fails the build
+  bool no_ssort = false;       // DC3HIP_NO_SSORT=1: the straight orderings always run the stable LSD passes (no splitter ordering)
+  u32 ssort_min = 1u << 23;    // DC3HIP_SSORT_MIN: fewest records the splitter ordering is used for (tests lower it)
+  u32 msd_min = 1u << 20;      // DC3HIP_MSD_MIN: fewest records the bucket ordering is used for (tests lower it)
+  bool no_tup8 = false;        // DC3HIP_NO_TUP8=1: the slot table of the merge tuples is always 16 bytes per sample
+  bool trace = false;          // DC3HIP_TRACE=1: per-level checksums of SA12 / SA0 / SA (dc3hip_stats.trace_*)
+  u64 *d_trace = nullptr;      // [3][DC3HIP_MAX_LEVELS]
+  std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
+  std::vector<PhaseMark> marks;
+  hipEvent_t ev_build_a = nullptr, ev_build_b = nullptr;
+  dc3hip_stats stats;
+  int num_cu = 256;
+};
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct ArenaMark { size_t off; };
+static ArenaMark arena_mark(dc3hip_ctx *c) { return ArenaMark{c->arena_off}; }
+static void arena_release(dc3hip_ctx *c, ArenaMark m) { c->arena_off = m.off; }
+template <class T>
+static int arena_alloc(dc3hip_ctx *c, size_t count, T **out) {
+  const size_t bytes = align_up(count * sizeof(T), 256);
+  if (c->arena_off + bytes > c->arena_bytes) {
+    set_err("device work arena exhausted: need %zu more bytes (arena %zu, used %zu)", bytes, c->arena_bytes,
+            c->arena_off);
+    c->arena_exhausted = true;
+    return E_ALLOC;
+  }
+  *out = reinterpret_cast<T *>(c->arena + c->arena_off);
+  c->arena_off += bytes;
+  c->arena_peak = std::max(c->arena_peak, c->arena_off);
+  return E_OK;
+}
+
+// Upper bound of the arena a build of n bytes can use (see DESIGN.md "Memory plan"):
+// a level of length m holds 3 index arrays of m02 (+pad) while its child runs and at most
+// 2 record arrays (16 B) or 2 tuple arrays (16 B) + 2 mod-0 tuple arrays (20 B) at its own peak.
+static size_t arena_requirement(int64_t n) {
+  size_t total = 0, held = 0;
+  int64_t m = n;
+  for (int lvl = 0; lvl < DC3HIP_MAX_LEVELS && m >= 2; lvl++) {
+    const int64_t m0 = (m + 2) / 3, m02 = m0 + m / 3;
+    const size_t keep = 4 * align_up((size_t)(m02 + 16) * 4, 256);
+    const size_t tbl = 2 * align_up((size_t)4 * 4096 * 256, 256);
+    const size_t recs = 2 * align_up((size_t)m02 * 16, 256) + 2 * align_up((size_t)m02 * 8, 256) + tbl;
+    const size_t after = 2 * align_up((size_t)m0 * 20, 256) + align_up((size_t)(m / 1024 + 16) * 4, 256) +
+                         (lvl > 0 ? 2 * align_up((size_t)m * 8, 256) : 0) + tbl;
+    const size_t tups = align_up((size_t)m02 * 16, 256) + std::max(align_up((size_t)m02 * 16, 256), after);
+    total = std::max(total, held + keep + std::max(recs, tups) + (1u << 20));
+    held += keep;
+    m = m02;
+  }
+  return total + (8u << 20);
+}
+
+// What the whole-text order (and every by-product except the LCP array) needs: two 8-byte record arrays, the image
+// side array, a flag byte per record, radix tables and the tie predictor.  A context starts with this much and grows
+// to arena_requirement() the first time a build enters the DC3 recursion (ensure_arena): high-entropy texts never
+// do, so their contexts hold half the memory and the first hipMalloc is half as long.
+static size_t arena_text_requirement(int64_t n) {
+  // (beyond 2^31 positions the whole-text order runs on 12-byte records: 2 x 12 + 1 bytes per position + tables)
+  // (+ the size tables of the bucket ordering: 2 x 8 words per sub-bucket, at most 2^20 sub-buckets)
+  return n > ((int64_t)1 << 31) ? (size_t)n * 26 + ((size_t)256 << 20) : (size_t)n * 24 + ((size_t)208 << 20);
+}
+
+// Grow the (empty) arena to at least `need` bytes.  Never shrinks; a size forced by DC3HIP_ARENA_BYTES stays as it is.
+static int ensure_arena(dc3hip_ctx *c, size_t need) {
+  if (c->arena_bytes >= need || c->arena_fixed) return E_OK;
+  if (c->arena_off != 0) { set_err("internal: arena grown while in use"); return E_HIP; }
+  HIPC(hipSetDevice(c->device));            // (callers may be on a thread whose current device is another one)
+  HIPC(hipStreamSynchronize(c->stream));
+  if (c->arena) { HIPC(hipFree(c->arena)); c->arena = nullptr; c->arena_bytes = 0; }
+  HIPC(hipMalloc(&c->arena, need));
+  c->arena_bytes = need;
+  return E_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// profiling helpers
+// ---------------------------------------------------------------------------------------------
+static hipEvent_t get_event(dc3hip_ctx *c) {
+  if (c->ev_used == c->ev_pool.size()) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    c->ev_pool.push_back(e);
+  }
+  return c->ev_pool[c->ev_used++];
+}
+struct PhaseScope {
+  dc3hip_ctx *c; size_t idx; bool on;
+  PhaseScope(dc3hip_ctx *ctx, int phase, int64_t elems = 0, int kclass = -1) : c(ctx), idx(0), on(ctx->profile) {
+    if (!on) return;
+    PhaseMark m; m.phase = phase; m.a = get_event(c); m.b = get_event(c); m.elems = elems; m.kclass = kclass; m.depth = c->cur_depth;
+    if (!m.a || !m.b) { on = false; return; }
+    (void)hipEventRecord(m.a, c->stream);
+    idx = c->marks.size(); c->marks.push_back(m);
+  }
+  ~PhaseScope() { if (on) (void)hipEventRecord(c->marks[idx].b, c->stream); }
+};
+
+static inline u32 bits_of(u64 v) { u32 b = 0; while (v) { b++; v >>= 1; } return b ? b : 1; }
+static inline int grid_for(dc3hip_ctx *c, u64 work_items, int per_block = kBlock) {
+  u64 g = (work_items + per_block - 1) / per_block;
+  const u64 cap = (u64)c->num_cu * 8;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ---------------------------------------------------------------------------------------------
+// chunking shared by the up-/down-sweep style kernels
+// ---------------------------------------------------------------------------------------------
+struct Chunking { u32 chunk, nchunks; };
+static Chunking make_chunks(dc3hip_ctx *c, u32 n, u32 tile) {
+  const u32 target_blocks = (u32)c->num_cu * 8;
+  u32 chunk = (n + target_blocks - 1) / target_blocks;
+  chunk = (chunk + tile - 1) / tile * tile;
+  if (chunk < tile) chunk = tile;
+  Chunking k; k.chunk = chunk; k.nchunks = (n + chunk - 1) / chunk;
+  if (k.nchunks == 0) k.nchunks = 1;
+  return k;
+}
+
