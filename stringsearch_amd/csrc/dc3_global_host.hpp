@@ -337,7 +337,8 @@ struct dc3hip_gctx {
   // wide mode: records of this rank's image range (w_ra / w_rb: pack / partition / sort buffers) and its shard of 64-bit
   // positions; every array with its own capacity (records / words)
   Rec16 *w_ra = nullptr, *w_rb = nullptr; u64 *w_shard = nullptr;
-  size_t w_cap_a = 0, w_cap_b = 0, w_cap_s = 0;
+  uint8_t *w_same = nullptr;            // one byte per word of the bucket ordering: same image as the word before
+  size_t w_cap_a = 0, w_cap_b = 0, w_cap_s = 0, w_cap_same = 0;
   dc3hip_gstats gs;
   char err[512] = "";
   std::vector<dc3hip_gctx *> group;             // loopback: all ranks of the group (rank 0 owns the list)
@@ -1393,17 +1394,17 @@ static int wide_msd_order(dc3hip_gctx *G, const WideKey &k, u32 ibits, u64 lo, u
   const u32 nrec = (u32)nrec64;
   *nrec_out = nrec;
   if (nrec < 4096) { arena_release(c, mk); return E_OK; }
-  u64 *wa = nullptr, *wb = nullptr; OutT *shard = nullptr;
-  RC(bufs(nrec, &wa, &wb, &shard));
+  u64 *wa = nullptr, *wb = nullptr; OutT *shard = nullptr; uint8_t *same = nullptr;
+  RC(bufs(nrec, &wa, &wb, &shard, &same));
   MsdGeom g;
   g.on = true; g.d1 = d1; g.d2 = d2; g.cpg = p1.cpg; g.ck.nchunks = p1.nchunks; g.ck.chunk = 0; g.img_lo = 0; g.ebits = E;
   HiMap hm; hm.mfix = 0; hm.shx = 0; hm.pbits = pb; hm.nbits = E; hm.exact = 0;
   Rec8 *res = nullptr, *where = nullptr; MsdRedo redo; bool ok = false;
-  RC(msd_sort(c, reinterpret_cast<Rec8 *>(wa), reinterpret_cast<Rec8 *>(wb), nrec, hm, g, table, nullptr, &res, &redo, &ok, &where, &p1));
+  RC(msd_sort(c, reinterpret_cast<Rec8 *>(wa), reinterpret_cast<Rec8 *>(wb), nrec, hm, g, table, nullptr, &res, &redo, &ok, &where, &p1, same));
   if (!ok) { arena_release(c, mk); return E_OK; }
   const u64 *h = reinterpret_cast<const u64 *>(res);
   RC(wide_tie_rounds_with(G, nrec, k, [&](const WideKey &kk) {
-    hipLaunchKernelGGL((k_wide_ties8<OutT>), dim3(grid_for(c, nrec)), dim3(kBlock), 0, c->stream, h, nrec, pb, kk, shard, c->d_words + 10);
+    hipLaunchKernelGGL((k_wide_ties8<OutT>), dim3(grid_for(c, nrec)), dim3(kBlock), 0, c->stream, h, (const uint8_t *)same, nrec, pb, kk, shard, c->d_words + 10);
   }));
   arena_release(c, mk);
   G->gs.wide_msd = 1;
@@ -1437,9 +1438,10 @@ static int gorder_text_msd(dc3hip_gctx *G, u32 sigma, bool *done, bool *tried) {
   RC(wide_splitters(G, k, &img, &lo, &hi));
   u32 nrec = 0; bool ordered = false;
   c->h_words[10] = c->h_words[11] = c->h_words[12] = 0;
-  const int rc = wide_msd_order<u32>(G, k, ibits, lo, hi, me + 1 == P, &nrec, &ordered, [&](u32 cnt, u64 **wa, u64 **wb, u32 **out) -> int {
+  const int rc = wide_msd_order<u32>(G, k, ibits, lo, hi, me + 1 == P, &nrec, &ordered, [&](u32 cnt, u64 **wa, u64 **wb, u32 **out, uint8_t **same) -> int {
     RC(arena_alloc(c, (size_t)cnt + 16, wa));
     RC(arena_alloc(c, (size_t)cnt + 16, wb));
+    RC(arena_alloc(c, (size_t)cnt + 16, same));
     *out = c->d_sa;
     return E_OK;
   });
@@ -1520,11 +1522,12 @@ static int gbuild_wide(dc3hip_gctx *G) {
     if (msd_static) {
       bool msd_done = false;
       // (two arrays of 8-byte words inside the record buffers, and the shard)
-      RC((wide_msd_order<u64>(G, k, ibits, lo, hi, me + 1 == P, &nrec, &msd_done, [&](u32 cnt, u64 **wa, u64 **wb, u64 **out) -> int {
+      RC((wide_msd_order<u64>(G, k, ibits, lo, hi, me + 1 == P, &nrec, &msd_done, [&](u32 cnt, u64 **wa, u64 **wb, u64 **out, uint8_t **same) -> int {
         RC(wide_ensure(c, &G->w_ra, &G->w_cap_a, (size_t)cnt / 2 + 16));
         RC(wide_ensure(c, &G->w_rb, &G->w_cap_b, (size_t)cnt / 2 + 16));
         RC(wide_ensure(c, &G->w_shard, &G->w_cap_s, (size_t)cnt + 16));
-        *wa = reinterpret_cast<u64 *>(G->w_ra); *wb = reinterpret_cast<u64 *>(G->w_rb); *out = G->w_shard;
+        RC(wide_ensure(c, &G->w_same, &G->w_cap_same, (size_t)cnt + 16));
+        *wa = reinterpret_cast<u64 *>(G->w_ra); *wb = reinterpret_cast<u64 *>(G->w_rb); *out = G->w_shard; *same = G->w_same;
         return E_OK;
       })));
       if (msd_done) return E_OK;
@@ -1788,6 +1791,7 @@ void dc3hip_global_destroy(dc3hip_gctx *G) {
   if (G->w_ra) (void)hipFree(G->w_ra);
   if (G->w_rb) (void)hipFree(G->w_rb);
   if (G->w_shard) (void)hipFree(G->w_shard);
+  if (G->w_same) (void)hipFree(G->w_same);
   if (G->c) dc3hip_ctx_destroy(G->c);
   delete G;
 }

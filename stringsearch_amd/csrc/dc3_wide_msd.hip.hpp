@@ -218,27 +218,27 @@ __global__ __launch_bounds__(kWideNT) void k_wide_part1(WideKey k, WideRange rg,
 // Words whose image part agrees with a neighbour's are ordered by their windows, one thread per group — k_wide_ties on
 // 8-byte words.  words[0] = a group larger than kWideTieBig, words[1] += tied words, words[2] += windows equal within k.W.
 // OutT: 64-bit positions (wide contexts) or 32-bit ones (the same order for texts below 2^32, whose slices are u32).
+// same[i] = 1 iff word i has the image part of word i - 1 (the byte the local sort leaves, MsdRecSameSink): the scan reads
+// one word and two bytes per entry instead of three words.
 template <class OutT>
-__global__ __launch_bounds__(kBlock) void k_wide_ties8(const u64 *__restrict__ h, u32 nrec, u32 pb, WideKey k, OutT *__restrict__ shard,
-                                                      u32 *words) {
+__global__ __launch_bounds__(kBlock) void k_wide_ties8(const u64 *__restrict__ h, const uint8_t *__restrict__ same, u32 nrec, u32 pb, WideKey k,
+                                                      OutT *__restrict__ shard, u32 *words) {
   __shared__ uint16_t lcode[256];
   if (threadIdx.x < 256) lcode[threadIdx.x] = k.code[threadIdx.x];
   __syncthreads();
   const u64 pmask = (1ull << pb) - 1ull;
   u32 tied = 0, dup = 0;
   for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < nrec; i += gridDim.x * kBlock) {
-    const u64 w = msd_word(h[i]);
-    const u64 a = w >> pb;
-    const bool eqp = i > 0 && (msd_word(h[i - 1]) >> pb) == a;
-    const bool eqn = i + 1 < nrec && (msd_word(h[i + 1]) >> pb) == a;
-    if (!eqp && !eqn) { shard[i] = (OutT)(w & pmask); continue; }
+    const bool eqp = same[i] != 0;
+    const bool eqn = i + 1 < nrec && same[i + 1] != 0;
+    if (!eqp && !eqn) { shard[i] = (OutT)(msd_word(h[i]) & pmask); continue; }
     tied++;
     if (eqp) continue;                                   // the group's first thread does the work
     u32 e = i + 2;
-    while (e < nrec && e - i <= kWideTieMax && (msd_word(h[e]) >> pb) == a) e++;
+    while (e < nrec && e - i <= kWideTieMax && same[e] != 0) e++;
     const u32 len = e - i;
     if (len > kWideTieMax) {
-      while (e < nrec && e - i <= kWideTieBig && (msd_word(h[e]) >> pb) == a) e++;
+      while (e < nrec && e - i <= kWideTieBig && same[e] != 0) e++;
       const u32 big = e - i;
       if (big > kWideTieBig) { words[0] = 1u; continue; }
       for (u32 x = 0; x < big; x++) {
