@@ -27,6 +27,21 @@
  *   - there is NO CPU fallback: without a usable gfx950 device the calls fail with -3.
  *
  * Plain C, no torch / HIP types in any signature.
+ *
+ * Environment (read when a context is created; NONE changes a result — every ordering is tested to give the same bytes):
+ *   policy       DC3HIP_PROFILE=1 (per-phase HIP events -> dc3hip_stats), DC3HIP_CACHE=0, DC3HIP_WORKERS_PER_DEVICE,
+ *                DC3HIP_ARENA_BYTES, DC3HIP_XCD_ASSUME=1 (keep the bucket ordering although the placement probe failed),
+ *                DC3HIP_GLOBAL_LOCAL_MAX (global mode: levels this small are finished on every rank's replica)
+ *   diagnostics  DC3HIP_TRACE=1 (stage checksums), DC3HIP_LEVEL_PHASES=1 (phase times per level on stderr),
+ *                DC3HIP_SSORT_VERIFY=1 (self-check of the splitter ordering)
+ *   test-only    force or forbid one of the orderings so that the parity suite can compare them:
+ *                DC3HIP_NO_TEXT_SHORTCUT, _NO_FULLSORT, _NO_HYBRID, _NO_HYBRID8, _NO_HYBRID12, _HYBRID12_MIN, _NO_LONG_KEYS,
+ *                _NO_DOUBLING, _TEXT_ORDER12, _NO_SPLIT_EMIT, _NO_SMALL_TIES, _NO_9BIT, _NO_REC12, _NO_DISCARD, _NO_MSD,
+ *                _MSD_MIN, _PACK_FUSE=0, _NO_PACK_STRIP, _NO_SSORT, _SSORT_MIN, _SSORT_REC12, _NO_WIDE_WINDOW,
+ *                _NO_PACK_COUNT, _NO_TUP8, _NO_TUP_SCATTER, _NO_TUP_REC8, _TUP_BIGTILE=0, _TUP_SCATTER_MIN, _NO_XCD_MAP;
+ *                global mode: DC3HIP_GLOBAL_NO_TEXT_ORDER, _GLOBAL_FORCE_DIST, _GLOBAL_FORCE_WIDE, _GLOBAL_NO_ROUTE,
+ *                DC3HIP_NO_WIDE_MSD, DC3HIP_WIDE_MSD_MIN, DC3HIP_WIDE_CORRUPT (verifier test hook)
+ * (DESIGN.md section 7 says what each one selects.)
  */
 #ifndef DC3HIP_H
 #define DC3HIP_H 1
