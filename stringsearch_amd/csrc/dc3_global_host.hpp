@@ -1398,7 +1398,7 @@ static int wide_msd_order(dc3hip_gctx *G, const WideKey &k, u32 ibits, u64 lo, u
   RC(bufs(nrec, &wa, &wb, &shard, &same));
   MsdGeom g;
   g.on = true; g.d1 = d1; g.d2 = d2; g.cpg = p1.cpg; g.ck.nchunks = p1.nchunks; g.ck.chunk = 0; g.img_lo = 0; g.ebits = E;
-  HiMap hm; hm.mfix = 0; hm.shx = 0; hm.pbits = pb; hm.nbits = E; hm.exact = 0;
+  HiMap hm; hm.mfix = 0; hm.shx = 0; hm.pbits = pb; hm.nbits = E; hm.exact = 0; hm.raw = 0;
   Rec8 *res = nullptr, *where = nullptr; MsdRedo redo; bool ok = false;
   RC(msd_sort(c, reinterpret_cast<Rec8 *>(wa), reinterpret_cast<Rec8 *>(wb), nrec, hm, g, table, nullptr, &res, &redo, &ok, &where, &p1, same));
   if (!ok) { arena_release(c, mk); return E_OK; }

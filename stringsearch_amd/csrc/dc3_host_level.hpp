@@ -538,13 +538,14 @@ static bool make_keyt(SymU8 S, u32 sigma, u32 L, u64 BL, u32 n, KeyT *km, HiMap 
   if (sigma < 2) return false;
   hm->pbits = image_bits ? 64 - image_bits : bits_of((u64)n - 1);        // positions 0..n-1 only
   hm->nbits = 64 - hm->pbits;
-  hm->shx = 0; hm->exact = 0;
+  hm->shx = 0; hm->exact = 0; hm->raw = 0;
   u32 J = 1; u64 SJ = sigma;                                             // sigma^J
   const u32 jmax = std::min<u32>(3 * L, kKeyTMaxImageSyms);
   while (J < jmax && (SJ >> std::min<u32>(hm->nbits + 2, 62)) == 0 && SJ * sigma < (1ull << 63)) { SJ *= sigma; J++; }
   if ((SJ >> hm->nbits) == 0) return false;                              // the image must be a proper scaling
   hm->mfix = (u64)(((((unsigned __int128)1) << (64 + hm->nbits)) - 1) / SJ);
   km->S = S; km->B = sigma + 1; km->BL = (u32)BL; km->L = L; km->sigma = sigma; km->J = J;
+  km->lg = (sigma & (sigma - 1)) == 0 ? bits_of((u64)sigma - 1) : 0;
   return true;
 }
 
@@ -718,10 +719,12 @@ static int build_core(dc3hip_ctx *c) {
         Key9 km; km.S = S; km.B = (u32)Bq; km.B3 = (u32)B3;
         u32 kbits = 0;
         { unsigned __int128 mx = (unsigned __int128)B3 * B3 * B3 - 1; while (mx) { kbits++; mx >>= 1; } }
-        if (wide)
-          RC(try_text_order12<Key9>(c, km, B3, make_himap(B3, kbits, (u32)n, 64 - ibits), sigma, &whole_text, &pre));
-        else
-          RC(try_text_order<Key9>(c, km, B3, make_himap(B3, kbits, (u32)n, bits_of((u64)n - 1)), sigma, &whole_text, &pre));
+        HiMap hm = make_himap(B3, kbits, (u32)n, wide ? 64 - ibits : bits_of((u64)n - 1));
+        // alphabets past half the byte values: the image is the window's leading bits as they lie in the text
+        // (HiMap::raw) — under one bit per symbol given away against the scaled key, and none of its arithmetic
+        hm.raw = sigma > 128 && !hm.exact && !c->no_raw_image ? 1u : 0u;
+        if (wide) RC(try_text_order12<Key9>(c, km, B3, hm, sigma, &whole_text, &pre));
+        else RC(try_text_order<Key9>(c, km, B3, hm, sigma, &whole_text, &pre));
       } else if (!c->no_long_keys) {
         // small alphabets: limbs of L > 3 symbols (as many as fit 32 bits), 3L-symbol windows
         u32 L = 1; u64 BL = Bq;

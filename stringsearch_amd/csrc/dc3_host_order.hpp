@@ -241,7 +241,7 @@ static HiMap make_himap(u64 B, u32 kbits, u32 m, u32 pbits = 0) {
   hm.nbits = std::min<u32>(64 - hm.pbits, kbits);
   hm.exact = kbits <= hm.nbits ? 1u : 0u;
   hm.shx = kbits > 64 ? kbits - 64 : 0;
-  hm.mfix = 0;
+  hm.mfix = 0; hm.raw = 0;
   if (!hm.exact) {
     const unsigned __int128 xmax1 = (mx >> hm.shx) + 1;                // > 2^nbits
     const unsigned __int128 num = (((unsigned __int128)1) << (64 + hm.nbits)) - 1;
@@ -1059,11 +1059,13 @@ static int order_all_positions(dc3hip_ctx *c, KM km, Map mp, u32 m, u32 kbits, c
   // save, 22.8 -> 27.9 ms.  A 5 % gain on one input class against a second variant of the dominant kernel: off by default.
   // (byte windows at level 0, name triples at the levels below; the small-alphabet windows KeyT keep a pack kernel
   //  that writes: their rolling image inside the partition pass was measured slower, 22.8 -> 27.9 ms at 1 GiB DNA)
-  constexpr bool kFusable = std::is_same<KM, Key9>::value || std::is_same<KM, Key3<SymU32>>::value;
-  const bool fuse = mg.on && c->pack_fuse && kFusable;
+  constexpr bool kKeyT = std::is_same<KM, KeyT>::value;
+  constexpr bool kFusable = std::is_same<KM, Key9>::value || std::is_same<KM, Key3<SymU32>>::value || kKeyT;
+  bool fuse = mg.on && c->pack_fuse && kFusable;
+  if constexpr (kKeyT) fuse = fuse && km.lg != 0 && c->keyt_fuse;       // (shifts only: power-of-two alphabets)
   MsdPass1Keys<KM> p1; p1.km = km; p1.hm = hm; p1.P1 = pass1_p1<KM>(km);
   MsdGeom mgx = mg;
-  if constexpr (kFusable) {
+  if constexpr (kFusable && !kKeyT) {
     // ... and since the words are made inside pass 1, they can come from an image d1 bits wider than a word has room
     // for (k_msd_part_keys<.., true>): the tie pass then finds next to nothing tied
     if (fuse && !c->no_pack_strip && hm.pbits >= 23 && !hm.exact && kbits >= hm.nbits + mg.d1) {
@@ -1071,6 +1073,7 @@ static int order_all_positions(dc3hip_ctx *c, KM km, Map mp, u32 m, u32 kbits, c
       if constexpr (std::is_same<KM, Key9>::value) limb = km.B3; else limb = km.B;
       p1.strip = true; p1.hm_plain = hm;
       p1.hm = make_himap(limb, kbits, m, hm.pbits - mg.d1);
+      p1.hm.raw = hm.raw;
       mgx.ebits = p1.hm.nbits;                       // (= hm.nbits + d1: the shifts of passes 2 and 3 follow from it)
     }
   }

@@ -404,7 +404,10 @@ __global__ __launch_bounds__(1024) void k_invperm_local(const Rec8 *__restrict__
 // uses the whole N-bit range whatever the packing base is, so as few samples as possible collide
 // (exact: the key itself fits N bits).  Any monotone map is valid for the tie-refine scheme.
 // The record is the 64-bit word (hi << pbits) | pos.
-struct HiMap { u64 mfix; u32 shx, pbits, nbits, exact; };
+// raw (Key9 only, alphabets that use most byte values): the image is the window's first nbits BITS read big-endian
+// straight off the text — no code table, no multiplies.  Byte order = code order, a bit prefix of the window is a
+// monotone map of it, and the zero padding behind the text reads as the smallest byte: valid for the tie refinement.
+struct HiMap { u64 mfix; u32 shx, pbits, nbits, exact, raw; };
 __device__ __forceinline__ u64 hyb_hi(const Rec16 &r, const HiMap &hm) {
   const u64 lo = (u64)r.k0 | ((u64)r.k1 << 32);
   if (hm.exact) return lo;
@@ -462,8 +465,17 @@ struct Key9 {
     const u32 t2 = (q[6] * B + q[7]) * B + q[8];
     return make_rec(t0, t1, t2, B3, p);
   }
-  __device__ __forceinline__ Rec8 image(u32 p, const uint16_t *lds, const HiMap &hm) const { return hyb_rec(make(p, lds), hm); }
-  __device__ __forceinline__ u64 image_hi(u32 p, const uint16_t *lds, const HiMap &hm) const { return hyb_hi(make(p, lds), hm); }
+  __device__ __forceinline__ u64 raw_hi(u32 p, const HiMap &hm) const {
+    u64 v; __builtin_memcpy(&v, S.t + p, 8);
+    return __builtin_bswap64(v) >> (64u - hm.nbits);
+  }
+  __device__ __forceinline__ Rec8 image(u32 p, const uint16_t *lds, const HiMap &hm) const {
+    if (hm.raw) { const u64 w = (raw_hi(p, hm) << hm.pbits) | p; return Rec8{(u32)(w >> 32), (u32)w}; }
+    return hyb_rec(make(p, lds), hm);
+  }
+  __device__ __forceinline__ u64 image_hi(u32 p, const uint16_t *lds, const HiMap &hm) const {
+    return hm.raw ? raw_hi(p, hm) : hyb_hi(make(p, lds), hm);
+  }
   __device__ __forceinline__ int cmp(u32 p, u32 q, const uint16_t *lds) const { return window_cmp(S, p, q, deep ? deep : 9u, lds); }
   __host__ __device__ u32 window_syms() const { return 9; }
 };
@@ -478,6 +490,7 @@ struct Key9 {
 constexpr u32 kKeyTMaxImageSyms = 48;
 struct KeyT {
   SymU8 S; u32 B, BL /* B^L */, L, sigma, J;
+  u32 lg = 0;       // sigma = 2^lg (DNA: 2): v is J*lg bits put together by shifts and the image its top nbits; 0 = scale by mfix
   u32 deep = 0;     // as Key9::deep
   __device__ __forceinline__ void stage(uint16_t *lds) const { S.stage(lds); }
   __device__ __forceinline__ Rec16 make(u32 p, const uint16_t *lds) const {
@@ -510,10 +523,10 @@ struct KeyT {
       if (k < J) {
         u32 q = (p + k < S.m) ? (u32)lds[(w[k >> 2] >> (8 * (k & 3u))) & 255u] : 0u;
         q = q ? q - 1 : 0u;
-        v = v * sigma + q;
+        v = lg ? (v << lg) | q : v * sigma + q;
       }
     }
-    return __umul64hi(v, hm.mfix);
+    return lg ? v >> (J * lg - hm.nbits) : __umul64hi(v, hm.mfix);
   }
   __device__ __forceinline__ Rec8 image(u32 p, const uint16_t *lds, const HiMap &hm) const {
     const u64 word = (image_hi(p, lds, hm) << hm.pbits) | p;
@@ -526,6 +539,15 @@ struct KeyT {
 __device__ __forceinline__ void images4(const Key9 &km, const HiMap &hm, u64, u32 p0, u32 n, const uint16_t *lcode, u64 img[4]) {
   const u32 *tw = reinterpret_cast<const u32 *>(km.S.t + p0);
   const u32 w[3] = {tw[0], tw[1], tw[2]};
+  if (hm.raw) {                                          // 12 bytes big-endian, the 4 windows are its byte shifts
+    const u64 hi = ((u64)__builtin_bswap32(w[0]) << 32) | __builtin_bswap32(w[1]);
+    const u32 lo = __builtin_bswap32(w[2]);
+    const u32 sh = 64u - hm.nbits;
+    img[0] = hi >> sh;
+#pragma unroll
+    for (int j = 1; j < 4; j++) img[j] = ((hi << (8 * j)) | (lo >> (32 - 8 * j))) >> sh;
+    return;
+  }
   u32 q[12];
 #pragma unroll
   for (int k = 0; k < 12; k++) q[k] = (p0 + k < n) ? (u32)lcode[(w[k >> 2] >> (8 * (k & 3))) & 255u] : 0u;
@@ -552,7 +574,7 @@ __device__ __forceinline__ void images4(const KeyT &km, const HiMap &hm, u64 P1,
       u32 q = (p0 + k < n) ? (u32)lcode[(w[k >> 2] >> (8 * (k & 3u))) & 255u] : 0u;
       q = q ? q - 1 : 0u;
       if (k < 3) dh[k] = q;
-      if (k < J) v = v * sigma + q;
+      if (k < J) v = km.lg ? (v << km.lg) | q : v * sigma + q;
       else if (k == J) dt0 = q;
       else if (k == J + 1) dt1 = q;
       else dt2 = q;
@@ -560,8 +582,14 @@ __device__ __forceinline__ void images4(const KeyT &km, const HiMap &hm, u64 P1,
   }
 #pragma unroll
   for (int j = 0; j < 4; j++) {
-    img[j] = __umul64hi(v, hm.mfix);
-    if (j < 3) v = (v - (u64)dh[j] * P1) * sigma + (j == 0 ? dt0 : j == 1 ? dt1 : dt2);
+    const u32 dt = j == 0 ? dt0 : j == 1 ? dt1 : dt2;
+    if (km.lg) {
+      img[j] = v >> (J * km.lg - hm.nbits);
+      if (j < 3) v = ((v & (P1 - 1)) << km.lg) | dt;
+    } else {
+      img[j] = __umul64hi(v, hm.mfix);
+      if (j < 3) v = (v - (u64)dh[j] * P1) * sigma + dt;
+    }
   }
 }
 // Key3 over a level's names: the six symbols p0 .. p0+5 loaded once (the string has >= 8 zero words behind its end)

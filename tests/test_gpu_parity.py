@@ -643,12 +643,28 @@ def test_bucket_ordering_matches_the_stable_passes(ss, oracle):
     mask = rng.random(7_000_000) < 0.97
     sk[mask] = rng.integers(0, 3, size=int(mask.sum())).astype(np.uint8)
     cases["skewed_symbols"] = sk
+    # byte alphabets take their image straight off the text bits (HiMap::raw): zero bytes against the zero padding
+    # behind the text, and repeats longer than the image but shorter than the window (tied images, distinct windows)
+    z = rng.integers(0, 256, size=5_000_000, dtype=np.uint8)
+    for at in rng.integers(0, 5_000_000 - 16, size=20_000):
+        z[at:at + int(rng.integers(1, 12))] = 0
+    z[-13:] = 0
+    cases["zero_runs"] = z
+    r = rng.integers(0, 256, size=5_000_000, dtype=np.uint8)
+    for at, src in zip(rng.integers(0, 5_000_000 - 16, size=30_000), rng.integers(0, 5_000_000 - 16, size=30_000)):
+        ln = int(rng.integers(5, 10))
+        r[at:at + ln] = r[src:src + ln].copy()
+    cases["short_repeats"] = r
+    # power-of-two alphabets below that put their image together by shifts (KeyT::lg)
+    cases["binary"] = rng.integers(0, 2, size=5_000_000).astype(np.uint8)
+    cases["hex"] = np.frombuffer(b"0123456789abcdef", dtype=np.uint8)[rng.integers(0, 16, size=5_000_000)].copy()
     for label, arr in cases.items():
         data = arr.tobytes()
         want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)
         for env in ({"DC3HIP_MSD_MIN": "4096"}, {"DC3HIP_MSD_MIN": "4096", "DC3HIP_NO_TEXT_SHORTCUT": "1"}, {"DC3HIP_NO_MSD": "1"},
                     {"DC3HIP_MSD_MIN": "4096", "DC3HIP_PACK_FUSE": "0"},        # the pack kernel writes the words, pass 1 reads them
                     {"DC3HIP_MSD_MIN": "4096", "DC3HIP_NO_PACK_STRIP": "1"},    # pass 1 makes them, from an image no wider than the word
+                    {"DC3HIP_MSD_MIN": "4096", "DC3HIP_NO_RAW_IMAGE": "1"},     # byte alphabets: the scaled 9-symbol key as the image
                     {"DC3HIP_MSD_MIN": "4096", "DC3HIP_NO_TUP_SCATTER": "1", "DC3HIP_NO_XCD_MAP": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1"}):
             os.environ.update(env)
             try:
