@@ -73,7 +73,6 @@ struct dc3hip_ctx {
   bool no_xcd_map = false;     // DC3HIP_NO_XCD_MAP=1: window partitions without the segment -> XCD-group tile order (measurement aid)
   bool pack_fuse = true;       // DC3HIP_PACK_FUSE=0: whole-text order of bytes with a pack kernel that WRITES the words (default: it only counts, partition pass 1 makes them on the fly)
   bool tup_bigtile = true;     // DC3HIP_TUP_BIGTILE=0 (lab / tests): level 0's tuple scatter pass 1 in the 4096-slot, 512-thread shape of the deeper levels
-  bool keyt_fuse = false;      // DC3HIP_KEYT_FUSE=1: small power-of-two alphabets also make their words inside partition pass 1
   bool no_raw_image = false;   // DC3HIP_NO_RAW_IMAGE=1: byte alphabets keep the scaled 9-symbol key as their sort image (default: the text's own leading bits, HiMap::raw)
   bool no_pack_strip = false;  // DC3HIP_NO_PACK_STRIP=1: ... from an image no wider than the word (default: d1 bits wider, the bucket's own bits dropped)
   bool no_msd = false;         // DC3HIP_NO_MSD=1: the prefix sorts always run the stable LSD passes (no bucket ordering)

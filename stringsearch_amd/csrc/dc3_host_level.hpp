@@ -532,23 +532,6 @@ static int build_alphabet(dc3hip_ctx *c, u32 *sigma_out) {
   return E_OK;
 }
 
-// KeyT and the map of its image (see the struct): J = fewest symbols whose base-sigma value exceeds the image width by
-// two bits, within 63 bits, the key's 3L symbols and kKeyTMaxImageSyms.  false = no such J (the caller skips the path).
-static bool make_keyt(SymU8 S, u32 sigma, u32 L, u64 BL, u32 n, KeyT *km, HiMap *hm, u32 image_bits = 0) {
-  if (sigma < 2) return false;
-  hm->pbits = image_bits ? 64 - image_bits : bits_of((u64)n - 1);        // positions 0..n-1 only
-  hm->nbits = 64 - hm->pbits;
-  hm->shx = 0; hm->exact = 0; hm->raw = 0;
-  u32 J = 1; u64 SJ = sigma;                                             // sigma^J
-  const u32 jmax = std::min<u32>(3 * L, kKeyTMaxImageSyms);
-  while (J < jmax && (SJ >> std::min<u32>(hm->nbits + 2, 62)) == 0 && SJ * sigma < (1ull << 63)) { SJ *= sigma; J++; }
-  if ((SJ >> hm->nbits) == 0) return false;                              // the image must be a proper scaling
-  hm->mfix = (u64)(((((unsigned __int128)1) << (64 + hm->nbits)) - 1) / SJ);
-  km->S = S; km->B = sigma + 1; km->BL = (u32)BL; km->L = L; km->sigma = sigma; km->J = J;
-  km->lg = (sigma & (sigma - 1)) == 0 ? bits_of((u64)sigma - 1) : 0;
-  return true;
-}
-
 // Whole-text shortcut with key maker KM (three limbs of base BL: Key9's 9 symbols or KeyT's 3L): predicted ties
 // permitting, order all n positions by their windows.  All windows distinct: that order is the suffix array
 // (*whole_text).  Otherwise the order, filtered down to level 1's samples with the dense ranks of the windows as

@@ -875,6 +875,56 @@ int launch_pack_all<KeyT>(dc3hip_ctx *c, KeyT km, u32 nrec, const HiMap &hm, Rec
   *first_table = table;
   return E_OK;
 }
+// KeyT and the map of its image (see the struct): J = fewest symbols whose base-sigma value exceeds the image width by
+// two bits, within 63 bits, the key's 3L symbols and kKeyTMaxImageSyms.  false = no such J (the caller skips the path).
+static bool make_keyt(SymU8 S, u32 sigma, u32 L, u64 BL, u32 n, KeyT *km, HiMap *hm, u32 image_bits = 0) {
+  if (sigma < 2) return false;
+  hm->pbits = image_bits ? 64 - image_bits : bits_of((u64)n - 1);        // positions 0..n-1 only
+  hm->nbits = 64 - hm->pbits;
+  hm->shx = 0; hm->exact = 0; hm->raw = 0;
+  u32 J = 1; u64 SJ = sigma;                                             // sigma^J
+  const u32 jmax = std::min<u32>(3 * L, kKeyTMaxImageSyms);
+  while (J < jmax && (SJ >> std::min<u32>(hm->nbits + 2, 62)) == 0 && SJ * sigma < (1ull << 63)) { SJ *= sigma; J++; }
+  if ((SJ >> hm->nbits) == 0) return false;                              // the image must be a proper scaling
+  hm->mfix = (u64)(((((unsigned __int128)1) << (64 + hm->nbits)) - 1) / SJ);
+  km->S = S; km->B = sigma + 1; km->BL = (u32)BL; km->L = L; km->sigma = sigma; km->J = J;
+  km->lg = (sigma & (sigma - 1)) == 0 ? bits_of((u64)sigma - 1) : 0;
+  return true;
+}
+
+// KeyT under the bucket ordering: the pack kernel writes the images alone, from a map d1 bits wider than the words' (a
+// second KeyT with more symbols), and pass 1 strips the bucket's own bits while it partitions (KeyImg) — the tie pass
+// then meets 2^-d1 of the ties, as it does for the key makers that compute their image inside pass 1.
+struct MsdPass1Img : MsdPass1 {
+  KeyImg ki; HiMap hm;                       // the wider map (hm.pbits = position bits - d1)
+  KeyT km_plain; HiMap hm_plain;             // the words' own key maker and layout (repack)
+  int repack(dc3hip_ctx *c, Rec8 *out, u32 nrec, u32 **first_table) override {
+    PhaseScope ps(c, DC3HIP_PH_PACK, nrec);
+    return launch_pack_all<KeyT>(c, km_plain, nrec, hm_plain, out, first_table, nullptr, true);
+  }
+  int launch(dc3hip_ctx *c, u64 *out, u32 n, u64 base, u32 sh1, const MsdGeom &g, u32 nb1, const u32 *plan, u32 *cur1) override {
+    static std::atomic<bool> attr_set[16];
+    if (!attr_set[c->device & 15]) {
+      HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_msd_part_keys<KeyImg, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
+      attr_set[c->device & 15] = true;
+    }
+    hipLaunchKernelGGL((k_msd_part_keys<KeyImg, true>), dim3(kMsdGroups * g.cpx1), dim3(kMsdNW * 64), kMsdPartSmem, c->stream, ki, hm, 0ull, out, n, base,
+                       sh1, g.d1, g.cpx1, g.ntiles1, plan, cur1, nb1, c->d_xcdmon);
+    KCHECK();
+    return E_OK;
+  }
+};
+static int launch_pack_images_keyt(dc3hip_ctx *c, KeyT km, u32 nrec, const HiMap &hm, Rec8 *out, u32 **first_table, const MsdGeom *mg) {
+  int nb = 0; Chunking ck; u32 hshift = 0;
+  pack_plan(c, nrec, hm, mg, &nb, &ck, &hshift);
+  u32 *table = nullptr;
+  RC(arena_alloc(c, (size_t)nb * ck.nchunks, &table));
+  hipLaunchKernelGGL((k_pack_image_textT<1024, false, true, true>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, km, nrec, hm, keyt_p1(km), (void *)out,
+                     ck.chunk, ck.nchunks, table, hshift);
+  KCHECK();
+  *first_table = table;
+  return E_OK;
+}
 template <class KM> static u64 pass1_p1(const KM &) { return 0; }
 template <> u64 pass1_p1<KeyT>(const KeyT &km) { return keyt_p1(km); }
 // The records of all m (+dummy) positions are in key order behind accessor `acc` (pos, neq): all keys distinct -> the
@@ -1060,12 +1110,11 @@ static int order_all_positions(dc3hip_ctx *c, KM km, Map mp, u32 m, u32 kbits, c
   // (byte windows at level 0, name triples at the levels below; the small-alphabet windows KeyT keep a pack kernel
   //  that writes: their rolling image inside the partition pass was measured slower, 22.8 -> 27.9 ms at 1 GiB DNA)
   constexpr bool kKeyT = std::is_same<KM, KeyT>::value;
-  constexpr bool kFusable = std::is_same<KM, Key9>::value || std::is_same<KM, Key3<SymU32>>::value || kKeyT;
-  bool fuse = mg.on && c->pack_fuse && kFusable;
-  if constexpr (kKeyT) fuse = fuse && km.lg != 0 && c->keyt_fuse;       // (shifts only: power-of-two alphabets)
+  constexpr bool kFusable = std::is_same<KM, Key9>::value || std::is_same<KM, Key3<SymU32>>::value;
+  const bool fuse = mg.on && c->pack_fuse && kFusable;
   MsdPass1Keys<KM> p1; p1.km = km; p1.hm = hm; p1.P1 = pass1_p1<KM>(km);
   MsdGeom mgx = mg;
-  if constexpr (kFusable && !kKeyT) {
+  if constexpr (kFusable) {
     // ... and since the words are made inside pass 1, they can come from an image d1 bits wider than a word has room
     // for (k_msd_part_keys<.., true>): the tie pass then finds next to nothing tied
     if (fuse && !c->no_pack_strip && hm.pbits >= 23 && !hm.exact && kbits >= hm.nbits + mg.d1) {
@@ -1077,14 +1126,29 @@ static int order_all_positions(dc3hip_ctx *c, KM km, Map mp, u32 m, u32 kbits, c
       mgx.ebits = p1.hm.nbits;                       // (= hm.nbits + d1: the shifts of passes 2 and 3 follow from it)
     }
   }
-  {
+  MsdPass1Img pimg;
+  MsdPass1 *pass1 = fuse ? &p1 : nullptr;
+  bool packed = false;
+  if constexpr (kKeyT) {
+    // KeyT: the image stays in a pack kernel (inside pass 1 it was measured slower), which writes it d1 bits wider
+    KeyT kw; HiMap hw;
+    if (mg.on && c->pack_fuse && !c->no_pack_strip && dummy == 0 && hm.pbits >= 23 && hm.nbits + mg.d1 <= 62 &&
+        make_keyt(km.S, km.sigma, km.L, km.BL, m, &kw, &hw, hm.nbits + mg.d1)) {
+      pimg.ki.img = reinterpret_cast<const u64 *>(ha); pimg.hm = hw; pimg.km_plain = km; pimg.hm_plain = hm;
+      mgx.ebits = hw.nbits;
+      PhaseScope ps(c, DC3HIP_PH_PACK, nrec);
+      RC(launch_pack_images_keyt(c, kw, nrec, hw, ha, &first_table, &mgx));
+      pass1 = &pimg; packed = true;
+    }
+  }
+  if (!packed) {
     PhaseScope ps(c, DC3HIP_PH_PACK, nrec);
     RC(launch_pack_all<KM>(c, km, nrec, p1.strip ? p1.hm : hm, ha, &first_table, &mgx, !fuse));
   }
   bool sorted_ok = false, distinct = false, all_distinct = false;
   RC((hybrid_sort_core<KM>(c, km, kbits, hm, ha, hb, nrec, &h, f, &sorted_ok, depth, out_rank ? nullptr : out_sa, dummy,
                            &distinct, first_table, std::is_same<Map, MapText>::value && dummy == 0 && !out_rank, &mgx, 0, 0,
-                           fuse ? &p1 : nullptr, &all_distinct)));
+                           pass1, &all_distinct)));
   if (sorted_ok && distinct) {
     *state = 1;                            // the tie pass already wrote the suffix array
   } else if (sorted_ok) {

@@ -563,6 +563,27 @@ __device__ __forceinline__ void images4(const KeyT &km, const HiMap &hm, u64 P1,
   const u32 J = km.J, sigma = km.sigma, nw = (J + 3 + 3) / 4;
   constexpr u32 kW = (kKeyTMaxImageSyms + 3 + 3) / 4;
   const u32 *tw = reinterpret_cast<const u32 *>(km.S.t + p0);
+  if (km.lg) {
+    // sigma = 2^lg: the 4*nw symbols as one big-endian number V of 4*nw*lg <= 128 bits, a word (4 symbols) at a time; the
+    // image of window j is V's bits below symbol j, nbits of them.  (Digit = code - 1 clamped at 0: the zero padding
+    // behind the text — absent byte or smallest symbol — reads as digit 0 without a bounds check.)
+    const u32 lg = km.lg;
+    unsigned __int128 V = 0;
+    for (u32 i = 0; i < nw; i++) {
+      const u32 w = tw[i];
+      u32 g = 0;
+#pragma unroll
+      for (u32 b = 0; b < 4; b++) {
+        const u32 cd = lcode[(w >> (8 * b)) & 255u];
+        g = (g << lg) | (cd ? cd - 1 : 0u);
+      }
+      V = (V << (4 * lg)) | g;
+    }
+    const u64 mask = hm.nbits >= 64 ? ~0ull : (1ull << hm.nbits) - 1;
+#pragma unroll
+    for (u32 j = 0; j < 4; j++) img[j] = (u64)(V >> ((4 * nw - j) * lg - hm.nbits)) & mask;
+    return;
+  }
   u32 w[kW];
 #pragma unroll
   for (u32 i = 0; i < kW; i++) w[i] = i < nw ? tw[i] : 0u;
@@ -574,7 +595,7 @@ __device__ __forceinline__ void images4(const KeyT &km, const HiMap &hm, u64 P1,
       u32 q = (p0 + k < n) ? (u32)lcode[(w[k >> 2] >> (8 * (k & 3u))) & 255u] : 0u;
       q = q ? q - 1 : 0u;
       if (k < 3) dh[k] = q;
-      if (k < J) v = km.lg ? (v << km.lg) | q : v * sigma + q;
+      if (k < J) v = v * sigma + q;
       else if (k == J) dt0 = q;
       else if (k == J + 1) dt1 = q;
       else dt2 = q;
@@ -582,14 +603,8 @@ __device__ __forceinline__ void images4(const KeyT &km, const HiMap &hm, u64 P1,
   }
 #pragma unroll
   for (int j = 0; j < 4; j++) {
-    const u32 dt = j == 0 ? dt0 : j == 1 ? dt1 : dt2;
-    if (km.lg) {
-      img[j] = v >> (J * km.lg - hm.nbits);
-      if (j < 3) v = ((v & (P1 - 1)) << km.lg) | dt;
-    } else {
-      img[j] = __umul64hi(v, hm.mfix);
-      if (j < 3) v = (v - (u64)dh[j] * P1) * sigma + dt;
-    }
+    img[j] = __umul64hi(v, hm.mfix);
+    if (j < 3) v = (v - (u64)dh[j] * P1) * sigma + (j == 0 ? dt0 : j == 1 ? dt1 : dt2);
   }
 }
 // Key3 over a level's names: the six symbols p0 .. p0+5 loaded once (the string has >= 8 zero words behind its end)
@@ -600,6 +615,19 @@ __device__ __forceinline__ void images4(const Key3<SymU32> &km, const HiMap &hm,
   for (int j = 0; j < 4; j++) img[j] = p0 + j < n ? hyb_hi(make_rec(q[j], q[j + 1], q[j + 2], km.B, 0u), hm) : 0ull;
 }
 // any other key maker: position by position
+// KeyImg: the images were written out by a pack kernel, one u64 per position and nothing else (the position is the
+// index) — how a key maker whose image is too dear to compute inside the partition pass (KeyT) still gets an image
+// wider than the word has room for (k_msd_part_keys<KeyImg, true>: pass 1 reads 8 bytes per position as before).
+struct KeyImg {
+  const u64 *img;
+  __device__ __forceinline__ void stage(uint16_t *) const {}
+};
+__device__ __forceinline__ void images4(const KeyImg &km, const HiMap &, u64, u32 p0, u32, const uint16_t *, u64 img[4]) {
+  const u32x4 *s = reinterpret_cast<const u32x4 *>(km.img + p0);       // (p0 % 4 == 0; the array is padded to a multiple of 4)
+  const u32x4 a = s[0], b = s[1];
+  img[0] = ((u64)a.x << 32) | a.y; img[1] = ((u64)a.z << 32) | a.w;       // (Rec8 order: high half first)
+  img[2] = ((u64)b.x << 32) | b.y; img[3] = ((u64)b.z << 32) | b.w;
+}
 template <class KM>
 __device__ __forceinline__ void images4(const KM &km, const HiMap &hm, u64, u32 p0, u32 n, const uint16_t *lcode, u64 img[4]) {
 #pragma unroll
@@ -610,7 +638,8 @@ __device__ __forceinline__ void images4(const KM &km, const HiMap &hm, u64, u32 
 // k_pack_image_text.  P1 = sigma^(J-1).
 // kWide: 12-byte records {image, position} (k_pack_image12_all_hist's output) instead of (image << pbits) | position.
 // kStore = false: count only (the records are made on the fly by the partition pass that follows, k_msd_part_keys).
-template <int NB, bool kWide, bool kStore = true>
+// kImageOnly: the 8-byte output is the image alone (KeyImg reads it back).
+template <int NB, bool kWide, bool kStore = true, bool kImageOnly = false>
 __global__ __launch_bounds__(kBlock) void k_pack_image_textT(KeyT km, u32 n, HiMap hm, u64 P1, void *__restrict__ outv,
                                                             u32 chunk, u32 nchunks, u32 *__restrict__ table, u32 hshift = 0) {
   __shared__ uint16_t lcode[256];
@@ -644,7 +673,7 @@ __global__ __launch_bounds__(kBlock) void k_pack_image_textT(KeyT km, u32 n, HiM
       Rec8 r[4];
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        const u64 word = (img[j] << hm.pbits) | (p0 + j);
+        const u64 word = kImageOnly ? img[j] : (img[j] << hm.pbits) | (p0 + j);
         r[j] = Rec8{(u32)(word >> 32), (u32)word};
       }
       if (p0 + 3 < end) {

@@ -84,7 +84,6 @@ static int ctx_create_impl(dc3hip_ctx **out, int32_t device, int64_t max_n, dc3h
   { const char *e = getenv("DC3HIP_NO_MSD"); c->no_msd = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_LEVEL_PHASES"); c->level_report = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_PACK_FUSE"); c->pack_fuse = !(e && e[0] == '0'); }
-  { const char *e = getenv("DC3HIP_KEYT_FUSE"); c->keyt_fuse = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_RAW_IMAGE"); c->no_raw_image = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_PACK_STRIP"); c->no_pack_strip = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_TUP_BIGTILE"); c->tup_bigtile = !(e && e[0] == '0'); }
