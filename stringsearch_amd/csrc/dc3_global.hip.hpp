@@ -98,6 +98,20 @@ struct SelPosImage {
     return img >= lo && (last || img < hi);
   }
 };
+// the selection a selecting partition pass (k_msd_part_keys<.., kSel>) makes, as plain words in position order: the image
+// comes from the map `hm` that pass uses (sel.sh bits wider than a word has room for), the word keeps its top bits
+template <class KM>
+struct SelPosImageW {
+  typedef Rec8 Out;
+  KM km; HiMap hm; MsdSel sel; u32 pbits;                // pbits: position bits of the word (= hm.pbits + sel.sh)
+  __device__ __forceinline__ void stage(uint16_t *lds) const { km.stage(lds); }
+  __device__ __forceinline__ bool pick(u32 p, const uint16_t *lds, Rec8 &o) const {
+    const u64 img = km.image_hi(p, lds, hm);
+    const u64 w = ((img >> sel.sh) << pbits) | p;
+    o = Rec8{(u32)(w >> 32), (u32)w};
+    return msd_sel_keep(sel, img);
+  }
+};
 // the same on 12-byte records (image of hm.nbits <= 63 bits beside a full 32-bit position): texts beyond 2^31 positions
 template <class KM>
 struct SelPosImage12 {

@@ -321,6 +321,7 @@ struct dc3hip_gctx {
   u64 wide_msd_min = 1ull << 22; // DC3HIP_WIDE_MSD_MIN (tests): fewest positions per rank for the wide bucket ordering
   bool wide_msd_forced = false;  // ... given explicitly: texts below 2^32 take the unrouted order at every rank count
   u32 w_depth = 0;             // wide mode: symbols the last tie pass of the last build compared (the verifier compares at least as deep)
+  bool no_select = false;      // DC3HIP_GLOBAL_NO_SELECT=1 (tests): no selecting partition pass (MsdPass1KeysSel); the routed / scanned forms as before
   bool route = true;           // DC3HIP_GLOBAL_NO_ROUTE=1: every rank evaluates all positions and keeps its key range (the round-2 form)
   dc3hip_ctx *c = nullptr;
   GComm *comm = nullptr;
@@ -553,6 +554,41 @@ static int image_splitters(dc3hip_ctx *c, const Rec8 *d_sample, u32 ns, u32 pbit
   return E_OK;
 }
 
+// Pass 1 of the bucket ordering that SELECTS (k_msd_part_keys<.., kSel>): the rank walks the replicated text / level
+// string, makes every position's image (as the single device's pass 1 does) and partitions the words of its image
+// range only.  Everything behind it — bucket sizes, pass 2, local order, tie pass — is the single device's code on a
+// P-th of the words.  m = positions walked.
+template <class KM>
+struct MsdPass1KeysSel : MsdPass1Keys<KM> {
+  MsdSel sel{0, 0, 1, 0}; u32 m = 0;
+  // (the ordering gave up before pass 2: the plain words of the selection, in position order, for the LSD passes)
+  int repack(dc3hip_ctx *c, Rec8 *out, u32 nrec, u32 **first_table) override {
+    SelPosImageW<KM> s; s.km = this->km; s.hm = this->hm; s.sel = sel; s.pbits = this->hm.pbits + sel.sh;
+    Rec8 *tmp = nullptr; u32 cnt = 0;
+    RC(select_records(c, s, m, &tmp, &cnt, DC3HIP_PH_PACK));
+    if (cnt != nrec) { set_err("internal: the selection repacked %u words of %u", cnt, nrec); return E_HIP; }
+    HIPC(hipMemcpyAsync(out, tmp, (size_t)cnt * sizeof(Rec8), hipMemcpyDeviceToDevice, c->stream));
+    *first_table = nullptr;
+    return E_OK;
+  }
+  int launch(dc3hip_ctx *c, u64 *out, u32, u64 base, u32 sh1, const MsdGeom &g, u32 nb1, const u32 *plan, u32 *cur1) override {
+    static std::atomic<bool> attr_set[16];
+    if (!attr_set[c->device & 15]) {
+      HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_msd_part_keys<KM, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
+      HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_msd_part_keys<KM, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
+      attr_set[c->device & 15] = true;
+    }
+    if (this->strip)
+      hipLaunchKernelGGL((k_msd_part_keys<KM, true, true>), dim3(kMsdGroups * g.cpx1), dim3(kMsdNW * 64), kMsdPartSmem, c->stream, this->km, this->hm,
+                         this->P1, out, m, base, sh1, g.d1, g.cpx1, g.ntiles1, plan, cur1, nb1, c->d_xcdmon, sel);
+    else
+      hipLaunchKernelGGL((k_msd_part_keys<KM, false, true>), dim3(kMsdGroups * g.cpx1), dim3(kMsdNW * 64), kMsdPartSmem, c->stream, this->km, this->hm,
+                         this->P1, out, m, base, sh1, g.d1, g.cpx1, g.ntiles1, plan, cur1, nb1, c->d_xcdmon, sel);
+    KCHECK();
+    return E_OK;
+  }
+};
+
 // ---------------------------------------------------------------------------------------------
 // Whole-level order, split by key range (the distributed form of order_all_positions): every rank orders the positions
 // p in [0, m) whose key image falls into its range by prefix sort + tie refinement.  If every key on every rank is
@@ -576,7 +612,58 @@ static int gorder_positions(dc3hip_gctx *G, KM km, u32 m, u32 kbits, const HiMap
   Rec8 *ha = nullptr, *hb = nullptr, *h = nullptr; uint8_t *f = nullptr;
   u32 nrec = 0;
   u64 img_lo = 0, img_span = 0;
-  if (G->route && hm.nbits >= 8) {
+  // SELECTED (default up to 16 ranks, key makers whose image pass 1 of the bucket ordering can make itself): no records
+  // are built or sent at all — see MsdPass1KeysSel.  A rank reads the m positions twice (count, partition) and orders
+  // m / P words; on one GPU shared by P loopback ranks that is the least total work of the three forms, and on P GPUs
+  // the walk (HBM rate) costs less than routing 8 m / P bytes over xGMI.
+  constexpr bool kFusable = std::is_same<KM, Key9>::value || std::is_same<KM, Key3<SymU32>>::value;
+  typename std::conditional<kFusable, MsdPass1KeysSel<KM>, MsdPass1Keys<KM>>::type psel;     // (the selecting kernels only where they are used)
+  MsdGeom mgx;
+  u32 *sel_table = nullptr;
+  bool selected = false;
+  if constexpr (kFusable) {
+    const MsdGeom mg = msd_geometry(c, m, hm);
+    if (!G->no_select && mg.on && c->pack_fuse && P <= 16) {
+      u64 lo = 0, hi = ~0ull;
+      {
+        u32 ns = (u32)std::min<u64>(m, (u64)2048 * P);
+        const u32 stride = std::max<u32>(1, m / ns);
+        ns = (m - 1) / stride + 1;
+        Rec8 *smp = nullptr;
+        RC(arena_alloc(c, (size_t)ns, &smp));
+        hipLaunchKernelGGL((k_pack_image_pos<KM>), dim3(grid_for(c, ns)), dim3(kBlock), 0, c->stream, km, ns, stride, hm, smp);
+        KCHECK();
+        RC(image_splitters(c, smp, ns, hm.pbits, P, me, &lo, &hi));
+      }
+      mgx = mg;
+      psel.km = km; psel.hm = hm; psel.P1 = 0; psel.m = m;
+      if (!c->no_pack_strip && hm.pbits >= 23 && !hm.exact && kbits >= hm.nbits + mg.d1) {      // (as order_all_positions)
+        u64 limb = 0;
+        if constexpr (std::is_same<KM, Key9>::value) limb = km.B3; else limb = km.B;
+        psel.strip = true; psel.hm_plain = hm;
+        psel.hm = make_himap(limb, kbits, m, hm.pbits - mg.d1);
+        psel.hm.raw = hm.raw;
+        mgx.ebits = psel.hm.nbits;
+      }
+      psel.sel = MsdSel{lo, hi, (me + 1 == P) ? 1u : 0u, psel.strip ? mg.d1 : 0u};
+      RC(arena_alloc(c, (size_t)kMsdMaxDig * mg.ck.nchunks, &sel_table));
+      {
+        PhaseScope ps(c, DC3HIP_PH_PACK, m);
+        HIPC(hipMemsetAsync(c->d_words + 33, 0, sizeof(u32), c->stream));
+        hipLaunchKernelGGL((k_msd_count_sel<KM>), dim3(mg.ck.nchunks), dim3(kBlock), 0, c->stream, km, psel.hm, 0ull, m, psel.sel, mg.ck.chunk,
+                           mg.ck.nchunks, sel_table, psel.hm.nbits - mg.d1, c->d_words + 33);
+        KCHECK();
+        HIPC(hipMemcpyAsync(c->h_words + 33, c->d_words + 33, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+      }
+      HIPC(hipStreamSynchronize(c->stream));
+      nrec = c->h_words[33];
+      RC(arena_alloc(c, (size_t)nrec + 16, &ha));            // (pass 1 makes the words: scratch of pass 2)
+      selected = true;
+      G->gs.select_p1 += 1;
+    }
+  }
+  if (selected) {
+  } else if (G->route && hm.nbits >= 8) {
     // ROUTED (default): every rank packs the records of ITS block of positions only (m / P of them), partitions them by
     // the top 8 image bits — rank h owns a contiguous digit range, chosen from a replicated sample so that the ranges hold
     // about m / P records each — and sends every record to its owner: one all-to-all of 8-byte records
@@ -671,8 +758,11 @@ static int gorder_positions(dc3hip_gctx *G, KM km, u32 m, u32 kbits, const HiMap
   RC(arena_alloc(c, (size_t)nrec + 16, &hb));
   RC(arena_alloc(c, (size_t)nrec + 16, &f));
   bool ok = true, distinct = true;
-  if (nrec) RC((hybrid_sort_core<KM>(c, km, kbits, hm, ha, hb, nrec, &h, f, &ok, depth, slice, 0, &distinct, nullptr, false, nullptr,
-                                     img_lo, img_span)));
+  if (nrec && selected)
+    RC((hybrid_sort_core<KM>(c, km, kbits, hm, ha, hb, nrec, &h, f, &ok, depth, slice, 0, &distinct, sel_table, false, &mgx, 0, 0, &psel)));
+  else if (nrec)
+    RC((hybrid_sort_core<KM>(c, km, kbits, hm, ha, hb, nrec, &h, f, &ok, depth, slice, 0, &distinct, nullptr, false, nullptr,
+                             img_lo, img_span)));
   uint64_t good = 0, ngood = 0, pre = 0, tot = 0, all[kMaxRanks];
   RC(gather_counts(cm, (ok && distinct) ? 1 : 0, &good, &ngood));
   RC(gather_counts(cm, nrec, &pre, &tot, all));
@@ -1136,7 +1226,7 @@ static int glevel(dc3hip_gctx *G, Sym S, u32 m, u64 K, int depth, u32 *out, GOut
 
 // level 0 shortcut: the whole-text order by 9-symbol (Key9) or, on small alphabets, 3L-symbol windows (KeyT), split by
 // key range (conditions as in build_core; no reuse of the order when windows repeat: the recursion decides then)
-static int gorder_text_msd(dc3hip_gctx *G, u32 sigma, bool *done, bool *tried);     // (defined behind the wide mode's pieces)
+static int gorder_text_msd(dc3hip_gctx *G, u32 sigma, bool *done, bool *tried, bool have_select);     // (defined behind the wide mode's pieces)
 template <class KM>
 static int gtext_order_with(dc3hip_gctx *G, KM km, u64 BL, const HiMap &hm, u32 sigma, bool wide, bool *done) {
   dc3hip_ctx *c = G->c;
@@ -1160,14 +1250,17 @@ static int gtext_order_with(dc3hip_gctx *G, KM km, u64 BL, const HiMap &hm, u32 
     c->stats.level_tie_pred[0] = pred;
     if (!(pred < kTextSortMaxPredicted)) return E_OK;
     bool tried = false;
-    RC(gorder_text_msd(G, sigma, done, &tried));
+    RC(gorder_text_msd(G, sigma, done, &tried, false));
     if (!tried) RC((gorder_positions12<KM>(G, km, n, kbits, hm, done)));
   } else {
     RC(predict_tie_fraction_pos<KM>(c, km, n, hm, &pred));
     c->stats.level_tie_pred[0] = pred;
     if (!text_order_worth_trying(pred, (u64)n, hm.nbits)) return E_OK;
     bool tried = false;
-    RC(gorder_text_msd(G, sigma, done, &tried));
+    // (byte windows: gorder_positions has the selecting pass 1 of the single device's own kernels, cheaper still)
+    const bool have_select = std::is_same<KM, Key9>::value && !G->no_select && c->pack_fuse && G->comm->nranks <= 16 &&
+                             msd_geometry(c, n, hm).on;
+    RC(gorder_text_msd(G, sigma, done, &tried, have_select));
     if (!tried) RC((gorder_positions<KM>(G, km, n, kbits, hm, 0, nullptr, G_TOP, done)));
   }
   if (*done) {
@@ -1191,7 +1284,9 @@ static int gtext_order(dc3hip_gctx *G, SymU8 S, u32 sigma, bool *done) {
     u32 kbits = 0;
     { unsigned __int128 mx = (unsigned __int128)B3 * B3 * B3 - 1; while (mx) { kbits++; mx >>= 1; } }
     Key9 km; km.S = S; km.B = (u32)Bq; km.B3 = (u32)B3;
-    return gtext_order_with<Key9>(G, km, B3, make_himap(B3, kbits, n, wide ? 64 - ibits : bits_of((u64)n - 1)), sigma, wide, done);
+    HiMap hm = make_himap(B3, kbits, n, wide ? 64 - ibits : bits_of((u64)n - 1));
+    hm.raw = sigma > 128 && !hm.exact && !c->no_raw_image ? 1u : 0u;       // (as build_core: byte alphabets)
+    return gtext_order_with<Key9>(G, km, B3, hm, sigma, wide, done);
   }
   if (!c->no_long_keys) {
     u32 L = 1; u64 BL = Bq;
@@ -1417,7 +1512,7 @@ static int wide_msd_order(dc3hip_gctx *G, const WideKey &k, u32 ibits, u64 lo, u
 // selection, 8-byte passes 2 and 3, tie rounds with lazily compared windows — and nothing but the text blocks has crossed
 // the transport.  Replaces the routed order (pack own block, partition by owner, all-to-all of 8-byte records, count the
 // top digit again) where the bucket ordering applies: numbers in DESIGN.md §6.  *done = false: some rank's windows repeat (or the ordering does not apply): the caller goes on as before.
-static int gorder_text_msd(dc3hip_gctx *G, u32 sigma, bool *done, bool *tried) {
+static int gorder_text_msd(dc3hip_gctx *G, u32 sigma, bool *done, bool *tried, bool have_select) {
   dc3hip_ctx *c = G->c; GComm *cm = G->comm;
   const int P = cm->nranks, me = cm->rank;
   const u64 n = (u64)G->total_n;
@@ -1430,7 +1525,7 @@ static int gorder_text_msd(dc3hip_gctx *G, u32 sigma, bool *done, bool *tried) {
   // Where it pays (total work of P loopback ranks on one GPU, 256 MiB random bytes: routed 8.1 / 9.0 ms for P = 2 / 4,
   // unrouted 8.3 / 11.5 — every rank evaluates all n positions twice): from 2^31 positions on, where the routed order
   // would sort 12-byte records with LSD passes, and for two ranks.  DC3HIP_WIDE_MSD_MIN set explicitly (tests) forces it.
-  if (!(G->wide_msd_forced || P <= 2 || bits_of(n - 1) >= 32)) return E_OK;
+  if (!(G->wide_msd_forced || (P <= 2 && !have_select) || bits_of(n - 1) >= 32)) return E_OK;
   *tried = true;
   const ArenaMark mk = arena_mark(c);
   u64 lo = 0, hi = ~0ull;
@@ -1664,6 +1759,7 @@ static void gctx_env(dc3hip_gctx *G) {
   if (const char *e = getenv("DC3HIP_GLOBAL_NO_TEXT_ORDER")) G->no_text_order = e[0] == '1';
   if (const char *e = getenv("DC3HIP_GLOBAL_FORCE_DIST")) G->force_dist = e[0] == '1';
   if (const char *e = getenv("DC3HIP_GLOBAL_NO_ROUTE")) G->route = e[0] != '1';
+  if (const char *e = getenv("DC3HIP_GLOBAL_NO_SELECT")) G->no_select = e[0] == '1';
   if (const char *e = getenv("DC3HIP_NO_WIDE_MSD")) G->no_wide_msd = e[0] == '1';
   if (const char *e = getenv("DC3HIP_WIDE_MSD_MIN")) { const long long v = atoll(e); if (v >= 0) { G->wide_msd_min = (u64)v; G->wide_msd_forced = true; } }
 }

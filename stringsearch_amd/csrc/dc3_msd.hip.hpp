@@ -209,10 +209,52 @@ __global__ __launch_bounds__(kMsdNW * 64) void k_msd_part(const u64 *__restrict_
 // bucket boundary are compared by the tie pass like any tie, consistently with their images.  Inside the tile the
 // position field of the LDS copy carries (digit, tile-local index) instead — the position is begin + index — so the
 // digit survives the reorder without a second LDS array.  Needs hm.pbits + dbits >= 23.
-template <class KM, bool kStrip>
-__global__ __launch_bounds__(kMsdNW * 64) void k_msd_part_keys(KM km, HiMap hm, u64 P1, u64 *__restrict__ out, u32 n, u64 base, u32 shift,
+// kSel (one rank of the global mode, "replicate what is read at random, split the work by key range"): the tile is still
+// 8192 consecutive positions of the REPLICATED text / level, but only the words whose image lies in the rank's range are
+// partitioned — the buckets are those of the whole image range, a rank simply fills its share of them, and a tile's runs
+// are as long as the single device's (a P-th of the words into a P-th of the buckets).
+// (MsdSel: dc3_order.hip.hpp)
+// the counting pack kernel of a selecting pass 1: table[d * nchunks + chunk] = selected words of bucket d in the chunk
+// (hshift = image bits below the bucket's), *total += all of them
+template <class KM>
+__global__ __launch_bounds__(kBlock) void k_msd_count_sel(KM km, HiMap hm, u64 P1, u32 n, MsdSel sel, u32 chunk, u32 nchunks,
+                                                         u32 *__restrict__ table, u32 hshift, u32 *__restrict__ total) {
+  __shared__ uint16_t lcode[256];
+  __shared__ u32 hist[kWaves][kMsdMaxDig];
+  __shared__ u32 bsum;
+  km.stage(lcode);
+#pragma unroll
+  for (int w = 0; w < kWaves; w++)
+    for (int j = threadIdx.x; j < (int)kMsdMaxDig; j += kBlock) hist[w][j] = 0;
+  if (threadIdx.x == 0) bsum = 0;
+  __syncthreads();
+  u32 *myh = hist[wave_id()];
+  const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);       // chunk is a multiple of 4
+  for (u32 p0 = begin + 4 * threadIdx.x; p0 < end; p0 += 4 * kBlock) {
+    u64 img[4];
+    images4(km, hm, P1, p0, n, lcode, img);
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (p0 + j < end && msd_sel_keep(sel, img[j])) atomicAdd(&myh[(u32)(img[j] >> hshift) & (kMsdMaxDig - 1)], 1u);
+  }
+  __syncthreads();
+  u32 mine = 0;
+  for (int j = threadIdx.x; j < (int)kMsdMaxDig; j += kBlock) {
+    u32 sum = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; w++) sum += hist[w][j];
+    table[(size_t)j * nchunks + blockIdx.x] = sum;
+    mine += sum;
+  }
+  if (mine) atomicAdd(&bsum, mine);
+  __syncthreads();
+  if (threadIdx.x == 0 && bsum) atomicAdd(total, bsum);
+}
+template <class KM, bool kStrip, bool kSel = false>
+__global__ __launch_bounds__(kMsdNW * 64, 8) void k_msd_part_keys(KM km, HiMap hm, u64 P1, u64 *__restrict__ out, u32 n, u64 base, u32 shift,
                                                               u32 dbits, u32 cpx, u32 ntiles, const u32 *__restrict__ plan,
-                                                              u32 *__restrict__ cursors, u32 gstride, u32 *__restrict__ xcdmon) {
+                                                              u32 *__restrict__ cursors, u32 gstride, u32 *__restrict__ xcdmon,
+                                                              MsdSel sel = MsdSel{0, 0, 1, 0}) {
   constexpr int NT = kMsdNW * 64;
   static_assert(kMsdIPT == 8, "two rounds of 4 positions per thread");
   static_assert(kMsdTile == 8192 && kMsdMaxDig == 1024, "kStrip keeps (digit, index) in 10 + 13 bits");
@@ -237,7 +279,8 @@ __global__ __launch_bounds__(kMsdNW * 64) void k_msd_part_keys(KM km, HiMap hm, 
   const u32 pb = hm.pbits + (kStrip ? dbits : 0u);                 // position bits of the stored word
   const u32 rbits = hm.nbits - dbits;                              // (kStrip) image bits the word keeps
   u64 r[kMsdIPT];
-  u32 rk[kMsdIPT], dg[kMsdIPT];
+  u32 rk[kMsdIPT], dg[kMsdIPT];       // kStrip: the digit rides in the word (bits 13..22), dg[] is not kept
+  auto digit = [&](int k) -> u32 { return kStrip ? (u32)(r[k] >> 13) & mask : dg[k]; };
 #pragma unroll
   for (int k = 0; k < 2; k++) {
     const u32 p0 = begin + (u32)(k * NT + tid) * 4u;
@@ -245,22 +288,21 @@ __global__ __launch_bounds__(kMsdNW * 64) void k_msd_part_keys(KM km, HiMap hm, 
     if (p0 < end) images4(km, hm, P1, p0, n, lcode, img);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
+      const u32 t = (u32)(k * NT + tid) * 4u + (u32)j;
       if (kStrip) {
-        const u32 t = (u32)(k * NT + tid) * 4u + (u32)j;
-        dg[k * 4 + j] = (u32)(img[j] >> rbits) & mask;
-        r[k * 4 + j] = ((img[j] & ((1ull << rbits) - 1ull)) << pb) | ((u64)dg[k * 4 + j] << 13) | t;
+        r[k * 4 + j] = ((img[j] & ((1ull << rbits) - 1ull)) << pb) | ((u64)((u32)(img[j] >> rbits) & mask) << 13) | t;
       } else {
         r[k * 4 + j] = (img[j] << hm.pbits) | (u64)(p0 + j);
         dg[k * 4 + j] = (u32)((r[k * 4 + j] - base) >> shift) & mask;
       }
+      // rk = ~0: not a word of this tile (past the end, or — kSel — not in this rank's image range)
+      rk[k * 4 + j] = (t < nvalid && (!kSel || msd_sel_keep(sel, img[j]))) ? 0u : ~0u;
     }
   }
   // word k * 4 + j of thread tid is tile element t = (k * NT + tid) * 4 + j
 #pragma unroll
-  for (int k = 0; k < kMsdIPT; k++) {
-    const u32 t = (u32)((k >> 2) * NT + tid) * 4u + (k & 3);
-    if (t < nvalid) rk[k] = atomicAdd(&hist[dg[k]], 1u);
-  }
+  for (int k = 0; k < kMsdIPT; k++)
+    if (rk[k] != ~0u) rk[k] = atomicAdd(&hist[digit(k)], 1u);
   __syncthreads();
   u32 cnt = 0;
   if (tid < ndig) {
@@ -272,12 +314,11 @@ __global__ __launch_bounds__(kMsdNW * 64) void k_msd_part_keys(KM km, HiMap hm, 
   hist[tid] = ex;
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < kMsdIPT; k++) {
-    const u32 t = (u32)((k >> 2) * NT + tid) * 4u + (k & 3);
-    if (t < nvalid) srec[hist[dg[k]] + rk[k]] = r[k];
-  }
+  for (int k = 0; k < kMsdIPT; k++)
+    if (rk[k] != ~0u) srec[hist[digit(k)] + rk[k]] = r[k];
   __syncthreads();
-  for (u32 q = tid; q < nvalid; q += NT) {
+  const u32 nout = kSel ? tot : nvalid;              // (tot = the tile's selected words)
+  for (u32 q = tid; q < nout; q += NT) {
     const u64 x = srec[q];
     if (kStrip) {
       const u32 dd = (u32)(x >> 13) & mask;

@@ -408,6 +408,12 @@ __global__ __launch_bounds__(1024) void k_invperm_local(const Rec8 *__restrict__
 // straight off the text — no code table, no multiplies.  Byte order = code order, a bit prefix of the window is a
 // monotone map of it, and the zero padding behind the text reads as the smallest byte: valid for the tie refinement.
 struct HiMap { u64 mfix; u32 shx, pbits, nbits, exact, raw; };
+// an image range (one rank's share of the global mode's orderings), tested sh bits above the image's lowest
+struct MsdSel { u64 lo, hi; u32 last, sh; };                  // keep image x iff lo <= (x >> sh) and ((x >> sh) < hi or last)
+__device__ __forceinline__ bool msd_sel_keep(const MsdSel &s, u64 img) {
+  const u64 v = img >> s.sh;
+  return v >= s.lo && (s.last || v < s.hi);
+}
 __device__ __forceinline__ u64 hyb_hi(const Rec16 &r, const HiMap &hm) {
   const u64 lo = (u64)r.k0 | ((u64)r.k1 << 32);
   if (hm.exact) return lo;

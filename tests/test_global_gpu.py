@@ -316,6 +316,52 @@ def test_unrouted_bucket_order_of_texts_below_2pow32(ss, oracle):
                     assert np.array_equal(g.sa(), want), (name, P, "second build")
 
 
+def test_selecting_partition_pass_of_the_global_orderings(ss, oracle):
+    """The default form of the global mode's whole-text and whole-level orderings (MsdPass1KeysSel): every rank walks its
+    replica of the string, and partition pass 1 of the single device's bucket ordering keeps the words of the rank's image
+    range only — no records built, none routed.  Forced onto small inputs (DC3HIP_MSD_MIN=4096): same array as the
+    reference for random bytes (top level: byte images straight off the text bits), bytes with zero runs against the zero
+    padding and short repeats (tied images, distinct windows), a planted long repeat and generated text (the recursion:
+    name triples selected at the levels below), for 2, 3, 4 and 7 ranks, with and without the wider image; and the
+    previous forms behind DC3HIP_GLOBAL_NO_SELECT=1."""
+    rng = np.random.default_rng(404)
+    n = 5_000_011
+    rnd = rng.integers(0, 256, size=n, dtype=np.uint8)
+    z = rnd.copy()
+    for at in rng.integers(0, n - 16, size=20_000):
+        z[at:at + int(rng.integers(1, 12))] = 0
+    z[-13:] = 0
+    rep = rnd.copy()
+    for at, src in zip(rng.integers(0, n - 16, size=30_000), rng.integers(0, n - 16, size=30_000)):
+        ln = int(rng.integers(5, 10))
+        rep[at:at + ln] = rep[src:src + ln].copy()
+    long_ = rnd.copy(); long_[1_000_000:1_400_000] = long_[3_000_000:3_400_000]
+    text = oracle.gen(3_000_001, 5, 2)
+    for name, t in (("random", rnd), ("zero_runs", z), ("short_repeats", rep), ("long_repeat", long_), ("text", text)):
+        want = want_sa(oracle, t)
+        for P in (2, 3, 4, 7):
+            # (without the whole-text order random bytes reach level 1 with 16 M names: its whole-level order selects name triples)
+            for extra in ({}, {"DC3HIP_NO_PACK_STRIP": "1"}, {"DC3HIP_GLOBAL_NO_SELECT": "1"}, {"DC3HIP_GLOBAL_NO_TEXT_ORDER": "1", "DC3HIP_GLOBAL_LOCAL_MAX": "64"}):
+                if extra and P in (3, 7):
+                    continue
+                if "DC3HIP_GLOBAL_NO_TEXT_ORDER" in extra and name != "random":
+                    continue
+                with env(DC3HIP_MSD_MIN=4096, **extra):
+                    with ss.LoopbackGroup(P, len(t)) as g:
+                        g.set_text(t)
+                        g.build()
+                        st = g.stats()
+                        assert np.array_equal(g.sa(), want), (name, P, extra)
+                        if "DC3HIP_GLOBAL_NO_SELECT" in extra:
+                            assert all(s["select_p1"] == 0 for s in st), (name, P)
+                        elif name in ("random", "zero_runs", "short_repeats"):
+                            assert all(s["select_p1"] >= 1 for s in st), (name, P, extra, [s["select_p1"] for s in st])
+                            if name == "random" and "DC3HIP_GLOBAL_NO_TEXT_ORDER" not in extra:       # (nothing but the text blocks crossed the transport)
+                                assert all(s["text_order"] == 1 and s["comm_bytes_in"] <= len(t) + 4096 for s in st), (name, P)
+                        g.build()
+                        assert np.array_equal(g.sa(), want), (name, P, extra, "second build")
+
+
 def test_transport_selftest_and_recovery_after_a_failed_collective(ss, oracle):
     """dc3hip_global_selftest (ragged all-to-all / all-gather of known bytes, every byte checked) on loopback groups, and
     the failure semantics of the header: after a collective that failed on every rank (a one-symbol text in a wide
