@@ -317,7 +317,7 @@ __global__ __launch_bounds__(kTupNT) void k_tup_part2(const typename Out::Rec *_
 constexpr int kTup8NT = 1024, kTup8IPT = 6, kTup8Tile = kTup8NT * kTup8IPT;
 constexpr size_t kTup8PartSmem = sizeof(u64) * kTup8Tile + sizeof(uint16_t) * kTup8Tile + sizeof(u32) * (2 * 1024 + 64);
 template <class Sym>
-__global__ __launch_bounds__(kTup8NT) void k_tup8_part1(Sym S, u32 m, u32 m0, u32 m02, const u32 *__restrict__ rank12, u32 cpx,
+__global__ __launch_bounds__(kTup8NT, 8) void k_tup8_part1(Sym S, u32 m, u32 m0, u32 m02, const u32 *__restrict__ rank12, u32 cpx,
                                                        u32 ntiles, u32 ndig, u32 *__restrict__ cursors /*[8][ndig]*/,
                                                        TupOut8 out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

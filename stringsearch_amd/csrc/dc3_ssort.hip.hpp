@@ -134,7 +134,7 @@ __global__ __launch_bounds__(kBlock) void k_ss_splitters(const Rec *__restrict__
 // Sizes of the coarse buckets per group: block j belongs to group g = j % 8 and counts tiles
 // [g * cpx + idx * tpb, ... + tpb) of that group's eighth (idx = j / 8); cntg[d * 8 + g] += its counts.
 template <class Rec>
-__global__ __launch_bounds__(kSsNT) void k_ss_count1(const Rec *__restrict__ in, u32 n, const SsVal *__restrict__ coarse, u32 nb1,
+__global__ __launch_bounds__(kSsNT, 8) void k_ss_count1(const Rec *__restrict__ in, u32 n, const SsVal *__restrict__ coarse, u32 nb1,
                                                     u32 tile, u32 cpx, u32 ntiles, u32 tpb, u32 *__restrict__ cntg,
                                                     uint16_t *__restrict__ dig) {
   __shared__ SsVal spl[kSsMaxDig];
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(kBlock) void k_ss_sample_window(Sym S, u32 sb, u32 
   out[i] = ss_window_at<Sym, W>(S, ss_sample_index(i, n, Sn), sb);
 }
 template <class Sym, int W>
-__global__ __launch_bounds__(kSsNT) void k_ss_pack_count1(Sym S, u32 sb, Rec16 *__restrict__ recs, u32 n, const SsVal *__restrict__ coarse,
+__global__ __launch_bounds__(kSsNT, 8) void k_ss_pack_count1(Sym S, u32 sb, Rec16 *__restrict__ recs, u32 n, const SsVal *__restrict__ coarse,
                                                          u32 nb1, u32 tile, u32 cpx, u32 ntiles, u32 tpb, u32 *__restrict__ cntg,
                                                          uint16_t *__restrict__ dig) {
   __shared__ SsVal spl[kSsMaxDig];
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(1024) void k_ss_plan1(const u32 *__restrict__ cntg,
 //   cursors[g * gstride + b * F2 + digit].
 // Not stable.
 template <class Rec, bool kSeg>
-__global__ __launch_bounds__(kSsNT) void k_ss_part(const Rec *__restrict__ in, Rec *__restrict__ out, u32 n, const uint16_t *__restrict__ dig,
+__global__ __launch_bounds__(kSsNT, 8) void k_ss_part(const Rec *__restrict__ in, Rec *__restrict__ out, u32 n, const uint16_t *__restrict__ dig,
                                                   u32 F2, u32 cpx, u32 ntiles, const u32 *__restrict__ tpre,
                                                   const u32 *__restrict__ bstart, u32 nb1, const u32 *__restrict__ plan,
                                                   u32 *__restrict__ cursors, u32 gstride) {
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(kSsNT) void k_ss_part(const Rec *__restrict__ in, R
 // ds_add_u32 pending around the loop's back-edge — counts off by a few records; tools/isa_barrier_scan.py
 // checks every barrier of every kernel for this.)
 template <class Rec>
-__global__ __launch_bounds__(kSsNT) void k_ss_hist2(const Rec *__restrict__ in, const SsVal *__restrict__ fine, u32 F2, u32 tile,
+__global__ __launch_bounds__(kSsNT, 8) void k_ss_hist2(const Rec *__restrict__ in, const SsVal *__restrict__ fine, u32 F2, u32 tile,
                                                    const u32 *__restrict__ tpre, const u32 *__restrict__ tpreh,
                                                    const u32 *__restrict__ bstart, u32 nb1, const u32 *__restrict__ plan,
                                                    u32 *__restrict__ cnt2g, uint16_t *__restrict__ dig) {
