@@ -313,6 +313,7 @@ typedef struct dc3hip_gstats {
   double  wall_ms;           /* host wall time of dc3hip_global_build on this rank */
   int64_t wide_msd;          /* wide mode: 1 = this rank's order came from the bucket ordering on 8-byte words, 0 = 16-byte LSD passes */
   int64_t select_p1;         /* orderings of this rank whose partition pass 1 selected the rank's key range from the replicated string (no records built or routed) */
+  int64_t wide_deepen_rounds; /* wide mode: rounds of deepening by rank look-ups (windows repeated beyond the symbol compares; 0 = not needed) */
 } dc3hip_gstats;
 
 /* P loopback ranks on `device` (-1 = current), each able to take part in builds of up to max_total_n bytes.

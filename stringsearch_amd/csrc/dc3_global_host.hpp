@@ -340,6 +340,11 @@ struct dc3hip_gctx {
   Rec16 *w_ra = nullptr, *w_rb = nullptr; u64 *w_shard = nullptr;
   uint8_t *w_same = nullptr;            // one byte per word of the bucket ordering: same image as the word before
   size_t w_cap_a = 0, w_cap_b = 0, w_cap_s = 0, w_cap_same = 0;
+  // wide mode, deepening by rank look-ups (wide_deepen): the whole order, its equal-window flags and its inverse on every rank
+  u64 *w_sa_all = nullptr, *w_isa = nullptr; uint8_t *w_eq_all = nullptr, *w_eq2 = nullptr;
+  size_t w_cap_sa = 0, w_cap_isa = 0, w_cap_eq = 0, w_cap_eq2 = 0;
+  bool w_isa_valid = false;             // the last build ended with w_isa = the exact inverse of the order (the verifier uses it)
+  bool no_wide_deepen = false;          // DC3HIP_NO_WIDE_DEEPEN=1 (tests): windows that repeat beyond the symbol compares' budget are refused, as before round 4
   dc3hip_gstats gs;
   char err[512] = "";
   std::vector<dc3hip_gctx *> group;             // loopback: all ranks of the group (rank 0 owns the list)
@@ -1363,7 +1368,10 @@ static int wide_tie_rounds_with(dc3hip_gctx *G, u32 nrec, WideKey k, Launch laun
       if (c->h_words[10] != 0 || c->h_words[12] == 0) break;
       if (round == 0) { if (c->h_words[12] > (1u << 20)) break; depth = kWideWindowDeep; continue; }
       const u64 next = (u64)depth * 16;
-      if (next > kWideMaxDepth || (u64)c->h_words[12] * next > kWideTieBudget) break;
+      // (with the deepening by rank look-ups behind it, a symbol round is only worth its reads while they stay below what
+      //  one exchange of the shards moves)
+      const u64 budget = G->no_wide_deepen ? kWideTieBudget : std::max<u64>(1ull << 28, 4 * (u64)G->total_n);
+      if (next > kWideMaxDepth || (u64)c->h_words[12] * next > budget) break;
       depth = (u32)next;
     }
     return E_OK;
@@ -1555,12 +1563,88 @@ static int gorder_text_msd(dc3hip_gctx *G, u32 sigma, bool *done, bool *tried, b
   return E_OK;
 }
 
+template <class T> static void wide_release(T **p, size_t *cap) { if (*p) (void)hipFree(*p); *p = nullptr; *cap = 0; }
+// Deepening by rank look-ups (kernels and the idea: dc3_wide.hip.hpp): collective; entered when some rank's windows still
+// agree after the last symbol compare (depth G->w_depth) and no rank met an oversized group.  Every round all ranks
+// exchange their shards and equal-window flags (9 bytes per suffix of the text), build the inverse, and order their
+// groups by kWideDeepenW + 1 rank look-ups per compare.  *ok = every window of every rank is distinct now; the shards are
+// in suffix order and G->w_isa is the exact inverse (kept for the verifier).  *ok = false: no memory, or an oversized group.
+constexpr u32 kWideDeepenW = 16;
+static int wide_deepen(dc3hip_gctx *G, WideKey k, u32 nrec, u64 pre, const uint64_t *all, bool *ok) {
+  dc3hip_ctx *c = G->c; GComm *cm = G->comm;
+  const int P = cm->nranks;
+  const u64 n = k.n;
+  *ok = false;
+  HIPC(hipStreamSynchronize(c->stream));
+  wide_release(&G->w_ra, &G->w_cap_a);                     // the sort's buffers are done with: room for the whole order
+  wide_release(&G->w_rb, &G->w_cap_b);
+  int rc_alloc = wide_ensure(c, &G->w_sa_all, &G->w_cap_sa, (size_t)n + 16);
+  if (rc_alloc == E_OK) rc_alloc = wide_ensure(c, &G->w_isa, &G->w_cap_isa, (size_t)n + 16);
+  if (rc_alloc == E_OK) rc_alloc = wide_ensure(c, &G->w_eq_all, &G->w_cap_eq, (size_t)n + 16);
+  if (rc_alloc == E_OK) rc_alloc = wide_ensure(c, &G->w_eq2, &G->w_cap_eq2, (size_t)nrec + 16);
+  if (rc_alloc != E_OK && rc_alloc != E_ALLOC) return rc_alloc;
+  uint64_t badp = 0, nbad = 0;
+  RC(gather_counts(cm, rc_alloc != E_OK ? 1u : 0u, &badp, &nbad));
+  if (nbad) return E_OK;                                   // (every rank returns here: the caller refuses the text as before)
+  size_t roff8[kMaxRanks], rb8[kMaxRanks], roff1[kMaxRanks], rb1[kMaxRanks];
+  { u64 acc = 0; for (int r = 0; r < P; r++) { roff8[r] = (size_t)acc * 8; rb8[r] = (size_t)all[r] * 8; roff1[r] = (size_t)acc; rb1[r] = (size_t)all[r]; acc += all[r]; } }
+  // the depth the look-ups start from: what EVERY rank's symbol compares reached (a rank stops deepening them by its own
+  // count of agreeing windows; its shard is in order at least that deep)
+  u64 D = G->w_depth;
+  { uint64_t mine = G->w_depth, depths[kMaxRanks]; RC(cm->all_gather_host(&mine, depths, sizeof(uint64_t))); for (int r = 0; r < P; r++) D = std::min<u64>(D, depths[r]); }
+  k.W = (u32)D;
+  if (nrec) {
+    PhaseScope ps(c, DC3HIP_PH_TIES, nrec);
+    hipLaunchKernelGGL(k_wide_eq, dim3(grid_for(c, nrec)), dim3(kBlock), 0, c->stream, (const u64 *)G->w_shard, nrec, k, G->w_eq_all + pre);
+    KCHECK();
+  }
+  bool final_round = false;
+  for (int round = 0; round < 40; round++) {
+    if (nrec) HIPC(hipMemcpyAsync(G->w_sa_all + pre, G->w_shard, (size_t)nrec * 8, hipMemcpyDeviceToDevice, c->stream));
+    RC(cm->all_gather_v(G->w_sa_all + pre, (size_t)nrec * 8, G->w_sa_all, roff8, rb8, c->stream));
+    RC(cm->all_gather_v(G->w_eq_all + pre, (size_t)nrec, G->w_eq_all, roff1, rb1, c->stream));
+    G->gs.exchanges += 1;
+    {
+      PhaseScope ps(c, DC3HIP_PH_RANKS, n);
+      HIPC(hipMemsetAsync(G->w_isa + n, 0, 8, c->stream));
+      hipLaunchKernelGGL(k_wide_isa_scatter, dim3(grid_for(c, n)), dim3(kBlock), 0, c->stream, (const u64 *)G->w_sa_all, (const uint8_t *)G->w_eq_all, n, G->w_isa);
+      KCHECK();
+    }
+    if (final_round) { *ok = true; break; }
+    HIPC(hipMemsetAsync(c->d_words + 10, 0, 3 * sizeof(u32), c->stream));
+    if (nrec) {
+      PhaseScope ps(c, DC3HIP_PH_TIES, nrec);
+      hipLaunchKernelGGL(k_wide_ties_isa, dim3(grid_for(c, nrec)), dim3(kBlock), 0, c->stream, G->w_shard, (const uint8_t *)(G->w_eq_all + pre), nrec,
+                         (const u64 *)G->w_isa, n, D, kWideDeepenW, G->w_eq2, c->d_words + 10);
+      KCHECK();
+      HIPC(hipMemcpyAsync(G->w_eq_all + pre, G->w_eq2, (size_t)nrec, hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIPC(hipMemcpyAsync(c->h_words + 10, c->d_words + 10, 3 * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    G->gs.wide_deepen_rounds += 1;
+    uint64_t p0 = 0, nover = 0, ntied = 0;
+    RC(gather_counts(cm, c->h_words[10] ? 1u : 0u, &p0, &nover));
+    RC(gather_counts(cm, c->h_words[12] ? 1u : 0u, &p0, &ntied));
+    if (nover) break;
+    D *= (u64)kWideDeepenW + 1;
+    if (!ntied) final_round = true;                        // (one more exchange: the inverse of the finished order)
+    else if (D > 2 * n) { set_err("internal: suffixes still tied %llu symbols deep", (unsigned long long)D); return E_HIP; }
+  }
+  if (*ok) { G->w_isa_valid = true; c->h_words[10] = 0; c->h_words[12] = 0; G->w_depth = (u32)std::min<u64>(D, 1u << 30); }
+  return E_OK;
+}
+
 static int gbuild_wide(dc3hip_gctx *G) {
   dc3hip_ctx *c = G->c; GComm *cm = G->comm;
   const int P = cm->nranks, me = cm->rank;
   const u64 n = (u64)G->total_n;
   c->n = 0;
   c->arena_off = 0;
+  G->w_isa_valid = false;
+  if (G->w_sa_all || G->w_isa) {             // (a deepened build's whole-order arrays: the sort needs the room again)
+    HIPC(hipStreamSynchronize(c->stream));
+    wide_release(&G->w_sa_all, &G->w_cap_sa); wide_release(&G->w_isa, &G->w_cap_isa); wide_release(&G->w_eq_all, &G->w_cap_eq); wide_release(&G->w_eq2, &G->w_cap_eq2);
+  }
   RC(ensure_arena(c, (size_t)256 << 20));   // the sorts' tables: digit table 8 MB, 2 x 2^20 sub-buckets x 8 groups x 4 bytes, counts
   RC(build_begin(c));
   {
@@ -1667,11 +1751,21 @@ static int gbuild_wide(dc3hip_gctx *G) {
   arena_release(c, mk);
   c->stats.level_tied[0] = c->h_words[11];
   const bool mine_ok = local_rc == E_OK && c->h_words[10] == 0 && c->h_words[12] == 0;
-  uint64_t good = 0, ngood = 0, pre = 0, tot = 0;
+  uint64_t good = 0, ngood = 0, pre = 0, tot = 0, all[kMaxRanks];
   RC(agree(local_rc));
   RC(gather_counts(cm, mine_ok ? 1 : 0, &good, &ngood));
-  RC(gather_counts(cm, nrec, &pre, &tot));
+  RC(gather_counts(cm, nrec, &pre, &tot, all));
   if (tot != n) { set_err("wide global order: %llu of %llu positions selected", (unsigned long long)tot, (unsigned long long)n); return E_HIP; }
+  if (ngood != (uint64_t)P && !G->no_wide_deepen) {
+    // windows repeat beyond what the symbol compares settle: rank look-ups (wide_deepen), unless a group is oversized
+    uint64_t p0 = 0, nover = 0;
+    RC(gather_counts(cm, c->h_words[10] ? 1u : 0u, &p0, &nover));
+    if (!nover) {
+      bool deep_ok = false;
+      RC(wide_deepen(G, k, nrec, pre, all, &deep_ok));
+      if (deep_ok) ngood = (uint64_t)P;
+    }
+  }
   if (ngood != (uint64_t)P) {
     set_err("wide global mode: some %u-symbol window of the text repeats; texts of 2^32 bytes and more are only built when all windows "
             "are distinct (no recursion with 64-bit positions) [rank %d: %u records, %u tied, %u equal windows, oversized group %u]",
@@ -1761,6 +1855,7 @@ static void gctx_env(dc3hip_gctx *G) {
   if (const char *e = getenv("DC3HIP_GLOBAL_NO_ROUTE")) G->route = e[0] != '1';
   if (const char *e = getenv("DC3HIP_GLOBAL_NO_SELECT")) G->no_select = e[0] == '1';
   if (const char *e = getenv("DC3HIP_NO_WIDE_MSD")) G->no_wide_msd = e[0] == '1';
+  if (const char *e = getenv("DC3HIP_NO_WIDE_DEEPEN")) G->no_wide_deepen = e[0] == '1';
   if (const char *e = getenv("DC3HIP_WIDE_MSD_MIN")) { const long long v = atoll(e); if (v >= 0) { G->wide_msd_min = (u64)v; G->wide_msd_forced = true; } }
 }
 
@@ -1888,6 +1983,10 @@ void dc3hip_global_destroy(dc3hip_gctx *G) {
   if (G->w_rb) (void)hipFree(G->w_rb);
   if (G->w_shard) (void)hipFree(G->w_shard);
   if (G->w_same) (void)hipFree(G->w_same);
+  if (G->w_sa_all) (void)hipFree(G->w_sa_all);
+  if (G->w_isa) (void)hipFree(G->w_isa);
+  if (G->w_eq_all) (void)hipFree(G->w_eq_all);
+  if (G->w_eq2) (void)hipFree(G->w_eq2);
   if (G->c) dc3hip_ctx_destroy(G->c);
   delete G;
 }
@@ -2056,7 +2155,12 @@ int32_t dc3hip_global_sufcheck(dc3hip_gctx *G) {
     WideKey k; u32 ibits = 0;
     RC(wide_key(G, sigma, &k, &ibits));
     HIPC(hipMemsetAsync(c->d_words + 20, 0, sizeof(u32), c->stream));
-    if (G->shard_count > 0) {
+    if (G->shard_count > 0 && G->w_isa_valid) {
+      // a deepened order: linear-time check against its own inverse (symbol compares would be as deep as the repeats are long)
+      hipLaunchKernelGGL(k_wide_check_isa, dim3(grid_for(c, G->shard_count)), dim3(kBlock), 0, c->stream, (const u64 *)G->w_shard,
+                         (u32)G->shard_count, (u64)G->shard_first, next_first, k, (const u64 *)G->w_isa, c->d_words + 20);
+      KCHECK();
+    } else if (G->shard_count > 0) {
       hipLaunchKernelGGL(k_wide_check, dim3(grid_for(c, G->shard_count)), dim3(kBlock), 0, c->stream, (const u64 *)G->w_shard,
                          (u32)G->shard_count, next_first, k, std::max<u32>(4 * kWideWindowDeep, G->w_depth), c->d_words + 20);
       KCHECK();

@@ -209,6 +209,93 @@ __global__ __launch_bounds__(kBlock) void k_wide_check(const u64 *__restrict__ s
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Deepening by rank look-ups (host: wide_deepen): the form of prefix doubling a range-partitioned order allows.  When
+// windows still agree after the last symbol compare of depth D, every rank receives the whole order and builds
+//     isa[p] = 1 + global index of the first entry whose D-symbol window equals that of p      (isa[n] = 0: the empty suffix)
+// — the rank of p by its first D symbols.  Two suffixes that agree on D symbols are then ordered by the ranks of their
+// continuations p + D, p + 2D, ..., p + W D: W + 1 look-ups settle (W + 1) D symbols, and the next round starts from
+// ranks that deep.  Depth grows (W + 1)-fold per round whatever the text looks like; no symbol is compared again.
+// ---------------------------------------------------------------------------------------------
+// eq[i] = 1 iff entry i's window equals entry i - 1's within k.W symbols (eq[0] = 0: a rank's range begins with a new window)
+__global__ __launch_bounds__(kBlock) void k_wide_eq(const u64 *__restrict__ shard, u32 nrec, WideKey k, uint8_t *__restrict__ eq) {
+  __shared__ uint16_t lcode[256];
+  if (threadIdx.x < 256) lcode[threadIdx.x] = k.code[threadIdx.x];
+  __syncthreads();
+  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < nrec; i += gridDim.x * kBlock)
+    eq[i] = (i > 0 && wide_cmp(k, shard[i - 1], shard[i], k.W, lcode) == 0) ? 1 : 0;
+}
+// sa / eq: the whole order and its flags (all ranks' shards in rank order); groups are at most kWideTieBig long
+__global__ __launch_bounds__(kBlock) void k_wide_isa_scatter(const u64 *__restrict__ sa, const uint8_t *__restrict__ eq, u64 n, u64 *__restrict__ isa) {
+  for (u64 g = (u64)blockIdx.x * kBlock + threadIdx.x; g < n; g += (u64)gridDim.x * kBlock) {
+    u64 s = g;
+    while (eq[s]) s--;
+    isa[sa[g]] = s + 1;
+  }
+}
+__device__ __forceinline__ int wide_cmp_isa(const u64 *__restrict__ isa, u64 n, u64 p, u64 q, u64 D, u32 W) {
+#pragma unroll 1
+  for (u32 j = 0; j <= W; j++) {
+    const u64 pp = p + (u64)j * D, qq = q + (u64)j * D;
+    const u64 a = pp < n ? isa[pp] : 0ull, b = qq < n ? isa[qq] : 0ull;
+    if (a != b) return a < b ? -1 : 1;
+    if (pp >= n) return 0;
+  }
+  return 0;
+}
+// One thread per group of entries that agree on D symbols (eq): the group is put in the order of (W + 1) D symbols, and
+// neweq says which neighbours still agree that far.  words[0] = a group beyond kWideTieBig, words[2] += such neighbours.
+__global__ __launch_bounds__(kBlock) void k_wide_ties_isa(u64 *__restrict__ shard, const uint8_t *__restrict__ eq, u32 nrec,
+                                                         const u64 *__restrict__ isa, u64 n, u64 D, u32 W,
+                                                         uint8_t *__restrict__ neweq, u32 *words) {
+  u32 dup = 0;
+  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < nrec; i += gridDim.x * kBlock) {
+    if (eq[i]) continue;                                  // a member: its group's first thread does the work
+    neweq[i] = 0;
+    if (!(i + 1 < nrec && eq[i + 1])) continue;
+    u32 e = i + 1;
+    while (e < nrec && eq[e] && e - i <= kWideTieBig) e++;
+    if (e - i > kWideTieBig) { words[0] = 1u; continue; }
+    for (u32 x = i + 1; x < e; x++) {                     // binary insertion: log2 compares (W + 1 look-ups each) per entry
+      const u64 v = shard[x];
+      u32 lo = i, hi = x;                                 // first y in [i, x) whose entry is greater than v
+      while (lo < hi) {
+        const u32 mid = lo + ((hi - lo) >> 1);             // (indices reach beyond 2^31: no lo + hi)
+        if (wide_cmp_isa(isa, n, v, shard[mid], D, W) < 0) hi = mid; else lo = mid + 1;
+      }
+      for (u32 y = x; y > lo; y--) shard[y] = shard[y - 1];
+      shard[lo] = v;
+    }
+    for (u32 x = i + 1; x < e; x++) {
+      const bool same = wide_cmp_isa(isa, n, shard[x - 1], shard[x], D, W) == 0;
+      neweq[x] = same ? 1 : 0;
+      dup += same ? 1u : 0u;
+    }
+  }
+  dup = wave_reduce(dup);
+  if (lane_id() == 0 && dup) atomicAdd(&words[2], dup);
+}
+// The verifier of an order that was deepened (isa is then the exact inverse: all ranks distinct), linear in the shard:
+// the entry's rank is its index, and neighbours p < q satisfy (T[p], rank of p + 1) < (T[q], rank of q + 1) — by induction
+// over the ranks that is the suffix order.  err as k_wide_check (3 also when isa is not the inverse of the order).
+__global__ __launch_bounds__(kBlock) void k_wide_check_isa(const u64 *__restrict__ shard, u32 cnt, u64 first, u64 next_first, WideKey k,
+                                                          const u64 *__restrict__ isa, u32 *err) {
+  __shared__ uint16_t lcode[256];
+  if (threadIdx.x < 256) lcode[threadIdx.x] = k.code[threadIdx.x];
+  __syncthreads();
+  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < cnt; i += gridDim.x * kBlock) {
+    const u64 p = shard[i];
+    if (p >= k.n) { atomicMax(err, 2u); continue; }
+    if (isa[p] != first + i + 1) { atomicMax(err, 3u); continue; }
+    const u64 q = i + 1 < cnt ? shard[i + 1] : next_first;
+    if (q == ~0ull) continue;
+    if (q >= k.n) { atomicMax(err, 2u); continue; }
+    const u32 cp = lcode[k.t[p]], cq = lcode[k.t[q]];
+    const u64 rp = p + 1 < k.n ? isa[p + 1] : 0ull, rq = q + 1 < k.n ? isa[q + 1] : 0ull;
+    if (cp > cq || (cp == cq && rp >= rq)) atomicMax(err, 3u);
+  }
+}
+
 // order-sensitive checksum of a shard with global indices (64-bit values: sum of mix(mix(index) ^ position))
 __global__ __launch_bounds__(kBlock) void k_wide_checksum(const u64 *__restrict__ shard, u32 cnt, u64 first, u64 *out) {
   u64 acc = 0;

@@ -519,7 +519,8 @@ def test_wide_mode_small_texts_match_the_oracle(ss, oracle, P):
     random bytes, DNA, binary, an alphabet with 0x00, texts ending in a run of the smallest symbol; bit-exact shards
     (fetched as int64), the collective verifier agrees, the u32 getter refuses.  Planted repeats of 100, 400, 20 000 and
     150 000 symbols are settled by the tie rounds (each 16 times deeper than the last); a text half of which is a copy of
-    the other half and a text over one symbol are refused with -4 on every rank."""
+    the other half goes through the deepening by rank look-ups (and is refused with -4 on every rank without it, as a text
+    over one symbol always is)."""
     rng = np.random.default_rng(47)
     # (texts this small stay below the bucket ordering's threshold: the 16-byte LSD form, unrouted selection)
     with env(DC3HIP_GLOBAL_FORCE_WIDE=1), ss.LoopbackGroup(P, 3_000_000) as g:
@@ -550,13 +551,22 @@ def test_wide_mode_small_texts_match_the_oracle(ss, oracle, P):
         rep3[1_000_000:1_150_000] = rep3[5:150_005]; rep3[2_500_000:2_650_000] = rep3[5:150_005]   # of them reaching close to the end
         g.set_text(rep3); g.build()
         assert np.array_equal(g.sa(), want_sa(oracle, rep3)) and g.sufcheck() == 0
-        huge = cases["dna"].copy(); huge[1_500_000:2_900_000] = huge[5:1_400_005]      # more than 2^20 positions share their window: refused
-        for bad in (huge, np.full(100_000, 65, dtype=np.uint8)):
-            g.set_text(bad)
-            with pytest.raises(ss.Dc3HipError) as ei:
-                g.build()
-            assert ei.value.code == -4, ei.value
-        g.set_text(cases["bytes"]); g.build()                        # the group is usable again
+        huge = cases["dna"].copy(); huge[1_500_000:2_900_000] = huge[5:1_400_005]      # more than 2^20 positions share their window:
+        g.set_text(huge); g.build()                                                    # deepened by rank look-ups (round 4)
+        assert np.array_equal(g.sa(), want_sa(oracle, huge)) and g.sufcheck() == 0
+        assert all(s["wide_deepen_rounds"] >= 1 for s in g.stats())
+        with env(DC3HIP_WIDE_CORRUPT="1"):                                             # (the verifier of a deepened order sees a swap too)
+            g.build()
+        assert g.sufcheck() == -3
+        for bad, switch in ((huge, "1"), (np.full(100_000, 65, dtype=np.uint8), "0")):  # refused: without the deepening; one symbol
+            with env(DC3HIP_NO_WIDE_DEEPEN=switch), ss.LoopbackGroup(P, 3_000_000) as g2:
+                g2.set_text(bad)
+                with pytest.raises(ss.Dc3HipError) as ei:
+                    g2.build()
+                assert ei.value.code == -4, ei.value
+                g2.set_text(cases["tiny"]); g2.build()               # the group is usable again
+                assert np.array_equal(g2.sa(), want_sa(oracle, cases["tiny"]))
+        g.set_text(cases["bytes"]); g.build()                        # (and so is this one, after a deepened build)
         assert np.array_equal(g.sa(), want_sa(oracle, cases["bytes"]))
         # the verifier must see a damaged array (test hook: two neighbours swapped / one position out of range)
         for how, code in (("1", -3), ("2", -2)):
@@ -593,14 +603,57 @@ def test_wide_mode_bucket_ordering_on_small_texts(ss, oracle, P):
                 assert all(s["text_order"] == 1 and s["levels"] == 1 for s in st)
                 assert all(s["wide_msd"] == (0 if "DC3HIP_NO_WIDE_MSD" in extra else 1) for s in st), (label, [s["wide_msd"] for s in st])
                 sums.setdefault(label, set()).add(g.checksum())
-            huge = cases["dna"].copy(); huge[1_500_000:2_900_000] = huge[5:1_400_005]      # refused as before, on every rank
-            g.set_text(huge)
+            huge = cases["dna"].copy(); huge[1_500_000:2_900_000] = huge[5:1_400_005]      # deepened by rank look-ups, on every rank
+            g.set_text(huge); g.build()
+            assert np.array_equal(g.sa(), want_sa(oracle, huge)) and g.sufcheck() == 0
+            g.set_text(cases["bytes"]); g.build()                        # the sort's buffers come back
+            assert np.array_equal(g.sa(), wants["bytes"])
+    assert all(len(v) == 1 for v in sums.values()), sums
+
+
+@pytest.mark.parametrize("P", [2, 3, 5])
+def test_wide_mode_deepening_by_rank_lookups(ss, oracle, P):
+    """Repetitive texts in the wide mode (64-bit positions: no recursion): where windows still agree after the symbol
+    compares, all ranks exchange their shards, build the inverse of the order so far and settle 17 times the depth per round
+    with 17 rank look-ups per compare (wide_deepen).  Two copies of one text, eight copies of a block with a few point
+    mutations, a 1.4 M-symbol repeat, a period of 5000 symbols (300 suffixes per group), repeats reaching the end of the
+    text; the bucket ordering and the 16-byte LSD form; bit-exact against divsufsort, accepted by the collective verifier
+    (which checks a deepened order in linear time against its own inverse).  Beyond 1024 suffixes sharing a window the
+    text is still refused."""
+    rng = np.random.default_rng(4900 + P)
+    base = oracle.gen(1_200_000, 31, 1)
+    cases = {"two_copies": np.concatenate([base, base])}
+    blk = rng.integers(0, 256, size=300_000, dtype=np.uint8)
+    eight = np.tile(blk, 8)
+    for at in rng.integers(0, len(eight), size=40):
+        eight[at] ^= 1
+    cases["eight_copies_with_mutations"] = eight
+    h = oracle.gen(3_000_000, 5, 1).copy(); h[1_500_000:2_900_000] = h[5:1_400_005]
+    cases["long_repeat"] = h
+    cases["period_5000"] = np.tile(rng.integers(0, 4, size=5000, dtype=np.uint8) + 65, 300)[:1_499_999]
+    e = oracle.gen(2_000_000, 7, 0).copy(); e[-700_000:] = e[100:700_100]
+    cases["repeat_at_the_end"] = e
+    for extra in ({"DC3HIP_WIDE_MSD_MIN": 1}, {"DC3HIP_NO_WIDE_MSD": 1}):
+        with env(DC3HIP_GLOBAL_FORCE_WIDE=1, **extra), ss.LoopbackGroup(P, 3_000_000) as g:
+            for label, t in cases.items():
+                want = want_sa(oracle, t)
+                g.set_text(t)
+                g.build()
+                assert np.array_equal(g.sa(), want), (label, P, extra)
+                assert g.sufcheck() == 0, (label, P)
+                st = g.stats()
+                if label in ("two_copies", "long_repeat", "period_5000"):       # (the others may fit the symbol compares' budget)
+                    assert all(s["wide_deepen_rounds"] >= 1 for s in st), (label, [s["wide_deepen_rounds"] for s in st])
+                g.build()
+                assert np.array_equal(g.sa(), want), (label, P, extra, "second build")
+            g.set_text(np.tile(rng.integers(0, 4, size=1000, dtype=np.uint8) + 65, 2900))     # 2900 suffixes per group
             with pytest.raises(ss.Dc3HipError) as ei:
                 g.build()
             assert ei.value.code == -4, ei.value
-            g.set_text(cases["bytes"]); g.build()                        # the group is usable again
-            assert np.array_equal(g.sa(), wants["bytes"])
-    assert all(len(v) == 1 for v in sums.values()), sums
+            t = rng.integers(0, 256, size=1_000_003, dtype=np.uint8)
+            g.set_text(t); g.build()
+            assert np.array_equal(g.sa(), want_sa(oracle, t))
+            assert all(s["wide_deepen_rounds"] == 0 for s in g.stats())
 
 
 def test_wide_mode_beyond_2pow32(ss):

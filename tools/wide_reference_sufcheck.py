@@ -7,7 +7,11 @@ handed to the REFERENCE's sufcheck() compiled with 64-bit saidx_t (oracle/_ref/l
 c-sources/utils.c:160-241: range, first-character order, then the psi-style "SA[C[T[SA[i]-1]]++] == SA[i]-1" scan).
 rc 0 means: this array is the suffix array of this text.  One JSON line (profiles/r03*_wide_reference_sufcheck64.json).
 
-    python tools/wide_reference_sufcheck.py [extra_bytes=1048579 | n >= 2^32] [kind=0] [ranks=2]"""
+    python tools/wide_reference_sufcheck.py [extra_bytes=1048579 | n >= 2^32] [kind=0] [ranks=2] [repeat_bytes=0]
+
+repeat_bytes > 0: the last repeat_bytes of the text (but 7) are a copy of its bytes 11 .. 11 + repeat_bytes — windows that
+repeat far beyond any symbol compare, settled by the deepening by rank look-ups (wide_deepen); the text then goes in
+through set_text."""
 import ctypes
 import json
 import os
@@ -25,6 +29,7 @@ import stringsearch_amd as ss  # noqa: E402
 extra = int(sys.argv[1]) if len(sys.argv) > 1 else (1 << 20) + 3
 kind = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 P = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+repeat = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 seed = 6 if kind == 0 else 5
 n = extra if extra >= (1 << 32) else (1 << 32) + extra
 path = os.path.join(ROOT, "oracle", "_ref", "libdivsufsort64_ref.so")
@@ -32,10 +37,25 @@ ref = ctypes.CDLL(path)
 ref.sufcheck.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32]
 ref.sufcheck.restype = ctypes.c_int32
 
-out = {"n": n, "kind": kind, "seed": seed, "ranks": P, "transport": "loopback (all ranks on one GPU)"}
+out = {"n": n, "kind": kind, "seed": seed, "ranks": P, "transport": "loopback (all ranks on one GPU)", "planted_repeat_bytes": repeat}
+# the text, from the same device generator stream, in pieces a single context can hold
+text = np.zeros(n, dtype=np.uint8)
+piece = 1 << 30
+with ss.Context(piece) as c:
+    off = 0
+    while off < n:
+        m = min(piece, n - off)
+        c.generate(m, seed, kind, offset=off)
+        text[off:off + m] = c.text()
+        off += m
+if repeat:
+    text[n - 7 - repeat:n - 7] = text[11:11 + repeat]
 sa = np.zeros(n, dtype=np.int64)
 with ss.LoopbackGroup(P, n) as g:
-    g.generate(n, seed, kind)
+    if repeat:
+        g.set_text(text)
+    else:
+        g.generate(n, seed, kind)
     g.build()
     t0 = time.time(); g.build(); out["build_wall_ms"] = round((time.time() - t0) * 1e3, 1)
     out["library_global_sufcheck"] = g.sufcheck()
@@ -52,16 +72,7 @@ with ss.LoopbackGroup(P, n) as g:
     st = g.stats()
     out["ordered_by"] = ["bucket ordering on 8-byte words" if x.get("wide_msd") else "LSD passes on 16-byte records" for x in st]
     out["tied_records_per_rank"] = [x["ctx"]["level_tied"][0] for x in st]
-# the text, from the same device generator stream, in pieces a single context can hold
-text = np.zeros(n, dtype=np.uint8)
-piece = 1 << 30
-with ss.Context(piece) as c:
-    off = 0
-    while off < n:
-        m = min(piece, n - off)
-        c.generate(m, seed, kind, offset=off)
-        text[off:off + m] = c.text()
-        off += m
+    out["deepening_rounds_per_rank"] = [x.get("wide_deepen_rounds", 0) for x in st]
 t0 = time.time()
 rc = int(ref.sufcheck(text.ctypes.data, sa.ctypes.data, n, 0))
 out["reference_sufcheck64_rc"] = rc
