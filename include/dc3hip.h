@@ -36,11 +36,11 @@
  *                DC3HIP_SSORT_VERIFY=1 (self-check of the splitter ordering)
  *   test-only    force or forbid one of the orderings so that the parity suite can compare them:
  *                DC3HIP_NO_TEXT_SHORTCUT, _NO_FULLSORT, _NO_HYBRID, _NO_HYBRID8, _NO_HYBRID12, _HYBRID12_MIN, _NO_LONG_KEYS,
- *                _NO_DOUBLING, _TEXT_ORDER12, _NO_SPLIT_EMIT, _NO_SMALL_TIES, _NO_9BIT, _NO_REC12, _NO_DISCARD, _NO_MSD,
+ *                _NO_RAW_IMAGE, _NO_DOUBLING, _TEXT_ORDER12, _NO_SPLIT_EMIT, _NO_SMALL_TIES, _NO_9BIT, _NO_REC12, _NO_DISCARD, _NO_MSD,
  *                _MSD_MIN, _PACK_FUSE=0, _NO_PACK_STRIP, _NO_SSORT, _SSORT_MIN, _SSORT_REC12, _NO_WIDE_WINDOW,
  *                _NO_PACK_COUNT, _NO_TUP8, _NO_TUP_SCATTER, _NO_TUP_REC8, _TUP_BIGTILE=0, _TUP_SCATTER_MIN, _NO_XCD_MAP;
  *                global mode: DC3HIP_GLOBAL_NO_TEXT_ORDER, _GLOBAL_FORCE_DIST, _GLOBAL_FORCE_WIDE, _GLOBAL_NO_ROUTE,
- *                DC3HIP_NO_WIDE_MSD, DC3HIP_WIDE_MSD_MIN, DC3HIP_WIDE_CORRUPT (verifier test hook)
+ *                _GLOBAL_NO_SELECT, DC3HIP_NO_WIDE_DEEPEN, DC3HIP_NO_WIDE_MSD, DC3HIP_WIDE_MSD_MIN, DC3HIP_WIDE_CORRUPT (verifier test hook)
  * (DESIGN.md section 7 says what each one selects.)
  */
 #ifndef DC3HIP_H
@@ -290,11 +290,14 @@ DC3HIP_API int32_t dc3hip_ctx_debug_radix_pass_u64(dc3hip_ctx *ctx, const uint64
  * inside a collective, as in any NCCL program: the host job's watchdog has to tear the group down.
  * Environment: DC3HIP_GLOBAL_LOCAL_MAX (levels up to this length are finished by every rank on its own replicated
  * copy, default 2^22), DC3HIP_GLOBAL_NO_TEXT_ORDER=1 (skip the distributed whole-text order).
- * WIDE contexts (max_total_n > DC3HIP_MAX_N, up to 2^40; or DC3HIP_GLOBAL_FORCE_WIDE=1): positions are 64-bit, and only
- * the distributed whole-text order exists at that size — the text is built if all its 256-symbol windows are distinct (a few repeats of up to 8192 symbols are settled too)
- * (high-entropy inputs: BASELINE.json configs[3] random bytes at 4 GiB, configs[4] random DNA at 16 GiB); a text with a
- * repeated window is refused with -4 (no recursion with 64-bit positions), as is a rank whose share would exceed
- * DC3HIP_MAX_N suffixes.  Shards are fetched with dc3hip_global_get_shard_i64 (…_u32 returns -4) and verified with the
+ * WIDE contexts (max_total_n > DC3HIP_MAX_N, up to 2^40; or DC3HIP_GLOBAL_FORCE_WIDE=1): positions are 64-bit, and the
+ * order is the distributed whole-text order (BASELINE.json configs[3] random bytes at 4 GiB, configs[4] random DNA at
+ * 16 GiB).  Windows that repeat are compared deeper (256, 8192, then 16x more symbols per round while that is cheap) and
+ * beyond that settled by rank look-ups: all ranks exchange their shards, build the inverse of the order so far, and 17
+ * look-ups per compare settle 17x the depth per round (needs 17 bytes per suffix of the TEXT on every rank).  Refused
+ * with -4 on every rank: a text over one symbol, more than 1024 suffixes sharing one sort image (a long run of one
+ * symbol, a period below n/1024), a rank whose share would exceed DC3HIP_MAX_N suffixes, no memory for the look-ups.
+ * Shards are fetched with dc3hip_global_get_shard_i64 (…_u32 returns -4) and verified with the
  * collective dc3hip_global_sufcheck. */
 typedef struct dc3hip_gctx dc3hip_gctx;
 

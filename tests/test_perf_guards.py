@@ -17,12 +17,12 @@ pytestmark = pytest.mark.gpu
 GIB = 1 << 30
 # case -> measured ms at the shipping head (MI355X); the guard is 1.3x
 MEASURED_MS = {
-    "random_1GiB": 17.0,
-    "random_1GiB_recursion_only": 44.5,
-    "random_1GiB_dup_1MB_block": 41.5,
-    "dna_1GiB": 22.6,
-    "text_1GiB": 127.6,
-    "real_text_256MiB": 60.5,
+    "random_1GiB": 15.3,
+    "random_1GiB_recursion_only": 43.1,
+    "random_1GiB_dup_1MB_block": 39.7,
+    "dna_1GiB": 18.3,
+    "text_1GiB": 127.5,
+    "real_text_256MiB": 59.7,
 }
 SLACK = 1.3
 
