@@ -579,8 +579,8 @@ struct MsdPass1KeysSel : MsdPass1Keys<KM> {
   int launch(dc3hip_ctx *c, u64 *out, u32, u64 base, u32 sh1, const MsdGeom &g, u32 nb1, const u32 *plan, u32 *cur1) override {
     static std::atomic<bool> attr_set[16];
     if (!attr_set[c->device & 15]) {
-      HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_msd_part_keys<KM, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
-      HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_msd_part_keys<KM, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
+      HIPC(dc3_func_set_attribute(reinterpret_cast<const void *>(k_msd_part_keys<KM, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
+      HIPC(dc3_func_set_attribute(reinterpret_cast<const void *>(k_msd_part_keys<KM, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
       attr_set[c->device & 15] = true;
     }
     if (this->strip)
@@ -1390,7 +1390,7 @@ struct WidePass1 : MsdPass1 {
   int launch(dc3hip_ctx *c, u64 *out, u32, u64, u32, const MsdGeom &, u32, const u32 *, u32 *cur1) override {
     static std::atomic<bool> attr_set[16];
     if (!attr_set[c->device & 15]) {
-#define DC3_WIDE_ATTR(JM, PW) HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_wide_part1<JM, PW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWidePartSmem))
+#define DC3_WIDE_ATTR(JM, PW) HIPC(dc3_func_set_attribute(reinterpret_cast<const void *>(k_wide_part1<JM, PW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWidePartSmem))
       DC3_WIDE_ATTR(8, false); DC3_WIDE_ATTR(16, false); DC3_WIDE_ATTR(24, false); DC3_WIDE_ATTR(kWideMaxImageSyms, false);
       DC3_WIDE_ATTR(8, true); DC3_WIDE_ATTR(16, true); DC3_WIDE_ATTR(24, true); DC3_WIDE_ATTR(kWideMaxImageSyms, true);
 #undef DC3_WIDE_ATTR

@@ -11,6 +11,14 @@ static void set_err(const char *fmt, ...) {
 }
 enum { E_OK = 0, E_ARGS = -1, E_ALLOC = -2, E_HIP = -3, E_TOOBIG = -4 };
 
+// hipFuncSetAttribute is reached by several host threads at once (the loopback ranks' first build, sacapart's workers, each
+// behind its own "already set" flag): one at a time — a round-4 soak died twice, seconds into the process, with a corrupted
+// host heap, and the runtime's per-function state is the one thing those threads all write.
+static std::mutex g_func_attr_mu;
+static inline hipError_t dc3_func_set_attribute(const void *fn, hipFuncAttribute attr, int value) {
+  std::lock_guard<std::mutex> lk(g_func_attr_mu);
+  return hipFuncSetAttribute(fn, attr, value);
+}
 #define HIPC(expr)                                                                              \
   do {                                                                                          \
     hipError_t e__ = (expr);                                                                    \

@@ -7,7 +7,7 @@ static int launch_merge(dc3hip_ctx *c, u32 ntiles, const TA *A, u32 nA, const TB
                         u32 *out_sa, Rec8 *out_pairs, u32 rank_base = 0) {
   auto kern = k_merge<NT, VT, TA, TB>;
   const size_t smem = MergeSmem<NT, VT>::kBytes;
-  HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  HIPC(dc3_func_set_attribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipLaunchKernelGGL(kern, dim3(ntiles), dim3(NT), smem, c->stream, A, nA, B, nB, part, out_sa, out_pairs, rank_base);
   return E_OK;
 }
@@ -50,9 +50,9 @@ static int scatter_tuples_run(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, cons
   if (c->arena_bytes - c->arena_off < (size_t)m02 * 2 * sizeof(Rec) + (size_t)1024 * nchunks * 4 + ((size_t)nb << 11) + (16u << 20)) return E_OK;
   static std::atomic<bool> attr_set[16];
   if (!attr_set[c->device & 15]) {
-    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tup_part1<Sym, Out>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTupPartSmem));
-    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tup_part2<Out>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTupPartSmem));
-    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tup_local<Out, kDerive>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * kTupWin * 4)));
+    HIPC(dc3_func_set_attribute(reinterpret_cast<const void *>(k_tup_part1<Sym, Out>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTupPartSmem));
+    HIPC(dc3_func_set_attribute(reinterpret_cast<const void *>(k_tup_part2<Out>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTupPartSmem));
+    HIPC(dc3_func_set_attribute(reinterpret_cast<const void *>(k_tup_local<Out, kDerive>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * kTupWin * 4)));
     attr_set[c->device & 15] = true;
   }
   const ArenaMark mk = arena_mark(c);
@@ -94,7 +94,7 @@ static int scatter_tuples_run(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, cons
       if (big) {
         static std::atomic<bool> attr8[16];
         if (!attr8[c->device & 15]) {
-          HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tup8_part1<Sym>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTup8PartSmem));
+          HIPC(dc3_func_set_attribute(reinterpret_cast<const void *>(k_tup8_part1<Sym>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTup8PartSmem));
           attr8[c->device & 15] = true;
         }
         hipLaunchKernelGGL((k_tup8_part1<Sym>), dim3(8 * cpx), dim3(kTup8NT), kTup8PartSmem, c->stream, S, m, m0, m02, rank12, cpx, ntiles, nb, cur1, oa);

@@ -13,11 +13,11 @@ template <class Src>
 static int inverse_permute_from(dc3hip_ctx *c, Src first, bool first_is_a, Rec8 *a, Rec8 *b, u32 n, u32 *out, int phase) {
   static std::atomic<bool> attr_set[16];   // (per function and device, process-wide; a double set is harmless)
   if (!attr_set[c->device & 15]) {
-    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_invperm_local),
+    HIPC(dc3_func_set_attribute(reinterpret_cast<const void *>(k_invperm_local),
                              hipFuncAttributeMaxDynamicSharedMemorySize, kInvWindow * 4));
-    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_part_msd<Src>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIPC(dc3_func_set_attribute(reinterpret_cast<const void *>(k_part_msd<Src>), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)kPartSmem));
-    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_part_msd<PairArray>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIPC(dc3_func_set_attribute(reinterpret_cast<const void *>(k_part_msd<PairArray>), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)kPartSmem));
     attr_set[c->device & 15] = true;
   }
@@ -905,7 +905,7 @@ struct MsdPass1Img : MsdPass1 {
   int launch(dc3hip_ctx *c, u64 *out, u32 n, u64 base, u32 sh1, const MsdGeom &g, u32 nb1, const u32 *plan, u32 *cur1) override {
     static std::atomic<bool> attr_set[16];
     if (!attr_set[c->device & 15]) {
-      HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_msd_part_keys<KeyImg, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
+      HIPC(dc3_func_set_attribute(reinterpret_cast<const void *>(k_msd_part_keys<KeyImg, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
       attr_set[c->device & 15] = true;
     }
     hipLaunchKernelGGL((k_msd_part_keys<KeyImg, true>), dim3(kMsdGroups * g.cpx1), dim3(kMsdNW * 64), kMsdPartSmem, c->stream, ki, hm, 0ull, out, n, base,

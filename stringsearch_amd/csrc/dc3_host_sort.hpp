@@ -36,7 +36,7 @@ static int launch_downsweep_to(dc3hip_ctx *c, Loader in, Sink dst, u32 n, const 
   auto kern = k_rs_downsweep<Rec, NB, IPT, NW, PF, Loader, Sink>;
   static std::atomic<bool> attr_set[16];   // (per function and device, process-wide; a double set is harmless)
   if (!attr_set[c->device & 15]) {
-    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIPC(dc3_func_set_attribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)smem));
     attr_set[c->device & 15] = true;
   }
@@ -213,8 +213,8 @@ struct MsdPass1Keys : MsdPass1 {
   int launch(dc3hip_ctx *c, u64 *out, u32 n, u64 base, u32 sh1, const MsdGeom &g, u32 nb1, const u32 *plan, u32 *cur1) override {
     static std::atomic<bool> attr_set[16];
     if (!attr_set[c->device & 15]) {
-      HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_msd_part_keys<KM, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
-      HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_msd_part_keys<KM, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
+      HIPC(dc3_func_set_attribute(reinterpret_cast<const void *>(k_msd_part_keys<KM, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
+      HIPC(dc3_func_set_attribute(reinterpret_cast<const void *>(k_msd_part_keys<KM, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
       attr_set[c->device & 15] = true;
     }
     if (strip)
@@ -259,8 +259,8 @@ static int msd_sort(dc3hip_ctx *c, Rec8 *ha, Rec8 *hb, u32 n, const HiMap &hm, c
   if (p1 && !table) { set_err("internal: on-the-fly pass 1 without a digit table"); return E_HIP; }
   static std::atomic<bool> attr_set[16];
   if (!attr_set[c->device & 15]) {
-    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_msd_part<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
-    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_msd_part<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
+    HIPC(dc3_func_set_attribute(reinterpret_cast<const void *>(k_msd_part<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
+    HIPC(dc3_func_set_attribute(reinterpret_cast<const void *>(k_msd_part<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
     attr_set[c->device & 15] = true;
   }
   const u32 nb1 = 1u << g.d1, tb = g.d1 + g.d2, n2 = 1u << tb;
@@ -424,9 +424,9 @@ static int ssort(dc3hip_ctx *c, Rec *a, Rec *b, u32 n, u32 kbits, Rec **result, 
   constexpr size_t part_smem = ss_part_smem<Rec>(), loc_smem = sizeof(Rec) * kSsCap + kSsCap;
   static std::atomic<bool> attr_set[16];
   if (!attr_set[c->device & 15]) {
-    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ss_part<Rec, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_smem));
-    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ss_part<Rec, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_smem));
-    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ss_local<Rec, kLocNT, kLocIPT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)loc_smem));
+    HIPC(dc3_func_set_attribute(reinterpret_cast<const void *>(k_ss_part<Rec, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_smem));
+    HIPC(dc3_func_set_attribute(reinterpret_cast<const void *>(k_ss_part<Rec, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_smem));
+    HIPC(dc3_func_set_attribute(reinterpret_cast<const void *>(k_ss_local<Rec, kLocNT, kLocIPT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)loc_smem));
     attr_set[c->device & 15] = true;
   }
   const u32 nb1 = geo.nb1, F2 = geo.F2, n2 = geo.n2, S = geo.S;

@@ -54,6 +54,8 @@ while time.time() - t0 < budget:
         envs["DC3HIP_HYBRID12_MIN"] = "0"
     text = make_text(n)
     for k, v in envs.items(): os.environ[k] = v
+    if os.environ.get("GLOBAL_FUZZ_VERBOSE"):          # (the case on stderr before it runs: a crash names its input)
+        np.save("gpurun_out/global_fuzz_last.npy", text); print(json.dumps({"it": it, "P": P, "n": n, "env": envs}), file=sys.stderr, flush=True)
     try:
         with ss.LoopbackGroup(P, max(n, 1)) as g:
             g.set_text(text)
