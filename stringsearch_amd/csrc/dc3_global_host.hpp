@@ -20,6 +20,7 @@
 
 #include <condition_variable>
 #include <memory>
+#include <functional>
 #include <mutex>
 #include <chrono>
 #include <dlfcn.h>
@@ -462,8 +463,9 @@ static int rank_exchange(dc3hip_gctx *G, Rec8 *pairs, u32 cnt, u32 M, u32 *out, 
       KCHECK();
     }
     RC(scan_digit_table(c, table, ck.nchunks, digit_base, 256, phase));
-    std::vector<u32> tmp(256);
-    HIPC(hipMemcpyAsync(tmp.data(), digit_base, 256 * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    void *tmpp = nullptr;
+    RC(stage_d2h_async(c, digit_base, 256 * sizeof(u32), &tmpp));
+    const u32 *tmp = static_cast<const u32 *>(tmpp);
     ArrayLoader<Rec8> ld; ld.p = pairs;
     RC((launch_downsweep<Rec8, 256, ArrayLoader<Rec8>>(c, ld, pb, cnt, ck, dig, table, digit_base, phase)));
     HIPC(hipStreamSynchronize(c->stream));
@@ -543,9 +545,9 @@ static int deliver(dc3hip_gctx *G, const u32 *slice, u32 cnt, u64 pre, const uin
 
 // splitters of a 64-bit image order from ns sampled records ((image << pbits) | pos): every rank computes the same
 static int image_splitters(dc3hip_ctx *c, const Rec8 *d_sample, u32 ns, u32 pbits, int P, int me, u64 *lo, u64 *hi) {
-  std::vector<Rec8> hs(ns);
-  HIPC(hipMemcpyAsync(hs.data(), d_sample, (size_t)ns * sizeof(Rec8), hipMemcpyDeviceToHost, c->stream));
-  HIPC(hipStreamSynchronize(c->stream));
+  void *hsp = nullptr;
+  RC(stage_d2h(c, d_sample, (size_t)ns * sizeof(Rec8), &hsp));
+  const Rec8 *hs = static_cast<const Rec8 *>(hsp);
   // a few thousand candidates per rank are plenty (a host sort of the whole 2^20-record predictor sample cost 60 ms)
   const u32 step = std::max<u32>(1, ns / (u32)(4096 * P));
   std::vector<u64> img;
@@ -682,9 +684,9 @@ static int gorder_positions(dc3hip_gctx *G, KM km, u32 m, u32 kbits, const HiMap
       RC(arena_alloc(c, (size_t)ns, &smp));
       hipLaunchKernelGGL((k_pack_image_pos<KM>), dim3(grid_for(c, ns)), dim3(kBlock), 0, c->stream, km, ns, stride, hm, smp);
       KCHECK();
-      std::vector<Rec8> hs(ns);
-      HIPC(hipMemcpyAsync(hs.data(), smp, (size_t)ns * sizeof(Rec8), hipMemcpyDeviceToHost, c->stream));
-      HIPC(hipStreamSynchronize(c->stream));
+      void *hsp = nullptr;
+      RC(stage_d2h(c, smp, (size_t)ns * sizeof(Rec8), &hsp));
+      const Rec8 *hs = static_cast<const Rec8 *>(hsp);
       u32 cnt256[257] = {0};
       for (u32 i = 0; i < ns; i++) cnt256[(u32)((((((u64)hs[i].key) << 32) | hs[i].val) >> (hm.pbits + hm.nbits - 8)) & 255u)]++;
       // boundaries: rank h starts at the first digit whose prefix count reaches h * ns / P (identical on all ranks)
@@ -721,8 +723,9 @@ static int gorder_positions(dc3hip_gctx *G, KM km, u32 m, u32 kbits, const HiMap
         KCHECK();
       }
       RC(scan_digit_table(c, table, ck.nchunks, digit_base, 256, DC3HIP_PH_PACK));
-      std::vector<u32> tmp(256);
-      HIPC(hipMemcpyAsync(tmp.data(), digit_base, 256 * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+      void *tmpp = nullptr;
+      RC(stage_d2h_async(c, digit_base, 256 * sizeof(u32), &tmpp));
+      const u32 *tmp = static_cast<const u32 *>(tmpp);
       ArrayLoader<Rec8> ld; ld.p = mine;
       RC((launch_downsweep<Rec8, 256, ArrayLoader<Rec8>>(c, ld, sorted, blen, ck, dig, table, digit_base, DC3HIP_PH_PACK)));
       HIPC(hipStreamSynchronize(c->stream));
@@ -1083,11 +1086,11 @@ static int glevel(dc3hip_gctx *G, Sym S, u32 m, u64 K, int depth, u32 *out, GOut
         ns = (m02 - 1) / stride + 1;
         Rec16 *smp = nullptr;
         RC(arena_alloc(c, (size_t)ns, &smp));
-        std::vector<Rec16> hs(ns);
         hipLaunchKernelGGL((k_sample_triple_keys<Sym>), dim3(grid_for(c, ns)), dim3(kBlock), 0, c->stream, S, b, ns, stride, smp, W, wsb);
         KCHECK();
-        HIPC(hipMemcpyAsync(hs.data(), smp, (size_t)ns * sizeof(Rec16), hipMemcpyDeviceToHost, c->stream));
-        HIPC(hipStreamSynchronize(c->stream));
+        void *hsp = nullptr;
+        RC(stage_d2h(c, smp, (size_t)ns * sizeof(Rec16), &hsp));
+        std::vector<Rec16> hs(static_cast<const Rec16 *>(hsp), static_cast<const Rec16 *>(hsp) + ns);
         std::sort(hs.begin(), hs.end(), [](const Rec16 &x, const Rec16 &y) {
           if (x.k2 != y.k2) return x.k2 < y.k2;
           if (x.k1 != y.k1) return x.k1 < y.k1;
@@ -1115,9 +1118,9 @@ static int glevel(dc3hip_gctx *G, Sym S, u32 m, u64 K, int depth, u32 *out, GOut
       memset(&mine, 0, sizeof(mine));
       if (cnt) {
         Rec16 fl[2];
-        HIPC(hipMemcpyAsync(&fl[0], sorted, sizeof(Rec16), hipMemcpyDeviceToHost, c->stream));
-        HIPC(hipMemcpyAsync(&fl[1], sorted + (cnt - 1), sizeof(Rec16), hipMemcpyDeviceToHost, c->stream));
-        HIPC(hipStreamSynchronize(c->stream));
+        void *fp = nullptr;
+        RC(stage_d2h(c, sorted, sizeof(Rec16), &fp)); fl[0] = *static_cast<const Rec16 *>(fp);
+        RC(stage_d2h(c, sorted + (cnt - 1), sizeof(Rec16), &fp)); fl[1] = *static_cast<const Rec16 *>(fp);
         mine.f[0] = fl[0].k0; mine.f[1] = fl[0].k1; mine.f[2] = fl[0].k2;
         mine.l[0] = fl[1].k0; mine.l[1] = fl[1].k1; mine.l[2] = fl[1].k2; mine.has = 1;
       }
@@ -1199,8 +1202,9 @@ static int glevel(dc3hip_gctx *G, Sym S, u32 m, u64 K, int depth, u32 *out, GOut
       RC((build_gather_tuples<Sym>(c, S, m, m0, m02, K, rank12, sa12l, cnt, ckc, A, table0)));
     }
     if (nsp) {
-      HIPC(hipMemcpyAsync(sp.a, A + nA, nsp * sizeof(Tup12), hipMemcpyDeviceToHost, c->stream));
-      HIPC(hipStreamSynchronize(c->stream));
+      void *spp = nullptr;
+      RC(stage_d2h(c, A + nA, nsp * sizeof(Tup12), &spp));
+      memcpy(sp.a, spp, nsp * sizeof(Tup12));
     }
     arena_release(c, mkA);
   }
@@ -1419,9 +1423,9 @@ static int wide_splitters(dc3hip_gctx *G, const WideKey &k, std::vector<u64> *im
   RC(arena_alloc(c, (size_t)cnt, &d_img));
   hipLaunchKernelGGL(k_wide_sample, dim3(grid_for(c, cnt)), dim3(kBlock), 0, c->stream, k, stride, cnt, d_img);
   KCHECK();
-  img->resize(cnt);
-  HIPC(hipMemcpyAsync(img->data(), d_img, (size_t)cnt * 8, hipMemcpyDeviceToHost, c->stream));
-  HIPC(hipStreamSynchronize(c->stream));
+  void *ip = nullptr;
+  RC(stage_d2h(c, d_img, (size_t)cnt * 8, &ip));
+  img->assign(static_cast<const u64 *>(ip), static_cast<const u64 *>(ip) + cnt);
   arena_release(c, mk);
   std::sort(img->begin(), img->end());
   *lo = 0; *hi = ~0ull;
@@ -1488,11 +1492,10 @@ static int wide_msd_order(dc3hip_gctx *G, const WideKey &k, u32 ibits, u64 lo, u
     hipLaunchKernelGGL(k_msd_cnt1, dim3(nb1), dim3(kBlock), 0, c->stream, (const u32 *)table, p1.nchunks, p1.cpg, cntg);
     KCHECK();
   }
-  std::vector<u32> hc((size_t)nb1 * kMsdGroups);
-  HIPC(hipMemcpyAsync(hc.data(), cntg, hc.size() * 4, hipMemcpyDeviceToHost, c->stream));
-  HIPC(hipStreamSynchronize(c->stream));
+  void *hcp = nullptr;
+  RC(stage_d2h(c, cntg, (size_t)nb1 * kMsdGroups * 4, &hcp));
   u64 nrec64 = 0;
-  for (u32 v : hc) nrec64 += v;
+  for (size_t i = 0; i < (size_t)nb1 * kMsdGroups; i++) nrec64 += static_cast<const u32 *>(hcp)[i];
   if (nrec64 > (u64)DC3HIP_MAX_N) { set_err("wide global mode: rank %d would hold %llu suffixes (more ranks needed)", cm->rank, (unsigned long long)nrec64); return E_TOOBIG; }
   const u32 nrec = (u32)nrec64;
   *nrec_out = nrec;
@@ -1726,9 +1729,9 @@ static int gbuild_wide(dc3hip_gctx *G) {
       KCHECK();
     }
     // (the per-block counts are summed in 64 bits on the host: a rank's share must stay below 2^32 - 2^24 records)
-    std::vector<u32> hc(nblocks);
-    HIPC(hipMemcpyAsync(hc.data(), counts, (size_t)nblocks * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPC(hipStreamSynchronize(c->stream));
+    void *hcp = nullptr;
+    RC(stage_d2h(c, counts, (size_t)nblocks * 4, &hcp));
+    std::vector<u32> hc(static_cast<const u32 *>(hcp), static_cast<const u32 *>(hcp) + nblocks);
     u64 nrec64 = 0;
     for (u32 b = 0; b < nblocks; b++) { const u32 v = hc[b]; hc[b] = (u32)nrec64; nrec64 += v; }
     if (nrec64 > (u64)DC3HIP_MAX_N) { set_err("wide global mode: rank %d would hold %llu suffixes (more ranks needed)", me, (unsigned long long)nrec64); return E_TOOBIG; }
@@ -2036,15 +2039,47 @@ int32_t dc3hip_global_generate(dc3hip_gctx *G, int64_t total_n, uint64_t seed, i
 
 int32_t dc3hip_global_build(dc3hip_gctx *G) { return gbuild(G); }
 
-// loopback convenience: run the P ranks of a group on P host threads and wait for all of them
+// loopback convenience: run the P ranks of a group on P host threads and wait for all of them.
+// The threads are PERSISTENT (one process-wide set, started on demand, never joined): a round-4 hunt found the host heap
+// damaged — use after free, always noticed by the main thread inside group creation / destruction — in a few per cent of
+// short processes that built many loopback groups with fresh std::threads per build; nothing in this library frees what
+// those threads touch, but every HIP call makes per-thread runtime state that dies with its thread while the streams it
+// worked on live on.  Rank threads that never exit take that pattern away (profiles/r04u_fresh_process_crash_hunt.md).
+struct LoopPool {
+  std::mutex run_mu;                      // one group's build at a time through the pool
+  std::mutex mu; std::condition_variable cv_work, cv_done;
+  std::function<void()> job[kMaxRanks]; bool has[kMaxRanks] = {};
+  int started = 0, pending = 0;
+  void worker(int i) {
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      cv_work.wait(lk, [&] { return has[i]; });
+      std::function<void()> f = std::move(job[i]);
+      has[i] = false;
+      lk.unlock();
+      f();
+      lk.lock();
+      if (--pending == 0) cv_done.notify_all();
+    }
+  }
+  void run(int P, const std::function<void(int)> &f) {
+    std::lock_guard<std::mutex> one(run_mu);
+    std::unique_lock<std::mutex> lk(mu);
+    while (started < P) { const int i = started++; std::thread([this, i] { worker(i); }).detach(); }
+    for (int r = 0; r < P; r++) { job[r] = [&f, r] { f(r); }; has[r] = true; }
+    pending = P;
+    cv_work.notify_all();
+    cv_done.wait(lk, [&] { return pending == 0; });
+  }
+};
+static LoopPool *loop_pool() { static LoopPool *p = new LoopPool(); return p; }       // (leaked on purpose: its threads never exit)
+
 int32_t dc3hip_global_loopback_build(dc3hip_gctx **ranks, int32_t P) {
   if (!ranks || P < 1 || P > kMaxRanks) { set_err("invalid arguments"); return E_ARGS; }
   for (int r = 0; r < P; r++) if (!ranks[r] || ranks[r]->comm->nranks != P) { set_err("not a loopback group of %d ranks", P); return E_ARGS; }
   ranks[0]->comm->reset_all();         // a failure of an earlier build no longer poisons the group
   std::vector<int> rcs((size_t)P, E_OK);
-  std::vector<std::thread> pool;
-  for (int r = 0; r < P; r++) pool.emplace_back([&, r]() { rcs[(size_t)r] = gbuild(ranks[r]); });
-  for (auto &t : pool) t.join();
+  loop_pool()->run(P, [&](int r) { rcs[(size_t)r] = gbuild(ranks[r]); });
   for (int r = 0; r < P; r++)
     if (rcs[(size_t)r] != E_OK && strstr(ranks[r]->err, "another rank failed") == nullptr) { set_err("rank %d: %s", r, ranks[r]->err); return rcs[(size_t)r]; }
   for (int r = 0; r < P; r++) if (rcs[(size_t)r] != E_OK) { set_err("rank %d: %s", r, ranks[r]->err); return rcs[(size_t)r]; }
@@ -2141,8 +2176,9 @@ int32_t dc3hip_global_sufcheck(dc3hip_gctx *G) {
     // first entries of all shards (a rank with an empty shard passes ~0 and is skipped)
     u64 first_mine = ~0ull, firsts[kMaxRanks], counts[kMaxRanks];
     if (G->shard_count > 0) {
-      HIPC(hipMemcpyAsync(&first_mine, G->w_shard, 8, hipMemcpyDeviceToHost, c->stream));
-      HIPC(hipStreamSynchronize(c->stream));
+      void *fp = nullptr;
+      RC(stage_d2h(c, G->w_shard, 8, &fp));
+      memcpy(&first_mine, fp, 8);
     }
     RC(cm->all_gather_host(&first_mine, firsts, 8));
     const u64 cnt_mine = (u64)G->shard_count;

@@ -61,6 +61,7 @@ struct dc3hip_ctx {
   u32 *d_xcdmon = nullptr;     // [64] (block group, XCD) counts of the XCD-grouped partition kernels (xcd_note)
   int xcd_rr = -1;             // creation-time placement probe: 1 = blocks b and b + 8 shared an XCD and the 8 groups had 8 XCDs
   u32 *h_words = nullptr;      // pinned mirror
+  unsigned char *h_stage = nullptr; size_t h_stage_bytes = 0;   // pinned landing area of every other device-to-host read (stage_d2h)
   // profiling
   bool profile = true;
   bool no_hybrid = false;
@@ -163,6 +164,33 @@ static int ensure_arena(dc3hip_ctx *c, size_t need) {
   if (c->arena) { HIPC(hipFree(c->arena)); c->arena = nullptr; c->arena_bytes = 0; }
   HIPC(hipMalloc(&c->arena, need));
   c->arena_bytes = need;
+  return E_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device-to-host reads of small results (samples, digit tables, monitor words) land in PINNED memory of the context.  An
+// asynchronous copy into pageable memory — a std::vector, a stack array of a rank thread — makes the runtime register
+// and unregister the caller's pages on the fly; with several rank threads doing that at once a round-4 hunt saw glibc's
+// free() called on the base address of the runtime's host aperture a few per cent of the time
+// (profiles/r04u_fresh_process_crash_hunt.md).  stage_d2h_async: the copy is queued, the caller synchronises the stream
+// before reading *host; the area is reused by the next call.
+// ---------------------------------------------------------------------------------------------
+static int stage_d2h_async(dc3hip_ctx *c, const void *dev, size_t bytes, void **host) {
+  if (bytes > c->h_stage_bytes) {
+    HIPC(hipStreamSynchronize(c->stream));
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    c->h_stage = nullptr; c->h_stage_bytes = 0;
+    const size_t want = std::max<size_t>(bytes + bytes / 4, (size_t)1 << 20);
+    HIPC(hipHostMalloc(&c->h_stage, want, hipHostMallocDefault));
+    c->h_stage_bytes = want;
+  }
+  if (bytes) HIPC(hipMemcpyAsync(c->h_stage, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+  *host = c->h_stage;
+  return E_OK;
+}
+static int stage_d2h(dc3hip_ctx *c, const void *dev, size_t bytes, void **host) {
+  RC(stage_d2h_async(c, dev, bytes, host));
+  HIPC(hipStreamSynchronize(c->stream));
   return E_OK;
 }
 

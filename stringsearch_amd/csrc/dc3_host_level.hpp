@@ -458,9 +458,9 @@ static int build_end(dc3hip_ctx *c) {
     HIPC(hipMemcpyAsync(c->stats.trace_sa0, c->d_trace + DC3HIP_MAX_LEVELS, DC3HIP_MAX_LEVELS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIPC(hipMemcpyAsync(c->stats.trace_sa, c->d_trace + 2 * DC3HIP_MAX_LEVELS, DC3HIP_MAX_LEVELS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
   }
-  u32 mon[64];
-  HIPC(hipMemcpyAsync(mon, c->d_xcdmon, sizeof(mon), hipMemcpyDeviceToHost, c->stream));
-  HIPC(hipStreamSynchronize(c->stream));
+  void *monp = nullptr;
+  RC(stage_d2h(c, c->d_xcdmon, 64 * sizeof(u32), &monp));
+  const u32 *mon = static_cast<const u32 *>(monp);
   {
     // where the XCD-grouped partition blocks of this build really ran: share of them on their group's majority XCD
     u64 all = 0, hit = 0;

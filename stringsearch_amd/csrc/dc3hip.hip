@@ -142,10 +142,10 @@ static int ctx_create_impl(dc3hip_ctx **out, int32_t device, int64_t max_n, dc3h
       // ordering's partition passes are only fast when blocks b and b + 8 share an XCD (XCD-grouped reservation,
       // dc3_msd.hip.hpp); on a device that places blocks otherwise the context keeps to the stable 256-bucket LSD passes,
       // whose speed does not depend on placement (DC3HIP_XCD_ASSUME=1: keep the bucket ordering anyway).
-      std::vector<u32> xs(4096);
       hipLaunchKernelGGL(k_xcd_probe, dim3(4096), dim3(64), 0, c->stream, c->d_xcdmon);
-      HIPC(hipMemcpyAsync(xs.data(), c->d_xcdmon, 4096 * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
-      HIPC(hipStreamSynchronize(c->stream));
+      void *hp = nullptr;
+      RC(stage_d2h(c, c->d_xcdmon, 4096 * sizeof(u32), &hp));
+      const u32 *xs = static_cast<const u32 *>(hp);
       u32 cnt[8][8] = {};
       for (u32 b = 0; b < 4096; b++) cnt[b & 7][xs[b] & 7]++;
       u32 hit = 0, seen = 0;
@@ -181,6 +181,7 @@ void dc3hip_ctx_destroy(dc3hip_ctx *c) {
   if (c->d_words) (void)hipFree(c->d_words);
   if (c->d_trace) (void)hipFree(c->d_trace);
   if (c->h_words) (void)hipHostFree(c->h_words);
+  if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
