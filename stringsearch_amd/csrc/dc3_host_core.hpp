@@ -175,14 +175,42 @@ static int ensure_arena(dc3hip_ctx *c, size_t need) {
 // (profiles/r04u_fresh_process_crash_hunt.md).  stage_d2h_async: the copy is queued, the caller synchronises the stream
 // before reading *host; the area is reused by the next call.
 // ---------------------------------------------------------------------------------------------
+// Pinned host buffers are RECYCLED across contexts and never given back to the runtime: the one pointer the crash hunt saw
+// in glibc's free() was the base of the runtime's host-memory mapping — the kind of address hipHostMalloc returns — and the
+// only calls that hand such addresses back are the hipHostFree()s of a context's teardown.  A process holds at most as many
+// of these buffers as it ever had contexts alive at once.
+struct PinnedPool {
+  std::mutex mu;
+  std::vector<std::pair<void *, size_t>> free_list;
+  void *take(size_t bytes, size_t *got) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      for (size_t i = 0; i < free_list.size(); i++)
+        if (free_list[i].second >= bytes && free_list[i].second <= 4 * bytes + 4096) {
+          void *p = free_list[i].first; *got = free_list[i].second;
+          free_list[i] = free_list.back(); free_list.pop_back();
+          return p;
+        }
+    }
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    *got = bytes;
+    return p;
+  }
+  void give(void *p, size_t bytes) { if (p) { std::lock_guard<std::mutex> lk(mu); free_list.emplace_back(p, bytes); } }
+};
+static PinnedPool *pinned_pool() { static PinnedPool *p = new PinnedPool(); return p; }      // (leaked on purpose)
+
 static int stage_d2h_async(dc3hip_ctx *c, const void *dev, size_t bytes, void **host) {
   if (bytes > c->h_stage_bytes) {
     HIPC(hipStreamSynchronize(c->stream));
-    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    pinned_pool()->give(c->h_stage, c->h_stage_bytes);
     c->h_stage = nullptr; c->h_stage_bytes = 0;
     const size_t want = std::max<size_t>(bytes + bytes / 4, (size_t)1 << 20);
-    HIPC(hipHostMalloc(&c->h_stage, want, hipHostMallocDefault));
-    c->h_stage_bytes = want;
+    size_t got = 0;
+    c->h_stage = static_cast<unsigned char *>(pinned_pool()->take(want, &got));
+    if (!c->h_stage) { set_err("no pinned host memory for %zu bytes", want); return E_ALLOC; }
+    c->h_stage_bytes = got;
   }
   if (bytes) HIPC(hipMemcpyAsync(c->h_stage, dev, bytes, hipMemcpyDeviceToHost, c->stream));
   *host = c->h_stage;

@@ -134,7 +134,8 @@ static int ctx_create_impl(dc3hip_ctx **out, int32_t device, int64_t max_n, dc3h
     HIPC(hipMalloc(&c->d_words, 64 * sizeof(u32)));
     HIPC(hipMalloc(&c->d_xcdmon, 4096 * sizeof(u32)));         // (64 monitor words; 4096 for the placement probe below)
     HIPC(hipMalloc(&c->d_trace, 3 * DC3HIP_MAX_LEVELS * sizeof(u64)));
-    HIPC(hipHostMalloc(&c->h_words, 64 * sizeof(u32), hipHostMallocDefault));
+    { size_t got = 0; c->h_words = static_cast<u32 *>(pinned_pool()->take(64 * sizeof(u32), &got)); }
+    if (!c->h_words) { set_err("no pinned host memory"); return E_ALLOC; }
     HIPC(hipEventCreate(&c->ev_build_a));
     HIPC(hipEventCreate(&c->ev_build_b));
     {
@@ -180,8 +181,8 @@ void dc3hip_ctx_destroy(dc3hip_ctx *c) {
   if (c->d_code) (void)hipFree(c->d_code);
   if (c->d_words) (void)hipFree(c->d_words);
   if (c->d_trace) (void)hipFree(c->d_trace);
-  if (c->h_words) (void)hipHostFree(c->h_words);
-  if (c->h_stage) (void)hipHostFree(c->h_stage);
+  pinned_pool()->give(c->h_words, 64 * sizeof(u32));         // (recycled, never hipHostFree'd: PinnedPool)
+  pinned_pool()->give(c->h_stage, c->h_stage_bytes);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
