@@ -94,7 +94,11 @@ template <class Acc>
 static int name_and_rank(dc3hip_ctx *c, Acc acc, u32 m02, u32 m0, u32 *sa12, u32 *rank12, u32 *R, u32 *sslot,
                          u32 *names_out, int *mode) {
   const ArenaMark mk = arena_mark(c);
-  const Chunking ck = make_chunks(c, m02, kBlock * kNameIPT);
+  // fused form (levels beyond one inversion window): the names are made inside the first partition pass of their
+  // inversion (PairsOfNames) from per-tile counts, so the counting kernel works in the partition's tiles
+  const bool fused = m02 > (1u << kInvWindowBits) && !c->no_fuse_names;
+  Chunking ck = make_chunks(c, m02, kBlock * kNameIPT);
+  if (fused) { ck.chunk = kPartTile; ck.nchunks = (m02 + kPartTile - 1) / kPartTile; }
   u32 *counts = nullptr;
   RC(arena_alloc(c, (size_t)ck.nchunks + 16, &counts));
   {
@@ -129,13 +133,18 @@ static int name_and_rank(dc3hip_ctx *c, Acc acc, u32 m02, u32 m0, u32 *sa12, u32
     const bool discard = sslot && !c->no_discard && m02 < 0x7fffffffu && drop_est * kDiscardMinDropInv >= (double)m02 &&
                          c->arena_bytes - c->arena_off >= (size_t)m02 * 16 + (64u << 20);
     *mode = discard ? 2 : 1;
-    {
-      PhaseScope ps(c, DC3HIP_PH_NAMING, m02);
-      hipLaunchKernelGGL((k_name_assign<Acc>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, acc, m02, ck.chunk,
-                         counts, m0, pa, discard ? sslot : (u32 *)nullptr);
-      KCHECK();
+    if (fused) {
+      PairsOfNames<Acc> src; src.acc = acc; src.n = m02; src.m0 = m0; src.base_excl = counts; src.sslot = discard ? sslot : nullptr;
+      RC((inverse_permute_from<PairsOfNames<Acc>>(c, src, false, pa, pb, m02, R, DC3HIP_PH_NAMING)));
+    } else {
+      {
+        PhaseScope ps(c, DC3HIP_PH_NAMING, m02);
+        hipLaunchKernelGGL((k_name_assign<Acc>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, acc, m02, ck.chunk,
+                           counts, m0, pa, discard ? sslot : (u32 *)nullptr);
+        KCHECK();
+      }
+      RC(inverse_permute(c, pa, pb, m02, R, DC3HIP_PH_NAMING));
     }
-    RC(inverse_permute(c, pa, pb, m02, R, DC3HIP_PH_NAMING));
     hipLaunchKernelGGL(k_zero_tail, dim3(1), dim3(64), 0, c->stream, R, m02, 8u);
     KCHECK();
   }
@@ -197,6 +206,23 @@ static int discard_recurse(dc3hip_ctx *c, const u32 *RU, const u32 *sslot, u32 m
   Rec8 *pa = nullptr, *pb = nullptr;
   RC(arena_alloc(c, (size_t)m02, &pa));
   RC(arena_alloc(c, (size_t)m02, &pb));
+  if (m02 > (1u << kInvWindowBits) && !c->no_fuse_names) {
+    // the final order is put together inside the first partition pass of the rank inversion (PairsOfFinal)
+    const u32 ntile = (m02 + kPartTile - 1) / kPartTile;
+    u32 *tc = nullptr;
+    RC(arena_alloc(c, (size_t)ntile + 16, &tc));
+    {
+      PhaseScope ps(c, DC3HIP_PH_DISCARD, m02);
+      hipLaunchKernelGGL(k_nonuniq_count, dim3(ntile), dim3(kBlock), 0, c->stream, sslot, m02, (u32)kPartTile, tc);
+      KCHECK();
+      hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, tc, ntile, (u32 *)nullptr);
+      KCHECK();
+    }
+    PairsOfFinal src; src.sslot = sslot; src.pt = pt; src.base_excl = tc; src.sa12 = sa12;
+    RC((inverse_permute_from<PairsOfFinal>(c, src, false, pa, pb, m02, rank12, DC3HIP_PH_RANKS)));
+    arena_release(c, mk);
+    return E_OK;
+  }
   {
     PhaseScope ps(c, DC3HIP_PH_DISCARD, m02);
     hipLaunchKernelGGL(k_nonuniq_count, dim3(ck.nchunks), dim3(kBlock), 0, c->stream, sslot, m02, ck.chunk, counts);

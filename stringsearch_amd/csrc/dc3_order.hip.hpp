@@ -297,19 +297,25 @@ __global__ __launch_bounds__(kBlock) void k_final_assign(const u32 *__restrict__
 //   pass 1: shift = 22, seg_bits = 32 (one segment), ndig = ceil(n / 2^22) <= 1024
 //   pass 2: shift = 14, seg_bits = 22, ndig = 256   (tiles never straddle a 2^22-pair segment)
 constexpr int kPartNW = 16, kPartIPT = 8, kPartTile = kPartNW * 64 * kPartIPT;   // 8192 pairs
-constexpr size_t kPartSmem = sizeof(Rec8) * kPartTile + sizeof(u32) * (2 * 1024 + 64);
+constexpr size_t kPartSmem = sizeof(Rec8) * kPartTile + sizeof(u32) * (2 * 1024 + 64 + kPartNW * kPartIPT);
 // xcd_tps != 0 (pass 2): the tiles of segment s (xcd_tps tiles each) are worked by the blocks with blockIdx % 8 == s % 8 —
 // the blocks that share an XCD under the dispatcher's round-robin placement (a speed assumption only) — so that every
 // run written into a segment's windows goes through ONE L2 and the partial lines of neighbouring runs meet there
 // (dc3_msd.hip.hpp explains the effect; grid = 8 * ceil(nseg / 8) * xcd_tps).
 // Src: where the pairs come from — an array (PairArray), or made on the fly from a sorted order (PairsOfOrder: pair k =
 // (pos_k, k + 1), which also leaves out_sa[k] = pos_k; saves writing the pairs and reading them back).
+// Sources with kScan make a whole tile at once, because pair k needs a running count over the entries before it (the
+// name of lib.rs:86-92, the number of non-unique entries of the discarding recursion): the count up to the tile comes
+// from a table the caller scanned (one entry per tile of kPartTile pairs), the count inside the tile from ballots and one
+// exchange through LDS.  PairsOfNames replaces k_name_assign + the read of its pairs, PairsOfFinal k_final_assign.
 struct PairArray {
+  static constexpr bool kScan = false;
   const Rec8 *p;
   __device__ __forceinline__ Rec8 load(u32 i) const { return p[i]; }
 };
 template <class Acc>
 struct PairsOfOrder {
+  static constexpr bool kScan = false;
   Acc acc; u32 skip; u32 *out_sa;
   __device__ __forceinline__ Rec8 load(u32 k) const {
     const u32 p = acc.pos(k + skip);
@@ -317,8 +323,83 @@ struct PairsOfOrder {
     return Rec8{p, k + 1};
   }
 };
+// Flags (bit k of fm: the tile entry k * NT + tid, row k, NT = kPartNW * 64 threads) -> ex[k] = flags set among the
+// tile's entries before that entry (index order).  lds: kPartNW * kPartIPT words.  Two barriers.
+__device__ __forceinline__ void part_tile_scan(u32 fm, u32 (&ex)[kPartIPT], u32 *lds) {
+  const u32 w = wave_id(), lane = lane_id();
+#pragma unroll
+  for (int k = 0; k < kPartIPT; k++) {
+    const u64 b = __ballot(((fm >> k) & 1u) != 0u);
+    ex[k] = mbcnt(b);
+    if (lane == 0) lds[k * kPartNW + w] = (u32)__popcll(b);
+  }
+  __syncthreads();
+  if (w == 0) {                                   // exclusive scan of the kPartIPT * kPartNW = 128 row-wave counts, two per lane
+    static_assert(kPartNW * kPartIPT == 128, "two counts per lane of one wave");
+    const u32 a = lds[2 * lane], b = lds[2 * lane + 1];
+    const u32 inc = wave_incl_scan(a + b);
+    lds[2 * lane] = inc - a - b;
+    lds[2 * lane + 1] = inc - b;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kPartIPT; k++) ex[k] += lds[k * kPartNW + w];
+}
+template <class Acc>
+struct PairsOfNames {
+  static constexpr bool kScan = true;
+  Acc acc; u32 n, m0; const u32 *base_excl; u32 *sslot;      // sslot != nullptr: names and slots carry the unique bit
+  __device__ __forceinline__ void load_tile(u32 begin, u32 nvalid, Rec8 (&r)[kPartIPT], u32 *lds) const {
+    constexpr u32 NT = kPartNW * 64;
+    const u32 tid = threadIdx.x;
+    u32 sl[kPartIPT], ex[kPartIPT], fm = 0, um = 0;         // slots; flags and unique bits as masks over the rows
+#pragma unroll
+    for (int k = 0; k < kPartIPT; k++) {
+      const u32 t = k * NT + tid, i = begin + min(t, nvalid - 1u);
+      const u32 f = t < nvalid ? acc.neq(i) : 0u;
+      sl[k] = slot_of(acc.pos(i), m0);
+      fm |= f << k;
+      if (sslot) {
+        u32 fn = __shfl_down(f, 1);
+        if (lane_id() == 63u || t + 1 >= nvalid) fn = i + 1 >= n ? acc.tail_differs() : acc.neq(i + 1);
+        const u32 u = f & fn;
+        um |= u << k;
+        if (t < nvalid) sslot[i] = sl[k] | (u ? kUniqBit : 0u);
+      }
+    }
+    part_tile_scan(fm, ex, lds);
+    const u32 base = base_excl[begin / (u32)kPartTile];
+#pragma unroll
+    for (int k = 0; k < kPartIPT; k++)
+      r[k] = Rec8{sl[k], (base + ex[k] + ((fm >> k) & 1u)) | (((um >> k) & 1u) ? kUniqBit : 0u)};
+  }
+};
+struct PairsOfFinal {
+  static constexpr bool kScan = true;
+  const u32 *sslot, *pt, *base_excl; u32 *sa12;
+  __device__ __forceinline__ void load_tile(u32 begin, u32 nvalid, Rec8 (&r)[kPartIPT], u32 *lds) const {
+    constexpr u32 NT = kPartNW * 64;
+    const u32 tid = threadIdx.x;
+    u32 v[kPartIPT], ex[kPartIPT], fm = 0;
+#pragma unroll
+    for (int k = 0; k < kPartIPT; k++) {
+      const u32 t = k * NT + tid;
+      v[k] = sslot[begin + min(t, nvalid - 1u)];
+      fm |= ((t < nvalid && !(v[k] & kUniqBit)) ? 1u : 0u) << k;
+    }
+    part_tile_scan(fm, ex, lds);
+    const u32 base = base_excl[begin / (u32)kPartTile];
+#pragma unroll
+    for (int k = 0; k < kPartIPT; k++) {
+      const u32 t = k * NT + tid, i = begin + min(t, nvalid - 1u);
+      const u32 sl = ((fm >> k) & 1u) ? pt[base + ex[k]] : (v[k] & ~kUniqBit);
+      if (sa12 && t < nvalid) sa12[i] = sl;
+      r[k] = Rec8{sl, i + 1};
+    }
+  }
+};
 template <class Src>
-__global__ __launch_bounds__(kPartNW * 64) void k_part_msd(Src in, Rec8 *__restrict__ out, u32 n,
+__global__ __launch_bounds__(kPartNW * 64, 8) void k_part_msd(Src in, Rec8 *__restrict__ out, u32 n,
                                                           u32 shift, u32 seg_bits, u32 ndig,
                                                           u32 *__restrict__ cursors, u32 xcd_tps) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -342,8 +423,11 @@ __global__ __launch_bounds__(kPartNW * 64) void k_part_msd(Src in, Rec8 *__restr
   Rec8 r[kPartIPT];
   u32 d[kPartIPT], rk[kPartIPT];
   // (all loads issued back to back: the index is clamped instead of guarded, a guard would put a wait behind every load)
+  if constexpr (Src::kScan) in.load_tile(begin, nvalid, r, tmp + 64);
+  else {
 #pragma unroll
-  for (int k = 0; k < kPartIPT; k++) r[k] = in.load(begin + min((u32)(k * (kPartNW * 64)) + tid, nvalid - 1u));
+    for (int k = 0; k < kPartIPT; k++) r[k] = in.load(begin + min((u32)(k * (kPartNW * 64)) + tid, nvalid - 1u));
+  }
 #pragma unroll
   for (int k = 0; k < kPartIPT; k++) {
     const u32 t = k * (kPartNW * 64) + tid;

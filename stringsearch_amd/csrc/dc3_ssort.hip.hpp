@@ -149,14 +149,15 @@ __global__ __launch_bounds__(kSsNT, 8) void k_ss_count1(const Rec *__restrict__ 
   hist[tid] = 0;
   __syncthreads();
   const u32 begin = t0 * tile, end = min(n, t1 * tile);     // (32-bit: n < 2^32 - tile)
-  for (u32 i = begin + tid; i < end; i += 8 * kSsNT) {
-    SsVal v[8];
-    u32 d[8];
+  // (four searches in lockstep: eight held 64 registers of values and splitters, past the two-blocks-per-CU bound)
+  for (u32 i = begin + tid; i < end; i += 4 * kSsNT) {
+    SsVal v[4];
+    u32 d[4];
 #pragma unroll
-    for (int k = 0; k < 8; k++) v[k] = ss_val(in[min(i + (u32)k * kSsNT, end - 1u)]);
-    ss_count_le_multi<8>(spl, steps, v, d);
+    for (int k = 0; k < 4; k++) v[k] = ss_val(in[min(i + (u32)k * kSsNT, end - 1u)]);
+    ss_count_le_multi<4>(spl, steps, v, d);
 #pragma unroll
-    for (int k = 0; k < 8; k++)
+    for (int k = 0; k < 4; k++)
       if (i + (u32)k * kSsNT < end) { atomicAdd(&hist[d[k]], 1u); dig[i + (u32)k * kSsNT] = (uint16_t)d[k]; }
   }
   __syncthreads();
@@ -237,6 +238,12 @@ __global__ __launch_bounds__(1024) void k_ss_plan1(const u32 *__restrict__ cntg,
   if (d == 0) { tpreh[nb1] = tot; bstart[nb1] = n; startg[nb1 * kSsGroups] = n; }
 }
 
+// a record in registers as one vector (the fourth word of a Rec12 is unused)
+__device__ __forceinline__ u32x4 ss_ld(const Rec16 *p) { return *reinterpret_cast<const u32x4 *>(p); }
+__device__ __forceinline__ void ss_st(Rec16 *p, const u32x4 &v) { *reinterpret_cast<u32x4 *>(p) = v; }
+__device__ __forceinline__ u32x4 ss_ld(const Rec12 *p) { u32x4 v; v.x = p->k0; v.y = p->k1; v.z = p->pos; v.w = 0u; return v; }
+__device__ __forceinline__ void ss_st(Rec12 *p, const u32x4 &v) { p->k0 = v.x; p->k1 = v.y; p->pos = v.z; }
+
 // One partition pass (cf. k_msd_part): block j belongs to group g = j % 8 and works that group's tile number j / 8.
 // The digit of record i is dig[i], left there by the counting kernel that sized the buckets (k_ss_count1 / k_ss_hist2):
 // the splitter search is done once per pass pair, 2 bytes per record carry it over.
@@ -281,17 +288,17 @@ __global__ __launch_bounds__(kSsNT, 8) void k_ss_part(const Rec *__restrict__ in
   const u32 nvalid = end - begin;                  // >= 1
   hist[tid] = 0;
   __syncthreads();
-  Rec r[IPT];
-  u32 rk[IPT], dg[IPT];
+  // The digits first, the records after the ranks are known: with the six 16-byte records held across the ranking and
+  // the scan the kernel did not fit 64 VGPRs and hipcc kept them in scratch — 112 bytes per thread written and read
+  // back, as much memory traffic again as the tile itself (profiles/r05a: WRITE_SIZE 2.1 x the records).
+  u32 pk[IPT];                                     // digit | rank inside the tile's run << 16   (tile < 65536 records)
   // (clamped, not guarded: all loads in flight at once)
 #pragma unroll
-  for (int k = 0; k < IPT; k++) r[k] = in[begin + min((u32)(k * NT) + tid, nvalid - 1u)];
-#pragma unroll
-  for (int k = 0; k < IPT; k++) dg[k] = dig[begin + min((u32)(k * NT) + tid, nvalid - 1u)];
+  for (int k = 0; k < IPT; k++) pk[k] = dig[begin + min((u32)(k * NT) + tid, nvalid - 1u)];
 #pragma unroll
   for (int k = 0; k < IPT; k++) {
     const u32 t = k * NT + tid;
-    rk[k] = t < nvalid ? atomicAdd(&hist[dg[k]], 1u) : 0u;
+    if (t < nvalid) pk[k] |= atomicAdd(&hist[pk[k]], 1u) << 16;
   }
   __syncthreads();
   u32 cnt = 0;
@@ -299,6 +306,10 @@ __global__ __launch_bounds__(kSsNT, 8) void k_ss_part(const Rec *__restrict__ in
     cnt = hist[tid];
     if (cnt) gbase[tid] = atomicAdd(&cur[tid], cnt);
   }
+  // (held as vectors: hipcc left an array of record structs in scratch whatever the register count was)
+  u32x4 r[IPT];
+#pragma unroll
+  for (int k = 0; k < IPT; k++) r[k] = ss_ld(in + begin + min((u32)(k * NT) + tid, nvalid - 1u));
   u32 tot;
   const u32 ex = block_excl_scan<NT / 64>(cnt, tmp, tot);
   hist[tid] = ex;
@@ -306,7 +317,7 @@ __global__ __launch_bounds__(kSsNT, 8) void k_ss_part(const Rec *__restrict__ in
 #pragma unroll
   for (int k = 0; k < IPT; k++) {
     const u32 t = k * NT + tid;
-    if (t < nvalid) { const u32 q = hist[dg[k]] + rk[k]; srec[q] = r[k]; sdig[q] = (uint16_t)dg[k]; }
+    if (t < nvalid) { const u32 dd = pk[k] & 0xffffu, q = hist[dd] + (pk[k] >> 16); ss_st(srec + q, r[k]); sdig[q] = (uint16_t)dd; }
   }
   __syncthreads();
   for (u32 q = tid; q < nvalid; q += NT) {
@@ -345,14 +356,14 @@ __global__ __launch_bounds__(kSsNT, 8) void k_ss_hist2(const Rec *__restrict__ i
     const u32 pb = begin + pt * tile;
     if (pb >= end) break;
     const u32 pe = min(pb + tile, end);
-    for (u32 i = pb + tid; i < pe; i += 8 * kSsNT) {
-      SsVal v[8];
-      u32 d[8];
+    for (u32 i = pb + tid; i < pe; i += 4 * kSsNT) {
+      SsVal v[4];
+      u32 d[4];
 #pragma unroll
-      for (int k = 0; k < 8; k++) v[k] = ss_val(in[min(i + (u32)k * kSsNT, pe - 1u)]);
-      ss_count_le_multi<8>(spl, steps, v, d);
+      for (int k = 0; k < 4; k++) v[k] = ss_val(in[min(i + (u32)k * kSsNT, pe - 1u)]);
+      ss_count_le_multi<4>(spl, steps, v, d);
 #pragma unroll
-      for (int k = 0; k < 8; k++)
+      for (int k = 0; k < 4; k++)
         if (i + (u32)k * kSsNT < pe) { atomicAdd(&hist[d[k]], 1u); dig[i + (u32)k * kSsNT] = (uint16_t)d[k]; }
     }
   }

@@ -94,6 +94,7 @@ static int ctx_create_impl(dc3hip_ctx **out, int32_t device, int64_t max_n, dc3h
   { const char *e = getenv("DC3HIP_TUP_SCATTER_MIN"); if (e && *e) c->tup_scatter_min = (u32)strtoul(e, nullptr, 10); }
   { const char *e = getenv("DC3HIP_MSD_MIN"); if (e) c->msd_min = (u32)std::max(4096ll, atoll(e)); }
   { const char *e = getenv("DC3HIP_NO_SSORT"); c->no_ssort = (e && e[0] == '1'); }
+  { const char *e = getenv("DC3HIP_NO_FUSE_NAMES"); c->no_fuse_names = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_SSORT_VERIFY"); c->ssort_verify = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_NO_PACK_COUNT"); c->no_pack_count = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_SSORT_REC12"); c->ssort_rec12 = (e && e[0] == '1'); }

@@ -7,7 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def kernels(asm=None):
-    """[(demangled name, max threads per block, VGPRs incl. AGPRs, static LDS bytes, scratch bytes, blocks per CU by VGPRs)]"""
+    """[(demangled name, max threads per block, VGPRs, static LDS bytes, scratch bytes, blocks per CU by VGPRs)]
+    (.vgpr_count of gfx90a+ metadata is the unified total, accumulation registers included: .agpr_count is not added)"""
     s = open(asm or os.path.join(ROOT, "stringsearch_amd", "csrc", "dc3hip.gfx950.s")).read()
     meta = s[s.index("amdhsa.kernels:"):]
     rows = []
@@ -20,9 +21,9 @@ def kernels(asm=None):
         lds, sc = int(g("group_segment_fixed_size")), int(g("private_segment_fixed_size"))
         waves = (wg + 63) // 64
         per_simd = (waves + 3) // 4
-        gran = max(8, (v + a + 7) // 8 * 8)
+        gran = max(8, (max(v, a) + 7) // 8 * 8)
         by_v = min(8, 512 // gran) // per_simd
-        rows.append((name, wg, v + a, lds, sc, by_v))
+        rows.append((name, wg, max(v, a), lds, sc, by_v))
     names = subprocess.run(["c++filt"], input="\n".join(r[0] for r in rows), capture_output=True, text=True).stdout.splitlines()
     return [(d,) + r[1:] for r, d in zip(rows, names)]
 

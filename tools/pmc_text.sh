@@ -1,0 +1,36 @@
+#!/bin/bash
+# GPU box: PMC counters of ONE build of a synthetic input (default: the 1 GiB low-entropy text of configs[2]), per kernel.
+# Separate passes (FETCH_SIZE and WRITE_SIZE cannot share one; SQ groups of <= 8 counters), the program directly after `--`.
+# usage: tools/pmc_text.sh TAG [n:kind]   ->  gpurun_out/pmc_TAG_<group>_by_kernel.csv, gpurun_out/pmc_TAG_stats.json
+tag=${1:-text}
+spec=${2:-1073741824:2}
+: "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}"
+cd /tmp && export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out
+i=0
+for grp in "FETCH_SIZE" "WRITE_SIZE" \
+           "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
+  i=$((i+1))
+  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d gpurun_out/pmcrun_${tag}_$i -- python3 tools/one_build.py $spec --dump gpurun_out/pmc_${tag}_stats.json > gpurun_out/pmc_${tag}_$i.json 2> gpurun_out/pmc_${tag}_$i.err
+  f=$(find gpurun_out/pmcrun_${tag}_$i -name "*counter_collection.csv" | head -1)
+  [ -z "$f" ] && { echo "group $i ($grp): no output"; tail -3 gpurun_out/pmc_${tag}_$i.err; continue; }
+  python3 - "$f" "$tag" "$i" <<'PY'
+import csv, sys, collections
+f, tag, i = sys.argv[1:4]
+agg = collections.defaultdict(lambda: collections.defaultdict(float)); calls = collections.defaultdict(set)
+for row in csv.DictReader(open(f)):
+    k = row["Kernel_Name"].split("(")[0]
+    agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
+    calls[k].add(row.get("Dispatch_Id") or row.get("Correlation_Id"))
+ctrs = sorted({c for k in agg for c in agg[k]})
+out = open(f"gpurun_out/pmc_{tag}_g{i}_by_kernel.csv", "w")
+out.write("kernel,calls," + ",".join(ctrs) + "\n")
+for k in sorted(agg, key=lambda k: -agg[k][ctrs[0]]):
+    out.write(f"\"{k}\",{len(calls[k])}," + ",".join(f"{agg[k][c]:.1f}" for c in ctrs) + "\n")
+out.close()
+PY
+  rm -rf gpurun_out/pmcrun_${tag}_$i
+  head -6 gpurun_out/pmc_${tag}_g${i}_by_kernel.csv | cut -c1-220
+done
