@@ -33,7 +33,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from stringsearch_amd.benchlib import HBM_PEAK_GBS, KINDS, PATH_NAMES, KernelAcc, kernel_rooflines, parse_size, path_roofline  # noqa: E402
+from stringsearch_amd.benchlib import HBM_PEAK_GBS, KINDS, PATH_NAMES, KernelAcc, build_block, kernel_rooflines, parse_size, path_roofline  # noqa: E402
 
 
 def host_cpu_model():
@@ -387,14 +387,12 @@ def main():
                 with ss.Context(n, device=local_rank) as c2:
                     c2.generate(n, args.seed, kind, offset=off)
                     c2.build()
-                    ms = []
-                    for _ in range(min(args.steps, 3)):
-                        c2.build(); ms.append(c2.stats()["build_ms"])
-                    st2 = c2.stats()
-                    out["dc3_recursion_only"] = {"switch": "DC3HIP_NO_TEXT_SHORTCUT=1", "device_ms_per_step": sum(ms) / len(ms),
-                                                 "MBps": n / (sum(ms) / len(ms)) / 1e3, "sufcheck": c2.sufcheck(),
+                    st2, m2, blk = build_block(ss, c2, min(args.steps, 3), "pmc_traffic_recursion.json")
+                    out["dc3_recursion_only"] = {"switch": "DC3HIP_NO_TEXT_SHORTCUT=1", "device_ms_per_step": m2,
+                                                 "MBps": n / m2 / 1e3, "sufcheck": c2.sufcheck(),
                                                  "checksum_equal": (c2.checksum() == chk0) if chk0 is not None else None,
                                                  "levels": list(zip(st2["level_n"], st2["level_K"], st2["level_sorted"]))}
+                    out["dc3_recursion_only"].update(blk)
             finally:
                 os.environ.pop("DC3HIP_NO_TEXT_SHORTCUT", None)
         # BASELINE.json configs[2] (low-entropy text) and the per-GPU class of configs[4] (DNA) at the same size:
@@ -406,11 +404,7 @@ def main():
                     continue
                 c3.generate(n, seed, kd)
                 c3.build()
-                ms = []
-                for _ in range(3):
-                    c3.build(); ms.append(c3.stats()["build_ms"])
-                st3 = c3.stats()
-                m = sum(ms) / len(ms)
+                st3, m, blk = build_block(ss, c3, 3, "pmc_traffic_text.json" if name == "text" else "pmc_traffic_dna.json")
                 per_cfg[f"{name}_{per_gpu / 2**30:g}GiB"] = {
                     "ms": m, "MB/s": n / m / 1e3, "sufcheck": c3.sufcheck(), "levels": st3["levels"],
                     "path": PATH_NAMES.get(st3.get("text_sort_state", 0), "?"),
@@ -418,8 +412,8 @@ def main():
                     # wider window than the triple (dc3_ssort.hip.hpp)
                     "splitter_ordering": {k: st3.get(k) for k in ("ssort_sorts", "ssort_fallbacks", "ssort_max_subbucket",
                                                                   "ssort_part_ms", "ssort_local_ms")},
-                    "level_name_width": st3.get("level_name_width"),
-                    "roofline_path": path_roofline(st3, m)}
+                    "level_name_width": st3.get("level_name_width")}
+                per_cfg[f"{name}_{per_gpu / 2**30:g}GiB"].update(blk)
                 if st3.get("text_sort_state", 0) != 0:
                     # finished (or started) by the whole-text order: the DC3 recursion proper on the same text beside it
                     chk3 = c3.checksum()
@@ -562,6 +556,9 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        # HIP_VERSION the library was compiled against vs the runtime it really ran on (torch is imported first here, so
+        # it is the wheel's): profiles/r05_crash_hunt.md
+        out["hip_runtime"] = ss.hip_versions()
         print(json.dumps(out))
 
 

@@ -99,6 +99,10 @@ DC3HIP_API void dc3hip_release_cache(void);
 DC3HIP_API const char *dc3hip_version(void);
 DC3HIP_API const char *dc3hip_last_error(void); /* thread-local, never NULL */
 DC3HIP_API int32_t dc3hip_device_count(void);   /* number of visible HIP devices, <0 on error */
+/* HIP_VERSION the library was compiled against and hipRuntimeGetVersion() of the runtime the process really runs on (a
+ * host program that maps its own libamdhip64 first — a PyTorch wheel does — makes the library run on that one).  Returns 1
+ * when major and minor agree, 0 when they differ (the library also says so once on stderr), <0 on error. */
+DC3HIP_API int32_t dc3hip_hip_versions(int32_t *compiled, int32_t *runtime);
 
 /* ---- context API: device-resident builds (bench / repeated calls / multi-GPU hosts) ---------- */
 
@@ -318,6 +322,25 @@ typedef struct dc3hip_gstats {
   int64_t select_p1;         /* orderings of this rank whose partition pass 1 selected the rank's key range from the replicated string (no records built or routed) */
   int64_t wide_deepen_rounds; /* wide mode: rounds of deepening by rank look-ups (windows repeated beyond the symbol compares; 0 = not needed) */
 } dc3hip_gstats;
+
+/* Per-rank HBM need of a global-mode build of total_n bytes over nranks ranks, computed by the library's own sizing rules
+ * (the formulas its allocations use) WITHOUT touching a device: what a deployment checks before it asks for an 8-GPU node.
+ * wide = 1: total_n > DC3HIP_MAX_N, 64-bit positions.  All figures in bytes, per rank. */
+typedef struct dc3hip_gplan {
+  int32_t struct_size, wide;
+  int64_t total_n;
+  int32_t nranks, reserved;
+  int64_t records_per_rank;   /* suffixes a rank is planned to hold: ceil(n / P) * 9/8 (key-range splitters from a sample) */
+  int64_t text_bytes;         /* the replicated text */
+  int64_t context_bytes;      /* SA / small buffers of the rank's context (not wide: 4 bytes per text byte) */
+  int64_t arena_bytes;        /* work arena at its largest */
+  int64_t order_bytes;        /* wide: record buffers + shard (+ flags) of the ordering at their largest; else 0 (inside the arena) */
+  int64_t deepen_bytes;       /* wide: shard + inverse + flags + one rank's shard while repeats are settled by rank look-ups */
+  int64_t big_group_bytes_per_member; /* wide: on top, per suffix that sits in a group of more than 1024 tied suffixes */
+  int64_t peak_bytes;         /* text + context + arena + max(order, deepen) */
+  int64_t hbm_bytes;          /* 288e9: one MI355X */
+} dc3hip_gplan;
+DC3HIP_API int32_t dc3hip_global_plan(int64_t total_n, int32_t nranks, dc3hip_gplan *out);
 
 /* P loopback ranks on `device` (-1 = current), each able to take part in builds of up to max_total_n bytes.
  * device = DC3HIP_DEVICE_SPREAD puts rank r on device r % (visible devices): ONE process drives all GPUs of the node

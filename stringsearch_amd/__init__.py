@@ -9,7 +9,7 @@ The compute path is libdc3hip.so ONLY.  There is no CPU fallback: importing work
 (so the ABI can be inspected), but every build call fails loudly if the library or a device is missing.
 """
 from ._lib import lib, lib_path, Dc3HipError, Stats, GStats, PHASES  # noqa: F401
-from .global_sa import GlobalRank, LoopbackGroup  # noqa: F401
+from .global_sa import GlobalRank, LoopbackGroup, global_plan  # noqa: F401
 from .api import (  # noqa: F401
     Context,
     LongestCommonSubstring,
@@ -18,6 +18,7 @@ from .api import (  # noqa: F401
     SuffixArray,
     common_prefix_len,
     device_count,
+    hip_versions,
     last_error,
     release_cache,
     sort,
@@ -30,6 +31,6 @@ from .api import (  # noqa: F401
 
 __all__ = [
     "Context", "Dc3HipError", "GlobalRank", "GStats", "LoopbackGroup", "LongestCommonSubstring", "NotSorted", "PartitionedSuffixArray", "PHASES", "Stats",
-    "SuffixArray", "common_prefix_len", "device_count", "last_error", "lib", "release_cache", "lib_path", "sort", "sort_i64",
+    "SuffixArray", "common_prefix_len", "device_count", "global_plan", "hip_versions", "last_error", "lib", "release_cache", "lib_path", "sort", "sort_i64",
     "sort_in_place", "sufcheck", "verify", "version",
 ]

@@ -20,6 +20,17 @@ F_DEVICE_PTRS = 1      # DC3HIP_F_DEVICE_PTRS
 F_ALL_DEVICES = 2      # DC3HIP_F_ALL_DEVICES
 
 
+class GPlan(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_int32), ("wide", ctypes.c_int32), ("total_n", ctypes.c_int64), ("nranks", ctypes.c_int32),
+                ("reserved", ctypes.c_int32), ("records_per_rank", ctypes.c_int64), ("text_bytes", ctypes.c_int64),
+                ("context_bytes", ctypes.c_int64), ("arena_bytes", ctypes.c_int64), ("order_bytes", ctypes.c_int64),
+                ("deepen_bytes", ctypes.c_int64), ("big_group_bytes_per_member", ctypes.c_int64), ("peak_bytes", ctypes.c_int64),
+                ("hbm_bytes", ctypes.c_int64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
 class Opts(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_int32), ("index_bits", ctypes.c_int32), ("device", ctypes.c_int32),
                 ("num_partitions", ctypes.c_int32), ("flags", ctypes.c_int32)]
@@ -125,6 +136,7 @@ SYMBOLS = {
     "dc3hip_divbwt_i32": (_i32, [_vp, _vp, _vp, _i32]),
     "dc3hip_release_cache": (None, []),
     "dc3hip_version": (ctypes.c_char_p, []),
+    "dc3hip_hip_versions": (ctypes.c_int32, [ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "dc3hip_last_error": (ctypes.c_char_p, []),
     "dc3hip_device_count": (_i32, []),
     "dc3hip_ctx_create": (_i32, [ctypes.POINTER(_vp), _i32, _i64]),
@@ -163,6 +175,7 @@ SYMBOLS = {
     "dc3hip_global_get_shard_u32": (_i32, [_vp, _vp]),
     "dc3hip_global_shard_checksum": (_i32, [_vp, ctypes.POINTER(_u64)]),
     "dc3hip_global_sufcheck": (_i32, [_vp]),
+    "dc3hip_global_plan": (_i32, [_i64, _i32, ctypes.POINTER(GPlan)]),
     "dc3hip_global_stats": (_i32, [_vp, ctypes.POINTER(GStats), ctypes.POINTER(Stats)]),
     "dc3hip_global_last_error": (ctypes.c_char_p, [_vp]),
     "dc3hip_global_transport": (ctypes.c_char_p, [_vp]),

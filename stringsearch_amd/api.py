@@ -12,6 +12,16 @@ def version():
     return lib().dc3hip_version().decode()
 
 
+def hip_versions():
+    """{"compiled": HIP_VERSION of the build, "runtime": hipRuntimeGetVersion(), "match": major.minor agree} —
+    the runtime is the wheel's when torch was imported before the library was loaded."""
+    import ctypes
+    ct, rt = ctypes.c_int32(0), ctypes.c_int32(0)
+    rc = lib().dc3hip_hip_versions(ctypes.byref(ct), ctypes.byref(rt))
+    fmt = lambda v: f"{v // 10000000}.{v // 100000 % 100}.{v % 100000}"
+    return {"compiled": fmt(ct.value), "runtime": fmt(rt.value), "match": rc == 1}
+
+
 def last_error():
     return lib().dc3hip_last_error().decode()
 

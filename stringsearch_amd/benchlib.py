@@ -91,17 +91,23 @@ _FAM = {
 }
 
 
-def kernel_rooflines(acc, steps, st_last, kernel_ms=None):
+def load_pmc(pmc_name):
+    """(profiles/<pmc_name> or None, collected on exactly these kernel sources?)"""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
+    except Exception:
+        return None, False
+    return pmc, pmc.get("kernel_sources_sha") == kernel_sources_sha()
+
+
+def kernel_rooflines(acc, steps, st_last, kernel_ms=None, pmc_name="pmc_traffic.json"):
     """roofline objects of the kernel families of a build, keyed by family; `dominant` = the one with the largest share
     of the build time.  achieved = algorithmic bytes per launch / average launch duration (HIP events recorded on the
-    build's own stream around every launch)."""
+    build's own stream around every launch).  pmc_name: the PMC collection of THIS workload (default build, recursion only,
+    text) whose per-record HBM bytes are replayed into `traffic`."""
     kernel_ms = kernel_ms if kernel_ms is not None else acc.build_ms
     kernel_ms = max(kernel_ms, 1e-9)
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-    except Exception:
-        pmc = None
-    pmc_ok = pmc is not None and pmc.get("kernel_sources_sha") == kernel_sources_sha()
+    pmc, pmc_ok = load_pmc(pmc_name)
     out = {}
     for fam, (name, alg_b, moved_b, pkey) in _FAM.items():
         if not acc.launches[fam]:
@@ -119,7 +125,7 @@ def kernel_rooflines(acc, steps, st_last, kernel_ms=None):
         r["moved_frac_of_achievable"] = r["moved_GBps"] / HBM_ACHIEVABLE_GBS
         if pmc_ok and pkey in pmc.get("bytes_per_record", {}):
             r["traffic"] = pmc["bytes_per_record"][pkey] * per_launch
-            r["traffic_from"] = {"file": "profiles/pmc_traffic.json", "source": pmc.get("source"), "commit": pmc.get("commit"),
+            r["traffic_from"] = {"file": "profiles/" + pmc_name, "source": pmc.get("source"), "commit": pmc.get("commit"),
                                  "kernel_sources_sha": pmc.get("kernel_sources_sha"),
                                  "note": "per-record bytes of the rocprofv3 --pmc passes made on exactly these kernel sources x this run's records per launch"}
         out[fam] = r
@@ -145,17 +151,56 @@ def kernel_rooflines(acc, steps, st_last, kernel_ms=None):
         out["gather"] = r
     dominant = max(out.values(), key=lambda r: r["share_of_build_time"]) if out else None
     if dominant is not None and pmc is not None and not pmc_ok:
-        dominant["traffic_note"] = ("profiles/pmc_traffic.json was collected on other kernel sources (sha %s, these are %s): not replayed"
-                                    % (pmc.get("kernel_sources_sha"), kernel_sources_sha()))
+        dominant["traffic_note"] = ("profiles/%s was collected on other kernel sources (sha %s, these are %s): not replayed"
+                                    % (pmc_name, pmc.get("kernel_sources_sha"), kernel_sources_sha()))
     return dominant, out
 
 
-def path_roofline(st, ms):
-    alg = algorithmic_bytes(st["level_n"])
-    return {"algorithmic_bytes_per_step": alg, "device_ms_per_step": ms,
-            "achieved_GBps": alg / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "levels": list(zip(st["level_n"], st["level_K"], st["level_sorted"])),
-            "phase_ms": {k: round(v, 3) for k, v in st["phase_ms"].items() if v}}
+def path_roofline(st, ms, pmc_name="pmc_traffic.json"):
+    """Whole-build figure.  A build that ran DC3 levels is priced by SURVEY §8(d) — B(n_l) = n_l (46 w + 29 c_l) / 3 summed
+    over the levels that really ran — and its fraction of the HBM peak follows from those ALGORITHMIC bytes.  A build that
+    finished in the whole-text order ran no DC3 level: §8(d)'s 71 B per input byte is not its work (priced that way it
+    would "move" more than the 8 TB/s peak), so it is priced by the bytes it MOVED — the PMC collection of this workload on
+    exactly these kernel sources, or, without one, the kernels' design traffic — and says so in `priced_by`."""
+    pmc, pmc_ok = load_pmc(pmc_name)
+    moved = pmc.get("whole_build_bytes_streaming_corrected") if (pmc is not None and pmc_ok) else None
+    out = {"device_ms_per_step": ms,
+           "levels": list(zip(st["level_n"], st["level_K"], st["level_sorted"])),
+           "phase_ms": {k: round(v, 3) for k, v in st["phase_ms"].items() if v},
+           "moved_bytes_per_step": moved,
+           "moved_bytes_from": ("profiles/" + pmc_name + " (rocprofv3 FETCH_SIZE / WRITE_SIZE of one build of this workload, gfx950 corrections)") if moved else None}
+    if moved:
+        out["moved_GBps"] = moved / (ms * 1e-3) / 1e9
+        out["moved_frac_of_hbm_peak"] = out["moved_GBps"] / HBM_PEAK_GBS
+    if st.get("text_sort_state", 0) == 1:
+        n = st["level_n"][0] if st["level_n"] else 0
+        # design traffic of the whole-text order, per position: count pass 1 B, pass 1 from the text 1 + 8, pass 2 8 + 8, local
+        # order 8 + 5, tie pass 1 (+ gathers for the tied)  = 40 B
+        design = 40.0 * n
+        use = moved if moved else design
+        out.update({"priced_by": "moved bytes (whole-text order: no DC3 level ran, SURVEY 8(d)'s per-level bytes do not apply)" + ("" if moved else " — design traffic, no PMC collection on these sources"),
+                    "algorithmic_bytes_per_step": None, "design_bytes_per_step": design,
+                    "achieved_GBps": use / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": use / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+    else:
+        alg = algorithmic_bytes(st["level_n"])
+        out.update({"priced_by": "SURVEY 8(d): B(n_l) = n_l (46 w + 29 c_l) / 3 over the DC3 levels this build ran",
+                    "algorithmic_bytes_per_step": alg,
+                    "achieved_GBps": alg / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+    return out
+
+
+def build_block(ss, ctx, n_builds, pmc_name):
+    """Timed builds of a prepared context -> a bench block with its own `roofline` (dominant kernel family), every family
+    and the whole-build figure, priced with the PMC collection of this workload."""
+    acc = KernelAcc()
+    ms = []
+    for _ in range(n_builds):
+        ctx.build()
+        st = ctx.stats()
+        acc.add(st); ms.append(st["build_ms"])
+    m = sum(ms) / len(ms)
+    roof, roof_all = kernel_rooflines(acc, n_builds, st, acc.build_ms, pmc_name)
+    return st, m, {"roofline": roof, "roofline_kernels": roof_all, "roofline_path": path_roofline(st, m, pmc_name)}
 
 
 PATH_NAMES = {0: "dc3 recursion", 1: "whole-text order (all windows distinct: 9 bytes, or 3L symbols of a small alphabet; no recursion level built)",

@@ -342,8 +342,13 @@ struct dc3hip_gctx {
   uint8_t *w_same = nullptr;            // one byte per word of the bucket ordering: same image as the word before
   size_t w_cap_a = 0, w_cap_b = 0, w_cap_s = 0, w_cap_same = 0;
   // wide mode, deepening by rank look-ups (wide_deepen): the whole order, its equal-window flags and its inverse on every rank
+  // (w_sa_all: one rank's shard at a time while the inverse is built — the whole order is never held, round 5)
   u64 *w_sa_all = nullptr, *w_isa = nullptr; uint8_t *w_eq_all = nullptr, *w_eq2 = nullptr;
   size_t w_cap_sa = 0, w_cap_isa = 0, w_cap_eq = 0, w_cap_eq2 = 0;
+  // groups beyond kWideTieBig members (a run of one symbol, a short period): group starts of the shard (w_aux, 4 bytes per
+  // entry) and the compacted members with their sort records (w_aux2, 48 bytes per member of such a group)
+  unsigned char *w_aux = nullptr, *w_aux2 = nullptr;
+  size_t w_cap_aux = 0, w_cap_aux2 = 0;
   bool w_isa_valid = false;             // the last build ended with w_isa = the exact inverse of the order (the verifier uses it)
   bool no_wide_deepen = false;          // DC3HIP_NO_WIDE_DEEPEN=1 (tests): windows that repeat beyond the symbol compares' budget are refused, as before round 4
   dc3hip_gstats gs;
@@ -1314,7 +1319,9 @@ static uint8_t *gtext(dc3hip_gctx *G) { return G->wide ? G->w_text : G->c->d_tex
 
 static int wide_key(dc3hip_gctx *G, u32 sigma, WideKey *k, u32 *ibits_out) {
   const double n = (double)G->total_n;
-  if (sigma < 2) { set_err("wide global mode: a text over one symbol has no distinct windows"); return E_TOOBIG; }
+  // (a text over one symbol: every image is 0 and every window repeats — one group that the deepening orders; the image
+  //  arithmetic runs as for two symbols)
+  if (sigma < 2) { if (G->no_wide_deepen) { set_err("wide global mode: a text over one symbol has no distinct windows"); return E_TOOBIG; } sigma = 2; }
   const u32 ibits = std::min<u32>(63, 9 * (u32)ceil((log2(n) + 4.2) / 9.0));
   u32 J = 1; u64 SJ = sigma;
   while (J < kWideMaxImageSyms && (SJ >> std::min<u32>(ibits + 2, 62)) == 0 && SJ * sigma < (1ull << 63)) { SJ *= sigma; J++; }
@@ -1347,6 +1354,133 @@ static int wide_ensure(dc3hip_ctx *c, T **p, size_t *cap, size_t need) {
   *cap = want;
   return E_OK;
 }
+// ---- groups of any size (kernels: dc3_wide.hip.hpp, "Groups of any size") -------------------------------------------
+// f(i, start of i's group) for the n entries whose run structure `same` describes (same[0] = 0)
+template <class F>
+static int wide_seg_apply(dc3hip_ctx *c, const uint8_t *same, u32 n, F f) {
+  if (n == 0) return E_OK;
+  const u32 ntiles = (n + kSegTile - 1) / kSegTile;
+  const ArenaMark mk = arena_mark(c);
+  u32 *tiles = nullptr;
+  RC(arena_alloc(c, (size_t)ntiles + 16, &tiles));
+  hipLaunchKernelGGL(k_seg_last, dim3(ntiles), dim3(kBlock), 0, c->stream, same, n, tiles);
+  KCHECK();
+  hipLaunchKernelGGL(k_seg_carry, dim3(1), dim3(1024), 0, c->stream, tiles, ntiles);
+  KCHECK();
+  hipLaunchKernelGGL((k_seg_apply<F>), dim3(ntiles), dim3(kBlock), 0, c->stream, same, n, (const u32 *)tiles, f);
+  KCHECK();
+  arena_release(c, mk);      // (the stream orders the launches before whatever reuses the table)
+  return E_OK;
+}
+// the members of this rank's groups of more than kWideTieBig entries, compacted in index order
+struct WideBig { u32 nb = 0; u32 *cslot = nullptr, *gid = nullptr; u64 *cpos = nullptr; Rec16 *ra = nullptr, *rb = nullptr; };
+template <class Pos>
+static int wide_big_collect(dc3hip_gctx *G, const uint8_t *same, u32 nrec, Pos pos, WideBig *bg) {
+  dc3hip_ctx *c = G->c;
+  bg->nb = 0;
+  if (nrec == 0) return E_OK;
+  RC(wide_ensure(c, &G->w_aux, &G->w_cap_aux, ((size_t)nrec + 16) * 4));
+  u32 *gstart = reinterpret_cast<u32 *>(G->w_aux);
+  SegStore st; st.gstart = gstart;
+  RC(wide_seg_apply(c, same, nrec, st));
+  const u32 ntiles = (nrec + kSegTile - 1) / kSegTile;
+  const ArenaMark mk = arena_mark(c);
+  u32 *counts = nullptr;
+  RC(arena_alloc(c, (size_t)ntiles + 16, &counts));
+  hipLaunchKernelGGL(k_big_count, dim3(ntiles), dim3(kBlock), 0, c->stream, (const u32 *)gstart, nrec, kWideTieBig, counts);
+  KCHECK();
+  hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, counts, ntiles, c->d_words + 34);
+  KCHECK();
+  HIPC(hipMemcpyAsync(c->h_words + 34, c->d_words + 34, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipStreamSynchronize(c->stream));
+  const u32 nb = c->h_words[34];
+  if (nb) {
+    const size_t per = 4 + 4 + 8 + 16 + 16;
+    const int rc = wide_ensure(c, &G->w_aux2, &G->w_cap_aux2, ((size_t)nb + 16) * per);
+    if (rc != E_OK) { arena_release(c, mk); return rc; }
+    unsigned char *b = G->w_aux2;
+    bg->ra = reinterpret_cast<Rec16 *>(b); b += ((size_t)nb + 16) * 16;
+    bg->rb = reinterpret_cast<Rec16 *>(b); b += ((size_t)nb + 16) * 16;
+    bg->cpos = reinterpret_cast<u64 *>(b); b += ((size_t)nb + 16) * 8;
+    bg->cslot = reinterpret_cast<u32 *>(b); b += ((size_t)nb + 16) * 4;
+    bg->gid = reinterpret_cast<u32 *>(b);
+    hipLaunchKernelGGL((k_big_write<Pos>), dim3(ntiles), dim3(kBlock), 0, c->stream, (const u32 *)gstart, nrec, kWideTieBig, (const u32 *)counts, pos,
+                       bg->cslot, bg->gid, bg->cpos);
+    KCHECK();
+  }
+  bg->nb = nb;
+  arena_release(c, mk);
+  return E_OK;
+}
+// Segmented sort of the collected members: `ncomp` key components of `bits` bits, most significant first, made by
+// make(component, order so far, records out); the stable LSD passes order them last component first, the group's start
+// index last.  *sorted = the records in final order (pos = index of the member in the compacted list).
+template <class Make>
+static int wide_big_sort(dc3hip_gctx *G, const WideBig &bg, u32 nrec, int ncomp, u32 bits, Make make, const Rec16 **sorted) {
+  dc3hip_ctx *c = G->c;
+  const Rec16 *prev = nullptr;
+  for (int comp = ncomp - 1; comp >= -1; comp--) {
+    // (the records of a component are made IN PLACE over the order so far: place j reads and writes element j only)
+    Rec16 *in = prev ? const_cast<Rec16 *>(prev) : bg.ra, *other = (in == bg.ra) ? bg.rb : bg.ra, *res = nullptr;
+    if (comp >= 0) RC(make(comp, prev, in));
+    else {
+      hipLaunchKernelGGL(k_seg_recs_gid, dim3(grid_for(c, bg.nb)), dim3(kBlock), 0, c->stream, prev, bg.nb, (const u32 *)bg.gid, in);
+      KCHECK();
+    }
+    RC(radix_sort<Rec16>(c, in, other, bg.nb, 0, comp >= 0 ? bits : bits_of((u64)nrec), &res, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT12_DOWN));
+    prev = res;
+  }
+  *sorted = prev;
+  return E_OK;
+}
+// Big groups of the symbol tie pass (entries with one sort image): ordered by their first kWideBigSyms symbols, exactly.
+// pos: positions of the sorted records; same: same-image flags.  The shard then is in order kWideBigSyms symbols deep
+// wherever such a group stood (and deeper elsewhere): the caller lowers its depth to that.
+constexpr u32 kWideBigSyms = 56;           // 8 components of 7 symbols (a multiple of 4: wide_cmp's depth)
+template <class Pos>
+static int wide_big_syms(dc3hip_gctx *G, const uint8_t *same, u32 nrec, Pos pos, const WideKey &k, u32 *nb_out) {
+  dc3hip_ctx *c = G->c;
+  WideBig bg;
+  RC(wide_big_collect(G, same, nrec, pos, &bg));
+  *nb_out = bg.nb;
+  if (!bg.nb) return E_OK;
+  PhaseScope ps(c, DC3HIP_PH_TIES, bg.nb);
+  const Rec16 *sorted = nullptr;
+  RC(wide_big_sort(G, bg, nrec, (int)(kWideBigSyms / 7), 63u, [&](int comp, const Rec16 *prev, Rec16 *out) -> int {
+    SegKeySyms key; key.k = k; key.off = (u32)comp * 7u;
+    hipLaunchKernelGGL((k_seg_recs<SegKeySyms>), dim3(grid_for(c, bg.nb)), dim3(kBlock), 0, c->stream, prev, bg.nb, (const u64 *)bg.cpos, key, k.code, out);
+    KCHECK();
+    return E_OK;
+  }, &sorted));
+  hipLaunchKernelGGL(k_seg_writeback, dim3(grid_for(c, bg.nb)), dim3(kBlock), 0, c->stream, sorted, bg.nb, (const u32 *)bg.cslot, (const u64 *)bg.cpos, G->w_shard);
+  KCHECK();
+  return E_OK;
+}
+// Big groups of a deepening round (entries that agree on D symbols): ordered by the W rank look-ups isa[p + j D], j = 1..W,
+// the new flags written for all their members (words[2] of c->d_words + 10 counts those that still agree).
+static int wide_big_isa(dc3hip_gctx *G, const uint8_t *eq, u32 nrec, u64 n, u64 D, u32 W, uint8_t *neweq) {
+  dc3hip_ctx *c = G->c;
+  WideBig bg;
+  PosShard ps; ps.s = G->w_shard;
+  RC(wide_big_collect(G, eq, nrec, ps, &bg));
+  if (!bg.nb) return E_OK;
+  PhaseScope pss(c, DC3HIP_PH_TIES, bg.nb);
+  const Rec16 *sorted = nullptr;
+  RC(wide_big_sort(G, bg, nrec, (int)W, bits_of(n), [&](int comp, const Rec16 *prev, Rec16 *out) -> int {
+    SegKeyIsa key; key.isa = G->w_isa; key.n = n; key.add = (u64)(comp + 1) * D;
+    hipLaunchKernelGGL((k_seg_recs<SegKeyIsa>), dim3(grid_for(c, bg.nb)), dim3(kBlock), 0, c->stream, prev, bg.nb, (const u64 *)bg.cpos, key, (const uint16_t *)nullptr, out);
+    KCHECK();
+    return E_OK;
+  }, &sorted));
+  hipLaunchKernelGGL(k_seg_writeback, dim3(grid_for(c, bg.nb)), dim3(kBlock), 0, c->stream, sorted, bg.nb, (const u32 *)bg.cslot, (const u64 *)bg.cpos, G->w_shard);
+  KCHECK();
+  SegCmpIsa cmp; cmp.isa = G->w_isa; cmp.n = n; cmp.D = D; cmp.W = W;
+  hipLaunchKernelGGL((k_seg_neweq<SegCmpIsa>), dim3(grid_for(c, bg.nb)), dim3(kBlock), 0, c->stream, sorted, bg.nb, (const u32 *)bg.cslot, (const u32 *)bg.gid,
+                     (const u64 *)bg.cpos, cmp, neweq, c->d_words + 10);
+  KCHECK();
+  return E_OK;
+}
+
 // The tie rounds of a wide build over the sorted records h[0..nrec): positions to G->w_shard, statistics in
 // c->h_words[10..12] (oversized group, tied records, windows that still agree after the last round).
 template <class Launch>
@@ -1512,6 +1646,15 @@ static int wide_msd_order(dc3hip_gctx *G, const WideKey &k, u32 ibits, u64 lo, u
   RC(wide_tie_rounds_with(G, nrec, k, [&](const WideKey &kk) {
     hipLaunchKernelGGL((k_wide_ties8<OutT>), dim3(grid_for(c, nrec)), dim3(kBlock), 0, c->stream, h, (const uint8_t *)same, nrec, pb, kk, shard, c->d_words + 10);
   }));
+  if constexpr (sizeof(OutT) == 8) {
+    if (c->h_words[10] && G->wide && !G->no_wide_deepen) {      // (groups beyond kWideTieBig records: see gbuild_wide)
+      PosWord8 ph; ph.h = h; ph.pmask = (1ull << pb) - 1ull;
+      u32 nbig = 0;
+      RC(wide_big_syms(G, same, nrec, ph, k, &nbig));
+      G->w_depth = std::min<u32>(G->w_depth, kWideBigSyms);
+      c->h_words[10] = 0; c->h_words[12] = std::max<u32>(c->h_words[12], 1u);
+    }
+  }
   arena_release(c, mk);
   G->gs.wide_msd = 1;
   *done = true;
@@ -1575,13 +1718,16 @@ template <class T> static void wide_release(T **p, size_t *cap) { if (*p) (void)
 constexpr u32 kWideDeepenW = 16;
 static int wide_deepen(dc3hip_gctx *G, WideKey k, u32 nrec, u64 pre, const uint64_t *all, bool *ok) {
   dc3hip_ctx *c = G->c; GComm *cm = G->comm;
-  const int P = cm->nranks;
+  const int P = cm->nranks, me = cm->rank;
   const u64 n = k.n;
   *ok = false;
   HIPC(hipStreamSynchronize(c->stream));
-  wide_release(&G->w_ra, &G->w_cap_a);                     // the sort's buffers are done with: room for the whole order
+  wide_release(&G->w_ra, &G->w_cap_a);                     // the sort's buffers are done with: room for the inverse
   wide_release(&G->w_rb, &G->w_cap_b);
-  int rc_alloc = wide_ensure(c, &G->w_sa_all, &G->w_cap_sa, (size_t)n + 16);
+  u64 maxshard = 0;
+  for (int r = 0; r < P; r++) maxshard = std::max<u64>(maxshard, all[r]);
+  // the inverse is built from one rank's shard at a time (w_sa_all = the largest shard), never from the whole order
+  int rc_alloc = wide_ensure(c, &G->w_sa_all, &G->w_cap_sa, (size_t)maxshard + 16);
   if (rc_alloc == E_OK) rc_alloc = wide_ensure(c, &G->w_isa, &G->w_cap_isa, (size_t)n + 16);
   if (rc_alloc == E_OK) rc_alloc = wide_ensure(c, &G->w_eq_all, &G->w_cap_eq, (size_t)n + 16);
   if (rc_alloc == E_OK) rc_alloc = wide_ensure(c, &G->w_eq2, &G->w_cap_eq2, (size_t)nrec + 16);
@@ -1589,8 +1735,9 @@ static int wide_deepen(dc3hip_gctx *G, WideKey k, u32 nrec, u64 pre, const uint6
   uint64_t badp = 0, nbad = 0;
   RC(gather_counts(cm, rc_alloc != E_OK ? 1u : 0u, &badp, &nbad));
   if (nbad) return E_OK;                                   // (every rank returns here: the caller refuses the text as before)
-  size_t roff8[kMaxRanks], rb8[kMaxRanks], roff1[kMaxRanks], rb1[kMaxRanks];
-  { u64 acc = 0; for (int r = 0; r < P; r++) { roff8[r] = (size_t)acc * 8; rb8[r] = (size_t)all[r] * 8; roff1[r] = (size_t)acc; rb1[r] = (size_t)all[r]; acc += all[r]; } }
+  size_t roff1[kMaxRanks], rb1[kMaxRanks];
+  u64 first[kMaxRanks];
+  { u64 acc = 0; for (int r = 0; r < P; r++) { first[r] = acc; roff1[r] = (size_t)acc; rb1[r] = (size_t)all[r]; acc += all[r]; } }
   // the depth the look-ups start from: what EVERY rank's symbol compares reached (a rank stops deepening them by its own
   // count of agreeing windows; its shard is in order at least that deep)
   u64 D = G->w_depth;
@@ -1602,38 +1749,67 @@ static int wide_deepen(dc3hip_gctx *G, WideKey k, u32 nrec, u64 pre, const uint6
     KCHECK();
   }
   bool final_round = false;
-  for (int round = 0; round < 40; round++) {
-    if (nrec) HIPC(hipMemcpyAsync(G->w_sa_all + pre, G->w_shard, (size_t)nrec * 8, hipMemcpyDeviceToDevice, c->stream));
-    RC(cm->all_gather_v(G->w_sa_all + pre, (size_t)nrec * 8, G->w_sa_all, roff8, rb8, c->stream));
+  for (int round = 0; round < 64; round++) {
     RC(cm->all_gather_v(G->w_eq_all + pre, (size_t)nrec, G->w_eq_all, roff1, rb1, c->stream));
     G->gs.exchanges += 1;
-    {
-      PhaseScope ps(c, DC3HIP_PH_RANKS, n);
-      HIPC(hipMemsetAsync(G->w_isa + n, 0, 8, c->stream));
-      hipLaunchKernelGGL(k_wide_isa_scatter, dim3(grid_for(c, n)), dim3(kBlock), 0, c->stream, (const u64 *)G->w_sa_all, (const uint8_t *)G->w_eq_all, n, G->w_isa);
-      KCHECK();
+    // isa[p] = 1 + index of the first entry of p's group, rank by rank: every rank receives rank r's shard (an all-gather
+    // in which only r contributes) and scatters the group starts of that range; a rank's range begins with a new group
+    HIPC(hipMemsetAsync(G->w_isa + n, 0, 8, c->stream));
+    for (int r = 0; r < P; r++) {
+      if (all[r] == 0) continue;
+      size_t ro[kMaxRanks], rbz[kMaxRanks];
+      for (int q = 0; q < P; q++) { ro[q] = 0; rbz[q] = 0; }
+      rbz[r] = (size_t)all[r] * 8;
+      RC(cm->all_gather_v(r == me ? (const void *)G->w_shard : (const void *)G->w_sa_all, r == me ? (size_t)nrec * 8 : 0, G->w_sa_all, ro, rbz, c->stream));
+      PhaseScope ps(c, DC3HIP_PH_RANKS, (int64_t)all[r]);
+      SegIsa f; f.sa = G->w_sa_all; f.isa = G->w_isa; f.base = first[r];
+      RC(wide_seg_apply(c, G->w_eq_all + first[r], (u32)all[r], f));
     }
     if (final_round) { *ok = true; break; }
     HIPC(hipMemsetAsync(c->d_words + 10, 0, 3 * sizeof(u32), c->stream));
+    int rc_big = E_OK;
     if (nrec) {
-      PhaseScope ps(c, DC3HIP_PH_TIES, nrec);
-      hipLaunchKernelGGL(k_wide_ties_isa, dim3(grid_for(c, nrec)), dim3(kBlock), 0, c->stream, G->w_shard, (const uint8_t *)(G->w_eq_all + pre), nrec,
-                         (const u64 *)G->w_isa, n, D, kWideDeepenW, G->w_eq2, c->d_words + 10);
-      KCHECK();
+      {
+        PhaseScope ps(c, DC3HIP_PH_TIES, nrec);
+        hipLaunchKernelGGL(k_wide_ties_isa, dim3(grid_for(c, nrec)), dim3(kBlock), 0, c->stream, G->w_shard, (const uint8_t *)(G->w_eq_all + pre), nrec,
+                           (const u64 *)G->w_isa, n, D, kWideDeepenW, G->w_eq2, c->d_words + 10);
+        KCHECK();
+      }
+      HIPC(hipMemcpyAsync(c->h_words + 10, c->d_words + 10, 3 * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+      HIPC(hipStreamSynchronize(c->stream));
+      if (c->h_words[10]) {
+        // groups beyond kWideTieBig members: a segmented sort by the same look-ups (rank-local; its failure is agreed on below)
+        rc_big = wide_big_isa(G, G->w_eq_all + pre, nrec, n, D, kWideDeepenW, G->w_eq2);
+        if (rc_big != E_OK && rc_big != E_ALLOC) return rc_big;
+      }
       HIPC(hipMemcpyAsync(G->w_eq_all + pre, G->w_eq2, (size_t)nrec, hipMemcpyDeviceToDevice, c->stream));
     }
     HIPC(hipMemcpyAsync(c->h_words + 10, c->d_words + 10, 3 * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
+    c->h_words[10] = 0;
     G->gs.wide_deepen_rounds += 1;
-    uint64_t p0 = 0, nover = 0, ntied = 0;
-    RC(gather_counts(cm, c->h_words[10] ? 1u : 0u, &p0, &nover));
+    uint64_t p0 = 0, nfail = 0, ntied = 0;
+    RC(gather_counts(cm, rc_big != E_OK ? 1u : 0u, &p0, &nfail));
     RC(gather_counts(cm, c->h_words[12] ? 1u : 0u, &p0, &ntied));
-    if (nover) break;
+    if (nfail) { if (rc_big == E_OK) set_err("wide global mode: another rank has no memory for its groups of tied suffixes"); break; }
     D *= (u64)kWideDeepenW + 1;
     if (!ntied) final_round = true;                        // (one more exchange: the inverse of the finished order)
-    else if (D > 2 * n) { set_err("internal: suffixes still tied %llu symbols deep", (unsigned long long)D); return E_HIP; }
+    else if (D > 2 * n * ((u64)kWideDeepenW + 1)) { set_err("internal: suffixes still tied %llu symbols deep", (unsigned long long)D); return E_HIP; }
   }
   if (*ok) { G->w_isa_valid = true; c->h_words[10] = 0; c->h_words[12] = 0; G->w_depth = (u32)std::min<u64>(D, 1u << 30); }
+  return E_OK;
+}
+
+// The placement probe of context creation (xcd_rr -> no_msd) is a per-device observation, but no_msd decides which COLLECTIVE
+// schedule a rank runs (selected pass 1 without an all-to-all, or the routed form; whether the wide bucket ordering is
+// tried): ranks on different devices — or a probe disturbed on one of them — must not disagree.  One host all-gather per
+// build: the bucket ordering is used only if every rank may use it.
+static int gagree_placement(dc3hip_gctx *G) {
+  GComm *cm = G->comm;
+  if (cm->nranks == 1) return E_OK;
+  uint64_t mine = G->c->no_msd ? 1u : 0u, all[kMaxRanks];
+  RC(cm->all_gather_host(&mine, all, sizeof(uint64_t)));
+  for (int r = 0; r < cm->nranks; r++) if (all[r]) G->c->no_msd = true;
   return E_OK;
 }
 
@@ -1643,6 +1819,7 @@ static int gbuild_wide(dc3hip_gctx *G) {
   const u64 n = (u64)G->total_n;
   c->n = 0;
   c->arena_off = 0;
+  RC(gagree_placement(G));
   G->w_isa_valid = false;
   if (G->w_sa_all || G->w_isa) {             // (a deepened build's whole-order arrays: the sort needs the room again)
     HIPC(hipStreamSynchronize(c->stream));
@@ -1670,7 +1847,7 @@ static int gbuild_wide(dc3hip_gctx *G) {
   const u32 sigma = c->h_words[1];
   WideKey k; u32 ibits = 0;
   RC(wide_key(G, sigma, &k, &ibits));
-  if ((double)k.W * log2((double)sigma) < 2.0 * log2((double)n) + 2.0) {
+  if (G->no_wide_deepen && (double)k.W * log2((double)sigma) < 2.0 * log2((double)n) + 2.0) {
     set_err("wide global mode: %u-symbol windows over %u symbols cannot all be distinct in %llu bytes", k.W, sigma, (unsigned long long)n);
     return E_TOOBIG;
   }
@@ -1748,7 +1925,20 @@ static int gbuild_wide(dc3hip_gctx *G) {
     }
     Rec16 *h = G->w_ra;
     if (nrec) RC(radix_sort<Rec16>(c, G->w_ra, G->w_rb, nrec, 0, ibits, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN, DC3HIP_PH_SORT12_DOWN));
-    return wide_tie_rounds(G, h, nrec, k);
+    RC(wide_tie_rounds(G, h, nrec, k));
+    if (c->h_words[10] && !G->no_wide_deepen) {
+      // images shared by more than kWideTieBig records (a run of one symbol, a short period): those groups are ordered by
+      // their first kWideBigSyms symbols here and go on through the deepening like every other repeat
+      RC(wide_ensure(c, &G->w_same, &G->w_cap_same, (size_t)nrec + 16));
+      hipLaunchKernelGGL(k_wide_same16, dim3(grid_for(c, nrec)), dim3(kBlock), 0, c->stream, (const Rec16 *)h, nrec, G->w_same);
+      KCHECK();
+      PosRec16 ph; ph.h = h;
+      u32 nbig = 0;
+      RC(wide_big_syms(G, G->w_same, nrec, ph, k, &nbig));
+      G->w_depth = std::min<u32>(G->w_depth, kWideBigSyms);
+      c->h_words[10] = 0; c->h_words[12] = std::max<u32>(c->h_words[12], 1u);
+    }
+    return E_OK;
   }();
   if (local_rc != E_OK && local_rc != E_TOOBIG && local_rc != E_ALLOC) return local_rc;     // HIP / transport faults: as before
   arena_release(c, mk);
@@ -1760,14 +1950,10 @@ static int gbuild_wide(dc3hip_gctx *G) {
   RC(gather_counts(cm, nrec, &pre, &tot, all));
   if (tot != n) { set_err("wide global order: %llu of %llu positions selected", (unsigned long long)tot, (unsigned long long)n); return E_HIP; }
   if (ngood != (uint64_t)P && !G->no_wide_deepen) {
-    // windows repeat beyond what the symbol compares settle: rank look-ups (wide_deepen), unless a group is oversized
-    uint64_t p0 = 0, nover = 0;
-    RC(gather_counts(cm, c->h_words[10] ? 1u : 0u, &p0, &nover));
-    if (!nover) {
-      bool deep_ok = false;
-      RC(wide_deepen(G, k, nrec, pre, all, &deep_ok));
-      if (deep_ok) ngood = (uint64_t)P;
-    }
+    // windows repeat beyond what the symbol compares settle: rank look-ups (wide_deepen)
+    bool deep_ok = false;
+    RC(wide_deepen(G, k, nrec, pre, all, &deep_ok));
+    if (deep_ok) ngood = (uint64_t)P;
   }
   if (ngood != (uint64_t)P) {
     set_err("wide global mode: some %u-symbol window of the text repeats; texts of 2^32 bytes and more are only built when all windows "
@@ -1799,6 +1985,7 @@ static int gbuild_inner(dc3hip_gctx *G) {
   if (G->wide) return gbuild_wide(G);
   c->n = n;
   c->arena_off = 0;
+  RC(gagree_placement(G));
   RC(ensure_arena(c, arena_requirement(n)));      // a rank may end up with a whole level's key range: the full budget
   RC(build_begin(c));
   // 1. the text, replicated: all-gather of the ranks' blocks (n x (P-1)/P bytes in per rank)
@@ -1880,6 +2067,47 @@ static int gctx_make_ctx(dc3hip_gctx *G, int device, int64_t max_total_n) {
 // C ABI of the global mode
 // ---------------------------------------------------------------------------------------------
 extern "C" {
+
+// wide_ensure()'s growth rule (elements)
+static size_t wide_slack(size_t need) { return need + need / 16 + 1024; }
+int32_t dc3hip_global_plan(int64_t total_n, int32_t nranks, dc3hip_gplan *out) {
+  if (!out || total_n < 0 || nranks < 1 || nranks > kMaxRanks) { set_err("dc3hip_global_plan: invalid arguments (1 <= nranks <= %d)", kMaxRanks); return E_ARGS; }
+  if (total_n > ((int64_t)1 << 40)) { set_err("n=%lld exceeds 2^40", (long long)total_n); return E_TOOBIG; }
+  memset(out, 0, sizeof(*out));
+  out->struct_size = (int32_t)sizeof(*out);
+  out->total_n = total_n; out->nranks = nranks;
+  out->hbm_bytes = 288000000000ll;
+  const size_t n = (size_t)total_n;
+  const size_t share = (n + (size_t)nranks - 1) / (size_t)nranks;
+  const size_t nrec = nranks == 1 ? n : std::min(n, share + share / 8 + 4096);
+  out->records_per_rank = (int64_t)nrec;
+  out->wide = total_n > DC3HIP_MAX_N ? 1 : 0;
+  const size_t small = 256 * 4 + 256 * 2 + 64 * 4 + 4096 * 4 + 3 * DC3HIP_MAX_LEVELS * 8;     // d_present, d_code, d_words, d_xcdmon, d_trace
+  if (!out->wide) {
+    // a rank is a whole single-device context of the text (gctx_make_ctx): text, SA, and the arena at arena_requirement()
+    out->text_bytes = (int64_t)(n + 64);
+    out->context_bytes = (int64_t)((n + 16) * 4 + small);
+    out->arena_bytes = (int64_t)arena_requirement(total_n);
+    out->peak_bytes = out->text_bytes + out->context_bytes + out->arena_bytes;
+    return E_OK;
+  }
+  out->text_bytes = (int64_t)(n + 64);
+  out->context_bytes = (int64_t)(64 + 64 + small);
+  out->arena_bytes = (int64_t)((size_t)256 << 20);                                            // gbuild_wide: ensure_arena(256 MiB)
+  // ordering (gbuild_wide): two 16-byte record arrays + the 8-byte shard (the 16-byte LSD form: the larger of the two forms;
+  // the bucket ordering holds two 8-byte word arrays, the shard and a flag byte per word)
+  const size_t lsd = 2 * 16 * wide_slack(nrec + 16) + 8 * wide_slack(nrec + 16);
+  const size_t msd = 2 * 16 * wide_slack(nrec / 2 + 16) + 8 * wide_slack(nrec + 16) + wide_slack(nrec + 16);
+  out->order_bytes = (int64_t)std::max(lsd, msd);
+  // deepening (wide_deepen): the record arrays are released; shard and flags stay, one rank's shard at a time (8 bytes per
+  // suffix of the largest share), the inverse (8 n), the flags of the whole order (n) and of the rank's range, the group
+  // starts of the rank's range (4 bytes per entry, only while a group beyond kWideTieBig members is being ordered)
+  out->deepen_bytes = (int64_t)(8 * wide_slack(nrec + 16) + wide_slack(nrec + 16) + 8 * wide_slack(nrec + 16) + 8 * wide_slack(n + 16) +
+                                wide_slack(n + 16) + wide_slack(nrec + 16) + wide_slack((nrec + 16) * 4));
+  out->big_group_bytes_per_member = 48;                                                       // wide_big_collect: two records, position, slot, group
+  out->peak_bytes = out->text_bytes + out->context_bytes + out->arena_bytes + std::max(out->order_bytes, out->deepen_bytes);
+  return E_OK;
+}
 
 int32_t dc3hip_global_loopback_create(dc3hip_gctx **ranks, int32_t P, int32_t device, int64_t max_total_n) {
   if (!ranks || P < 1 || P > kMaxRanks || max_total_n < 0) { set_err("dc3hip_global_loopback_create: invalid arguments (1 <= P <= %d)", kMaxRanks); return E_ARGS; }
@@ -1990,6 +2218,8 @@ void dc3hip_global_destroy(dc3hip_gctx *G) {
   if (G->w_isa) (void)hipFree(G->w_isa);
   if (G->w_eq_all) (void)hipFree(G->w_eq_all);
   if (G->w_eq2) (void)hipFree(G->w_eq2);
+  if (G->w_aux) (void)hipFree(G->w_aux);
+  if (G->w_aux2) (void)hipFree(G->w_aux2);
   if (G->c) dc3hip_ctx_destroy(G->c);
   delete G;
 }
@@ -2205,6 +2435,31 @@ int32_t dc3hip_global_sufcheck(dc3hip_gctx *G) {
     HIPC(hipStreamSynchronize(c->stream));
     u64 err = c->h_words[20], errs[kMaxRanks];
     if (tot != (u64)G->total_n) err = std::max<u64>(err, 2);
+    {
+      // A deepened order is checked against the rank's OWN copy of the inverse: each slice of it is verified by its owner
+      // against the real shard (isa[p] == index, above), and a rank reads other ranks' slices for the neighbour test — so
+      // all copies must be the same array.  Order-sensitive checksum of the whole inverse on every rank, compared.
+      u64 have = G->w_isa_valid ? 1ull : 0ull, sum = 0, haves[kMaxRanks], sums[kMaxRanks];
+      RC(cm->all_gather_host(&have, haves, 8));
+      bool any = false, all_have = true;
+      for (int r = 0; r < P; r++) { any = any || haves[r]; all_have = all_have && haves[r]; }
+      if (any && !all_have) err = std::max<u64>(err, 3);
+      if (all_have) {
+        u64 *acc = reinterpret_cast<u64 *>(c->d_words + 22);
+        HIPC(hipMemsetAsync(acc, 0, 8, c->stream));
+        const u64 nn = (u64)G->total_n;
+        for (u64 off = 0; off < nn; off += (u64)1 << 30) {
+          const u32 cnt = (u32)std::min<u64>((u64)1 << 30, nn - off);
+          hipLaunchKernelGGL(k_wide_checksum, dim3(grid_for(c, cnt)), dim3(kBlock), 0, c->stream, (const u64 *)G->w_isa + off, cnt, off, acc);
+          KCHECK();
+        }
+        void *sp = nullptr;
+        RC(stage_d2h(c, acc, 8, &sp));
+        memcpy(&sum, sp, 8);
+        RC(cm->all_gather_host(&sum, sums, 8));
+        for (int r = 0; r < P; r++) if (sums[r] != sums[0]) err = std::max<u64>(err, 3);
+      }
+    }
     RC(cm->all_gather_host(&err, errs, 8));
     u64 worst = 0;
     for (int r = 0; r < P; r++) worst = std::max(worst, errs[r]);

@@ -60,7 +60,7 @@ struct dc3hip_ctx {
   u32 *d_words = nullptr;      // [64] misc totals / error words
   u32 *d_xcdmon = nullptr;     // [64] (block group, XCD) counts of the XCD-grouped partition kernels (xcd_note)
   int xcd_rr = -1;             // creation-time placement probe: 1 = blocks b and b + 8 shared an XCD and the 8 groups had 8 XCDs
-  u32 *h_words = nullptr;      // pinned mirror
+  u32 *h_words = nullptr; size_t h_words_bytes = 0;   // pinned mirror (and the size the pool gave)
   unsigned char *h_stage = nullptr; size_t h_stage_bytes = 0;   // pinned landing area of every other device-to-host read (stage_d2h)
   // profiling
   bool profile = true;
@@ -176,31 +176,47 @@ static int ensure_arena(dc3hip_ctx *c, size_t need) {
 // (profiles/r04u_fresh_process_crash_hunt.md).  stage_d2h_async: the copy is queued, the caller synchronises the stream
 // before reading *host; the area is reused by the next call.
 // ---------------------------------------------------------------------------------------------
-// Pinned host buffers are RECYCLED across contexts and never given back to the runtime: the one pointer the crash hunt saw
-// in glibc's free() was the base of the runtime's host-memory mapping — the kind of address hipHostMalloc returns — and the
-// only calls that hand such addresses back are the hipHostFree()s of a context's teardown.  A process holds at most as many
-// of these buffers as it ever had contexts alive at once.
+// Pinned host buffers are RECYCLED across contexts: a context pins at least 1 MiB and sacapart-style callers create many
+// worker and child contexts.  (Round 4 never handed them back at all: the one pointer its crash hunt saw in glibc's free()
+// was the base of the runtime's host-memory mapping, the kind hipHostMalloc returns.  Round 5: the deaths follow the HIP
+// runtime — 0 of 110 perturbed fresh processes on the ROCm 7.2 runtime the library is compiled against, 1 of 110 and all 13
+// of round 4 on the 7.0 runtime bundled with a PyTorch wheel that was mapped first — and the host half runs clean under
+// ASan and TSan on a mock runtime, tools/hostmock; profiles/r05_crash_hunt.md.)  The pool is best-fit and capped: beyond
+// kKeepBuffers / kKeepBytes idle buffers go back to the runtime.
 struct PinnedPool {
+  static constexpr size_t kKeepBuffers = 64, kKeepBytes = (size_t)256 << 20;
   std::mutex mu;
   std::vector<std::pair<void *, size_t>> free_list;
+  size_t idle_bytes = 0;
   void *take(size_t bytes, size_t *got) {
     {
       std::lock_guard<std::mutex> lk(mu);
+      size_t best = free_list.size();
       for (size_t i = 0; i < free_list.size(); i++)
-        if (free_list[i].second >= bytes && free_list[i].second <= 4 * bytes + 4096) {
-          void *p = free_list[i].first; *got = free_list[i].second;
-          free_list[i] = free_list.back(); free_list.pop_back();
-          return p;
-        }
+        if (free_list[i].second >= bytes && free_list[i].second <= 4 * bytes + 4096 && (best == free_list.size() || free_list[i].second < free_list[best].second)) best = i;
+      if (best != free_list.size()) {
+        void *p = free_list[best].first; *got = free_list[best].second;
+        idle_bytes -= free_list[best].second;
+        free_list[best] = free_list.back(); free_list.pop_back();
+        return p;
+      }
     }
     void *p = nullptr;
     if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     *got = bytes;
     return p;
   }
-  void give(void *p, size_t bytes) { if (p) { std::lock_guard<std::mutex> lk(mu); free_list.emplace_back(p, bytes); } }
+  // bytes: the size take() reported for this buffer
+  void give(void *p, size_t bytes) {
+    if (!p) return;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (free_list.size() < kKeepBuffers && idle_bytes + bytes <= kKeepBytes) { free_list.emplace_back(p, bytes); idle_bytes += bytes; return; }
+    }
+    (void)hipHostFree(p);
+  }
 };
-static PinnedPool *pinned_pool() { static PinnedPool *p = new PinnedPool(); return p; }      // (leaked on purpose)
+static PinnedPool *pinned_pool() { static PinnedPool *p = new PinnedPool(); return p; }      // (lives as long as the process)
 
 static int stage_d2h_async(dc3hip_ctx *c, const void *dev, size_t bytes, void **host) {
   if (bytes > c->h_stage_bytes) {

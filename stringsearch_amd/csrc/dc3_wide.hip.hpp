@@ -225,14 +225,6 @@ __global__ __launch_bounds__(kBlock) void k_wide_eq(const u64 *__restrict__ shar
   for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < nrec; i += gridDim.x * kBlock)
     eq[i] = (i > 0 && wide_cmp(k, shard[i - 1], shard[i], k.W, lcode) == 0) ? 1 : 0;
 }
-// sa / eq: the whole order and its flags (all ranks' shards in rank order); groups are at most kWideTieBig long
-__global__ __launch_bounds__(kBlock) void k_wide_isa_scatter(const u64 *__restrict__ sa, const uint8_t *__restrict__ eq, u64 n, u64 *__restrict__ isa) {
-  for (u64 g = (u64)blockIdx.x * kBlock + threadIdx.x; g < n; g += (u64)gridDim.x * kBlock) {
-    u64 s = g;
-    while (eq[s]) s--;
-    isa[sa[g]] = s + 1;
-  }
-}
 __device__ __forceinline__ int wide_cmp_isa(const u64 *__restrict__ isa, u64 n, u64 p, u64 q, u64 D, u32 W) {
 #pragma unroll 1
   for (u32 j = 0; j <= W; j++) {
@@ -294,6 +286,177 @@ __global__ __launch_bounds__(kBlock) void k_wide_check_isa(const u64 *__restrict
     const u64 rp = p + 1 < k.n ? isa[p + 1] : 0ull, rq = q + 1 < k.n ? isa[q + 1] : 0ull;
     if (cp > cq || (cp == cq && rp >= rq)) atomicMax(err, 3u);
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Groups of any size (round 5: the one-thread-per-group kernels above stop at kWideTieBig members and used to refuse the
+// text: a run of one symbol, a short period).  A group = a maximal run of entries whose flag same[i] says "belongs to the
+// group of entry i - 1" (same[0] = 0).
+//   k_seg_last / k_seg_carry / k_seg_apply   start of every entry's group, in three streaming launches (no walk back)
+//   k_big_count / k_big_write                 the members of groups beyond T entries, compacted in index order
+//   k_seg_recs*                               16-byte records (one key component, index of the member) for the stable LSD
+//                                             passes: the members are ordered component by component, last component
+//                                             first, the group's start index last — a segmented sort by a key of any width
+//   k_seg_writeback, k_seg_neweq              the members go back to their slots in the new order, with the flags
+// The key components are 7 text symbols (9 bits each: 0 = past the end) or one rank look-up isa[p + j D].
+// ---------------------------------------------------------------------------------------------
+constexpr u32 kSegTile = 4096, kSegIPT = kSegTile / kBlock;     // entries per block, per thread (consecutive)
+constexpr u32 kSegNone = 0xffffffffu;
+// last[b] = index of the last entry of tile b that starts a group, kSegNone if it has none
+__global__ __launch_bounds__(kBlock) void k_seg_last(const uint8_t *__restrict__ same, u32 n, u32 *__restrict__ last) {
+  __shared__ u32 tmp[kWaves];
+  const u32 base = blockIdx.x * kSegTile + threadIdx.x * kSegIPT;
+  u32 cur = 0;                                             // index + 1 of the last start seen (0 = none)
+#pragma unroll
+  for (u32 j = 0; j < kSegIPT; j++) { const u32 i = base + j; if (i < n && same[i] == 0) cur = i + 1; }
+  cur = wave_reduce_max(cur);
+  if (lane_id() == 0) tmp[wave_id()] = cur;
+  __syncthreads();
+  if (threadIdx.x == 0) { u32 m = 0; for (int w = 0; w < kWaves; w++) m = max(m, tmp[w]); last[blockIdx.x] = m ? m - 1 : kSegNone; }
+}
+// in place: last[b] -> start of the group that reaches into tile b (entry 0 starts a group, so tile 0 carries 0 in)
+__global__ __launch_bounds__(1024) void k_seg_carry(u32 *__restrict__ last, u32 ntiles) {
+  __shared__ u32 tmp[16];
+  u32 carry = 1;                                           // index + 1
+  for (u32 base = 0; base < ntiles; base += 1024) {
+    const u32 b = base + threadIdx.x;
+    const u32 v = (b < ntiles && last[b] != kSegNone) ? last[b] + 1 : 0u;
+    u32 inc = v;                                           // inclusive running max inside the wave, then across waves
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const u32 t = __shfl_up(inc, o); if (lane_id() >= (u32)o) inc = max(inc, t); }
+    if (lane_id() == 63) tmp[wave_id()] = inc;
+    __syncthreads();
+    u32 pre = carry;
+    for (u32 w = 0; w < wave_id(); w++) pre = max(pre, tmp[w]);
+    u32 all = carry;
+    for (u32 w = 0; w < 16; w++) all = max(all, tmp[w]);
+    const u32 up = __shfl_up(inc, 1);
+    const u32 excl = max(pre, lane_id() ? up : 0u);        // max over everything before tile b
+    if (b < ntiles) last[b] = excl - 1;
+    __syncthreads();
+    carry = all;
+  }
+}
+// f(i, start of i's group) for every entry
+template <class F>
+__global__ __launch_bounds__(kBlock) void k_seg_apply(const uint8_t *__restrict__ same, u32 n, const u32 *__restrict__ carry, F f) {
+  __shared__ u32 tmp[kWaves];
+  const u32 base = blockIdx.x * kSegTile + threadIdx.x * kSegIPT;
+  u32 g[kSegIPT], cur = 0;
+#pragma unroll
+  for (u32 j = 0; j < kSegIPT; j++) { const u32 i = base + j; if (i < n && same[i] == 0) cur = i + 1; g[j] = cur; }
+  u32 inc = cur;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const u32 t = __shfl_up(inc, o); if (lane_id() >= (u32)o) inc = max(inc, t); }
+  if (lane_id() == 63) tmp[wave_id()] = inc;
+  __syncthreads();
+  u32 pre = carry[blockIdx.x] + 1;
+  for (u32 w = 0; w < wave_id(); w++) pre = max(pre, tmp[w]);
+  const u32 up = __shfl_up(inc, 1);
+  pre = max(pre, lane_id() ? up : 0u);
+#pragma unroll
+  for (u32 j = 0; j < kSegIPT; j++) { const u32 i = base + j; if (i < n) f(i, (g[j] ? g[j] : pre) - 1u); }
+}
+struct SegStore { u32 *gstart; __device__ __forceinline__ void operator()(u32 i, u32 s) const { gstart[i] = s; } };
+// isa[sa[i]] = base + (start of i's group) + 1: the rank of the suffix by the symbols its group agrees on
+struct SegIsa { const u64 *sa; u64 *isa; u64 base; __device__ __forceinline__ void operator()(u32 i, u32 s) const { isa[sa[i]] = base + s + 1; } };
+
+// member of a group of more than T entries?  (its group's start + T is still inside the group)
+__device__ __forceinline__ bool seg_big(const u32 *__restrict__ gstart, u32 n, u32 i, u32 T) {
+  const u32 s = gstart[i];
+  return s + T < n && gstart[s + T] == s;
+}
+__global__ __launch_bounds__(kBlock) void k_big_count(const u32 *__restrict__ gstart, u32 n, u32 T, u32 *__restrict__ counts) {
+  __shared__ u32 tmp[kWaves];
+  const u32 base = blockIdx.x * kSegTile + threadIdx.x * kSegIPT;
+  u32 c = 0;
+#pragma unroll
+  for (u32 j = 0; j < kSegIPT; j++) { const u32 i = base + j; if (i < n && seg_big(gstart, n, i, T)) c++; }
+  c = wave_reduce(c);
+  if (lane_id() == 0) tmp[wave_id()] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) { u32 t = 0; for (int w = 0; w < kWaves; w++) t += tmp[w]; counts[blockIdx.x] = t; }
+}
+// where the position of entry i comes from: the sorted records of the tie pass (16-byte, 8-byte words) or the shard
+struct PosRec16 { const Rec16 *h; __device__ __forceinline__ u64 operator()(u32 i) const { return wide_pos(h[i]); } };
+struct PosWord8 { const u64 *h; u64 pmask; __device__ __forceinline__ u64 operator()(u32 i) const { return h[i] & pmask; } };
+struct PosShard { const u64 *s; __device__ __forceinline__ u64 operator()(u32 i) const { return s[i]; } };
+template <class Pos>
+__global__ __launch_bounds__(kBlock) void k_big_write(const u32 *__restrict__ gstart, u32 n, u32 T, const u32 *__restrict__ base_excl, Pos pos,
+                                                     u32 *__restrict__ cslot, u32 *__restrict__ gid, u64 *__restrict__ cpos) {
+  __shared__ u32 tmp[kWaves];
+  const u32 base = blockIdx.x * kSegTile + threadIdx.x * kSegIPT;
+  bool b[kSegIPT]; u32 c = 0;
+#pragma unroll
+  for (u32 j = 0; j < kSegIPT; j++) { const u32 i = base + j; b[j] = i < n && seg_big(gstart, n, i, T); c += b[j] ? 1u : 0u; }
+  u32 tot;
+  u32 ex = base_excl[blockIdx.x] + block_excl_scan<kWaves>(c, tmp, tot);
+#pragma unroll
+  for (u32 j = 0; j < kSegIPT; j++) {
+    const u32 i = base + j;
+    if (b[j]) { cslot[ex] = i; gid[ex] = gstart[i]; cpos[ex] = pos(i); ex++; }
+  }
+}
+// key components
+struct SegKeySyms {                       // 7 symbols from offset off: 9 bits each, 0 = past the end of the text
+  WideKey k; u32 off;
+  __device__ __forceinline__ u64 operator()(u64 p, const uint16_t *lcode) const {
+    u64 v = 0;
+#pragma unroll
+    for (u32 j = 0; j < 7; j++) { const u64 q = p + off + j; v = (v << 9) | (q < k.n ? (u64)lcode[k.t[q]] : 0ull); }
+    return v;
+  }
+};
+struct SegKeyIsa {                        // rank of the continuation add symbols further on (0 = the suffix has ended)
+  const u64 *isa; u64 n, add;
+  __device__ __forceinline__ u64 operator()(u64 p, const uint16_t *) const { return p + add < n ? isa[p + add] : 0ull; }
+};
+// records of one LSD component: out[j] = {key of the member that stands at place j now, its index}; prev = the order so far
+// (nullptr: members in index order)
+template <class Key>
+__global__ __launch_bounds__(kBlock) void k_seg_recs(const Rec16 *prev, u32 nb, const u64 *__restrict__ cpos, Key key,
+                                                    const uint16_t *__restrict__ code, Rec16 *out) {   // (out may be prev: element j only)
+  __shared__ uint16_t lcode[256];
+  if (threadIdx.x < 256) lcode[threadIdx.x] = code ? code[threadIdx.x] : (uint16_t)0;
+  __syncthreads();
+  for (u32 j = blockIdx.x * kBlock + threadIdx.x; j < nb; j += gridDim.x * kBlock) {
+    const u32 idx = prev ? prev[j].pos : j;
+    const u64 v = key(cpos[idx], lcode);
+    out[j] = Rec16{(u32)v, (u32)(v >> 32), 0u, idx};
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_seg_recs_gid(const Rec16 *prev, u32 nb, const u32 *__restrict__ gid, Rec16 *out) {
+  for (u32 j = blockIdx.x * kBlock + threadIdx.x; j < nb; j += gridDim.x * kBlock) {
+    const u32 idx = prev ? prev[j].pos : j;
+    out[j] = Rec16{gid[idx], 0u, 0u, idx};
+  }
+}
+// the members in their new order: place j of the compacted list is slot cslot[j] of the shard (groups are index ranges and
+// the last component ordered was the group's start, so every member stays inside its group's range)
+__global__ __launch_bounds__(kBlock) void k_seg_writeback(const Rec16 *__restrict__ sorted, u32 nb, const u32 *__restrict__ cslot,
+                                                         const u64 *__restrict__ cpos, u64 *__restrict__ shard) {
+  for (u32 j = blockIdx.x * kBlock + threadIdx.x; j < nb; j += gridDim.x * kBlock) shard[cslot[j]] = cpos[sorted[j].pos];
+}
+// neweq[slot] = the member agrees with the one before it in ALL components (same group, compared by cmp); words[2] += those
+struct SegCmpIsa { const u64 *isa; u64 n, D; u32 W; __device__ __forceinline__ bool operator()(u64 p, u64 q) const { return wide_cmp_isa(isa, n, p, q, D, W) == 0; } };
+template <class Cmp>
+__global__ __launch_bounds__(kBlock) void k_seg_neweq(const Rec16 *__restrict__ sorted, u32 nb, const u32 *__restrict__ cslot, const u32 *__restrict__ gid,
+                                                     const u64 *__restrict__ cpos, Cmp cmp, uint8_t *__restrict__ neweq, u32 *words) {
+  u32 dup = 0;
+  for (u32 j = blockIdx.x * kBlock + threadIdx.x; j < nb; j += gridDim.x * kBlock) {
+    const u32 a = sorted[j].pos;
+    bool same = false;
+    if (j > 0) { const u32 b = sorted[j - 1].pos; same = gid[a] == gid[b] && cmp(cpos[b], cpos[a]); }
+    neweq[cslot[j]] = same ? 1 : 0;
+    dup += same ? 1u : 0u;
+  }
+  dup = wave_reduce(dup);
+  if (lane_id() == 0 && dup) atomicAdd(&words[2], dup);
+}
+// same-image flags of the 16-byte records of the tie pass (the 8-byte form has them from its local sort)
+__global__ __launch_bounds__(kBlock) void k_wide_same16(const Rec16 *__restrict__ h, u32 nrec, uint8_t *__restrict__ same) {
+  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < nrec; i += gridDim.x * kBlock)
+    same[i] = (i > 0 && wide_img(h[i]) == wide_img(h[i - 1])) ? 1 : 0;
 }
 
 // order-sensitive checksum of a shard with global indices (64-bit values: sum of mix(mix(index) ^ position))

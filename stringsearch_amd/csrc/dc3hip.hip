@@ -47,6 +47,24 @@ extern "C" {
 const char *dc3hip_version(void) { return DC3HIP_VERSION_STR; }
 const char *dc3hip_last_error(void) { return g_err; }
 
+int32_t dc3hip_hip_versions(int32_t *compiled, int32_t *runtime) {
+  int rt = 0;
+  if (hipRuntimeGetVersion(&rt) != hipSuccess) { (void)hipGetLastError(); set_err("hipRuntimeGetVersion failed"); return E_HIP; }
+  if (compiled) *compiled = (int32_t)HIP_VERSION;
+  if (runtime) *runtime = rt;
+  return (HIP_VERSION / 100000) == (rt / 100000) ? 1 : 0;
+}
+// once per process, from the first context: a runtime other than the one the library was compiled against is legal
+// (same soname) but nothing this library's tests ran on; say so where a crash report would be read
+static void warn_runtime_mismatch_once() {
+  static std::atomic<bool> done{false};
+  if (done.exchange(true)) return;
+  int32_t ct = 0, rt = 0;
+  if (dc3hip_hip_versions(&ct, &rt) == 0 && !getenv("DC3HIP_QUIET"))
+    std::fprintf(stderr, "dc3hip: compiled against HIP %d.%d.%d, running on HIP runtime %d.%d.%d (another libamdhip64 was mapped first)\n",
+                 ct / 10000000, ct / 100000 % 100, ct % 100000, rt / 10000000, rt / 100000 % 100, rt % 100000);
+}
+
 int32_t dc3hip_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) { set_err("hipGetDeviceCount failed"); return E_HIP; }
@@ -66,6 +84,7 @@ static int ctx_create_impl(dc3hip_ctx **out, int32_t device, int64_t max_n, dc3h
   if (ndev <= 0) { set_err("no HIP device visible (no CPU fallback exists)"); return E_HIP; }
   if (device < 0) HIPC(hipGetDevice(&device));
   if (device >= ndev) { set_err("device %d out of range (%d devices)", device, ndev); return E_ARGS; }
+  warn_runtime_mismatch_once();
   dc3hip_ctx *c = new (std::nothrow) dc3hip_ctx();
   if (!c) { set_err("host allocation failed"); return E_ALLOC; }
   c->device = device; c->max_n = max_n;
@@ -135,7 +154,7 @@ static int ctx_create_impl(dc3hip_ctx **out, int32_t device, int64_t max_n, dc3h
     HIPC(hipMalloc(&c->d_words, 64 * sizeof(u32)));
     HIPC(hipMalloc(&c->d_xcdmon, 4096 * sizeof(u32)));         // (64 monitor words; 4096 for the placement probe below)
     HIPC(hipMalloc(&c->d_trace, 3 * DC3HIP_MAX_LEVELS * sizeof(u64)));
-    { size_t got = 0; c->h_words = static_cast<u32 *>(pinned_pool()->take(64 * sizeof(u32), &got)); }
+    c->h_words = static_cast<u32 *>(pinned_pool()->take(64 * sizeof(u32), &c->h_words_bytes));
     if (!c->h_words) { set_err("no pinned host memory"); return E_ALLOC; }
     HIPC(hipEventCreate(&c->ev_build_a));
     HIPC(hipEventCreate(&c->ev_build_b));
@@ -144,19 +163,29 @@ static int ctx_create_impl(dc3hip_ctx **out, int32_t device, int64_t max_n, dc3h
       // ordering's partition passes are only fast when blocks b and b + 8 share an XCD (XCD-grouped reservation,
       // dc3_msd.hip.hpp); on a device that places blocks otherwise the context keeps to the stable 256-bucket LSD passes,
       // whose speed does not depend on placement (DC3HIP_XCD_ASSUME=1: keep the bucket ordering anyway).
-      hipLaunchKernelGGL(k_xcd_probe, dim3(4096), dim3(64), 0, c->stream, c->d_xcdmon);
-      void *hp = nullptr;
-      RC(stage_d2h(c, c->d_xcdmon, 4096 * sizeof(u32), &hp));
-      const u32 *xs = static_cast<const u32 *>(hp);
-      u32 cnt[8][8] = {};
-      for (u32 b = 0; b < 4096; b++) cnt[b & 7][xs[b] & 7]++;
-      u32 hit = 0, seen = 0;
-      for (int g = 0; g < 8; g++) {
-        u32 mx = 0, arg = 0;
-        for (int x = 0; x < 8; x++) if (cnt[g][x] > mx) { mx = cnt[g][x]; arg = (u32)x; }
-        hit += mx; seen |= 1u << arg;
+      // (once per device and process: the answer is a property of the device's dispatcher, and a context per sacapart
+      //  worker would otherwise launch 4096 blocks and wait for a copy each)
+      static std::mutex probe_mu;
+      static int probe_cache[64];
+      static bool probe_init = false;
+      std::lock_guard<std::mutex> lk(probe_mu);
+      if (!probe_init) { for (int &v : probe_cache) v = -1; probe_init = true; }
+      if (probe_cache[device & 63] < 0) {
+        hipLaunchKernelGGL(k_xcd_probe, dim3(4096), dim3(64), 0, c->stream, c->d_xcdmon);
+        void *hp = nullptr;
+        RC(stage_d2h(c, c->d_xcdmon, 4096 * sizeof(u32), &hp));
+        const u32 *xs = static_cast<const u32 *>(hp);
+        u32 cnt[8][8] = {};
+        for (u32 b = 0; b < 4096; b++) cnt[b & 7][xs[b] & 7]++;
+        u32 hit = 0, seen = 0;
+        for (int g = 0; g < 8; g++) {
+          u32 mx = 0, arg = 0;
+          for (int x = 0; x < 8; x++) if (cnt[g][x] > mx) { mx = cnt[g][x]; arg = (u32)x; }
+          hit += mx; seen |= 1u << arg;
+        }
+        probe_cache[device & 63] = (hit >= 4096 * 9 / 10 && seen == 0xffu) ? 1 : 0;
       }
-      c->xcd_rr = (hit >= 4096 * 9 / 10 && seen == 0xffu) ? 1 : 0;
+      c->xcd_rr = probe_cache[device & 63];
       const char *e = getenv("DC3HIP_XCD_ASSUME");
       if (!c->xcd_rr && !(e && e[0] == '1')) c->no_msd = true;
     }
@@ -182,7 +211,7 @@ void dc3hip_ctx_destroy(dc3hip_ctx *c) {
   if (c->d_code) (void)hipFree(c->d_code);
   if (c->d_words) (void)hipFree(c->d_words);
   if (c->d_trace) (void)hipFree(c->d_trace);
-  pinned_pool()->give(c->h_words, 64 * sizeof(u32));         // (recycled, never hipHostFree'd: PinnedPool)
+  pinned_pool()->give(c->h_words, c->h_words_bytes);         // (recycled: PinnedPool)
   pinned_pool()->give(c->h_stage, c->h_stage_bytes);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;

@@ -64,6 +64,14 @@ def torch_host_callbacks(dist, rank, nranks):
     return a2a, ag
 
 
+def global_plan(total_n, nranks):
+    """Per-rank HBM need of a global-mode build (dc3hip_global_plan: the library's own sizing rules, no device touched)."""
+    from ._lib import GPlan
+    p = GPlan()
+    _check(lib().dc3hip_global_plan(total_n, nranks, ctypes.byref(p)))
+    return p.as_dict()
+
+
 def block_of(total_n, nranks, rank):
     """(offset, length) of the text block rank `rank` owns: sacapart-style blocks of len/P + 1 bytes
     (crates/sacapart/src/lib.rs:43-46), the same arithmetic as dc3hip_global_block."""

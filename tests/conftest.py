@@ -12,7 +12,11 @@ import pytest
 # imports torch afterwards carries two runtimes and aborts at exit (double free).  So torch — where installed — is
 # imported before anything can load the library; libdc3hip then binds to the runtime torch mapped (as bench.py and
 # __graft_entry__.smoke() do).
+# DC3HIP_TEST_NO_TORCH=1 (tools/fresh_process_fuzz.sh notorch): leave torch out, so that the library runs on the SYSTEM HIP
+# runtime it was compiled against instead of the one bundled with the wheel.
 try:
+    if os.environ.get("DC3HIP_TEST_NO_TORCH") == "1":
+        raise ImportError("torch left out on request")
     import torch  # noqa: F401
 except Exception:  # pragma: no cover - torch is optional for the CPU-only tests
     torch = None

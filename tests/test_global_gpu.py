@@ -558,7 +558,7 @@ def test_wide_mode_small_texts_match_the_oracle(ss, oracle, P):
         with env(DC3HIP_WIDE_CORRUPT="1"):                                             # (the verifier of a deepened order sees a swap too)
             g.build()
         assert g.sufcheck() == -3
-        for bad, switch in ((huge, "1"), (np.full(100_000, 65, dtype=np.uint8), "0")):  # refused: without the deepening; one symbol
+        for bad, switch in ((huge, "1"), (np.full(100_000, 65, dtype=np.uint8), "1")):  # refused WITHOUT the deepening (with it both build: round 5)
             with env(DC3HIP_NO_WIDE_DEEPEN=switch), ss.LoopbackGroup(P, 3_000_000) as g2:
                 g2.set_text(bad)
                 with pytest.raises(ss.Dc3HipError) as ei:
@@ -618,8 +618,10 @@ def test_wide_mode_deepening_by_rank_lookups(ss, oracle, P):
     with 17 rank look-ups per compare (wide_deepen).  Two copies of one text, eight copies of a block with a few point
     mutations, a 1.4 M-symbol repeat, a period of 5000 symbols (300 suffixes per group), repeats reaching the end of the
     text; the bucket ordering and the 16-byte LSD form; bit-exact against divsufsort, accepted by the collective verifier
-    (which checks a deepened order in linear time against its own inverse).  Beyond 1024 suffixes sharing a window the
-    text is still refused."""
+    (which checks a deepened order in linear time against its own inverse).  Groups of any size (round 5: beyond 1024
+    suffixes sharing a window the text used to be refused): a period of 1000 symbols (2900 suffixes per group), a text
+    over ONE symbol (a single group of all suffixes), a long run of one symbol inside random text, a short period —
+    ordered by the segmented LSD sort of the big groups' members (wide_big_syms / wide_big_isa)."""
     rng = np.random.default_rng(4900 + P)
     base = oracle.gen(1_200_000, 31, 1)
     cases = {"two_copies": np.concatenate([base, base])}
@@ -646,10 +648,18 @@ def test_wide_mode_deepening_by_rank_lookups(ss, oracle, P):
                     assert all(s["wide_deepen_rounds"] >= 1 for s in st), (label, [s["wide_deepen_rounds"] for s in st])
                 g.build()
                 assert np.array_equal(g.sa(), want), (label, P, extra, "second build")
-            g.set_text(np.tile(rng.integers(0, 4, size=1000, dtype=np.uint8) + 65, 2900))     # 2900 suffixes per group
-            with pytest.raises(ss.Dc3HipError) as ei:
+            run = rng.integers(0, 256, size=700_001, dtype=np.uint8); run[200_000:500_000] = 78      # 300 000 x 'N'
+            big = {"period_1000": np.tile(rng.integers(0, 4, size=1000, dtype=np.uint8) + 65, 2900),     # 2900 suffixes per group
+                   "one_symbol": np.full(150_001, 65, dtype=np.uint8),
+                   "run_of_one_symbol_in_random_text": run,
+                   "period_3": np.tile(np.frombuffer(b"abc", dtype=np.uint8), 70_000)[:209_998]}
+            for label, t in big.items():
+                want = want_sa(oracle, t)
+                g.set_text(t)
                 g.build()
-            assert ei.value.code == -4, ei.value
+                assert np.array_equal(g.sa(), want), (label, P, extra)
+                assert g.sufcheck() == 0, (label, P)
+                assert all(s["wide_deepen_rounds"] >= 1 for s in g.stats()), label
             t = rng.integers(0, 256, size=1_000_003, dtype=np.uint8)
             g.set_text(t); g.build()
             assert np.array_equal(g.sa(), want_sa(oracle, t))

@@ -68,4 +68,4 @@ while time.time() - t0 < budget:
     want = (o.ref_sufsort(text) if o.ref is not None and n > 0 else o.sufsort(text)).astype(np.int64) if n else np.zeros(0, dtype=np.int64)
     if not np.array_equal(got, want):
         print(json.dumps({"MISMATCH": True, "P": P, "n": n, "env": envs}), flush=True); np.save("gpurun_out/global_fuzz_fail.npy", text); sys.exit(1)
-print(json.dumps({"ok": True, "iterations": it, "seconds": round(time.time() - t0, 1)}))
+print(json.dumps({"ok": True, "iterations": it, "seconds": round(time.time() - t0, 1), "hip": ss.hip_versions(), "torch_in_process": "torch" in sys.modules}))

@@ -1,7 +1,9 @@
 #!/bin/bash
 # GPU box: PMC counters of ONE build of a synthetic input (default: the 1 GiB low-entropy text of configs[2]), per kernel.
 # Separate passes (FETCH_SIZE and WRITE_SIZE cannot share one; SQ groups of <= 8 counters), the program directly after `--`.
-# usage: tools/pmc_text.sh TAG [n:kind]   ->  gpurun_out/pmc_TAG_<group>_by_kernel.csv, gpurun_out/pmc_TAG_stats.json
+# usage: tools/pmc_build.sh TAG [n:kind[:seed]] [hbm]  ->  gpurun_out/pmc_TAG_g<i>_by_kernel.csv, gpurun_out/pmc_TAG_stats.json
+#   "hbm": the two HBM passes only (what profiles/pmc_traffic*.json is made of: python tools/pmc_to_json.py gpurun_out TAG)
+#   bench.py's workloads: default 1073741824:0:2 | recursion = the same under DC3HIP_NO_TEXT_SHORTCUT=1 | text 1073741824:2:3 | dna 1073741824:1:5
 tag=${1:-text}
 spec=${2:-1073741824:2}
 : "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}"
@@ -9,9 +11,11 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 i=0
-for grp in "FETCH_SIZE" "WRITE_SIZE" \
+groups=("FETCH_SIZE" "WRITE_SIZE" \
            "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" \
-           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR")
+[ "$3" = hbm ] && groups=("FETCH_SIZE" "WRITE_SIZE")
+for grp in "${groups[@]}"; do
   i=$((i+1))
   rocprofv3 --pmc $grp --kernel-trace --output-format csv -d gpurun_out/pmcrun_${tag}_$i -- python3 tools/one_build.py $spec --dump gpurun_out/pmc_${tag}_stats.json > gpurun_out/pmc_${tag}_$i.json 2> gpurun_out/pmc_${tag}_$i.err
   f=$(find gpurun_out/pmcrun_${tag}_$i -name "*counter_collection.csv" | head -1)

@@ -7,11 +7,14 @@ handed to the REFERENCE's sufcheck() compiled with 64-bit saidx_t (oracle/_ref/l
 c-sources/utils.c:160-241: range, first-character order, then the psi-style "SA[C[T[SA[i]-1]]++] == SA[i]-1" scan).
 rc 0 means: this array is the suffix array of this text.  One JSON line (profiles/r03*_wide_reference_sufcheck64.json).
 
-    python tools/wide_reference_sufcheck.py [extra_bytes=1048579 | n >= 2^32] [kind=0] [ranks=2] [repeat_bytes=0]
+    python tools/wide_reference_sufcheck.py [extra_bytes=1048579 | n >= 2^32] [kind=0] [ranks=2] [repeat_bytes=0] [run_bytes=0]
 
 repeat_bytes > 0: the last repeat_bytes of the text (but 7) are a copy of its bytes 11 .. 11 + repeat_bytes — windows that
 repeat far beyond any symbol compare, settled by the deepening by rank look-ups (wide_deepen); the text then goes in
-through set_text."""
+through set_text.
+run_bytes > 0: run_bytes bytes in the middle of the text are ONE symbol ('N') — every suffix inside the run shares its sort
+image and its window with hundreds of thousands of others: the groups beyond 1024 members that were refused before round 5
+(ordered now by the segmented sort of wide_big_syms / wide_big_isa)."""
 import ctypes
 import json
 import os
@@ -30,6 +33,7 @@ extra = int(sys.argv[1]) if len(sys.argv) > 1 else (1 << 20) + 3
 kind = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 P = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 repeat = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+run = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 seed = 6 if kind == 0 else 5
 n = extra if extra >= (1 << 32) else (1 << 32) + extra
 path = os.path.join(ROOT, "oracle", "_ref", "libdivsufsort64_ref.so")
@@ -37,7 +41,7 @@ ref = ctypes.CDLL(path)
 ref.sufcheck.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32]
 ref.sufcheck.restype = ctypes.c_int32
 
-out = {"n": n, "kind": kind, "seed": seed, "ranks": P, "transport": "loopback (all ranks on one GPU)", "planted_repeat_bytes": repeat}
+out = {"n": n, "kind": kind, "seed": seed, "ranks": P, "transport": "loopback (all ranks on one GPU)", "planted_repeat_bytes": repeat, "planted_run_of_one_symbol_bytes": run}
 # the text, from the same device generator stream, in pieces a single context can hold
 text = np.zeros(n, dtype=np.uint8)
 piece = 1 << 30
@@ -50,9 +54,11 @@ with ss.Context(piece) as c:
         off += m
 if repeat:
     text[n - 7 - repeat:n - 7] = text[11:11 + repeat]
+if run:
+    text[n // 2:n // 2 + run] = 78
 sa = np.zeros(n, dtype=np.int64)
 with ss.LoopbackGroup(P, n) as g:
-    if repeat:
+    if repeat or run:
         g.set_text(text)
     else:
         g.generate(n, seed, kind)
