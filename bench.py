@@ -382,19 +382,19 @@ def main():
             # The timed builds above finished in the whole-text shortcut (every 9-byte window distinct, no
             # recursion level built).  For reference, the same input through the DC3 recursion proper
             # (levels, tuples, merge): not part of `value`.
-            os.environ["DC3HIP_NO_TEXT_SHORTCUT"] = "1"
+            ss.debug_set("no_text_shortcut", "1")
             try:
                 with ss.Context(n, device=local_rank) as c2:
                     c2.generate(n, args.seed, kind, offset=off)
                     c2.build()
                     st2, m2, blk = build_block(ss, c2, min(args.steps, 3), "pmc_traffic_recursion.json")
-                    out["dc3_recursion_only"] = {"switch": "DC3HIP_NO_TEXT_SHORTCUT=1", "device_ms_per_step": m2,
+                    out["dc3_recursion_only"] = {"switch": "DC3HIP_DEBUG=no_text_shortcut", "device_ms_per_step": m2,
                                                  "MBps": n / m2 / 1e3, "sufcheck": c2.sufcheck(),
                                                  "checksum_equal": (c2.checksum() == chk0) if chk0 is not None else None,
                                                  "levels": list(zip(st2["level_n"], st2["level_K"], st2["level_sorted"]))}
                     out["dc3_recursion_only"].update(blk)
             finally:
-                os.environ.pop("DC3HIP_NO_TEXT_SHORTCUT", None)
+                ss.debug_unset("no_text_shortcut")
         # BASELINE.json configs[2] (low-entropy text) and the per-GPU class of configs[4] (DNA) at the same size:
         # device-resident builds, GPU sufcheck each; reported beside `value`, never part of it.
         per_cfg = {}
@@ -417,16 +417,16 @@ def main():
                 if st3.get("text_sort_state", 0) != 0:
                     # finished (or started) by the whole-text order: the DC3 recursion proper on the same text beside it
                     chk3 = c3.checksum()
-                    os.environ["DC3HIP_NO_TEXT_SHORTCUT"] = "1"
+                    ss.debug_set("no_text_shortcut", "1")
                     try:
                         with ss.Context(n, device=local_rank) as c5:
                             c5.generate(n, seed, kd)
                             c5.build(); c5.build()
                             per_cfg[f"{name}_{per_gpu / 2**30:g}GiB"]["dc3_recursion_only"] = {
-                                "switch": "DC3HIP_NO_TEXT_SHORTCUT=1", "ms": c5.stats()["build_ms"], "levels": c5.stats()["levels"],
+                                "switch": "DC3HIP_DEBUG=no_text_shortcut", "ms": c5.stats()["build_ms"], "levels": c5.stats()["levels"],
                                 "checksum_equal": c5.checksum() == chk3}
                     finally:
-                        os.environ.pop("DC3HIP_NO_TEXT_SHORTCUT", None)
+                        ss.debug_unset("no_text_shortcut")
         # the per-GPU chunk of BASELINE.json configs[4] (16 GiB DNA over 8 GPUs, sacapart chunks of 2 GiB + 1 byte, 64-bit
         # indices at the boundary): beyond 2^31 positions, device-resident, GPU sufcheck
         if per_gpu == 1 << 30 and not args.no_verify:
@@ -456,17 +456,36 @@ def main():
             with ss.Context(gn, device=local_rank) as c4:
                 c4.generate(gn, gseed, gkind); c4.build(); c4.build()
                 single_ms = c4.stats()["build_ms"]; single_chk = c4.checksum()
-            for P in (2, 4):
-                with ss.LoopbackGroup(P, gn, device=local_rank) as g:
+            for P in (2, 4, 8):
+                # DC3HIP_GLOBAL_LINK_GBPS=153: the select-or-route policy decides as it would on xGMI (on one shared device it
+                # would always select), so the prediction below is for the schedule P real GPUs run
+                ss.debug_set("global_link_gbps", "153")
+                try:
+                    grp = ss.LoopbackGroup(P, gn, device=local_rank)
+                finally:
+                    ss.debug_unset("global_link_gbps")
+                with grp as g:
                     g.generate(gn, gseed, gkind)
                     g.build()
-                    walls = []
+                    walls, best = [], None
                     for _ in range(3):
-                        t1 = time.perf_counter(); g.build(); walls.append((time.perf_counter() - t1) * 1e3)
+                        t1 = time.perf_counter(); g.build(); w = (time.perf_counter() - t1) * 1e3
+                        if not walls or w < min(walls):
+                            best = g.stats()
+                        walls.append(w)
                     wall = min(walls)
-                    gst = g.stats()
+                    gst = best
+                    work = [x["work_ms"] for x in gst]; link = [x["link_ms"] for x in gst]
+                    pred = max(work) + max(link)
                     gl.append({"input": f"{gn >> 20} MiB {gname}", "ranks": P, "wall_ms": wall, "single_device_ms": single_ms,
                                "work_inflation": wall / single_ms, "checksum_equal_single_device": g.checksum() == single_chk,
+                               # what P GPUs would take: the slowest rank's own work (the ranks pass a device token, so a rank's
+                               # work_ms is not its share of a time-sliced GPU) + the transport priced per collective at the most
+                               # bytes a rank exchanges with ONE peer / 153 GB/s (one xGMI link); no overlap assumed
+                               "predicted_wall_ms_on_P_gpus": pred, "predicted_MBps_on_P_gpus": gn / pred / 1e3,
+                               "predicted_speedup_over_one_gpu": single_ms / pred,
+                               "work_ms_per_rank": [round(v, 3) for v in work], "link_ms_per_rank": [round(v, 3) for v in link],
+                               "collectives": gst[0]["collectives"], "selecting_pass1": gst[0]["select_p1"],
                                "text_order": gst[0]["text_order"], "levels": gst[0]["levels"], "rank_exchanges": gst[0]["exchanges"],
                                "bytes_in_per_rank": [x["comm_bytes_in"] for x in gst],
                                "shard_counts": [x["shard_count"] for x in gst],

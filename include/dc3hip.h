@@ -298,9 +298,10 @@ DC3HIP_API int32_t dc3hip_ctx_debug_radix_pass_u64(dc3hip_ctx *ctx, const uint64
  * order is the distributed whole-text order (BASELINE.json configs[3] random bytes at 4 GiB, configs[4] random DNA at
  * 16 GiB).  Windows that repeat are compared deeper (256, 8192, then 16x more symbols per round while that is cheap) and
  * beyond that settled by rank look-ups: all ranks exchange their shards, build the inverse of the order so far, and 17
- * look-ups per compare settle 17x the depth per round (needs 17 bytes per suffix of the TEXT on every rank).  Refused
- * with -4 on every rank: a text over one symbol, more than 1024 suffixes sharing one sort image (a long run of one
- * symbol, a period below n/1024), a rank whose share would exceed DC3HIP_MAX_N suffixes, no memory for the look-ups.
+ * look-ups per compare settle 17x the depth per round (9 bytes per suffix of the TEXT on every rank plus one rank's shard
+ * at a time: dc3hip_global_plan).  Groups of tied suffixes of any size are ordered (beyond 1024 members by a segmented
+ * sort of the members: a run of one symbol, a short period, a text over one symbol).  Refused with -4 on every rank: a rank
+ * whose share would exceed DC3HIP_MAX_N suffixes, no memory for the look-ups.
  * Shards are fetched with dc3hip_global_get_shard_i64 (…_u32 returns -4) and verified with the
  * collective dc3hip_global_sufcheck. */
 typedef struct dc3hip_gctx dc3hip_gctx;
@@ -321,6 +322,13 @@ typedef struct dc3hip_gstats {
   int64_t wide_msd;          /* wide mode: 1 = this rank's order came from the bucket ordering on 8-byte words, 0 = 16-byte LSD passes */
   int64_t select_p1;         /* orderings of this rank whose partition pass 1 selected the rank's key range from the replicated string (no records built or routed) */
   int64_t wide_deepen_rounds; /* wide mode: rounds of deepening by rank look-ups (windows repeated beyond the symbol compares; 0 = not needed) */
+  /* What one rank costs on its OWN GPU, from a run in which the ranks may share one (loopback): */
+  double  work_ms;           /* host wall time this rank spent OUTSIDE collectives.  Loopback ranks that share a device hold a device
+                              * token while they work and hand it over inside collectives, so this is the rank's own work, not its
+                              * share of a time-sliced GPU */
+  double  link_ms;           /* model of the transport on xGMI: per collective, the most bytes this rank exchanges with ONE peer
+                              * (a link) / 153 GB/s, summed over the build's collectives */
+  int64_t collectives;       /* collectives of the build (device-side all-to-all / all-gather) */
 } dc3hip_gstats;
 
 /* Per-rank HBM need of a global-mode build of total_n bytes over nranks ranks, computed by the library's own sizing rules

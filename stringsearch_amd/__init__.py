@@ -11,12 +11,17 @@ The compute path is libdc3hip.so ONLY.  There is no CPU fallback: importing work
 from ._lib import lib, lib_path, Dc3HipError, Stats, GStats, PHASES  # noqa: F401
 from .global_sa import GlobalRank, LoopbackGroup, global_plan  # noqa: F401
 from .api import (  # noqa: F401
+    POLICY_VARS,
+    adopt_legacy_env,
     Context,
     LongestCommonSubstring,
     NotSorted,
     PartitionedSuffixArray,
     SuffixArray,
     common_prefix_len,
+    debug_set,
+    debug_switches,
+    debug_unset,
     device_count,
     hip_versions,
     last_error,
@@ -30,7 +35,7 @@ from .api import (  # noqa: F401
 )
 
 __all__ = [
-    "Context", "Dc3HipError", "GlobalRank", "GStats", "LoopbackGroup", "LongestCommonSubstring", "NotSorted", "PartitionedSuffixArray", "PHASES", "Stats",
-    "SuffixArray", "common_prefix_len", "device_count", "global_plan", "hip_versions", "last_error", "lib", "release_cache", "lib_path", "sort", "sort_i64",
+    "Context", "Dc3HipError", "POLICY_VARS", "adopt_legacy_env", "GlobalRank", "GStats", "LoopbackGroup", "LongestCommonSubstring", "NotSorted", "PartitionedSuffixArray", "PHASES", "Stats",
+    "SuffixArray", "common_prefix_len", "debug_set", "debug_switches", "debug_unset", "device_count", "global_plan", "hip_versions", "last_error", "lib", "release_cache", "lib_path", "sort", "sort_i64",
     "sort_in_place", "sufcheck", "verify", "version",
 ]

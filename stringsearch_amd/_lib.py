@@ -110,7 +110,8 @@ class GStats(ctypes.Structure):
                 ("comm_bytes_out", ctypes.c_int64), ("comm_bytes_in", ctypes.c_int64),
                 ("comm_ms", ctypes.c_double), ("device_ms", ctypes.c_double), ("wall_ms", ctypes.c_double),
                 ("wide_msd", ctypes.c_int64), ("select_p1", ctypes.c_int64),
-                ("wide_deepen_rounds", ctypes.c_int64)]
+                ("wide_deepen_rounds", ctypes.c_int64),
+                ("work_ms", ctypes.c_double), ("link_ms", ctypes.c_double), ("collectives", ctypes.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "struct_size"}

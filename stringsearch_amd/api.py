@@ -8,6 +8,80 @@ from ._lib import Dc3HipError, Opts, Stats, lib
 I32_MAX = 2**31 - 1
 
 
+# ---- DC3HIP_DEBUG: the one variable that carries every test / diagnosis switch of the library -----------------------------
+# (dc3_host_core.hpp; read when a context or a global rank is created).  Policy variables a deployment may set stay plain
+# environment variables: DC3HIP_PROFILE, DC3HIP_CACHE, DC3HIP_WORKERS_PER_DEVICE, DC3HIP_ARENA_BYTES, DC3HIP_XCD_ASSUME,
+# DC3HIP_GLOBAL_LOCAL_MAX, DC3HIP_QUIET, and the diagnostics DC3HIP_TRACE / DC3HIP_LEVEL_PHASES.
+POLICY_VARS = frozenset(["DC3HIP_PROFILE", "DC3HIP_CACHE", "DC3HIP_WORKERS_PER_DEVICE", "DC3HIP_ARENA_BYTES", "DC3HIP_XCD_ASSUME",
+                         "DC3HIP_GLOBAL_LOCAL_MAX", "DC3HIP_QUIET", "DC3HIP_TRACE", "DC3HIP_LEVEL_PHASES", "DC3HIP_DEBUG"])
+_debug = {}
+
+
+def _debug_init():
+    """switches already in DC3HIP_DEBUG when the package is imported (a shell line: DC3HIP_DEBUG=msd_min=4096 python ...)"""
+    import os
+    for tok in filter(None, os.environ.get("DC3HIP_DEBUG", "").split(",")):
+        k, _, v = tok.partition("=")
+        _debug[k] = v if v else 1
+
+
+_debug_init()
+
+
+def adopt_legacy_env():
+    """Tools and tests only: fold old-style one-variable-per-switch settings found in the environment (DC3HIP_NO_HYBRID=1,
+    DC3HIP_MSD_MIN=4096, ...) into DC3HIP_DEBUG — the library itself no longer reads them."""
+    import os
+    skip = ("DC3HIP_BENCH_", "DC3HIP_TEST_", "DC3HIP_SKIP_", "DC3HIP_PERF_GUARD_")
+    for k in [k for k in os.environ if k.startswith("DC3HIP_") and k not in POLICY_VARS and not k.startswith(skip)]:
+        debug_set(k, os.environ.pop(k))
+
+
+def _debug_write():
+    import os
+    if _debug:
+        os.environ["DC3HIP_DEBUG"] = ",".join(f"{k}={1 if v is True else v}" for k, v in _debug.items())     # (always name=value: numeric switches may be 1)
+    else:
+        os.environ.pop("DC3HIP_DEBUG", None)
+
+
+def debug_name(var):
+    """'DC3HIP_NO_HYBRID' or 'no_hybrid' -> 'no_hybrid' (the switch's name inside DC3HIP_DEBUG)"""
+    return (var[7:] if var.startswith("DC3HIP_") else var).lower()
+
+
+def debug_set(name, value=1):
+    """Switch a test / diagnosis path of the library on for contexts created from now on (tests and tools only)."""
+    _debug[debug_name(name)] = value
+    _debug_write()
+
+
+def debug_unset(name):
+    _debug.pop(debug_name(name), None)
+    _debug_write()
+
+
+class debug_switches:
+    """with debug_switches(no_text_shortcut=1, msd_min=4096): contexts created inside see DC3HIP_DEBUG="no_text_shortcut,msd_min=4096"."""
+
+    def __init__(self, **kv):
+        self.kv = {debug_name(k): v for k, v in kv.items()}
+
+    def __enter__(self):
+        self.old = {k: _debug.get(k) for k in self.kv}
+        _debug.update(self.kv)
+        _debug_write()
+        return self
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                _debug.pop(k, None)
+            else:
+                _debug[k] = v
+        _debug_write()
+
+
 def version():
     return lib().dc3hip_version().decode()
 

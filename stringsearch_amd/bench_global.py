@@ -15,7 +15,7 @@ XGMI_LINK_GBS = 153.0         # per direction and link (prompt / MI355X guide: 7
 def global_total(total, kind):
     """(bytes of the one text, wide?, clipped?): beyond DC3HIP_MAX_N the library switches to 64-bit positions (wide mode) —
     high-entropy inputs only, so the low-entropy text generator is clipped to the 32-bit limit instead."""
-    wide = (total > MAX_N or os.environ.get("DC3HIP_GLOBAL_FORCE_WIDE") == "1") and kind != 2
+    wide = (total > MAX_N or "global_force_wide" in os.environ.get("DC3HIP_DEBUG", "").split(",")) and kind != 2
     clipped = total > MAX_N and not wide
     return (MAX_N if clipped else total), wide, clipped
 

@@ -29,10 +29,26 @@
 // ---------------------------------------------------------------------------------------------
 // transport
 // ---------------------------------------------------------------------------------------------
+constexpr double kXgmiLinkGBps = 153.0;    // one xGMI link of an MI355X (7 per GPU, point to point): the rate the link model prices with
 struct GComm {
   int rank = 0, nranks = 1;
   double comm_ms = 0;                 // host wall time inside collectives (they are synchronous)
   uint64_t bytes_out = 0, bytes_in = 0;   // payload that left / reached this rank (self copies excluded)
+  // prediction for P real GPUs from a run whose ranks may share one (dc3hip_gstats.work_ms / link_ms / collectives)
+  double work_ms = 0, link_ms = 0; uint64_t ncoll = 0;
+  std::chrono::steady_clock::time_point work_t0;
+  bool working = false;
+  // a rank starts / stops working on its device (a build's begin and end, and around every collective).  Loopback ranks on
+  // one device pass a token (LoopComm): then work_ms is the rank's own work even though the ranks time-share the GPU.
+  virtual void device_enter() { work_t0 = std::chrono::steady_clock::now(); working = true; }
+  virtual void device_leave() {
+    if (working) work_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - work_t0).count();
+    working = false;
+  }
+  // one collective in which this rank exchanges at most `peer_bytes` with a single peer: P - 1 links work at once
+  void note_link(size_t peer_bytes) { ncoll++; link_ms += (double)peer_bytes / (kXgmiLinkGBps * 1e9) * 1e3; }
+  // GB/s of one link of THIS transport, for the policies that weigh recomputation against routing (0: the ranks share a device)
+  virtual double link_GBps() const { return kXgmiLinkGBps; }
   virtual ~GComm() {}
   // every rank sends send[soff[r] .. +sbytes[r]) to rank r and receives rbytes[r] bytes from rank r at recv + roff[r]
   virtual int all_to_all_v(const void *send, const size_t *soff, const size_t *sbytes, void *recv, const size_t *roff,
@@ -50,16 +66,27 @@ struct GComm {
   virtual const char *name() const = 0;
 };
 struct CommTimer {
-  GComm *g; std::chrono::steady_clock::time_point t0;
-  explicit CommTimer(GComm *gc) : g(gc), t0(std::chrono::steady_clock::now()) {}
-  ~CommTimer() { g->comm_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+  GComm *g; std::chrono::steady_clock::time_point t0; bool was_working;
+  explicit CommTimer(GComm *gc) : g(gc), t0(std::chrono::steady_clock::now()), was_working(gc->working) { if (was_working) g->device_leave(); }
+  ~CommTimer() {
+    g->comm_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (was_working) g->device_enter();
+  }
 };
+static size_t max_peer_bytes(const size_t *a, const size_t *b, int P, int me) {
+  size_t m = 0;
+  for (int r = 0; r < P; r++) if (r != me) { if (a) m = std::max(m, a[r]); if (b) m = std::max(m, b[r]); }
+  return m;
+}
 
 // ---- loopback: P ranks = P host threads of one process, each with its own context/stream on the same device -------
 struct LoopWorld {
   int P;
   std::mutex mu; std::condition_variable cv;
   int arrived = 0; uint64_t gen = 0; bool failed = false;
+  // ranks that share one device work one at a time (the token is handed over inside collectives): a rank's work_ms is then
+  // its own work.  Nothing depends on it but the timing; one_device = all ranks of the group sit on the same device.
+  std::mutex dev_mu; bool one_device = false;
   struct Post { const void *send; const size_t *soff; const size_t *sbytes; size_t one; };
   std::vector<Post> post;
   explicit LoopWorld(int p) : P(p), post((size_t)p) {}
@@ -85,6 +112,10 @@ struct LoopWorld {
 };
 struct LoopComm : GComm {
   std::shared_ptr<LoopWorld> w;
+  double model_link_GBps = 0;        // DC3HIP_DEBUG=global_link_gbps=.. (tests): the link rate the policies see (0: ranks share a device)
+  void device_enter() override { if (w->one_device) w->dev_mu.lock(); GComm::device_enter(); }
+  void device_leave() override { const bool had = working; GComm::device_leave(); if (had && w->one_device) w->dev_mu.unlock(); }
+  double link_GBps() const override { return model_link_GBps > 0 ? model_link_GBps : (w->one_device ? 0.0 : kXgmiLinkGBps); }
   const char *name() const override { return "loopback (in-process, hipMemcpyAsync; peer copies between devices)"; }
   void abort_all() override { w->fail(); }
   void reset_all() override { w->reset(); }
@@ -92,8 +123,9 @@ struct LoopComm : GComm {
   int sync_fail() { set_err("loopback transport: another rank failed"); return E_HIP; }
   int all_to_all_v(const void *send, const size_t *soff, const size_t *sbytes, void *recv, const size_t *roff,
                    const size_t *rbytes, hipStream_t st) override {
-    CommTimer tm(this);
     HIPC(hipStreamSynchronize(st));                      // my outgoing bytes are complete
+    CommTimer tm(this);
+    note_link(max_peer_bytes(sbytes, rbytes, nranks, rank));
     w->post[(size_t)rank] = LoopWorld::Post{send, soff, sbytes, 0};
     if (!w->barrier()) return sync_fail();
     for (int r = 0; r < nranks; r++) {
@@ -110,8 +142,9 @@ struct LoopComm : GComm {
   }
   int all_gather_v(const void *send, size_t sbytes, void *recv, const size_t *roff, const size_t *rbytes,
                    hipStream_t st) override {
-    CommTimer tm(this);
     HIPC(hipStreamSynchronize(st));
+    CommTimer tm(this);
+    note_link(std::max(nranks > 1 ? sbytes : (size_t)0, max_peer_bytes(rbytes, nullptr, nranks, rank)));
     w->post[(size_t)rank] = LoopWorld::Post{send, nullptr, nullptr, sbytes};
     if (!w->barrier()) return sync_fail();
     for (int r = 0; r < nranks; r++) {
@@ -207,6 +240,7 @@ struct RcclComm : GComm {
   int all_to_all_v(const void *send, const size_t *soff, const size_t *sbytes, void *recv, const size_t *roff,
                    const size_t *rbytes, hipStream_t st) override {
     CommTimer tm(this);
+    note_link(max_peer_bytes(sbytes, rbytes, nranks, rank));
     NCCLC(g_rccl.GroupStart());
     for (int r = 0; r < nranks; r++) {
       if (r == rank) continue;
@@ -224,6 +258,7 @@ struct RcclComm : GComm {
   int all_gather_v(const void *send, size_t sbytes, void *recv, const size_t *roff, const size_t *rbytes,
                    hipStream_t st) override {
     CommTimer tm(this);
+    note_link(std::max(nranks > 1 ? sbytes : (size_t)0, max_peer_bytes(rbytes, nullptr, nranks, rank)));
     NCCLC(g_rccl.GroupStart());
     for (int r = 0; r < nranks; r++) {
       if (r == rank) continue;
@@ -256,6 +291,7 @@ struct HostComm : GComm {
   dc3hip_host_transport t;
   char *hs = nullptr, *hr = nullptr; size_t cap_s = 0, cap_r = 0;     // pinned staging
   const char *name() const override { return "host-staged (caller's collectives on pinned host buffers)"; }
+  double link_GBps() const override { return 25.0; }      // staged through host memory: PCIe-class, not xGMI
   ~HostComm() override { if (hs) (void)hipHostFree(hs); if (hr) (void)hipHostFree(hr); }
   int grow(char **p, size_t *cap, size_t need) {
     if (need <= *cap) return E_OK;
@@ -269,6 +305,7 @@ struct HostComm : GComm {
   int all_to_all_v(const void *send, const size_t *soff, const size_t *sbytes, void *recv, const size_t *roff,
                    const size_t *rbytes, hipStream_t st) override {
     CommTimer tm(this);
+    note_link(max_peer_bytes(sbytes, rbytes, nranks, rank));
     uint64_t so[kMaxRanks], sb[kMaxRanks], ro[kMaxRanks], rb[kMaxRanks];
     size_t send_hi = 0, recv_hi = 0;
     for (int r = 0; r < nranks; r++) {
@@ -287,6 +324,7 @@ struct HostComm : GComm {
   int all_gather_v(const void *send, size_t sbytes, void *recv, const size_t *roff, const size_t *rbytes,
                    hipStream_t st) override {
     CommTimer tm(this);
+    note_link(std::max(nranks > 1 ? sbytes : (size_t)0, max_peer_bytes(rbytes, nullptr, nranks, rank)));
     uint64_t ro[kMaxRanks], rb[kMaxRanks];
     size_t recv_hi = 0;
     for (int r = 0; r < nranks; r++) {
@@ -355,6 +393,20 @@ struct dc3hip_gctx {
   char err[512] = "";
   std::vector<dc3hip_gctx *> group;             // loopback: all ranks of the group (rank 0 owns the list)
 };
+
+// SELECT (every rank walks all positions of the replicated string and keeps its key range: nothing is routed) or ROUTE (every
+// rank packs its own block and sends each 8-byte record to its owner) — by the per-rank cost of the two forms on P GPUs, in
+// ms per GiB of the level's string (MI355X, profiles/r04*): the selecting count + partition pass 1 walk ALL positions,
+// 4.46; packing and partitioning a rank's own block costs 4.5 / P, and the all-to-all puts 8 / P^2 bytes per position on each
+// link.  On xGMI (153 GB/s per link) that is select up to 4 ranks and route beyond (8 ranks: 4.46 against 0.56 + 0.88);
+// ranks that share one device (loopback) have no link to pay and select.  Both forms give the same array and are tested.
+static bool gselect_pays(const dc3hip_gctx *G, int P) {
+  const double link = G->comm->link_GBps();
+  if (link <= 0 || P <= 1) return true;
+  const double walk = 4.46, pack = 4.5;
+  const double xfer = 8.0 * 1073741824.0 / (link * 1e9) * 1e3;       // ms for 8 bytes per position of one GiB over one link
+  return walk <= pack / P + xfer / ((double)P * P);
+}
 
 static void block_of(int64_t n, int P, int r, int64_t *off, int64_t *len) {
   const int64_t S = n / P + 1;                  // sacapart/src/lib.rs:43
@@ -635,7 +687,7 @@ static int gorder_positions(dc3hip_gctx *G, KM km, u32 m, u32 kbits, const HiMap
   bool selected = false;
   if constexpr (kFusable) {
     const MsdGeom mg = msd_geometry(c, m, hm);
-    if (!G->no_select && mg.on && c->pack_fuse && P <= 16) {
+    if (!G->no_select && mg.on && c->pack_fuse && gselect_pays(G, P)) {
       u64 lo = 0, hi = ~0ull;
       {
         u32 ns = (u32)std::min<u64>(m, (u64)2048 * P);
@@ -1272,7 +1324,7 @@ static int gtext_order_with(dc3hip_gctx *G, KM km, u64 BL, const HiMap &hm, u32 
     if (!text_order_worth_trying(pred, (u64)n, hm.nbits)) return E_OK;
     bool tried = false;
     // (byte windows: gorder_positions has the selecting pass 1 of the single device's own kernels, cheaper still)
-    const bool have_select = std::is_same<KM, Key9>::value && !G->no_select && c->pack_fuse && G->comm->nranks <= 16 &&
+    const bool have_select = std::is_same<KM, Key9>::value && !G->no_select && c->pack_fuse && gselect_pays(G, G->comm->nranks) &&
                              msd_geometry(c, n, hm).on;
     RC(gorder_text_msd(G, sigma, done, &tried, have_select));
     if (!tried) RC((gorder_positions<KM>(G, km, n, kbits, hm, 0, nullptr, G_TOP, done)));
@@ -1962,8 +2014,10 @@ static int gbuild_wide(dc3hip_gctx *G) {
     return E_TOOBIG;
   }
   G->shard_first = (int64_t)pre; G->shard_count = (int64_t)nrec; G->shard_ptr = nullptr;
-  if (const char *e = getenv("DC3HIP_WIDE_CORRUPT")) {
+  long long corrupt = 0;
+  if (dbg_num("wide_corrupt", &corrupt)) {
     // test hook for the verifier: 1 = swap two neighbours of the last rank's shard, 2 = put one position out of range
+    const char e[2] = {(char)('0' + corrupt), 0};
     if (me == P - 1 && nrec >= 2 && (e[0] == '1' || e[0] == '2')) {
       u64 two[2];
       HIPC(hipMemcpy(two, G->w_shard + nrec / 2, 16, hipMemcpyDeviceToHost));
@@ -2022,9 +2076,13 @@ static int gbuild(dc3hip_gctx *G) {
   HIPC(hipSetDevice(G->c->device));
   GComm *cm = G->comm;
   cm->comm_ms = 0; cm->bytes_in = cm->bytes_out = 0;
+  cm->work_ms = 0; cm->link_ms = 0; cm->ncoll = 0;
   memset(&G->gs, 0, sizeof(G->gs));
   const auto t0 = std::chrono::steady_clock::now();
+  cm->device_enter();
   const int rc = gbuild_inner(G);
+  if (rc == E_OK && G->c->stream) (void)hipStreamSynchronize(G->c->stream);     // (the rank's last kernels are its own work)
+  cm->device_leave();
   if (rc != E_OK) { snprintf(G->err, sizeof(G->err), "%s", g_err); cm->abort_all(); cm->leave_failed(); return rc; }
   G->gs.struct_size = (int32_t)sizeof(dc3hip_gstats);
   G->gs.nranks = cm->nranks; G->gs.rank = cm->rank;
@@ -2032,6 +2090,7 @@ static int gbuild(dc3hip_gctx *G) {
   G->gs.wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   G->gs.comm_ms = cm->comm_ms; G->gs.comm_bytes_out = (int64_t)cm->bytes_out; G->gs.comm_bytes_in = (int64_t)cm->bytes_in;
   G->gs.device_ms = G->c->stats.build_ms;
+  G->gs.work_ms = cm->work_ms; G->gs.link_ms = cm->link_ms; G->gs.collectives = (int64_t)cm->ncoll;
   G->gs.levels = G->c->stats.levels;
   G->gs.text_order = G->c->stats.text_sort_state == 1 ? 1 : 0;
   G->built = true;
@@ -2040,20 +2099,18 @@ static int gbuild(dc3hip_gctx *G) {
 
 static void gctx_env(dc3hip_gctx *G) {
   if (const char *e = getenv("DC3HIP_GLOBAL_LOCAL_MAX")) { const long long v = atoll(e); if (v >= 0) G->local_max = (u32)std::min<long long>(v, 0x7fffffffll); }
-  if (const char *e = getenv("DC3HIP_GLOBAL_NO_TEXT_ORDER")) G->no_text_order = e[0] == '1';
-  if (const char *e = getenv("DC3HIP_GLOBAL_FORCE_DIST")) G->force_dist = e[0] == '1';
-  if (const char *e = getenv("DC3HIP_GLOBAL_NO_ROUTE")) G->route = e[0] != '1';
-  if (const char *e = getenv("DC3HIP_GLOBAL_NO_SELECT")) G->no_select = e[0] == '1';
-  if (const char *e = getenv("DC3HIP_NO_WIDE_MSD")) G->no_wide_msd = e[0] == '1';
-  if (const char *e = getenv("DC3HIP_NO_WIDE_DEEPEN")) G->no_wide_deepen = e[0] == '1';
-  if (const char *e = getenv("DC3HIP_WIDE_MSD_MIN")) { const long long v = atoll(e); if (v >= 0) { G->wide_msd_min = (u64)v; G->wide_msd_forced = true; } }
+  // (test switches: DC3HIP_DEBUG, dc3_host_core.hpp)
+  G->no_text_order = dbg_on("global_no_text_order"); G->force_dist = dbg_on("global_force_dist");
+  G->route = !dbg_on("global_no_route"); G->no_select = dbg_on("global_no_select");
+  G->no_wide_msd = dbg_on("no_wide_msd"); G->no_wide_deepen = dbg_on("no_wide_deepen");
+  { long long v; if (dbg_num("wide_msd_min", &v) && v >= 0) { G->wide_msd_min = (u64)v; G->wide_msd_forced = true; } }
 }
 
 // the rank's device context: a full one (text, SA, arena for max_total_n) — or, in wide mode, a minimal one (stream,
 // scratch words, a small arena for the sort's tables) next to the wide text buffer
 static int gctx_make_ctx(dc3hip_gctx *G, int device, int64_t max_total_n) {
   bool force_wide = false;
-  if (const char *e = getenv("DC3HIP_GLOBAL_FORCE_WIDE")) force_wide = e[0] == '1';
+  force_wide = dbg_on("global_force_wide");
   G->wide = force_wide || max_total_n > DC3HIP_MAX_N;
   if (!G->wide) return dc3hip_ctx_create(&G->c, device, max_total_n);
   if (max_total_n > ((int64_t)1 << 40)) { set_err("n=%lld exceeds 2^40", (long long)max_total_n); return E_TOOBIG; }
@@ -2132,9 +2189,11 @@ int32_t dc3hip_global_loopback_create(dc3hip_gctx **ranks, int32_t P, int32_t de
     const int rc = gctx_make_ctx(G, device == DC3HIP_DEVICE_SPREAD ? r % ndev : device, max_total_n);
     if (rc != E_OK) { for (auto *g : made) dc3hip_global_destroy(g); return rc; }
     LoopComm *lc = new LoopComm(); lc->rank = r; lc->nranks = P; lc->w = world;
+    (void)dbg_real("global_link_gbps", &lc->model_link_GBps);
     G->comm = lc; G->max_total = max_total_n;
     gctx_env(G);
   }
+  world->one_device = device != DC3HIP_DEVICE_SPREAD || ndev == 1;
   for (int r = 0; r < P; r++) { ranks[r] = made[(size_t)r]; made[(size_t)r]->group = made; }
   return E_OK;
 }

@@ -169,6 +169,33 @@ static int ensure_arena(dc3hip_ctx *c, size_t need) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Switches.  A deployment sets at most the POLICY variables — DC3HIP_PROFILE, DC3HIP_CACHE, DC3HIP_WORKERS_PER_DEVICE,
+// DC3HIP_ARENA_BYTES, DC3HIP_XCD_ASSUME, DC3HIP_GLOBAL_LOCAL_MAX, DC3HIP_QUIET — and the diagnostics DC3HIP_TRACE and
+// DC3HIP_LEVEL_PHASES.  Everything that only selects among orderings that are tested to give the same bytes, or plants a
+// fault for a test, travels in ONE variable read when a context is created:
+//     DC3HIP_DEBUG="name[=value],name,..."      e.g.  DC3HIP_DEBUG="no_text_shortcut,msd_min=4096"
+// (round 4 had 48 getenv sites, one per switch: each a reachable code path of the shipped library that looked like an
+// interface).  The names are the old variables' without the DC3HIP_ prefix, in lower case.
+// ---------------------------------------------------------------------------------------------
+static const char *dbg_find(const char *name) {       // -> the text behind "name" (at '=', ',' or the end), or nullptr
+  const char *s = getenv("DC3HIP_DEBUG");
+  if (!s) return nullptr;
+  const size_t ln = strlen(name);
+  while (*s) {
+    const char *e = strchr(s, ',');
+    const size_t tl = e ? (size_t)(e - s) : strlen(s);
+    if (tl >= ln && strncmp(s, name, ln) == 0 && (tl == ln || s[ln] == '=')) return s + ln;
+    if (!e) break;
+    s = e + 1;
+  }
+  return nullptr;
+}
+static bool dbg_on(const char *name) { const char *v = dbg_find(name); return v && !(v[0] == '=' && v[1] == '0'); }   // "name" or "name=1"
+static bool dbg_off(const char *name) { const char *v = dbg_find(name); return v && v[0] == '=' && v[1] == '0'; }    // "name=0"
+static bool dbg_num(const char *name, long long *out) { const char *v = dbg_find(name); if (!v || v[0] != '=') return false; *out = atoll(v + 1); return true; }
+static bool dbg_real(const char *name, double *out) { const char *v = dbg_find(name); if (!v || v[0] != '=') return false; *out = atof(v + 1); return true; }
+
+// ---------------------------------------------------------------------------------------------
 // Device-to-host reads of small results (samples, digit tables, monitor words) land in PINNED memory of the context.  An
 // asynchronous copy into pageable memory — a std::vector, a stack array of a rank thread — makes the runtime register
 // and unregister the caller's pages on the fly; with several rank threads doing that at once a round-4 hunt saw glibc's

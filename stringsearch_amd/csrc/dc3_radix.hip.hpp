@@ -97,6 +97,21 @@ struct SplitSink {
   }
 };
 
+// How a record is held in registers between its load and the LDS reorder.  hipcc left the array of 20-byte Tup0 structs
+// in scratch (112 bytes per thread stored and reloaded, profiles/r05a occupancy report) although every index is a
+// constant after unrolling; the same words as one 5-wide vector per record stay in VGPRs.  Other record types as they are.
+template <class Rec> struct RegRec {
+  typedef Rec T;
+  static __device__ __forceinline__ T pack(const Rec &r) { return r; }
+  static __device__ __forceinline__ Rec unpack(const T &v) { return v; }
+};
+typedef u32 u32x5 __attribute__((ext_vector_type(5)));
+template <> struct RegRec<Tup0> {
+  typedef u32x5 T;
+  static __device__ __forceinline__ T pack(const Tup0 &r) { T v; v[0] = r.pos; v[1] = r.c0; v[2] = r.c1; v[3] = r.r1; v[4] = r.r2; return v; }
+  static __device__ __forceinline__ Tup0 unpack(const T &v) { return Tup0{v[0], v[1], v[2], v[3], v[4]}; }
+};
+
 // PF: prefetch the next tile into registers while the current one is ranked/reordered (pays for
 // 8-byte records: 2.3 -> 3.4 TB/s; costs registers and loses for 16/20-byte records, see
 // profiles/r01_radix_downsweep_variants_v2.txt).
@@ -130,13 +145,16 @@ __global__ __launch_bounds__(NW * 64) void k_rs_downsweep(Loader in, Sink out, u
   const u32 end = min(n, begin + chunk);
   if (tid < NB) dbase[tid] = digit_base[tid] + table[(size_t)tid * nchunks + cid];
   u32 *mycnt = wcnt + w * NB;
-  Rec r[IPT], rn[PF ? IPT : 1];
+  typedef RegRec<Rec> RR;
+  typename RR::T r[IPT], rn[PF ? IPT : 1];
   bool okn[PF ? IPT : 1];
   if (PF) {
 #pragma unroll
     for (int k = 0; k < IPT; k++) {
       const u32 t = w * kWItems + k * 64 + lane;
-      okn[PF ? k : 0] = (begin + t < end) && in.load(begin + t, rn[PF ? k : 0]);
+      Rec tmp_rec;
+      okn[PF ? k : 0] = (begin + t < end) && in.load(begin + t, tmp_rec);
+      rn[PF ? k : 0] = RR::pack(tmp_rec);
     }
   }
 
@@ -151,15 +169,17 @@ __global__ __launch_bounds__(NW * 64) void k_rs_downsweep(Loader in, Sink out, u
     for (int k = 0; k < IPT; k++) {
       const u32 t = w * kWItems + k * 64 + lane;
       if (PF) { r[k] = rn[PF ? k : 0]; ok[k] = okn[PF ? k : 0]; }
-      else ok[k] = (t < nin) && in.load(tile + t, r[k]);
-      d[k] = ok[k] ? digit_of(r[k], dig) : 0u;
+      else { Rec tmp_rec; ok[k] = (t < nin) && in.load(tile + t, tmp_rec); r[k] = RR::pack(tmp_rec); }
+      d[k] = ok[k] ? digit_of(RR::unpack(r[k]), dig) : 0u;
     }
     if (PF) {
       const u32 nt = tile + kTile;
 #pragma unroll
       for (int k = 0; k < IPT; k++) {
         const u32 t = w * kWItems + k * 64 + lane;
-        okn[PF ? k : 0] = (nt + t < end) && in.load(nt + t, rn[PF ? k : 0]);
+        Rec tmp_rec;
+        okn[PF ? k : 0] = (nt + t < end) && in.load(nt + t, tmp_rec);
+        rn[PF ? k : 0] = RR::pack(tmp_rec);
       }
     }
     // stable ranking: items of one wave-round with equal digit are ordered by lane.  The lowest
@@ -211,7 +231,7 @@ __global__ __launch_bounds__(NW * 64) void k_rs_downsweep(Loader in, Sink out, u
     // reorder through LDS so every digit run is contiguous
 #pragma unroll
     for (int k = 0; k < IPT; k++) {
-      if (ok[k]) srec[texcl[d[k]] + wcnt[w * NB + d[k]] + rk[k]] = r[k];
+      if (ok[k]) srec[texcl[d[k]] + wcnt[w * NB + d[k]] + rk[k]] = RR::unpack(r[k]);
     }
     __syncthreads();
     for (u32 q = tid; q < nkeep; q += kB) {

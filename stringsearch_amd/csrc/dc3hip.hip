@@ -91,47 +91,25 @@ static int ctx_create_impl(dc3hip_ctx **out, int32_t device, int64_t max_n, dc3h
   memset(&c->stats, 0, sizeof(c->stats));
   const char *prof = getenv("DC3HIP_PROFILE");
   c->profile = !(prof && prof[0] == '0');
-  const char *nh = getenv("DC3HIP_NO_HYBRID");
-  c->no_hybrid = (nh && nh[0] == '1');
-  const char *nst = getenv("DC3HIP_NO_SMALL_TIES");
-  c->no_small_ties = (nst && nst[0] == '1');
-  { const char *e = getenv("DC3HIP_NO_SPLIT_EMIT"); c->no_split_emit = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_TRACE"); c->trace = (e && e[0] == '1'); }
-  { const char *e = getenv("DC3HIP_NO_LONG_KEYS"); c->no_long_keys = (e && e[0] == '1'); }
-  { const char *e = getenv("DC3HIP_NO_DOUBLING"); c->no_doubling = (e && e[0] == '1'); }
-  { const char *e = getenv("DC3HIP_TEXT_ORDER12"); if (e && (e[0] == '0' || e[0] == '1')) c->text_order12 = e[0] - '0'; }
-  { const char *e = getenv("DC3HIP_NO_TUP8"); c->no_tup8 = (e && e[0] == '1'); }
-  { const char *e = getenv("DC3HIP_NO_MSD"); c->no_msd = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_LEVEL_PHASES"); c->level_report = (e && e[0] == '1'); }
-  { const char *e = getenv("DC3HIP_PACK_FUSE"); c->pack_fuse = !(e && e[0] == '0'); }
-  { const char *e = getenv("DC3HIP_NO_RAW_IMAGE"); c->no_raw_image = (e && e[0] == '1'); }
-  { const char *e = getenv("DC3HIP_NO_PACK_STRIP"); c->no_pack_strip = (e && e[0] == '1'); }
-  { const char *e = getenv("DC3HIP_TUP_BIGTILE"); c->tup_bigtile = !(e && e[0] == '0'); }
-  { const char *e = getenv("DC3HIP_NO_XCD_MAP"); c->no_xcd_map = (e && e[0] == '1'); }
-  { const char *e = getenv("DC3HIP_NO_TUP_SCATTER"); c->no_tup_scatter = (e && e[0] == '1'); }
-  { const char *e = getenv("DC3HIP_NO_TUP_REC8"); c->no_tup_rec8 = (e && e[0] == '1'); }
-  { const char *e = getenv("DC3HIP_TUP_SCATTER_MIN"); if (e && *e) c->tup_scatter_min = (u32)strtoul(e, nullptr, 10); }
-  { const char *e = getenv("DC3HIP_MSD_MIN"); if (e) c->msd_min = (u32)std::max(4096ll, atoll(e)); }
-  { const char *e = getenv("DC3HIP_NO_SSORT"); c->no_ssort = (e && e[0] == '1'); }
-  { const char *e = getenv("DC3HIP_NO_FUSE_NAMES"); c->no_fuse_names = (e && e[0] == '1'); }
-  { const char *e = getenv("DC3HIP_SSORT_VERIFY"); c->ssort_verify = (e && e[0] == '1'); }
-  { const char *e = getenv("DC3HIP_NO_PACK_COUNT"); c->no_pack_count = (e && e[0] == '1'); }
-  { const char *e = getenv("DC3HIP_SSORT_REC12"); c->ssort_rec12 = (e && e[0] == '1'); }
-  { const char *e = getenv("DC3HIP_NO_WIDE_WINDOW"); c->no_wide_window = (e && e[0] == '1'); }
-  { const char *e = getenv("DC3HIP_SSORT_MIN"); if (e) c->ssort_min = (u32)std::max(8192ll, atoll(e)); }
-  { const char *e = getenv("DC3HIP_NO_HYBRID12"); c->no_hybrid12 = (e && e[0] == '1'); }
-  { const char *e = getenv("DC3HIP_NO_HYBRID8"); c->no_hybrid8 = (e && e[0] == '1'); }
-  { const char *e = getenv("DC3HIP_HYBRID12_MIN"); if (e) c->hybrid12_min = (u32)std::max(0ll, atoll(e)); }
-  const char *nts = getenv("DC3HIP_NO_TEXT_SHORTCUT");
-  c->no_text_shortcut = (nts && nts[0] == '1');
-  const char *nf = getenv("DC3HIP_NO_FULLSORT");
-  c->no_fullsort = (nf && nf[0] == '1');
-  const char *nd = getenv("DC3HIP_NO_DISCARD");
-  c->no_discard = (nd && nd[0] == '1');
-  const char *n9 = getenv("DC3HIP_NO_9BIT");
-  c->no_nine_bit = (n9 && n9[0] == '1');
-  const char *n12 = getenv("DC3HIP_NO_REC12");
-  c->no_rec12 = (n12 && n12[0] == '1');
+  // test / diagnosis switches (DC3HIP_DEBUG, dc3_host_core.hpp): none changes a result
+  c->no_hybrid = dbg_on("no_hybrid"); c->no_hybrid8 = dbg_on("no_hybrid8"); c->no_hybrid12 = dbg_on("no_hybrid12");
+  c->no_small_ties = dbg_on("no_small_ties"); c->no_split_emit = dbg_on("no_split_emit");
+  c->no_long_keys = dbg_on("no_long_keys"); c->no_doubling = dbg_on("no_doubling");
+  if (dbg_on("text_order12")) c->text_order12 = 1; else if (dbg_off("text_order12")) c->text_order12 = 0;
+  c->no_tup8 = dbg_on("no_tup8"); c->no_tup_scatter = dbg_on("no_tup_scatter"); c->no_tup_rec8 = dbg_on("no_tup_rec8");
+  c->tup_bigtile = !dbg_off("tup_bigtile"); c->pack_fuse = !dbg_off("pack_fuse");
+  c->no_msd = dbg_on("no_msd"); c->no_xcd_map = dbg_on("no_xcd_map");
+  c->no_raw_image = dbg_on("no_raw_image"); c->no_pack_strip = dbg_on("no_pack_strip"); c->no_pack_count = dbg_on("no_pack_count");
+  c->no_ssort = dbg_on("no_ssort"); c->ssort_verify = dbg_on("ssort_verify"); c->ssort_rec12 = dbg_on("ssort_rec12");
+  c->no_wide_window = dbg_on("no_wide_window"); c->no_fuse_names = dbg_on("no_fuse_names");
+  c->no_text_shortcut = dbg_on("no_text_shortcut"); c->no_fullsort = dbg_on("no_fullsort"); c->no_discard = dbg_on("no_discard");
+  c->no_nine_bit = dbg_on("no_9bit"); c->no_rec12 = dbg_on("no_rec12");
+  { long long v; if (dbg_num("tup_scatter_min", &v)) c->tup_scatter_min = (u32)std::max(0ll, v); }
+  { long long v; if (dbg_num("msd_min", &v)) c->msd_min = (u32)std::max(4096ll, v); }
+  { long long v; if (dbg_num("ssort_min", &v)) c->ssort_min = (u32)std::max(8192ll, v); }
+  { long long v; if (dbg_num("hybrid12_min", &v)) c->hybrid12_min = (u32)std::max(0ll, v); }
   int rc = [&]() -> int {
     HIPC(hipSetDevice(device));
     hipDeviceProp_t prop;

@@ -216,6 +216,20 @@ class GlobalLoopback {
   }
   GlobalLoopback(const GlobalLoopback &) = delete;
   ~GlobalLoopback() { for (auto *g : h_) if (g) dc3hip_global_destroy(g); }
+  // What the last build would take on P GPUs (the ranks here may share one): the slowest rank's own work + the transport
+  // priced per collective at the most bytes a rank exchanges with one peer over a 153 GB/s xGMI link (dc3hip_gstats).
+  double predicted_wall_ms(double *max_work_ms = nullptr, double *max_link_ms = nullptr) const {
+    double w = 0, l = 0;
+    for (auto *g : h_) {
+      dc3hip_gstats gs;
+      if (dc3hip_global_stats(g, &gs, nullptr) != 0) throw Error(-3, dc3hip_last_error());
+      if (gs.work_ms > w) w = gs.work_ms;
+      if (gs.link_ms > l) l = gs.link_ms;
+    }
+    if (max_work_ms) *max_work_ms = w;
+    if (max_link_ms) *max_link_ms = l;
+    return w + l;
+  }
   // the whole text lives on this host: every rank takes its block
   sacabase::SuffixArray<int64_t> sort(sacabase::Bytes text) {
     for (auto *g : h_) {

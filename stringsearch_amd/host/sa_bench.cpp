@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <dlfcn.h>
 #include <fstream>
+#include <sys/stat.h>
 #include <functional>
 #include <iostream>
 #include <string>
@@ -38,7 +39,9 @@ static std::string fmt_binary(double v) {   // SizeFormatterBinary
 }
 static uint64_t splitmix64(uint64_t x) { x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; return x ^ (x >> 31); }
 
-static std::vector<uint8_t> load_input(const std::string &spec) {
+// limit: at most this many bytes are read (LENGTH of the command line; ~0 = the whole file).  A stream without an end
+// (/dev/urandom, a pipe) must come with a LENGTH: reading "all of it" exhausts the host's memory.
+static std::vector<uint8_t> load_input(const std::string &spec, size_t limit) {
   if (spec.rfind("gen:", 0) == 0) {
     const size_t a = spec.find(':', 4), b = spec.find(':', a + 1);
     if (a == std::string::npos || b == std::string::npos) usage();
@@ -53,7 +56,14 @@ static std::vector<uint8_t> load_input(const std::string &spec) {
   }
   std::ifstream f(spec, std::ios::binary);
   if (!f) { std::fprintf(stderr, "cannot read %s\n", spec.c_str()); std::exit(1); }
-  return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  struct stat st;
+  const bool regular = stat(spec.c_str(), &st) == 0 && S_ISREG(st.st_mode);
+  if (!regular && limit == ~(size_t)0) { std::fprintf(stderr, "%s is not a regular file: give a LENGTH\n", spec.c_str()); std::exit(1); }
+  const size_t want = regular ? std::min<size_t>(limit, (size_t)st.st_size) : limit;
+  std::vector<uint8_t> t(want);
+  f.read(reinterpret_cast<char *>(t.data()), (std::streamsize)want);
+  t.resize((size_t)f.gcount());
+  return t;
 }
 
 int main(int argc, char **argv) {
@@ -69,8 +79,9 @@ int main(int argc, char **argv) {
   if (free_args.size() < 2) usage();
   const std::string cmd = free_args[0];
   if (cmd != "bench" && cmd != "run" && cmd != "verify") { std::printf("Command should be one of bench, run or verify\n"); return 1; }
-  std::vector<uint8_t> full = load_input(free_args[1]);
-  const size_t len = free_args.size() > 2 ? parse_size(free_args[2]) : full.size();
+  const size_t limit = free_args.size() > 2 ? parse_size(free_args[2]) : ~(size_t)0;
+  std::vector<uint8_t> full = load_input(free_args[1], limit);
+  const size_t len = free_args.size() > 2 ? limit : full.size();
   if (len > full.size()) { std::fprintf(stderr, "LENGTH exceeds input\n"); return 1; }
   sacabase::Bytes input(full.data(), len);
   std::printf("Input is size %sB\n", fmt_binary((double)len).c_str());            // main.rs:52-55
@@ -113,6 +124,7 @@ int main(int argc, char **argv) {
     }
     measure("dc3-hip", [&] { dc3hip::sort(input); });
     double resident_ms = 0;
+    std::string global_note;
     measure("dc3-hip-resident", [&] {
       dc3hip_ctx *c = nullptr;
       if (dc3hip_ctx_create(&c, -1, (int64_t)len) || dc3hip_ctx_set_text(c, input.ptr, (int64_t)len) || dc3hip_ctx_build(c))
@@ -124,17 +136,22 @@ int main(int argc, char **argv) {
       // the global mode (one suffix array over P ranks) with the P ranks as loopback ranks on this GPU; checked against
       // the one-shot result
       bool same = false;
+      double pred = 0, pw = 0, pl = 0;
       measure(("dc3-hip-global(" + std::to_string(global_ranks) + ")").c_str(), [&] {
         dc3hip::GlobalLoopback grp(global_ranks, (int64_t)len);
         auto all = grp.sort(input);
+        pred = grp.predicted_wall_ms(&pw, &pl);
         auto one = dc3hip::sort_i64(input);
         same = all.sa() == one.sa();
       });
       if (!same) { std::fprintf(stderr, "\nglobal-mode result differs from the single-device result\n"); return 2; }
+      global_note = "dc3-hip-global(" + std::to_string(global_ranks) + ") on " + std::to_string(global_ranks) + " GPUs, predicted: " + std::to_string(pred) +
+                    " ms = slowest rank's own work " + std::to_string(pw) + " ms + transport " + std::to_string(pl) + " ms at 153 GB/s per xGMI link (the row above: ranks time-sharing this GPU, incl. host transfers)";
     }
     std::printf("done!\n");
     std::printf("%-20s %-14s %s\n", "Algorithm", "Time", "Average speed");
     for (auto &r : rows) std::printf("%-20s %-14s %sB/s\n", r.name.c_str(), (std::to_string(r.secs) + "s").c_str(), fmt_binary((double)len / r.secs).c_str());
+    if (!global_note.empty()) std::printf("%s\n", global_note.c_str());
     std::printf("%-20s %-14s %sB/s   (HIP-event time of the device-resident build only)\n", "dc3-hip-kernels", (std::to_string(resident_ms / 1e3) + "s").c_str(),
                 fmt_binary((double)len / (resident_ms / 1e3)).c_str());
   } catch (const std::exception &e) {

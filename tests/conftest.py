@@ -29,6 +29,28 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    import stringsearch_amd
+    stringsearch_amd.adopt_legacy_env()     # (DC3HIP_NO_HYBRID=1 pytest ...: the library itself reads DC3HIP_DEBUG only)
+
+
+def env_apply(d):
+    """Old-style {"DC3HIP_NO_HYBRID": "1", ...} settings of a test case: policy variables go to the environment, every other
+    DC3HIP_* name is a test switch and travels in DC3HIP_DEBUG (the only variable the library reads them from)."""
+    import stringsearch_amd as ss
+    for k, v in d.items():
+        if k in ss.POLICY_VARS or not k.startswith("DC3HIP_"):
+            os.environ[k] = str(v)
+        else:
+            ss.debug_set(k, v)
+
+
+def env_clear(keys):
+    import stringsearch_amd as ss
+    for k in keys:
+        if k in ss.POLICY_VARS or not k.startswith("DC3HIP_"):
+            os.environ.pop(k, None)
+        else:
+            ss.debug_unset(k)
 
 
 class Oracle:

@@ -18,15 +18,22 @@ def ss():
 
 
 class env:
+    """with env(DC3HIP_GLOBAL_LOCAL_MAX=64, DC3HIP_NO_HYBRID=1): policy variables go to the environment, every other DC3HIP_*
+    name is a test switch and travels in DC3HIP_DEBUG (stringsearch_amd.debug_switches) — the library reads nothing else."""
+
     def __init__(self, **kv):
-        self.kv = kv
+        import stringsearch_amd as ss
+        self.kv = {k: v for k, v in kv.items() if k in ss.POLICY_VARS or not k.startswith("DC3HIP_")}
+        self.dbg = ss.debug_switches(**{k: v for k, v in kv.items() if k not in self.kv})
 
     def __enter__(self):
         self.old = {k: os.environ.get(k) for k in self.kv}
         for k, v in self.kv.items():
             os.environ[k] = str(v)
+        self.dbg.__enter__()
 
     def __exit__(self, *a):
+        self.dbg.__exit__()
         for k, v in self.old.items():
             if v is None:
                 os.environ.pop(k, None)
@@ -229,7 +236,7 @@ def test_bench_global_two_processes_on_one_gpu(ss, oracle, tmp_path):
     from conftest import ROOT
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     size = 3 << 20
-    for kind, extra in (("random", {}), ("text", {"DC3HIP_GLOBAL_LOCAL_MAX": "4096"}), ("random", {"DC3HIP_GLOBAL_FORCE_WIDE": "1"})):
+    for kind, extra in (("random", {}), ("text", {"DC3HIP_GLOBAL_LOCAL_MAX": "4096"}), ("random", {"DC3HIP_DEBUG": "global_force_wide"})):
         env2 = dict(os.environ, DC3HIP_BENCH_BACKEND="gloo", DC3HIP_BENCH_DUMP_SA=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--mode", "global", "--size", str(size),
@@ -238,7 +245,7 @@ def test_bench_global_two_processes_on_one_gpu(ss, oracle, tmp_path):
         assert p.returncode == 0, (p.stdout[-1000:], p.stderr[-3000:])
         line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
         assert line["n_gpus"] == 2 and "global SA" in line["config"]["partitioning"] and line["config"]["total_bytes"] == 2 * size
-        if extra.get("DC3HIP_GLOBAL_FORCE_WIDE"):     # the 64-bit-position mode of texts beyond 2^32 bytes, two processes
+        if extra.get("DC3HIP_DEBUG"):     # the 64-bit-position mode of texts beyond 2^32 bytes, two processes
             assert line["verify"]["shards_tile_0_n"] and line["verify"]["global_sufcheck"] == 0 and "64-bit" in line["config"]["workload"]
         else:
             assert line["verify"]["shards_tile_0_n"] and line["verify"]["equal_single_device_checksum"]
@@ -360,17 +367,34 @@ def test_selecting_partition_pass_of_the_global_orderings(ss, oracle):
                                 assert all(s["text_order"] == 1 and s["comm_bytes_in"] <= len(t) + 4096 for s in st), (name, P)
                         g.build()
                         assert np.array_equal(g.sa(), want), (name, P, extra, "second build")
+    # select or route, by the per-rank cost model (gselect_pays): ranks that share a device have no link to pay and select
+    # whatever P is; told that the links are xGMI (DC3HIP_GLOBAL_LINK_GBPS=153, what an RCCL group reports) the same groups
+    # select up to 4 ranks and route beyond — same array either way — and the build says what P GPUs would take
+    want = want_sa(oracle, rnd)
+    for link, P, selects in (("0", 8, True), ("153", 2, True), ("153", 4, True), ("153", 5, False), ("153", 8, False), ("25", 8, True)):
+        with env(DC3HIP_MSD_MIN=4096, DC3HIP_GLOBAL_LINK_GBPS=link):
+            with ss.LoopbackGroup(P, len(rnd)) as g:
+                g.set_text(rnd)
+                g.build()
+                st = g.stats()
+                assert np.array_equal(g.sa(), want), (link, P)
+                assert all((s["select_p1"] >= 1) == selects for s in st), (link, P, [s["select_p1"] for s in st])
+                assert all(s["work_ms"] > 0 and s["collectives"] >= 1 and s["link_ms"] > 0 for s in st), st
+                # the ranks pass a device token: a rank's own work is well below the wall time of P ranks sharing the GPU
+                assert max(s["work_ms"] for s in st) <= max(s["wall_ms"] for s in st) + 1e-6
+                if P == 8:
+                    assert sum(s["work_ms"] for s in st) <= 1.25 * max(s["wall_ms"] for s in st) + 5.0, [(s["work_ms"], s["wall_ms"]) for s in st]
 
 
 def test_transport_selftest_and_recovery_after_a_failed_collective(ss, oracle):
     """dc3hip_global_selftest (ragged all-to-all / all-gather of known bytes, every byte checked) on loopback groups, and
     the failure semantics of the header: after a collective that failed on every rank (a one-symbol text in a wide
-    context is refused with -4) the group works again through ANY entry point — the self-test and a build — without the
+    context without the deepening is refused with -4) the group works again through ANY entry point — the self-test and a build — without the
     loopback_build wrapper having to reset it (round-2 advisor finding)."""
     for P in (2, 3, 8):
         with ss.LoopbackGroup(P, 100_000) as g:
             assert g.selftest() == [P] * P
-    with env(DC3HIP_GLOBAL_FORCE_WIDE=1):
+    with env(DC3HIP_GLOBAL_FORCE_WIDE=1, DC3HIP_NO_WIDE_DEEPEN=1):
         with ss.LoopbackGroup(2, 50_000) as g:
             g.set_text(b"a" * 20_000)
             with pytest.raises(ss.Dc3HipError):

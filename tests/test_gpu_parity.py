@@ -12,7 +12,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, naive_sa
+from conftest import GOLDEN, env_apply, env_clear, naive_sa
 
 pytestmark = pytest.mark.gpu
 
@@ -449,7 +449,7 @@ def test_hybrid_and_straight_paths_agree(ss, oracle):
                     {"DC3HIP_NO_TEXT_SHORTCUT": "1", "DC3HIP_NO_HYBRID8": "1", "DC3HIP_HYBRID12_MIN": "0"},   # 12-byte prefix sort
                     {"DC3HIP_NO_HYBRID12": "1"},
                     {"DC3HIP_NO_HYBRID": "1", "DC3HIP_NO_9BIT": "1", "DC3HIP_NO_REC12": "1"}):
-            os.environ.update(env)
+            env_apply(env)
             try:
                 with ss.Context(len(data)) as c:
                     c.set_text(data); c.build()
@@ -457,8 +457,7 @@ def test_hybrid_and_straight_paths_agree(ss, oracle):
                     assert np.array_equal(c.sa(), want), (label, env)
                     seen[tuple(sorted(env))] = st
             finally:
-                for k in env:
-                    os.environ.pop(k, None)
+                env_clear(env)
         assert not any(v in (2, 4, 5) for v in seen[("DC3HIP_NO_HYBRID",)]["level_sorted"])
         h12 = seen[("DC3HIP_HYBRID12_MIN", "DC3HIP_NO_HYBRID8", "DC3HIP_NO_TEXT_SHORTCUT")]
         if label in ("random", "zero_run", "dup_block"):
@@ -505,8 +504,8 @@ def test_whole_text_order_reused_by_level1(ss, oracle):
         want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)
         for wide in ("0", "1"):                           # 8-byte records, and the 12-byte ones of texts beyond 2^31
             for nodbl in ("1", "0"):                      # the order handed to level 1 / finished by prefix doubling
-                os.environ["DC3HIP_TEXT_ORDER12"] = wide
-                os.environ["DC3HIP_NO_DOUBLING"] = nodbl
+                ss.debug_set("text_order12", wide)
+                ss.debug_set("no_doubling", nodbl)
                 try:
                     with ss.Context(n) as c:
                         c.set_text(data); c.build()
@@ -517,8 +516,8 @@ def test_whole_text_order_reused_by_level1(ss, oracle):
                         else:
                             assert st["text_sort_state"] == 1 and st["level_sorted"][0] == 6 and st["levels"] == 1, st
                 finally:
-                    os.environ.pop("DC3HIP_TEXT_ORDER12", None)
-                    os.environ.pop("DC3HIP_NO_DOUBLING", None)
+                    ss.debug_unset("text_order12")
+                    ss.debug_unset("no_doubling")
         m0 = (n + 2) // 3; m1 = m0 + n // 3
         combos.add((n % 3, m1 % 3))
     assert len(combos) == 9
@@ -553,15 +552,14 @@ def test_small_alphabet_long_windows(ss, oracle):
         for env in ({}, {"DC3HIP_NO_LONG_KEYS": "1"}, {"DC3HIP_NO_SPLIT_EMIT": "1"}, {"DC3HIP_NO_SMALL_TIES": "1"},
                     {"DC3HIP_TEXT_ORDER12": "1"}, {"DC3HIP_TEXT_ORDER12": "1", "DC3HIP_NO_SMALL_TIES": "1"},
                     {"DC3HIP_NO_DOUBLING": "1"}, {"DC3HIP_NO_DOUBLING": "1", "DC3HIP_TEXT_ORDER12": "1"}):
-            os.environ.update(env)
+            env_apply(env)
             try:
                 with ss.Context(len(data)) as c:
                     c.set_text(data); c.build()
                     assert np.array_equal(c.sa(), want), (label, env)
                     seen[tuple(sorted(env))] = c.stats()
             finally:
-                for k in env:
-                    os.environ.pop(k, None)
+                env_clear(env)
         assert seen[("DC3HIP_NO_LONG_KEYS",)]["text_sort_state"] == 0, label
         if label.startswith("random") or label == "alphabet_with_zero_byte":
             assert seen[()]["text_sort_state"] == 1 and seen[()]["levels"] == 1, (label, seen[()]["text_sort_state"])
@@ -607,7 +605,7 @@ def test_prefix_doubling_finish_of_few_repeated_windows(ss, oracle):
         data = arr.tobytes()
         want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)
         for env in ({}, {"DC3HIP_TEXT_ORDER12": "1"}, {"DC3HIP_NO_DOUBLING": "1"}):
-            os.environ.update(env)
+            env_apply(env)
             try:
                 with ss.Context(len(data)) as c:
                     c.set_text(data); c.build()
@@ -619,8 +617,7 @@ def test_prefix_doubling_finish_of_few_repeated_windows(ss, oracle):
                         assert st["text_sort_state"] == 1 and st["levels"] == 1 and st["level_sorted"][0] == 6, (label, env, st["level_sorted"])
                         assert st["level_tied"][0] > 0 and st["level_kept"][0] >= 2, (label, st["level_tied"][0], st["level_kept"][0])
             finally:
-                for k in env:
-                    os.environ.pop(k, None)
+                env_clear(env)
 
 
 def test_bucket_ordering_matches_the_stable_passes(ss, oracle):
@@ -666,7 +663,7 @@ def test_bucket_ordering_matches_the_stable_passes(ss, oracle):
                     {"DC3HIP_MSD_MIN": "4096", "DC3HIP_NO_PACK_STRIP": "1"},    # pass 1 makes them, from an image no wider than the word
                     {"DC3HIP_MSD_MIN": "4096", "DC3HIP_NO_RAW_IMAGE": "1"},     # byte alphabets: the scaled 9-symbol key as the image
                     {"DC3HIP_MSD_MIN": "4096", "DC3HIP_NO_TUP_SCATTER": "1", "DC3HIP_NO_XCD_MAP": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1"}):
-            os.environ.update(env)
+            env_apply(env)
             try:
                 with ss.Context(len(data)) as c:
                     c.set_text(data); c.build()
@@ -677,8 +674,7 @@ def test_bucket_ordering_matches_the_stable_passes(ss, oracle):
                     elif (label.startswith("bytes") or label == "dna") and "DC3HIP_NO_TEXT_SHORTCUT" not in env:
                         assert st["msd_sorts"] >= 1, (label, env, st["msd_sorts"], st["msd_fallbacks"])
             finally:
-                for k in env:
-                    os.environ.pop(k, None)
+                env_clear(env)
 
 
 def test_splitter_ordering_matches_the_stable_passes(ss, oracle):
@@ -713,7 +709,7 @@ def test_splitter_ordering_matches_the_stable_passes(ss, oracle):
                     {"DC3HIP_SSORT_MIN": "8192", "DC3HIP_NO_DISCARD": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1"},
                     {"DC3HIP_SSORT_MIN": "8192", "DC3HIP_NO_PACK_COUNT": "1"},
                     {"DC3HIP_NO_SSORT": "1"}):
-            os.environ.update(env)
+            env_apply(env)
             try:
                 with ss.Context(len(data)) as c:
                     c.set_text(data); c.build()
@@ -725,8 +721,7 @@ def test_splitter_ordering_matches_the_stable_passes(ss, oracle):
                     elif "DC3HIP_NO_HYBRID" in env and "DC3HIP_SSORT_REC12" in env:
                         assert st["ssort_sorts"] >= 1, (label, env)
             finally:
-                for k in env:
-                    os.environ.pop(k, None)
+                env_clear(env)
     # the default threshold
     data = oracle.gen(40_000_000, 9, 2).tobytes()
     want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)
@@ -747,7 +742,7 @@ def test_splitter_ordering_geometries_with_self_check(ss):
     sizes, built repeatedly with DC3HIP_SSORT_VERIFY=1 — every splitter ordering compares record checksums after each
     pass, the cursors with the region bounds after pass 2, and the order of its output, and fails the build on any
     difference — plus the GPU sufcheck of every result."""
-    os.environ["DC3HIP_SSORT_VERIFY"] = "1"
+    ss.debug_set("ssort_verify", "1")
     try:
         sorts = fallbacks = 0
         with ss.Context(64 << 20) as c:
@@ -762,7 +757,7 @@ def test_splitter_ordering_geometries_with_self_check(ss):
         # sample it should be rare: the regular stride of the first version resonated with this generator's repeats)
         assert sorts >= 10 and fallbacks <= 1, (sorts, fallbacks)
     finally:
-        os.environ.pop("DC3HIP_SSORT_VERIFY", None)
+        ss.debug_unset("ssort_verify")
 
 
 def test_deep_tie_pass_then_doubling_on_12_byte_records(ss, oracle):
@@ -794,14 +789,13 @@ def test_deep_tie_pass_then_doubling_on_12_byte_records(ss, oracle):
         data = d.tobytes()
         want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)
         for env in ({"DC3HIP_TEXT_ORDER12": "1"}, {}, {"DC3HIP_TEXT_ORDER12": "1", "DC3HIP_NO_DOUBLING": "1"}):
-            os.environ.update(env)
+            env_apply(env)
             try:
                 with ss.Context(len(data)) as c:
                     c.set_text(data); c.build()
                     assert np.array_equal(c.sa(), want), (name, env, c.stats()["level_sorted"][:3])
             finally:
-                for k in env:
-                    os.environ.pop(k, None)
+                env_clear(env)
 
 
 def test_compact_unwinding_matches_the_general_form(ss, oracle, corpus):
@@ -831,15 +825,14 @@ def test_compact_unwinding_matches_the_general_form(ss, oracle, corpus):
             {"DC3HIP_NO_TUP_SCATTER": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1"})
     wants = {label: (oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)) for label, data in cases.items()}
     for env in envs:
-        os.environ.update(env)
+        env_apply(env)
         try:
             with ss.Context(max(len(d) for d in cases.values())) as c:
                 for label, data in cases.items():
                     c.set_text(data); c.build()
                     assert np.array_equal(c.sa(), wants[label]), (label, env)
         finally:
-            for k in env:
-                os.environ.pop(k, None)
+            env_clear(env)
 
 
 def test_discarding_recursion_agrees_and_shrinks(ss, oracle, corpus):
@@ -855,7 +848,7 @@ def test_discarding_recursion_agrees_and_shrinks(ss, oracle, corpus):
         want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)
         res = {}
         for flag in ("0", "1"):
-            os.environ["DC3HIP_NO_DISCARD"] = flag
+            ss.debug_set("no_discard", flag)
             try:
                 with ss.Context(len(data)) as c:
                     c.set_text(data); c.build()
@@ -863,7 +856,7 @@ def test_discarding_recursion_agrees_and_shrinks(ss, oracle, corpus):
                     assert c.sufcheck() == 0
                     res[flag] = c.stats()
             finally:
-                os.environ.pop("DC3HIP_NO_DISCARD", None)
+                ss.debug_unset("no_discard")
         assert not any(res["1"]["level_kept"])
         if label == "text":
             assert any(res["0"]["level_kept"]), res["0"]["level_sorted"]
@@ -924,7 +917,7 @@ def test_full_size_1gib_properties(ss):
         st = c.stats()
         assert st["levels"] == 1 and st["level_sorted"][0] == 5      # whole-text shortcut
     import os
-    os.environ["DC3HIP_NO_TEXT_SHORTCUT"] = "1"                      # the DC3 recursion proper at full size
+    ss.debug_set("no_text_shortcut", "1")                      # the DC3 recursion proper at full size
     try:
         with ss.Context(n) as c:
             c.generate(n, 2, 0)
@@ -932,7 +925,7 @@ def test_full_size_1gib_properties(ss):
             assert c.sufcheck() == 0 and c.checksum() == chk
             assert c.stats()["level_n"][:2] == [n, 715827883]
     finally:
-        os.environ.pop("DC3HIP_NO_TEXT_SHORTCUT", None)
+        ss.debug_unset("no_text_shortcut")
 
 
 @pytest.mark.parametrize("kind,label", [(2, "low-entropy text (configs[2])"), (1, "DNA alphabet (configs[4] per-GPU class)")])
@@ -958,7 +951,7 @@ def test_full_size_1gib_text_and_dna_properties(ss, kind, label):
         assert np.array_equal(np.bincount(u, minlength=256), np.bincount(c.text(), minlength=256))
     if kind == 1:       # and the DC3 recursion proper on the same text gives the same array
         import os
-        os.environ["DC3HIP_NO_LONG_KEYS"] = "1"
+        ss.debug_set("no_long_keys", "1")
         try:
             with ss.Context(n) as c:
                 c.generate(n, 3, kind)
@@ -966,7 +959,7 @@ def test_full_size_1gib_text_and_dna_properties(ss, kind, label):
                 assert c.stats()["levels"] >= 3 and c.stats()["text_sort_state"] == 0
                 assert c.checksum() == chk and c.sufcheck() == 0
         finally:
-            os.environ.pop("DC3HIP_NO_LONG_KEYS", None)
+            ss.debug_unset("no_long_keys")
 
 
 def test_beyond_2pow31_needs_64bit_indices(ss):
@@ -986,7 +979,7 @@ def test_beyond_2pow31_needs_64bit_indices(ss):
         with pytest.raises(ss.Dc3HipError) as ei:
             c.sa(np.int32)                         # int32 cannot hold these positions
         assert ei.value.code == -4
-    os.environ["DC3HIP_NO_LONG_KEYS"] = "1"        # and the recursion proper at this size
+    ss.debug_set("no_long_keys", "1")        # and the recursion proper at this size
     try:
         with ss.Context(n) as c:
             c.generate(n, 5, 1, offset=7 * n)
@@ -994,7 +987,7 @@ def test_beyond_2pow31_needs_64bit_indices(ss):
             st = c.stats()
             assert st["levels"] >= 3 and st["level_name_width"][0] == 3 and c.checksum() == chk and c.sufcheck() == 0
     finally:
-        os.environ.pop("DC3HIP_NO_LONG_KEYS", None)
+        ss.debug_unset("no_long_keys")
     import ctypes
     t = np.zeros(8, dtype=np.uint8); sa = np.zeros(8, dtype=np.int32)
     from stringsearch_amd._lib import Opts
@@ -1037,7 +1030,7 @@ def test_sample_count_beyond_2pow31(ss):
         assert c.sufcheck() == 0
         assert c.stats()["levels"] == 1 and c.stats()["text_sort_state"] == 1
         chk = c.checksum()
-    os.environ["DC3HIP_TEXT_ORDER12"] = "0"        # the recursion at this size (8-byte images tie too much here)
+    ss.debug_set("text_order12", "0")        # the recursion at this size (8-byte images tie too much here)
     try:
         with ss.Context(n) as c:
             c.generate(n, 9, 0)
@@ -1045,7 +1038,7 @@ def test_sample_count_beyond_2pow31(ss):
             assert c.sufcheck() == 0 and c.checksum() == chk
             assert c.stats()["level_n"][1] > (1 << 31)
     finally:
-        os.environ.pop("DC3HIP_TEXT_ORDER12", None)
+        ss.debug_unset("text_order12")
 
 
 def test_boundary_sizes_sufcheck(ss):
@@ -1199,9 +1192,8 @@ def test_stage_level_trace_matches_oracle(ss, oracle, corpus):
     keys = ("DC3HIP_TRACE", "DC3HIP_NO_DISCARD", "DC3HIP_NO_HYBRID", "DC3HIP_NO_FULLSORT", "DC3HIP_NO_TEXT_SHORTCUT")
     # (second round: the same stages through the compact unwinding — scattered 12-byte sample tuples, 16-byte mod-0 tuples)
     for extra in ({}, {"DC3HIP_TUP_SCATTER_MIN": "1"}):
-        for k in keys:
-            os.environ[k] = "1"
-        os.environ.update(extra)
+        env_apply({k: "1" for k in keys})
+        env_apply(extra)
         try:
             with ss.Context(max(len(v) for v in cases.values())) as c:
                 for name, data in cases.items():
@@ -1217,8 +1209,7 @@ def test_stage_level_trace_matches_oracle(ss, oracle, corpus):
                         for stage in ("sa12", "sa0", "sa"):
                             assert g[stage] == w[stage], f"{name}: level {lvl} stage {stage} differs ({extra})"
         finally:
-            for k in keys + tuple(extra):
-                os.environ.pop(k, None)
+            env_clear(keys + tuple(extra))
 
 
 @pytest.mark.parametrize("nb,shift", [(256, 0), (256, 13), (512, 0), (512, 23), (256, 48)])

@@ -108,14 +108,14 @@ def test_generated_inputs_stay_on_their_routes(ss):
         # level 1 sorts 6-symbol windows by the splitter ordering; a fallback to the LSD passes costs ~40 ms
         assert st["ssort_sorts"] >= 1 and st["ssort_fallbacks"] == 0 and max(st["level_name_width"]) >= 4, (st["ssort_sorts"], st["ssort_fallbacks"])
         report("text_1GiB", ms, {"levels": st["levels"], "ssort_sorts": st["ssort_sorts"], "ssort_max_subbucket": st["ssort_max_subbucket"]})
-    os.environ["DC3HIP_NO_TEXT_SHORTCUT"] = "1"
+    ss.debug_set("no_text_shortcut", "1")
     try:
         with ss.Context(GIB) as c:
             c.generate(GIB, 2, 0)
             ms = best_ms(c)
             report("random_1GiB_recursion_only", ms, {"levels": c.stats()["levels"]})
     finally:
-        os.environ.pop("DC3HIP_NO_TEXT_SHORTCUT", None)
+        ss.debug_unset("no_text_shortcut")
 
 
 def test_real_text_stays_on_its_route(ss):
@@ -129,7 +129,7 @@ def test_real_text_stays_on_its_route(ss):
         report("real_text_256MiB", ms, {"levels": c.stats()["levels"], "ssort_sorts": c.stats()["ssort_sorts"]})
     # the corpus whose level 4 (9.8 M samples: 2-3 partition tiles per bucket) found the group-boundary bug of the first
     # splitter ordering, one build in eight: a few more builds with the ordering's self-check on
-    os.environ["DC3HIP_SSORT_VERIFY"] = "1"
+    ss.debug_set("ssort_verify", "1")
     try:
         with ss.Context(len(data)) as c:
             c.set_text(data)
@@ -137,4 +137,4 @@ def test_real_text_stays_on_its_route(ss):
                 c.build()
             assert c.sufcheck() == 0
     finally:
-        os.environ.pop("DC3HIP_SSORT_VERIFY", None)
+        ss.debug_unset("ssort_verify")

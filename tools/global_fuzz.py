@@ -7,6 +7,7 @@ import numpy as np
 import stringsearch_amd as ss
 from conftest import Oracle
 
+ss.adopt_legacy_env()        # (DC3HIP_MSD_MIN=4096 python tools/global_fuzz.py ...: old-style switches of the command line)
 o = Oracle()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -53,7 +54,9 @@ while time.time() - t0 < budget:
     if rng.random() < 0.5:
         envs["DC3HIP_HYBRID12_MIN"] = "0"
     text = make_text(n)
-    for k, v in envs.items(): os.environ[k] = v
+    for k, v in envs.items():                            # (policy variables as they are, test switches through DC3HIP_DEBUG)
+        if k in ss.POLICY_VARS: os.environ[k] = v
+        else: ss.debug_set(k, v)
     if os.environ.get("GLOBAL_FUZZ_VERBOSE"):          # (the case on stderr before it runs: a crash names its input)
         np.save("gpurun_out/global_fuzz_last.npy", text); print(json.dumps({"it": it, "P": P, "n": n, "env": envs}), file=sys.stderr, flush=True)
     try:
@@ -64,7 +67,9 @@ while time.time() - t0 < budget:
     except Exception as e:
         print(json.dumps({"FAIL": repr(e), "P": P, "n": n, "env": envs}), flush=True); np.save("gpurun_out/global_fuzz_fail.npy", text); sys.exit(1)
     finally:
-        for k in envs: os.environ.pop(k, None)
+        for k in envs:
+            if k in ss.POLICY_VARS: os.environ.pop(k, None)
+            else: ss.debug_unset(k)
     want = (o.ref_sufsort(text) if o.ref is not None and n > 0 else o.sufsort(text)).astype(np.int64) if n else np.zeros(0, dtype=np.int64)
     if not np.array_equal(got, want):
         print(json.dumps({"MISMATCH": True, "P": P, "n": n, "env": envs}), flush=True); np.save("gpurun_out/global_fuzz_fail.npy", text); sys.exit(1)

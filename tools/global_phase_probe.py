@@ -6,6 +6,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("DC3HIP_PROFILE", "1")
 import torch  # noqa: F401  (first: one HIP runtime per process)
 import stringsearch_amd as ss
+ss.adopt_legacy_env()        # (old-style one-variable switches of the command line -> DC3HIP_DEBUG)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256 << 20
 kind = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 P = int(sys.argv[3]) if len(sys.argv) > 3 else 2

@@ -10,9 +10,10 @@ Usage: python tools/global_wide_fuzz.py SECONDS [SEED]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-os.environ["DC3HIP_GLOBAL_FORCE_WIDE"] = "1"
 import numpy as np
 import stringsearch_amd as ss
+ss.adopt_legacy_env()        # (old-style one-variable switches of the command line -> DC3HIP_DEBUG)
+ss.debug_set("global_force_wide", "1")
 from conftest import Oracle
 
 o = Oracle()

@@ -3,6 +3,7 @@ import os, sys, json, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import stringsearch_amd as ss
+ss.adopt_legacy_env()        # (old-style one-variable switches of the command line -> DC3HIP_DEBUG)
 cases = [(1 << 26, 2), (1 << 28, 2), (1 << 30, 2), (1 << 28, 1), (1 << 30, 1), (1 << 30, 0)]
 if len(sys.argv) > 1:
     cases = [(int(a.split(":")[0]), int(a.split(":")[1])) for a in sys.argv[1:]]

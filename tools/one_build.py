@@ -7,6 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("DC3HIP_PROFILE", "1")
 import stringsearch_amd as ss
+ss.adopt_legacy_env()        # (old-style one-variable switches of the command line -> DC3HIP_DEBUG)
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 builds = int(sys.argv[sys.argv.index("--builds") + 1]) if "--builds" in sys.argv else 1

@@ -3,7 +3,7 @@
 # Separate passes (FETCH_SIZE and WRITE_SIZE cannot share one; SQ groups of <= 8 counters), the program directly after `--`.
 # usage: tools/pmc_build.sh TAG [n:kind[:seed]] [hbm]  ->  gpurun_out/pmc_TAG_g<i>_by_kernel.csv, gpurun_out/pmc_TAG_stats.json
 #   "hbm": the two HBM passes only (what profiles/pmc_traffic*.json is made of: python tools/pmc_to_json.py gpurun_out TAG)
-#   bench.py's workloads: default 1073741824:0:2 | recursion = the same under DC3HIP_NO_TEXT_SHORTCUT=1 | text 1073741824:2:3 | dna 1073741824:1:5
+#   bench.py's workloads: default 1073741824:0:2 | recursion = the same under DC3HIP_DEBUG=no_text_shortcut | text 1073741824:2:3 | dna 1073741824:1:5
 tag=${1:-text}
 spec=${2:-1073741824:2}
 : "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun sets GRAFT_REPO_ROOT)}"

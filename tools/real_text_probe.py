@@ -9,6 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import stringsearch_amd as ss
+ss.adopt_legacy_env()        # (old-style one-variable switches of the command line -> DC3HIP_DEBUG)
 
 ROOTS = ["/opt/rocm/include", "/usr/lib/python3.10", "/usr/local/lib/python3.10/dist-packages", "/usr/share/doc", "/opt/rocm/share"]
 EXTS = (".h", ".hpp", ".py", ".txt", ".md", ".rst", ".cuh", ".inc", ".cpp", ".c", ".pyi", ".cmake", ".html", ".hip", ".cu")

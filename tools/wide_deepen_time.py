@@ -3,11 +3,12 @@
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("DC3HIP_GLOBAL_FORCE_WIDE", "1")
 os.environ.setdefault("DC3HIP_PROFILE", "1")
 import numpy as np
 import torch  # noqa: F401
 import stringsearch_amd as ss
+ss.adopt_legacy_env()        # (old-style one-variable switches of the command line -> DC3HIP_DEBUG)
+ss.debug_set("global_force_wide")
 n, rep = int(sys.argv[1]), int(sys.argv[2])
 P = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 t = np.random.default_rng(5).integers(0, 256, size=n, dtype=np.uint8)

@@ -5,6 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: F401  (first: one HIP runtime per process)
 import stringsearch_amd as ss
+ss.adopt_legacy_env()        # (old-style one-variable switches of the command line -> DC3HIP_DEBUG)
 n, kind, P = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 with ss.LoopbackGroup(P, n) as g:
     g.generate(n, 5 if kind else 6, kind); g.build()

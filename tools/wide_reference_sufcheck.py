@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import stringsearch_amd as ss  # noqa: E402
+ss.adopt_legacy_env()        # (old-style one-variable switches of the command line -> DC3HIP_DEBUG)
 
 # argument 1: the text length in bytes when it is at least 2^32, else the bytes beyond 2^32; argument 3: loopback ranks
 # (BASELINE.json configs[4]'s class — DNA, 8 ranks, 64-bit indices — as far as one GPU's 288 GB allow:
