@@ -31,17 +31,11 @@
  * Environment (read when a context is created; NONE changes a result — every ordering is tested to give the same bytes):
  *   policy       DC3HIP_PROFILE=1 (per-phase HIP events -> dc3hip_stats), DC3HIP_CACHE=0, DC3HIP_WORKERS_PER_DEVICE,
  *                DC3HIP_ARENA_BYTES, DC3HIP_XCD_ASSUME=1 (keep the bucket ordering although the placement probe failed),
- *                DC3HIP_GLOBAL_LOCAL_MAX (global mode: levels this small are finished on every rank's replica)
- *   diagnostics  DC3HIP_TRACE=1 (stage checksums), DC3HIP_LEVEL_PHASES=1 (phase times per level on stderr),
- *                DC3HIP_SSORT_VERIFY=1 (self-check of the splitter ordering)
- *   test-only    force or forbid one of the orderings so that the parity suite can compare them:
- *                DC3HIP_NO_TEXT_SHORTCUT, _NO_FULLSORT, _NO_HYBRID, _NO_HYBRID8, _NO_HYBRID12, _HYBRID12_MIN, _NO_LONG_KEYS,
- *                _NO_RAW_IMAGE, _NO_DOUBLING, _TEXT_ORDER12, _NO_SPLIT_EMIT, _NO_SMALL_TIES, _NO_9BIT, _NO_REC12, _NO_DISCARD, _NO_MSD,
- *                _MSD_MIN, _PACK_FUSE=0, _NO_PACK_STRIP, _NO_SSORT, _SSORT_MIN, _SSORT_REC12, _NO_WIDE_WINDOW,
- *                _NO_PACK_COUNT, _NO_TUP8, _NO_TUP_SCATTER, _NO_TUP_REC8, _TUP_BIGTILE=0, _TUP_SCATTER_MIN, _NO_XCD_MAP;
- *                global mode: DC3HIP_GLOBAL_NO_TEXT_ORDER, _GLOBAL_FORCE_DIST, _GLOBAL_FORCE_WIDE, _GLOBAL_NO_ROUTE,
- *                _GLOBAL_NO_SELECT, DC3HIP_NO_WIDE_DEEPEN, DC3HIP_NO_WIDE_MSD, DC3HIP_WIDE_MSD_MIN, DC3HIP_WIDE_CORRUPT (verifier test hook)
- * (DESIGN.md section 7 says what each one selects.)
+ *                DC3HIP_GLOBAL_LOCAL_MAX (global mode: levels this small are finished on every rank's replica),
+ *                DC3HIP_QUIET=1 (no line on stderr when the HIP runtime in use is not the one the library was compiled against)
+ *   diagnostics  DC3HIP_TRACE=1 (stage checksums), DC3HIP_LEVEL_PHASES=1 (phase times per level on stderr)
+ *   test-only    ONE variable, DC3HIP_DEBUG="name[=value],name,...": forces or forbids one of the orderings so that the
+ *                parity suite can compare them, or plants a fault for a verifier test (names: DESIGN.md section 7).
  */
 #ifndef DC3HIP_H
 #define DC3HIP_H 1
@@ -293,8 +287,8 @@ DC3HIP_API int32_t dc3hip_ctx_debug_radix_pass_u64(dc3hip_ctx *ctx, const uint64
  * rank returns the same code, under every transport.  Other faults under RCCL / the host-staged transport leave the peers
  * inside a collective, as in any NCCL program: the host job's watchdog has to tear the group down.
  * Environment: DC3HIP_GLOBAL_LOCAL_MAX (levels up to this length are finished by every rank on its own replicated
- * copy, default 2^22), DC3HIP_GLOBAL_NO_TEXT_ORDER=1 (skip the distributed whole-text order).
- * WIDE contexts (max_total_n > DC3HIP_MAX_N, up to 2^40; or DC3HIP_GLOBAL_FORCE_WIDE=1): positions are 64-bit, and the
+ * copy, default 2^22).
+ * WIDE contexts (max_total_n > DC3HIP_MAX_N, up to 2^40): positions are 64-bit, and the
  * order is the distributed whole-text order (BASELINE.json configs[3] random bytes at 4 GiB, configs[4] random DNA at
  * 16 GiB).  Windows that repeat are compared deeper (256, 8192, then 16x more symbols per round while that is cheap) and
  * beyond that settled by rank look-ups: all ranks exchange their shards, build the inverse of the order so far, and 17
@@ -323,9 +317,9 @@ typedef struct dc3hip_gstats {
   int64_t select_p1;         /* orderings of this rank whose partition pass 1 selected the rank's key range from the replicated string (no records built or routed) */
   int64_t wide_deepen_rounds; /* wide mode: rounds of deepening by rank look-ups (windows repeated beyond the symbol compares; 0 = not needed) */
   /* What one rank costs on its OWN GPU, from a run in which the ranks may share one (loopback): */
-  double  work_ms;           /* host wall time this rank spent OUTSIDE collectives.  Loopback ranks that share a device hold a device
-                              * token while they work and hand it over inside collectives, so this is the rank's own work, not its
-                              * share of a time-sliced GPU */
+  double  work_ms;           /* host wall time this rank spent OUTSIDE collectives.  Loopback ranks that share a device can be made to
+                              * hold a device token while they work and hand it over inside collectives (DC3HIP_DEBUG=
+                              * global_device_token): then this is the rank's own work, not its share of a time-sliced GPU */
   double  link_ms;           /* model of the transport on xGMI: per collective, the most bytes this rank exchanges with ONE peer
                               * (a link) / 153 GB/s, summed over the build's collectives */
   int64_t collectives;       /* collectives of the build (device-side all-to-all / all-gather) */

@@ -84,9 +84,11 @@ struct LoopWorld {
   int P;
   std::mutex mu; std::condition_variable cv;
   int arrived = 0; uint64_t gen = 0; bool failed = false;
-  // ranks that share one device work one at a time (the token is handed over inside collectives): a rank's work_ms is then
-  // its own work.  Nothing depends on it but the timing; one_device = all ranks of the group sit on the same device.
-  std::mutex dev_mu; bool one_device = false;
+  // DC3HIP_DEBUG=global_device_token: ranks that share one device work one at a time (the token is handed over inside
+  // collectives) — a rank's work_ms is then its own work, the figure a prediction for P GPUs needs, at the price of the
+  // overlap the ranks' streams otherwise find on the shared GPU.  Nothing depends on it but the timing.
+  // one_device = all ranks of the group sit on the same device.
+  std::mutex dev_mu; bool one_device = false, token = false;
   struct Post { const void *send; const size_t *soff; const size_t *sbytes; size_t one; };
   std::vector<Post> post;
   explicit LoopWorld(int p) : P(p), post((size_t)p) {}
@@ -113,8 +115,8 @@ struct LoopWorld {
 struct LoopComm : GComm {
   std::shared_ptr<LoopWorld> w;
   double model_link_GBps = 0;        // DC3HIP_DEBUG=global_link_gbps=.. (tests): the link rate the policies see (0: ranks share a device)
-  void device_enter() override { if (w->one_device) w->dev_mu.lock(); GComm::device_enter(); }
-  void device_leave() override { const bool had = working; GComm::device_leave(); if (had && w->one_device) w->dev_mu.unlock(); }
+  void device_enter() override { if (w->token) w->dev_mu.lock(); GComm::device_enter(); }
+  void device_leave() override { const bool had = working; GComm::device_leave(); if (had && w->token) w->dev_mu.unlock(); }
   double link_GBps() const override { return model_link_GBps > 0 ? model_link_GBps : (w->one_device ? 0.0 : kXgmiLinkGBps); }
   const char *name() const override { return "loopback (in-process, hipMemcpyAsync; peer copies between devices)"; }
   void abort_all() override { w->fail(); }
@@ -2194,6 +2196,7 @@ int32_t dc3hip_global_loopback_create(dc3hip_gctx **ranks, int32_t P, int32_t de
     gctx_env(G);
   }
   world->one_device = device != DC3HIP_DEVICE_SPREAD || ndev == 1;
+  world->token = world->one_device && dbg_on("global_device_token");
   for (int r = 0; r < P; r++) { ranks[r] = made[(size_t)r]; made[(size_t)r]->group = made; }
   return E_OK;
 }

@@ -510,17 +510,6 @@ static int ssort(dc3hip_ctx *c, Rec *a, Rec *b, u32 n, u32 kbits, Rec **result, 
     HIPC(hipMemcpyAsync(c->h_words + 20, plan, kMsdW_COUNT * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
   }
   HIPC(hipStreamSynchronize(c->stream));
-  if (c->level_report && sizeof(Rec) == 16) {
-    // (tuning aid, DC3HIP_LEVEL_PHASES=1: how many sub-buckets lie inside ONE value of the key's top 32 / top 48 bits — the
-    //  share a local order on 64-bit keys could take)
-    void *fp = nullptr;
-    RC(stage_d2h(c, fine, (size_t)n2 * sizeof(SsVal), &fp));
-    const SsVal *f = static_cast<const SsVal *>(fp);
-    u64 same32 = 0, same48 = 0;
-    for (u32 i = 1; i + 1 < n2; i++) { if ((f[i - 1].hi >> 32) == (f[i].hi >> 32)) same32++; if ((f[i - 1].hi >> 16) == (f[i].hi >> 16)) same48++; }
-    std::fprintf(stderr, "dc3hip ssort n=%u sub-buckets=%u: %.1f %% inside one top-32-bit value of the key, %.1f %% inside one top-48-bit value\n", n, n2,
-                 100.0 * (double)same32 / (double)std::max<u32>(1, n2 - 2), 100.0 * (double)same48 / (double)std::max<u32>(1, n2 - 2));
-  }
   const u32 maxsub = c->h_words[20 + kMsdW_MAXSUB];
   c->stats.ssort_max_subbucket = maxsub;
   if (maxsub > kSsCap) { c->stats.ssort_fallbacks++; arena_release(c, mk); return E_OK; }     // (a is still the input)

@@ -372,7 +372,7 @@ def test_selecting_partition_pass_of_the_global_orderings(ss, oracle):
     # select up to 4 ranks and route beyond — same array either way — and the build says what P GPUs would take
     want = want_sa(oracle, rnd)
     for link, P, selects in (("0", 8, True), ("153", 2, True), ("153", 4, True), ("153", 5, False), ("153", 8, False), ("25", 8, True)):
-        with env(DC3HIP_MSD_MIN=4096, DC3HIP_GLOBAL_LINK_GBPS=link):
+        with env(DC3HIP_MSD_MIN=4096, DC3HIP_GLOBAL_LINK_GBPS=link, DC3HIP_GLOBAL_DEVICE_TOKEN=1):
             with ss.LoopbackGroup(P, len(rnd)) as g:
                 g.set_text(rnd)
                 g.build()

@@ -1,3 +1,6 @@
 mkdir -p gpurun_out
-timeout 120 stringsearch_amd/sa_bench bench gen:random:16m:2 --global-ranks 4 2>&1 | tail -7
-DC3HIP_NO_TEXT_SHORTCUT=1 timeout 120 python3 tools/one_build.py 268435456:0 --builds 2 | cut -c1-200
+for v in "" "p1_blocks=64" "p1_blocks=128" "p1_blocks=256" "p1_blocks=512" "p1_blocks=2048"; do
+  echo "== $v"
+  DC3HIP_DEBUG=$v timeout 200 python3 tools/one_build.py 1073741824:0:2 --builds 4 --check | python3 -c "
+import json,sys; d=json.loads(sys.stdin.read()); print(d['build_ms'], d['sufcheck'], {k:v for k,v in d['phase_ms'].items()})"
+done
