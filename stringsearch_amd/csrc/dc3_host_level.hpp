@@ -34,6 +34,7 @@ static int trace_sum(dc3hip_ctx *c, int which, int depth, const void *arr, u32 n
 // COMPACT tuples (TupC, 12 bytes).  Level 0 (bytes) moves 8-byte records through the two partition passes and reads the
 // first symbol off a table of cumulative counts; deeper levels whose symbols fit 16 bits move 12-byte records.
 // *done = false when the level is too small or the arena too short for the two record arrays (the caller gathers).
+static inline u32 nb_of(u32 m02) { return ((m02 - 1) >> kTupSh1) + 1; }
 template <class Sym, class Out, bool kDerive>
 static int scatter_tuples_run(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, const u32 *rank12, const u32 *sa12, const Chunking &ckc,
                               TupC *t12, u32 *table0, bool *done) {
@@ -41,12 +42,16 @@ static int scatter_tuples_run(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, cons
   *done = false;
   // (level 0, 8-byte words: pass 1 in tiles of 6144 slots on 1024 threads, k_tup8_part1, unless DC3HIP_TUP_BIGTILE=0)
   const bool big = kDerive && c->tup_bigtile;
+  // one cursor per bucket at its analytic base (k_tup_cur_init): level 0's 8-byte records only — the 12-byte records of the
+  // deeper levels lost 1.4 ms per 477 M without the split between the XCD groups (measured, round 5)
+  const bool analytic = kDerive && !c->tup_counted;
+  const u32 gstr = analytic ? 0u : nb_of(m02);
   const u32 tile1 = big ? (u32)kTup8Tile : (u32)kTupTile;
   const u32 ntiles = (m02 + tile1 - 1) / tile1;
   const u32 tpc = std::max<u32>(1, (ntiles + 2047) / 2048);
   const u32 cpg = ((ntiles + 7) / 8 + tpc - 1) / tpc, cpx = cpg * tpc;
   const u32 chunk = tpc * tile1, nchunks = (m02 + chunk - 1) / chunk;
-  const u32 nb = ((m02 - 1) >> kTupSh1) + 1;                     // buckets of 2^22 destinations (<= 1024)
+  const u32 nb = nb_of(m02);                                     // buckets of 2^22 destinations (<= 1024)
   if (c->arena_bytes - c->arena_off < (size_t)m02 * 2 * sizeof(Rec) + (size_t)1024 * nchunks * 4 + ((size_t)nb << 11) + (16u << 20)) return E_OK;
   static std::atomic<bool> attr_set[16];
   if (!attr_set[c->device & 15]) {
@@ -72,12 +77,17 @@ static int scatter_tuples_run(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, cons
   if constexpr (kDerive) { oa.rb = rbits; ob.rb = rbits; }
   {
     PhaseScope ps(c, DC3HIP_PH_TUPLES, m02);
-    hipLaunchKernelGGL(k_tup_hist1, dim3(nchunks), dim3(kBlock), 0, c->stream, rank12, m02, chunk, nchunks, table1);
-    KCHECK();
-    hipLaunchKernelGGL(k_msd_cnt1, dim3(nb), dim3(kBlock), 0, c->stream, (const u32 *)table1, nchunks, cpg, cntg);
-    KCHECK();
-    hipLaunchKernelGGL(k_msd_plan1, dim3(1), dim3(1024), 0, c->stream, (const u32 *)cntg, nb, m02, startg, cur1, bstart, tpre, tpreh, plan);
-    KCHECK();
+    if (analytic) {
+      hipLaunchKernelGGL(k_tup_cur_init, dim3((nb + 255) / 256), dim3(256), 0, c->stream, cur1, nb);
+      KCHECK();
+    } else {
+      hipLaunchKernelGGL(k_tup_hist1, dim3(nchunks), dim3(kBlock), 0, c->stream, rank12, m02, chunk, nchunks, table1);
+      KCHECK();
+      hipLaunchKernelGGL(k_msd_cnt1, dim3(nb), dim3(kBlock), 0, c->stream, (const u32 *)table1, nchunks, cpg, cntg);
+      KCHECK();
+      hipLaunchKernelGGL(k_msd_plan1, dim3(1), dim3(1024), 0, c->stream, (const u32 *)cntg, nb, m02, startg, cur1, bstart, tpre, tpreh, plan);
+      KCHECK();
+    }
     HIPC(hipMemsetAsync(cur2, 0, (size_t)nb * 512 * sizeof(u32), c->stream));
     HIPC(hipMemsetAsync(table0, 0, (size_t)256 * ckc.nchunks * sizeof(u32), c->stream));
     if (kDerive) {
@@ -97,12 +107,12 @@ static int scatter_tuples_run(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, cons
           HIPC(dc3_func_set_attribute(reinterpret_cast<const void *>(k_tup8_part1<Sym>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTup8PartSmem));
           attr8[c->device & 15] = true;
         }
-        hipLaunchKernelGGL((k_tup8_part1<Sym>), dim3(8 * cpx), dim3(kTup8NT), kTup8PartSmem, c->stream, S, m, m0, m02, rank12, cpx, ntiles, nb, cur1, oa);
+        hipLaunchKernelGGL((k_tup8_part1<Sym>), dim3(8 * cpx), dim3(kTup8NT), kTup8PartSmem, c->stream, S, m, m0, m02, rank12, cpx, ntiles, nb, cur1, oa, gstr);
       } else {
-        hipLaunchKernelGGL((k_tup_part1<Sym, Out>), dim3(8 * cpx), dim3(kTupNT), kTupPartSmem, c->stream, S, m, m0, m02, rank12, cpx, ntiles, nb, cur1, oa);
+        hipLaunchKernelGGL((k_tup_part1<Sym, Out>), dim3(8 * cpx), dim3(kTupNT), kTupPartSmem, c->stream, S, m, m0, m02, rank12, cpx, ntiles, nb, cur1, oa, gstr);
       }
     } else {
-      hipLaunchKernelGGL((k_tup_part1<Sym, Out>), dim3(8 * cpx), dim3(kTupNT), kTupPartSmem, c->stream, S, m, m0, m02, rank12, cpx, ntiles, nb, cur1, oa);
+      hipLaunchKernelGGL((k_tup_part1<Sym, Out>), dim3(8 * cpx), dim3(kTupNT), kTupPartSmem, c->stream, S, m, m0, m02, rank12, cpx, ntiles, nb, cur1, oa, gstr);
     }
     KCHECK();
   }

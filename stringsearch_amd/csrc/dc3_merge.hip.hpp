@@ -159,6 +159,14 @@ constexpr int kTupNT = 512, kTupIPT = 8, kTupTile = kTupNT * kTupIPT;           
 constexpr size_t kTupPartSmem = sizeof(u32) * (3 * kTupTile + 2 * 1024 + 64);
 struct TupRec { u32 dest, r, cc; };
 
+// gstride 0 (round 5): dest is a bijection onto [0, m02), so bucket d of pass 1 is exactly the region [d << 22, ...) and a
+// tile only reserves inside it — ONE cursor per bucket, starting at the bucket's base, shared by all blocks; no counting
+// pass (k_tup_hist1 / k_msd_cnt1 / k_msd_plan1: 1.4 ms per GiB of text, 4 bytes read per slot) and no split of a bucket
+// between the XCD groups: a tile's run in a bucket is ~36 records (290-430 bytes), long enough without it (as k_part_msd).
+__global__ void k_tup_cur_init(u32 *__restrict__ cur, u32 nb) {
+  const u32 d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d < nb) cur[d] = d << kTupSh1;
+}
 __global__ __launch_bounds__(kBlock) void k_tup_hist1(const u32 *__restrict__ rank12, u32 m02, u32 chunk, u32 nchunks,
                                                      u32 *__restrict__ table /*[1024][nchunks]*/) {
   __shared__ u32 hist[kWaves][1024];
@@ -262,8 +270,8 @@ struct TupOut8 {
 
 template <class Sym, class Out>
 __global__ __launch_bounds__(kTupNT) void k_tup_part1(Sym S, u32 m, u32 m0, u32 m02, const u32 *__restrict__ rank12, u32 cpx,
-                                                     u32 ntiles, u32 ndig, u32 *__restrict__ cursors /*[8][ndig]*/,
-                                                     Out out) {
+                                                     u32 ntiles, u32 ndig, u32 *__restrict__ cursors /*[8][ndig], or [ndig] with gstride 0*/,
+                                                     Out out, u32 gstride) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ uint16_t lcode[256];
   const u32 g = blockIdx.x % 8u, idx = blockIdx.x / 8u;
@@ -279,7 +287,7 @@ __global__ __launch_bounds__(kTupNT) void k_tup_part1(Sym S, u32 m, u32 m0, u32 
     dest[k] = rank12[s] - 1u;
     tup_payload(S, lcode, m, m0, dummy, rank12, s, rr[k], cc[k]);
   }
-  u32 *cur = cursors + (size_t)g * ndig;
+  u32 *cur = cursors + (size_t)g * gstride;
   tup_partition_tile(dest, rr, cc, nvalid, ndig, [](u32 d) { return d >> kTupSh1; },
                      [&](u32 d, u32 cnt) { return atomicAdd(&cur[d], cnt); }, out, smem);
 }
@@ -318,8 +326,8 @@ constexpr int kTup8NT = 1024, kTup8IPT = 6, kTup8Tile = kTup8NT * kTup8IPT;
 constexpr size_t kTup8PartSmem = sizeof(u64) * kTup8Tile + sizeof(uint16_t) * kTup8Tile + sizeof(u32) * (2 * 1024 + 64);
 template <class Sym>
 __global__ __launch_bounds__(kTup8NT, 8) void k_tup8_part1(Sym S, u32 m, u32 m0, u32 m02, const u32 *__restrict__ rank12, u32 cpx,
-                                                       u32 ntiles, u32 ndig, u32 *__restrict__ cursors /*[8][ndig]*/,
-                                                       TupOut8 out) {
+                                                       u32 ntiles, u32 ndig, u32 *__restrict__ cursors /*[8][ndig], or [ndig] with gstride 0*/,
+                                                       TupOut8 out, u32 gstride) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u64 *srec = reinterpret_cast<u64 *>(smem);
   uint16_t *sdig = reinterpret_cast<uint16_t *>(smem + sizeof(u64) * kTup8Tile);
@@ -350,7 +358,7 @@ __global__ __launch_bounds__(kTup8NT, 8) void k_tup8_part1(Sym S, u32 m, u32 m0,
   for (int k = 0; k < kTup8IPT; k++)
     if ((u32)(k * kTup8NT) + tid < nvalid) rk[k] = atomicAdd(&hist[dg[k]], 1u);
   __syncthreads();
-  u32 *cur = cursors + (size_t)g * ndig;
+  u32 *cur = cursors + (size_t)g * gstride;
   u32 cnt = 0;
   if (tid < ndig) { cnt = hist[tid]; if (cnt) gbase[tid] = atomicAdd(&cur[tid], cnt); }
   u32 tot;

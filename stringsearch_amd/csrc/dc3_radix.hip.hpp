@@ -146,15 +146,17 @@ __global__ __launch_bounds__(NW * 64) void k_rs_downsweep(Loader in, Sink out, u
   if (tid < NB) dbase[tid] = digit_base[tid] + table[(size_t)tid * nchunks + cid];
   u32 *mycnt = wcnt + w * NB;
   typedef RegRec<Rec> RR;
+  // (record types held as they are load straight into their register slot, as before round 5: going through a temporary
+  //  cost the 12-byte down-sweep 20 % — 66.5 -> 79.6 ms at 2^31 records — with the same register count)
+  constexpr bool kSameRec = std::is_same<typename RR::T, Rec>::value;
   typename RR::T r[IPT], rn[PF ? IPT : 1];
   bool okn[PF ? IPT : 1];
   if (PF) {
 #pragma unroll
     for (int k = 0; k < IPT; k++) {
       const u32 t = w * kWItems + k * 64 + lane;
-      Rec tmp_rec;
-      okn[PF ? k : 0] = (begin + t < end) && in.load(begin + t, tmp_rec);
-      rn[PF ? k : 0] = RR::pack(tmp_rec);
+      if constexpr (kSameRec) okn[PF ? k : 0] = (begin + t < end) && in.load(begin + t, rn[PF ? k : 0]);
+      else { Rec tmp_rec; okn[PF ? k : 0] = (begin + t < end) && in.load(begin + t, tmp_rec); rn[PF ? k : 0] = RR::pack(tmp_rec); }
     }
   }
 
@@ -169,17 +171,18 @@ __global__ __launch_bounds__(NW * 64) void k_rs_downsweep(Loader in, Sink out, u
     for (int k = 0; k < IPT; k++) {
       const u32 t = w * kWItems + k * 64 + lane;
       if (PF) { r[k] = rn[PF ? k : 0]; ok[k] = okn[PF ? k : 0]; }
+      else if constexpr (kSameRec) ok[k] = (t < nin) && in.load(tile + t, r[k]);
       else { Rec tmp_rec; ok[k] = (t < nin) && in.load(tile + t, tmp_rec); r[k] = RR::pack(tmp_rec); }
-      d[k] = ok[k] ? digit_of(RR::unpack(r[k]), dig) : 0u;
+      if constexpr (kSameRec) d[k] = ok[k] ? digit_of(r[k], dig) : 0u;
+      else d[k] = ok[k] ? digit_of(RR::unpack(r[k]), dig) : 0u;
     }
     if (PF) {
       const u32 nt = tile + kTile;
 #pragma unroll
       for (int k = 0; k < IPT; k++) {
         const u32 t = w * kWItems + k * 64 + lane;
-        Rec tmp_rec;
-        okn[PF ? k : 0] = (nt + t < end) && in.load(nt + t, tmp_rec);
-        rn[PF ? k : 0] = RR::pack(tmp_rec);
+        if constexpr (kSameRec) okn[PF ? k : 0] = (nt + t < end) && in.load(nt + t, rn[PF ? k : 0]);
+        else { Rec tmp_rec; okn[PF ? k : 0] = (nt + t < end) && in.load(nt + t, tmp_rec); rn[PF ? k : 0] = RR::pack(tmp_rec); }
       }
     }
     // stable ranking: items of one wave-round with equal digit are ordered by lane.  The lowest
@@ -231,7 +234,8 @@ __global__ __launch_bounds__(NW * 64) void k_rs_downsweep(Loader in, Sink out, u
     // reorder through LDS so every digit run is contiguous
 #pragma unroll
     for (int k = 0; k < IPT; k++) {
-      if (ok[k]) srec[texcl[d[k]] + wcnt[w * NB + d[k]] + rk[k]] = RR::unpack(r[k]);
+      if constexpr (kSameRec) { if (ok[k]) srec[texcl[d[k]] + wcnt[w * NB + d[k]] + rk[k]] = r[k]; }
+      else { if (ok[k]) srec[texcl[d[k]] + wcnt[w * NB + d[k]] + rk[k]] = RR::unpack(r[k]); }
     }
     __syncthreads();
     for (u32 q = tid; q < nkeep; q += kB) {
