@@ -454,8 +454,11 @@ def main():
         gn = min(n, 256 << 20)
         for gkind, gseed, gname in ((0, 2, "random"), (2, 3, "text")):
             with ss.Context(gn, device=local_rank) as c4:
-                c4.generate(gn, gseed, gkind); c4.build(); c4.build()
-                single_ms = c4.stats()["build_ms"]; single_chk = c4.checksum()
+                c4.generate(gn, gseed, gkind); c4.build()
+                sms = []
+                for _ in range(3):                       # (best of 3, as the loopback walls beside it)
+                    c4.build(); sms.append(c4.stats()["build_ms"])
+                single_ms = min(sms); single_chk = c4.checksum()
             for P in (2, 4, 8):
                 # (a) the ranks' streams share the GPU freely: wall = about the sum of all ranks' work (as in rounds 3-4)
                 with ss.LoopbackGroup(P, gn, device=local_rank) as g:
