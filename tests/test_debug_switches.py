@@ -1,0 +1,53 @@
+"""CPU: the one variable that carries every test / diagnosis switch of the library (DC3HIP_DEBUG) as the
+Python helpers compose it: nesting, restoring, old-style variables folded in, policy variables left alone — and that the
+library's own sources read no other switch from the environment (at most 12 getenv sites, the last verdict's bound)."""
+import glob
+import os
+import re
+
+import stringsearch_amd as ss
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _cur():
+    return dict(tok.partition("=")[::2] for tok in filter(None, os.environ.get("DC3HIP_DEBUG", "").split(",")))
+
+
+def test_debug_switches_compose_and_restore():
+    before = os.environ.get("DC3HIP_DEBUG")
+    with ss.debug_switches(no_text_shortcut=1, msd_min=4096):
+        assert _cur() == {**_cur(), "no_text_shortcut": "1", "msd_min": "4096"}
+        with ss.debug_switches(DC3HIP_NO_HYBRID=1, msd_min=8192):            # old-style names are accepted; inner values win
+            cur = _cur()
+            assert cur["no_hybrid"] == "1" and cur["msd_min"] == "8192" and cur["no_text_shortcut"] == "1"
+        cur = _cur()
+        assert "no_hybrid" not in cur and cur["msd_min"] == "4096"
+        ss.debug_set("text_order12", 0)
+        assert _cur()["text_order12"] == "0"                                  # "=0" must survive: it forbids, it does not force
+        ss.debug_unset("text_order12")
+    assert os.environ.get("DC3HIP_DEBUG") == before
+
+
+def test_old_style_variables_are_folded_in_and_policy_variables_are_not():
+    os.environ["DC3HIP_NO_DISCARD"] = "1"
+    os.environ["DC3HIP_GLOBAL_LOCAL_MAX"] = "64"
+    os.environ["DC3HIP_BENCH_BACKEND"] = "gloo"
+    try:
+        ss.adopt_legacy_env()
+        assert "DC3HIP_NO_DISCARD" not in os.environ and _cur().get("no_discard") == "1"
+        assert os.environ["DC3HIP_GLOBAL_LOCAL_MAX"] == "64" and os.environ["DC3HIP_BENCH_BACKEND"] == "gloo"
+    finally:
+        ss.debug_unset("no_discard")
+        os.environ.pop("DC3HIP_GLOBAL_LOCAL_MAX", None)
+        os.environ.pop("DC3HIP_BENCH_BACKEND", None)
+
+
+def test_the_library_reads_few_variables():
+    sites = []
+    for f in glob.glob(os.path.join(ROOT, "stringsearch_amd", "csrc", "*.hpp")) + glob.glob(os.path.join(ROOT, "stringsearch_amd", "csrc", "*.hip")):
+        for ln in open(f):
+            code = ln.split("//")[0]
+            sites += re.findall(r'getenv\("([A-Z0-9_]+)"\)', code)
+    assert len(sites) <= 12, sites
+    assert set(sites) <= set(ss.POLICY_VARS), set(sites) - set(ss.POLICY_VARS)

@@ -1304,3 +1304,14 @@ def test_real_text_corpus_bit_exact(ss, oracle):
     want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)
     assert np.array_equal(got, want)
     assert st["levels"] >= 8 and st["text_sort_state"] == 0, st["level_sorted"]
+
+
+def test_hip_runtime_versions_are_reported(ss):
+    """dc3hip_hip_versions: the HIP_VERSION the library was compiled against and hipRuntimeGetVersion() of the runtime the
+    process really runs on (tests import torch first, so that is the wheel's when the wheel ships its own) — the pair every
+    death of the round-4 crash hunt ran on is visible to a host program (profiles/r05_crash_hunt.md)."""
+    v = ss.hip_versions()
+    cmaj, cmin = (int(x) for x in v["compiled"].split(".")[:2])
+    rmaj, rmin = (int(x) for x in v["runtime"].split(".")[:2])
+    assert cmaj >= 6 and rmaj >= 6, v
+    assert v["match"] == ((cmaj, cmin) == (rmaj, rmin)), v
