@@ -91,6 +91,7 @@ struct dc3hip_ctx {
   bool ssort_rec12 = false;    // DC3HIP_SSORT_REC12=1: the splitter ordering also for keys of at most 64 bits (tests)
   bool no_pack_count = false;  // DC3HIP_NO_PACK_COUNT=1: the wide-window records are packed by their own kernel, then counted
   bool ssort_verify = false;   // DC3HIP_SSORT_VERIFY=1 (tests): every splitter ordering checks its passes (record checksums, cursors, order); a mismatch fails the build
+  bool no_merge_keys64 = false; // DC3HIP_DEBUG=no_merge_keys64: the merge compares tuple fields (16-byte LDS image) also where 64-bit keys would do
   bool tup_counted = false;    // DC3HIP_DEBUG=tup_counted: the tuple scatter's pass 1 counts its buckets per XCD group first (the round-4 form)
   bool no_fuse_names = false;  // DC3HIP_NO_FUSE_NAMES=1: names / final slots are written as pairs first (k_name_assign, k_final_assign)
   bool no_ssort = false;       // DC3HIP_NO_SSORT=1: the straight orderings always run the stable LSD passes (no splitter ordering)

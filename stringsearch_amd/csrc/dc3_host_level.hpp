@@ -2,11 +2,20 @@
 // Host side of libdc3hip (single translation unit: included by dc3hip.hip in this order; everything here is static).
 #pragma once
 
+// keys64: compact tuples whose symbols fit 15 bits (the caller knows K): the 64-bit-key image of k_merge
 template <int NT, int VT, class TA, class TB>
 static int launch_merge(dc3hip_ctx *c, u32 ntiles, const TA *A, u32 nA, const TB *B, u32 nB, const u32 *part,
-                        u32 *out_sa, Rec8 *out_pairs, u32 rank_base = 0) {
-  auto kern = k_merge<NT, VT, TA, TB>;
+                        u32 *out_sa, Rec8 *out_pairs, u32 rank_base = 0, bool keys64 = false) {
   const size_t smem = MergeSmem<NT, VT>::kBytes;
+  if constexpr (std::is_same<TA, TupC>::value) {
+    if (keys64) {
+      auto kern = k_merge<NT, VT, TA, TB, true>;
+      HIPC(dc3_func_set_attribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      hipLaunchKernelGGL(kern, dim3(ntiles), dim3(NT), smem, c->stream, A, nA, B, nB, part, out_sa, out_pairs, rank_base);
+      return E_OK;
+    }
+  }
+  auto kern = k_merge<NT, VT, TA, TB, false>;
   HIPC(dc3_func_set_attribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipLaunchKernelGGL(kern, dim3(ntiles), dim3(NT), smem, c->stream, A, nA, B, nB, part, out_sa, out_pairs, rank_base);
   return E_OK;
@@ -177,7 +186,7 @@ static int build_gather_tuples(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u64
 
 template <int kMergeNT, int kMergeVT, class TA, class TB>
 static int merge_lists_shape(dc3hip_ctx *c, const TA *A, u32 nA, const TB *B, u32 nB, u32 *out_sa, Rec8 *out_pairs,
-                             u32 rank_base) {
+                             u32 rank_base, bool keys64) {
   const u32 total = nA + nB;
   if (total == 0) return E_OK;
   const u32 tile = (u32)kMergeNT * kMergeVT;
@@ -198,7 +207,7 @@ static int merge_lists_shape(dc3hip_ctx *c, const TA *A, u32 nA, const TB *B, u3
     hipLaunchKernelGGL((k_merge_partition<TA, TB>), dim3((ntiles + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, A, nA, B, nB,
                        ntiles, tile, (const u32 *)coarse, kRatio, part);
     KCHECK();
-    RC((launch_merge<kMergeNT, kMergeVT, TA, TB>(c, ntiles, A, nA, B, nB, part, out_sa, out_pairs, rank_base)));
+    RC((launch_merge<kMergeNT, kMergeVT, TA, TB>(c, ntiles, A, nA, B, nB, part, out_sa, out_pairs, rank_base, keys64)));
     KCHECK();
   }
   arena_release(c, mk);
@@ -208,10 +217,10 @@ static int merge_lists_shape(dc3hip_ctx *c, const TA *A, u32 nA, const TB *B, u3
 // out_sa[0 .. nA+nB) (and, when out_pairs != nullptr, the (pos, rank_base + k + 1) pairs of the rank inversion).
 template <class TA, class TB>
 static int merge_lists(dc3hip_ctx *c, const TA *A, u32 nA, const TB *B, u32 nB, u32 *out_sa, Rec8 *out_pairs,
-                       u32 rank_base) {
+                       u32 rank_base, bool keys64 = false) {
   // 1024 threads x 2 outputs: re-measured in round 4 on the compact tuples against 512 x 4, 1024 x 4, 256 x 8, 512 x 8
   // (merge of 1.07 G suffixes: 6.2 / 7.0 / 8.0 / 10.2 / 10.7 ms, profiles/r04g_lab_shapes.jsonl)
-  return merge_lists_shape<1024, 2, TA, TB>(c, A, nA, B, nB, out_sa, out_pairs, rank_base);
+  return merge_lists_shape<1024, 2, TA, TB>(c, A, nA, B, nB, out_sa, out_pairs, rank_base, keys64 && !c->no_merge_keys64);
 }
 
 // Steps 2 + 3 of a level (lib.rs:118-192) on compact tuples: sample tuples scattered into SA12 order (TupC), mod-0
@@ -251,7 +260,7 @@ static int unwind_compact(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m1, u32 m02, 
       RC(arena_alloc(c, (size_t)m, &pa));
       RC(arena_alloc(c, (size_t)m, &pb));
     }
-    RC(merge_lists(c, t12 + dskip, m02 - dskip, zs, m0, out_sa, pa, 0u));
+    RC(merge_lists(c, t12 + dskip, m02 - dskip, zs, m0, out_sa, pa, 0u, K < 32768));     // (symbols of 15 bits: 64-bit merge keys)
     if (out_sa) RC(trace_sum(c, TR_SA, depth, out_sa, m, 0, m0));
     if (out_rank) RC(inverse_permute(c, pa, pb, m, out_rank, DC3HIP_PH_RANKS));
   }

@@ -538,35 +538,81 @@ __global__ __launch_bounds__(kBlock) void k_merge_partition(const TA *__restrict
 template <int NT, int VT>
 struct MergeSmem { static constexpr size_t kBytes = (16 + 16 + 4) * (size_t)(NT * VT) + 64; };
 
-template <int NT, int VT, class TA, class TB>
+// kKeys64 (compact tuples whose symbols fit 15 bits: level 0, and level 1 of texts): the tile's LDS image holds ONE 64-bit
+// comparison key per sample — (c0, r) for a mod-1 sample, bit 63 set; (c0, c1, r) for a mod-2 sample — and BOTH keys of a
+// mod-0 tuple, (c0, r1) and (c0, c1, r2), side by side: a comparison is two ds_read_b64 and one 64-bit compare instead of two
+// ds_read_b128, a position mod 3 and leq2 / leq3 field by field (the kernel was bound by vector instructions: 65 % of the
+// SIMD time at 1024 x 2, profiles/r05a_pmc_text SQ counters).
+__device__ __forceinline__ u64 merge_key_a(u32 pos, u32 r, u32 c0, u32 cx) {
+  return is_mod1(pos) ? ((((u64)c0 << 32) | r) | (1ull << 63)) : (((u64)c0 << 47) | ((u64)cx << 32) | r);
+}
+template <int NT, int VT, class TA, class TB, bool kKeys64 = false>
 __global__ __launch_bounds__(NT) void k_merge(const TA *__restrict__ A, u32 nA, const TB *__restrict__ B, u32 nB,
                                              const u32 *__restrict__ part, u32 *__restrict__ out_sa,
                                              Rec8 *__restrict__ out_pairs, u32 rank_base) {
   constexpr u32 kTile = NT * VT;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  u32x4 *sa = reinterpret_cast<u32x4 *>(smem);
-  u32x4 *sbk = reinterpret_cast<u32x4 *>(smem + 16 * kTile);
-  u32 *sbpos = reinterpret_cast<u32 *>(smem + 32 * kTile);
   const u32 total = nA + nB;
   const u32 d0 = blockIdx.x * kTile;
   const u32 d1 = min(d0 + kTile, total);
   const u32 a0 = part[blockIdx.x], a1 = part[blockIdx.x + 1];
   const u32 b0 = d0 - a0, b1 = d1 - a1;
   const u32 na = a1 - a0, nb = b1 - b0;
+  const u32 dl = min(threadIdx.x * (u32)VT, na + nb);
+  u32 outp[VT];
+  if constexpr (kKeys64) {
+    u64 *sk = reinterpret_cast<u64 *>(smem);                         // [kTile]     sample keys
+    u64 *sb = reinterpret_cast<u64 *>(smem + 8 * kTile);             // [kTile][2]  mod-0 keys: against a mod-1 / a mod-2 sample
+    u32 *spos = reinterpret_cast<u32 *>(smem + 24 * kTile);          // [kTile]
+    u32 *sbpos = reinterpret_cast<u32 *>(smem + 28 * kTile);         // [kTile]
+    for (u32 i = threadIdx.x; i < na; i += NT) {
+      const u32x4 a = tupa_words(A[a0 + i]);
+      sk[i] = merge_key_a(a.x, a.y, a.z, a.w); spos[i] = a.x;
+    }
+    for (u32 i = threadIdx.x; i < nb; i += NT) {
+      const TB z = B[b0 + i];
+      const u32x4 k = tupb_key(z);
+      sb[2 * i] = ((u64)k.x << 32) | k.z; sb[2 * i + 1] = ((u64)k.x << 47) | ((u64)k.y << 32) | k.w;
+      sbpos[i] = z.pos;
+    }
+    __syncthreads();
+    auto before = [&](u32 i, u32 j) -> bool {                        // sample i of the tile before mod-0 suffix j?
+      const u64 ks = sk[i];
+      const u64 kb = sb[2 * j + ((ks >> 63) ? 0u : 1u)];
+      return (ks & ~(1ull << 63)) <= kb;
+    };
+    u32 lo = dl > nb ? dl - nb : 0u, hi = min(dl, na);
+    while (lo < hi) {
+      const u32 mid = lo + ((hi - lo) >> 1);
+      if (before(mid, dl - 1 - mid)) lo = mid + 1; else hi = mid;
+    }
+    u32 ai = lo, bi = dl - lo;
+#pragma unroll
+    for (int v = 0; v < VT; v++) {
+      const u32 k = dl + v;
+      outp[v] = 0;
+      if (k < na + nb) {
+        const bool takeA = (bi >= nb) || (ai < na && before(ai, bi));
+        outp[v] = takeA ? spos[ai] : sbpos[bi];
+        ai += takeA ? 1u : 0u; bi += takeA ? 0u : 1u;
+      }
+    }
+  } else {
+  u32x4 *sa = reinterpret_cast<u32x4 *>(smem);
+  u32x4 *sbk = reinterpret_cast<u32x4 *>(smem + 16 * kTile);
+  u32 *sbpos = reinterpret_cast<u32 *>(smem + 32 * kTile);
   for (u32 i = threadIdx.x; i < na; i += NT) sa[i] = tupa_words(A[a0 + i]);
   for (u32 i = threadIdx.x; i < nb; i += NT) {
     const TB z = B[b0 + i];
     sbk[i] = tupb_key(z); sbpos[i] = z.pos;
   }
   __syncthreads();
-  const u32 dl = min(threadIdx.x * (u32)VT, na + nb);
   u32 lo = dl > nb ? dl - nb : 0u, hi = min(dl, na);
   while (lo < hi) {
     const u32 mid = lo + ((hi - lo) >> 1);     // (lo + hi) would overflow u32 beyond 2^31 samples
     if (sample_before4(sa[mid], sbk[dl - 1 - mid])) lo = mid + 1; else hi = mid;
   }
   u32 ai = lo, bi = dl - lo;
-  u32 outp[VT];
 #pragma unroll
   for (int v = 0; v < VT; v++) {
     const u32 k = dl + v;
@@ -576,6 +622,7 @@ __global__ __launch_bounds__(NT) void k_merge(const TA *__restrict__ A, u32 nA, 
       outp[v] = takeA ? sa[ai].x : sbpos[bi];
       ai += takeA ? 1u : 0u; bi += takeA ? 0u : 1u;
     }
+  }
   }
   __syncthreads();                       // inputs are dead: reuse the front of LDS as the output stage
   u32 *so = reinterpret_cast<u32 *>(smem);
