@@ -421,7 +421,7 @@ static int ssort(dc3hip_ctx *c, Rec *a, Rec *b, u32 n, u32 kbits, Rec **result, 
   constexpr int IPT = SsCfg<Rec>::IPT;
   constexpr u32 tile = (u32)kSsNT * IPT, htile = tile * kSsHistTiles;
   constexpr int kLocNT = 1024, kLocIPT = (int)(kSsCap / kLocNT);
-  constexpr size_t part_smem = ss_part_smem<Rec>(), loc_smem = sizeof(Rec) * kSsCap + kSsCap;
+  constexpr size_t part_smem = ss_part_smem<Rec>(), loc_smem = sizeof(Rec) * (kSsCap + kSsLocPad) + kSsCap;
   static std::atomic<bool> attr_set[16];
   if (!attr_set[c->device & 15]) {
     HIPC(dc3_func_set_attribute(reinterpret_cast<const void *>(k_ss_part<Rec, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_smem));

@@ -29,13 +29,38 @@ namespace dc3 {
 
 struct __attribute__((aligned(16))) SsVal { u64 hi, lo; };
 __device__ __forceinline__ SsVal ss_val(const Rec12 &r) { SsVal v; v.hi = ((u64)r.k1 << 32) | r.k0; v.lo = (u64)r.pos; return v; }
+template <class Rec> __device__ __forceinline__ Rec ss_max_rec();
+template <> __device__ __forceinline__ Rec12 ss_max_rec<Rec12>() { Rec12 r; r.k0 = r.k1 = r.pos = ~0u; return r; }
+template <> __device__ __forceinline__ Rec16 ss_max_rec<Rec16>() { Rec16 r; r.k0 = r.k1 = r.k2 = r.pos = ~0u; return r; }
 __device__ __forceinline__ SsVal ss_val(const Rec16 &r) { SsVal v; v.hi = ((u64)r.k2 << 32) | r.k1; v.lo = ((u64)r.k0 << 32) | r.pos; return v; }
-__device__ __forceinline__ bool ss_le(const SsVal &a, const SsVal &b) { return a.hi < b.hi || (a.hi == b.hi && a.lo <= b.lo); }
-__device__ __forceinline__ bool ss_lt(const SsVal &a, const SsVal &b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }
+// a < b is the borrow out of the 128-bit difference a - b: four subtract-with-borrow instructions on the 32-bit words.
+// (Written as a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo) it compiles to three 64-bit compares, two mask operations and
+// two moves — the halves of lo, k0 and pos, are not neighbours in a Rec16 — and the compiler folds __builtin_subc chains
+// back into that form: hence the assembly.  The ordering kernels are bound by exactly these instructions.)
+#define DC3_SS_BORROW(A, B)                                                                                              \
+  "v_sub_co_u32 %[t], vcc, %[" #A "0], %[" #B "0]\n\tv_subb_co_u32 %[t], vcc, %[" #A "1], %[" #B "1], vcc\n\t"            \
+  "v_subb_co_u32 %[t], vcc, %[" #A "2], %[" #B "2], vcc\n\tv_subb_co_u32 %[t], vcc, %[" #A "3], %[" #B "3], vcc\n\t"
+#define DC3_SS_WORDS(a, b)                                                                                               \
+  [a0] "v"((u32)a.lo), [a1] "v"((u32)(a.lo >> 32)), [a2] "v"((u32)a.hi), [a3] "v"((u32)(a.hi >> 32)), [b0] "v"((u32)b.lo),  \
+      [b1] "v"((u32)(b.lo >> 32)), [b2] "v"((u32)b.hi), [b3] "v"((u32)(b.hi >> 32))
+// acc += (a < b)
+__device__ __forceinline__ void ss_acc_lt(u32 &acc, const SsVal &a, const SsVal &b) {
+  u32 t;
+  asm(DC3_SS_BORROW(a, b) "v_addc_co_u32 %[acc], vcc, 0, %[acc], vcc" : [t] "=&v"(t), [acc] "+v"(acc) : DC3_SS_WORDS(a, b) : "vcc");
+}
+// s <= x ? yes : no      (s <= x is "no borrow out of x - s")
+__device__ __forceinline__ u32 ss_sel_le(const SsVal &s, const SsVal &x, u32 yes, u32 no) {
+  u32 t, r;
+  asm(DC3_SS_BORROW(b, a) "v_cndmask_b32 %[r], %[yes], %[no], vcc" : [t] "=&v"(t), [r] "=v"(r) : DC3_SS_WORDS(s, x), [yes] "v"(yes), [no] "v"(no) : "vcc");
+  return r;
+}
+__device__ __forceinline__ bool ss_lt(const SsVal &a, const SsVal &b) { u32 c = 0; ss_acc_lt(c, a, b); return c != 0u; }
+__device__ __forceinline__ bool ss_le(const SsVal &a, const SsVal &b) { u32 c = 0; ss_acc_lt(c, b, a); return c == 0u; }
 
 constexpr int kSsNT = 1024;                    // threads of a partition block
 constexpr u32 kSsGroups = 8;                   // XCDs (as kMsdGroups)
 constexpr u32 kSsMaxDig = 1024;                // coarse buckets, and the most fine splitters + 1 per bucket
+constexpr u32 kSsLocPad = 4;                   // records of all ones behind a sub-bucket's LDS image (k_ss_local's last step)
 constexpr u32 kSsHistTiles = 8;                // partition tiles per block of k_ss_hist2
 template <class Rec> struct SsCfg;
 template <> struct SsCfg<Rec12> { static constexpr int IPT = 8; };      // 8192-record tiles (96 KB)
@@ -44,40 +69,42 @@ template <class Rec> constexpr size_t ss_part_smem() {
   return sizeof(Rec) * kSsNT * SsCfg<Rec>::IPT + sizeof(u32) * (2 * kSsMaxDig + 64) + sizeof(uint16_t) * kSsNT * SsCfg<Rec>::IPT;
 }
 
-// splitters[0 .. ns) ascending in LDS: how many are <= x
-__device__ __forceinline__ u32 ss_count_le(const SsVal *spl, u32 ns, const SsVal &x) {
-  u32 base = 0, len = ns;
-  while (len > 0) {
-    const u32 half = len >> 1, mid = base + half;
-    const SsVal s = spl[mid];
-    const bool le = ss_le(s, x);
-    base = le ? mid + 1 : base;
-    len = le ? len - half - 1 : half;
-  }
-  return base;
+// Splitter tables in LDS are search trees in breadth-first order: (1 << steps) - 1 entries (padded with +inf), the root
+// at slot 0, the children of slot j - 1 at slots 2j - 1 and 2j.  ss_tree_slot(t) is the slot of the t-th smallest entry.
+// (In ascending order the probes of one step of a binary search lie a power of two of 16-byte entries apart — from the
+// second step to the seventh every lane's probe falls into the same four LDS banks, and the counters showed three of
+// four LDS cycles of k_ss_hist2 as bank conflicts; in breadth-first order the entries one step can probe are neighbours.)
+__device__ __forceinline__ u32 ss_tree_slot(u32 t, u32 steps) {
+  const u32 z = (u32)__builtin_ctz(t + 1u);
+  return (1u << (steps - 1u - z)) + ((t + 1u) >> (z + 1u)) - 1u;
 }
-
-// The same count for K values at once, the K searches advancing in lockstep (K independent LDS reads in flight per
-// step instead of one dependent chain per value).  spl holds (1 << steps) - 1 entries, padded with +inf.
+// how many of the table's entries are <= x, for K values at once, the K searches advancing in lockstep (K independent
+// LDS reads in flight per step instead of one dependent chain per value).  x, pos: K registers each.
 template <int K>
-__device__ __forceinline__ void ss_count_le_multi(const SsVal *spl, u32 steps, const SsVal (&x)[K], u32 (&pos)[K]) {
+__device__ __forceinline__ void ss_count_le_n(const SsVal *spl, u32 steps, const SsVal *x, u32 *pos) {
 #pragma unroll
-  for (int k = 0; k < K; k++) pos[k] = 0;
-  for (u32 half = 1u << (steps - 1); half; half >>= 1) {
+  for (int k = 0; k < K; k++) pos[k] = 1;                  // node numbers (slot + 1)
+  for (u32 l = 0; l < steps; l++) {
     SsVal s[K];
 #pragma unroll
-    for (int k = 0; k < K; k++) s[k] = spl[pos[k] + half - 1];
+    for (int k = 0; k < K; k++) s[k] = spl[pos[k] - 1u];
 #pragma unroll
-    for (int k = 0; k < K; k++) pos[k] += ss_le(s[k], x[k]) ? half : 0u;
+    for (int k = 0; k < K; k++) pos[k] = ss_sel_le(s[k], x[k], 2u * pos[k] + 1u, 2u * pos[k]);
   }
+#pragma unroll
+  for (int k = 0; k < K; k++) pos[k] -= 1u << steps;
 }
-// stage ns splitters from global memory into spl[0 .. (1 << steps) - 1), +inf behind them; blockDim.x >= (1 << steps) - 1
+template <int K>
+__device__ __forceinline__ void ss_count_le_multi(const SsVal *spl, u32 steps, const SsVal (&x)[K], u32 (&pos)[K]) {
+  ss_count_le_n<K>(spl, steps, x, pos);
+}
+// stage ns ascending splitters from global memory as such a table; blockDim.x >= (1 << steps) - 1
 __device__ __forceinline__ void ss_stage(SsVal *spl, const SsVal *__restrict__ g, u32 ns, u32 steps) {
   const u32 t = threadIdx.x;
   if (t < (1u << steps) - 1u) {
     SsVal v;
     if (t < ns) v = g[t]; else { v.hi = ~0ull; v.lo = ~0ull; }
-    spl[t] = v;
+    spl[ss_tree_slot(t, steps)] = v;
   }
 }
 __device__ __forceinline__ u32 ss_steps(u32 ns) { u32 s = 1; while (((1u << s) - 1u) < ns) s++; return s; }   // ns >= 1
@@ -412,7 +439,7 @@ __global__ __launch_bounds__(NT) void k_ss_local(const Rec *__restrict__ in, con
   static_assert(NT >= NSMAX && NT % NSMAX == 0, "threads share the candidate pairs");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Rec *A = reinterpret_cast<Rec *>(smem);                                   // CAP records
-  uint8_t *binid = reinterpret_cast<uint8_t *>(smem + sizeof(Rec) * CAP);   // bin of the record placed at A[q]
+  uint8_t *binid = reinterpret_cast<uint8_t *>(smem + sizeof(Rec) * (CAP + kSsLocPad));   // bin of the record placed at A[q]
   __shared__ SsVal cand[NSMAX], spl[NSMAX];
   __shared__ u32 crank[NSMAX], cnt[NSMAX], cex[NSMAX + 1];
   __shared__ u32 tmp[NT / 64];
@@ -435,7 +462,7 @@ __global__ __launch_bounds__(NT) void k_ss_local(const Rec *__restrict__ in, con
     if (tid < m) {
       const SsVal v = ss_val(r[0]);
       u32 less = 0;
-      for (u32 j = 0; j < m; j++) less += ss_lt(ss_val(A[j]), v) ? 1u : 0u;
+      for (u32 j = 0; j < m; j++) ss_acc_lt(less, ss_val(A[j]), v);
       out[begin + less] = r[0];
     }
     return;
@@ -444,25 +471,34 @@ __global__ __launch_bounds__(NT) void k_ss_local(const Rec *__restrict__ in, con
   if (tid < ns) cand[tid] = ss_val(A[(u32)(((u64)tid * m) / ns)]);
   __syncthreads();
   {
-    // thread t compares candidate t % (ns + 1) with its share of the others
-    const u32 ci = tid & ns, part = tid >> steps, parts = (u32)NT >> steps, span = (ns + parts) / parts;
-    if (ci < ns) {
-      const SsVal v = cand[ci];
-      const u32 j0 = part * span, j1 = min(ns, j0 + span);
-      u32 less = 0;
-      for (u32 j = j0; j < j1; j++) less += ss_lt(cand[j], v) ? 1u : 0u;
-      if (less) atomicAdd(&crank[ci], less);
-    }
+    // all pairs: thread t holds two candidates, c and c + (ns + 1) / 2, and compares them with its share of all of them
+    // (two per LDS read)
+    const u32 hs = steps - 1u, hn = (ns + 1u) >> 1, ci = tid & (hn - 1u), part = tid >> hs, parts = (u32)NT >> hs, span = (ns + parts - 1u) / parts;
+    const SsVal va = cand[ci], vb = cand[min(ci + hn, ns - 1u)];
+    const u32 j0 = min(ns, part * span), j1 = min(ns, j0 + span);
+    u32 la = 0, lb = 0;
+    for (u32 j = j0; j < j1; j++) { const SsVal w = cand[j]; ss_acc_lt(la, w, va); ss_acc_lt(lb, w, vb); }
+    if (la) atomicAdd(&crank[ci], la);
+    if (lb && ci + hn < ns) atomicAdd(&crank[ci + hn], lb);
   }
   __syncthreads();
-  if (tid < ns) spl[crank[tid]] = cand[tid];
+  if (tid < ns) spl[ss_tree_slot(crank[tid], steps)] = cand[tid];
   __syncthreads();
   u32 bin[IPT], rk[IPT];
   {
     SsVal v[IPT];
 #pragma unroll
     for (int k = 0; k < IPT; k++) v[k] = ss_val(r[k]);
-    ss_count_le_multi<IPT>(spl, steps, v, bin);                            // 0 .. ns
+    // 0 .. ns; a wave searches only for the rounds of the load in which it holds records (a sub-bucket has about 1400 of
+    // the 4096 the block has room for: the searches are LDS reads at scattered addresses, what this kernel is bound by)
+    static_assert(IPT == 4, "rounds of the search");
+#pragma unroll
+    for (int k = 0; k < IPT; k++) bin[k] = 0;
+    const u32 w0 = tid & ~63u;                              // the wave's first record of round 0
+    if (w0 + 3u * NT < m) ss_count_le_n<4>(spl, steps, v, bin);
+    else if (w0 + 2u * NT < m) ss_count_le_n<3>(spl, steps, v, bin);
+    else if (w0 + (u32)NT < m) ss_count_le_n<2>(spl, steps, v, bin);
+    else if (w0 < m) ss_count_le_n<1>(spl, steps, v, bin);
   }
 #pragma unroll
   for (int k = 0; k < IPT; k++) {
@@ -483,6 +519,7 @@ __global__ __launch_bounds__(NT) void k_ss_local(const Rec *__restrict__ in, con
     const u32 t = k * NT + tid;
     if (t < m) { const u32 q = cex[bin[k]] + rk[k]; A[q] = r[k]; binid[q] = (uint8_t)bin[k]; }
   }
+  if (tid < kSsLocPad) A[m + tid] = ss_max_rec<Rec>();
   __syncthreads();
   for (u32 q = tid; q < m; q += NT) {
     const Rec x = A[q];
@@ -490,13 +527,15 @@ __global__ __launch_bounds__(NT) void k_ss_local(const Rec *__restrict__ in, con
     const u32 bb = binid[q];
     const u32 lo = cex[bb], hi = cex[bb + 1];
     u32 less = 0;
-    // (4 independent reads per round: bins hold about 11 records — rounds of 8 read 16 for them, rounds of 4 read 12)
+    // 4 independent reads per round (bins hold about 11 records: rounds of 8 would read 16 for them, rounds of 4 read 12),
+    // and no bound inside the round: what follows the bin in LDS are the later bins — every record there is above the
+    // bin's upper boundary, so "smaller than mine" is false for it — and behind the last bin kSsLocPad records of all ones
     for (u32 j0 = lo; j0 < hi; j0 += 4) {
       SsVal w[4];
 #pragma unroll
-      for (int i = 0; i < 4; i++) w[i] = ss_val(A[min(j0 + (u32)i, hi - 1u)]);
+      for (int i = 0; i < 4; i++) w[i] = ss_val(A[j0 + (u32)i]);
 #pragma unroll
-      for (int i = 0; i < 4; i++) less += (j0 + (u32)i < hi && ss_lt(w[i], v)) ? 1u : 0u;
+      for (int i = 0; i < 4; i++) ss_acc_lt(less, w[i], v);
     }
     out[begin + lo + less] = x;
   }
