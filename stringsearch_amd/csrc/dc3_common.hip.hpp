@@ -73,10 +73,24 @@ struct SymU32 {
 __device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ u32 wave_id() { return threadIdx.x >> 6; }
 
+// v + (the value a DPP pattern brings from another lane, 0 where the pattern has no source lane or the row is masked out)
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ u32 dpp_add(u32 v) { return v + (u32)__builtin_amdgcn_update_dpp(0, (int)v, kCtrl, kRowMask, 0xf, false); }
+// inclusive prefix sums inside every row of 16 lanes (row_shr:1, 2, 4, 8)
+__device__ __forceinline__ u32 row_incl_scan(u32 v) {
+  v = dpp_add<0x111, 0xf>(v);
+  v = dpp_add<0x112, 0xf>(v);
+  v = dpp_add<0x114, 0xf>(v);
+  v = dpp_add<0x118, 0xf>(v);
+  return v;
+}
+// ... and across the wave: lane 15 of a row into the next row (rows 1 and 3), then lane 31 into rows 2 and 3.  Six data
+// parallel primitive adds in the VALU where __shfl_up makes six round trips through the LDS crossbar (ds_bpermute) with a
+// compare and a select each: the block scans were 14 of the 62 VALU instructions per word of the partition kernels.
 __device__ __forceinline__ u32 wave_incl_scan(u32 v) {
-  const u32 lane = lane_id();
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { u32 t = __shfl_up(v, o); if (lane >= (u32)o) v += t; }
+  v = row_incl_scan(v);
+  v = dpp_add<0x142, 0xa>(v);      // row_bcast:15
+  v = dpp_add<0x143, 0xc>(v);      // row_bcast:31
   return v;
 }
 __device__ __forceinline__ u32 wave_reduce_max(u32 v) {
@@ -89,17 +103,20 @@ __device__ __forceinline__ u32 wave_reduce(u32 v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
-// Exclusive scan of one value per thread over a block of NW waves; tmp needs NW words of LDS.
+// Exclusive scan of one value per thread over a block of NW <= 16 waves; tmp needs NW words of LDS.  Every wave scans the
+// NW wave totals itself (one row of lanes) and reads its own offset and the block's total out of that row.
 template <int NW>
 __device__ __forceinline__ u32 block_excl_scan(u32 v, u32 *tmp, u32 &total) {
+  static_assert(NW >= 1 && NW <= 16, "the wave totals fit one row of lanes");
   const u32 inc = wave_incl_scan(v);
   if (lane_id() == 63) tmp[wave_id()] = inc;
   __syncthreads();
-  u32 woff = 0, tot = 0;
-#pragma unroll
-  for (int i = 0; i < NW; i++) { u32 t = tmp[i]; if ((u32)i < wave_id()) woff += t; tot += t; }
+  const u32 t = lane_id() < (u32)NW ? tmp[lane_id()] : 0u;
+  const u32 p = row_incl_scan(t);
+  const u32 w = (u32)__builtin_amdgcn_readfirstlane((int)wave_id());
+  const u32 woff = (u32)__builtin_amdgcn_readlane((int)(p - t), (int)w);
+  total = (u32)__builtin_amdgcn_readlane((int)p, NW - 1);
   __syncthreads();
-  total = tot;
   return woff + inc - v;
 }
 
