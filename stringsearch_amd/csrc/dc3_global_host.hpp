@@ -644,6 +644,7 @@ struct MsdPass1KeysSel : MsdPass1Keys<KM> {
       HIPC(dc3_func_set_attribute(reinterpret_cast<const void *>(k_msd_part_keys<KM, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
       attr_set[c->device & 15] = true;
     }
+    if (this->strip && (this->hm.nbits + this->hm.pbits != 64 || g.d1 == 0)) { set_err("internal: a stripped image must fill the word"); return E_HIP; }
     if (this->strip)
       hipLaunchKernelGGL((k_msd_part_keys<KM, true, true>), dim3(kMsdGroups * g.cpx1), dim3(kMsdNW * 64), kMsdPartSmem, c->stream, this->km, this->hm,
                          this->P1, out, m, base, sh1, g.d1, g.cpx1, g.ntiles1, plan, cur1, nb1, c->d_xcdmon, sel);

@@ -217,6 +217,7 @@ struct MsdPass1Keys : MsdPass1 {
       HIPC(dc3_func_set_attribute(reinterpret_cast<const void *>(k_msd_part_keys<KM, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
       attr_set[c->device & 15] = true;
     }
+    if (strip && (hm.nbits + hm.pbits != 64 || g.d1 == 0)) { set_err("internal: a stripped image must fill the word"); return E_HIP; }
     if (strip)
       hipLaunchKernelGGL((k_msd_part_keys<KM, true>), dim3(kMsdGroups * g.cpx1), dim3(kMsdNW * 64), kMsdPartSmem, c->stream, km, hm, P1, out, n, base, sh1,
                          g.d1, g.cpx1, g.ntiles1, plan, cur1, nb1, c->d_xcdmon);
@@ -259,8 +260,10 @@ static int msd_sort(dc3hip_ctx *c, Rec8 *ha, Rec8 *hb, u32 n, const HiMap &hm, c
   if (p1 && !table) { set_err("internal: on-the-fly pass 1 without a digit table"); return E_HIP; }
   static std::atomic<bool> attr_set[16];
   if (!attr_set[c->device & 15]) {
-    HIPC(dc3_func_set_attribute(reinterpret_cast<const void *>(k_msd_part<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
-    HIPC(dc3_func_set_attribute(reinterpret_cast<const void *>(k_msd_part<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
+    HIPC(dc3_func_set_attribute(reinterpret_cast<const void *>(k_msd_part<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
+    HIPC(dc3_func_set_attribute(reinterpret_cast<const void *>(k_msd_part<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
+    HIPC(dc3_func_set_attribute(reinterpret_cast<const void *>(k_msd_part<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
+    HIPC(dc3_func_set_attribute(reinterpret_cast<const void *>(k_msd_part<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
     attr_set[c->device & 15] = true;
   }
   const u32 nb1 = 1u << g.d1, tb = g.d1 + g.d2, n2 = 1u << tb;
@@ -294,7 +297,9 @@ static int msd_sort(dc3hip_ctx *c, Rec8 *ha, Rec8 *hb, u32 n, const HiMap &hm, c
     if (p1) {
       RC(p1->launch(c, wb, n, base, sh1, g, nb1, plan, cur1));
     } else {
-      hipLaunchKernelGGL((k_msd_part<false>), dim3(kMsdGroups * g.cpx1), dim3(kMsdNW * 64), kMsdPartSmem, c->stream, (const u64 *)wa, wb, n,
+      // (base == 0 and the digit inside the word's upper half: the digit is one bit-field instruction, k_msd_part<.., kHi>)
+      auto kern = (base == 0 && sh1 >= 32) ? k_msd_part<false, true> : k_msd_part<false, false>;
+      hipLaunchKernelGGL(kern, dim3(kMsdGroups * g.cpx1), dim3(kMsdNW * 64), kMsdPartSmem, c->stream, (const u64 *)wa, wb, n,
                          base, sh1, g.d1, g.cpx1, g.ntiles1, (const u32 *)nullptr, (const u32 *)nullptr, nb1, (const u32 *)plan, cur1, nb1, c->d_xcdmon);
       KCHECK();
     }
@@ -327,7 +332,8 @@ static int msd_sort(dc3hip_ctx *c, Rec8 *ha, Rec8 *hb, u32 n, const HiMap &hm, c
     {
       PhaseScope ps(c, DC3HIP_PH_SORT8_DOWN, n, 5);
       const u32 grid2 = kMsdGroups * ((n / kMsdTile + nb1 + 1 + kMsdGroups - 1) / kMsdGroups);
-      hipLaunchKernelGGL((k_msd_part<true>), dim3(grid2), dim3(kMsdNW * 64), kMsdPartSmem, c->stream, (const u64 *)wb, wa, n, base, sh2, g.d2,
+      auto kern = (base == 0 && sh2 >= 32) ? k_msd_part<true, true> : k_msd_part<true, false>;
+      hipLaunchKernelGGL(kern, dim3(grid2), dim3(kMsdNW * 64), kMsdPartSmem, c->stream, (const u64 *)wb, wa, n, base, sh2, g.d2,
                          0u, 0u, (const u32 *)tpre, (const u32 *)bstart, nb1, (const u32 *)plan, cur2, n2, c->d_xcdmon);
       KCHECK();
     }

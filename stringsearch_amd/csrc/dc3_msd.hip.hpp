@@ -127,18 +127,32 @@ __device__ __forceinline__ u32 msd_find_bucket(const u32 *__restrict__ tpre, u32
 //   digit = word >> shift (the top d1 bits), cursors[g * ndig + digit].
 // kSeg = true (pass 2): the tiles are those of the bucket list (tpre / bstart: tile t lies inside one bucket b), group g
 //   owns tiles [g * cpx2, (g + 1) * cpx2), digit = (word >> shift) & mask, cursors[g * gstride + (b << dbits) + digit].
+// kHi (the host's choice: base == 0 and shift >= 32): the digit is a bit field of the word's upper half — one instruction
+//   instead of a 64-bit subtraction and a 64-bit shift, three times per word.
+// LDS: the two digit tables first — their reads take a constant offset from the digit's own address — the words behind
+//   them.  After the scan gbase[d] holds (start of the tile's run of d in the output) - (its start inside the tile), so
+//   the word at tile index q goes to gbase[d] + q.  A full tile (all but the last of a bucket) runs without the per-word
+//   guards.  These kernels are bound by instruction issue as much as by HBM (62 VALU instructions per word at first).
 // Not stable.
-template <bool kSeg>
+template <bool kHi>
+__device__ __forceinline__ u32 msd_digit(u64 x, u64 base, u32 shift, u32 mask) {
+  if (kHi) return ((u32)(x >> 32) >> (shift - 32u)) & mask;
+  return (u32)((x - base) >> shift) & mask;
+}
+struct MsdPartLds {
+  u32 *hist, *gbase, *tmp; u64 *srec;
+  __device__ __forceinline__ explicit MsdPartLds(unsigned char *smem)
+      : hist(reinterpret_cast<u32 *>(smem)), gbase(hist + kMsdMaxDig), tmp(gbase + kMsdMaxDig),
+        srec(reinterpret_cast<u64 *>(smem + sizeof(u32) * (2 * kMsdMaxDig + 64))) {}
+};
+template <bool kSeg, bool kHi>
 __global__ __launch_bounds__(kMsdNW * 64) void k_msd_part(const u64 *__restrict__ in, u64 *__restrict__ out, u32 n, u64 base, u32 shift,
                                                          u32 dbits, u32 cpx, u32 ntiles, const u32 *__restrict__ tpre,
                                                          const u32 *__restrict__ bstart, u32 nb1, const u32 *__restrict__ plan,
                                                          u32 *__restrict__ cursors, u32 gstride, u32 *__restrict__ xcdmon) {
   constexpr int NT = kMsdNW * 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  u64 *srec = reinterpret_cast<u64 *>(smem);
-  u32 *hist = reinterpret_cast<u32 *>(smem + sizeof(u64) * kMsdTile);   // [1024] counts -> tile-exclusive prefix
-  u32 *gbase = hist + kMsdMaxDig;                                        // [1024] global start of the tile's run
-  u32 *tmp = gbase + kMsdMaxDig;
+  const MsdPartLds L(smem);
   const u32 tid = threadIdx.x;
   const u32 ndig = 1u << dbits, mask = ndig - 1u;
   const u32 g = blockIdx.x % kMsdGroups, idx = blockIdx.x / kMsdGroups;
@@ -160,41 +174,50 @@ __global__ __launch_bounds__(kMsdNW * 64) void k_msd_part(const u64 *__restrict_
   }
   const u32 nvalid = end - begin;                  // >= 1
   xcd_note(xcdmon, g);
-  hist[tid] = 0;
+  L.hist[tid] = 0;
   __syncthreads();
-  u64 r[kMsdIPT];
-  u32 rk[kMsdIPT];
-  // (all loads issued back to back: the index is clamped instead of guarded, a guard would put a wait behind every load)
+  auto body = [&](auto full_tag) {
+    constexpr bool kFull = decltype(full_tag)::value;
+    u64 r[kMsdIPT];
+    u32 rk[kMsdIPT], dg[kMsdIPT];
+    // (all loads issued back to back: the index is clamped instead of guarded, a guard would put a wait behind every load)
 #pragma unroll
-  for (int k = 0; k < kMsdIPT; k++) r[k] = in[begin + min((u32)(k * NT) + tid, nvalid - 1u)];
+    for (int k = 0; k < kMsdIPT; k++) r[k] = in[begin + (kFull ? (u32)(k * NT) + tid : min((u32)(k * NT) + tid, nvalid - 1u))];
 #pragma unroll
-  for (int k = 0; k < kMsdIPT; k++) r[k] = msd_word(r[k]);
+    for (int k = 0; k < kMsdIPT; k++) { r[k] = msd_word(r[k]); dg[k] = msd_digit<kHi>(r[k], base, shift, mask); }
 #pragma unroll
-  for (int k = 0; k < kMsdIPT; k++) {
-    const u32 t = k * NT + tid;
-    if (t < nvalid) rk[k] = atomicAdd(&hist[(u32)((r[k] - base) >> shift) & mask], 1u);
-  }
-  __syncthreads();
-  u32 cnt = 0;
-  if (tid < ndig) {
-    cnt = hist[tid];
-    if (cnt) gbase[tid] = atomicAdd(&cur[tid], cnt);
-  }
-  u32 tot;
-  const u32 ex = block_excl_scan<kMsdNW>(cnt, tmp, tot);
-  hist[tid] = ex;
-  __syncthreads();
+    for (int k = 0; k < kMsdIPT; k++)
+      if (kFull || (u32)(k * NT) + tid < nvalid) rk[k] = atomicAdd(&L.hist[dg[k]], 1u);
+    __syncthreads();
+    u32 cnt = 0, gb = 0;
+    if (tid < ndig) {
+      cnt = L.hist[tid];
+      if (cnt) gb = atomicAdd(&cur[tid], cnt);
+    }
+    u32 tot;
+    const u32 ex = block_excl_scan<kMsdNW>(cnt, L.tmp, tot);
+    L.hist[tid] = ex;
+    L.gbase[tid] = gb - ex;
+    __syncthreads();
 #pragma unroll
-  for (int k = 0; k < kMsdIPT; k++) {
-    const u32 t = k * NT + tid;
-    if (t < nvalid) srec[hist[(u32)((r[k] - base) >> shift) & mask] + rk[k]] = r[k];
-  }
-  __syncthreads();
-  for (u32 q = tid; q < nvalid; q += NT) {
-    const u64 x = srec[q];
-    const u32 dd = (u32)((x - base) >> shift) & mask;
-    out[gbase[dd] + (q - hist[dd])] = msd_word(x);
-  }
+    for (int k = 0; k < kMsdIPT; k++)
+      if (kFull || (u32)(k * NT) + tid < nvalid) L.srec[L.hist[dg[k]] + rk[k]] = r[k];
+    __syncthreads();
+    if (kFull) {
+#pragma unroll
+      for (int k = 0; k < kMsdIPT; k++) {
+        const u32 q = (u32)(k * NT) + tid;
+        const u64 x = L.srec[q];
+        out[L.gbase[msd_digit<kHi>(x, base, shift, mask)] + q] = msd_word(x);
+      }
+    } else {
+      for (u32 q = tid; q < nvalid; q += NT) {
+        const u64 x = L.srec[q];
+        out[L.gbase[msd_digit<kHi>(x, base, shift, mask)] + q] = msd_word(x);
+      }
+    }
+  };
+  if (nvalid == (u32)kMsdTile) body(std::true_type{}); else body(std::false_type{});
 }
 
 // Pass 1 that makes its words on the fly: tile t = the positions [t * kMsdTile, ...) of the text / level, their words
@@ -259,10 +282,7 @@ __global__ __launch_bounds__(kMsdNW * 64, 8) void k_msd_part_keys(KM km, HiMap h
   static_assert(kMsdIPT == 8, "two rounds of 4 positions per thread");
   static_assert(kMsdTile == 8192 && kMsdMaxDig == 1024, "kStrip keeps (digit, index) in 10 + 13 bits");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  u64 *srec = reinterpret_cast<u64 *>(smem);
-  u32 *hist = reinterpret_cast<u32 *>(smem + sizeof(u64) * kMsdTile);
-  u32 *gbase = hist + kMsdMaxDig;
-  u32 *tmp = gbase + kMsdMaxDig;
+  const MsdPartLds L(smem);
   __shared__ uint16_t lcode[256];
   const u32 tid = threadIdx.x;
   const u32 ndig = 1u << dbits, mask = ndig - 1u;
@@ -274,61 +294,74 @@ __global__ __launch_bounds__(kMsdNW * 64, 8) void k_msd_part_keys(KM km, HiMap h
   const u32 nvalid = end - begin;
   xcd_note(xcdmon, g);
   km.stage(lcode);
-  hist[tid] = 0;
+  L.hist[tid] = 0;
   __syncthreads();
   const u32 pb = hm.pbits + (kStrip ? dbits : 0u);                 // position bits of the stored word
-  const u32 rbits = hm.nbits - dbits;                              // (kStrip) image bits the word keeps
-  u64 r[kMsdIPT];
-  u32 rk[kMsdIPT], dg[kMsdIPT];       // kStrip: the digit rides in the word (bits 13..22), dg[] is not kept
-  auto digit = [&](int k) -> u32 { return kStrip ? (u32)(r[k] >> 13) & mask : dg[k]; };
+  auto body = [&](auto full_tag) {
+    constexpr bool kFull = decltype(full_tag)::value;               // a whole tile, every word kept: no per-word guards
+    u64 r[kMsdIPT];
+    u32 rk[kMsdIPT], dg[kMsdIPT];
 #pragma unroll
-  for (int k = 0; k < 2; k++) {
-    const u32 p0 = begin + (u32)(k * NT + tid) * 4u;
-    u64 img[4] = {0, 0, 0, 0};
-    if (p0 < end) images4(km, hm, P1, p0, n, lcode, img);
+    for (int k = 0; k < 2; k++) {
+      const u32 p0 = begin + (u32)(k * NT + tid) * 4u;
+      u64 img[4] = {0, 0, 0, 0};
+      if (kFull || p0 < end) images4(km, hm, P1, p0, n, lcode, img);
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const u32 t = (u32)(k * NT + tid) * 4u + (u32)j;
-      if (kStrip) {
-        r[k * 4 + j] = ((img[j] & ((1ull << rbits) - 1ull)) << pb) | ((u64)((u32)(img[j] >> rbits) & mask) << 13) | t;
-      } else {
-        r[k * 4 + j] = (img[j] << hm.pbits) | (u64)(p0 + j);
-        dg[k * 4 + j] = (u32)((r[k * 4 + j] - base) >> shift) & mask;
+      for (int j = 0; j < 4; j++) {
+        const u32 t = (u32)(k * NT + tid) * 4u + (u32)j;
+        if (kStrip) {
+          // hm.nbits + hm.pbits = 64 (the host makes it so): with the image at the top of 64 bits the digit is the top of
+          // the upper half and the kept bits are one shift away; (digit, index) sit in the lower half's bits 0 .. 22
+          const u64 y = img[j] << hm.pbits;
+          dg[k * 4 + j] = (u32)(y >> 32) >> (32u - dbits);
+          r[k * 4 + j] = (y << dbits) | (u64)((dg[k * 4 + j] << 13) | t);
+        } else {
+          r[k * 4 + j] = (img[j] << hm.pbits) | (u64)(p0 + j);
+          dg[k * 4 + j] = (u32)((r[k * 4 + j] - base) >> shift) & mask;
+        }
+        // rk = ~0: not a word of this tile (past the end, or — kSel — not in this rank's image range)
+        if (!kFull) rk[k * 4 + j] = (t < nvalid && (!kSel || msd_sel_keep(sel, img[j]))) ? 0u : ~0u;
       }
-      // rk = ~0: not a word of this tile (past the end, or — kSel — not in this rank's image range)
-      rk[k * 4 + j] = (t < nvalid && (!kSel || msd_sel_keep(sel, img[j]))) ? 0u : ~0u;
     }
-  }
-  // word k * 4 + j of thread tid is tile element t = (k * NT + tid) * 4 + j
+    // word k * 4 + j of thread tid is tile element t = (k * NT + tid) * 4 + j
 #pragma unroll
-  for (int k = 0; k < kMsdIPT; k++)
-    if (rk[k] != ~0u) rk[k] = atomicAdd(&hist[digit(k)], 1u);
-  __syncthreads();
-  u32 cnt = 0;
-  if (tid < ndig) {
-    cnt = hist[tid];
-    if (cnt) gbase[tid] = atomicAdd(&cur[tid], cnt);
-  }
-  u32 tot;
-  const u32 ex = block_excl_scan<kMsdNW>(cnt, tmp, tot);
-  hist[tid] = ex;
-  __syncthreads();
+    for (int k = 0; k < kMsdIPT; k++)
+      if (kFull || rk[k] != ~0u) rk[k] = atomicAdd(&L.hist[dg[k]], 1u);
+    __syncthreads();
+    u32 cnt = 0, gb = 0;
+    if (tid < ndig) {
+      cnt = L.hist[tid];
+      if (cnt) gb = atomicAdd(&cur[tid], cnt);
+    }
+    u32 tot;
+    const u32 ex = block_excl_scan<kMsdNW>(cnt, L.tmp, tot);
+    L.hist[tid] = ex;
+    L.gbase[tid] = gb - ex;                      // word at tile index q of digit d goes to gbase[d] + q
+    __syncthreads();
 #pragma unroll
-  for (int k = 0; k < kMsdIPT; k++)
-    if (rk[k] != ~0u) srec[hist[digit(k)] + rk[k]] = r[k];
-  __syncthreads();
-  const u32 nout = kSel ? tot : nvalid;              // (tot = the tile's selected words)
-  for (u32 q = tid; q < nout; q += NT) {
-    const u64 x = srec[q];
-    if (kStrip) {
-      const u32 dd = (u32)(x >> 13) & mask;
-      const u64 w = (x & ~((1ull << pb) - 1ull)) | (u64)(begin + ((u32)x & (kMsdTile - 1u)));
-      out[gbase[dd] + (q - hist[dd])] = msd_word(w);
+    for (int k = 0; k < kMsdIPT; k++)
+      if (kFull || rk[k] != ~0u) L.srec[L.hist[dg[k]] + rk[k]] = r[k];
+    __syncthreads();
+    auto emit = [&](u32 q) {
+      const u64 x = L.srec[q];
+      if (kStrip) {
+        const u32 dd = ((u32)x >> 13) & mask;
+        const u64 w = (x & ~((1ull << pb) - 1ull)) | (u64)(begin + ((u32)x & (kMsdTile - 1u)));
+        out[L.gbase[dd] + q] = msd_word(w);
+      } else {
+        const u32 dd = (u32)((x - base) >> shift) & mask;
+        out[L.gbase[dd] + q] = msd_word(x);
+      }
+    };
+    if (kFull) {
+#pragma unroll
+      for (int k = 0; k < kMsdIPT; k++) emit((u32)(k * NT) + tid);
     } else {
-      const u32 dd = (u32)((x - base) >> shift) & mask;
-      out[gbase[dd] + (q - hist[dd])] = msd_word(x);
+      const u32 nout = kSel ? tot : nvalid;              // (tot = the tile's selected words)
+      for (u32 q = tid; q < nout; q += NT) emit(q);
     }
-  }
+  };
+  if (!kSel && nvalid == (u32)kMsdTile) body(std::true_type{}); else body(std::false_type{});
 }
 
 // Sizes of the sub-buckets per group: block h counts the d2-digits of its piece (8 pass-2 tiles) of bucket b in LDS and
