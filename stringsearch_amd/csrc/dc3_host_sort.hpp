@@ -233,12 +233,12 @@ struct MsdRedo { const u64 *src = nullptr; u64 *dst = nullptr; const u32 *start 
 template <class Sink>
 static int msd_launch_local(dc3hip_ctx *c, const MsdRedo &r, u32 n, Sink sink) {
   PhaseScope ps(c, DC3HIP_PH_SORT8_DOWN, n, 6);
-  if (r.large)
-    hipLaunchKernelGGL((k_msd_local<512, (int)kMsdCapLarge, 12, Sink>), dim3(r.nsub), dim3(512), kMsdCapLarge * 8, c->stream, r.src,
-                       r.start, r.base, r.shb, sink);
-  else
-    hipLaunchKernelGGL((k_msd_local<256, (int)kMsdCapSmall, 10, Sink>), dim3(r.nsub), dim3(256), kMsdCapSmall * 8, c->stream, r.src,
-                       r.start, r.base, r.shb, sink);
+  const bool hi = r.base == 0 && r.shb >= 32;          // the bin is a bit field of the word's upper half
+  auto go = [&](auto kern, u32 nt, size_t cap) {
+    hipLaunchKernelGGL(kern, dim3(r.nsub), dim3(nt), (cap + kMsdLocPad) * 8, c->stream, r.src, r.start, r.base, r.shb, sink);
+  };
+  if (r.large) { if (hi) go(k_msd_local<512, (int)kMsdCapLarge, 12, Sink, true>, 512, kMsdCapLarge); else go(k_msd_local<512, (int)kMsdCapLarge, 12, Sink, false>, 512, kMsdCapLarge); }
+  else { if (hi) go(k_msd_local<256, (int)kMsdCapSmall, 10, Sink, true>, 256, kMsdCapSmall); else go(k_msd_local<256, (int)kMsdCapSmall, 10, Sink, false>, 256, kMsdCapSmall); }
   KCHECK();
   return E_OK;
 }

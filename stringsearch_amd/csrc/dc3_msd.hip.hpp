@@ -451,17 +451,18 @@ __global__ __launch_bounds__(1024) void k_msd_scan2c(u32 *__restrict__ cnt, u32 
 // Sinks of the local sort: where word x of global output index g goes (cf. RecSink / SplitSink of the LSD passes).
 // kSame: the sink also wants to know whether the word's image equals its predecessor's in the sorted order (= some
 // smaller word of its bin has the same image: equal images share every image bit, hence the sub-bucket and the bin).
+// image_floor(x) = x with its position bits cleared: a smaller word w has x's image iff w >= image_floor(x).
 struct MsdRecSink {
   u64 *p;
   static constexpr bool kSame = false;
-  __device__ __forceinline__ bool same_image(u64, u64) const { return false; }
+  __device__ __forceinline__ u64 image_floor(u64 x) const { return x; }
   __device__ __forceinline__ void store(u32 g, u64 x, bool) const { p[g] = msd_word(x); }
 };
 // the sorted words + the tie pass's byte (the orderings that keep records: whole-level orders inside the recursion)
 struct MsdRecSameSink {
   u64 *p; uint8_t *same; u32 pbits;
   static constexpr bool kSame = true;
-  __device__ __forceinline__ bool same_image(u64 a, u64 b) const { return ((a ^ b) >> pbits) == 0; }
+  __device__ __forceinline__ u64 image_floor(u64 x) const { return x & ~((1ull << pbits) - 1ull); }
   __device__ __forceinline__ void store(u32 g, u64 x, bool sm) const { p[g] = msd_word(x); same[g] = sm ? 1 : 0; }
 };
 // positions to the suffix-array buffer + ONE BYTE per word for the tie pass: 1 = same image as the word before it.  (The
@@ -470,7 +471,7 @@ struct MsdRecSameSink {
 struct MsdSplitSink {
   u32 *sa; uint8_t *same; u32 pbits;
   static constexpr bool kSame = true;
-  __device__ __forceinline__ bool same_image(u64 a, u64 b) const { return ((a ^ b) >> pbits) == 0; }
+  __device__ __forceinline__ u64 image_floor(u64 x) const { return x & ~((1ull << pbits) - 1ull); }
   __device__ __forceinline__ void store(u32 g, u64 x, bool sm) const {
     sa[g] = (u32)(x & ((1ull << pbits) - 1ull));
     same[g] = sm ? 1 : 0;
@@ -484,11 +485,15 @@ struct MsdSplitSink {
 //   3. words are placed bin by bin in LDS (arrival order inside a bin)
 //   4. every word counts the smaller words of its own bin (about one word per bin): final index = bin start + count
 // The words are distinct, so the result is the unique ascending order.
-template <int NT, int CAP, int BB, class Sink>
+// kHi (the host's choice: base == 0, shb >= 32): the bin is a bit field of the word's upper half.
+// LDS holds kMsdLocPad words of all ones behind the sub-bucket: step 4 reads its bin two words at a time without a bound —
+// what follows a bin are the later bins, all of them larger words.
+constexpr int kMsdLocPad = 2;
+template <int NT, int CAP, int BB, class Sink, bool kHi>
 __global__ __launch_bounds__(NT) void k_msd_local(const u64 *__restrict__ in, const u32 *__restrict__ start, u64 base, u32 shb, Sink out) {
   constexpr int IPT = CAP / NT, NBIN = 1 << BB, BPT = NBIN / NT;
   static_assert(CAP % NT == 0 && NBIN % NT == 0, "shape");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // CAP words (dynamic: CAP * 8 bytes)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // CAP + kMsdLocPad words
   u64 *srec = reinterpret_cast<u64 *>(smem);
   __shared__ u32 cnt[NBIN + 1];
   __shared__ u32 tmp[NT / 64];
@@ -498,18 +503,19 @@ __global__ __launch_bounds__(NT) void k_msd_local(const u64 *__restrict__ in, co
   if (m == 0) return;
 #pragma unroll
   for (int j = 0; j < BPT; j++) cnt[j * NT + tid] = 0;
+  if (tid < (u32)kMsdLocPad) srec[m + tid] = ~0ull;
   __syncthreads();
   u64 r[IPT];
-  u32 rk[IPT];
+  u32 rk[IPT], bn[IPT];
   // (clamped, not guarded: all loads in flight at once)
 #pragma unroll
   for (int k = 0; k < IPT; k++) r[k] = in[begin + min((u32)(k * NT) + tid, m - 1u)];
 #pragma unroll
-  for (int k = 0; k < IPT; k++) r[k] = msd_word(r[k]);
+  for (int k = 0; k < IPT; k++) { r[k] = msd_word(r[k]); bn[k] = msd_digit<kHi>(r[k], base, shb, NBIN - 1); }
 #pragma unroll
   for (int k = 0; k < IPT; k++) {
     const u32 t = k * NT + tid;
-    if (t < m) rk[k] = atomicAdd(&cnt[(u32)((r[k] - base) >> shb) & (NBIN - 1)], 1u);
+    if (t < m) rk[k] = atomicAdd(&cnt[bn[k]], 1u);
   }
   __syncthreads();
   // exclusive scan of the bins: thread tid owns bins [tid * BPT, (tid + 1) * BPT)
@@ -525,20 +531,21 @@ __global__ __launch_bounds__(NT) void k_msd_local(const u64 *__restrict__ in, co
 #pragma unroll
   for (int k = 0; k < IPT; k++) {
     const u32 t = k * NT + tid;
-    if (t < m) srec[cnt[(u32)((r[k] - base) >> shb) & (NBIN - 1)] + rk[k]] = r[k];
+    if (t < m) srec[cnt[bn[k]] + rk[k]] = r[k];
   }
   __syncthreads();
   for (u32 q = tid; q < m; q += NT) {
     const u64 x = srec[q];
-    const u32 bin = (u32)((x - base) >> shb) & (NBIN - 1);
+    const u64 xf = out.image_floor(x);
+    const u32 bin = msd_digit<kHi>(x, base, shb, NBIN - 1);
     const u32 lo = cnt[bin], hi = cnt[bin + 1];
-    u32 less = 0, eql = 0;
-    for (u32 j = lo; j < hi; j++) {
-      const u64 w = srec[j];
-      less += w < x ? 1u : 0u;
-      if (Sink::kSame) eql += (w < x && out.same_image(w, x)) ? 1u : 0u;
+    u32 less = 0, lessf = 0;              // words of the bin below x / below x's image
+    for (u32 j = lo; j < hi; j += 2) {
+      const u64 w0 = srec[j], w1 = srec[j + 1];
+      less += (w0 < x ? 1u : 0u) + (w1 < x ? 1u : 0u);
+      if (Sink::kSame) lessf += (w0 < xf ? 1u : 0u) + (w1 < xf ? 1u : 0u);
     }
-    out.store(begin + lo + less, x, eql != 0);
+    out.store(begin + lo + less, x, less != lessf);
   }
 }
 
