@@ -1266,16 +1266,40 @@ struct SameImg {
   __device__ __forceinline__ bool operator()(u32 i) const { return i > 0 && img[i] == img[i - 1]; }
 };
 struct SameFlag {
-  const uint8_t *f;
+  const uint8_t *f;         // 0 / 1 per record (MsdSplitSink), 16-byte aligned, 16 readable bytes behind the last record
   __device__ __forceinline__ bool operator()(u32 i) const { return f[i] != 0; }
 };
+// bit j = same(i0 + j) for j = 0 .. 16, 0 past the end (i0 a multiple of 16): what a thread of the tie pass needs to know
+// about its 16 records and the one behind them.  The flag bytes come as one 16-byte load and one byte — read a byte at a
+// time, twice per record, the scan of 2^30 flags was 1.3 ms of a 14 ms build for 0.006 % tied records.
+template <class Same>
+__device__ __forceinline__ u32 same_mask17(const Same &same, u32 i0, u32 n) {
+  u32 m = 0;
+#pragma unroll
+  for (u32 j = 0; j <= 16; j++) m |= (i0 + j < n && same(i0 + j)) ? 1u << j : 0u;
+  return m;
+}
+template <>
+__device__ __forceinline__ u32 same_mask17<SameFlag>(const SameFlag &same, u32 i0, u32 n) {
+  const uint4 w = *reinterpret_cast<const uint4 *>(same.f + i0);
+  const u32 ws[4] = {w.x, w.y, w.z, w.w};
+  u32 m = 0;
+#pragma unroll
+  for (u32 k = 0; k < 4; k++) {
+    const u32 x = ws[k] & 0x01010101u;                               // bytes b0 .. b3, each 0 / 1
+    m |= ((x | (x >> 7) | (x >> 14) | (x >> 21)) & 15u) << (4 * k);
+  }
+  m |= (same.f[i0 + 16] & 1u) << 16;
+  const u32 left = n - i0;                                           // >= 1
+  return left >= 17 ? m : m & ((1u << left) - 1u);
+}
 template <class KM, class Same>
 __global__ __launch_bounds__(kBlock) void k_tie_resolve_split(KM km, Same same, u32 *__restrict__ sa,
                                                              u32 n, u32 *words) {
   // Group starts are sparse (3 % of the records on random input): a block keeps collecting them tile after tile and
   // works the list only in full batches of kBlock groups (one per lane), so that every wave has 64 dependent gathers
   // in flight instead of a handful.
-  constexpr u32 kIPT = 4, kTile = kBlock * kIPT, kCap = kTile / 2 + kBlock;
+  constexpr u32 kIPT = 16, kTile = kBlock * kIPT, kCap = kTile / 2 + kBlock;      // a thread scans 16 consecutive records
   __shared__ uint16_t lcode[256];
   __shared__ u32 starts[kCap];
   __shared__ u32 nstart, ntied, ndup;
@@ -1285,14 +1309,18 @@ __global__ __launch_bounds__(kBlock) void k_tie_resolve_split(KM km, Same same, 
   __syncthreads();
   for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     u32 tied = 0;
-#pragma unroll
-    for (u32 j = 0; j < kIPT; j++) {
-      const u32 i = tile * kTile + j * kBlock + threadIdx.x;
-      if (i < n) {
-        const bool eqp = same(i);
-        const bool eqn = i + 1 < n && same(i + 1);
-        if (eqn && !eqp) starts[atomicAdd(&nstart, 1u)] = i;
-        if (eqn || eqp) tied++;
+    {
+      const u32 i0 = tile * kTile + threadIdx.x * kIPT;
+      if (i0 < n) {
+        const u32 m = same_mask17(same, i0, n);
+        const u32 eqp = m & 0xffffu, eqn = (m >> 1) & 0xffffu;       // bit j: record i0 + j equals its predecessor / successor
+        u32 st = eqn & ~eqp;                                         // group starts
+        tied = (u32)__popc(eqn | eqp);
+        while (st) {
+          const u32 j = (u32)__builtin_ctz(st);
+          st &= st - 1u;
+          starts[atomicAdd(&nstart, 1u)] = i0 + j;
+        }
       }
     }
     tied = wave_reduce(tied);
