@@ -19,12 +19,12 @@ pytestmark = pytest.mark.gpu
 GIB = 1 << 30
 # case -> measured ms at the shipping head (MI355X); the guard is 1.2x
 MEASURED_MS = {
-    "random_1GiB": 15.3,
-    "random_1GiB_recursion_only": 43.0,
-    "random_1GiB_dup_1MB_block": 39.7,
-    "dna_1GiB": 18.4,
-    "text_1GiB": 120.0,
-    "real_text_256MiB": 57.3,
+    "random_1GiB": 13.3,
+    "random_1GiB_recursion_only": 40.5,
+    "random_1GiB_dup_1MB_block": 37.3,
+    "dna_1GiB": 16.8,
+    "text_1GiB": 111.0,
+    "real_text_256MiB": 53.4,
 }
 SLACK = 1.2
 
