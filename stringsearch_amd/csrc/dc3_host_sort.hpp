@@ -15,7 +15,7 @@ template <> struct SortCfg<Rec16, 256> { static constexpr int IPT = 8, NW = 16; 
 template <> struct SortCfg<Rec16, 512> { static constexpr int IPT = 7, NW = 16; static constexpr bool PF = false; };
 template <> struct SortCfg<Tup0, 256>  { static constexpr int IPT = 6, NW = 16; static constexpr bool PF = false; };
 template <> struct SortCfg<Tup0, 512>  { static constexpr int IPT = 6, NW = 16; static constexpr bool PF = false; };
-template <> struct SortCfg<Tup0C, 256> { static constexpr int IPT = 8, NW = 16; static constexpr bool PF = false; };
+template <> struct SortCfg<Tup0C, 256> { static constexpr int IPT = 8, NW = 8; static constexpr bool PF = false; };
 template <> struct SortCfg<Tup0C, 512> { static constexpr int IPT = 7, NW = 16; static constexpr bool PF = false; };
 template <> struct SortCfg<Tup0G, 256> { static constexpr int IPT = 6, NW = 16; static constexpr bool PF = false; };
 template <> struct SortCfg<Tup0G, 512> { static constexpr int IPT = 6, NW = 16; static constexpr bool PF = false; };

@@ -412,11 +412,15 @@ template <class Src>
 __global__ __launch_bounds__(kPartNW * 64, 8) void k_part_msd(Src in, Rec8 *__restrict__ out, u32 n,
                                                           u32 shift, u32 seg_bits, u32 ndig,
                                                           u32 *__restrict__ cursors, u32 xcd_tps) {
+  // LDS: the two digit tables first (their reads take a constant offset from the digit's own address), the pairs behind
+  // them; after the scan gbase[d] = (start of the tile's run of d in the output) - (its start inside the tile), so the
+  // pair at tile index q goes to gbase[d] + q.  Full tiles run without the per-pair guards (cf. k_msd_part).
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  Rec8 *srec = reinterpret_cast<Rec8 *>(smem);
-  u32 *hist = reinterpret_cast<u32 *>(smem + sizeof(Rec8) * kPartTile);   // [1024] counts -> tile-exclusive prefix
-  u32 *gbase = hist + 1024;                                                // [1024] global base of the tile's run
-  u32 *tmp = gbase + 1024;
+  u32 *hist = reinterpret_cast<u32 *>(smem);                               // [1024] counts -> tile-exclusive prefix
+  u32 *gbase = hist + 1024;                                                // [1024]
+  u32 *tmp = gbase + 1024;                                                 // [64 + kPartNW * kPartIPT]
+  Rec8 *srec = reinterpret_cast<Rec8 *>(smem + sizeof(u32) * (2 * 1024 + 64 + kPartNW * kPartIPT));
+  constexpr u32 NT = kPartNW * 64;
   const u32 tid = threadIdx.x;
   u32 tile = blockIdx.x;
   if (xcd_tps) {
@@ -430,41 +434,51 @@ __global__ __launch_bounds__(kPartNW * 64, 8) void k_part_msd(Src in, Rec8 *__re
   const u32 seg_base = seg_bits >= 32 ? 0u : (seg << seg_bits);
   hist[tid] = 0;
   __syncthreads();
-  Rec8 r[kPartIPT];
-  u32 d[kPartIPT], rk[kPartIPT];
-  // (all loads issued back to back: the index is clamped instead of guarded, a guard would put a wait behind every load)
-  if constexpr (Src::kScan) in.load_tile(begin, nvalid, r, tmp + 64);
-  else {
+  auto body = [&](auto full_tag) {
+    constexpr bool kFull = decltype(full_tag)::value;
+    Rec8 r[kPartIPT];
+    u32 d[kPartIPT], rk[kPartIPT];
+    // (all loads issued back to back: the index is clamped instead of guarded, a guard would put a wait behind every load)
+    if constexpr (Src::kScan) in.load_tile(begin, nvalid, r, tmp + 64);
+    else {
 #pragma unroll
-    for (int k = 0; k < kPartIPT; k++) r[k] = in.load(begin + min((u32)(k * (kPartNW * 64)) + tid, nvalid - 1u));
-  }
+      for (int k = 0; k < kPartIPT; k++) r[k] = in.load(begin + (kFull ? (u32)(k * NT) + tid : min((u32)(k * NT) + tid, nvalid - 1u)));
+    }
 #pragma unroll
-  for (int k = 0; k < kPartIPT; k++) {
-    const u32 t = k * (kPartNW * 64) + tid;
-    d[k] = ((r[k].key - seg_base) >> shift);
-    if (t < nvalid) rk[k] = atomicAdd(&hist[d[k]], 1u);
-  }
-  __syncthreads();
-  u32 cnt = 0;
-  if (tid < ndig) {
-    cnt = hist[tid];
-    if (cnt) gbase[tid] = seg_base + (tid << shift) + atomicAdd(&cursors[seg * ndig + tid], cnt);
-  }
-  u32 tot;
-  const u32 ex = block_excl_scan<kPartNW>(tid < ndig ? cnt : 0u, tmp, tot);
-  hist[tid] = ex;
-  __syncthreads();
+    for (int k = 0; k < kPartIPT; k++) {
+      d[k] = ((r[k].key - seg_base) >> shift);
+      if (kFull || (u32)(k * NT) + tid < nvalid) rk[k] = atomicAdd(&hist[d[k]], 1u);
+    }
+    __syncthreads();
+    u32 cnt = 0, gb = 0;
+    if (tid < ndig) {
+      cnt = hist[tid];
+      if (cnt) gb = seg_base + (tid << shift) + atomicAdd(&cursors[seg * ndig + tid], cnt);
+    }
+    u32 tot;
+    const u32 ex = block_excl_scan<kPartNW>(tid < ndig ? cnt : 0u, tmp, tot);
+    hist[tid] = ex;
+    gbase[tid] = gb - ex;
+    __syncthreads();
 #pragma unroll
-  for (int k = 0; k < kPartIPT; k++) {
-    const u32 t = k * (kPartNW * 64) + tid;
-    if (t < nvalid) srec[hist[d[k]] + rk[k]] = r[k];
-  }
-  __syncthreads();
-  for (u32 q = tid; q < nvalid; q += kPartNW * 64) {
-    const Rec8 x = srec[q];
-    const u32 dd = (x.key - seg_base) >> shift;
-    out[gbase[dd] + (q - hist[dd])] = x;
-  }
+    for (int k = 0; k < kPartIPT; k++)
+      if (kFull || (u32)(k * NT) + tid < nvalid) srec[hist[d[k]] + rk[k]] = r[k];
+    __syncthreads();
+    if (kFull) {
+#pragma unroll
+      for (int k = 0; k < kPartIPT; k++) {
+        const u32 q = (u32)(k * NT) + tid;
+        const Rec8 x = srec[q];
+        out[gbase[(x.key - seg_base) >> shift] + q] = x;
+      }
+    } else {
+      for (u32 q = tid; q < nvalid; q += NT) {
+        const Rec8 x = srec[q];
+        out[gbase[(x.key - seg_base) >> shift] + q] = x;
+      }
+    }
+  };
+  if (nvalid == (u32)kPartTile) body(std::true_type{}); else body(std::false_type{});
 }
 
 // Final step of the windowed inversion.  The keys are a bijection onto [0,n), and the pairs are

@@ -31,3 +31,16 @@ def test_partition_kernels_fit_two_blocks_per_cu():
             assert scratch <= 128, (name[:100], scratch)        # (a few spilled registers at most: the price of the bound)
     assert seen >= 20, seen
     assert not bad, bad
+
+
+def test_fused_mod0_pass_fits_two_blocks_per_cu():
+    """the stable radix pass that also selects the mod-0 tuples (k_rs_downsweep<Tup0C, .., Mod0LoaderC>): 512-thread blocks with a
+    64 KB tile — two per CU by LDS, so its registers must allow two as well (round 5: one 1024-thread block of 106 VGPRs before)"""
+    asm = os.path.join(ROOT, "stringsearch_amd", "csrc", "dc3hip.gfx950.s")
+    if not os.path.exists(asm):
+        pytest.skip("the library has not been built here")
+    import occupancy_report as occ
+    rows = [r for r in occ.kernels(asm) if "k_rs_downsweep<dc3::Tup0C, 256" in r[0]]
+    assert rows, "no instantiation of the fused mod-0 pass in the ISA"
+    for name, wg, vgpr, lds, scratch, by_v in rows:
+        assert wg == 512 and by_v >= 2 and scratch == 0, (name[:120], wg, vgpr, scratch)
