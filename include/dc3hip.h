@@ -254,7 +254,8 @@ typedef struct dc3hip_stats {
    * stable 256-bucket LSD passes instead (DC3HIP_XCD_ASSUME=1 keeps the bucket ordering).  xcd_blocks / xcd_group_hit:
    * the grouped partition blocks of the LAST build and the share of them that ran on their group's majority XCD (1.0 = the
    * assumption held throughout, 0.125 = placement unrelated to blockIdx) — also under other streams on the device. */
-  int32_t xcd_round_robin, xcd_reserved;
+  int32_t xcd_round_robin;
+  int32_t msd_slot_sorts;                 /* MSD sorts of the last build whose pass 2 wrote into sub-bucket slots (no counting sweep) */
   int64_t xcd_blocks;
   double  xcd_group_hit;
   /* k_msd_part_keys / k_wide_part1: partition pass 1 of a bucket ordering that also MAKES the words it partitions (from

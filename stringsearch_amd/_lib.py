@@ -60,7 +60,7 @@ class Stats(ctypes.Structure):
                 ("ssort_part_ms", ctypes.c_double), ("ssort_part_launches", ctypes.c_int64), ("ssort_part_elems", ctypes.c_int64),
                 ("ssort_local_ms", ctypes.c_double), ("ssort_local_launches", ctypes.c_int64), ("ssort_local_elems", ctypes.c_int64),
                 ("ssort_sorts", ctypes.c_int32), ("ssort_fallbacks", ctypes.c_int32), ("ssort_max_subbucket", ctypes.c_int64),
-                ("xcd_round_robin", ctypes.c_int32), ("xcd_reserved", ctypes.c_int32), ("xcd_blocks", ctypes.c_int64),
+                ("xcd_round_robin", ctypes.c_int32), ("msd_slot_sorts", ctypes.c_int32), ("xcd_blocks", ctypes.c_int64),
                 ("xcd_group_hit", ctypes.c_double),
                 ("msd_part_keys_ms", ctypes.c_double), ("msd_part_keys_launches", ctypes.c_int64), ("msd_part_keys_elems", ctypes.c_int64)]
 
@@ -87,7 +87,7 @@ class Stats(ctypes.Structure):
             "msd_part_ms": self.msd_part_ms, "msd_part_launches": self.msd_part_launches, "msd_part_elems": self.msd_part_elems,
             "msd_local_ms": self.msd_local_ms, "msd_local_launches": self.msd_local_launches,
             "msd_local_elems": self.msd_local_elems, "msd_sorts": self.msd_sorts, "msd_fallbacks": self.msd_fallbacks,
-            "msd_max_subbucket": self.msd_max_subbucket,
+            "msd_max_subbucket": self.msd_max_subbucket, "msd_slot_sorts": self.msd_slot_sorts,
             "ssort_part_ms": self.ssort_part_ms, "ssort_part_launches": self.ssort_part_launches, "ssort_part_elems": self.ssort_part_elems,
             "ssort_local_ms": self.ssort_local_ms, "ssort_local_launches": self.ssort_local_launches,
             "ssort_local_elems": self.ssort_local_elems, "ssort_sorts": self.ssort_sorts, "ssort_fallbacks": self.ssort_fallbacks,

@@ -91,6 +91,8 @@ struct dc3hip_ctx {
   bool ssort_rec12 = false;    // DC3HIP_SSORT_REC12=1: the splitter ordering also for keys of at most 64 bits (tests)
   bool no_pack_count = false;  // DC3HIP_NO_PACK_COUNT=1: the wide-window records are packed by their own kernel, then counted
   bool ssort_verify = false;   // DC3HIP_SSORT_VERIFY=1 (tests): every splitter ordering checks its passes (record checksums, cursors, order); a mismatch fails the build
+  u32 msd_slot_cap = 0;        // DC3HIP_DEBUG=msd_slot_cap=N (tests): slots of N words instead of twice the mean — small N makes them overflow
+  bool no_msd_slots = false;   // DC3HIP_DEBUG=no_msd_slots: pass 2 of the bucket ordering always in its counted form (k_msd_hist2 first)
   bool no_merge_keys64 = false; // DC3HIP_DEBUG=no_merge_keys64: the merge compares tuple fields (16-byte LDS image) also where 64-bit keys would do
   bool tup_counted = false;    // DC3HIP_DEBUG=tup_counted: the tuple scatter's pass 1 counts its buckets per XCD group first (the round-4 form)
   bool no_fuse_names = false;  // DC3HIP_NO_FUSE_NAMES=1: names / final slots are written as pairs first (k_name_assign, k_final_assign)
@@ -155,7 +157,8 @@ static size_t arena_requirement(int64_t n) {
 static size_t arena_text_requirement(int64_t n) {
   // (beyond 2^31 positions the whole-text order runs on 12-byte records: 2 x 12 + 1 bytes per position + tables)
   // (+ the size tables of the bucket ordering: 2 x 8 words per sub-bucket, at most 2^20 sub-buckets)
-  return n > ((int64_t)1 << 31) ? (size_t)n * 26 + ((size_t)256 << 20) : (size_t)n * 24 + ((size_t)208 << 20);
+  // (+ up to 2^31 positions the slots of the bucket ordering's second pass, 16 bytes per position: msd_sort)
+  return n > ((int64_t)1 << 31) ? (size_t)n * 26 + ((size_t)256 << 20) : (size_t)n * 40 + ((size_t)224 << 20);
 }
 
 // Grow the (empty) arena to at least `need` bytes.  Never shrinks; a size forced by DC3HIP_ARENA_BYTES stays as it is.

@@ -229,13 +229,14 @@ struct MsdPass1Keys : MsdPass1 {
   }
 };
 // what a finished sort leaves behind so that its last pass can be repeated into records (cf. LastPass)
-struct MsdRedo { const u64 *src = nullptr; u64 *dst = nullptr; const u32 *start = nullptr; u32 nsub = 0, shb = 0; bool large = false; u64 base = 0; };
+struct MsdRedo { const u64 *src = nullptr; u64 *dst = nullptr; const u32 *start = nullptr; u32 nsub = 0, shb = 0; bool large = false; u64 base = 0;
+                 u32 slot_cap = 0; /* != 0: sub-bucket s lies in src[s * slot_cap ..) (k_msd_part<.., kSlot>) */ };
 template <class Sink>
 static int msd_launch_local(dc3hip_ctx *c, const MsdRedo &r, u32 n, Sink sink) {
   PhaseScope ps(c, DC3HIP_PH_SORT8_DOWN, n, 6);
   const bool hi = r.base == 0 && r.shb >= 32;          // the bin is a bit field of the word's upper half
   auto go = [&](auto kern, u32 nt, size_t cap) {
-    hipLaunchKernelGGL(kern, dim3(r.nsub), dim3(nt), (cap + kMsdLocPad) * 8, c->stream, r.src, r.start, r.base, r.shb, sink);
+    hipLaunchKernelGGL(kern, dim3(r.nsub), dim3(nt), (cap + kMsdLocPad) * 8, c->stream, r.src, r.start, r.base, r.shb, sink, r.slot_cap);
   };
   if (r.large) { if (hi) go(k_msd_local<512, (int)kMsdCapLarge, 12, Sink, true>, 512, kMsdCapLarge); else go(k_msd_local<512, (int)kMsdCapLarge, 12, Sink, false>, 512, kMsdCapLarge); }
   else { if (hi) go(k_msd_local<256, (int)kMsdCapSmall, 10, Sink, true>, 256, kMsdCapSmall); else go(k_msd_local<256, (int)kMsdCapSmall, 10, Sink, false>, 256, kMsdCapSmall); }
@@ -264,6 +265,8 @@ static int msd_sort(dc3hip_ctx *c, Rec8 *ha, Rec8 *hb, u32 n, const HiMap &hm, c
     HIPC(dc3_func_set_attribute(reinterpret_cast<const void *>(k_msd_part<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
     HIPC(dc3_func_set_attribute(reinterpret_cast<const void *>(k_msd_part<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
     HIPC(dc3_func_set_attribute(reinterpret_cast<const void *>(k_msd_part<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
+    HIPC(dc3_func_set_attribute(reinterpret_cast<const void *>(k_msd_part<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
+    HIPC(dc3_func_set_attribute(reinterpret_cast<const void *>(k_msd_part<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMsdPartSmem));
     attr_set[c->device & 15] = true;
   }
   const u32 nb1 = 1u << g.d1, tb = g.d1 + g.d2, n2 = 1u << tb;
@@ -300,13 +303,63 @@ static int msd_sort(dc3hip_ctx *c, Rec8 *ha, Rec8 *hb, u32 n, const HiMap &hm, c
       // (base == 0 and the digit inside the word's upper half: the digit is one bit-field instruction, k_msd_part<.., kHi>)
       auto kern = (base == 0 && sh1 >= 32) ? k_msd_part<false, true> : k_msd_part<false, false>;
       hipLaunchKernelGGL(kern, dim3(kMsdGroups * g.cpx1), dim3(kMsdNW * 64), kMsdPartSmem, c->stream, (const u64 *)wa, wb, n,
-                         base, sh1, g.d1, g.cpx1, g.ntiles1, (const u32 *)nullptr, (const u32 *)nullptr, nb1, (const u32 *)plan, cur1, nb1, c->d_xcdmon);
+                         base, sh1, g.d1, g.cpx1, g.ntiles1, (const u32 *)nullptr, (const u32 *)nullptr, nb1, (const u32 *)plan, cur1, nb1, c->d_xcdmon, 0u, 0u);
       KCHECK();
     }
   }
   MsdRedo r;
   r.base = base;
-  if (g.d2 > 0) {
+  // Pass 2 into SLOTS (k_msd_part<.., kSlot>): when the pass-1 buckets are even (largest <= 1.25 x the mean: the sub-buckets of
+  // such inputs are Poisson-sized around n / n2 <= 1024) and the arena has 16 bytes per word to spare, every sub-bucket gets
+  // a slot of twice the mean and pass 2 needs no sizes in advance: k_msd_hist2 (a read of all words) and its scans before the
+  // pass are not run, the sizes are read off the slot cursors afterwards.  A slot that overflows (seen in the same maximum the
+  // counted form checks) sends the sort through the counted form below, from the untouched output of pass 1.
+  bool slot_done = false;
+  if (g.d2 > 0 && !c->no_msd_slots) {
+    const u32 mean = (u32)(((u64)n + n2 - 1) / n2);
+    const u32 slot_cap = c->msd_slot_cap ? std::min<u32>(kMsdCapSmall, c->msd_slot_cap) : std::min<u32>(kMsdCapSmall, (2 * mean + 63) & ~63u);
+    const u64 slot_words = (u64)n2 * slot_cap + kMsdTile;
+    const size_t N = (size_t)n2 * kMsdGroups;
+    const size_t need = align_up(slot_words * 8, 256) + 2 * align_up((N + 16) * 4, 256) + ((size_t)n * 2 + (64u << 20));   // (+ what the tie pass takes afterwards)
+    HIPC(hipMemcpyAsync(c->h_words + 20, plan, kMsdW_COUNT * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    const u32 maxb1 = c->h_words[20 + kMsdW_MAXB1];
+    if (slot_words < (1ull << 32) && (u64)maxb1 * nb1 * 4 <= (u64)n * 5 && c->arena_off + need <= c->arena_bytes) {
+      u64 *slots = nullptr; u32 *cnt2g = nullptr, *cur2 = nullptr;
+      RC(arena_alloc(c, (size_t)slot_words, &slots));
+      RC(arena_alloc(c, N + 16, &cnt2g));
+      RC(arena_alloc(c, N + 16, &cur2));
+      const u32 nseg = (u32)((N + kMsdScanSeg - 1) / kMsdScanSeg);       // <= 1024
+      {
+        PhaseScope ps(c, DC3HIP_PH_SORT8_DOWN, n, 5);
+        HIPC(hipMemsetAsync(cnt2g, 0, (N + 1) * sizeof(u32), c->stream));
+        const u32 grid2 = kMsdGroups * ((n / kMsdTile + nb1 + 1 + kMsdGroups - 1) / kMsdGroups);
+        auto kern = (base == 0 && sh2 >= 32) ? k_msd_part<true, true, true> : k_msd_part<true, false, true>;
+        hipLaunchKernelGGL(kern, dim3(grid2), dim3(kMsdNW * 64), kMsdPartSmem, c->stream, (const u64 *)wb, slots, n, base, sh2, g.d2,
+                           0u, 0u, (const u32 *)tpre, (const u32 *)bstart, nb1, (const u32 *)plan, cnt2g, n2, c->d_xcdmon, slot_cap,
+                           (u32)(slot_words - kMsdTile));
+        KCHECK();
+      }
+      {
+        PhaseScope ps(c, DC3HIP_PH_SORT12_SCAN, N);
+        hipLaunchKernelGGL(k_msd_scan2a, dim3(nseg), dim3(1024), 0, c->stream, (const u32 *)cnt2g, (u32)N, segsum, plan);
+        KCHECK();
+        hipLaunchKernelGGL(k_msd_scan2c, dim3(nseg), dim3(1024), 0, c->stream, cnt2g, (u32)N, n2, (const u32 *)segsum, cur2);
+        KCHECK();
+        HIPC(hipMemcpyAsync(c->h_words + 20, plan, kMsdW_COUNT * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+      }
+      HIPC(hipStreamSynchronize(c->stream));
+      if (c->h_words[20 + kMsdW_MAXSUB] <= slot_cap) {
+        r.src = slots; r.dst = wb; r.start = cnt2g; r.nsub = n2; r.slot_cap = slot_cap;
+        slot_done = true;
+        c->stats.msd_slot_sorts++;
+      } else {
+        HIPC(hipMemsetAsync(plan + kMsdW_MAXSUB, 0, sizeof(u32), c->stream));      // (the counted form takes its own maximum)
+      }
+    }
+  }
+  if (slot_done) {
+  } else if (g.d2 > 0) {
     const size_t N = (size_t)n2 * kMsdGroups;
     u32 *cnt2g = nullptr, *cur2 = nullptr;
     RC(arena_alloc(c, N + 16, &cnt2g));
@@ -334,7 +387,7 @@ static int msd_sort(dc3hip_ctx *c, Rec8 *ha, Rec8 *hb, u32 n, const HiMap &hm, c
       const u32 grid2 = kMsdGroups * ((n / kMsdTile + nb1 + 1 + kMsdGroups - 1) / kMsdGroups);
       auto kern = (base == 0 && sh2 >= 32) ? k_msd_part<true, true> : k_msd_part<true, false>;
       hipLaunchKernelGGL(kern, dim3(grid2), dim3(kMsdNW * 64), kMsdPartSmem, c->stream, (const u64 *)wb, wa, n, base, sh2, g.d2,
-                         0u, 0u, (const u32 *)tpre, (const u32 *)bstart, nb1, (const u32 *)plan, cur2, n2, c->d_xcdmon);
+                         0u, 0u, (const u32 *)tpre, (const u32 *)bstart, nb1, (const u32 *)plan, cur2, n2, c->d_xcdmon, 0u, 0u);
       KCHECK();
     }
     r.src = wa; r.dst = wb; r.start = cnt2g; r.nsub = n2;

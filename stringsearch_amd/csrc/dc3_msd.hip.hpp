@@ -45,7 +45,7 @@ constexpr u32 kMsdHistTile = 8u * kMsdTile;                                    /
 constexpr u32 kMsdGroups = 8;                                                  // XCDs
 constexpr u32 kMsdScanSeg = 8192;                                              // entries per block of the size scans
 // device words of a sort (plan[] in the kernels below)
-enum { kMsdW_T2 = 0, kMsdW_CPX2 = 1, kMsdW_MAXSUB = 2, kMsdW_COUNT = 4 };
+enum { kMsdW_T2 = 0, kMsdW_CPX2 = 1, kMsdW_MAXSUB = 2, kMsdW_MAXB1 = 3 /* largest pass-1 bucket */, kMsdW_COUNT = 4 };
 
 // Digit table of the top d1 image bits when the records were not packed for this ordering (callers that build their
 // records elsewhere, e.g. the ranks of the global mode): table[d * nchunks + c] as the pack kernels write it.
@@ -110,6 +110,7 @@ __global__ __launch_bounds__(1024) void k_msd_plan1(const u32 *__restrict__ cntg
   const u32 ext = block_excl_scan<16>((c + kMsdTile - 1) / kMsdTile, tmp, tot);
   if (d < nb1) tpre[d] = ext;
   if (d == 0) { tpre[nb1] = tot; plan[kMsdW_T2] = tot; plan[kMsdW_CPX2] = max(1u, (tot + kMsdGroups - 1) / kMsdGroups); }
+  { const u32 mx = wave_reduce_max(c); if (lane_id() == 0 && mx) atomicMax(&plan[kMsdW_MAXB1], mx); }
   const u32 exh = block_excl_scan<16>((c + kMsdHistTile - 1) / kMsdHistTile, tmp, tot);
   if (d < nb1) tpreh[d] = exh;
   if (d == 0) { tpreh[nb1] = tot; bstart[nb1] = n; startg[nb1 * kMsdGroups] = n; }
@@ -145,19 +146,26 @@ struct MsdPartLds {
       : hist(reinterpret_cast<u32 *>(smem)), gbase(hist + kMsdMaxDig), tmp(gbase + kMsdMaxDig),
         srec(reinterpret_cast<u64 *>(smem + sizeof(u32) * (2 * kMsdMaxDig + 64))) {}
 };
-template <bool kSeg, bool kHi>
+// kSlot (pass 2 only; the host's choice when the pass-1 buckets are even and the arena has room): sub-bucket s of the output
+//   is a SLOT of slot_cap words at s * slot_cap — no sizes are needed before the pass, so the counting sweep over all words
+//   (k_msd_hist2: 8.6 GB read for 2^30 words) and its scans before the pass are not run.  cursors[s * 8] counts the words of s;
+//   a run that does not fit goes to the dump area behind the slots (dump_base) and the host — which sees the largest count
+//   after the pass — runs the counted form from the untouched input.
+template <bool kSeg, bool kHi, bool kSlot = false>
 __global__ __launch_bounds__(kMsdNW * 64) void k_msd_part(const u64 *__restrict__ in, u64 *__restrict__ out, u32 n, u64 base, u32 shift,
                                                          u32 dbits, u32 cpx, u32 ntiles, const u32 *__restrict__ tpre,
                                                          const u32 *__restrict__ bstart, u32 nb1, const u32 *__restrict__ plan,
-                                                         u32 *__restrict__ cursors, u32 gstride, u32 *__restrict__ xcdmon) {
+                                                         u32 *__restrict__ cursors, u32 gstride, u32 *__restrict__ xcdmon,
+                                                         u32 slot_cap = 0, u32 dump_base = 0) {
+  static_assert(!kSlot || kSeg, "slots are sub-buckets");
   constexpr int NT = kMsdNW * 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const MsdPartLds L(smem);
   const u32 tid = threadIdx.x;
   const u32 ndig = 1u << dbits, mask = ndig - 1u;
   const u32 g = blockIdx.x % kMsdGroups, idx = blockIdx.x / kMsdGroups;
-  u32 begin, end;
-  u32 *cur = cursors + (size_t)g * gstride;
+  u32 begin, end, bkt = 0;
+  u32 *cur = cursors + (kSlot ? (size_t)0 : (size_t)g * gstride);
   if (kSeg) {
     const u32 cpx2 = plan[kMsdW_CPX2], t2 = plan[kMsdW_T2];
     const u32 tile = g * cpx2 + idx;
@@ -165,7 +173,8 @@ __global__ __launch_bounds__(kMsdNW * 64) void k_msd_part(const u64 *__restrict_
     const u32 b = msd_find_bucket(tpre, nb1, tile);
     begin = bstart[b] + (tile - tpre[b]) * (u32)kMsdTile;
     end = min(begin + (u32)kMsdTile, bstart[b + 1]);
-    cur += (size_t)b << dbits;
+    if (!kSlot) cur += (size_t)b << dbits;
+    bkt = b;
   } else {
     const u32 tile = g * cpx + idx;
     if (idx >= cpx || tile >= ntiles) return;
@@ -192,7 +201,15 @@ __global__ __launch_bounds__(kMsdNW * 64) void k_msd_part(const u64 *__restrict_
     u32 cnt = 0, gb = 0;
     if (tid < ndig) {
       cnt = L.hist[tid];
-      if (cnt) gb = atomicAdd(&cur[tid], cnt);
+      if (cnt) {
+        if (kSlot) {
+          const u32 s = (bkt << dbits) + tid;
+          const u32 old = atomicAdd(&cur[(size_t)s * kMsdGroups], cnt);
+          gb = old + cnt <= slot_cap ? s * slot_cap + old : dump_base;
+        } else {
+          gb = atomicAdd(&cur[tid], cnt);
+        }
+      }
     }
     u32 tot;
     const u32 ex = block_excl_scan<kMsdNW>(cnt, L.tmp, tot);
@@ -479,7 +496,8 @@ struct MsdSplitSink {
 };
 
 // Pass 3: block s orders sub-bucket s = words [start[8 s], start[8 (s + 1)]) (at most CAP of them; larger ones were
-// refused on the host) and writes it through the sink at the same indices.
+// refused on the host) and writes it through the sink at the same indices.  (start = the exclusive prefix of the sub-bucket
+// sizes either way: counted before pass 2, or read off the slot cursors after it.)
 //   1. bin = BB bits below the sub-bucket bits; one returning LDS atomic per word gives its arrival number in the bin
 //   2. exclusive scan of the bin counts
 //   3. words are placed bin by bin in LDS (arrival order inside a bin)
@@ -490,7 +508,8 @@ struct MsdSplitSink {
 // what follows a bin are the later bins, all of them larger words.
 constexpr int kMsdLocPad = 2;
 template <int NT, int CAP, int BB, class Sink, bool kHi>
-__global__ __launch_bounds__(NT) void k_msd_local(const u64 *__restrict__ in, const u32 *__restrict__ start, u64 base, u32 shb, Sink out) {
+__global__ __launch_bounds__(NT) void k_msd_local(const u64 *__restrict__ in, const u32 *__restrict__ start, u64 base, u32 shb, Sink out,
+                                                  u32 slot_cap) {
   constexpr int IPT = CAP / NT, NBIN = 1 << BB, BPT = NBIN / NT;
   static_assert(CAP % NT == 0 && NBIN % NT == 0, "shape");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // CAP + kMsdLocPad words
@@ -508,8 +527,10 @@ __global__ __launch_bounds__(NT) void k_msd_local(const u64 *__restrict__ in, co
   u64 r[IPT];
   u32 rk[IPT], bn[IPT];
   // (clamped, not guarded: all loads in flight at once)
+  // (slot_cap != 0: the sub-bucket's words lie in its slot, k_msd_part<.., kSlot>; they go out at `begin` all the same)
+  const size_t src0 = slot_cap ? (size_t)blockIdx.x * slot_cap : (size_t)begin;
 #pragma unroll
-  for (int k = 0; k < IPT; k++) r[k] = in[begin + min((u32)(k * NT) + tid, m - 1u)];
+  for (int k = 0; k < IPT; k++) r[k] = in[src0 + min((u32)(k * NT) + tid, m - 1u)];
 #pragma unroll
   for (int k = 0; k < IPT; k++) { r[k] = msd_word(r[k]); bn[k] = msd_digit<kHi>(r[k], base, shb, NBIN - 1); }
 #pragma unroll

@@ -103,11 +103,12 @@ static int ctx_create_impl(dc3hip_ctx **out, int32_t device, int64_t max_n, dc3h
   c->no_msd = dbg_on("no_msd"); c->no_xcd_map = dbg_on("no_xcd_map");
   c->no_raw_image = dbg_on("no_raw_image"); c->no_pack_strip = dbg_on("no_pack_strip"); c->no_pack_count = dbg_on("no_pack_count");
   c->no_ssort = dbg_on("no_ssort"); c->ssort_verify = dbg_on("ssort_verify"); c->ssort_rec12 = dbg_on("ssort_rec12");
-  c->no_wide_window = dbg_on("no_wide_window"); c->no_fuse_names = dbg_on("no_fuse_names"); c->tup_counted = dbg_on("tup_counted"); c->no_merge_keys64 = dbg_on("no_merge_keys64");
+  c->no_wide_window = dbg_on("no_wide_window"); c->no_fuse_names = dbg_on("no_fuse_names"); c->tup_counted = dbg_on("tup_counted"); c->no_merge_keys64 = dbg_on("no_merge_keys64"); c->no_msd_slots = dbg_on("no_msd_slots");
   c->no_text_shortcut = dbg_on("no_text_shortcut"); c->no_fullsort = dbg_on("no_fullsort"); c->no_discard = dbg_on("no_discard");
   c->no_nine_bit = dbg_on("no_9bit"); c->no_rec12 = dbg_on("no_rec12");
   { long long v; if (dbg_num("tup_scatter_min", &v)) c->tup_scatter_min = (u32)std::max(0ll, v); }
   { long long v; if (dbg_num("msd_min", &v)) c->msd_min = (u32)std::max(4096ll, v); }
+  { long long v; if (dbg_num("msd_slot_cap", &v)) c->msd_slot_cap = (u32)std::max(1ll, v); }
   { long long v; if (dbg_num("ssort_min", &v)) c->ssort_min = (u32)std::max(8192ll, v); }
   { long long v; if (dbg_num("hybrid12_min", &v)) c->hybrid12_min = (u32)std::max(0ll, v); }
   int rc = [&]() -> int {

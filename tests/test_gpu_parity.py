@@ -631,7 +631,7 @@ def test_bucket_ordering_matches_the_stable_passes(ss, oracle):
     image distribution)."""
     rng = np.random.default_rng(91)
     cases = {}
-    for n in ((1 << 22) + 3, 5_000_001, (1 << 23) + 8191):
+    for n in ((1 << 22) + 3, 5_000_001, (1 << 23) + 8191, (1 << 25) + 77):
         cases[f"bytes_{n}"] = rng.integers(0, 256, size=n, dtype=np.uint8)
     cases["dna"] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=6_000_000)].copy()
     d = rng.integers(0, 256, size=6_000_000, dtype=np.uint8); d[3_000_000:3_040_000] = d[10_000:50_000]
@@ -662,7 +662,9 @@ def test_bucket_ordering_matches_the_stable_passes(ss, oracle):
                     {"DC3HIP_MSD_MIN": "4096", "DC3HIP_PACK_FUSE": "0"},        # the pack kernel writes the words, pass 1 reads them
                     {"DC3HIP_MSD_MIN": "4096", "DC3HIP_NO_PACK_STRIP": "1"},    # pass 1 makes them, from an image no wider than the word
                     {"DC3HIP_MSD_MIN": "4096", "DC3HIP_NO_RAW_IMAGE": "1"},     # byte alphabets: the scaled 9-symbol key as the image
-                    {"DC3HIP_MSD_MIN": "4096", "DC3HIP_NO_TUP_SCATTER": "1", "DC3HIP_NO_XCD_MAP": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1"}):
+                    {"DC3HIP_MSD_MIN": "4096", "DC3HIP_NO_TUP_SCATTER": "1", "DC3HIP_NO_XCD_MAP": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1"},
+                    {"DC3HIP_MSD_MIN": "4096", "DC3HIP_NO_MSD_SLOTS": "1"},     # pass 2 counted (k_msd_hist2 first) instead of into slots
+                    {"DC3HIP_MSD_MIN": "4096", "DC3HIP_MSD_SLOT_CAP": "64"}):   # slots far too small: they overflow, the counted form runs
             env_apply(env)
             try:
                 with ss.Context(len(data)) as c:
@@ -673,6 +675,11 @@ def test_bucket_ordering_matches_the_stable_passes(ss, oracle):
                         assert st["msd_sorts"] == 0
                     elif (label.startswith("bytes") or label == "dna") and "DC3HIP_NO_TEXT_SHORTCUT" not in env:
                         assert st["msd_sorts"] >= 1, (label, env, st["msd_sorts"], st["msd_fallbacks"])
+                        # even buckets + room in the arena: pass 2 wrote into slots — unless switched off or made to overflow
+                        if "DC3HIP_NO_MSD_SLOTS" in env or "DC3HIP_MSD_SLOT_CAP" in env:
+                            assert st["msd_slot_sorts"] == 0, (label, env)
+                        elif label == f"bytes_{(1 << 25) + 77}" and len(env) == 1:     # (smaller contexts hold the smaller DC3 arena: no room)
+                            assert st["msd_slot_sorts"] >= 1, (label, env, st["msd_max_subbucket"])
             finally:
                 env_clear(env)
 
