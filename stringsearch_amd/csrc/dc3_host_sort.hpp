@@ -319,38 +319,37 @@ static int msd_sort(dc3hip_ctx *c, Rec8 *ha, Rec8 *hb, u32 n, const HiMap &hm, c
     const u32 mean = (u32)(((u64)n + n2 - 1) / n2);
     const u32 slot_cap = c->msd_slot_cap ? std::min<u32>(kMsdCapSmall, c->msd_slot_cap) : std::min<u32>(kMsdCapSmall, (2 * mean + 63) & ~63u);
     const u64 slot_words = (u64)n2 * slot_cap + kMsdTile;
-    const size_t N = (size_t)n2 * kMsdGroups;
-    const size_t need = align_up(slot_words * 8, 256) + 2 * align_up((N + 16) * 4, 256) + ((size_t)n * 2 + (64u << 20));   // (+ what the tie pass takes afterwards)
+    const size_t N = n2;                                                 // one cursor per sub-bucket
+    const size_t need = align_up(slot_words * 8, 256) + align_up((N + 16) * 4, 256) + ((size_t)n * 2 + (64u << 20));   // (+ what the tie pass takes afterwards)
     HIPC(hipMemcpyAsync(c->h_words + 20, plan, kMsdW_COUNT * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
     const u32 maxb1 = c->h_words[20 + kMsdW_MAXB1];
     if (slot_words < (1ull << 32) && (u64)maxb1 * nb1 * 4 <= (u64)n * 5 && c->arena_off + need <= c->arena_bytes) {
-      u64 *slots = nullptr; u32 *cnt2g = nullptr, *cur2 = nullptr;
+      u64 *slots = nullptr; u32 *scnt = nullptr;
       RC(arena_alloc(c, (size_t)slot_words, &slots));
-      RC(arena_alloc(c, N + 16, &cnt2g));
-      RC(arena_alloc(c, N + 16, &cur2));
-      const u32 nseg = (u32)((N + kMsdScanSeg - 1) / kMsdScanSeg);       // <= 1024
+      RC(arena_alloc(c, N + 16, &scnt));
+      const u32 nseg = (u32)((N + kMsdScanSeg - 1) / kMsdScanSeg);       // <= 256
       {
         PhaseScope ps(c, DC3HIP_PH_SORT8_DOWN, n, 5);
-        HIPC(hipMemsetAsync(cnt2g, 0, (N + 1) * sizeof(u32), c->stream));
+        HIPC(hipMemsetAsync(scnt, 0, (N + 1) * sizeof(u32), c->stream));
         const u32 grid2 = kMsdGroups * ((n / kMsdTile + nb1 + 1 + kMsdGroups - 1) / kMsdGroups);
         auto kern = (base == 0 && sh2 >= 32) ? k_msd_part<true, true, true> : k_msd_part<true, false, true>;
         hipLaunchKernelGGL(kern, dim3(grid2), dim3(kMsdNW * 64), kMsdPartSmem, c->stream, (const u64 *)wb, slots, n, base, sh2, g.d2,
-                           0u, 0u, (const u32 *)tpre, (const u32 *)bstart, nb1, (const u32 *)plan, cnt2g, n2, c->d_xcdmon, slot_cap,
+                           0u, 0u, (const u32 *)tpre, (const u32 *)bstart, nb1, (const u32 *)plan, scnt, n2, c->d_xcdmon, slot_cap,
                            (u32)(slot_words - kMsdTile));
         KCHECK();
       }
       {
         PhaseScope ps(c, DC3HIP_PH_SORT12_SCAN, N);
-        hipLaunchKernelGGL(k_msd_scan2a, dim3(nseg), dim3(1024), 0, c->stream, (const u32 *)cnt2g, (u32)N, segsum, plan);
+        hipLaunchKernelGGL(k_msd_slot_scan_a, dim3(nseg), dim3(1024), 0, c->stream, (const u32 *)scnt, (u32)N, segsum, plan);
         KCHECK();
-        hipLaunchKernelGGL(k_msd_scan2c, dim3(nseg), dim3(1024), 0, c->stream, cnt2g, (u32)N, n2, (const u32 *)segsum, cur2);
+        hipLaunchKernelGGL(k_msd_slot_scan_c, dim3(nseg), dim3(1024), 0, c->stream, scnt, (u32)N, (const u32 *)segsum);
         KCHECK();
         HIPC(hipMemcpyAsync(c->h_words + 20, plan, kMsdW_COUNT * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
       }
       HIPC(hipStreamSynchronize(c->stream));
       if (c->h_words[20 + kMsdW_MAXSUB] <= slot_cap) {
-        r.src = slots; r.dst = wb; r.start = cnt2g; r.nsub = n2; r.slot_cap = slot_cap;
+        r.src = slots; r.dst = wb; r.start = scnt; r.nsub = n2; r.slot_cap = slot_cap;
         slot_done = true;
         c->stats.msd_slot_sorts++;
       } else {

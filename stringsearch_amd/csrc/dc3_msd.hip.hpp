@@ -148,7 +148,7 @@ struct MsdPartLds {
 };
 // kSlot (pass 2 only; the host's choice when the pass-1 buckets are even and the arena has room): sub-bucket s of the output
 //   is a SLOT of slot_cap words at s * slot_cap — no sizes are needed before the pass, so the counting sweep over all words
-//   (k_msd_hist2: 8.6 GB read for 2^30 words) and its scans before the pass are not run.  cursors[s * 8] counts the words of s;
+//   (k_msd_hist2: 8.6 GB read for 2^30 words) and its scans before the pass are not run.  cursors[s] counts the words of s;
 //   a run that does not fit goes to the dump area behind the slots (dump_base) and the host — which sees the largest count
 //   after the pass — runs the counted form from the untouched input.
 template <bool kSeg, bool kHi, bool kSlot = false>
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(kMsdNW * 64) void k_msd_part(const u64 *__restrict_
       if (cnt) {
         if (kSlot) {
           const u32 s = (bkt << dbits) + tid;
-          const u32 old = atomicAdd(&cur[(size_t)s * kMsdGroups], cnt);
+          const u32 old = atomicAdd(&cur[s], cnt);
           gb = old + cnt <= slot_cap ? s * slot_cap + old : dump_base;
         } else {
           gb = atomicAdd(&cur[tid], cnt);
@@ -465,6 +465,36 @@ __global__ __launch_bounds__(1024) void k_msd_scan2c(u32 *__restrict__ cnt, u32 
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 1023) cnt[N] = base + tot;
 }
 
+// The same two launches for the slot cursors of k_msd_part<.., kSlot>: cnt[0..N) = words per sub-bucket (one entry each) ->
+// exclusive prefix in place, cnt[N] = total, plan[MAXSUB] = the largest entry.
+__global__ __launch_bounds__(1024) void k_msd_slot_scan_a(const u32 *__restrict__ cnt, u32 N, u32 *__restrict__ segsum, u32 *__restrict__ plan) {
+  __shared__ u32 tmp[16];
+  const u32 i0 = blockIdx.x * kMsdScanSeg + threadIdx.x * 8u;
+  u32 s = 0, mx = 0;
+#pragma unroll
+  for (u32 g = 0; g < 8u; g++) { const u32 v = (i0 + g < N) ? cnt[i0 + g] : 0u; s += v; mx = max(mx, v); }
+  mx = wave_reduce_max(mx);
+  u32 tot;
+  (void)block_excl_scan<16>(s, tmp, tot);
+  if (threadIdx.x == 0) segsum[blockIdx.x] = tot;
+  if (lane_id() == 0 && mx) atomicMax(&plan[kMsdW_MAXSUB], mx);
+}
+__global__ __launch_bounds__(1024) void k_msd_slot_scan_c(u32 *__restrict__ cnt, u32 N, const u32 *__restrict__ segsum) {
+  __shared__ u32 tmp[16];
+  u32 before = (threadIdx.x < blockIdx.x) ? segsum[threadIdx.x] : 0u;     // gridDim.x <= 1024
+  u32 tot;
+  (void)block_excl_scan<16>(before, tmp, tot);
+  const u32 base = tot;
+  const u32 i0 = blockIdx.x * kMsdScanSeg + threadIdx.x * 8u;
+  u32 v[8], s = 0;
+#pragma unroll
+  for (u32 g = 0; g < 8u; g++) { v[g] = (i0 + g < N) ? cnt[i0 + g] : 0u; s += v[g]; }
+  u32 ex = block_excl_scan<16>(s, tmp, tot) + base;
+#pragma unroll
+  for (u32 g = 0; g < 8u; g++) { if (i0 + g < N) cnt[i0 + g] = ex; ex += v[g]; }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 1023) cnt[N] = base + tot;
+}
+
 // Sinks of the local sort: where word x of global output index g goes (cf. RecSink / SplitSink of the LSD passes).
 // kSame: the sink also wants to know whether the word's image equals its predecessor's in the sorted order (= some
 // smaller word of its bin has the same image: equal images share every image bit, hence the sub-bucket and the bin).
@@ -517,7 +547,9 @@ __global__ __launch_bounds__(NT) void k_msd_local(const u64 *__restrict__ in, co
   __shared__ u32 cnt[NBIN + 1];
   __shared__ u32 tmp[NT / 64];
   const u32 tid = threadIdx.x;
-  const u32 begin = start[(size_t)blockIdx.x * kMsdGroups], end = start[(size_t)(blockIdx.x + 1) * kMsdGroups];
+  // (start: one entry per (sub-bucket, group) in the counted form, one per sub-bucket with slots)
+  const u32 sstr = slot_cap ? 1u : kMsdGroups;
+  const u32 begin = start[(size_t)blockIdx.x * sstr], end = start[(size_t)(blockIdx.x + 1) * sstr];
   const u32 m = end - begin;
   if (m == 0) return;
 #pragma unroll
