@@ -253,8 +253,11 @@ static int msd_launch_local(dc3hip_ctx *c, const MsdRedo &r, u32 n, Sink sink) {
 // until the caller releases its mark (redo reads them).
 static int msd_sort(dc3hip_ctx *c, Rec8 *ha, Rec8 *hb, u32 n, const HiMap &hm, const MsdGeom &g, const u32 *table,
                     const SplitSink *split, Rec8 **result, MsdRedo *redo, bool *ok, Rec8 **where, MsdPass1 *p1 = nullptr,
-                    uint8_t *same_out = nullptr) {
+                    uint8_t *same_out = nullptr, bool allow_slots = false) {
   // same_out (record form only): same_out[i] = 1 iff sorted record i has the image of record i - 1
+  // allow_slots: the caller allocates nothing large before it releases its arena mark (the whole-text order of a single
+  // device): pass 2 may take 16 bytes per word of the arena for its slots.  (Inside the recursion the level's rank inversion
+  // follows with two more record arrays, and a rank of the global mode keeps to its memory plan: the counted form.)
   // p1 != nullptr: the words do not exist yet — pass 1 makes them from the key maker (`ha` is then only the scratch of
   // pass 2); needs `table` (the counting pack kernel's)
   *ok = false; *where = ha; *result = nullptr;
@@ -315,7 +318,7 @@ static int msd_sort(dc3hip_ctx *c, Rec8 *ha, Rec8 *hb, u32 n, const HiMap &hm, c
   // pass are not run, the sizes are read off the slot cursors afterwards.  A slot that overflows (seen in the same maximum the
   // counted form checks) sends the sort through the counted form below, from the untouched output of pass 1.
   bool slot_done = false;
-  if (g.d2 > 0 && !c->no_msd_slots) {
+  if (g.d2 > 0 && allow_slots && !c->no_msd_slots) {
     const u32 mean = (u32)(((u64)n + n2 - 1) / n2);
     const u32 slot_cap = c->msd_slot_cap ? std::min<u32>(kMsdCapSmall, c->msd_slot_cap) : std::min<u32>(kMsdCapSmall, (2 * mean + 63) & ~63u);
     const u64 slot_words = (u64)n2 * slot_cap + kMsdTile;
