@@ -19,11 +19,11 @@ pytestmark = pytest.mark.gpu
 GIB = 1 << 30
 # case -> measured ms at the shipping head (MI355X); the guard is 1.2x
 MEASURED_MS = {
-    "random_1GiB": 13.3,
-    "random_1GiB_recursion_only": 40.5,
-    "random_1GiB_dup_1MB_block": 37.3,
-    "dna_1GiB": 16.8,
-    "text_1GiB": 111.0,
+    "random_1GiB": 11.5,
+    "random_1GiB_recursion_only": 39.9,
+    "random_1GiB_dup_1MB_block": 36.9,
+    "dna_1GiB": 15.0,
+    "text_1GiB": 110.0,
     "real_text_256MiB": 53.4,
 }
 SLACK = 1.2
