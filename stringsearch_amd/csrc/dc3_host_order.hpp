@@ -439,7 +439,8 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
                             Rec8 **h_out, uint8_t *f, bool *ok, int depth, u32 *emit_sa = nullptr, u32 skip = 0,
                             bool *emitted_distinct = nullptr, u32 *first_table = nullptr, bool whole_text = false,
                             const MsdGeom *mg = nullptr, u64 img_lo = 0, u64 img_span = 0, MsdPass1 *p1 = nullptr,
-                            bool *keys_distinct = nullptr) {
+                            bool *keys_distinct = nullptr, bool slots_ok = false) {
+  // slots_ok: a single device's ordering (not a rank of the global mode): the bucket ordering may write its second pass into slots
   // keys_distinct (record form): set when the tie pass settled every tied group and found no two equal keys — the caller
   // then knows that all nrec keys are distinct without counting the flags
   // p1 (only with mg->on): the records of `ha` were NOT written — the pack kernel only counted, pass 1 of the bucket
@@ -475,7 +476,7 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
     MsdRedo mredo; bool msd_ok = false;
     if (mg && mg->on) {
       Rec8 *where = ha;
-      RC(msd_sort(c, ha, hb, nrec, hm, *mg, first_table, &sink, &h, &mredo, &msd_ok, &where, p1, nullptr, whole_text));
+      RC(msd_sort(c, ha, hb, nrec, hm, *mg, first_table, &sink, &h, &mredo, &msd_ok, &where, p1, nullptr, whole_text && slots_ok));
       if (msd_ok) lp.src = const_cast<u64 *>(mredo.src);               // (non-null = "the order lives in the sink")
       else { first_table = nullptr; if (p1) RC(p1->repack(c, ha, nrec, &first_table)); }      // from scratch: `ha` in position order
     }
@@ -550,7 +551,7 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
     if (mg && mg->on) {
       MsdRedo mredo; Rec8 *where = ha;
       if (!c->no_small_ties) RC(arena_alloc(c, (size_t)nrec + 16, &same_rec));
-      RC(msd_sort(c, ha, hb, nrec, hm, *mg, first_table, nullptr, &h, &mredo, &msd_ok, &where, p1, same_rec));
+      RC(msd_sort(c, ha, hb, nrec, hm, *mg, first_table, nullptr, &h, &mredo, &msd_ok, &where, p1, same_rec, slots_ok));
       if (!msd_ok) { first_table = nullptr; if (p1) RC(p1->repack(c, ha, nrec, &first_table)); }
     }
     if (!msd_ok)
@@ -1174,7 +1175,7 @@ static int order_all_positions(dc3hip_ctx *c, KM km, Map mp, u32 m, u32 kbits, c
   bool sorted_ok = false, distinct = false, all_distinct = false;
   RC((hybrid_sort_core<KM>(c, km, kbits, hm, ha, hb, nrec, &h, f, &sorted_ok, depth, out_rank ? nullptr : out_sa, dummy,
                            &distinct, first_table, std::is_same<Map, MapText>::value && dummy == 0 && !out_rank, &mgx, 0, 0,
-                           pass1, &all_distinct)));
+                           pass1, &all_distinct, true)));
   if (sorted_ok && distinct) {
     *state = 1;                            // the tie pass already wrote the suffix array
   } else if (sorted_ok) {

@@ -255,9 +255,11 @@ static int msd_sort(dc3hip_ctx *c, Rec8 *ha, Rec8 *hb, u32 n, const HiMap &hm, c
                     const SplitSink *split, Rec8 **result, MsdRedo *redo, bool *ok, Rec8 **where, MsdPass1 *p1 = nullptr,
                     uint8_t *same_out = nullptr, bool allow_slots = false) {
   // same_out (record form only): same_out[i] = 1 iff sorted record i has the image of record i - 1
-  // allow_slots: the caller allocates nothing large before it releases its arena mark (the whole-text order of a single
-  // device): pass 2 may take 16 bytes per word of the arena for its slots.  (Inside the recursion the level's rank inversion
-  // follows with two more record arrays, and a rank of the global mode keeps to its memory plan: the counted form.)
+  // allow_slots (single device only: a rank of the global mode keeps to its memory plan and the counted form): pass 2 may take
+  // 16 bytes per word of the arena for its slots.  With a split sink they stay until the caller releases its mark (the last
+  // pass may be repeated into records: msd_redo), so the caller must not need that room — the whole-text order does not.  In
+  // the record form nothing reads them after the local pass: they are released here, before the caller's rank inversion
+  // takes its two record arrays (kept, they made the first build of a process run out of arena and be retried).
   // p1 != nullptr: the words do not exist yet — pass 1 makes them from the key maker (`ha` is then only the scratch of
   // pass 2); needs `table` (the counting pack kernel's)
   *ok = false; *where = ha; *result = nullptr;
@@ -318,12 +320,13 @@ static int msd_sort(dc3hip_ctx *c, Rec8 *ha, Rec8 *hb, u32 n, const HiMap &hm, c
   // pass are not run, the sizes are read off the slot cursors afterwards.  A slot that overflows (seen in the same maximum the
   // counted form checks) sends the sort through the counted form below, from the untouched output of pass 1.
   bool slot_done = false;
+  const ArenaMark slot_mk = arena_mark(c);
   if (g.d2 > 0 && allow_slots && !c->no_msd_slots) {
     const u32 mean = (u32)(((u64)n + n2 - 1) / n2);
     const u32 slot_cap = c->msd_slot_cap ? std::min<u32>(kMsdCapSmall, c->msd_slot_cap) : std::min<u32>(kMsdCapSmall, (2 * mean + 63) & ~63u);
     const u64 slot_words = (u64)n2 * slot_cap + kMsdTile;
     const size_t N = n2;                                                 // one cursor per sub-bucket
-    const size_t need = align_up(slot_words * 8, 256) + align_up((N + 16) * 4, 256) + ((size_t)n * 2 + (64u << 20));   // (+ what the tie pass takes afterwards)
+    const size_t need = align_up(slot_words * 8, 256) + align_up((N + 16) * 4, 256) + (split ? (size_t)n * 2 + (64u << 20) : (size_t)(1u << 20));   // (+ what the tie pass takes afterwards)
     HIPC(hipMemcpyAsync(c->h_words + 20, plan, kMsdW_COUNT * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
     const u32 maxb1 = c->h_words[20 + kMsdW_MAXB1];
@@ -357,6 +360,7 @@ static int msd_sort(dc3hip_ctx *c, Rec8 *ha, Rec8 *hb, u32 n, const HiMap &hm, c
         c->stats.msd_slot_sorts++;
       } else {
         HIPC(hipMemsetAsync(plan + kMsdW_MAXSUB, 0, sizeof(u32), c->stream));      // (the counted form takes its own maximum)
+        arena_release(c, slot_mk);
       }
     }
   }
@@ -422,6 +426,7 @@ static int msd_sort(dc3hip_ctx *c, Rec8 *ha, Rec8 *hb, u32 n, const HiMap &hm, c
     *result = reinterpret_cast<Rec8 *>(r.dst);
   }
   c->stats.msd_sorts++;
+  if (slot_done && !split) { arena_release(c, slot_mk); r.src = nullptr; r.start = nullptr; }   // (stream order: later kernels run behind the local pass)
   *redo = r;
   *ok = true;
   return E_OK;
