@@ -103,7 +103,9 @@ DC3HIP_API int32_t dc3hip_hip_versions(int32_t *compiled, int32_t *runtime);
 typedef struct dc3hip_ctx dc3hip_ctx;
 
 /* Creates a context on `device` (-1 = current) able to index texts of up to max_n bytes.
- * All device memory (text, SA, work arena) is allocated here, never inside a build. */
+ * Device memory: text (max_n + 64 bytes), suffix array (4 max_n) and a work arena of about 40 bytes per text byte (+ 224 MB),
+ * allocated here; the arena grows once, to about 44 bytes per text byte, the first time a build enters the DC3 recursion
+ * (high-entropy texts never do).  dc3hip_stats.arena_bytes / arena_peak report it. */
 DC3HIP_API int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n);
 DC3HIP_API void dc3hip_ctx_destroy(dc3hip_ctx *ctx);
 
