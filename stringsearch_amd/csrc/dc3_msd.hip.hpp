@@ -310,9 +310,11 @@ __global__ __launch_bounds__(kMsdNW * 64, 8) void k_msd_part_keys(KM km, HiMap h
   const u32 begin = tile * (u32)kMsdTile, end = min(n, begin + (u32)kMsdTile);
   const u32 nvalid = end - begin;
   xcd_note(xcdmon, g);
-  km.stage(lcode);
+  // (the code table only where the images need it — the raw image of byte alphabets and the key makers without a table do
+  //  not, and the tile then starts with its text loads instead of a table load and a barrier; the barrier in front of the
+  //  ranking orders the zeroed counters)
+  if (KM::kCodes && !hm.raw) { km.stage(lcode); __syncthreads(); }
   L.hist[tid] = 0;
-  __syncthreads();
   const u32 pb = hm.pbits + (kStrip ? dbits : 0u);                 // position bits of the stored word
   auto body = [&](auto full_tag) {
     constexpr bool kFull = decltype(full_tag)::value;               // a whole tile, every word kept: no per-word guards
@@ -341,6 +343,7 @@ __global__ __launch_bounds__(kMsdNW * 64, 8) void k_msd_part_keys(KM km, HiMap h
       }
     }
     // word k * 4 + j of thread tid is tile element t = (k * NT + tid) * 4 + j
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < kMsdIPT; k++)
       if (kFull || rk[k] != ~0u) rk[k] = atomicAdd(&L.hist[dg[k]], 1u);

@@ -558,6 +558,7 @@ __device__ __forceinline__ int window_cmp(const SymU8 &S, u32 p, u32 q, u32 nsym
 template <class Sym>
 struct Key3 {
   Sym S; u32 B;
+  static constexpr bool kCodes = false;        // (no code table: stage() is empty)
   __device__ __forceinline__ void stage(uint16_t *) const {}
   __device__ __forceinline__ Rec16 make(u32 p, const uint16_t *) const {
     return make_rec(S.get(p), S.get(p + 1), S.get(p + 2), B, p);
@@ -566,6 +567,7 @@ struct Key3 {
   __device__ __forceinline__ u64 image_hi(u32 p, const uint16_t *lds, const HiMap &hm) const { return hyb_hi(make(p, lds), hm); }
 };
 struct Key9 {
+  static constexpr bool kCodes = true;
   SymU8 S; u32 B /* sigma+1 */, B3 /* B^3 */;
   u32 deep = 0;     // tie passes only: compare this many symbols instead of the window's 9 (second attempt, few repeats)
   __device__ __forceinline__ void stage(uint16_t *lds) const { S.stage(lds); }
@@ -603,6 +605,7 @@ struct Key9 {
 // width: floor(v * mfix / 2^64), sigma^J in (2^nbits, 2^63), J <= 3L, J <= kKeyTMaxImageSyms.
 constexpr u32 kKeyTMaxImageSyms = 48;
 struct KeyT {
+  static constexpr bool kCodes = true;
   SymU8 S; u32 B, BL /* B^L */, L, sigma, J;
   u32 lg = 0;       // sigma = 2^lg (DNA: 2): v is J*lg bits put together by shifts and the image its top nbits; 0 = scale by mfix
   u32 deep = 0;     // as Key9::deep
@@ -733,6 +736,7 @@ __device__ __forceinline__ void images4(const Key3<SymU32> &km, const HiMap &hm,
 // index) — how a key maker whose image is too dear to compute inside the partition pass (KeyT) still gets an image
 // wider than the word has room for (k_msd_part_keys<KeyImg, true>: pass 1 reads 8 bytes per position as before).
 struct KeyImg {
+  static constexpr bool kCodes = false;
   const u64 *img;
   __device__ __forceinline__ void stage(uint16_t *) const {}
 };
