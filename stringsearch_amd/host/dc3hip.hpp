@@ -218,7 +218,8 @@ class GlobalLoopback {
   ~GlobalLoopback() { for (auto *g : h_) if (g) dc3hip_global_destroy(g); }
   // What the last build would take on P GPUs (the ranks here may share one): the slowest rank's own work + the transport
   // priced per collective at the most bytes a rank exchanges with one peer over a 153 GB/s xGMI link (dc3hip_gstats).
-  // (Own work of ranks that share a device: create the group under DC3HIP_DEBUG=global_device_token,global_link_gbps=153.)
+  // (Own work of ranks that share a device: create the group under DC3HIP_DEBUG=global_device_token,global_link_gbps=153
+  //  and ask after a second build — the first one of a group also allocates; sa_bench --global-ranks does both.)
   double predicted_wall_ms(double *max_work_ms = nullptr, double *max_link_ms = nullptr) const {
     double w = 0, l = 0;
     for (auto *g : h_) {

@@ -145,6 +145,20 @@ int main(int argc, char **argv) {
         same = all.sa() == one.sa();
       });
       if (!same) { std::fprintf(stderr, "\nglobal-mode result differs from the single-device result\n"); return 2; }
+      {
+        // the prediction for P GPUs, from a second (untimed) build in which ranks that share this device work one at a time
+        // (device token) and the select-or-route policy sees the xGMI link rate: a rank's work_ms is then its OWN work
+        const char *old_dbg = std::getenv("DC3HIP_DEBUG");
+        const std::string keep = old_dbg ? old_dbg : "";
+        setenv("DC3HIP_DEBUG", (keep.empty() ? std::string() : keep + ",").append("global_device_token,global_link_gbps=153").c_str(), 1);
+        {
+          dc3hip::GlobalLoopback grp(global_ranks, (int64_t)len);
+          (void)grp.sort(input);                 // (the first build of a group also allocates: not a rank's steady work)
+          (void)grp.sort(input);
+          pred = grp.predicted_wall_ms(&pw, &pl);
+        }
+        if (old_dbg) setenv("DC3HIP_DEBUG", keep.c_str(), 1); else unsetenv("DC3HIP_DEBUG");
+      }
       global_note = "dc3-hip-global(" + std::to_string(global_ranks) + ") on " + std::to_string(global_ranks) + " GPUs, predicted: " + std::to_string(pred) +
                     " ms = slowest rank's own work " + std::to_string(pw) + " ms + transport " + std::to_string(pl) + " ms at 153 GB/s per xGMI link (the row above: ranks time-sharing this GPU, incl. host transfers)";
     }
