@@ -16,7 +16,9 @@ the host (P chunks of len/P + 1 bytes on P pinned threads, one divsufsort() each
 self-test (ragged all-to-all / all-gather of known bytes through the library's RCCL communicator, every byte checked,
 ncclCommCount compared with N) and exits non-zero if it fails — a run never reports a host-staged number as xGMI.
 
-Rank 0 prints ONE JSON line.
+Rank 0 prints ONE JSON line — compact (< 4 KB, strict JSON: metric, value, roofline, cpu_baseline, verify, the recursion-only
+and per-config figures as a few numbers each); every block in full (all kernel families, the loopback table, per-level
+traces) goes to the side file named in its `detail` field (gpurun_out/bench_detail.json).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--size BYTES] [--kind random|dna|text] [--mode auto|sacapart|global]
                     [--cpu-sample-mib M] [--no-cpu] [--no-verify] [--no-extras]
@@ -33,7 +35,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from stringsearch_amd.benchlib import HBM_PEAK_GBS, KINDS, PATH_NAMES, KernelAcc, build_block, kernel_rooflines, parse_size, path_roofline  # noqa: E402
+from stringsearch_amd.benchlib import (HBM_PEAK_GBS, KINDS, PATH_NAMES, KernelAcc, build_block, compact_line, kernel_rooflines,  # noqa: E402
+                                        parse_size, path_roofline, write_detail)
 
 
 def host_cpu_model():
@@ -172,14 +175,13 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the legs that are not part of `value`: recursion-only build, text/DNA configs, end-to-end FFI")
     ap.add_argument("--no-recursion-line", action="store_true", help="(kept for old command lines) same as --no-extras")
+    ap.add_argument("--detail", type=str, default=None, help="where the full record goes (default gpurun_out/bench_detail.json)")
     ap.add_argument("--dump-stats", type=str, default=None, help="write the last build's dc3hip_stats as JSON here")
     args = ap.parse_args()
     if args.no_recursion_line:
         args.no_extras = True
 
     import numpy as np
-    import torch            # first: libdc3hip.so then shares the HIP runtime torch loaded
-    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -192,13 +194,19 @@ def main():
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}", file=sys.stderr)
         sys.exit(2)
-    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
-    # one rank per GPU; DC3HIP_BENCH_BACKEND=gloo lets several ranks share one GPU (plumbing test on 1-GPU boxes)
+    # One GPU: nothing of torch is needed, and nothing of it is imported — the library then runs on the HIP runtime it was
+    # compiled against (`hip_runtime.match`), not on the older one a PyTorch wheel maps first (profiles/r05_crash_hunt.md).
+    # N > 1: torch.distributed is the rendezvous (and must be imported BEFORE the library is loaded: one runtime per process).
+    use_dist = world > 1
+    torch = dist = None
     backend = os.environ.get("DC3HIP_BENCH_BACKEND", "nccl")
-    local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
-    torch.cuda.set_device(local_rank)
-    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ      # launched by torch.distributed.run
     if use_dist:
+        import torch
+        import torch.distributed as dist
+        assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
+        # one rank per GPU; DC3HIP_BENCH_BACKEND=gloo lets several ranks share one GPU (plumbing test on 1-GPU boxes)
+        local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+        torch.cuda.set_device(local_rank)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -207,13 +215,24 @@ def main():
 
     import stringsearch_amd as ss
 
+    if not use_dist:
+        ndev = ss.device_count()
+        assert ndev > 0, "bench.py needs a GPU (there is no CPU path): " + ss.last_error()
+        local_rank = local_rank % ndev
+
     per_gpu = parse_size(args.size)
     kind = KINDS[args.kind]
 
     def barrier():
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
+        ss.device_synchronize(local_rank)       # hipDeviceSynchronize through the C ABI (all streams of this rank's device)
+
+    def emit(full):
+        """rank 0's ONE line: the compact object (< 4 KB, strict JSON); every block in full goes to the side file it names"""
+        full["hip_runtime"] = ss.hip_versions()
+        print(compact_line(full, write_detail(full, args.detail)), flush=True)
 
     # ---- N > 1: the library's own transport first — created strictly (no silent fallback) and self-tested
     G = None
@@ -267,7 +286,7 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps(out))
+            emit(out)
         return
 
     from stringsearch_amd.partition import rank_chunk
@@ -548,7 +567,7 @@ def main():
                         sac["value"] = None
                         sac["value_mode"] = "none (the global leg did not finish: see global_mode.error; the sacapart leg is value_sacapart)"
                         sac["transport_selftest"] = selftest
-                        print(json.dumps(sac), flush=True)
+                        emit(sac)
                     os._exit(6)
             wd = threading.Timer(args.global_timeout, give_up, args=(f"no result after {args.global_timeout} s",))
             wd.daemon = True
@@ -582,10 +601,9 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        # HIP_VERSION the library was compiled against vs the runtime it really ran on (torch is imported first here, so
-        # it is the wheel's): profiles/r05_crash_hunt.md
-        out["hip_runtime"] = ss.hip_versions()
-        print(json.dumps(out))
+        # (`hip_runtime`: HIP_VERSION the library was compiled against vs the runtime it really ran on — the wheel's when
+        # torch had to be imported, N > 1: profiles/r05_crash_hunt.md)
+        emit(out)
 
 
 if __name__ == "__main__":

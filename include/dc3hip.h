@@ -93,6 +93,9 @@ DC3HIP_API void dc3hip_release_cache(void);
 DC3HIP_API const char *dc3hip_version(void);
 DC3HIP_API const char *dc3hip_last_error(void); /* thread-local, never NULL */
 DC3HIP_API int32_t dc3hip_device_count(void);   /* number of visible HIP devices, <0 on error */
+/* Waits until every stream of `device` (-1 = current) has drained: what a host program without HIP bindings of its own
+ * brackets a timed region with (bench.py at one GPU runs without torch, on the HIP runtime the library was compiled for). */
+DC3HIP_API int32_t dc3hip_device_synchronize(int32_t device);
 /* HIP_VERSION the library was compiled against and hipRuntimeGetVersion() of the runtime the process really runs on (a
  * host program that maps its own libamdhip64 first — a PyTorch wheel does — makes the library run on that one).  Returns 1
  * when major and minor agree, 0 when they differ (the library also says so once on stderr), <0 on error. */

@@ -140,6 +140,7 @@ SYMBOLS = {
     "dc3hip_hip_versions": (ctypes.c_int32, [ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "dc3hip_last_error": (ctypes.c_char_p, []),
     "dc3hip_device_count": (_i32, []),
+    "dc3hip_device_synchronize": (_i32, [_i32]),
     "dc3hip_ctx_create": (_i32, [ctypes.POINTER(_vp), _i32, _i64]),
     "dc3hip_ctx_destroy": (None, [_vp]),
     "dc3hip_ctx_set_text": (_i32, [_vp, _vp, _i64]),

@@ -28,12 +28,24 @@ def _debug_init():
 _debug_init()
 
 
+# every switch name the library looks up in DC3HIP_DEBUG (dbg_on / dbg_off / dbg_num in csrc/; tests/test_debug_switches.py
+# compares this list with the sources)
+DEBUG_NAMES = frozenset("""
+global_device_token global_force_dist global_force_wide global_link_gbps global_no_route global_no_select global_no_text_order
+hybrid12_min msd_min msd_slot_cap no_9bit no_discard no_doubling no_fullsort no_fuse_names no_hybrid no_hybrid12 no_hybrid8
+no_long_keys no_merge_keys64 no_msd no_msd_slots no_pack_count no_pack_strip no_raw_image no_rec12 no_small_ties no_split_emit
+no_ssort no_text_shortcut no_tup8 no_tup_rec8 no_tup_scatter no_wide_deepen no_wide_msd no_wide_window no_xcd_map pack_fuse
+ssort_min ssort_rec12 ssort_verify text_order12 tup_bigtile tup_counted tup_scatter_min wide_corrupt wide_msd_min
+""".split())
+
+
 def adopt_legacy_env():
     """Tools and tests only: fold old-style one-variable-per-switch settings found in the environment (DC3HIP_NO_HYBRID=1,
-    DC3HIP_MSD_MIN=4096, ...) into DC3HIP_DEBUG — the library itself no longer reads them."""
+    DC3HIP_MSD_MIN=4096, ...) into DC3HIP_DEBUG — the library itself no longer reads them.  Only names the library knows
+    as switches (DEBUG_NAMES) are taken: every other DC3HIP_* variable (DC3HIP_RUN_HOSTMOCK, DC3HIP_BENCH_*, a typo) stays
+    where it is."""
     import os
-    skip = ("DC3HIP_BENCH_", "DC3HIP_TEST_", "DC3HIP_SKIP_", "DC3HIP_PERF_GUARD_")
-    for k in [k for k in os.environ if k.startswith("DC3HIP_") and k not in POLICY_VARS and not k.startswith(skip)]:
+    for k in [k for k in os.environ if k.startswith("DC3HIP_") and k not in POLICY_VARS and debug_name(k) in DEBUG_NAMES]:
         debug_set(k, os.environ.pop(k))
 
 
@@ -107,6 +119,10 @@ def release_cache():
 
 def device_count():
     return int(lib().dc3hip_device_count())
+
+
+def device_synchronize(device=-1):
+    _check(lib().dc3hip_device_synchronize(device))
 
 
 def _check(rc):

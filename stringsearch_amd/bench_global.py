@@ -15,7 +15,9 @@ XGMI_LINK_GBS = 153.0         # per direction and link (prompt / MI355X guide: 7
 def global_total(total, kind):
     """(bytes of the one text, wide?, clipped?): beyond DC3HIP_MAX_N the library switches to 64-bit positions (wide mode) —
     high-entropy inputs only, so the low-entropy text generator is clipped to the 32-bit limit instead."""
-    wide = (total > MAX_N or "global_force_wide" in os.environ.get("DC3HIP_DEBUG", "").split(",")) and kind != 2
+    forced = any(k == "global_force_wide" and v != "0"            # "name" and "name=1" alike (dbg_on in the library)
+                 for k, _, v in (tok.strip().partition("=") for tok in os.environ.get("DC3HIP_DEBUG", "").split(",")))
+    wide = (total > MAX_N or forced) and kind != 2
     clipped = total > MAX_N and not wide
     return (MAX_N if clipped else total), wide, clipped
 

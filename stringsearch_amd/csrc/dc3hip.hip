@@ -71,6 +71,12 @@ int32_t dc3hip_device_count(void) {
   return n;
 }
 
+int32_t dc3hip_device_synchronize(int32_t device) {
+  if (device >= 0) HIPC(hipSetDevice(device));
+  HIPC(hipDeviceSynchronize());
+  return E_OK;
+}
+
 static int ctx_create_impl(dc3hip_ctx **out, int32_t device, int64_t max_n, dc3hip_ctx *arena_from);
 int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) { return ctx_create_impl(out, device, max_n, nullptr); }
 // arena_from != nullptr: the new context works in that context's arena instead of allocating its own (the lender must not

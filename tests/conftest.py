@@ -53,6 +53,21 @@ def env_clear(keys):
             ss.debug_unset(k)
 
 
+def bench_line(stdout):
+    """(compact line, full record of the side file) of a bench.py run: the LAST stdout line must be one strict-JSON object
+    below 4 KB (what the driver's parser takes: BENCH_r05.json had `parsed: null` for a 31 KB line) that names its detail file."""
+    last = stdout.rstrip("\n").splitlines()[-1]
+    assert len(last.encode()) < 4096, len(last)
+
+    def no_const(x):
+        raise AssertionError(f"non-finite constant {x} in the bench line")
+    line = json.loads(last, parse_constant=no_const)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in line, k
+    full = json.load(open(os.path.join(ROOT, line["detail"])))
+    return line, full
+
+
 class Oracle:
     """ctypes view of oracle/liboracle_dc3.so (+ oracle/_ref/libdivsufsort_ref.so when built).
     Test infrastructure only."""

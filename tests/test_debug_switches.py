@@ -51,3 +51,43 @@ def test_the_library_reads_few_variables():
             sites += re.findall(r'getenv\("([A-Z0-9_]+)"\)', code)
     assert len(sites) <= 12, sites
     assert set(sites) <= set(ss.POLICY_VARS), set(sites) - set(ss.POLICY_VARS)
+
+
+def _names_in_sources():
+    names = set()
+    for f in glob.glob(os.path.join(ROOT, "stringsearch_amd", "csrc", "*.hpp")) + glob.glob(os.path.join(ROOT, "stringsearch_amd", "csrc", "*.hip")):
+        names |= set(re.findall(r'dbg_(?:on|off|num|real)\("([a-z0-9_]+)"', open(f).read()))
+    return names
+
+
+def test_debug_names_list_equals_what_the_sources_look_up():
+    assert _names_in_sources() == set(ss.api.DEBUG_NAMES), _names_in_sources() ^ set(ss.api.DEBUG_NAMES)
+
+
+def test_gate_variables_of_the_test_suite_survive_adoption():
+    """(round-5 advice) adopt_legacy_env used to swallow every unknown DC3HIP_* name: DC3HIP_RUN_HOSTMOCK=1 was gone before
+    tests/test_hostmock.py evaluated its skipif, and DC3HIP_DEBUG gained a stray run_hostmock=1."""
+    os.environ["DC3HIP_RUN_HOSTMOCK"] = "1"
+    os.environ["DC3HIP_NO_SUCH_SWITCH"] = "1"
+    try:
+        ss.adopt_legacy_env()
+        assert os.environ.get("DC3HIP_RUN_HOSTMOCK") == "1" and os.environ.get("DC3HIP_NO_SUCH_SWITCH") == "1"
+        assert "run_hostmock" not in _cur() and "no_such_switch" not in _cur()
+    finally:
+        os.environ.pop("DC3HIP_RUN_HOSTMOCK", None)
+        os.environ.pop("DC3HIP_NO_SUCH_SWITCH", None)
+
+
+def test_bench_global_reads_force_wide_in_either_spelling():
+    from stringsearch_amd.bench_global import global_total
+    before = os.environ.get("DC3HIP_DEBUG")
+    try:
+        for v, want in (("global_force_wide", True), ("global_force_wide=1", True), ("msd_min=4096,global_force_wide=1", True),
+                        ("global_force_wide=0", False), ("", False)):
+            os.environ["DC3HIP_DEBUG"] = v
+            assert global_total(1 << 20, 0)[1] is want, v
+    finally:
+        if before is None:
+            os.environ.pop("DC3HIP_DEBUG", None)
+        else:
+            os.environ["DC3HIP_DEBUG"] = before

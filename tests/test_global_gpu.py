@@ -232,24 +232,24 @@ def test_bench_global_two_processes_on_one_gpu(ss, oracle, tmp_path):
     """bench.py --mode global as the driver would launch it (python -m torch.distributed.run, 2 processes), both ranks on
     GPU 0 with the host-staged transport over gloo (RCCL refuses two ranks on one device): the rank-0 line is well formed
     and the dumped shards concatenate to the reference suffix array of the whole text."""
-    import json, subprocess, sys, socket
-    from conftest import ROOT
+    import subprocess, sys, socket
+    from conftest import ROOT, bench_line
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     size = 3 << 20
     for kind, extra in (("random", {}), ("text", {"DC3HIP_GLOBAL_LOCAL_MAX": "4096"}), ("random", {"DC3HIP_DEBUG": "global_force_wide"})):
         env2 = dict(os.environ, DC3HIP_BENCH_BACKEND="gloo", DC3HIP_BENCH_DUMP_SA=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--mode", "global", "--size", str(size),
-               "--kind", kind, "--steps", "2", "--warmup", "1"]
+               "--kind", kind, "--steps", "2", "--warmup", "1", "--detail", str(tmp_path / "detail.json")]
         p = subprocess.run(cmd, env=env2, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, (p.stdout[-1000:], p.stderr[-3000:])
-        line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+        line, full = bench_line(p.stdout)
         assert line["n_gpus"] == 2 and "global SA" in line["config"]["partitioning"] and line["config"]["total_bytes"] == 2 * size
         if extra.get("DC3HIP_DEBUG"):     # the 64-bit-position mode of texts beyond 2^32 bytes, two processes
             assert line["verify"]["shards_tile_0_n"] and line["verify"]["global_sufcheck"] == 0 and "64-bit" in line["config"]["workload"]
         else:
             assert line["verify"]["shards_tile_0_n"] and line["verify"]["equal_single_device_checksum"]
-        assert all(b > 0 for b in line["interconnect"]["bytes_in_per_rank_per_step"]) and line["interconnect"]["comm_ms"] > 0
+        assert all(b > 0 for b in full["interconnect"]["bytes_in_per_rank_per_step"]) and line["interconnect"]["comm_ms"] > 0
         assert line["transport_selftest"]["passed"] is True and line["transport_selftest"]["ranks_seen_by_transport"] == 2
         text = oracle.gen(2 * size, 2, {"random": 0, "text": 2}[kind])
         got = np.concatenate([np.load(tmp_path / f"gshard_{r}.npy") for r in range(2)])

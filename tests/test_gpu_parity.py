@@ -1113,31 +1113,32 @@ def test_bench_two_ranks_on_one_gpu_matches_oracle(ss, oracle, tmp_path):
     threads) and the transport self-test; every rank's sacapart chunk SA and the concatenated global shards are compared
     with the oracle."""
     import subprocess, sys, socket
-    from conftest import ROOT
+    from conftest import ROOT, bench_line
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, DC3HIP_BENCH_BACKEND="gloo", DC3HIP_BENCH_DUMP_SA=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0")
     size = 4 << 20
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", str(size), "--steps", "2",
            "--warmup", "1"]
+    cmd += ["--detail", str(tmp_path / "detail.json")]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
-    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    line, full = bench_line(p.stdout)
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["total_bytes"] == 2 * size
     # the global leg defines `value` ...
     assert line["value_mode"].startswith("global") and "global SA" in line["config"]["partitioning"]
     ic = line["interconnect"]
-    assert all(b > 0 for b in ic["bytes_in_per_rank_per_step"]) and all(b > 0 for b in ic["bytes_out_per_rank_per_step"])
-    assert ic["comm_ms"] > 0 and "host-staged" in ic["transport"]          # (says so: this is not an xGMI number)
+    assert ic["bytes_in_max_per_step"] > 0 and ic["comm_ms"] > 0 and "host-staged" in ic["transport"]          # (says so: this is not an xGMI number)
+    assert all(b > 0 for b in full["interconnect"]["bytes_in_per_rank_per_step"]) and all(b > 0 for b in full["interconnect"]["bytes_out_per_rank_per_step"])
     assert line["verify"]["shards_tile_0_n"] and line["verify"]["equal_single_device_checksum"]
     # ... after the transport self-test ...
     tst = line["transport_selftest"]
     assert tst["passed"] is True and tst["ranks_seen_by_transport"] == 2 and tst["world_size"] == 2
     # ... with the sacapart leg, the partitioned CPU baseline and the roofline beside it
     sp = line["sacapart"]
-    assert sp["value"] > 0 and sp["ms_per_step"] > 0 and "sacapart" in sp["config"]["partitioning"]
+    assert sp["value"] > 0 and sp["ms_per_step"] > 0 and "sacapart" in full["sacapart"]["config"]["partitioning"]
     cb = line["cpu_baseline"]
-    assert cb["cores"] == 2 and cb["value"] > 0 and "2 chunks of len/2+1" in cb["sample"] and len(cb["per_thread_seconds"]) == 2
+    assert cb["cores"] == 2 and cb["value"] > 0 and "2 chunks of len/2+1" in cb["sample"] and len(full["cpu_baseline"]["per_thread_seconds"]) == 2
     assert line["roofline"] is None or line["roofline"]["bound"] == "hbm"
     from stringsearch_amd.partition import chunk_bounds
     full = oracle.gen(2 * size, 2, 0)
@@ -1155,22 +1156,23 @@ def test_bench_gpus_2_without_a_launcher(ss, oracle, tmp_path):
     as a fresh child (python -m torch.distributed.run ...), relays rank 0's one JSON line and the exit code.  Same keys as
     the launched form above; both ranks on GPU 0 (DC3HIP_BENCH_BACKEND=gloo, host-staged transport)."""
     import subprocess, sys
-    from conftest import ROOT
+    from conftest import ROOT, bench_line
     env = dict(os.environ, DC3HIP_BENCH_BACKEND="gloo", DC3HIP_BENCH_DUMP_SA=str(tmp_path), HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     size = 4 << 20
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "4MiB", "--steps", "2", "--warmup", "1"],
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "4MiB", "--steps", "2", "--warmup", "1",
+                        "--detail", str(tmp_path / "detail.json")],
                        env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     assert "no launcher around --gpus 2" in p.stderr
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, lines
-    line = json.loads(lines[0])
+    line, full = bench_line(p.stdout)
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["total_bytes"] == 2 * size
     assert line["value"] > 0 and line["value_mode"].startswith("global") and "global SA" in line["config"]["partitioning"]
     ic = line["interconnect"]
-    assert all(b > 0 for b in ic["bytes_in_per_rank_per_step"]) and ic["comm_ms"] > 0 and "host-staged" in ic["transport"]
+    assert all(b > 0 for b in full["interconnect"]["bytes_in_per_rank_per_step"]) and ic["comm_ms"] > 0 and "host-staged" in ic["transport"]
     assert line["verify"]["shards_tile_0_n"] and line["verify"]["equal_single_device_checksum"]
     tst = line["transport_selftest"]
     assert tst["passed"] is True and tst["ranks_seen_by_transport"] == 2 and tst["world_size"] == 2

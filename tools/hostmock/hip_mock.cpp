@@ -99,6 +99,7 @@ hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t st) {
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { MockStream *m = new MockStream{kStreamMagic, t_device}; *s = reinterpret_cast<hipStream_t>(m); return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t s) { check_stream(s); MockStream *m = reinterpret_cast<MockStream *>(s); m->magic = 0; delete m; return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t s) { check_stream(s); return hipSuccess; }
+hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t *e) { *e = reinterpret_cast<hipEvent_t>(new MockEvent{kEventMagic}); return hipSuccess; }
 hipError_t hipEventDestroy(hipEvent_t e) { MockEvent *m = reinterpret_cast<MockEvent *>(e); if (m->magic != kEventMagic) die("hipEventDestroy of a dead event", e); m->magic = 0; delete m; return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) { check_stream(s); if (reinterpret_cast<MockEvent *>(e)->magic != kEventMagic) die("hipEventRecord on a dead event", e); return hipSuccess; }
