@@ -556,15 +556,19 @@ static int build_alphabet(dc3hip_ctx *c, u32 *sigma_out) {
 // (*whole_text).  Otherwise the order, filtered down to level 1's samples with the dense ranks of the windows as
 // their names, still serves level 1 (*pre): a name built from a window LONGER than the K-S triple orders the samples
 // consistently and equal names still imply equal triples, which is all lib.rs:78-104 needs of a name.
+// km_pred / hm_pred (beyond 2^31 positions): the key maker and map of the image pass 1 really sorts by — d1 bits wider than
+// the 32 image bits of the word — so that the tie prediction is that of the words the tie pass will meet.
 template <class KM>
-static int try_text_order(dc3hip_ctx *c, KM km, u64 BL, const HiMap &hm, u32 sigma, bool *whole_text, Presort *pre) {
+static int try_text_order(dc3hip_ctx *c, KM km, u64 BL, const HiMap &hm, u32 sigma, bool *whole_text, Presort *pre,
+                          const KM *km_pred = nullptr, const HiMap *hm_pred = nullptr) {
   const int64_t n = c->n;
   u32 kbits = 0;                          // of the full key (limb base BL)
   { unsigned __int128 mx = (unsigned __int128)BL * BL * BL - 1; while (mx) { kbits++; mx >>= 1; } }
   double pred = 1.0;
-  RC(predict_tie_fraction_pos<KM>(c, km, (u32)n, hm, &pred));
+  if (km_pred && hm_pred) RC(predict_tie_fraction_img<KM>(c, *km_pred, (u32)n, *hm_pred, &pred));
+  else RC(predict_tie_fraction_pos<KM>(c, km, (u32)n, hm, &pred));
   c->stats.level_tie_pred[0] = pred;
-  if (!text_order_worth_trying(pred, (u64)n, hm.nbits)) return E_OK;
+  if (!text_order_worth_trying(pred, (u64)n, hm_pred ? hm_pred->nbits : hm.nbits)) return E_OK;
   const u32 m0 = (u32)((n + 2) / 3), m1 = m0 + (u32)(n / 3);            // level 1 = string of m1 names
   const u32 m02_1 = (m1 + 2) / 3 + m1 / 3;                              // its samples (incl. the dummy)
   // The filtered order (2 * m02_1 words < n) lives in the output buffer: the optimistic SA written there
@@ -695,6 +699,9 @@ static int try_text_order12(dc3hip_ctx *c, KM km, u64 BL, const HiMap &hm, u32 s
   return E_OK;
 }
 
+// largest text ordered as 8-byte words: its 2^20 sub-buckets average n / 2^20 words and the local sort holds 4096
+// (Poisson: mean 3530 + 5.5 sigma = 3857)
+static constexpr u64 kText8MaxN = 3700000000ull;
 // the device-resident build proper: SA of c->d_text[0..n) into c->d_sa
 static int build_core(dc3hip_ctx *c) {
   const int64_t n = c->n;
@@ -715,7 +722,15 @@ static int build_core(dc3hip_ctx *c) {
       // them is the suffix array (the same test level 1 would make on its triples, without building level 1)
       // 12-byte records (image beside the position) once positions take all 32 bits; DC3HIP_TEXT_ORDER12=1/0 forces
       // / forbids them (tests).  Image width: log2 n + 4.2 bits, rounded up to whole 9-bit digits.
-      const bool wide = c->text_order12 >= 0 ? c->text_order12 == 1 : bits_of((u64)n - 1) >= 32;
+      // Round 6: 8-byte words up to kText8MaxN positions.  Pass 1 of the bucket ordering makes its words from an image d1 = 10
+      // bits wider than the word has room for and drops the bucket's own bits (MsdPass1Keys::strip), so a word with a 32-bit
+      // position still orders by a 42-bit image: 2^19 tied pairs expected among 2^31 random windows, not 39 % of them.
+      // The 12-byte records remain for what that needs and does not have (no bucket ordering on this device, switched off
+      // by a test) and for texts whose mean sub-bucket (n / 2^20) would pass the local sort's capacity.
+      const bool big = bits_of((u64)n - 1) >= 32;
+      const bool strip8 = big && !c->no_msd && c->pack_fuse && !c->no_pack_strip && (u64)n >= c->msd_min && (u64)n <= kText8MaxN;
+      const bool wide = c->text_order12 >= 0 ? c->text_order12 == 1 : (big && !strip8);
+      constexpr u32 kStripBits = 10;                 // msd_geometry's d1 for 2^29 words and more
       const u32 ibits = std::min<u32>(63, 9 * (u32)ceil((log2((double)n) + 4.2) / 9.0));
       if (9.0 * sym_bits >= need_bits && B3 * B3 * B3 > 0x7fffffffull) {
         Key9 km; km.S = S; km.B = (u32)Bq; km.B3 = (u32)B3;
@@ -726,14 +741,21 @@ static int build_core(dc3hip_ctx *c) {
         // (HiMap::raw) — under one bit per symbol given away against the scaled key, and none of its arithmetic
         hm.raw = sigma > 128 && !hm.exact && !c->no_raw_image ? 1u : 0u;
         if (wide) RC(try_text_order12<Key9>(c, km, B3, hm, sigma, &whole_text, &pre));
-        else RC(try_text_order<Key9>(c, km, B3, hm, sigma, &whole_text, &pre));
+        else if (strip8 && !hm.exact && kbits >= hm.nbits + kStripBits) {
+          HiMap hp = make_himap(B3, kbits, (u32)n, hm.pbits - kStripBits);
+          hp.raw = hm.raw;
+          RC(try_text_order<Key9>(c, km, B3, hm, sigma, &whole_text, &pre, &km, &hp));
+        } else RC(try_text_order<Key9>(c, km, B3, hm, sigma, &whole_text, &pre));
       } else if (!c->no_long_keys) {
         // small alphabets: limbs of L > 3 symbols (as many as fit 32 bits), 3L-symbol windows
         u32 L = 1; u64 BL = Bq;
         while (L < 20 && BL * Bq <= 0xffffffffull) { BL *= Bq; L++; }
         KeyT km; HiMap hm;
         if (L > 3 && 3.0 * L * sym_bits >= need_bits && make_keyt(S, sigma, L, BL, (u32)n, &km, &hm, wide ? ibits : 0u)) {
+          KeyT kp; HiMap hp;
           if (wide) RC(try_text_order12<KeyT>(c, km, BL, hm, sigma, &whole_text, &pre));
+          else if (strip8 && make_keyt(S, sigma, L, BL, (u32)n, &kp, &hp, hm.nbits + kStripBits))
+            RC(try_text_order<KeyT>(c, km, BL, hm, sigma, &whole_text, &pre, &kp, &hp));
           else RC(try_text_order<KeyT>(c, km, BL, hm, sigma, &whole_text, &pre));
         }
       }

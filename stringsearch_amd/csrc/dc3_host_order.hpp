@@ -462,7 +462,7 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
   Rec8 *h = nullptr;
   bool msd_ok = false;                 // (record form) the bucket ordering delivered, with its same-image bytes in same_rec
   uint8_t *same_rec = nullptr;
-  if (emit_sa && emitted_distinct && skip == 0 && !c->no_small_ties && !c->no_split_emit && hm.pbits < 32) {
+  if (emit_sa && emitted_distinct && skip == 0 && !c->no_small_ties && !c->no_split_emit && hm.pbits <= 32) {
     // optimistic end of the whole-text order: the last pass writes positions to the SA buffer and 32 image bits to a
     // side array; the tie pass settles the tied groups in place.  Complete unless a key repeats or a group is large.
     // (what the tie pass reads: a "same image as the record before" byte from the bucket ordering, or the 32 image bits
@@ -791,6 +791,28 @@ static int predict_tie_fraction_pos(dc3hip_ctx *c, KM km, u32 n, const HiMap &hm
   KCHECK();
   u32 ts = 0;
   RC(sample_ties(c, a, ns, hm.pbits, &ts));
+  const double fs = (double)ts / (double)ns;
+  const double ratio = (double)(n - 1) / (double)(ns > 1 ? ns - 1 : 1);
+  *pred = fs >= 1.0 ? 1.0 : 1.0 - pow(1.0 - fs, ratio);
+  arena_release(c, mk);
+  return E_OK;
+}
+
+// The same prediction from the images alone (hm.nbits <= 63 bits, no position beside them): what the whole-text order beyond
+// 2^31 positions uses — its words carry a 32-bit position and 32 image bits, but pass 1 of the bucket ordering strips the
+// bucket's d1 bits off an image that much wider (MsdPass1Keys::strip), and the ties that matter are those of the wider image.
+template <class KM>
+static int predict_tie_fraction_img(dc3hip_ctx *c, KM km, u32 n, const HiMap &hm, double *pred) {
+  const ArenaMark mk = arena_mark(c);
+  const u32 stride = std::max<u32>(1, n >> 20);
+  const u32 ns = (n - 1) / stride + 1;
+  Rec8 *a = nullptr;
+  RC(arena_alloc(c, (size_t)ns, &a));
+  PhaseScope ps(c, DC3HIP_PH_PACK, ns);
+  hipLaunchKernelGGL((k_pack_image12_pos<KM>), dim3(grid_for(c, ns)), dim3(kBlock), 0, c->stream, km, ns, stride, hm, a);
+  KCHECK();
+  u32 ts = 0;
+  RC(sample_ties(c, a, ns, 1u, &ts));
   const double fs = (double)ts / (double)ns;
   const double ratio = (double)(n - 1) / (double)(ns > 1 ? ns - 1 : 1);
   *pred = fs >= 1.0 ? 1.0 : 1.0 - pow(1.0 - fs, ratio);

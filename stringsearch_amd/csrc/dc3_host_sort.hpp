@@ -170,11 +170,11 @@ struct MsdGeom {
 };
 static constexpr u32 kMsdCapSmall = 2048, kMsdCapLarge = 4096;     // sub-bucket capacities of the two local-sort shapes
 // Geometry for nrec words with hm's layout, or .on = false when the bucket ordering does not apply (switched off, too
-// few records, 32-bit positions, or too few image bits below the bucket bits for the local sort's bins).
+// few records, or too few image bits below the bucket bits for the local sort's bins).
 // img_lo / img_span: the records hold only the images in [img_lo, img_lo + img_span) (0 = the whole range).
 static MsdGeom msd_geometry(const dc3hip_ctx *c, u32 nrec, const HiMap &hm, u64 img_lo = 0, u64 img_span = 0) {
   MsdGeom g;
-  if (c->no_msd || nrec < c->msd_min || nrec < 4096 || hm.pbits >= 32 || hm.pbits + hm.nbits > 64) return g;
+  if (c->no_msd || nrec < c->msd_min || nrec < 4096 || hm.pbits > 32 || hm.pbits + hm.nbits > 64) return g;
   g.img_lo = img_span ? img_lo : 0;
   g.ebits = img_span ? std::min<u32>(hm.nbits, bits_of(img_span - 1)) : hm.nbits;
   const u32 lg = bits_of((u64)nrec - 1);                       // ceil(log2 nrec)
@@ -327,10 +327,17 @@ static int msd_sort(dc3hip_ctx *c, Rec8 *ha, Rec8 *hb, u32 n, const HiMap &hm, c
     const u64 slot_words = (u64)n2 * slot_cap + kMsdTile;
     const size_t N = n2;                                                 // one cursor per sub-bucket
     const size_t need = align_up(slot_words * 8, 256) + align_up((N + 16) * 4, 256) + (split ? (size_t)n * 2 + (64u << 20) : (size_t)(1u << 20));   // (+ what the tie pass takes afterwards)
-    HIPC(hipMemcpyAsync(c->h_words + 20, plan, kMsdW_COUNT * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
-    HIPC(hipStreamSynchronize(c->stream));
-    const u32 maxb1 = c->h_words[20 + kMsdW_MAXB1];
-    if (slot_words < (1ull << 32) && (u64)maxb1 * nb1 * 4 <= (u64)n * 5 && c->arena_off + need <= c->arena_bytes) {
+    // what the host knows by itself comes first: slots that index with 32 bits, that hold the mean sub-bucket with room to
+    // spare (beyond 2^31 words the mean passes the local sort's small shape: counted form), an arena with room.  Only then
+    // is the largest pass-1 bucket read back (a pipeline drain that a sort without slots must not pay).
+    const bool host_ok = slot_words < (1ull << 32) && (c->msd_slot_cap || (u64)mean * 5 <= (u64)slot_cap * 4) && c->arena_off + need <= c->arena_bytes;
+    u32 maxb1 = 0;
+    if (host_ok) {
+      HIPC(hipMemcpyAsync(c->h_words + 20, plan, kMsdW_COUNT * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+      HIPC(hipStreamSynchronize(c->stream));
+      maxb1 = c->h_words[20 + kMsdW_MAXB1];
+    }
+    if (host_ok && (u64)maxb1 * nb1 * 4 <= (u64)n * 5) {
       u64 *slots = nullptr; u32 *scnt = nullptr;
       RC(arena_alloc(c, (size_t)slot_words, &slots));
       RC(arena_alloc(c, N + 16, &scnt));

@@ -979,9 +979,10 @@ def test_beyond_2pow31_needs_64bit_indices(ss):
         c.build()
         assert c.sufcheck() == 0
         st = c.stats()
-        # 32-bit images of 2^31 positions tie 39 % even on random symbols; the whole-text order (39-symbol windows) is
-        # taken all the same because the image width alone explains the ties
+        # the whole-text order (39-symbol windows) on 8-byte words: a 32-bit position beside 32 image bits, the image 10 bits
+        # wider inside partition pass 1 (round 6; 12-byte records before) — next to nothing ties
         assert st["level_n"][0] == n and st["levels"] == 1 and st["text_sort_state"] == 1, st["level_sorted"]
+        assert st["msd_sorts"] == 1 and st["msd_fallbacks"] == 0 and st["level_tied"][0] < n // 256, (st["msd_sorts"], st["level_tied"])
         chk = c.checksum()
         with pytest.raises(ss.Dc3HipError) as ei:
             c.sa(np.int32)                         # int32 cannot hold these positions
@@ -1031,21 +1032,25 @@ def test_sample_count_beyond_2pow31(ss):
     > 512 top buckets, 32-bit position fields completely used).  Regression test for a u32 midpoint overflow
     that only showed above 3.2e9 bytes."""
     n = 3_400_000_000
-    with ss.Context(n) as c:                       # default: the whole-text order on 12-byte records, one level
+    with ss.Context(n) as c:                       # default: the whole-text order on 8-byte words (bucket ordering), one level
         c.generate(n, 9, 0)
         c.build()
         assert c.sufcheck() == 0
-        assert c.stats()["levels"] == 1 and c.stats()["text_sort_state"] == 1
+        st = c.stats()
+        assert st["levels"] == 1 and st["text_sort_state"] == 1 and st["msd_sorts"] == 1 and st["msd_fallbacks"] == 0
+        assert st["level_tied"][0] < n // 256, st["level_tied"]          # (42-bit images: ~1.3 M tied pairs expected)
         chk = c.checksum()
-    ss.debug_set("text_order12", "0")        # the recursion at this size (8-byte images tie too much here)
-    try:
-        with ss.Context(n) as c:
-            c.generate(n, 9, 0)
-            c.build()
-            assert c.sufcheck() == 0 and c.checksum() == chk
-            assert c.stats()["level_n"][1] > (1 << 31)
-    finally:
-        ss.debug_unset("text_order12")
+        # the same order on 12-byte records (the form of rounds 2-5 beyond 2^31 positions; still what a context without the
+        # bucket ordering takes)
+        with ss.debug_switches(text_order12=1), ss.Context(n) as c2:
+            c2.generate(n, 9, 0)
+            c2.build()
+            assert c2.stats()["text_sort_state"] == 1 and c2.stats()["msd_sorts"] == 0 and c2.checksum() == chk
+    with ss.debug_switches(no_text_shortcut=1), ss.Context(n) as c:      # the recursion at this size
+        c.generate(n, 9, 0)
+        c.build()
+        assert c.sufcheck() == 0 and c.checksum() == chk
+        assert c.stats()["level_n"][1] > (1 << 31)
 
 
 def test_boundary_sizes_sufcheck(ss):
