@@ -96,6 +96,9 @@ DC3HIP_API int32_t dc3hip_device_count(void);   /* number of visible HIP devices
 /* Waits until every stream of `device` (-1 = current) has drained: what a host program without HIP bindings of its own
  * brackets a timed region with (bench.py at one GPU runs without torch, on the HIP runtime the library was compiled for). */
 DC3HIP_API int32_t dc3hip_device_synchronize(int32_t device);
+/* Architecture name ("gfx950:sramecc+:xnack-") and compute-unit count of `device` (-1 = current): lets a host program
+ * without HIP bindings tell an MI355X from anything else (the perf guards of the test suite do). */
+DC3HIP_API int32_t dc3hip_device_info(int32_t device, char *arch, int32_t arch_len, int32_t *compute_units);
 /* HIP_VERSION the library was compiled against and hipRuntimeGetVersion() of the runtime the process really runs on (a
  * host program that maps its own libamdhip64 first — a PyTorch wheel does — makes the library run on that one).  Returns 1
  * when major and minor agree, 0 when they differ (the library also says so once on stderr), <0 on error. */

@@ -23,6 +23,7 @@ from .api import (  # noqa: F401
     debug_switches,
     debug_unset,
     device_count,
+    device_info,
     device_synchronize,
     hip_versions,
     last_error,
@@ -37,6 +38,6 @@ from .api import (  # noqa: F401
 
 __all__ = [
     "Context", "Dc3HipError", "POLICY_VARS", "adopt_legacy_env", "GlobalRank", "GStats", "LoopbackGroup", "LongestCommonSubstring", "NotSorted", "PartitionedSuffixArray", "PHASES", "Stats",
-    "SuffixArray", "common_prefix_len", "debug_set", "debug_switches", "debug_unset", "device_count", "device_synchronize", "global_plan", "hip_versions", "last_error", "lib", "release_cache", "lib_path", "sort", "sort_i64",
+    "SuffixArray", "common_prefix_len", "debug_set", "debug_switches", "debug_unset", "device_count", "device_info", "device_synchronize", "global_plan", "hip_versions", "last_error", "lib", "release_cache", "lib_path", "sort", "sort_i64",
     "sort_in_place", "sufcheck", "verify", "version",
 ]

@@ -141,6 +141,7 @@ SYMBOLS = {
     "dc3hip_last_error": (ctypes.c_char_p, []),
     "dc3hip_device_count": (_i32, []),
     "dc3hip_device_synchronize": (_i32, [_i32]),
+    "dc3hip_device_info": (_i32, [_i32, ctypes.c_char_p, _i32, ctypes.POINTER(_i32)]),
     "dc3hip_ctx_create": (_i32, [ctypes.POINTER(_vp), _i32, _i64]),
     "dc3hip_ctx_destroy": (None, [_vp]),
     "dc3hip_ctx_set_text": (_i32, [_vp, _vp, _i64]),

@@ -34,8 +34,8 @@ DEBUG_NAMES = frozenset("""
 global_device_token global_force_dist global_force_wide global_link_gbps global_no_route global_no_select global_no_text_order
 hybrid12_min msd_min msd_slot_cap no_9bit no_discard no_doubling no_fullsort no_fuse_names no_hybrid no_hybrid12 no_hybrid8
 no_long_keys no_merge_keys64 no_msd no_msd_slots no_pack_count no_pack_strip no_raw_image no_rec12 no_small_ties no_split_emit
-no_ssort no_text_shortcut no_tup8 no_tup_rec8 no_tup_scatter no_wide_deepen no_wide_msd no_wide_window no_xcd_map pack_fuse
-ssort_min ssort_rec12 ssort_verify text_order12 tup_bigtile tup_counted tup_scatter_min wide_corrupt wide_msd_min
+no_ssort no_text_shortcut no_tup8 no_tup_rec8 no_tup_scatter no_vmm no_wide_deepen no_wide_msd no_wide_window no_xcd_map pack_fuse
+ssort_min ssort_rec12 ssort_verify text_order12 tup_bigtile tup_counted tup_scatter_min vmm_min wide_corrupt wide_msd_min
 """.split())
 
 
@@ -123,6 +123,14 @@ def device_count():
 
 def device_synchronize(device=-1):
     _check(lib().dc3hip_device_synchronize(device))
+
+
+def device_info(device=-1):
+    """(architecture name, compute units) of a device, e.g. ("gfx950:sramecc+:xnack-", 256)"""
+    buf = ctypes.create_string_buffer(256)
+    cus = ctypes.c_int32(0)
+    _check(lib().dc3hip_device_info(device, buf, 256, ctypes.byref(cus)))
+    return buf.value.decode(), int(cus.value)
 
 
 def _check(rc):

@@ -70,52 +70,152 @@ __global__ __launch_bounds__(kBlock) void k_generate(uint8_t *t, u64 n, u64 seed
 }
 
 // ---------------------------------------------------------------------------------------------
-// GPU verifier = sufcheck() of crates/cdivsufsort/c-sources/utils.c:160-241 restated as parallel
-// passes (equivalently sacabase::verify, sacabase/src/lib.rs:127-149).  With ISA = inverse of SA:
-//   (1) range: every SA[i] in [0,n) (-2); ISA a bijection (a duplicate entry reports -4 like the reference's scan)
-//   (2) first characters non-decreasing                                          (-3)
-//   (3) for T[SA[i]] == T[SA[i+1]]: rank of suffix SA[i]+1 < rank of suffix SA[i+1]+1, the end
-//       of text ranking lowest                                                   (-4)
-// (1)-(3) hold iff SA is the suffix array.  err receives the smallest failing code seen
-// (as in sufcheck, -2 is reported before -3 before -4).
+// GPU verifier = sufcheck() of crates/cdivsufsort/c-sources/utils.c:160-241 (equivalently sacabase::verify,
+// sacabase/src/lib.rs:127-149), its three loops as they are:
+//   (1) range: every SA[i] in [0, n)                                              utils.c:179-188   (-2)
+//   (2) first characters non-decreasing                                           utils.c:191-201   (-3)
+//   (3) the scan of utils.c:213-238: for i = 0, 1, ...: the suffix SA[i] - 1, whose first character is c = T[SA[i] - 1],
+//       must stand in the next free slot of c's bucket — C[c]++, buckets from the text's histogram; the slot
+//       q = (start of T[n-1]'s bucket) is reserved for the suffix n - 1, which the entry SA[i] = 0 claims        (-4)
+// Round 6: (3) is what one STABLE counting pass computes — partition the records (c, SA[i] - 1), i ascending, by c: the
+// record that arrives at slot t (the gap at q skipped) must equal SA[t].  So the verifier is one gather kernel (the only
+// random access: the two text bytes at SA[i] - 1, SA[i]; it also checks (1), (2), leaves the bytes c in rank order and
+// the pass's digit table), the text's byte histogram, and one down-sweep of the product's radix pass whose sink COMPARES
+// instead of storing (nothing is written but n bytes of c).  An array passes iff the reference's loops accept it: the
+// slots the pass assigns are the reference's C[c]++ as long as no bucket overflows, and bucket sizes that differ from the
+// text's histogram (an in-range array that is not a permutation) fail here (-4) as they make the reference run a cursor
+// out of its bucket.  Rounds 1-5 built the inverse array by a random scatter and gathered it twice per entry: 98 ms per
+// 2^30 entries against 11 ms for the build they verified.
+// err receives the largest failing value seen: 3 -> -2, 2 -> -3, 1 -> -4 (as in sufcheck, -2 before -3 before -4).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_check_fill(const u32 *__restrict__ sa, u32 n, u32 *__restrict__ isa,
-                                                      int *err) {
-  for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-    const u32 p = sa[i];
-    if (p >= n) { atomicMax(err, 3); continue; }   // code = -(5 - v): 3 -> -2
-    isa[p] = i + 1;
+constexpr int kCheckIPT = 4;      // ranks per lane and round of k_check_gather (independent gathers in flight)
+__global__ __launch_bounds__(kBlock) void k_check_text_hist(const uint8_t *__restrict__ t, u32 n, u32 *__restrict__ hist /*[256], zeroed*/) {
+  __shared__ u32 h[kWaves][256];
+  for (int j = threadIdx.x; j < kWaves * 256; j += kBlock) (&h[0][0])[j] = 0;
+  __syncthreads();
+  u32 *myh = h[wave_id()];
+  const u32 nw = n / 16;                        // 16-byte pieces (the text buffer is 16-byte aligned or this is a partition: see below)
+  const bool aligned = (reinterpret_cast<uintptr_t>(t) & 15) == 0;
+  if (aligned) {
+    const uint4 *t4 = reinterpret_cast<const uint4 *>(t);
+    for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < nw; i += gridDim.x * kBlock) {
+      const uint4 v = t4[i];
+      const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        atomicAdd(&myh[w[k] & 255u], 1u); atomicAdd(&myh[(w[k] >> 8) & 255u], 1u);
+        atomicAdd(&myh[(w[k] >> 16) & 255u], 1u); atomicAdd(&myh[w[k] >> 24], 1u);
+      }
+    }
+    for (u32 i = nw * 16 + blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) atomicAdd(&myh[t[i]], 1u);
+  } else {
+    for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) atomicAdd(&myh[t[i]], 1u);
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < 256; j += kBlock) {
+    u32 sum = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; w++) sum += h[w][j];
+    if (sum) atomicAdd(&hist[j], sum);
   }
 }
-__global__ __launch_bounds__(kBlock) void k_check_order(const uint8_t *__restrict__ t, const u32 *__restrict__ sa,
-                                                       const u32 *__restrict__ isa, u32 n, int *err) {
-  // a wave takes 64 consecutive ranks; the successor's position and first byte come from the next lane
-  // (one random text gather per rank instead of two), lane 63 fetches its own
+// Block b works chunk b of the ranks (the chunking of the radix pass that follows: table[c * nchunks + b] = its records
+// with first byte c).  bw[i] = T[SA[i] - 1] for 0 < SA[i] < n (0 otherwise: such entries are not records).
+__global__ __launch_bounds__(kBlock) void k_check_gather(const uint8_t *__restrict__ t, const u32 *__restrict__ sa, u32 n, u32 chunk,
+                                                        u32 nchunks, uint8_t *__restrict__ bw, u32 *__restrict__ table, int *err) {
+  __shared__ u32 hist[kWaves][256];
+  for (int j = threadIdx.x; j < kWaves * 256; j += kBlock) (&hist[0][0])[j] = 0;
+  __syncthreads();
+  u32 *myh = hist[wave_id()];
   const u32 lane = lane_id();
-  for (u32 base = blockIdx.x * kBlock + (threadIdx.x & ~63u); base < n; base += gridDim.x * kBlock) {
-    const u32 i = base + lane;
-    const bool valid = i < n;
-    const u32 p = valid ? sa[i] : 0xffffffffu;
-    const bool pin = valid && p < n;
-    const u32 cp = pin ? (u32)t[p] : 0u;
-    u32 q = __shfl_down(p, 1), cq = __shfl_down(cp, 1);
-    if (lane == 63) {
-      q = (i + 1 < n) ? sa[i + 1] : 0xffffffffu;
-      cq = (i + 1 < n && q < n) ? (u32)t[q] : 0u;
+  const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
+  int bad = 0;
+  // a wave takes 64 * kCheckIPT consecutive ranks per round: rank (k, lane) = base + 64 k + lane
+  for (u32 base = begin + wave_id() * (64u * kCheckIPT); base < end; base += kBlock * kCheckIPT) {
+    u32 p[kCheckIPT], cf[kCheckIPT], cp[kCheckIPT], in[kCheckIPT];
+#pragma unroll
+    for (int k = 0; k < kCheckIPT; k++) {
+      const u32 i = base + (u32)k * 64u + lane;
+      p[k] = i < end ? sa[i] : 0xffffffffu;
+      in[k] = p[k] < n ? 1u : 0u;
     }
-    if (!pin) continue;                                       // out of range: reported by k_check_fill
-    // an in-range array that is not a permutation (duplicate entries): the reference has no permutation test and
-    // fails such arrays in its psi scan (-4, utils.c:213-238) unless the first characters already disagree (-3)
-    if (isa[p] != i + 1) { atomicMax(err, 1); continue; }
-    if (i + 1 >= n || q >= n) continue;
-    if (cp > cq) { atomicMax(err, 2); continue; }           // -3
-    if (cp == cq) {
-      const u32 rp = (p + 1 < n) ? isa[p + 1] : 0u;
-      const u32 rq = (q + 1 < n) ? isa[q + 1] : 0u;
-      if (!(rp < rq)) atomicMax(err, 1);                    // -4
+#pragma unroll
+    for (int k = 0; k < kCheckIPT; k++) {
+      // T[p - 1], T[p] in one access where p > 0
+      uint16_t v = 0;
+      if (in[k]) { if (p[k] > 0) __builtin_memcpy(&v, t + p[k] - 1, 2); else v = (uint16_t)((u32)t[0] << 8); }
+      cp[k] = v & 255u; cf[k] = v >> 8;
+    }
+    // the successor's first byte: the next lane's, or the first lane's of the wave's next 64 ranks (all lanes take part in
+    // the shuffles; what they mean is sorted out below)
+    u32 cq[kCheckIPT], qin[kCheckIPT];
+#pragma unroll
+    for (int k = 0; k < kCheckIPT; k++) {
+      cq[k] = __shfl_down(cf[k], 1); qin[k] = __shfl_down(in[k], 1);
+      if (k + 1 < kCheckIPT) {
+        const u32 c0 = __shfl(cf[k + 1 < kCheckIPT ? k + 1 : k], 0), i0 = __shfl(in[k + 1 < kCheckIPT ? k + 1 : k], 0);
+        if (lane == 63) { cq[k] = c0; qin[k] = i0; }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kCheckIPT; k++) {
+      const u32 i = base + (u32)k * 64u + lane;
+      if (i >= end) continue;
+      if (!in[k]) { bad = max(bad, 3); bw[i] = 0; continue; }          // utils.c:179-188
+      bw[i] = p[k] > 0 ? (uint8_t)cp[k] : (uint8_t)0;
+      if (p[k] > 0) atomicAdd(&myh[cp[k]], 1u);
+      // (the last rank of the wave's run, and of the chunk: the successor belongs to another wave or block)
+      const bool own_fetch = (lane == 63 && k == kCheckIPT - 1) || i + 1 >= end;
+      if (!own_fetch) {
+        if (qin[k] && cf[k] > cq[k]) bad = max(bad, 2);                 // utils.c:191-201
+      } else if (i + 1 < n) {
+        const u32 q = sa[i + 1];
+        if (q < n && cf[k] > (u32)t[q]) bad = max(bad, 2);
+      }
     }
   }
+  if (bad) atomicMax(err, bad);
+  __syncthreads();
+  for (int j = threadIdx.x; j < 256; j += kBlock) {
+    u32 sum = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; w++) sum += hist[w][j];
+    table[(size_t)j * nchunks + blockIdx.x] = sum;
+  }
 }
+// One block of 256 threads: the bucket starts the pass found (start[c], exclusive prefix of its digit totals; *total = all
+// records) against the text's histogram — bucket c of utils.c:204-211 minus the slot of the suffix n - 1 in its own
+// bucket — and *q_out = that slot.  SA[q] must be n - 1 (the entry 0's claim, utils.c:219-221).
+__global__ __launch_bounds__(256) void k_check_counts(const u32 *__restrict__ hist, const u32 *__restrict__ start, const u32 *__restrict__ total,
+                                                     const uint8_t *__restrict__ t, const u32 *__restrict__ sa, u32 n, u32 *__restrict__ q_out, int *err) {
+  __shared__ u32 tmp[4];
+  const u32 c = threadIdx.x, last = t[n - 1];
+  u32 tot;
+  const u32 ex = block_excl_scan<4>(hist[c], tmp, tot);           // C[c] of utils.c:207-211
+  const u32 want = ex - (c > last ? 1u : 0u);                     // ... in the dense array of the n - 1 records
+  if (start[c] != want) atomicMax(err, 1);
+  if (c == last) {
+    *q_out = ex;
+    if (*total != n - 1 || tot != n || sa[ex] != n - 1) atomicMax(err, 1);
+  }
+}
+// the pass's records and where they must be found
+struct CheckLoader {
+  const u32 *sa; const uint8_t *bw; u32 n;
+  __device__ __forceinline__ bool load(u32 i, Rec8 &r) const {
+    const u32 p = sa[i];
+    if (p == 0 || p >= n) return false;
+    r.key = bw[i]; r.val = p - 1;
+    return true;
+  }
+};
+struct CheckSink {
+  const u32 *sa; const u32 *q; u32 n; int *err;
+  __device__ __forceinline__ void store(u32 g, const Rec8 &x) const {
+    const u32 t = g + (g >= *q ? 1u : 0u);                         // utils.c:212-213: slot q is skipped
+    if (t >= n || sa[t] != x.val) atomicMax(err, 1);               // utils.c:222 "p != SA[t]"
+  }
+};
 __global__ __launch_bounds__(kBlock) void k_checksum(const u32 *__restrict__ sa, u32 n, u64 *out) {
   u64 acc = 0;
   for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)

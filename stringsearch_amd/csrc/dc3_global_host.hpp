@@ -2115,9 +2115,11 @@ static int gctx_make_ctx(dc3hip_gctx *G, int device, int64_t max_total_n) {
   bool force_wide = false;
   force_wide = dbg_on("global_force_wide");
   G->wide = force_wide || max_total_n > DC3HIP_MAX_N;
-  if (!G->wide) return dc3hip_ctx_create(&G->c, device, max_total_n);
+  // (use_vm = false: a rank's buffers are what RCCL and peer copies read and write — plain hipMalloc, as every multi-rank
+  //  test so far ran; the reserve + commit buffers of round 6 are for the single-device contexts)
+  if (!G->wide) return ctx_create_impl(&G->c, device, max_total_n, nullptr, false);
   if (max_total_n > ((int64_t)1 << 40)) { set_err("n=%lld exceeds 2^40", (long long)max_total_n); return E_TOOBIG; }
-  RC(dc3hip_ctx_create(&G->c, device, 0));
+  RC(ctx_create_impl(&G->c, device, 0, nullptr, false));
   HIPC(hipSetDevice(G->c->device));
   HIPC(hipMalloc(&G->w_text, (size_t)max_total_n + 64));
   return E_OK;

@@ -32,6 +32,62 @@ static inline hipError_t dc3_func_set_attribute(const void *fn, hipFuncAttribute
 #define KCHECK() HIPC(hipGetLastError())
 
 // ---------------------------------------------------------------------------------------------
+// Large device buffers by virtual-memory reserve + commit (round 6).  What a first call pays on MI355X (ROCm 7.2,
+// tools/alloc_probe.hip, profiles/r06c_alloc_probe.jsonl): hipMalloc of up to 4 GiB 0.2 ms, of 8 GiB 0.5 s, 24 GiB 0.7-1.2 s,
+// 44 GiB 1.7 s — the un-warmed dc3hip_sufsort_i32 of 1 GiB spent 2.3 of its 2.4 s there (crates/divsuftest/src/main.rs:
+// 145-151 times exactly one such call) — against 1 ms for reserving 44 GiB of address space and mapping it in 1 GiB
+// pieces (hipMemAddressReserve / hipMemCreate / hipMemMap / hipMemSetAccess), with the same fill rate afterwards.  A DevBuf
+// reserves the most its owner can ever need and commits what it needs now: growing never moves the buffer, so the arena of
+// a context can grow in the middle of a build.  Where the calls are not available (a mock runtime, an old one) the owner
+// falls back to hipMalloc.
+// ---------------------------------------------------------------------------------------------
+struct DevBuf {
+  unsigned char *va = nullptr;
+  size_t reserved = 0, mapped = 0;
+  int device = 0;
+  std::vector<std::pair<hipMemGenericAllocationHandle_t, size_t>> pieces;
+};
+static constexpr size_t kDevBufPiece = (size_t)1 << 30, kDevBufGran = (size_t)2 << 20;
+static void devbuf_free(DevBuf *b) {
+  if (!b->va) return;
+  size_t off = 0;
+  for (auto &pc : b->pieces) { (void)hipMemUnmap(b->va + off, pc.second); (void)hipMemRelease(pc.first); off += pc.second; }
+  b->pieces.clear();
+  (void)hipMemAddressFree(b->va, b->reserved);
+  b->va = nullptr; b->reserved = b->mapped = 0;
+}
+// (errors here are not reported through set_err: the caller falls back to hipMalloc or reports its own)
+static bool devbuf_reserve(DevBuf *b, int device, size_t bytes) {
+  void *p = nullptr;
+  const size_t r = (bytes + kDevBufGran - 1) / kDevBufGran * kDevBufGran;
+  if (hipMemAddressReserve(&p, r, kDevBufGran, nullptr, 0) != hipSuccess || !p) { (void)hipGetLastError(); return false; }
+  b->va = static_cast<unsigned char *>(p); b->reserved = r; b->mapped = 0; b->device = device;
+  return true;
+}
+// commit until at least `bytes` are mapped; false: out of memory or address space (what is mapped stays mapped)
+static bool devbuf_commit(DevBuf *b, size_t bytes) {
+  if (bytes <= b->mapped) return true;
+  if (!b->va || bytes > b->reserved) return false;
+  const size_t target = std::min(b->reserved, (bytes + kDevBufGran - 1) / kDevBufGran * kDevBufGran);
+  hipMemAllocationProp prop; memset(&prop, 0, sizeof(prop));
+  prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = b->device;
+  hipMemAccessDesc acc; memset(&acc, 0, sizeof(acc));
+  acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
+  while (b->mapped < target) {
+    const size_t sz = std::min(kDevBufPiece, target - b->mapped);
+    hipMemGenericAllocationHandle_t h;
+    if (hipMemCreate(&h, sz, &prop, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (hipMemMap(b->va + b->mapped, sz, 0, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipMemRelease(h); return false; }
+    if (hipMemSetAccess(b->va + b->mapped, sz, &acc, 1) != hipSuccess) {
+      (void)hipGetLastError(); (void)hipMemUnmap(b->va + b->mapped, sz); (void)hipMemRelease(h); return false;
+    }
+    b->pieces.emplace_back(h, sz);
+    b->mapped += sz;
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------------------
 static constexpr double kHybrid12MaxPredicted = 0.75;   // 12-byte prefix sort: taken below this predicted tied fraction (the sample
@@ -51,6 +107,12 @@ struct dc3hip_ctx {
   u32 *d_sa = nullptr;         // max_n + 16 words
   unsigned char *arena = nullptr;
   size_t arena_bytes = 0, arena_off = 0, arena_peak = 0;
+  // round 6: big buffers are reserved address ranges, committed as needed (DevBuf): arena_vm.va == arena when the arena is
+  // one; sa_vm / text_vm likewise for d_sa / d_text beyond kDevBufMinBytes.  use_vm = false (ranks of the global mode, whose
+  // buffers RCCL and peer copies see; DC3HIP_DEBUG=no_vmm): plain hipMalloc as before
+  DevBuf arena_vm, sa_vm, text_vm;
+  bool use_vm = true;
+  size_t vm_min = (size_t)2 << 30;   // DC3HIP_DEBUG=vmm_min=<bytes> (tests): smallest buffer that is reserved + committed
   bool arena_fixed = false;    // DC3HIP_ARENA_BYTES given: never grown
   bool arena_borrowed = false; // the arena belongs to another context (ctx_create_impl): never grown, never freed here
   bool arena_exhausted = false; // the last E_ALLOC came from the bump allocator (not from hipMalloc)
@@ -155,22 +217,55 @@ static size_t arena_requirement(int64_t n) {
 // to arena_requirement() the first time a build enters the DC3 recursion (ensure_arena): high-entropy texts never
 // do, so their contexts hold half the memory and the first hipMalloc is half as long.
 static size_t arena_text_requirement(int64_t n) {
-  // (beyond 2^31 positions the whole-text order runs on 12-byte records: 2 x 12 + 1 bytes per position + tables)
+  // two 8-byte word arrays, 4 image bytes + 1 flag byte + 1 same byte per position, tables, the tie predictor: 22 n + tables
   // (+ the size tables of the bucket ordering: 2 x 8 words per sub-bucket, at most 2^20 sub-buckets)
-  // (+ up to 2^31 positions the slots of the bucket ordering's second pass, 16 bytes per position: msd_sort)
-  return n > ((int64_t)1 << 31) ? (size_t)n * 26 + ((size_t)256 << 20) : (size_t)n * 40 + ((size_t)224 << 20);
+  // The slots of the bucket ordering's second pass (16 bytes per position, msd_sort) are NOT part of it: a context whose
+  // arena can grow in place (DevBuf) commits them when a sort first takes slots (arena_grow_in_use); every other context
+  // — borrowed or fixed arenas, ranks of the global mode — keeps to the counted form.
+  return (size_t)n * 24 + ((size_t)208 << 20);
+}
+// most a context of max_n bytes may ever ask of its arena: the recursion's requirement or the whole-text order with slots,
+// the one retry of ctx_build (+ 50 %), the by-products (LCP: 26 n)
+static size_t arena_reserve_bytes(int64_t n) {
+  const size_t need = std::max(arena_requirement(n), (size_t)n * 42 + ((size_t)256 << 20));
+  return need + need / 2 + ((size_t)1 << 30);
 }
 
-// Grow the (empty) arena to at least `need` bytes.  Never shrinks; a size forced by DC3HIP_ARENA_BYTES stays as it is.
+// Grow the arena to at least `need` bytes.  Never shrinks; a size forced by DC3HIP_ARENA_BYTES stays as it is.  A reserved
+// arena (DevBuf) commits more pieces where it lies — also while in use; a hipMalloc'ed one is replaced and must be empty.
 static int ensure_arena(dc3hip_ctx *c, size_t need) {
   if (c->arena_bytes >= need || c->arena_fixed) return E_OK;
-  if (c->arena_off != 0) { set_err("internal: arena grown while in use"); return E_HIP; }
   HIPC(hipSetDevice(c->device));            // (callers may be on a thread whose current device is another one)
+  if (c->arena_vm.va && c->arena == c->arena_vm.va && need <= c->arena_vm.reserved) {
+    if (!devbuf_commit(&c->arena_vm, need)) {
+      c->arena_bytes = c->arena_vm.mapped;
+      set_err("device allocation failed: arena of %zu bytes (committed %zu)", need, c->arena_vm.mapped);
+      return E_ALLOC;
+    }
+    c->arena_bytes = c->arena_vm.mapped;
+    return E_OK;
+  }
+  if (c->arena_off != 0) { set_err("internal: arena grown while in use"); return E_HIP; }
   HIPC(hipStreamSynchronize(c->stream));
-  if (c->arena) { HIPC(hipFree(c->arena)); c->arena = nullptr; c->arena_bytes = 0; }
+  if (c->arena_vm.va && c->arena == c->arena_vm.va) { devbuf_free(&c->arena_vm); c->arena = nullptr; c->arena_bytes = 0; }
+  else if (c->arena) { HIPC(hipFree(c->arena)); c->arena = nullptr; c->arena_bytes = 0; }
+  if (c->use_vm && need >= c->vm_min && devbuf_reserve(&c->arena_vm, c->device, need + need / 2)) {
+    if (devbuf_commit(&c->arena_vm, need)) { c->arena = c->arena_vm.va; c->arena_bytes = c->arena_vm.mapped; return E_OK; }
+    devbuf_free(&c->arena_vm);
+  }
   HIPC(hipMalloc(&c->arena, need));
   c->arena_bytes = need;
   return E_OK;
+}
+// In the middle of a build: more room behind what is in use, if the arena can grow where it lies (else false: the caller
+// takes the path that needs no more memory).  Never an error.
+static bool arena_grow_in_use(dc3hip_ctx *c, size_t need_total) {
+  if (c->arena_bytes >= need_total) return true;
+  if (c->arena_fixed || c->arena_borrowed || !c->arena_vm.va || c->arena != c->arena_vm.va || need_total > c->arena_vm.reserved) return false;
+  if (hipSetDevice(c->device) != hipSuccess) { (void)hipGetLastError(); return false; }
+  const bool ok = devbuf_commit(&c->arena_vm, need_total);
+  c->arena_bytes = c->arena_vm.mapped;
+  return ok;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -328,9 +328,10 @@ static int msd_sort(dc3hip_ctx *c, Rec8 *ha, Rec8 *hb, u32 n, const HiMap &hm, c
     const size_t N = n2;                                                 // one cursor per sub-bucket
     const size_t need = align_up(slot_words * 8, 256) + align_up((N + 16) * 4, 256) + (split ? (size_t)n * 2 + (64u << 20) : (size_t)(1u << 20));   // (+ what the tie pass takes afterwards)
     // what the host knows by itself comes first: slots that index with 32 bits, that hold the mean sub-bucket with room to
-    // spare (beyond 2^31 words the mean passes the local sort's small shape: counted form), an arena with room.  Only then
+    // spare (beyond 2^31 words the mean passes the local sort's small shape: counted form), an arena with room — one that
+    // can grow where it lies commits the 16 bytes per word now (arena_grow_in_use; first sort of a context only).  Only then
     // is the largest pass-1 bucket read back (a pipeline drain that a sort without slots must not pay).
-    const bool host_ok = slot_words < (1ull << 32) && (c->msd_slot_cap || (u64)mean * 5 <= (u64)slot_cap * 4) && c->arena_off + need <= c->arena_bytes;
+    const bool host_ok = slot_words < (1ull << 32) && (c->msd_slot_cap || (u64)mean * 5 <= (u64)slot_cap * 4) && arena_grow_in_use(c, c->arena_off + need);
     u32 maxb1 = 0;
     if (host_ok) {
       HIPC(hipMemcpyAsync(c->h_words + 20, plan, kMsdW_COUNT * sizeof(u32), hipMemcpyDeviceToHost, c->stream));

@@ -77,11 +77,29 @@ int32_t dc3hip_device_synchronize(int32_t device) {
   return E_OK;
 }
 
-static int ctx_create_impl(dc3hip_ctx **out, int32_t device, int64_t max_n, dc3hip_ctx *arena_from);
+int32_t dc3hip_device_info(int32_t device, char *arch, int32_t arch_len, int32_t *compute_units) {
+  if (device < 0) HIPC(hipGetDevice(&device));
+  hipDeviceProp_t prop;
+  HIPC(hipGetDeviceProperties(&prop, device));
+  if (arch && arch_len > 0) { std::strncpy(arch, prop.gcnArchName, (size_t)arch_len - 1); arch[arch_len - 1] = 0; }
+  if (compute_units) *compute_units = prop.multiProcessorCount;
+  return E_OK;
+}
+
+static int ctx_create_impl(dc3hip_ctx **out, int32_t device, int64_t max_n, dc3hip_ctx *arena_from, bool use_vm = true);
 int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) { return ctx_create_impl(out, device, max_n, nullptr); }
+// one device buffer of a context: reserved + committed (DevBuf) from vm_min bytes on, else hipMalloc
+static int ctx_big_alloc(dc3hip_ctx *c, DevBuf *vm, size_t bytes, void **out) {
+  if (c->use_vm && bytes >= c->vm_min && devbuf_reserve(vm, c->device, bytes)) {
+    if (devbuf_commit(vm, bytes)) { *out = vm->va; return E_OK; }
+    devbuf_free(vm);
+  }
+  HIPC(hipMalloc(out, bytes));
+  return E_OK;
+}
 // arena_from != nullptr: the new context works in that context's arena instead of allocating its own (the lender must not
 // build meanwhile; dc3hip_ctx_build_partitions: the partitions are built one after the other in the parent's arena)
-static int ctx_create_impl(dc3hip_ctx **out, int32_t device, int64_t max_n, dc3hip_ctx *arena_from) {
+static int ctx_create_impl(dc3hip_ctx **out, int32_t device, int64_t max_n, dc3hip_ctx *arena_from, bool use_vm) {
   if (!out || max_n < 0) { set_err("dc3hip_ctx_create: invalid arguments"); return E_ARGS; }
   *out = nullptr;
   if (max_n > DC3HIP_MAX_N) { set_err("n=%lld exceeds DC3HIP_MAX_N", (long long)max_n); return E_TOOBIG; }
@@ -117,14 +135,16 @@ static int ctx_create_impl(dc3hip_ctx **out, int32_t device, int64_t max_n, dc3h
   { long long v; if (dbg_num("msd_slot_cap", &v)) c->msd_slot_cap = (u32)std::max(1ll, v); }
   { long long v; if (dbg_num("ssort_min", &v)) c->ssort_min = (u32)std::max(8192ll, v); }
   { long long v; if (dbg_num("hybrid12_min", &v)) c->hybrid12_min = (u32)std::max(0ll, v); }
+  c->use_vm = use_vm && !dbg_on("no_vmm");
+  { long long v; if (dbg_num("vmm_min", &v)) c->vm_min = (size_t)std::max(1ll, v); }
   int rc = [&]() -> int {
     HIPC(hipSetDevice(device));
     hipDeviceProp_t prop;
     HIPC(hipGetDeviceProperties(&prop, device));
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIPC(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIPC(hipMalloc(&c->d_text, (size_t)max_n + 64));
-    HIPC(hipMalloc(&c->d_sa, ((size_t)max_n + 16) * sizeof(u32)));
+    RC(ctx_big_alloc(c, &c->text_vm, (size_t)max_n + 64, reinterpret_cast<void **>(&c->d_text)));
+    RC(ctx_big_alloc(c, &c->sa_vm, ((size_t)max_n + 16) * sizeof(u32), reinterpret_cast<void **>(&c->d_sa)));
     c->arena_bytes = std::min(arena_requirement(max_n), arena_text_requirement(max_n));   // grown on demand (ensure_arena)
     // testing aid: DC3HIP_ARENA_BYTES=<bytes> replaces the computed size (a build then either fits — possibly through
     // a fallback ordering — or fails loudly with -2; it never returns a wrong array)
@@ -132,7 +152,14 @@ static int ctx_create_impl(dc3hip_ctx **out, int32_t device, int64_t max_n, dc3h
     if (arena_from && arena_from->arena && arena_from->device == device) {
       c->arena = arena_from->arena; c->arena_bytes = arena_from->arena_bytes; c->arena_borrowed = true; c->arena_fixed = true;
     } else {
-      HIPC(hipMalloc(&c->arena, c->arena_bytes));
+      // address space for everything a context of max_n bytes can ever ask for, memory for what the first build needs
+      const size_t want = c->arena_bytes;
+      bool done = false;
+      if (c->use_vm && !c->arena_fixed && arena_reserve_bytes(max_n) >= c->vm_min && devbuf_reserve(&c->arena_vm, device, arena_reserve_bytes(max_n))) {
+        if (devbuf_commit(&c->arena_vm, want)) { c->arena = c->arena_vm.va; c->arena_bytes = c->arena_vm.mapped; done = true; }
+        else devbuf_free(&c->arena_vm);
+      }
+      if (!done) HIPC(hipMalloc(&c->arena, c->arena_bytes));
     }
     HIPC(hipMalloc(&c->d_present, 256 * sizeof(u32)));
     HIPC(hipMalloc(&c->d_code, 256 * sizeof(uint16_t)));
@@ -188,9 +215,9 @@ void dc3hip_ctx_destroy(dc3hip_ctx *c) {
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->ev_build_a) (void)hipEventDestroy(c->ev_build_a);
   if (c->ev_build_b) (void)hipEventDestroy(c->ev_build_b);
-  if (c->d_text) (void)hipFree(c->d_text);
-  if (c->d_sa) (void)hipFree(c->d_sa);
-  if (c->arena && !c->arena_borrowed) (void)hipFree(c->arena);
+  if (c->text_vm.va) devbuf_free(&c->text_vm); else if (c->d_text) (void)hipFree(c->d_text);
+  if (c->sa_vm.va) devbuf_free(&c->sa_vm); else if (c->d_sa) (void)hipFree(c->d_sa);
+  if (c->arena_vm.va) devbuf_free(&c->arena_vm); else if (c->arena && !c->arena_borrowed) (void)hipFree(c->arena);
   if (c->d_xcdmon) (void)hipFree(c->d_xcdmon);
   if (c->d_present) (void)hipFree(c->d_present);
   if (c->d_code) (void)hipFree(c->d_code);
@@ -284,22 +311,46 @@ int32_t dc3hip_ctx_get_text(dc3hip_ctx *c, uint8_t *T) {
 // Runs the check; *code receives sufcheck()'s result (0, -2, -3, -4); the return value is the
 // library status (E_OK / E_ALLOC / E_HIP), kept apart because the two code spaces overlap.
 static int ctx_sufcheck(dc3hip_ctx *c, const u32 *d_sa, int *code, const uint8_t *text = nullptr, int64_t n_override = -1) {
-  // utils.c:160-241 as parallel passes; isa lives in the arena.  text / n_override: a partition of the resident text
+  // utils.c:160-241: range and first characters in the gather kernel, the scan of :213-238 as one stable counting pass
+  // whose sink compares (dc3_aux.hip.hpp).  text / n_override: a partition of the resident text
   const int64_t n = n_override >= 0 ? n_override : c->n;
   if (!text) text = c->d_text;
   *code = 0;
   if (n == 0) return E_OK;
   HIPC(hipSetDevice(c->device));
   c->arena_off = 0;
-  u32 *isa = nullptr;
-  RC(arena_alloc(c, (size_t)n + 16, &isa));
+  const u32 n32 = (u32)n;
+  int nb = 0; Chunking ck;
+  radix_plan<Rec8>(c, n32, 8, &nb, &ck);                         // (8 key bits: 256 bins)
+  uint8_t *bw = nullptr;
+  u32 *table = nullptr, *digit_base = nullptr, *hist = nullptr;
+  RC(arena_alloc(c, (size_t)n + 16, &bw));
+  RC(arena_alloc(c, (size_t)256 * ck.nchunks, &table));
+  RC(arena_alloc(c, (size_t)256, &digit_base));
+  RC(arena_alloc(c, (size_t)256, &hist));
   int *err = reinterpret_cast<int *>(c->d_words + 8);
+  u32 *total = c->d_words + 9, *qslot = c->d_words + 26;
   HIPC(hipMemsetAsync(err, 0, sizeof(int), c->stream));
-  hipLaunchKernelGGL(k_check_fill, dim3(grid_for(c, n)), dim3(kBlock), 0, c->stream, d_sa, (u32)n, isa, err);
+  HIPC(hipMemsetAsync(hist, 0, 256 * sizeof(u32), c->stream));
+  hipLaunchKernelGGL(k_check_text_hist, dim3(grid_for(c, (u64)n / 16 + 1)), dim3(kBlock), 0, c->stream, text, n32, hist);
   KCHECK();
-  hipLaunchKernelGGL(k_check_order, dim3(grid_for(c, n)), dim3(kBlock), 0, c->stream, text, d_sa, isa, (u32)n,
-                     err);
+  hipLaunchKernelGGL(k_check_gather, dim3(ck.nchunks), dim3(kBlock), 0, c->stream, text, d_sa, n32, ck.chunk, ck.nchunks, bw, table, err);
   KCHECK();
+  hipLaunchKernelGGL(k_scan_rows, dim3(256), dim3(kBlock), 0, c->stream, table, ck.nchunks, digit_base);
+  KCHECK();
+  hipLaunchKernelGGL(k_scan_excl_inplace, dim3(1), dim3(1024), 0, c->stream, digit_base, 256u, total);
+  KCHECK();
+  hipLaunchKernelGGL(k_check_counts, dim3(1), dim3(256), 0, c->stream, (const u32 *)hist, (const u32 *)digit_base, (const u32 *)total, text, d_sa, n32, qslot, err);
+  KCHECK();
+  {
+    CheckLoader ld; ld.sa = d_sa; ld.bw = bw; ld.n = n32;
+    CheckSink sk; sk.sa = d_sa; sk.q = qslot; sk.n = n32; sk.err = err;
+    KeyDig dig; dig.shift = 32; dig.mask = 255;                  // (Rec8.key = the byte)
+    const bool saved = c->profile; c->profile = false;           // (not a phase of a build)
+    const int rc = launch_downsweep_to<Rec8, 256, CheckLoader, CheckSink>(c, ld, sk, n32, ck, dig, table, digit_base, DC3HIP_PH_OTHER);
+    c->profile = saved;
+    RC(rc);
+  }
   HIPC(hipMemcpyAsync(c->h_words + 8, err, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPC(hipStreamSynchronize(c->stream));
   const int v = (int)c->h_words[8];

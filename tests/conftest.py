@@ -7,16 +7,20 @@ import sys
 import numpy as np
 import pytest
 
-# One HIP runtime per process: PyTorch wheels ship their own libamdhip64 / librccl.  Some tests need torch (bench.py's
-# children, the perf guards' device check, torch.distributed); a process that had loaded libdc3hip on the SYSTEM runtime and
-# imports torch afterwards carries two runtimes and aborts at exit (double free).  So torch — where installed — is
-# imported before anything can load the library; libdc3hip then binds to the runtime torch mapped (as bench.py and
-# __graft_entry__.smoke() do).
-# DC3HIP_TEST_NO_TORCH=1 (tools/fresh_process_fuzz.sh notorch): leave torch out, so that the library runs on the SYSTEM HIP
-# runtime it was compiled against instead of the one bundled with the wheel.
+# One HIP runtime per process: PyTorch wheels ship their own libamdhip64 / librccl (ROCm 7.0 in this image, the library is
+# compiled against 7.2).  A process that has loaded libdc3hip on the SYSTEM runtime and imports torch afterwards carries two
+# runtimes and aborts at exit (double free).
+#   * On a GPU box (/dev/kfd exists) the pytest process runs WITHOUT torch (round 6): every test talks to the GPU through
+#     the C ABI on the runtime the library was compiled against — rounds 1-5 ran on the wheel's, and round 5's crash hunt
+#     tied its rare teardown deaths to exactly that pair (profiles/r05_crash_hunt.md).  The tests that need torch
+#     (torch.distributed ranks, bench.py with N > 1, device-pointer tensors) start fresh child processes, which import torch
+#     first.  DC3HIP_TEST_WITH_TORCH=1 restores the old order (torch first, in this process).
+#   * Without a GPU (the CPU suite) torch — where installed — is imported first, as before: tests/test_bench_cli.py and
+#     tests/test_dist.py's parents may import it later, and the library is only loaded for its symbol table there.
+GPU_BOX = os.path.exists("/dev/kfd")
 try:
-    if os.environ.get("DC3HIP_TEST_NO_TORCH") == "1":
-        raise ImportError("torch left out on request")
+    if os.environ.get("DC3HIP_TEST_NO_TORCH") == "1" or (GPU_BOX and os.environ.get("DC3HIP_TEST_WITH_TORCH") != "1"):
+        raise ImportError("torch left out on purpose")
     import torch  # noqa: F401
 except Exception:  # pragma: no cover - torch is optional for the CPU-only tests
     torch = None
@@ -25,6 +29,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    # the rule above, enforced: a GPU-box session that ran without torch must not have picked it up on the way (it would
+    # abort at exit with two HIP runtimes mapped, after a green report)
+    if GPU_BOX and torch is None and "torch" in sys.modules and os.environ.get("DC3HIP_TEST_NO_TORCH") != "1":
+        print("\nconftest: torch was imported into the pytest process AFTER the session started without it — "
+              "a test imports torch in-process; move it into a child process", file=sys.stderr)
+        session.exitstatus = 3
 
 
 def pytest_configure(config):

@@ -7,13 +7,15 @@ import os
 import socket
 import sys
 
+import multiprocessing as mp
+
 import numpy as np
 import pytest
-import torch
-import torch.distributed as dist
-import torch.multiprocessing as mp
 
 from conftest import ROOT
+
+# torch is imported by the spawned rank processes only (each a fresh process: torch first, then the library); the pytest
+# process itself stays without it on a GPU box (conftest.py: one HIP runtime per process)
 
 
 def _free_port():
@@ -21,6 +23,8 @@ def _free_port():
 
 
 def _worker(rank, world, port, total_len, seed, q, use_product=False):
+    import torch
+    import torch.distributed as dist
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -82,6 +86,8 @@ def _two_rank(oracle, use_product):
 
 
 def _transport_worker(rank, world, port, q):
+    import torch  # noqa: F401
+    import torch.distributed as dist
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)

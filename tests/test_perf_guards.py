@@ -35,10 +35,8 @@ def ss():
     assert ss.device_count() >= 1
     # the bounds are MI355X milliseconds: on any other device the guards say nothing (DC3HIP_PERF_GUARD_ANY_DEVICE=1 runs them)
     # (the pool's MI355X reports the marketing name "AMD Radeon Graphics": go by architecture and CU count)
-    import torch
-    prop = torch.cuda.get_device_properties(0) if torch.cuda.is_available() else None
-    arch = getattr(prop, "gcnArchName", "") if prop else ""
-    if not (arch.startswith("gfx950") and prop.multi_processor_count == 256) and os.environ.get("DC3HIP_PERF_GUARD_ANY_DEVICE") != "1":
+    arch, cus = ss.device_info(0)            # (through the C ABI: no torch in this process, see conftest.py)
+    if not (arch.startswith("gfx950") and cus == 256) and os.environ.get("DC3HIP_PERF_GUARD_ANY_DEVICE") != "1":
         pytest.skip(f"perf guards are calibrated on MI355X (gfx950, 256 CUs), this is {arch!r}")
     return ss
 

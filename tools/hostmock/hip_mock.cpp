@@ -100,6 +100,14 @@ hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { MockStream *m = 
 hipError_t hipStreamDestroy(hipStream_t s) { check_stream(s); MockStream *m = reinterpret_cast<MockStream *>(s); m->magic = 0; delete m; return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t s) { check_stream(s); return hipSuccess; }
 hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
+// no virtual-memory management in the mock: the library falls back to hipMalloc (DevBuf, dc3_host_core.hpp)
+hipError_t hipMemAddressReserve(void **, size_t, size_t, void *, unsigned long long) { return t_last = hipErrorNotSupported; }
+hipError_t hipMemAddressFree(void *, size_t) { return hipSuccess; }
+hipError_t hipMemCreate(hipMemGenericAllocationHandle_t *, size_t, const hipMemAllocationProp *, unsigned long long) { return t_last = hipErrorNotSupported; }
+hipError_t hipMemRelease(hipMemGenericAllocationHandle_t) { return hipSuccess; }
+hipError_t hipMemMap(void *, size_t, size_t, hipMemGenericAllocationHandle_t, unsigned long long) { return t_last = hipErrorNotSupported; }
+hipError_t hipMemUnmap(void *, size_t) { return hipSuccess; }
+hipError_t hipMemSetAccess(void *, size_t, const hipMemAccessDesc *, size_t) { return t_last = hipErrorNotSupported; }
 hipError_t hipEventCreate(hipEvent_t *e) { *e = reinterpret_cast<hipEvent_t>(new MockEvent{kEventMagic}); return hipSuccess; }
 hipError_t hipEventDestroy(hipEvent_t e) { MockEvent *m = reinterpret_cast<MockEvent *>(e); if (m->magic != kEventMagic) die("hipEventDestroy of a dead event", e); m->magic = 0; delete m; return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) { check_stream(s); if (reinterpret_cast<MockEvent *>(e)->magic != kEventMagic) die("hipEventRecord on a dead event", e); return hipSuccess; }
