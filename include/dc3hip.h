@@ -19,9 +19,9 @@
  *   - all entry points are re-entrant and thread-safe: every call owns its context and HIP stream
  *     (sacapart calls the SACA concurrently from rayon workers, crates/sacapart/src/lib.rs:41-49).
  *     The one-shot calls keep that context (device buffers only, never caller data) in a per-thread
- *     cache so that repeated calls do not pay hipMalloc again; dc3hip_release_cache() or thread exit
- *     frees it, DC3HIP_CACHE=0 disables it.  Footprint: a cached context holds n + 4n + ~44n bytes of HBM for
- *     the largest n the thread has sorted (~50 GB per 1 GiB of text); it is dropped when a later call needs
+ *     cache so that repeated calls do not allocate again; dc3hip_release_cache() or thread exit
+ *     frees it, DC3HIP_CACHE=0 disables it.  Footprint: a cached context holds n + 4n + 24n..44n bytes of HBM for
+ *     the largest n the thread has sorted (29-50 GB per 1 GiB of text: what its builds committed); it is dropped when a later call needs
  *     less than a quarter of it.  Partitioned use should go through dc3hip_sufsort_ex(num_partitions), which
  *     runs one worker per GPU, rather than through concurrent one-shot calls on one device.
  *   - there is NO CPU fallback: without a usable gfx950 device the calls fail with -3.
@@ -35,7 +35,17 @@
  *                DC3HIP_QUIET=1 (no line on stderr when the HIP runtime in use is not the one the library was compiled against)
  *   diagnostics  DC3HIP_TRACE=1 (stage checksums), DC3HIP_LEVEL_PHASES=1 (phase times per level on stderr)
  *   test-only    ONE variable, DC3HIP_DEBUG="name[=value],name,...": forces or forbids one of the orderings so that the
- *                parity suite can compare them, or plants a fault for a verifier test (names: DESIGN.md section 7).
+ *                parity suite can compare them, lowers a size threshold so that small inputs reach a path, or plants a
+ *                fault for a verifier test.  The 30 names (round 6: pruned from 47; tests/test_debug_switches.py compares
+ *                this list with the sources):
+ *                  structure   no_text_shortcut, no_fullsort, no_hybrid, no_hybrid8, hybrid12_min=, no_long_keys,
+ *                              no_doubling, text_order12=0|1, no_small_ties, no_discard
+ *                  sorts       no_msd, msd_min=, msd_slot_cap=, no_pack_strip, ssort_min=, ssort_verify, no_wide_window,
+ *                              tup_scatter_min=
+ *                  memory      vmm_min= (smallest device buffer that is reserved + committed instead of hipMalloc'ed)
+ *                  global mode global_no_text_order, global_force_dist, global_force_wide, global_no_route,
+ *                              global_no_select, global_link_gbps=, global_device_token, no_wide_msd, wide_msd_min=,
+ *                              no_wide_deepen, wide_corrupt=1|2
  */
 #ifndef DC3HIP_H
 #define DC3HIP_H 1
@@ -109,9 +119,11 @@ DC3HIP_API int32_t dc3hip_hip_versions(int32_t *compiled, int32_t *runtime);
 typedef struct dc3hip_ctx dc3hip_ctx;
 
 /* Creates a context on `device` (-1 = current) able to index texts of up to max_n bytes.
- * Device memory: text (max_n + 64 bytes), suffix array (4 max_n) and a work arena of about 40 bytes per text byte (+ 224 MB),
- * allocated here; the arena grows once, to about 44 bytes per text byte, the first time a build enters the DC3 recursion
- * (high-entropy texts never do).  dc3hip_stats.arena_bytes / arena_peak report it. */
+ * Device memory: text (max_n + 64 bytes), suffix array (4 max_n) and a work arena of about 24 bytes per text byte (+ 208 MB)
+ * committed here.  From 2 GiB on a buffer is a reserved address range committed in equal pieces (hipMemAddressReserve /
+ * hipMemMap: 1 ms where hipMalloc of 44 GiB takes 1.7 s on MI355X), so the arena grows where it lies: by 16 bytes per text
+ * byte when the bucket ordering first takes slots for its second pass, to about 44 bytes per text byte the first time a
+ * build enters the DC3 recursion (high-entropy texts never do).  dc3hip_stats.arena_bytes / arena_peak report it. */
 DC3HIP_API int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n);
 DC3HIP_API void dc3hip_ctx_destroy(dc3hip_ctx *ctx);
 

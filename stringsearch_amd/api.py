@@ -32,10 +32,9 @@ _debug_init()
 # compares this list with the sources)
 DEBUG_NAMES = frozenset("""
 global_device_token global_force_dist global_force_wide global_link_gbps global_no_route global_no_select global_no_text_order
-hybrid12_min msd_min msd_slot_cap no_9bit no_discard no_doubling no_fullsort no_fuse_names no_hybrid no_hybrid12 no_hybrid8
-no_long_keys no_merge_keys64 no_msd no_msd_slots no_pack_count no_pack_strip no_raw_image no_rec12 no_small_ties no_split_emit
-no_ssort no_text_shortcut no_tup8 no_tup_rec8 no_tup_scatter no_vmm no_wide_deepen no_wide_msd no_wide_window no_xcd_map pack_fuse
-ssort_min ssort_rec12 ssort_verify text_order12 tup_bigtile tup_counted tup_scatter_min vmm_min wide_corrupt wide_msd_min
+hybrid12_min msd_min msd_slot_cap no_discard no_doubling no_fullsort no_hybrid no_hybrid8 no_long_keys no_msd no_pack_strip no_small_ties
+no_text_shortcut no_wide_deepen no_wide_msd no_wide_window ssort_min ssort_verify text_order12 tup_scatter_min vmm_min
+wide_corrupt wide_msd_min
 """.split())
 
 

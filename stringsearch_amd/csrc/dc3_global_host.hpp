@@ -690,7 +690,7 @@ static int gorder_positions(dc3hip_gctx *G, KM km, u32 m, u32 kbits, const HiMap
   bool selected = false;
   if constexpr (kFusable) {
     const MsdGeom mg = msd_geometry(c, m, hm);
-    if (!G->no_select && mg.on && c->pack_fuse && gselect_pays(G, P)) {
+    if (!G->no_select && mg.on && gselect_pays(G, P)) {
       u64 lo = 0, hi = ~0ull;
       {
         u32 ns = (u32)std::min<u64>(m, (u64)2048 * P);
@@ -1327,7 +1327,7 @@ static int gtext_order_with(dc3hip_gctx *G, KM km, u64 BL, const HiMap &hm, u32 
     if (!text_order_worth_trying(pred, (u64)n, hm.nbits)) return E_OK;
     bool tried = false;
     // (byte windows: gorder_positions has the selecting pass 1 of the single device's own kernels, cheaper still)
-    const bool have_select = std::is_same<KM, Key9>::value && !G->no_select && c->pack_fuse && gselect_pays(G, G->comm->nranks) &&
+    const bool have_select = std::is_same<KM, Key9>::value && !G->no_select && gselect_pays(G, G->comm->nranks) &&
                              msd_geometry(c, n, hm).on;
     RC(gorder_text_msd(G, sigma, done, &tried, have_select));
     if (!tried) RC((gorder_positions<KM>(G, km, n, kbits, hm, 0, nullptr, G_TOP, done)));
@@ -1354,7 +1354,7 @@ static int gtext_order(dc3hip_gctx *G, SymU8 S, u32 sigma, bool *done) {
     { unsigned __int128 mx = (unsigned __int128)B3 * B3 * B3 - 1; while (mx) { kbits++; mx >>= 1; } }
     Key9 km; km.S = S; km.B = (u32)Bq; km.B3 = (u32)B3;
     HiMap hm = make_himap(B3, kbits, n, wide ? 64 - ibits : bits_of((u64)n - 1));
-    hm.raw = sigma > 128 && !hm.exact && !c->no_raw_image ? 1u : 0u;       // (as build_core: byte alphabets)
+    hm.raw = sigma > 128 && !hm.exact ? 1u : 0u;       // (as build_core: byte alphabets)
     return gtext_order_with<Key9>(G, km, B3, hm, sigma, wide, done);
   }
   if (!c->no_long_keys) {

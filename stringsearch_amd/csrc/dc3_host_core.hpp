@@ -43,45 +43,51 @@ static inline hipError_t dc3_func_set_attribute(const void *fn, hipFuncAttribute
 // ---------------------------------------------------------------------------------------------
 struct DevBuf {
   unsigned char *va = nullptr;
-  size_t reserved = 0, mapped = 0;
+  size_t reserved = 0, mapped = 0, piece = 0;
   int device = 0;
-  std::vector<std::pair<hipMemGenericAllocationHandle_t, size_t>> pieces;
+  std::vector<hipMemGenericAllocationHandle_t> pieces;
 };
-static constexpr size_t kDevBufPiece = (size_t)1 << 30, kDevBufGran = (size_t)2 << 20;
+// All pieces of a buffer have ONE size: on ROCm 7.2 hipMemSetAccess refuses ("invalid argument") a mapping that is smaller
+// than the one mapped before it in the same reservation (976 + 464 MiB, 1024 + 464 MiB fail; 64 + 976, 512 x 3, 1024 x 6 pass:
+// tools/vmm_probe.hip, profiles/r06f_vmm_probe.jsonl).  The piece is a 64th of the reservation, a power of two between
+// 2 MiB and 1 GiB; commits are rounded up to whole pieces.
+static constexpr size_t kDevBufPieceMax = (size_t)1 << 30, kDevBufPieceMin = (size_t)2 << 20;
 static void devbuf_free(DevBuf *b) {
   if (!b->va) return;
   size_t off = 0;
-  for (auto &pc : b->pieces) { (void)hipMemUnmap(b->va + off, pc.second); (void)hipMemRelease(pc.first); off += pc.second; }
+  for (auto &h : b->pieces) { (void)hipMemUnmap(b->va + off, b->piece); (void)hipMemRelease(h); off += b->piece; }
   b->pieces.clear();
   (void)hipMemAddressFree(b->va, b->reserved);
-  b->va = nullptr; b->reserved = b->mapped = 0;
+  b->va = nullptr; b->reserved = b->mapped = b->piece = 0;
 }
 // (errors here are not reported through set_err: the caller falls back to hipMalloc or reports its own)
 static bool devbuf_reserve(DevBuf *b, int device, size_t bytes) {
+  size_t piece = kDevBufPieceMin;
+  while (piece < kDevBufPieceMax && piece * 64 < bytes) piece <<= 1;
   void *p = nullptr;
-  const size_t r = (bytes + kDevBufGran - 1) / kDevBufGran * kDevBufGran;
-  if (hipMemAddressReserve(&p, r, kDevBufGran, nullptr, 0) != hipSuccess || !p) { (void)hipGetLastError(); return false; }
-  b->va = static_cast<unsigned char *>(p); b->reserved = r; b->mapped = 0; b->device = device;
+  const size_t r = (bytes + piece - 1) / piece * piece;
+  if (hipMemAddressReserve(&p, r, kDevBufPieceMin, nullptr, 0) != hipSuccess || !p) { (void)hipGetLastError(); return false; }
+  b->va = static_cast<unsigned char *>(p); b->reserved = r; b->mapped = 0; b->piece = piece; b->device = device;
   return true;
 }
 // commit until at least `bytes` are mapped; false: out of memory or address space (what is mapped stays mapped)
 static bool devbuf_commit(DevBuf *b, size_t bytes) {
   if (bytes <= b->mapped) return true;
   if (!b->va || bytes > b->reserved) return false;
-  const size_t target = std::min(b->reserved, (bytes + kDevBufGran - 1) / kDevBufGran * kDevBufGran);
+  const size_t target = (bytes + b->piece - 1) / b->piece * b->piece;      // <= reserved (a multiple of the piece)
   hipMemAllocationProp prop; memset(&prop, 0, sizeof(prop));
   prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = b->device;
   hipMemAccessDesc acc; memset(&acc, 0, sizeof(acc));
   acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
   while (b->mapped < target) {
-    const size_t sz = std::min(kDevBufPiece, target - b->mapped);
+    const size_t sz = b->piece;
     hipMemGenericAllocationHandle_t h;
     if (hipMemCreate(&h, sz, &prop, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
     if (hipMemMap(b->va + b->mapped, sz, 0, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipMemRelease(h); return false; }
     if (hipMemSetAccess(b->va + b->mapped, sz, &acc, 1) != hipSuccess) {
       (void)hipGetLastError(); (void)hipMemUnmap(b->va + b->mapped, sz); (void)hipMemRelease(h); return false;
     }
-    b->pieces.emplace_back(h, sz);
+    b->pieces.push_back(h);
     b->mapped += sz;
   }
   return true;
@@ -109,7 +115,7 @@ struct dc3hip_ctx {
   size_t arena_bytes = 0, arena_off = 0, arena_peak = 0;
   // round 6: big buffers are reserved address ranges, committed as needed (DevBuf): arena_vm.va == arena when the arena is
   // one; sa_vm / text_vm likewise for d_sa / d_text beyond kDevBufMinBytes.  use_vm = false (ranks of the global mode, whose
-  // buffers RCCL and peer copies see; DC3HIP_DEBUG=no_vmm): plain hipMalloc as before
+  // buffers RCCL and peer copies see): plain hipMalloc as before
   DevBuf arena_vm, sa_vm, text_vm;
   bool use_vm = true;
   size_t vm_min = (size_t)2 << 30;   // DC3HIP_DEBUG=vmm_min=<bytes> (tests): smallest buffer that is reserved + committed
@@ -128,40 +134,24 @@ struct dc3hip_ctx {
   bool profile = true;
   bool no_hybrid = false;
   bool no_small_ties = false;
-  bool no_nine_bit = false, no_rec12 = false, no_discard = false, no_fullsort = false, no_text_shortcut = false;
-  bool no_split_emit = false;
+  bool no_discard = false, no_fullsort = false, no_text_shortcut = false;
   bool no_long_keys = false;   // DC3HIP_NO_LONG_KEYS=1: the whole-text shortcut only with 9-symbol windows (no KeyT)
   bool no_doubling = false;    // DC3HIP_NO_DOUBLING=1: repeated windows always hand the whole-text order to level 1
   int text_order12 = -1;       // DC3HIP_TEXT_ORDER12=1/0: whole-text shortcut on 12-byte records always / never (default: n > 2^31)
   double hybrid_max_pred = 0.50;                      // 8-byte prefix sort of a level's samples: taken below this predicted tied fraction
   double hybrid12_max_pred = kHybrid12MaxPredicted;   // 12-byte prefix sort: taken below this predicted tied fraction
+  bool no_hybrid8 = false;     // DC3HIP_DEBUG=no_hybrid8 (tests): skip the 8-byte prefix sort / whole-level order of a level (the 12-byte one is reached)
   u32 hybrid12_min = 1u << 22; // DC3HIP_HYBRID12_MIN: smallest level (samples) that tries it (tests lower it)
-  bool no_hybrid8 = false;     // DC3HIP_NO_HYBRID8=1 (tests): skip the 8-byte prefix sort / whole-level order of a level
-  bool no_hybrid12 = false;    // DC3HIP_NO_HYBRID12=1: no 63-bit-prefix sort on 12-byte records for keys wider than 64 bits
-  bool no_tup_scatter = false; // DC3HIP_NO_TUP_SCATTER=1: sample tuples always by the random gather
   u32 tup_scatter_min = 1u << 25; // DC3HIP_TUP_SCATTER_MIN (tests): smallest level (samples) whose tuples are scattered
-  bool no_tup_rec8 = false;    // DC3HIP_NO_TUP_REC8=1 (tests): level 0 moves 12-byte records through the tuple scatter, as deeper levels do
-  bool no_xcd_map = false;     // DC3HIP_NO_XCD_MAP=1: window partitions without the segment -> XCD-group tile order (measurement aid)
-  bool pack_fuse = true;       // DC3HIP_PACK_FUSE=0: whole-text order of bytes with a pack kernel that WRITES the words (default: it only counts, partition pass 1 makes them on the fly)
-  bool tup_bigtile = true;     // DC3HIP_TUP_BIGTILE=0 (lab / tests): level 0's tuple scatter pass 1 in the 4096-slot, 512-thread shape of the deeper levels
-  bool no_raw_image = false;   // DC3HIP_NO_RAW_IMAGE=1: byte alphabets keep the scaled 9-symbol key as their sort image (default: the text's own leading bits, HiMap::raw)
-  bool no_pack_strip = false;  // DC3HIP_NO_PACK_STRIP=1: ... from an image no wider than the word (default: d1 bits wider, the bucket's own bits dropped)
+  bool no_pack_strip = false;  // DC3HIP_DEBUG=no_pack_strip: partition pass 1 makes its words from an image no wider than the word (default: d1 bits wider, the bucket's own bits dropped)
   bool no_msd = false;         // DC3HIP_NO_MSD=1: the prefix sorts always run the stable LSD passes (no bucket ordering)
   u32 ssort_over = 24;         // splitter ordering: sample values per sub-bucket
   u32 ssort_mean = 1400;       // splitter ordering: records per sub-bucket it aims at (capacity 4096)
   bool no_wide_window = false; // DC3HIP_NO_WIDE_WINDOW=1: straight orderings always sort the triple (no wider window)
-  bool ssort_rec12 = false;    // DC3HIP_SSORT_REC12=1: the splitter ordering also for keys of at most 64 bits (tests)
-  bool no_pack_count = false;  // DC3HIP_NO_PACK_COUNT=1: the wide-window records are packed by their own kernel, then counted
   bool ssort_verify = false;   // DC3HIP_SSORT_VERIFY=1 (tests): every splitter ordering checks its passes (record checksums, cursors, order); a mismatch fails the build
   u32 msd_slot_cap = 0;        // DC3HIP_DEBUG=msd_slot_cap=N (tests): slots of N words instead of twice the mean — small N makes them overflow
-  bool no_msd_slots = false;   // DC3HIP_DEBUG=no_msd_slots: pass 2 of the bucket ordering always in its counted form (k_msd_hist2 first)
-  bool no_merge_keys64 = false; // DC3HIP_DEBUG=no_merge_keys64: the merge compares tuple fields (16-byte LDS image) also where 64-bit keys would do
-  bool tup_counted = false;    // DC3HIP_DEBUG=tup_counted: the tuple scatter's pass 1 counts its buckets per XCD group first (the round-4 form)
-  bool no_fuse_names = false;  // DC3HIP_NO_FUSE_NAMES=1: names / final slots are written as pairs first (k_name_assign, k_final_assign)
-  bool no_ssort = false;       // DC3HIP_NO_SSORT=1: the straight orderings always run the stable LSD passes (no splitter ordering)
   u32 ssort_min = 1u << 23;    // DC3HIP_SSORT_MIN: fewest records the splitter ordering is used for (tests lower it)
   u32 msd_min = 1u << 20;      // DC3HIP_MSD_MIN: fewest records the bucket ordering is used for (tests lower it)
-  bool no_tup8 = false;        // DC3HIP_NO_TUP8=1: the slot table of the merge tuples is always 16 bytes per sample
   bool trace = false;          // DC3HIP_TRACE=1: per-level checksums of SA12 / SA0 / SA (dc3hip_stats.trace_*)
   u64 *d_trace = nullptr;      // [3][DC3HIP_MAX_LEVELS]
   std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;

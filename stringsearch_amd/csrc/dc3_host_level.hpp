@@ -50,10 +50,10 @@ static int scatter_tuples_run(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, cons
   typedef typename Out::Rec Rec;
   *done = false;
   // (level 0, 8-byte words: pass 1 in tiles of 6144 slots on 1024 threads, k_tup8_part1, unless DC3HIP_TUP_BIGTILE=0)
-  const bool big = kDerive && c->tup_bigtile;
+  const bool big = kDerive;
   // one cursor per bucket at its analytic base (k_tup_cur_init): level 0's 8-byte records only — the 12-byte records of the
   // deeper levels lost 1.4 ms per 477 M without the split between the XCD groups (measured, round 5)
-  const bool analytic = kDerive && !c->tup_counted;
+  const bool analytic = kDerive;
   const u32 gstr = analytic ? 0u : nb_of(m02);
   const u32 tile1 = big ? (u32)kTup8Tile : (u32)kTupTile;
   const u32 ntiles = (m02 + tile1 - 1) / tile1;
@@ -145,9 +145,9 @@ template <class Sym>
 static int scatter_tuples(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, const u32 *rank12, const u32 *sa12, const Chunking &ckc,
                           TupC *t12, u32 *table0, bool *done) {
   *done = false;
-  if (c->no_tup_scatter || m02 < c->tup_scatter_min || m02 < 2 || ckc.chunk < kTupWin) return E_OK;
+  if (m02 < c->tup_scatter_min || m02 < 2 || ckc.chunk < kTupWin) return E_OK;
   if constexpr (std::is_same<Sym, SymU8>::value) {
-    if (!c->no_tup_rec8) return scatter_tuples_run<Sym, TupOut8, true>(c, S, m, m0, m02, rank12, sa12, ckc, t12, table0, done);
+    return scatter_tuples_run<Sym, TupOut8, true>(c, S, m, m0, m02, rank12, sa12, ckc, t12, table0, done);
   }
   return scatter_tuples_run<Sym, TupOut12, false>(c, S, m, m0, m02, rank12, sa12, ckc, t12, table0, done);
 }
@@ -157,7 +157,7 @@ static int build_gather_tuples(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u64
                                u32 cnt, const Chunking &ckc, Tup12 *t12, u32 *table0) {
   const ArenaMark mk = arena_mark(c);
   PhaseScope ps(c, DC3HIP_PH_TUPLES, m02);
-  if (K < 65536 && !c->no_tup8) {
+  if (K < 65536) {
     TupS8 *ts = nullptr;
     RC(arena_alloc(c, (size_t)m02, &ts));
     hipLaunchKernelGGL((k_build_tuples8<Sym>), dim3(grid_for(c, m0)), dim3(kBlock), 0, c->stream, S, m, m0, m02, rank12, ts);
@@ -220,7 +220,7 @@ static int merge_lists(dc3hip_ctx *c, const TA *A, u32 nA, const TB *B, u32 nB, 
                        u32 rank_base, bool keys64 = false) {
   // 1024 threads x 2 outputs: re-measured in round 4 on the compact tuples against 512 x 4, 1024 x 4, 256 x 8, 512 x 8
   // (merge of 1.07 G suffixes: 6.2 / 7.0 / 8.0 / 10.2 / 10.7 ms, profiles/r04g_lab_shapes.jsonl)
-  return merge_lists_shape<1024, 2, TA, TB>(c, A, nA, B, nB, out_sa, out_pairs, rank_base, keys64 && !c->no_merge_keys64);
+  return merge_lists_shape<1024, 2, TA, TB>(c, A, nA, B, nB, out_sa, out_pairs, rank_base, keys64);
 }
 
 // Steps 2 + 3 of a level (lib.rs:118-192) on compact tuples: sample tuples scattered into SA12 order (TupC), mod-0
@@ -365,7 +365,7 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
       }
     }
     // (with the splitter ordering the full 96-bit key costs three passes: no prefix + tie rounds then)
-    if (!done && kbits > 64 && m02 >= c->hybrid12_min && !c->no_hybrid && !c->no_hybrid12 && !ssort_applies(c, m02, kbits)) {
+    if (!done && kbits > 64 && m02 >= c->hybrid12_min && !c->no_hybrid && !ssort_applies(c, m02, kbits)) {
       // wide keys whose 34-bit image collides everywhere: try the 63-bit prefix on 12-byte records
       bool ok = false;
       RC(order_hybrid12<Sym>(c, S, m, m0, m02, b, kbits, sa12, rank12, R, sslot, &names, &mode, &ok, depth));
@@ -383,7 +383,7 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
     }
     if (!done) {
       c->stats.level_sorted[depth] = 1;
-      if (kbits <= 64 && !c->no_rec12)
+      if (kbits <= 64)
         RC((order_straight<Sym, Rec12>(c, S, m, m0, m02, b, kbits, sa12, rank12, R, sslot, &names, &mode)));
       else
         RC((order_straight<Sym, Rec16>(c, S, m, m0, m02, b, kbits, sa12, rank12, R, sslot, &names, &mode)));
@@ -409,7 +409,7 @@ static int dc3_level(dc3hip_ctx *c, Sym S, u32 m, u64 K, u32 *out_sa, u32 *out_r
   // t12 = sample tuples in SA12 order.  The gather also produces the digit table of the fused
   // "select mod-0 + first radix pass" (Step 2, lib.rs:118-126).
   // Levels whose symbols fit 16 bits and that are large enough for the scatter: compact tuples (12 / 16 bytes).
-  if (K < 65536 && !c->no_tup8) {
+  if (K < 65536) {
     bool done = false;
     RC((unwind_compact<Sym>(c, S, m, m0, m1, m02, K, rank12, sa12, out_sa, out_rank, depth, &done)));
     if (done) { arena_release(c, mk0); return E_OK; }
@@ -728,7 +728,7 @@ static int build_core(dc3hip_ctx *c) {
       // The 12-byte records remain for what that needs and does not have (no bucket ordering on this device, switched off
       // by a test) and for texts whose mean sub-bucket (n / 2^20) would pass the local sort's capacity.
       const bool big = bits_of((u64)n - 1) >= 32;
-      const bool strip8 = big && !c->no_msd && c->pack_fuse && !c->no_pack_strip && (u64)n >= c->msd_min && (u64)n <= kText8MaxN;
+      const bool strip8 = big && !c->no_msd && !c->no_pack_strip && (u64)n >= c->msd_min && (u64)n <= kText8MaxN;
       const bool wide = c->text_order12 >= 0 ? c->text_order12 == 1 : (big && !strip8);
       constexpr u32 kStripBits = 10;                 // msd_geometry's d1 for 2^29 words and more
       const u32 ibits = std::min<u32>(63, 9 * (u32)ceil((log2((double)n) + 4.2) / 9.0));
@@ -739,7 +739,7 @@ static int build_core(dc3hip_ctx *c) {
         HiMap hm = make_himap(B3, kbits, (u32)n, wide ? 64 - ibits : bits_of((u64)n - 1));
         // alphabets past half the byte values: the image is the window's leading bits as they lie in the text
         // (HiMap::raw) — under one bit per symbol given away against the scaled key, and none of its arithmetic
-        hm.raw = sigma > 128 && !hm.exact && !c->no_raw_image ? 1u : 0u;
+        hm.raw = sigma > 128 && !hm.exact ? 1u : 0u;
         if (wide) RC(try_text_order12<Key9>(c, km, B3, hm, sigma, &whole_text, &pre));
         else if (strip8 && !hm.exact && kbits >= hm.nbits + kStripBits) {
           HiMap hp = make_himap(B3, kbits, (u32)n, hm.pbits - kStripBits);

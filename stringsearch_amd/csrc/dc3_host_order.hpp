@@ -47,7 +47,7 @@ static int inverse_permute_from(dc3hip_ctx *c, Src first, bool first_is_a, Rec8 
     HIPC(hipMemsetAsync(cur, 0, (size_t)nseg * 256 * sizeof(u32), c->stream));
     // (with more than one 2^22-pair segment: segment s on the XCD group s % 8, see k_part_msd)
     const u32 tps = (1u << 22) / kPartTile;
-    const bool xcd = kb > 22 && !c->no_xcd_map;
+    const bool xcd = kb > 22;
     const u32 grid = xcd ? 8u * ((nseg + 7) / 8) * tps : ntiles;
     if (at_first)
       hipLaunchKernelGGL((k_part_msd<Src>), dim3(grid), dim3(kPartNW * 64), kPartSmem, c->stream, first, dst, n,
@@ -96,7 +96,7 @@ static int name_and_rank(dc3hip_ctx *c, Acc acc, u32 m02, u32 m0, u32 *sa12, u32
   const ArenaMark mk = arena_mark(c);
   // fused form (levels beyond one inversion window): the names are made inside the first partition pass of their
   // inversion (PairsOfNames) from per-tile counts, so the counting kernel works in the partition's tiles
-  const bool fused = m02 > (1u << kInvWindowBits) && !c->no_fuse_names;
+  const bool fused = m02 > (1u << kInvWindowBits);
   Chunking ck = make_chunks(c, m02, kBlock * kNameIPT);
   if (fused) { ck.chunk = kPartTile; ck.nchunks = (m02 + kPartTile - 1) / kPartTile; }
   u32 *counts = nullptr;
@@ -206,7 +206,7 @@ static int discard_recurse(dc3hip_ctx *c, const u32 *RU, const u32 *sslot, u32 m
   Rec8 *pa = nullptr, *pb = nullptr;
   RC(arena_alloc(c, (size_t)m02, &pa));
   RC(arena_alloc(c, (size_t)m02, &pb));
-  if (m02 > (1u << kInvWindowBits) && !c->no_fuse_names) {
+  if (m02 > (1u << kInvWindowBits)) {
     // the final order is put together inside the first partition pass of the rank inversion (PairsOfFinal)
     const u32 ntile = (m02 + kPartTile - 1) / kPartTile;
     u32 *tc = nullptr;
@@ -400,7 +400,7 @@ static int order_wide(dc3hip_ctx *c, Sym S, u32 m, u32 m0, u32 m02, u32 sb, u32 
   RC(arena_alloc(c, (size_t)m02, &recB));
   bool by_splitters = false;
   SsGeom geo;
-  if (ssort_geometry(c, m02, W * sb, &geo) && !c->no_pack_count) {
+  if (ssort_geometry(c, m02, W * sb, &geo)) {
     // the records are made by the kernel that counts the coarse buckets (written once, not read back for the count)
     WideProducer<Sym> prod; prod.S = S; prod.sb = sb; prod.W = W;
     RC(ssort<Rec16>(c, recA, recB, m02, W * sb, &sorted, &by_splitters, &prod));
@@ -462,7 +462,7 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
   Rec8 *h = nullptr;
   bool msd_ok = false;                 // (record form) the bucket ordering delivered, with its same-image bytes in same_rec
   uint8_t *same_rec = nullptr;
-  if (emit_sa && emitted_distinct && skip == 0 && !c->no_small_ties && !c->no_split_emit && hm.pbits <= 32) {
+  if (emit_sa && emitted_distinct && skip == 0 && !c->no_small_ties && hm.pbits <= 32) {
     // optimistic end of the whole-text order: the last pass writes positions to the SA buffer and 32 image bits to a
     // side array; the tie pass settles the tied groups in place.  Complete unless a key repeats or a group is large.
     // (what the tie pass reads: a "same image as the record before" byte from the bucket ordering, or the 32 image bits
@@ -1160,7 +1160,7 @@ static int order_all_positions(dc3hip_ctx *c, KM km, Map mp, u32 m, u32 kbits, c
   //  that writes: their rolling image inside the partition pass was measured slower, 22.8 -> 27.9 ms at 1 GiB DNA)
   constexpr bool kKeyT = std::is_same<KM, KeyT>::value;
   constexpr bool kFusable = std::is_same<KM, Key9>::value || std::is_same<KM, Key3<SymU32>>::value;
-  const bool fuse = mg.on && c->pack_fuse && kFusable;
+  const bool fuse = mg.on && kFusable;
   MsdPass1Keys<KM> p1; p1.km = km; p1.hm = hm; p1.P1 = pass1_p1<KM>(km);
   MsdGeom mgx = mg;
   if constexpr (kFusable) {
@@ -1181,7 +1181,7 @@ static int order_all_positions(dc3hip_ctx *c, KM km, Map mp, u32 m, u32 kbits, c
   if constexpr (kKeyT) {
     // KeyT: the image stays in a pack kernel (inside pass 1 it was measured slower), which writes it d1 bits wider
     KeyT kw; HiMap hw;
-    if (mg.on && c->pack_fuse && !c->no_pack_strip && dummy == 0 && hm.pbits >= 23 && hm.nbits + mg.d1 <= 62 &&
+    if (mg.on && !c->no_pack_strip && dummy == 0 && hm.pbits >= 23 && hm.nbits + mg.d1 <= 62 &&
         make_keyt(km.S, km.sigma, km.L, km.BL, m, &kw, &hw, hm.nbits + mg.d1)) {
       pimg.ki.img = reinterpret_cast<const u64 *>(ha); pimg.hm = hw; pimg.km_plain = km; pimg.hm_plain = hm;
       mgx.ebits = hw.nbits;

@@ -136,7 +136,7 @@ static int radix_redo_last(dc3hip_ctx *c, const LastPass &lp, u32 n, Rec8 **resu
   return lp.nb == 512 ? radix_redo_last_nb<512>(c, lp, n, result, ph_up, ph_scan, ph_down)
                       : radix_redo_last_nb<256>(c, lp, n, result, ph_up, ph_scan, ph_down);
 }
-static bool radix_nine(const dc3hip_ctx *c, u32 bits) { return !c->no_nine_bit && ((bits + 8) / 9 < (bits + 7) / 8); }
+static bool radix_nine(const dc3hip_ctx *, u32 bits) { return (bits + 8) / 9 < (bits + 7) / 8; }
 template <class Rec>
 static int radix_sort(dc3hip_ctx *c, Rec *a, Rec *b, u32 n, u32 bit_lo, u32 bit_hi, Rec **result, int ph_up,
                       int ph_scan, int ph_down, u32 *first_table = nullptr, const SplitSink *final_sink = nullptr,
@@ -321,7 +321,7 @@ static int msd_sort(dc3hip_ctx *c, Rec8 *ha, Rec8 *hb, u32 n, const HiMap &hm, c
   // counted form checks) sends the sort through the counted form below, from the untouched output of pass 1.
   bool slot_done = false;
   const ArenaMark slot_mk = arena_mark(c);
-  if (g.d2 > 0 && allow_slots && !c->no_msd_slots) {
+  if (g.d2 > 0 && allow_slots) {
     const u32 mean = (u32)(((u64)n + n2 - 1) / n2);
     const u32 slot_cap = c->msd_slot_cap ? std::min<u32>(kMsdCapSmall, c->msd_slot_cap) : std::min<u32>(kMsdCapSmall, (2 * mean + 63) & ~63u);
     const u64 slot_words = (u64)n2 * slot_cap + kMsdTile;
@@ -458,7 +458,7 @@ static constexpr u32 kSsCap = 4096;
 // prefix + tie rounds (and 9 LSD passes for the straight order); 477 M 12-byte records with 45-bit keys, 28 ms against
 // 21 ms for the 5 LSD passes — so the keys of at most 64 bits stay with the LSD passes (DC3HIP_SSORT_REC12=1: tests).
 static bool ssort_applies(const dc3hip_ctx *c, u32 n, u32 kbits) {
-  return !c->no_ssort && n >= c->ssort_min && n >= 8192 && (kbits > 64 || c->ssort_rec12);
+  return n >= c->ssort_min && n >= 8192 && kbits > 64;
 }
 // A caller whose records do not exist yet hands in a producer: sample() computes S of them (ascending index),
 // pack_count() makes all of them into `a` while it counts the coarse buckets (k_ss_count1's arguments).

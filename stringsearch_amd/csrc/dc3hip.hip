@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <climits>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <mutex>
@@ -117,25 +118,20 @@ static int ctx_create_impl(dc3hip_ctx **out, int32_t device, int64_t max_n, dc3h
   c->profile = !(prof && prof[0] == '0');
   { const char *e = getenv("DC3HIP_TRACE"); c->trace = (e && e[0] == '1'); }
   { const char *e = getenv("DC3HIP_LEVEL_PHASES"); c->level_report = (e && e[0] == '1'); }
-  // test / diagnosis switches (DC3HIP_DEBUG, dc3_host_core.hpp): none changes a result
-  c->no_hybrid = dbg_on("no_hybrid"); c->no_hybrid8 = dbg_on("no_hybrid8"); c->no_hybrid12 = dbg_on("no_hybrid12");
-  c->no_small_ties = dbg_on("no_small_ties"); c->no_split_emit = dbg_on("no_split_emit");
+  // test / diagnosis switches (DC3HIP_DEBUG, dc3_host_core.hpp; the names: include/dc3hip.h): none changes a result
+  c->no_hybrid = dbg_on("no_hybrid"); c->no_hybrid8 = dbg_on("no_hybrid8");
+  c->no_small_ties = dbg_on("no_small_ties");
   c->no_long_keys = dbg_on("no_long_keys"); c->no_doubling = dbg_on("no_doubling");
   if (dbg_on("text_order12")) c->text_order12 = 1; else if (dbg_off("text_order12")) c->text_order12 = 0;
-  c->no_tup8 = dbg_on("no_tup8"); c->no_tup_scatter = dbg_on("no_tup_scatter"); c->no_tup_rec8 = dbg_on("no_tup_rec8");
-  c->tup_bigtile = !dbg_off("tup_bigtile"); c->pack_fuse = !dbg_off("pack_fuse");
-  c->no_msd = dbg_on("no_msd"); c->no_xcd_map = dbg_on("no_xcd_map");
-  c->no_raw_image = dbg_on("no_raw_image"); c->no_pack_strip = dbg_on("no_pack_strip"); c->no_pack_count = dbg_on("no_pack_count");
-  c->no_ssort = dbg_on("no_ssort"); c->ssort_verify = dbg_on("ssort_verify"); c->ssort_rec12 = dbg_on("ssort_rec12");
-  c->no_wide_window = dbg_on("no_wide_window"); c->no_fuse_names = dbg_on("no_fuse_names"); c->tup_counted = dbg_on("tup_counted"); c->no_merge_keys64 = dbg_on("no_merge_keys64"); c->no_msd_slots = dbg_on("no_msd_slots");
+  c->no_msd = dbg_on("no_msd"); c->no_pack_strip = dbg_on("no_pack_strip");
+  c->ssort_verify = dbg_on("ssort_verify"); c->no_wide_window = dbg_on("no_wide_window");
   c->no_text_shortcut = dbg_on("no_text_shortcut"); c->no_fullsort = dbg_on("no_fullsort"); c->no_discard = dbg_on("no_discard");
-  c->no_nine_bit = dbg_on("no_9bit"); c->no_rec12 = dbg_on("no_rec12");
   { long long v; if (dbg_num("tup_scatter_min", &v)) c->tup_scatter_min = (u32)std::max(0ll, v); }
   { long long v; if (dbg_num("msd_min", &v)) c->msd_min = (u32)std::max(4096ll, v); }
   { long long v; if (dbg_num("msd_slot_cap", &v)) c->msd_slot_cap = (u32)std::max(1ll, v); }
   { long long v; if (dbg_num("ssort_min", &v)) c->ssort_min = (u32)std::max(8192ll, v); }
   { long long v; if (dbg_num("hybrid12_min", &v)) c->hybrid12_min = (u32)std::max(0ll, v); }
-  c->use_vm = use_vm && !dbg_on("no_vmm");
+  c->use_vm = use_vm;
   { long long v; if (dbg_num("vmm_min", &v)) c->vm_min = (size_t)std::max(1ll, v); }
   int rc = [&]() -> int {
     HIPC(hipSetDevice(device));
@@ -673,14 +669,27 @@ static int sufsort_one(const uint8_t *T, void *SA, int64_t n, int bits, int devi
   if (n == 0) return E_OK;
   dc3hip_ctx *c = nullptr;
   bool cached = false;
+  typedef std::chrono::steady_clock clk;
+  auto ms_since = [](clk::time_point a) { return std::chrono::duration<double, std::milli>(clk::now() - a).count(); };
+  const clk::time_point t0 = clk::now();
   RC(acquire_ctx(&c, device, n, &cached));
+  const double t_ctx = ms_since(t0);
+  double t_h2d = 0, t_build = 0, t_d2h = 0;
   int rc = [&]() -> int {
+    clk::time_point t1 = clk::now();
     RC(dc3hip_ctx_set_text(c, T, n));          // hipMemcpyDefault handles host or device sources
+    t_h2d = ms_since(t1); t1 = clk::now();
     RC(ctx_build(c));
+    t_build = ms_since(t1); t1 = clk::now();
     if (bits == 32) RC(dc3hip_ctx_get_sa_i32(c, static_cast<int32_t *>(SA)));
     else RC(dc3hip_ctx_get_sa_i64(c, static_cast<int64_t *>(SA)));
+    t_d2h = ms_since(t1);
     return E_OK;
   }();
+  // DC3HIP_LEVEL_PHASES=1: where a one-shot call's wall time went (what crates/divsuftest/src/main.rs:145-151 times)
+  if (c->level_report)
+    std::fprintf(stderr, "dc3hip one-shot n=%lld: context %.1f ms (%s), text to device %.1f, build %.1f (device %.1f), array to host %.1f\n", (long long)n, t_ctx,
+                 t_ctx > 1.0 ? "created" : "cached", t_h2d, t_build, c->stats.build_ms, t_d2h);
   if (!cached) dc3hip_ctx_destroy(c);
   else if (rc != E_OK) { dc3hip_ctx_destroy(c); g_cache.c = nullptr; }   // do not keep a context in an unknown state
   return rc;

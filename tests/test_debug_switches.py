@@ -91,3 +91,17 @@ def test_bench_global_reads_force_wide_in_either_spelling():
             os.environ.pop("DC3HIP_DEBUG", None)
         else:
             os.environ["DC3HIP_DEBUG"] = before
+
+
+def test_header_lists_the_switches_and_there_are_at_most_30():
+    """(round-5 verdict, item 9) the test-only switch surface: at most 30 names, listed in include/dc3hip.h."""
+    hdr = open(os.path.join(ROOT, "include", "dc3hip.h")).read()
+    block = hdr[hdr.index("test-only    ONE variable"):hdr.index("*/", hdr.index("test-only    ONE variable"))]
+    listed = set()
+    for line in block.splitlines():
+        if re.search(r"^\s*\*\s+(structure|sorts|memory|global mode)?\s{2,}", line) and ("=" in line or "," in line or "no_" in line):
+            body = re.sub(r"\(.*?\)", "", line.split("*", 1)[1])
+            body = re.sub(r"^\s*(structure|sorts|memory|global mode)", "", body)
+            listed |= {tok.strip().split("=")[0] for tok in body.split(",") if re.fullmatch(r"[a-z0-9_]+(=[0-9|]*)?", tok.strip())}
+    assert listed == set(ss.api.DEBUG_NAMES), (listed ^ set(ss.api.DEBUG_NAMES))
+    assert len(ss.api.DEBUG_NAMES) <= 30

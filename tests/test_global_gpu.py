@@ -436,8 +436,8 @@ def test_loopback_env_matrix_agrees(ss, oracle):
     t = np.concatenate([oracle.gen(1_200_000, 3, 2), oracle.gen(600_000, 2, 0), oracle.gen(1_200_000, 3, 2)[100_000:700_000]])
     want = want_sa(oracle, t)
     for extra in ({}, {"DC3HIP_NO_HYBRID": 1}, {"DC3HIP_NO_FULLSORT": 1}, {"DC3HIP_NO_DISCARD": 1},
-                  {"DC3HIP_NO_HYBRID": 1, "DC3HIP_NO_DISCARD": 1}, {"DC3HIP_NO_SMALL_TIES": 1}, {"DC3HIP_NO_SPLIT_EMIT": 1},
-                  {"DC3HIP_NO_TUP8": 1}, {"DC3HIP_NO_HYBRID8": 1}, {"DC3HIP_NO_HYBRID8": 1, "DC3HIP_NO_DISCARD": 1},
+                  {"DC3HIP_NO_HYBRID": 1, "DC3HIP_NO_DISCARD": 1}, {"DC3HIP_NO_SMALL_TIES": 1},
+                  {"DC3HIP_NO_HYBRID8": 1}, {"DC3HIP_NO_HYBRID8": 1, "DC3HIP_NO_DISCARD": 1},
                   # the straight key-range sort on W-symbol windows, by the splitter ordering (threshold lowered)
                   {"DC3HIP_SSORT_MIN": 8192}, {"DC3HIP_SSORT_MIN": 8192, "DC3HIP_NO_HYBRID8": 1},
                   {"DC3HIP_SSORT_MIN": 8192, "DC3HIP_NO_HYBRID8": 1, "DC3HIP_NO_DISCARD": 1},

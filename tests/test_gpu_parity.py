@@ -444,11 +444,8 @@ def test_hybrid_and_straight_paths_agree(ss, oracle):
         want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)
         seen = {}
         for env in ({}, {"DC3HIP_NO_HYBRID": "1"}, {"DC3HIP_NO_SMALL_TIES": "1"}, {"DC3HIP_NO_FULLSORT": "1"},
-                    {"DC3HIP_NO_TEXT_SHORTCUT": "1"}, {"DC3HIP_NO_SPLIT_EMIT": "1"}, {"DC3HIP_TEXT_ORDER12": "1"}, {"DC3HIP_NO_DOUBLING": "1"},
-                    {"DC3HIP_NO_TEXT_SHORTCUT": "1", "DC3HIP_NO_TUP8": "1"},
-                    {"DC3HIP_NO_TEXT_SHORTCUT": "1", "DC3HIP_NO_HYBRID8": "1", "DC3HIP_HYBRID12_MIN": "0"},   # 12-byte prefix sort
-                    {"DC3HIP_NO_HYBRID12": "1"},
-                    {"DC3HIP_NO_HYBRID": "1", "DC3HIP_NO_9BIT": "1", "DC3HIP_NO_REC12": "1"}):
+                    {"DC3HIP_NO_TEXT_SHORTCUT": "1"}, {"DC3HIP_TEXT_ORDER12": "1"}, {"DC3HIP_NO_DOUBLING": "1"},
+                    {"DC3HIP_NO_TEXT_SHORTCUT": "1", "DC3HIP_NO_HYBRID8": "1", "DC3HIP_HYBRID12_MIN": "0"}):   # 12-byte prefix sort
             env_apply(env)
             try:
                 with ss.Context(len(data)) as c:
@@ -549,7 +546,7 @@ def test_small_alphabet_long_windows(ss, oracle):
         data = arr.tobytes()
         want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)
         seen = {}
-        for env in ({}, {"DC3HIP_NO_LONG_KEYS": "1"}, {"DC3HIP_NO_SPLIT_EMIT": "1"}, {"DC3HIP_NO_SMALL_TIES": "1"},
+        for env in ({}, {"DC3HIP_NO_LONG_KEYS": "1"}, {"DC3HIP_NO_SMALL_TIES": "1"},
                     {"DC3HIP_TEXT_ORDER12": "1"}, {"DC3HIP_TEXT_ORDER12": "1", "DC3HIP_NO_SMALL_TIES": "1"},
                     {"DC3HIP_NO_DOUBLING": "1"}, {"DC3HIP_NO_DOUBLING": "1", "DC3HIP_TEXT_ORDER12": "1"}):
             env_apply(env)
@@ -659,11 +656,9 @@ def test_bucket_ordering_matches_the_stable_passes(ss, oracle):
         data = arr.tobytes()
         want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)
         for env in ({"DC3HIP_MSD_MIN": "4096"}, {"DC3HIP_MSD_MIN": "4096", "DC3HIP_NO_TEXT_SHORTCUT": "1"}, {"DC3HIP_NO_MSD": "1"},
-                    {"DC3HIP_MSD_MIN": "4096", "DC3HIP_PACK_FUSE": "0"},        # the pack kernel writes the words, pass 1 reads them
                     {"DC3HIP_MSD_MIN": "4096", "DC3HIP_NO_PACK_STRIP": "1"},    # pass 1 makes them, from an image no wider than the word
-                    {"DC3HIP_MSD_MIN": "4096", "DC3HIP_NO_RAW_IMAGE": "1"},     # byte alphabets: the scaled 9-symbol key as the image
-                    {"DC3HIP_MSD_MIN": "4096", "DC3HIP_NO_TUP_SCATTER": "1", "DC3HIP_NO_XCD_MAP": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1"},
-                    {"DC3HIP_MSD_MIN": "4096", "DC3HIP_NO_MSD_SLOTS": "1"},     # pass 2 counted (k_msd_hist2 first) instead of into slots
+                    {"DC3HIP_MSD_MIN": "4096", "DC3HIP_VMM_MIN": str(1 << 62)}, # an arena that cannot grow in place (hipMalloc): pass 2 counted (k_msd_hist2 first)
+                    {"DC3HIP_MSD_MIN": "4096", "DC3HIP_VMM_MIN": "1"},          # every device buffer reserved + committed, whatever its size
                     {"DC3HIP_MSD_MIN": "4096", "DC3HIP_MSD_SLOT_CAP": "64"}):   # slots far too small: they overflow, the counted form runs
             env_apply(env)
             try:
@@ -676,9 +671,12 @@ def test_bucket_ordering_matches_the_stable_passes(ss, oracle):
                     elif (label.startswith("bytes") or label == "dna") and "DC3HIP_NO_TEXT_SHORTCUT" not in env:
                         assert st["msd_sorts"] >= 1, (label, env, st["msd_sorts"], st["msd_fallbacks"])
                         # even buckets + room in the arena: pass 2 wrote into slots — unless switched off or made to overflow
-                        if "DC3HIP_NO_MSD_SLOTS" in env or "DC3HIP_MSD_SLOT_CAP" in env:
+                        if "DC3HIP_MSD_SLOT_CAP" in env:
                             assert st["msd_slot_sorts"] == 0, (label, env)
-                        elif label == f"bytes_{(1 << 25) + 77}" and len(env) == 1:     # (smaller contexts hold the smaller DC3 arena: no room)
+                        elif env.get("DC3HIP_VMM_MIN") == str(1 << 62):
+                            assert st["msd_slot_sorts"] == 0, (label, env)        # (24 n of hipMalloc'ed arena: no room, and none to be had)
+                        elif label == f"bytes_{(1 << 25) + 77}" and (len(env) == 1 or env.get("DC3HIP_VMM_MIN") == "1"):
+                            # a reserved arena commits the slots' 16 bytes per word when the sort first asks (arena_grow_in_use)
                             assert st["msd_slot_sorts"] >= 1, (label, env, st["msd_max_subbucket"])
             finally:
                 env_clear(env)
@@ -687,7 +685,7 @@ def test_bucket_ordering_matches_the_stable_passes(ss, oracle):
 def test_splitter_ordering_matches_the_stable_passes(ss, oracle):
     """The splitter (sample) ordering of the 12- and 16-byte sample-triple records (dc3_ssort.hip.hpp: partition passes
     over sampled splitters + in-LDS comparison order of the sub-buckets) against the stable LSD passes it replaces
-    (DC3HIP_NO_SSORT=1): same suffix array, equal to divsufsort's.  Inputs that reach the straight orderings with skewed
+    (the threshold out of reach): same suffix array, equal to divsufsort's.  Inputs that reach the straight orderings with skewed
     and heavily repeated keys: generated low-entropy text, a period-2 and a period-7 text (every key of a level occurs
     thousands of times: only the position separates the records), three symbols at random, Fibonacci-like repeats, bytes
     through the recursion; the threshold lowered so that every level above 8192 samples takes the path, and the default
@@ -709,13 +707,11 @@ def test_splitter_ordering_matches_the_stable_passes(ss, oracle):
     for label, arr in cases.items():
         data = arr.tobytes()
         want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)
-        for env in ({"DC3HIP_SSORT_MIN": "8192"}, {"DC3HIP_SSORT_MIN": "8192", "DC3HIP_SSORT_REC12": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1"},
-                    {"DC3HIP_SSORT_MIN": "8192", "DC3HIP_SSORT_REC12": "1", "DC3HIP_NO_HYBRID": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1"},
-                    {"DC3HIP_SSORT_MIN": "8192", "DC3HIP_NO_REC12": "1", "DC3HIP_NO_HYBRID": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1"},
-                    {"DC3HIP_SSORT_MIN": "8192", "DC3HIP_SSORT_REC12": "1", "DC3HIP_NO_WIDE_WINDOW": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1"},
+        for env in ({"DC3HIP_SSORT_MIN": "8192"}, {"DC3HIP_SSORT_MIN": "8192", "DC3HIP_NO_TEXT_SHORTCUT": "1"},
+                    {"DC3HIP_SSORT_MIN": "8192", "DC3HIP_NO_HYBRID": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1"},
+                    {"DC3HIP_SSORT_MIN": "8192", "DC3HIP_NO_WIDE_WINDOW": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1"},
                     {"DC3HIP_SSORT_MIN": "8192", "DC3HIP_NO_DISCARD": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1"},
-                    {"DC3HIP_SSORT_MIN": "8192", "DC3HIP_NO_PACK_COUNT": "1"},
-                    {"DC3HIP_NO_SSORT": "1"}):
+                    {"DC3HIP_SSORT_MIN": str(1 << 31)}):          # never: the stable LSD passes order every level
             env_apply(env)
             try:
                 with ss.Context(len(data)) as c:
@@ -723,10 +719,8 @@ def test_splitter_ordering_matches_the_stable_passes(ss, oracle):
                     st = c.stats()
                     assert np.array_equal(c.sa(), want), (label, env)
                     assert st["ssort_fallbacks"] == 0, (label, env, st["ssort_max_subbucket"])
-                    if "DC3HIP_NO_SSORT" in env:
+                    if env["DC3HIP_SSORT_MIN"] != "8192":
                         assert st["ssort_sorts"] == 0
-                    elif "DC3HIP_NO_HYBRID" in env and "DC3HIP_SSORT_REC12" in env:
-                        assert st["ssort_sorts"] >= 1, (label, env)
             finally:
                 env_clear(env)
     # the default threshold
@@ -826,10 +820,8 @@ def test_compact_unwinding_matches_the_general_form(ss, oracle, corpus):
     cases["all_equal"] = b"a" * 50_001
     cases["period3"] = b"abc" * 33_334
     envs = ({"DC3HIP_TUP_SCATTER_MIN": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1"},
-            {"DC3HIP_TUP_SCATTER_MIN": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1", "DC3HIP_NO_TUP_REC8": "1"},
-            {"DC3HIP_TUP_SCATTER_MIN": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1", "DC3HIP_TUP_BIGTILE": "0"},
-            {"DC3HIP_TUP_SCATTER_MIN": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1", "DC3HIP_NO_XCD_MAP": "1", "DC3HIP_NO_DISCARD": "1"},
-            {"DC3HIP_NO_TUP_SCATTER": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1"})
+            {"DC3HIP_TUP_SCATTER_MIN": "1", "DC3HIP_NO_TEXT_SHORTCUT": "1", "DC3HIP_NO_DISCARD": "1"},
+            {"DC3HIP_TUP_SCATTER_MIN": str(1 << 31), "DC3HIP_NO_TEXT_SHORTCUT": "1"})
     wants = {label: (oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)) for label, data in cases.items()}
     for env in envs:
         env_apply(env)
