@@ -164,7 +164,7 @@ def main():
     ap.add_argument("--size", type=str, default="1GiB", help="bytes per GPU")
     ap.add_argument("--kind", type=str, default="random", choices=list(KINDS))
     ap.add_argument("--mode", type=str, default="auto", choices=["auto", "sacapart", "global"])
-    ap.add_argument("--global-timeout", type=int, default=900, help="N > 1, --mode auto: seconds the global leg may take before the "
+    ap.add_argument("--global-timeout", type=int, default=420, help="N > 1, --mode auto: seconds the global leg may take before the "
                     "line is printed with the sacapart leg alone (and the failure stated)")
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--cpu-sample-mib", type=int, default=0,
@@ -234,35 +234,27 @@ def main():
         full["hip_runtime"] = ss.hip_versions()
         print(compact_line(full, write_detail(full, args.detail)), flush=True)
 
-    # ---- N > 1: the library's own transport first — created strictly (no silent fallback) and self-tested
+    # ---- N > 1: the library's own transport — created strictly (no silent fallback) and self-tested.  --mode auto runs the
+    # sacapart leg FIRST and everything of the global leg (communicator, self-test, builds) afterwards under one watchdog: a
+    # transport that cannot be had, fails its self-test or hangs costs the run its global number, never its line.
     G = None
     selftest = None
-    global_unavailable = None
     do_global = world > 1 and args.mode in ("auto", "global")
     do_sacapart = world == 1 or args.mode in ("auto", "sacapart")
-    if do_global:
+
+    class TransportRefused(RuntimeError):
+        pass
+
+    def global_setup():
+        """(G, selftest record): this rank of the library's group over the job's transport, after the transport self-test.
+        Raises on every rank when RCCL cannot be had (make_rank all-reduces the decision); TransportRefused = a run that must
+        not be labelled RCCL over xGMI."""
         from stringsearch_amd.bench_global import make_rank, global_total
         gtotal, gwide, gclipped = global_total(per_gpu * world, kind)
-        try:
-            G = make_rank(ss, dist, backend, world, rank, local_rank, gtotal)      # raises on every rank if RCCL cannot be had
-        except RuntimeError as e:
-            # no transport, no global number: the sacapart leg alone, and the line says why (never a host-staged number
-            # under an xGMI label)
-            G = None
-            global_unavailable = str(e)
-            if args.mode == "global":
-                os._exit(4)
-            do_global = False
-    if do_global:
-        try:
-            seen = G.selftest()
-        except Exception as e:
-            print(f"bench.py: rank {rank}: transport self-test FAILED: {e!r}", file=sys.stderr, flush=True)
-            os._exit(4)
+        g = make_rank(ss, dist, backend, world, rank, local_rank, gtotal)      # raises on every rank if RCCL cannot be had
+        seen = g.selftest()
         if backend == "nccl" and seen != world:
-            print(f"bench.py: rank {rank}: the RCCL communicator reports {seen} ranks, the job has {world}: refusing to call this run RCCL over xGMI",
-                  file=sys.stderr, flush=True)
-            os._exit(4)
+            raise TransportRefused(f"the RCCL communicator reports {seen} ranks, the job has {world}: refusing to call this run RCCL over xGMI")
         rccl_binding = None
         if backend == "nccl":
             # one RCCL per process: the library must have bound to the librccl torch already mapped (same file in
@@ -270,13 +262,18 @@ def main():
             path, pre = ss.GlobalRank.rccl_library()
             mapped = sorted({l.split()[-1] for l in open("/proc/self/maps") if "librccl" in l})
             rccl_binding = {"library": path, "was_already_mapped_by_host_program": pre, "librccl_files_mapped": mapped}
-            same = len(mapped) == 1 and os.path.realpath(mapped[0]) == os.path.realpath(path)
-            if not same:
-                print(f"bench.py: rank {rank}: libdc3hip bound to {path} but the process maps {mapped}: two RCCL instances in one "
-                      "process — refusing", file=sys.stderr, flush=True)
-                os._exit(4)
-        selftest = {"passed": True, "transport": G.transport(), "ranks_seen_by_transport": seen, "world_size": world, "rccl": rccl_binding,
-                    "what": "ragged all_to_all_v + ragged all_gather_v + host all-gather of known bytes through the library's communicator, every byte checked on every rank"}
+            if not (len(mapped) == 1 and os.path.realpath(mapped[0]) == os.path.realpath(path)):
+                raise TransportRefused(f"libdc3hip bound to {path} but the process maps {mapped}: two RCCL instances in one process")
+        st = {"passed": True, "transport": g.transport(), "ranks_seen_by_transport": seen, "world_size": world, "rccl": rccl_binding,
+              "what": "ragged all_to_all_v + ragged all_gather_v + host all-gather of known bytes through the library's communicator, every byte checked on every rank"}
+        return g, st
+
+    if do_global and not do_sacapart:
+        try:
+            G, selftest = global_setup()
+        except BaseException as e:              # noqa: BLE001 - --mode global has nothing else to report
+            print(f"bench.py: rank {rank}: no global leg: {e!r}", file=sys.stderr, flush=True)
+            os._exit(4)
     if not do_sacapart:
         from stringsearch_amd.bench_global import run_global
         out = run_global(args, ss, dist, backend, world, rank, local_rank, per_gpu, kind, barrier, G=G)
@@ -392,6 +389,18 @@ def main():
                               "pcie_floor_ms": 5.0 * n / 56e9 * 1e3}
             del sa_host
             ss.release_cache()
+            # ... and what divsuftest's measure() would really see (main.rs:145-151: ONE un-warmed call in a fresh process, the
+            # array a fresh `vec![0; n]`): a child process that loads the library, calls once and reports (tools/first_call_probe.py)
+            try:
+                import subprocess
+                p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "first_call_probe.py"), "untouched", str(n)],
+                                   capture_output=True, text=True, timeout=300)
+                fc = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+                out["e2e_ffi"]["first_call_fresh_process_ms"] = fc["first_call_ms"]
+                out["e2e_ffi"]["fresh_process"] = fc
+            except Exception as e:                # (reported, never fatal: not part of `value`)
+                out["e2e_ffi"]["first_call_fresh_process_ms"] = None
+                out["e2e_ffi"]["fresh_process"] = {"error": repr(e)}
     if args.dump_stats and rank == 0:
         json.dump(st, open(args.dump_stats, "w"))
     if ctx is not None:
@@ -542,21 +551,22 @@ def main():
                 out["global_mode_beyond_2pow32"] = {"skipped": str(e)}
     if world > 1:
         sac = out                                   # rank 0: the sacapart leg's line; others: None
-        if rank == 0 and args.mode == "auto" and not do_global:
-            out["global_mode"] = {"error": global_unavailable}
-            out["value_mode"] = "sacapart (no global leg: see global_mode.error)"
+        if rank == 0 and not args.no_cpu:
+            sample = (args.cpu_sample_mib << 20) if args.cpu_sample_mib > 0 else (256 << 20)
+            cb = cpu_baseline_partitions(ss, world, per_gpu * world, sample, args.seed, kind, local_rank)
+            if cb is not None:
+                sac["cpu_baseline"] = cb
         if do_global:
-            # ---- the global leg (defines `value` of an N > 1 line).  A failure or a hang of this leg must not cost the
-            # run its line: after --global-timeout seconds, or on an exception, rank 0 prints the sacapart leg alone and
-            # says so.
+            # ---- the global leg (defines `value` of an N > 1 line when it finishes).  A failure or a hang anywhere in it —
+            # communicator, self-test, builds — must not cost the run its line: after --global-timeout seconds, or on an
+            # exception, rank 0 prints the sacapart leg (the reference's own multi-GPU semantics, measured above) as `value`,
+            # says so in `value_mode` and `global_mode.error`, and every rank exits 0 (ranks may be stuck inside a collective:
+            # os._exit).
             import threading
             done = threading.Event()
-
             give_lock = threading.Lock()
 
             def give_up(why):
-                # The global leg did not finish: rank 0 still prints a line (the sacapart leg, `value` = null so that no
-                # harness reads the partitioned number as the global one) and EVERY rank exits non-zero (6).
                 with give_lock:
                     if done.is_set():
                         return
@@ -564,19 +574,22 @@ def main():
                     if rank == 0:
                         sac["global_mode"] = {"error": why}
                         sac["value_sacapart"] = sac.get("value")
-                        sac["value"] = None
-                        sac["value_mode"] = "none (the global leg did not finish: see global_mode.error; the sacapart leg is value_sacapart)"
+                        sac["value_mode"] = ("sacapart: N independent local suffix arrays, one chunk per GPU, no collective (crates/sacapart/src/lib.rs:39-58) — "
+                                             "the global leg did not finish, see global_mode.error")
                         sac["transport_selftest"] = selftest
                         emit(sac)
-                    os._exit(6)
+                    sys.stdout.flush(); sys.stderr.flush()
+                    os._exit(0)
             wd = threading.Timer(args.global_timeout, give_up, args=(f"no result after {args.global_timeout} s",))
             wd.daemon = True
             wd.start()
             outg = None
             try:
                 from stringsearch_amd.bench_global import run_global
+                G, selftest = global_setup()
                 outg = run_global(args, ss, dist, backend, world, rank, local_rank, per_gpu, kind, barrier, G=G)
             except BaseException as e:          # noqa: BLE001 - reported in the line
+                print(f"bench.py: rank {rank}: the global leg failed: {e!r}", file=sys.stderr, flush=True)
                 give_up(repr(e))
                 time.sleep(3600)                # (the watchdog thread is printing / exiting: never fall through)
             with give_lock:
@@ -591,12 +604,9 @@ def main():
                                             "suffix arrays, one chunk per GPU, no data-path collective; same K timed steps")
                 outg["value_mode"] = "global (ONE suffix array over all ranks, rank exchange over the transport in `interconnect`)"
                 outg["transport_selftest"] = selftest
+                if "cpu_baseline" in sac:
+                    outg["cpu_baseline"] = sac["cpu_baseline"]
                 out = outg
-        if rank == 0 and not args.no_cpu:
-            sample = (args.cpu_sample_mib << 20) if args.cpu_sample_mib > 0 else (256 << 20)
-            cb = cpu_baseline_partitions(ss, world, per_gpu * world, sample, args.seed, kind, local_rank)
-            if cb is not None:
-                out["cpu_baseline"] = cb
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -25,13 +25,13 @@ inline void sort_in_place(sacabase::Bytes text, int32_t *sa, size_t sa_len) {
 }
 
 inline sacabase::SuffixArray<int32_t> sort(sacabase::Bytes text) {
-  std::vector<int32_t> sa(text.len, 0);                   // vec![0; text.len()], :27
+  sacabase::ZVec<int32_t> sa(text.len);                   // vec![0; text.len()], :27 (calloc: sacabase.hpp)
   sort_in_place(text, sa.data(), sa.size());
   return sacabase::SuffixArray<int32_t>(text, std::move(sa));
 }
 
 inline sacabase::SuffixArray<int64_t> sort_i64(sacabase::Bytes text) {
-  std::vector<int64_t> sa(text.len, 0);
+  sacabase::ZVec<int64_t> sa(text.len);
   static const uint8_t zero = 0; static int64_t dummy = 0;
   const int32_t ret = dc3hip_sufsort_i64(text.len ? text.ptr : &zero, sa.size() ? sa.data() : &dummy, (int64_t)text.len);
   if (ret != 0) throw Error(ret, dc3hip_last_error());
@@ -71,7 +71,7 @@ class DeviceIndex : public sacabase::StringIndex {
   ~DeviceIndex() { dc3hip_ctx_destroy(ctx_); }
 
   sacabase::SuffixArray<int32_t> to_host() const {
-    std::vector<int32_t> sa(text_.len);
+    sacabase::ZVec<int32_t> sa(text_.len);
     check(dc3hip_ctx_get_sa_i32(ctx_, sa.data()));
     return sacabase::SuffixArray<int32_t>(text_, std::move(sa));
   }
@@ -242,7 +242,7 @@ class GlobalLoopback {
     }
     const int rc = dc3hip_global_loopback_build(h_.data(), (int32_t)h_.size());
     if (rc != 0) throw Error(rc, dc3hip_last_error());
-    std::vector<int64_t> sa;
+    sacabase::ZVec<int64_t> sa;
     sa.reserve(text.len);
     for (auto *g : h_) {
       GlobalRank r(g);

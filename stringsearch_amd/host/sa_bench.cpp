@@ -120,7 +120,7 @@ int main(int argc, char **argv) {
       if (!h) { std::fprintf(stderr, "\ncannot dlopen %s: %s\n", ref_path.c_str(), dlerror()); return 1; }
       auto fn = reinterpret_cast<int32_t (*)(const uint8_t *, int32_t *, int32_t)>(dlsym(h, "divsufsort"));
       if (!fn) { std::fprintf(stderr, "\nno divsufsort symbol in %s\n", ref_path.c_str()); return 1; }
-      measure("c-divsufsort", [&] { std::vector<int32_t> sa(len, 0); if (fn(input.ptr, sa.data(), (int32_t)len) != 0) std::abort(); });
+      measure("c-divsufsort", [&] { sacabase::ZVec<int32_t> sa(len); if (fn(input.ptr, sa.data(), (int32_t)len) != 0) std::abort(); });
     }
     measure("dc3-hip", [&] { dc3hip::sort(input); });
     double resident_ms = 0;

@@ -2,6 +2,8 @@
 // suffix-array search + verifier).  Same names, argument meaning and error behaviour; Rust panics
 // become C++ exceptions.  Header-only, no device code.
 #pragma once
+#include <cstdlib>
+#include <new>
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
@@ -81,18 +83,37 @@ struct StringIndex {
   virtual ~StringIndex() {}
 };
 
+// `vec![0; n]` (cdivsufsort/src/lib.rs:27) is alloc_zeroed, i.e. calloc: zero pages the OS hands out when they are first
+// written.  std::vector<T>(n, 0) writes every page first — a second for the 4 GiB array of a 1 GiB text, inside the one
+// un-warmed call divsuftest times (main.rs:145-151) and three times the whole GPU call.  ZVec<T>(n) is the Rust
+// semantics: calloc'ed storage whose value-initialisation is a no-op.
+template <class T>
+struct ZeroedAlloc {
+  typedef T value_type;
+  ZeroedAlloc() = default;
+  template <class U> ZeroedAlloc(const ZeroedAlloc<U> &) {}
+  T *allocate(size_t n) { void *p = std::calloc(n ? n : 1, sizeof(T)); if (!p) throw std::bad_alloc(); return static_cast<T *>(p); }
+  void deallocate(T *p, size_t) { std::free(p); }
+  template <class U> void construct(U *) noexcept {}                        // value-initialisation: the storage is zero already
+  template <class U, class A0, class... A> void construct(U *p, A0 &&a0, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A0>(a0), std::forward<A>(a)...); }
+  template <class U> bool operator==(const ZeroedAlloc<U> &) const { return true; }
+  template <class U> bool operator!=(const ZeroedAlloc<U> &) const { return false; }
+};
+template <class T> using ZVec = std::vector<T, ZeroedAlloc<T>>;
+
 // lib.rs:152-197 — owns `sa`, borrows `text`
 template <class Index>
 class SuffixArray : public StringIndex {
-  std::vector<Index> sa_;
+  ZVec<Index> sa_;
   Bytes text_;
 
  public:
-  SuffixArray(Bytes text, std::vector<Index> sa) : sa_(std::move(sa)), text_(text) {}          // new, :170
-  std::pair<Bytes, std::vector<Index>> into_parts() && { return {text_, std::move(sa_)}; }      // :175
+  SuffixArray(Bytes text, ZVec<Index> sa) : sa_(std::move(sa)), text_(text) {}                  // new, :170
+  SuffixArray(Bytes text, const std::vector<Index> &sa) : sa_(sa.begin(), sa.end()), text_(text) {}
+  std::pair<Bytes, ZVec<Index>> into_parts() && { return {text_, std::move(sa_)}; }             // :175
   void verify() const { sacabase::verify(text_, sa_.data()); }                                  // :180
   Bytes text() const { return text_; }                                                          // :185
-  const std::vector<Index> &sa() const { return sa_; }
+  const ZVec<Index> &sa() const { return sa_; }
   LongestCommonSubstring longest_substring_match(Bytes needle) const override {                 // :190-196
     return sacabase::longest_substring_match(text_, sa_.data(), sa_.size(), needle);
   }

@@ -25,7 +25,7 @@ class PartitionedSuffixArray : public sacabase::StringIndex {
     std::vector<sacabase::Bytes> chunks;
     for (size_t off = 0; off < text.len; off += partition_size_)
       chunks.push_back(text.slice(off, std::min(text.len, off + partition_size_)));
-    std::vector<std::vector<Index>> out(chunks.size());
+    std::vector<sacabase::ZVec<Index>> out(chunks.size());
     std::vector<std::exception_ptr> err(chunks.size());
     std::vector<std::thread> th;
     for (size_t i = 0; i < chunks.size(); i++)
