@@ -827,10 +827,10 @@ static int gorder_positions(dc3hip_gctx *G, KM km, u32 m, u32 kbits, const HiMap
   RC(arena_alloc(c, (size_t)nrec + 16, &f));
   bool ok = true, distinct = true;
   if (nrec && selected)
-    RC((hybrid_sort_core<KM>(c, km, kbits, hm, ha, hb, nrec, &h, f, &ok, depth, slice, 0, &distinct, sel_table, false, &mgx, 0, 0, &psel)));
+    RC((hybrid_sort_core<KM>(c, km, kbits, hm, ha, hb, nrec, &h, f, &ok, depth, slice, 0, &distinct, sel_table, false, &mgx, 0, 0, &psel, nullptr, true)));
   else if (nrec)
     RC((hybrid_sort_core<KM>(c, km, kbits, hm, ha, hb, nrec, &h, f, &ok, depth, slice, 0, &distinct, nullptr, false, nullptr,
-                             img_lo, img_span)));
+                             img_lo, img_span, nullptr, nullptr, true)));      // (slots: the routed records fill their image range evenly)
   uint64_t good = 0, ngood = 0, pre = 0, tot = 0, all[kMaxRanks];
   RC(gather_counts(cm, (ok && distinct) ? 1 : 0, &good, &ngood));
   RC(gather_counts(cm, nrec, &pre, &tot, all));

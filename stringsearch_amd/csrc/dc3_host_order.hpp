@@ -440,7 +440,9 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
                             bool *emitted_distinct = nullptr, u32 *first_table = nullptr, bool whole_text = false,
                             const MsdGeom *mg = nullptr, u64 img_lo = 0, u64 img_span = 0, MsdPass1 *p1 = nullptr,
                             bool *keys_distinct = nullptr, bool slots_ok = false) {
-  // slots_ok: a single device's ordering (not a rank of the global mode): the bucket ordering may write its second pass into slots
+  // slots_ok: the bucket ordering may write its second pass into slots where the arena has (or can commit) the room — a single
+  // device's ordering, and since round 6 a rank's ordering of its key range too (its arena is sized for a whole level: 16 bytes
+  // per word of a P-th of the words fit)
   // keys_distinct (record form): set when the tie pass settled every tied group and found no two equal keys — the caller
   // then knows that all nrec keys are distinct without counting the flags
   // p1 (only with mg->on): the records of `ha` were NOT written — the pack kernel only counted, pass 1 of the bucket
@@ -476,7 +478,7 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
     MsdRedo mredo; bool msd_ok = false;
     if (mg && mg->on) {
       Rec8 *where = ha;
-      RC(msd_sort(c, ha, hb, nrec, hm, *mg, first_table, &sink, &h, &mredo, &msd_ok, &where, p1, nullptr, whole_text && slots_ok));
+      RC(msd_sort(c, ha, hb, nrec, hm, *mg, first_table, &sink, &h, &mredo, &msd_ok, &where, p1, nullptr, slots_ok));
       if (msd_ok) lp.src = const_cast<u64 *>(mredo.src);               // (non-null = "the order lives in the sink")
       else { first_table = nullptr; if (p1) RC(p1->repack(c, ha, nrec, &first_table)); }      // from scratch: `ha` in position order
     }
