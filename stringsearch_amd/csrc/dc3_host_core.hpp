@@ -253,8 +253,13 @@ static bool arena_grow_in_use(dc3hip_ctx *c, size_t need_total) {
   if (c->arena_bytes >= need_total) return true;
   if (c->arena_fixed || c->arena_borrowed || !c->arena_vm.va || c->arena != c->arena_vm.va || need_total > c->arena_vm.reserved) return false;
   if (hipSetDevice(c->device) != hipSuccess) { (void)hipGetLastError(); return false; }
+  const auto t0 = std::chrono::steady_clock::now();
+  const size_t before = c->arena_vm.mapped;
   const bool ok = devbuf_commit(&c->arena_vm, need_total);
   c->arena_bytes = c->arena_vm.mapped;
+  if (c->level_report)
+    std::fprintf(stderr, "dc3hip arena grown in use: %.1f -> %.1f GiB in %.2f ms%s\n", before / 1073741824.0, c->arena_vm.mapped / 1073741824.0,
+                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), ok ? "" : " (failed)");
   return ok;
 }
 

@@ -1178,12 +1178,32 @@ static int order_all_positions(dc3hip_ctx *c, KM km, Map mp, u32 m, u32 kbits, c
     }
   }
   MsdPass1Img pimg;
+  MsdPass1Keys<KeyBits> pbits;
   MsdPass1 *pass1 = fuse ? &p1 : nullptr;
   bool packed = false;
   if constexpr (kKeyT) {
-    // KeyT: the image stays in a pack kernel (inside pass 1 it was measured slower), which writes it d1 bits wider
+    // power-of-two alphabets (DNA): the image comes off a bit-packed copy of the text, inside pass 1 (KeyBits) — no image
+    // array is written or read back; the pack kernel only counts the top digit
+    if (mg.on && !c->no_pack_strip && dummy == 0 && hm.pbits >= 23 && km.lg != 0 && hm.nbits + mg.d1 + 7 + 3 * km.lg <= 64 &&
+        (u64)3 * km.L * km.lg >= hm.nbits + mg.d1) {        // (the image spans no more symbols than the window the ties are compared by)
+      const u32 groups = (nrec + 7) / 8 + 2;
+      uint8_t *bits = nullptr;
+      RC(arena_alloc(c, (size_t)groups * km.lg + 64, &bits));
+      HiMap hw; hw.mfix = 0; hw.shx = 0; hw.exact = 0; hw.raw = 0; hw.pbits = hm.pbits - mg.d1; hw.nbits = hm.nbits + mg.d1;
+      HiMap hpl = hw; hpl.pbits = hm.pbits; hpl.nbits = hm.nbits;
+      pbits.km.bits = bits; pbits.km.lg = km.lg; pbits.hm = hw; pbits.P1 = 0; pbits.strip = true; pbits.hm_plain = hpl;
+      mgx.ebits = hw.nbits;
+      PhaseScope ps(c, DC3HIP_PH_PACK, nrec);
+      hipLaunchKernelGGL(k_pack_bits, dim3(grid_for(c, groups)), dim3(kBlock), 0, c->stream, km.S, m, km.lg, groups, bits);
+      KCHECK();
+      RC(launch_pack_all<KeyBits>(c, pbits.km, nrec, hw, ha, &first_table, &mgx, false));
+      pass1 = &pbits; packed = true;
+    }
+  }
+  if constexpr (kKeyT) {
+    // other small alphabets: the image stays in a pack kernel (inside pass 1 it was measured slower), which writes it d1 bits wider
     KeyT kw; HiMap hw;
-    if (mg.on && !c->no_pack_strip && dummy == 0 && hm.pbits >= 23 && hm.nbits + mg.d1 <= 62 &&
+    if (!packed && mg.on && !c->no_pack_strip && dummy == 0 && hm.pbits >= 23 && hm.nbits + mg.d1 <= 62 &&
         make_keyt(km.S, km.sigma, km.L, km.BL, m, &kw, &hw, hm.nbits + mg.d1)) {
       pimg.ki.img = reinterpret_cast<const u64 *>(ha); pimg.hm = hw; pimg.km_plain = km; pimg.hm_plain = hm;
       mgx.ebits = hw.nbits;

@@ -731,6 +731,56 @@ __device__ __forceinline__ void images4(const Key3<SymU32> &km, const HiMap &hm,
 #pragma unroll
   for (int j = 0; j < 4; j++) img[j] = p0 + j < n ? hyb_hi(make_rec(q[j], q[j + 1], q[j + 2], km.B, 0u), hm) : 0ull;
 }
+// KeyBits (round 6): the sort image of a power-of-two alphabet (sigma = 2^lg: DNA lg = 2, binary 1, hex 4) read off a
+// BIT-PACKED copy of the text — lg bits per symbol, digit = code - 1, most significant bit first, zero bits behind the
+// end (k_pack_bits makes it: n lg / 8 bytes, a quarter of a DNA text).  The image of position p is then the stream's bits
+// [p lg, p lg + nbits): one unaligned 8-byte load, a byte swap and two shifts — the same "leading bits as they lie in the
+// text" that byte alphabets take straight from the text (HiMap::raw), and cheap enough to be made inside partition pass 1
+// (k_msd_part_keys<KeyBits, true>).  KeyT's own image took a table look-up and a shift per symbol, 21 symbols per
+// position: inside pass 1 it was measured slower twice (round 4), so a pack kernel wrote the images out (8 bytes per
+// position written and read back, 3.8 of DNA's 14.4 ms at 1 GiB).  It is the same monotone map of the window (the first
+// nbits / lg digits and the top bits of the next), so everything behind pass 1 — tie flags, KeyT's window compares — is
+// unchanged.  Needs nbits + 7 + 3 lg <= 64.
+struct KeyBits {
+  static constexpr bool kCodes = false;
+  const uint8_t *bits; u32 lg;
+  __device__ __forceinline__ void stage(uint16_t *) const {}
+  __device__ __forceinline__ u64 image_hi(u32 p, const uint16_t *, const HiMap &hm) const {
+    const u64 b = (u64)p * lg;
+    u64 v; __builtin_memcpy(&v, bits + (b >> 3), 8);
+    return (__builtin_bswap64(v) << (u32)(b & 7u)) >> (64u - hm.nbits);
+  }
+  __device__ __forceinline__ Rec8 image(u32 p, const uint16_t *lds, const HiMap &hm) const {
+    const u64 w = (image_hi(p, lds, hm) << hm.pbits) | p;
+    return Rec8{(u32)(w >> 32), (u32)w};
+  }
+};
+__device__ __forceinline__ void images4(const KeyBits &km, const HiMap &hm, u64, u32 p0, u32, const uint16_t *, u64 img[4]) {
+  const u64 b = (u64)p0 * km.lg;
+  u64 v; __builtin_memcpy(&v, km.bits + (b >> 3), 8);
+  const u64 V = __builtin_bswap64(v) << (u32)(b & 7u);
+  const u32 sh = 64u - hm.nbits;
+#pragma unroll
+  for (u32 j = 0; j < 4; j++) img[j] = (V << (j * km.lg)) >> sh;      // (positions >= n read the zero bits behind the end: image 0 or a prefix of the last symbols, never kept)
+}
+// bits[g lg .. (g + 1) lg) = the 8 symbols 8 g .. 8 g + 7 as 8 lg bits, first symbol in the top bits; groups up to `groups`
+// (>= ceil(n / 8) + 2: the loads above read 8 bytes from the byte a position's bits start in)
+__global__ __launch_bounds__(kBlock) void k_pack_bits(SymU8 S, u32 n, u32 lg, u32 groups, uint8_t *__restrict__ bits) {
+  __shared__ uint16_t lcode[256];
+  S.stage(lcode);
+  for (u32 g = blockIdx.x * kBlock + threadIdx.x; g < groups; g += gridDim.x * kBlock) {
+    const u64 p0 = (u64)g * 8u;
+    u64 w = 0;
+    if (p0 < n) __builtin_memcpy(&w, S.t + p0, 8);            // (64 zero bytes pad the text)
+    u64 acc = 0;
+#pragma unroll
+    for (u32 k = 0; k < 8; k++) {
+      const u32 cd = (p0 + k < n) ? (u32)lcode[(w >> (8 * k)) & 255u] : 0u;
+      acc = (acc << lg) | (u64)(cd ? cd - 1 : 0u);
+    }
+    for (u32 i = 0; i < lg; i++) bits[(size_t)g * lg + i] = (uint8_t)(acc >> (8 * (lg - 1 - i)));
+  }
+}
 // any other key maker: position by position
 // KeyImg: the images were written out by a pack kernel, one u64 per position and nothing else (the position is the
 // index) — how a key maker whose image is too dear to compute inside the partition pass (KeyT) still gets an image
