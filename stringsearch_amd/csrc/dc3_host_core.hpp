@@ -122,6 +122,7 @@ struct dc3hip_ctx {
   bool arena_fixed = false;    // DC3HIP_ARENA_BYTES given: never grown
   bool arena_borrowed = false; // the arena belongs to another context (ctx_create_impl): never grown, never freed here
   bool arena_exhausted = false; // the last E_ALLOC came from the bump allocator (not from hipMalloc)
+  u32 builds_done = 0;          // builds this context has finished (policy: a one-shot context never commits the slots' 16 n)
   // small device scratch
   u32 *d_present = nullptr;    // [256]
   uint16_t *d_code = nullptr;  // [256]
@@ -175,6 +176,14 @@ static int arena_alloc(dc3hip_ctx *c, size_t count, T **out) {
     c->arena_exhausted = true;
     return E_ALLOC;
   }
+  // a reserved arena (DevBuf) is committed as the allocator advances: a build pays for the memory it uses, not for what
+  // the largest path of its size could use (arena_bytes is the LIMIT the policies see; arena_vm.mapped what is backed)
+  if (c->arena_vm.va && c->arena == c->arena_vm.va && c->arena_off + bytes > c->arena_vm.mapped) {
+    if (!devbuf_commit(&c->arena_vm, c->arena_off + bytes)) {
+      set_err("device allocation failed: %zu bytes of the arena committed, %zu needed", c->arena_vm.mapped, c->arena_off + bytes);
+      return E_ALLOC;
+    }
+  }
   *out = reinterpret_cast<T *>(c->arena + c->arena_off);
   c->arena_off += bytes;
   c->arena_peak = std::max(c->arena_peak, c->arena_off);
@@ -221,18 +230,14 @@ static size_t arena_reserve_bytes(int64_t n) {
   return need + need / 2 + ((size_t)1 << 30);
 }
 
-// Grow the arena to at least `need` bytes.  Never shrinks; a size forced by DC3HIP_ARENA_BYTES stays as it is.  A reserved
-// arena (DevBuf) commits more pieces where it lies — also while in use; a hipMalloc'ed one is replaced and must be empty.
+// Raise the arena's limit to at least `need` bytes.  Never shrinks; a size forced by DC3HIP_ARENA_BYTES stays as it is.  A
+// reserved arena (DevBuf) grows where it lies — also while in use — and commits memory as the allocator advances; a
+// hipMalloc'ed one is replaced and must be empty.
 static int ensure_arena(dc3hip_ctx *c, size_t need) {
   if (c->arena_bytes >= need || c->arena_fixed) return E_OK;
   HIPC(hipSetDevice(c->device));            // (callers may be on a thread whose current device is another one)
   if (c->arena_vm.va && c->arena == c->arena_vm.va && need <= c->arena_vm.reserved) {
-    if (!devbuf_commit(&c->arena_vm, need)) {
-      c->arena_bytes = c->arena_vm.mapped;
-      set_err("device allocation failed: arena of %zu bytes (committed %zu)", need, c->arena_vm.mapped);
-      return E_ALLOC;
-    }
-    c->arena_bytes = c->arena_vm.mapped;
+    c->arena_bytes = need;                 // (the limit; memory is committed when the allocator gets there: arena_alloc)
     return E_OK;
   }
   if (c->arena_off != 0) { set_err("internal: arena grown while in use"); return E_HIP; }
@@ -240,27 +245,20 @@ static int ensure_arena(dc3hip_ctx *c, size_t need) {
   if (c->arena_vm.va && c->arena == c->arena_vm.va) { devbuf_free(&c->arena_vm); c->arena = nullptr; c->arena_bytes = 0; }
   else if (c->arena) { HIPC(hipFree(c->arena)); c->arena = nullptr; c->arena_bytes = 0; }
   if (c->use_vm && need >= c->vm_min && devbuf_reserve(&c->arena_vm, c->device, need + need / 2)) {
-    if (devbuf_commit(&c->arena_vm, need)) { c->arena = c->arena_vm.va; c->arena_bytes = c->arena_vm.mapped; return E_OK; }
-    devbuf_free(&c->arena_vm);
+    c->arena = c->arena_vm.va; c->arena_bytes = need;
+    return E_OK;
   }
   HIPC(hipMalloc(&c->arena, need));
   c->arena_bytes = need;
   return E_OK;
 }
-// In the middle of a build: more room behind what is in use, if the arena can grow where it lies (else false: the caller
-// takes the path that needs no more memory).  Never an error.
+// In the middle of a build: a higher limit for what is in use, if the arena can grow where it lies (else false: the caller
+// takes the path that needs no more memory).  Never an error; the memory itself is committed by arena_alloc.
 static bool arena_grow_in_use(dc3hip_ctx *c, size_t need_total) {
   if (c->arena_bytes >= need_total) return true;
   if (c->arena_fixed || c->arena_borrowed || !c->arena_vm.va || c->arena != c->arena_vm.va || need_total > c->arena_vm.reserved) return false;
-  if (hipSetDevice(c->device) != hipSuccess) { (void)hipGetLastError(); return false; }
-  const auto t0 = std::chrono::steady_clock::now();
-  const size_t before = c->arena_vm.mapped;
-  const bool ok = devbuf_commit(&c->arena_vm, need_total);
-  c->arena_bytes = c->arena_vm.mapped;
-  if (c->level_report)
-    std::fprintf(stderr, "dc3hip arena grown in use: %.1f -> %.1f GiB in %.2f ms%s\n", before / 1073741824.0, c->arena_vm.mapped / 1073741824.0,
-                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), ok ? "" : " (failed)");
-  return ok;
+  c->arena_bytes = need_total;
+  return true;
 }
 
 // ---------------------------------------------------------------------------------------------

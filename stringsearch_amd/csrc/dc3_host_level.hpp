@@ -527,6 +527,7 @@ static int build_end(dc3hip_ctx *c) {
     }
   }
   c->built = true;
+  c->builds_done++;
   c->sa_trusted = true;
   c->parts_trusted = 0;
   return E_OK;

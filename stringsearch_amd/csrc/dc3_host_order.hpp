@@ -469,11 +469,10 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
     // side array; the tie pass settles the tied groups in place.  Complete unless a key repeats or a group is large.
     // (what the tie pass reads: a "same image as the record before" byte from the bucket ordering, or the 32 image bits
     //  the LSD passes leave when that ordering does not apply or gave up; the image array is only touched in that case)
-    u32 *img = nullptr;
+    u32 *img = nullptr;                      // (4 bytes per record that only the LSD passes write: allocated when they run)
     uint8_t *same = nullptr;
-    RC(arena_alloc(c, (size_t)nrec + 16, &img));
     RC(arena_alloc(c, (size_t)nrec + 16, &same));
-    SplitSink sink; sink.sa = emit_sa; sink.img = img; sink.same = same; sink.pbits = hm.pbits;
+    SplitSink sink; sink.sa = emit_sa; sink.img = nullptr; sink.same = same; sink.pbits = hm.pbits;
     LastPass lp;
     MsdRedo mredo; bool msd_ok = false;
     if (mg && mg->on) {
@@ -482,9 +481,12 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
       if (msd_ok) lp.src = const_cast<u64 *>(mredo.src);               // (non-null = "the order lives in the sink")
       else { first_table = nullptr; if (p1) RC(p1->repack(c, ha, nrec, &first_table)); }      // from scratch: `ha` in position order
     }
-    if (!msd_ok)
+    if (!msd_ok) {
+      RC(arena_alloc(c, (size_t)nrec + 16, &img));
+      sink.img = img;
       RC(radix_sort<Rec8>(c, ha, hb, nrec, hm.pbits, hm.pbits + hm.nbits, &h, DC3HIP_PH_SORT12_UP, DC3HIP_PH_SORT12_SCAN,
                           DC3HIP_PH_SORT8_DOWN, first_table, &sink, &lp));
+    }
     if (lp.src) {
       {
         PhaseScope ps(c, DC3HIP_PH_TIES, nrec);

@@ -331,7 +331,12 @@ static int msd_sort(dc3hip_ctx *c, Rec8 *ha, Rec8 *hb, u32 n, const HiMap &hm, c
     // spare (beyond 2^31 words the mean passes the local sort's small shape: counted form), an arena with room — one that
     // can grow where it lies commits the 16 bytes per word now (arena_grow_in_use; first sort of a context only).  Only then
     // is the largest pass-1 bucket read back (a pipeline drain that a sort without slots must not pay).
-    const bool host_ok = slot_words < (1ull << 32) && (c->msd_slot_cap || (u64)mean * 5 <= (u64)slot_cap * 4) && arena_grow_in_use(c, c->arena_off + need);
+    // A context's FIRST build keeps to the counted form unless the room is there already: the slots cost 16 bytes per word of
+    // device memory, and memory another process has used is handed out at about 30 ms per GiB (the driver wipes it) — more
+    // than a one-shot call gains; a context that builds again commits them then.
+    const bool may_grow = c->builds_done > 0 || c->msd_slot_cap != 0;
+    const bool host_ok = slot_words < (1ull << 32) && (c->msd_slot_cap || (u64)mean * 5 <= (u64)slot_cap * 4) &&
+                         (c->arena_off + need <= c->arena_bytes || (may_grow && arena_grow_in_use(c, c->arena_off + need)));
     u32 maxb1 = 0;
     if (host_ok) {
       HIPC(hipMemcpyAsync(c->h_words + 20, plan, kMsdW_COUNT * sizeof(u32), hipMemcpyDeviceToHost, c->stream));

@@ -146,14 +146,17 @@ static int ctx_create_impl(dc3hip_ctx **out, int32_t device, int64_t max_n, dc3h
     // a fallback ordering — or fails loudly with -2; it never returns a wrong array)
     if (const char *e = getenv("DC3HIP_ARENA_BYTES")) { const long long v = atoll(e); if (v > 0) { c->arena_bytes = (size_t)v; c->arena_fixed = true; } }
     if (arena_from && arena_from->arena && arena_from->device == device) {
+      // (a borrowed arena is used through this context's allocator, which cannot commit for the lender: all of it is backed first)
+      if (arena_from->arena_vm.va && arena_from->arena == arena_from->arena_vm.va && !devbuf_commit(&arena_from->arena_vm, arena_from->arena_bytes)) {
+        set_err("device allocation failed: arena of %zu bytes for a partition build", arena_from->arena_bytes); return E_ALLOC;
+      }
       c->arena = arena_from->arena; c->arena_bytes = arena_from->arena_bytes; c->arena_borrowed = true; c->arena_fixed = true;
     } else {
       // address space for everything a context of max_n bytes can ever ask for, memory for what the first build needs
       const size_t want = c->arena_bytes;
       bool done = false;
       if (c->use_vm && !c->arena_fixed && arena_reserve_bytes(max_n) >= c->vm_min && devbuf_reserve(&c->arena_vm, device, arena_reserve_bytes(max_n))) {
-        if (devbuf_commit(&c->arena_vm, want)) { c->arena = c->arena_vm.va; c->arena_bytes = c->arena_vm.mapped; done = true; }
-        else devbuf_free(&c->arena_vm);
+        c->arena = c->arena_vm.va; c->arena_bytes = want; done = true;        // (nothing committed yet: arena_alloc does)
       }
       if (!done) HIPC(hipMalloc(&c->arena, c->arena_bytes));
     }
@@ -284,8 +287,11 @@ int32_t dc3hip_ctx_get_sa_i64(dc3hip_ctx *c, int64_t *SA) {
   if (c->n == 0) return E_OK;
   // widen on the device in arena-sized pieces, then copy
   c->arena_off = 0;
-  const size_t piece = std::min<size_t>((size_t)c->n, c->arena_bytes / 8 > 0 ? c->arena_bytes / 8 : 1);
-  int64_t *tmp = reinterpret_cast<int64_t *>(c->arena);
+  // (at most 1 GiB of it at a time: a reserved arena commits what is allocated)
+  const size_t piece = std::min<size_t>((size_t)c->n, std::min<size_t>(c->arena_bytes / 8 > 0 ? c->arena_bytes / 8 : 1, (size_t)1 << 27));
+  int64_t *tmp = nullptr;
+  RC(arena_alloc(c, piece, &tmp));
+  c->arena_off = 0;
   for (size_t off = 0; off < (size_t)c->n; off += piece) {
     const size_t cnt = std::min(piece, (size_t)c->n - off);
     hipLaunchKernelGGL(k_widen, dim3(grid_for(c, cnt)), dim3(kBlock), 0, c->stream, c->d_sa + off, tmp, (u32)cnt);
