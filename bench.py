@@ -286,6 +286,21 @@ def main():
             emit(out)
         return
 
+    fresh = None
+    if world == 1 and not args.no_extras:
+        # What divsuftest's measure() would see (crates/divsuftest/src/main.rs:145-151: ONE un-warmed call in a fresh process,
+        # the array a fresh `vec![0; n]`): a child process that loads the library, calls dc3hip_sufsort_i32 once and reports
+        # (tools/first_call_probe.py).  It runs BEFORE this process touches the device: memory a process has just freed is
+        # wiped by the driver before it is handed out again (about 30 ms per GiB), and a first call behind this bench's
+        # own 45 GiB contexts would mostly measure that.  Never part of `value`.
+        try:
+            import subprocess
+            p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "first_call_probe.py"), "untouched", str(per_gpu)],
+                               capture_output=True, text=True, timeout=300)
+            fresh = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+        except Exception as e:                # (reported, never fatal)
+            fresh = {"error": repr(e)}
+
     from stringsearch_amd.partition import rank_chunk
     total_len = per_gpu * world
     off, n = (0, total_len) if world == 1 else rank_chunk(total_len, world, rank)   # sacapart/src/lib.rs:43-46
@@ -384,23 +399,13 @@ def main():
                 assert rc == 0, ss.last_error()
             warm = min(ts[1:])
             out["e2e_ffi"] = {"entry": "dc3hip_sufsort_i32(T, SA, n) on pageable host buffers", "ms": warm * 1e3,
-                              "MB/s": n / warm / 1e6, "first_call_ms": ts[0] * 1e3,
-                              "includes": "H2D of n bytes, device build, D2H of 4n bytes; first call also allocates the cached context",
+                              "MB/s": n / warm / 1e6,
+                              "first_call_in_this_process_ms": ts[0] * 1e3,       # (behind the contexts this bench has just freed: incl. the driver's wipe)
+                              "first_call_fresh_process_ms": (fresh or {}).get("first_call_ms"), "fresh_process": fresh,
+                              "includes": "H2D of n bytes, device build, D2H of 4n bytes; a first call also creates the cached context",
                               "pcie_floor_ms": 5.0 * n / 56e9 * 1e3}
             del sa_host
             ss.release_cache()
-            # ... and what divsuftest's measure() would really see (main.rs:145-151: ONE un-warmed call in a fresh process, the
-            # array a fresh `vec![0; n]`): a child process that loads the library, calls once and reports (tools/first_call_probe.py)
-            try:
-                import subprocess
-                p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "first_call_probe.py"), "untouched", str(n)],
-                                   capture_output=True, text=True, timeout=300)
-                fc = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
-                out["e2e_ffi"]["first_call_fresh_process_ms"] = fc["first_call_ms"]
-                out["e2e_ffi"]["fresh_process"] = fc
-            except Exception as e:                # (reported, never fatal: not part of `value`)
-                out["e2e_ffi"]["first_call_fresh_process_ms"] = None
-                out["e2e_ffi"]["fresh_process"] = {"error": repr(e)}
     if args.dump_stats and rank == 0:
         json.dump(st, open(args.dump_stats, "w"))
     if ctx is not None:

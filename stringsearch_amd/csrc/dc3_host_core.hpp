@@ -32,14 +32,16 @@ static inline hipError_t dc3_func_set_attribute(const void *fn, hipFuncAttribute
 #define KCHECK() HIPC(hipGetLastError())
 
 // ---------------------------------------------------------------------------------------------
-// Large device buffers by virtual-memory reserve + commit (round 6).  What a first call pays on MI355X (ROCm 7.2,
-// tools/alloc_probe.hip, profiles/r06c_alloc_probe.jsonl): hipMalloc of up to 4 GiB 0.2 ms, of 8 GiB 0.5 s, 24 GiB 0.7-1.2 s,
-// 44 GiB 1.7 s — the un-warmed dc3hip_sufsort_i32 of 1 GiB spent 2.3 of its 2.4 s there (crates/divsuftest/src/main.rs:
-// 145-151 times exactly one such call) — against 1 ms for reserving 44 GiB of address space and mapping it in 1 GiB
-// pieces (hipMemAddressReserve / hipMemCreate / hipMemMap / hipMemSetAccess), with the same fill rate afterwards.  A DevBuf
-// reserves the most its owner can ever need and commits what it needs now: growing never moves the buffer, so the arena of
-// a context can grow in the middle of a build.  Where the calls are not available (a mock runtime, an old one) the owner
-// falls back to hipMalloc.
+// Large device buffers by virtual-memory reserve + commit (round 6).  Device memory that a process has freed is wiped by
+// the driver before it is handed out again: about 30 ms per GiB on MI355X / ROCm 7.2, whichever call allocates it (hipMalloc
+// of 44 GiB behind a free of as much: 1.7 s; the first 18 GiB of a context behind the destruction of two others: 2.4 s;
+// clean memory: a millisecond — tools/alloc_probe.hip, tools/ctx_probe.py, profiles/r06c_*, r06l_*, r06m_*).  The un-warmed
+// dc3hip_sufsort_i32 of 1 GiB that round 5 measured at 2.4 s (crates/divsuftest/src/main.rs:145-151 times exactly one such
+// call) was waiting for that.  The wait cannot be avoided, only kept proportional to what a build USES: a DevBuf reserves
+// the most its owner can ever need (hipMemAddressReserve) and commits pieces as they are needed (hipMemCreate / hipMemMap /
+// hipMemSetAccess); growing never moves the buffer, so the arena of a context grows in the middle of a build and is
+// committed as its bump allocator advances.  Where the calls are not available (a mock runtime, an old one) the owner falls
+// back to hipMalloc.
 // ---------------------------------------------------------------------------------------------
 struct DevBuf {
   unsigned char *va = nullptr;
