@@ -652,6 +652,13 @@ def test_bucket_ordering_matches_the_stable_passes(ss, oracle):
     # power-of-two alphabets below that put their image together by shifts (KeyT::lg)
     cases["binary"] = rng.integers(0, 2, size=5_000_000).astype(np.uint8)
     cases["hex"] = np.frombuffer(b"0123456789abcdef", dtype=np.uint8)[rng.integers(0, 16, size=5_000_000)].copy()
+    # (round 6: these take their image off a bit-packed copy of the text, KeyBits — lg = 1, 4 above, 2 = "dna"; 3 bits per
+    #  symbol put a position's first bit anywhere in a byte, and runs of the smallest symbol at the very end read like the
+    #  zero bits behind the packed text: tied images that only the window compare can order)
+    cases["octal"] = np.frombuffer(b"01234567", dtype=np.uint8)[rng.integers(0, 8, size=5_000_003)].copy()
+    o2 = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=4_500_001)].copy()
+    o2[-70:] = ord("A"); o2[1_000_000:1_000_060] = ord("A"); o2[2_000_000:2_000_045] = o2[3_000_000:3_000_045]
+    cases["dna_runs_of_the_smallest_symbol"] = o2
     for label, arr in cases.items():
         data = arr.tobytes()
         want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)

@@ -4,7 +4,7 @@ The library chooses among several orderings (whole-text order by bucket or LSD p
 order handed to level 1, DC3 recursion with prefix sorts / straight sorts / discarding) by sampled predictors and
 thresholds; every route gives the same bytes (the parity tests), but a threshold that drifts sends an input down a
 slower route without failing anything.  These bounds are the measured time of each case at the head that shipped
-(profiles/r05*_perf_guards.json; the largest of the round's runs) times 1.2, so a route change — typically 1.5x to 4x —
+(profiles/r05*_perf_guards.json, r06*; the largest of the round's runs) times 1.2, so a route change — typically 1.5x to 4x —
 trips them, and so does losing most of a round's progress (round 4's 1.3 would not have noticed a target missed by 5 %),
 while the pool's boxes do not: the same build ran 2-4 % apart on most of them and once 10 % slower (a 2 GiB build at 103 ms
 on one box and 91-95 ms on three others, round 5), which is why the slack is not the 1.15 the last verdict asked for.  Times are HIP-event times of dc3hip_ctx_build (text resident), best of 3."""
@@ -22,7 +22,9 @@ MEASURED_MS = {
     "random_1GiB": 11.5,
     "random_1GiB_recursion_only": 38.5,
     "random_1GiB_dup_1MB_block": 36.9,
-    "dna_1GiB": 15.0,
+    "dna_1GiB": 11.9,                       # (round 6: the image off the bit-packed text inside pass 1 — 15.0 before)
+    "dna_2GiB_plus_1_chunk_of_configs4": 28.0,   # (round 6: 8-byte words beyond 2^31 positions — 91.5 on 12-byte records before)
+    "sufcheck_1GiB": 33.0,                  # (round 6: the verifier as one counting pass — 98 before; wall time of dc3hip_ctx_sufcheck)
     "text_1GiB": 110.0,
     "real_text_256MiB": 53.4,
 }
@@ -102,6 +104,13 @@ def test_generated_inputs_stay_on_their_routes(ss):
         ms = best_ms(c)
         assert c.stats()["levels"] == 1
         report("dna_1GiB", ms)
+        import time
+        assert c.sufcheck() == 0
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter(); rc = c.sufcheck(); ts.append((time.perf_counter() - t0) * 1e3)
+        assert rc == 0
+        report("sufcheck_1GiB", min(ts))
         c.generate(GIB, 3, 2)
         ms = best_ms(c, reps=2)
         st = c.stats()
@@ -116,6 +125,16 @@ def test_generated_inputs_stay_on_their_routes(ss):
             report("random_1GiB_recursion_only", ms, {"levels": c.stats()["levels"]})
     finally:
         ss.debug_unset("no_text_shortcut")
+
+
+def test_configs4_chunk_stays_on_8_byte_words(ss):
+    n = (1 << 31) + 1
+    with ss.Context(n) as c:
+        c.generate(n, 5, 1, offset=7 * n)
+        ms = best_ms(c, reps=2)
+        st = c.stats()
+        assert st["levels"] == 1 and st["msd_sorts"] == 1 and st["msd_fallbacks"] == 0
+        report("dna_2GiB_plus_1_chunk_of_configs4", ms, {"tied": st["level_tied"][0]})
 
 
 def test_real_text_stays_on_its_route(ss):
