@@ -591,6 +591,8 @@ def main():
             outg = None
             try:
                 from stringsearch_amd.bench_global import run_global
+                if os.environ.get("DC3HIP_BENCH_FAIL_GLOBAL") == "1":        # (tests: the fallback line below)
+                    raise RuntimeError("global leg failed on request (DC3HIP_BENCH_FAIL_GLOBAL=1)")
                 G, selftest = global_setup()
                 outg = run_global(args, ss, dist, backend, world, rank, local_rank, per_gpu, kind, barrier, G=G)
             except BaseException as e:          # noqa: BLE001 - reported in the line

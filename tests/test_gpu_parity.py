@@ -1197,6 +1197,26 @@ def test_bench_gpus_2_without_a_launcher(ss, oracle, tmp_path):
     assert p.returncode != 0 and not [l for l in p.stdout.splitlines() if l.startswith("{")]
 
 
+def test_bench_prints_the_sacapart_leg_when_the_global_leg_fails(ss, tmp_path):
+    """bench.py --gpus 2 whose global leg fails (here on request; on real hardware: an RCCL communicator that cannot be had, a
+    self-test that fails, a collective that hangs until --global-timeout): rank 0 still prints ONE parsable line — the sacapart
+    leg (the reference's own multi-GPU semantics, crates/sacapart/src/lib.rs:39-58) as `value`, labelled in `value_mode`, the
+    reason in `global_mode.error` — and the job exits 0."""
+    import subprocess, sys
+    from conftest import ROOT, bench_line
+    env = dict(os.environ, DC3HIP_BENCH_BACKEND="gloo", DC3HIP_BENCH_FAIL_GLOBAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--size", "4MiB", "--steps", "2", "--warmup", "1",
+                        "--detail", str(tmp_path / "detail.json")], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line, full = bench_line(p.stdout)
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["value"] == line["value_sacapart"]
+    assert line["value_mode"].startswith("sacapart") and "failed on request" in line["global_mode"]["error"]
+    assert "sacapart" in line["config"]["partitioning"] and line["cpu_baseline"]["cores"] == 2
+    assert line["roofline"] is None or line["roofline"]["bound"] == "hbm"
+
+
 def test_stage_level_trace_matches_oracle(ss, oracle, corpus):
     """Stage-level parity (SURVEY §5 tracing row; the counterpart of the reference's crosscheck!, crosscheck.rs:17-84):
     with DC3HIP_TRACE=1 the library reports, per level, checksums of the sorted samples SA12, the sorted mod-0 suffixes

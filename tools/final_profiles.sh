@@ -24,10 +24,11 @@ unset DC3HIP_DEBUG
 prof text_1GiB python3 tools/gpu_scale.py 1073741824:2
 prof dna_1GiB python3 tools/gpu_scale.py 1073741824:1
 # HBM counters of bench.py's three workloads (then, in the repo: python tools/pmc_to_json.py gpurun_out default|recursion|text)
-bash tools/pmc_build.sh default 1073741824:0:2 hbm > gpurun_out/${tag}_pmc_default.log 2>&1
+bash tools/pmc_build.sh default 1073741824:0:2 > gpurun_out/${tag}_pmc_default.log 2>&1          # (HBM and SQ / LDS groups)
 DC3HIP_DEBUG=no_text_shortcut bash tools/pmc_build.sh recursion 1073741824:0:2 hbm > gpurun_out/${tag}_pmc_recursion.log 2>&1
 bash tools/pmc_build.sh text 1073741824:2:3 > gpurun_out/${tag}_pmc_text.log 2>&1
 DC3HIP_PERF_GUARD_LOG=gpurun_out/${tag}_perf_guards.json python3 -m pytest tests/test_perf_guards.py -x -q -m gpu 2>&1 | tail -2
 [ -x tools/radix_lab ] && timeout 300 tools/radix_lab 30 5 > gpurun_out/${tag}_radix_lab.jsonl 2> gpurun_out/${tag}_radix_lab.err
+bash tools/pmc_build.sh dna 1073741824:1:5 hbm > gpurun_out/${tag}_pmc_dna.log 2>&1
 python3 bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 tail -c 600 gpurun_out/${tag}_bench.json

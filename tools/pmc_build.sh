@@ -15,6 +15,9 @@ groups=("FETCH_SIZE" "WRITE_SIZE" \
            "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR")
 [ "$3" = hbm ] && groups=("FETCH_SIZE" "WRITE_SIZE")
+# ONE build per pass, and it must be the build the bench times: a context's first build keeps to the counted second pass
+# unless slots are asked for (round 6) — msd_slot_cap=2048 is the cap the steady-state builds of these sizes take anyway
+export DC3HIP_DEBUG="${DC3HIP_DEBUG:+$DC3HIP_DEBUG,}msd_slot_cap=2048"
 for grp in "${groups[@]}"; do
   i=$((i+1))
   rocprofv3 --pmc $grp --kernel-trace --output-format csv -d gpurun_out/pmcrun_${tag}_$i -- python3 tools/one_build.py $spec --dump gpurun_out/pmc_${tag}_stats.json > gpurun_out/pmc_${tag}_$i.json 2> gpurun_out/pmc_${tag}_$i.err
