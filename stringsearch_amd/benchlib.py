@@ -29,14 +29,19 @@ def algorithmic_bytes(level_n):
 
 
 def kernel_sources_sha():
-    """sha256 over the kernel and host-driver sources the timed kernels are compiled from.  A PMC collection is only
-    replayed into `roofline.traffic` when it was made on exactly these sources (profiles/pmc_traffic.json carries the hash
-    of the tree it profiled): the GPU box has no .git, so a commit id cannot be checked there."""
+    """sha256 over the sources the timed kernels and their orchestration are compiled from: every csrc/*.hpp of the single-device
+    path (device kernels *.hip.hpp, the sorts / orderings / level driver dc3_host_*.hpp).  Not covered: dc3hip.hip (the C ABI
+    and the plumbing of the one-shot calls) and dc3_global_*.hpp (the multi-rank host driver) — neither decides which kernels
+    a single-device build runs or what they move.  A PMC collection is only replayed into `roofline.traffic` when it was made
+    on exactly these sources (profiles/pmc_traffic.json carries the hash of the tree it profiled): the GPU box has no .git, so
+    a commit id cannot be checked there."""
     import glob
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "stringsearch_amd", "csrc")
-    for f in sorted(glob.glob(os.path.join(d, "*.hpp")) + glob.glob(os.path.join(d, "*.hip"))):
+    for f in sorted(glob.glob(os.path.join(d, "*.hpp"))):
+        if os.path.basename(f).startswith("dc3_global_"):
+            continue
         h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 
