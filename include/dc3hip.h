@@ -121,8 +121,8 @@ typedef struct dc3hip_ctx dc3hip_ctx;
 /* Creates a context on `device` (-1 = current) able to index texts of up to max_n bytes.
  * Device memory: text (max_n + 64 bytes), suffix array (4 max_n) and a work arena.  From 2 GiB on a buffer is a reserved
  * address range (hipMemAddressReserve / hipMemMap) that is committed as it is used, and the arena grows where it lies: a
- * build of random bytes commits about 17 bytes per text byte, 16 more from a context's second build on (the bucket
- * ordering's slots), about 44 when a build enters the DC3 recursion (high-entropy texts never do).  Memory another process
+ * build of random bytes commits about 17 bytes per text byte + 16 for the bucket ordering's slots (a one-shot call's
+ * context takes those from its second build on), about 44 when a build enters the DC3 recursion (high-entropy texts never do).  Memory another process
  * or context freed shortly before is handed out by the driver at about 30 ms per GiB (it is wiped first), so a first build
  * can take that much longer than the next.  dc3hip_stats.arena_bytes (the limit) / arena_peak (what the last build used). */
 DC3HIP_API int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n);

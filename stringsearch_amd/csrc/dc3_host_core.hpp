@@ -124,7 +124,8 @@ struct dc3hip_ctx {
   bool arena_fixed = false;    // DC3HIP_ARENA_BYTES given: never grown
   bool arena_borrowed = false; // the arena belongs to another context (ctx_create_impl): never grown, never freed here
   bool arena_exhausted = false; // the last E_ALLOC came from the bump allocator (not from hipMalloc)
-  u32 builds_done = 0;          // builds this context has finished (policy: a one-shot context never commits the slots' 16 n)
+  u32 builds_done = 0;          // builds this context has finished
+  bool one_shot = false;        // created by a one-shot call (dc3hip_sufsort_*): its FIRST build does not commit the slots' 16 n
   // small device scratch
   u32 *d_present = nullptr;    // [256]
   uint16_t *d_code = nullptr;  // [256]

@@ -331,10 +331,11 @@ static int msd_sort(dc3hip_ctx *c, Rec8 *ha, Rec8 *hb, u32 n, const HiMap &hm, c
     // spare (beyond 2^31 words the mean passes the local sort's small shape: counted form), an arena with room — one that
     // can grow where it lies commits the 16 bytes per word now (arena_grow_in_use; first sort of a context only).  Only then
     // is the largest pass-1 bucket read back (a pipeline drain that a sort without slots must not pay).
-    // A context's FIRST build keeps to the counted form unless the room is there already: the slots cost 16 bytes per word of
-    // device memory, and memory another process has used is handed out at about 30 ms per GiB (the driver wipes it) — more
-    // than a one-shot call gains; a context that builds again commits them then.
-    const bool may_grow = c->builds_done > 0 || c->msd_slot_cap != 0;
+    // The FIRST build of a one-shot call's context keeps to the counted form unless the room is there already: the slots cost
+    // 16 bytes per word of device memory, and memory somebody freed shortly before is handed out at about 30 ms per GiB (the
+    // driver wipes it) — more than one call gains; when the cached context builds again it commits them.  A context the
+    // caller created (dc3hip_ctx_create: repeated builds) takes them at once.
+    const bool may_grow = !c->one_shot || c->builds_done > 0 || c->msd_slot_cap != 0;
     const bool host_ok = slot_words < (1ull << 32) && (c->msd_slot_cap || (u64)mean * 5 <= (u64)slot_cap * 4) &&
                          (c->arena_off + need <= c->arena_bytes || (may_grow && arena_grow_in_use(c, c->arena_off + need)));
     u32 maxb1 = 0;

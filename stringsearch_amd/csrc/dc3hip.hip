@@ -665,10 +665,13 @@ static int acquire_ctx(dc3hip_ctx **out, int device, int64_t n, bool *cached) {
     if (cc && dev >= 0 && cc->device == dev && cc->max_n >= n && !oversized) { *out = cc; *cached = true; return E_OK; }
     if (cc) { dc3hip_ctx_destroy(cc); g_cache.c = nullptr; }
     RC(dc3hip_ctx_create(out, device, n));
+    (*out)->one_shot = true;
     g_cache.c = *out; *cached = true;
     return E_OK;
   }
-  return dc3hip_ctx_create(out, device, n);
+  RC(dc3hip_ctx_create(out, device, n));
+  (*out)->one_shot = true;
+  return E_OK;
 }
 
 static int sufsort_one(const uint8_t *T, void *SA, int64_t n, int bits, int device, bool devptrs) {

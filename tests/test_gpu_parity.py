@@ -685,12 +685,10 @@ def test_bucket_ordering_matches_the_stable_passes(ss, oracle):
                             c.build()
                             assert c.stats()["msd_slot_sorts"] == 0 and np.array_equal(c.sa(), want), (label, env)
                         elif label == f"bytes_{(1 << 25) + 77}" and (len(env) == 1 or env.get("DC3HIP_VMM_MIN") == "1"):
-                            # a context's first build keeps to the counted form (a one-shot call must not pay for 16 more bytes
-                            # per word of device memory); from its second build on a reserved arena takes the slots
-                            assert st["msd_slot_sorts"] == 0, (label, env)
+                            # a reserved arena commits the slots' 16 bytes per word when the sort first asks (arena_grow_in_use)
+                            assert st["msd_slot_sorts"] >= 1, (label, env, st["msd_max_subbucket"])
                             c.build()
-                            assert c.stats()["msd_slot_sorts"] >= 1, (label, env, c.stats()["msd_max_subbucket"])
-                            assert np.array_equal(c.sa(), want), (label, env, "second build, slots")
+                            assert c.stats()["msd_slot_sorts"] >= 1 and np.array_equal(c.sa(), want), (label, env, "second build")
             finally:
                 env_clear(env)
 
