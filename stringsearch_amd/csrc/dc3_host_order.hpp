@@ -1188,7 +1188,10 @@ static int order_all_positions(dc3hip_ctx *c, KM km, Map mp, u32 m, u32 kbits, c
     // array is written or read back; the pack kernel only counts the top digit
     if (mg.on && !c->no_pack_strip && dummy == 0 && hm.pbits >= 23 && km.lg != 0 && hm.nbits + mg.d1 + 7 + 3 * km.lg <= 64 &&
         (u64)3 * km.L * km.lg >= hm.nbits + mg.d1) {        // (the image spans no more symbols than the window the ties are compared by)
-      const u32 groups = (nrec + 7) / 8 + 2;
+      // (+ 10 groups of zero digits: an image is read with ONE 8-byte load from the byte its first bit lies in, i.e. up to 8 bytes
+      //  behind the last symbol's — with lg = 1 a group is one byte.  Two groups were not enough: the soak of round 6 found the
+      //  last few suffixes of binary and DNA texts misplaced whenever the arena behind the stream was not zero.)
+      const u32 groups = (nrec + 7) / 8 + 10;
       uint8_t *bits = nullptr;
       RC(arena_alloc(c, (size_t)groups * km.lg + 64, &bits));
       HiMap hw; hw.mfix = 0; hw.shx = 0; hw.exact = 0; hw.raw = 0; hw.pbits = hm.pbits - mg.d1; hw.nbits = hm.nbits + mg.d1;

@@ -693,6 +693,30 @@ def test_bucket_ordering_matches_the_stable_passes(ss, oracle):
                 env_clear(env)
 
 
+def test_small_alphabets_in_a_context_that_has_built_before(ss, oracle):
+    """(round-6 soak) The bit-packed copy of a power-of-two alphabet's text (KeyBits) is read 8 bytes at a time from the byte a
+    position's first bit lies in — up to 8 bytes behind the last symbol's — and what it reads there must be zero bits.  A fresh
+    context's arena happens to be zero; one that has built before is not: binary and DNA texts in a context whose arena an
+    earlier build of random bytes has filled, one-shot calls through the cached context alike."""
+    rng = np.random.default_rng(77)
+    n = 6_000_000
+    with ss.Context(n) as c:
+        for k, (sigma, m) in enumerate(((2, n), (4, n - 1), (2, n - 3), (16, n - 5), (8, n - 7), (4, 4_200_001))):
+            c.set_text(rng.integers(1, 256, size=n, dtype=np.uint8)); c.build()          # fills the arena with non-zero words
+            data = (rng.integers(0, sigma, size=m) * (255 // sigma)).astype(np.uint8)
+            data[-int(rng.integers(1, 40)):] = data.min()                               # the smallest symbol at the very end
+            c.set_text(data); c.build()
+            assert c.stats()["text_sort_state"] == 1 and c.stats()["msd_sorts"] == 1, (sigma, m)
+            want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)
+            assert np.array_equal(c.sa(), want), (sigma, m)
+    for sigma in (2, 4):
+        ss.sort(rng.integers(1, 256, size=n, dtype=np.uint8))                            # the cached one-shot context, dirtied
+        data = rng.integers(0, sigma, size=n - 11).astype(np.uint8)
+        want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)
+        assert np.array_equal(ss.sort(data).into_parts()[1], want), sigma
+    ss.release_cache()
+
+
 def test_splitter_ordering_matches_the_stable_passes(ss, oracle):
     """The splitter (sample) ordering of the 12- and 16-byte sample-triple records (dc3_ssort.hip.hpp: partition passes
     over sampled splitters + in-LDS comparison order of the sub-buckets) against the stable LSD passes it replaces

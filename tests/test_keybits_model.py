@@ -11,12 +11,14 @@ import pytest
 
 
 def pack_bits(digits, lg):
-    """k_pack_bits: groups of 8 symbols -> lg bytes, first symbol in the top bits; 2 zero groups + 64 zero bytes behind"""
+    """k_pack_bits: groups of 8 symbols -> lg bytes, first symbol in the top bits; 10 zero groups behind, then whatever the arena holds"""
     n = len(digits)
-    groups = (n + 7) // 8 + 2
+    groups = (n + 7) // 8 + 10             # order_all_positions' formula: 10 groups of zero digits behind the text
     d = np.zeros(groups * 8, dtype=np.uint64)
     d[:n] = digits
-    out = np.zeros(groups * lg + 64, dtype=np.uint8)
+    # what lies behind the stream in the arena is NOT zero (a context that has built before): all ones here — an image that
+    # reads it breaks the monotone map for the last suffixes of the text (the bug the round-6 soak found with + 2 groups)
+    out = np.full(groups * lg + 64, 255, dtype=np.uint8)
     for g in range(groups):
         acc = 0
         for k in range(8):
