@@ -879,21 +879,6 @@ __global__ __launch_bounds__(kBlock) void k_pack_image_text(Key9 km, u32 n, HiMa
   __syncthreads();
   u32 *myh = hist[wave_id()];
   const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);       // chunk is a multiple of 4
-  if (!kStore) {
-    // count only (pass 1 of the bucket ordering makes the words): two rounds of 4 positions per iteration — two independent
-    // 12-byte loads in flight per thread (one left the kernel at 2.3 TB/s of a 1-byte-per-position read)
-    for (u32 p0 = begin + 4 * threadIdx.x; p0 < end; p0 += 8 * kBlock) {
-      const u32 p1 = p0 + 4 * kBlock;
-      u64 ia[4], ib[4] = {0, 0, 0, 0};
-      images4(km, hm, 0ull, p0, n, lcode, ia);
-      if (p1 < end) images4(km, hm, 0ull, p1, n, lcode, ib);
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        if (p0 + j < end) atomicAdd(&myh[(u32)(ia[j] >> hshift) & (NB - 1)], 1u);
-        if (p1 + j < end) atomicAdd(&myh[(u32)(ib[j] >> hshift) & (NB - 1)], 1u);
-      }
-    }
-  } else
   for (u32 p0 = begin + 4 * threadIdx.x; p0 < end; p0 += 4 * kBlock) {
     u64 img[4];
     images4(km, hm, 0ull, p0, n, lcode, img);
