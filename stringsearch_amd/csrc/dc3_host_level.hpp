@@ -746,6 +746,13 @@ static int build_core(dc3hip_ctx *c) {
           HiMap hp = make_himap(B3, kbits, (u32)n, hm.pbits - kStripBits);
           hp.raw = hm.raw;
           RC(try_text_order<Key9>(c, km, B3, hm, sigma, &whole_text, &pre, &km, &hp));
+          if (!whole_text && !pre.spos && c->stats.msd_fallbacks > 0) {
+            // the bucket ordering gave up (a sub-bucket beyond the local sort: a long run, a crowded corner of the image
+            // range): the same order on 12-byte records, whose image is as wide as the text needs without the strip
+            HiMap h12 = make_himap(B3, kbits, (u32)n, 64 - ibits);
+            h12.raw = hm.raw;
+            RC(try_text_order12<Key9>(c, km, B3, h12, sigma, &whole_text, &pre));
+          }
         } else RC(try_text_order<Key9>(c, km, B3, hm, sigma, &whole_text, &pre));
       } else if (!c->no_long_keys) {
         // small alphabets: limbs of L > 3 symbols (as many as fit 32 bits), 3L-symbol windows
@@ -755,8 +762,12 @@ static int build_core(dc3hip_ctx *c) {
         if (L > 3 && 3.0 * L * sym_bits >= need_bits && make_keyt(S, sigma, L, BL, (u32)n, &km, &hm, wide ? ibits : 0u)) {
           KeyT kp; HiMap hp;
           if (wide) RC(try_text_order12<KeyT>(c, km, BL, hm, sigma, &whole_text, &pre));
-          else if (strip8 && make_keyt(S, sigma, L, BL, (u32)n, &kp, &hp, hm.nbits + kStripBits))
+          else if (strip8 && make_keyt(S, sigma, L, BL, (u32)n, &kp, &hp, hm.nbits + kStripBits)) {
             RC(try_text_order<KeyT>(c, km, BL, hm, sigma, &whole_text, &pre, &kp, &hp));
+            KeyT k12; HiMap h12;
+            if (!whole_text && !pre.spos && c->stats.msd_fallbacks > 0 && make_keyt(S, sigma, L, BL, (u32)n, &k12, &h12, ibits))
+              RC(try_text_order12<KeyT>(c, k12, BL, h12, sigma, &whole_text, &pre));          // (as above)
+          }
           else RC(try_text_order<KeyT>(c, km, BL, hm, sigma, &whole_text, &pre));
         }
       }

@@ -479,6 +479,12 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
       Rec8 *where = ha;
       RC(msd_sort(c, ha, hb, nrec, hm, *mg, first_table, &sink, &h, &mredo, &msd_ok, &where, p1, nullptr, slots_ok));
       if (msd_ok) lp.src = const_cast<u64 *>(mredo.src);               // (non-null = "the order lives in the sink")
+      else if (hm.pbits >= 32 && p1) {
+        // Beyond 2^31 positions the word itself holds 32 image bits — it only orders by 42 through pass 1's strip — and the LSD
+        // passes over plain words would tie 39-58 % of even random windows (then the recursion: 2.9 s at 3.7e9 bytes in the
+        // round-6 soak, for one run of a symbol).  The caller takes the 12-byte records instead (build_core).
+        return E_OK;                                                   // (*ok stays false, stats.msd_fallbacks says why)
+      }
       else { first_table = nullptr; if (p1) RC(p1->repack(c, ha, nrec, &first_table)); }      // from scratch: `ha` in position order
     }
     if (!msd_ok) {

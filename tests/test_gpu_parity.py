@@ -1080,6 +1080,23 @@ def test_sample_count_beyond_2pow31(ss):
         assert c.stats()["level_n"][1] > (1 << 31)
 
 
+def test_long_run_beyond_2pow31_takes_the_12_byte_records(ss):
+    """Beyond 2^31 positions an 8-byte word only orders by more than 32 image bits through pass 1 of the bucket ordering; when
+    that ordering gives up (here: a run of one symbol — 60 000 windows with one image, a sub-bucket beyond the local sort's 4096)
+    the stable passes over plain words would tie 39 % of all windows.  The build takes the 12-byte records instead (round 6; the
+    soak measured 825 -> 188 ms for this shape, and 2.9 s where the plain words sent a 3.7e9-byte text into the recursion)."""
+    n = (1 << 31) + 1
+    with ss.Context(n) as c:
+        c.generate(n, 4, 0)
+        t = c.text()
+        t[1_000_000_000:1_000_060_000] = 7
+        c.set_text(t); del t
+        c.build()
+        st = c.stats()
+        assert c.sufcheck() == 0
+        assert st["msd_fallbacks"] >= 1 and st["levels"] == 1 and st["text_sort_state"] == 1, (st["msd_fallbacks"], st["levels"], st["level_sorted"])
+
+
 def test_boundary_sizes_sufcheck(ss):
     """Sizes that put n, m02 or a child length on the boundaries of the size-dependent machinery (2^14-entry
     inversion windows, 2^22-pair partition segments, radix / merge tiles), all generator kinds, GPU sufcheck."""
