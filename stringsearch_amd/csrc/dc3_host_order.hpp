@@ -607,7 +607,7 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
     // the tied subset is re-sorted as 16-byte records (2 x 16 B + index + radix tables): when the arena cannot hold
     // that on top of what the caller holds, give the ordering up (*ok stays false -> the caller's next ordering
     // runs instead); arena_requirement() only bounds the straight ordering
-    if (c->arena_bytes - c->arena_off < (size_t)tied * 36 + (32u << 20)) return E_OK;
+    if (!arena_grow_in_use(c, c->arena_off + (size_t)tied * 36 + (32u << 20))) return E_OK;      // (a reserved arena raises its limit where it lies)
     const ArenaMark mk_general = arena_mark(c);     // the tied subset is dead after the write-back: released there
     Rec16 *sa = nullptr, *sb = nullptr, *ss = nullptr;
     u32 *tiedidx = nullptr;
@@ -688,7 +688,7 @@ static int hybrid12_refine(dc3hip_ctx *c, KM km, u32 kbits, Rec12 *h, u32 n, uin
   if (general) {
     // some tied group is larger than kTieSmallMax: re-sort ALL tied records by the full key (the small groups that were
     // already settled are re-done consistently)
-    if (c->arena_bytes - c->arena_off < (size_t)tied * 36 + (32u << 20)) return E_OK;
+    if (!arena_grow_in_use(c, c->arena_off + (size_t)tied * 36 + (32u << 20))) return E_OK;      // (a reserved arena raises its limit where it lies)
     const ArenaMark mk_general = arena_mark(c);     // the tied subset is dead after the write-back: released there
     const Chunking ck = make_chunks(c, n, kBlock);
     u32 *counts = nullptr, *tiedidx = nullptr;
@@ -1068,7 +1068,7 @@ static int doubling_finish(dc3hip_ctx *c, KM km, Acc acc, u32 n, u32 W, u32 *out
   }
   HIPC(hipStreamSynchronize(c->stream));
   const u32 t = c->h_words[2];
-  if (t == 0 || t > kDoublingMaxTied || t > n / 64 || c->arena_bytes - c->arena_off < (size_t)t * 128 + (32u << 20)) {
+  if (t == 0 || t > kDoublingMaxTied || t > n / 64 || !arena_grow_in_use(c, c->arena_off + (size_t)t * 128 + (32u << 20))) {
     arena_release(c, mk);
     return E_OK;
   }
