@@ -398,9 +398,17 @@ def main():
                 ts.append(time.perf_counter() - t1)
                 assert rc == 0, ss.last_error()
             warm = min(ts[1:])
-            out["e2e_ffi"] = {"entry": "dc3hip_sufsort_i32(T, SA, n) on pageable host buffers", "ms": warm * 1e3,
-                              "MB/s": n / warm / 1e6,
-                              "first_call_in_this_process_ms": ts[0] * 1e3,       # (behind the contexts this bench has just freed: incl. the driver's wipe)
+            # `ms` = a warm call: the second call of the fresh child process when there is one (a host program that indexes
+            # texts: 108 ms at the 56 GB/s most boxes copy at), beside the warm calls of THIS process — which by then has moved
+            # some 40 GiB through pageable numpy arrays and whose copies the runtime has been seen to serve at half that rate
+            # (190 ms; profiles/r06v_*) — both are reported.
+            child_warm = (fresh or {}).get("second_call_ms")
+            out["e2e_ffi"] = {"entry": "dc3hip_sufsort_i32(T, SA, n) on pageable host buffers",
+                              "ms": child_warm if child_warm else warm * 1e3,
+                              "MB/s": n / ((child_warm if child_warm else warm * 1e3) * 1e-3) / 1e6,
+                              "ms_is": "second call of a fresh process" if child_warm else "warm call of the bench process",
+                              "in_bench_process_ms": warm * 1e3,
+                              "first_call_in_this_process_ms": ts[0] * 1e3,       # (behind the contexts this bench has just freed)
                               "first_call_fresh_process_ms": (fresh or {}).get("first_call_ms"), "fresh_process": fresh,
                               "includes": "H2D of n bytes, device build, D2H of 4n bytes; a first call also creates the cached context",
                               "pcie_floor_ms": 5.0 * n / 56e9 * 1e3}

@@ -309,7 +309,7 @@ def compact_line(full, detail_path=None):
     c["verify"] = full.get("verify")
     if "e2e_ffi" in full:
         e = full["e2e_ffi"]
-        c["e2e_ffi"] = {k: e.get(k) for k in ("ms", "MB/s", "first_call_ms", "first_call_fresh_process_ms", "first_call_in_this_process_ms", "pcie_floor_ms") if k in e}
+        c["e2e_ffi"] = {k: e.get(k) for k in ("ms", "MB/s", "ms_is", "in_bench_process_ms", "first_call_ms", "first_call_fresh_process_ms", "first_call_in_this_process_ms", "pcie_floor_ms") if k in e}
     gl = full.get("global_mode_loopback")
     if gl:
         # predicted speed-up over one GPU at P ranks (own work under the device token + link model); full rows in the detail file
