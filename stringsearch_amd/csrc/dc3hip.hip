@@ -175,8 +175,8 @@ static int ctx_create_impl(dc3hip_ctx **out, int32_t device, int64_t max_n, dc3h
       // ordering's partition passes are only fast when blocks b and b + 8 share an XCD (XCD-grouped reservation,
       // dc3_msd.hip.hpp); on a device that places blocks otherwise the context keeps to the stable 256-bucket LSD passes,
       // whose speed does not depend on placement (DC3HIP_XCD_ASSUME=1: keep the bucket ordering anyway).
-      // (once per device and process: the answer is a property of the device's dispatcher, and a context per sacapart
-      //  worker would otherwise launch 4096 blocks and wait for a copy each)
+      // (a positive answer once per device and process: it is a property of the device's dispatcher, and a context per
+      //  sacapart worker would otherwise launch 4096 blocks and wait for a copy each)
       static std::mutex probe_mu;
       static int probe_cache[64];
       static bool probe_init = false;
@@ -195,9 +195,14 @@ static int ctx_create_impl(dc3hip_ctx **out, int32_t device, int64_t max_n, dc3h
           for (int x = 0; x < 8; x++) if (cnt[g][x] > mx) { mx = cnt[g][x]; arg = (u32)x; }
           hit += mx; seen |= 1u << arg;
         }
-        probe_cache[device & 63] = (hit >= 4096 * 9 / 10 && seen == 0xffu) ? 1 : 0;
+        // (only a positive answer is kept for the process: a probe taken while other streams or ranks load the device can
+        //  come out negative without the dispatcher being any different — the next context probes again)
+        const int ok = (hit >= 4096 * 9 / 10 && seen == 0xffu) ? 1 : 0;
+        if (ok) probe_cache[device & 63] = 1;
+        c->xcd_rr = ok;
+      } else {
+        c->xcd_rr = 1;
       }
-      c->xcd_rr = probe_cache[device & 63];
       const char *e = getenv("DC3HIP_XCD_ASSUME");
       if (!c->xcd_rr && !(e && e[0] == '1')) c->no_msd = true;
     }
