@@ -211,11 +211,15 @@ struct CheckLoader {
 };
 struct CheckSink {
   const u32 *sa; const u32 *q; u32 n; int *err;
-  __device__ __forceinline__ void store(u32 g, const Rec8 &x) const {
-    const u32 t = g + (g >= *q ? 1u : 0u);                         // utils.c:212-213: slot q is skipped
-    if (t >= n || sa[t] != x.val) atomicMax(err, 1);               // utils.c:222 "p != SA[t]"
+  typedef u32 Fetched;
+  __device__ __forceinline__ u32 slot(u32 g) const { return g + (g >= *q ? 1u : 0u); }     // utils.c:212-213: slot q is skipped
+  __device__ __forceinline__ u32 fetch(u32 g) const { const u32 t = slot(g); return t < n ? sa[t] : 0xffffffffu; }
+  __device__ __forceinline__ void check(u32 g, const Rec8 &x, u32 v) const {
+    if (slot(g) >= n || v != x.val) atomicMax(err, 1);             // utils.c:222 "p != SA[t]"
   }
+  __device__ __forceinline__ void store(u32 g, const Rec8 &x) const { check(g, x, fetch(g)); }
 };
+template <> struct SinkReads<CheckSink> { static constexpr bool value = true; };
 __global__ __launch_bounds__(kBlock) void k_checksum(const u32 *__restrict__ sa, u32 n, u64 *out) {
   u64 acc = 0;
   for (u32 i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)

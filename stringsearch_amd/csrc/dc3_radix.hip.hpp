@@ -97,6 +97,10 @@ struct SplitSink {
   }
 };
 
+// Sinks that read at the destination instead of storing (SinkReads<S>::value): fetch(g) issues the load, check(g, x, v)
+// judges it — see the write-out loop of k_rs_downsweep.
+template <class S> struct SinkReads { static constexpr bool value = false; };
+
 // How a record is held in registers between its load and the LDS reorder.  hipcc left the array of 20-byte Tup0 structs
 // in scratch (112 bytes per thread stored and reloaded, profiles/r05a occupancy report) although every index is a
 // constant after unrolling; the same words as one 5-wide vector per record stay in VGPRs.  Other record types as they are.
@@ -238,10 +242,31 @@ __global__ __launch_bounds__(NW * 64) void k_rs_downsweep(Loader in, Sink out, u
       else { if (ok[k]) srec[texcl[d[k]] + wcnt[w * NB + d[k]] + rk[k]] = RR::unpack(r[k]); }
     }
     __syncthreads();
-    for (u32 q = tid; q < nkeep; q += kB) {
-      const Rec x = srec[q];
-      const u32 dd = digit_of(x, dig);
-      out.store(dbase[dd] + (q - texcl[dd]), x);
+    if constexpr (SinkReads<Sink>::value) {
+      // a sink that READS at the destination (the verifier's comparing sink): four destinations per thread and round, their
+      // loads issued together — one dependent load per loop iteration left the pass waiting on memory latency (9 ms per 2^30
+      // records against 6 for the storing form)
+      for (u32 q0 = tid; q0 < nkeep; q0 += 4 * kB) {
+        Rec x[4]; u32 g[4]; typename Sink::Fetched v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const u32 q = min(q0 + (u32)u * kB, nkeep - 1u);
+          x[u] = srec[q];
+          const u32 dd = digit_of(x[u], dig);
+          g[u] = dbase[dd] + (q - texcl[dd]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = out.fetch(g[u]);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (q0 + (u32)u * kB < nkeep) out.check(g[u], x[u], v[u]);
+      }
+    } else {
+      for (u32 q = tid; q < nkeep; q += kB) {
+        const Rec x = srec[q];
+        const u32 dd = digit_of(x, dig);
+        out.store(dbase[dd] + (q - texcl[dd]), x);
+      }
     }
     __syncthreads();
     if (tid < NB) dbase[tid] += tot;
