@@ -116,7 +116,7 @@ struct dc3hip_ctx {
   unsigned char *arena = nullptr;
   size_t arena_bytes = 0, arena_off = 0, arena_peak = 0;
   // round 6: big buffers are reserved address ranges, committed as needed (DevBuf): arena_vm.va == arena when the arena is
-  // one; sa_vm / text_vm likewise for d_sa / d_text beyond kDevBufMinBytes.  use_vm = false (ranks of the global mode, whose
+  // one; sa_vm / text_vm likewise for d_sa / d_text from vm_min bytes on.  use_vm = false (ranks of the global mode, whose
   // buffers RCCL and peer copies see): plain hipMalloc as before
   DevBuf arena_vm, sa_vm, text_vm;
   bool use_vm = true;
@@ -214,10 +214,9 @@ static size_t arena_requirement(int64_t n) {
   return total + (8u << 20);
 }
 
-// What the whole-text order (and every by-product except the LCP array) needs: two 8-byte record arrays, the image
-// side array, a flag byte per record, radix tables and the tie predictor.  A context starts with this much and grows
-// to arena_requirement() the first time a build enters the DC3 recursion (ensure_arena): high-entropy texts never
-// do, so their contexts hold half the memory and the first hipMalloc is half as long.
+// What the whole-text order (and every by-product except the LCP array) needs: two 8-byte word arrays, the image side
+// array, a flag byte per record, radix tables and the tie predictor.  A context starts with this LIMIT and raises it to
+// arena_requirement() the first time a build enters the DC3 recursion (ensure_arena): high-entropy texts never do.
 static size_t arena_text_requirement(int64_t n) {
   // two 8-byte word arrays, 4 image bytes + 1 flag byte + 1 same byte per position, tables, the tie predictor: 22 n + tables
   // (+ the size tables of the bucket ordering: 2 x 8 words per sub-bucket, at most 2^20 sub-buckets)
