@@ -697,9 +697,7 @@ static int sufsort_one(const uint8_t *T, void *SA, int64_t n, int bits, int devi
     ~Prefault() { join(); }
   } prefault;
   const size_t sa_bytes = (size_t)n * (size_t)(bits / 8);
-  // (only pages that do not exist yet: touching a resident array from other cores was measured to SLOW the copies of a
-  //  long-lived host process down — 77 -> 142 ms for the 4 GiB back, 19 -> 36 ms for the text — so 64 sample pages are asked
-  //  for with mincore first)
+  // (only pages that do not exist yet — a resident array needs nothing: 64 sample pages are asked for with mincore first)
   auto mostly_absent = [](unsigned char *base, size_t bytes) {
     const uintptr_t pg = 4096;
     unsigned char *lo = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(base) + pg - 1) & ~(pg - 1));
@@ -718,10 +716,12 @@ static int sufsort_one(const uint8_t *T, void *SA, int64_t n, int bits, int devi
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     const unsigned nt = std::min(8u, std::max(1u, hw / 4));
     unsigned char *base = static_cast<unsigned char *>(SA);
-    for (unsigned t = 0; t < nt; t++) {
-      const size_t lo = sa_bytes / nt * t, hi = t + 1 == nt ? sa_bytes : sa_bytes / nt * (t + 1);
-      prefault.th.emplace_back([base, lo, hi] { for (size_t o = lo; o < hi; o += 4096) *reinterpret_cast<volatile unsigned char *>(base + o) = 0; });
-    }
+    try {
+      for (unsigned t = 0; t < nt; t++) {
+        const size_t lo = sa_bytes / nt * t, hi = t + 1 == nt ? sa_bytes : sa_bytes / nt * (t + 1);
+        prefault.th.emplace_back([base, lo, hi] { for (size_t o = lo; o < hi; o += 4096) *reinterpret_cast<volatile unsigned char *>(base + o) = 0; });
+      }
+    } catch (...) {}                           // (no thread to be had: the copy faults the pages in itself, as before)
   }
   RC(acquire_ctx(&c, device, n, &cached));
   const double t_ctx = ms_since(t0);
