@@ -74,7 +74,7 @@ static int gbuild(dc3hip_gctx *G) {
   G->built = false;
   // the calling thread may be a fresh one (loopback ranks, a host program's worker) whose current device is 0: every
   // allocation of the build (ensure_arena comes before build_begin) must land on the rank's own device
-  HIPC(hipSetDevice(G->c->device));
+  HIPC(dc3_set_device(G->c->device));
   GComm *cm = G->comm;
   cm->comm_ms = 0; cm->bytes_in = cm->bytes_out = 0;
   cm->work_ms = 0; cm->link_ms = 0; cm->ncoll = 0;
@@ -118,7 +118,7 @@ static int gctx_make_ctx(dc3hip_gctx *G, int device, int64_t max_total_n) {
   if (!G->wide) return ctx_create_impl(&G->c, device, max_total_n, nullptr, false);
   if (max_total_n > ((int64_t)1 << 40)) { set_err("n=%lld exceeds 2^40", (long long)max_total_n); return E_TOOBIG; }
   RC(ctx_create_impl(&G->c, device, 0, nullptr, false));
-  HIPC(hipSetDevice(G->c->device));
+  HIPC(dc3_set_device(G->c->device));
   HIPC(hipMalloc(&G->w_text, (size_t)max_total_n + 64));
   return E_OK;
 }
@@ -238,7 +238,7 @@ int32_t dc3hip_global_rccl_create(dc3hip_gctx **out, const uint8_t *id128, int32
   RcclComm *rcm = new RcclComm(); rcm->rank = rank; rcm->nranks = nranks;
   G->comm = rcm; G->max_total = max_total_n;
   rc = [&]() -> int {
-    HIPC(hipSetDevice(G->c->device));
+    HIPC(dc3_set_device(G->c->device));
     HIPC(hipMalloc(&rcm->d_small, RcclComm::kSmall * (size_t)(nranks + 1)));
     ncclUniqueId id; memcpy(&id, id128, 128);
     NCCLC(g_rccl.CommInitRank(&rcm->comm, nranks, id, rank));
@@ -306,7 +306,7 @@ int32_t dc3hip_global_set_text_block(dc3hip_gctx *G, const uint8_t *block, int64
   RC(gctx_set_total(G, total_n, &off, &len));
   if (!block && len > 0) { set_err("block is NULL"); return E_ARGS; }
   dc3hip_ctx *c = G->c;
-  HIPC(hipSetDevice(c->device));
+  HIPC(dc3_set_device(c->device));
   if (len > 0) HIPC(hipMemcpyAsync(gtext(G) + off, block, (size_t)len, hipMemcpyDefault, c->stream));
   HIPC(hipStreamSynchronize(c->stream));
   G->text_set = true;
@@ -318,7 +318,7 @@ int32_t dc3hip_global_generate(dc3hip_gctx *G, int64_t total_n, uint64_t seed, i
   RC(gctx_set_total(G, total_n, &off, &len));
   if (kind < 0 || kind > 2) { set_err("unknown generator kind %d", kind); return E_ARGS; }
   dc3hip_ctx *c = G->c;
-  HIPC(hipSetDevice(c->device));
+  HIPC(dc3_set_device(c->device));
   if (len > 0) {
     // only this rank's block: the others arrive by the all-gather of the build
     hipLaunchKernelGGL(k_generate, dim3(grid_for(c, (u64)len / 8 + 1)), dim3(kBlock), 0, c->stream, gtext(G) + off, (u64)len,
@@ -390,7 +390,7 @@ int32_t dc3hip_global_get_shard_i64(dc3hip_gctx *G, int64_t *out) {
   if (!G || (!out && G->shard_count > 0)) { set_err("invalid arguments"); return E_ARGS; }
   if (!G->built) { set_err("no suffix array built in this global context"); return E_ARGS; }
   dc3hip_ctx *c = G->c;
-  HIPC(hipSetDevice(c->device));
+  HIPC(dc3_set_device(c->device));
   if (G->shard_count == 0) return E_OK;
   if (G->wide) {
     HIPC(hipMemcpyAsync(out, G->w_shard, (size_t)G->shard_count * 8, hipMemcpyDefault, c->stream));
@@ -415,7 +415,7 @@ int32_t dc3hip_global_get_shard_u32(dc3hip_gctx *G, uint32_t *out) {
   if (!G->built) { set_err("no suffix array built in this global context"); return E_ARGS; }
   dc3hip_ctx *c = G->c;
   if (G->wide) { set_err("this global context holds 64-bit positions: use dc3hip_global_get_shard_i64"); return E_TOOBIG; }
-  HIPC(hipSetDevice(c->device));
+  HIPC(dc3_set_device(c->device));
   if (G->shard_count > 0) HIPC(hipMemcpyAsync(out, G->shard_ptr, (size_t)G->shard_count * 4, hipMemcpyDefault, c->stream));
   HIPC(hipStreamSynchronize(c->stream));
   return E_OK;
@@ -427,7 +427,7 @@ int32_t dc3hip_global_shard_checksum(dc3hip_gctx *G, uint64_t *out) {
   if (!G || !out) { set_err("invalid arguments"); return E_ARGS; }
   if (!G->built) { set_err("no suffix array built in this global context"); return E_ARGS; }
   dc3hip_ctx *c = G->c;
-  HIPC(hipSetDevice(c->device));
+  HIPC(dc3_set_device(c->device));
   u64 *acc = reinterpret_cast<u64 *>(c->d_words + 16);
   HIPC(hipMemsetAsync(acc, 0, sizeof(u64), c->stream));
   if (G->shard_count > 0 && G->wide) {       // (its own mixing: there is no single-device array to compare with)
@@ -465,7 +465,7 @@ int32_t dc3hip_global_sufcheck(dc3hip_gctx *G) {
   const int P = cm->nranks, me = cm->rank;
   int verdict = 0;
   auto run = [&]() -> int {
-    HIPC(hipSetDevice(c->device));
+    HIPC(dc3_set_device(c->device));
     // first entries of all shards (a rank with an empty shard passes ~0 and is skipped)
     u64 first_mine = ~0ull, firsts[kMaxRanks], counts[kMaxRanks];
     if (G->shard_count > 0) {
@@ -545,7 +545,7 @@ static inline uint8_t selftest_byte(int from, int to, size_t k) {
 static int gselftest(dc3hip_gctx *G) {
   dc3hip_ctx *c = G->c; GComm *cm = G->comm;
   const int P = cm->nranks, me = cm->rank;
-  HIPC(hipSetDevice(c->device));
+  HIPC(dc3_set_device(c->device));
   auto a2a_len = [](int from, int to) -> size_t { return 1000 + 37 * (size_t)from + 101 * (size_t)to + (size_t)((from * 7 + to * 3) % 11); };
   auto ag_len = [](int from) -> size_t { return 5000 + 313 * (size_t)from; };
   // ---- all_to_all_v

@@ -23,6 +23,7 @@ static inline hipError_t dc3_func_set_attribute(const void *fn, hipFuncAttribute
   do {                                                                                          \
     hipError_t e__ = (expr);                                                                    \
     if (e__ != hipSuccess) {                                                                    \
+      (void)hipGetLastError(); /* the runtime keeps the last error until somebody reads it */   \
       set_err("HIP error %d (%s) at %s:%d: %s", (int)e__, hipGetErrorString(e__), __FILE__,     \
               __LINE__, #expr);                                                                 \
       return (e__ == hipErrorOutOfMemory) ? E_ALLOC : E_HIP;                                    \
@@ -30,6 +31,15 @@ static inline hipError_t dc3_func_set_attribute(const void *fn, hipFuncAttribute
   } while (0)
 #define RC(expr) do { int rc__ = (expr); if (rc__ != E_OK) return rc__; } while (0)
 #define KCHECK() HIPC(hipGetLastError())
+// Every entry point selects its context's device first; the same call drops an error that an EARLIER call left behind in
+// the runtime's per-thread slot (one of ours that was reported or recovered from, or the application's own): hipGetLastError()
+// behind a launch would otherwise blame this call for it (tools/oom_probe.py: a generator launch reported the out-of-memory
+// of a context creation that had failed — and had been reported — two calls before).
+static inline hipError_t dc3_set_device(int device) {
+  const hipError_t e = hipSetDevice(device);
+  (void)hipGetLastError();
+  return e;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Large device buffers by virtual-memory reserve + commit (round 6).  Device memory that a process has freed is wiped by
@@ -237,7 +247,7 @@ static size_t arena_reserve_bytes(int64_t n) {
 // hipMalloc'ed one is replaced and must be empty.
 static int ensure_arena(dc3hip_ctx *c, size_t need) {
   if (c->arena_bytes >= need || c->arena_fixed) return E_OK;
-  HIPC(hipSetDevice(c->device));            // (callers may be on a thread whose current device is another one)
+  HIPC(dc3_set_device(c->device));            // (callers may be on a thread whose current device is another one)
   if (c->arena_vm.va && c->arena == c->arena_vm.va && need <= c->arena_vm.reserved) {
     c->arena_bytes = need;                 // (the limit; memory is committed when the allocator gets there: arena_alloc)
     return E_OK;

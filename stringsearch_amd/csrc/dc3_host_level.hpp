@@ -461,7 +461,7 @@ static int build_begin(dc3hip_ctx *c) {
   c->stats.struct_size = (int32_t)sizeof(dc3hip_stats);
   c->stats.arena_bytes = (int64_t)c->arena_bytes;
   if (c->n < 0) return E_ARGS;
-  HIPC(hipSetDevice(c->device));
+  HIPC(dc3_set_device(c->device));
   for (int l = 0; l < DC3HIP_MAX_LEVELS; l++) c->stats.trace_names[l] = -1;
   if (c->trace) HIPC(hipMemsetAsync(c->d_trace, 0, 3 * DC3HIP_MAX_LEVELS * sizeof(u64), c->stream));
   HIPC(hipMemsetAsync(c->d_xcdmon, 0, 64 * sizeof(u32), c->stream));

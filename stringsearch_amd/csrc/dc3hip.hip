@@ -74,7 +74,7 @@ int32_t dc3hip_device_count(void) {
 }
 
 int32_t dc3hip_device_synchronize(int32_t device) {
-  if (device >= 0) HIPC(hipSetDevice(device));
+  if (device >= 0) HIPC(dc3_set_device(device));
   HIPC(hipDeviceSynchronize());
   return E_OK;
 }
@@ -135,7 +135,7 @@ static int ctx_create_impl(dc3hip_ctx **out, int32_t device, int64_t max_n, dc3h
   c->use_vm = use_vm;
   { long long v; if (dbg_num("vmm_min", &v)) c->vm_min = (size_t)std::max(1ll, v); }
   int rc = [&]() -> int {
-    HIPC(hipSetDevice(device));
+    HIPC(dc3_set_device(device));
     hipDeviceProp_t prop;
     HIPC(hipGetDeviceProperties(&prop, device));
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -243,7 +243,7 @@ static int ctx_check_n(dc3hip_ctx *c, int64_t n) {
 int32_t dc3hip_ctx_set_text(dc3hip_ctx *c, const uint8_t *T, int64_t n) {
   RC(ctx_check_n(c, n));
   if (!T && n > 0) { set_err("T is NULL"); return E_ARGS; }
-  HIPC(hipSetDevice(c->device));
+  HIPC(dc3_set_device(c->device));
   if (n > 0) HIPC(hipMemcpyAsync(c->d_text, T, (size_t)n, hipMemcpyDefault, c->stream));
   HIPC(hipMemsetAsync(c->d_text + n, 0, 64, c->stream));
   HIPC(hipStreamSynchronize(c->stream));
@@ -259,7 +259,7 @@ int32_t dc3hip_ctx_generate_at(dc3hip_ctx *c, int64_t n, uint64_t seed, int32_t 
   RC(ctx_check_n(c, n));
   if (offset < 0) { set_err("negative offset"); return E_ARGS; }
   if (kind < 0 || kind > 2) { set_err("unknown generator kind %d", kind); return E_ARGS; }
-  HIPC(hipSetDevice(c->device));
+  HIPC(dc3_set_device(c->device));
   if (n > 0) {
     hipLaunchKernelGGL(k_generate, dim3(grid_for(c, (u64)n / 8 + 1)), dim3(kBlock), 0, c->stream, c->d_text, (u64)n,
                        (u64)seed, (int)kind, (u64)offset);
@@ -280,7 +280,7 @@ int32_t dc3hip_ctx_get_sa_i32(dc3hip_ctx *c, int32_t *SA) {
   if (!c || (!SA && c->n > 0)) { set_err("invalid arguments"); return E_ARGS; }
   if (c->n > (int64_t)INT32_MAX) { set_err("text of %lld bytes needs 64-bit indices", (long long)c->n); return E_TOOBIG; }
   if (!c->built) { set_err("no suffix array built in this context"); return E_ARGS; }
-  HIPC(hipSetDevice(c->device));
+  HIPC(dc3_set_device(c->device));
   if (c->n > 0) HIPC(hipMemcpyAsync(SA, c->d_sa, (size_t)c->n * 4, hipMemcpyDefault, c->stream));
   HIPC(hipStreamSynchronize(c->stream));
   return E_OK;
@@ -289,7 +289,7 @@ int32_t dc3hip_ctx_get_sa_i32(dc3hip_ctx *c, int32_t *SA) {
 int32_t dc3hip_ctx_get_sa_i64(dc3hip_ctx *c, int64_t *SA) {
   if (!c || (!SA && c->n > 0)) { set_err("invalid arguments"); return E_ARGS; }
   if (!c->built) { set_err("no suffix array built in this context"); return E_ARGS; }
-  HIPC(hipSetDevice(c->device));
+  HIPC(dc3_set_device(c->device));
   if (c->n == 0) return E_OK;
   // widen on the device in arena-sized pieces, then copy
   c->arena_off = 0;
@@ -310,7 +310,7 @@ int32_t dc3hip_ctx_get_sa_i64(dc3hip_ctx *c, int64_t *SA) {
 
 int32_t dc3hip_ctx_get_text(dc3hip_ctx *c, uint8_t *T) {
   if (!c || (!T && c->n > 0)) { set_err("invalid arguments"); return E_ARGS; }
-  HIPC(hipSetDevice(c->device));
+  HIPC(dc3_set_device(c->device));
   if (c->n > 0) HIPC(hipMemcpyAsync(T, c->d_text, (size_t)c->n, hipMemcpyDefault, c->stream));
   HIPC(hipStreamSynchronize(c->stream));
   return E_OK;
@@ -325,7 +325,7 @@ static int ctx_sufcheck(dc3hip_ctx *c, const u32 *d_sa, int *code, const uint8_t
   if (!text) text = c->d_text;
   *code = 0;
   if (n == 0) return E_OK;
-  HIPC(hipSetDevice(c->device));
+  HIPC(dc3_set_device(c->device));
   c->arena_off = 0;
   const u32 n32 = (u32)n;
   int nb = 0; Chunking ck;
@@ -390,7 +390,7 @@ int32_t dc3hip_ctx_sufcheck(dc3hip_ctx *c) {
 int32_t dc3hip_ctx_sa_checksum(dc3hip_ctx *c, uint64_t *out) {
   if (!c || !out) { set_err("invalid arguments"); return E_ARGS; }
   if (!c->built) { set_err("no suffix array built in this context"); return E_ARGS; }
-  HIPC(hipSetDevice(c->device));
+  HIPC(dc3_set_device(c->device));
   u64 *acc = reinterpret_cast<u64 *>(c->d_words + 16);
   HIPC(hipMemsetAsync(acc, 0, sizeof(u64), c->stream));
   if (c->n > 0) {
@@ -405,7 +405,7 @@ int32_t dc3hip_ctx_sa_checksum(dc3hip_ctx *c, uint64_t *out) {
 
 int32_t dc3hip_ctx_set_sa_i32(dc3hip_ctx *c, const int32_t *SA) {
   if (!c || (!SA && c->n > 0)) { set_err("invalid arguments"); return E_ARGS; }
-  HIPC(hipSetDevice(c->device));
+  HIPC(dc3_set_device(c->device));
   if (c->n > 0) HIPC(hipMemcpyAsync(c->d_sa, SA, (size_t)c->n * 4, hipMemcpyDefault, c->stream));
   HIPC(hipStreamSynchronize(c->stream));
   c->built = true;
@@ -422,7 +422,7 @@ int32_t dc3hip_ctx_lcp_i32(dc3hip_ctx *c, int32_t *LCP) {
   if (n64 == 0) return E_OK;
   if (n64 > (int64_t)INT32_MAX) { set_err("LCP values of %lld bytes do not fit int32", (long long)n64); return E_TOOBIG; }
   const u32 n = (u32)n64;
-  HIPC(hipSetDevice(c->device));
+  HIPC(dc3_set_device(c->device));
   c->arena_off = 0;
   RC(ensure_arena(c, (size_t)n * 26 + ((size_t)64 << 20)));
   u32 *phi = nullptr, *plcp = nullptr;
@@ -462,7 +462,7 @@ int32_t dc3hip_ctx_bwt(dc3hip_ctx *c, uint8_t *U, int64_t *primary_index) {
   if (!c || !primary_index || (!U && c->n > 0)) { set_err("invalid arguments"); return E_ARGS; }   // utils.c:60
   if (!c->built) { set_err("no suffix array built in this context"); return E_ARGS; }
   const int64_t n = c->n;
-  HIPC(hipSetDevice(c->device));
+  HIPC(dc3_set_device(c->device));
   RC(ensure_trusted_sa(c));
   if (n <= 1) {                                                                                    // utils.c:61-65
     if (n == 1) HIPC(hipMemcpy(U, c->d_text, 1, hipMemcpyDefault));
@@ -495,7 +495,7 @@ int32_t dc3hip_ctx_search(dc3hip_ctx *c, const uint8_t *needles, const int64_t *
   if (!c->built) { set_err("no suffix array built in this context"); return E_ARGS; }
   if (c->n == 0) { set_err("empty suffix array (the reference indexes out of bounds here)"); return E_ARGS; }
   if (count == 0) return E_OK;
-  HIPC(hipSetDevice(c->device));
+  HIPC(dc3_set_device(c->device));
   // offsets is a HOST array of count+1 non-decreasing byte offsets into needles, offsets[0] >= 0
   for (int32_t k = 0; k < count; k++)
     if (offsets[k] < 0 || offsets[k + 1] < offsets[k]) { set_err("invalid needle offsets (must be non-negative and non-decreasing)"); return E_ARGS; }
@@ -526,7 +526,7 @@ int32_t dc3hip_ctx_build_partitions(dc3hip_ctx *c, int32_t num_partitions) {
   if (!c || num_partitions < 1) { set_err("invalid arguments"); return E_ARGS; }
   const int64_t n = c->n;
   if (n > (int64_t)INT32_MAX) { set_err("partitioned build of %lld bytes needs 64-bit indices", (long long)n); return E_TOOBIG; }
-  HIPC(hipSetDevice(c->device));
+  HIPC(dc3_set_device(c->device));
   const int64_t S = n / num_partitions + 1;
   if (S >= n) {                      // one partition: its array is the suffix array of the whole text
     RC(dc3hip_ctx_build(c));
@@ -561,7 +561,7 @@ int32_t dc3hip_ctx_search_partitioned(dc3hip_ctx *c, int32_t num_partitions, con
   if (c->n == 0) { set_err("empty text (the reference indexes out of bounds here)"); return E_ARGS; }
   if (c->n > (int64_t)INT32_MAX) { set_err("partitioned search of %lld bytes needs 64-bit indices", (long long)c->n); return E_TOOBIG; }
   if (count == 0) return E_OK;
-  HIPC(hipSetDevice(c->device));
+  HIPC(dc3_set_device(c->device));
   for (int32_t k = 0; k < count; k++)
     if (offsets[k] < 0 || offsets[k + 1] < offsets[k]) { set_err("invalid needle offsets (must be non-negative and non-decreasing)"); return E_ARGS; }
   const int64_t n = c->n, S = n / num_partitions + 1;
@@ -600,7 +600,7 @@ int32_t dc3hip_ctx_search_partitioned(dc3hip_ctx *c, int32_t num_partitions, con
 int32_t dc3hip_ctx_debug_radix_pass_u64(dc3hip_ctx *c, const uint64_t *words, uint64_t *out, int64_t n, int32_t shift,
                                         int32_t nb) {
   if (!c || !words || !out || n < 1 || shift < 0 || shift > 55 || (nb != 256 && nb != 512)) { set_err("invalid arguments"); return E_ARGS; }
-  HIPC(hipSetDevice(c->device));
+  HIPC(dc3_set_device(c->device));
   c->arena_off = 0;
   RC(ensure_arena(c, (size_t)n * 40 + ((size_t)64 << 20)));
   Rec8 *a = nullptr, *b = nullptr, *res = nullptr;

@@ -1314,6 +1314,38 @@ def test_one_radix_pass_equals_reference_radix_pass(ss, oracle, nb, shift):
             assert np.array_equal(out, words[want.astype(np.int64)])
 
 
+def test_an_error_left_in_the_runtime_by_an_earlier_call_is_not_blamed_on_this_one(ss, oracle):
+    """The HIP runtime keeps the last error of a thread until somebody reads it; the library reads it behind every kernel
+    launch (KCHECK).  An error the APPLICATION left behind with a call of its own (here: a hipMalloc of 2^60 bytes), or an
+    earlier library call that failed and was reported, must not make the next library call fail (round 6,
+    tools/oom_probe.py: a generator launch reported the out-of-memory of a context creation two calls before)."""
+    import ctypes
+    path = None
+    with open("/proc/self/maps") as f:
+        for line in f:
+            if "libamdhip64" in line:
+                path = line.split()[-1]; break
+    assert path, "the library is loaded, so the HIP runtime must be mapped"
+    hip = ctypes.CDLL(path)                                            # the SAME runtime instance (already loaded)
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    data = np.frombuffer(b"mississippi$abracadabra" * 4000, dtype=np.uint8)
+    want = oracle.sufsort(data)
+    with ss.Context(len(data)) as c:
+        for _ in range(2):
+            p = ctypes.c_void_p()
+            assert hip.hipMalloc(ctypes.byref(p), 1 << 60) != 0          # fails, and stays in the thread's error slot
+            c.set_text(data); c.build()
+            assert np.array_equal(c.sa(), want)
+            assert c.sufcheck() == 0
+        p = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(p), 1 << 60) != 0
+        c.generate(len(data), 3, 1); c.build()                           # the generator launch is the first thing behind the failure
+        assert c.sufcheck() == 0
+    p = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(p), 1 << 60) != 0
+    assert np.array_equal(ss.sort(data).into_parts()[1], want)         # the one-shot entry point
+
+
 def test_short_arena_falls_back_or_fails_loudly(ss, oracle):
     """ADVICE r1 (arena_requirement is not a bound for the whole-level order + general tie path): with the work arena
     cut down step by step (DC3HIP_ARENA_BYTES) a build must take a cheaper ordering and still return the exact suffix
