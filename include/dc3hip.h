@@ -24,6 +24,10 @@
  *     the largest n the thread has sorted (29-50 GB per 1 GiB of text: what its builds committed); it is dropped when a later call needs
  *     less than a quarter of it.  Partitioned use should go through dc3hip_sufsort_ex(num_partitions), which
  *     runs one worker per GPU, rather than through concurrent one-shot calls on one device.
+ *   - shared HIP runtime state: a call leaves the calling thread's CURRENT DEVICE at the device it worked on, and it reads
+ *     (clears) the thread's hipGetLastError() slot on entry — an error the application left there is dropped, not reported
+ *     as this call's.  Nothing else of the runtime is touched (own non-blocking stream; no device-wide synchronisation outside
+ *     dc3hip_device_synchronize; no hipDeviceReset).
  *   - there is NO CPU fallback: without a usable gfx950 device the calls fail with -3.
  *
  * Plain C, no torch / HIP types in any signature.
@@ -79,7 +83,9 @@ typedef struct dc3hip_opts {
                             suffix arrays back to back (chunk c at offset c*(n/P+1)), local indices */
   int32_t flags;         /* DC3HIP_F_* */
 } dc3hip_opts;
-#define DC3HIP_F_DEVICE_PTRS 1 /* T and SA are device pointers on `device` (no H2D/D2H) */
+#define DC3HIP_F_DEVICE_PTRS 1 /* T and SA are device pointers on `device` (no H2D/D2H).  The library works on a stream of its own
+                                  (non-blocking: NOT ordered behind the null stream): whatever produced T must have completed
+                                  before the call; SA is complete when the call returns */
 #define DC3HIP_F_ALL_DEVICES 2 /* num_partitions > 1, host pointers: the partitions are shared by all visible GPUs, one
                                   host worker thread per GPU (the rayon par_chunks of sacapart/src/lib.rs:45-49);
                                   `device` is ignored.  DC3HIP_WORKERS_PER_DEVICE=2 lets a GPU overlap one chunk's

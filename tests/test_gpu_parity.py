@@ -392,12 +392,14 @@ o = Oracle()
 data = o.gen(300007, 5, 2)
 t = torch.from_numpy(data).cuda(); sa = torch.zeros(len(data), dtype=torch.int32, device="cuda")
 opts = Opts(ctypes.sizeof(Opts), 32, 0, 0, 1)
+torch.cuda.synchronize()          # include/dc3hip.h: the library's stream is not ordered behind torch's (the zero fill is a kernel)
 rc = ss.lib().dc3hip_sufsort_ex(t.data_ptr(), sa.data_ptr(), len(data), ctypes.byref(opts))
 assert rc == 0, ss.last_error()
 torch.cuda.synchronize()
 assert np.array_equal(sa.cpu().numpy(), o.sufsort(data))
 sa64 = torch.zeros(len(data), dtype=torch.int64, device="cuda")
 opts = Opts(ctypes.sizeof(Opts), 64, 0, 0, 1)
+torch.cuda.synchronize()
 assert ss.lib().dc3hip_sufsort_ex(t.data_ptr(), sa64.data_ptr(), len(data), ctypes.byref(opts)) == 0
 assert np.array_equal(sa64.cpu().numpy(), o.sufsort(data).astype(np.int64))
 import __graft_entry__ as g
