@@ -28,6 +28,9 @@
  *     (clears) the thread's hipGetLastError() slot on entry — an error the application left there is dropped, not reported
  *     as this call's.  Nothing else of the runtime is touched (own non-blocking stream; no device-wide synchronisation outside
  *     dc3hip_device_synchronize; no hipDeviceReset).
+ *   - no C++ exception leaves the library (std::bad_alloc, a thread that cannot be started: -2 / -3 and a message; where a
+ *     helper thread is optional — partition workers, the page-touching threads of a one-shot call — the calling thread
+ *     does its work instead).
  *   - there is NO CPU fallback: without a usable gfx950 device the calls fail with -3.
  *
  * Plain C, no torch / HIP types in any signature.

@@ -81,7 +81,8 @@ static int gbuild(dc3hip_gctx *G) {
   memset(&G->gs, 0, sizeof(G->gs));
   const auto t0 = std::chrono::steady_clock::now();
   cm->device_enter();
-  const int rc = gbuild_inner(G);
+  int rc;
+  try { rc = gbuild_inner(G); } catch (...) { rc = abi_exception(); }      // (a rank thread: the other ranks must be released, below)
   if (rc == E_OK && G->c->stream) (void)hipStreamSynchronize(G->c->stream);     // (the rank's last kernels are its own work)
   cm->device_leave();
   if (rc != E_OK) { snprintf(G->err, sizeof(G->err), "%s", g_err); cm->abort_all(); cm->leave_failed(); return rc; }
@@ -130,7 +131,7 @@ extern "C" {
 
 // wide_ensure()'s growth rule (elements)
 static size_t wide_slack(size_t need) { return need + need / 16 + 1024; }
-int32_t dc3hip_global_plan(int64_t total_n, int32_t nranks, dc3hip_gplan *out) {
+int32_t dc3hip_global_plan(int64_t total_n, int32_t nranks, dc3hip_gplan *out) try {
   if (!out || total_n < 0 || nranks < 1 || nranks > kMaxRanks) { set_err("dc3hip_global_plan: invalid arguments (1 <= nranks <= %d)", kMaxRanks); return E_ARGS; }
   if (total_n > ((int64_t)1 << 40)) { set_err("n=%lld exceeds 2^40", (long long)total_n); return E_TOOBIG; }
   memset(out, 0, sizeof(*out));
@@ -167,9 +168,9 @@ int32_t dc3hip_global_plan(int64_t total_n, int32_t nranks, dc3hip_gplan *out) {
   out->big_group_bytes_per_member = 48;                                                       // wide_big_collect: two records, position, slot, group
   out->peak_bytes = out->text_bytes + out->context_bytes + out->arena_bytes + std::max(out->order_bytes, out->deepen_bytes);
   return E_OK;
-}
+} DC3_ABI_CATCH
 
-int32_t dc3hip_global_loopback_create(dc3hip_gctx **ranks, int32_t P, int32_t device, int64_t max_total_n) {
+int32_t dc3hip_global_loopback_create(dc3hip_gctx **ranks, int32_t P, int32_t device, int64_t max_total_n) try {
   if (!ranks || P < 1 || P > kMaxRanks || max_total_n < 0) { set_err("dc3hip_global_loopback_create: invalid arguments (1 <= P <= %d)", kMaxRanks); return E_ARGS; }
   for (int r = 0; r < P; r++) ranks[r] = nullptr;
   // device == DC3HIP_DEVICE_SPREAD: rank r on device r % (visible devices) — one process drives all GPUs of the node,
@@ -200,9 +201,9 @@ int32_t dc3hip_global_loopback_create(dc3hip_gctx **ranks, int32_t P, int32_t de
   world->token = world->one_device && dbg_on("global_device_token");
   for (int r = 0; r < P; r++) { ranks[r] = made[(size_t)r]; made[(size_t)r]->group = made; }
   return E_OK;
-}
+} DC3_ABI_CATCH
 
-int32_t dc3hip_rccl_unique_id(uint8_t *id128) {
+int32_t dc3hip_rccl_unique_id(uint8_t *id128) try {
   if (!id128) { set_err("id is NULL"); return E_ARGS; }
   std::lock_guard<std::mutex> lk(g_rccl_mu);
   if (!g_rccl.load()) return E_HIP;
@@ -211,9 +212,9 @@ int32_t dc3hip_rccl_unique_id(uint8_t *id128) {
   NCCLC(g_rccl.GetUniqueId(&id));
   memcpy(id128, &id, 128);
   return E_OK;
-}
+} DC3_ABI_CATCH
 
-int32_t dc3hip_rccl_library_path(char *buf, int32_t len, int32_t *was_already_mapped) {
+int32_t dc3hip_rccl_library_path(char *buf, int32_t len, int32_t *was_already_mapped) try {
   if (!buf || len < 2) { set_err("buffer is NULL or too short"); return E_ARGS; }
   std::lock_guard<std::mutex> lk(g_rccl_mu);
   if (!g_rccl.load()) return E_HIP;
@@ -222,10 +223,10 @@ int32_t dc3hip_rccl_library_path(char *buf, int32_t len, int32_t *was_already_ma
   snprintf(buf, (size_t)len, "%s", di.dli_fname);
   if (was_already_mapped) *was_already_mapped = g_rccl.preloaded ? 1 : 0;
   return E_OK;
-}
+} DC3_ABI_CATCH
 
 int32_t dc3hip_global_rccl_create(dc3hip_gctx **out, const uint8_t *id128, int32_t rank, int32_t nranks, int32_t device,
-                                  int64_t max_total_n) {
+                                  int64_t max_total_n) try {
   if (!out || !id128 || nranks < 1 || nranks > kMaxRanks || rank < 0 || rank >= nranks || max_total_n < 0) {
     set_err("dc3hip_global_rccl_create: invalid arguments (1 <= nranks <= %d)", kMaxRanks); return E_ARGS;
   }
@@ -248,10 +249,10 @@ int32_t dc3hip_global_rccl_create(dc3hip_gctx **out, const uint8_t *id128, int32
   gctx_env(G);
   *out = G;
   return E_OK;
-}
+} DC3_ABI_CATCH
 
 int32_t dc3hip_global_host_create(dc3hip_gctx **out, const dc3hip_host_transport *t, int32_t rank, int32_t nranks,
-                                  int32_t device, int64_t max_total_n) {
+                                  int32_t device, int64_t max_total_n) try {
   if (!out || !t || !t->all_to_all_v || !t->all_gather_v || nranks < 1 || nranks > kMaxRanks || rank < 0 || rank >= nranks ||
       max_total_n < 0) {
     set_err("dc3hip_global_host_create: invalid arguments (1 <= nranks <= %d)", kMaxRanks); return E_ARGS;
@@ -266,9 +267,9 @@ int32_t dc3hip_global_host_create(dc3hip_gctx **out, const dc3hip_host_transport
   gctx_env(G);
   *out = G;
   return E_OK;
-}
+} DC3_ABI_CATCH
 
-void dc3hip_global_destroy(dc3hip_gctx *G) {
+void dc3hip_global_destroy(dc3hip_gctx *G) try {
   if (!G) return;
   if (G->c) { (void)hipSetDevice(G->c->device); if (G->c->stream) (void)hipStreamSynchronize(G->c->stream); }
   delete G->comm;
@@ -285,7 +286,7 @@ void dc3hip_global_destroy(dc3hip_gctx *G) {
   if (G->w_aux2) (void)hipFree(G->w_aux2);
   if (G->c) dc3hip_ctx_destroy(G->c);
   delete G;
-}
+} DC3_ABI_CATCH_VOID
 
 static int gctx_set_total(dc3hip_gctx *G, int64_t total_n, int64_t *off, int64_t *len) {
   if (!G || total_n < 0) { set_err("invalid arguments"); return E_ARGS; }
@@ -295,13 +296,13 @@ static int gctx_set_total(dc3hip_gctx *G, int64_t total_n, int64_t *off, int64_t
   return E_OK;
 }
 
-int32_t dc3hip_global_block(dc3hip_gctx *G, int64_t total_n, int64_t *offset, int64_t *length) {
+int32_t dc3hip_global_block(dc3hip_gctx *G, int64_t total_n, int64_t *offset, int64_t *length) try {
   if (!G || !offset || !length || total_n < 0) { set_err("invalid arguments"); return E_ARGS; }
   block_of(total_n, G->comm->nranks, G->comm->rank, offset, length);
   return E_OK;
-}
+} DC3_ABI_CATCH
 
-int32_t dc3hip_global_set_text_block(dc3hip_gctx *G, const uint8_t *block, int64_t total_n) {
+int32_t dc3hip_global_set_text_block(dc3hip_gctx *G, const uint8_t *block, int64_t total_n) try {
   int64_t off, len;
   RC(gctx_set_total(G, total_n, &off, &len));
   if (!block && len > 0) { set_err("block is NULL"); return E_ARGS; }
@@ -311,9 +312,9 @@ int32_t dc3hip_global_set_text_block(dc3hip_gctx *G, const uint8_t *block, int64
   HIPC(hipStreamSynchronize(c->stream));
   G->text_set = true;
   return E_OK;
-}
+} DC3_ABI_CATCH
 
-int32_t dc3hip_global_generate(dc3hip_gctx *G, int64_t total_n, uint64_t seed, int32_t kind) {
+int32_t dc3hip_global_generate(dc3hip_gctx *G, int64_t total_n, uint64_t seed, int32_t kind) try {
   int64_t off, len;
   RC(gctx_set_total(G, total_n, &off, &len));
   if (kind < 0 || kind > 2) { set_err("unknown generator kind %d", kind); return E_ARGS; }
@@ -328,9 +329,9 @@ int32_t dc3hip_global_generate(dc3hip_gctx *G, int64_t total_n, uint64_t seed, i
   HIPC(hipStreamSynchronize(c->stream));
   G->text_set = true;
   return E_OK;
-}
+} DC3_ABI_CATCH
 
-int32_t dc3hip_global_build(dc3hip_gctx *G) { return gbuild(G); }
+int32_t dc3hip_global_build(dc3hip_gctx *G) try { return gbuild(G); } DC3_ABI_CATCH
 
 // loopback convenience: run the P ranks of a group on P host threads and wait for all of them.
 // The threads are PERSISTENT (one process-wide set, started on demand, never joined): a round-4 hunt found the host heap
@@ -358,7 +359,7 @@ struct LoopPool {
   void run(int P, const std::function<void(int)> &f) {
     std::lock_guard<std::mutex> one(run_mu);
     std::unique_lock<std::mutex> lk(mu);
-    while (started < P) { const int i = started++; std::thread([this, i] { worker(i); }).detach(); }
+    while (started < P) { const int i = started; std::thread([this, i] { worker(i); }).detach(); started++; }   // (may throw: no rank thread to be had)
     for (int r = 0; r < P; r++) { job[r] = [&f, r] { f(r); }; has[r] = true; }
     pending = P;
     cv_work.notify_all();
@@ -367,7 +368,7 @@ struct LoopPool {
 };
 static LoopPool *loop_pool() { static LoopPool *p = new LoopPool(); return p; }       // (leaked on purpose: its threads never exit)
 
-int32_t dc3hip_global_loopback_build(dc3hip_gctx **ranks, int32_t P) {
+int32_t dc3hip_global_loopback_build(dc3hip_gctx **ranks, int32_t P) try {
   if (!ranks || P < 1 || P > kMaxRanks) { set_err("invalid arguments"); return E_ARGS; }
   for (int r = 0; r < P; r++) if (!ranks[r] || ranks[r]->comm->nranks != P) { set_err("not a loopback group of %d ranks", P); return E_ARGS; }
   ranks[0]->comm->reset_all();         // a failure of an earlier build no longer poisons the group
@@ -377,16 +378,16 @@ int32_t dc3hip_global_loopback_build(dc3hip_gctx **ranks, int32_t P) {
     if (rcs[(size_t)r] != E_OK && strstr(ranks[r]->err, "another rank failed") == nullptr) { set_err("rank %d: %s", r, ranks[r]->err); return rcs[(size_t)r]; }
   for (int r = 0; r < P; r++) if (rcs[(size_t)r] != E_OK) { set_err("rank %d: %s", r, ranks[r]->err); return rcs[(size_t)r]; }
   return E_OK;
-}
+} DC3_ABI_CATCH
 
-int32_t dc3hip_global_shard(dc3hip_gctx *G, int64_t *first, int64_t *count) {
+int32_t dc3hip_global_shard(dc3hip_gctx *G, int64_t *first, int64_t *count) try {
   if (!G || !first || !count) { set_err("invalid arguments"); return E_ARGS; }
   if (!G->built) { set_err("no suffix array built in this global context"); return E_ARGS; }
   *first = G->shard_first; *count = G->shard_count;
   return E_OK;
-}
+} DC3_ABI_CATCH
 
-int32_t dc3hip_global_get_shard_i64(dc3hip_gctx *G, int64_t *out) {
+int32_t dc3hip_global_get_shard_i64(dc3hip_gctx *G, int64_t *out) try {
   if (!G || (!out && G->shard_count > 0)) { set_err("invalid arguments"); return E_ARGS; }
   if (!G->built) { set_err("no suffix array built in this global context"); return E_ARGS; }
   dc3hip_ctx *c = G->c;
@@ -408,9 +409,9 @@ int32_t dc3hip_global_get_shard_i64(dc3hip_gctx *G, int64_t *out) {
     HIPC(hipStreamSynchronize(c->stream));
   }
   return E_OK;
-}
+} DC3_ABI_CATCH
 
-int32_t dc3hip_global_get_shard_u32(dc3hip_gctx *G, uint32_t *out) {
+int32_t dc3hip_global_get_shard_u32(dc3hip_gctx *G, uint32_t *out) try {
   if (!G || (!out && G->shard_count > 0)) { set_err("invalid arguments"); return E_ARGS; }
   if (!G->built) { set_err("no suffix array built in this global context"); return E_ARGS; }
   dc3hip_ctx *c = G->c;
@@ -419,11 +420,11 @@ int32_t dc3hip_global_get_shard_u32(dc3hip_gctx *G, uint32_t *out) {
   if (G->shard_count > 0) HIPC(hipMemcpyAsync(out, G->shard_ptr, (size_t)G->shard_count * 4, hipMemcpyDefault, c->stream));
   HIPC(hipStreamSynchronize(c->stream));
   return E_OK;
-}
+} DC3_ABI_CATCH
 
 // order-sensitive checksum of this rank's shard with GLOBAL indices: the sum over all ranks equals
 // dc3hip_ctx_sa_checksum of a single-device build of the same text
-int32_t dc3hip_global_shard_checksum(dc3hip_gctx *G, uint64_t *out) {
+int32_t dc3hip_global_shard_checksum(dc3hip_gctx *G, uint64_t *out) try {
   if (!G || !out) { set_err("invalid arguments"); return E_ARGS; }
   if (!G->built) { set_err("no suffix array built in this global context"); return E_ARGS; }
   dc3hip_ctx *c = G->c;
@@ -443,21 +444,21 @@ int32_t dc3hip_global_shard_checksum(dc3hip_gctx *G, uint64_t *out) {
   HIPC(hipStreamSynchronize(c->stream));
   memcpy(out, c->h_words + 16, sizeof(u64));
   return E_OK;
-}
+} DC3_ABI_CATCH
 
-int32_t dc3hip_global_stats(dc3hip_gctx *G, dc3hip_gstats *out, dc3hip_stats *ctx_stats) {
+int32_t dc3hip_global_stats(dc3hip_gctx *G, dc3hip_gstats *out, dc3hip_stats *ctx_stats) try {
   if (!G || !out) { set_err("invalid arguments"); return E_ARGS; }
   *out = G->gs;
   out->struct_size = (int32_t)sizeof(dc3hip_gstats);
   if (ctx_stats) { *ctx_stats = G->c->stats; ctx_stats->struct_size = (int32_t)sizeof(dc3hip_stats); }
   return E_OK;
-}
+} DC3_ABI_CATCH
 
 // Collective check of a wide-mode result (every rank calls it): positions in range, every shard entry's suffix strictly
 // smaller than its successor's — across the rank boundaries too — and the shard sizes add up to n.  Returns 0 when the
 // concatenated shards are the suffix array, else the reference sufcheck's codes (-2 range, -3 order), the same on all
 // ranks; < -10 = the check itself failed (dc3hip error code - 10).
-int32_t dc3hip_global_sufcheck(dc3hip_gctx *G) {
+int32_t dc3hip_global_sufcheck(dc3hip_gctx *G) try {
   if (!G || !G->comm) { set_err("invalid arguments"); return E_ARGS - 10; }
   if (!G->built) { set_err("no suffix array built in this global context"); return E_ARGS - 10; }
   if (!G->wide) { set_err("dc3hip_global_sufcheck: only for contexts with 64-bit positions (fetch the shards and use dc3hip_ctx_sufcheck)"); return E_ARGS - 10; }
@@ -532,7 +533,7 @@ int32_t dc3hip_global_sufcheck(dc3hip_gctx *G) {
   const int rc = run();
   if (rc != E_OK) { snprintf(G->err, sizeof(G->err), "%s", g_err); cm->abort_all(); cm->leave_failed(); return rc - 10; }
   return verdict;
-}
+} DC3_ABI_CATCH_GLOBAL_SUFCHECK
 
 const char *dc3hip_global_last_error(dc3hip_gctx *G) { return G ? G->err : ""; }
 // Transport self-test (a COLLECTIVE): a ragged all_to_all_v, a ragged all_gather_v and a host all-gather of known bytes
@@ -602,13 +603,13 @@ static int gselftest(dc3hip_gctx *G) {
     if (all[r] != 0x5eed000000000000ull + (uint64_t)r * 1000003ull) { set_err("transport self-test: all_gather_host delivered a wrong word for rank %d", r); return E_HIP; }
   return E_OK;
 }
-int32_t dc3hip_global_selftest(dc3hip_gctx *G, int32_t *transport_ranks) {
+int32_t dc3hip_global_selftest(dc3hip_gctx *G, int32_t *transport_ranks) try {
   if (!G || !G->c || !G->comm) { set_err("invalid global context"); return E_ARGS; }
   if (transport_ranks) *transport_ranks = G->comm->transport_ranks();
   const int rc = gselftest(G);
   if (rc != E_OK) { snprintf(G->err, sizeof(G->err), "%s", g_err); G->comm->abort_all(); G->comm->leave_failed(); }
   return rc;
-}
+} DC3_ABI_CATCH
 const char *dc3hip_global_transport(dc3hip_gctx *G) { return (G && G->comm) ? G->comm->name() : ""; }
 
 }  // extern "C"

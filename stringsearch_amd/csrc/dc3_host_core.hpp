@@ -10,6 +10,20 @@ static void set_err(const char *fmt, ...) {
   va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
 }
 enum { E_OK = 0, E_ARGS = -1, E_ALLOC = -2, E_HIP = -3, E_TOOBIG = -4 };
+// No C++ exception leaves the C ABI: every exported function is a function-try-block that ends in one of these.  The library
+// throws nothing itself; what can arrive is the standard library's (std::bad_alloc of a host container, std::system_error of a
+// thread that cannot be started in a container with a process limit).  Device buffers of the failed call may stay allocated
+// until their context is destroyed.
+static int abi_exception() {
+  try { throw; }
+  catch (const std::bad_alloc &) { set_err("host allocation failed (std::bad_alloc)"); return E_ALLOC; }
+  catch (const std::exception &e) { set_err("C++ exception inside the library: %s", e.what()); return E_HIP; }
+  catch (...) { set_err("unknown C++ exception inside the library"); return E_HIP; }
+}
+#define DC3_ABI_CATCH catch (...) { return abi_exception(); }
+#define DC3_ABI_CATCH_SUFCHECK catch (...) { return abi_exception() == E_ALLOC ? -5 : -6; }        /* dc3hip_sufcheck_*: outside -1..-4 */
+#define DC3_ABI_CATCH_GLOBAL_SUFCHECK catch (...) { return abi_exception() - 10; }
+#define DC3_ABI_CATCH_VOID catch (...) { (void)abi_exception(); }
 
 // hipFuncSetAttribute is reached by several host threads at once (the loopback ranks' first build, sacapart's workers, each
 // behind its own "already set" flag): one at a time — a round-4 soak died twice, seconds into the process, with a corrupted

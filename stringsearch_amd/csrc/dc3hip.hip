@@ -49,13 +49,13 @@ extern "C" {
 const char *dc3hip_version(void) { return DC3HIP_VERSION_STR; }
 const char *dc3hip_last_error(void) { return g_err; }
 
-int32_t dc3hip_hip_versions(int32_t *compiled, int32_t *runtime) {
+int32_t dc3hip_hip_versions(int32_t *compiled, int32_t *runtime) try {
   int rt = 0;
   if (hipRuntimeGetVersion(&rt) != hipSuccess) { (void)hipGetLastError(); set_err("hipRuntimeGetVersion failed"); return E_HIP; }
   if (compiled) *compiled = (int32_t)HIP_VERSION;
   if (runtime) *runtime = rt;
   return (HIP_VERSION / 100000) == (rt / 100000) ? 1 : 0;
-}
+} DC3_ABI_CATCH
 // once per process, from the first context: a runtime other than the one the library was compiled against is legal
 // (same soname) but nothing this library's tests ran on; say so where a crash report would be read
 static void warn_runtime_mismatch_once() {
@@ -67,29 +67,29 @@ static void warn_runtime_mismatch_once() {
                  ct / 10000000, ct / 100000 % 100, ct % 100000, rt / 10000000, rt / 100000 % 100, rt % 100000);
 }
 
-int32_t dc3hip_device_count(void) {
+int32_t dc3hip_device_count(void) try {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) { set_err("hipGetDeviceCount failed"); return E_HIP; }
   return n;
-}
+} DC3_ABI_CATCH
 
-int32_t dc3hip_device_synchronize(int32_t device) {
+int32_t dc3hip_device_synchronize(int32_t device) try {
   if (device >= 0) HIPC(dc3_set_device(device));
   HIPC(hipDeviceSynchronize());
   return E_OK;
-}
+} DC3_ABI_CATCH
 
-int32_t dc3hip_device_info(int32_t device, char *arch, int32_t arch_len, int32_t *compute_units) {
+int32_t dc3hip_device_info(int32_t device, char *arch, int32_t arch_len, int32_t *compute_units) try {
   if (device < 0) HIPC(hipGetDevice(&device));
   hipDeviceProp_t prop;
   HIPC(hipGetDeviceProperties(&prop, device));
   if (arch && arch_len > 0) { std::strncpy(arch, prop.gcnArchName, (size_t)arch_len - 1); arch[arch_len - 1] = 0; }
   if (compute_units) *compute_units = prop.multiProcessorCount;
   return E_OK;
-}
+} DC3_ABI_CATCH
 
 static int ctx_create_impl(dc3hip_ctx **out, int32_t device, int64_t max_n, dc3hip_ctx *arena_from, bool use_vm = true);
-int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) { return ctx_create_impl(out, device, max_n, nullptr); }
+int32_t dc3hip_ctx_create(dc3hip_ctx **out, int32_t device, int64_t max_n) try { return ctx_create_impl(out, device, max_n, nullptr); } DC3_ABI_CATCH
 // one device buffer of a context: reserved + committed (DevBuf) from vm_min bytes on, else hipMalloc
 static int ctx_big_alloc(dc3hip_ctx *c, DevBuf *vm, size_t bytes, void **out) {
   if (c->use_vm && bytes >= c->vm_min && devbuf_reserve(vm, c->device, bytes)) {
@@ -213,7 +213,7 @@ static int ctx_create_impl(dc3hip_ctx **out, int32_t device, int64_t max_n, dc3h
   return E_OK;
 }
 
-void dc3hip_ctx_destroy(dc3hip_ctx *c) {
+void dc3hip_ctx_destroy(dc3hip_ctx *c) try {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -232,7 +232,7 @@ void dc3hip_ctx_destroy(dc3hip_ctx *c) {
   pinned_pool()->give(c->h_stage, c->h_stage_bytes);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
-}
+} DC3_ABI_CATCH_VOID
 
 static int ctx_check_n(dc3hip_ctx *c, int64_t n) {
   if (!c || n < 0) { set_err("invalid arguments"); return E_ARGS; }
@@ -240,7 +240,7 @@ static int ctx_check_n(dc3hip_ctx *c, int64_t n) {
   return E_OK;
 }
 
-int32_t dc3hip_ctx_set_text(dc3hip_ctx *c, const uint8_t *T, int64_t n) {
+int32_t dc3hip_ctx_set_text(dc3hip_ctx *c, const uint8_t *T, int64_t n) try {
   RC(ctx_check_n(c, n));
   if (!T && n > 0) { set_err("T is NULL"); return E_ARGS; }
   HIPC(dc3_set_device(c->device));
@@ -249,13 +249,13 @@ int32_t dc3hip_ctx_set_text(dc3hip_ctx *c, const uint8_t *T, int64_t n) {
   HIPC(hipStreamSynchronize(c->stream));
   c->n = n; c->built = false;
   return E_OK;
-}
+} DC3_ABI_CATCH
 
-int32_t dc3hip_ctx_generate(dc3hip_ctx *c, int64_t n, uint64_t seed, int32_t kind) {
+int32_t dc3hip_ctx_generate(dc3hip_ctx *c, int64_t n, uint64_t seed, int32_t kind) try {
   return dc3hip_ctx_generate_at(c, n, seed, kind, 0);
-}
+} DC3_ABI_CATCH
 
-int32_t dc3hip_ctx_generate_at(dc3hip_ctx *c, int64_t n, uint64_t seed, int32_t kind, int64_t offset) {
+int32_t dc3hip_ctx_generate_at(dc3hip_ctx *c, int64_t n, uint64_t seed, int32_t kind, int64_t offset) try {
   RC(ctx_check_n(c, n));
   if (offset < 0) { set_err("negative offset"); return E_ARGS; }
   if (kind < 0 || kind > 2) { set_err("unknown generator kind %d", kind); return E_ARGS; }
@@ -269,14 +269,14 @@ int32_t dc3hip_ctx_generate_at(dc3hip_ctx *c, int64_t n, uint64_t seed, int32_t 
   HIPC(hipStreamSynchronize(c->stream));
   c->n = n; c->built = false;
   return E_OK;
-}
+} DC3_ABI_CATCH
 
-int32_t dc3hip_ctx_build(dc3hip_ctx *c) {
+int32_t dc3hip_ctx_build(dc3hip_ctx *c) try {
   if (!c) { set_err("ctx is NULL"); return E_ARGS; }
   return ctx_build(c);
-}
+} DC3_ABI_CATCH
 
-int32_t dc3hip_ctx_get_sa_i32(dc3hip_ctx *c, int32_t *SA) {
+int32_t dc3hip_ctx_get_sa_i32(dc3hip_ctx *c, int32_t *SA) try {
   if (!c || (!SA && c->n > 0)) { set_err("invalid arguments"); return E_ARGS; }
   if (c->n > (int64_t)INT32_MAX) { set_err("text of %lld bytes needs 64-bit indices", (long long)c->n); return E_TOOBIG; }
   if (!c->built) { set_err("no suffix array built in this context"); return E_ARGS; }
@@ -284,9 +284,9 @@ int32_t dc3hip_ctx_get_sa_i32(dc3hip_ctx *c, int32_t *SA) {
   if (c->n > 0) HIPC(hipMemcpyAsync(SA, c->d_sa, (size_t)c->n * 4, hipMemcpyDefault, c->stream));
   HIPC(hipStreamSynchronize(c->stream));
   return E_OK;
-}
+} DC3_ABI_CATCH
 
-int32_t dc3hip_ctx_get_sa_i64(dc3hip_ctx *c, int64_t *SA) {
+int32_t dc3hip_ctx_get_sa_i64(dc3hip_ctx *c, int64_t *SA) try {
   if (!c || (!SA && c->n > 0)) { set_err("invalid arguments"); return E_ARGS; }
   if (!c->built) { set_err("no suffix array built in this context"); return E_ARGS; }
   HIPC(dc3_set_device(c->device));
@@ -306,15 +306,15 @@ int32_t dc3hip_ctx_get_sa_i64(dc3hip_ctx *c, int64_t *SA) {
     HIPC(hipStreamSynchronize(c->stream));
   }
   return E_OK;
-}
+} DC3_ABI_CATCH
 
-int32_t dc3hip_ctx_get_text(dc3hip_ctx *c, uint8_t *T) {
+int32_t dc3hip_ctx_get_text(dc3hip_ctx *c, uint8_t *T) try {
   if (!c || (!T && c->n > 0)) { set_err("invalid arguments"); return E_ARGS; }
   HIPC(dc3_set_device(c->device));
   if (c->n > 0) HIPC(hipMemcpyAsync(T, c->d_text, (size_t)c->n, hipMemcpyDefault, c->stream));
   HIPC(hipStreamSynchronize(c->stream));
   return E_OK;
-}
+} DC3_ABI_CATCH
 
 // Runs the check; *code receives sufcheck()'s result (0, -2, -3, -4); the return value is the
 // library status (E_OK / E_ALLOC / E_HIP), kept apart because the two code spaces overlap.
@@ -378,16 +378,16 @@ static int ensure_trusted_sa(dc3hip_ctx *c) {
   return E_OK;
 }
 
-int32_t dc3hip_ctx_sufcheck(dc3hip_ctx *c) {
+int32_t dc3hip_ctx_sufcheck(dc3hip_ctx *c) try {
   if (!c) { set_err("ctx is NULL"); return E_ARGS; }
   if (!c->built) { set_err("no suffix array built in this context"); return E_ARGS; }
   int code = 0;
   const int rc = ctx_sufcheck(c, c->d_sa, &code);
   if (rc != E_OK) return rc == E_ALLOC ? -5 : -6;   // library failure, distinct from sufcheck's -1..-4
   return code;
-}
+} DC3_ABI_CATCH_SUFCHECK
 
-int32_t dc3hip_ctx_sa_checksum(dc3hip_ctx *c, uint64_t *out) {
+int32_t dc3hip_ctx_sa_checksum(dc3hip_ctx *c, uint64_t *out) try {
   if (!c || !out) { set_err("invalid arguments"); return E_ARGS; }
   if (!c->built) { set_err("no suffix array built in this context"); return E_ARGS; }
   HIPC(dc3_set_device(c->device));
@@ -401,9 +401,9 @@ int32_t dc3hip_ctx_sa_checksum(dc3hip_ctx *c, uint64_t *out) {
   HIPC(hipStreamSynchronize(c->stream));
   memcpy(out, c->h_words + 16, sizeof(u64));
   return E_OK;
-}
+} DC3_ABI_CATCH
 
-int32_t dc3hip_ctx_set_sa_i32(dc3hip_ctx *c, const int32_t *SA) {
+int32_t dc3hip_ctx_set_sa_i32(dc3hip_ctx *c, const int32_t *SA) try {
   if (!c || (!SA && c->n > 0)) { set_err("invalid arguments"); return E_ARGS; }
   HIPC(dc3_set_device(c->device));
   if (c->n > 0) HIPC(hipMemcpyAsync(c->d_sa, SA, (size_t)c->n * 4, hipMemcpyDefault, c->stream));
@@ -412,10 +412,10 @@ int32_t dc3hip_ctx_set_sa_i32(dc3hip_ctx *c, const int32_t *SA) {
   c->sa_trusted = false;
   c->parts_trusted = 0;
   return E_OK;
-}
+} DC3_ABI_CATCH
 
 // LCP array of the resident SA (kernels and method: dc3_aux.hip.hpp).  LCP may be a host or a device pointer (n x int32).
-int32_t dc3hip_ctx_lcp_i32(dc3hip_ctx *c, int32_t *LCP) {
+int32_t dc3hip_ctx_lcp_i32(dc3hip_ctx *c, int32_t *LCP) try {
   if (!c || (!LCP && c->n > 0)) { set_err("invalid arguments"); return E_ARGS; }
   if (!c->built) { set_err("no suffix array built in this context"); return E_ARGS; }
   const int64_t n64 = c->n;
@@ -456,9 +456,9 @@ int32_t dc3hip_ctx_lcp_i32(dc3hip_ctx *c, int32_t *LCP) {
   HIPC(hipStreamSynchronize(c->stream));
   c->arena_off = 0;
   return E_OK;
-}
+} DC3_ABI_CATCH
 
-int32_t dc3hip_ctx_bwt(dc3hip_ctx *c, uint8_t *U, int64_t *primary_index) {
+int32_t dc3hip_ctx_bwt(dc3hip_ctx *c, uint8_t *U, int64_t *primary_index) try {
   if (!c || !primary_index || (!U && c->n > 0)) { set_err("invalid arguments"); return E_ARGS; }   // utils.c:60
   if (!c->built) { set_err("no suffix array built in this context"); return E_ARGS; }
   const int64_t n = c->n;
@@ -485,10 +485,10 @@ int32_t dc3hip_ctx_bwt(dc3hip_ctx *c, uint8_t *U, int64_t *primary_index) {
   *primary_index = (int64_t)c->h_words[24] + 1;                                                    // utils.c:97
   c->arena_off = 0;
   return E_OK;
-}
+} DC3_ABI_CATCH
 
 int32_t dc3hip_ctx_search(dc3hip_ctx *c, const uint8_t *needles, const int64_t *offsets, int32_t count,
-                          int64_t *out_start, int64_t *out_len) {
+                          int64_t *out_start, int64_t *out_len) try {
   if (!c || count < 0 || (count > 0 && (!needles || !offsets || !out_start || !out_len))) {
     set_err("invalid arguments"); return E_ARGS;
   }
@@ -518,11 +518,11 @@ int32_t dc3hip_ctx_search(dc3hip_ctx *c, const uint8_t *needles, const int64_t *
   HIPC(hipStreamSynchronize(c->stream));
   c->arena_off = 0;
   return E_OK;
-}
+} DC3_ABI_CATCH
 
 // Partition arrays (sacapart semantics) in the resident SA buffer: chunk c = text[c*S .. min(n,(c+1)*S)), S = n/P + 1
 // (crates/sacapart/src/lib.rs:43-46), local indices, back to back — built here chunk by chunk on the device.
-int32_t dc3hip_ctx_build_partitions(dc3hip_ctx *c, int32_t num_partitions) {
+int32_t dc3hip_ctx_build_partitions(dc3hip_ctx *c, int32_t num_partitions) try {
   if (!c || num_partitions < 1) { set_err("invalid arguments"); return E_ARGS; }
   const int64_t n = c->n;
   if (n > (int64_t)INT32_MAX) { set_err("partitioned build of %lld bytes needs 64-bit indices", (long long)n); return E_TOOBIG; }
@@ -550,10 +550,10 @@ int32_t dc3hip_ctx_build_partitions(dc3hip_ctx *c, int32_t num_partitions) {
   if (rc != E_OK) return rc;
   c->built = true; c->sa_trusted = false; c->parts_trusted = num_partitions;
   return E_OK;
-}
+} DC3_ABI_CATCH
 
 int32_t dc3hip_ctx_search_partitioned(dc3hip_ctx *c, int32_t num_partitions, const uint8_t *needles, const int64_t *offsets,
-                                      int32_t count, int64_t *out_start, int64_t *out_len) {
+                                      int32_t count, int64_t *out_start, int64_t *out_len) try {
   if (!c || num_partitions < 1 || count < 0 || (count > 0 && (!needles || !offsets || !out_start || !out_len))) {
     set_err("invalid arguments"); return E_ARGS;
   }
@@ -593,12 +593,12 @@ int32_t dc3hip_ctx_search_partitioned(dc3hip_ctx *c, int32_t num_partitions, con
   HIPC(hipStreamSynchronize(c->stream));
   c->arena_off = 0;
   return E_OK;
-}
+} DC3_ABI_CATCH
 
 // Test hook for kernel-level parity (the reference's radix_pass, crates/dc3/src/lib.rs:15-39): ONE stable pass of
 // the product's radix scatter (up-sweep, scan, down-sweep) over n host words, digit = (word >> shift) & (nb - 1).
 int32_t dc3hip_ctx_debug_radix_pass_u64(dc3hip_ctx *c, const uint64_t *words, uint64_t *out, int64_t n, int32_t shift,
-                                        int32_t nb) {
+                                        int32_t nb) try {
   if (!c || !words || !out || n < 1 || shift < 0 || shift > 55 || (nb != 256 && nb != 512)) { set_err("invalid arguments"); return E_ARGS; }
   HIPC(dc3_set_device(c->device));
   c->arena_off = 0;
@@ -621,14 +621,14 @@ int32_t dc3hip_ctx_debug_radix_pass_u64(dc3hip_ctx *c, const uint64_t *words, ui
   for (int64_t i = 0; i < n; i++) out[i] = ((uint64_t)h[(size_t)i].key << 32) | h[(size_t)i].val;
   c->arena_off = 0;
   return E_OK;
-}
+} DC3_ABI_CATCH
 
-int32_t dc3hip_ctx_stats(dc3hip_ctx *c, dc3hip_stats *out) {
+int32_t dc3hip_ctx_stats(dc3hip_ctx *c, dc3hip_stats *out) try {
   if (!c || !out) { set_err("invalid arguments"); return E_ARGS; }
   *out = c->stats;
   out->struct_size = (int32_t)sizeof(dc3hip_stats);
   return E_OK;
-}
+} DC3_ABI_CATCH
 
 // ---- one-shot entry points -------------------------------------------------------------------
 
@@ -748,7 +748,7 @@ static int sufsort_one(const uint8_t *T, void *SA, int64_t n, int bits, int devi
   return rc;
 }
 
-int32_t dc3hip_sufsort_ex(const uint8_t *T, void *SA, int64_t n, const dc3hip_opts *o) {
+int32_t dc3hip_sufsort_ex(const uint8_t *T, void *SA, int64_t n, const dc3hip_opts *o) try {
   dc3hip_opts d; memset(&d, 0, sizeof(d)); d.index_bits = 32; d.device = -1;
   if (o) {
     if (o->struct_size != (int32_t)sizeof(dc3hip_opts)) { set_err("dc3hip_opts.struct_size mismatch"); return E_ARGS; }
@@ -788,9 +788,8 @@ int32_t dc3hip_sufsort_ex(const uint8_t *T, void *SA, int64_t n, const dc3hip_op
   // w, w+W, ... on device w % ndev with its own context and stream; no data is exchanged between partitions.
   std::vector<int> rcs((size_t)workers, E_OK);
   std::vector<std::string> msgs((size_t)workers);
-  std::vector<std::thread> pool;
-  for (int w = 0; w < workers; w++) {
-    pool.emplace_back([&, w]() {
+  auto work = [&](int w) {
+    try {
       const int dev = w % ndev;
       for (int64_t part = w; part < nparts; part += workers) {
         const int64_t off = part * S, len = std::min(S, n - off);
@@ -798,32 +797,42 @@ int32_t dc3hip_sufsort_ex(const uint8_t *T, void *SA, int64_t n, const dc3hip_op
                                    false);
         if (rc != E_OK) { rcs[(size_t)w] = rc; msgs[(size_t)w] = dc3hip_last_error(); break; }
       }
-      dc3hip_release_cache();            // the worker thread ends here: give its arena back now
-    });
-  }
-  for (auto &t : pool) t.join();
+    } catch (...) { rcs[(size_t)w] = abi_exception(); try { msgs[(size_t)w] = dc3hip_last_error(); } catch (...) {} }
+    dc3hip_release_cache();            // the worker thread ends here: give its arena back now
+  };
+  struct Pool {                        // (joined on every way out: a joinable std::thread must not be destroyed)
+    std::vector<std::thread> th;
+    ~Pool() { for (auto &t : th) if (t.joinable()) t.join(); }
+  } pool;
+  int started = 0;
+  try {
+    pool.th.reserve((size_t)workers);
+    for (int w = 0; w < workers; w++) { pool.th.emplace_back(work, w); started++; }
+  } catch (...) {}                     // (a container's process limit: the calling thread takes the chunks of the workers it could not start)
+  for (int w = started; w < workers; w++) work(w);
+  for (auto &t : pool.th) t.join();
   for (int w = 0; w < workers; w++)
     if (rcs[(size_t)w] != E_OK) { set_err("partition worker %d: %s", w, msgs[(size_t)w].c_str()); return rcs[(size_t)w]; }
   return E_OK;
-}
+} DC3_ABI_CATCH
 
-int32_t dc3hip_sufsort_i32(const uint8_t *T, int32_t *SA, int32_t n) {
+int32_t dc3hip_sufsort_i32(const uint8_t *T, int32_t *SA, int32_t n) try {
   return dc3hip_sufsort_ex(T, SA, (int64_t)n, nullptr);
-}
+} DC3_ABI_CATCH
 
-int32_t dc3hip_sufsort_i64(const uint8_t *T, int64_t *SA, int64_t n) {
+int32_t dc3hip_sufsort_i64(const uint8_t *T, int64_t *SA, int64_t n) try {
   dc3hip_opts o; memset(&o, 0, sizeof(o));
   o.struct_size = (int32_t)sizeof(o); o.index_bits = 64; o.device = -1;
   return dc3hip_sufsort_ex(T, SA, n, &o);
-}
+} DC3_ABI_CATCH
 
-void dc3hip_release_cache(void) {
+void dc3hip_release_cache(void) try {
   if (g_cache.c) { dc3hip_ctx_destroy(g_cache.c); g_cache.c = nullptr; }
-}
+} DC3_ABI_CATCH_VOID
 
 // divbwt(T, U, A, n) (divsufsort.c:372-405): returns the primary index, -1 / -2 on error; A is an
 // optional temporary in the reference and unused here.
-int32_t dc3hip_divbwt_i32(const uint8_t *T, uint8_t *U, int32_t *A, int32_t n) {
+int32_t dc3hip_divbwt_i32(const uint8_t *T, uint8_t *U, int32_t *A, int32_t n) try {
   (void)A;
   if (T == nullptr || U == nullptr || n < 0) { set_err("invalid arguments"); return -1; }
   if (n <= 1) { if (n == 1) U[0] = T[0]; return n; }
@@ -840,9 +849,9 @@ int32_t dc3hip_divbwt_i32(const uint8_t *T, uint8_t *U, int32_t *A, int32_t n) {
   dc3hip_ctx_destroy(c);
   if (rc != E_OK) return rc;
   return (int32_t)pidx;
-}
+} DC3_ABI_CATCH
 
-int32_t dc3hip_sufcheck_i32(const uint8_t *T, const int32_t *SA, int32_t n) {
+int32_t dc3hip_sufcheck_i32(const uint8_t *T, const int32_t *SA, int32_t n) try {
   if (T == nullptr || SA == nullptr || n < 0) { set_err("invalid arguments"); return -1; }  // utils.c:169-172
   if (n == 0) return 0;
   dc3hip_ctx *c = nullptr;
@@ -859,7 +868,7 @@ int32_t dc3hip_sufcheck_i32(const uint8_t *T, const int32_t *SA, int32_t n) {
   dc3hip_ctx_destroy(c);
   if (rc != E_OK) return rc == E_ALLOC ? -5 : -6;
   return code;
-}
+} DC3_ABI_CATCH_SUFCHECK
 
 }  // extern "C"
 

@@ -1348,6 +1348,21 @@ def test_an_error_left_in_the_runtime_by_an_earlier_call_is_not_blamed_on_this_o
     assert np.array_equal(ss.sort(data).into_parts()[1], want)         # the one-shot entry point
 
 
+def test_no_thread_to_be_had_is_an_error_code_or_a_slower_call_never_an_abort(ss):
+    """A process that may not start another thread (a container's pids limit; here RLIMIT_NPROC, which only binds an
+    ordinary user): the partition workers fall back to the calling thread, the one-shot call copies without its page-touching
+    threads, a loopback group reports an error — no C++ exception leaves the C ABI (tools/thread_limit_probe.py)."""
+    import subprocess, sys
+    from conftest import ROOT
+    if os.getuid() == 0:
+        pytest.skip("RLIMIT_NPROC does not bind root")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "thread_limit_probe.py")], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    row = json.loads(out.stdout.strip().splitlines()[-1])
+    assert row["ok"] and row["limit_effective"] and row["partitions_equal"] and row.get("one_shot_equal"), row
+    assert row["loopback"] == "built" or row["loopback"].startswith("error -"), row
+
+
 def test_short_arena_falls_back_or_fails_loudly(ss, oracle):
     """ADVICE r1 (arena_requirement is not a bound for the whole-level order + general tie path): with the work arena
     cut down step by step (DC3HIP_ARENA_BYTES) a build must take a cheaper ordering and still return the exact suffix
