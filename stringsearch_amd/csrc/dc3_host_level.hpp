@@ -533,20 +533,30 @@ static int build_end(dc3hip_ctx *c) {
   return E_OK;
 }
 // level-0 alphabet: dense order-preserving codes 1..sigma of the bytes that occur
+// The set of byte values only grows with the bytes looked at: once a PREFIX shows all 256, the rest of the text cannot change
+// the code table, and the pass over it (1 GiB: 0.24 ms of an 11 ms build) is left out — exactly, no sampling argument.
+// Texts of fewer symbols pay one more launch and stream synchronisation (~0.03 ms) and then scan the rest as before.
+static constexpr int64_t kAlphabetPrefix = (int64_t)1 << 20, kAlphabetPrefixMinN = (int64_t)16 << 20;
 static int build_alphabet(dc3hip_ctx *c, u32 *sigma_out) {
   const int64_t n = c->n;
-  {
-    PhaseScope ps(c, DC3HIP_PH_ALPHABET, n);
-    HIPC(hipMemsetAsync(c->d_present, 0, 256 * sizeof(u32), c->stream));
-    hipLaunchKernelGGL(k_byte_presence, dim3(grid_for(c, (u64)n / 16 + 1)), dim3(kBlock), 0, c->stream, c->d_text,
-                       (u32)n, c->d_present);
-    KCHECK();
-    hipLaunchKernelGGL(k_make_codes, dim3(1), dim3(kBlock), 0, c->stream, c->d_present, c->d_code, c->d_words + 1);
-    KCHECK();
-    HIPC(hipMemcpyAsync(c->h_words + 1, c->d_words + 1, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+  HIPC(hipMemsetAsync(c->d_present, 0, 256 * sizeof(u32), c->stream));
+  int64_t from = 0, to = n >= kAlphabetPrefixMinN ? kAlphabetPrefix : n;       // (the prefix is a multiple of the kernel's 16-byte loads)
+  u32 sigma = 0;
+  for (;;) {
+    {
+      PhaseScope ps(c, DC3HIP_PH_ALPHABET, to - from);
+      hipLaunchKernelGGL(k_byte_presence, dim3(grid_for(c, (u64)(to - from) / 16 + 1)), dim3(kBlock), 0, c->stream, c->d_text + from,
+                         (u32)(to - from), c->d_present);
+      KCHECK();
+      hipLaunchKernelGGL(k_make_codes, dim3(1), dim3(kBlock), 0, c->stream, c->d_present, c->d_code, c->d_words + 1);
+      KCHECK();
+      HIPC(hipMemcpyAsync(c->h_words + 1, c->d_words + 1, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPC(hipStreamSynchronize(c->stream));
+    sigma = c->h_words[1];
+    if (to == n || sigma == 256) break;
+    from = to; to = n;
   }
-  HIPC(hipStreamSynchronize(c->stream));
-  const u32 sigma = c->h_words[1];
   if (sigma < 1 || sigma > 256) { set_err("internal: alphabet size %u", sigma); return E_HIP; }
   *sigma_out = sigma;
   return E_OK;

@@ -1363,6 +1363,26 @@ def test_no_thread_to_be_had_is_an_error_code_or_a_slower_call_never_an_abort(ss
     assert row["loopback"] == "built" or row["loopback"].startswith("error -"), row
 
 
+def test_alphabet_from_a_prefix_only_when_the_prefix_shows_every_byte(ss, oracle):
+    """build_alphabet (round 6): from 16 MiB on the byte-presence scan stops behind the first MiB when that prefix already
+    holds all 256 values (the set only grows) and otherwise goes on over the rest.  (a) a value that first occurs as the very
+    last byte / just behind the prefix must still get its code; (b) a prefix with all 256 values in front of a two-symbol
+    remainder takes the early exit.  Bit-exact against the reference both ways."""
+    rng = np.random.default_rng(77)
+    n = (17 << 20) + 5
+    a = rng.integers(0, 255, n, dtype=np.uint8); a[-1] = 255                      # 255 only at the very end
+    b = rng.integers(0, 255, n, dtype=np.uint8); b[(1 << 20)] = 255              # ... only in the first byte behind the prefix
+    c = rng.integers(97, 99, n, dtype=np.uint8); c[:1 << 20] = rng.integers(0, 256, 1 << 20, dtype=np.uint8)
+    assert len(np.unique(c[:1 << 20])) == 256
+    d = rng.integers(0, 3, n, dtype=np.uint8)                                    # three symbols: the full scan, as before
+    for data, sigma in ((a, 256), (b, 256), (c, 256), (d, 3)):
+        want = oracle.ref_sufsort(data) if oracle.ref is not None else oracle.sufsort(data)
+        with ss.Context(n) as ctx:
+            ctx.set_text(data); ctx.build()
+            assert ctx.stats()["level_K"][0] == sigma
+            assert np.array_equal(ctx.sa(), want)
+
+
 def test_short_arena_falls_back_or_fails_loudly(ss, oracle):
     """ADVICE r1 (arena_requirement is not a bound for the whole-level order + general tie path): with the work arena
     cut down step by step (DC3HIP_ARENA_BYTES) a build must take a cheaper ordering and still return the exact suffix
