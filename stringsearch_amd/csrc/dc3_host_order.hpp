@@ -472,7 +472,11 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
     u32 *img = nullptr;                      // (4 bytes per record that only the LSD passes write: allocated when they run)
     uint8_t *same = nullptr;
     RC(arena_alloc(c, (size_t)nrec + 16, &same));
-    SplitSink sink; sink.sa = emit_sa; sink.img = nullptr; sink.same = same; sink.pbits = hm.pbits;
+    // (one byte per tile of the tie pass, set by the local sort where a tile holds a tie: MsdSplitSink::tilef)
+    uint8_t *tilef = nullptr;
+    RC(arena_alloc(c, (size_t)nrec / kTieTile + 16, &tilef));
+    HIPC(hipMemsetAsync(tilef, 0, (size_t)nrec / kTieTile + 16, c->stream));
+    SplitSink sink; sink.sa = emit_sa; sink.img = nullptr; sink.same = same; sink.pbits = hm.pbits; sink.tilef = tilef;
     LastPass lp;
     MsdRedo mredo; bool msd_ok = false;
     if (mg && mg->on) {
@@ -499,7 +503,7 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
         HIPC(hipMemsetAsync(c->d_words + 10, 0, 3 * sizeof(u32), c->stream));
         if (msd_ok)
           hipLaunchKernelGGL((k_tie_resolve_split<KM, SameFlag>), dim3(grid_for(c, nrec / 4 + 1)), dim3(kBlock), 0, c->stream, km,
-                             SameFlag{same}, emit_sa, nrec, c->d_words + 10);
+                             SameFlag{same, tilef}, emit_sa, nrec, c->d_words + 10);
         else
           hipLaunchKernelGGL((k_tie_resolve_split<KM, SameImg>), dim3(grid_for(c, nrec / 4 + 1)), dim3(kBlock), 0, c->stream, km,
                              SameImg{img}, emit_sa, nrec, c->d_words + 10);
@@ -521,7 +525,7 @@ static int hybrid_sort_core(dc3hip_ctx *c, KM km, u32 kbits, const HiMap &hm, Re
             HIPC(hipMemsetAsync(c->d_words + 10, 0, 3 * sizeof(u32), c->stream));
             if (msd_ok)
               hipLaunchKernelGGL((k_tie_resolve_split<KM, SameFlag>), dim3(grid_for(c, nrec / 4 + 1)), dim3(kBlock), 0, c->stream, kd,
-                                 SameFlag{same}, emit_sa, nrec, c->d_words + 10);
+                                 SameFlag{same, tilef}, emit_sa, nrec, c->d_words + 10);
             else
               hipLaunchKernelGGL((k_tie_resolve_split<KM, SameImg>), dim3(grid_for(c, nrec / 4 + 1)), dim3(kBlock), 0, c->stream, kd,
                                  SameImg{img}, emit_sa, nrec, c->d_words + 10);
@@ -898,12 +902,38 @@ int launch_pack_all<Key9>(dc3hip_ctx *c, Key9 km, u32 nrec, const HiMap &hm, Rec
   pack_plan(c, nrec, hm, mg, &nb, &ck, &hshift);
   u32 *table = nullptr;
   RC(arena_alloc(c, (size_t)nb * ck.nchunks, &table));
-  if (!store) {
+  if (!store && hm.raw && hshift <= hm.nbits && hm.nbits - hshift <= 10u) {
+    // (the raw image is KeyBits' with 8 bits per symbol and the text as the stream: dc3_order.hip.hpp)
+    hipLaunchKernelGGL(k_count_image_bits<7>, dim3(ck.nchunks), dim3(kBlock), 0, c->stream, KeyBits{km.S.t, 8u}, nrec, hm, ck.chunk, ck.nchunks,
+                       table, hshift);
+    KCHECK();
+  } else if (!store) {
     hipLaunchKernelGGL((k_pack_image_text<1024, false>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, km, nrec, hm, out, ck.chunk, ck.nchunks,
                        table, hshift);
     KCHECK();
   } else {
 #define K_(NB) (k_pack_image_text<NB>)
+    DC3_PACK_LAUNCH(K_, km, nrec, hm, out, ck.chunk, ck.nchunks, table, hshift);
+#undef K_
+  }
+  *first_table = table;
+  return E_OK;
+}
+template <>
+int launch_pack_all<KeyBits>(dc3hip_ctx *c, KeyBits km, u32 nrec, const HiMap &hm, Rec8 *out, u32 **first_table, const MsdGeom *mg, bool store) {
+  int nb = 0; Chunking ck; u32 hshift = 0;
+  pack_plan(c, nrec, hm, mg, &nb, &ck, &hshift);
+  u32 *table = nullptr;
+  RC(arena_alloc(c, (size_t)nb * ck.nchunks, &table));
+  if (!store && hshift <= hm.nbits && 7u * km.lg + 7u + (hm.nbits - hshift) <= 64u && hm.nbits - hshift <= 10u) {
+    hipLaunchKernelGGL(k_count_image_bits<8>, dim3(ck.nchunks), dim3(kBlock), 0, c->stream, km, nrec, hm, ck.chunk, ck.nchunks, table, hshift);
+    KCHECK();
+  } else if (!store) {
+    hipLaunchKernelGGL((k_pack_image_all_hist<KeyBits, 1024, false>), dim3(ck.nchunks), dim3(kBlock), 0, c->stream, km, nrec, hm, out, ck.chunk,
+                       ck.nchunks, table, hshift);
+    KCHECK();
+  } else {
+#define K_(NB) (k_pack_image_all_hist<KeyBits, NB>)
     DC3_PACK_LAUNCH(K_, km, nrec, hm, out, ck.chunk, ck.nchunks, table, hshift);
 #undef K_
   }

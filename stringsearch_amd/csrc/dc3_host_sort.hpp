@@ -428,7 +428,7 @@ static int msd_sort(dc3hip_ctx *c, Rec8 *ha, Rec8 *hb, u32 n, const HiMap &hm, c
   r.large = maxsub > kMsdCapSmall;
   r.shb = sh2 - std::min<u32>(r.large ? 12u : 10u, rb);
   if (split) {
-    MsdSplitSink sk; sk.sa = split->sa; sk.same = split->same; sk.pbits = split->pbits;
+    MsdSplitSink sk; sk.sa = split->sa; sk.same = split->same; sk.pbits = split->pbits; sk.tilef = split->tilef;
     RC(msd_launch_local(c, r, n, sk));
   } else if (same_out) {
     MsdRecSameSink sk; sk.p = r.dst; sk.same = same_out; sk.pbits = hm.pbits;

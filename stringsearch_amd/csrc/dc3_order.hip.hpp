@@ -782,6 +782,40 @@ __global__ __launch_bounds__(kBlock) void k_pack_bits(SymU8 S, u32 n, u32 lg, u3
     for (u32 i = 0; i < lg; i++) bits[(size_t)g * lg + i] = (uint8_t)(acc >> (8 * (lg - 1 - i)));
   }
 }
+// The counting pack kernel of KeyBits (the digit table of partition pass 1; the images themselves are made inside the pass):
+// a digit is the top nbits - hshift (<= 10) bits of an image, so ONE unaligned 8-byte load serves PER consecutive positions
+// ((PER - 1) lg + 7 + 10 <= 64 bits, the host checks) where k_pack_image_all_hist loads and swaps once per position —
+// 0.99 -> 0.33 ms of DNA's 11.7 ms at 1 GiB.  The raw image of byte alphabets (HiMap::raw) is the same thing with lg = 8 and
+// the text itself as the bit stream (byte-aligned: 6 * 8 + 10 <= 64, PER = 7): 0.47 -> ms of random bytes' 10.7.
+// Same table as k_pack_image_all_hist<KeyBits, 1024, false> / k_pack_image_text<1024, false>.
+template <int PER>
+__global__ __launch_bounds__(kBlock) void k_count_image_bits(KeyBits km, u32 n, HiMap hm, u32 chunk, u32 nchunks,
+                                                            u32 *__restrict__ table, u32 hshift) {
+  constexpr int NB = 1024;
+  __shared__ u32 hist[kWaves][NB];
+#pragma unroll
+  for (int w = 0; w < kWaves; w++)
+    for (int j = threadIdx.x; j < NB; j += kBlock) hist[w][j] = 0;
+  __syncthreads();
+  u32 *myh = hist[wave_id()];
+  const u32 begin = blockIdx.x * chunk, end = min(n, begin + chunk);
+  const u32 sh = 64u - hm.nbits + hshift;
+  for (u32 p0 = begin + (u32)PER * threadIdx.x; p0 < end; p0 += (u32)PER * kBlock) {
+    const u64 b = (u64)p0 * km.lg;
+    u64 v; __builtin_memcpy(&v, km.bits + (b >> 3), 8);
+    const u64 V = __builtin_bswap64(v) << (u32)(b & 7u);
+#pragma unroll
+    for (u32 j = 0; j < (u32)PER; j++)
+      if (p0 + j < end) atomicAdd(&myh[(u32)((V << (j * km.lg)) >> sh) & (NB - 1)], 1u);
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < NB; j += kBlock) {
+    u32 sum = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; w++) sum += hist[w][j];
+    table[(size_t)j * nchunks + blockIdx.x] = sum;
+  }
+}
 // any other key maker: position by position
 // KeyImg: the images were written out by a pack kernel, one u64 per position and nothing else (the position is the
 // index) — how a key maker whose image is too dear to compute inside the partition pass (KeyT) still gets an image
@@ -1330,13 +1364,17 @@ __global__ __launch_bounds__(kBlock) void k_tie_resolve(KM km, Same same, Rec8 *
 // words as for k_tie_resolve.
 // Same = how the pass learns that record i has the image of record i - 1: SameImg compares the 32 image bits the LSD
 // passes' SplitSink left, SameFlag reads the byte the bucket ordering's local sort left (1 byte per record instead of 4).
+constexpr u32 kTieTileShift = 12, kTieTile = 1u << kTieTileShift;     // records per tile of k_tie_resolve_split (and per byte of MsdSplitSink::tilef)
 struct SameImg {
   const u32 *img;
   __device__ __forceinline__ bool operator()(u32 i) const { return i > 0 && img[i] == img[i - 1]; }
+  __device__ __forceinline__ bool tile_clear(u32) const { return false; }
 };
 struct SameFlag {
   const uint8_t *f;         // 0 / 1 per record (MsdSplitSink), 16-byte aligned, 16 readable bytes behind the last record
+  const uint8_t *tilef = nullptr;   // optional: byte per kTieTile records, 0 = no record of the tile is tied or precedes a tied one
   __device__ __forceinline__ bool operator()(u32 i) const { return f[i] != 0; }
+  __device__ __forceinline__ bool tile_clear(u32 tile) const { return tilef != nullptr && tilef[tile] == 0; }
 };
 // bit j = same(i0 + j) for j = 0 .. 16, 0 past the end (i0 a multiple of 16): what a thread of the tie pass needs to know
 // about its 16 records and the one behind them.  The flag bytes come as one 16-byte load and one byte — read a byte at a
@@ -1369,6 +1407,7 @@ __global__ __launch_bounds__(kBlock) void k_tie_resolve_split(KM km, Same same, 
   // works the list only in full batches of kBlock groups (one per lane), so that every wave has 64 dependent gathers
   // in flight instead of a handful.
   constexpr u32 kIPT = 16, kTile = kBlock * kIPT, kCap = kTile / 2 + kBlock;      // a thread scans 16 consecutive records
+  static_assert(kTile == kTieTile, "the sink's tile flags (MsdSplitSink::tilef) are per tile of this pass");
   __shared__ uint16_t lcode[256];
   __shared__ u32 starts[kCap];
   __shared__ u32 nstart, ntied, ndup;
@@ -1380,7 +1419,7 @@ __global__ __launch_bounds__(kBlock) void k_tie_resolve_split(KM km, Same same, 
     u32 tied = 0;
     {
       const u32 i0 = tile * kTile + threadIdx.x * kIPT;
-      if (i0 < n) {
+      if (i0 < n && !same.tile_clear(tile)) {                        // (a clear tile holds no tied record and no group start)
         const u32 m = same_mask17(same, i0, n);
         const u32 eqp = m & 0xffffu, eqn = (m >> 1) & 0xffffu;       // bit j: record i0 + j equals its predecessor / successor
         u32 st = eqn & ~eqp;                                         // group starts

@@ -90,6 +90,7 @@ struct SplitSink {
   u32 *sa, *img; u32 pbits;
   uint8_t *same = nullptr;     // (not written by the LSD passes: the bucket ordering's local sort leaves "same image as the
                                //  record before" bytes here instead of the image array, see MsdSplitSink)
+  uint8_t *tilef = nullptr;    // (optional, zeroed by the host: byte t becomes 1 when a record of tie-pass tile t is tied, see MsdSplitSink)
   __device__ __forceinline__ void store(u32 g, const Rec8 &x) const {
     const u64 w = rec8_word(x);
     sa[g] = (u32)(w & ((1ull << pbits) - 1ull));
