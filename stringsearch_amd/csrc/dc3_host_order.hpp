@@ -902,7 +902,7 @@ int launch_pack_all<Key9>(dc3hip_ctx *c, Key9 km, u32 nrec, const HiMap &hm, Rec
   pack_plan(c, nrec, hm, mg, &nb, &ck, &hshift);
   u32 *table = nullptr;
   RC(arena_alloc(c, (size_t)nb * ck.nchunks, &table));
-  if (!store && hm.raw && hshift <= hm.nbits && hm.nbits - hshift <= 10u) {
+  if (!store && hm.raw && hshift < hm.nbits && hm.nbits - hshift <= 10u) {
     // (the raw image is KeyBits' with 8 bits per symbol and the text as the stream: dc3_order.hip.hpp)
     hipLaunchKernelGGL(k_count_image_bits<7>, dim3(ck.nchunks), dim3(kBlock), 0, c->stream, KeyBits{km.S.t, 8u}, nrec, hm, ck.chunk, ck.nchunks,
                        table, hshift);
@@ -925,7 +925,7 @@ int launch_pack_all<KeyBits>(dc3hip_ctx *c, KeyBits km, u32 nrec, const HiMap &h
   pack_plan(c, nrec, hm, mg, &nb, &ck, &hshift);
   u32 *table = nullptr;
   RC(arena_alloc(c, (size_t)nb * ck.nchunks, &table));
-  if (!store && hshift <= hm.nbits && 7u * km.lg + 7u + (hm.nbits - hshift) <= 64u && hm.nbits - hshift <= 10u) {
+  if (!store && hshift < hm.nbits && 7u * km.lg + 7u + (hm.nbits - hshift) <= 64u && hm.nbits - hshift <= 10u) {      // (at least one digit bit: the kernel shifts by 64 - that)
     hipLaunchKernelGGL(k_count_image_bits<8>, dim3(ck.nchunks), dim3(kBlock), 0, c->stream, km, nrec, hm, ck.chunk, ck.nchunks, table, hshift);
     KCHECK();
   } else if (!store) {
