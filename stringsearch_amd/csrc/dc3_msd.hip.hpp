@@ -520,7 +520,7 @@ struct MsdRecSameSink {
 // read back, against 5 and 1 here.)
 // tilef (optional): one byte per tile of the tie pass (kTieTile records, k_tie_resolve_split), set when a record of the tile
 // is tied or is the predecessor of a tied record — 0.006 % of random records are, so the pass reads one byte instead of 4 KB
-// of flags for the nine tiles in ten that hold no tie (0.23 -> 0.05 ms per GiB).
+// of flags for the nine tiles in ten that hold no tie (0.21 -> 0.14 ms per GiB; what remains are the gathers of the tied records).
 // (kTieTileShift, kTieTile: dc3_order.hip.hpp)
 struct MsdSplitSink {
   u32 *sa; uint8_t *same; u32 pbits; uint8_t *tilef;

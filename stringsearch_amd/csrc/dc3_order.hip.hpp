@@ -786,7 +786,7 @@ __global__ __launch_bounds__(kBlock) void k_pack_bits(SymU8 S, u32 n, u32 lg, u3
 // a digit is the top nbits - hshift (<= 10) bits of an image, so ONE unaligned 8-byte load serves PER consecutive positions
 // ((PER - 1) lg + 7 + 10 <= 64 bits, the host checks) where k_pack_image_all_hist loads and swaps once per position —
 // 0.99 -> 0.33 ms of DNA's 11.7 ms at 1 GiB.  The raw image of byte alphabets (HiMap::raw) is the same thing with lg = 8 and
-// the text itself as the bit stream (byte-aligned: 6 * 8 + 10 <= 64, PER = 7): 0.47 -> ms of random bytes' 10.7.
+// the text itself as the bit stream (byte-aligned: 6 * 8 + 10 <= 64, PER = 7): 0.47 -> 0.35 ms of random bytes' 10.7.
 // Same table as k_pack_image_all_hist<KeyBits, 1024, false> / k_pack_image_text<1024, false>.
 template <int PER>
 __global__ __launch_bounds__(kBlock) void k_count_image_bits(KeyBits km, u32 n, HiMap hm, u32 chunk, u32 nchunks,
