@@ -323,7 +323,13 @@ static int msd_sort(dc3hip_ctx *c, Rec8 *ha, Rec8 *hb, u32 n, const HiMap &hm, c
   const ArenaMark slot_mk = arena_mark(c);
   if (g.d2 > 0 && allow_slots) {
     const u32 mean = (u32)(((u64)n + n2 - 1) / n2);
-    const u32 slot_cap = c->msd_slot_cap ? std::min<u32>(kMsdCapSmall, c->msd_slot_cap) : std::min<u32>(kMsdCapSmall, (2 * mean + 63) & ~63u);
+    // (slots of twice the mean for the small local shape; where the mean passes what that shape holds with room to spare — texts
+    //  beyond 1.7e9 positions, whose 2^20 sub-buckets average more than 1638 words — slots of 1.5 x the mean for the large
+    //  shape, up to the 4032 words at which 2^20 slots still index with 32 bits: Poisson sizes around 2049 stay below 2300)
+    const bool small_fits = (u64)mean * 5 <= (u64)kMsdCapSmall * 4;
+    const u32 slot_cap = c->msd_slot_cap ? std::min<u32>(kMsdCapSmall, c->msd_slot_cap)
+                         : small_fits ? std::min<u32>(kMsdCapSmall, (2 * mean + 63) & ~63u)
+                                      : std::min<u32>(kMsdCapLarge - 64u, (mean + mean / 2 + 63) & ~63u);
     const u64 slot_words = (u64)n2 * slot_cap + kMsdTile;
     const size_t N = n2;                                                 // one cursor per sub-bucket
     const size_t need = align_up(slot_words * 8, 256) + align_up((N + 16) * 4, 256) + (split ? (size_t)n * 2 + (64u << 20) : (size_t)(1u << 20));   // (+ what the tie pass takes afterwards)
