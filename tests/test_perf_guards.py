@@ -23,7 +23,7 @@ MEASURED_MS = {
     "random_1GiB_recursion_only": 38.5,
     "random_1GiB_dup_1MB_block": 36.9,
     "dna_1GiB": 11.9,                       # (round 6: the image off the bit-packed text inside pass 1 — 15.0 before)
-    "dna_2GiB_plus_1_chunk_of_configs4": 28.0,   # (round 6: 8-byte words beyond 2^31 positions — 91.5 on 12-byte records before)
+    "dna_2GiB_plus_1_chunk_of_configs4": 24.0,   # (round 6: 8-byte words beyond 2^31 positions, slots for the large local shape — 91.5 on 12-byte records before; 27-28 without the slots)
     "sufcheck_1GiB": 30.5,                  # (round 6: the verifier as one counting pass — 98 before; wall time of dc3hip_ctx_sufcheck)
     "text_1GiB": 110.0,
     "real_text_256MiB": 53.4,
